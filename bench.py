@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py — voice*samples/s of the Subtractive patch (BASELINE.json metric) on N MI355X of one node.
+
+A "step" is one audio block (256 samples @ 48 kHz) of every voice resident on the GPU: one klg_render launch
+(+ the tiny partial-sum reduce) accumulating into a device-resident stereo block; with N > 1 the voices are
+sharded across ranks (independent voice ranges, weak scaling) and the only exchange is one RCCL all-reduce of
+the [2][256] stereo block per step (BASELINE.json north_star).  Inputs (voice state) are resident in HBM when the
+timed region starts.
+
+Prints ONE JSON line (driver contract) with the extra `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3        # fp32 vector peak
+FLOPS_PER_VOICE_SAMPLE = {"sub2a": 21, "sub2b": 120, "supersaw": 120, "fm4": 95, "fm3": 72, "sine": 12}   # SURVEY.md §8(d) estimates
+# algorithmic HBM bytes per voice per block: record read + words written back (klang_amd/csrc/klg_patches.hpp)
+STORE_WORDS = {"sub2a": 8, "sub2b": 19, "supersaw": 12, "fm3": 20, "fm4": 25, "sine": 2}
+
+
+def cpu_baseline(patch, block, budget_s=12.0):
+    """The TEST-ONLY oracle (C restatement, bit-exact vs the reference header) timed on ONE host core on a
+    bounded sample of the same workload: 128 voices (one Synth instance) x `block` samples x M blocks."""
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True, stdout=subprocess.DEVNULL)
+    ko = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libklang_oracle.so"))
+    ko.ko_bank_create.restype = C.c_void_p
+    ko.ko_bank_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float]
+    ko.ko_bank_note_on.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_long]
+    ko.ko_bank_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    ko.ko_patch_from_name.argtypes = [C.c_char_p]
+    pid = ko.ko_patch_from_name(patch.encode())
+    notes = 128 if patch in ("sub2a", "sine", "bsine") else 32
+    synths = 128 // notes
+    bank = ko.ko_bank_create(pid, synths, notes, C.c_float(48000.0))
+    rng = np.random.default_rng(20250314)
+    for sy in range(synths):
+        for p in rng.integers(36, 97, size=notes):
+            ko.ko_bank_note_on(bank, sy, int(p), C.c_float(0.8), 1)
+    mix = np.zeros((2, block), np.float32)
+    mp = mix.ctypes.data_as(C.c_void_p)
+    t0 = time.perf_counter()
+    blocks = 0
+    while True:
+        for _ in range(50):
+            ko.ko_bank_process(bank, None, mp, None, block)
+        blocks += 50
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": 128 * block * blocks / dt, "unit": "voice*samples/s", "cores": 1, "kind": "port",
+            "sample": f"{patch}: 128 voices x {block} samples x {blocks} blocks, oracle/klang_oracle.c -O2 single thread, {os.cpu_count()} host cores present"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--patch", default="sub2a")
+    ap.add_argument("--voices", type=int, default=1 << 20, help="voices per GPU (weak scaling)")
+    ap.add_argument("--block", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: klang_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import klang_amd
+    notes = 128 if args.patch in ("sub2a", "sine", "bsine") else 32
+    synths = max(1, args.voices // notes)
+    bank = klang_amd.SynthBank(args.patch, synths=synths, notes=notes, fs=48000.0, max_block=args.block, device=local_rank)
+    V, N = bank.voices, args.block
+
+    # synthetic MIDI / random-parameter workload: every voice sounding, uniform pitches 36..96
+    rng = np.random.default_rng(20250314 + rank)
+    pitches = rng.integers(36, 97, size=V)
+    vels = rng.uniform(0.25, 1.0, size=V)
+    bank.random(rank + 1)
+    for v in range(V):
+        bank.note_on(v // notes, int(pitches[v]), float(vels[v]))
+    mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        mix.zero_()
+        bank.process_device(mix.data_ptr(), N, stream)
+        if world > 1:
+            dist.all_reduce(mix)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    bank.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    launches, kernel_ms = bank.timing_end()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    checksum = float(mix.abs().sum().item())
+
+    if rank == 0:
+        total_voices = V * world
+        value = total_voices * N * args.steps / dt
+        ms_per_step = 1e3 * dt / args.steps
+        kern_s = 1e-3 * kernel_ms / max(1, launches)
+        rec_bytes = bank.state_bytes
+        alg_bytes = V * (rec_bytes + 4 * STORE_WORDS.get(args.patch, rec_bytes // 4)) + 2 * N * 4
+        achieved = alg_bytes / kern_s / 1e9
+        flops = FLOPS_PER_VOICE_SAMPLE.get(args.patch, 0) * V * N / kern_s / 1e12
+        out = {
+            "metric": "voice*samples/s @48kHz Subtractive",
+            "value": value, "unit": "voice*samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.patch}: {V} voices/GPU (Saw>>Biquad LPF>>ADSR), {N}-sample blocks @48kHz, all voices sounding, stereo mix resident in HBM",
+                       "voices_per_gpu": V, "block": N, "parallelism": f"voice-shard x{world}" + (" + RCCL all-reduce of [2][%d] per block" % N if world > 1 else ""),
+                       "realtime_voices_equiv": int(value / 48000.0), "block_deadline_ms": 1e3 * N / 48000.0, "mix_checksum": checksum},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "klg_render<%s>" % args.patch, "kernel_ms": 1e3 * kern_s, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "synth patches keep voice state in registers: the binding unit is fp32 VALU issue, see `valu`",
+                         "valu": {"achieved_tflops_est": flops, "peak_tflops": FP32_PEAK_TFLOPS, "frac": flops / FP32_PEAK_TFLOPS,
+                                  "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(args.patch, 0)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.patch, N)
+        print(json.dumps(out))
+    bank.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

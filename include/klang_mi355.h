@@ -1,0 +1,140 @@
+/* include/klang_mi355.h — C-ABI of libklang_mi355.so, the MI355X (gfx950) replacement for klang's
+ * per-block signal-graph evaluation path.
+ *
+ * The reference (nashaudio/klang, single header klang.h v0.7.8) has no FFI: a host calls C++
+ * virtual methods on a user-derived Synth/Effect object once per audio block.  Each entry point
+ * below names the reference interface it replaces (file:line into the reference's klang.h); the
+ * binding a maintainer would add to klang.h is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on success
+ * or a negative klg_status, and klg_last_error() describes the last failure of the calling thread;
+ * no exceptions cross this boundary; one calling thread per handle (the reference is single audio
+ * thread per plugin instance, klang.h:4440-4466); sample buffers are caller-owned, non-interleaved
+ * float32, processed in place (Synth ACCUMULATES into a pre-cleared buffer like klang.h:4751-4752,
+ * Effect overwrites like klang.h:4708-4716).
+ *
+ * There is NO CPU fallback: if no gfx950 device is usable every create/process call fails with
+ * KLG_ERR_NO_DEVICE.
+ */
+#ifndef KLANG_MI355_H
+#define KLANG_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+	KLG_OK = 0,
+	KLG_ERR_NO_DEVICE = -1,   /* no HIP device / hipSetDevice failed */
+	KLG_ERR_INVALID = -2,     /* bad argument (index out of range, n > max_block, NULL, ...) */
+	KLG_ERR_HIP = -3,         /* a HIP runtime call failed; see klg_last_error() */
+	KLG_ERR_NOMEM = -4
+} klg_status;
+
+/* Patch ids: the hand-written kernels shipped in this library (SURVEY.md §2 "Config patches"). */
+typedef enum {
+	KLG_PATCH_SINE = 0,       /* 1 x Generators::Fast::Sine note         (BASELINE config 1) */
+	KLG_PATCH_BSINE = 1,      /* 1 x Generators::Basic::Sine note        (BASELINE config 1) */
+	KLG_PATCH_SUB2A = 2,      /* Saw >> Biquad LPF (static) >> ADSR      (BASELINE config 2, north_star) */
+	KLG_PATCH_SUB2B = 3,      /* shipped subtractive.k: Square >> swept LPF >> ADSR (config 2b) */
+	KLG_PATCH_SUPERSAW = 4,   /* shipped SuperSaw.k: 7 x OSM saw / 7 * ADSR         (config 3) */
+	KLG_PATCH_FM3 = 5,        /* shipped FM.k: 3 x Operator<Sine> * ADSR * 0.1 */
+	KLG_PATCH_FM4 = 6,        /* 4-operator FM chain                               (config 5) */
+	KLG_PATCH_PINGPONG = 7,   /* shipped PingPong.k (Stereo::Effect)               (config 4) */
+	KLG_PATCH_REVERB = 8,     /* shipped Reverb.k   (Stereo::Effect)               (config 4) */
+	KLG_PATCH_COUNT
+} klg_patch;
+
+/* NoteBase::Stage, klang.h:4286 */
+enum { KLG_STAGE_ONSET = 0, KLG_STAGE_SUSTAIN = 1, KLG_STAGE_RELEASE = 2, KLG_STAGE_OFF = 3 };
+
+const char* klg_last_error(void);
+int klg_version(void);
+
+/* Select the GPU this process renders on (one process per GPU).  device_ids[0] is used; n_devices
+ * must be 1.  Without this call device 0 is used.  (No reference equivalent: the reference is CPU.) */
+int klg_init(const int* device_ids, int n_devices);
+
+/* klang::random(seed) (klang.h:239): seeds the libc rand() stream the host-side on() code of
+ * SuperSaw-style patches draws detune from (SuperSaw.k:17). */
+void klg_random_seed(unsigned seed);
+
+/* ------------------------------------------------------------------------------------------------
+ * Synth banks.  One klg_synth = `synths` independent instances of klang::Synth / Stereo::Synth
+ * (klang.h:4375-4466, 4761-4860) of one patch, each with `notes_per_synth` <= 128 Note slots
+ * (Array<NOTE*,128>, klang.h:4311), rendered by ONE kernel launch per block: voice v = instance
+ * v / notes_per_synth, slot v % notes_per_synth, one GPU lane per voice.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct klg_synth klg_synth;
+
+/* replaces: constructing the user's Synth subclass + notes.add<T>(n) (klang.h:4324-4331); klang::fs (1604) */
+klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_synth, float sample_rate, int max_block);
+void klg_synth_destroy(klg_synth* s);
+int klg_synth_voices(const klg_synth* s);
+int klg_synth_controls(const klg_synth* s);              /* controls.size() of the patch */
+size_t klg_synth_state_bytes(const klg_synth* s);        /* resident HBM bytes per voice */
+
+/* replaces: Synth::noteOn(int pitch, float velocity) klang.h:4423-4427 / 4813-4817 — Notes::assign()
+ * voice allocation + NoteBase::start() + the patch's on() run on the HOST; the resulting lane state is
+ * queued and applied on the GPU at the start of the next block.  Returns the slot (>= 0) or an error. */
+int klg_note_on(klg_synth* s, int synth, int pitch, float velocity);
+/* replaces: Synth::noteOff(int pitch, float velocity) klang.h:4430-4434 / 4820-4824 (NoteBase::release + off()) */
+int klg_note_off(klg_synth* s, int synth, int pitch, float velocity);
+/* replaces: controls[index].set(value) (clamped, klang.h:1725-1728) as done by the parameter sync of
+ * Synth::process (klang.h:4444-4447, 4836-4839) followed by Synth::onControl (4399-4404). */
+int klg_set_control(klg_synth* s, int synth, int index, float value);
+int klg_get_control(klg_synth* s, int synth, int index, float* value);
+
+/* replaces: Stereo::Synth::process(float** buffers, int length, float* parameters) klang.h:4830-4858
+ * (and mono Synth::process(float*, int, float*) 4440-4466 with channels == 1): pending events are applied,
+ * every voice whose stage != Off renders n samples, voices are summed, the sum is ADDED to out[c][0..n).
+ * `parameters`, if not NULL, holds klg_synth_controls() floats per instance [synths][controls] and is
+ * copied in (clamped) before and out after the block.  Synchronous on return. */
+int klg_process(klg_synth* s, float* const* out, int channels, int n, float* parameters);
+/* Same block, additionally returning every voice's own n samples (per_voice[v*n + i], zeros for Off voices):
+ * the quantity Note::process(buffer) writes (klang.h:4295-4303).  Parity/debug path. */
+int klg_process_voices(klg_synth* s, float* per_voice, float* const* out, int channels, int n);
+/* replaces: reading note->stage after the block (klang.h:4455-4456: `if (!note->process(..)) note->stop()`). */
+int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices);
+
+/* Throughput path: d_mix is a DEVICE pointer to [2][n] floats that the block is accumulated into on
+ * `hip_stream` (a hipStream_t, or NULL for the handle's own stream); no host copies, no synchronisation.
+ * klg_sync() waits for everything queued on the handle. */
+int klg_process_device(klg_synth* s, float* d_mix, int n, void* hip_stream);
+int klg_sync(klg_synth* s);
+
+/* Voice state transfer (checkpoint / debugging).  `state` is the patch's packed per-voice record of
+ * klg_synth_state_bytes() bytes.  Replaces nothing in the reference (it has no checkpointing). */
+int klg_voice_download(klg_synth* s, int voice, void* state, size_t bytes);
+int klg_voice_upload(klg_synth* s, int voice, const void* state, size_t bytes);
+
+/* Measurement hooks used by bench.py: timing of the render kernel with HIP events recorded on the
+ * stream the kernel is launched on.  klg_timing_begin() arms it, klg_timing_end() returns the number of
+ * render launches since begin and their summed duration in milliseconds. */
+int klg_timing_begin(klg_synth* s);
+int klg_timing_end(klg_synth* s, int* launches, float* total_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * Effect banks: `instances` independent Stereo::Effect objects (klang.h:4703-4717) of one patch.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct klg_fx klg_fx;
+klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate, int max_block);
+void klg_fx_destroy(klg_fx* f);
+int klg_fx_set_control(klg_fx* f, int instance, int index, float value);
+/* replaces: Stereo::Effect::process(Stereo::buffer) klang.h:4708-4716 for every instance:
+ * io[(k*2 + c)*n + i] is channel c of instance k, processed in place.  Host buffers, synchronous. */
+int klg_fx_process(klg_fx* f, float* io, int n);
+/* Device-resident variant (d_io device pointer, asynchronous on hip_stream). */
+int klg_fx_process_device(klg_fx* f, float* d_io, int n, void* hip_stream);
+int klg_fx_sync(klg_fx* f);
+size_t klg_fx_state_bytes(const klg_fx* f);
+int klg_fx_timing_begin(klg_fx* f);
+int klg_fx_timing_end(klg_fx* f, int* launches, float* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KLANG_MI355_H */

@@ -1,0 +1,160 @@
+"""SynthBank / FxBank: Python mirrors of the reference's host-facing interface
+(Synth::noteOn / noteOff / onControl / process(float**, int) — klang.h:4399-4466, 4789-4858),
+implemented by forwarding to the C-ABI."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import KlangError, check, lib
+
+PATCH_IDS = {"sine": 0, "bsine": 1, "sub2a": 2, "sub2b": 3, "supersaw": 4, "fm3": 5, "fm4": 6, "pingpong": 7, "reverb": 8}
+F32P = C.POINTER(C.c_float)
+
+
+def _fp(a):
+    return a.ctypes.data_as(F32P)
+
+
+class SynthBank:
+    """`synths` instances of one patch, `notes` Note slots each; one GPU lane per voice."""
+
+    def __init__(self, patch, synths=1, notes=32, fs=48000.0, max_block=256, device=None):
+        self._L = lib()
+        self._h = None
+        if device is not None:
+            ids = (C.c_int * 1)(int(device))
+            check(self._L.klg_init(ids, 1), "klg_init")
+        pid = PATCH_IDS[patch] if isinstance(patch, str) else int(patch)
+        h = self._L.klg_synth_create(pid, int(synths), int(notes), float(fs), int(max_block))
+        if not h:
+            raise KlangError("klg_synth_create failed: " + self._L.klg_last_error().decode())
+        self._h = h
+        self.patch, self.synths, self.notes, self.fs, self.max_block = patch, synths, notes, fs, max_block
+        self.voices = self._L.klg_synth_voices(h)
+        self.state_bytes = self._L.klg_synth_state_bytes(h)
+        self.n_controls = self._L.klg_synth_controls(h)
+
+    def close(self):
+        if self._h:
+            self._L.klg_synth_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- events (host side of the reference API) ---
+    def random(self, seed):
+        self._L.klg_random_seed(int(seed) & 0xFFFFFFFF)
+
+    def note_on(self, synth, pitch, velocity=1.0):
+        return check(self._L.klg_note_on(self._h, int(synth), int(pitch), float(velocity)), "klg_note_on")
+
+    def note_off(self, synth, pitch, velocity=0.0):
+        return check(self._L.klg_note_off(self._h, int(synth), int(pitch), float(velocity)), "klg_note_off")
+
+    def set_control(self, synth, index, value):
+        return check(self._L.klg_set_control(self._h, int(synth), int(index), float(value)), "klg_set_control")
+
+    def get_control(self, synth, index):
+        v = C.c_float()
+        check(self._L.klg_get_control(self._h, int(synth), int(index), C.byref(v)), "klg_get_control")
+        return v.value
+
+    # --- blocks ---
+    def process(self, out, parameters=None):
+        """out: float32 [channels][n] (accumulated into, like Stereo::Synth::process)."""
+        assert out.dtype == np.float32 and out.ndim == 2 and out.flags.c_contiguous
+        ch, n = out.shape
+        ptrs = (F32P * ch)(*[_fp(out[c]) for c in range(ch)])
+        par = _fp(parameters) if parameters is not None else None
+        check(self._L.klg_process(self._h, ptrs, ch, n, par), "klg_process")
+        return out
+
+    def process_voices(self, n, out=None):
+        pv = np.empty((self.voices, n), dtype=np.float32)
+        if out is None:
+            out = np.zeros((2, n), dtype=np.float32)
+        ch = out.shape[0]
+        ptrs = (F32P * ch)(*[_fp(out[c]) for c in range(ch)])
+        check(self._L.klg_process_voices(self._h, _fp(pv), ptrs, ch, n), "klg_process_voices")
+        return pv, out
+
+    def stages(self):
+        st = np.empty(self.voices, dtype=np.uint8)
+        check(self._L.klg_voice_stages(self._h, st.ctypes.data_as(C.POINTER(C.c_uint8)), self.voices), "klg_voice_stages")
+        return st
+
+    def process_device(self, d_mix_ptr, n, stream=None):
+        check(self._L.klg_process_device(self._h, C.c_void_p(int(d_mix_ptr)), int(n), C.c_void_p(int(stream)) if stream else None), "klg_process_device")
+
+    def sync(self):
+        check(self._L.klg_sync(self._h), "klg_sync")
+
+    def voice_download(self, voice):
+        buf = np.empty(self.state_bytes // 4, dtype=np.uint32)
+        check(self._L.klg_voice_download(self._h, int(voice), buf.ctypes.data_as(C.c_void_p), self.state_bytes), "klg_voice_download")
+        return buf
+
+    def voice_upload(self, voice, words):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        check(self._L.klg_voice_upload(self._h, int(voice), words.ctypes.data_as(C.c_void_p), words.nbytes), "klg_voice_upload")
+
+    def timing_begin(self):
+        check(self._L.klg_timing_begin(self._h), "klg_timing_begin")
+
+    def timing_end(self):
+        n, ms = C.c_int(), C.c_float()
+        check(self._L.klg_timing_end(self._h, C.byref(n), C.byref(ms)), "klg_timing_end")
+        return n.value, ms.value
+
+
+class FxBank:
+    """`instances` independent Stereo::Effect objects of one patch (PingPong.k / Reverb.k)."""
+
+    def __init__(self, patch, instances, fs=48000.0, max_block=256):
+        self._L = lib()
+        self._h = None
+        pid = PATCH_IDS[patch] if isinstance(patch, str) else int(patch)
+        h = self._L.klg_fx_create(pid, int(instances), float(fs), int(max_block))
+        if not h:
+            raise KlangError("klg_fx_create failed: " + self._L.klg_last_error().decode())
+        self._h = h
+        self.instances = instances
+        self.state_bytes = self._L.klg_fx_state_bytes(h)
+
+    def close(self):
+        if self._h:
+            self._L.klg_fx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_control(self, instance, index, value):
+        return check(self._L.klg_fx_set_control(self._h, int(instance), int(index), float(value)), "klg_fx_set_control")
+
+    def process(self, io):
+        """io: float32 [instances][2][n], processed in place."""
+        assert io.dtype == np.float32 and io.flags.c_contiguous and io.shape[:2] == (self.instances, 2)
+        check(self._L.klg_fx_process(self._h, _fp(io), io.shape[2]), "klg_fx_process")
+        return io
+
+    def process_device(self, d_io_ptr, n, stream=None):
+        check(self._L.klg_fx_process_device(self._h, C.c_void_p(int(d_io_ptr)), int(n), C.c_void_p(int(stream)) if stream else None), "klg_fx_process_device")
+
+    def sync(self):
+        check(self._L.klg_fx_sync(self._h), "klg_fx_sync")
+
+    def timing_begin(self):
+        check(self._L.klg_fx_timing_begin(self._h), "klg_fx_timing_begin")
+
+    def timing_end(self):
+        n, ms = C.c_int(), C.c_float()
+        check(self._L.klg_fx_timing_end(self._h, C.byref(n), C.byref(ms)), "klg_fx_timing_end")
+        return n.value, ms.value

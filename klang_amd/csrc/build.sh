@@ -1,0 +1,10 @@
+#!/bin/bash
+# klang_amd/csrc/build.sh — builds klang_amd/libklang_mi355.so for gfx950 (cross-compiles without a GPU).
+# -ffp-contract=off is REQUIRED: the reference path is bit-stable only without FMA contraction.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../libklang_mi355.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared \
+    -Wall -Wno-unused-function "$@" "$HERE/klg_api.hip" -o "$OUT"
+echo "built $OUT"

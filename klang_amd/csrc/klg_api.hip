@@ -1,0 +1,533 @@
+// klang_amd/csrc/klg_api.hip — libklang_mi355.so: the C-ABI of include/klang_mi355.h.
+//
+// Host side (this file): voice allocation (Notes::assign), note lifecycle (NoteBase::start/release/stop),
+// controls, the patches' on()/off() code and event dispatch — all on the CPU, as in the reference.
+// Device side (klg_kernels.hpp): everything per sample.  There is no CPU rendering path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/klang_mi355.h"
+#include "klg_host_dsl.hpp"
+#include "klg_kernels.hpp"
+#include "klg_fx.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace klg;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int g_device = -1;
+
+static int fail(int code, const char* fmt, ...) {
+	char buf[512];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+	g_err = buf;
+	return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(KLG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" const char* klg_last_error(void) { return g_err.c_str(); }
+extern "C" int klg_version(void) { return 100; }
+
+int klg_ensure_device() {
+	if (g_device >= 0) { if (hipSetDevice(g_device) != hipSuccess) return fail(KLG_ERR_NO_DEVICE, "hipSetDevice(%d) failed", g_device); return 0; }
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+		return fail(KLG_ERR_NO_DEVICE, "no HIP device visible: libklang_mi355 has no CPU fallback");
+	if (hipSetDevice(0) != hipSuccess) return fail(KLG_ERR_NO_DEVICE, "hipSetDevice(0) failed");
+	g_device = 0;
+	return 0;
+}
+
+extern "C" int klg_init(const int* device_ids, int n_devices) {
+	if (!device_ids || n_devices != 1) return fail(KLG_ERR_INVALID, "klg_init: one device per process (got %d)", n_devices);
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(KLG_ERR_NO_DEVICE, "no HIP device visible: libklang_mi355 has no CPU fallback");
+	if (device_ids[0] < 0 || device_ids[0] >= count) return fail(KLG_ERR_INVALID, "device id %d out of range (0..%d)", device_ids[0], count - 1);
+	if (hipSetDevice(device_ids[0]) != hipSuccess) return fail(KLG_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device_ids[0]);
+	g_device = device_ids[0];
+	return 0;
+}
+
+extern "C" void klg_random_seed(unsigned seed) { srand(seed); }     // klang::random(seed) klang.h:239
+
+// ------------------------------------------------------------------------------------------------
+// patch table
+// ------------------------------------------------------------------------------------------------
+struct DialDef { float min, max, initial; };
+struct PatchInfo { int words; int ncontrols; DialDef dials[KLG_MAX_CTL]; int fsines; };
+
+static const PatchInfo* patch_info(int id) {
+	static const PatchInfo T[KLG_PATCH_COUNT] = {
+		/* SINE     */ { (int)sizeof(PatchSine::Rec) / 4, 0, {}, 1 },
+		/* BSINE    */ { (int)sizeof(PatchBSine::Rec) / 4, 0, {}, 0 },
+		/* SUB2A    */ { (int)sizeof(PatchSub2a::Rec) / 4, 0, {}, 0 },
+		/* SUB2B    */ { (int)sizeof(PatchSub2b::Rec) / 4, 0, {}, 0 },
+		/* SUPERSAW */ { (int)sizeof(PatchSuperSaw::Rec) / 4, 3, { { 0.001f, 1.f, 0.001f }, { 0.f, 1.f, 0.05f }, { 0.f, 1.f, 0.6f } }, 0 },   // SuperSaw.k:38-43
+		/* FM3      */ { (int)sizeof(PatchFM<3>::Rec) / 4, 4, { { 0.001f, 10.f, 1.0f }, { 0.f, 10.f, 0.37f }, { 0.f, 10.f, 0.37f }, { 0.f, 1.f, 0.5f } }, 3 },  // FM.k:79-85
+		/* FM4      */ { (int)sizeof(PatchFM<4>::Rec) / 4, 5, { { 0.001f, 10.f, 1.0f }, { 0.f, 10.f, 0.37f }, { 0.f, 10.f, 0.37f }, { 0.f, 10.f, 0.37f }, { 0.f, 1.f, 0.5f } }, 4 },
+		/* PINGPONG */ { 0, 0, {}, 0 },
+		/* REVERB   */ { 0, 0, {}, 0 },
+	};
+	return (id >= 0 && id < KLG_PATCH_COUNT) ? &T[id] : nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct HostVoice { uint8_t stage = ST_OFF; float pitch = 0.f, velocity = 0.f; host::FSineH fs[4]; host::OsmH osm[7]; };
+struct Event { int voice, type, payload; unsigned seq; };
+
+struct klg_synth {
+	int patch = 0, S = 0, P = 0, V = 0, W = 0, max_block = 0, nctl = 0;
+	size_t stride = 0;
+	host::Fs fs;
+	SampleRate dfs;
+	hipStream_t stream = nullptr;
+	uint32_t* d_state = nullptr;
+	float *d_controls = nullptr, *d_partials = nullptr, *d_mix = nullptr, *d_per_voice = nullptr;
+	uint32_t* d_scratch_rec = nullptr;
+	int grid = 0;
+	// host mirrors
+	std::vector<host::ControlH> controls;        // [S][nctl]
+	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
+	bool controls_dirty = true;
+	std::vector<HostVoice> voices;
+	std::vector<unsigned> noteOns;               // [S]
+	std::vector<unsigned> noteStart;             // [S][128]
+	bool stages_dirty = false;
+	// events
+	std::vector<Event> events;
+	std::vector<uint32_t> payload;
+	unsigned seq = 0;
+	void* h_stage = nullptr; size_t h_stage_cap = 0;      // pinned
+	void* d_stage = nullptr; size_t d_stage_cap = 0;
+	hipEvent_t stage_done = nullptr;
+	// pinned readback
+	float* h_mix = nullptr; uint32_t* h_flags = nullptr; float* h_per_voice = nullptr;
+	// timing
+	bool timing = false; std::vector<hipEvent_t> tev; int launches = 0;
+};
+
+static void synth_free(klg_synth* s) {
+	if (!s) return;
+	if (s->stream) (void)hipStreamSynchronize(s->stream);
+	void* dev[] = { s->d_state, s->d_controls, s->d_partials, s->d_mix, s->d_per_voice, s->d_scratch_rec, s->d_stage };
+	for (void* p : dev) if (p) (void)hipFree(p);
+	void* pinned[] = { s->h_stage, s->h_mix, s->h_flags, s->h_per_voice };
+	for (void* p : pinned) if (p) (void)hipHostFree(p);
+	if (s->stage_done) (void)hipEventDestroy(s->stage_done);
+	for (auto e : s->tev) (void)hipEventDestroy(e);
+	if (s->stream) (void)hipStreamDestroy(s->stream);
+	delete s;
+}
+
+extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_synth, float sample_rate, int max_block) {
+	const PatchInfo* pi = patch_info(patch_id);
+	if (!pi || pi->words == 0) { fail(KLG_ERR_INVALID, "klg_synth_create: patch %d is not a synth patch", patch_id); return nullptr; }
+	if (synths <= 0 || notes_per_synth <= 0 || notes_per_synth > 128) { fail(KLG_ERR_INVALID, "klg_synth_create: synths=%d notes_per_synth=%d (1..128, Array<NOTE*,128>)", synths, notes_per_synth); return nullptr; }
+	if (max_block <= 0 || max_block > MAX_BLOCK) { fail(KLG_ERR_INVALID, "klg_synth_create: max_block %d not in 1..%d", max_block, (int)MAX_BLOCK); return nullptr; }
+	if (!(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_synth_create: bad sample rate"); return nullptr; }
+	if (klg_ensure_device()) return nullptr;
+	klg_synth* s = new klg_synth();
+	s->patch = patch_id; s->S = synths; s->P = notes_per_synth; s->V = synths * notes_per_synth; s->W = pi->words;
+	s->max_block = max_block; s->nctl = pi->ncontrols;
+	s->stride = ((size_t)s->V + WG - 1) / WG * WG;
+	s->fs = host::Fs(sample_rate);
+	s->dfs.f = s->fs.f; s->dfs.w = s->fs.w; s->dfs.timeInc = 1.0f / s->fs.f;
+	hipDeviceProp_t prop;
+	bool ok = hipGetDeviceProperties(&prop, g_device) == hipSuccess;
+	const int groups = (int)(s->stride / WG);
+	s->grid = std::min(groups, (ok ? prop.multiProcessorCount : 256) * 16);
+	ok = ok && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+	ok = ok && hipMalloc(&s->d_state, (size_t)s->W * s->stride * 4) == hipSuccess;
+	ok = ok && hipMalloc(&s->d_controls, (size_t)s->S * KLG_MAX_CTL * 4) == hipSuccess;
+	ok = ok && hipMalloc(&s->d_partials, (size_t)s->grid * max_block * 4) == hipSuccess;
+	ok = ok && hipMalloc(&s->d_mix, (size_t)2 * max_block * 4) == hipSuccess;
+	ok = ok && hipMalloc(&s->d_scratch_rec, 64 * 4) == hipSuccess;
+	ok = ok && hipHostMalloc(&s->h_mix, (size_t)2 * max_block * 4) == hipSuccess;
+	ok = ok && hipHostMalloc(&s->h_flags, s->stride * 4) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags(&s->stage_done, hipEventDisableTiming) == hipSuccess;
+	if (!ok) { fail(KLG_ERR_NOMEM, "klg_synth_create: device allocation failed (%zu state bytes): %s", (size_t)s->W * s->stride * 4, hipGetErrorString(hipGetLastError())); synth_free(s); return nullptr; }
+	// every voice starts Off (NoteBase::stage = Off, klang.h:4286): flags plane = ST_OFF, rest zero
+	std::vector<uint32_t> init((size_t)s->W * s->stride, 0u);
+	std::fill(init.begin(), init.begin() + s->stride, (uint32_t)ST_OFF);
+	if (hipMemcpy(s->d_state, init.data(), init.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { fail(KLG_ERR_HIP, "state init copy failed"); synth_free(s); return nullptr; }
+	s->controls.resize((size_t)s->S * std::max(1, s->nctl));
+	s->h_controls.assign((size_t)s->S * KLG_MAX_CTL, 0.f);
+	for (int i = 0; i < s->S; i++) for (int c = 0; c < s->nctl; c++) {
+		s->controls[(size_t)i * s->nctl + c] = { pi->dials[c].min, pi->dials[c].max, pi->dials[c].initial };
+		s->h_controls[(size_t)i * KLG_MAX_CTL + c] = pi->dials[c].initial;
+	}
+	s->voices.resize(s->V);
+	if (patch_id == KLG_PATCH_SUPERSAW) for (auto& v : s->voices) for (auto& o : v.osm) o = host::OsmH(0.f);
+	s->noteOns.assign(s->S, 0u);
+	s->noteStart.assign((size_t)s->S * 128, 0u);
+	return s;
+}
+
+extern "C" void klg_synth_destroy(klg_synth* s) { if (s && g_device >= 0) (void)hipSetDevice(g_device); synth_free(s); }
+extern "C" int klg_synth_voices(const klg_synth* s) { return s ? s->V : KLG_ERR_INVALID; }
+extern "C" int klg_synth_controls(const klg_synth* s) { return s ? s->nctl : KLG_ERR_INVALID; }
+extern "C" size_t klg_synth_state_bytes(const klg_synth* s) { return s ? (size_t)s->W * 4 : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// kernel dispatch by patch
+// ------------------------------------------------------------------------------------------------
+template<class P> static void launch_render_t(klg_synth* s, const RenderArgs& a, bool pv, hipStream_t st) {
+	if (pv) hipLaunchKernelGGL((klg_render<P, true>), dim3(s->grid), dim3(WG), 0, st, a);
+	else hipLaunchKernelGGL((klg_render<P, false>), dim3(s->grid), dim3(WG), 0, st, a);
+}
+static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_t st) {
+	switch (s->patch) {
+	case KLG_PATCH_SINE: launch_render_t<PatchSine>(s, a, pv, st); break;
+	case KLG_PATCH_BSINE: launch_render_t<PatchBSine>(s, a, pv, st); break;
+	case KLG_PATCH_SUB2A: launch_render_t<PatchSub2a>(s, a, pv, st); break;
+	case KLG_PATCH_SUB2B: launch_render_t<PatchSub2b>(s, a, pv, st); break;
+	case KLG_PATCH_SUPERSAW: launch_render_t<PatchSuperSaw>(s, a, pv, st); break;
+	case KLG_PATCH_FM3: launch_render_t<PatchFM<3>>(s, a, pv, st); break;
+	case KLG_PATCH_FM4: launch_render_t<PatchFM<4>>(s, a, pv, st); break;
+	}
+}
+static void launch_events(klg_synth* s, const EventArgs& a, hipStream_t st) {
+	const dim3 g((a.runs + 63) / 64), b(64);
+	switch (s->patch) {
+	case KLG_PATCH_SINE: hipLaunchKernelGGL(klg_apply_events<PatchSine>, g, b, 0, st, a); break;
+	case KLG_PATCH_BSINE: hipLaunchKernelGGL(klg_apply_events<PatchBSine>, g, b, 0, st, a); break;
+	case KLG_PATCH_SUB2A: hipLaunchKernelGGL(klg_apply_events<PatchSub2a>, g, b, 0, st, a); break;
+	case KLG_PATCH_SUB2B: hipLaunchKernelGGL(klg_apply_events<PatchSub2b>, g, b, 0, st, a); break;
+	case KLG_PATCH_SUPERSAW: hipLaunchKernelGGL(klg_apply_events<PatchSuperSaw>, g, b, 0, st, a); break;
+	case KLG_PATCH_FM3: hipLaunchKernelGGL(klg_apply_events<PatchFM<3>>, g, b, 0, st, a); break;
+	case KLG_PATCH_FM4: hipLaunchKernelGGL(klg_apply_events<PatchFM<4>>, g, b, 0, st, a); break;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// events: host queue -> one staged H2D copy -> klg_apply_events
+// ------------------------------------------------------------------------------------------------
+static int flush_events(klg_synth* s, hipStream_t st) {
+	if (s->events.empty()) return 0;
+	std::stable_sort(s->events.begin(), s->events.end(), [](const Event& a, const Event& b) { return a.voice != b.voice ? a.voice < b.voice : a.seq < b.seq; });
+	const size_t E = s->events.size();
+	std::vector<int> run_voice, run_first, run_count;
+	for (size_t e = 0; e < E; e++) {
+		if (e == 0 || s->events[e].voice != s->events[e - 1].voice) { run_voice.push_back(s->events[e].voice); run_first.push_back((int)e); run_count.push_back(0); }
+		run_count.back()++;
+	}
+	const size_t R = run_voice.size();
+	const size_t bytes = (3 * R + 2 * E) * 4 + s->payload.size() * 4;
+	if (bytes > s->h_stage_cap) {
+		HIP_TRY(hipEventSynchronize(s->stage_done));
+		if (s->h_stage) (void)hipHostFree(s->h_stage);
+		if (s->d_stage) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(s->d_stage); }
+		s->h_stage_cap = s->d_stage_cap = bytes * 2;
+		HIP_TRY(hipHostMalloc(&s->h_stage, s->h_stage_cap));
+		HIP_TRY(hipMalloc(&s->d_stage, s->d_stage_cap));
+	}
+	HIP_TRY(hipEventSynchronize(s->stage_done));           // previous staged copy has left the pinned buffer
+	HIP_TRY(hipStreamSynchronize(st));                     // previous apply kernel has consumed the device copy
+	int* h = (int*)s->h_stage;
+	int* h_rv = h; int* h_rf = h + R; int* h_rc = h + 2 * R; int* h_et = h + 3 * R; int* h_ep = h + 3 * R + E; uint32_t* h_pl = (uint32_t*)(h + 3 * R + 2 * E);
+	std::copy(run_voice.begin(), run_voice.end(), h_rv);
+	std::copy(run_first.begin(), run_first.end(), h_rf);
+	std::copy(run_count.begin(), run_count.end(), h_rc);
+	for (size_t e = 0; e < E; e++) { h_et[e] = s->events[e].type; h_ep[e] = s->events[e].payload; }
+	std::copy(s->payload.begin(), s->payload.end(), h_pl);
+	HIP_TRY(hipMemcpyAsync(s->d_stage, s->h_stage, bytes, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipEventRecord(s->stage_done, st));
+	int* d = (int*)s->d_stage;
+	EventArgs a;
+	a.state = s->d_state; a.stride = s->stride;
+	a.run_voice = d; a.run_first = d + R; a.run_count = d + 2 * R; a.runs = (int)R;
+	a.ev_type = d + 3 * R; a.ev_payload = d + 3 * R + E; a.payload = (const uint32_t*)(d + 3 * R + 2 * E);
+	a.fs = s->fs.f;
+	launch_events(s, a, st);
+	HIP_TRY(hipGetLastError());
+	s->events.clear(); s->payload.clear();
+	return 0;
+}
+
+static int upload_controls(klg_synth* s, hipStream_t st) {
+	if (!s->controls_dirty) return 0;
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipMemcpyAsync(s->d_controls, s->h_controls.data(), s->h_controls.size() * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));   // h_controls is pageable and may change right after return
+	s->controls_dirty = false;
+	return 0;
+}
+
+// device flags -> host NoteBase::stage mirror (a note the GPU stopped becomes Off: klang.h:4455-4456)
+static int refresh_stages(klg_synth* s) {
+	if (!s->stages_dirty) return 0;
+	if (int rc = flush_events(s, s->stream)) return rc;
+	HIP_TRY(hipMemcpyAsync(s->h_flags, s->d_state, (size_t)s->V * 4, hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	for (int v = 0; v < s->V; v++) if ((s->h_flags[v] & 3u) == (uint32_t)ST_OFF) s->voices[v].stage = ST_OFF;
+	s->stages_dirty = false;
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the patches' on() code (host) -> lane record
+// ------------------------------------------------------------------------------------------------
+static void push_note_on(klg_synth* s, int voice, const void* rec) {
+	const int idx = (int)(s->payload.size() / s->W);
+	const uint32_t* w = (const uint32_t*)rec;
+	s->payload.insert(s->payload.end(), w, w + s->W);
+	s->events.push_back({ voice, 0, idx, s->seq++ });
+}
+
+static void patch_on(klg_synth* s, int synth, int voice) {
+	HostVoice& hv = s->voices[voice];
+	const host::Fs& fs = s->fs;
+	const host::ControlH* ctl = s->nctl ? &s->controls[(size_t)synth * s->nctl] : nullptr;
+	const float f = host::pitch_to_frequency(hv.pitch);          // const param f = pitch -> Frequency;
+	switch (s->patch) {
+	case KLG_PATCH_SINE: {                                        // osc(f, 0)
+		hv.fs[0].set(f, 0.f, fs);
+		PatchSine::Rec r; r.flags = ST_SUSTAIN; r.inc = hv.fs[0].inc; r.pos = hv.fs[0].pos;
+		push_note_on(s, voice, &r);
+	} break;
+	case KLG_PATCH_BSINE: {
+		host::BOscH o; o.set(f, 0.f, fs);
+		PatchBSine::Rec r; r.flags = ST_SUSTAIN; r.increment = o.increment; r.position = o.position; r.offset = o.offset;
+		push_note_on(s, voice, &r);
+	} break;
+	case KLG_PATCH_SUB2A: {                                       // osc(f,0); lpf.reset(); lpf.set(4*f, 2); adsr(0.01,0.1,0.7,0.25)
+		host::OsmH osc(0.f); osc.set(f, 0.f, fs);
+		host::BiquadLpfH lpf; lpf.reset(); lpf.set(4.f * f, 2.f, fs);
+		host::AdsrH adsr; adsr.set(0.01f, 0.1f, 0.7f, 0.25f, fs);
+		PatchSub2a::Rec r;
+		osc.pack(r.osc); lpf.pack(r.lpf); adsr.pack(r.adsr);
+		r.flags = (uint32_t)ST_SUSTAIN | (adsr.env.bits() << 2) | ((uint32_t)osc.state << 8);
+		push_note_on(s, voice, &r);
+	} break;
+	case KLG_PATCH_SUB2B: {                                       // subtractive.k:14-23
+		host::OsmH osc(1.0f); osc.set(f, 0.f, fs);
+		host::AdsrH adsr; adsr.set(0.f, 0.f, 1.f, 0.25f, fs);
+		host::EnvH env; const float xy[6] = { 0.f, f * 2.f, 0.25f, f * 10.f, 2.f, f * 5.f }; env.set_points(3, xy, fs);
+		host::BiquadLpfH filter; filter.reset();
+		PatchSub2b::Rec r;
+		osc.pack(r.osc); adsr.pack(r.adsr);
+		r.env.r_out = env.r_out; r.env.r_target = env.r_target; r.env.r_rate = env.r_rate; r.env.time = env.time;
+		for (int k = 0; k < 3; k++) { r.env.px[k] = env.px[k]; r.env.py[k] = env.py[k]; }
+		r.filter.f = filter.f; r.filter.Q = filter.Q; filter.pack(r.filter.c);
+		r.flags = (uint32_t)ST_SUSTAIN | (adsr.env.bits() << 2) | (env.bits() << 8) | ((uint32_t)osc.state << 14);
+		push_note_on(s, voice, &r);
+	} break;
+	case KLG_PATCH_SUPERSAW: {                                    // SuperSaw.k:12-19
+		const float detune = (float)(0.01 * (double)ctl[2].value * (double)f);
+		PatchSuperSaw::Rec r;
+		uint32_t flags = ST_SUSTAIN;
+		for (int k = 0; k < 7; k++) {
+			const double d = (double)((float)(k - 3) * detune) * host::random_d(0.999, 1.001);
+			hv.osm[k].set(f + (float)d, 0.f, ctl[1].value, fs);
+			hv.osm[k].pack(r.osc[k]);
+			flags |= (uint32_t)hv.osm[k].state << (8 + 2 * k);
+		}
+		host::AdsrH adsr; adsr.set(ctl[0].value, 0.25f, 1.0f, 0.5f, fs);
+		adsr.pack(r.adsr);
+		r.flags = flags | (adsr.env.bits() << 2);
+		push_note_on(s, voice, &r);
+	} break;
+	case KLG_PATCH_FM3: case KLG_PATCH_FM4: {                     // FM.k:36-55 / 4-operator variant (oracle/ref/ref_fm.cpp)
+		const int NOPS = s->patch == KLG_PATCH_FM3 ? 3 : 4;
+		const float fc = f, fd = fc * ctl[0].value;
+		static const float e1[4] = { 0, 0, 3, 1 }, e2[4] = { 0, 1.5f, 3, 0.5f }, e3[4] = { 0, 1, 2, 0.25f };
+		const float* envs[4] = { e1, e2, NOPS == 4 ? e3 : nullptr, nullptr };
+		uint32_t rec_words[64] = { 0 };
+		uint32_t flags = ST_SUSTAIN, meta = 0;
+		PatchFM<4>::OpRec* ops = (PatchFM<4>::OpRec*)(rec_words + 2);
+		for (int k = 0; k < NOPS; k++) {
+			hv.fs[k].set(k == NOPS - 1 ? fc : fd, 0.f, fs);
+			host::EnvH env;                                      // Operator::env default = Envelope() : one point (0,1)
+			if (envs[k]) env.set_points(2, envs[k], fs);
+			else { const float one[2] = { 0.f, 1.f }; env.set_points(1, one, fs); }
+			PatchFM<4>::OpRec& q = ops[k];
+			q.inc = hv.fs[k].inc; q.pos = hv.fs[k].pos;
+			q.r_out = env.r_out; q.r_target = env.r_target; q.r_rate = env.r_rate; q.time = env.time;
+			q.px[0] = env.px[0]; q.px[1] = env.px[1]; q.py[0] = env.py[0]; q.py[1] = env.py[1];
+			flags |= env.bits() << (8 + 6 * k);
+			meta |= (uint32_t)env.npoints << (2 * k);
+		}
+		host::AdsrH adsr; adsr.set(ctl[NOPS].value, 0.1f, 1.f, 1.f, fs);
+		adsr.pack(*(AdsrRec*)(ops + NOPS));
+		rec_words[0] = flags | (adsr.env.bits() << 2); rec_words[1] = meta;
+		push_note_on(s, voice, rec_words);
+	} break;
+	}
+}
+
+// Notes::assign klang.h:4336-4372
+static int synth_assign(klg_synth* s, int synth) {
+	HostVoice* n = &s->voices[(size_t)synth * s->P];
+	unsigned* start = &s->noteStart[(size_t)synth * 128];
+	unsigned& ons = s->noteOns[synth];
+	for (int i = 0; i < s->P; i++) if (n[i].stage == ST_OFF) { start[i] = ons++; return i; }
+	int oldest = -1; unsigned oldest_start = 0;
+	for (int i = 0; i < s->P; i++) if (n[i].stage == ST_RELEASE && (oldest == -1 || start[i] < oldest_start)) { oldest = i; oldest_start = start[i]; }
+	if (oldest != -1) { start[oldest] = ons++; return oldest; }
+	oldest = -1; oldest_start = 0;
+	for (int i = 0; i < s->P; i++) if (oldest == -1 || start[i] < oldest_start) { oldest = i; oldest_start = start[i]; }
+	start[oldest] = ons++;
+	return oldest;
+}
+
+extern "C" int klg_note_on(klg_synth* s, int synth, int pitch, float velocity) {
+	if (!s || synth < 0 || synth >= s->S) return fail(KLG_ERR_INVALID, "klg_note_on: bad handle or synth index %d", synth);
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (int rc = refresh_stages(s)) return rc;
+	const int slot = synth_assign(s, synth);
+	const int voice = synth * s->P + slot;
+	HostVoice& hv = s->voices[voice];
+	hv.stage = ST_ONSET;                                         // NoteBase::start klang.h:4257-4263
+	hv.pitch = (float)pitch; hv.velocity = velocity;
+	patch_on(s, synth, voice);
+	hv.stage = ST_SUSTAIN;
+	return slot;
+}
+
+extern "C" int klg_note_off(klg_synth* s, int synth, int pitch, float velocity) {
+	(void)velocity;
+	if (!s || synth < 0 || synth >= s->S) return fail(KLG_ERR_INVALID, "klg_note_off: bad handle or synth index %d", synth);
+	for (int i = 0; i < s->P; i++) {
+		const int voice = synth * s->P + i;
+		HostVoice& hv = s->voices[voice];
+		if (hv.pitch == (float)pitch && hv.stage == ST_SUSTAIN) { // klang.h:4432 ; NoteBase::release 4265-4275
+			hv.stage = ST_RELEASE;
+			if (s->patch == KLG_PATCH_SINE || s->patch == KLG_PATCH_BSINE) hv.stage = ST_OFF;   // off() { stop(); }
+			s->events.push_back({ voice, 1, -1, s->seq++ });
+		}
+	}
+	return 0;
+}
+
+extern "C" int klg_set_control(klg_synth* s, int synth, int index, float value) {
+	if (!s || synth < 0 || synth >= s->S || index < 0 || index >= s->nctl) return fail(KLG_ERR_INVALID, "klg_set_control: synth %d / control %d out of range", synth, index);
+	host::ControlH& c = s->controls[(size_t)synth * s->nctl + index];
+	c.set(value);
+	s->h_controls[(size_t)synth * KLG_MAX_CTL + index] = c.value;
+	s->controls_dirty = true;
+	return 0;
+}
+extern "C" int klg_get_control(klg_synth* s, int synth, int index, float* value) {
+	if (!s || !value || synth < 0 || synth >= s->S || index < 0 || index >= s->nctl) return fail(KLG_ERR_INVALID, "klg_get_control: out of range");
+	*value = s->controls[(size_t)synth * s->nctl + index].value;
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// block processing
+// ------------------------------------------------------------------------------------------------
+static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipStream_t st) {
+	if (int rc = flush_events(s, st)) return rc;
+	if (int rc = upload_controls(s, st)) return rc;
+	RenderArgs a;
+	a.state = s->d_state; a.stride = s->stride; a.voices = s->V; a.notes_per_synth = s->P; a.n = n;
+	a.controls = s->d_controls; a.fs = s->dfs; a.partials = s->d_partials; a.per_voice = per_voice ? s->d_per_voice : nullptr;
+	if (s->timing) {
+		if ((int)s->tev.size() < 2 * (s->launches + 1)) { hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); s->tev.push_back(e0); s->tev.push_back(e1); }
+		HIP_TRY(hipEventRecord(s->tev[2 * s->launches], st));
+	}
+	launch_render(s, a, per_voice, st);
+	if (s->timing) { HIP_TRY(hipEventRecord(s->tev[2 * s->launches + 1], st)); s->launches++; }
+	hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)s->d_partials, s->grid, n, d_mix, 2);
+	HIP_TRY(hipGetLastError());
+	s->stages_dirty = true;
+	return 0;
+}
+
+static int process_host(klg_synth* s, float* per_voice, float* const* out, int channels, int n, float* parameters) {
+	if (!s || n <= 0 || n > s->max_block) return fail(KLG_ERR_INVALID, "klg_process: n=%d not in 1..max_block", n);
+	if (out && (channels < 1 || channels > 2)) return fail(KLG_ERR_INVALID, "klg_process: channels must be 1 or 2");
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (parameters && s->nctl)                                   // sync parameters in (klang.h:4836-4839)
+		for (int i = 0; i < s->S; i++) for (int c = 0; c < s->nctl; c++) klg_set_control(s, i, c, parameters[(size_t)i * s->nctl + c]);
+	hipStream_t st = s->stream;
+	if (per_voice && !s->d_per_voice) {
+		HIP_TRY(hipMalloc(&s->d_per_voice, (size_t)s->V * s->max_block * 4));
+		HIP_TRY(hipHostMalloc(&s->h_per_voice, (size_t)s->V * s->max_block * 4));
+	}
+	HIP_TRY(hipMemsetAsync(s->d_mix, 0, (size_t)2 * n * 4, st));
+	if (int rc = enqueue_block(s, s->d_mix, n, per_voice != nullptr, st)) return rc;
+	HIP_TRY(hipMemcpyAsync(s->h_mix, s->d_mix, (size_t)2 * n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(s->h_flags, s->d_state, (size_t)s->V * 4, hipMemcpyDeviceToHost, st));
+	if (per_voice) HIP_TRY(hipMemcpyAsync(s->h_per_voice, s->d_per_voice, (size_t)s->V * n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (out) for (int c = 0; c < channels; c++) { float* dst = out[c]; const float* src = s->h_mix + (size_t)c * n; for (int i = 0; i < n; i++) dst[i] += src[i]; }
+	if (per_voice) std::memcpy(per_voice, s->h_per_voice, (size_t)s->V * n * 4);
+	for (int v = 0; v < s->V; v++) if ((s->h_flags[v] & 3u) == (uint32_t)ST_OFF) s->voices[v].stage = ST_OFF;
+	s->stages_dirty = false;
+	if (parameters && s->nctl)                                   // sync update out (klang.h:4854-4857)
+		for (int i = 0; i < s->S; i++) for (int c = 0; c < s->nctl; c++) parameters[(size_t)i * s->nctl + c] = s->controls[(size_t)i * s->nctl + c].value;
+	return 0;
+}
+
+extern "C" int klg_process(klg_synth* s, float* const* out, int channels, int n, float* parameters) {
+	if (!out) return fail(KLG_ERR_INVALID, "klg_process: out is NULL");
+	return process_host(s, nullptr, out, channels, n, parameters);
+}
+extern "C" int klg_process_voices(klg_synth* s, float* per_voice, float* const* out, int channels, int n) {
+	if (!per_voice) return fail(KLG_ERR_INVALID, "klg_process_voices: per_voice is NULL");
+	return process_host(s, per_voice, out, channels, n, nullptr);
+}
+extern "C" int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices) {
+	if (!s || !stages || n_voices < 0 || n_voices > s->V) return fail(KLG_ERR_INVALID, "klg_voice_stages: bad arguments");
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (int rc = refresh_stages(s)) return rc;
+	for (int v = 0; v < n_voices; v++) stages[v] = s->voices[v].stage;
+	return 0;
+}
+
+extern "C" int klg_process_device(klg_synth* s, float* d_mix, int n, void* hip_stream) {
+	if (!s || !d_mix || n <= 0 || n > s->max_block) return fail(KLG_ERR_INVALID, "klg_process_device: bad arguments (n=%d)", n);
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	return enqueue_block(s, d_mix, n, false, hip_stream ? (hipStream_t)hip_stream : s->stream);
+}
+extern "C" int klg_sync(klg_synth* s) {
+	if (!s) return fail(KLG_ERR_INVALID, "klg_sync: NULL handle");
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	HIP_TRY(hipDeviceSynchronize());
+	return 0;
+}
+
+extern "C" int klg_voice_download(klg_synth* s, int voice, void* state, size_t bytes) {
+	if (!s || !state || voice < 0 || voice >= s->V || bytes != (size_t)s->W * 4) return fail(KLG_ERR_INVALID, "klg_voice_download: bad arguments (record is %d bytes)", s ? s->W * 4 : 0);
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (int rc = flush_events(s, s->stream)) return rc;
+	hipLaunchKernelGGL(klg_copy_record, dim3(1), dim3(64), 0, s->stream, s->d_state, s->stride, voice, s->d_scratch_rec, s->W, 0);
+	HIP_TRY(hipMemcpyAsync(state, s->d_scratch_rec, bytes, hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return 0;
+}
+extern "C" int klg_voice_upload(klg_synth* s, int voice, const void* state, size_t bytes) {
+	if (!s || !state || voice < 0 || voice >= s->V || bytes != (size_t)s->W * 4) return fail(KLG_ERR_INVALID, "klg_voice_upload: bad arguments (record is %d bytes)", s ? s->W * 4 : 0);
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (int rc = flush_events(s, s->stream)) return rc;
+	HIP_TRY(hipMemcpyAsync(s->d_scratch_rec, state, bytes, hipMemcpyHostToDevice, s->stream));
+	hipLaunchKernelGGL(klg_copy_record, dim3(1), dim3(64), 0, s->stream, s->d_state, s->stride, voice, s->d_scratch_rec, s->W, 1);
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	s->voices[voice].stage = (uint8_t)(((const uint32_t*)state)[0] & 3u);
+	return 0;
+}
+
+extern "C" int klg_timing_begin(klg_synth* s) { if (!s) return fail(KLG_ERR_INVALID, "NULL handle"); s->timing = true; s->launches = 0; return 0; }
+extern "C" int klg_timing_end(klg_synth* s, int* launches, float* total_ms) {
+	if (!s || !launches || !total_ms) return fail(KLG_ERR_INVALID, "klg_timing_end: bad arguments");
+	HIP_TRY(hipDeviceSynchronize());
+	float total = 0.f;
+	for (int i = 0; i < s->launches; i++) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, s->tev[2 * i], s->tev[2 * i + 1])); total += ms; }
+	*launches = s->launches; *total_ms = total;
+	s->timing = false;
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// effect banks: see klg_fx_api.hpp
+// ------------------------------------------------------------------------------------------------
+#include "klg_fx_api.hpp"

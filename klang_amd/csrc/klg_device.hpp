@@ -1,0 +1,247 @@
+// klang_amd/csrc/klg_device.hpp — hand-written CDNA4 (gfx950) device primitives of the klang hot path.
+//
+// One GPU lane evaluates one voice; everything here is a __device__ function that keeps its state in
+// registers (plain structs passed by reference, fully inlined).  Arithmetic follows the reference's
+// fp32 evaluation order operation by operation (citations are file:line into the reference's klang.h,
+// v0.7.8) and this translation unit is compiled with -ffp-contract=off: the reference path is only
+// bit-stable without FMA contraction.  Divisions and sqrt are IEEE (hipcc default).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace klg {
+
+// ---- constants: `constant` klang.h:93-111, pi/root2 227-233, DENORMALISE 90 ----
+#define KLG_PI_F      3.14159274101257324f            /* (float)3.14159265358979... */
+#define KLG_PI_INV    0.318309873342514038f           /* (float)(1.0/pi) */
+#define KLG_TWO_PI    6.28318548202514648f            /* 2 * pi.f */
+#define KLG_HALF_PI   1.57079637050628662f            /* pi.f / 2.f */
+#define KLG_3HALF_PI  4.71238899230957031f            /* 3.f / 2.f * pi.f */
+#define KLG_DENORM    1.175494e-38f
+#define KLG_FINTMAX   2147483648.0f
+
+struct SampleRate { float f, w, timeInc; };           // SampleRate klang.h:1593-1604; timeInc = 1.0f / fs (3976)
+
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// float -> unsigned exactly as the pinned oracle build does it (clang, baseline x86-64: cvttss2si r64,
+// truncate to 32 bits; "integer indefinite" = 0 in the low word when out of range / NaN).  Reproduces the
+// wrap of negative FM phase offsets (F3, klang.h:4995-4996).
+__device__ __forceinline__ uint32_t f2u_wrap(float x) {
+	const bool in_range = fabsf(x) < 9223372036854775808.0f;
+	return in_range ? (uint32_t)(int64_t)x : 0u;
+}
+
+// ---- Generators::Fast helpers ----
+__device__ __forceinline__ uint32_t fast_phase(float radians) {          // Fast::Phase::operator= klang.h:4993-4998
+	return f2u_wrap(radians * KLG_FINTMAX / KLG_TWO_PI);
+}
+__device__ __forceinline__ float fast_phase_float(uint32_t pos) {        // Fast::Phase::operator float 5004-5007
+	return u2f((pos >> 9) | 0x3f800000u) - 1.f;
+}
+__device__ __forceinline__ float fast_increment_float(int32_t amount) {  // Fast::Increment::operator float 4979-4983
+	return u2f((uint32_t)((amount >> 9) | 0x3f800000)) - 1.f;
+}
+__device__ __forceinline__ float polysin(float x) {                      // klang.h:5093-5096
+	const float x2 = x * x;
+	return (((-0.00018542f * x2 + 0.0083143f) * x2 - 0.16666f) * x2 + 1.0f) * x;
+}
+__device__ __forceinline__ float fastsinp(uint32_t p) {                  // klang.h:5117-5132 (+ fast_modp 1424-1428)
+	float x = (u2f((p >> 9) | 0x3f800000u) - 1.f) * KLG_TWO_PI;
+	if (x > KLG_3HALF_PI) x -= KLG_TWO_PI;
+	else if (x > KLG_HALF_PI) x = KLG_PI_F - x;
+	return polysin(x);
+}
+
+// ---- Generators::Fast::Sine klang.h:5135-5172 (lane state: inc, pos; offset only lives inside a sample) ----
+struct FSine { int32_t inc; uint32_t pos; };
+__device__ __forceinline__ float fsine_process(FSine& o, uint32_t off) {
+	const float y = fastsinp(o.pos + off);
+	o.pos += (uint32_t)o.inc;
+	return y;
+}
+// Sine::set(relative phase) klang.h:5160-5162: offset = phase * twoPi -> Fast::Phase
+__device__ __forceinline__ uint32_t fsine_rel_offset(float rel) { return fast_phase(rel * KLG_TWO_PI); }
+
+// ---- Generic::Oscillator + Generators::Basic klang.h:2849-2880, 4899-4944 ----
+struct BOsc { float increment, position, offset; };
+__device__ __forceinline__ void phase_advance(float& value, float inc) {  // Phase::operator+=(float) 1518-1525
+	if (inc >= KLG_TWO_PI) return;
+	value += inc;
+	if (value > KLG_TWO_PI) value -= KLG_TWO_PI;
+}
+__device__ __forceinline__ float basic_sine(BOsc& o) {                    // double ::sin, rounded
+	const float y = (float)sin((double)(o.position + o.offset));
+	phase_advance(o.position, o.increment);
+	return y;
+}
+__device__ __forceinline__ float basic_saw(BOsc& o) { const float y = o.position * KLG_PI_INV - 1.f; phase_advance(o.position, o.increment); return y; }
+__device__ __forceinline__ float basic_triangle(BOsc& o) { const float y = fabsf(2.f * o.position * KLG_PI_INV - 2.f) - 1.f; phase_advance(o.position, o.increment); return y; }
+__device__ __forceinline__ float basic_square(BOsc& o) { const float y = o.position > KLG_PI_F ? 1.f : -1.f; phase_advance(o.position, o.increment); return y; }
+__device__ __forceinline__ float basic_pulse(BOsc& o, float duty) { const float y = o.position > (duty * KLG_PI_F) ? 1.f : -1.f; phase_advance(o.position, o.increment); return y; }
+
+// ---- Fast::OSM klang.h:5175-5317 ----
+// persistent: inc, offset, duty, delta, state(2 bits); the seven coefficients are re-derived per block with the
+// reference's own fp32 operations (OSM::init 5206-5215) so they cost registers, not HBM bytes.
+struct Osm {
+	int32_t inc; uint32_t offset, duty; int state; float delta;
+	float f, omf, rcpf, rcpf2, col, c1, c2;
+};
+__device__ __forceinline__ void osm_derive(Osm& o) {
+	o.f = o.delta;
+	o.omf = 1.f - o.f;
+	o.rcpf = 1.f / o.f;
+	o.rcpf2 = 2.f * o.rcpf;
+	o.col = fast_phase_float(o.duty);
+	o.c1 = 1.f / o.col;
+	o.c2 = -1.f / (1.0f - o.col);
+}
+__device__ __forceinline__ int osm_tick(Osm& o) {                           // klang.h:5251-5263
+	o.state = ((o.state << 1) | (o.offset < o.duty ? 1 : 0)) & 3;
+	const int tr = o.state | (o.offset < (uint32_t)o.inc ? 4 : 0);
+	o.offset += (uint32_t)o.inc;
+	return tr;
+}
+__device__ __forceinline__ float sqrf(float x) { return x * x; }
+__device__ __forceinline__ float osm_saw(Osm& o) {                          // saw() 5290-5302: p evaluated before tick()
+	const float p = fast_phase_float(o.offset) - o.col;
+	const int tr = osm_tick(o);
+	const float f = o.f, omf = o.omf, rcpf = o.rcpf, c1 = o.c1, c2 = o.c2;
+	float y;
+	if ((tr & 4) == 0) {
+		if (tr == 3) y = c1 * (p + p - f) + 1.f;                                // Up
+		else if (tr == 0) y = c2 * (p + p - f) + 1.f;                           // Down
+		else if (tr == 2) y = rcpf * (c2 * sqrf(p) - c1 * sqrf(p - f)) + 1.f;   // UpDown
+		else y = 0.f;
+	}
+	else {
+		if (tr == 4) y = -rcpf * (1.f + c2 * omf * (p + p + omf)) + 1.f;        // DownUpDown
+		else if (tr == 5) y = -rcpf * (1.f + c2 * sqrf(p + omf) - c1 * sqrf(p)) + 1.f;  // DownUp
+		else if (tr == 7) y = -rcpf * (1.f + c1 * omf * (p + p + omf)) + 1.f;   // UpDownUp
+		else y = 0.f;
+	}
+	return y;
+}
+__device__ __forceinline__ float osm_pulse(Osm& o) {                        // pulse() 5304-5316
+	const float p = fast_phase_float(o.offset);
+	const int tr = osm_tick(o);
+	const float rcpf2 = o.rcpf2, col = o.col;
+	float y;
+	switch (tr) {
+	case 3: y = 1.f; break;
+	case 0: y = -1.f; break;
+	case 2: y = rcpf2 * (col - p) + 1.f; break;
+	case 5: y = rcpf2 * p - 1.f; break;
+	case 7: y = rcpf2 * (col - 1.0f) + 1.f; break;
+	case 4: y = rcpf2 * col - 1.f; break;
+	default: y = 0.f;
+	}
+	return y;
+}
+
+// ---- Filters::Biquad klang.h:5550-5773 ----
+struct Biquad { float b0, b1, b2, a1, a2, z0, z1; };
+__device__ __forceinline__ float biquad_process(Biquad& q, float in) {      // TDF-II 5605-5612
+	const float z0 = q.z0, z1 = q.z1;
+	const float y = q.b0 * in + z0;
+	q.z0 = q.b1 * in - q.a1 * y + z1;
+	q.z1 = q.b2 * in - q.a2 * y;
+	return y;
+}
+// Biquad::Filter::set(f, Q) 5584-5600 + LPF::init 5658-5665, evaluated on the device for per-sample swept
+// cutoffs (shipped subtractive.k:29, F6).  cosf/sinf: the reference calls glibc's; here the double-precision
+// OCML cos/sin rounded to float (differs from glibc in at most the last bit; see DESIGN.md "libm").
+struct BiquadSweep { float f, Q; };
+__device__ __forceinline__ void biquad_lpf_set(Biquad& q, BiquadSweep& c, float f, float Q, float fs_w) {
+	if (Q < 0) Q = f / -Q;
+	if (c.f != f || c.Q != Q) {
+		c.f = f; c.Q = Q;
+		const float w = f * fs_w;
+		const float cos0 = (float)cos((double)w);
+		const float sin0 = (float)sin((double)w);
+		if (Q < 0.5f) Q = 0.5f;
+		const float a = sin0 / (2.f * Q);
+		const double a0 = (double)(1.f + a);                               // constant a0 = { 1.f + a }  klang.h:97
+		const float inv = (a0 == 0.0) ? 0.0f : (float)(1.0 / a0);
+		q.a1 = inv * (-2.f * cos0);
+		q.a2 = inv * (1.f - a);
+		q.b2 = q.b0 = inv * (1.f - cos0) * 0.5f;
+		q.b1 = inv * (1.f - cos0);
+	}
+}
+
+// ---- Filters::OnePole klang.h:5470-5543 ----
+struct OnePole { float b0, b1, a1, z, out; };
+__device__ __forceinline__ float onepole_lpf_process(OnePole& q, float in) { q.out = q.b0 * in + q.a1 * q.out + KLG_DENORM; return q.out; }
+__device__ __forceinline__ float onepole_process(OnePole& q, float in) { q.out = q.b0 * in + q.b1 * q.z + q.a1 * q.out + KLG_DENORM; q.z = in; return q.out; }
+
+// ---- Envelope klang.h:3722-4102 ----
+// Lane state: the Linear ramp (out, target, rate, active 3731-3807), stage, point, time.  Breakpoints live in
+// a small register array; they are only touched on the (rare) segment change.
+enum { ENV_SUSTAIN = 0, ENV_RELEASE = 1, ENV_OFF = 2 };
+struct Env { float r_out, r_target, r_rate, time; int stage, point; bool active; };
+
+__device__ __forceinline__ void env_set_value(Env& e, float v) { e.r_out = v; e.r_target = v; e.active = false; }      // 3762-3766
+__device__ __forceinline__ void env_set_target_time(Env& e, float px, float py, float time, float fs) {              // 4077-4081
+	e.time = time;
+	e.r_target = py; e.active = (e.r_out != py);
+	e.r_rate = fabsf(py - e.r_out) / ((px - time) * fs);
+}
+__device__ __forceinline__ void env_release(Env& e, float time, float level, float fs) {                             // 3961-3966
+	e.stage = ENV_RELEASE;
+	env_set_target_time(e, time, level, 0.f, fs);
+}
+// Breakpoints are held in SCALAR registers and selected with compare/select chains: a register array indexed by
+// the (run-time) point number would be demoted to scratch memory, dragging the whole lane state with it.
+struct Pts2 { float x0, x1, y0, y1;
+	__device__ __forceinline__ float x(int i) const { const float a = x0, b = x1; return i == 1 ? b : a; }
+	__device__ __forceinline__ float y(int i) const { const float a = y0, b = y1; return i == 1 ? b : a; } };
+struct Pts3 { float x0, x1, x2, y0, y1, y2;
+	__device__ __forceinline__ float x(int i) const { const float a = x0, b = x1, c = x2; return i == 2 ? c : (i == 1 ? b : a); }
+	__device__ __forceinline__ float y(int i) const { const float a = y0, b = y1, c = y2; return i == 2 ? c : (i == 1 ? b : a); } };
+
+// Envelope::process 4018-4051.  HOLD = the ADSR loop (setLoop(2,2), klang.h:4128): hold at the last point (NP-1).
+template<int NP, bool HOLD, class PTS>
+__device__ __forceinline__ float env_process(Env& e, const PTS& p, int npoints, const SampleRate& fs) {
+	const float out = e.r_out;                                          // out = (*ramp)++ : pre-step value
+	if (e.active) {                                                     // Linear::operator++ 3785-3806
+		if (e.r_target > e.r_out) {
+			e.r_out += e.r_rate;
+			if (e.r_out >= e.r_target) { e.r_out = e.r_target; e.active = false; }
+		}
+		else {
+			e.r_out -= e.r_rate;
+			if (e.r_out <= e.r_target) { e.r_out = e.r_target; e.active = false; }
+		}
+	}
+	if (e.stage == ENV_SUSTAIN) {
+		e.time += fs.timeInc;
+		if (!e.active) {
+			if (HOLD && (e.point + 1) >= (NP - 1)) {                    // loop.isActive() && (point + 1) >= loop.end
+				e.point = NP - 1;
+				env_set_value(e, p.y(NP - 1));
+			}
+			else if ((e.point + 1) < npoints) {
+				if (e.time >= p.x(e.point + 1)) {
+					e.point++;
+					env_set_value(e, p.y(e.point));
+					if ((e.point + 1) < npoints)
+						env_set_target_time(e, p.x(e.point + 1), p.y(e.point + 1), p.x(e.point), fs.f);
+				}
+			}
+			else e.stage = ENV_OFF;
+		}
+	}
+	else if (e.stage == ENV_RELEASE) {
+		if (!e.active) e.stage = ENV_OFF;
+	}
+	return out;
+}
+
+// Envelope state <-> 6 flag bits: stage(2) | point(3) | active(1)
+__device__ __forceinline__ uint32_t env_pack(const Env& e) { return (uint32_t)e.stage | ((uint32_t)e.point << 2) | ((uint32_t)e.active << 5); }
+__device__ __forceinline__ void env_unpack(Env& e, uint32_t b) { e.stage = (int)(b & 3u); e.point = (int)((b >> 2) & 7u); e.active = ((b >> 5) & 1u) != 0; }
+
+} // namespace klg

@@ -1,0 +1,146 @@
+// klang_amd/csrc/klg_host_dsl.hpp — HOST side of the drop-in: the parts of klang's DSL that stay on the CPU
+// (north_star: "host-side C++ keeps the DSL, voice allocation and event dispatch").
+//
+// These are the set()/initialise()/release() halves of the reference's primitives — the code a patch's
+// on()/off() runs when a note event arrives — producing the packed lane records the GPU kernels consume.
+// The per-sample process() halves exist ONLY as device code (klg_device.hpp); there is no CPU rendering
+// path in this library.  Citations are file:line into the reference's klang.h (v0.7.8).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#include "klg_patches.hpp"
+
+#pragma clang fp contract(off)
+
+namespace klg { namespace host {
+
+constexpr float PI_F = 3.14159274101257324f;
+constexpr float TWO_PI = 2.f * PI_F;
+constexpr float ROOT2_INV = 0.707106769084930420f;      // root2.inv = (float)(1.0 / 1.41421356...)
+
+struct Fs {                                              // struct SampleRate klang.h:1593-1604
+	float f, inv, w;
+	explicit Fs(float sr = 44100.f) : f(sr), inv(1.f / sr), w(2.0f * PI_F * inv) {}
+};
+
+inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+// Pitch::operator-> klang.h:1568-1571 with power(float, float) 191-217
+inline float pitch_to_frequency(float pitch) {
+	const float e = (pitch - 69.f) / 12.f;
+	float p;
+	if (e == 0.f) p = 1.f;
+	else if (e == 1.f) p = 2.f;
+	else if (e == 2.f) p = 2.f * 2.f;
+	else if (e == 3.f) p = 2.f * 2.f * 2.f;
+	else if (e == 4.f) p = 2.f * 2.f * 2.f * 2.f;
+	else if (e == -1.f) p = 1.f / 2.f;
+	else if (e == -2.f) p = 1.f / (2.f * 2.f);
+	else if (e == -3.f) p = 1.f / (2.f * 2.f * 2.f);
+	else if (e == -4.f) p = 1.f / (2.f * 2.f * 2.f * 2.f);
+	else p = std::pow(2.f, e);
+	return 440.f * p;
+}
+
+// klang::random<double>(min, max) klang.h:236
+inline double random_d(double mn, double mx) { return std::rand() * ((mx - mn) / (double)RAND_MAX) + mn; }
+
+// ---- Generators::Fast::Increment / Phase (klang.h:4960-5007) ----
+inline int32_t fast_increment(float f, const Fs& fs) {
+	constexpr float FC4 = float(261.62556530059862);
+	constexpr float FC4_FINTMAX = float(261.62556530059862 * 2147483648.0);
+	const float FBASE = FC4_FINTMAX / fs.f;
+	return (int32_t)(2u * (uint32_t)(int32_t)(FBASE / FC4 * f));
+}
+inline float fast_increment_float(int32_t amount) { return u2f((uint32_t)((amount >> 9) | 0x3f800000)) - 1.f; }
+inline uint32_t fast_phase(float radians) { return (uint32_t)(int64_t)(radians * 2147483648.0f / (2.f * PI_F)); }
+inline float fast_phase_float(uint32_t pos) { return u2f((pos >> 9) | 0x3f800000u) - 1.f; }
+
+// ---- Fast::Sine set() side (klang.h:5142-5153); frequency cache reproduces the `if (frequency != cached)` guard ----
+struct FSineH {
+	float frequency = 1000.f; int32_t inc = 0; uint32_t pos = 0;
+	void set(float f, float phase, const Fs& fs) {
+		pos = fast_phase(phase);
+		if (f != frequency) { frequency = f; inc = fast_increment(f, fs); }
+	}
+};
+
+// ---- Generic::Oscillator set() side (klang.h:2862-2870) ----
+struct BOscH {
+	float frequency = 1000.f, increment = 0.f, position = 0.f, offset = 0.f;
+	void set(float f, float phase, const Fs& fs) { position = phase; frequency = f; increment = f * 2.f * PI_F / fs.f; }
+};
+
+// ---- Fast::OSM set() side (klang.h:5206-5249) ----
+struct OsmH {
+	int32_t inc = 0; uint32_t offset = 0, duty = 0; int state = 0; float delta = 0.f, frequency = 0.f;
+	explicit OsmH(float duty_ = 0.f) { set_duty(duty_); }                      // Osm ctor klang.h:5323
+	void init() { state = ((uint32_t)(offset - (uint32_t)inc) < duty) ? 3 : 0; }  // the coefficient half of init() is re-derived on the GPU
+	void refresh(float f, const Fs& fs) { if (frequency != f) { frequency = f; inc = fast_increment(f, fs); delta = fast_increment_float(inc); } }
+	void set_duty(float d) { duty = fast_phase(d * (2.f * PI_F)); init(); }
+	void set(float f, float phase, const Fs& fs) { refresh(f, fs); offset = fast_phase(phase); init(); }
+	void set(float f, float phase, float d, const Fs& fs) { refresh(f, fs); offset = fast_phase(phase); set_duty(d); }
+	void pack(OsmRec& r) const { r.inc = inc; r.offset = offset; r.duty = duty; r.delta = delta; }
+};
+
+// ---- Filters::Biquad::LPF set()/reset() side (klang.h:5565-5600, 5658-5665); libm: this host's glibc cosf/sinf ----
+struct BiquadLpfH {
+	float f = 0, Q = 0, a1 = 0, a2 = 0, b0 = 1, b1 = 0, b2 = 0, a = 0, cos0 = 1, sin0 = 0, z0 = 0, z1 = 0;
+	void reset() { f = 0; Q = 0; b0 = 1; a1 = a2 = b1 = b2 = 0; a = 0; z0 = z1 = 0; }
+	void set(float f_, float Q_, const Fs& fs) {
+		if (Q_ < 0) Q_ = f_ / -Q_;
+		if (f != f_ || Q != Q_) {
+			f = f_; Q = Q_;
+			const float w = f_ * fs.w;
+			cos0 = cosf(w); sin0 = sinf(w);
+			if (Q_ < 0.5) Q_ = 0.5f;
+			a = sin0 / (2.f * Q_);
+			const double a0 = (double)(1.f + a);
+			const float inv = (a0 == 0.0f) ? 0.0f : (float)(1.0 / a0);
+			a1 = inv * (-2.f * cos0);
+			a2 = inv * (1.f - a);
+			b2 = b0 = inv * (1.f - cos0) * 0.5f;
+			b1 = inv * (1.f - cos0);
+		}
+	}
+	void pack(BiquadRec& r) const { r.b0 = b0; r.b1 = b1; r.b2 = b2; r.a1 = a1; r.a2 = a2; r.z0 = z0; r.z1 = z1; }
+};
+
+// ---- Envelope set()/initialise() side (klang.h:3893-3989, 4077-4081) ----
+struct EnvH {
+	float r_out = 1.f, r_target = 1.f, r_rate = 0.f; bool active = false;
+	int npoints = 0; float px[4] = { 0 }, py[4] = { 0 };
+	int point = 0; float time = 0.f; int stage = ENV_SUSTAIN;
+	void set_value(float v) { r_out = v; r_target = v; active = false; }
+	void set_target(float x, float y, float t, const Fs& fs) {
+		time = t; r_target = y; active = (r_out != y);
+		r_rate = std::fabs(y - r_out) / ((x - t) * fs.f);
+	}
+	void set_points(int n, const float* xy, const Fs& fs) {
+		npoints = n;
+		for (int i = 0; i < n; i++) { px[i] = xy[2 * i]; py[i] = xy[2 * i + 1]; }
+		point = 0; stage = ENV_SUSTAIN;
+		set_value(py[0]);
+		if (n > 1) set_target(px[1], py[1], px[0], fs);
+	}
+	uint32_t bits() const { return (uint32_t)stage | ((uint32_t)point << 2) | ((uint32_t)active << 5); }
+};
+
+// ---- ADSR::set (klang.h:4116-4129) ----
+struct AdsrH {
+	EnvH env; float A = 0, D = 0, S = 0, R = 0;
+	void set(float attack, float decay, float sustain, float release, const Fs& fs) {
+		A = attack; D = decay + 0.005f; S = sustain; R = release + 0.005f;
+		const float xy[6] = { 0.f, 0.f, A, 1.f, A + D, S };
+		env.set_points(3, xy, fs);
+	}
+	void pack(AdsrRec& r) const { r.r_out = env.r_out; r.r_target = env.r_target; r.r_rate = env.r_rate; r.time = env.time; r.A = A; r.AD = env.px[2]; r.S = S; r.R = R; }
+};
+
+// Control::set (klang.h:1725-1728) / Dial() (1797-1800)
+struct ControlH { float min, max, value; void set(float x) { value = (x < min) ? min : (max < x) ? max : x; } };
+
+} } // namespace klg::host

@@ -1,0 +1,192 @@
+// klang_amd/csrc/klg_kernels.hpp — the synth-bank kernels (gfx950, wave64).
+//
+//   klg_apply_events<P>  one lane per voice that received events this block: note-on = overwrite the lane's
+//                        record with the host-computed one; note-off = the patch's off() on the resident state.
+//   klg_render<P,PV>     THE hot kernel.  One lane per voice, 256 voices per workgroup (4 waves).  Each lane loads
+//                        its record (coalesced SoA planes), runs the patch body for n samples with all state in
+//                        registers, and writes back only the words that change.  Voice mix: every 32 samples a wave
+//                        transposes its 64x32 outputs through a padded LDS tile (stride 65 dwords: conflict-free
+//                        ds_write_b32 / ds_read_b32), each lane sums 32 voices for one sample, the two half-sums are
+//                        combined with one cross-lane exchange and accumulated into the workgroup's [n] LDS
+//                        accumulator with ds_add_f32.  The workgroup then writes its partial [n] row.
+//   klg_reduce           partial rows -> the stereo block (ADDED to the destination, like the reference's `+=`).
+//
+// Workgroups are independent (no inter-workgroup communication inside a launch); groups of 256 voices are dealt
+// round-robin to workgroups (group g -> block g % gridDim.x), which with the observed block->XCD mapping spreads
+// consecutive voice groups over the 8 XCDs; nothing depends on that placement.
+#pragma once
+#include "klg_patches.hpp"
+
+#pragma clang fp contract(off)
+
+namespace klg {
+
+enum { WG = 256, WAVES = 4, CHUNK = 32, TILE_LD = 65, MAX_BLOCK = 1024 };
+
+struct RenderArgs {
+	uint32_t* state;          // [W][stride]
+	size_t stride;            // voices rounded up to WG
+	int voices, notes_per_synth, n;
+	const float* controls;    // [synths][KLG_MAX_CTL]
+	SampleRate fs;
+	float* partials;          // [gridDim.x][n]
+	float* per_voice;         // [voices][n] or null
+};
+
+// record <-> word planes.  Words are moved with static indices only (fully unrolled) and converted with
+// memcpy, which SROA turns into plain register moves: the record never touches scratch.
+template<class REC> struct RecWords {
+	static constexpr int W = sizeof(REC) / 4;
+	uint32_t w[W];
+	__device__ __forceinline__ void to(REC& r) const { __builtin_memcpy(&r, w, sizeof(REC)); }
+	__device__ __forceinline__ void from(const REC& r) { __builtin_memcpy(w, &r, sizeof(REC)); }
+};
+
+template<class P, bool PER_VOICE>
+__global__ __launch_bounds__(WG) void klg_render(const RenderArgs a) {
+	using Rec = typename P::Rec;
+	constexpr int W = sizeof(Rec) / 4;
+	__shared__ float lds[WAVES * CHUNK * TILE_LD + MAX_BLOCK];
+	float* acc = lds + WAVES * CHUNK * TILE_LD;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	float* tile = lds + wave * CHUNK * TILE_LD;
+	const int n = a.n;
+
+	for (int i = tid; i < n; i += WG) acc[i] = 0.f;
+	__syncthreads();
+
+	const int groups = (int)(a.stride / WG);
+	for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+		const int v = g * WG + tid;
+		uint32_t flags = (v < a.voices) ? a.state[v] : (uint32_t)ST_OFF;
+		const bool live = (flags & 3u) != (uint32_t)ST_OFF;
+		if (__ballot(live) == 0ull) {                        // whole wave silent: nothing to add
+			if (PER_VOICE) {
+				const int v0 = g * WG + wave * 64;
+				for (int j = 0; j < 64 && v0 + j < a.voices; j++)
+					for (int i = lane; i < n; i += 64) a.per_voice[(size_t)(v0 + j) * n + i] = 0.f;
+			}
+			continue;
+		}
+		RecWords<Rec> rw;
+		Rec rec;
+		typename P::Live L;
+		BlockCtx ctx;
+		ctx.fs = a.fs;
+		ctx.ctl = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
+		if (live) {
+			rw.w[0] = flags;
+#pragma unroll
+			for (int w = 1; w < W; w++) rw.w[w] = a.state[(size_t)w * a.stride + v];
+			rw.to(rec);
+			P::begin(L, rec, ctx);
+		}
+		for (int c0 = 0; c0 < n; c0 += CHUNK) {
+			const int cl = (n - c0 < CHUNK) ? (n - c0) : CHUNK;
+			for (int s = 0; s < cl; s++) {
+				float y = 0.f;
+				if (live) y = P::sample(L, ctx);
+				tile[s * TILE_LD + lane] = y;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			if (PER_VOICE) {
+				const int v0 = g * WG + wave * 64;
+				const int s = lane & 31, h = lane >> 5;
+				for (int j = 0; j < 32; j++) {
+					const int jj = 2 * j + h;
+					if (s < cl && v0 + jj < a.voices) a.per_voice[(size_t)(v0 + jj) * n + c0 + s] = tile[s * TILE_LD + jj];
+				}
+			}
+			{
+				const int s = lane & 31, h = lane >> 5;
+				float sum = 0.f;
+				if (s < cl) {
+					const float* row = tile + s * TILE_LD + h * 32;
+#pragma unroll
+					for (int j = 0; j < 32; j++) sum += row[j];
+				}
+				sum += __shfl_xor(sum, 32);
+				if (lane < cl) atomicAdd(&acc[c0 + lane], sum);     // LDS ds_add_f32
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+		if (live) {
+			P::end(L, rec);
+			rw.from(rec);
+#pragma unroll
+			for (int w = 0; w < W; w++)
+				if ((P::kStoreMask >> w) & 1ull) a.state[(size_t)w * a.stride + v] = rw.w[w];
+		}
+	}
+	__syncthreads();
+	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = acc[i];
+}
+
+// partial rows [rows][n] -> mix[0][i] += sum, mix[1][i] += sum  (Stereo::Mono::Note: L += out; R += out, klang.h:4751-4752)
+__global__ __launch_bounds__(256) void klg_reduce(const float* __restrict__ partials, int rows, int n, float* mix, int channels) {
+	__shared__ float part[8][32];
+	const int s = blockIdx.x * 32 + (threadIdx.x & 31), p = threadIdx.x >> 5;
+	float sum = 0.f;
+	if (s < n) for (int r = p; r < rows; r += 8) sum += partials[(size_t)r * n + s];
+	part[p][threadIdx.x & 31] = sum;
+	__syncthreads();
+	if (p == 0 && s < n) {
+		float t = 0.f;
+#pragma unroll
+		for (int k = 0; k < 8; k++) t += part[k][threadIdx.x];
+		for (int c = 0; c < channels; c++) mix[(size_t)c * n + s] += t;
+	}
+}
+
+// Events: runs[r] = {voice, first, count}; ev_type[e] (0 = note-on with payload ev_payload[e], 1 = note-off);
+// payload records are AoS [k][W] words as produced by the host-side on() code.
+struct EventArgs {
+	uint32_t* state; size_t stride;
+	const int* run_voice; const int* run_first; const int* run_count; int runs;
+	const int* ev_type; const int* ev_payload; const uint32_t* payload;
+	float fs;
+};
+template<class P>
+__global__ __launch_bounds__(64) void klg_apply_events(const EventArgs a) {
+	using Rec = typename P::Rec;
+	constexpr int W = sizeof(Rec) / 4;
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= a.runs) return;
+	const int v = a.run_voice[r];
+	RecWords<Rec> rw;
+	bool loaded = false;
+	for (int e = a.run_first[r]; e < a.run_first[r] + a.run_count[r]; e++) {
+		if (a.ev_type[e] == 0) {
+			const uint32_t* src = a.payload + (size_t)a.ev_payload[e] * W;
+#pragma unroll
+			for (int w = 0; w < W; w++) rw.w[w] = src[w];
+			loaded = true;
+		}
+		else {
+			if (!loaded) {
+#pragma unroll
+				for (int w = 0; w < W; w++) rw.w[w] = a.state[(size_t)w * a.stride + v];
+				loaded = true;
+			}
+			if ((rw.w[0] & 3u) == (uint32_t)ST_SUSTAIN) {               // Synth::noteOff only releases Sustain notes (klang.h:4432)
+				Rec rec; rw.to(rec); P::release(rec, a.fs); rw.from(rec);
+			}
+		}
+	}
+	if (loaded) {
+#pragma unroll
+		for (int w = 0; w < W; w++) a.state[(size_t)w * a.stride + v] = rw.w[w];
+	}
+}
+
+// single-voice record copy (klg_voice_download / klg_voice_upload)
+__global__ void klg_copy_record(uint32_t* state, size_t stride, int v, uint32_t* rec, int W, int to_state) {
+	const int w = threadIdx.x;
+	if (w < W) { if (to_state) state[(size_t)w * stride + v] = rec[w]; else rec[w] = state[(size_t)w * stride + v]; }
+}
+
+} // namespace klg

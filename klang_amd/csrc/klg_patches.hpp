@@ -1,0 +1,268 @@
+// klang_amd/csrc/klg_patches.hpp — per-patch voice records (the HBM-resident lane state) and the hand-written
+// per-sample bodies of the shipped patch kernels.
+//
+// Data layout in HBM: struct-of-arrays, one 32-bit word plane per record field, `state[w * stride + v]`, so a
+// wavefront (64 consecutive voices) loads/stores each field as one coalesced 256-byte access.  A record is read
+// once at block start, lives in registers for the n samples of the block, and is written back once: algorithmic
+// HBM traffic per voice-block = 2 * sizeof(Rec) (+ the event records of voices that were started).
+//
+// Word 0 of every record is `flags`: bits 0-1 NoteBase::stage (klang.h:4286), the rest patch-specific small
+// integers (envelope stage/point/active, OSM state) packed so they cost one word instead of a dozen.
+#pragma once
+#include "klg_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace klg {
+
+enum { ST_ONSET = 0, ST_SUSTAIN = 1, ST_RELEASE = 2, ST_OFF = 3 };
+enum { KLG_MAX_CTL = 8 };
+
+struct OsmRec { int32_t inc; uint32_t offset, duty; float delta; };
+struct AdsrRec { float r_out, r_target, r_rate, time, A, AD, S, R; };     // points (0,0) (A,1) (A+D,S); R for release()
+struct BiquadRec { float b0, b1, b2, a1, a2, z0, z1; };
+
+// Per-block view every patch body gets.
+struct BlockCtx {
+	SampleRate fs;
+	const float* ctl;        // this voice's synth instance controls [KLG_MAX_CTL]
+};
+
+// ---------------------------------------------------------------------------------------------
+// helpers shared by the patch bodies
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void osm_load(Osm& o, const OsmRec& r, uint32_t state_bits) {
+	o.inc = r.inc; o.offset = r.offset; o.duty = r.duty; o.delta = r.delta; o.state = (int)(state_bits & 3u);
+	osm_derive(o);
+}
+__device__ __forceinline__ void osm_store(const Osm& o, OsmRec& r) { r.inc = o.inc; r.offset = o.offset; r.duty = o.duty; r.delta = o.delta; }
+
+struct Adsr { Env e; Pts3 p; float R; };
+__device__ __forceinline__ void adsr_load(Adsr& a, const AdsrRec& r, uint32_t bits) {
+	a.e.r_out = r.r_out; a.e.r_target = r.r_target; a.e.r_rate = r.r_rate; a.e.time = r.time;
+	env_unpack(a.e, bits);
+	a.p.x0 = 0.f; a.p.x1 = r.A; a.p.x2 = r.AD;
+	a.p.y0 = 0.f; a.p.y1 = 1.f; a.p.y2 = r.S;
+	a.R = r.R;
+}
+__device__ __forceinline__ void adsr_store(const Adsr& a, AdsrRec& r) {
+	r.r_out = a.e.r_out; r.r_target = a.e.r_target; r.r_rate = a.e.r_rate; r.time = a.e.time;
+}
+__device__ __forceinline__ float adsr_process(Adsr& a, const SampleRate& fs) { return env_process<3, true>(a.e, a.p, 3, fs); }
+// ADSR::release(time = 0, level = 0) klang.h:4131-4133 on the packed record (event kernel)
+__device__ __forceinline__ void adsr_release_rec(AdsrRec& r, uint32_t& bits, float fs) {
+	Env e; e.r_out = r.r_out; e.r_target = r.r_target; e.r_rate = r.r_rate; e.time = r.time; env_unpack(e, bits);
+	env_release(e, r.R, 0.f, fs);
+	r.r_out = e.r_out; r.r_target = e.r_target; r.r_rate = e.r_rate; r.time = e.time; bits = env_pack(e);
+}
+
+#define KLG_FLAG_GET(flags, shift, width) (((flags) >> (shift)) & ((1u << (width)) - 1u))
+
+// Store masks: bit w set = record word w changes during a block and is written back (coefficients,
+// breakpoints and increments are read-only for the render kernel, so they cost a read but no write).
+constexpr uint64_t words(size_t byte_off, int n) { return ((1ull << n) - 1ull) << (byte_off / 4); }
+#define KLG_W(REC, member, n) words(__builtin_offsetof(REC, member), n)
+
+// ---------------------------------------------------------------------------------------------
+// config 1: one Generators::Fast::Sine per note  (oracle/ref/ref_sine.cpp: `osc >> out`)
+// ---------------------------------------------------------------------------------------------
+struct PatchSine {
+	struct Rec { uint32_t flags; int32_t inc; uint32_t pos; };
+	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, pos, 1);
+	struct Live { FSine osc; int stage; };
+	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) { L.osc.inc = r.inc; L.osc.pos = r.pos; L.stage = (int)(r.flags & 3u); }
+	static __device__ __forceinline__ float sample(Live& L, const BlockCtx&) { return fsine_process(L.osc, 0u); }
+	static __device__ __forceinline__ void end(const Live& L, Rec& r) { r.inc = L.osc.inc; r.pos = L.osc.pos; r.flags = (uint32_t)L.stage; }
+	static __device__ __forceinline__ void release(Rec& r, float) { r.flags = (r.flags & ~3u) | ST_OFF; }   // off() { stop(); }
+};
+
+struct PatchBSine {
+	struct Rec { uint32_t flags; float increment, position, offset; };
+	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, position, 1);
+	struct Live { BOsc osc; int stage; };
+	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) { L.osc.increment = r.increment; L.osc.position = r.position; L.osc.offset = r.offset; L.stage = (int)(r.flags & 3u); }
+	static __device__ __forceinline__ float sample(Live& L, const BlockCtx&) { return basic_sine(L.osc); }
+	static __device__ __forceinline__ void end(const Live& L, Rec& r) { r.position = L.osc.position; r.flags = (uint32_t)L.stage; }
+	static __device__ __forceinline__ void release(Rec& r, float) { r.flags = (r.flags & ~3u) | ST_OFF; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// config 2a (north_star "Saw >> LPF >> ADSR"): `osc >> lpf >> out; out *= adsr++; if (adsr.finished()) stop();`
+// flags: [0:2) note stage | [2:8) adsr | [8:10) osm state
+// ---------------------------------------------------------------------------------------------
+struct PatchSub2a {
+	struct Rec { uint32_t flags; OsmRec osc; BiquadRec lpf; AdsrRec adsr; };                 // 20 words = 80 B read, 8 words = 32 B written
+	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc.offset, 1) | KLG_W(Rec, lpf.z0, 2) | KLG_W(Rec, adsr.r_out, 4);
+	struct Live { Osm osc; Biquad lpf; Adsr adsr; int stage; };
+	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {
+		L.stage = (int)(r.flags & 3u);
+		adsr_load(L.adsr, r.adsr, KLG_FLAG_GET(r.flags, 2, 6));
+		osm_load(L.osc, r.osc, KLG_FLAG_GET(r.flags, 8, 2));
+		L.lpf.b0 = r.lpf.b0; L.lpf.b1 = r.lpf.b1; L.lpf.b2 = r.lpf.b2; L.lpf.a1 = r.lpf.a1; L.lpf.a2 = r.lpf.a2; L.lpf.z0 = r.lpf.z0; L.lpf.z1 = r.lpf.z1;
+	}
+	static __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {
+		float out = biquad_process(L.lpf, osm_saw(L.osc));
+		out *= adsr_process(L.adsr, c.fs);
+		if (L.adsr.e.stage == ENV_OFF) L.stage = ST_OFF;
+		return out;
+	}
+	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
+		osm_store(L.osc, r.osc);
+		r.lpf.z0 = L.lpf.z0; r.lpf.z1 = L.lpf.z1;
+		adsr_store(L.adsr, r.adsr);
+		r.flags = (uint32_t)L.stage | (env_pack(L.adsr.e) << 2) | ((uint32_t)L.osc.state << 8);
+	}
+	static __device__ __forceinline__ void release(Rec& r, float fs) {                        // off(): adsr.release()
+		uint32_t bits = KLG_FLAG_GET(r.flags, 2, 6);
+		adsr_release_rec(r.adsr, bits, fs);
+		r.flags = (r.flags & ~(0x3Fu << 2) & ~3u) | (bits << 2) | ST_RELEASE;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------
+// config 2b: the shipped subtractive.k (Square >> filter(env++, 10) >> out; out *= adsr)
+// flags: [0:2) note | [2:8) adsr | [8:14) env | [14:16) osm state
+// ---------------------------------------------------------------------------------------------
+struct PatchSub2b {
+	struct EnvRec { float r_out, r_target, r_rate, time, px[3], py[3]; };
+	struct SweepRec { float f, Q; BiquadRec c; };
+	struct Rec { uint32_t flags; OsmRec osc; AdsrRec adsr; EnvRec env; SweepRec filter; };   // 1+4+8+10+9 = 32 words
+	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc.offset, 1) | KLG_W(Rec, adsr.r_out, 4) | KLG_W(Rec, env.r_out, 4) | KLG_W(Rec, filter, 9);
+	struct Live { Osm osc; Adsr adsr; Env env; Pts3 p; Biquad lpf; BiquadSweep sw; int stage; };
+	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {
+		L.stage = (int)(r.flags & 3u);
+		adsr_load(L.adsr, r.adsr, KLG_FLAG_GET(r.flags, 2, 6));
+		L.env.r_out = r.env.r_out; L.env.r_target = r.env.r_target; L.env.r_rate = r.env.r_rate; L.env.time = r.env.time;
+		env_unpack(L.env, KLG_FLAG_GET(r.flags, 8, 6));
+		L.p.x0 = r.env.px[0]; L.p.x1 = r.env.px[1]; L.p.x2 = r.env.px[2];
+		L.p.y0 = r.env.py[0]; L.p.y1 = r.env.py[1]; L.p.y2 = r.env.py[2];
+		osm_load(L.osc, r.osc, KLG_FLAG_GET(r.flags, 14, 2));
+		L.sw.f = r.filter.f; L.sw.Q = r.filter.Q;
+		L.lpf.b0 = r.filter.c.b0; L.lpf.b1 = r.filter.c.b1; L.lpf.b2 = r.filter.c.b2; L.lpf.a1 = r.filter.c.a1; L.lpf.a2 = r.filter.c.a2;
+		L.lpf.z0 = r.filter.c.z0; L.lpf.z1 = r.filter.c.z1;
+	}
+	static __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {
+		const float fc = env_process<3, false>(L.env, L.p, 3, c.fs);   // filter(env++, 10) is evaluated first (C++17 order)
+		biquad_lpf_set(L.lpf, L.sw, fc, 10.f, c.fs.w);
+		float out = biquad_process(L.lpf, osm_pulse(L.osc));
+		out *= adsr_process(L.adsr, c.fs);
+		if (L.adsr.e.stage == ENV_OFF) L.stage = ST_OFF;
+		return out;
+	}
+	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
+		osm_store(L.osc, r.osc);
+		adsr_store(L.adsr, r.adsr);
+		r.env.r_out = L.env.r_out; r.env.r_target = L.env.r_target; r.env.r_rate = L.env.r_rate; r.env.time = L.env.time;
+		r.filter.f = L.sw.f; r.filter.Q = L.sw.Q;
+		r.filter.c.b0 = L.lpf.b0; r.filter.c.b1 = L.lpf.b1; r.filter.c.b2 = L.lpf.b2; r.filter.c.a1 = L.lpf.a1; r.filter.c.a2 = L.lpf.a2;
+		r.filter.c.z0 = L.lpf.z0; r.filter.c.z1 = L.lpf.z1;
+		r.flags = (uint32_t)L.stage | (env_pack(L.adsr.e) << 2) | (env_pack(L.env) << 8) | ((uint32_t)L.osc.state << 14);
+	}
+	static __device__ __forceinline__ void release(Rec& r, float fs) {
+		uint32_t bits = KLG_FLAG_GET(r.flags, 2, 6);
+		adsr_release_rec(r.adsr, bits, fs);
+		r.flags = (r.flags & ~(0x3Fu << 2) & ~3u) | (bits << 2) | ST_RELEASE;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------
+// config 3: the shipped SuperSaw.k: `for s<7: out += osc[s] / 7; out *= adsr++;`
+// flags: [0:2) note | [2:8) adsr | [8:22) 7 x osm state
+// ---------------------------------------------------------------------------------------------
+struct PatchSuperSaw {
+	struct Rec { uint32_t flags; OsmRec osc[7]; AdsrRec adsr; };                              // 37 words = 148 B read, 12 words written
+	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc[0].offset, 1) | KLG_W(Rec, osc[1].offset, 1) | KLG_W(Rec, osc[2].offset, 1)
+		| KLG_W(Rec, osc[3].offset, 1) | KLG_W(Rec, osc[4].offset, 1) | KLG_W(Rec, osc[5].offset, 1) | KLG_W(Rec, osc[6].offset, 1) | KLG_W(Rec, adsr.r_out, 4);
+	struct Live { Osm osc[7]; Adsr adsr; int stage; };
+	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {
+		L.stage = (int)(r.flags & 3u);
+		adsr_load(L.adsr, r.adsr, KLG_FLAG_GET(r.flags, 2, 6));
+#pragma unroll
+		for (int k = 0; k < 7; k++) osm_load(L.osc[k], r.osc[k], KLG_FLAG_GET(r.flags, 8 + 2 * k, 2));
+	}
+	static __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {
+		float out = 0.f;
+#pragma unroll
+		for (int k = 0; k < 7; k++) out += osm_saw(L.osc[k]) / 7.f;
+		out *= adsr_process(L.adsr, c.fs);
+		if (L.adsr.e.stage == ENV_OFF) L.stage = ST_OFF;
+		return out;
+	}
+	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
+		uint32_t f = (uint32_t)L.stage | (env_pack(L.adsr.e) << 2);
+#pragma unroll
+		for (int k = 0; k < 7; k++) { osm_store(L.osc[k], r.osc[k]); f |= (uint32_t)L.osc[k].state << (8 + 2 * k); }
+		adsr_store(L.adsr, r.adsr);
+		r.flags = f;
+	}
+	static __device__ __forceinline__ void release(Rec& r, float fs) {
+		uint32_t bits = KLG_FLAG_GET(r.flags, 2, 6);
+		adsr_release_rec(r.adsr, bits, fs);
+		r.flags = (r.flags & ~(0x3Fu << 2) & ~3u) | (bits << 2) | ST_RELEASE;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------
+// FM.k (3 operators) and the 4-operator chain of BASELINE config 5:
+//   op1 * I1 >> op2 * I2 >> [op3 * I3 >>] opN >> out;  out *= adsr++ * 0.1f;
+// flags: [0:2) note | [2:8) adsr | [8+6k : 14+6k) operator k envelope ; meta: 2 bits npoints per operator
+// ---------------------------------------------------------------------------------------------
+template<int NOPS>
+struct PatchFM {
+	struct OpRec { int32_t inc; uint32_t pos; float r_out, r_target, r_rate, time, px[2], py[2]; };   // 10 words
+	struct Rec { uint32_t flags, meta; OpRec op[NOPS]; AdsrRec adsr; };
+	static constexpr uint64_t op_mask(int k) { return words(8 + 40 * (size_t)k + 4, 5); }   // pos, r_out, r_target, r_rate, time of operator k
+	static constexpr uint64_t kStoreMask = 1ull | op_mask(0) | op_mask(1) | op_mask(2) | (NOPS > 3 ? op_mask(3) : 0ull) | words(8 + 40 * (size_t)NOPS, 4);
+	struct Op { FSine osc; Env env; Pts2 p; int np; float amp; };
+	struct Live { Op op[NOPS]; Adsr adsr; int stage; };
+	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx& c) {
+		L.stage = (int)(r.flags & 3u);
+		adsr_load(L.adsr, r.adsr, KLG_FLAG_GET(r.flags, 2, 6));
+#pragma unroll
+		for (int k = 0; k < NOPS; k++) {
+			Op& o = L.op[k]; const OpRec& q = r.op[k];
+			o.osc.inc = q.inc; o.osc.pos = q.pos;
+			o.env.r_out = q.r_out; o.env.r_target = q.r_target; o.env.r_rate = q.r_rate; o.env.time = q.time;
+			env_unpack(o.env, KLG_FLAG_GET(r.flags, 8 + 6 * k, 6));
+			o.p.x0 = q.px[0]; o.p.x1 = q.px[1]; o.p.y0 = q.py[0]; o.p.y1 = q.py[1];
+			o.np = (int)KLG_FLAG_GET(r.meta, 2 * k, 2);
+			// `op * I` sets amp every sample from controls[1 + k] (FM.k:64-68); the last operator keeps amp = 1
+			o.amp = (k < NOPS - 1) ? c.ctl[1 + k] : 1.f;
+		}
+	}
+	// Operator::process klang.h:4164-4168
+	static __device__ __forceinline__ float op_process(Op& o, float in, const BlockCtx& c) {
+		const uint32_t off = fsine_rel_offset(in);                 // OSCILLATOR::set(+in)
+		float y = fsine_process(o.osc, off);
+		y *= env_process<2, false>(o.env, o.p, o.np, c.fs) * o.amp;
+		return y;
+	}
+	static __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {
+		float m = 0.f;
+#pragma unroll
+		for (int k = 0; k < NOPS; k++) m = op_process(L.op[k], m, c);
+		float out = m;
+		out *= adsr_process(L.adsr, c.fs) * 0.1f;
+		if (L.adsr.e.stage == ENV_OFF) L.stage = ST_OFF;
+		return out;
+	}
+	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
+		uint32_t f = (uint32_t)L.stage | (env_pack(L.adsr.e) << 2);
+#pragma unroll
+		for (int k = 0; k < NOPS; k++) {
+			const Op& o = L.op[k]; OpRec& q = r.op[k];
+			q.pos = o.osc.pos;
+			q.r_out = o.env.r_out; q.r_target = o.env.r_target; q.r_rate = o.env.r_rate; q.time = o.env.time;
+			f |= env_pack(o.env) << (8 + 6 * k);
+		}
+		adsr_store(L.adsr, r.adsr);
+		r.flags = f;
+	}
+	static __device__ __forceinline__ void release(Rec& r, float fs) {
+		uint32_t bits = KLG_FLAG_GET(r.flags, 2, 6);
+		adsr_release_rec(r.adsr, bits, fs);
+		r.flags = (r.flags & ~(0x3Fu << 2) & ~3u) | (bits << 2) | ST_RELEASE;
+	}
+};
+
+} // namespace klg
