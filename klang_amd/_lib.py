@@ -27,6 +27,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise KlangError(f"{LIB_PATH} is missing: build it with klang_amd/csrc/build.sh (python -c 'import __graft_entry__ as g; g.build()'). "
                          "klang_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  If torch is going to be
+    # used in this process (bench.py, torch.distributed) it must be loaded FIRST so that libklang_mi355.so's
+    # DT_NEEDED libamdhip64 resolves to the already-loaded copy; two runtimes in one process fight over the
+    # device (observed: hipGetDeviceCount() == 0 in the second one).  C/C++ hosts have no torch and no issue.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     f32p, u8p, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_void_p
     sig = {
