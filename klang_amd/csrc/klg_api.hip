@@ -142,7 +142,7 @@ extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_s
 	hipDeviceProp_t prop;
 	bool ok = hipGetDeviceProperties(&prop, g_device) == hipSuccess;
 	const int groups = (int)(s->stride / WG);
-	s->grid = std::min(groups, (ok ? prop.multiProcessorCount : 256) * 16);
+	s->grid = std::min(groups, (ok ? prop.multiProcessorCount : 256) * 8);   // 2 x the 4 resident workgroups per CU (LDS-limited); more groups are strided
 	ok = ok && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_state, (size_t)s->W * s->stride * 4) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_controls, (size_t)s->S * KLG_MAX_CTL * 4) == hipSuccess;
@@ -435,7 +435,7 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	}
 	launch_render(s, a, per_voice, st);
 	if (s->timing) { HIP_TRY(hipEventRecord(s->tev[2 * s->launches + 1], st)); s->launches++; }
-	hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)s->d_partials, s->grid, n, d_mix, 2);
+	hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, s->grid, n, d_mix, 2);
 	HIP_TRY(hipGetLastError());
 	s->stages_dirty = true;
 	return 0;

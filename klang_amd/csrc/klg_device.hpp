@@ -105,40 +105,51 @@ __device__ __forceinline__ int osm_tick(Osm& o) {                           // k
 	return tr;
 }
 __device__ __forceinline__ float sqrf(float x) { return x * x; }
+// The six-case formula tables of saw()/pulse() (klang.h:5290-5316) are evaluated BRANCH-FREE: with 64 voices at
+// 64 different phases some lane of the wave is in a transition state on most samples, so a per-case branch makes
+// the wave walk every case anyway and pays the exec-mask bookkeeping on top.  Each case keeps the reference's
+// exact fp32 operation order; the unused candidates (which may be inf/NaN when col == 0) are discarded by selects.
 __device__ __forceinline__ float osm_saw(Osm& o) {                          // saw() 5290-5302: p evaluated before tick()
 	const float p = fast_phase_float(o.offset) - o.col;
 	const int tr = osm_tick(o);
 	const float f = o.f, omf = o.omf, rcpf = o.rcpf, c1 = o.c1, c2 = o.c2;
-	float y;
-	if ((tr & 4) == 0) {
-		if (tr == 3) y = c1 * (p + p - f) + 1.f;                                // Up
-		else if (tr == 0) y = c2 * (p + p - f) + 1.f;                           // Down
-		else if (tr == 2) y = rcpf * (c2 * sqrf(p) - c1 * sqrf(p - f)) + 1.f;   // UpDown
-		else y = 0.f;
-	}
-	else {
-		if (tr == 4) y = -rcpf * (1.f + c2 * omf * (p + p + omf)) + 1.f;        // DownUpDown
-		else if (tr == 5) y = -rcpf * (1.f + c2 * sqrf(p + omf) - c1 * sqrf(p)) + 1.f;  // DownUp
-		else if (tr == 7) y = -rcpf * (1.f + c1 * omf * (p + p + omf)) + 1.f;   // UpDownUp
-		else y = 0.f;
-	}
-	return y;
+	const bool n_up = (tr & 1) != 0, o_up = (tr & 2) != 0, carry = (tr & 4) != 0;
+	const float cN = n_up ? c1 : c2;
+	const float pp = p + p;
+	const float y_lin = cN * (pp - f) + 1.f;                                    // Up (3) / Down (0)
+	const float y_wrap = -rcpf * (1.f + cN * omf * (pp + omf)) + 1.f;           // UpDownUp (7) / DownUpDown (4)
+	const float p2 = sqrf(p);
+	const float y_ud = rcpf * (c2 * p2 - c1 * sqrf(p - f)) + 1.f;               // UpDown (2)
+	const float y_du = -rcpf * (1.f + c2 * sqrf(p + omf) - c1 * p2) + 1.f;      // DownUp (5)
+	const float y_same = carry ? y_wrap : y_lin;                                // old == new
+	const float y_edge = carry ? y_du : y_ud;                                   // old != new: (carry, !o_up, n_up) or (!carry, o_up, !n_up)
+	const bool valid_edge = carry ? (!o_up && n_up) : (o_up && !n_up);
+	return (o_up == n_up) ? y_same : (valid_edge ? y_edge : 0.f);               // states 1 and 6 "should never happen" -> 0
+}
+// Saw() : Osm(&OSM::saw, 0.f) whose duty is never changed (patch invariant, e.g. config 2a): duty == 0 so
+// col = 0, c2 = -1, `offset < duty` is never true, state stays Down and only Down (0) / DownUpDown (4) occur.
+__device__ __forceinline__ float osm_saw_duty0(Osm& o) {
+	const float p = fast_phase_float(o.offset) - o.col;
+	const bool carry = o.offset < (uint32_t)o.inc;
+	o.offset += (uint32_t)o.inc;
+	const float pp = p + p;
+	const float y_lin = o.c2 * (pp - o.f) + 1.f;
+	const float y_wrap = -o.rcpf * (1.f + o.c2 * o.omf * (pp + o.omf)) + 1.f;
+	return carry ? y_wrap : y_lin;
 }
 __device__ __forceinline__ float osm_pulse(Osm& o) {                        // pulse() 5304-5316
 	const float p = fast_phase_float(o.offset);
 	const int tr = osm_tick(o);
 	const float rcpf2 = o.rcpf2, col = o.col;
-	float y;
-	switch (tr) {
-	case 3: y = 1.f; break;
-	case 0: y = -1.f; break;
-	case 2: y = rcpf2 * (col - p) + 1.f; break;
-	case 5: y = rcpf2 * p - 1.f; break;
-	case 7: y = rcpf2 * (col - 1.0f) + 1.f; break;
-	case 4: y = rcpf2 * col - 1.f; break;
-	default: y = 0.f;
-	}
-	return y;
+	const bool n_up = (tr & 1) != 0, o_up = (tr & 2) != 0, carry = (tr & 4) != 0;
+	const float y_flat = n_up ? 1.f : -1.f;                                     // Up (3) / Down (0)
+	const float y_wrap = n_up ? (rcpf2 * (col - 1.0f) + 1.f) : (rcpf2 * col - 1.f);   // UpDownUp (7) / DownUpDown (4)
+	const float y_ud = rcpf2 * (col - p) + 1.f;                                 // UpDown (2)
+	const float y_du = rcpf2 * p - 1.f;                                         // DownUp (5)
+	const float y_same = carry ? y_wrap : y_flat;
+	const float y_edge = carry ? y_du : y_ud;
+	const bool valid_edge = carry ? (!o_up && n_up) : (o_up && !n_up);
+	return (o_up == n_up) ? y_same : (valid_edge ? y_edge : 0.f);
 }
 
 // ---- Filters::Biquad klang.h:5550-5773 ----
@@ -203,39 +214,43 @@ struct Pts3 { float x0, x1, x2, y0, y1, y2;
 	__device__ __forceinline__ float y(int i) const { const float a = y0, b = y1, c = y2; return i == 2 ? c : (i == 1 ? b : a); } };
 
 // Envelope::process 4018-4051.  HOLD = the ADSR loop (setLoop(2,2), klang.h:4128): hold at the last point (NP-1).
+// The ramp step (Linear::operator++ 3785-3806) is branch-free.  Segment changes / stage changes are rare per lane
+// and sit behind ONE wave-uniform branch.  While an ADSR holds at its last point the reference re-applies
+// setValue(S) every sample, which changes nothing: that state is treated as settled and skips the rare path.
+template<int NP, bool HOLD, class PTS>
+__device__ __forceinline__ void env_segment_end(Env& e, const PTS& p, int npoints, const SampleRate& fs) {
+	if (e.stage == ENV_SUSTAIN) {
+		if (HOLD && (e.point + 1) >= (NP - 1)) {                        // loop.isActive() && (point + 1) >= loop.end
+			e.point = NP - 1;
+			env_set_value(e, p.y(NP - 1));
+		}
+		else if ((e.point + 1) < npoints) {
+			if (e.time >= p.x(e.point + 1)) {
+				e.point++;
+				env_set_value(e, p.y(e.point));
+				if ((e.point + 1) < npoints)
+					env_set_target_time(e, p.x(e.point + 1), p.y(e.point + 1), p.x(e.point), fs.f);
+			}
+		}
+		else e.stage = ENV_OFF;
+	}
+	else if (e.stage == ENV_RELEASE) e.stage = ENV_OFF;
+}
 template<int NP, bool HOLD, class PTS>
 __device__ __forceinline__ float env_process(Env& e, const PTS& p, int npoints, const SampleRate& fs) {
 	const float out = e.r_out;                                          // out = (*ramp)++ : pre-step value
-	if (e.active) {                                                     // Linear::operator++ 3785-3806
-		if (e.r_target > e.r_out) {
-			e.r_out += e.r_rate;
-			if (e.r_out >= e.r_target) { e.r_out = e.r_target; e.active = false; }
-		}
-		else {
-			e.r_out -= e.r_rate;
-			if (e.r_out <= e.r_target) { e.r_out = e.r_target; e.active = false; }
-		}
-	}
-	if (e.stage == ENV_SUSTAIN) {
-		e.time += fs.timeInc;
-		if (!e.active) {
-			if (HOLD && (e.point + 1) >= (NP - 1)) {                    // loop.isActive() && (point + 1) >= loop.end
-				e.point = NP - 1;
-				env_set_value(e, p.y(NP - 1));
-			}
-			else if ((e.point + 1) < npoints) {
-				if (e.time >= p.x(e.point + 1)) {
-					e.point++;
-					env_set_value(e, p.y(e.point));
-					if ((e.point + 1) < npoints)
-						env_set_target_time(e, p.x(e.point + 1), p.y(e.point + 1), p.x(e.point), fs.f);
-				}
-			}
-			else e.stage = ENV_OFF;
-		}
-	}
-	else if (e.stage == ENV_RELEASE) {
-		if (!e.active) e.stage = ENV_OFF;
+	const bool up = e.r_target > e.r_out;
+	const float nxt = up ? (e.r_out + e.r_rate) : (e.r_out - e.r_rate);
+	const bool reached = up ? (nxt >= e.r_target) : (nxt <= e.r_target);
+	const float stepped = reached ? e.r_target : nxt;
+	e.r_out = e.active ? stepped : e.r_out;
+	e.active = e.active && !reached;
+	const bool sustain = (e.stage == ENV_SUSTAIN);
+	e.time = sustain ? (e.time + fs.timeInc) : e.time;
+	const bool settled = HOLD && (e.point == NP - 1);
+	const bool rare = !e.active && ((sustain && !settled) || e.stage == ENV_RELEASE);
+	if (__ballot(rare) != 0ull) {
+		if (rare) env_segment_end<NP, HOLD>(e, p, npoints, fs);
 	}
 	return out;
 }

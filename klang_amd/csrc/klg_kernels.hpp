@@ -74,19 +74,18 @@ __global__ __launch_bounds__(WG) void klg_render(const RenderArgs a) {
 		BlockCtx ctx;
 		ctx.fs = a.fs;
 		ctx.ctl = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
-		if (live) {
-			rw.w[0] = flags;
+		// Dead lanes of a live wave run the same instruction stream on an all-zero record (no per-sample exec
+		// masking); their output is forced to 0 at the tile write and their record is never stored.
+		rw.w[0] = live ? flags : 0u;
 #pragma unroll
-			for (int w = 1; w < W; w++) rw.w[w] = a.state[(size_t)w * a.stride + v];
-			rw.to(rec);
-			P::begin(L, rec, ctx);
-		}
+		for (int w = 1; w < W; w++) rw.w[w] = live ? a.state[(size_t)w * a.stride + v] : 0u;
+		rw.to(rec);
+		P::begin(L, rec, ctx);
 		for (int c0 = 0; c0 < n; c0 += CHUNK) {
 			const int cl = (n - c0 < CHUNK) ? (n - c0) : CHUNK;
 			for (int s = 0; s < cl; s++) {
-				float y = 0.f;
-				if (live) y = P::sample(L, ctx);
-				tile[s * TILE_LD + lane] = y;
+				const float y = P::sample(L, ctx);
+				tile[s * TILE_LD + lane] = live ? y : 0.f;
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
@@ -126,18 +125,20 @@ __global__ __launch_bounds__(WG) void klg_render(const RenderArgs a) {
 	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = acc[i];
 }
 
-// partial rows [rows][n] -> mix[0][i] += sum, mix[1][i] += sum  (Stereo::Mono::Note: L += out; R += out, klang.h:4751-4752)
-__global__ __launch_bounds__(256) void klg_reduce(const float* __restrict__ partials, int rows, int n, float* mix, int channels) {
-	__shared__ float part[8][32];
-	const int s = blockIdx.x * 32 + (threadIdx.x & 31), p = threadIdx.x >> 5;
+// partial rows [rows][n] -> mix[c][i] += sum  (Stereo::Mono::Note: L += out; R += out, klang.h:4751-4752).
+// 1024 threads = 32 samples x 32 row partitions; fixed summation order (deterministic, no float atomics).
+__global__ __launch_bounds__(1024) void klg_reduce(const float* __restrict__ partials, int rows, int n, float* mix, int channels) {
+	__shared__ float part[32][33];
+	const int sl = threadIdx.x & 31, p = threadIdx.x >> 5;
+	const int s = blockIdx.x * 32 + sl;
 	float sum = 0.f;
-	if (s < n) for (int r = p; r < rows; r += 8) sum += partials[(size_t)r * n + s];
-	part[p][threadIdx.x & 31] = sum;
+	if (s < n) for (int r = p; r < rows; r += 32) sum += partials[(size_t)r * n + s];
+	part[p][sl] = sum;
 	__syncthreads();
 	if (p == 0 && s < n) {
 		float t = 0.f;
 #pragma unroll
-		for (int k = 0; k < 8; k++) t += part[k][threadIdx.x];
+		for (int k = 0; k < 32; k++) t += part[k][sl];
 		for (int c = 0; c < channels; c++) mix[(size_t)c * n + s] += t;
 	}
 }

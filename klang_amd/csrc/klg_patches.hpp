@@ -101,9 +101,9 @@ struct PatchSub2a {
 		L.lpf.b0 = r.lpf.b0; L.lpf.b1 = r.lpf.b1; L.lpf.b2 = r.lpf.b2; L.lpf.a1 = r.lpf.a1; L.lpf.a2 = r.lpf.a2; L.lpf.z0 = r.lpf.z0; L.lpf.z1 = r.lpf.z1;
 	}
 	static __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {
-		float out = biquad_process(L.lpf, osm_saw(L.osc));
+		float out = biquad_process(L.lpf, osm_saw_duty0(L.osc));     // `Saw osc` never gets a duty: duty == 0 (patch invariant)
 		out *= adsr_process(L.adsr, c.fs);
-		if (L.adsr.e.stage == ENV_OFF) L.stage = ST_OFF;
+		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;
 	}
 	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
@@ -146,7 +146,7 @@ struct PatchSub2b {
 		biquad_lpf_set(L.lpf, L.sw, fc, 10.f, c.fs.w);
 		float out = biquad_process(L.lpf, osm_pulse(L.osc));
 		out *= adsr_process(L.adsr, c.fs);
-		if (L.adsr.e.stage == ENV_OFF) L.stage = ST_OFF;
+		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;
 	}
 	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
@@ -185,7 +185,7 @@ struct PatchSuperSaw {
 #pragma unroll
 		for (int k = 0; k < 7; k++) out += osm_saw(L.osc[k]) / 7.f;
 		out *= adsr_process(L.adsr, c.fs);
-		if (L.adsr.e.stage == ENV_OFF) L.stage = ST_OFF;
+		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;
 	}
 	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
@@ -243,7 +243,7 @@ struct PatchFM {
 		for (int k = 0; k < NOPS; k++) m = op_process(L.op[k], m, c);
 		float out = m;
 		out *= adsr_process(L.adsr, c.fs) * 0.1f;
-		if (L.adsr.e.stage == ENV_OFF) L.stage = ST_OFF;
+		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;
 	}
 	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
