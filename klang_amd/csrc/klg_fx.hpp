@@ -1,4 +1,319 @@
-// klang_amd/csrc/klg_fx.hpp — effect banks (Stereo::Effect instances: PingPong.k, Reverb.k).
+// klang_amd/csrc/klg_fx.hpp — effect banks (BASELINE config 4): the shipped PingPong.k and Reverb.k as gfx950 kernels.
+//
+// One lane = one Stereo::Effect instance; one wave (64 instances) per workgroup so a bank of K instances
+// spreads over K/64 CUs.
+//
+// Data layout in HBM
+//   state   [word][Kpad]            per-instance scalars (controls, smoothing, filter state, tap tables), SoA
+//   rings   [line][pos][Kpad]       delay lines, POSITION-major / instance-minor: all instances advance their
+//                                   write cursor in lock-step (it only counts samples), so the 64 lanes of a wave
+//                                   write one contiguous 256-byte row per line per sample, and read taps coalesce
+//                                   whenever instances share a delay time (and degrade to a gather, never to a
+//                                   768-KB-strided walk, when they do not).
+//   io      [K][2][n]               caller layout (per-instance channel buffers, as the reference host owns them);
+//                                   staged through a padded LDS tile in 32-sample chunks so global accesses are
+//                                   128-byte row segments and the per-sample loop reads/writes LDS only.
+//
+// Arithmetic order follows examples/PingPong.k / examples/Reverb.k exactly as restated and pinned in
+// oracle/... (test infrastructure) — citations are into the reference files.
 #pragma once
-#include <hip/hip_runtime.h>
-#include "../../include/klang_mi355.h"
+#include "klg_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace klg {
+
+enum { FX_WG = 64, FX_CHUNK = 32, FX_LD = 65 };
+
+struct BiquadCoef { float b0, b1, b2, a1, a2; };
+
+// ---- Delay<SIZE> on an interleaved ring (klang.h:3381-3512) ----
+struct Ring {
+	float* base;          // this wave's column: &rings[line][0][k]
+	size_t stride;        // Kpad
+	int size;
+	__device__ __forceinline__ float rd(int i) const { return base[(size_t)i * stride]; }
+	__device__ __forceinline__ void wr(int i, float v) const { base[(size_t)i * stride] = v; }
+};
+struct Tap { int position; float fraction; };
+__device__ __forceinline__ Tap delay_set(int position, int size, float samples) {      // Delay::set 3480-3489
+	const float time = samples < size ? samples : (float)size;
+	float read = (float)(position - 1) - time;
+	if (read < 0.f) read += size;
+	Tap t; t.position = (int)read; t.fraction = read - t.position;
+	return t;
+}
+__device__ __forceinline__ float delay_process(const Ring& r, Tap& t) {               // tap() 3461-3468 + process 3470-3473
+	const int i = t.position;
+	const int j = (i + 1 == r.size) ? 0 : i + 1;                                      // (i + 1) % SIZE for 0 <= i < SIZE
+	const float a = r.rd(i), b = r.rd(j);
+	const float out = a + t.fraction * (b - a);
+	t.position = j;
+	return out;
+}
+
+// LDS staging of the [K][2][n] io block: tile[ch][sample][FX_LD]
+__device__ __forceinline__ void io_load_chunk(float* tile, const float* io, int k0, int K, int n, int s0, int cl, int lane) {
+	const int col = lane & 31, half = lane >> 5;
+	for (int it = 0; it < 64; it++) {                    // 128 rows (64 instances x 2 channels), 2 rows per wave access
+		const int row = 2 * it + half, inst = row >> 1, ch = row & 1;
+		float v = 0.f;
+		if (col < cl && k0 + inst < K) v = io[((size_t)(k0 + inst) * 2 + ch) * n + s0 + col];
+		tile[(ch * FX_CHUNK + col) * FX_LD + inst] = v;
+	}
+}
+__device__ __forceinline__ void io_store_chunk(const float* tile, float* io, int k0, int K, int n, int s0, int cl, int lane) {
+	const int col = lane & 31, half = lane >> 5;
+	for (int it = 0; it < 64; it++) {
+		const int row = 2 * it + half, inst = row >> 1, ch = row & 1;
+		if (col < cl && k0 + inst < K) io[((size_t)(k0 + inst) * 2 + ch) * n + s0 + col] = tile[(ch * FX_CHUNK + col) * FX_LD + inst];
+	}
+}
+__device__ __forceinline__ void wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// =================================================================================================
+// PingPong.k
+// =================================================================================================
+enum { PP_C0 = 0, PP_SM1 = 6, PP_SM5 = 7, PP_DELAY = 8, PP_LFO_POS = 9, PP_LFO_INC = 10, PP_Z = 11, PP_WORDS = 15 };
+
+struct PingPongArgs {
+	float* state; size_t kpad; int K;
+	float* rings;               // [2][192000][kpad]
+	int position;               // write cursor of both lines at block start (samples processed % 192000)
+	float* io; int n;
+	SampleRate fs;
+	BiquadCoef dc;              // dcfilter[k].set(50, 1) — PingPong.k:39-40, computed on the host
+	float c1_min, c1_max;
+};
+
+__global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
+	__shared__ float tile[2 * FX_CHUNK * FX_LD];
+	const int lane = threadIdx.x, k0 = blockIdx.x * FX_WG, k = k0 + lane;
+	const int SIZE = 192000;
+	float st[PP_WORDS];
+#pragma unroll
+	for (int w = 0; w < PP_WORDS; w++) st[w] = a.state[(size_t)w * a.kpad + k];
+	float c0 = st[0], c1 = st[1], c2 = st[2], c3 = st[3], c4 = st[4], c5 = st[5];
+	float sm1 = st[PP_SM1], sm5 = st[PP_SM5], mdelay = st[PP_DELAY];
+	BOsc lfo; lfo.position = st[PP_LFO_POS]; lfo.increment = st[PP_LFO_INC]; lfo.offset = 0.f;
+	Biquad dcl = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, st[PP_Z + 0], st[PP_Z + 1] };
+	Biquad dcr = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, st[PP_Z + 2], st[PP_Z + 3] };
+	Ring left = { a.rings + k, a.kpad, SIZE }, right = { a.rings + (size_t)SIZE * a.kpad + k, a.kpad, SIZE };
+	int position = a.position;
+
+	for (int s0 = 0; s0 < a.n; s0 += FX_CHUNK) {
+		const int cl = (a.n - s0 < FX_CHUNK) ? (a.n - s0) : FX_CHUNK;
+		io_load_chunk(tile, a.io, k0, a.K, a.n, s0, cl, lane);
+		wave_sync();
+		for (int s = 0; s < cl; s++) {
+			const float in_l = tile[(0 * FX_CHUNK + s) * FX_LD + lane], in_r = tile[(1 * FX_CHUNK + s) * FX_LD + lane];
+			// process() PingPong.k:44-71
+			const float rate = (c3 * c3) * 100.f;
+			sm5 = sm5 * 0.999f + (1.f - 0.999f) * c5;                               // controls[5].smooth()  klang.h:1715
+			const float new_delay = sm5;
+			if ((double)fabsf(mdelay - new_delay) > 0.001) {
+				mdelay = new_delay;
+				c1 = (new_delay < a.c1_min) ? a.c1_min : (a.c1_max < new_delay) ? a.c1_max : new_delay;   // controls[1].set()
+				lfo.position = KLG_PI_F;                                            // lfo.set(rate, pi)
+				lfo.increment = rate * 2.f * KLG_PI_F / a.fs.f;
+			}
+			else {
+				mdelay = c5;
+				lfo.increment = rate * 2.f * KLG_PI_F / a.fs.f;                       // lfo.set(rate)
+			}
+			const float gain = c0;
+			sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                               // controls[1].smooth()
+			const float delay = sm1;
+			const float vibrato = (c2 * c2) * rate * 1.41421354f;                   // sqr(controls[2]) * rate * root2
+			const float dry = c4;
+			const float nc1 = c1 + basic_sine(lfo) * vibrato * 0.00005f;
+			c1 = (nc1 < a.c1_min) ? a.c1_min : (a.c1_max < nc1) ? a.c1_max : nc1;
+
+			Tap tl = delay_set(position, SIZE, delay * a.fs.f);                     // left.set(delay * fs)
+			Tap tr = delay_set(position, SIZE, 0.5f * delay * a.fs.f);              // right.set(0.5f * delay * fs)
+
+			const float r1 = delay_process(right, tr);
+			left.wr(position, in_l + r1 * gain);                                    // (in.l + right * gain) >> left
+			const float l1 = delay_process(left, tl);
+			float out_l = dry * in_l + l1 * (1.f - dry);
+			const float l2 = delay_process(left, tl);
+			right.wr(position, in_r + l2 * gain);                                   // (in.r + left * gain) >> right
+			const float r2 = delay_process(right, tr);
+			float out_r = dry * in_r + r2 * (1.f - dry);
+			position = (position + 1 == SIZE) ? 0 : position + 1;
+
+			out_l = biquad_process(dcl, out_l);
+			out_r = biquad_process(dcr, out_r);
+			tile[(0 * FX_CHUNK + s) * FX_LD + lane] = out_l;
+			tile[(1 * FX_CHUNK + s) * FX_LD + lane] = out_r;
+		}
+		wave_sync();
+		io_store_chunk(tile, a.io, k0, a.K, a.n, s0, cl, lane);
+		wave_sync();
+	}
+	if (k < a.K) {
+		a.state[(size_t)1 * a.kpad + k] = c1;
+		a.state[(size_t)PP_SM1 * a.kpad + k] = sm1;
+		a.state[(size_t)PP_SM5 * a.kpad + k] = sm5;
+		a.state[(size_t)PP_DELAY * a.kpad + k] = mdelay;
+		a.state[(size_t)PP_LFO_POS * a.kpad + k] = lfo.position;
+		a.state[(size_t)PP_LFO_INC * a.kpad + k] = lfo.increment;
+		a.state[(size_t)(PP_Z + 0) * a.kpad + k] = dcl.z0; a.state[(size_t)(PP_Z + 1) * a.kpad + k] = dcl.z1;
+		a.state[(size_t)(PP_Z + 2) * a.kpad + k] = dcr.z0; a.state[(size_t)(PP_Z + 3) * a.kpad + k] = dcr.z1;
+	}
+}
+
+// =================================================================================================
+// Reverb.k
+// =================================================================================================
+// per-instance words
+enum {
+	RV_CTL = 0,                 // dry(c0) c1 c2 c3 wet(c4)
+	RV_EZ = 5,                  // early: lpf z0,z1 (L), lpf z0,z1 (R), hpf z0,z1 (L), hpf z0,z1 (R)
+	RV_ELPF = 13, RV_EHPF = 18, // early filter coefficients (b0 b1 b2 a1 a2)
+	RV_ECOUNT = 23,
+	RV_ETIMES = 24, RV_EGL = 44, RV_EGR = 64,
+	RV_FD = 84,                 // 16 x FilteredDelay
+	FD_Z0 = 0, FD_Z1 = 1, FD_IN = 2, FD_LASTP = 3, FD_LASTF = 4, FD_GAIN = 5, FD_COEF = 6, FD_WORDS = 11,
+	RV_WORDS = RV_FD + 16 * FD_WORDS
+};
+enum { RV_ESIZE = 21600, RV_FSIZE = 192000 };
+
+struct ReverbArgs {
+	float* state; size_t kpad; int K;
+	float* early_rings;         // [2][21600][kpad]
+	float* fd_rings;            // [16][192000][kpad]
+	int epos;                   // early write cursor at block start
+	int fpos;                   // FilteredDelay write cursor at block start (advances 2 per sample)
+	float* io; int n;
+};
+
+struct FDelay { Biquad f; float in, gain; Tap last; Ring ring; };
+
+// FilteredDelay::process Reverb.k:130-132 : (in >> delay >> filter) * gain >> out
+__device__ __forceinline__ float fd_process(FDelay& d, int& wpos) {
+	d.ring.wr(wpos, d.in);
+	const float t = delay_process(d.ring, d.last);
+	return biquad_process(d.f, t) * d.gain;
+}
+
+__device__ __forceinline__ void fd_load(FDelay& d, const ReverbArgs& a, int idx, int k) {
+	const float* s = a.state + (size_t)(RV_FD + idx * FD_WORDS) * a.kpad + k;
+	d.f.z0 = s[(size_t)FD_Z0 * a.kpad]; d.f.z1 = s[(size_t)FD_Z1 * a.kpad]; d.in = s[(size_t)FD_IN * a.kpad];
+	d.last.position = __float_as_int(s[(size_t)FD_LASTP * a.kpad]); d.last.fraction = s[(size_t)FD_LASTF * a.kpad];
+	d.gain = s[(size_t)FD_GAIN * a.kpad];
+	d.f.b0 = s[(size_t)(FD_COEF + 0) * a.kpad]; d.f.b1 = s[(size_t)(FD_COEF + 1) * a.kpad]; d.f.b2 = s[(size_t)(FD_COEF + 2) * a.kpad];
+	d.f.a1 = s[(size_t)(FD_COEF + 3) * a.kpad]; d.f.a2 = s[(size_t)(FD_COEF + 4) * a.kpad];
+	d.ring.base = a.fd_rings + (size_t)idx * RV_FSIZE * a.kpad + k; d.ring.stride = a.kpad; d.ring.size = RV_FSIZE;
+}
+__device__ __forceinline__ void fd_store(const FDelay& d, const ReverbArgs& a, int idx, int k) {
+	float* s = a.state + (size_t)(RV_FD + idx * FD_WORDS) * a.kpad + k;
+	s[(size_t)FD_Z0 * a.kpad] = d.f.z0; s[(size_t)FD_Z1 * a.kpad] = d.f.z1; s[(size_t)FD_IN * a.kpad] = d.in;
+	s[(size_t)FD_LASTP * a.kpad] = __int_as_float(d.last.position);
+}
+
+// LateReflections::process Reverb.k:153-168 (each FilteredDelay is processed twice per sample, see the oracle notes)
+__device__ __forceinline__ float late_process(FDelay (&d)[4], float in, int wpos0) {
+	int w0 = wpos0, w1 = (wpos0 + 1 == RV_FSIZE) ? 0 : wpos0 + 1;
+	float dl[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) dl[k] = fd_process(d[k], w0);
+	// signals<4> >> Matrix klang.h:1462-1467 with the FDN matrix of Reverb.k:158-161, row-major, products summed left to right
+	float fb[4];
+	fb[0] = 0.f * dl[0] + 1.f * dl[1] + 1.f * dl[2] + -1.f * dl[3];
+	fb[1] = -1.f * dl[0] + 0.f * dl[1] + -1.f * dl[2] + 1.f * dl[3];
+	fb[2] = -1.f * dl[0] + 1.f * dl[1] + 0.f * dl[2] + -1.f * dl[3];
+	fb[3] = 1.f * dl[0] + -1.f * dl[1] + 1.f * dl[2] + 0.f * dl[3];
+#pragma unroll
+	for (int k = 0; k < 4; k++) d[k].in = fb[k] + in;
+	const float o0 = fd_process(d[0], w1);
+	const float o1 = fd_process(d[1], w1);
+	const float s01 = o0 + o1;
+	const float s012 = fd_process(d[2], w1) + s01;
+	return fd_process(d[3], w1) + s012;
+}
+
+__global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
+	__shared__ float tile[2 * FX_CHUNK * FX_LD];
+	const int lane = threadIdx.x, k0 = blockIdx.x * FX_WG, k = k0 + lane;
+	const size_t KP = a.kpad;
+	const float* S = a.state + k;
+#define RVW(w) S[(size_t)(w) * KP]
+	const float dry = RVW(RV_CTL + 0), c1 = RVW(RV_CTL + 1), c2 = RVW(RV_CTL + 2), c3 = RVW(RV_CTL + 3), wet = RVW(RV_CTL + 4);
+	Biquad elpf[2], ehpf[2];
+#pragma unroll
+	for (int c = 0; c < 2; c++) {
+		elpf[c] = { RVW(RV_ELPF + 0), RVW(RV_ELPF + 1), RVW(RV_ELPF + 2), RVW(RV_ELPF + 3), RVW(RV_ELPF + 4), RVW(RV_EZ + 2 * c), RVW(RV_EZ + 2 * c + 1) };
+		ehpf[c] = { RVW(RV_EHPF + 0), RVW(RV_EHPF + 1), RVW(RV_EHPF + 2), RVW(RV_EHPF + 3), RVW(RV_EHPF + 4), RVW(RV_EZ + 4 + 2 * c), RVW(RV_EZ + 4 + 2 * c + 1) };
+	}
+	const int ecount = __float_as_int(RVW(RV_ECOUNT));
+	Ring el = { a.early_rings + k, KP, RV_ESIZE }, er = { a.early_rings + (size_t)RV_ESIZE * KP + k, KP, RV_ESIZE };
+	FDelay mid0[4], mid1[4], late0[4], late1[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++) { fd_load(mid0[j], a, 0 + j, k); fd_load(mid1[j], a, 4 + j, k); fd_load(late0[j], a, 8 + j, k); fd_load(late1[j], a, 12 + j, k); }
+	int epos = a.epos, fpos = a.fpos;
+
+	for (int s0 = 0; s0 < a.n; s0 += FX_CHUNK) {
+		const int cl = (a.n - s0 < FX_CHUNK) ? (a.n - s0) : FX_CHUNK;
+		io_load_chunk(tile, a.io, k0, a.K, a.n, s0, cl, lane);
+		wave_sync();
+		for (int s = 0; s < cl; s++) {
+			const float in_l = tile[(0 * FX_CHUNK + s) * FX_LD + lane], in_r = tile[(1 * FX_CHUNK + s) * FX_LD + lane];
+			// EarlyReflections::process Reverb.k:87-93 : in >> lpf >> hpf >> delay; out = sum delay(times[d]) * gains[d]
+			const float fl = biquad_process(ehpf[0], biquad_process(elpf[0], in_l));
+			const float fr = biquad_process(ehpf[1], biquad_process(elpf[1], in_r));
+			el.wr(epos, fl); er.wr(epos, fr);
+			epos = (epos + 1 == RV_ESIZE) ? 0 : epos + 1;
+			float r1l = 0.f, r1r = 0.f;
+			for (int d = 0; d < ecount; d++) {                                          // Stereo::Delay::tap(float) klang.h:4668-4681
+				float read = (float)(epos - 1) - RVW(RV_ETIMES + d);
+				if (read < 0.f) read += RV_ESIZE;
+				const float f = (float)floor((double)read);
+				const float frac = read - f;
+				const int i = (int)read;
+				const int j = (i == RV_ESIZE - 1) ? 0 : (i + 1);
+				const float tl = el.rd(i) * (1.f - frac) + el.rd(j) * frac;
+				const float tr = er.rd(i) * (1.f - frac) + er.rd(j) * frac;
+				r1l += tl * RVW(RV_EGL + d);
+				r1r += tr * RVW(RV_EGR + d);
+			}
+			// Reflections::process Reverb.k:223-245
+			const float r2l = late_process(mid0, r1l, fpos);
+			const float r2r = late_process(mid1, r1r, fpos);
+			const float r3l = late_process(late0, r2l, fpos);
+			const float r3r = late_process(late1, r2r, fpos);
+			fpos += 2; if (fpos >= RV_FSIZE) fpos -= RV_FSIZE;
+			const float refl_l = (r1l * c1 + r2l * c2) + r3l * c3;
+			const float refl_r = (r1r * c1 + r2r * c2) + r3r * c3;
+			// (in * dry + (in >> reflections) * wet) >> out  Reverb.k:271 — `reflections * wet` multiplies by signals<2>{ wet, 0 }
+			tile[(0 * FX_CHUNK + s) * FX_LD + lane] = in_l * dry + refl_l * wet;
+			tile[(1 * FX_CHUNK + s) * FX_LD + lane] = in_r * dry + refl_r * 0.f;
+		}
+		wave_sync();
+		io_store_chunk(tile, a.io, k0, a.K, a.n, s0, cl, lane);
+		wave_sync();
+	}
+	if (k < a.K) {
+		float* W = a.state + k;
+#pragma unroll
+		for (int c = 0; c < 2; c++) {
+			W[(size_t)(RV_EZ + 2 * c) * KP] = elpf[c].z0; W[(size_t)(RV_EZ + 2 * c + 1) * KP] = elpf[c].z1;
+			W[(size_t)(RV_EZ + 4 + 2 * c) * KP] = ehpf[c].z0; W[(size_t)(RV_EZ + 4 + 2 * c + 1) * KP] = ehpf[c].z1;
+		}
+#pragma unroll
+		for (int j = 0; j < 4; j++) { fd_store(mid0[j], a, 0 + j, k); fd_store(mid1[j], a, 4 + j, k); fd_store(late0[j], a, 8 + j, k); fd_store(late1[j], a, 12 + j, k); }
+	}
+#undef RVW
+}
+
+// scatter host-side updates into the SoA state: upd = { k, word, value_bits } triples
+__global__ void klg_fx_apply_updates(float* state, size_t kpad, const int* upd, int count) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < count) state[(size_t)upd[3 * i + 1] * kpad + upd[3 * i + 0]] = __int_as_float(upd[3 * i + 2]);
+}
+
+} // namespace klg

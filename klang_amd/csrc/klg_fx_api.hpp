@@ -1,11 +1,267 @@
 // klang_amd/csrc/klg_fx_api.hpp — C-ABI entry points of the effect banks (included by klg_api.hip).
+//
+// Host side: controls (clamping, Controls::changed()), and the patches' prepare() code — everything that runs
+// once per block or per control change in the reference (rand(), expf, cosf/sinf coefficient design, tap-table
+// construction) stays on the CPU and is shipped to the lanes as state-word updates.  Per-sample code is device only.
 #pragma once
-extern "C" klg_fx* klg_fx_create(int patch_id, int, float, int) { fail(KLG_ERR_INVALID, "klg_fx_create: effect patch %d is not built into this library yet", patch_id); return nullptr; }
-extern "C" void klg_fx_destroy(klg_fx*) {}
-extern "C" int klg_fx_set_control(klg_fx*, int, int, float) { return fail(KLG_ERR_INVALID, "effects not built"); }
-extern "C" int klg_fx_process(klg_fx*, float*, int) { return fail(KLG_ERR_INVALID, "effects not built"); }
-extern "C" int klg_fx_process_device(klg_fx*, float*, int, void*) { return fail(KLG_ERR_INVALID, "effects not built"); }
-extern "C" int klg_fx_sync(klg_fx*) { return fail(KLG_ERR_INVALID, "effects not built"); }
-extern "C" size_t klg_fx_state_bytes(const klg_fx*) { return 0; }
-extern "C" int klg_fx_timing_begin(klg_fx*) { return fail(KLG_ERR_INVALID, "effects not built"); }
-extern "C" int klg_fx_timing_end(klg_fx*, int*, float*) { return fail(KLG_ERR_INVALID, "effects not built"); }
+
+struct FxUpdate { int k, word, bits; };
+
+struct RvFilterCache { float f = 0.f, Q = 0.f; };
+struct RvHost {                                        // host mirror of one Reverb instance's prepare() state
+	float cache[10] = { 0 };                           // Controls::value[] klang.h:1878
+	float e_length = 0.f, e_size = 0.f;                // EarlyReflections::length / size
+};
+
+struct klg_fx {
+	int patch = 0, K = 0, max_block = 0, nctl = 0, words = 0;
+	size_t kpad = 0;
+	host::Fs fs;
+	hipStream_t stream = nullptr;
+	float *d_state = nullptr, *d_rings = nullptr, *d_rings2 = nullptr, *d_io = nullptr;
+	int* d_upd = nullptr; size_t d_upd_cap = 0;
+	unsigned long long samples = 0;                    // samples processed so far (defines every write cursor)
+	std::vector<host::ControlH> controls;              // [K][nctl]
+	std::vector<FxUpdate> upd;
+	std::vector<RvHost> rv;
+	BiquadCoef pp_dc;
+	bool timing = false; std::vector<hipEvent_t> tev; int launches = 0;
+};
+
+static inline int f2i(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+
+static void fx_free(klg_fx* f) {
+	if (!f) return;
+	if (f->stream) (void)hipStreamSynchronize(f->stream);
+	void* dev[] = { f->d_state, f->d_rings, f->d_rings2, f->d_io, f->d_upd };
+	for (void* p : dev) if (p) (void)hipFree(p);
+	for (auto e : f->tev) (void)hipEventDestroy(e);
+	if (f->stream) (void)hipStreamDestroy(f->stream);
+	delete f;
+}
+
+static const DialDef PP_DIALS[6] = { { 0.0f, 0.999f, 0.5f }, { 0.001f, 1.0f, 0.5f }, { 0.0f, 1.0f, 0.0f }, { 0.01f, 1.0f, 0.0f }, { 0.001f, 2.0f, 1.0f }, { 0.f, 1.f, 0.f } };   // PingPong.k:14-21
+static const DialDef RV_DIALS[10] = { { 0, 1, 0 }, { 0, 1, 1 }, { 0, 1, 0 }, { 0, 1, 0 }, { 0, 1, 1 }, { 0, 100, 10 }, { 0, 1, 1 }, { 0.01f, 1, 1 }, { 0.01f, 1, 1 }, { 0, 0.2f, 0 } };   // Reverb.k:100-113
+
+// Biquad coefficient design on the host (klang.h:5584-5600 + LPF/HPF::init 5658-5682); glibc cosf/sinf
+static BiquadCoef design_biquad(bool hpf, float f, float Q, const host::Fs& fs) {
+	if (Q < 0) Q = f / -Q;
+	const float w = f * fs.w;
+	const float cos0 = cosf(w), sin0 = sinf(w);
+	if (Q < 0.5) Q = 0.5f;
+	const float a = sin0 / (2.f * Q);
+	const double a0 = (double)(1.f + a);
+	const float inv = (a0 == 0.0f) ? 0.0f : (float)(1.0 / a0);
+	BiquadCoef c;
+	c.a1 = inv * (-2.f * cos0);
+	c.a2 = inv * (1.f - a);
+	if (!hpf) { c.b2 = c.b0 = inv * (1.f - cos0) * 0.5f; c.b1 = inv * (1.f - cos0); }
+	else { c.b2 = c.b0 = inv * (1.f + cos0) * 0.5f; c.b1 = inv * -(1.f + cos0); }
+	return c;
+}
+
+extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate, int max_block) {
+	if (patch_id != KLG_PATCH_PINGPONG && patch_id != KLG_PATCH_REVERB) { fail(KLG_ERR_INVALID, "klg_fx_create: patch %d is not an effect patch", patch_id); return nullptr; }
+	if (instances <= 0 || max_block <= 0 || max_block > MAX_BLOCK || !(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_fx_create: bad arguments"); return nullptr; }
+	if (klg_ensure_device()) return nullptr;
+	klg_fx* f = new klg_fx();
+	f->patch = patch_id; f->K = instances; f->max_block = max_block;
+	f->kpad = ((size_t)instances + FX_WG - 1) / FX_WG * FX_WG;
+	f->fs = host::Fs(sample_rate);
+	const bool pp = patch_id == KLG_PATCH_PINGPONG;
+	f->nctl = pp ? 6 : 10;
+	f->words = pp ? (int)PP_WORDS : (int)RV_WORDS;
+	const size_t ring1 = pp ? (size_t)2 * 192000 * f->kpad : (size_t)2 * RV_ESIZE * f->kpad;
+	const size_t ring2 = pp ? 0 : (size_t)16 * RV_FSIZE * f->kpad;
+	bool ok = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) == hipSuccess;
+	ok = ok && hipMalloc(&f->d_state, (size_t)f->words * f->kpad * 4) == hipSuccess;
+	ok = ok && hipMalloc(&f->d_rings, ring1 * 4) == hipSuccess;
+	ok = ok && (ring2 == 0 || hipMalloc(&f->d_rings2, ring2 * 4) == hipSuccess);
+	ok = ok && hipMalloc(&f->d_io, (size_t)f->kpad * 2 * max_block * 4) == hipSuccess;
+	ok = ok && hipMemset(f->d_state, 0, (size_t)f->words * f->kpad * 4) == hipSuccess;
+	ok = ok && hipMemset(f->d_rings, 0, ring1 * 4) == hipSuccess;                      // Delay() : buffer(SIZE + 1, 0)
+	ok = ok && (ring2 == 0 || hipMemset(f->d_rings2, 0, ring2 * 4) == hipSuccess);
+	if (!ok) { fail(KLG_ERR_NOMEM, "klg_fx_create: device allocation failed (%zu ring bytes): %s", (ring1 + ring2) * 4, hipGetErrorString(hipGetLastError())); fx_free(f); return nullptr; }
+	f->controls.resize((size_t)instances * f->nctl);
+	const DialDef* dials = pp ? PP_DIALS : RV_DIALS;
+	for (int k = 0; k < instances; k++) for (int c = 0; c < f->nctl; c++) {
+		f->controls[(size_t)k * f->nctl + c] = { dials[c].min, dials[c].max, dials[c].initial };
+		if (pp) f->upd.push_back({ k, c, f2i(dials[c].initial) });
+		else if (c < 5) f->upd.push_back({ k, RV_CTL + c, f2i(dials[c].initial) });
+	}
+	if (pp) f->pp_dc = design_biquad(true, 50.f, 1.f, f->fs);                          // dcfilter[k].set(50, 1)  PingPong.k:39-40
+	else f->rv.resize(instances);
+	return f;
+}
+
+extern "C" void klg_fx_destroy(klg_fx* f) { if (f && g_device >= 0) (void)hipSetDevice(g_device); fx_free(f); }
+extern "C" size_t klg_fx_state_bytes(const klg_fx* f) {
+	if (!f) return 0;
+	return (size_t)f->words * 4 + (f->patch == KLG_PATCH_PINGPONG ? (size_t)2 * 192000 * 4 : ((size_t)2 * RV_ESIZE + (size_t)16 * RV_FSIZE) * 4);
+}
+
+extern "C" int klg_fx_set_control(klg_fx* f, int instance, int index, float value) {
+	if (!f || instance < 0 || instance >= f->K || index < 0 || index >= f->nctl) return fail(KLG_ERR_INVALID, "klg_fx_set_control: instance %d / control %d out of range", instance, index);
+	host::ControlH& c = f->controls[(size_t)instance * f->nctl + index];
+	c.set(value);                                                                   // Control::set clamps (klang.h:1725-1728)
+	if (f->patch == KLG_PATCH_PINGPONG) f->upd.push_back({ instance, index, f2i(c.value) });
+	else if (index < 5) f->upd.push_back({ instance, RV_CTL + index, f2i(c.value) });
+	return 0;
+}
+
+// ---- Reverb.k prepare() on the host (Reverb.k:237-241 -> Reflections::set 188-214) ----
+static float random_f(float mn, float mx) { return rand() * ((mx - mn) / (float)RAND_MAX) + mn; }   // klang::random<float> klang.h:236
+
+static void rv_push_coef(klg_fx* f, int k, int word0, const BiquadCoef& c) {
+	const float v[5] = { c.b0, c.b1, c.b2, c.a1, c.a2 };
+	for (int i = 0; i < 5; i++) f->upd.push_back({ k, word0 + i, f2i(v[i]) });
+}
+static void rv_prepare(klg_fx* f, int k) {
+	RvHost& h = f->rv[k];
+	const host::ControlH* c = &f->controls[(size_t)k * 10];
+	bool changed = false;                                                           // Controls::changed() klang.h:1914-1923
+	for (int i = 0; i < 10; i++) if (c[i].value != h.cache[i]) { h.cache[i] = c[i].value; changed = true; }
+	if (!changed) return;
+	srand(272839);                                                                  // random(272839)  Reverb.k:239
+	const float length = c[5].value, size = c[6].value;
+	float dampening1 = c[7].value, dampening2 = c[8].value;
+	const host::Fs& fs = f->fs;
+	// early.set((length / 10.f) * 1000.f + 50.f, size)  Reverb.k:189, 63-73
+	{
+		float el = (length / 10.f) * 1000.f + 50.f;
+		el *= 1 / 1000.f;
+		if (h.e_length != el || h.e_size != size) {
+			h.e_length = el; h.e_size = size;
+			static const float primes[20] = { 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71 };
+			const int count = 10 + (int)(size * (float)10.999);                        // Reverb.k:26
+			const float scale = 50.f / primes[count - 1];
+			const float ms = fs.f / 1000.f;
+			f->upd.push_back({ k, RV_ECOUNT, count });
+			for (int r = 0; r < count; r++) {
+				const float t = ((50.f + primes[r] * scale) * ms * random_f(0.9f, 1.1f));
+				const float x = (float)(r + 1.f) / (float)(unsigned)count;
+				const float g = random_f(0.5f, 1.5f) * expf(-3.f * x);
+				const float pan = random_f(0.f, 1.f);
+				f->upd.push_back({ k, RV_ETIMES + r, f2i(t) });
+				f->upd.push_back({ k, RV_EGL + r, f2i(g * (1.f - pan)) });
+				f->upd.push_back({ k, RV_EGR + r, f2i(g * pan) });
+			}
+			rv_push_coef(f, k, RV_EHPF, design_biquad(true, 100.f, host::ROOT2_INV, fs));     // hpf.set(100)
+			rv_push_coef(f, k, RV_ELPF, design_biquad(false, 15000.f, host::ROOT2_INV, fs));  // lpf.set(15000)
+		}
+	}
+	dampening1 *= 10000.f;
+	dampening2 *= dampening1;
+	const int fpos = (int)((2ull * f->samples) % RV_FSIZE);                          // every FilteredDelay line has had 2 inputs per sample
+	const float delays1[4] = { 7, 11, 13, 17 }, delays2[4] = { 19, 23, 29, 31 };
+	for (int a = 0; a < 4; a++) {                                                   // mid[0], mid[1], late[0], late[1]  Reverb.k:198-207
+		const float* delays = a < 2 ? delays1 : delays2;
+		const float damp = a < 2 ? dampening1 : dampening2;
+		const float gain = a < 2 ? 0.25f : 0.35f;
+		for (int j = 0; j < 4; j++) {                                               // FilteredDelay::set Reverb.k:123-127
+			const float time = delays[j] * random_f(.9f, 1.1f);
+			const float samples = time * fs.f / 1000.f;
+			const float t = samples < RV_FSIZE ? samples : (float)RV_FSIZE;            // Delay::set klang.h:3480-3489
+			float read = (float)(fpos - 1) - t;
+			if (read < 0.f) read += RV_FSIZE;
+			const int lastp = (int)read;
+			const float lastf = read - lastp;
+			const int w0 = RV_FD + (a * 4 + j) * FD_WORDS;
+			f->upd.push_back({ k, w0 + FD_LASTP, lastp });
+			f->upd.push_back({ k, w0 + FD_LASTF, f2i(lastf) });
+			f->upd.push_back({ k, w0 + FD_GAIN, f2i(gain) });
+			rv_push_coef(f, k, w0 + FD_COEF, design_biquad(false, damp, host::ROOT2_INV, fs));   // filter.set(cutoff)
+		}
+	}
+}
+
+static int fx_flush_updates(klg_fx* f, hipStream_t st) {
+	if (f->upd.empty()) return 0;
+	{	// several updates of one word in a batch: the LAST one wins (the scatter kernel has no ordering)
+		std::stable_sort(f->upd.begin(), f->upd.end(), [](const FxUpdate& a, const FxUpdate& b) { return a.k != b.k ? a.k < b.k : a.word < b.word; });
+		size_t o = 0;
+		for (size_t i = 0; i < f->upd.size(); i++) {
+			if (i + 1 < f->upd.size() && f->upd[i + 1].k == f->upd[i].k && f->upd[i + 1].word == f->upd[i].word) continue;
+			f->upd[o++] = f->upd[i];
+		}
+		f->upd.resize(o);
+	}
+	const size_t bytes = f->upd.size() * sizeof(FxUpdate);
+	if (bytes > f->d_upd_cap) {
+		HIP_TRY(hipStreamSynchronize(st));
+		if (f->d_upd) (void)hipFree(f->d_upd);
+		f->d_upd_cap = bytes * 2;
+		HIP_TRY(hipMalloc(&f->d_upd, f->d_upd_cap));
+	}
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipMemcpyAsync(f->d_upd, f->upd.data(), bytes, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const int count = (int)f->upd.size();
+	hipLaunchKernelGGL(klg_fx_apply_updates, dim3((count + 255) / 256), dim3(256), 0, st, f->d_state, f->kpad, (const int*)f->d_upd, count);
+	HIP_TRY(hipGetLastError());
+	f->upd.clear();
+	return 0;
+}
+
+static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
+	if (f->patch == KLG_PATCH_REVERB) for (int k = 0; k < f->K; k++) rv_prepare(f, k);
+	if (int rc = fx_flush_updates(f, st)) return rc;
+	if (f->timing) {
+		if ((int)f->tev.size() < 2 * (f->launches + 1)) { hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); f->tev.push_back(e0); f->tev.push_back(e1); }
+		HIP_TRY(hipEventRecord(f->tev[2 * f->launches], st));
+	}
+	const dim3 grid((unsigned)(f->kpad / FX_WG)), block(FX_WG);
+	if (f->patch == KLG_PATCH_PINGPONG) {
+		PingPongArgs a;
+		a.state = f->d_state; a.kpad = f->kpad; a.K = f->K; a.rings = f->d_rings;
+		a.position = (int)(f->samples % 192000ull);
+		a.io = d_io; a.n = n;
+		a.fs.f = f->fs.f; a.fs.w = f->fs.w; a.fs.timeInc = 1.0f / f->fs.f;
+		a.dc = f->pp_dc; a.c1_min = PP_DIALS[1].min; a.c1_max = PP_DIALS[1].max;
+		hipLaunchKernelGGL(klg_fx_pingpong, grid, block, 0, st, a);
+	}
+	else {
+		ReverbArgs a;
+		a.state = f->d_state; a.kpad = f->kpad; a.K = f->K; a.early_rings = f->d_rings; a.fd_rings = f->d_rings2;
+		a.epos = (int)(f->samples % (unsigned long long)RV_ESIZE);
+		a.fpos = (int)((2ull * f->samples) % (unsigned long long)RV_FSIZE);
+		a.io = d_io; a.n = n;
+		hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);
+	}
+	HIP_TRY(hipGetLastError());
+	if (f->timing) { HIP_TRY(hipEventRecord(f->tev[2 * f->launches + 1], st)); f->launches++; }
+	f->samples += (unsigned long long)n;
+	return 0;
+}
+
+extern "C" int klg_fx_process(klg_fx* f, float* io, int n) {
+	if (!f || !io || n <= 0 || n > f->max_block) return fail(KLG_ERR_INVALID, "klg_fx_process: bad arguments (n=%d)", n);
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	const size_t bytes = (size_t)f->K * 2 * n * 4;
+	HIP_TRY(hipMemcpyAsync(f->d_io, io, bytes, hipMemcpyHostToDevice, f->stream));
+	if (int rc = fx_enqueue(f, f->d_io, n, f->stream)) return rc;
+	HIP_TRY(hipMemcpyAsync(io, f->d_io, bytes, hipMemcpyDeviceToHost, f->stream));
+	HIP_TRY(hipStreamSynchronize(f->stream));
+	return 0;
+}
+extern "C" int klg_fx_process_device(klg_fx* f, float* d_io, int n, void* hip_stream) {
+	if (!f || !d_io || n <= 0 || n > f->max_block) return fail(KLG_ERR_INVALID, "klg_fx_process_device: bad arguments (n=%d)", n);
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	return fx_enqueue(f, d_io, n, hip_stream ? (hipStream_t)hip_stream : f->stream);
+}
+extern "C" int klg_fx_sync(klg_fx* f) {
+	if (!f) return fail(KLG_ERR_INVALID, "klg_fx_sync: NULL handle");
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	HIP_TRY(hipDeviceSynchronize());
+	return 0;
+}
+extern "C" int klg_fx_timing_begin(klg_fx* f) { if (!f) return fail(KLG_ERR_INVALID, "NULL handle"); f->timing = true; f->launches = 0; return 0; }
+extern "C" int klg_fx_timing_end(klg_fx* f, int* launches, float* total_ms) {
+	if (!f || !launches || !total_ms) return fail(KLG_ERR_INVALID, "klg_fx_timing_end: bad arguments");
+	HIP_TRY(hipDeviceSynchronize());
+	float total = 0.f;
+	for (int i = 0; i < f->launches; i++) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, f->tev[2 * i], f->tev[2 * i + 1])); total += ms; }
+	*launches = f->launches; *total_ms = total;
+	f->timing = false;
+	return 0;
+}

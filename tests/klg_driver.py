@@ -72,3 +72,34 @@ def bit_exact_fraction(got, ref):
     b = np.ascontiguousarray(ref, np.float32).view(np.uint32)
     same = (a == b) | ((np.asarray(got) == 0) & (np.asarray(ref) == 0))
     return float(np.mean(same))
+
+
+def run_fx_scenario_gpu(s: Scenario):
+    """Effect scenario through the C-ABI: per-instance hash-noise burst input (scenario_io.fx_input), in place."""
+    import klang_amd
+    from scenario_io import fx_input
+    K, N, B = s.instances, s.block, s.blocks
+    bank = klang_amd.FxBank(s.patch, K, fs=s.fs, max_block=N)
+    try:
+        for k in range(K):
+            for i, v in s.ctl:
+                bank.set_control(k, i, v)
+        dumps = []
+        evi = 0
+        t = np.arange(N, dtype=np.uint64)
+        for b in range(B):
+            while evi < len(s.ev) and s.ev[evi][0] <= b:
+                _, ty, inst, a, bb, _seed = s.ev[evi]
+                if ty == EV_CTL:
+                    bank.set_control(inst, int(a), bb)
+                evi += 1
+            io = np.empty((K, 2, N), np.float32)
+            for k in range(K):
+                for ch in range(2):
+                    io[k, ch] = fx_input(s.seed, k, ch, t + np.uint64(b * N), s.burst)
+            bank.process(io)
+            if b in s.dump:
+                dumps.append(io.copy())
+        return dict(per_voice=np.stack(dumps))
+    finally:
+        bank.close()

@@ -48,4 +48,4 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp", ".sh")):
                 text = open(os.path.join(d, f), errors="ignore").read()
-                assert "klang_oracle" not in text and "oracle/" not in text.replace("oracle/ref/ref_", ""), f"{f} references the oracle"
+                assert "klang_oracle" not in text and "oracle/" not in text.replace("oracle/ref/ref_", "").replace("oracle/...", ""), f"{f} references the oracle"

@@ -1,0 +1,70 @@
+"""GPU parity of the effect banks (BASELINE config 4: PingPong.k + Reverb.k) through the C-ABI, against the golden
+vectors produced by the genuine reference and against the TEST-ONLY oracle on more instances.
+Tolerance: 1e-5 relative to max(|ref|, channel-block peak) (north_star)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from klg_driver import bit_exact_fraction, rel_err, run_fx_scenario_gpu, run_scenario_oracle
+from scenario_io import Scenario
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FX_SCENARIOS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.scn")) if Scenario.load(p).instances > 0)
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("name", FX_SCENARIOS)
+def test_fx_golden(name):
+    s = Scenario.load(os.path.join(GOLDEN, name + ".scn"))
+    ref = np.load(os.path.join(GOLDEN, name + ".npz"))["per_voice"]
+    got = run_fx_scenario_gpu(s)["per_voice"]
+    assert got.shape == ref.shape
+    err = rel_err(got, ref)
+    print(f"{name}: rel err {err:.3e}, bit-exact samples {100 * bit_exact_fraction(got, ref):.2f}%")
+    assert err <= TOL
+
+
+@pytest.mark.parametrize("patch,instances,blocks", [("pingpong", 200, 24), ("reverb", 70, 16)])
+def test_fx_against_oracle_many_instances(patch, instances, blocks, oracle_build):
+    """More instances than one wave, instance count not a multiple of 64, per-instance controls differ."""
+    s = Scenario(patch=patch, block=256, blocks=blocks, instances=instances, burst=3000, seed=77, dump=list(range(0, blocks, 3)))
+    rng = np.random.default_rng(3)
+    for k in range(instances):
+        if patch == "pingpong":
+            s.control(0, k, 1, float(rng.uniform(0.01, 0.2)))
+            s.control(0, k, 5, float(rng.uniform(0.0, 0.2)))
+            s.control(0, k, 0, float(rng.uniform(0.2, 0.9)))
+        else:
+            s.control(0, k, 2, float(rng.uniform(0.0, 1.0)))
+            s.control(0, k, 3, float(rng.uniform(0.0, 1.0)))
+            s.control(0, k, 6, float(rng.uniform(0.0, 1.0)))
+            s.control(0, k, 7, float(rng.uniform(0.1, 1.0)))
+    ref = run_scenario_oracle(s, oracle_build)["per_voice"]
+    got = run_fx_scenario_gpu(s)["per_voice"]
+    err = rel_err(got, ref)
+    print(f"{patch}: {instances} instances, rel err {err:.3e}, bit-exact {100 * bit_exact_fraction(got, ref):.2f}%")
+    assert err <= TOL
+
+
+def test_fx_block_size_independence():
+    """Property: 4 x 64-sample blocks == 1 x 256-sample block, bit for bit (PingPong, GPU vs GPU)."""
+    def render(block, blocks):
+        s = Scenario(patch="pingpong", block=block, blocks=blocks, instances=3, burst=700, seed=5, dump=list(range(blocks)))
+        s.ctl = [(0, 0.8), (1, 0.01), (5, 0.01)]
+        pv = run_fx_scenario_gpu(s)["per_voice"]           # [B][K][2][N]
+        return pv.transpose(1, 2, 0, 3).reshape(3, 2, -1)
+    a, b = render(256, 4), render(64, 16)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_fx_silence_in_silence_out():
+    import klang_amd
+    bank = klang_amd.FxBank("reverb", 5, max_block=128)
+    io = np.zeros((5, 2, 128), np.float32)
+    for _ in range(3):
+        bank.process(io)
+    assert not np.any(io)
+    bank.close()
