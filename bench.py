@@ -89,7 +89,8 @@ def main():
     import klang_amd
     notes = 128 if args.patch in ("sub2a", "sine", "bsine") else 32
     synths = max(1, args.voices // notes)
-    bank = klang_amd.SynthBank(args.patch, synths=synths, notes=notes, fs=48000.0, max_block=args.block, device=local_rank)
+    # weak scaling: every rank owns `synths` instances of the global bank (klang_amd/shard.py: contiguous ranges)
+    bank = klang_amd.ShardedSynthBank(args.patch, synths * world, notes, fs=48000.0, max_block=args.block, rank=rank, world=world, device=local_rank)
     V, N = bank.voices, args.block
 
     # synthetic MIDI / random-parameter workload: every voice sounding, uniform pitches 36..96
@@ -98,15 +99,13 @@ def main():
     vels = rng.uniform(0.25, 1.0, size=V)
     bank.random(rank + 1)
     for v in range(V):
-        bank.note_on(v // notes, int(pitches[v]), float(vels[v]))
+        bank.note_on(bank.lo + v // notes, int(pitches[v]), float(vels[v]))
     mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         mix.zero_()
-        bank.process_device(mix.data_ptr(), N, stream)
-        if world > 1:
-            dist.all_reduce(mix)
+        bank.process_device(mix, N, stream)          # render + (world > 1) one RCCL all-reduce of the [2][N] block
 
     for _ in range(args.warmup):
         step()
@@ -114,7 +113,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    bank.timing_begin()
+    bank.bank.timing_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -123,7 +122,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    launches, kernel_ms = bank.timing_end()
+    launches, kernel_ms = bank.bank.timing_end()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -135,7 +134,7 @@ def main():
         value = total_voices * N * args.steps / dt
         ms_per_step = 1e3 * dt / args.steps
         kern_s = 1e-3 * kernel_ms / max(1, launches)
-        rec_bytes = bank.state_bytes
+        rec_bytes = bank.bank.state_bytes
         alg_bytes = V * (rec_bytes + 4 * STORE_WORDS.get(args.patch, rec_bytes // 4)) + 2 * N * 4
         achieved = alg_bytes / kern_s / 1e9
         flops = FLOPS_PER_VOICE_SAMPLE.get(args.patch, 0) * V * N / kern_s / 1e12

@@ -6,3 +6,4 @@ There is no CPU rendering path anywhere in this package.
 """
 from ._lib import KlangError, lib, LIB_PATH  # noqa: F401
 from .bank import SynthBank, FxBank, PATCH_IDS  # noqa: F401
+from .shard import ShardedSynthBank, shard_range, owner_of  # noqa: F401

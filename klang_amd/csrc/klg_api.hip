@@ -15,6 +15,7 @@
 #include "klg_host_dsl.hpp"
 #include "klg_kernels.hpp"
 #include "klg_fx.hpp"
+#include "klg_render_x2.hpp"
 
 #pragma clang fp contract(off)
 
@@ -92,6 +93,7 @@ struct klg_synth {
 	float *d_controls = nullptr, *d_partials = nullptr, *d_mix = nullptr, *d_per_voice = nullptr;
 	uint32_t* d_scratch_rec = nullptr;
 	int grid = 0;
+	bool x2 = true;               // KLG_RENDER_X1=1 in the environment selects the one-voice-per-lane kernel (A/B tests)
 	// host mirrors
 	std::vector<host::ControlH> controls;        // [S][nctl]
 	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
@@ -165,6 +167,7 @@ extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_s
 	}
 	s->voices.resize(s->V);
 	if (patch_id == KLG_PATCH_SUPERSAW) for (auto& v : s->voices) for (auto& o : v.osm) o = host::OsmH(0.f);
+	if (const char* e = getenv("KLG_RENDER_X1")) s->x2 = !(e[0] == '1');
 	s->noteOns.assign(s->S, 0u);
 	s->noteStart.assign((size_t)s->S * 128, 0u);
 	return s;
@@ -182,7 +185,17 @@ template<class P> static void launch_render_t(klg_synth* s, const RenderArgs& a,
 	if (pv) hipLaunchKernelGGL((klg_render<P, true>), dim3(s->grid), dim3(WG), 0, st, a);
 	else hipLaunchKernelGGL((klg_render<P, false>), dim3(s->grid), dim3(WG), 0, st, a);
 }
+static int render_grid(const klg_synth* s) {      // workgroups (= partial rows) of the render launch
+	if (s->patch == KLG_PATCH_SUB2A && s->x2) return std::min((int)((s->stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG), s->grid);
+	return s->grid;
+}
 static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_t st) {
+	if (s->patch == KLG_PATCH_SUB2A && s->x2) {           // two voices per lane, packed fp32 (klg_render_x2.hpp)
+		const dim3 g(render_grid(s)), b(WG);
+		if (pv) hipLaunchKernelGGL(klg_render_sub2a_x2<true>, g, b, 0, st, a);
+		else hipLaunchKernelGGL(klg_render_sub2a_x2<false>, g, b, 0, st, a);
+		return;
+	}
 	switch (s->patch) {
 	case KLG_PATCH_SINE: launch_render_t<PatchSine>(s, a, pv, st); break;
 	case KLG_PATCH_BSINE: launch_render_t<PatchBSine>(s, a, pv, st); break;
@@ -435,7 +448,7 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	}
 	launch_render(s, a, per_voice, st);
 	if (s->timing) { HIP_TRY(hipEventRecord(s->tev[2 * s->launches + 1], st)); s->launches++; }
-	hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, s->grid, n, d_mix, 2);
+	hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
 	HIP_TRY(hipGetLastError());
 	s->stages_dirty = true;
 	return 0;

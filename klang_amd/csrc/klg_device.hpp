@@ -239,12 +239,15 @@ __device__ __forceinline__ void env_segment_end(Env& e, const PTS& p, int npoint
 template<int NP, bool HOLD, class PTS>
 __device__ __forceinline__ float env_process(Env& e, const PTS& p, int npoints, const SampleRate& fs) {
 	const float out = e.r_out;                                          // out = (*ramp)++ : pre-step value
+	// Linear::operator++ (3785-3806) without branches.  While a ramp is active r_out != r_target, so r_out is the
+	// smallest (ramp up) or largest (ramp down) of { r_out, r_out +/- rate, target } and the reference's
+	// "step, then clamp to target when reached or overshot" is exactly the median of the three: one v_med3_f32.
+	// (rate = +inf, the zero-length segment of ADSR(0, ...), gives +/-inf and the median is the target.)
 	const bool up = e.r_target > e.r_out;
-	const float nxt = up ? (e.r_out + e.r_rate) : (e.r_out - e.r_rate);
-	const bool reached = up ? (nxt >= e.r_target) : (nxt <= e.r_target);
-	const float stepped = reached ? e.r_target : nxt;
+	const float nxt = e.r_out + (up ? e.r_rate : -e.r_rate);
+	const float stepped = __builtin_amdgcn_fmed3f(e.r_out, nxt, e.r_target);
 	e.r_out = e.active ? stepped : e.r_out;
-	e.active = e.active && !reached;
+	e.active = e.active && (stepped != e.r_target);
 	const bool sustain = (e.stage == ENV_SUSTAIN);
 	e.time = sustain ? (e.time + fs.timeInc) : e.time;
 	const bool settled = HOLD && (e.point == NP - 1);

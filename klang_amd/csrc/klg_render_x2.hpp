@@ -1,0 +1,224 @@
+// klang_amd/csrc/klg_render_x2.hpp — the Subtractive (config 2a) voice kernel with TWO voices per lane.
+//
+// Why: the synth patches are bound by fp32 VALU issue, -ffp-contract=off forbids FMA, and a plain
+// v_mul/v_add retires one fp32 op per lane.  gfx950's packed fp32 pipe (v_pk_mul_f32 / v_pk_add_f32) retires two.
+// Giving every lane two voices (a float2 of independent state) turns ~60 % of the per-sample instruction stream
+// into packed ops and doubles the independent work between dependent instructions.  Each half of every packed op
+// is an ordinary IEEE fp32 mul/add, so results stay bit-identical to the one-voice-per-lane kernel (and to the
+// reference); tests/test_gpu_parity.py runs both.
+//
+// Layout: lane l of wave w of workgroup g owns voices v = g*512 + w*128 + 2*l + {0,1}: state planes are read as
+// 8-byte (dwordx2) coalesced accesses.  Mix: 16-sample chunks, tile[s][lane] of float2 with a 65-slot row stride
+// (conflict-free ds_write_b64 / ds_read_b64), lane (s = l & 15, q = l >> 4) sums a quarter row with packed adds.
+#pragma once
+#include "klg_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace klg {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+enum { X2_CHUNK = 16, X2_LD = 65, X2_VOICES_PER_WG = 2 * WG };
+
+__device__ __forceinline__ f2 as_f2(u2 v) { return __builtin_bit_cast(f2, v); }
+__device__ __forceinline__ u2 as_u2(f2 v) { return __builtin_bit_cast(u2, v); }
+__device__ __forceinline__ f2 splat(float x) { f2 r = { x, x }; return r; }
+
+struct Sub2aX2 {
+	using Rec = PatchSub2a::Rec;
+	// OSM (Saw, duty == 0: only Down / DownUpDown occur, see osm_saw_duty0)
+	u2 offset, inc; f2 f, omf, c2, k2, nrcpf;
+	// Biquad
+	f2 b0, b1, b2, a1, a2, z0, z1;
+	// ADSR
+	f2 r_out, r_target, r_rate, time, A, AD, S;
+	i2 estage, point, active;      // active: 0 / -1 mask
+	i2 stage;                      // NoteBase::stage
+};
+
+__device__ __forceinline__ void sub2a_x2_begin(Sub2aX2& L, const u2 (&w)[sizeof(PatchSub2a::Rec) / 4]) {
+	// word order of PatchSub2a::Rec: flags | inc offset duty delta | b0 b1 b2 a1 a2 z0 z1 | r_out r_target r_rate time A AD S R
+	const u2 flags = w[0];
+	L.stage = __builtin_convertvector(flags & 3u, i2);
+	const u2 eb = (flags >> 2) & 0x3Fu;
+	L.estage = __builtin_convertvector(eb & 3u, i2);
+	L.point = __builtin_convertvector((eb >> 2) & 7u, i2);
+	L.active = -__builtin_convertvector((eb >> 5) & 1u, i2);
+	L.inc = w[1]; L.offset = w[2];
+	const f2 delta = as_f2(w[4]);
+	L.f = delta;                                   // OSM::init klang.h:5206-5215 with col = 0
+	L.omf = 1.f - L.f;
+	const f2 rcpf = 1.f / L.f;
+	L.nrcpf = -rcpf;
+	const f2 col = as_f2(((w[3] >> 9) | 0x3f800000u)) - 1.f;
+	L.c2 = -1.f / (1.0f - col);
+	L.k2 = L.c2 * L.omf;                           // `c2 * omf * (...)` associates left: (c2 * omf) is loop invariant
+	L.b0 = as_f2(w[5]); L.b1 = as_f2(w[6]); L.b2 = as_f2(w[7]); L.a1 = as_f2(w[8]); L.a2 = as_f2(w[9]); L.z0 = as_f2(w[10]); L.z1 = as_f2(w[11]);
+	L.r_out = as_f2(w[12]); L.r_target = as_f2(w[13]); L.r_rate = as_f2(w[14]); L.time = as_f2(w[15]);
+	L.A = as_f2(w[16]); L.AD = as_f2(w[17]); L.S = as_f2(w[18]);
+}
+
+// rare path of one voice (element c): segment end / stage change, the scalar code of klg_device.hpp
+template<int c>
+__device__ __forceinline__ void sub2a_x2_rare(Sub2aX2& L, const SampleRate& fs) {
+	Env e; e.r_out = L.r_out[c]; e.r_target = L.r_target[c]; e.r_rate = L.r_rate[c]; e.time = L.time[c];
+	e.stage = L.estage[c]; e.point = L.point[c]; e.active = L.active[c] != 0;
+	Pts3 p; p.x0 = 0.f; p.x1 = L.A[c]; p.x2 = L.AD[c]; p.y0 = 0.f; p.y1 = 1.f; p.y2 = L.S[c];
+	env_segment_end<3, true>(e, p, 3, fs);
+	L.r_out[c] = e.r_out; L.r_target[c] = e.r_target; L.r_rate[c] = e.r_rate; L.time[c] = e.time;
+	L.estage[c] = e.stage; L.point[c] = e.point; L.active[c] = e.active ? -1 : 0;
+}
+
+__device__ __forceinline__ f2 sub2a_x2_osc_filter(Sub2aX2& L) {
+	// ---- Fast::Saw (OSM, duty 0)  klang.h:5251-5302 ----
+	const f2 p = as_f2((L.offset >> 9) | 0x3f800000u) - 1.f;          // float(offset) - col, col == 0
+	const i2 carry = L.offset < L.inc;
+	L.offset += L.inc;
+	const f2 pp = p + p;
+	const f2 y_lin = L.c2 * (pp - L.f) + 1.f;
+	const f2 y_wrap = L.nrcpf * (1.f + L.k2 * (pp + L.omf)) + 1.f;
+	const f2 osc = carry ? y_wrap : y_lin;
+	// ---- Biquad LPF, TDF-II  klang.h:5605-5612 ----
+	const f2 y = L.b0 * osc + L.z0;
+	L.z0 = L.b1 * osc - L.a1 * y + L.z1;
+	L.z1 = L.b2 * osc - L.a2 * y;
+	return y;
+}
+
+// A voice is QUIET when its envelope needs no work this block beyond the Sustain time counter: the ramp is idle
+// and the voice either holds at the ADSR sustain point or is already Off.  Nothing inside a block can end that
+// state (only host events between blocks do), so a wave whose voices are all quiet runs the short loop below.
+__device__ __forceinline__ i2 sub2a_x2_quiet(const Sub2aX2& L) {
+	return ~L.active & (((L.estage == (int)ENV_SUSTAIN) & (L.point == 2)) | (L.estage == (int)ENV_OFF));
+}
+__device__ __forceinline__ f2 sub2a_x2_sample_quiet(Sub2aX2& L, const SampleRate& fs) {
+	const f2 y = sub2a_x2_osc_filter(L);
+	const i2 sustain = (L.estage == (int)ENV_SUSTAIN);
+	L.time = sustain ? (L.time + fs.timeInc) : L.time;                // Envelope::process, case Sustain: time += timeInc
+	return y * L.r_out;                                               // out *= adsr++ (ramp idle: value unchanged)
+}
+
+__device__ __forceinline__ f2 sub2a_x2_sample(Sub2aX2& L, const SampleRate& fs) {
+	const f2 y = sub2a_x2_osc_filter(L);
+	// ---- ADSR: Envelope::process fast path  klang.h:4018-4051 (see env_process) ----
+	const f2 env = L.r_out;
+	const i2 up = L.r_target > L.r_out;
+	const f2 nxt = L.r_out + (up ? L.r_rate : -L.r_rate);
+	f2 stepped;
+	stepped.x = __builtin_amdgcn_fmed3f(L.r_out.x, nxt.x, L.r_target.x);
+	stepped.y = __builtin_amdgcn_fmed3f(L.r_out.y, nxt.y, L.r_target.y);
+	L.r_out = L.active ? stepped : L.r_out;
+	L.active = L.active & (stepped != L.r_target);
+	const i2 sustain = (L.estage == (int)ENV_SUSTAIN);
+	L.time = sustain ? (L.time + fs.timeInc) : L.time;
+	const i2 rare = ~L.active & ((sustain & (L.point != 2)) | (L.estage == (int)ENV_RELEASE));
+	if (__ballot((rare.x | rare.y) != 0) != 0ull) {
+		if (rare.x) sub2a_x2_rare<0>(L, fs);
+		if (rare.y) sub2a_x2_rare<1>(L, fs);
+	}
+	L.stage = (L.estage == (int)ENV_OFF) ? (i2)(int)ST_OFF : L.stage;  // if (adsr.finished()) stop();
+	return y * env;                                                    // out *= adsr++
+}
+
+__device__ __forceinline__ void sub2a_x2_end(const Sub2aX2& L, u2& flags, u2& offset, u2& z0, u2& z1, u2& r_out, u2& r_target, u2& r_rate, u2& time) {
+	const u2 eb = __builtin_convertvector(L.estage, u2) | (__builtin_convertvector(L.point, u2) << 2) | ((__builtin_convertvector(L.active, u2) & 1u) << 5);
+	flags = __builtin_convertvector(L.stage, u2) | (eb << 2);                 // osm state bits stay 0 (Down)
+	offset = L.offset; z0 = as_u2(L.z0); z1 = as_u2(L.z1);
+	r_out = as_u2(L.r_out); r_target = as_u2(L.r_target); r_rate = as_u2(L.r_rate); time = as_u2(L.time);
+}
+
+template<bool PER_VOICE>
+__global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
+	constexpr int W = sizeof(PatchSub2a::Rec) / 4;
+	__shared__ __attribute__((aligned(16))) float lds[WAVES * X2_CHUNK * X2_LD * 2 + MAX_BLOCK];
+	float* acc = lds + WAVES * X2_CHUNK * X2_LD * 2;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	f2* tile = reinterpret_cast<f2*>(lds) + wave * X2_CHUNK * X2_LD;
+	const int n = a.n;
+	for (int i = tid; i < n; i += WG) acc[i] = 0.f;
+	__syncthreads();
+
+	const int groups = (int)((a.stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG);
+	for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+		const int v0 = g * X2_VOICES_PER_WG + wave * 128;         // this wave's first voice
+		const int v = v0 + 2 * lane;                              // this lane's first voice (v, v + 1)
+		const bool in_range = (size_t)v < a.stride;              // stride is a multiple of 256 and v is even: v + 1 is in range too
+		u2 w[W];
+		w[0] = in_range ? *reinterpret_cast<const u2*>(a.state + v) : (u2)(unsigned)ST_OFF;
+		i2 live = ((w[0] & 3u) != (unsigned)ST_OFF);
+		live.x = (v < a.voices) ? live.x : 0; live.y = (v + 1 < a.voices) ? live.y : 0;
+		const bool any_live = (live.x | live.y) != 0;
+		if (__ballot(any_live) == 0ull) {
+			if (PER_VOICE)
+				for (int j = 0; j < 128 && v0 + j < a.voices; j++)
+					for (int i = lane; i < n; i += 64) a.per_voice[(size_t)(v0 + j) * n + i] = 0.f;
+			continue;
+		}
+		w[0] = live ? w[0] : (u2)0u;
+#pragma unroll
+		for (int k = 1; k < W; k++) {
+			const u2 t = any_live ? *reinterpret_cast<const u2*>(a.state + (size_t)k * a.stride + v) : (u2)0u;
+			w[k] = live ? t : (u2)0u;
+		}
+		Sub2aX2 L;
+		sub2a_x2_begin(L, w);
+		for (int c0 = 0; c0 < n; c0 += X2_CHUNK) {
+			const int cl = (n - c0 < X2_CHUNK) ? (n - c0) : X2_CHUNK;
+			const i2 quiet = sub2a_x2_quiet(L);
+			if (__ballot((quiet.x & quiet.y) == 0) == 0ull) {         // every voice of the wave is quiet
+				for (int s = 0; s < cl; s++) {
+					const f2 y = sub2a_x2_sample_quiet(L, a.fs);
+					tile[s * X2_LD + lane] = live ? y : splat(0.f);
+				}
+			}
+			else {
+				for (int s = 0; s < cl; s++) {
+					const f2 y = sub2a_x2_sample(L, a.fs);
+					tile[s * X2_LD + lane] = live ? y : splat(0.f);
+				}
+			}
+			wave_sync();
+			if (PER_VOICE) {
+				const int s = lane & 15, q = lane >> 4;
+				const float* tf = reinterpret_cast<const float*>(tile);
+				for (int j = 0; j < 32; j++) {
+					const int vv = 4 * j + q;                             // voice within the wave's 128
+					if (s < cl && v0 + vv < a.voices) a.per_voice[(size_t)(v0 + vv) * n + c0 + s] = tf[(s * X2_LD) * 2 + vv];
+				}
+			}
+			{
+				const int s = lane & 15, q = lane >> 4;
+				f2 sum2 = splat(0.f);
+				if (s < cl) {
+					const f2* row = tile + s * X2_LD + q * 16;
+#pragma unroll
+					for (int j = 0; j < 16; j++) sum2 += row[j];
+				}
+				float sum = sum2.x + sum2.y;
+				sum += __shfl_xor(sum, 16);
+				sum += __shfl_xor(sum, 32);
+				if (lane < cl) atomicAdd(&acc[c0 + lane], sum);
+			}
+			wave_sync();
+		}
+		if (any_live) {
+			u2 flags, offset, z0, z1, r_out, r_target, r_rate, time;
+			sub2a_x2_end(L, flags, offset, z0, z1, r_out, r_target, r_rate, time);
+			// only the words PatchSub2a::kStoreMask names: flags(0) offset(2) z0 z1 (10,11) r_out..time (12..15)
+			auto st = [&](int k, u2 val) {
+				u2* dst = reinterpret_cast<u2*>(a.state + (size_t)k * a.stride + v);
+				if (live.x && live.y) *dst = val;
+				else if (live.x) a.state[(size_t)k * a.stride + v] = val.x;
+				else if (live.y) a.state[(size_t)k * a.stride + v + 1] = val.y;
+			};
+			st(0, flags); st(2, offset); st(10, z0); st(11, z1); st(12, r_out); st(13, r_target); st(14, r_rate); st(15, time);
+		}
+	}
+	__syncthreads();
+	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = acc[i];
+}
+
+} // namespace klg

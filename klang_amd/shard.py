@@ -1,0 +1,71 @@
+"""Multi-GPU sharding of a synth bank: one process per GPU, voices partitioned by contiguous
+ranges of synth instances, no data-path collective except ONE all-reduce (RCCL over xGMI; `nccl` backend on ROCm)
+of the [2][n] stereo block per step, and only when the bank spans more than one GPU.
+
+The renderer is injectable (`bank_factory`) so the partition / event-routing / reduce logic can be exercised on CPU
+with the gloo backend (tests/test_sharding_gloo.py); the product default is the HIP SynthBank.
+"""
+from .bank import SynthBank
+
+
+def shard_range(n_items, world, rank):
+    """Contiguous split of n_items over `world` ranks; the first n_items % world ranks own one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def owner_of(item, n_items, world):
+    base, extra = divmod(n_items, world)
+    split = extra * (base + 1)
+    return item // (base + 1) if item < split else extra + (item - split) // max(base, 1)
+
+
+class ShardedSynthBank:
+    def __init__(self, patch, synths, notes, fs=48000.0, max_block=256, rank=0, world=1, device=None,
+                 bank_factory=None, all_reduce=None):
+        self.rank, self.world, self.synths, self.notes = rank, world, synths, notes
+        self.lo, self.hi = shard_range(synths, world, rank)
+        if self.hi <= self.lo:
+            raise ValueError(f"rank {rank} of {world} owns no synth instance (synths={synths})")
+        factory = bank_factory or (lambda **kw: SynthBank(device=device, **kw))
+        self.bank = factory(patch=patch, synths=self.hi - self.lo, notes=notes, fs=fs, max_block=max_block)
+        self._all_reduce = all_reduce
+        self.voices = self.bank.voices
+        self.total_voices = synths * notes
+
+    def owns(self, synth):
+        return self.lo <= synth < self.hi
+
+    # events: every rank sees the same (global) event stream and keeps its own share
+    def random(self, seed):
+        self.bank.random(seed)
+
+    def note_on(self, synth, pitch, velocity=1.0, seed=None):
+        if not self.owns(synth):
+            return None
+        if seed is not None:
+            self.bank.random(seed)
+        return self.bank.note_on(synth - self.lo, pitch, velocity)
+
+    def note_off(self, synth, pitch, velocity=0.0):
+        if self.owns(synth):
+            self.bank.note_off(synth - self.lo, pitch, velocity)
+
+    def set_control(self, synth, index, value):
+        if self.owns(synth):
+            self.bank.set_control(synth - self.lo, index, value)
+
+    def process_device(self, mix, n, stream=None):
+        """mix: torch tensor [2][n] on this rank's device, ACCUMULATED into; afterwards every rank holds the global sum."""
+        self.bank.process_device(mix.data_ptr(), n, stream)
+        if self.world > 1:
+            if self._all_reduce is not None:
+                self._all_reduce(mix)
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(mix)
+        return mix
+
+    def close(self):
+        self.bank.close()

@@ -138,3 +138,15 @@ def test_voice_state_roundtrip_and_abi_errors():
     with pytest.raises(klang_amd.KlangError):
         klang_amd.SynthBank("sub2a", synths=1, notes=129)     # Array<NOTE*,128>
     bank.close()
+
+
+@pytest.mark.parametrize("name", ["sub2a_poly", "sub2a_steal", "sub2a_long"])
+def test_one_voice_per_lane_kernel_matches_too(name, monkeypatch):
+    """Config 2a normally runs the two-voices-per-lane packed-fp32 kernel (klg_render_x2.hpp); KLG_RENDER_X1=1
+    selects the generic one-voice-per-lane kernel.  Both must reproduce the reference bit for bit."""
+    monkeypatch.setenv("KLG_RENDER_X1", "1")
+    s = Scenario.load(os.path.join(GOLDEN, name + ".scn"))
+    ref = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = run_scenario_gpu(s)
+    assert np.array_equal(got["stages"], ref["stages"])
+    assert bit_exact_fraction(got["per_voice"], ref["per_voice"]) == 1.0
