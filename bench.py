@@ -28,6 +28,17 @@ FLOPS_PER_VOICE_SAMPLE = {"sub2a": 21, "sub2b": 120, "supersaw": 120, "fm4": 95,
 STORE_WORDS = {"sub2a": 8, "sub2b": 19, "supersaw": 12, "fm3": 20, "fm4": 25, "sine": 2}
 
 
+def pmc_traffic(patch, voices):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE x 2 per the
+    gfx950 half-count correction of MI355X_MICROARCH.md + WRITE_SIZE), or None when no matching profile exists."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        e = t.get(f"{patch}:{voices}")
+        return e["bytes_per_launch"] if e else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(patch, block, budget_s=12.0):
     """The TEST-ONLY oracle (C restatement, bit-exact vs the reference header) timed on ONE host core on a
     bounded sample of the same workload: 128 voices (one Synth instance) x `block` samples x M blocks."""
@@ -107,6 +118,10 @@ def main():
         mix.zero_()
         bank.process_device(mix, N, stream)          # render + (world > 1) one RCCL all-reduce of the [2][N] block
 
+    # settle: run the attack + decay segments (0.01 s + 0.105 s = 22 blocks) untimed so the timed region measures
+    # the steady state of a sounding voice (sustain); the all-voices-ramping worst case is measured separately below
+    for _ in range(24):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -129,6 +144,25 @@ def main():
         dt = float(t.item())
     checksum = float(mix.abs().sum().item())
 
+    # worst case for the envelope code: every voice in its release ramp (not part of `value`)
+    for v in range(V):
+        bank.note_off(bank.lo + v // notes, int(pitches[v]), 0.0)
+    step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt_release = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dt_release], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_release = float(t.item())
+
     if rank == 0:
         total_voices = V * world
         value = total_voices * N * args.steps / dt
@@ -145,9 +179,11 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.patch}: {V} voices/GPU (Saw>>Biquad LPF>>ADSR), {N}-sample blocks @48kHz, all voices sounding, stereo mix resident in HBM",
                        "voices_per_gpu": V, "block": N, "parallelism": f"voice-shard x{world}" + (" + RCCL all-reduce of [2][%d] per block" % N if world > 1 else ""),
-                       "realtime_voices_equiv": int(value / 48000.0), "block_deadline_ms": 1e3 * N / 48000.0, "mix_checksum": checksum},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "klg_render<%s>" % args.patch, "kernel_ms": 1e3 * kern_s, "algorithmic_bytes_per_launch": alg_bytes,
+                       "phase": "sustain (all voices held)", "value_all_voices_in_release_ramp": total_voices * N * 20 / dt_release,
+                       "realtime_voices_equiv": int(value / 48000.0), "realtime_voices_equiv_worst_case": int(total_voices * N * 20 / dt_release / 48000.0),
+                       "block_deadline_ms": 1e3 * N / 48000.0, "mix_checksum": checksum},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.patch, V),
+                         "kernel": ("klg_render_sub2a_x2<false>" if args.patch == "sub2a" and os.environ.get("KLG_RENDER_X1") != "1" else "klg_render<%s>" % args.patch), "kernel_ms": 1e3 * kern_s, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "synth patches keep voice state in registers: the binding unit is fp32 VALU issue, see `valu`",
                          "valu": {"achieved_tflops_est": flops, "peak_tflops": FP32_PEAK_TFLOPS, "frac": flops / FP32_PEAK_TFLOPS,
                                   "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(args.patch, 0)}},

@@ -55,15 +55,23 @@ __device__ __forceinline__ float delay_process(const Ring& r, Tap& t) {         
 // LDS staging of the [K][2][n] io block: tile[ch][sample][FX_LD]
 __device__ __forceinline__ void io_load_chunk(float* tile, const float* io, int k0, int K, int n, int s0, int cl, int lane) {
 	const int col = lane & 31, half = lane >> 5;
-	for (int it = 0; it < 64; it++) {                    // 128 rows (64 instances x 2 channels), 2 rows per wave access
-		const int row = 2 * it + half, inst = row >> 1, ch = row & 1;
-		float v = 0.f;
-		if (col < cl && k0 + inst < K) v = io[((size_t)(k0 + inst) * 2 + ch) * n + s0 + col];
-		tile[(ch * FX_CHUNK + col) * FX_LD + inst] = v;
+	for (int it0 = 0; it0 < 64; it0 += 16) {             // 128 rows (64 instances x 2 channels), 2 rows per wave access,
+		float v[16];                                     // 16 accesses in flight before the first LDS write
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const int row = 2 * (it0 + j) + half, inst = row >> 1, ch = row & 1;
+			v[j] = (col < cl && k0 + inst < K) ? io[((size_t)(k0 + inst) * 2 + ch) * n + s0 + col] : 0.f;
+		}
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const int row = 2 * (it0 + j) + half, inst = row >> 1, ch = row & 1;
+			tile[(ch * FX_CHUNK + col) * FX_LD + inst] = v[j];
+		}
 	}
 }
 __device__ __forceinline__ void io_store_chunk(const float* tile, float* io, int k0, int K, int n, int s0, int cl, int lane) {
 	const int col = lane & 31, half = lane >> 5;
+#pragma unroll 16
 	for (int it = 0; it < 64; it++) {
 		const int row = 2 * it + half, inst = row >> 1, ch = row & 1;
 		if (col < cl && k0 + inst < K) io[((size_t)(k0 + inst) * 2 + ch) * n + s0 + col] = tile[(ch * FX_CHUNK + col) * FX_LD + inst];
@@ -90,6 +98,18 @@ struct PingPongArgs {
 	float c1_min, c1_max;
 };
 
+// The kernel works in sub-chunks of PP_SUB samples:
+//   1. CONTROL PRE-PASS.  Everything that decides WHERE the delay lines are read — the two Control::smooth()
+//      one-poles, the scratch detector, the LFO, controls[1].set() — depends on control state only, never on audio.
+//      It is run PP_SUB samples ahead and yields the read taps (position, fraction) of both lines per sample.
+//   2. PREFETCH.  If every tap of the sub-chunk lies more than PP_SUB + 2 samples behind the write cursor (true for
+//      any delay longer than ~0.2 ms) none of this sub-chunk's writes can alias them, so all 6 x PP_SUB ring reads are
+//      issued back to back — one exposed HBM latency per sub-chunk instead of three to four per sample.
+//      Otherwise (very short delays) the sub-chunk falls back to in-order loads.
+//   3. AUDIO PASS.  Per sample: interpolate, cross-feed, write both rings (stores are fire-and-forget), DC filters.
+// Arithmetic and its order are identical in both paths (bit-exact vs the reference, tests/test_gpu_fx.py).
+enum { PP_SUB = 8 };
+
 __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 	__shared__ float tile[2 * FX_CHUNK * FX_LD];
 	const int lane = threadIdx.x, k0 = blockIdx.x * FX_WG, k = k0 + lane;
@@ -97,59 +117,99 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 	float st[PP_WORDS];
 #pragma unroll
 	for (int w = 0; w < PP_WORDS; w++) st[w] = a.state[(size_t)w * a.kpad + k];
-	float c0 = st[0], c1 = st[1], c2 = st[2], c3 = st[3], c4 = st[4], c5 = st[5];
+	const float c0 = st[0], c2 = st[2], c3 = st[3], c4 = st[4], c5 = st[5];
+	float c1 = st[1];
 	float sm1 = st[PP_SM1], sm5 = st[PP_SM5], mdelay = st[PP_DELAY];
 	BOsc lfo; lfo.position = st[PP_LFO_POS]; lfo.increment = st[PP_LFO_INC]; lfo.offset = 0.f;
 	Biquad dcl = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, st[PP_Z + 0], st[PP_Z + 1] };
 	Biquad dcr = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, st[PP_Z + 2], st[PP_Z + 3] };
 	Ring left = { a.rings + k, a.kpad, SIZE }, right = { a.rings + (size_t)SIZE * a.kpad + k, a.kpad, SIZE };
 	int position = a.position;
+	// loop invariants of process() PingPong.k:44-60 (controls 0, 2, 3, 4, 5 only change between blocks)
+	const float rate = (c3 * c3) * 100.f;                                       // sqr(controls[3]) * 100.f
+	const float lfo_inc = rate * 2.f * KLG_PI_F / a.fs.f;                       // Oscillator::set(rate)  klang.h:2862-2865
+	const float gain = c0, dry = c4;
+	const float vibrato = (c2 * c2) * rate * 1.41421354f;                       // sqr(controls[2]) * rate * root2
+	const bool any_vibrato = __ballot(vibrato != 0.f) != 0ull;
 
 	for (int s0 = 0; s0 < a.n; s0 += FX_CHUNK) {
 		const int cl = (a.n - s0 < FX_CHUNK) ? (a.n - s0) : FX_CHUNK;
 		io_load_chunk(tile, a.io, k0, a.K, a.n, s0, cl, lane);
 		wave_sync();
-		for (int s = 0; s < cl; s++) {
-			const float in_l = tile[(0 * FX_CHUNK + s) * FX_LD + lane], in_r = tile[(1 * FX_CHUNK + s) * FX_LD + lane];
-			// process() PingPong.k:44-71
-			const float rate = (c3 * c3) * 100.f;
-			sm5 = sm5 * 0.999f + (1.f - 0.999f) * c5;                               // controls[5].smooth()  klang.h:1715
-			const float new_delay = sm5;
-			if ((double)fabsf(mdelay - new_delay) > 0.001) {
-				mdelay = new_delay;
-				c1 = (new_delay < a.c1_min) ? a.c1_min : (a.c1_max < new_delay) ? a.c1_max : new_delay;   // controls[1].set()
-				lfo.position = KLG_PI_F;                                            // lfo.set(rate, pi)
-				lfo.increment = rate * 2.f * KLG_PI_F / a.fs.f;
+		for (int u0 = 0; u0 < cl; u0 += PP_SUB) {
+			const int ul = (cl - u0 < PP_SUB) ? (cl - u0) : PP_SUB;
+			// ---- 1. control pre-pass ----
+			Tap tl[PP_SUB], tr[PP_SUB];
+			bool far = true;
+#pragma unroll
+			for (int u = 0; u < PP_SUB; u++) {
+				if (u < ul) {
+					sm5 = sm5 * 0.999f + (1.f - 0.999f) * c5;                       // controls[5].smooth()  klang.h:1715
+					const float new_delay = sm5;
+					if ((double)fabsf(mdelay - new_delay) > 0.001) {
+						mdelay = new_delay;
+						c1 = (new_delay < a.c1_min) ? a.c1_min : (a.c1_max < new_delay) ? a.c1_max : new_delay;   // controls[1].set()
+						lfo.position = KLG_PI_F;                                    // lfo.set(rate, pi)
+					}
+					else mdelay = c5;
+					lfo.increment = lfo_inc;
+					sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                       // controls[1].smooth()
+					const float delay = sm1;
+					float lfo_out = 0.f;
+					if (any_vibrato) lfo_out = basic_sine(lfo);                     // fp64 sin only when some instance uses it;
+					else phase_advance(lfo.position, lfo.increment);                // x * 0 * 5e-5 == +-0 and c1 + (+-0) == c1 exactly
+					const float nc1 = c1 + lfo_out * vibrato * 0.00005f;
+					c1 = (nc1 < a.c1_min) ? a.c1_min : (a.c1_max < nc1) ? a.c1_max : nc1;
+					const int pos = (position + u >= SIZE) ? position + u - SIZE : position + u;
+					const float dl = delay * a.fs.f, dr = 0.5f * delay * a.fs.f;
+					tl[u] = delay_set(pos, SIZE, dl);                               // left.set(delay * fs)
+					tr[u] = delay_set(pos, SIZE, dr);                               // right.set(0.5f * delay * fs)
+					far = far && dr >= (float)(PP_SUB + 3) && dl <= (float)(SIZE - PP_SUB - 4);
+				}
 			}
-			else {
-				mdelay = c5;
-				lfo.increment = rate * 2.f * KLG_PI_F / a.fs.f;                       // lfo.set(rate)
+			// ---- 2. prefetch ----
+			float pl[PP_SUB][3], pr[PP_SUB][3];
+			const bool prefetch = __ballot(k < a.K && !far) == 0ull;           // padding lanes (zero state, zero delay) do not veto
+			if (prefetch) {
+#pragma unroll
+				for (int u = 0; u < PP_SUB; u++) {
+					if (u < ul) {
+						const int i0 = tl[u].position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
+						const int j0 = tr[u].position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
+						pl[u][0] = left.rd(i0); pl[u][1] = left.rd(i1); pl[u][2] = left.rd(i2);
+						pr[u][0] = right.rd(j0); pr[u][1] = right.rd(j1); pr[u][2] = right.rd(j2);
+					}
+				}
 			}
-			const float gain = c0;
-			sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                               // controls[1].smooth()
-			const float delay = sm1;
-			const float vibrato = (c2 * c2) * rate * 1.41421354f;                   // sqr(controls[2]) * rate * root2
-			const float dry = c4;
-			const float nc1 = c1 + basic_sine(lfo) * vibrato * 0.00005f;
-			c1 = (nc1 < a.c1_min) ? a.c1_min : (a.c1_max < nc1) ? a.c1_max : nc1;
-
-			Tap tl = delay_set(position, SIZE, delay * a.fs.f);                     // left.set(delay * fs)
-			Tap tr = delay_set(position, SIZE, 0.5f * delay * a.fs.f);              // right.set(0.5f * delay * fs)
-
-			const float r1 = delay_process(right, tr);
-			left.wr(position, in_l + r1 * gain);                                    // (in.l + right * gain) >> left
-			const float l1 = delay_process(left, tl);
-			float out_l = dry * in_l + l1 * (1.f - dry);
-			const float l2 = delay_process(left, tl);
-			right.wr(position, in_r + l2 * gain);                                   // (in.r + left * gain) >> right
-			const float r2 = delay_process(right, tr);
-			float out_r = dry * in_r + r2 * (1.f - dry);
-			position = (position + 1 == SIZE) ? 0 : position + 1;
-
-			out_l = biquad_process(dcl, out_l);
-			out_r = biquad_process(dcr, out_r);
-			tile[(0 * FX_CHUNK + s) * FX_LD + lane] = out_l;
-			tile[(1 * FX_CHUNK + s) * FX_LD + lane] = out_r;
+			// ---- 3. audio pass ----
+#pragma unroll
+			for (int u = 0; u < PP_SUB; u++) {
+				if (u < ul) {
+					const int s = u0 + u;
+					const float in_l = tile[(0 * FX_CHUNK + s) * FX_LD + lane], in_r = tile[(1 * FX_CHUNK + s) * FX_LD + lane];
+					float r1, l1, l2, r2;
+					// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
+					if (prefetch) r1 = pr[u][0] + tr[u].fraction * (pr[u][1] - pr[u][0]);
+					else r1 = delay_process(right, tr[u]);
+					left.wr(position, in_l + r1 * gain);
+					if (prefetch) {
+						l1 = pl[u][0] + tl[u].fraction * (pl[u][1] - pl[u][0]);
+						l2 = pl[u][1] + tl[u].fraction * (pl[u][2] - pl[u][1]);
+					}
+					else { l1 = delay_process(left, tl[u]); l2 = delay_process(left, tl[u]); }
+					float out_l = dry * in_l + l1 * (1.f - dry);
+					// dry * in.r + (1.f - dry) * ((in.r + left * gain) >> right) >> out.r;   PingPong.k:67
+					right.wr(position, in_r + l2 * gain);
+					if (prefetch) r2 = pr[u][1] + tr[u].fraction * (pr[u][2] - pr[u][1]);
+					else r2 = delay_process(right, tr[u]);
+					float out_r = dry * in_r + r2 * (1.f - dry);
+					position = (position + 1 == SIZE) ? 0 : position + 1;
+					out_l = biquad_process(dcl, out_l);                             // out.l >> dcfilter[0] >> out.l
+					out_r = biquad_process(dcr, out_r);
+					tile[(0 * FX_CHUNK + s) * FX_LD + lane] = out_l;
+					tile[(1 * FX_CHUNK + s) * FX_LD + lane] = out_r;
+				}
+			}
 		}
 		wave_sync();
 		io_store_chunk(tile, a.io, k0, a.K, a.n, s0, cl, lane);
