@@ -132,7 +132,10 @@ __global__ __launch_bounds__(1024) void klg_reduce(const float* __restrict__ par
 	const int sl = threadIdx.x & 31, p = threadIdx.x >> 5;
 	const int s = blockIdx.x * 32 + sl;
 	float sum = 0.f;
-	if (s < n) for (int r = p; r < rows; r += 32) sum += partials[(size_t)r * n + s];
+	if (s < n) {
+#pragma unroll 8
+		for (int r = p; r < rows; r += 32) sum += partials[(size_t)r * n + s];       // 8 independent loads in flight
+	}
 	part[p][sl] = sum;
 	__syncthreads();
 	if (p == 0 && s < n) {
