@@ -134,6 +134,15 @@ size_t klg_fx_state_bytes(const klg_fx* f);
 int klg_fx_timing_begin(klg_fx* f);
 int klg_fx_timing_end(klg_fx* f, int* launches, float* total_ms);
 
+/* ------------------------------------------------------------------------------------------------
+ * Diagnostics (no reference equivalent): run ONE device primitive (oscillator, filter, envelope, delay tap, ...)
+ * for n samples in a single GPU lane, so each row of the hot-path table can be checked against the reference's
+ * known-answer vectors on its own.  Primitive ids and parameter packs: klang_amd/csrc/klg_selftest.hpp.
+ * klg_selftest_host exposes the host halves (set(): increments, coefficient design, breakpoint state).
+ * ------------------------------------------------------------------------------------------------ */
+int klg_selftest(int primitive, const float* params, int n_params, const float* in, int n_in, float* out, int n_out, int n);
+int klg_selftest_host(int kind, const float* args, int n_args, float sample_rate, float* out, int n_out);
+
 #ifdef __cplusplus
 }
 #endif

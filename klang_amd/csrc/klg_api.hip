@@ -544,3 +544,4 @@ extern "C" int klg_timing_end(klg_synth* s, int* launches, float* total_ms) {
 // effect banks: see klg_fx_api.hpp
 // ------------------------------------------------------------------------------------------------
 #include "klg_fx_api.hpp"
+#include "klg_selftest.hpp"

@@ -82,6 +82,13 @@ __device__ __forceinline__ float basic_triangle(BOsc& o) { const float y = fabsf
 __device__ __forceinline__ float basic_square(BOsc& o) { const float y = o.position > KLG_PI_F ? 1.f : -1.f; phase_advance(o.position, o.increment); return y; }
 __device__ __forceinline__ float basic_pulse(BOsc& o, float duty) { const float y = o.position > (duty * KLG_PI_F) ? 1.f : -1.f; phase_advance(o.position, o.increment); return y; }
 
+// ---- Noise klang.h:4947-4951 (Basic), 5357-5366 (Fast) ----
+// The reference draws from libc rand(), one global sequential stream shared by every voice (F5).  The device
+// functions are the pure arithmetic applied to a rand() result; the stream itself is produced on the host
+// (glibc) and injected, which keeps the reference's exact sequence.
+__device__ __forceinline__ float basic_noise(int r) { return (float)r * 2.f / 2147483648.0f - 1.f; }   // RAND_MAX = 2^31 - 1 -> (float) 2^31
+__device__ __forceinline__ float fast_noise(int r) { return u2f((((uint32_t)r & 0x7FFFu) << 1) | 0x43800000u) - 257.f; }
+
 // ---- Fast::OSM klang.h:5175-5317 ----
 // persistent: inc, offset, duty, delta, state(2 bits); the seven coefficients are re-derived per block with the
 // reference's own fp32 operations (OSM::init 5206-5215) so they cost registers, not HBM bytes.

@@ -52,6 +52,46 @@ __device__ __forceinline__ float delay_process(const Ring& r, Tap& t) {         
 	return out;
 }
 
+// Delay::tap(int) 3405-3410, tap(float) 3412-3427, lagrange(float) 3429-3458 — `position` is the write cursor
+__device__ __forceinline__ float delay_tap_int(const Ring& r, int position, int delay) {
+	int read = (position - 1) - delay;
+	if (read < 0) read += r.size;
+	return r.rd(read);
+}
+__device__ __forceinline__ float delay_tap_float(const Ring& r, int position, float delay) {
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += r.size;
+	const int i = (int)read;
+	const float fraction = read - i;
+	const int j = (i + 1) % r.size;
+	const float a = r.rd(i), b = r.rd(j);
+	return a + fraction * (b - a);
+}
+__device__ __forceinline__ float delay_lagrange(const Ring& r, int position, float delay) {
+	const int SIZE = r.size;
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += SIZE;
+	const int i = (int)read;
+	const float x = read - i;
+	const float y0 = r.rd((i - 1 + SIZE) % SIZE), y1 = r.rd(i), y2 = r.rd((i + 1) % SIZE), y3 = r.rd((i + 2) % SIZE);
+	const float c0 = (-x * (x - 1) * (x - 2)) / 6.0f;
+	const float c1 = ((x + 1) * (x - 1) * (x - 2)) / 2.0f;
+	const float c2 = (-x * (x + 1) * (x - 2)) / 2.0f;
+	const float c3 = (x * (x + 1) * (x - 1)) / 6.0f;
+	return c0 * y0 + c1 * y1 + c2 * y2 + c3 * y3;
+}
+// Stereo::Delay::tap(float) klang.h:4668-4681: both channels read at the LEFT line's cursor, a*(1-frac) + b*frac form
+__device__ __forceinline__ void stereo_delay_tap(const Ring& l, const Ring& r, int position, float delay, float& outl, float& outr) {
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += l.size;
+	const float f = (float)floor((double)read);
+	const float frac = read - f;
+	const int i = (int)read;
+	const int j = (i == l.size - 1) ? 0 : (i + 1);
+	outl = l.rd(i) * (1.f - frac) + l.rd(j) * frac;
+	outr = r.rd(i) * (1.f - frac) + r.rd(j) * frac;
+}
+
 // LDS staging of the [K][2][n] io block: tile[ch][sample][FX_LD]
 __device__ __forceinline__ void io_load_chunk(float* tile, const float* io, int k0, int K, int n, int s0, int cl, int lane) {
 	const int col = lane & 31, half = lane >> 5;
@@ -330,14 +370,8 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
 			epos = (epos + 1 == RV_ESIZE) ? 0 : epos + 1;
 			float r1l = 0.f, r1r = 0.f;
 			for (int d = 0; d < ecount; d++) {                                          // Stereo::Delay::tap(float) klang.h:4668-4681
-				float read = (float)(epos - 1) - RVW(RV_ETIMES + d);
-				if (read < 0.f) read += RV_ESIZE;
-				const float f = (float)floor((double)read);
-				const float frac = read - f;
-				const int i = (int)read;
-				const int j = (i == RV_ESIZE - 1) ? 0 : (i + 1);
-				const float tl = el.rd(i) * (1.f - frac) + el.rd(j) * frac;
-				const float tr = er.rd(i) * (1.f - frac) + er.rd(j) * frac;
+				float tl, tr;
+				stereo_delay_tap(el, er, epos, RVW(RV_ETIMES + d), tl, tr);
 				r1l += tl * RVW(RV_EGL + d);
 				r1r += tr * RVW(RV_EGR + d);
 			}
