@@ -5,11 +5,13 @@
 //
 // Data layout in HBM
 //   state   [word][Kpad]            per-instance scalars (controls, smoothing, filter state, tap tables), SoA
-//   rings   [line][pos][Kpad]       delay lines, POSITION-major / instance-minor: all instances advance their
-//                                   write cursor in lock-step (it only counts samples), so the 64 lanes of a wave
-//                                   write one contiguous 256-byte row per line per sample, and read taps coalesce
-//                                   whenever instances share a delay time (and degrade to a gather, never to a
-//                                   768-KB-strided walk, when they do not).
+//   rings   [wave][line][pos][64]   delay lines, tiled per wave of 64 instances and, inside a tile, POSITION-major /
+//                                   instance-minor: all instances advance their write cursor in lock-step (it only
+//                                   counts samples), so the 64 lanes of a wave write one contiguous 256-byte row per
+//                                   line per sample, rows of consecutive positions are adjacent (a wave streams
+//                                   through its own contiguous tile: DRAM-page and TLB friendly at 100+ GB of rings),
+//                                   and read taps coalesce whenever instances share a delay time (and degrade to a
+//                                   gather inside the tile, never to a 768-KB-strided walk, when they do not).
 //   io      [K][2][n]               caller layout (per-instance channel buffers, as the reference host owns them);
 //                                   staged through a padded LDS tile in 32-sample chunks so global accesses are
 //                                   128-byte row segments and the per-sample loop reads/writes LDS only.
@@ -130,7 +132,7 @@ enum { PP_C0 = 0, PP_SM1 = 6, PP_SM5 = 7, PP_DELAY = 8, PP_LFO_POS = 9, PP_LFO_I
 
 struct PingPongArgs {
 	float* state; size_t kpad; int K;
-	float* rings;               // [2][192000][kpad]
+	float* rings;               // [kpad/64][2][192000][64]
 	int position;               // write cursor of both lines at block start (samples processed % 192000)
 	float* io; int n;
 	SampleRate fs;
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 	BOsc lfo; lfo.position = st[PP_LFO_POS]; lfo.increment = st[PP_LFO_INC]; lfo.offset = 0.f;
 	Biquad dcl = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, st[PP_Z + 0], st[PP_Z + 1] };
 	Biquad dcr = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, st[PP_Z + 2], st[PP_Z + 3] };
-	Ring left = { a.rings + k, a.kpad, SIZE }, right = { a.rings + (size_t)SIZE * a.kpad + k, a.kpad, SIZE };
+	float* tile0 = a.rings + (size_t)blockIdx.x * 2 * SIZE * FX_WG + lane;               // this wave's ring tile
+	Ring left = { tile0, FX_WG, SIZE }, right = { tile0 + (size_t)SIZE * FX_WG, FX_WG, SIZE };
 	int position = a.position;
 	// loop invariants of process() PingPong.k:44-60 (controls 0, 2, 3, 4, 5 only change between blocks)
 	const float rate = (c3 * c3) * 100.f;                                       // sqr(controls[3]) * 100.f
@@ -285,8 +288,8 @@ enum { RV_ESIZE = 21600, RV_FSIZE = 192000 };
 
 struct ReverbArgs {
 	float* state; size_t kpad; int K;
-	float* early_rings;         // [2][21600][kpad]
-	float* fd_rings;            // [16][192000][kpad]
+	float* early_rings;         // [kpad/64][2][21600][64]
+	float* fd_rings;            // [kpad/64][16][192000][64]
 	int epos;                   // early write cursor at block start
 	int fpos;                   // FilteredDelay write cursor at block start (advances 2 per sample)
 	float* io; int n;
@@ -308,7 +311,7 @@ __device__ __forceinline__ void fd_load(FDelay& d, const ReverbArgs& a, int idx,
 	d.gain = s[(size_t)FD_GAIN * a.kpad];
 	d.f.b0 = s[(size_t)(FD_COEF + 0) * a.kpad]; d.f.b1 = s[(size_t)(FD_COEF + 1) * a.kpad]; d.f.b2 = s[(size_t)(FD_COEF + 2) * a.kpad];
 	d.f.a1 = s[(size_t)(FD_COEF + 3) * a.kpad]; d.f.a2 = s[(size_t)(FD_COEF + 4) * a.kpad];
-	d.ring.base = a.fd_rings + (size_t)idx * RV_FSIZE * a.kpad + k; d.ring.stride = a.kpad; d.ring.size = RV_FSIZE;
+	d.ring.base = a.fd_rings + ((size_t)blockIdx.x * 16 + idx) * RV_FSIZE * FX_WG + threadIdx.x; d.ring.stride = FX_WG; d.ring.size = RV_FSIZE;
 }
 __device__ __forceinline__ void fd_store(const FDelay& d, const ReverbArgs& a, int idx, int k) {
 	float* s = a.state + (size_t)(RV_FD + idx * FD_WORDS) * a.kpad + k;
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
 		ehpf[c] = { RVW(RV_EHPF + 0), RVW(RV_EHPF + 1), RVW(RV_EHPF + 2), RVW(RV_EHPF + 3), RVW(RV_EHPF + 4), RVW(RV_EZ + 4 + 2 * c), RVW(RV_EZ + 4 + 2 * c + 1) };
 	}
 	const int ecount = __float_as_int(RVW(RV_ECOUNT));
-	Ring el = { a.early_rings + k, KP, RV_ESIZE }, er = { a.early_rings + (size_t)RV_ESIZE * KP + k, KP, RV_ESIZE };
+	float* etile = a.early_rings + (size_t)blockIdx.x * 2 * RV_ESIZE * FX_WG + lane;
+	Ring el = { etile, FX_WG, RV_ESIZE }, er = { etile + (size_t)RV_ESIZE * FX_WG, FX_WG, RV_ESIZE };
 	FDelay mid0[4], mid1[4], late0[4], late1[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) { fd_load(mid0[j], a, 0 + j, k); fd_load(mid1[j], a, 4 + j, k); fd_load(late0[j], a, 8 + j, k); fd_load(late1[j], a, 12 + j, k); }
