@@ -1,9 +1,9 @@
-// klang_amd/csrc/klg_host_dsl.hpp — HOST side of the drop-in: the parts of klang's DSL that stay on the CPU
+// include/klang/host_dsl.hpp — HOST side of the drop-in: the parts of klang's DSL that stay on the CPU
 // (north_star: "host-side C++ keeps the DSL, voice allocation and event dispatch").
 //
 // These are the set()/initialise()/release() halves of the reference's primitives — the code a patch's
 // on()/off() runs when a note event arrives — producing the packed lane records the GPU kernels consume.
-// The per-sample process() halves exist ONLY as device code (klg_device.hpp); there is no CPU rendering
+// The per-sample process() halves exist ONLY as device code (klang_amd/csrc/klg_device.hpp); there is no CPU rendering
 // path in this library.  Citations are file:line into the reference's klang.h (v0.7.8).
 #pragma once
 #include <cmath>
@@ -11,9 +11,12 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "klg_patches.hpp"
+#include "../klang_mi355_records.h"
 
+// Build every translation unit that includes this with -ffp-contract=off (bit parity with the reference).
+#if defined(__clang__)
 #pragma clang fp contract(off)
+#endif
 
 namespace klg { namespace host {
 

@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/klang_mi355.h"
-#include "klg_host_dsl.hpp"
+#include "../../include/klang/host_dsl.hpp"
 #include "klg_kernels.hpp"
 #include "klg_fx.hpp"
 #include "klg_render_x2.hpp"
@@ -36,6 +36,16 @@ static int fail(int code, const char* fmt, ...) {
 extern "C" const char* klg_last_error(void) { return g_err.c_str(); }
 extern "C" int klg_version(void) { return 100; }
 
+// HIP/HSA runtime initialisation draws from libc's random() state (observed: the first hipMalloc after srand(seed)
+// shifts the rand() sequence).  The reference's patches use that same global stream on the host (klang::random /
+// SuperSaw.k:17), so every entry point that may initialise the runtime or allocate runs under this guard: it parks
+// the caller's generator state and restores it on exit (rand() and random() share state in glibc).
+struct RandGuard {
+	char buf[128]; char* prev;
+	RandGuard() { prev = initstate(1u, buf, sizeof buf); }
+	~RandGuard() { if (prev) setstate(prev); }
+};
+
 int klg_ensure_device() {
 	if (g_device >= 0) { if (hipSetDevice(g_device) != hipSuccess) return fail(KLG_ERR_NO_DEVICE, "hipSetDevice(%d) failed", g_device); return 0; }
 	int count = 0;
@@ -47,6 +57,7 @@ int klg_ensure_device() {
 }
 
 extern "C" int klg_init(const int* device_ids, int n_devices) {
+	RandGuard rg;
 	if (!device_ids || n_devices != 1) return fail(KLG_ERR_INVALID, "klg_init: one device per process (got %d)", n_devices);
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(KLG_ERR_NO_DEVICE, "no HIP device visible: libklang_mi355 has no CPU fallback");
@@ -134,6 +145,7 @@ extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_s
 	if (synths <= 0 || notes_per_synth <= 0 || notes_per_synth > 128) { fail(KLG_ERR_INVALID, "klg_synth_create: synths=%d notes_per_synth=%d (1..128, Array<NOTE*,128>)", synths, notes_per_synth); return nullptr; }
 	if (max_block <= 0 || max_block > MAX_BLOCK) { fail(KLG_ERR_INVALID, "klg_synth_create: max_block %d not in 1..%d", max_block, (int)MAX_BLOCK); return nullptr; }
 	if (!(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_synth_create: bad sample rate"); return nullptr; }
+	RandGuard rg;
 	if (klg_ensure_device()) return nullptr;
 	klg_synth* s = new klg_synth();
 	s->patch = patch_id; s->S = synths; s->P = notes_per_synth; s->V = synths * notes_per_synth; s->W = pi->words;
@@ -354,13 +366,13 @@ static void patch_on(klg_synth* s, int synth, int voice) {
 		const float* envs[4] = { e1, e2, NOPS == 4 ? e3 : nullptr, nullptr };
 		uint32_t rec_words[64] = { 0 };
 		uint32_t flags = ST_SUSTAIN, meta = 0;
-		PatchFM<4>::OpRec* ops = (PatchFM<4>::OpRec*)(rec_words + 2);
+		OpRec* ops = (OpRec*)(rec_words + 2);
 		for (int k = 0; k < NOPS; k++) {
 			hv.fs[k].set(k == NOPS - 1 ? fc : fd, 0.f, fs);
 			host::EnvH env;                                      // Operator::env default = Envelope() : one point (0,1)
 			if (envs[k]) env.set_points(2, envs[k], fs);
 			else { const float one[2] = { 0.f, 1.f }; env.set_points(1, one, fs); }
-			PatchFM<4>::OpRec& q = ops[k];
+			OpRec& q = ops[k];
 			q.inc = hv.fs[k].inc; q.pos = hv.fs[k].pos;
 			q.r_out = env.r_out; q.r_target = env.r_target; q.r_rate = env.r_rate; q.time = env.time;
 			q.px[0] = env.px[0]; q.px[1] = env.px[1]; q.py[0] = env.py[0]; q.py[1] = env.py[1];

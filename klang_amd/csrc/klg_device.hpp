@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/klang_mi355_records.h"
 
 #pragma clang fp contract(off)
 
@@ -198,7 +199,6 @@ __device__ __forceinline__ float onepole_process(OnePole& q, float in) { q.out =
 // ---- Envelope klang.h:3722-4102 ----
 // Lane state: the Linear ramp (out, target, rate, active 3731-3807), stage, point, time.  Breakpoints live in
 // a small register array; they are only touched on the (rare) segment change.
-enum { ENV_SUSTAIN = 0, ENV_RELEASE = 1, ENV_OFF = 2 };
 struct Env { float r_out, r_target, r_rate, time; int stage, point; bool active; };
 
 __device__ __forceinline__ void env_set_value(Env& e, float v) { e.r_out = v; e.r_target = v; e.active = false; }      // 3762-3766

@@ -63,6 +63,7 @@ static BiquadCoef design_biquad(bool hpf, float f, float Q, const host::Fs& fs) 
 extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate, int max_block) {
 	if (patch_id != KLG_PATCH_PINGPONG && patch_id != KLG_PATCH_REVERB) { fail(KLG_ERR_INVALID, "klg_fx_create: patch %d is not an effect patch", patch_id); return nullptr; }
 	if (instances <= 0 || max_block <= 0 || max_block > MAX_BLOCK || !(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_fx_create: bad arguments"); return nullptr; }
+	RandGuard rg;
 	if (klg_ensure_device()) return nullptr;
 	klg_fx* f = new klg_fx();
 	f->patch = patch_id; f->K = instances; f->max_block = max_block;

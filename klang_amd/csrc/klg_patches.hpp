@@ -10,17 +10,13 @@
 // integers (envelope stage/point/active, OSM state) packed so they cost one word instead of a dozen.
 #pragma once
 #include "klg_device.hpp"
+#include "../../include/klang_mi355_records.h"
 
 #pragma clang fp contract(off)
 
 namespace klg {
 
-enum { ST_ONSET = 0, ST_SUSTAIN = 1, ST_RELEASE = 2, ST_OFF = 3 };
-enum { KLG_MAX_CTL = 8 };
-
-struct OsmRec { int32_t inc; uint32_t offset, duty; float delta; };
-struct AdsrRec { float r_out, r_target, r_rate, time, A, AD, S, R; };     // points (0,0) (A,1) (A+D,S); R for release()
-struct BiquadRec { float b0, b1, b2, a1, a2, z0, z1; };
+// record layouts: include/klang_mi355_records.h (shared with the host side and the DSL header)
 
 // Per-block view every patch body gets.
 struct BlockCtx {
@@ -67,7 +63,7 @@ constexpr uint64_t words(size_t byte_off, int n) { return ((1ull << n) - 1ull) <
 // config 1: one Generators::Fast::Sine per note  (oracle/ref/ref_sine.cpp: `osc >> out`)
 // ---------------------------------------------------------------------------------------------
 struct PatchSine {
-	struct Rec { uint32_t flags; int32_t inc; uint32_t pos; };
+	using Rec = rec::Sine;
 	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, pos, 1);
 	struct Live { FSine osc; int stage; };
 	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) { L.osc.inc = r.inc; L.osc.pos = r.pos; L.stage = (int)(r.flags & 3u); }
@@ -77,7 +73,7 @@ struct PatchSine {
 };
 
 struct PatchBSine {
-	struct Rec { uint32_t flags; float increment, position, offset; };
+	using Rec = rec::BSine;
 	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, position, 1);
 	struct Live { BOsc osc; int stage; };
 	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) { L.osc.increment = r.increment; L.osc.position = r.position; L.osc.offset = r.offset; L.stage = (int)(r.flags & 3u); }
@@ -91,7 +87,7 @@ struct PatchBSine {
 // flags: [0:2) note stage | [2:8) adsr | [8:10) osm state
 // ---------------------------------------------------------------------------------------------
 struct PatchSub2a {
-	struct Rec { uint32_t flags; OsmRec osc; BiquadRec lpf; AdsrRec adsr; };                 // 20 words = 80 B read, 8 words = 32 B written
+	using Rec = rec::Sub2a;                                                                  // 20 words = 80 B read, 8 words = 32 B written
 	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc.offset, 1) | KLG_W(Rec, lpf.z0, 2) | KLG_W(Rec, adsr.r_out, 4);
 	struct Live { Osm osc; Biquad lpf; Adsr adsr; int stage; };
 	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {
@@ -124,9 +120,7 @@ struct PatchSub2a {
 // flags: [0:2) note | [2:8) adsr | [8:14) env | [14:16) osm state
 // ---------------------------------------------------------------------------------------------
 struct PatchSub2b {
-	struct EnvRec { float r_out, r_target, r_rate, time, px[3], py[3]; };
-	struct SweepRec { float f, Q; BiquadRec c; };
-	struct Rec { uint32_t flags; OsmRec osc; AdsrRec adsr; EnvRec env; SweepRec filter; };   // 1+4+8+10+9 = 32 words
+	using Rec = rec::Sub2b;                                                                  // 1+4+8+10+9 = 32 words
 	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc.offset, 1) | KLG_W(Rec, adsr.r_out, 4) | KLG_W(Rec, env.r_out, 4) | KLG_W(Rec, filter, 9);
 	struct Live { Osm osc; Adsr adsr; Env env; Pts3 p; Biquad lpf; BiquadSweep sw; int stage; };
 	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {
@@ -170,7 +164,7 @@ struct PatchSub2b {
 // flags: [0:2) note | [2:8) adsr | [8:22) 7 x osm state
 // ---------------------------------------------------------------------------------------------
 struct PatchSuperSaw {
-	struct Rec { uint32_t flags; OsmRec osc[7]; AdsrRec adsr; };                              // 37 words = 148 B read, 12 words written
+	using Rec = rec::SuperSaw;                                                               // 37 words = 148 B read, 12 words written
 	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc[0].offset, 1) | KLG_W(Rec, osc[1].offset, 1) | KLG_W(Rec, osc[2].offset, 1)
 		| KLG_W(Rec, osc[3].offset, 1) | KLG_W(Rec, osc[4].offset, 1) | KLG_W(Rec, osc[5].offset, 1) | KLG_W(Rec, osc[6].offset, 1) | KLG_W(Rec, adsr.r_out, 4);
 	struct Live { Osm osc[7]; Adsr adsr; int stage; };
@@ -209,8 +203,8 @@ struct PatchSuperSaw {
 // ---------------------------------------------------------------------------------------------
 template<int NOPS>
 struct PatchFM {
-	struct OpRec { int32_t inc; uint32_t pos; float r_out, r_target, r_rate, time, px[2], py[2]; };   // 10 words
-	struct Rec { uint32_t flags, meta; OpRec op[NOPS]; AdsrRec adsr; };
+	using OpRec = klg::OpRec;                                                                // 10 words
+	using Rec = rec::FM<NOPS>;
 	static constexpr uint64_t op_mask(int k) { return words(8 + 40 * (size_t)k + 4, 5); }   // pos, r_out, r_target, r_rate, time of operator k
 	static constexpr uint64_t kStoreMask = 1ull | op_mask(0) | op_mask(1) | op_mask(2) | (NOPS > 3 ? op_mask(3) : 0ull) | words(8 + 40 * (size_t)NOPS, 4);
 	struct Op { FSine osc; Env env; Pts2 p; int np; float amp; };

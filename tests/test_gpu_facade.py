@@ -1,0 +1,53 @@
+"""The source-compatible DSL façade (include/klang/klang.h): a .k patch's own on()/off() run on the host, blocks are
+rendered on the GPU through the C-ABI.  tests/cpp/facade_scenario.cpp is compiled (a) with our tests/patches/sub2a.k and
+(b) — in the build container, where the reference exists — with the reference's SHIPPED subtractive.k and SuperSaw.k,
+UNCHANGED.  Outputs are compared with the golden mixes / note stages produced by the genuine reference header."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def run_facade(binary, scenario, tmp_path):
+    out = tmp_path / "facade.bin"
+    subprocess.run([binary, os.path.join(GOLDEN, scenario + ".scn"), str(out)], check=True)
+    d = open(out, "rb").read()
+    magic, N, B, P = (int(x) for x in np.frombuffer(d, np.int32, 4))
+    assert magic == 0x4D474C4B
+    mix = np.frombuffer(d, np.float32, B * 2 * N, 16).reshape(B, 2, N)
+    stages = np.frombuffer(d, np.uint8, B * P, 16 + B * 2 * N * 4).reshape(B, P)
+    return mix, stages
+
+
+def check(mix, stages, scenario):
+    ref = np.load(os.path.join(GOLDEN, scenario + ".npz"))
+    assert np.array_equal(stages, ref["stages"]), "note stages (voice allocation / lifecycle) differ from the reference"
+    peak = float(np.max(np.abs(ref["per_voice"])))
+    V = ref["stages"].shape[1]
+    if "mix" in ref:
+        err = float(np.max(np.abs(mix.astype(np.float64) - ref["mix"])))
+    else:
+        err = float(np.max(np.abs(mix[ref["dump"]].astype(np.float64) - ref["mix_dump"])))
+    assert err <= 1e-5 * peak * np.sqrt(V) * 4, err
+    np.testing.assert_allclose(np.abs(mix.astype(np.float64)).sum(axis=(1, 2)), ref["mix_abs_sum"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("binary,scenario", [("facade_sub2a_n4", "sub2a_steal"), ("facade_sub2a_n4", "sub2a_n64"), ("facade_sub2a_n16", "sub2a_long")])
+def test_own_dsl_patch_through_facade(binary, scenario, tmp_path):
+    path = os.path.join(ROOT, "tests", "cpp", "_bin", binary)
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    check(*run_facade(path, scenario, tmp_path), scenario)
+
+
+@pytest.mark.parametrize("binary,scenario", [("facade_sub2b", "sub2b_poly"), ("facade_supersaw", "supersaw_poly"), ("facade_supersaw", "supersaw_ctl")])
+def test_shipped_k_files_unchanged_through_facade(binary, scenario, tmp_path):
+    path = os.path.join(ROOT, "oracle", "_ref", binary)
+    if not os.path.exists(path):
+        pytest.skip("built only where the reference's .k files exist (build container); the binary travels in oracle/_ref/")
+    check(*run_facade(path, scenario, tmp_path), scenario)
