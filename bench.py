@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--patch", default="sub2a")
-    ap.add_argument("--voices", type=int, default=1 << 20, help="voices per GPU (weak scaling)")
+    ap.add_argument("--voices", type=int, default=1 << 22, help="voices per GPU (weak scaling); 4 Mi voices = 336 MB of lane records")
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -109,8 +109,8 @@ def main():
     pitches = rng.integers(36, 97, size=V)
     vels = rng.uniform(0.25, 1.0, size=V)
     bank.random(rank + 1)
-    for v in range(V):
-        bank.note_on(bank.lo + v // notes, int(pitches[v]), float(vels[v]))
+    owner = bank.lo + np.arange(V) // notes
+    bank.note_on_many(owner, pitches, vels)
     mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -145,8 +145,7 @@ def main():
     checksum = float(mix.abs().sum().item())
 
     # worst case for the envelope code: every voice in its release ramp (not part of `value`)
-    for v in range(V):
-        bank.note_off(bank.lo + v // notes, int(pitches[v]), 0.0)
+    bank.note_off_many(owner, pitches, np.zeros(V, np.float32))
     step()
     torch.cuda.synchronize()
     if world > 1:

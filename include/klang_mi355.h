@@ -83,6 +83,10 @@ size_t klg_synth_state_bytes(const klg_synth* s);        /* resident HBM bytes p
 int klg_note_on(klg_synth* s, int synth, int pitch, float velocity);
 /* replaces: Synth::noteOff(int pitch, float velocity) klang.h:4430-4434 / 4820-4824 (NoteBase::release + off()) */
 int klg_note_off(klg_synth* s, int synth, int pitch, float velocity);
+/* Batched forms for banks of many instances: event i is (synth[i], pitch[i], velocity[i]); applied in order, exactly
+ * as n successive klg_note_on / klg_note_off calls (one host->device transfer at the next block either way). */
+int klg_note_on_many(klg_synth* s, int n, const int* synth, const int* pitch, const float* velocity);
+int klg_note_off_many(klg_synth* s, int n, const int* synth, const int* pitch, const float* velocity);
 /* replaces: controls[index].set(value) (clamped, klang.h:1725-1728) as done by the parameter sync of
  * Synth::process (klang.h:4444-4447, 4836-4839) followed by Synth::onControl (4399-4404). */
 int klg_set_control(klg_synth* s, int synth, int index, float value);

@@ -49,6 +49,8 @@ def load():
         "klg_synth_state_bytes": (C.c_size_t, [vp]),
         "klg_note_on": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),
         "klg_note_off": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),
+        "klg_note_on_many": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]),
+        "klg_note_off_many": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]),
         "klg_set_control": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),
         "klg_get_control": (C.c_int, [vp, C.c_int, C.c_int, f32p]),
         "klg_process": (C.c_int, [vp, C.POINTER(f32p), C.c_int, C.c_int, f32p]),

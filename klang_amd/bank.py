@@ -55,6 +55,19 @@ class SynthBank:
     def note_off(self, synth, pitch, velocity=0.0):
         return check(self._L.klg_note_off(self._h, int(synth), int(pitch), float(velocity)), "klg_note_off")
 
+    def _many(self, fn, name, synths, pitches, velocities):
+        sy = np.ascontiguousarray(synths, dtype=np.int32); pi = np.ascontiguousarray(pitches, dtype=np.int32)
+        ve = np.ascontiguousarray(velocities, dtype=np.float32)
+        assert sy.shape == pi.shape == ve.shape
+        ip = C.POINTER(C.c_int)
+        return check(fn(self._h, len(sy), sy.ctypes.data_as(ip), pi.ctypes.data_as(ip), _fp(ve)), name)
+
+    def note_on_many(self, synths, pitches, velocities):
+        return self._many(self._L.klg_note_on_many, "klg_note_on_many", synths, pitches, velocities)
+
+    def note_off_many(self, synths, pitches, velocities):
+        return self._many(self._L.klg_note_off_many, "klg_note_off_many", synths, pitches, velocities)
+
     def set_control(self, synth, index, value):
         return check(self._L.klg_set_control(self._h, int(synth), int(index), float(value)), "klg_set_control")
 

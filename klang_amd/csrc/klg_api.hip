@@ -431,6 +431,17 @@ extern "C" int klg_note_off(klg_synth* s, int synth, int pitch, float velocity) 
 	return 0;
 }
 
+extern "C" int klg_note_on_many(klg_synth* s, int n, const int* synth, const int* pitch, const float* velocity) {
+	if (!s || n < 0 || !synth || !pitch || !velocity) return fail(KLG_ERR_INVALID, "klg_note_on_many: bad arguments");
+	for (int i = 0; i < n; i++) { const int rc = klg_note_on(s, synth[i], pitch[i], velocity[i]); if (rc < 0) return rc; }
+	return 0;
+}
+extern "C" int klg_note_off_many(klg_synth* s, int n, const int* synth, const int* pitch, const float* velocity) {
+	if (!s || n < 0 || !synth || !pitch || !velocity) return fail(KLG_ERR_INVALID, "klg_note_off_many: bad arguments");
+	for (int i = 0; i < n; i++) { const int rc = klg_note_off(s, synth[i], pitch[i], velocity[i]); if (rc < 0) return rc; }
+	return 0;
+}
+
 extern "C" int klg_set_control(klg_synth* s, int synth, int index, float value) {
 	if (!s || synth < 0 || synth >= s->S || index < 0 || index >= s->nctl) return fail(KLG_ERR_INVALID, "klg_set_control: synth %d / control %d out of range", synth, index);
 	host::ControlH& c = s->controls[(size_t)synth * s->nctl + index];

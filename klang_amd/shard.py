@@ -48,6 +48,16 @@ class ShardedSynthBank:
             self.bank.random(seed)
         return self.bank.note_on(synth - self.lo, pitch, velocity)
 
+    def note_on_many(self, synths, pitches, velocities):
+        import numpy as np
+        sy = np.asarray(synths); m = (sy >= self.lo) & (sy < self.hi)
+        return self.bank.note_on_many(sy[m] - self.lo, np.asarray(pitches)[m], np.asarray(velocities)[m])
+
+    def note_off_many(self, synths, pitches, velocities):
+        import numpy as np
+        sy = np.asarray(synths); m = (sy >= self.lo) & (sy < self.hi)
+        return self.bank.note_off_many(sy[m] - self.lo, np.asarray(pitches)[m], np.asarray(velocities)[m])
+
     def note_off(self, synth, pitch, velocity=0.0):
         if self.owns(synth):
             self.bank.note_off(synth - self.lo, pitch, velocity)
