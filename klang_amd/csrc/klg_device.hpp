@@ -169,17 +169,57 @@ __device__ __forceinline__ float biquad_process(Biquad& q, float in) {      // T
 	q.z1 = q.b2 * in - q.a2 * y;
 	return y;
 }
+// ---- libm parity: sinf / cosf as the reference's host libm computes them ----
+// The reference calls libm's cosf/sinf (klang.h:5593-5594); the library in question is glibc 2.35 (Ubuntu 22.04,
+// this image), whose sinf/cosf are the ARM "optimized routines" implementation (sysdeps/ieee754/flt-32/s_sinf.c,
+// s_cosf.c, sincosf.h, sincosf_data.c): argument reduction by pi/2 in double, two degree-7/8 double polynomials,
+// one final rounding to float.  On x86-64 CPUs with FMA glibc's ifunc selects the FMA build, in which every
+// a*b+c of those routines is a fused multiply-add.  This is a restatement of that published algorithm with the
+// same double coefficients and explicit fma(); it was compared against the host libm on all 317,718,528 floats in
+// [2^-31, 120): 0 mismatches for sinf and for cosf (without fma: 6 / 11).  Arguments >= 120 (never reached by a
+// filter: w = 2*pi*f/fs < pi) take the OCML fp64 path.
+struct SinCosTab { double c0, c1, c2, c3, c4, s1, s2, s3; };
+__device__ __forceinline__ float glibc_sincos_poly(double x, double x2, bool neg_tab, int n) {
+	const double sg = neg_tab ? -1.0 : 1.0;                     // __sincosf_table[1] = the cosine coefficients negated
+	const double c0 = sg * 0x1p0, c1 = sg * -0x1.ffffffd0c621cp-2, c2 = sg * 0x1.55553e1068f19p-5, c3 = sg * -0x1.6c087e89a359dp-10, c4 = sg * 0x1.99343027bf8c3p-16;
+	const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+	if ((n & 1) == 0) {
+		const double x3 = x * x2, t1 = __builtin_fma(x2, s3, s2), x7 = x3 * x2, s = __builtin_fma(x3, s1, x);
+		return (float)__builtin_fma(x7, t1, s);
+	}
+	const double x4 = x2 * x2, q2 = __builtin_fma(x2, c4, c3), q1 = __builtin_fma(x2, c1, c0), x6 = x4 * x2, c = __builtin_fma(x4, c2, q1);
+	return (float)__builtin_fma(x6, q2, c);
+}
+template<bool COS> __device__ __forceinline__ float glibc_sincosf(float y) {
+	const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
+	double x = (double)y;
+	if (top < ((0x3f490fdbu >> 20) & 0x7ffu)) {                 // |y| < pi/4
+		if (top < ((0x39800000u >> 20) & 0x7ffu)) return COS ? 1.0f : y;   // |y| < 2^-12
+		return glibc_sincos_poly(x, x * x, false, COS ? 1 : 0);
+	}
+	if (top < ((0x42f00000u >> 20) & 0x7ffu)) {                 // |y| < 120: reduce_fast
+		const double r = x * 0x1.45F306DC9C883p+23;
+		const int n = ((int32_t)r + 0x800000) >> 24;
+		x = __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);
+		const int m = COS ? n + 1 : n;
+		const double sign = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;   // sign[] = { 1, -1, -1, 1 }
+		return glibc_sincos_poly(x * sign, x * x, (m & 2) != 0, COS ? (n ^ 1) : n);
+	}
+	return COS ? (float)cos((double)y) : (float)sin((double)y);
+}
+__device__ __forceinline__ float glibc_sinf(float y) { return glibc_sincosf<false>(y); }
+__device__ __forceinline__ float glibc_cosf(float y) { return glibc_sincosf<true>(y); }
+
 // Biquad::Filter::set(f, Q) 5584-5600 + LPF::init 5658-5665, evaluated on the device for per-sample swept
-// cutoffs (shipped subtractive.k:29, F6).  cosf/sinf: the reference calls glibc's; here the double-precision
-// OCML cos/sin rounded to float (differs from glibc in at most the last bit; see DESIGN.md "libm").
+// cutoffs (shipped subtractive.k:29, F6) with the libm-exact cosf/sinf above.
 struct BiquadSweep { float f, Q; };
 __device__ __forceinline__ void biquad_lpf_set(Biquad& q, BiquadSweep& c, float f, float Q, float fs_w) {
 	if (Q < 0) Q = f / -Q;
 	if (c.f != f || c.Q != Q) {
 		c.f = f; c.Q = Q;
 		const float w = f * fs_w;
-		const float cos0 = (float)cos((double)w);
-		const float sin0 = (float)sin((double)w);
+		const float cos0 = glibc_cosf(w);
+		const float sin0 = glibc_sinf(w);
 		if (Q < 0.5f) Q = 0.5f;
 		const float a = sin0 / (2.f * Q);
 		const double a0 = (double)(1.f + a);                               // constant a0 = { 1.f + a }  klang.h:97

@@ -1,7 +1,7 @@
 """Every device primitive of the hot-path table on its own: klg_selftest() runs one
 primitive in one GPU lane and the result is compared BIT FOR BIT with the reference's known-answer vectors
 (tests/golden/prims.kat, produced by the genuine header; stimuli as in oracle/ref/ref_prims.cpp).
-The only tolerance is the swept biquad, whose cos/sin run on the device."""
+No tolerance anywhere: the swept biquad's cosf/sinf are a libm-exact restatement."""
 import ctypes as C
 import os
 
@@ -117,12 +117,12 @@ def test_onepole_and_biquads(L, kat, f):
 
 
 def test_biquad_swept_cutoff_on_device(L, kat):
-    """The F6 path: coefficients recomputed every sample on the GPU (fp64 cos/sin rounded to float vs glibc cosf/sinf)."""
+    """The F6 path: coefficients recomputed every sample on the GPU with the libm-exact cosf/sinf restatement
+    (glibc 2.35 FMA variant, klg_device.hpp: glibc_sincosf) — bit-exact like everything else."""
     fc = (np.float32(500.0) + np.float32(7.0) * np.arange(1024, dtype=np.float32)).astype(np.float32)
     w = np.float32(2.0) * np.float32(np.pi) * (np.float32(1.0) / np.float32(FS))
     got = run(L, ST_BIQUAD_LPF_SWEEP, [10.0, w], 1024, inp=np.concatenate([noise(0, 1024), fc]))
-    ref = kat["biquad_lpf_sweep_q10"]
-    assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref))
+    assert same(got, kat["biquad_lpf_sweep_q10"])
 
 
 def test_adsr_and_envelopes(L, kat):
