@@ -92,10 +92,18 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: klang_amd has no CPU path")
+    # test hook: KLG_BENCH_ONE_GPU=1 runs every rank on cuda:0 with the gloo backend so the N > 1 code path (sharding,
+    # barriers, max-over-ranks timing, all-reduce of the mix) can be smoke-tested on a 1-GPU box.  Never set by the driver.
+    one_gpu = os.environ.get("KLG_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import klang_amd
     notes = 128 if args.patch in ("sub2a", "sine", "bsine") else 32
