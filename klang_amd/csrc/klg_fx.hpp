@@ -138,6 +138,7 @@ struct PingPongArgs {
 	SampleRate fs;
 	BiquadCoef dc;              // dcfilter[k].set(50, 1) — PingPong.k:39-40, computed on the host
 	float c1_min, c1_max;
+	int ablate;                 // measurement only (KLG_FX_ABLATE): 1 = no ring reads, 2 = no ring writes, 4 = no io staging
 };
 
 // The kernel works in sub-chunks of PP_SUB samples:
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 
 	for (int s0 = 0; s0 < a.n; s0 += FX_CHUNK) {
 		const int cl = (a.n - s0 < FX_CHUNK) ? (a.n - s0) : FX_CHUNK;
-		io_load_chunk(tile, a.io, k0, a.K, a.n, s0, cl, lane);
+		if (!(a.ablate & 4)) io_load_chunk(tile, a.io, k0, a.K, a.n, s0, cl, lane);
 		wave_sync();
 		for (int u0 = 0; u0 < cl; u0 += PP_SUB) {
 			const int ul = (cl - u0 < PP_SUB) ? (cl - u0) : PP_SUB;
@@ -219,8 +220,11 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 					if (u < ul) {
 						const int i0 = tl[u].position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
 						const int j0 = tr[u].position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
-						pl[u][0] = left.rd(i0); pl[u][1] = left.rd(i1); pl[u][2] = left.rd(i2);
-						pr[u][0] = right.rd(j0); pr[u][1] = right.rd(j1); pr[u][2] = right.rd(j2);
+						if (a.ablate & 1) { pl[u][0] = pl[u][1] = pl[u][2] = 0.f; pr[u][0] = pr[u][1] = pr[u][2] = 0.f; }
+						else {
+							pl[u][0] = left.rd(i0); pl[u][1] = left.rd(i1); pl[u][2] = left.rd(i2);
+							pr[u][0] = right.rd(j0); pr[u][1] = right.rd(j1); pr[u][2] = right.rd(j2);
+						}
 					}
 				}
 			}
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 					// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
 					if (prefetch) r1 = pr[u][0] + tr[u].fraction * (pr[u][1] - pr[u][0]);
 					else r1 = delay_process(right, tr[u]);
-					left.wr(position, in_l + r1 * gain);
+					if (!(a.ablate & 2)) left.wr(position, in_l + r1 * gain);
 					if (prefetch) {
 						l1 = pl[u][0] + tl[u].fraction * (pl[u][1] - pl[u][0]);
 						l2 = pl[u][1] + tl[u].fraction * (pl[u][2] - pl[u][1]);
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 					else { l1 = delay_process(left, tl[u]); l2 = delay_process(left, tl[u]); }
 					float out_l = dry * in_l + l1 * (1.f - dry);
 					// dry * in.r + (1.f - dry) * ((in.r + left * gain) >> right) >> out.r;   PingPong.k:67
-					right.wr(position, in_r + l2 * gain);
+					if (!(a.ablate & 2)) right.wr(position, in_r + l2 * gain);
 					if (prefetch) r2 = pr[u][1] + tr[u].fraction * (pr[u][2] - pr[u][1]);
 					else r2 = delay_process(right, tr[u]);
 					float out_r = dry * in_r + r2 * (1.f - dry);
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 			}
 		}
 		wave_sync();
-		io_store_chunk(tile, a.io, k0, a.K, a.n, s0, cl, lane);
+		if (!(a.ablate & 4)) io_store_chunk(tile, a.io, k0, a.K, a.n, s0, cl, lane);
 		wave_sync();
 	}
 	if (k < a.K) {

@@ -219,6 +219,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		a.io = d_io; a.n = n;
 		a.fs.f = f->fs.f; a.fs.w = f->fs.w; a.fs.timeInc = 1.0f / f->fs.f;
 		a.dc = f->pp_dc; a.c1_min = PP_DIALS[1].min; a.c1_max = PP_DIALS[1].max;
+		{ const char* e = getenv("KLG_FX_ABLATE"); a.ablate = e ? atoi(e) : 0; }
 		hipLaunchKernelGGL(klg_fx_pingpong, grid, block, 0, st, a);
 	}
 	else {
