@@ -412,6 +412,195 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
 #undef RVW
 }
 
+// =================================================================================================
+// Reverb.k, sixteen waves per 64 instances
+// =================================================================================================
+// klg_fx_reverb above walks the whole per-sample graph of an instance in ONE lane: ~2000 dependent instructions and
+// 144 ring reads per sample with a single wave per CU to hide them.  The graph has far more parallelism than that:
+//   * the 16 FilteredDelays only meet in the 4x4 feedback matrix of their LateReflections and in the output sum;
+//   * the delay lines are read >= 150 samples behind their write cursors, so no ring value read in a block segment
+//     depends on anything computed in it: every tap address is known ahead of time;
+//   * the 40 (tap, channel) products of the early reflections are independent; only their SUM is ordered.
+// This kernel gives the same 64 instances (lane = instance, as before) to a workgroup of SIXTEEN waves:
+//   wave w  = FilteredDelay w   (LateReflections a = w / 4: mid[0], mid[1], late[0], late[1]; line k = w % 4)
+//           + the early-reflection products of channel w / 8 for taps (w % 8), +8, +16
+//   waves 0 / 8 also run the early LPF >> HPF of the left / right channel and write the early rings,
+//   waves 1 / 9 produce the left / right output sample.
+// The three stages run skewed so that every wave has work between the same two barriers: in iteration t the early
+// stage handles sample t+2, mid[] handles t+1, late[] handles t, the output sample t-1.  Values cross waves through
+// LDS (double-buffered by sample slot); there is no cross-lane traffic at all.  Each wave prefetches the ring rows of
+// its next sample into registers, so HBM latency is hidden behind the other three waves of its SIMD.
+// Arithmetic, operand order and summation order are exactly those of klg_fx_reverb / the reference; the two kernels
+// are compared bit for bit in tests/test_gpu_fx.py (KLG_FX_REVERB1=1 selects the single-wave kernel).
+enum { RV16_WAVES = 16, RV16_THREADS = 1024, RV16_SLOTS = 4 };
+
+struct Rv16Lds {
+	float tile[2][2][FX_CHUNK][FX_LD];          // [buffer][channel][sample][instance]  in-place io staging
+	float P[2][40][64];                         // early products  [slot e&1][ch*20 + d][instance]
+	float R1[RV16_SLOTS][2][64];                // early reflections  r1[ch]
+	float DL[16][64];                           // FilteredDelay outputs of the first process() (feedback-matrix input)
+	float OM[RV16_SLOTS][8][64];                // second-process outputs of mid[0], mid[1]
+	float OL[RV16_SLOTS][8][64];                // second-process outputs of late[0], late[1]
+};
+
+__device__ __forceinline__ int ring_next(int i, int size) { return (i + 1 == size) ? 0 : i + 1; }
+
+__global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs a) {
+	__shared__ Rv16Lds S;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int k0 = blockIdx.x * FX_WG, k = k0 + lane;
+	const size_t KP = a.kpad;
+	const float* W = a.state + k;
+#define RVW(w) W[(size_t)(w) * KP]
+	const int n = a.n;
+	// ---- this wave's FilteredDelay ----
+	const int fd = wv, lr = wv >> 2, kk = wv & 3;
+	const int fw = RV_FD + fd * FD_WORDS;
+	Biquad ff = { RVW(fw + FD_COEF + 0), RVW(fw + FD_COEF + 1), RVW(fw + FD_COEF + 2), RVW(fw + FD_COEF + 3), RVW(fw + FD_COEF + 4), RVW(fw + FD_Z0), RVW(fw + FD_Z1) };
+	float fin = RVW(fw + FD_IN);
+	const float fgain = RVW(fw + FD_GAIN), ffrac = RVW(fw + FD_LASTF);
+	int flast = __float_as_int(RVW(fw + FD_LASTP));
+	Ring fring = { a.fd_rings + ((size_t)blockIdx.x * 16 + fd) * RV_FSIZE * FX_WG + lane, FX_WG, RV_FSIZE };
+	// ---- this wave's share of the early reflections ----
+	const int ech = wv >> 3, ej = wv & 7;
+	const int ecount = __float_as_int(RVW(RV_ECOUNT));
+	float etime[3], egain[3]; bool ehas[3];
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+		const int d = ej + 8 * q;
+		ehas[q] = d < 20 && d < ecount;
+		etime[q] = ehas[q] ? RVW(RV_ETIMES + d) : 0.f;
+		egain[q] = ehas[q] ? RVW((ech ? RV_EGR : RV_EGL) + d) : 0.f;
+	}
+	float* etile = a.early_rings + (size_t)blockIdx.x * 2 * RV_ESIZE * FX_WG + lane;
+	Ring ering = { etile + (size_t)ech * RV_ESIZE * FX_WG, FX_WG, RV_ESIZE };
+	const bool efilter = (wv & 7) == 0;         // waves 0 and 8: in >> lpf >> hpf >> delay for their channel
+	Biquad elpf = { RVW(RV_ELPF + 0), RVW(RV_ELPF + 1), RVW(RV_ELPF + 2), RVW(RV_ELPF + 3), RVW(RV_ELPF + 4), RVW(RV_EZ + 2 * ech), RVW(RV_EZ + 2 * ech + 1) };
+	Biquad ehpf = { RVW(RV_EHPF + 0), RVW(RV_EHPF + 1), RVW(RV_EHPF + 2), RVW(RV_EHPF + 3), RVW(RV_EHPF + 4), RVW(RV_EZ + 4 + 2 * ech), RVW(RV_EZ + 4 + 2 * ech + 1) };
+	const bool outwave = (wv & 7) == 1;         // waves 1 and 9: output of channel ech
+	const float dry = RVW(RV_CTL + 0), c1 = RVW(RV_CTL + 1), c2 = RVW(RV_CTL + 2), c3 = RVW(RV_CTL + 3), wet = RVW(RV_CTL + 4);
+
+	// ---- prefetch registers ----
+	float fr0, fr1, fr2;                        // ring rows last, last+1, last+2 of the FilteredDelay's NEXT sample
+	{ const int r1 = ring_next(flast, RV_FSIZE), r2 = ring_next(r1, RV_FSIZE); fr0 = fring.rd(flast); fr1 = fring.rd(r1); fr2 = fring.rd(r2); }
+	float ea[3], eb[3], efr[3];                 // early taps of the NEXT early sample: rows i, j and the fraction
+	auto early_taps = [&](int e, float (&xa)[3], float (&xb)[3], float (&xf)[3]) {   // Stereo::Delay::tap(float) klang.h:4668-4681 for sample e
+		const int wpos = (a.epos + e) % RV_ESIZE;                                    // write cursor of sample e
+		const int pos = ring_next(wpos, RV_ESIZE);                                   // cursor after Delay::input()
+#pragma unroll
+		for (int q = 0; q < 3; q++) {
+			float read = (float)(pos - 1) - etime[q];
+			if (read < 0.f) read += RV_ESIZE;
+			const float f = (float)floor((double)read);
+			xf[q] = read - f;
+			const int i = (int)read, j = (i == RV_ESIZE - 1) ? 0 : (i + 1);
+			xa[q] = ehas[q] ? ering.rd(i) : 0.f;
+			xb[q] = ehas[q] ? ering.rd(j) : 0.f;
+		}
+	};
+	early_taps(0, ea, eb, efr);
+
+	auto load_chunk = [&](int c) {              // all 1024 threads: 128 (instance, channel) rows x <= 32 samples
+		const int s0 = c * FX_CHUNK, cl = (n - s0 < FX_CHUNK) ? (n - s0) : FX_CHUNK, col = tid & 31;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int row = (tid >> 5) + 32 * j, inst = row >> 1, ch = row & 1;
+			S.tile[c & 1][ch][col][inst] = (col < cl && k0 + inst < a.K) ? a.io[((size_t)(k0 + inst) * 2 + ch) * n + s0 + col] : 0.f;
+		}
+	};
+	auto store_chunk = [&](int c) {
+		const int s0 = c * FX_CHUNK, cl = (n - s0 < FX_CHUNK) ? (n - s0) : FX_CHUNK, col = tid & 31;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int row = (tid >> 5) + 32 * j, inst = row >> 1, ch = row & 1;
+			if (col < cl && k0 + inst < a.K) a.io[((size_t)(k0 + inst) * 2 + ch) * n + s0 + col] = S.tile[c & 1][ch][col][inst];
+		}
+	};
+	// FilteredDelay::process Reverb.k:130-132 with this sample's prefetched rows: (in >> delay >> filter) * gain
+	auto fd_proc = [&](float ra, float rb, int wpos) {
+		fring.wr(wpos, fin);
+		const float t = ra + ffrac * (rb - ra);
+		return biquad_process(ff, t) * fgain;
+	};
+
+	float lr_in = 0.f;                          // input of this wave's LateReflections for the sample in flight
+	for (int t = -2; t <= n; t++) {
+		const int e = t + 2, m = t + 1, l = t, o = t - 1;
+		if (e < n && (e & (FX_CHUNK - 1)) == 0) { load_chunk(e >> 5); __syncthreads(); }
+		// ================= phase 1 =================
+		if (e < n) {                                                               // ---- early stage, sample e ----
+			const int wpos = (a.epos + e) % RV_ESIZE;
+			if (efilter) {                                                         // EarlyReflections: in >> lpf >> hpf >> delay  Reverb.k:88
+				const float x = S.tile[(e >> 5) & 1][ech][e & 31][lane];
+				ering.wr(wpos, biquad_process(ehpf, biquad_process(elpf, x)));
+			}
+#pragma unroll
+			for (int q = 0; q < 3; q++) if (ej + 8 * q < 20) {
+				const float tap = ea[q] * (1.f - efr[q]) + eb[q] * efr[q];           // delay(times[d])
+				S.P[e & 1][ech * 20 + ej + 8 * q][lane] = tap * egain[q];            // ... * gains[d]
+			}
+			if (e + 1 < n) early_taps(e + 1, ea, eb, efr);                          // prefetch the next sample's rows
+		}
+		const int s_fd = (lr < 2) ? m : l;                                          // the sample this wave's FilteredDelay works on
+		const bool fd_on = s_fd >= 0 && s_fd < n;
+		float r0 = 0.f, r1v = 0.f, r2v = 0.f;
+		if (fd_on) {
+			if (lr < 2) {                                                           // mid[lr]: input = early reflections of channel lr
+				float sum = 0.f;                                                    // out = 0; for d: out += delay(times[d]) * gains[d]   Reverb.k:90-92
+				for (int d = 0; d < ecount; d++) sum += S.P[m & 1][lr * 20 + d][lane];
+				lr_in = sum;
+				if (kk == 0) S.R1[m & 3][lr][lane] = sum;
+			}
+			else {                                                                  // late[lr-2]: input = mid[lr-2] of the same sample
+				const float* om = &S.OM[l & 3][(lr - 2) * 4][lane];
+				lr_in = om[3 * 64] + (om[2 * 64] + (om[0] + om[64]));               // ((o0 + o1) + o2) + o3 as the reference's `+` chain associates
+			}
+			r0 = fr0; r1v = fr1; r2v = fr2;
+			const int wpos = (int)(((long long)a.fpos + 2LL * s_fd) % RV_FSIZE);
+			S.DL[wv][lane] = fd_proc(r0, r1v, wpos);                                // signals<4> delays = { delay[0..3] }: first process()
+		}
+		if (o >= 0 && o < n && outwave) {                                           // ---- output, sample o ----  Reflections::process + Reverb::process
+			const float in = S.tile[(o >> 5) & 1][ech][o & 31][lane];
+			const float* om = &S.OM[o & 3][ech * 4][lane]; const float* ol = &S.OL[o & 3][ech * 4][lane];
+			const float r1o = S.R1[o & 3][ech][lane];
+			const float r2o = om[3 * 64] + (om[2 * 64] + (om[0] + om[64]));
+			const float r3o = ol[3 * 64] + (ol[2 * 64] + (ol[0] + ol[64]));
+			const float refl = (r1o * c1 + r2o * c2) + r3o * c3;
+			S.tile[(o >> 5) & 1][ech][o & 31][lane] = in * dry + refl * (ech ? 0.f : wet);   // wet side is signals<2>{ wet, 0 }
+		}
+		__syncthreads();
+		// ================= phase 2 =================
+		if (fd_on) {
+			const float* dl = &S.DL[lr * 4][lane];
+			const float d0 = dl[0], d1 = dl[64], d2 = dl[128], d3 = dl[192];
+			float fb;                                                               // row kk of the FDN matrix (Reverb.k:158-161), products summed left to right
+			if (kk == 0) fb = 0.f * d0 + 1.f * d1 + 1.f * d2 + -1.f * d3;
+			else if (kk == 1) fb = -1.f * d0 + 0.f * d1 + -1.f * d2 + 1.f * d3;
+			else if (kk == 2) fb = -1.f * d0 + 1.f * d1 + 0.f * d2 + -1.f * d3;
+			else fb = 1.f * d0 + -1.f * d1 + 1.f * d2 + 0.f * d3;
+			fin = fb + lr_in;                                                       // fb = (delays >> matrix) + in ; fb[k] >> delay[k]
+			const int wpos = (int)(((long long)a.fpos + 2LL * s_fd + 1) % RV_FSIZE);
+			const float o2 = fd_proc(r1v, r2v, wpos);                               // the `+` chain processes each FilteredDelay a second time
+			if (lr < 2) S.OM[s_fd & 3][wv][lane] = o2; else S.OL[s_fd & 3][wv - 8][lane] = o2;
+			flast = ring_next(ring_next(flast, RV_FSIZE), RV_FSIZE);
+			if (s_fd + 1 < n) { const int q1 = ring_next(flast, RV_FSIZE), q2 = ring_next(q1, RV_FSIZE); fr0 = fring.rd(flast); fr1 = fring.rd(q1); fr2 = fring.rd(q2); }
+		}
+		__syncthreads();
+		if (o >= 0 && o < n && ((o & (FX_CHUNK - 1)) == FX_CHUNK - 1 || o == n - 1)) { store_chunk(o >> 5); }
+	}
+	// ---- write back what changed ----
+	if (k < a.K) {
+		float* Wr = a.state + k;
+		Wr[(size_t)(fw + FD_Z0) * KP] = ff.z0; Wr[(size_t)(fw + FD_Z1) * KP] = ff.z1; Wr[(size_t)(fw + FD_IN) * KP] = fin;
+		Wr[(size_t)(fw + FD_LASTP) * KP] = __int_as_float(flast);
+		if (efilter) {
+			Wr[(size_t)(RV_EZ + 2 * ech) * KP] = elpf.z0; Wr[(size_t)(RV_EZ + 2 * ech + 1) * KP] = elpf.z1;
+			Wr[(size_t)(RV_EZ + 4 + 2 * ech) * KP] = ehpf.z0; Wr[(size_t)(RV_EZ + 4 + 2 * ech + 1) * KP] = ehpf.z1;
+		}
+	}
+#undef RVW
+}
+
 // scatter host-side updates into the SoA state: upd = { k, word, value_bits } triples
 __global__ void klg_fx_apply_updates(float* state, size_t kpad, const int* upd, int count) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -228,7 +228,9 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		a.epos = (int)(f->samples % (unsigned long long)RV_ESIZE);
 		a.fpos = (int)((2ull * f->samples) % (unsigned long long)RV_FSIZE);
 		a.io = d_io; a.n = n;
-		hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);
+		static const bool single_wave = []() { const char* e = getenv("KLG_FX_REVERB1"); return e && e[0] == '1'; }();
+		if (single_wave) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);                 // one lane walks the whole graph (A/B reference)
+		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances
 	}
 	HIP_TRY(hipGetLastError());
 	if (f->timing) { HIP_TRY(hipEventRecord(f->tev[2 * f->launches + 1], st)); f->launches++; }
