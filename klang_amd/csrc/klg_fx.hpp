@@ -441,71 +441,97 @@ struct Rv16Lds {
 	float DL[16][64];                           // FilteredDelay outputs of the first process() (feedback-matrix input)
 	float OM[RV16_SLOTS][8][64];                // second-process outputs of mid[0], mid[1]
 	float OL[RV16_SLOTS][8][64];                // second-process outputs of late[0], late[1]
+	float CF[15][64];                           // per-instance constants only two waves per channel need: early LPF / HPF coefficients, dry/c1/c2/c3/wet
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every ring-row
+// prefetch and ring store in flight twice per sample; the rings need no cross-wave ordering inside a block (a row written at
+// sample e is next read `time` >= 45 ms later, and only after the writer's in-order vmcnt has retired the store).
+__device__ __forceinline__ void wg_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ int ring_next(int i, int size) { return (i + 1 == size) ? 0 : i + 1; }
 
 __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs a) {
 	__shared__ Rv16Lds S;
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: every role test below is a scalar branch
 	const int k0 = blockIdx.x * FX_WG, k = k0 + lane;
 	const size_t KP = a.kpad;
 	const float* W = a.state + k;
 #define RVW(w) W[(size_t)(w) * KP]
 	const int n = a.n;
+	// ring rows are addressed as (wave-uniform base pointer) + (32-bit per-lane byte offset): one VGPR per address
+	struct URing {
+		float* base; unsigned lane4;
+		__device__ __forceinline__ float rd(int i) const { return *(const float*)((const char*)base + ((unsigned)i * (FX_WG * 4u) + lane4)); }
+		__device__ __forceinline__ void wr(int i, float v) const { *(float*)((char*)base + ((unsigned)i * (FX_WG * 4u) + lane4)) = v; }
+	};
 	// ---- this wave's FilteredDelay ----
 	const int fd = wv, lr = wv >> 2, kk = wv & 3;
 	const int fw = RV_FD + fd * FD_WORDS;
 	Biquad ff = { RVW(fw + FD_COEF + 0), RVW(fw + FD_COEF + 1), RVW(fw + FD_COEF + 2), RVW(fw + FD_COEF + 3), RVW(fw + FD_COEF + 4), RVW(fw + FD_Z0), RVW(fw + FD_Z1) };
 	float fin = RVW(fw + FD_IN);
 	const float fgain = RVW(fw + FD_GAIN), ffrac = RVW(fw + FD_LASTF);
-	int flast = __float_as_int(RVW(fw + FD_LASTP));
-	Ring fring = { a.fd_rings + ((size_t)blockIdx.x * 16 + fd) * RV_FSIZE * FX_WG + lane, FX_WG, RV_FSIZE };
+	const int flast = __float_as_int(RVW(fw + FD_LASTP));
+	const URing fring = { a.fd_rings + ((size_t)blockIdx.x * 16 + fd) * RV_FSIZE * FX_WG, (unsigned)lane * 4u };
 	// ---- this wave's share of the early reflections ----
 	const int ech = wv >> 3, ej = wv & 7;
 	const int ecount = __float_as_int(RVW(RV_ECOUNT));
-	float etime[3], egain[3]; bool ehas[3];
+	float etime[3], egain[3]; bool eload[3];    // eload[q]: some instance of this wave has tap d (wave-uniform: its loads are never lane-predicated)
 #pragma unroll
 	for (int q = 0; q < 3; q++) {
 		const int d = ej + 8 * q;
-		ehas[q] = d < 20 && d < ecount;
-		etime[q] = ehas[q] ? RVW(RV_ETIMES + d) : 0.f;
-		egain[q] = ehas[q] ? RVW((ech ? RV_EGR : RV_EGL) + d) : 0.f;
+		const bool has = d < 20 && d < ecount;
+		eload[q] = __ballot(has) != 0ull;
+		etime[q] = has ? RVW(RV_ETIMES + d) : 0.f;                                  // an instance without the tap reads a valid row and its product is never summed
+		egain[q] = has ? RVW((ech ? RV_EGR : RV_EGL) + d) : 0.f;
 	}
-	float* etile = a.early_rings + (size_t)blockIdx.x * 2 * RV_ESIZE * FX_WG + lane;
-	Ring ering = { etile + (size_t)ech * RV_ESIZE * FX_WG, FX_WG, RV_ESIZE };
-	const bool efilter = (wv & 7) == 0;         // waves 0 and 8: in >> lpf >> hpf >> delay for their channel
-	Biquad elpf = { RVW(RV_ELPF + 0), RVW(RV_ELPF + 1), RVW(RV_ELPF + 2), RVW(RV_ELPF + 3), RVW(RV_ELPF + 4), RVW(RV_EZ + 2 * ech), RVW(RV_EZ + 2 * ech + 1) };
-	Biquad ehpf = { RVW(RV_EHPF + 0), RVW(RV_EHPF + 1), RVW(RV_EHPF + 2), RVW(RV_EHPF + 3), RVW(RV_EHPF + 4), RVW(RV_EZ + 4 + 2 * ech), RVW(RV_EZ + 4 + 2 * ech + 1) };
-	const bool outwave = (wv & 7) == 1;         // waves 1 and 9: output of channel ech
-	const float dry = RVW(RV_CTL + 0), c1 = RVW(RV_CTL + 1), c2 = RVW(RV_CTL + 2), c3 = RVW(RV_CTL + 3), wet = RVW(RV_CTL + 4);
+	const URing ering = { a.early_rings + ((size_t)blockIdx.x * 2 + ech) * RV_ESIZE * FX_WG, (unsigned)lane * 4u };
+	// the three per-channel extras are spread over the four SIMDs (wave w runs on SIMD w % 4): filter L/R on waves 1 / 11,
+	// sum on 2 / 8, output on 3 / 13
+	const bool efilter = wv == 1 || wv == 11;   // in >> lpf >> hpf >> delay for channel ech
+	float elz0 = RVW(RV_EZ + 2 * ech), elz1 = RVW(RV_EZ + 2 * ech + 1), ehz0 = RVW(RV_EZ + 4 + 2 * ech), ehz1 = RVW(RV_EZ + 4 + 2 * ech + 1);
+	const bool outwave = wv == 3 || wv == 13;   // output of channel ech
+	const bool sumwave = wv == 2 || wv == 8;    // sum of the early products of channel ech
+	if (wv < 15) S.CF[wv][lane] = RVW(wv < 5 ? RV_ELPF + wv : wv < 10 ? RV_EHPF + (wv - 5) : RV_CTL + (wv - 10));
+	__syncthreads();
 
-	// ---- prefetch registers ----
-	float fr0, fr1, fr2;                        // ring rows last, last+1, last+2 of the FilteredDelay's NEXT sample
-	{ const int r1 = ring_next(flast, RV_FSIZE), r2 = ring_next(r1, RV_FSIZE); fr0 = fring.rd(flast); fr1 = fring.rd(r1); fr2 = fring.rd(r2); }
-	float ea[3], eb[3], efr[3];                 // early taps of the NEXT early sample: rows i, j and the fraction
-	auto early_taps = [&](int e, float (&xa)[3], float (&xb)[3], float (&xf)[3]) {   // Stereo::Delay::tap(float) klang.h:4668-4681 for sample e
-		const int wpos = (a.epos + e) % RV_ESIZE;                                    // write cursor of sample e
+	// ---- prefetch registers: two sets, used alternately by even / odd iterations (the loop is unrolled by two so that
+	// a set is loaded at the TOP of the iteration before the one that consumes it: a whole iteration hides the latency) ----
+	struct Pre { float fr1, fr2, ea[3], eb[3], ef[3]; };
+	Pre A, B;
+	float fr0;                                  // ring row `last` of the FilteredDelay's current sample ( = row last+2 of the previous one)
+	// rows are fetched by byte offset (row * 256 + lane * 4), advanced by two rows per sample with one compare-and-wrap each
+	const unsigned FROW = FX_WG * 4u, FEND = (unsigned)RV_FSIZE * FROW;
+	auto frow = [&](unsigned off) { return *(const float*)((const char*)fring.base + off); };
+	auto fwrap = [&](unsigned off) { return off >= FEND ? off - FEND : off; };
+	unsigned foff = (unsigned)flast * FROW + fring.lane4;       // byte offset of row `last` of this wave's current sample
+	auto fd_rows = [&](unsigned off, Pre& X) { const unsigned o1 = fwrap(off + FROW), o2 = fwrap(o1 + FROW); X.fr1 = frow(o1); X.fr2 = frow(o2); };
+	fr0 = frow(foff); fd_rows(foff, A);
+	auto early_taps = [&](int wpos, Pre& X) {   // Stereo::Delay::tap(float) klang.h:4668-4681; wpos = write cursor of the sample
 		const int pos = ring_next(wpos, RV_ESIZE);                                   // cursor after Delay::input()
 #pragma unroll
 		for (int q = 0; q < 3; q++) {
 			float read = (float)(pos - 1) - etime[q];
 			if (read < 0.f) read += RV_ESIZE;
-			const float f = (float)floor((double)read);
-			xf[q] = read - f;
+			X.ef[q] = read - (float)floor((double)read);
 			const int i = (int)read, j = (i == RV_ESIZE - 1) ? 0 : (i + 1);
-			xa[q] = ehas[q] ? ering.rd(i) : 0.f;
-			xb[q] = ehas[q] ? ering.rd(j) : 0.f;
+			if (eload[q]) { X.ea[q] = ering.rd(i); X.eb[q] = ering.rd(j); }
 		}
 	};
-	early_taps(0, ea, eb, efr);
+	int ewpos = a.epos % RV_ESIZE;              // early write cursor of sample e (advanced once per iteration)
+	A.ea[0] = A.ea[1] = A.ea[2] = A.eb[0] = A.eb[1] = A.eb[2] = 0.f;
+	early_taps(ewpos, A);
+	B = A;
+	int fwpos = a.fpos % RV_FSIZE;              // FilteredDelay write cursor of this wave's sample (two inputs per sample)
 
 	auto load_chunk = [&](int c) {              // all 1024 threads: 128 (instance, channel) rows x <= 32 samples
 		const int s0 = c * FX_CHUNK, cl = (n - s0 < FX_CHUNK) ? (n - s0) : FX_CHUNK, col = tid & 31;
+		const char* src = (const char*)(a.io + (size_t)k0 * 2 * n + s0);
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int row = (tid >> 5) + 32 * j, inst = row >> 1, ch = row & 1;
-			S.tile[c & 1][ch][col][inst] = (col < cl && k0 + inst < a.K) ? a.io[((size_t)(k0 + inst) * 2 + ch) * n + s0 + col] : 0.f;
+			S.tile[c & 1][ch][col][inst] = (col < cl && k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + col) * 4u) : 0.f;
 		}
 	};
 	auto store_chunk = [&](int c) {
@@ -513,62 +539,61 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int row = (tid >> 5) + 32 * j, inst = row >> 1, ch = row & 1;
-			if (col < cl && k0 + inst < a.K) a.io[((size_t)(k0 + inst) * 2 + ch) * n + s0 + col] = S.tile[c & 1][ch][col][inst];
+			if (col < cl && k0 + inst < a.K) *(float*)((char*)(a.io + (size_t)k0 * 2 * n + s0) + (unsigned)(row * n + col) * 4u) = S.tile[c & 1][ch][col][inst];
 		}
 	};
-	// FilteredDelay::process Reverb.k:130-132 with this sample's prefetched rows: (in >> delay >> filter) * gain
-	auto fd_proc = [&](float ra, float rb, int wpos) {
-		fring.wr(wpos, fin);
-		const float t = ra + ffrac * (rb - ra);
-		return biquad_process(ff, t) * fgain;
-	};
-
 	float lr_in = 0.f;                          // input of this wave's LateReflections for the sample in flight
-	for (int t = -2; t <= n; t++) {
+	// One iteration.  G = guarded: the ramp-up / ramp-down iterations test which stages are active; the steady-state
+	// iterations (1 <= t <= n-4: every stage active and a next sample to prefetch) run the same code with no guards, so the
+	// compiler's vmcnt bookkeeping stays exact and nothing waits for a load younger than one iteration.
+	auto step = [&](auto guarded, const int t, const Pre& C, Pre& N) {   // C: rows of this iteration's samples; N: loaded here for the next iteration
+		constexpr bool G = decltype(guarded)::value;
 		const int e = t + 2, m = t + 1, l = t, o = t - 1;
-		if (e < n && (e & (FX_CHUNK - 1)) == 0) { load_chunk(e >> 5); __syncthreads(); }
+		const int s_fd = (lr < 2) ? m : l;                                          // the sample this wave's FilteredDelay works on
+		const bool fd_on = !G || (s_fd >= 0 && s_fd < n);
+		const bool e_on = !G || e < n, o_on = !G || (o >= 0 && o < n);
+		if (!G || (fd_on && s_fd + 1 < n)) fd_rows(fwrap(fwrap(foff + FROW) + FROW), N);
+		if (!G || e + 1 < n) early_taps(ring_next(ewpos, RV_ESIZE), N);
+		// the early taps of sample e are consumed first: after this point nothing in the iteration depends on a load in flight
+		float prod[3];
+#pragma unroll
+		for (int q = 0; q < 3; q++) prod[q] = (C.ea[q] * (1.f - C.ef[q]) + C.eb[q] * C.ef[q]) * egain[q];   // delay(times[d]) * gains[d]
+		float r0 = fr0, r1v = C.fr1, r2v = C.fr2;
+		const float fdt1 = r0 + ffrac * (r1v - r0), fdt2 = r1v + ffrac * (r2v - r1v);    // the two delay reads of this sample (Delay::operator>> klang.h:3491-3500)
+		if (e_on && (e & (FX_CHUNK - 1)) == 0) { load_chunk(e >> 5); wg_sync_lds(); }
 		// ================= phase 1 =================
-		if (e < n) {                                                               // ---- early stage, sample e ----
-			const int wpos = (a.epos + e) % RV_ESIZE;
+		if (e_on) {                                                                // ---- early stage, sample e ----
 			if (efilter) {                                                         // EarlyReflections: in >> lpf >> hpf >> delay  Reverb.k:88
 				const float x = S.tile[(e >> 5) & 1][ech][e & 31][lane];
-				ering.wr(wpos, biquad_process(ehpf, biquad_process(elpf, x)));
+				Biquad elpf = { S.CF[0][lane], S.CF[1][lane], S.CF[2][lane], S.CF[3][lane], S.CF[4][lane], elz0, elz1 };
+				Biquad ehpf = { S.CF[5][lane], S.CF[6][lane], S.CF[7][lane], S.CF[8][lane], S.CF[9][lane], ehz0, ehz1 };
+				ering.wr(ewpos, biquad_process(ehpf, biquad_process(elpf, x)));
+				elz0 = elpf.z0; elz1 = elpf.z1; ehz0 = ehpf.z0; ehz1 = ehpf.z1;
 			}
 #pragma unroll
-			for (int q = 0; q < 3; q++) if (ej + 8 * q < 20) {
-				const float tap = ea[q] * (1.f - efr[q]) + eb[q] * efr[q];           // delay(times[d])
-				S.P[e & 1][ech * 20 + ej + 8 * q][lane] = tap * egain[q];            // ... * gains[d]
-			}
-			if (e + 1 < n) early_taps(e + 1, ea, eb, efr);                          // prefetch the next sample's rows
+			for (int q = 0; q < 3; q++) if (eload[q]) S.P[e & 1][ech * 20 + ej + 8 * q][lane] = prod[q];
+			ewpos = ring_next(ewpos, RV_ESIZE);
 		}
-		const int s_fd = (lr < 2) ? m : l;                                          // the sample this wave's FilteredDelay works on
-		const bool fd_on = s_fd >= 0 && s_fd < n;
-		float r0 = 0.f, r1v = 0.f, r2v = 0.f;
 		if (fd_on) {
-			if (lr < 2) {                                                           // mid[lr]: input = early reflections of channel lr
-				float sum = 0.f;                                                    // out = 0; for d: out += delay(times[d]) * gains[d]   Reverb.k:90-92
-				for (int d = 0; d < ecount; d++) sum += S.P[m & 1][lr * 20 + d][lane];
-				lr_in = sum;
-				if (kk == 0) S.R1[m & 3][lr][lane] = sum;
-			}
+			if (lr < 2) lr_in = S.R1[m & 3][lr][lane];                              // mid[lr]: input = early reflections of channel lr (summed in phase 2 of the previous iteration)
 			else {                                                                  // late[lr-2]: input = mid[lr-2] of the same sample
 				const float* om = &S.OM[l & 3][(lr - 2) * 4][lane];
 				lr_in = om[3 * 64] + (om[2 * 64] + (om[0] + om[64]));               // ((o0 + o1) + o2) + o3 as the reference's `+` chain associates
 			}
-			r0 = fr0; r1v = fr1; r2v = fr2;
-			const int wpos = (int)(((long long)a.fpos + 2LL * s_fd) % RV_FSIZE);
-			S.DL[wv][lane] = fd_proc(r0, r1v, wpos);                                // signals<4> delays = { delay[0..3] }: first process()
+			fring.wr(fwpos, fin);                                                   // FilteredDelay::process Reverb.k:130-132: (in >> delay >> filter) * gain
+			S.DL[wv][lane] = biquad_process(ff, fdt1) * fgain;                      // signals<4> delays = { delay[0..3] }: first process()
 		}
-		if (o >= 0 && o < n && outwave) {                                           // ---- output, sample o ----  Reflections::process + Reverb::process
+		if (o_on && outwave) {                                                      // ---- output, sample o ----  Reflections::process + Reverb::process
 			const float in = S.tile[(o >> 5) & 1][ech][o & 31][lane];
 			const float* om = &S.OM[o & 3][ech * 4][lane]; const float* ol = &S.OL[o & 3][ech * 4][lane];
 			const float r1o = S.R1[o & 3][ech][lane];
 			const float r2o = om[3 * 64] + (om[2 * 64] + (om[0] + om[64]));
 			const float r3o = ol[3 * 64] + (ol[2 * 64] + (ol[0] + ol[64]));
+			const float dry = S.CF[10][lane], c1 = S.CF[11][lane], c2 = S.CF[12][lane], c3 = S.CF[13][lane], wet = S.CF[14][lane];
 			const float refl = (r1o * c1 + r2o * c2) + r3o * c3;
 			S.tile[(o >> 5) & 1][ech][o & 31][lane] = in * dry + refl * (ech ? 0.f : wet);   // wet side is signals<2>{ wet, 0 }
 		}
-		__syncthreads();
+		wg_sync_lds();
 		// ================= phase 2 =================
 		if (fd_on) {
 			const float* dl = &S.DL[lr * 4][lane];
@@ -579,23 +604,38 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 			else if (kk == 2) fb = -1.f * d0 + 1.f * d1 + 0.f * d2 + -1.f * d3;
 			else fb = 1.f * d0 + -1.f * d1 + 1.f * d2 + 0.f * d3;
 			fin = fb + lr_in;                                                       // fb = (delays >> matrix) + in ; fb[k] >> delay[k]
-			const int wpos = (int)(((long long)a.fpos + 2LL * s_fd + 1) % RV_FSIZE);
-			const float o2 = fd_proc(r1v, r2v, wpos);                               // the `+` chain processes each FilteredDelay a second time
+			fring.wr(fwpos + 1, fin);                                               // fpos is even and RV_FSIZE is even: +1 never wraps
+			const float o2 = biquad_process(ff, fdt2) * fgain;                      // the `+` chain processes each FilteredDelay a second time
+			fwpos = (fwpos + 2 >= RV_FSIZE) ? fwpos + 2 - RV_FSIZE : fwpos + 2;
 			if (lr < 2) S.OM[s_fd & 3][wv][lane] = o2; else S.OL[s_fd & 3][wv - 8][lane] = o2;
-			flast = ring_next(ring_next(flast, RV_FSIZE), RV_FSIZE);
-			if (s_fd + 1 < n) { const int q1 = ring_next(flast, RV_FSIZE), q2 = ring_next(q1, RV_FSIZE); fr0 = fring.rd(flast); fr1 = fring.rd(q1); fr2 = fring.rd(q2); }
+			foff = fwrap(fwrap(foff + FROW) + FROW);
+			fr0 = r2v;                                                              // row last+2 of this sample is row `last` of the next
 		}
-		__syncthreads();
-		if (o >= 0 && o < n && ((o & (FX_CHUNK - 1)) == FX_CHUNK - 1 || o == n - 1)) { store_chunk(o >> 5); }
-	}
+		if (e_on && sumwave) {                                                      // waves 2 / 10: out = 0; for d < count: out += delay(times[d]) * gains[d]   Reverb.k:90-92
+			float p[20], sum = 0.f;                                                 // all twenty LDS reads are issued before the (sequential, as in the reference) add chain
+#pragma unroll
+			for (int d = 0; d < 20; d++) p[d] = S.P[e & 1][ech * 20 + d][lane];
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int d = 0; d < 20; d++) sum = (d < ecount) ? sum + p[d] : sum;
+			S.R1[e & 3][ech][lane] = sum;
+		}
+		wg_sync_lds();
+		if (o_on && ((o & (FX_CHUNK - 1)) == FX_CHUNK - 1 || o == n - 1)) { store_chunk(o >> 5); }
+	};
+	const std::true_type ramp; const std::false_type steady;
+	int t = -2;
+	for (; t <= 0 && t <= n; t++) { if (t & 1) step(ramp, t, B, A); else step(ramp, t, A, B); }      // even t: set A holds this iteration's rows
+	for (; t + 1 <= n - 4; t += 2) { step(steady, t, B, A); step(steady, t + 1, A, B); }                 // t is odd here
+	for (; t <= n; t++) { if (t & 1) step(ramp, t, B, A); else step(ramp, t, A, B); }
 	// ---- write back what changed ----
 	if (k < a.K) {
 		float* Wr = a.state + k;
 		Wr[(size_t)(fw + FD_Z0) * KP] = ff.z0; Wr[(size_t)(fw + FD_Z1) * KP] = ff.z1; Wr[(size_t)(fw + FD_IN) * KP] = fin;
-		Wr[(size_t)(fw + FD_LASTP) * KP] = __int_as_float(flast);
+		Wr[(size_t)(fw + FD_LASTP) * KP] = __int_as_float((int)((foff - fring.lane4) / FROW));
 		if (efilter) {
-			Wr[(size_t)(RV_EZ + 2 * ech) * KP] = elpf.z0; Wr[(size_t)(RV_EZ + 2 * ech + 1) * KP] = elpf.z1;
-			Wr[(size_t)(RV_EZ + 4 + 2 * ech) * KP] = ehpf.z0; Wr[(size_t)(RV_EZ + 4 + 2 * ech + 1) * KP] = ehpf.z1;
+			Wr[(size_t)(RV_EZ + 2 * ech) * KP] = elz0; Wr[(size_t)(RV_EZ + 2 * ech + 1) * KP] = elz1;
+			Wr[(size_t)(RV_EZ + 4 + 2 * ech) * KP] = ehz0; Wr[(size_t)(RV_EZ + 4 + 2 * ech + 1) * KP] = ehz1;
 		}
 	}
 #undef RVW
