@@ -274,6 +274,208 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 	}
 }
 
+// -------------------------------------------------------------------------------------------------
+// PingPong.k, eleven waves per 64 instances (the production kernel).
+//
+// Once every tap of a chunk lies further behind the write cursor than the chunk is long, the samples of the chunk no
+// longer depend on each other through the delay lines: only three short recurrences are sequential in time — the control
+// smoothing, and the two DC filters.  The kernel therefore cuts the block into chunks of PPX_CHUNK samples and runs
+// them through a three-stage pipeline, one stage per group of waves, one __syncthreads() per chunk:
+//   wave 0       CONTROL  of chunk j+1: Control::smooth x2, scratch detector, LFO, controls[1].set() -> delay time per sample
+//   waves 1..8   AUDIO    of chunk j:   wave w owns 4 consecutive samples: Delay::set, 24 ring rows in flight, interpolate,
+//                                       cross-feed, both ring writes; also fetches the io rows of chunk j+1
+//   waves 9, 10  FILTER   of chunk j-1: out.l / out.r >> dcfilter over the chunk; the io rows of chunk j-2 are stored
+// A chunk with a near tap (delay < ~0.8 ms, or within a chunk of the full line) is walked in order by wave 1 alone.
+// Arithmetic and its order are those of klg_fx_pingpong (KLG_FX_PINGPONG1=1) and the reference, bit for bit.
+enum { PPX_CHUNK = 32, PPX_AUDIO = 8, PPX_PER = PPX_CHUNK / PPX_AUDIO, PPX_WAVES = 1 + PPX_AUDIO + 2, PPX_THREADS = PPX_WAVES * 64 };
+
+struct PpxLds {
+	float tile[4][2][PPX_CHUNK][FX_LD];         // [chunk & 3][channel][sample][instance]: loaded, audio, filter, store
+	float D[2][PPX_CHUNK][64];                  // delay time (smoothed controls[1]) per sample, [chunk & 1]
+	int far[2];                                 // 1: every tap of the chunk is far from the write cursor
+};
+
+__global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongArgs a) {
+	__shared__ PpxLds S;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int k0 = blockIdx.x * FX_WG, k = k0 + lane;
+	const int SIZE = 192000, n = a.n;
+	const int nchunks = (n + PPX_CHUNK - 1) / PPX_CHUNK;
+	const bool w_control = wv == 0, w_audio = wv >= 1 && wv <= PPX_AUDIO, w_filter = wv > PPX_AUDIO;
+	const float* W = a.state + k;
+#define PPW(w) W[(size_t)(w) * a.kpad]
+	// ---- control wave state (PingPong.k:44-60) ----
+	float c1 = 0.f, c5 = 0.f, sm1 = 0.f, sm5 = 0.f, mdelay = 0.f, lfo_inc = 0.f, vibrato = 0.f;
+	BOsc lfo; lfo.position = 0.f; lfo.increment = 0.f; lfo.offset = 0.f;
+	bool any_vibrato = false;
+	if (w_control) {
+		const float c2 = PPW(2), c3 = PPW(3);
+		c1 = PPW(1); c5 = PPW(5); sm1 = PPW(PP_SM1); sm5 = PPW(PP_SM5); mdelay = PPW(PP_DELAY);
+		lfo.position = PPW(PP_LFO_POS); lfo.increment = PPW(PP_LFO_INC);
+		const float rate = (c3 * c3) * 100.f;                                      // sqr(controls[3]) * 100.f
+		lfo_inc = rate * 2.f * KLG_PI_F / a.fs.f;                                  // Oscillator::set(rate)  klang.h:2862-2865
+		vibrato = (c2 * c2) * rate * 1.41421354f;                                  // sqr(controls[2]) * rate * root2
+		any_vibrato = __ballot(vibrato != 0.f) != 0ull;
+	}
+	// ---- audio wave state ----
+	float gain = 0.f, dry = 0.f;
+	if (w_audio) { gain = PPW(0); dry = PPW(4); }
+	float* ring0 = a.rings + (size_t)blockIdx.x * 2 * SIZE * FX_WG;                // this workgroup's ring tile: [2][SIZE][64]
+	const unsigned lane4 = (unsigned)lane * 4u, ROW = FX_WG * 4u;
+	auto ring_rd = [&](int line, int i) { return *(const float*)((const char*)(ring0 + (size_t)line * SIZE * FX_WG) + ((unsigned)i * ROW + lane4)); };
+	auto ring_wr = [&](int line, int i, float v) { *(float*)((char*)(ring0 + (size_t)line * SIZE * FX_WG) + ((unsigned)i * ROW + lane4)) = v; };
+	auto wrap = [&](int i) { return i >= SIZE ? i - SIZE : i; };
+	// ---- filter wave state: dcfilter[ch].set(50, 1)  PingPong.k:39-40 ----
+	const int fch = wv - (PPX_AUDIO + 1);
+	Biquad dc = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, 0.f, 0.f };
+	if (w_filter) { dc.z0 = PPW(PP_Z + 2 * fch); dc.z1 = PPW(PP_Z + 2 * fch + 1); }
+
+	for (int j = -1; j <= nchunks + 1; j++) {
+		// ---------------- io rows of chunk j+1 (audio waves; landed in LDS at the end of the step) ----------------
+		const int jn = j + 1;
+		const bool load_next = w_audio && jn < nchunks;
+		float iov[8];
+		// (the thread index is laundered through an empty asm once per step: otherwise every per-thread address and bounds
+		//  predicate below is loop-invariant, gets hoisted out of the chunk loop, and ~100 VGPRs stay live for the whole kernel)
+		int at = tid - 64; asm volatile("" : "+v"(at));
+		const int acol = at & 31, arow = at >> 5;                                  // 512 audio threads: 16 rows x 32 samples per pass, 8 passes
+		const int ns0 = jn * PPX_CHUNK, ncl = (n - ns0 < PPX_CHUNK) ? (n - ns0) : PPX_CHUNK;
+		if (load_next) {
+			const char* src = (const char*)(a.io + (size_t)k0 * 2 * n + ns0);
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				const int row = arow + 16 * i, inst = row >> 1;
+				iov[i] = (acol < ncl && k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + acol) * 4u) : 0.f;
+			}
+		}
+		// ---------------- CONTROL of chunk j+1 ----------------
+		if (w_control && jn < nchunks) {
+			float dmin = 3.0e38f, dmax = 0.f;                                         // range of the delay time over the chunk
+			lfo.increment = lfo_inc;
+#pragma unroll 4
+			for (int u = 0; u < ncl; u++) {
+				sm5 = sm5 * 0.999f + (1.f - 0.999f) * c5;                           // controls[5].smooth()  klang.h:1715
+				const float new_delay = sm5;
+				// (double)fabsf(d) > 0.001  <=>  fabsf(d) >= 0.001f: 0.001f is the smallest float above the double 0.001
+				if (fabsf(mdelay - new_delay) >= 0.001f) {
+					mdelay = new_delay;
+					c1 = (new_delay < a.c1_min) ? a.c1_min : (a.c1_max < new_delay) ? a.c1_max : new_delay;   // controls[1].set()
+					lfo.position = KLG_PI_F;                                        // lfo.set(rate, pi)
+				}
+				else mdelay = c5;
+				sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                           // controls[1].smooth()
+				const float delay = sm1;
+				if (any_vibrato) {
+					const float lfo_out = basic_sine(lfo);                          // fp64 sin only when some instance uses it
+					const float nc1 = c1 + lfo_out * vibrato * 0.00005f;
+					c1 = (nc1 < a.c1_min) ? a.c1_min : (a.c1_max < nc1) ? a.c1_max : nc1;
+				}
+				else phase_advance(lfo.position, lfo_inc);                          // lfo * 0 * 5e-5 == +-0, c1 + (+-0) == c1 (c1 >= c1_min > 0) and c1 is already clamped
+				S.D[jn & 1][u][lane] = delay;
+				dmin = fminf(dmin, delay); dmax = fmaxf(dmax, delay);
+			}
+			// x -> 0.5f * x * fs and x -> x * fs are monotonic, so the extreme delays decide for the whole chunk
+			const bool far = 0.5f * dmin * a.fs.f >= (float)(PPX_CHUNK + 3) && dmax * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
+			const bool all_far = __ballot(k < a.K && !far) == 0ull;                 // padding lanes (zero state, zero delay) do not veto
+			if (lane == 0) S.far[jn & 1] = all_far ? 1 : 0;
+		}
+		// ---------------- AUDIO of chunk j ----------------
+		if (w_audio && j >= 0 && j < nchunks) {
+			const int s0 = j * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
+			const int pos0 = (int)(((long long)a.position + s0) % SIZE);
+			float (*T)[PPX_CHUNK][FX_LD] = S.tile[j & 3];
+			if (S.far[j & 1]) {
+				const int u0 = (wv - 1) * PPX_PER;
+				Tap tl[PPX_PER], tr[PPX_PER];
+				float pl[PPX_PER][3], pr[PPX_PER][3];
+#pragma unroll
+				for (int q = 0; q < PPX_PER; q++) if (u0 + q < cl) {
+					const float delay = S.D[j & 1][u0 + q][lane];
+					const int pos = wrap(pos0 + u0 + q);
+					tl[q] = delay_set(pos, SIZE, delay * a.fs.f);                   // left.set(delay * fs)
+					tr[q] = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);            // right.set(0.5f * delay * fs)
+					const int i0 = tl[q].position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
+					const int j0 = tr[q].position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
+					pl[q][0] = ring_rd(0, i0); pl[q][1] = ring_rd(0, i1); pl[q][2] = ring_rd(0, i2);
+					pr[q][0] = ring_rd(1, j0); pr[q][1] = ring_rd(1, j1); pr[q][2] = ring_rd(1, j2);
+				}
+#pragma unroll
+				for (int q = 0; q < PPX_PER; q++) if (u0 + q < cl) {
+					const int u = u0 + q, pos = wrap(pos0 + u);
+					const float in_l = T[0][u][lane], in_r = T[1][u][lane];
+					// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
+					const float r1 = pr[q][0] + tr[q].fraction * (pr[q][1] - pr[q][0]);
+					ring_wr(0, pos, in_l + r1 * gain);
+					const float l1 = pl[q][0] + tl[q].fraction * (pl[q][1] - pl[q][0]);
+					const float l2 = pl[q][1] + tl[q].fraction * (pl[q][2] - pl[q][1]);
+					T[0][u][lane] = dry * in_l + l1 * (1.f - dry);
+					// dry * in.r + (1.f - dry) * ((in.r + left * gain) >> right) >> out.r;   PingPong.k:67
+					ring_wr(1, pos, in_r + l2 * gain);
+					const float r2 = pr[q][1] + tr[q].fraction * (pr[q][2] - pr[q][1]);
+					T[1][u][lane] = dry * in_r + r2 * (1.f - dry);
+				}
+			}
+			else if (wv == 1) {                                                     // a near tap: the chunk is walked in order by one wave
+				Ring left = { ring0 + lane, FX_WG, SIZE }, right = { ring0 + (size_t)SIZE * FX_WG + lane, FX_WG, SIZE };
+				for (int u = 0; u < cl; u++) {
+					const float delay = S.D[j & 1][u][lane];
+					const int pos = wrap(pos0 + u);
+					Tap tl = delay_set(pos, SIZE, delay * a.fs.f), tr = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);
+					const float in_l = T[0][u][lane], in_r = T[1][u][lane];
+					const float r1 = delay_process(right, tr);
+					left.wr(pos, in_l + r1 * gain);
+					const float l1 = delay_process(left, tl), l2 = delay_process(left, tl);
+					T[0][u][lane] = dry * in_l + l1 * (1.f - dry);
+					right.wr(pos, in_r + l2 * gain);
+					const float r2 = delay_process(right, tr);
+					T[1][u][lane] = dry * in_r + r2 * (1.f - dry);
+				}
+			}
+		}
+		// ---------------- store of chunk j-2 (first: its write acknowledgements have the whole step to arrive), FILTER of chunk j-1 ----------------
+		if (w_filter && j >= 2) {
+			const int js = j - 2, s0 = js * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
+			float (*T)[FX_LD] = S.tile[js & 3][fch];
+			int sl = lane; asm volatile("" : "+v"(sl));
+			const int col = sl & 31, half = sl >> 5;
+			char* dst = (char*)(a.io + (size_t)k0 * 2 * n + s0);
+#pragma unroll 8
+			for (int it = 0; it < 32; it++) {
+				const int inst = 2 * it + half;
+				if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
+			}
+		}
+		if (w_filter && j >= 1 && j <= nchunks) {
+			const int jf = j - 1, s0 = jf * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
+			float (*T)[FX_LD] = S.tile[jf & 3][fch];
+			for (int b = 0; b < PPX_CHUNK; b += 8) {                                  // eight LDS reads in flight, then the (sequential) filter
+				float x[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++) x[u] = T[b + u][lane];
+#pragma unroll
+				for (int u = 0; u < 8; u++) if (b + u < cl) x[u] = biquad_process(dc, x[u]);     // out >> dcfilter[ch] >> out
+#pragma unroll
+				for (int u = 0; u < 8; u++) T[b + u][lane] = x[u];
+			}
+		}
+		if (load_next) {
+#pragma unroll
+			for (int i = 0; i < 8; i++) { const int row = arow + 16 * i; S.tile[jn & 3][row & 1][acol][row >> 1] = iov[i]; }
+		}
+		__syncthreads();
+	}
+	if (k < a.K) {
+		float* Wr = a.state + k;
+		if (w_control) {
+			Wr[(size_t)1 * a.kpad] = c1; Wr[(size_t)PP_SM1 * a.kpad] = sm1; Wr[(size_t)PP_SM5 * a.kpad] = sm5; Wr[(size_t)PP_DELAY * a.kpad] = mdelay;
+			Wr[(size_t)PP_LFO_POS * a.kpad] = lfo.position; Wr[(size_t)PP_LFO_INC * a.kpad] = lfo.increment;
+		}
+		if (w_filter) { Wr[(size_t)(PP_Z + 2 * fch) * a.kpad] = dc.z0; Wr[(size_t)(PP_Z + 2 * fch + 1) * a.kpad] = dc.z1; }
+	}
+#undef PPW
+}
+
 // =================================================================================================
 // Reverb.k
 // =================================================================================================

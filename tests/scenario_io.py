@@ -11,6 +11,10 @@ import numpy as np
 EV_ON, EV_OFF, EV_CTL = 0, 1, 2
 
 
+def _f32(x):
+    return float(np.float32(x))
+
+
 @dataclass
 class Scenario:
     patch: str
@@ -26,14 +30,17 @@ class Scenario:
     burst: int = 0
     seed: int = 0
 
+    # Event values are quantised to float32 HERE: the text form ("%.9g") round-trips a float32 exactly, whereas a python
+    # double printed with 9 digits and re-read can round to the neighbouring float32 (the oracle reads the text, the GPU
+    # driver gets the python value: they must see the same float).
     def on(self, block, synth, pitch, velocity, seed=-1):
-        self.ev.append((int(block), EV_ON, int(synth), float(pitch), float(velocity), int(seed)))
+        self.ev.append((int(block), EV_ON, int(synth), float(pitch), _f32(velocity), int(seed)))
 
     def off(self, block, synth, pitch, velocity=0.0):
-        self.ev.append((int(block), EV_OFF, int(synth), float(pitch), float(velocity), -1))
+        self.ev.append((int(block), EV_OFF, int(synth), float(pitch), _f32(velocity), -1))
 
     def control(self, block, synth, index, value):
-        self.ev.append((int(block), EV_CTL, int(synth), float(index), float(value), -1))
+        self.ev.append((int(block), EV_CTL, int(synth), float(index), _f32(value), -1))
 
     def sort(self):
         self.ev.sort(key=lambda e: e[0])             # stable: keeps file order inside a block
@@ -50,7 +57,7 @@ class Scenario:
             lines += [f"synths {self.synths}", f"notes {self.notes}"]
         lines.append("dump %d %s" % (len(self.dump), " ".join(str(d) for d in self.dump)))
         for i, v in self.ctl:
-            lines.append(f"ctl {i} {v:.9g}")
+            lines.append(f"ctl {i} {_f32(v):.9g}")
         for b, t, s, a, bb, seed in self.ev:
             lines.append(f"ev {b} {t} {s} {a:.9g} {bb:.9g} {seed}")
         lines.append("end")

@@ -49,6 +49,28 @@ def test_fx_against_oracle_many_instances(patch, instances, blocks, oracle_build
     assert err <= TOL
 
 
+def test_pingpong_near_taps_and_vibrato(oracle_build):
+    """Delays shorter than a pipeline chunk (the in-order path of klg_fx_pingpong_x), delays that cross the near/far
+    threshold while the smoothed control glides, and LFO vibrato — all against the oracle."""
+    K = 130
+    s = Scenario(patch="pingpong", block=192, blocks=20, instances=K, burst=2500, seed=11, dump=list(range(0, 20, 2)))
+    rng = np.random.default_rng(9)
+    for k in range(K):
+        s.control(0, k, 0, float(rng.uniform(0.3, 0.95)))
+        s.control(0, k, 1, float(rng.choice([0.001, 0.0012, 0.0016, 0.002, 0.004, 0.3])))
+        s.control(0, k, 2, float(rng.uniform(0.0, 1.0)))
+        s.control(0, k, 3, float(rng.uniform(0.01, 1.0)))
+        s.control(0, k, 4, float(rng.uniform(0.0, 1.0)))
+    for k in range(0, K, 3):                                   # glide from short to long and back
+        s.control(6, k, 1, 0.5)
+        s.control(12, k, 1, 0.001)
+    ref = run_scenario_oracle(s, oracle_build)["per_voice"]
+    got = run_fx_scenario_gpu(s)["per_voice"]
+    err = rel_err(got, ref)
+    print(f"pingpong near: rel err {err:.3e}, bit-exact {100 * bit_exact_fraction(got, ref):.2f}%")
+    assert err <= TOL
+
+
 def test_fx_block_size_independence():
     """Property: 4 x 64-sample blocks == 1 x 256-sample block, bit for bit (PingPong, GPU vs GPU)."""
     def render(block, blocks):

@@ -155,10 +155,10 @@ def main():
         r = gpu_synth("fm4", 131072, 256, 50, 30); r["config"] = "cfg5 (per-GPU share): 131,072-voice 4-operator FM, N=256"; r["cpu_1core"] = cpu_synth(ko, "fm4", 256, args.cpu_budget); emit(r)
         r = gpu_synth("fm3", 131072, 256, 50, 30); r["config"] = "FM.k (3 operators): 131,072 voices"; r["cpu_1core"] = cpu_synth(ko, "fm3", 256, args.cpu_budget); emit(r)
     if want("cfg4"):
-        for K in ((256, 4096) if not args.quick else (256,)):
+        for K in ((256, 4096, 65536) if not args.quick else (256,)):
             r = gpu_fx("pingpong", K, 256, 40, 5); r["config"] = f"cfg4: {K} x PingPong.k, N=256"; emit(r)
         rows[-1]["cpu_1core"] = cpu_fx(ko, "pingpong", 256, args.cpu_budget)
-        for K in ((256, 4096) if not args.quick else (64,)):
+        for K in ((256, 4096, 16384) if not args.quick else (64,)):
             r = gpu_fx("reverb", K, 256, 20, 3); r["config"] = f"cfg4: {K} x Reverb.k, N=256"; emit(r)
         rows[-1]["cpu_1core"] = cpu_fx(ko, "reverb", 256, args.cpu_budget)
         print(json.dumps({"cpu_pingpong_1core": rows[-3].get("cpu_1core"), "cpu_reverb_1core": rows[-1]["cpu_1core"]}))

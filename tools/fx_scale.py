@@ -1,8 +1,12 @@
+"""tools/fx_scale.py [patch K K ...]... — effect kernel time vs instance count (HIP-event kernel time via klg_fx_timing_*)."""
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, klang_amd
-patch = sys.argv[1]
-for K in [int(x) for x in sys.argv[2:]]:
+jobs, patch = [], None
+for a in sys.argv[1:]:
+    if a.isdigit(): jobs.append((patch, int(a)))
+    else: patch = a
+for patch, K in jobs:
     N = 256
     bank = klang_amd.FxBank(patch, K, max_block=N)
     g = torch.Generator(device="cuda").manual_seed(1)
