@@ -626,8 +626,9 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
 // This kernel gives the same 64 instances (lane = instance, as before) to a workgroup of SIXTEEN waves:
 //   wave w  = FilteredDelay w   (LateReflections a = w / 4: mid[0], mid[1], late[0], late[1]; line k = w % 4)
 //           + the early-reflection products of channel w / 8 for taps (w % 8), +8, +16
-//   waves 0 / 8 also run the early LPF >> HPF of the left / right channel and write the early rings,
-//   waves 1 / 9 produce the left / right output sample.
+//   three per-channel extras are spread over the four SIMDs (wave w runs on SIMD w % 4): waves 1 / 11 run the early
+//   LPF >> HPF of the left / right channel and write the early rings, waves 2 / 8 sum the forty early products, waves
+//   3 / 13 produce the left / right output sample.
 // The three stages run skewed so that every wave has work between the same two barriers: in iteration t the early
 // stage handles sample t+2, mid[] handles t+1, late[] handles t, the output sample t-1.  Values cross waves through
 // LDS (double-buffered by sample slot); there is no cross-lane traffic at all.  Each wave prefetches the ring rows of

@@ -231,7 +231,8 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		a.fpos = (int)((2ull * f->samples) % (unsigned long long)RV_FSIZE);
 		a.io = d_io; a.n = n;
 		static const bool single_wave = []() { const char* e = getenv("KLG_FX_REVERB1"); return e && e[0] == '1'; }();
-		if (single_wave) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);                 // one lane walks the whole graph (A/B reference)
+		// klg_fx_reverb16 requests ring rows one sample ahead: safe while the shortest line (7 ms * 0.9) is a few samples long
+		if (single_wave || f->fs.f < 4000.f) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);   // one lane walks the whole graph (A/B reference)
 		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances
 	}
 	HIP_TRY(hipGetLastError());
