@@ -115,6 +115,23 @@ int klg_sync(klg_synth* s);
 int klg_voice_download(klg_synth* s, int voice, void* state, size_t bytes);
 int klg_voice_upload(klg_synth* s, int voice, const void* state, size_t bytes);
 
+/* Bulk form of klg_voice_upload: record i (AoS, klg_synth_state_bytes() bytes each) replaces the state of voices[i];
+ * queued and applied by one kernel at the start of the next block (how a host starts many notes at once). */
+int klg_voices_upload(klg_synth* s, int n, const int* voices, const void* states);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph patches (format and record layout: include/klang_mi355_graph.h).
+ * replaces: constructing a user Synth whose Note::process() body (klang.h:4295-4303 calls it per sample) is not one of
+ * the klg_patch ids above.  `program` is the body recorded by the DSL facade (include/klang/klang.h runs the user's
+ * process() once in recording mode); it is compiled for gfx950 with hipRTC on top of the same device primitives and
+ * render kernel as the shipped patches.  on()/off() stay with the caller: note events arrive as voice records
+ * (klg_voice_download / klg_voice_upload / klg_voices_upload); klg_note_on / klg_note_off are rejected for such a bank.
+ * klg_graph_check compiles a program WITHOUT a device (0, or KLG_ERR_INVALID with the message in `out`; with
+ * want_source != 0 a successful check returns the generated HIP source instead).
+ * ------------------------------------------------------------------------------------------------ */
+klg_synth* klg_synth_create_graph(const char* program, int synths, int notes_per_synth, float sample_rate, int max_block);
+int klg_graph_check(const char* program, int want_source, char* out, size_t out_cap);
+
 /* Measurement hooks used by bench.py: timing of the render kernel with HIP events recorded on the
  * stream the kernel is launched on.  klg_timing_begin() arms it, klg_timing_end() returns the number of
  * render launches since begin and their summed duration in milliseconds. */

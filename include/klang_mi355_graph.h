@@ -1,0 +1,200 @@
+/* include/klang_mi355_graph.h — "graph patches": the per-sample body of a user Note::process(), recorded as a
+ * straight-line program over klang's primitives and compiled for gfx950 at run time.
+ *
+ * The five shipped patch ids of klang_mi355.h are hand-written kernels.  A graph patch removes that limit for
+ * synth notes whose process() is a feed-forward chain of the primitives below: the DSL façade
+ * (include/klang/klang.h) runs the user's process() ONCE in recording mode — every `>>`, `++`, arithmetic
+ * operator and set() call appends an op instead of computing — and hands the program text to
+ * klg_synth_create_graph(), which generates a patch body on top of the same device primitives
+ * (klang_amd/csrc/klg_device.hpp) and the same render kernel (klg_render<P>) the shipped patches use, compiles it
+ * with hipRTC for gfx950 and loads it.  on()/off() keep running on the host as written; voice state moves with
+ * klg_voice_download / klg_voice_upload in the record layout defined here.
+ *
+ * Program text (one statement per line, '#' starts a comment):
+ *     klgg 1
+ *     ctl <count>                         number of controls of the synth (<= 8)
+ *     dial <i> <min> <max> <initial>      Dial(...) of control i              klang.h:1797-1800
+ *     node <id> <kind>                    a primitive object of the Note, ids 0,1,2,... in order
+ *     op <code> <dst> <a> <b> <node> <imm>   one op; unused fields are -1; imm = IEEE-754 bits (hex) of a constant
+ *     ret <reg>                           the register holding `out` at the end of process()
+ *     end
+ * Registers are single-assignment fp32 values.  Record layout: word 0 = flags (bits 0-1 NoteBase::stage), then the
+ * words of node 0, node 1, ... in order (node_words()).
+ */
+#ifndef KLANG_MI355_GRAPH_H
+#define KLANG_MI355_GRAPH_H
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace klg { namespace graph {
+
+/* node kinds and their record words */
+enum NodeKind {
+	N_FSINE = 0,    /* Generators::Fast::Sine          klang.h:5135-5172   words: inc, pos */
+	N_SAW = 1,      /* Fast::OSM, saw family (Saw, Triangle)   5175-5354   words: inc, offset, duty, delta, state */
+	N_PULSE = 2,    /* Fast::OSM, pulse family (Square, Pulse)             same words */
+	N_LPF = 3,      /* Filters::Biquad::LPF             5550-5666           words: b0 b1 b2 a1 a2 z0 z1 f Q */
+	N_ENV = 4,      /* Envelope, <= 4 breakpoints, no loop  3867-4102       words: r_out r_target r_rate time bits npoints px[4] py[4] */
+	N_ADSR = 5,     /* ADSR                             4105-4137           words: r_out r_target r_rate time bits A AD S R */
+	N_PARAM = 6,    /* a signal / param member of the Note that process() reads (and may write)   words: value */
+	N_KINDS
+};
+enum { FSINE_INC = 0, FSINE_POS, FSINE_WORDS };
+enum { OSM_INC = 0, OSM_OFFSET, OSM_DUTY, OSM_DELTA, OSM_STATE, OSM_WORDS };
+enum { LPF_B0 = 0, LPF_B1, LPF_B2, LPF_A1, LPF_A2, LPF_Z0, LPF_Z1, LPF_F, LPF_Q, LPF_WORDS };
+enum { ENV_OUT = 0, ENV_TARGET, ENV_RATE, ENV_TIME, ENV_BITS, ENV_NPOINTS, ENV_PX, ENV_PY = ENV_PX + 4, ENV_WORDS = ENV_PY + 4 };
+enum { ADSR_OUT = 0, ADSR_TARGET, ADSR_RATE, ADSR_TIME, ADSR_BITS, ADSR_A, ADSR_AD, ADSR_S, ADSR_R, ADSR_WORDS };
+enum { MAX_WORDS = 128, MAX_NODES = 64, MAX_OPS = 1024 };
+
+inline int node_words(int kind) {
+	switch (kind) {
+	case N_FSINE: return FSINE_WORDS;
+	case N_SAW: case N_PULSE: return OSM_WORDS;
+	case N_LPF: return LPF_WORDS;
+	case N_ENV: return ENV_WORDS;
+	case N_ADSR: return ADSR_WORDS;
+	case N_PARAM: return 1;
+	}
+	return 0;
+}
+inline const char* node_name(int kind) {
+	static const char* names[N_KINDS] = { "fsine", "saw", "pulse", "lpf", "env", "adsr", "param" };
+	return (kind >= 0 && kind < N_KINDS) ? names[kind] : "?";
+}
+
+/* ops: dst = code(a, b, node, imm) */
+enum OpCode {
+	OP_CONST = 0,   /* dst = imm                                                                      */
+	OP_CTL,         /* dst = controls[imm]                 (the synth instance's control value)      */
+	OP_PARAM,       /* dst = value word of N_PARAM node                                               */
+	OP_OSC,         /* dst = oscillator node process()     Fast::Sine / OSM saw / OSM pulse           */
+	OP_LPF,         /* dst = (a >> lpf node)               Biquad::Filter::process klang.h:5605-5612  */
+	OP_LPFSET,      /* lpf node .set(f = a, Q = b)         Biquad::LPF::set klang.h:5575-5600, 5658   */
+	OP_ENV,         /* dst = env/adsr node ++              Envelope::operator++ klang.h:4013-4051     */
+	OP_ADD, OP_SUB, OP_MUL, OP_DIV,   /* dst = a op b      fp32, IEEE, no contraction                 */
+	OP_NEG,         /* dst = -a                                                                       */
+	OP_STOPIF,      /* if (env/adsr node .finished()) stop();   klang.h:4094, 4276-4279               */
+	OP_STOP,        /* stop();                                                                        */
+	OP_SETPARAM,    /* N_PARAM node = a                    (a member written by process(): next sample reads it) */
+	OP_CODES
+};
+inline const char* op_name(int code) {
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam" };
+	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
+}
+
+struct Op { int code, dst, a, b, node; uint32_t imm; };
+struct Dial { float min, max, initial; };
+
+struct Program {
+	int nctl = 0;
+	Dial dials[8] = {};
+	std::vector<int> nodes;      /* kind of node i */
+	std::vector<Op> ops;
+	int ret = -1;
+
+	int words() const { int w = 1; for (int k : nodes) w += node_words(k); return w; }
+	int node_word0(int node) const { int w = 1; for (int i = 0; i < node; i++) w += node_words(nodes[(size_t)i]); return w; }
+
+	std::string text() const {
+		std::string s = "klgg 1\n";
+		char line[160];
+		snprintf(line, sizeof line, "ctl %d\n", nctl); s += line;
+		for (int i = 0; i < nctl; i++) { snprintf(line, sizeof line, "dial %d %.9g %.9g %.9g\n", i, dials[i].min, dials[i].max, dials[i].initial); s += line; }
+		for (size_t i = 0; i < nodes.size(); i++) { snprintf(line, sizeof line, "node %zu %s\n", i, node_name(nodes[i])); s += line; }
+		for (const Op& o : ops) { snprintf(line, sizeof line, "op %s %d %d %d %d %08x\n", op_name(o.code), o.dst, o.a, o.b, o.node, o.imm); s += line; }
+		snprintf(line, sizeof line, "ret %d\nend\n", ret); s += line;
+		return s;
+	}
+
+	/* returns "" on success, else a message */
+	std::string parse(const char* text) {
+		*this = Program();
+		if (!text) return "program is NULL";
+		std::string t(text);
+		size_t pos = 0; int lineno = 0; bool header = false, ended = false;
+		while (pos < t.size() && !ended) {
+			size_t e = t.find('\n', pos); if (e == std::string::npos) e = t.size();
+			std::string ln = t.substr(pos, e - pos); pos = e + 1; lineno++;
+			const size_t hash = ln.find('#'); if (hash != std::string::npos) ln.resize(hash);
+			char kw[32] = { 0 }; int n = 0;
+			if (sscanf(ln.c_str(), " %31s%n", kw, &n) != 1) continue;
+			const char* rest = ln.c_str() + n;
+			auto bad = [&](const char* why) { char m[200]; snprintf(m, sizeof m, "graph program line %d: %s: '%s'", lineno, why, ln.c_str()); return std::string(m); };
+			if (!strcmp(kw, "klgg")) { int v = 0; if (sscanf(rest, "%d", &v) != 1 || v != 1) return bad("unsupported version"); header = true; }
+			else if (!header) return bad("missing 'klgg 1' header");
+			else if (!strcmp(kw, "ctl")) { if (sscanf(rest, "%d", &nctl) != 1 || nctl < 0 || nctl > 8) return bad("ctl count must be 0..8"); }
+			else if (!strcmp(kw, "dial")) { int i; float a, b, c; if (sscanf(rest, "%d %g %g %g", &i, &a, &b, &c) != 4 || i < 0 || i >= nctl) return bad("bad dial"); dials[i] = { a, b, c }; }
+			else if (!strcmp(kw, "node")) {
+				int id; char kind[32];
+				if (sscanf(rest, "%d %31s", &id, kind) != 2 || id != (int)nodes.size()) return bad("nodes must be numbered 0,1,2,... in order");
+				int k = -1; for (int q = 0; q < N_KINDS; q++) if (!strcmp(kind, node_name(q))) k = q;
+				if (k < 0) return bad("unknown node kind");
+				if ((int)nodes.size() >= MAX_NODES) return bad("too many nodes");
+				nodes.push_back(k);
+			}
+			else if (!strcmp(kw, "op")) {
+				char code[32]; Op o; unsigned imm;
+				if (sscanf(rest, "%31s %d %d %d %d %x", code, &o.dst, &o.a, &o.b, &o.node, &imm) != 6) return bad("op needs: code dst a b node imm");
+				o.imm = imm; o.code = -1; for (int q = 0; q < OP_CODES; q++) if (!strcmp(code, op_name(q))) o.code = q;
+				if (o.code < 0) return bad("unknown op code");
+				if ((int)ops.size() >= MAX_OPS) return bad("too many ops");
+				ops.push_back(o);
+			}
+			else if (!strcmp(kw, "ret")) { if (sscanf(rest, "%d", &ret) != 1) return bad("bad ret"); }
+			else if (!strcmp(kw, "end")) ended = true;
+			else return bad("unknown statement");
+		}
+		if (!header) return "graph program: missing 'klgg 1' header";
+		if (!ended) return "graph program: missing 'end'";
+		return validate();
+	}
+
+	/* single assignment, defined-before-use, node kinds match their ops */
+	std::string validate() const {
+		if (words() > MAX_WORDS) return "graph program: the voice record exceeds 128 words";
+		std::vector<char> defined;
+		auto def = [&](int r) { return r >= 0 && r < (int)defined.size() && defined[(size_t)r]; };
+		auto kind = [&](int n) { return (n >= 0 && n < (int)nodes.size()) ? nodes[(size_t)n] : -1; };
+		char m[160];
+		for (size_t i = 0; i < ops.size(); i++) {
+			const Op& o = ops[i];
+			auto bad = [&](const char* why) { snprintf(m, sizeof m, "graph program op %zu (%s): %s", i, op_name(o.code), why); return std::string(m); };
+			bool need_a = false, need_b = false, has_dst = true; int k = kind(o.node);
+			switch (o.code) {
+			case OP_CONST: break;
+			case OP_CTL: if ((int)o.imm >= nctl) return bad("control index out of range"); break;
+			case OP_PARAM: if (k != N_PARAM) return bad("node is not a param"); break;
+			case OP_OSC: if (k != N_FSINE && k != N_SAW && k != N_PULSE) return bad("node is not an oscillator"); break;
+			case OP_LPF: if (k != N_LPF) return bad("node is not an lpf"); need_a = true; break;
+			case OP_LPFSET: if (k != N_LPF) return bad("node is not an lpf"); need_a = need_b = true; has_dst = false; break;
+			case OP_ENV: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); break;
+			case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: need_a = need_b = true; break;
+			case OP_NEG: need_a = true; break;
+			case OP_STOPIF: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); has_dst = false; break;
+			case OP_STOP: has_dst = false; break;
+			case OP_SETPARAM: if (k != N_PARAM) return bad("node is not a param"); need_a = true; has_dst = false; break;
+			default: return bad("unknown code");
+			}
+			if (need_a && !def(o.a)) return bad("operand a is not defined");
+			if (need_b && !def(o.b)) return bad("operand b is not defined");
+			if (has_dst) {
+				if (o.dst < 0 || o.dst >= MAX_OPS) return bad("bad destination register");
+				if ((int)defined.size() <= o.dst) defined.resize((size_t)o.dst + 1, 0);
+				if (defined[(size_t)o.dst]) return bad("register assigned twice");
+				defined[(size_t)o.dst] = 1;
+			}
+		}
+		if (!def(ret)) return "graph program: 'ret' names an undefined register";
+		return "";
+	}
+};
+
+} }  /* namespace klg::graph */
+#endif

@@ -9,7 +9,13 @@
  */
 #ifndef KLANG_MI355_RECORDS_H
 #define KLANG_MI355_RECORDS_H
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#else            /* hiprtc (generated patches): no libc headers, the fixed-width types are spelled out */
+typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;
+typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+#endif
 
 namespace klg {
 

@@ -24,8 +24,12 @@ class SynthBank:
         if device is not None:
             ids = (C.c_int * 1)(int(device))
             check(self._L.klg_init(ids, 1), "klg_init")
-        pid = PATCH_IDS[patch] if isinstance(patch, str) else int(patch)
-        h = self._L.klg_synth_create(pid, int(synths), int(notes), float(fs), int(max_block))
+        if isinstance(patch, str) and patch.lstrip().startswith("klgg"):       # a graph program (include/klang_mi355_graph.h)
+            h = self._L.klg_synth_create_graph(patch.encode(), int(synths), int(notes), float(fs), int(max_block))
+            patch = "graph"
+        else:
+            pid = PATCH_IDS[patch] if isinstance(patch, str) else int(patch)
+            h = self._L.klg_synth_create(pid, int(synths), int(notes), float(fs), int(max_block))
         if not h:
             raise KlangError("klg_synth_create failed: " + self._L.klg_last_error().decode())
         self._h = h
@@ -114,6 +118,12 @@ class SynthBank:
     def voice_upload(self, voice, words):
         words = np.ascontiguousarray(words, dtype=np.uint32)
         check(self._L.klg_voice_upload(self._h, int(voice), words.ctypes.data_as(C.c_void_p), words.nbytes), "klg_voice_upload")
+
+    def voices_upload(self, voices, words):
+        """words[i] (one record each) replaces the state of voices[i]; applied at the start of the next block."""
+        voices = np.ascontiguousarray(voices, dtype=np.int32)
+        words = np.ascontiguousarray(words, dtype=np.uint32).reshape(len(voices), self.state_bytes // 4)
+        check(self._L.klg_voices_upload(self._h, len(voices), voices.ctypes.data_as(C.POINTER(C.c_int)), words.ctypes.data_as(C.c_void_p)), "klg_voices_upload")
 
     def timing_begin(self):
         check(self._L.klg_timing_begin(self._h), "klg_timing_begin")

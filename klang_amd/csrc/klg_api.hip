@@ -14,6 +14,7 @@
 #include "../../include/klang_mi355.h"
 #include "../../include/klang/host_dsl.hpp"
 #include "klg_kernels.hpp"
+#include "klg_graph.hpp"
 #include "klg_fx.hpp"
 #include "klg_render_x2.hpp"
 
@@ -105,6 +106,10 @@ struct klg_synth {
 	uint32_t* d_scratch_rec = nullptr;
 	int grid = 0;
 	bool x2 = true;               // KLG_RENDER_X1=1 in the environment selects the one-voice-per-lane kernel (A/B tests)
+	// graph patches (klg_graph.hpp): the render kernels come from a hipRTC code object instead of this library
+	const graphrt::Compiled* graph = nullptr;
+	hipModule_t module = nullptr;
+	hipFunction_t graph_fn[2] = { nullptr, nullptr };
 	// host mirrors
 	std::vector<host::ControlH> controls;        // [S][nctl]
 	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
@@ -134,14 +139,15 @@ static void synth_free(klg_synth* s) {
 	void* pinned[] = { s->h_stage, s->h_mix, s->h_flags, s->h_per_voice };
 	for (void* p : pinned) if (p) (void)hipHostFree(p);
 	if (s->stage_done) (void)hipEventDestroy(s->stage_done);
+	if (s->module) (void)hipModuleUnload(s->module);
 	for (auto e : s->tev) (void)hipEventDestroy(e);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	delete s;
 }
 
-extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_synth, float sample_rate, int max_block) {
-	const PatchInfo* pi = patch_info(patch_id);
-	if (!pi || pi->words == 0) { fail(KLG_ERR_INVALID, "klg_synth_create: patch %d is not a synth patch", patch_id); return nullptr; }
+enum { KLG_PATCH_GRAPH = 1000 };     // klg_synth::patch of a graph patch (not a klg_patch id)
+
+static klg_synth* synth_create_common(int patch_id, const PatchInfo* pi, int synths, int notes_per_synth, float sample_rate, int max_block) {
 	if (synths <= 0 || notes_per_synth <= 0 || notes_per_synth > 128) { fail(KLG_ERR_INVALID, "klg_synth_create: synths=%d notes_per_synth=%d (1..128, Array<NOTE*,128>)", synths, notes_per_synth); return nullptr; }
 	if (max_block <= 0 || max_block > MAX_BLOCK) { fail(KLG_ERR_INVALID, "klg_synth_create: max_block %d not in 1..%d", max_block, (int)MAX_BLOCK); return nullptr; }
 	if (!(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_synth_create: bad sample rate"); return nullptr; }
@@ -162,7 +168,7 @@ extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_s
 	ok = ok && hipMalloc(&s->d_controls, (size_t)s->S * KLG_MAX_CTL * 4) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_partials, (size_t)s->grid * max_block * 4) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_mix, (size_t)2 * max_block * 4) == hipSuccess;
-	ok = ok && hipMalloc(&s->d_scratch_rec, 64 * 4) == hipSuccess;
+	ok = ok && hipMalloc(&s->d_scratch_rec, (size_t)std::max(64, s->W) * 4) == hipSuccess;
 	ok = ok && hipHostMalloc(&s->h_mix, (size_t)2 * max_block * 4) == hipSuccess;
 	ok = ok && hipHostMalloc(&s->h_flags, s->stride * 4) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&s->stage_done, hipEventDisableTiming) == hipSuccess;
@@ -185,6 +191,40 @@ extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_s
 	return s;
 }
 
+extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_synth, float sample_rate, int max_block) {
+	const PatchInfo* pi = patch_info(patch_id);
+	if (!pi || pi->words == 0) { fail(KLG_ERR_INVALID, "klg_synth_create: patch %d is not a synth patch", patch_id); return nullptr; }
+	return synth_create_common(patch_id, pi, synths, notes_per_synth, sample_rate, max_block);
+}
+
+// replaces: constructing a user Synth whose Note::process() is NOT one of the shipped patch ids: the recorded body
+// (include/klang_mi355_graph.h) is compiled for gfx950 with hipRTC and rendered by the same klg_render kernel.
+extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, int notes_per_synth, float sample_rate, int max_block) {
+	const graphrt::Compiled* c = nullptr;
+	const std::string err = graphrt::compile(program, &c);
+	if (!err.empty()) { fail(KLG_ERR_INVALID, "klg_synth_create_graph: %s", err.c_str()); return nullptr; }
+	graph::Program g; (void)g.parse(program);
+	PatchInfo pi = {};
+	pi.words = c->words; pi.ncontrols = g.nctl;
+	for (int i = 0; i < g.nctl; i++) pi.dials[i] = { g.dials[i].min, g.dials[i].max, g.dials[i].initial };
+	klg_synth* s = synth_create_common(KLG_PATCH_GRAPH, &pi, synths, notes_per_synth, sample_rate, max_block);
+	if (!s) return nullptr;
+	s->graph = c;
+	bool ok = hipModuleLoadData(&s->module, c->code.data()) == hipSuccess;
+	for (int i = 0; i < 2 && ok; i++) ok = hipModuleGetFunction(&s->graph_fn[i], s->module, c->name[i].c_str()) == hipSuccess;
+	if (!ok) { fail(KLG_ERR_HIP, "klg_synth_create_graph: loading the compiled patch failed: %s", hipGetErrorString(hipGetLastError())); synth_free(s); return nullptr; }
+	return s;
+}
+// Parse, generate and compile a graph program for gfx950 WITHOUT touching a device (build-time / CI check).
+// Returns 0 or KLG_ERR_INVALID; the message (or the generated source when `want_source`) is copied into `out`.
+extern "C" int klg_graph_check(const char* program, int want_source, char* out, size_t out_cap) {
+	const graphrt::Compiled* c = nullptr;
+	const std::string err = graphrt::compile(program, &c);
+	const std::string& msg = err.empty() ? (want_source ? c->source : err) : err;
+	if (out && out_cap) { const size_t n = std::min(out_cap - 1, msg.size()); memcpy(out, msg.data(), n); out[n] = 0; }
+	return err.empty() ? 0 : fail(KLG_ERR_INVALID, "klg_graph_check: %s", err.c_str());
+}
+
 extern "C" void klg_synth_destroy(klg_synth* s) { if (s && g_device >= 0) (void)hipSetDevice(g_device); synth_free(s); }
 extern "C" int klg_synth_voices(const klg_synth* s) { return s ? s->V : KLG_ERR_INVALID; }
 extern "C" int klg_synth_controls(const klg_synth* s) { return s ? s->nctl : KLG_ERR_INVALID; }
@@ -202,6 +242,12 @@ static int render_grid(const klg_synth* s) {      // workgroups (= partial rows)
 	return s->grid;
 }
 static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_t st) {
+	if (s->graph) {                                       // hipRTC code object: klg_render<PatchGen, pv>
+		RenderArgs args = a;
+		void* params[] = { &args };
+		(void)hipModuleLaunchKernel(s->graph_fn[pv ? 1 : 0], (unsigned)s->grid, 1, 1, WG, 1, 1, 0, st, params, nullptr);
+		return;
+	}
 	if (s->patch == KLG_PATCH_SUB2A && s->x2) {           // two voices per lane, packed fp32 (klg_render_x2.hpp)
 		const dim3 g(render_grid(s)), b(WG);
 		if (pv) hipLaunchKernelGGL(klg_render_sub2a_x2<true>, g, b, 0, st, a);
@@ -220,6 +266,7 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 }
 static void launch_events(klg_synth* s, const EventArgs& a, hipStream_t st) {
 	const dim3 g((a.runs + 63) / 64), b(64);
+	if (s->graph) { hipLaunchKernelGGL(klg_apply_records, g, b, 0, st, a, s->W); return; }
 	switch (s->patch) {
 	case KLG_PATCH_SINE: hipLaunchKernelGGL(klg_apply_events<PatchSine>, g, b, 0, st, a); break;
 	case KLG_PATCH_BSINE: hipLaunchKernelGGL(klg_apply_events<PatchBSine>, g, b, 0, st, a); break;
@@ -402,8 +449,10 @@ static int synth_assign(klg_synth* s, int synth) {
 	return oldest;
 }
 
+static const char* const kGraphEvents = "graph patches keep on()/off() in the caller (the DSL facade): move voice records with klg_voice_download / klg_voice_upload / klg_voices_upload";
 extern "C" int klg_note_on(klg_synth* s, int synth, int pitch, float velocity) {
 	if (!s || synth < 0 || synth >= s->S) return fail(KLG_ERR_INVALID, "klg_note_on: bad handle or synth index %d", synth);
+	if (s->graph) return fail(KLG_ERR_INVALID, "klg_note_on: %s", kGraphEvents);
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	if (int rc = refresh_stages(s)) return rc;
 	const int slot = synth_assign(s, synth);
@@ -419,6 +468,7 @@ extern "C" int klg_note_on(klg_synth* s, int synth, int pitch, float velocity) {
 extern "C" int klg_note_off(klg_synth* s, int synth, int pitch, float velocity) {
 	(void)velocity;
 	if (!s || synth < 0 || synth >= s->S) return fail(KLG_ERR_INVALID, "klg_note_off: bad handle or synth index %d", synth);
+	if (s->graph) return fail(KLG_ERR_INVALID, "klg_note_off: %s", kGraphEvents);
 	for (int i = 0; i < s->P; i++) {
 		const int voice = synth * s->P + i;
 		HostVoice& hv = s->voices[voice];
@@ -536,7 +586,7 @@ extern "C" int klg_voice_download(klg_synth* s, int voice, void* state, size_t b
 	if (!s || !state || voice < 0 || voice >= s->V || bytes != (size_t)s->W * 4) return fail(KLG_ERR_INVALID, "klg_voice_download: bad arguments (record is %d bytes)", s ? s->W * 4 : 0);
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	if (int rc = flush_events(s, s->stream)) return rc;
-	hipLaunchKernelGGL(klg_copy_record, dim3(1), dim3(64), 0, s->stream, s->d_state, s->stride, voice, s->d_scratch_rec, s->W, 0);
+	hipLaunchKernelGGL(klg_copy_record, dim3(1), dim3(128), 0, s->stream, s->d_state, s->stride, voice, s->d_scratch_rec, s->W, 0);
 	HIP_TRY(hipMemcpyAsync(state, s->d_scratch_rec, bytes, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	return 0;
@@ -546,9 +596,22 @@ extern "C" int klg_voice_upload(klg_synth* s, int voice, const void* state, size
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	if (int rc = flush_events(s, s->stream)) return rc;
 	HIP_TRY(hipMemcpyAsync(s->d_scratch_rec, state, bytes, hipMemcpyHostToDevice, s->stream));
-	hipLaunchKernelGGL(klg_copy_record, dim3(1), dim3(64), 0, s->stream, s->d_state, s->stride, voice, s->d_scratch_rec, s->W, 1);
+	hipLaunchKernelGGL(klg_copy_record, dim3(1), dim3(128), 0, s->stream, s->d_state, s->stride, voice, s->d_scratch_rec, s->W, 1);
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->voices[voice].stage = (uint8_t)(((const uint32_t*)state)[0] & 3u);
+	return 0;
+}
+
+// Bulk form: record i (klg_synth_state_bytes() bytes each, AoS) replaces the state of voices[i]; queued like note events
+// and applied by one kernel at the start of the next block.
+extern "C" int klg_voices_upload(klg_synth* s, int n, const int* voices, const void* states) {
+	if (!s || n < 0 || !voices || !states) return fail(KLG_ERR_INVALID, "klg_voices_upload: bad arguments");
+	for (int i = 0; i < n; i++) if (voices[i] < 0 || voices[i] >= s->V) return fail(KLG_ERR_INVALID, "klg_voices_upload: voice %d out of range", voices[i]);
+	const uint32_t* w = (const uint32_t*)states;
+	for (int i = 0; i < n; i++) {
+		push_note_on(s, voices[i], w + (size_t)i * s->W);
+		s->voices[voices[i]].stage = (uint8_t)(w[(size_t)i * s->W] & 3u);
+	}
 	return 0;
 }
 

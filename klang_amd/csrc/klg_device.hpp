@@ -6,8 +6,10 @@
 // v0.7.8) and this translation unit is compiled with -ffp-contract=off: the reference path is only
 // bit-stable without FMA contraction.  Divisions and sqrt are IEEE (hipcc default).
 #pragma once
+#ifndef __HIPCC_RTC__            // hiprtc (generated patches, klg_graph.hpp) has the HIP runtime and the fixed-width integers built in
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 #include "../../include/klang_mi355_records.h"
 
 #pragma clang fp contract(off)
@@ -259,6 +261,10 @@ struct Pts2 { float x0, x1, y0, y1;
 struct Pts3 { float x0, x1, x2, y0, y1, y2;
 	__device__ __forceinline__ float x(int i) const { const float a = x0, b = x1, c = x2; return i == 2 ? c : (i == 1 ? b : a); }
 	__device__ __forceinline__ float y(int i) const { const float a = y0, b = y1, c = y2; return i == 2 ? c : (i == 1 ? b : a); } };
+
+struct Pts4 { float x0, x1, x2, x3, y0, y1, y2, y3;
+	__device__ __forceinline__ float x(int i) const { const float a = x0, b = x1, c = x2, d = x3; return i == 3 ? d : (i == 2 ? c : (i == 1 ? b : a)); }
+	__device__ __forceinline__ float y(int i) const { const float a = y0, b = y1, c = y2, d = y3; return i == 3 ? d : (i == 2 ? c : (i == 1 ? b : a)); } };
 
 // Envelope::process 4018-4051.  HOLD = the ADSR loop (setLoop(2,2), klang.h:4128): hold at the last point (NP-1).
 // The ramp step (Linear::operator++ 3785-3806) is branch-free.  Segment changes / stage changes are rare per lane

@@ -1,0 +1,219 @@
+// klang_amd/csrc/klg_graph.hpp — graph patches (include/klang_mi355_graph.h): program text -> HIP source of a patch
+// body over the device primitives of klg_device.hpp -> hipRTC (gfx950) -> code object with klg_render<PatchGen, *>.
+//
+// The generated struct has exactly the shape of the hand-written patches in klg_patches.hpp (Rec / kStoreMask / Live /
+// begin / sample / end), so the render kernel, the voice mix, the record planes in HBM and the host protocol are the
+// ones the shipped patches use; only sample() comes from the recorded program.  hipRTC is loaded with dlopen at the
+// first use (a process that never creates a graph patch does not need it).  Compiling needs no GPU.
+#pragma once
+#include <dlfcn.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/klang_mi355_graph.h"
+
+namespace klg { namespace graphrt {
+
+using graph::Program;
+using graph::Op;
+
+// ------------------------------------------------------------------------------------------------
+// source generation
+// ------------------------------------------------------------------------------------------------
+inline std::string fmt(const char* f, ...) {
+	char b[512]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return std::string(b);
+}
+
+inline std::string generate_source(const Program& g) {
+	using namespace graph;
+	const int NW = g.words();
+	std::vector<bool> swept(g.nodes.size(), false), written(g.nodes.size(), false);
+	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; }
+	uint64_t mask[2] = { 1ull, 0ull };                                   // word 0 (flags) is always written back
+	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
+	std::string live = "\tstruct Live { int stage;", begin, end, body;
+	for (size_t i = 0; i < g.nodes.size(); i++) {
+		const int k = g.nodes[i], w0 = g.node_word0((int)i);
+		const std::string n = fmt("L.n%zu", i);
+		auto R = [&](int off) { return fmt("r.w[%d]", w0 + off); };
+		auto F = [&](int off) { return fmt("u2f(r.w[%d])", w0 + off); };
+		auto W = [&](int off, const std::string& expr) { return fmt("\t\tr.w[%d] = ", w0 + off) + expr + ";\n"; };
+		switch (k) {
+		case N_FSINE:
+			live += fmt(" FSine n%zu;", i);
+			begin += "\t\t" + n + ".inc = (int32_t)" + R(FSINE_INC) + "; " + n + ".pos = " + R(FSINE_POS) + ";\n";
+			end += W(FSINE_POS, n + ".pos");
+			mark(w0 + FSINE_POS, 1);
+			break;
+		case N_SAW: case N_PULSE:
+			live += fmt(" Osm n%zu;", i);
+			begin += "\t\t" + n + ".inc = (int32_t)" + R(OSM_INC) + "; " + n + ".offset = " + R(OSM_OFFSET) + "; " + n + ".duty = " + R(OSM_DUTY) + "; " + n + ".delta = " + F(OSM_DELTA) + "; "
+				+ n + ".state = (int)(" + R(OSM_STATE) + " & 3u); osm_derive(" + n + ");\n";
+			end += W(OSM_OFFSET, n + ".offset") + W(OSM_STATE, "(uint32_t)" + n + ".state");
+			mark(w0 + OSM_OFFSET, 1); mark(w0 + OSM_STATE, 1);
+			break;
+		case N_LPF:
+			live += fmt(" Biquad n%zu; BiquadSweep n%zus;", i, i);
+			begin += "\t\t" + n + ".b0 = " + F(LPF_B0) + "; " + n + ".b1 = " + F(LPF_B1) + "; " + n + ".b2 = " + F(LPF_B2) + "; " + n + ".a1 = " + F(LPF_A1) + "; " + n + ".a2 = " + F(LPF_A2) + "; "
+				+ n + ".z0 = " + F(LPF_Z0) + "; " + n + ".z1 = " + F(LPF_Z1) + "; " + n + "s.f = " + F(LPF_F) + "; " + n + "s.Q = " + F(LPF_Q) + ";\n";
+			end += W(LPF_Z0, "f2u(" + n + ".z0)") + W(LPF_Z1, "f2u(" + n + ".z1)");
+			mark(w0 + LPF_Z0, 2);
+			if (swept[i]) {
+				end += W(LPF_B0, "f2u(" + n + ".b0)") + W(LPF_B1, "f2u(" + n + ".b1)") + W(LPF_B2, "f2u(" + n + ".b2)") + W(LPF_A1, "f2u(" + n + ".a1)") + W(LPF_A2, "f2u(" + n + ".a2)")
+					+ W(LPF_F, "f2u(" + n + "s.f)") + W(LPF_Q, "f2u(" + n + "s.Q)");
+				mark(w0, LPF_WORDS);
+			}
+			break;
+		case N_ENV:
+			live += fmt(" Env n%zu; Pts4 n%zup; int n%zunp;", i, i, i);
+			begin += "\t\t" + n + ".r_out = " + F(ENV_OUT) + "; " + n + ".r_target = " + F(ENV_TARGET) + "; " + n + ".r_rate = " + F(ENV_RATE) + "; " + n + ".time = " + F(ENV_TIME) + "; env_unpack(" + n + ", " + R(ENV_BITS) + "); "
+				+ n + "np = (int)" + R(ENV_NPOINTS) + ";\n";
+			begin += "\t\t" + n + "p.x0 = " + F(ENV_PX) + "; " + n + "p.x1 = " + F(ENV_PX + 1) + "; " + n + "p.x2 = " + F(ENV_PX + 2) + "; " + n + "p.x3 = " + F(ENV_PX + 3) + "; "
+				+ n + "p.y0 = " + F(ENV_PY) + "; " + n + "p.y1 = " + F(ENV_PY + 1) + "; " + n + "p.y2 = " + F(ENV_PY + 2) + "; " + n + "p.y3 = " + F(ENV_PY + 3) + ";\n";
+			end += W(ENV_OUT, "f2u(" + n + ".r_out)") + W(ENV_TARGET, "f2u(" + n + ".r_target)") + W(ENV_RATE, "f2u(" + n + ".r_rate)") + W(ENV_TIME, "f2u(" + n + ".time)") + W(ENV_BITS, "env_pack(" + n + ")");
+			mark(w0 + ENV_OUT, 5);
+			break;
+		case N_ADSR:
+			live += fmt(" Adsr n%zu;", i);
+			begin += "\t\t" + n + ".e.r_out = " + F(ADSR_OUT) + "; " + n + ".e.r_target = " + F(ADSR_TARGET) + "; " + n + ".e.r_rate = " + F(ADSR_RATE) + "; " + n + ".e.time = " + F(ADSR_TIME) + "; env_unpack(" + n + ".e, " + R(ADSR_BITS) + ");\n";
+			begin += "\t\t" + n + ".p.x0 = 0.f; " + n + ".p.x1 = " + F(ADSR_A) + "; " + n + ".p.x2 = " + F(ADSR_AD) + "; " + n + ".p.y0 = 0.f; " + n + ".p.y1 = 1.f; " + n + ".p.y2 = " + F(ADSR_S) + "; " + n + ".R = " + F(ADSR_R) + ";\n";
+			end += W(ADSR_OUT, "f2u(" + n + ".e.r_out)") + W(ADSR_TARGET, "f2u(" + n + ".e.r_target)") + W(ADSR_RATE, "f2u(" + n + ".e.r_rate)") + W(ADSR_TIME, "f2u(" + n + ".e.time)") + W(ADSR_BITS, "env_pack(" + n + ".e)");
+			mark(w0 + ADSR_OUT, 5);
+			break;
+		case N_PARAM:
+			live += fmt(" float n%zu;", i);
+			begin += "\t\t" + n + " = " + F(0) + ";\n";
+			if (written[i]) { end += W(0, "f2u(" + n + ")"); mark(w0, 1); }
+			break;
+		}
+	}
+	live += " };\n";
+	for (const Op& o : g.ops) {
+		const std::string d = fmt("\t\tconst float r%d = ", o.dst), n = fmt("L.n%d", o.node), a = fmt("r%d", o.a), b = fmt("r%d", o.b);
+		const int k = (o.node >= 0 && o.node < (int)g.nodes.size()) ? g.nodes[(size_t)o.node] : -1;
+		switch (o.code) {
+		case OP_CONST: body += d + fmt("u2f(0x%08xu);\n", o.imm); break;
+		case OP_CTL: body += d + fmt("c.ctl[%u];\n", o.imm); break;
+		case OP_PARAM: body += d + n + ";\n"; break;
+		case OP_OSC: body += d + (k == N_FSINE ? "fsine_process(" + n + ", 0u)" : k == N_SAW ? "osm_saw(" + n + ")" : "osm_pulse(" + n + ")") + ";\n"; break;
+		case OP_LPF: body += d + "biquad_process(" + n + ", " + a + ");\n"; break;
+		case OP_LPFSET: body += "\t\tbiquad_lpf_set(" + n + ", " + n + "s, " + a + ", " + b + ", c.fs.w);\n"; break;
+		case OP_ENV: body += d + (k == N_ADSR ? "adsr_process(" + n + ", c.fs)" : "env_process<4, false>(" + n + ", " + n + "p, " + n + "np, c.fs)") + ";\n"; break;
+		case OP_ADD: body += d + a + " + " + b + ";\n"; break;
+		case OP_SUB: body += d + a + " - " + b + ";\n"; break;
+		case OP_MUL: body += d + a + " * " + b + ";\n"; break;
+		case OP_DIV: body += d + a + " / " + b + ";\n"; break;
+		case OP_NEG: body += d + "-" + a + ";\n"; break;
+		case OP_STOPIF: body += "\t\tL.stage = (" + n + (k == N_ADSR ? ".e" : "") + ".stage == ENV_OFF) ? (int)ST_OFF : L.stage;\n"; break;
+		case OP_STOP: body += "\t\tL.stage = (int)ST_OFF;\n"; break;
+		case OP_SETPARAM: body += "\t\t" + n + " = " + a + ";\n"; break;
+		}
+	}
+	std::string s;
+	s += "// generated by klg_graph.hpp from a recorded klang process() body (include/klang_mi355_graph.h)\n";
+	s += "#include \"klg_kernels.hpp\"\n#pragma clang fp contract(off)\nnamespace klg {\n";
+	s += "__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }\n";
+	s += "struct PatchGen {\n";
+	s += fmt("\tstruct Rec { uint32_t w[%d]; };\n", NW);
+	s += fmt("\tstatic constexpr uint64_t kStoreMask = 0x%llxull;\n\tstatic constexpr uint64_t kStoreMask2 = 0x%llxull;\n", (unsigned long long)mask[0], (unsigned long long)mask[1]);
+	s += live;
+	s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {\n\t\tL.stage = (int)(r.w[0] & 3u);\n" + begin + "\t}\n";
+	s += "\tstatic __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {\n" + body + fmt("\t\treturn r%d;\n\t}\n", g.ret);
+	s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\tr.w[0] = (uint32_t)L.stage;\n" + end + "\t}\n";
+	s += "\tstatic __device__ __forceinline__ void release(Rec&, float) {}\n};\n}\n";
+	return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hipRTC (dlopen)
+// ------------------------------------------------------------------------------------------------
+struct Rtc {
+	void* lib = nullptr;
+	int (*CreateProgram)(void**, const char*, const char*, int, const char**, const char**) = nullptr;
+	int (*AddNameExpression)(void*, const char*) = nullptr;
+	int (*CompileProgram)(void*, int, const char**) = nullptr;
+	int (*GetProgramLogSize)(void*, size_t*) = nullptr;
+	int (*GetProgramLog)(void*, char*) = nullptr;
+	int (*GetCodeSize)(void*, size_t*) = nullptr;
+	int (*GetCode)(void*, char*) = nullptr;
+	int (*GetLoweredName)(void*, const char*, const char**) = nullptr;
+	int (*DestroyProgram)(void**) = nullptr;
+	std::string error;
+	bool load() {
+		if (lib) return true;
+		const char* names[] = { "libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so" };
+		for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+		if (!lib) { error = std::string("cannot load libhiprtc.so: ") + dlerror(); return false; }
+		bool ok = true;
+		auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) { ok = false; error = std::string("libhiprtc.so lacks ") + n; } return p; };
+		CreateProgram = (decltype(CreateProgram))sym("hiprtcCreateProgram");
+		AddNameExpression = (decltype(AddNameExpression))sym("hiprtcAddNameExpression");
+		CompileProgram = (decltype(CompileProgram))sym("hiprtcCompileProgram");
+		GetProgramLogSize = (decltype(GetProgramLogSize))sym("hiprtcGetProgramLogSize");
+		GetProgramLog = (decltype(GetProgramLog))sym("hiprtcGetProgramLog");
+		GetCodeSize = (decltype(GetCodeSize))sym("hiprtcGetCodeSize");
+		GetCode = (decltype(GetCode))sym("hiprtcGetCode");
+		GetLoweredName = (decltype(GetLoweredName))sym("hiprtcGetLoweredName");
+		DestroyProgram = (decltype(DestroyProgram))sym("hiprtcDestroyProgram");
+		if (!ok) { dlclose(lib); lib = nullptr; }
+		return ok;
+	}
+};
+
+struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; };   // name[pv]
+
+// directory holding klg_kernels.hpp etc.: next to the shared library (klang_amd/csrc), or $KLG_GRAPH_SRC
+inline std::string source_dir() {
+	if (const char* e = getenv("KLG_GRAPH_SRC")) return e;
+	Dl_info info;
+	if (dladdr((const void*)&source_dir, &info) && info.dli_fname) {
+		std::string p = info.dli_fname;
+		const size_t slash = p.rfind('/');
+		return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/csrc";
+	}
+	return "klang_amd/csrc";
+}
+
+// program text -> code object (cached per process by program text).  Returns "" on success.
+inline std::string compile(const char* text, const Compiled** out) {
+	static std::mutex mu;
+	static std::map<std::string, Compiled> cache;
+	static Rtc rtc;
+	std::lock_guard<std::mutex> lock(mu);
+	Program g;
+	const std::string perr = g.parse(text);
+	if (!perr.empty()) return perr;
+	const std::string key = g.text();
+	auto it = cache.find(key);
+	if (it != cache.end()) { *out = &it->second; return ""; }
+	if (!rtc.load()) return rtc.error;
+	Compiled c;
+	c.source = generate_source(g);
+	c.words = g.words();
+	void* prog = nullptr;
+	if (rtc.CreateProgram(&prog, c.source.c_str(), "klg_graph_patch.hip", 0, nullptr, nullptr) != 0) return "hiprtcCreateProgram failed";
+	const char* expr[2] = { "klg::klg_render<klg::PatchGen, false>", "klg::klg_render<klg::PatchGen, true>" };
+	rtc.AddNameExpression(prog, expr[0]); rtc.AddNameExpression(prog, expr[1]);
+	const std::string inc = "-I" + source_dir();
+	const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str() };
+	const int rc = rtc.CompileProgram(prog, 5, opts);
+	if (rc != 0) {
+		size_t n = 0; rtc.GetProgramLogSize(prog, &n);
+		std::string log(n, '\0'); if (n) rtc.GetProgramLog(prog, &log[0]);
+		rtc.DestroyProgram(&prog);
+		return "hipRTC compilation of the graph patch failed (headers expected in " + source_dir() + "; set KLG_GRAPH_SRC):\n" + log;
+	}
+	size_t n = 0; rtc.GetCodeSize(prog, &n);
+	c.code.resize(n); rtc.GetCode(prog, c.code.data());
+	for (int i = 0; i < 2; i++) { const char* ln = nullptr; rtc.GetLoweredName(prog, expr[i], &ln); c.name[i] = ln ? ln : ""; }
+	rtc.DestroyProgram(&prog);
+	if (c.name[0].empty() || c.name[1].empty()) return "hipRTC: lowered kernel names not found";
+	auto ins = cache.emplace(key, std::move(c));
+	*out = &ins.first->second;
+	return "";
+}
+
+} }  // namespace klg::graphrt

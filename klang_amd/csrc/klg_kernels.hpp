@@ -42,6 +42,12 @@ template<class REC> struct RecWords {
 	__device__ __forceinline__ void from(const REC& r) { __builtin_memcpy(w, &r, sizeof(REC)); }
 };
 
+// records longer than 64 words (generated graph patches, klg_graph.hpp) name their second store mask kStoreMask2
+template<class...> using klg_void_t = void;
+template<class P, class = void> struct StoreMask2 { static constexpr uint64_t value = 0; };
+template<class P> struct StoreMask2<P, klg_void_t<decltype(P::kStoreMask2)>> { static constexpr uint64_t value = P::kStoreMask2; };
+template<class P> __device__ __forceinline__ constexpr bool patch_stores(int w) { return w < 64 ? ((P::kStoreMask >> (w & 63)) & 1ull) != 0 : ((StoreMask2<P>::value >> (w & 63)) & 1ull) != 0; }
+
 template<class P, bool PER_VOICE>
 __global__ __launch_bounds__(WG) void klg_render(const RenderArgs a) {
 	using Rec = typename P::Rec;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(WG) void klg_render(const RenderArgs a) {
 			rw.from(rec);
 #pragma unroll
 			for (int w = 0; w < W; w++)
-				if ((P::kStoreMask >> w) & 1ull) a.state[(size_t)w * a.stride + v] = rw.w[w];
+				if (patch_stores<P>(w)) a.state[(size_t)w * a.stride + v] = rw.w[w];
 		}
 	}
 	__syncthreads();
@@ -187,10 +193,21 @@ __global__ __launch_bounds__(64) void klg_apply_events(const EventArgs a) {
 	}
 }
 
+// Record uploads of patches without a device-side off() (graph patches): the last record queued for a voice wins.
+__global__ __launch_bounds__(64) void klg_apply_records(const EventArgs a, int W) {
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= a.runs) return;
+	const int v = a.run_voice[r];
+	int last = -1;
+	for (int e = a.run_first[r]; e < a.run_first[r] + a.run_count[r]; e++) if (a.ev_type[e] == 0) last = a.ev_payload[e];
+	if (last < 0) return;
+	const uint32_t* src = a.payload + (size_t)last * W;
+	for (int w = 0; w < W; w++) a.state[(size_t)w * a.stride + v] = src[w];
+}
+
 // single-voice record copy (klg_voice_download / klg_voice_upload)
 __global__ void klg_copy_record(uint32_t* state, size_t stride, int v, uint32_t* rec, int W, int to_state) {
-	const int w = threadIdx.x;
-	if (w < W) { if (to_state) state[(size_t)w * stride + v] = rec[w]; else rec[w] = state[(size_t)w * stride + v]; }
+	for (int w = threadIdx.x; w < W; w += blockDim.x) { if (to_state) state[(size_t)w * stride + v] = rec[w]; else rec[w] = state[(size_t)w * stride + v]; }
 }
 
 } // namespace klg

@@ -182,24 +182,26 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
 			}
 			wave_sync();
 			if (PER_VOICE) {
-				const int s = lane & 15, q = lane >> 4;
+				constexpr int Q = 64 / X2_CHUNK;                          // lane groups per sample row
+				const int s = lane & (X2_CHUNK - 1), q = lane / X2_CHUNK;
 				const float* tf = reinterpret_cast<const float*>(tile);
-				for (int j = 0; j < 32; j++) {
-					const int vv = 4 * j + q;                             // voice within the wave's 128
+				for (int j = 0; j < 128 / Q; j++) {
+					const int vv = Q * j + q;                             // voice within the wave's 128
 					if (s < cl && v0 + vv < a.voices) a.per_voice[(size_t)(v0 + vv) * n + c0 + s] = tf[(s * X2_LD) * 2 + vv];
 				}
 			}
 			{
-				const int s = lane & 15, q = lane >> 4;
+				constexpr int Q = 64 / X2_CHUNK;                          // lane groups per sample row, each sums 64 / Q pairs
+				const int s = lane & (X2_CHUNK - 1), q = lane / X2_CHUNK;
 				f2 sum2 = splat(0.f);
 				if (s < cl) {
-					const f2* row = tile + s * X2_LD + q * 16;
+					const f2* row = tile + s * X2_LD + q * (64 / Q);
 #pragma unroll
-					for (int j = 0; j < 16; j++) sum2 += row[j];
+					for (int j = 0; j < 64 / Q; j++) sum2 += row[j];
 				}
 				float sum = sum2.x + sum2.y;
-				sum += __shfl_xor(sum, 16);
-				sum += __shfl_xor(sum, 32);
+#pragma unroll
+				for (int m = X2_CHUNK; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
 				if (lane < cl) atomicAdd(&acc[c0 + lane], sum);
 			}
 			wave_sync();
