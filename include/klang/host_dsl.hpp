@@ -117,6 +117,8 @@ struct EnvH {
 	float r_out = 1.f, r_target = 1.f, r_rate = 0.f; bool active = false;
 	int npoints = 0; float px[4] = { 0 }, py[4] = { 0 };
 	int point = 0; float time = 0.f; int stage = ENV_SUSTAIN;
+	int loop_start = -1, loop_end = -1;                                        // Envelope::Loop klang.h:3853-3864
+	void set_loop(int a, int b) { if (a >= 0 && b < npoints) { loop_start = a; loop_end = b; } }   // setLoop klang.h:3923-3926
 	void set_value(float v) { r_out = v; r_target = v; active = false; }
 	void set_target(float x, float y, float t, const Fs& fs) {
 		time = t; r_target = y; active = (r_out != y);
@@ -125,7 +127,7 @@ struct EnvH {
 	void set_points(int n, const float* xy, const Fs& fs) {
 		npoints = n;
 		for (int i = 0; i < n; i++) { px[i] = xy[2 * i]; py[i] = xy[2 * i + 1]; }
-		point = 0; stage = ENV_SUSTAIN;
+		point = 0; stage = ENV_SUSTAIN; loop_start = loop_end = -1;            // initialise() resets the loop (klang.h:3977)
 		set_value(py[0]);
 		if (n > 1) set_target(px[1], py[1], px[0], fs);
 	}
@@ -139,6 +141,7 @@ struct AdsrH {
 		A = attack; D = decay + 0.005f; S = sustain; R = release + 0.005f;
 		const float xy[6] = { 0.f, 0.f, A, 1.f, A + D, S };
 		env.set_points(3, xy, fs);
+		env.set_loop(2, 2);
 	}
 	void pack(AdsrRec& r) const { r.r_out = env.r_out; r.r_target = env.r_target; r.r_rate = env.r_rate; r.time = env.time; r.A = A; r.AD = env.px[2]; r.S = S; r.R = R; }
 };

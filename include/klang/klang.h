@@ -14,7 +14,17 @@
 //   * Synth::process(float** / float*, int, float*) renders the block on the GPU through the C-ABI
 //     (klang_mi355.h), after note events have moved the affected voices' state host <-> lane with
 //     klg_voice_download / klg_voice_upload.
-// A Note type is tied to its kernel with KLANG_GPU_BIND (klang/bindings.h holds the bindings of the shipped patches).
+// Which kernel renders a Note type:
+//   * a hand-written one, when the type is tied to a patch id with KLANG_GPU_BIND (klang/bindings.h holds the bindings of
+//     the shipped patches), or
+//   * a GENERATED one (graph patch, include/klang_mi355_graph.h): notes.add<T>() runs T::process() ONCE in recording mode —
+//     every primitive's process(), every `>>`, `++`, arithmetic operator and filter.set() appends an op to a program
+//     instead of computing — and the program is compiled for gfx950 by klg_synth_create_graph().  Supported in a
+//     recorded process(): Fast::{Sine,Saw,Triangle,Square,Pulse} (frequency set in on()), Biquad::LPF (static, or
+//     set(f, Q) per sample), Envelope (<= 4 points) and ADSR `++`, + - * / on signals / params / controls / constants,
+//     signal and param members of the Note (read, and written for next-sample state), `>> out`, `out *= x`, and
+//     `if (env.finished()) stop();`.  Anything else (a signal forced to a plain float, data-dependent branches, set() of
+//     an oscillator per sample) stops with a message naming the construct.
 // Effects (Stereo::Effect patches) are reached through klg_fx_* directly; their DSL façade is future work.
 //
 // Reference interface citations (file:line) are into nashaudio/klang's klang.h v0.7.8.
@@ -28,10 +38,12 @@
 #include <initializer_list>
 #include <string>
 #include <type_traits>
+#include <typeinfo>
 #include <vector>
 
 #include "../klang_mi355.h"
 #include "../klang_mi355_records.h"
+#include "../klang_mi355_graph.h"
 #include "host_dsl.hpp"
 
 namespace klang {
@@ -56,34 +68,101 @@ constexpr constant root2 = { 1.4142135623730950488016887242097 };
 template<typename T> inline T random(const T mn, const T mx) { return std::rand() * ((mx - mn) / (T)RAND_MAX) + mn; }   // klang.h:236
 inline void random(const unsigned seed) { std::srand(seed); klg_random_seed(seed); }                                     // klang.h:239
 
+// =================================================================================================
+// Recording a process() body into a graph program (include/klang_mi355_graph.h)
+// =================================================================================================
+struct signal;
+namespace gpu {
+struct Recorder {
+	struct Obj { const void* addr; size_t size; int kind; };     // a primitive or a signal member seen while the prototype Note was constructed
+	std::vector<Obj> objs;
+	bool constructing = false, recording = false;
+	klg::graph::Program prog;
+	int next_reg = 0, pending = -1;                              // pending: node whose finished() was just tested by an `if`
+	std::string error;
+	void fail(const std::string& what) { if (error.empty()) error = what; }
+	void note(const void* addr, size_t size, int kind) {
+		for (Obj& o : objs) if (o.addr == addr) { o.kind = kind; o.size = size; return; }       // ADSR refines the Envelope it derives from
+		objs.push_back({ addr, size, kind });
+	}
+	int emit(int code, int a, int b, int node, uint32_t imm, bool has_dst) {
+		if (pending >= 0 && code != klg::graph::OP_STOPIF) fail("`if (env.finished())` may only guard stop() in a recorded process()");
+		klg::graph::Op o; o.code = code; o.a = a; o.b = b; o.node = node; o.imm = imm; o.dst = has_dst ? next_reg++ : -1;
+		prog.ops.push_back(o);
+		return o.dst;
+	}
+	int reg_of(const signal& s);
+	std::vector<int> node_of_obj;                               // objs index -> provisional node id (== objs index)
+	int node(const void* addr, const char* what) {
+		for (size_t i = 0; i < objs.size(); i++) if (objs[i].addr == addr) return (int)i;
+		fail(std::string(what) + ": this object is not a member of the Note (only members can be used in a recorded process())");
+		return 0;
+	}
+};
+inline thread_local Recorder* rec = nullptr;
+inline Recorder* constructing() { return (rec && rec->constructing) ? rec : nullptr; }
+inline Recorder* recording() { return (rec && rec->recording) ? rec : nullptr; }
+inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+// host-side set()/reset()/release() calls inside a recorded process() would have to run per sample on the device
+inline bool no_set_while_recording(const char* what) { if (Recorder* r = recording()) { r->fail(std::string(what) + " inside process() is not supported in a recorded graph (set it in on())"); return true; } return false; }
+// the value of `if (env.finished())`: a plain bool on the host, a recorded condition while recording
+struct Cond { bool value; int node; explicit operator bool() const { if (node >= 0 && recording()) { rec->pending = node; return true; } return value; } bool operator!() const { if (node >= 0 && recording()) { rec->fail("`!env.finished()` is not supported in a recorded process()"); } return !value; } };
+}
+
 // ---- signal / relative / param (klang.h:1062-1200, 1357-1371) ----
+// `reg` >= 0 only while a process() body is being recorded: the value lives in that register of the program.
 struct relative;
 struct signal {
-	float value;
-	signal(constant c) : value(c.f) {}
-	signal(const float v = 0.f) : value(v) {}
-	signal(const double v) : value((float)v) {}
-	signal(const int v) : value((float)v) {}
-	const signal& operator<<(const signal& in) { value = in.value; return *this; }
-	signal& operator>>(signal& dst) const { dst.value = value; return dst; }
-	signal& operator+=(const signal& x) { value += x.value; return *this; }
-	signal& operator-=(const signal& x) { value -= x.value; return *this; }
-	signal& operator*=(const signal& x) { value *= x.value; return *this; }
-	signal& operator/=(const signal& x) { value /= x.value; return *this; }
+	float value; int reg = -1;
+	signal(constant c) : value(c.f) { reg_member(); }
+	signal(const float v = 0.f) : value(v) { reg_member(); }
+	signal(const double v) : value((float)v) { reg_member(); }
+	signal(const int v) : value((float)v) { reg_member(); }
+	signal(const signal&) = default;
+	signal& operator=(const signal&) = default;
+	void reg_member() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(signal), klg::graph::N_PARAM); }
+	static signal bin(int code, const signal& a, const signal& b, float concrete) {
+		gpu::Recorder* r = gpu::recording();
+		if (!r || (a.reg < 0 && b.reg < 0)) return signal(concrete);
+		signal s(concrete); const int ra = r->reg_of(a), rb = r->reg_of(b);
+		s.reg = r->emit(code, ra, rb, -1, 0, true); return s;
+	}
+	const signal& operator<<(const signal& in) { value = in.value; reg = in.reg; return *this; }
+	signal& operator>>(signal& dst) const { dst.value = value; dst.reg = reg; return dst; }
+	signal operator+(const signal& x) const { return bin(klg::graph::OP_ADD, *this, x, value + x.value); }
+	signal operator-(const signal& x) const { return bin(klg::graph::OP_SUB, *this, x, value - x.value); }
+	signal operator*(const signal& x) const { return bin(klg::graph::OP_MUL, *this, x, value * x.value); }
+	signal operator/(const signal& x) const { return bin(klg::graph::OP_DIV, *this, x, value / x.value); }
+	signal operator-() const { gpu::Recorder* r = gpu::recording(); signal s(-value); if (r && reg >= 0) s.reg = r->emit(klg::graph::OP_NEG, reg, -1, -1, 0, true); return s; }
+	signal& operator+=(const signal& x) { return *this = *this + x; }
+	signal& operator-=(const signal& x) { return *this = *this - x; }
+	signal& operator*=(const signal& x) { return *this = *this * x; }
+	signal& operator/=(const signal& x) { return *this = *this / x; }
 #define KLANG_SIGNAL_OPS(T) \
-	signal& operator+=(T x) { value += (float)x; return *this; } signal& operator-=(T x) { value -= (float)x; return *this; } \
-	signal& operator*=(T x) { value *= (float)x; return *this; } signal& operator/=(T x) { value /= (float)x; return *this; } \
-	signal operator+(T x) const { return value + (float)x; } signal operator-(T x) const { return value - (float)x; } \
-	signal operator*(T x) const { return value * (float)x; } signal operator/(T x) const { return value / (float)x; }
+	signal& operator+=(T x) { return *this = *this + signal((float)x); } signal& operator-=(T x) { return *this = *this - signal((float)x); } \
+	signal& operator*=(T x) { return *this = *this * signal((float)x); } signal& operator/=(T x) { return *this = *this / signal((float)x); } \
+	signal operator+(T x) const { return *this + signal((float)x); } signal operator-(T x) const { return *this - signal((float)x); } \
+	signal operator*(T x) const { return *this * signal((float)x); } signal operator/(T x) const { return *this / signal((float)x); }
 	KLANG_SIGNAL_OPS(float) KLANG_SIGNAL_OPS(double) KLANG_SIGNAL_OPS(int)
 #undef KLANG_SIGNAL_OPS
-	operator const float() const { return value; }
-	operator float&() { return value; }
+	// reading a recorded value as a plain float leaves the program: not representable
+	void concrete_only(const char* what) const { if (reg >= 0) if (gpu::Recorder* r = gpu::recording()) r->fail(std::string(what) + " of a signal computed in process(): keep it a signal / param (a plain float cannot be recorded)"); }
+	operator const float() const { concrete_only("float conversion"); return value; }
+	operator float&() { concrete_only("float& conversion"); return value; }
 	relative operator+() const;
 };
 struct relative : signal {};
-inline relative signal::operator+() const { relative r; r.value = value; return r; }
-inline signal& operator>>(float in, signal& dst) { dst.value = in; return dst; }
+inline relative signal::operator+() const { relative r; r.value = value; r.reg = reg; return r; }
+inline signal& operator>>(float in, signal& dst) { dst.value = in; dst.reg = -1; return dst; }
+// (templates: only a signal / param / ... on the right takes part — `constant` and `Control` keep their float conversions)
+#define KLANG_SIGNAL_LEFT(T) \
+	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator+(T x, const S& s) { return signal::bin(klg::graph::OP_ADD, signal((float)x), s, (float)x + s.value); } \
+	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator-(T x, const S& s) { return signal::bin(klg::graph::OP_SUB, signal((float)x), s, (float)x - s.value); } \
+	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator*(T x, const S& s) { return signal::bin(klg::graph::OP_MUL, signal((float)x), s, (float)x * s.value); } \
+	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator/(T x, const S& s) { return signal::bin(klg::graph::OP_DIV, signal((float)x), s, (float)x / s.value); }
+KLANG_SIGNAL_LEFT(float) KLANG_SIGNAL_LEFT(double) KLANG_SIGNAL_LEFT(int)
+#undef KLANG_SIGNAL_LEFT
+inline int gpu::Recorder::reg_of(const signal& s) { return s.reg >= 0 ? s.reg : emit(klg::graph::OP_CONST, -1, -1, -1, gpu::fbits(s.value), true); }
 
 struct Control;
 struct param : signal {
@@ -100,8 +179,11 @@ struct Control {
 	signal value, smoothed;
 	operator signal&() { return value; }
 	operator param() const { return param(value); }
-	operator float() const { return value.value; }
-	signal smooth() { smoothed = smoothed.value * 0.999f + (1.f - 0.999f) * value.value; return smoothed; }   // klang.h:1715
+	operator float() const { value.concrete_only("float conversion of a Control"); return value.value; }
+	signal smooth() {                                                                                        // klang.h:1715
+		if (gpu::Recorder* r = gpu::recording()) r->fail("Control::smooth() (per-synth state advanced per sample) is not supported in a recorded Note::process()");
+		smoothed = smoothed.value * 0.999f + (1.f - 0.999f) * value.value; return smoothed;
+	}
 	Control& set(float x) { value = (x < min) ? min : (max < x) ? max : x; return *this; }                    // klang.h:1725
 };
 inline param::param(Control& c) : signal(c.value) {}
@@ -221,21 +303,26 @@ namespace Basic {
 namespace Fast {
 	struct Sine : Oscillator {
 		klg::host::FSineH h;
+		Sine() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Sine), klg::graph::N_FSINE); }
 		using Oscillator::set;
-		void set(param f) override { if (f != h.frequency) { h.frequency = f; h.inc = klg::host::fast_increment(f, host_fs()); } }
-		void set(param f, param phase) override { h.set(f, phase, host_fs()); }
+		void set(param f) override { if (gpu::no_set_while_recording("Fast::Sine::set(f)")) return; if (f != h.frequency) { h.frequency = f; h.inc = klg::host::fast_increment(f, host_fs()); } }
+		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast::Sine::set(f, phase)")) return; h.set(f, phase, host_fs()); }
 		void set(param f, relative phase) override { set(f); set(phase); }
 		void set(relative) override { device_only("Fast::Sine::set(relative) [phase modulation]"); }
-		void process() override { device_only("Fast::Sine::process()"); }
+		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast::Sine"), 0, true); return; } device_only("Fast::Sine::process()"); }
+		void pack(uint32_t* w) const { w[klg::graph::FSINE_INC] = (uint32_t)h.inc; w[klg::graph::FSINE_POS] = h.pos; }
+		void unpack(const uint32_t* w) { h.pos = w[klg::graph::FSINE_POS]; }
 	};
 	struct Osm : Oscillator {
 		klg::host::OsmH h; int waveform;             // 0 = saw family, 1 = pulse family
-		Osm(int wf, float duty) : h(duty), waveform(wf) {}
+		Osm(int wf, float duty) : h(duty), waveform(wf) { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Osm), wf ? klg::graph::N_PULSE : klg::graph::N_SAW); }
 		using Oscillator::set;
-		void set(param f) override { if (h.frequency != f) { h.refresh(f, host_fs()); h.init(); } }
-		void set(param f, param phase) override { h.set(f, phase, host_fs()); }
-		void set(param f, param phase, param duty) override { h.set(f, phase, duty, host_fs()); }
-		void process() override { device_only("Fast::Osm::process()"); }
+		void set(param f) override { if (gpu::no_set_while_recording("Fast oscillator set(f)")) return; if (h.frequency != f) { h.refresh(f, host_fs()); h.init(); } }
+		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase)")) return; h.set(f, phase, host_fs()); }
+		void set(param f, param phase, param duty) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase, duty)")) return; h.set(f, phase, duty, host_fs()); }
+		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast oscillator"), 0, true); return; } device_only("Fast::Osm::process()"); }
+		void pack(uint32_t* w) const { using namespace klg::graph; w[OSM_INC] = (uint32_t)h.inc; w[OSM_OFFSET] = h.offset; w[OSM_DUTY] = h.duty; w[OSM_DELTA] = gpu::fbits(h.delta); w[OSM_STATE] = (uint32_t)h.state; }
+		void unpack(const uint32_t* w) { h.offset = w[klg::graph::OSM_OFFSET]; h.state = (int)(w[klg::graph::OSM_STATE] & 3u); }
 	};
 	struct Saw : Osm { Saw() : Osm(0, 0.f) {} };
 	struct Triangle : Osm { Triangle() : Osm(0, 1.f) {} };
@@ -248,11 +335,17 @@ namespace Fast {
 namespace Filters { namespace Biquad {
 	struct LPF : Modifier {
 		klg::host::BiquadLpfH h;
-		void reset() { h.reset(); }
+		LPF() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(LPF), klg::graph::N_LPF); }
+		void reset() { if (gpu::no_set_while_recording("Biquad::LPF::reset()")) return; h.reset(); }
 		using Modifier::set;
-		void set(param f) override { h.set(f, klg::host::ROOT2_INV, host_fs()); }
-		void set(param f, param Q) override { h.set(f, Q, host_fs()); }
-		void process() override { device_only("Biquad::LPF::process()"); }
+		void set(param f) override { set(f, param(klg::host::ROOT2_INV)); }
+		void set(param f, param Q) override {
+			if (gpu::Recorder* r = gpu::recording()) { const int rf = r->reg_of(f), rq = r->reg_of(Q); r->emit(klg::graph::OP_LPFSET, rf, rq, r->node(this, "Biquad::LPF"), 0, false); return; }
+			h.set(f, Q, host_fs());
+		}
+		void process() override { if (gpu::Recorder* r = gpu::recording()) { const int ri = r->reg_of(in); out.reg = r->emit(klg::graph::OP_LPF, ri, -1, r->node(this, "Biquad::LPF"), 0, true); return; } device_only("Biquad::LPF::process()"); }
+		void pack(uint32_t* w) const { using namespace klg::graph; const float v[LPF_WORDS] = { h.b0, h.b1, h.b2, h.a1, h.a2, h.z0, h.z1, h.f, h.Q }; for (int i = 0; i < LPF_WORDS; i++) w[i] = gpu::fbits(v[i]); }
+		void unpack(const uint32_t* w) { using namespace klg::graph; float* v[LPF_WORDS] = { &h.b0, &h.b1, &h.b2, &h.a1, &h.a2, &h.z0, &h.z1, &h.f, &h.Q }; for (int i = 0; i < LPF_WORDS; i++) std::memcpy(v[i], &w[i], 4); }
 	};
 } }
 
@@ -261,24 +354,41 @@ struct Envelope : Generator {
 	struct Point { float x, y; Point() : x(0), y(0) {} template<class A, class B> Point(A a, B b) : x(float(a)), y(float(b)) {} };
 	enum Stage { Sustain, Release, Off };
 	klg::host::EnvH h;
-	Envelope() { const float one[2] = { 0.f, 1.f }; h.set_points(1, one, host_fs()); }
-	Envelope(std::initializer_list<Point> p) { assign(p); }
+	void reg_member() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Envelope), klg::graph::N_ENV); }
+	Envelope() { reg_member(); const float one[2] = { 0.f, 1.f }; h.set_points(1, one, host_fs()); }
+	Envelope(std::initializer_list<Point> p) { reg_member(); assign(p); }
 	Envelope& operator=(std::initializer_list<Point> p) { assign(p); return *this; }
 	void assign(std::initializer_list<Point> p) {
 		float xy[8]; int n = 0;
 		for (const Point& q : p) if (n < 4) { xy[2 * n] = q.x; xy[2 * n + 1] = q.y; n++; }
 		h.set_points(n, xy, host_fs());
 	}
-	virtual void release(float time, float level = 0.f) { h.stage = klg::ENV_RELEASE; h.set_target(time, level, 0.f, host_fs()); }   // klang.h:3961-3966
-	bool finished() const { return h.stage == klg::ENV_OFF; }
+	virtual void release(float time, float level = 0.f) { if (gpu::no_set_while_recording("Envelope::release()")) return; h.stage = klg::ENV_RELEASE; h.set_target(time, level, 0.f, host_fs()); }   // klang.h:3961-3966
+	void setLoop(int startPoint, int endPoint) { if (gpu::no_set_while_recording("Envelope::setLoop()")) return; h.set_loop(startPoint, endPoint); }   // klang.h:3923-3926
+	gpu::Cond finished() const { gpu::Recorder* r = gpu::recording(); return gpu::Cond{ h.stage == klg::ENV_OFF, r ? r->node(this, "Envelope") : -1 }; }
 	signal& operator++(int) { this->process(); return out; }
-	void process() override { device_only("Envelope::process()"); }
+	void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_ENV, -1, -1, r->node(this, "Envelope"), 0, true); return; } device_only("Envelope::process()"); }
+	virtual void pack(uint32_t* w) const {
+		using namespace klg::graph;
+		w[ENV_OUT] = gpu::fbits(h.r_out); w[ENV_TARGET] = gpu::fbits(h.r_target); w[ENV_RATE] = gpu::fbits(h.r_rate); w[ENV_TIME] = gpu::fbits(h.time); w[ENV_BITS] = h.bits(); w[ENV_NPOINTS] = (uint32_t)h.npoints;
+		w[ENV_LOOP] = (uint32_t)(h.loop_start & 0xFF) | ((uint32_t)(h.loop_end & 0xFF) << 8);
+		for (int i = 0; i < 4; i++) { w[ENV_PX + i] = gpu::fbits(h.px[i]); w[ENV_PY + i] = gpu::fbits(h.py[i]); }
+	}
+	virtual void unpack(const uint32_t* w) {
+		std::memcpy(&h.r_out, &w[0], 4); std::memcpy(&h.r_target, &w[1], 4); std::memcpy(&h.r_rate, &w[2], 4); std::memcpy(&h.time, &w[3], 4);
+		const uint32_t bits = w[4]; h.stage = (int)(bits & 3u); h.point = (int)((bits >> 2) & 7u); h.active = ((bits >> 5) & 1u) != 0;
+	}
 };
 struct ADSR : Envelope {
 	klg::host::AdsrH a;
-	ADSR() { set(0.5, 0.5, 1, 0.5); }
+	ADSR() { if (gpu::Recorder* r = gpu::constructing()) r->note(static_cast<Envelope*>(this), sizeof(ADSR), klg::graph::N_ADSR); set(0.5, 0.5, 1, 0.5); }
 	using Envelope::set;
-	void set(param attack, param decay, param sustain, param release) override { a.set(attack, decay, sustain, release, host_fs()); h = a.env; }
+	void set(param attack, param decay, param sustain, param release) override { if (gpu::no_set_while_recording("ADSR::set()")) return; a.set(attack, decay, sustain, release, host_fs()); h = a.env; }
+	void pack(uint32_t* w) const override {
+		using namespace klg::graph;
+		w[ADSR_OUT] = gpu::fbits(h.r_out); w[ADSR_TARGET] = gpu::fbits(h.r_target); w[ADSR_RATE] = gpu::fbits(h.r_rate); w[ADSR_TIME] = gpu::fbits(h.time); w[ADSR_BITS] = h.bits();
+		w[ADSR_A] = gpu::fbits(a.A); w[ADSR_AD] = gpu::fbits(h.px[2]); w[ADSR_S] = gpu::fbits(a.S); w[ADSR_R] = gpu::fbits(a.R);
+	}
 	void release(float time = 0.f, float level = 0.f) override { Envelope::release(time ? time : a.R, level); }
 };
 
@@ -305,6 +415,40 @@ inline void klang_gpu_unpack(void*, const uint32_t*) {}
 
 struct NoteBinding { int patch; void (*pack)(const void*, uint32_t*); void (*unpack)(void*, const uint32_t*); };
 
+// A recorded Note type: the program, and where each node's object sits inside a Note of that type (every instance of the
+// type has the same layout, so the offsets found on the prototype serve all of them).
+namespace gpu {
+struct GraphLayout {
+	struct Member { size_t offset; int kind; int word0; };
+	std::vector<Member> members;
+	std::string program;
+	int words = 0;
+	template<class F> static void visit(int kind, void* obj, F&& f) {
+		using namespace klg::graph;
+		switch (kind) {
+		case N_FSINE: f(*static_cast<Generators::Fast::Sine*>(obj)); break;
+		case N_SAW: case N_PULSE: f(*static_cast<Generators::Fast::Osm*>(obj)); break;
+		case N_LPF: f(*static_cast<Filters::Biquad::LPF*>(obj)); break;
+		case N_ENV: case N_ADSR: f(*static_cast<Envelope*>(obj)); break;
+		}
+	}
+	void pack(const void* note, uint32_t* w) const {
+		for (const Member& m : members) {
+			void* obj = (char*)const_cast<void*>(note) + m.offset;
+			if (m.kind == klg::graph::N_PARAM) w[m.word0] = fbits(static_cast<signal*>(obj)->value);
+			else visit(m.kind, obj, [&](auto& o) { o.pack(w + m.word0); });
+		}
+	}
+	void unpack(void* note, const uint32_t* w) const {
+		for (const Member& m : members) {
+			void* obj = (char*)note + m.offset;
+			if (m.kind == klg::graph::N_PARAM) std::memcpy(&static_cast<signal*>(obj)->value, &w[m.word0], 4);
+			else visit(m.kind, obj, [&](auto& o) { o.unpack(w + m.word0); });
+		}
+	}
+};
+}
+
 // ---- Controller / Plugin / Effect / NoteBase (klang.h:4182-4292) ----
 struct Controller {
 protected:
@@ -329,7 +473,14 @@ public:
 	void attach(SYNTH* s) { synth = s; controls.c = &s->controls; }
 	virtual void start(Pitch p, Velocity v) { stage = Onset; pitch = p; velocity = v; on(pitch, velocity); stage = Sustain; }    // klang.h:4257-4263
 	virtual bool release(Velocity v = 0) { if (stage == Off) return true; if (stage != Release) { stage = Release; off(v); } return stage == Off; }
-	virtual bool stop(Velocity = 0) { stage = Off; return true; }
+	virtual bool stop(Velocity = 0) {
+		if (gpu::Recorder* r = gpu::recording()) {                 // `if (adsr.finished()) stop();` / `stop();` in a recorded process()
+			if (r->pending >= 0) { const int n = r->pending; r->emit(klg::graph::OP_STOPIF, -1, -1, n, 0, false); r->pending = -1; }
+			else r->emit(klg::graph::OP_STOP, -1, -1, -1, 0, false);
+			return true;
+		}
+		stage = Off; return true;
+	}
 	bool finished() const { return stage == Off; }
 };
 
@@ -337,19 +488,98 @@ public:
 // Synth: host voice allocation + event dispatch; blocks rendered by libklang_mi355.so
 // =================================================================================================
 template<class NOTEBASE> struct SynthCore : Plugin {
-	struct Slot { NOTEBASE* note = nullptr; NoteBinding b = { -1, nullptr, nullptr }; };
+	struct Slot { NOTEBASE* note = nullptr; NoteBinding b = { -1, nullptr, nullptr }; const gpu::GraphLayout* graph = nullptr; };
 	struct NotesT {
 		SynthCore* owner; std::vector<Slot> items; unsigned noteOns = 0; unsigned noteStart[128] = { 0 };
 		unsigned count = 0;
+		std::vector<gpu::GraphLayout*> layouts;
 		template<class T> void add(int n) {
+			const bool bound = klang_gpu_patch((const T*)nullptr) >= 0 && !std::getenv("KLANG_MI355_FORCE_GRAPH");
+			const gpu::GraphLayout* layout = nullptr;
 			for (int i = 0; i < n && items.size() < 128; i++) {
-				T* t = new T(); t->attach(static_cast<typename T::synth_type*>(owner));
-				Slot s; s.note = t;
-				s.b.patch = klang_gpu_patch((const T*)t);
+				T* t = nullptr;
+				if (!bound && !layout) { gpu::GraphLayout* l = new gpu::GraphLayout(); layouts.push_back(l); t = record<T>(*l); layout = l; }   // the prototype becomes note 0
+				else { t = new T(); t->attach(static_cast<typename T::synth_type*>(owner)); }
+				Slot s; s.note = t; s.graph = layout;
+				s.b.patch = bound ? klang_gpu_patch((const T*)t) : -1;
 				s.b.pack = [](const void* p, uint32_t* w) { klang_gpu_pack((const T*)p, w); };
 				s.b.unpack = [](void* p, const uint32_t* w) { klang_gpu_unpack((T*)p, w); };
 				items.push_back(s); count = (unsigned)items.size();
 			}
+		}
+		// Construct the prototype Note with every primitive / signal member announcing itself, run its process() once in
+		// recording mode, and turn what was recorded into a graph program + the member layout of the Note type.
+		template<class T> T* record(gpu::GraphLayout& L) {
+			using namespace klg::graph;
+			gpu::Recorder R;
+			gpu::rec = &R;
+			R.constructing = true;
+			T* t = new T();
+			R.constructing = false;
+			t->attach(static_cast<typename T::synth_type*>(owner));
+			const char* lo = (const char*)t; const char* hi = lo + sizeof(T);
+			std::vector<gpu::Recorder::Obj> kept;                            // members of THIS note; signals inside a primitive belong to the primitive
+			for (const auto& o : R.objs) {
+				const char* a = (const char*)o.addr;
+				if (a < lo || a >= hi) continue;
+				bool inside = false;
+				if (o.kind == N_PARAM) for (const auto& q : R.objs) if (q.kind != N_PARAM && a >= (const char*)q.addr && a < (const char*)q.addr + q.size) inside = true;
+				if (!inside) kept.push_back(o);
+			}
+			R.objs = kept;
+			Controls& ctl = owner->controls;
+			R.prog.nctl = (int)ctl.size() < 8 ? (int)ctl.size() : 8;
+			for (int c = 0; c < R.prog.nctl; c++) R.prog.dials[c] = { ctl[c].min, ctl[c].max, ctl[c].initial };
+			// ---- record ----
+			R.recording = true;
+			std::vector<int> first_reg(R.objs.size(), -1);
+			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; first_reg[i] = sg->reg = R.emit(OP_PARAM, -1, -1, (int)i, 0, true); }
+			for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = R.emit(OP_CTL, -1, -1, -1, (uint32_t)c, true);
+			NOTEBASE* nb = t;
+			nb->process();
+			if (R.pending >= 0) R.fail("`if (env.finished())` may only guard stop() in a recorded process()");
+			R.prog.ret = R.reg_of(nb->out);
+			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
+				signal* sg = (signal*)R.objs[i].addr;
+				if (sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);     // written by process(): the next sample reads it
+				sg->reg = -1;
+			}
+			for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = -1;
+			R.recording = false;
+			gpu::rec = nullptr;
+			if (!R.error.empty()) { std::fprintf(stderr, "klang-mi355: cannot record %s::process() as a graph patch: %s\n", typeid(T).name(), R.error.c_str()); std::abort(); }
+			// ---- dead code: pure ops nobody reads, params nobody reads (and their write-backs), primitives nobody uses ----
+			std::vector<Op>& ops = R.prog.ops;
+			std::vector<char> keep(ops.size(), 1), used;
+			auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG; };
+			for (bool changed = true; changed;) {
+				changed = false;
+				used.assign(MAX_OPS + 1, 0); used[(size_t)R.prog.ret] = 1;
+				for (size_t i = ops.size(); i-- > 0;) {                         // registers are defined before use: one backward sweep
+					if (!keep[i]) continue;
+					const Op& o = ops[i];
+					if (pure(o.code) && !used[(size_t)o.dst]) { keep[i] = 0; changed = true; continue; }
+					if (o.a >= 0) used[(size_t)o.a] = 1;
+					if (o.b >= 0) used[(size_t)o.b] = 1;
+				}
+				std::vector<char> param_read(R.objs.size(), 0);
+				for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].code == OP_PARAM) param_read[(size_t)ops[i].node] = 1;
+				for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].code == OP_SETPARAM && !param_read[(size_t)ops[i].node]) { keep[i] = 0; changed = true; }
+			}
+			std::vector<int> node_id(R.objs.size(), -1);
+			std::vector<char> node_used(R.objs.size(), 0);
+			for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].node >= 0) node_used[(size_t)ops[i].node] = 1;
+			for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) { node_id[i] = (int)R.prog.nodes.size(); R.prog.nodes.push_back(R.objs[i].kind); }
+			std::vector<Op> out_ops;
+			for (size_t i = 0; i < ops.size(); i++) if (keep[i]) { Op o = ops[i]; if (o.node >= 0) o.node = node_id[(size_t)o.node]; out_ops.push_back(o); }
+			ops = out_ops;
+			const std::string verr = R.prog.validate();
+			if (!verr.empty()) { std::fprintf(stderr, "klang-mi355: recorded program of %s is invalid: %s\n", typeid(T).name(), verr.c_str()); std::abort(); }
+			for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) L.members.push_back({ (size_t)((const char*)R.objs[i].addr - lo), R.objs[i].kind, R.prog.node_word0(node_id[i]) });
+			L.program = R.prog.text();
+			L.words = R.prog.words();
+			if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", typeid(T).name(), L.program.c_str());
+			return t;
 		}
 		NOTEBASE* operator[](int i) { return items[(size_t)i].note; }
 		int assign() {                                                       // Notes::assign klang.h:4336-4372
@@ -362,7 +592,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 			noteStart[oldest] = noteOns++;
 			return oldest;
 		}
-		~NotesT() { for (auto& s : items) delete s.note; }
+		~NotesT() { for (auto& s : items) delete s.note; for (auto* l : layouts) delete l; }
 	} notes;
 	klg_synth* gpu = nullptr;
 	std::vector<uint32_t> words;
@@ -376,9 +606,15 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		if (gpu) return;
 		if (!notes.count) { std::fprintf(stderr, "klang-mi355: Synth has no notes (call notes.add<T>(n))\n"); std::abort(); }
 		const int patch = notes.items[0].b.patch;
-		if (patch < 0) { std::fprintf(stderr, "klang-mi355: no GPU kernel is bound to this Note type: use KLANG_GPU_BIND (klang/bindings.h)\n"); std::abort(); }
-		gpu = klg_synth_create(patch, 1, (int)notes.count, fs.f, 1024);
-		if (!gpu) fail("klg_synth_create");
+		if (const gpu::GraphLayout* g = notes.items[0].graph) {              // recorded process(): compiled for gfx950 now (hipRTC)
+			gpu = klg_synth_create_graph(g->program.c_str(), 1, (int)notes.count, fs.f, 1024);
+			if (!gpu) fail("klg_synth_create_graph");
+		}
+		else {
+			if (patch < 0) { std::fprintf(stderr, "klang-mi355: no GPU kernel is bound to this Note type\n"); std::abort(); }
+			gpu = klg_synth_create(patch, 1, (int)notes.count, fs.f, 1024);
+			if (!gpu) fail("klg_synth_create");
+		}
 		words.resize(klg_synth_state_bytes(gpu) / 4);
 		stages.resize(notes.count);
 		sync_controls();
@@ -389,9 +625,9 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		ensure_gpu();
 		Slot& s = notes.items[(size_t)n];
 		if (klg_voice_download(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_download");
-		if ((words[0] & 3u) != (uint32_t)klg::ST_OFF || s.note->stage != NOTEBASE::Off) s.b.unpack(s.note, words.data());
+		if ((words[0] & 3u) != (uint32_t)klg::ST_OFF || s.note->stage != NOTEBASE::Off) { if (s.graph) s.graph->unpack(s.note, words.data()); else s.b.unpack(s.note, words.data()); }
 		event_code(s.note);
-		s.b.pack(s.note, words.data());
+		if (s.graph) s.graph->pack(s.note, words.data()); else s.b.pack(s.note, words.data());
 		words[0] = (words[0] & ~3u) | (uint32_t)s.note->stage;
 		if (klg_voice_upload(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_upload");
 	}

@@ -40,7 +40,7 @@ enum NodeKind {
 	N_SAW = 1,      /* Fast::OSM, saw family (Saw, Triangle)   5175-5354   words: inc, offset, duty, delta, state */
 	N_PULSE = 2,    /* Fast::OSM, pulse family (Square, Pulse)             same words */
 	N_LPF = 3,      /* Filters::Biquad::LPF             5550-5666           words: b0 b1 b2 a1 a2 z0 z1 f Q */
-	N_ENV = 4,      /* Envelope, <= 4 breakpoints, no loop  3867-4102       words: r_out r_target r_rate time bits npoints px[4] py[4] */
+	N_ENV = 4,      /* Envelope, <= 4 breakpoints       3867-4102           words: r_out r_target r_rate time bits npoints loop px[4] py[4] */
 	N_ADSR = 5,     /* ADSR                             4105-4137           words: r_out r_target r_rate time bits A AD S R */
 	N_PARAM = 6,    /* a signal / param member of the Note that process() reads (and may write)   words: value */
 	N_KINDS
@@ -48,7 +48,7 @@ enum NodeKind {
 enum { FSINE_INC = 0, FSINE_POS, FSINE_WORDS };
 enum { OSM_INC = 0, OSM_OFFSET, OSM_DUTY, OSM_DELTA, OSM_STATE, OSM_WORDS };
 enum { LPF_B0 = 0, LPF_B1, LPF_B2, LPF_A1, LPF_A2, LPF_Z0, LPF_Z1, LPF_F, LPF_Q, LPF_WORDS };
-enum { ENV_OUT = 0, ENV_TARGET, ENV_RATE, ENV_TIME, ENV_BITS, ENV_NPOINTS, ENV_PX, ENV_PY = ENV_PX + 4, ENV_WORDS = ENV_PY + 4 };
+enum { ENV_OUT = 0, ENV_TARGET, ENV_RATE, ENV_TIME, ENV_BITS, ENV_NPOINTS, ENV_LOOP /* start | end << 8, 0xFF = none (setLoop) */, ENV_PX, ENV_PY = ENV_PX + 4, ENV_WORDS = ENV_PY + 4 };
 enum { ADSR_OUT = 0, ADSR_TARGET, ADSR_RATE, ADSR_TIME, ADSR_BITS, ADSR_A, ADSR_AD, ADSR_S, ADSR_R, ADSR_WORDS };
 enum { MAX_WORDS = 128, MAX_NODES = 64, MAX_OPS = 1024 };
 

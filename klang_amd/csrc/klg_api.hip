@@ -200,6 +200,7 @@ extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_s
 // replaces: constructing a user Synth whose Note::process() is NOT one of the shipped patch ids: the recorded body
 // (include/klang_mi355_graph.h) is compiled for gfx950 with hipRTC and rendered by the same klg_render kernel.
 extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, int notes_per_synth, float sample_rate, int max_block) {
+	RandGuard rg;                 // hipRTC / comgr draw temporary names from libc random(): the caller's klang::random(seed) stream must survive
 	const graphrt::Compiled* c = nullptr;
 	const std::string err = graphrt::compile(program, &c);
 	if (!err.empty()) { fail(KLG_ERR_INVALID, "klg_synth_create_graph: %s", err.c_str()); return nullptr; }
@@ -218,6 +219,7 @@ extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, in
 // Parse, generate and compile a graph program for gfx950 WITHOUT touching a device (build-time / CI check).
 // Returns 0 or KLG_ERR_INVALID; the message (or the generated source when `want_source`) is copied into `out`.
 extern "C" int klg_graph_check(const char* program, int want_source, char* out, size_t out_cap) {
+	RandGuard rg;
 	const graphrt::Compiled* c = nullptr;
 	const std::string err = graphrt::compile(program, &c);
 	const std::string& msg = err.empty() ? (want_source ? c->source : err) : err;

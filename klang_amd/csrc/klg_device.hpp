@@ -311,6 +311,45 @@ __device__ __forceinline__ float env_process(Env& e, const PTS& p, int npoints, 
 	return out;
 }
 
+// The same with the breakpoint count and the loop (Envelope::setLoop, klang.h:3923-3926; Loop 3853-3864) known only at run
+// time: what a recorded graph patch uses for its Envelope members.  ls / le = loop.start / loop.end, -1 = no loop.
+__device__ __forceinline__ void env_segment_end_rt(Env& e, const Pts4& p, int npoints, int ls, int le, const SampleRate& fs) {
+	if (e.stage == ENV_SUSTAIN) {
+		if (ls >= 0 && le >= 0 && (e.point + 1) >= le) {                // loop.isActive() && (point + 1) >= loop.end
+			e.point = ls;
+			env_set_value(e, p.y(ls));
+			if (ls != le) env_set_target_time(e, p.x(ls + 1), p.y(ls + 1), p.x(ls), fs.f);
+		}
+		else if ((e.point + 1) < npoints) {
+			if (e.time >= p.x(e.point + 1)) {
+				e.point++;
+				env_set_value(e, p.y(e.point));
+				if ((e.point + 1) < npoints)
+					env_set_target_time(e, p.x(e.point + 1), p.y(e.point + 1), p.x(e.point), fs.f);
+			}
+		}
+		else e.stage = ENV_OFF;
+	}
+	else if (e.stage == ENV_RELEASE) e.stage = ENV_OFF;
+}
+__device__ __forceinline__ float env_process_rt(Env& e, const Pts4& p, int npoints, int ls, int le, const SampleRate& fs) {
+	const float out = e.r_out;
+	const bool up = e.r_target > e.r_out;
+	const float nxt = e.r_out + (up ? e.r_rate : -e.r_rate);
+	const float stepped = __builtin_amdgcn_fmed3f(e.r_out, nxt, e.r_target);
+	e.r_out = e.active ? stepped : e.r_out;
+	e.active = e.active && (stepped != e.r_target);
+	const bool sustain = (e.stage == ENV_SUSTAIN);
+	e.time = sustain ? (e.time + fs.timeInc) : e.time;
+	// holding on a one-point loop re-applies setValue(points[start].y) every sample: nothing changes once it has been applied
+	const bool settled = ls >= 0 && ls == le && e.point == ls && e.r_out == p.y(ls);
+	const bool rare = !e.active && ((sustain && !settled) || e.stage == ENV_RELEASE);
+	if (__ballot(rare) != 0ull) {
+		if (rare) env_segment_end_rt(e, p, npoints, ls, le, fs);
+	}
+	return out;
+}
+
 // Envelope state <-> 6 flag bits: stage(2) | point(3) | active(1)
 __device__ __forceinline__ uint32_t env_pack(const Env& e) { return (uint32_t)e.stage | ((uint32_t)e.point << 2) | ((uint32_t)e.active << 5); }
 __device__ __forceinline__ void env_unpack(Env& e, uint32_t b) { e.stage = (int)(b & 3u); e.point = (int)((b >> 2) & 7u); e.active = ((b >> 5) & 1u) != 0; }

@@ -68,9 +68,10 @@ inline std::string generate_source(const Program& g) {
 			}
 			break;
 		case N_ENV:
-			live += fmt(" Env n%zu; Pts4 n%zup; int n%zunp;", i, i, i);
+			live += fmt(" Env n%zu; Pts4 n%zup; int n%zunp, n%zuls, n%zule;", i, i, i, i, i);
 			begin += "\t\t" + n + ".r_out = " + F(ENV_OUT) + "; " + n + ".r_target = " + F(ENV_TARGET) + "; " + n + ".r_rate = " + F(ENV_RATE) + "; " + n + ".time = " + F(ENV_TIME) + "; env_unpack(" + n + ", " + R(ENV_BITS) + "); "
-				+ n + "np = (int)" + R(ENV_NPOINTS) + ";\n";
+				+ n + "np = (int)" + R(ENV_NPOINTS) + "; " + n + "ls = (int)(" + R(ENV_LOOP) + " & 0xFFu); " + n + "le = (int)((" + R(ENV_LOOP) + " >> 8) & 0xFFu); "
+				+ n + "ls = " + n + "ls == 255 ? -1 : " + n + "ls; " + n + "le = " + n + "le == 255 ? -1 : " + n + "le;\n";
 			begin += "\t\t" + n + "p.x0 = " + F(ENV_PX) + "; " + n + "p.x1 = " + F(ENV_PX + 1) + "; " + n + "p.x2 = " + F(ENV_PX + 2) + "; " + n + "p.x3 = " + F(ENV_PX + 3) + "; "
 				+ n + "p.y0 = " + F(ENV_PY) + "; " + n + "p.y1 = " + F(ENV_PY + 1) + "; " + n + "p.y2 = " + F(ENV_PY + 2) + "; " + n + "p.y3 = " + F(ENV_PY + 3) + ";\n";
 			end += W(ENV_OUT, "f2u(" + n + ".r_out)") + W(ENV_TARGET, "f2u(" + n + ".r_target)") + W(ENV_RATE, "f2u(" + n + ".r_rate)") + W(ENV_TIME, "f2u(" + n + ".time)") + W(ENV_BITS, "env_pack(" + n + ")");
@@ -101,7 +102,7 @@ inline std::string generate_source(const Program& g) {
 		case OP_OSC: body += d + (k == N_FSINE ? "fsine_process(" + n + ", 0u)" : k == N_SAW ? "osm_saw(" + n + ")" : "osm_pulse(" + n + ")") + ";\n"; break;
 		case OP_LPF: body += d + "biquad_process(" + n + ", " + a + ");\n"; break;
 		case OP_LPFSET: body += "\t\tbiquad_lpf_set(" + n + ", " + n + "s, " + a + ", " + b + ", c.fs.w);\n"; break;
-		case OP_ENV: body += d + (k == N_ADSR ? "adsr_process(" + n + ", c.fs)" : "env_process<4, false>(" + n + ", " + n + "p, " + n + "np, c.fs)") + ";\n"; break;
+		case OP_ENV: body += d + (k == N_ADSR ? "adsr_process(" + n + ", c.fs)" : "env_process_rt(" + n + ", " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs)") + ";\n"; break;
 		case OP_ADD: body += d + a + " + " + b + ";\n"; break;
 		case OP_SUB: body += d + a + " - " + b + ";\n"; break;
 		case OP_MUL: body += d + a + " * " + b + ";\n"; break;

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""oracle/gen_golden_examples.py — TEST INFRASTRUCTURE.  Golden vectors for shipped example synths that have NO hand-written
+kernel and NO C restatement: examples/Subtractive/{Breakpoint,Ramp,Release,Filter}.k run through the genuine reference
+header (oracle/_ref/ref_ex_*, built by `make -C oracle ref`, build container only).  They pin the recorded-graph path
+(include/klang_mi355_graph.h + the DSL facade): tests/test_gpu_facade.py renders the same .k files, compiled unchanged
+against include/klang/klang.h, on the GPU and compares with these fixtures.
+
+Run from the repo root in the build container:  python oracle/gen_golden_examples.py
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from scenario_io import load_ref_output, Scenario  # noqa: E402
+
+
+def scenarios():
+    rng = np.random.default_rng(20250928)
+    out = {}
+
+    def poly(patch, blocks, dump, ctl=(), off_base=6, ctl_events=()):
+        s = Scenario(patch=patch, block=256, blocks=blocks, synths=1, notes=32, dump=dump)
+        for i, v in ctl:
+            s.ctl.append((i, float(np.float32(v))))
+        pitches = rng.choice(np.arange(36, 97), size=20, replace=False)
+        for k, p in enumerate(pitches):
+            s.on(0 if k < 12 else k - 10, 0, int(p), float(rng.uniform(0.25, 1.0)))
+            s.off(off_base + (k % 7), 0, int(p), 0.0)
+        for b, i, v in ctl_events:
+            s.control(b, 0, i, v)
+        s.sort()
+        return s
+
+    out["ex_breakpoint"] = poly("ex_breakpoint", 40, [0, 1, 9, 10, 39], ctl=[(0, 0.05), (1, 0.1)], off_base=30, ctl_events=[(3, 0, 0.2), (3, 1, 0.35)])
+    out["ex_ramp"] = poly("ex_ramp", 40, [0, 1, 18, 19, 39], ctl=[(0, 0.1)], off_base=30, ctl_events=[(4, 0, 0.45)])
+    out["ex_release"] = poly("ex_release", 48, [0, 1, 6, 7, 20, 47], ctl=[(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)], ctl_events=[(5, 2, 0.4), (9, 3, 0.03)])
+    out["ex_filter"] = poly("ex_filter", 32, [0, 1, 8, 9, 31])
+    return out
+
+
+def main():
+    subprocess.run(["make", "-C", HERE, "ref"], check=True)
+    for name, s in scenarios().items():
+        scn = os.path.join(GOLD, name + ".scn")
+        s.save(scn)
+        tmp = f"/tmp/_ref_{name}.bin"
+        subprocess.run([os.path.join(HERE, "_ref", "ref_" + s.patch), scn, tmp], check=True)
+        ref = load_ref_output(tmp)
+        mix = ref["mix"]
+        keep = dict(per_voice=ref["per_voice"], dump=np.asarray(s.dump, dtype=np.int32), stages=ref["stages"],
+                    mix_abs_sum=np.abs(mix.astype(np.float64)).sum(axis=(1, 2)))
+        if mix.nbytes <= 100 * 1024:
+            keep["mix"] = mix
+        else:
+            keep["mix_dump"] = mix[np.asarray(s.dump)]
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **keep)
+        alive = int((ref["stages"] != 3).sum())
+        print(f"{name}: ok ({os.path.getsize(os.path.join(GOLD, name + '.npz')) // 1024} KiB), peak {np.abs(ref['per_voice']).max():.3f}, voice-blocks alive {alive}")
+
+
+if __name__ == "__main__":
+    main()

@@ -51,3 +51,31 @@ def test_shipped_k_files_unchanged_through_facade(binary, scenario, tmp_path):
     if not os.path.exists(path):
         pytest.skip("built only where the reference's .k files exist (build container); the binary travels in oracle/_ref/")
     check(*run_facade(path, scenario, tmp_path), scenario)
+
+
+# ---- recorded graph patches (include/klang_mi355_graph.h): the SAME .k files with no KLANG_GPU_BIND line — process() is
+# ---- recorded by the facade, compiled for gfx950 with hipRTC at Synth creation, and must match the same goldens
+@pytest.mark.parametrize("binary,scenario", [("facade_graph_sub2a_n4", "sub2a_steal"), ("facade_graph_sub2a_n4", "sub2a_n64"), ("facade_graph_sub2a_n16", "sub2a_long")])
+def test_own_dsl_patch_recorded_as_graph(binary, scenario, tmp_path):
+    path = os.path.join(ROOT, "tests", "cpp", "_bin", binary)
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    check(*run_facade(path, scenario, tmp_path), scenario)
+
+
+@pytest.mark.parametrize("binary,scenario", [("facade_graph_sub2b", "sub2b_poly"), ("facade_graph_supersaw", "supersaw_poly"), ("facade_graph_supersaw", "supersaw_ctl")])
+def test_shipped_k_files_recorded_as_graph(binary, scenario, tmp_path):
+    path = os.path.join(ROOT, "oracle", "_ref", binary)
+    if not os.path.exists(path):
+        pytest.skip("built only where the reference's .k files exist (build container); the binary travels in oracle/_ref/")
+    check(*run_facade(path, scenario, tmp_path), scenario)
+
+
+@pytest.mark.parametrize("name", ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter"])
+def test_example_synths_without_a_handwritten_kernel(name, tmp_path):
+    """examples/Subtractive/{Breakpoint,Ramp,Release,Filter}.k of the reference, compiled unchanged: there is no kernel for
+    them in the library, only the recorded graph.  Goldens: oracle/gen_golden_examples.py (genuine reference header)."""
+    path = os.path.join(ROOT, "oracle", "_ref", "facade_graph_" + name)
+    if not os.path.exists(path):
+        pytest.skip("built only where the reference's .k files exist (build container); the binary travels in oracle/_ref/")
+    check(*run_facade(path, name, tmp_path), name)
