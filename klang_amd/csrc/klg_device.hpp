@@ -147,6 +147,12 @@ __device__ __forceinline__ float osm_saw_duty0(Osm& o) {
 	const float y_wrap = -o.rcpf * (1.f + o.c2 * o.omf * (pp + o.omf)) + 1.f;
 	return carry ? y_wrap : y_lin;
 }
+// What a generated patch uses for a saw-family oscillator whose duty is only known at run time: when no voice of the wave
+// has a duty (and every state is Down) the short form above is exact, otherwise the general table.
+__device__ __forceinline__ float osm_saw_auto(Osm& o) {
+	if (__ballot(o.duty != 0u || o.state != 0) == 0ull) return osm_saw_duty0(o);
+	return osm_saw(o);
+}
 __device__ __forceinline__ float osm_pulse(Osm& o) {                        // pulse() 5304-5316
 	const float p = fast_phase_float(o.offset);
 	const int tr = osm_tick(o);

@@ -99,7 +99,7 @@ inline std::string generate_source(const Program& g) {
 		case OP_CONST: body += d + fmt("u2f(0x%08xu);\n", o.imm); break;
 		case OP_CTL: body += d + fmt("c.ctl[%u];\n", o.imm); break;
 		case OP_PARAM: body += d + n + ";\n"; break;
-		case OP_OSC: body += d + (k == N_FSINE ? "fsine_process(" + n + ", 0u)" : k == N_SAW ? "osm_saw(" + n + ")" : "osm_pulse(" + n + ")") + ";\n"; break;
+		case OP_OSC: body += d + (k == N_FSINE ? "fsine_process(" + n + ", 0u)" : k == N_SAW ? "osm_saw_auto(" + n + ")" : "osm_pulse(" + n + ")") + ";\n"; break;
 		case OP_LPF: body += d + "biquad_process(" + n + ", " + a + ");\n"; break;
 		case OP_LPFSET: body += "\t\tbiquad_lpf_set(" + n + ", " + n + "s, " + a + ", " + b + ", c.fs.w);\n"; break;
 		case OP_ENV: body += d + (k == N_ADSR ? "adsr_process(" + n + ", c.fs)" : "env_process_rt(" + n + ", " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs)") + ";\n"; break;
