@@ -112,6 +112,50 @@ struct BiquadLpfH {
 	void pack(BiquadRec& r) const { r.b0 = b0; r.b1 = b1; r.b2 = b2; r.a1 = a1; r.a2 = a2; r.z0 = z0; r.z1 = z1; }
 };
 
+// ---- row f2 set() sides: Butterworth::LPF<1>/<2> (klang.h:5786-5811), Modal (5822-5846), Envelope::Follower::AR (5872-5879) ----
+inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (hi < x ? hi : x); }
+struct Butter1H {
+	float f = 0, a1 = 0, b0 = 1, z = 0, out = 0;
+	void set(float f_, const Fs& fs) {
+		if (f != f_) {
+			f = f_;
+			const float c = 1.f / tanf(PI_F * f * fs.inv);
+			const double a0 = (double)(1.f + c);
+			const float inv = (a0 == 0.0f) ? 0.0f : (float)(1.0 / a0);
+			b0 = inv; a1 = (1.f - c) * inv;
+		}
+	}
+};
+inline void butter2_design(float f, const Fs& fs, float c[5]) {             // Biquad::Filter::set(f) with Butterworth::LPF<2>::init
+	const float Q = ROOT2_INV, w = f * fs.w, cos0 = cosf(w), sin0 = sinf(w);
+	const float a = sin0 / (2.f * Q);
+	const double a0 = (double)(1.f + a);
+	const float inv = (a0 == 0.0f) ? 0.0f : (float)(1.0 / a0);
+	c[0] = inv * ((1.f - cos0) / 2.f); c[1] = inv * (1.f - cos0); c[2] = inv * ((1.f - cos0) / 2.f); c[3] = inv * (-2.f * cos0); c[4] = inv * (1.f - a);
+}
+struct ModalH {
+	float a1 = 0, a2 = 0, y1 = 0, y2 = 0, gain = 0.05f;
+	void set(float f, float decay, const Fs& fs) {
+		gain = 0.05f;
+		const float w = f * fs.w;
+		const float d = clampf(expf(-PI_F / (decay * fs.f)), 1e-6f, 0.9999f);
+		a1 = 2.f * d * clampf(cosf(w), -0.9999f, 0.9999f);
+		a2 = -d * d;
+		y2 = 0; y1 = 0;
+	}
+	void set(float f, float decay, float g, const Fs& fs) { set(f, decay, fs); gain = clampf(g * 0.05f, -0.05f, 0.05f); }
+};
+struct FollowerArH {
+	float attack = 0, release = 0, A = 1, R = 1;
+	void set(float attack_, float release_, const Fs& fs) {
+		if (attack != attack_ || release != release_) {
+			attack = attack_; release = release_;
+			A = 1.f - (attack == 0.f ? 0.f : expf(-1.0f / (fs.f * attack)));
+			R = 1.f - (release == 0.f ? 0.f : expf(-1.0f / (fs.f * release)));
+		}
+	}
+};
+
 // ---- Envelope set()/initialise() side (klang.h:3893-3989, 4077-4081) ----
 struct EnvH {
 	float r_out = 1.f, r_target = 1.f, r_rate = 0.f; bool active = false;

@@ -244,6 +244,35 @@ struct OnePole { float b0, b1, a1, z, out; };
 __device__ __forceinline__ float onepole_lpf_process(OnePole& q, float in) { q.out = q.b0 * in + q.a1 * q.out + KLG_DENORM; return q.out; }
 __device__ __forceinline__ float onepole_process(OnePole& q, float in) { q.out = q.b0 * in + q.b1 * q.z + q.a1 * q.out + KLG_DENORM; q.z = in; return q.out; }
 
+// ---- the remaining filters / modifiers with the hot loop's shape ----
+struct Dcf { float r, z, out; };                                             // Filters::DCF klang.h:5386-5397 (r = 0.995 by default)
+__device__ __forceinline__ float dcf_process(Dcf& q, float in) { q.out = in - q.z + q.r * q.out; q.z = in; return q.out; }
+template<int ORDER> struct Iir { float a[ORDER], y[ORDER]; };                // Filters::IIR<ORDER> 5399-5432
+template<int ORDER> __device__ __forceinline__ float iir_process(Iir<ORDER>& q, float in) {
+	float out = in;
+#pragma unroll
+	for (int i = 0; i < ORDER; i++) out -= q.a[i] * q.y[i];
+#pragma unroll
+	for (int i = ORDER - 1; i > 0; --i) q.y[i] = q.y[i - 1];
+	q.y[0] = out;
+	return out;
+}
+struct Iir1 { float a, b, out; };                                            // Filters::IIR<1> 5434-5447
+__device__ __forceinline__ float iir1_process(Iir1& q, float in) { q.out = in * q.a + q.out * q.b; return q.out; }
+struct Butter1 { float b0, a1, z, out; };                                    // Filters::Butterworth::LPF<1> 5786-5799 (LPF<2> is a Biquad with its own init)
+__device__ __forceinline__ float butter1_process(Butter1& q, float in) { q.out = q.b0 * (in + q.z) - q.a1 * q.out; q.z = in; return q.out; }
+struct Modal { float a1, a2, y1, y2, gain; };                                // Modifiers::Modal 5815-5859
+__device__ __forceinline__ float modal_process(Modal& q, float in) {
+	in *= q.gain;                                                            // input()
+	const float out = in + q.a1 * q.y1 + q.a2 * q.y2;
+	q.y2 = q.y1; q.y1 = out;
+	return out;
+}
+struct FollowerAR { float A, R, out; };                                      // Envelope::Follower::AR 5865-5885
+__device__ __forceinline__ float follower_ar_process(FollowerAR& q, float in) { const float smoothing = in > q.out ? q.A : q.R; q.out = q.out + smoothing * (in - q.out); return q.out; }
+__device__ __forceinline__ float follower_peak(FollowerAR& q, float in) { return follower_ar_process(q, fabsf(in)); }          // abs(in) >> ar >> out   5902
+__device__ __forceinline__ float follower_rms(FollowerAR& q, float in) { return sqrtf(follower_ar_process(q, in * in)); } // (in * in) >> ar >> sqrt >> out   5903
+
 // ---- Envelope klang.h:3722-4102 ----
 // Lane state: the Linear ramp (out, target, rate, active 3731-3807), stage, point, time.  Breakpoints live in
 // a small register array; they are only touched on the (rare) segment change.

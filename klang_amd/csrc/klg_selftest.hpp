@@ -21,7 +21,14 @@ enum {
 	ST_STEREO_DELAY_TAP,     // p: size, delay ; in: L then R ; out interleaved l r
 	ST_MATRIX,               // in: 4 per row ; out 4 per row
 	ST_CONTROL_SMOOTH,       // p: value ; out smoothed
-	ST_NOISE_BASIC, ST_NOISE_FAST   // in: rand() results as float-encoded ints (bit pattern)
+	ST_NOISE_BASIC, ST_NOISE_FAST,  // in: rand() results as float-encoded ints (bit pattern)
+	// SURVEY §8 row f2
+	ST_DCF,                  // p: r ; in: signal
+	ST_IIR2, ST_IIR4,        // p: a[ORDER] ; in: signal
+	ST_IIR1,                 // p: a, b ; in: signal
+	ST_BUTTER1,              // p: b0, a1 ; in: signal
+	ST_MODAL,                // p: a1, a2, gain ; in: signal
+	ST_FOLLOWER_AR, ST_FOLLOWER_PEAK, ST_FOLLOWER_RMS   // p: A, R ; in: signal
 };
 
 struct SelfTestArgs { int prim, n, n_in; const float* p; const float* in; float* out; float* scratch; };
@@ -132,6 +139,16 @@ __global__ void klg_selftest_kernel(const SelfTestArgs a) {
 	} break;
 	case ST_NOISE_BASIC: for (int i = 0; i < n; i++) out[i] = basic_noise((int)__float_as_uint(in[i])); break;
 	case ST_NOISE_FAST: for (int i = 0; i < n; i++) out[i] = fast_noise((int)__float_as_uint(in[i])); break;
+	case ST_DCF: { Dcf q = { p[0], 0.f, 0.f }; for (int i = 0; i < n; i++) out[i] = dcf_process(q, in[i]); } break;
+	case ST_IIR2: { Iir<2> q = { { p[0], p[1] }, { 0.f, 0.f } }; for (int i = 0; i < n; i++) out[i] = iir_process(q, in[i]); } break;
+	case ST_IIR4: { Iir<4> q = { { p[0], p[1], p[2], p[3] }, { 0.f, 0.f, 0.f, 0.f } }; for (int i = 0; i < n; i++) out[i] = iir_process(q, in[i]); } break;
+	case ST_IIR1: { Iir1 q = { p[0], p[1], 0.f }; for (int i = 0; i < n; i++) out[i] = iir1_process(q, in[i]); } break;
+	case ST_BUTTER1: { Butter1 q = { p[0], p[1], 0.f, 0.f }; for (int i = 0; i < n; i++) out[i] = butter1_process(q, in[i]); } break;
+	case ST_MODAL: { Modal q = { p[0], p[1], 0.f, 0.f, p[2] }; for (int i = 0; i < n; i++) out[i] = modal_process(q, in[i]); } break;
+	case ST_FOLLOWER_AR: case ST_FOLLOWER_PEAK: case ST_FOLLOWER_RMS: {
+		FollowerAR q = { p[0], p[1], 0.f };
+		for (int i = 0; i < n; i++) out[i] = a.prim == ST_FOLLOWER_AR ? follower_ar_process(q, in[i]) : a.prim == ST_FOLLOWER_PEAK ? follower_peak(q, in[i]) : follower_rms(q, in[i]);
+	} break;
 	}
 }
 
@@ -165,6 +182,8 @@ extern "C" int klg_selftest(int prim, const float* params, int n_params, const f
 //       6 ADSR::set(a, d, s, r)              -> {r_out r_target r_rate time A AD S R bits}
 //       7 Envelope::set(points) (n <= 3: args = {n, x0, y0, ...}) -> {r_out r_target r_rate time bits}
 //       8 pitch -> Frequency
+//       9 Butterworth::LPF<1>::set(f) -> {b0, a1}     10 Butterworth::LPF<2>::set(f) -> {b0 b1 b2 a1 a2}
+//      11 Modal::set(f, decay[, gain (args[2] != 0)]) -> {a1, a2, gain}     12 Envelope::Follower::AR::set(attack, release) -> {A, R}
 extern "C" int klg_selftest_host(int kind, const float* args, int n_args, float sample_rate, float* out, int n_out) {
 	if (!args || !out) return fail(KLG_ERR_INVALID, "klg_selftest_host: bad arguments");
 	const host::Fs fs(sample_rate);
@@ -212,6 +231,10 @@ extern "C" int klg_selftest_host(int kind, const float* args, int n_args, float 
 		out[0] = e.r_out; out[1] = e.r_target; out[2] = e.r_rate; out[3] = e.time; out[4] = f2b(e.bits());
 	} return 0;
 	case 8: out[0] = host::pitch_to_frequency(args[0]); return 0;
+	case 9: { host::Butter1H q; q.set(args[0], fs); out[0] = q.b0; out[1] = q.a1; } return 0;
+	case 10: host::butter2_design(args[0], fs, out); return 0;
+	case 11: { host::ModalH q; if (args[2] != 0.f) q.set(args[0], args[1], args[2], fs); else q.set(args[0], args[1], fs); out[0] = q.a1; out[1] = q.a2; out[2] = q.gain; } return 0;
+	case 12: { host::FollowerArH q; q.set(args[0], args[1], fs); out[0] = q.A; out[1] = q.R; } return 0;
 	}
 	(void)n_args; (void)n_out;
 	return fail(KLG_ERR_INVALID, "klg_selftest_host: unknown kind %d", kind);

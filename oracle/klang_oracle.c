@@ -202,6 +202,85 @@ float ko_onepole_process(ko_onepole* q, float in) {
 	return q->out;
 }
 
+/* ---------- row f2: the remaining filters / modifiers ---------- */
+/* Filters::DCF klang.h:5386-5397 */
+void ko_dcf_init(ko_dcf* q) { q->r = 0.995f; q->z = 0; q->in = 0; q->out = 0; }
+float ko_dcf_process(ko_dcf* q, float in) { q->in = in; q->out = q->in - q->z + q->r * q->out; q->z = q->in; return q->out; }
+/* Filters::IIR<ORDER> klang.h:5399-5432 */
+void ko_iir_init(ko_iir* q, int order, const float* coeffs) { memset(q, 0, sizeof(*q)); q->order = order; for (int i = 0; i < order; i++) q->a[i] = coeffs[i]; }
+float ko_iir_process(ko_iir* q, float in) {
+	q->out = in;
+	for (int i = 0; i < q->order; i++) q->out -= q->a[i] * q->y[i];
+	for (int i = q->order - 1; i > 0; --i) q->y[i] = q->y[i - 1];
+	q->y[0] = q->out;
+	return q->out;
+}
+/* Filters::IIR<1> klang.h:5434-5464 */
+void ko_iir1_init(ko_iir1* q) { q->a = 1; q->b = 0; q->out = 0; }
+void ko_iir1_set(ko_iir1* q, float coeff) { q->a = coeff; q->b = 1.f - q->a; }
+float ko_iir1_process(ko_iir1* q, float in) { q->out = in * q->a + q->out * q->b; return q->out; }
+/* Filters::Butterworth::LPF<1> klang.h:5786-5799 over OnePole::Filter::set 5489-5494 */
+void ko_butter1_init(ko_butter1* q) { q->f = 0; q->a1 = 0; q->b0 = 1; q->z = 0; q->out = 0; }
+void ko_butter1_set(ko_butter1* q, float f) {
+	if (q->f != f) {
+		q->f = f;
+		const float c = 1.f / tanf(KO_PI_F * q->f * ko_fs.inv);
+		const double a0 = (double)(1.f + c);                        /* constant a0 = { 1.f + c } */
+		const float inv = (a0 == 0.0f) ? 0.0f : (float)(1.0 / a0);
+		q->b0 = inv;
+		q->a1 = (1.f - c) * inv;
+	}
+}
+float ko_butter1_process(ko_butter1* q, float in) { q->out = q->b0 * (in + q->z) - q->a1 * q->out; q->z = in; return q->out; }
+/* Filters::Butterworth::LPF<2> klang.h:5801-5811: Biquad::Filter::set(f) (Q = root2.inv) with this init() */
+void ko_butter2_set(ko_biquad* q, float f) {
+	float Q = KO_ROOT2_INV;
+	if (q->f != f || q->Q != Q) {
+		q->f = f; q->Q = Q;
+		const float w = f * ko_fs.w;
+		q->cos0 = cosf(w); q->sin0 = sinf(w);
+		if (Q < 0.5) Q = 0.5f;
+		q->a = q->sin0 / (2.f * Q);
+		const double a0 = (double)(1.f + q->a);
+		const float inv = (a0 == 0.0f) ? 0.0f : (float)(1.0 / a0);
+		q->b0 = inv * ((1.f - q->cos0) / 2.f);
+		q->b1 = inv * (1.f - q->cos0);
+		q->b2 = inv * ((1.f - q->cos0) / 2.f);
+		q->a1 = inv * (-2.f * q->cos0);
+		q->a2 = inv * (1.f - q->a);
+	}
+}
+/* Modifiers::Modal klang.h:5815-5859 */
+static float ko_clampf(float x, float lo, float hi) { return x < lo ? lo : (hi < x ? hi : x); }
+void ko_modal_init(ko_modal* q) { memset(q, 0, sizeof(*q)); q->gain = 0.05f; }
+void ko_modal_set(ko_modal* q, float f, float decay) {
+	q->gain = 0.05f;
+	const float w = f * ko_fs.w;
+	const float d = ko_clampf(expf(-KO_PI_F / (decay * ko_fs.f)), 1e-6f, 0.9999f);
+	q->a1 = 2.f * d * ko_clampf(cosf(w), -0.9999f, 0.9999f);
+	q->a2 = -d * d;
+	q->y2 = 0; q->y1 = 0; q->in = 0; q->out = 0;
+}
+void ko_modal_set_gain(ko_modal* q, float f, float decay, float gain) { ko_modal_set(q, f, decay); q->gain = ko_clampf(gain * 0.05f, -0.05f, 0.05f); }
+float ko_modal_process(ko_modal* q, float in) {
+	q->in = in; q->in *= q->gain;                                   /* input() */
+	q->out = q->in + q->a1 * q->y1 + q->a2 * q->y2;
+	q->y2 = q->y1; q->y1 = q->out; q->in = 0;
+	return q->out;
+}
+/* Envelope::Follower klang.h:5862-5903 */
+void ko_follower_ar_init(ko_follower_ar* q) { q->attack = 0; q->release = 0; q->A = 1; q->R = 1; q->out = 0; }
+void ko_follower_ar_set(ko_follower_ar* q, float attack, float release) {
+	if (q->attack != attack || q->release != release) {
+		q->attack = attack; q->release = release;
+		q->A = 1.f - (attack == 0.f ? 0.f : expf(-1.0f / (ko_fs.f * attack)));
+		q->R = 1.f - (release == 0.f ? 0.f : expf(-1.0f / (ko_fs.f * release)));
+	}
+}
+float ko_follower_ar_process(ko_follower_ar* q, float in) { const float smoothing = in > q->out ? q->A : q->R; q->out = q->out + smoothing * (in - q->out); return q->out; }
+float ko_follower_peak(ko_follower_ar* q, float in) { return ko_follower_ar_process(q, fabsf(in)); }
+float ko_follower_rms(ko_follower_ar* q, float in) { return sqrtf(ko_follower_ar_process(q, in * in)); }
+
 /* ---------- Filters::Biquad klang.h:5550-5773 ---------- */
 void ko_biquad_reset(ko_biquad* q) { q->f = 0; q->Q = 0; q->b0 = 1; q->a1 = q->a2 = q->b1 = q->b2 = 0; q->a = 0; q->z0 = q->z1 = 0; }  /* 5565-5572 */
 void ko_biquad_init(ko_biquad* q, int type) { memset(q, 0, sizeof(*q)); q->type = type; q->b0 = 1; q->cos0 = 1; }

@@ -3,6 +3,7 @@
  * with the C restatement, in the same record format, so tests/test_oracle_kat.py can compare the
  * two files record-by-record, bit-for-bit. */
 #include "klang_oracle.h"
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -156,6 +157,38 @@ int main(int argc, char** argv) {
 		ko_control_set(&c, 7.f); buf[512] = c.value; ko_control_set(&c, -7.f); buf[513] = c.value;
 		emit("control_smooth_0.5", buf, 514);
 	}
+	/* --- row f2 --- */
+	{ ko_dcf q; ko_dcf_init(&q); for (int i = 0; i < N; i++) buf[i] = ko_dcf_process(&q, noise(i)); emit("dcf_default", buf, N); }
+	{ ko_dcf q; ko_dcf_init(&q); q.r = 0.9f; for (int i = 0; i < N; i++) buf[i] = ko_dcf_process(&q, noise(i)); emit("dcf_0.9", buf, N); }
+	{ const float c[2] = { -1.2f, 0.5f }; ko_iir q; ko_iir_init(&q, 2, c); for (int i = 0; i < N; i++) buf[i] = ko_iir_process(&q, noise(i)); emit("iir2", buf, N); }
+	{ const float c[4] = { -0.5f, 0.25f, -0.125f, 0.0625f }; ko_iir q; ko_iir_init(&q, 4, c); for (int i = 0; i < N; i++) buf[i] = ko_iir_process(&q, noise(i)); emit("iir4", buf, N); }
+	{ ko_iir1 q; ko_iir1_init(&q); ko_iir1_set(&q, 0.25f); for (int i = 0; i < N; i++) buf[i] = ko_iir1_process(&q, noise(i)); emit("iir1_0.25", buf, N); }
+	for (int k = 0; k < NF; k++) {
+		const float f = freqs[k];
+		{ ko_butter1 q; ko_butter1_init(&q); ko_butter1_set(&q, f); const float c[2] = { q.b0, q.a1 }; snprintf(nm, 128, "butter1_coef_%g", f); emit(nm, c, 2);
+		  for (int i = 0; i < N; i++) buf[i] = ko_butter1_process(&q, noise(i));
+		  snprintf(nm, 128, "butter1_%g", f); emit(nm, buf, N); }
+		{ ko_biquad q; ko_biquad_init(&q, KO_BQ_LPF); ko_butter2_set(&q, f); const float c[5] = { q.b0, q.b1, q.b2, q.a1, q.a2 }; snprintf(nm, 128, "butter2_coef_%g", f); emit(nm, c, 5);
+		  for (int i = 0; i < N; i++) buf[i] = ko_biquad_process(&q, noise(i));
+		  snprintf(nm, 128, "butter2_%g", f); emit(nm, buf, N); }
+	}
+	{
+		const float modal[3][3] = { { 440.f, 0.5f, 0.f }, { 1000.f, 0.05f, 0.f }, { 110.f, 2.0f, 0.5f } };
+		for (int k = 0; k < 3; k++) {
+			ko_modal q; ko_modal_init(&q);
+			if (modal[k][2] != 0.f) ko_modal_set_gain(&q, modal[k][0], modal[k][1], modal[k][2]); else ko_modal_set(&q, modal[k][0], modal[k][1]);
+			const float c[3] = { q.a1, q.a2, q.gain }; snprintf(nm, 128, "modal_coef_%d", k); emit(nm, c, 3);
+			for (int i = 0; i < N; i++) buf[i] = ko_modal_process(&q, (i % 97) == 0 ? 1.f : 0.25f * noise(i));
+			snprintf(nm, 128, "modal_%d", k); emit(nm, buf, N);
+		}
+	}
+	{
+		ko_follower_ar q; ko_follower_ar_init(&q); ko_follower_ar_set(&q, 0.01f, 0.1f); const float c[2] = { q.A, q.R }; emit("follower_ar_coef", c, 2);
+		for (int i = 0; i < N; i++) buf[i] = ko_follower_ar_process(&q, fabsf(noise(i)) * ((i / 200) % 2 ? 0.1f : 1.f));
+		emit("follower_ar", buf, N);
+	}
+	{ ko_follower_ar q; ko_follower_ar_init(&q); ko_follower_ar_set(&q, 0.01f, 0.1f); for (int i = 0; i < N; i++) buf[i] = ko_follower_peak(&q, noise(i) * ((i / 200) % 2 ? 0.1f : 1.f)); emit("follower_peak", buf, N); }
+	{ ko_follower_ar q; ko_follower_ar_init(&q); ko_follower_ar_set(&q, 0.01f, 0.1f); for (int i = 0; i < N; i++) buf[i] = ko_follower_rms(&q, noise(i) * ((i / 200) % 2 ? 0.1f : 1.f)); emit("follower_rms", buf, N); }
 	fclose(g_out);
 	return 0;
 }

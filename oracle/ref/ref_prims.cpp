@@ -185,6 +185,37 @@ int main(int argc, char** argv) {
 		emit("control_smooth_0.5", v);
 	}
 
+	// --- row f2: the remaining filters / modifiers that share the hot loop's shape
+	auto run_mod = [&](auto& q, int n, float scale) { std::vector<float> v(n); for (int i = 0; i < n; i++) { signal x(scale * noise(i)), y; x >> q >> y; v[i] = y; } return v; };
+	{ Filters::DCF q; emit("dcf_default", run_mod(q, N, 1.f)); }
+	{ Filters::DCF q; q.set(0.9f); emit("dcf_0.9", run_mod(q, N, 1.f)); }
+	{ Filters::IIR<2> q; q.set(-1.2f, 0.5f); emit("iir2", run_mod(q, N, 1.f)); }
+	{ Filters::IIR<4> q; q.set(-0.5f, 0.25f, -0.125f, 0.0625f); emit("iir4", run_mod(q, N, 1.f)); }
+	{ Filters::IIR<1> q; q.set(0.25f); emit("iir1_0.25", run_mod(q, N, 1.f)); }
+	for (float f : freqs) {
+		{ Filters::Butterworth::LPF<1> q; q.set(f); snprintf(nm, 128, "butter1_coef_%g", f); emit(nm, { q.b0, q.a1 }); snprintf(nm, 128, "butter1_%g", f); emit(nm, run_mod(q, N, 1.f)); }
+		{ Filters::Butterworth::LPF<2> q; q.set(f); snprintf(nm, 128, "butter2_coef_%g", f); emit(nm, { q.b0, q.b1, q.b2, q.a1, q.a2 }); snprintf(nm, 128, "butter2_%g", f); emit(nm, run_mod(q, N, 1.f)); }
+	}
+	{
+		const float modal[3][3] = { { 440.f, 0.5f, 0.f }, { 1000.f, 0.05f, 0.f }, { 110.f, 2.0f, 0.5f } };
+		for (int k = 0; k < 3; k++) {
+			Modifiers::Modal q;
+			if (modal[k][2] != 0.f) q.set(modal[k][0], modal[k][1], modal[k][2]); else q.set(modal[k][0], modal[k][1]);
+			snprintf(nm, 128, "modal_coef_%d", k); emit(nm, { q.a1, q.a2, q.gain });
+			std::vector<float> v(N);
+			for (int i = 0; i < N; i++) { signal x((i % 97) == 0 ? 1.f : 0.25f * noise(i)), y; x >> q >> y; v[i] = y; }   // excitation: clicks on a noise floor
+			snprintf(nm, 128, "modal_%d", k); emit(nm, v);
+		}
+	}
+	{
+		Envelope::Follower::AR ar; ar.set(0.01f, 0.1f); emit("follower_ar_coef", { ar.A, ar.R });
+		std::vector<float> v(N);
+		for (int i = 0; i < N; i++) { signal x(fabsf(noise(i)) * ((i / 200) % 2 ? 0.1f : 1.f)), y; x >> ar >> y; v[i] = y; }
+		emit("follower_ar", v);
+	}
+	{ Envelope::Follower q; q = Peak; std::vector<float> v(N); for (int i = 0; i < N; i++) { signal x(noise(i) * ((i / 200) % 2 ? 0.1f : 1.f)), y; x >> q >> y; v[i] = y; } emit("follower_peak", v); }
+	{ Envelope::Follower q; q = RMS; std::vector<float> v(N); for (int i = 0; i < N; i++) { signal x(noise(i) * ((i / 200) % 2 ? 0.1f : 1.f)), y; x >> q >> y; v[i] = y; } emit("follower_rms", v); }
+
 	fclose(g_out);
 	return 0;
 }

@@ -16,7 +16,8 @@ FS = 48000.0
 FREQS = [27.5, 110.0, 440.0, 1000.0, 2093.0045, 7040.0, 15000.0]
 (ST_BASIC_SINE, ST_BASIC_SAW, ST_BASIC_TRIANGLE, ST_BASIC_SQUARE, ST_BASIC_PULSE, ST_FAST_SINE, ST_OSM_SAW, ST_OSM_PULSE,
  ST_ONEPOLE_LPF, ST_ONEPOLE_HPF, ST_BIQUAD, ST_BIQUAD_LPF_SWEEP, ST_ADSR, ST_ENV3, ST_OPERATOR3, ST_DELAY, ST_STEREO_DELAY_TAP,
- ST_MATRIX, ST_CONTROL_SMOOTH, ST_NOISE_BASIC, ST_NOISE_FAST) = range(21)
+ ST_MATRIX, ST_CONTROL_SMOOTH, ST_NOISE_BASIC, ST_NOISE_FAST,
+ ST_DCF, ST_IIR2, ST_IIR4, ST_IIR1, ST_BUTTER1, ST_MODAL, ST_FOLLOWER_AR, ST_FOLLOWER_PEAK, ST_FOLLOWER_RMS) = range(30)
 F32P = C.POINTER(C.c_float)
 
 
@@ -114,6 +115,43 @@ def test_onepole_and_biquads(L, kat, f):
             c = host(L, 5, [t, f, Q], 5)
             assert same(c, kat[f"biquad_{tag}_coef_{g(f)}_{g(np.float32(Q))}"]), (tag, Q)
             assert same(run(L, ST_BIQUAD, c, 256, inp=x[:256]), kat[f"biquad_{tag}_{g(f)}_{g(np.float32(Q))}"]), (tag, Q)
+
+
+# ---- DCF, IIR<N>, IIR<1>, Butterworth::LPF<1>/<2>, Modal, Envelope::Follower ----
+def test_f2_dcf_and_iir(L, kat):
+    x = noise(0, 1024)
+    assert same(run(L, ST_DCF, [0.995], 1024, inp=x), kat["dcf_default"])
+    assert same(run(L, ST_DCF, [0.9], 1024, inp=x), kat["dcf_0.9"])
+    assert same(run(L, ST_IIR2, [-1.2, 0.5], 1024, inp=x), kat["iir2"])
+    assert same(run(L, ST_IIR4, [-0.5, 0.25, -0.125, 0.0625], 1024, inp=x), kat["iir4"])
+    a = np.float32(0.25)
+    assert same(run(L, ST_IIR1, [a, np.float32(1.0) - a], 1024, inp=x), kat["iir1_0.25"])
+
+
+@pytest.mark.parametrize("f", FREQS)
+def test_f2_butterworth(L, kat, f):
+    x = noise(0, 1024)
+    c = host(L, 9, [f], 2)
+    assert same(c, kat[f"butter1_coef_{g(f)}"])
+    assert same(run(L, ST_BUTTER1, c, 1024, inp=x), kat[f"butter1_{g(f)}"])
+    c = host(L, 10, [f], 5)
+    assert same(c, kat[f"butter2_coef_{g(f)}"])
+    assert same(run(L, ST_BIQUAD, c, 1024, inp=x), kat[f"butter2_{g(f)}"])          # LPF<2> is a Biquad::Filter with its own init()
+
+
+def test_f2_modal_and_follower(L, kat):
+    i = np.arange(1024)
+    x = np.where(i % 97 == 0, np.float32(1.0), np.float32(0.25) * noise(0, 1024)).astype(np.float32)
+    for k, args in enumerate(([440.0, 0.5, 0.0], [1000.0, 0.05, 0.0], [110.0, 2.0, 0.5])):
+        c = host(L, 11, args, 3)
+        assert same(c, kat[f"modal_coef_{k}"]), k
+        assert same(run(L, ST_MODAL, c, 1024, inp=x), kat[f"modal_{k}"]), k
+    c = host(L, 12, [0.01, 0.1], 2)
+    assert same(c, kat["follower_ar_coef"])
+    gate = np.where((i // 200) % 2 == 1, np.float32(0.1), np.float32(1.0)).astype(np.float32)
+    assert same(run(L, ST_FOLLOWER_AR, c, 1024, inp=np.abs(noise(0, 1024)) * gate), kat["follower_ar"])
+    assert same(run(L, ST_FOLLOWER_PEAK, c, 1024, inp=noise(0, 1024) * gate), kat["follower_peak"])
+    assert same(run(L, ST_FOLLOWER_RMS, c, 1024, inp=noise(0, 1024) * gate), kat["follower_rms"])
 
 
 def test_biquad_swept_cutoff_on_device(L, kat):
