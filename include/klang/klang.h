@@ -20,11 +20,12 @@
 //   * a GENERATED one (graph patch, include/klang_mi355_graph.h): notes.add<T>() runs T::process() ONCE in recording mode —
 //     every primitive's process(), every `>>`, `++`, arithmetic operator and filter.set() appends an op to a program
 //     instead of computing — and the program is compiled for gfx950 by klg_synth_create_graph().  Supported in a
-//     recorded process(): Fast::{Sine,Saw,Triangle,Square,Pulse} (frequency set in on()), Biquad::LPF (static, or
-//     set(f, Q) per sample), Envelope (<= 4 points) and ADSR `++`, + - * / on signals / params / controls / constants,
-//     signal and param members of the Note (read, and written for next-sample state), `>> out`, `out *= x`, and
-//     `if (env.finished()) stop();`.  Anything else (a signal forced to a plain float, data-dependent branches, set() of
-//     an oscillator per sample) stops with a message naming the construct.
+//     recorded process(): Fast::{Sine,Saw,Triangle,Square,Pulse} with their frequency set in on() or per sample
+//     (`osc(f * (1 + lfo * depth))`: vibrato / FM by set(f)), Biquad::LPF (static, or set(f, Q) per sample), Envelope
+//     (<= 4 points, setLoop) and ADSR `++`, + - * / and unary minus on signals / params / controls / constants, `.out` of a
+//     member, signal and param members of the Note (read, and written for next-sample state), `>> out`, `out *= x`, and
+//     `if (env.finished()) stop();`.  Anything else (a signal forced to a plain float, other data-dependent branches,
+//     set(f, phase) / reset() inside process()) stops with a message naming the construct.
 // Effects (Stereo::Effect patches) are reached through klg_fx_* directly; their DSL façade is future work.
 //
 // Reference interface citations (file:line) are into nashaudio/klang's klang.h v0.7.8.
@@ -65,6 +66,8 @@ constexpr constant pi = { 3.1415926535897932384626433832795 };
 constexpr constant ln2 = { 0.6931471805599453094172321214581 };
 constexpr constant root2 = { 1.4142135623730950488016887242097 };
 
+template<typename T1, typename T2> inline T1 max(T1 a, T2 b) { return a > b ? a : (T1)b; }                              // klang.h:224 (returns the FIRST type)
+template<typename T1, typename T2> inline T1 min(T1 a, T2 b) { return a < b ? a : (T1)b; }                              // klang.h:223
 template<typename T> inline T random(const T mn, const T mx) { return std::rand() * ((mx - mn) / (T)RAND_MAX) + mn; }   // klang.h:236
 inline void random(const unsigned seed) { std::srand(seed); klg_random_seed(seed); }                                     // klang.h:239
 
@@ -162,6 +165,13 @@ inline signal& operator>>(float in, signal& dst) { dst.value = in; dst.reg = -1;
 	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator/(T x, const S& s) { return signal::bin(klg::graph::OP_DIV, signal((float)x), s, (float)x / s.value); }
 KLANG_SIGNAL_LEFT(float) KLANG_SIGNAL_LEFT(double) KLANG_SIGNAL_LEFT(int)
 #undef KLANG_SIGNAL_LEFT
+// param + param, Frequency * param, ...: both operands exactly as written (otherwise derived-to-base on one side ties with the
+// float conversion on the other and the call is ambiguous under ISO rules, which clang enforces)
+#define KLANG_SIGNAL_PAIR(OP, CODE) \
+	template<class A, class B, typename = std::enable_if_t<std::is_base_of_v<signal, A> && std::is_base_of_v<signal, B> && !(std::is_same_v<A, signal> && std::is_same_v<B, signal>)>> \
+	inline signal operator OP(const A& a, const B& b) { return signal::bin(klg::graph::CODE, a, b, a.value OP b.value); }
+KLANG_SIGNAL_PAIR(+, OP_ADD) KLANG_SIGNAL_PAIR(-, OP_SUB) KLANG_SIGNAL_PAIR(*, OP_MUL) KLANG_SIGNAL_PAIR(/, OP_DIV)
+#undef KLANG_SIGNAL_PAIR
 inline int gpu::Recorder::reg_of(const signal& s) { return s.reg >= 0 ? s.reg : emit(klg::graph::OP_CONST, -1, -1, -1, gpu::fbits(s.value), true); }
 
 struct Control;
@@ -245,6 +255,16 @@ template<class S> inline S operator-(Output<S>& o, float x) { return S(o) - x; }
 template<class S> inline S operator/(Output<S>& o, float x) { return S(o) / x; }
 template<class S> inline S operator+(float x, Output<S>& o) { return S(o) + x; }
 template<class S> inline S operator*(float x, Output<S>& o) { return S(o) * x; }
+// object (op) signal, also for temporaries (`osc * (a++ + b++)`): read the object, then combine
+inline signal operator+(Output<signal>& o, const signal& x) { const signal& a = o; return a + x; }
+inline signal operator-(Output<signal>& o, const signal& x) { const signal& a = o; return a - x; }
+inline signal operator*(Output<signal>& o, const signal& x) { const signal& a = o; return a * x; }
+inline signal operator/(Output<signal>& o, const signal& x) { const signal& a = o; return a / x; }
+// signal (op) object: the object is read (its process() runs) and combined — better than either user conversion alone
+inline signal operator+(const signal& a, Output<signal>& o) { const signal& b = o; return a + b; }
+inline signal operator-(const signal& a, Output<signal>& o) { const signal& b = o; return a - b; }
+inline signal operator*(const signal& a, Output<signal>& o) { const signal& b = o; return a * b; }
+inline signal operator/(const signal& a, Output<signal>& o) { const signal& b = o; return a / b; }
 template<class SIGNAL> struct Generator : Output<SIGNAL> {
 	template<typename... P> Output<SIGNAL>& operator()(P... p) { this->set(p...); return *this; }
 	using Output<SIGNAL>::operator>>;
@@ -305,24 +325,31 @@ namespace Fast {
 		klg::host::FSineH h;
 		Sine() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Sine), klg::graph::N_FSINE); }
 		using Oscillator::set;
-		void set(param f) override { if (gpu::no_set_while_recording("Fast::Sine::set(f)")) return; if (f != h.frequency) { h.frequency = f; h.inc = klg::host::fast_increment(f, host_fs()); } }
+		void reset() { if (gpu::no_set_while_recording("Fast::Sine::reset()")) return; h.pos = 0; }                        // klang.h:5136-5140
+		void set(param f) override {
+			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Fast::Sine"), 0, false); return; }   // per-sample set(f): vibrato / FM
+			if (f != h.frequency) { h.frequency = f; h.inc = klg::host::fast_increment(f, host_fs()); }
+		}
 		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast::Sine::set(f, phase)")) return; h.set(f, phase, host_fs()); }
 		void set(param f, relative phase) override { set(f); set(phase); }
 		void set(relative) override { device_only("Fast::Sine::set(relative) [phase modulation]"); }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast::Sine"), 0, true); return; } device_only("Fast::Sine::process()"); }
-		void pack(uint32_t* w) const { w[klg::graph::FSINE_INC] = (uint32_t)h.inc; w[klg::graph::FSINE_POS] = h.pos; }
-		void unpack(const uint32_t* w) { h.pos = w[klg::graph::FSINE_POS]; }
+		void pack(uint32_t* w) const { w[klg::graph::FSINE_INC] = (uint32_t)h.inc; w[klg::graph::FSINE_POS] = h.pos; w[klg::graph::FSINE_FREQ] = gpu::fbits(h.frequency); }
+		void unpack(const uint32_t* w) { h.inc = (int32_t)w[klg::graph::FSINE_INC]; h.pos = w[klg::graph::FSINE_POS]; std::memcpy(&h.frequency, &w[klg::graph::FSINE_FREQ], 4); }
 	};
 	struct Osm : Oscillator {
 		klg::host::OsmH h; int waveform;             // 0 = saw family, 1 = pulse family
 		Osm(int wf, float duty) : h(duty), waveform(wf) { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Osm), wf ? klg::graph::N_PULSE : klg::graph::N_SAW); }
 		using Oscillator::set;
-		void set(param f) override { if (gpu::no_set_while_recording("Fast oscillator set(f)")) return; if (h.frequency != f) { h.refresh(f, host_fs()); h.init(); } }
+		void set(param f) override {
+			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Fast oscillator"), 0, false); return; }
+			if (h.frequency != f) { h.refresh(f, host_fs()); h.init(); }
+		}
 		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase)")) return; h.set(f, phase, host_fs()); }
 		void set(param f, param phase, param duty) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase, duty)")) return; h.set(f, phase, duty, host_fs()); }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast oscillator"), 0, true); return; } device_only("Fast::Osm::process()"); }
-		void pack(uint32_t* w) const { using namespace klg::graph; w[OSM_INC] = (uint32_t)h.inc; w[OSM_OFFSET] = h.offset; w[OSM_DUTY] = h.duty; w[OSM_DELTA] = gpu::fbits(h.delta); w[OSM_STATE] = (uint32_t)h.state; }
-		void unpack(const uint32_t* w) { h.offset = w[klg::graph::OSM_OFFSET]; h.state = (int)(w[klg::graph::OSM_STATE] & 3u); }
+		void pack(uint32_t* w) const { using namespace klg::graph; w[OSM_INC] = (uint32_t)h.inc; w[OSM_OFFSET] = h.offset; w[OSM_DUTY] = h.duty; w[OSM_DELTA] = gpu::fbits(h.delta); w[OSM_STATE] = (uint32_t)h.state; w[OSM_FREQ] = gpu::fbits(h.frequency); }
+		void unpack(const uint32_t* w) { using namespace klg::graph; h.inc = (int32_t)w[OSM_INC]; h.offset = w[OSM_OFFSET]; h.state = (int)(w[OSM_STATE] & 3u); std::memcpy(&h.delta, &w[OSM_DELTA], 4); std::memcpy(&h.frequency, &w[OSM_FREQ], 4); }
 	};
 	struct Saw : Osm { Saw() : Osm(0, 0.f) {} };
 	struct Triangle : Osm { Triangle() : Osm(0, 1.f) {} };

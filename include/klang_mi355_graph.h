@@ -36,8 +36,8 @@ namespace klg { namespace graph {
 
 /* node kinds and their record words */
 enum NodeKind {
-	N_FSINE = 0,    /* Generators::Fast::Sine          klang.h:5135-5172   words: inc, pos */
-	N_SAW = 1,      /* Fast::OSM, saw family (Saw, Triangle)   5175-5354   words: inc, offset, duty, delta, state */
+	N_FSINE = 0,    /* Generators::Fast::Sine          klang.h:5135-5172   words: inc, pos, frequency (the set(f) cache) */
+	N_SAW = 1,      /* Fast::OSM, saw family (Saw, Triangle)   5175-5354   words: inc, offset, duty, delta, state, frequency */
 	N_PULSE = 2,    /* Fast::OSM, pulse family (Square, Pulse)             same words */
 	N_LPF = 3,      /* Filters::Biquad::LPF             5550-5666           words: b0 b1 b2 a1 a2 z0 z1 f Q */
 	N_ENV = 4,      /* Envelope, <= 4 breakpoints       3867-4102           words: r_out r_target r_rate time bits npoints loop px[4] py[4] */
@@ -45,8 +45,8 @@ enum NodeKind {
 	N_PARAM = 6,    /* a signal / param member of the Note that process() reads (and may write)   words: value */
 	N_KINDS
 };
-enum { FSINE_INC = 0, FSINE_POS, FSINE_WORDS };
-enum { OSM_INC = 0, OSM_OFFSET, OSM_DUTY, OSM_DELTA, OSM_STATE, OSM_WORDS };
+enum { FSINE_INC = 0, FSINE_POS, FSINE_FREQ, FSINE_WORDS };
+enum { OSM_INC = 0, OSM_OFFSET, OSM_DUTY, OSM_DELTA, OSM_STATE, OSM_FREQ, OSM_WORDS };
 enum { LPF_B0 = 0, LPF_B1, LPF_B2, LPF_A1, LPF_A2, LPF_Z0, LPF_Z1, LPF_F, LPF_Q, LPF_WORDS };
 enum { ENV_OUT = 0, ENV_TARGET, ENV_RATE, ENV_TIME, ENV_BITS, ENV_NPOINTS, ENV_LOOP /* start | end << 8, 0xFF = none (setLoop) */, ENV_PX, ENV_PY = ENV_PX + 4, ENV_WORDS = ENV_PY + 4 };
 enum { ADSR_OUT = 0, ADSR_TARGET, ADSR_RATE, ADSR_TIME, ADSR_BITS, ADSR_A, ADSR_AD, ADSR_S, ADSR_R, ADSR_WORDS };
@@ -74,6 +74,7 @@ enum OpCode {
 	OP_CTL,         /* dst = controls[imm]                 (the synth instance's control value)      */
 	OP_PARAM,       /* dst = value word of N_PARAM node                                               */
 	OP_OSC,         /* dst = oscillator node process()     Fast::Sine / OSM saw / OSM pulse           */
+	OP_OSCSET,      /* oscillator node .set(f = a)         Fast::Sine::set 5142-5147 / OSM::set 5217-5224 (per sample: vibrato, FM) */
 	OP_LPF,         /* dst = (a >> lpf node)               Biquad::Filter::process klang.h:5605-5612  */
 	OP_LPFSET,      /* lpf node .set(f = a, Q = b)         Biquad::LPF::set klang.h:5575-5600, 5658   */
 	OP_ENV,         /* dst = env/adsr node ++              Envelope::operator++ klang.h:4013-4051     */
@@ -85,7 +86,7 @@ enum OpCode {
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -172,6 +173,7 @@ struct Program {
 			case OP_CTL: if ((int)o.imm >= nctl) return bad("control index out of range"); break;
 			case OP_PARAM: if (k != N_PARAM) return bad("node is not a param"); break;
 			case OP_OSC: if (k != N_FSINE && k != N_SAW && k != N_PULSE) return bad("node is not an oscillator"); break;
+			case OP_OSCSET: if (k != N_FSINE && k != N_SAW && k != N_PULSE) return bad("node is not an oscillator"); need_a = true; has_dst = false; break;
 			case OP_LPF: if (k != N_LPF) return bad("node is not an lpf"); need_a = true; break;
 			case OP_LPFSET: if (k != N_LPF) return bad("node is not an lpf"); need_a = need_b = true; has_dst = false; break;
 			case OP_ENV: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); break;

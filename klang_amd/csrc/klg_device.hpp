@@ -59,7 +59,16 @@ __device__ __forceinline__ float fastsinp(uint32_t p) {                  // klan
 }
 
 // ---- Generators::Fast::Sine klang.h:5135-5172 (lane state: inc, pos; offset only lives inside a sample) ----
+// Fast::Increment::set(f) klang.h:4966-4972 on the device (per-sample set(f): vibrato, FM of a recorded graph patch)
+__device__ __forceinline__ int32_t fast_increment_set(float f, float fs) {
+	const float FC4 = float(261.62556530059862);
+	const float FC4_FINTMAX = float(261.62556530059862 * 2147483648.0);
+	const float FBASE = FC4_FINTMAX / fs;
+	return (int32_t)(2u * (uint32_t)(int32_t)(FBASE / FC4 * f));
+}
 struct FSine { int32_t inc; uint32_t pos; };
+// Fast::Sine::set(frequency) klang.h:5142-5147: only when it differs from the cached Oscillator::frequency
+__device__ __forceinline__ void fsine_set_f(FSine& o, float& cached, float f, float fs) { if (f != cached) { cached = f; o.inc = fast_increment_set(f, fs); } }
 __device__ __forceinline__ float fsine_process(FSine& o, uint32_t off) {
 	const float y = fastsinp(o.pos + off);
 	o.pos += (uint32_t)o.inc;
@@ -107,6 +116,16 @@ __device__ __forceinline__ void osm_derive(Osm& o) {
 	o.col = fast_phase_float(o.duty);
 	o.c1 = 1.f / o.col;
 	o.c2 = -1.f / (1.0f - o.col);
+}
+// OSM::set(frequency) klang.h:5217-5224: increment, delta and init() — which also re-derives the state from the phase
+__device__ __forceinline__ void osm_set_f(Osm& o, float& cached, float f, float fs) {
+	if (cached != f) {
+		cached = f;
+		o.inc = fast_increment_set(f, fs);
+		o.delta = fast_increment_float(o.inc);
+		o.state = ((uint32_t)(o.offset - (uint32_t)o.inc) < o.duty) ? 3 : 0;
+		osm_derive(o);
+	}
 }
 __device__ __forceinline__ int osm_tick(Osm& o) {                           // klang.h:5251-5263
 	o.state = ((o.state << 1) | (o.offset < o.duty ? 1 : 0)) & 3;

@@ -30,8 +30,8 @@ inline std::string fmt(const char* f, ...) {
 inline std::string generate_source(const Program& g) {
 	using namespace graph;
 	const int NW = g.words();
-	std::vector<bool> swept(g.nodes.size(), false), written(g.nodes.size(), false);
-	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; }
+	std::vector<bool> swept(g.nodes.size(), false), written(g.nodes.size(), false), retuned(g.nodes.size(), false);
+	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; if (o.code == OP_OSCSET) retuned[(size_t)o.node] = true; }
 	uint64_t mask[2] = { 1ull, 0ull };                                   // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
 	std::string live = "\tstruct Live { int stage;", begin, end, body;
@@ -43,17 +43,19 @@ inline std::string generate_source(const Program& g) {
 		auto W = [&](int off, const std::string& expr) { return fmt("\t\tr.w[%d] = ", w0 + off) + expr + ";\n"; };
 		switch (k) {
 		case N_FSINE:
-			live += fmt(" FSine n%zu;", i);
-			begin += "\t\t" + n + ".inc = (int32_t)" + R(FSINE_INC) + "; " + n + ".pos = " + R(FSINE_POS) + ";\n";
+			live += fmt(" FSine n%zu; float n%zuf;", i, i);
+			begin += "\t\t" + n + ".inc = (int32_t)" + R(FSINE_INC) + "; " + n + ".pos = " + R(FSINE_POS) + "; " + n + "f = " + F(FSINE_FREQ) + ";\n";
 			end += W(FSINE_POS, n + ".pos");
 			mark(w0 + FSINE_POS, 1);
+			if (retuned[i]) { end += W(FSINE_INC, "(uint32_t)" + n + ".inc") + W(FSINE_FREQ, "f2u(" + n + "f)"); mark(w0 + FSINE_INC, 1); mark(w0 + FSINE_FREQ, 1); }
 			break;
 		case N_SAW: case N_PULSE:
-			live += fmt(" Osm n%zu;", i);
+			live += fmt(" Osm n%zu; float n%zuf;", i, i);
 			begin += "\t\t" + n + ".inc = (int32_t)" + R(OSM_INC) + "; " + n + ".offset = " + R(OSM_OFFSET) + "; " + n + ".duty = " + R(OSM_DUTY) + "; " + n + ".delta = " + F(OSM_DELTA) + "; "
-				+ n + ".state = (int)(" + R(OSM_STATE) + " & 3u); osm_derive(" + n + ");\n";
+				+ n + ".state = (int)(" + R(OSM_STATE) + " & 3u); " + n + "f = " + F(OSM_FREQ) + "; osm_derive(" + n + ");\n";
 			end += W(OSM_OFFSET, n + ".offset") + W(OSM_STATE, "(uint32_t)" + n + ".state");
 			mark(w0 + OSM_OFFSET, 1); mark(w0 + OSM_STATE, 1);
+			if (retuned[i]) { end += W(OSM_INC, "(uint32_t)" + n + ".inc") + W(OSM_DELTA, "f2u(" + n + ".delta)") + W(OSM_FREQ, "f2u(" + n + "f)"); mark(w0 + OSM_INC, 1); mark(w0 + OSM_DELTA, 1); mark(w0 + OSM_FREQ, 1); }
 			break;
 		case N_LPF:
 			live += fmt(" Biquad n%zu; BiquadSweep n%zus;", i, i);
@@ -99,7 +101,8 @@ inline std::string generate_source(const Program& g) {
 		case OP_CONST: body += d + fmt("u2f(0x%08xu);\n", o.imm); break;
 		case OP_CTL: body += d + fmt("c.ctl[%u];\n", o.imm); break;
 		case OP_PARAM: body += d + n + ";\n"; break;
-		case OP_OSC: body += d + (k == N_FSINE ? "fsine_process(" + n + ", 0u)" : k == N_SAW ? "osm_saw_auto(" + n + ")" : "osm_pulse(" + n + ")") + ";\n"; break;
+		case OP_OSC: body += d + (k == N_FSINE ? "fsine_process(" + n + ", 0u)" : k == N_SAW ? (retuned[(size_t)o.node] ? "osm_saw(" : "osm_saw_auto(") + n + ")" : "osm_pulse(" + n + ")") + ";\n"; break;
+		case OP_OSCSET: body += "\t\t" + std::string(k == N_FSINE ? "fsine_set_f(" : "osm_set_f(") + n + ", " + n + "f, " + a + ", c.fs.f);\n"; break;
 		case OP_LPF: body += d + "biquad_process(" + n + ", " + a + ");\n"; break;
 		case OP_LPFSET: body += "\t\tbiquad_lpf_set(" + n + ", " + n + "s, " + a + ", " + b + ", c.fs.w);\n"; break;
 		case OP_ENV: body += d + (k == N_ADSR ? "adsr_process(" + n + ", c.fs)" : "env_process_rt(" + n + ", " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs)") + ";\n"; break;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """oracle/gen_golden_examples.py — TEST INFRASTRUCTURE.  Golden vectors for shipped example synths that have NO hand-written
-kernel and NO C restatement: examples/Subtractive/{Breakpoint,Ramp,Release,Filter}.k run through the genuine reference
+kernel and NO C restatement: examples/Subtractive/{Breakpoint,Ramp,Release,Filter,Expression}.k run through the genuine reference
 header (oracle/_ref/ref_ex_*, built by `make -C oracle ref`, build container only).  They pin the recorded-graph path
 (include/klang_mi355_graph.h + the DSL facade): tests/test_gpu_facade.py renders the same .k files, compiled unchanged
 against include/klang/klang.h, on the GPU and compares with these fixtures.
@@ -24,13 +24,13 @@ def scenarios():
     rng = np.random.default_rng(20250928)
     out = {}
 
-    def poly(patch, blocks, dump, ctl=(), off_base=6, ctl_events=()):
+    def poly(patch, blocks, dump, ctl=(), off_base=6, ctl_events=(), seeded=False):
         s = Scenario(patch=patch, block=256, blocks=blocks, synths=1, notes=32, dump=dump)
         for i, v in ctl:
             s.ctl.append((i, float(np.float32(v))))
         pitches = rng.choice(np.arange(36, 97), size=20, replace=False)
         for k, p in enumerate(pitches):
-            s.on(0 if k < 12 else k - 10, 0, int(p), float(rng.uniform(0.25, 1.0)))
+            s.on(0 if k < 12 else k - 10, 0, int(p), float(rng.uniform(0.25, 1.0)), int(rng.integers(1, 2**31 - 1)) if seeded else -1)
             s.off(off_base + (k % 7), 0, int(p), 0.0)
         for b, i, v in ctl_events:
             s.control(b, 0, i, v)
@@ -41,6 +41,9 @@ def scenarios():
     out["ex_ramp"] = poly("ex_ramp", 40, [0, 1, 18, 19, 39], ctl=[(0, 0.1)], off_base=30, ctl_events=[(4, 0, 0.45)])
     out["ex_release"] = poly("ex_release", 48, [0, 1, 6, 7, 20, 47], ctl=[(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)], ctl_events=[(5, 2, 0.4), (9, 3, 0.03)])
     out["ex_filter"] = poly("ex_filter", 32, [0, 1, 8, 9, 31])
+    # Expression.k: per-sample vibrato (osc.set(f) from an LFO whose rate is itself an envelope), three 3/4-point envelopes,
+    # swept LPF, random() in on() -> every note-on carries a seed
+    out["ex_expression"] = poly("ex_expression", 64, [0, 1, 30, 31, 63], off_base=20, seeded=True)
     return out
 
 

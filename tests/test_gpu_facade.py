@@ -71,9 +71,9 @@ def test_shipped_k_files_recorded_as_graph(binary, scenario, tmp_path):
     check(*run_facade(path, scenario, tmp_path), scenario)
 
 
-@pytest.mark.parametrize("name", ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter"])
+@pytest.mark.parametrize("name", ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter", "ex_expression"])
 def test_example_synths_without_a_handwritten_kernel(name, tmp_path):
-    """examples/Subtractive/{Breakpoint,Ramp,Release,Filter}.k of the reference, compiled unchanged: there is no kernel for
+    """examples/Subtractive/{Breakpoint,Ramp,Release,Filter,Expression}.k of the reference, compiled unchanged: there is no kernel for
     them in the library, only the recorded graph.  Goldens: oracle/gen_golden_examples.py (genuine reference header)."""
     path = os.path.join(ROOT, "oracle", "_ref", "facade_graph_" + name)
     if not os.path.exists(path):

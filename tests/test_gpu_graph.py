@@ -21,13 +21,13 @@ end
 
 
 def sub2a_to_graph(r):
-    """rec::Sub2a (20 words: flags | OsmRec | BiquadRec | AdsrRec) -> the graph record of SUB2A_PROGRAM (24 words)."""
+    """rec::Sub2a (20 words: flags | OsmRec | BiquadRec | AdsrRec) -> the graph record of SUB2A_PROGRAM (25 words)."""
     flags = int(r[0])
-    g = np.zeros(24, np.uint32)
+    g = np.zeros(25, np.uint32)
     g[0] = flags & 3
-    g[1:5] = r[1:5]; g[5] = (flags >> 8) & 3                       # osm: inc offset duty delta | state
-    g[6:13] = r[5:12]                                              # lpf: b0 b1 b2 a1 a2 z0 z1 (f, Q unused)
-    g[15:19] = r[12:16]; g[19] = (flags >> 2) & 0x3F; g[20:24] = r[16:20]   # adsr: ramp, time | bits | A AD S R
+    g[1:5] = r[1:5]; g[5] = (flags >> 8) & 3                       # osm: inc offset duty delta | state | frequency cache (unused: no set(f) in process())
+    g[7:14] = r[5:12]                                              # lpf: b0 b1 b2 a1 a2 z0 z1 (f, Q unused)
+    g[16:20] = r[12:16]; g[20] = (flags >> 2) & 0x3F; g[21:25] = r[16:20]   # adsr: ramp, time | bits | A AD S R
     return g
 
 
@@ -36,7 +36,7 @@ def test_graph_sub2a_equals_handwritten_kernel():
     S, P, N = 3, 32, 192
     hand = klang_amd.SynthBank("sub2a", synths=S, notes=P, max_block=N)
     gen = klang_amd.SynthBank(SUB2A_PROGRAM, synths=S, notes=P, max_block=N)
-    assert gen.state_bytes == 24 * 4 and gen.voices == hand.voices
+    assert gen.state_bytes == 25 * 4 and gen.voices == hand.voices
     rng = np.random.default_rng(4)
     held = []
     def mirror(voices):

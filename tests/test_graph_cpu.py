@@ -46,7 +46,7 @@ def test_program_compiles_for_gfx950_without_a_device():
     for needle in ("struct PatchGen", "osm_pulse(L.n0)", "biquad_lpf_set(L.n3, L.n3s, r3, r4, c.fs.w)", "adsr_process(L.n1, c.fs)",
                    "env_process_rt(L.n2", "c.ctl[0]", "L.n4 = r8;", "ENV_OFF) ? (int)ST_OFF : L.stage"):
         assert needle in src, needle
-    words = 1 + 5 + 9 + 15 + 9 + 1
+    words = 1 + 6 + 9 + 15 + 9 + 1
     assert f"uint32_t w[{words}]" in src
 
 
