@@ -90,10 +90,36 @@ struct OsmH {
 };
 
 // ---- Filters::Biquad::LPF set()/reset() side (klang.h:5565-5600, 5658-5665); libm: this host's glibc cosf/sinf ----
-struct BiquadLpfH {
+enum { BQ_LPF = 0, BQ_HPF, BQ_BPF_PEAK, BQ_BPF_SKIRT, BQ_BRF, BQ_APF, BQ_BUTTER2 };
+struct BiquadLpfH {                                      // (name kept: the LPF was first) — every Filters::Biquad type by `type`
+	int type = BQ_LPF;
 	float f = 0, Q = 0, a1 = 0, a2 = 0, b0 = 1, b1 = 0, b2 = 0, a = 0, cos0 = 1, sin0 = 0, z0 = 0, z1 = 0;
 	void reset() { f = 0; Q = 0; b0 = 1; a1 = a2 = b1 = b2 = 0; a = 0; z0 = z1 = 0; }
+	void init(const Fs& fs) {                            // the per-type init() klang.h:5658-5665, 5675-5682, 5708-5729, 5734-5739, 5765-5772, 5801-5811
+		if (type == BQ_APF) {
+			const float omega = 2.0f * PI_F * f / fs.f;
+			const float c = (float)cos((double)omega);
+			b0 = a2 = a * a; b1 = a1 = (-2.f * a * c); b2 = 1.f;
+			return;
+		}
+		const double a0 = (double)(1.f + a);
+		const float inv = (a0 == 0.0f) ? 0.0f : (float)(1.0 / a0);
+		a1 = inv * (-2.f * cos0);
+		a2 = inv * (1.f - a);
+		switch (type) {
+		case BQ_LPF: b2 = b0 = inv * (1.f - cos0) * 0.5f; b1 = inv * (1.f - cos0); break;
+		case BQ_HPF: b2 = b0 = inv * (1.f + cos0) * 0.5f; b1 = inv * -(1.f + cos0); break;
+		case BQ_BPF_PEAK: b0 = inv * a; b1 = 0; b2 = inv * -a; break;
+		case BQ_BPF_SKIRT: b0 = inv * sin0 * 0.5f; b1 = 0; b2 = -b0; break;
+		case BQ_BRF: b1 = a1; b0 = b2 = inv; break;
+		case BQ_BUTTER2: b0 = inv * ((1.f - cos0) / 2.f); b1 = inv * (1.f - cos0); b2 = inv * ((1.f - cos0) / 2.f); break;
+		}
+	}
 	void set(float f_, float Q_, const Fs& fs) {
+		if (type == BQ_APF) {                               // APF::set(f, r) klang.h:5752-5763
+			if (f != f_ || a != Q_) { f = f_; a = Q_; const float w = f_ * fs.w; cos0 = cosf(w); sin0 = sinf(w); init(fs); }
+			return;
+		}
 		if (Q_ < 0) Q_ = f_ / -Q_;
 		if (f != f_ || Q != Q_) {
 			f = f_; Q = Q_;
@@ -101,15 +127,23 @@ struct BiquadLpfH {
 			cos0 = cosf(w); sin0 = sinf(w);
 			if (Q_ < 0.5) Q_ = 0.5f;
 			a = sin0 / (2.f * Q_);
-			const double a0 = (double)(1.f + a);
-			const float inv = (a0 == 0.0f) ? 0.0f : (float)(1.0 / a0);
-			a1 = inv * (-2.f * cos0);
-			a2 = inv * (1.f - a);
-			b2 = b0 = inv * (1.f - cos0) * 0.5f;
-			b1 = inv * (1.f - cos0);
+			init(fs);
 		}
 	}
 	void pack(BiquadRec& r) const { r.b0 = b0; r.b1 = b1; r.b2 = b2; r.a1 = a1; r.a2 = a2; r.z0 = z0; r.z1 = z1; }
+};
+
+// ---- Filters::OnePole::LPF / HPF set() side (klang.h:5489-5494, 5510-5514, 5537-5542) ----
+struct OnePoleH {
+	bool hpf = false; float f = 0, a1 = 0, b0 = 1, b1 = 0, z = 0;
+	void reset() { a1 = 0; b0 = 1; b1 = 0; f = 0; z = 0; }
+	void set(float f_, const Fs& fs) {
+		if (f != f_) {
+			f = f_;
+			const float e = expf(-f * fs.w);
+			if (hpf) { b0 = 0.5f * (1.f + e); b1 = -b0; a1 = e; } else { b0 = 1 - e; a1 = e; }
+		}
+	}
 };
 
 // ---- row f2 set() sides: Butterworth::LPF<1>/<2> (klang.h:5786-5811), Modal (5822-5846), Envelope::Follower::AR (5872-5879) ----

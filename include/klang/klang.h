@@ -76,17 +76,19 @@ inline void random(const unsigned seed) { std::srand(seed); klg_random_seed(seed
 // =================================================================================================
 struct signal;
 namespace gpu {
+// a primitive that lives in a lane record: host mirror <-> its block of record words (include/klang_mi355_graph.h)
+struct Packable { virtual void pack(uint32_t* w) const = 0; virtual void unpack(const uint32_t* w) = 0; virtual ~Packable() {} };
 struct Recorder {
-	struct Obj { const void* addr; size_t size; int kind; };     // a primitive or a signal member seen while the prototype Note was constructed
+	struct Obj { const void* addr; size_t size; int kind; const Packable* packable; };     // a primitive or a signal member seen while the prototype Note was constructed
 	std::vector<Obj> objs;
 	bool constructing = false, recording = false;
 	klg::graph::Program prog;
 	int next_reg = 0, pending = -1;                              // pending: node whose finished() was just tested by an `if`
 	std::string error;
 	void fail(const std::string& what) { if (error.empty()) error = what; }
-	void note(const void* addr, size_t size, int kind) {
-		for (Obj& o : objs) if (o.addr == addr) { o.kind = kind; o.size = size; return; }       // ADSR refines the Envelope it derives from
-		objs.push_back({ addr, size, kind });
+	void note(const void* addr, size_t size, int kind, const Packable* p = nullptr) {
+		for (Obj& o : objs) if (o.addr == addr) { o.kind = kind; o.size = size; if (p) o.packable = p; return; }       // ADSR refines the Envelope it derives from
+		objs.push_back({ addr, size, kind, p });
 	}
 	int emit(int code, int a, int b, int node, uint32_t imm, bool has_dst) {
 		if (pending >= 0 && code != klg::graph::OP_STOPIF) fail("`if (env.finished())` may only guard stop() in a recorded process()");
@@ -311,19 +313,37 @@ struct Oscillator : Generator {
 };
 namespace Generators {
 namespace Basic {
-	struct Sine : Oscillator {
-		klg::host::BOscH h;
+	// Generic::Oscillator set() (klang.h:2862-2880) + the five Basic waveforms (4899-4944); process() is device code
+	struct Osc : Oscillator, gpu::Packable {
+		klg::host::BOscH h; float duty_ = 0.5f; int kind;
+		explicit Osc(int k) : kind(k) { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Osc), k, this); }
 		using Oscillator::set;
-		void set(param f) override { h.frequency = f; h.increment = f * 2.f * pi.f / fs.f; }
-		void set(param f, param phase) override { h.set(f, phase, host_fs()); }
-		void set(relative phase) override { h.offset = phase.value * (2 * pi); }
-		void process() override { device_only("Basic::Sine::process()"); }
+		void reset() { if (gpu::no_set_while_recording("Basic oscillator reset()")) return; h.position = 0; }
+		void set(param f) override {
+			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Basic oscillator"), 0, false); return; }
+			h.frequency = f; h.increment = f * 2.f * pi.f / fs.f;
+		}
+		void set(param f, param phase) override { if (gpu::no_set_while_recording("Basic oscillator set(f, phase)")) return; h.set(f, phase, host_fs()); }
+		void set(param f, relative phase) override { set(f); set(phase); }
+		void set(relative phase) override { if (gpu::no_set_while_recording("Basic oscillator set(relative)")) return; h.offset = phase.value * (2 * pi); }
+		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Basic oscillator"), 0, true); return; } device_only("Basic oscillator process()"); }
+		void pack(uint32_t* w) const override { using namespace klg::graph; w[BOSC_INC] = gpu::fbits(h.increment); w[BOSC_POS] = gpu::fbits(h.position); w[BOSC_OFFSET] = gpu::fbits(h.offset); w[BOSC_DUTY] = gpu::fbits(duty_); }
+		void unpack(const uint32_t* w) override { using namespace klg::graph; std::memcpy(&h.increment, &w[BOSC_INC], 4); std::memcpy(&h.position, &w[BOSC_POS], 4); }
+	};
+	struct Sine : Osc { Sine() : Osc(klg::graph::N_BSINE) {} };
+	struct Saw : Osc { Saw() : Osc(klg::graph::N_BSAW) {} };
+	struct Triangle : Osc { Triangle() : Osc(klg::graph::N_BTRI) {} };
+	struct Square : Osc { Square() : Osc(klg::graph::N_BSQUARE) {} };
+	struct Pulse : Osc {
+		Pulse() : Osc(klg::graph::N_BPULSE) {}
+		using Osc::set;
+		void set(param f, param phase, param duty) override { Osc::set(f, phase); duty_ = duty; }           // klang.h:4932-4935
 	};
 }
 namespace Fast {
-	struct Sine : Oscillator {
+	struct Sine : Oscillator, gpu::Packable {
 		klg::host::FSineH h;
-		Sine() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Sine), klg::graph::N_FSINE); }
+		Sine() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Sine), klg::graph::N_FSINE, this); }
 		using Oscillator::set;
 		void reset() { if (gpu::no_set_while_recording("Fast::Sine::reset()")) return; h.pos = 0; }                        // klang.h:5136-5140
 		void set(param f) override {
@@ -334,12 +354,12 @@ namespace Fast {
 		void set(param f, relative phase) override { set(f); set(phase); }
 		void set(relative) override { device_only("Fast::Sine::set(relative) [phase modulation]"); }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast::Sine"), 0, true); return; } device_only("Fast::Sine::process()"); }
-		void pack(uint32_t* w) const { w[klg::graph::FSINE_INC] = (uint32_t)h.inc; w[klg::graph::FSINE_POS] = h.pos; w[klg::graph::FSINE_FREQ] = gpu::fbits(h.frequency); }
-		void unpack(const uint32_t* w) { h.inc = (int32_t)w[klg::graph::FSINE_INC]; h.pos = w[klg::graph::FSINE_POS]; std::memcpy(&h.frequency, &w[klg::graph::FSINE_FREQ], 4); }
+		void pack(uint32_t* w) const override { w[klg::graph::FSINE_INC] = (uint32_t)h.inc; w[klg::graph::FSINE_POS] = h.pos; w[klg::graph::FSINE_FREQ] = gpu::fbits(h.frequency); }
+		void unpack(const uint32_t* w) override { h.inc = (int32_t)w[klg::graph::FSINE_INC]; h.pos = w[klg::graph::FSINE_POS]; std::memcpy(&h.frequency, &w[klg::graph::FSINE_FREQ], 4); }
 	};
-	struct Osm : Oscillator {
+	struct Osm : Oscillator, gpu::Packable {
 		klg::host::OsmH h; int waveform;             // 0 = saw family, 1 = pulse family
-		Osm(int wf, float duty) : h(duty), waveform(wf) { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Osm), wf ? klg::graph::N_PULSE : klg::graph::N_SAW); }
+		Osm(int wf, float duty) : h(duty), waveform(wf) { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Osm), wf ? klg::graph::N_PULSE : klg::graph::N_SAW, this); }
 		using Oscillator::set;
 		void set(param f) override {
 			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Fast oscillator"), 0, false); return; }
@@ -348,8 +368,8 @@ namespace Fast {
 		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase)")) return; h.set(f, phase, host_fs()); }
 		void set(param f, param phase, param duty) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase, duty)")) return; h.set(f, phase, duty, host_fs()); }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast oscillator"), 0, true); return; } device_only("Fast::Osm::process()"); }
-		void pack(uint32_t* w) const { using namespace klg::graph; w[OSM_INC] = (uint32_t)h.inc; w[OSM_OFFSET] = h.offset; w[OSM_DUTY] = h.duty; w[OSM_DELTA] = gpu::fbits(h.delta); w[OSM_STATE] = (uint32_t)h.state; w[OSM_FREQ] = gpu::fbits(h.frequency); }
-		void unpack(const uint32_t* w) { using namespace klg::graph; h.inc = (int32_t)w[OSM_INC]; h.offset = w[OSM_OFFSET]; h.state = (int)(w[OSM_STATE] & 3u); std::memcpy(&h.delta, &w[OSM_DELTA], 4); std::memcpy(&h.frequency, &w[OSM_FREQ], 4); }
+		void pack(uint32_t* w) const override { using namespace klg::graph; w[OSM_INC] = (uint32_t)h.inc; w[OSM_OFFSET] = h.offset; w[OSM_DUTY] = h.duty; w[OSM_DELTA] = gpu::fbits(h.delta); w[OSM_STATE] = (uint32_t)h.state; w[OSM_FREQ] = gpu::fbits(h.frequency); }
+		void unpack(const uint32_t* w) override { using namespace klg::graph; h.inc = (int32_t)w[OSM_INC]; h.offset = w[OSM_OFFSET]; h.state = (int)(w[OSM_STATE] & 3u); std::memcpy(&h.delta, &w[OSM_DELTA], 4); std::memcpy(&h.frequency, &w[OSM_FREQ], 4); }
 	};
 	struct Saw : Osm { Saw() : Osm(0, 0.f) {} };
 	struct Triangle : Osm { Triangle() : Osm(0, 1.f) {} };
@@ -359,29 +379,116 @@ namespace Fast {
 }
 
 // ---- filters ----
-namespace Filters { namespace Biquad {
-	struct LPF : Modifier {
+namespace gpu {
+// every modifier is recorded the same way: `in >> node` is one op whose result is the node's `out`
+template<class M> inline void record_modifier(M* m, const char* what) {
+	Recorder* r = recording();
+	const int ri = r->reg_of(m->in);
+	m->out.reg = r->emit(klg::graph::OP_LPF, ri, -1, r->node(m, what), 0, true);
+}
+}
+namespace Filters {
+namespace Biquad {
+	// Biquad::Filter (klang.h:5550-5652): one host design per type, one type-independent process() on the device
+	struct Filter : Modifier, gpu::Packable {
 		klg::host::BiquadLpfH h;
-		LPF() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(LPF), klg::graph::N_LPF); }
-		void reset() { if (gpu::no_set_while_recording("Biquad::LPF::reset()")) return; h.reset(); }
+		explicit Filter(int type) { h.type = type; if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Filter), klg::graph::N_LPF, this); }
+		void reset() { if (gpu::no_set_while_recording("Biquad filter reset()")) return; h.reset(); }
 		using Modifier::set;
-		void set(param f) override { set(f, param(klg::host::ROOT2_INV)); }
+		void set(param f) override { set(f, param(h.type == klg::host::BQ_APF ? 1.f : klg::host::ROOT2_INV)); }
 		void set(param f, param Q) override {
-			if (gpu::Recorder* r = gpu::recording()) { const int rf = r->reg_of(f), rq = r->reg_of(Q); r->emit(klg::graph::OP_LPFSET, rf, rq, r->node(this, "Biquad::LPF"), 0, false); return; }
+			if (gpu::Recorder* r = gpu::recording()) {
+				if (h.type != klg::host::BQ_LPF) { r->fail("set(f, Q) inside process() is recorded for Biquad::LPF only"); return; }
+				const int rf = r->reg_of(f), rq = r->reg_of(Q); r->emit(klg::graph::OP_LPFSET, rf, rq, r->node(this, "Biquad::LPF"), 0, false); return;
+			}
 			h.set(f, Q, host_fs());
 		}
-		void process() override { if (gpu::Recorder* r = gpu::recording()) { const int ri = r->reg_of(in); out.reg = r->emit(klg::graph::OP_LPF, ri, -1, r->node(this, "Biquad::LPF"), 0, true); return; } device_only("Biquad::LPF::process()"); }
-		void pack(uint32_t* w) const { using namespace klg::graph; const float v[LPF_WORDS] = { h.b0, h.b1, h.b2, h.a1, h.a2, h.z0, h.z1, h.f, h.Q }; for (int i = 0; i < LPF_WORDS; i++) w[i] = gpu::fbits(v[i]); }
-		void unpack(const uint32_t* w) { using namespace klg::graph; float* v[LPF_WORDS] = { &h.b0, &h.b1, &h.b2, &h.a1, &h.a2, &h.z0, &h.z1, &h.f, &h.Q }; for (int i = 0; i < LPF_WORDS; i++) std::memcpy(v[i], &w[i], 4); }
+		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "Biquad filter"); return; } device_only("Biquad filter process()"); }
+		void pack(uint32_t* w) const override { using namespace klg::graph; const float v[LPF_WORDS] = { h.b0, h.b1, h.b2, h.a1, h.a2, h.z0, h.z1, h.f, h.Q }; for (int i = 0; i < LPF_WORDS; i++) w[i] = gpu::fbits(v[i]); }
+		void unpack(const uint32_t* w) override { using namespace klg::graph; float* v[LPF_WORDS] = { &h.b0, &h.b1, &h.b2, &h.a1, &h.a2, &h.z0, &h.z1, &h.f, &h.Q }; for (int i = 0; i < LPF_WORDS; i++) std::memcpy(v[i], &w[i], 4); }
 	};
-} }
+	struct LPF : Filter { LPF() : Filter(klg::host::BQ_LPF) {} };
+	struct HPF : Filter { HPF() : Filter(klg::host::BQ_HPF) {} };
+	struct BPF : Filter {                                                       // klang.h:5689-5730
+		enum Gain { ConstantSkirtGain, ConstantPeakGain };
+		BPF() : Filter(klg::host::BQ_BPF_PEAK) {}
+		BPF& operator=(Gain g) { h.type = g == ConstantSkirtGain ? klg::host::BQ_BPF_SKIRT : klg::host::BQ_BPF_PEAK; h.init(host_fs()); return *this; }
+	};
+	struct BRF : Filter { BRF() : Filter(klg::host::BQ_BRF) {} };
+	struct APF : Filter { APF() : Filter(klg::host::BQ_APF) {} };
+	typedef LPF HCF; typedef LPF HRF; typedef HPF LCF; typedef HPF LRF; typedef BRF BSF;
+}
+	// Filters::DCF klang.h:5386-5397
+	struct DCF : Modifier, gpu::Packable {
+		float r = 0.995f, z = 0;
+		DCF() { if (gpu::Recorder* rr = gpu::constructing()) rr->note(this, sizeof(DCF), klg::graph::N_DCF, this); }
+		void set(float r_) { r = r_; }
+		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "DCF"); return; } device_only("DCF::process()"); }
+		void pack(uint32_t* w) const override { w[klg::graph::DCF_R] = gpu::fbits(r); w[klg::graph::DCF_Z] = gpu::fbits(z); w[klg::graph::DCF_OUT] = gpu::fbits(out.value); }
+		void unpack(const uint32_t* w) override { std::memcpy(&z, &w[klg::graph::DCF_Z], 4); std::memcpy(&out.value, &w[klg::graph::DCF_OUT], 4); }
+	};
+	// Filters::IIR<1> klang.h:5434-5447 (the general IIR<ORDER> exists as a device primitive, not as a recorded node yet)
+	template<int ORDER> struct IIR;
+	template<> struct IIR<1> : Modifier, gpu::Packable {
+		float a = 1, b = 0;
+		IIR() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(IIR<1>), klg::graph::N_IIR1, this); }
+		using Modifier::set;
+		void set(param coeff) override { if (gpu::no_set_while_recording("IIR<1>::set()")) return; a = coeff; b = 1.f - a; }
+		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "IIR<1>"); return; } device_only("IIR<1>::process()"); }
+		void pack(uint32_t* w) const override { w[klg::graph::IIR1_A] = gpu::fbits(a); w[klg::graph::IIR1_B] = gpu::fbits(b); w[klg::graph::IIR1_OUT] = gpu::fbits(out.value); }
+		void unpack(const uint32_t* w) override { std::memcpy(&out.value, &w[klg::graph::IIR1_OUT], 4); }
+	};
+namespace OnePole {
+	// OnePole::Filter / LPF / HPF klang.h:5470-5543
+	struct Filter : Modifier, gpu::Packable {
+		klg::host::OnePoleH h;
+		explicit Filter(bool hpf) { h.hpf = hpf; if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Filter), hpf ? klg::graph::N_OPHPF : klg::graph::N_OPLPF, this); }
+		void reset() { if (gpu::no_set_while_recording("OnePole reset()")) return; h.reset(); }
+		using Modifier::set;
+		void set(param f) override { if (gpu::no_set_while_recording("OnePole set(f)")) return; h.set(f, host_fs()); }
+		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "OnePole filter"); return; } device_only("OnePole filter process()"); }
+		void pack(uint32_t* w) const override { using namespace klg::graph; w[OP1_B0] = gpu::fbits(h.b0); w[OP1_B1] = gpu::fbits(h.b1); w[OP1_A1] = gpu::fbits(h.a1); w[OP1_Z] = gpu::fbits(h.z); w[OP1_OUT] = gpu::fbits(out.value); }
+		void unpack(const uint32_t* w) override { std::memcpy(&h.z, &w[klg::graph::OP1_Z], 4); std::memcpy(&out.value, &w[klg::graph::OP1_OUT], 4); }
+	};
+	struct LPF : Filter { LPF() : Filter(false) {} };
+	struct HPF : Filter { HPF() : Filter(true) {} };
+}
+namespace Butterworth {
+	template<int ORDER> struct LPF;
+	template<> struct LPF<1> : Modifier, gpu::Packable {                        // klang.h:5786-5799
+		klg::host::Butter1H h;
+		LPF() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(LPF<1>), klg::graph::N_BUTTER1, this); }
+		using Modifier::set;
+		void set(param f) override { if (gpu::no_set_while_recording("Butterworth::LPF<1>::set()")) return; h.set(f, host_fs()); }
+		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "Butterworth::LPF<1>"); return; } device_only("Butterworth::LPF<1>::process()"); }
+		void pack(uint32_t* w) const override { using namespace klg::graph; w[BW1_B0] = gpu::fbits(h.b0); w[BW1_A1] = gpu::fbits(h.a1); w[BW1_Z] = gpu::fbits(h.z); w[BW1_OUT] = gpu::fbits(out.value); }
+		void unpack(const uint32_t* w) override { std::memcpy(&h.z, &w[klg::graph::BW1_Z], 4); std::memcpy(&out.value, &w[klg::graph::BW1_OUT], 4); }
+	};
+	template<> struct LPF<2> : Biquad::Filter { LPF() : Biquad::Filter(klg::host::BQ_BUTTER2) {} };   // klang.h:5801-5811
+}
+}
+namespace Modifiers {
+	// Modifiers::Modal klang.h:5815-5859
+	struct Modal : Modifier, gpu::Packable {
+		klg::host::ModalH h;
+		Modal() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Modal), klg::graph::N_MODAL, this); }
+		using Modifier::set;
+		void set(param f, param decay) override { if (gpu::no_set_while_recording("Modal::set()")) return; h.set(f, decay, host_fs()); in = 0; out = 0; }
+		void set(param f, param decay, param gain) override { if (gpu::no_set_while_recording("Modal::set()")) return; h.set(f, decay, gain.value, host_fs()); in = 0; out = 0; }
+		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "Modal"); return; } device_only("Modal::process()"); }
+		void pack(uint32_t* w) const override { using namespace klg::graph; w[MODAL_A1] = gpu::fbits(h.a1); w[MODAL_A2] = gpu::fbits(h.a2); w[MODAL_Y1] = gpu::fbits(h.y1); w[MODAL_Y2] = gpu::fbits(h.y2); w[MODAL_GAIN] = gpu::fbits(h.gain); }
+		void unpack(const uint32_t* w) override { std::memcpy(&h.y1, &w[klg::graph::MODAL_Y1], 4); std::memcpy(&h.y2, &w[klg::graph::MODAL_Y2], 4); }
+	};
+}
+enum Mode { Peak, RMS, Mean };
 
 // ---- Envelope / ADSR (klang.h:3722-4137) ----
-struct Envelope : Generator {
+struct Envelope : Generator, gpu::Packable {
+	struct Follower;
 	struct Point { float x, y; Point() : x(0), y(0) {} template<class A, class B> Point(A a, B b) : x(float(a)), y(float(b)) {} };
 	enum Stage { Sustain, Release, Off };
 	klg::host::EnvH h;
-	void reg_member() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Envelope), klg::graph::N_ENV); }
+	void reg_member() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Envelope), klg::graph::N_ENV, this); }
 	Envelope() { reg_member(); const float one[2] = { 0.f, 1.f }; h.set_points(1, one, host_fs()); }
 	Envelope(std::initializer_list<Point> p) { reg_member(); assign(p); }
 	Envelope& operator=(std::initializer_list<Point> p) { assign(p); return *this; }
@@ -395,20 +502,20 @@ struct Envelope : Generator {
 	gpu::Cond finished() const { gpu::Recorder* r = gpu::recording(); return gpu::Cond{ h.stage == klg::ENV_OFF, r ? r->node(this, "Envelope") : -1 }; }
 	signal& operator++(int) { this->process(); return out; }
 	void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_ENV, -1, -1, r->node(this, "Envelope"), 0, true); return; } device_only("Envelope::process()"); }
-	virtual void pack(uint32_t* w) const {
+	void pack(uint32_t* w) const override {
 		using namespace klg::graph;
 		w[ENV_OUT] = gpu::fbits(h.r_out); w[ENV_TARGET] = gpu::fbits(h.r_target); w[ENV_RATE] = gpu::fbits(h.r_rate); w[ENV_TIME] = gpu::fbits(h.time); w[ENV_BITS] = h.bits(); w[ENV_NPOINTS] = (uint32_t)h.npoints;
 		w[ENV_LOOP] = (uint32_t)(h.loop_start & 0xFF) | ((uint32_t)(h.loop_end & 0xFF) << 8);
 		for (int i = 0; i < 4; i++) { w[ENV_PX + i] = gpu::fbits(h.px[i]); w[ENV_PY + i] = gpu::fbits(h.py[i]); }
 	}
-	virtual void unpack(const uint32_t* w) {
+	void unpack(const uint32_t* w) override {
 		std::memcpy(&h.r_out, &w[0], 4); std::memcpy(&h.r_target, &w[1], 4); std::memcpy(&h.r_rate, &w[2], 4); std::memcpy(&h.time, &w[3], 4);
 		const uint32_t bits = w[4]; h.stage = (int)(bits & 3u); h.point = (int)((bits >> 2) & 7u); h.active = ((bits >> 5) & 1u) != 0;
 	}
 };
 struct ADSR : Envelope {
 	klg::host::AdsrH a;
-	ADSR() { if (gpu::Recorder* r = gpu::constructing()) r->note(static_cast<Envelope*>(this), sizeof(ADSR), klg::graph::N_ADSR); set(0.5, 0.5, 1, 0.5); }
+	ADSR() { if (gpu::Recorder* r = gpu::constructing()) r->note(static_cast<Envelope*>(this), sizeof(ADSR), klg::graph::N_ADSR, this); set(0.5, 0.5, 1, 0.5); }
 	using Envelope::set;
 	void set(param attack, param decay, param sustain, param release) override { if (gpu::no_set_while_recording("ADSR::set()")) return; a.set(attack, decay, sustain, release, host_fs()); h = a.env; }
 	void pack(uint32_t* w) const override {
@@ -417,6 +524,22 @@ struct ADSR : Envelope {
 		w[ADSR_A] = gpu::fbits(a.A); w[ADSR_AD] = gpu::fbits(h.px[2]); w[ADSR_S] = gpu::fbits(a.S); w[ADSR_R] = gpu::fbits(a.R);
 	}
 	void release(float time = 0.f, float level = 0.f) override { Envelope::release(time ? time : a.R, level); }
+};
+
+// ---- Envelope::Follower (klang.h:5862-5903): the AR smoother with abs / square-sqrt around it ----
+struct Envelope::Follower : Modifier, gpu::Packable {
+	klg::host::FollowerArH ar; Mode mode = RMS;
+	Follower() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Follower), klg::graph::N_FOLLOWRMS, this); set(0.01f, 0.1f); }
+	using Modifier::set;
+	void set(param attack, param release) override { if (gpu::no_set_while_recording("Envelope::Follower::set()")) return; ar.set(attack, release, host_fs()); }
+	Follower& operator=(Mode m) {                                              // klang.h:5892-5895 (choose before the Synth is created: the mode is part of the recorded program)
+		mode = m;
+		if (gpu::Recorder* r = gpu::rec) r->note(this, sizeof(Follower), m == RMS ? klg::graph::N_FOLLOWRMS : klg::graph::N_FOLLOWPEAK, this);
+		return *this;
+	}
+	void process() override { if (gpu::recording()) { gpu::record_modifier(this, "Envelope::Follower"); return; } device_only("Envelope::Follower::process()"); }
+	void pack(uint32_t* w) const override { w[klg::graph::FOLLOW_A] = gpu::fbits(ar.A); w[klg::graph::FOLLOW_R] = gpu::fbits(ar.R); w[klg::graph::FOLLOW_OUT] = gpu::fbits(out.value); }
+	void unpack(const uint32_t* w) override { std::memcpy(&out.value, &w[klg::graph::FOLLOW_OUT], 4); }
 };
 
 // ---- FM operator (klang.h:4140-4180) ----
@@ -446,31 +569,22 @@ struct NoteBinding { int patch; void (*pack)(const void*, uint32_t*); void (*unp
 // type has the same layout, so the offsets found on the prototype serve all of them).
 namespace gpu {
 struct GraphLayout {
-	struct Member { size_t offset; int kind; int word0; };
+	struct Member { size_t offset; int kind; int word0; };        // offset: of the Packable subobject (primitives) or of the signal (params)
 	std::vector<Member> members;
 	std::string program;
 	int words = 0;
-	template<class F> static void visit(int kind, void* obj, F&& f) {
-		using namespace klg::graph;
-		switch (kind) {
-		case N_FSINE: f(*static_cast<Generators::Fast::Sine*>(obj)); break;
-		case N_SAW: case N_PULSE: f(*static_cast<Generators::Fast::Osm*>(obj)); break;
-		case N_LPF: f(*static_cast<Filters::Biquad::LPF*>(obj)); break;
-		case N_ENV: case N_ADSR: f(*static_cast<Envelope*>(obj)); break;
-		}
-	}
 	void pack(const void* note, uint32_t* w) const {
 		for (const Member& m : members) {
-			void* obj = (char*)const_cast<void*>(note) + m.offset;
-			if (m.kind == klg::graph::N_PARAM) w[m.word0] = fbits(static_cast<signal*>(obj)->value);
-			else visit(m.kind, obj, [&](auto& o) { o.pack(w + m.word0); });
+			const char* obj = (const char*)note + m.offset;
+			if (m.kind == klg::graph::N_PARAM) w[m.word0] = fbits(reinterpret_cast<const signal*>(obj)->value);
+			else reinterpret_cast<const Packable*>(obj)->pack(w + m.word0);
 		}
 	}
 	void unpack(void* note, const uint32_t* w) const {
 		for (const Member& m : members) {
-			void* obj = (char*)note + m.offset;
-			if (m.kind == klg::graph::N_PARAM) std::memcpy(&static_cast<signal*>(obj)->value, &w[m.word0], 4);
-			else visit(m.kind, obj, [&](auto& o) { o.unpack(w + m.word0); });
+			char* obj = (char*)note + m.offset;
+			if (m.kind == klg::graph::N_PARAM) std::memcpy(&reinterpret_cast<signal*>(obj)->value, &w[m.word0], 4);
+			else reinterpret_cast<Packable*>(obj)->unpack(w + m.word0);
 		}
 	}
 };
@@ -602,7 +716,10 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 			ops = out_ops;
 			const std::string verr = R.prog.validate();
 			if (!verr.empty()) { std::fprintf(stderr, "klang-mi355: recorded program of %s is invalid: %s\n", typeid(T).name(), verr.c_str()); std::abort(); }
-			for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) L.members.push_back({ (size_t)((const char*)R.objs[i].addr - lo), R.objs[i].kind, R.prog.node_word0(node_id[i]) });
+			for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) {
+				const void* at = R.objs[i].kind == N_PARAM ? R.objs[i].addr : (const void*)R.objs[i].packable;
+				L.members.push_back({ (size_t)((const char*)at - lo), R.objs[i].kind, R.prog.node_word0(node_id[i]) });
+			}
 			L.program = R.prog.text();
 			L.words = R.prog.words();
 			if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", typeid(T).name(), L.program.c_str());

@@ -39,10 +39,17 @@ enum NodeKind {
 	N_FSINE = 0,    /* Generators::Fast::Sine          klang.h:5135-5172   words: inc, pos, frequency (the set(f) cache) */
 	N_SAW = 1,      /* Fast::OSM, saw family (Saw, Triangle)   5175-5354   words: inc, offset, duty, delta, state, frequency */
 	N_PULSE = 2,    /* Fast::OSM, pulse family (Square, Pulse)             same words */
-	N_LPF = 3,      /* Filters::Biquad::LPF             5550-5666           words: b0 b1 b2 a1 a2 z0 z1 f Q */
+	N_LPF = 3,      /* Filters::Biquad::{LPF,HPF,BPF,BRF,APF}  5550-5773   words: b0 b1 b2 a1 a2 z0 z1 f Q  (process() is type-independent; only LPF may be set() per sample) */
 	N_ENV = 4,      /* Envelope, <= 4 breakpoints       3867-4102           words: r_out r_target r_rate time bits npoints loop px[4] py[4] */
 	N_ADSR = 5,     /* ADSR                             4105-4137           words: r_out r_target r_rate time bits A AD S R */
 	N_PARAM = 6,    /* a signal / param member of the Note that process() reads (and may write)   words: value */
+	N_BSINE = 7, N_BSAW, N_BTRI, N_BSQUARE, N_BPULSE,   /* Generators::Basic::*   2849-2880, 4899-4944   words: increment, position, offset, duty */
+	N_OPLPF = 12, N_OPHPF,   /* Filters::OnePole::LPF / HPF   5470-5543           words: b0 b1 a1 z out */
+	N_DCF = 14,     /* Filters::DCF                     5386-5397           words: r z out */
+	N_IIR1 = 15,    /* Filters::IIR<1>                  5434-5447           words: a b out */
+	N_BUTTER1 = 16, /* Filters::Butterworth::LPF<1>     5786-5799           words: b0 a1 z out */
+	N_MODAL = 17,   /* Modifiers::Modal                 5815-5859           words: a1 a2 y1 y2 gain */
+	N_FOLLOWPEAK = 18, N_FOLLOWRMS,   /* Envelope::Follower (Peak / RMS)  5862-5903   words: A R out */
 	N_KINDS
 };
 enum { FSINE_INC = 0, FSINE_POS, FSINE_FREQ, FSINE_WORDS };
@@ -50,8 +57,17 @@ enum { OSM_INC = 0, OSM_OFFSET, OSM_DUTY, OSM_DELTA, OSM_STATE, OSM_FREQ, OSM_WO
 enum { LPF_B0 = 0, LPF_B1, LPF_B2, LPF_A1, LPF_A2, LPF_Z0, LPF_Z1, LPF_F, LPF_Q, LPF_WORDS };
 enum { ENV_OUT = 0, ENV_TARGET, ENV_RATE, ENV_TIME, ENV_BITS, ENV_NPOINTS, ENV_LOOP /* start | end << 8, 0xFF = none (setLoop) */, ENV_PX, ENV_PY = ENV_PX + 4, ENV_WORDS = ENV_PY + 4 };
 enum { ADSR_OUT = 0, ADSR_TARGET, ADSR_RATE, ADSR_TIME, ADSR_BITS, ADSR_A, ADSR_AD, ADSR_S, ADSR_R, ADSR_WORDS };
+enum { BOSC_INC = 0, BOSC_POS, BOSC_OFFSET, BOSC_DUTY, BOSC_WORDS };
+enum { OP1_B0 = 0, OP1_B1, OP1_A1, OP1_Z, OP1_OUT, OP1_WORDS };
+enum { DCF_R = 0, DCF_Z, DCF_OUT, DCF_WORDS };
+enum { IIR1_A = 0, IIR1_B, IIR1_OUT, IIR1_WORDS };
+enum { BW1_B0 = 0, BW1_A1, BW1_Z, BW1_OUT, BW1_WORDS };
+enum { MODAL_A1 = 0, MODAL_A2, MODAL_Y1, MODAL_Y2, MODAL_GAIN, MODAL_WORDS };
+enum { FOLLOW_A = 0, FOLLOW_R, FOLLOW_OUT, FOLLOW_WORDS };
 enum { MAX_WORDS = 128, MAX_NODES = 64, MAX_OPS = 1024 };
 
+inline bool is_oscillator(int k) { return k == N_FSINE || k == N_SAW || k == N_PULSE || (k >= N_BSINE && k <= N_BPULSE); }
+inline bool is_modifier(int k) { return k == N_LPF || (k >= N_OPLPF && k <= N_FOLLOWRMS); }
 inline int node_words(int kind) {
 	switch (kind) {
 	case N_FSINE: return FSINE_WORDS;
@@ -60,11 +76,19 @@ inline int node_words(int kind) {
 	case N_ENV: return ENV_WORDS;
 	case N_ADSR: return ADSR_WORDS;
 	case N_PARAM: return 1;
+	case N_BSINE: case N_BSAW: case N_BTRI: case N_BSQUARE: case N_BPULSE: return BOSC_WORDS;
+	case N_OPLPF: case N_OPHPF: return OP1_WORDS;
+	case N_DCF: return DCF_WORDS;
+	case N_IIR1: return IIR1_WORDS;
+	case N_BUTTER1: return BW1_WORDS;
+	case N_MODAL: return MODAL_WORDS;
+	case N_FOLLOWPEAK: case N_FOLLOWRMS: return FOLLOW_WORDS;
 	}
 	return 0;
 }
 inline const char* node_name(int kind) {
-	static const char* names[N_KINDS] = { "fsine", "saw", "pulse", "lpf", "env", "adsr", "param" };
+	static const char* names[N_KINDS] = { "fsine", "saw", "pulse", "lpf", "env", "adsr", "param", "bsine", "bsaw", "btri", "bsquare", "bpulse",
+	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms" };
 	return (kind >= 0 && kind < N_KINDS) ? names[kind] : "?";
 }
 
@@ -73,9 +97,9 @@ enum OpCode {
 	OP_CONST = 0,   /* dst = imm                                                                      */
 	OP_CTL,         /* dst = controls[imm]                 (the synth instance's control value)      */
 	OP_PARAM,       /* dst = value word of N_PARAM node                                               */
-	OP_OSC,         /* dst = oscillator node process()     Fast::Sine / OSM saw / OSM pulse           */
-	OP_OSCSET,      /* oscillator node .set(f = a)         Fast::Sine::set 5142-5147 / OSM::set 5217-5224 (per sample: vibrato, FM) */
-	OP_LPF,         /* dst = (a >> lpf node)               Biquad::Filter::process klang.h:5605-5612  */
+	OP_OSC,         /* dst = oscillator node process()     Fast::Sine / OSM saw / OSM pulse / Basic::*   */
+	OP_OSCSET,      /* oscillator node .set(f = a)         Fast::Sine::set 5142-5147 / OSM::set 5217-5224 / Oscillator::set 2862 (per sample: vibrato, FM) */
+	OP_LPF,         /* dst = (a >> modifier node)          any modifier kind: Biquad::Filter::process 5605-5612, OnePole, DCF, IIR<1>, ... */
 	OP_LPFSET,      /* lpf node .set(f = a, Q = b)         Biquad::LPF::set klang.h:5575-5600, 5658   */
 	OP_ENV,         /* dst = env/adsr node ++              Envelope::operator++ klang.h:4013-4051     */
 	OP_ADD, OP_SUB, OP_MUL, OP_DIV,   /* dst = a op b      fp32, IEEE, no contraction                 */
@@ -172,9 +196,9 @@ struct Program {
 			case OP_CONST: break;
 			case OP_CTL: if ((int)o.imm >= nctl) return bad("control index out of range"); break;
 			case OP_PARAM: if (k != N_PARAM) return bad("node is not a param"); break;
-			case OP_OSC: if (k != N_FSINE && k != N_SAW && k != N_PULSE) return bad("node is not an oscillator"); break;
-			case OP_OSCSET: if (k != N_FSINE && k != N_SAW && k != N_PULSE) return bad("node is not an oscillator"); need_a = true; has_dst = false; break;
-			case OP_LPF: if (k != N_LPF) return bad("node is not an lpf"); need_a = true; break;
+			case OP_OSC: if (!is_oscillator(k)) return bad("node is not an oscillator"); break;
+			case OP_OSCSET: if (!is_oscillator(k)) return bad("node is not an oscillator"); need_a = true; has_dst = false; break;
+			case OP_LPF: if (!is_modifier(k)) return bad("node is not a modifier"); need_a = true; break;
 			case OP_LPFSET: if (k != N_LPF) return bad("node is not an lpf"); need_a = need_b = true; has_dst = false; break;
 			case OP_ENV: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); break;
 			case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: need_a = need_b = true; break;

@@ -86,6 +86,49 @@ inline std::string generate_source(const Program& g) {
 			end += W(ADSR_OUT, "f2u(" + n + ".e.r_out)") + W(ADSR_TARGET, "f2u(" + n + ".e.r_target)") + W(ADSR_RATE, "f2u(" + n + ".e.r_rate)") + W(ADSR_TIME, "f2u(" + n + ".e.time)") + W(ADSR_BITS, "env_pack(" + n + ".e)");
 			mark(w0 + ADSR_OUT, 5);
 			break;
+		case N_BSINE: case N_BSAW: case N_BTRI: case N_BSQUARE: case N_BPULSE:
+			live += fmt(" BOsc n%zu; float n%zud;", i, i);
+			begin += "\t\t" + n + ".increment = " + F(BOSC_INC) + "; " + n + ".position = " + F(BOSC_POS) + "; " + n + ".offset = " + F(BOSC_OFFSET) + "; " + n + "d = " + F(BOSC_DUTY) + ";\n";
+			end += W(BOSC_POS, "f2u(" + n + ".position)");
+			mark(w0 + BOSC_POS, 1);
+			if (retuned[i]) { end += W(BOSC_INC, "f2u(" + n + ".increment)"); mark(w0 + BOSC_INC, 1); }
+			break;
+		case N_OPLPF: case N_OPHPF:
+			live += fmt(" OnePole n%zu;", i);
+			begin += "\t\t" + n + ".b0 = " + F(OP1_B0) + "; " + n + ".b1 = " + F(OP1_B1) + "; " + n + ".a1 = " + F(OP1_A1) + "; " + n + ".z = " + F(OP1_Z) + "; " + n + ".out = " + F(OP1_OUT) + ";\n";
+			end += W(OP1_Z, "f2u(" + n + ".z)") + W(OP1_OUT, "f2u(" + n + ".out)");
+			mark(w0 + OP1_Z, 2);
+			break;
+		case N_DCF:
+			live += fmt(" Dcf n%zu;", i);
+			begin += "\t\t" + n + ".r = " + F(DCF_R) + "; " + n + ".z = " + F(DCF_Z) + "; " + n + ".out = " + F(DCF_OUT) + ";\n";
+			end += W(DCF_Z, "f2u(" + n + ".z)") + W(DCF_OUT, "f2u(" + n + ".out)");
+			mark(w0 + DCF_Z, 2);
+			break;
+		case N_IIR1:
+			live += fmt(" Iir1 n%zu;", i);
+			begin += "\t\t" + n + ".a = " + F(IIR1_A) + "; " + n + ".b = " + F(IIR1_B) + "; " + n + ".out = " + F(IIR1_OUT) + ";\n";
+			end += W(IIR1_OUT, "f2u(" + n + ".out)");
+			mark(w0 + IIR1_OUT, 1);
+			break;
+		case N_BUTTER1:
+			live += fmt(" Butter1 n%zu;", i);
+			begin += "\t\t" + n + ".b0 = " + F(BW1_B0) + "; " + n + ".a1 = " + F(BW1_A1) + "; " + n + ".z = " + F(BW1_Z) + "; " + n + ".out = " + F(BW1_OUT) + ";\n";
+			end += W(BW1_Z, "f2u(" + n + ".z)") + W(BW1_OUT, "f2u(" + n + ".out)");
+			mark(w0 + BW1_Z, 2);
+			break;
+		case N_MODAL:
+			live += fmt(" Modal n%zu;", i);
+			begin += "\t\t" + n + ".a1 = " + F(MODAL_A1) + "; " + n + ".a2 = " + F(MODAL_A2) + "; " + n + ".y1 = " + F(MODAL_Y1) + "; " + n + ".y2 = " + F(MODAL_Y2) + "; " + n + ".gain = " + F(MODAL_GAIN) + ";\n";
+			end += W(MODAL_Y1, "f2u(" + n + ".y1)") + W(MODAL_Y2, "f2u(" + n + ".y2)");
+			mark(w0 + MODAL_Y1, 2);
+			break;
+		case N_FOLLOWPEAK: case N_FOLLOWRMS:
+			live += fmt(" FollowerAR n%zu;", i);
+			begin += "\t\t" + n + ".A = " + F(FOLLOW_A) + "; " + n + ".R = " + F(FOLLOW_R) + "; " + n + ".out = " + F(FOLLOW_OUT) + ";\n";
+			end += W(FOLLOW_OUT, "f2u(" + n + ".out)");
+			mark(w0 + FOLLOW_OUT, 1);
+			break;
 		case N_PARAM:
 			live += fmt(" float n%zu;", i);
 			begin += "\t\t" + n + " = " + F(0) + ";\n";
@@ -101,9 +144,29 @@ inline std::string generate_source(const Program& g) {
 		case OP_CONST: body += d + fmt("u2f(0x%08xu);\n", o.imm); break;
 		case OP_CTL: body += d + fmt("c.ctl[%u];\n", o.imm); break;
 		case OP_PARAM: body += d + n + ";\n"; break;
-		case OP_OSC: body += d + (k == N_FSINE ? "fsine_process(" + n + ", 0u)" : k == N_SAW ? (retuned[(size_t)o.node] ? "osm_saw(" : "osm_saw_auto(") + n + ")" : "osm_pulse(" + n + ")") + ";\n"; break;
-		case OP_OSCSET: body += "\t\t" + std::string(k == N_FSINE ? "fsine_set_f(" : "osm_set_f(") + n + ", " + n + "f, " + a + ", c.fs.f);\n"; break;
-		case OP_LPF: body += d + "biquad_process(" + n + ", " + a + ");\n"; break;
+		case OP_OSC: {
+			std::string e;
+			switch (k) {
+			case N_FSINE: e = "fsine_process(" + n + ", 0u)"; break;
+			case N_SAW: e = (retuned[(size_t)o.node] ? "osm_saw(" : "osm_saw_auto(") + n + ")"; break;
+			case N_PULSE: e = "osm_pulse(" + n + ")"; break;
+			case N_BSINE: e = "basic_sine(" + n + ")"; break;
+			case N_BSAW: e = "basic_saw(" + n + ")"; break;
+			case N_BTRI: e = "basic_triangle(" + n + ")"; break;
+			case N_BSQUARE: e = "basic_square(" + n + ")"; break;
+			case N_BPULSE: e = "basic_pulse(" + n + ", " + n + "d)"; break;
+			}
+			body += d + e + ";\n";
+		} break;
+		case OP_OSCSET:
+			if (k >= N_BSINE && k <= N_BPULSE) body += "\t\t" + n + ".increment = " + a + " * 2.f * KLG_PI_F / c.fs.f;\n";   // Oscillator::set(f) klang.h:2862-2865
+			else body += "\t\t" + std::string(k == N_FSINE ? "fsine_set_f(" : "osm_set_f(") + n + ", " + n + "f, " + a + ", c.fs.f);\n";
+			break;
+		case OP_LPF: {
+			const char* fn = k == N_LPF ? "biquad_process" : k == N_OPLPF ? "onepole_lpf_process" : k == N_OPHPF ? "onepole_process" : k == N_DCF ? "dcf_process" : k == N_IIR1 ? "iir1_process"
+				: k == N_BUTTER1 ? "butter1_process" : k == N_MODAL ? "modal_process" : k == N_FOLLOWPEAK ? "follower_peak" : "follower_rms";
+			body += d + fn + "(" + n + ", " + a + ");\n";
+		} break;
 		case OP_LPFSET: body += "\t\tbiquad_lpf_set(" + n + ", " + n + "s, " + a + ", " + b + ", c.fs.w);\n"; break;
 		case OP_ENV: body += d + (k == N_ADSR ? "adsr_process(" + n + ", c.fs)" : "env_process_rt(" + n + ", " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs)") + ";\n"; break;
 		case OP_ADD: body += d + a + " + " + b + ";\n"; break;

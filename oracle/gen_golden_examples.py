@@ -24,8 +24,8 @@ def scenarios():
     rng = np.random.default_rng(20250928)
     out = {}
 
-    def poly(patch, blocks, dump, ctl=(), off_base=6, ctl_events=(), seeded=False):
-        s = Scenario(patch=patch, block=256, blocks=blocks, synths=1, notes=32, dump=dump)
+    def poly(patch, blocks, dump, ctl=(), off_base=6, ctl_events=(), seeded=False, notes=32):
+        s = Scenario(patch=patch, block=256, blocks=blocks, synths=1, notes=notes, dump=dump)
         for i, v in ctl:
             s.ctl.append((i, float(np.float32(v))))
         pitches = rng.choice(np.arange(36, 97), size=20, replace=False)
@@ -44,6 +44,20 @@ def scenarios():
     # Expression.k: per-sample vibrato (osc.set(f) from an LFO whose rate is itself an envelope), three 3/4-point envelopes,
     # swept LPF, random() in on() -> every note-on carries a seed
     out["ex_expression"] = poly("ex_expression", 64, [0, 1, 30, 31, 63], off_base=20, seeded=True)
+    # OUR OWN patches (tests/patches/*.k; 16 notes, so the 20 note-ons also exercise voice stealing)
+    out["own_basic_mix"] = poly("own_basic_mix", 48, [0, 1, 7, 8, 47], off_base=10, notes=16)
+    out["own_filters_f2"] = poly("own_filters_f2", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
+    out["own_modal_follow"] = poly("own_modal_follow", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
+    # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
+    solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)]}
+    for name in list(out):
+        src = out[name]
+        s = Scenario(patch=src.patch, block=256, blocks=24, synths=1, notes=src.notes, dump=[0, 23])
+        for i, v in solo_ctl.get(name, []):
+            s.ctl.append((i, float(np.float32(v))))
+        s.on(0, 0, 57, 0.8, 4242 if name == "ex_expression" else -1)
+        s.off(14, 0, 57, 0.0)
+        out[name + "_solo"] = s
     return out
 
 

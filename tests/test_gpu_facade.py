@@ -79,3 +79,33 @@ def test_example_synths_without_a_handwritten_kernel(name, tmp_path):
     if not os.path.exists(path):
         pytest.skip("built only where the reference's .k files exist (build container); the binary travels in oracle/_ref/")
     check(*run_facade(path, name, tmp_path), name)
+
+
+@pytest.mark.parametrize("name", ["own_basic_mix", "own_filters_f2", "own_modal_follow"])
+def test_own_patches_for_the_other_node_kinds(name, tmp_path):
+    """tests/patches/{basic_mix,filters_f2,modal_follow}.k (ours): Basic oscillators incl. per-sample set(f), OnePole LPF/HPF, DCF,
+    Butterworth<1>/<2>, IIR<1>, Biquad HPF/BPF/BRF/APF, Modal, Envelope::Follower, a member written back by process().
+    Fixtures: the same files driven through the genuine header (oracle/gen_golden_examples.py)."""
+    path = os.path.join(ROOT, "tests", "cpp", "_bin", "facade_graph_" + name)
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    check(*run_facade(path, name, tmp_path), name)
+
+
+SOLO = ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter", "ex_expression", "own_basic_mix", "own_filters_f2", "own_modal_follow"]
+
+
+@pytest.mark.parametrize("name", SOLO)
+def test_recorded_graph_single_voice_is_bit_exact(name, tmp_path):
+    """One note held and released: the stereo mix is that voice's output, so it must equal the genuine header's BIT FOR BIT."""
+    d = os.path.join(ROOT, "oracle", "_ref") if name.startswith("ex_") else os.path.join(ROOT, "tests", "cpp", "_bin")
+    path = os.path.join(d, "facade_graph_" + name)
+    if not os.path.exists(path):
+        if name.startswith("ex_"):
+            pytest.skip("built only where the reference's .k files exist (build container); the binary travels in oracle/_ref/")
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    mix, stages = run_facade(path, name + "_solo", tmp_path)
+    ref = np.load(os.path.join(GOLDEN, name + "_solo.npz"))
+    assert np.array_equal(stages, ref["stages"])
+    assert np.array_equal(mix.view(np.uint32), ref["mix"].view(np.uint32)), f"max abs err {np.abs(mix - ref['mix']).max()}"
+    assert np.abs(mix).max() > 0
