@@ -66,16 +66,20 @@ class ShardedSynthBank:
         if self.owns(synth):
             self.bank.set_control(synth - self.lo, index, value)
 
-    def process_device(self, mix, n, stream=None):
-        """mix: torch tensor [2][n] on this rank's device, ACCUMULATED into; afterwards every rank holds the global sum."""
+    def process_device(self, mix, n, stream=None, async_reduce=False):
+        """mix: torch tensor [2][n] on this rank's device, ACCUMULATED into; afterwards every rank holds the global sum.
+        async_reduce=True (throughput mode): the all-reduce is only enqueued and its work handle returned — call .wait()
+        on it before touching `mix` again; the next block's render then overlaps the (latency-bound, 2 KiB) collective."""
         self.bank.process_device(mix.data_ptr(), n, stream)
         if self.world > 1:
             if self._all_reduce is not None:
                 self._all_reduce(mix)
             else:
                 import torch.distributed as dist
+                if async_reduce:
+                    return dist.all_reduce(mix, async_op=True)
                 dist.all_reduce(mix)
-        return mix
+        return None
 
     def close(self):
         self.bank.close()
