@@ -21,7 +21,8 @@
 //     every primitive's process(), every `>>`, `++`, arithmetic operator and filter.set() appends an op to a program
 //     instead of computing — and the program is compiled for gfx950 by klg_synth_create_graph().  Supported in a
 //     recorded process(): Fast::{Sine,Saw,Triangle,Square,Pulse} with their frequency set in on() or per sample
-//     (`osc(f * (1 + lfo * depth))`: vibrato / FM by set(f)), Biquad::LPF (static, or set(f, Q) per sample), Envelope
+//     (`osc(f * (1 + lfo * depth))`: vibrato / FM by set(f)), the Basic oscillators, Operator<Sine> chains (`op1 * I >> op2 >> out`),
+//     every Biquad type, OnePole, DCF, IIR<1>, Butterworth, Modal, Envelope::Follower (Biquad::LPF also set(f, Q) per sample), Envelope
 //     (<= 4 points, setLoop) and ADSR `++`, + - * / and unary minus on signals / params / controls / constants, `.out` of a
 //     member, signal and param members of the Note (read, and written for next-sample state), `>> out`, `out *= x`, and
 //     `if (env.finished()) stop();`.  Anything else (a signal forced to a plain float, other data-dependent branches,
@@ -199,6 +200,13 @@ struct Control {
 	Control& set(float x) { value = (x < min) ? min : (max < x) ? max : x; return *this; }                    // klang.h:1725
 };
 inline param::param(Control& c) : signal(c.value) {}
+// signal (op) Control and Control (op) signal: the control's value (recorded as a control read inside a recorded process()).
+// Templates, so that only a signal / param / ... operand takes part (plain numbers keep the Control's float conversion).
+#define KLANG_CONTROL_OPS(OP) \
+	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator OP(const S& a, Control& c) { return static_cast<const signal&>(a) OP c.value; } \
+	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator OP(Control& c, const S& a) { return c.value OP static_cast<const signal&>(a); }
+KLANG_CONTROL_OPS(+) KLANG_CONTROL_OPS(-) KLANG_CONTROL_OPS(*) KLANG_CONTROL_OPS(/)
+#undef KLANG_CONTROL_OPS
 inline Control Dial(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f) { Control c; c.name = name; c.min = mn; c.max = mx; c.initial = initial; c.value = initial; return c; }
 struct Controls {
 	std::vector<Control> items; float cache[128] = { 0 };
@@ -545,12 +553,60 @@ struct Envelope::Follower : Modifier, gpu::Packable {
 // ---- FM operator (klang.h:4140-4180) ----
 template<class OSC> struct Operator : OSC, Input {
 	Envelope env; Amplitude amp = 1.f;
+	Operator() { if (gpu::Recorder* r = gpu::constructing()) r->note(static_cast<OSC*>(this), sizeof(Operator), klg::graph::N_OPERATOR, static_cast<gpu::Packable*>(static_cast<OSC*>(this))); }
 	Operator& operator()(param f) { OSC::set(f); return *this; }
+	Operator& operator()(param f, relative phase) { OSC::set(f, phase); return *this; }
 	Operator& operator=(std::initializer_list<Envelope::Point> p) { env = p; return *this; }
-	Operator& operator*(signal a) { amp = a; return *this; }
+	Operator& operator*(signal a) { amp = a; return *this; }                     // (while recording, `a` may be a recorded value: the operator's amp operand)
 	Operator& operator>>(Operator& carrier) { carrier << *this; return carrier; }
-	void process() override { device_only("Operator::process()"); }
+	void process() override {
+		if (gpu::Recorder* r = gpu::recording()) {
+			const int ri = in.reg, ra = amp.reg;                                  // a concrete modulator / amp stays what on() left in the record
+			const int rin = (ri >= 0 || in.value != 0.f) ? r->reg_of(in) : -1;
+			this->out.reg = r->emit(klg::graph::OP_OPERATOR, rin, ra, r->node(static_cast<OSC*>(this), "Operator"), 0, true);
+			return;
+		}
+		device_only("Operator::process()");
+	}
+	void pack(uint32_t* w) const override {
+		using namespace klg::graph;
+		w[OPER_INC] = (uint32_t)this->h.inc; w[OPER_POS] = this->h.pos; w[OPER_FREQ] = gpu::fbits(this->h.frequency); w[OPER_AMP] = gpu::fbits(amp.value);
+		env.pack(w + OPER_ENV);
+	}
+	void unpack(const uint32_t* w) override {
+		using namespace klg::graph;
+		this->h.pos = w[OPER_POS]; std::memcpy(&amp.value, &w[OPER_AMP], 4);
+		env.unpack(w + OPER_ENV);
+	}
 };
+template<class OSC> inline const signal& operator>>(signal modulator, Operator<OSC>& carrier) { carrier << modulator; return carrier; }   // klang.h:4176-4180
+
+// ---- Table / graph: host-side conveniences a patch's on() may touch (klang.h:3303-3378, 2943-3024); no device role ----
+template<typename TYPE> struct Result {
+	TYPE* y; int i = 0; TYPE sum = 0;
+	Result(TYPE* array, int index) : y(&array[index]), i(index) {}
+	TYPE& operator[](int index) { return *(y + index); }
+	operator TYPE const() { return *y; }
+	Result& operator=(const TYPE& in) { *y = in; return *this; }
+	TYPE& operator++(int) { i++; return *++y; }
+};
+#define FUNCTION(type) (void(*)(type, klang::Result<type>&))[](type x, klang::Result<type>& y)
+template<typename TYPE, int SIZE> struct Table {
+	TYPE items[SIZE] = {}; unsigned count = 0;
+	void add(const TYPE& v) { if (count < (unsigned)SIZE) items[count++] = v; }
+	Table(TYPE (*function)(TYPE)) { for (int x = 0; x < SIZE; x++) add(function((TYPE)x)); }
+	Table(void (*function)(TYPE x, Result<TYPE>& y)) { count = SIZE; Result<TYPE> y(items, 0); for (int x = 0; x < SIZE; x++) { function((TYPE)x, y); y.sum += items[x]; y++; } }
+	Table(std::initializer_list<TYPE> values) { for (TYPE v : values) add(v); }
+	TYPE operator[](int index) const { return items[index]; }
+	TYPE operator[](float index) const {
+		if (index < 0) return items[0];
+		if (index >= (SIZE - 1)) return items[SIZE - 1];
+		const float x = std::floor(index); const int i = int(x);
+		return items[i] + (index - x) * (items[i + 1] - items[i]);
+	}
+};
+struct GraphStub { void clear() {} template<class... A> void add(A...) {} template<class... A> void plot(A...) {} };   // the UI line plotter: nothing to draw on here
+inline thread_local GraphStub graph;
 
 // =================================================================================================
 // GPU binding of a Note type: found by ADL on the note pointer / reference (see klang/bindings.h)

@@ -50,6 +50,7 @@ enum NodeKind {
 	N_BUTTER1 = 16, /* Filters::Butterworth::LPF<1>     5786-5799           words: b0 a1 z out */
 	N_MODAL = 17,   /* Modifiers::Modal                 5815-5859           words: a1 a2 y1 y2 gain */
 	N_FOLLOWPEAK = 18, N_FOLLOWRMS,   /* Envelope::Follower (Peak / RMS)  5862-5903   words: A R out */
+	N_OPERATOR = 20,   /* Operator<Fast::Sine>          4140-4180           words: inc pos frequency amp + the N_ENV words of its envelope */
 	N_KINDS
 };
 enum { FSINE_INC = 0, FSINE_POS, FSINE_FREQ, FSINE_WORDS };
@@ -64,6 +65,7 @@ enum { IIR1_A = 0, IIR1_B, IIR1_OUT, IIR1_WORDS };
 enum { BW1_B0 = 0, BW1_A1, BW1_Z, BW1_OUT, BW1_WORDS };
 enum { MODAL_A1 = 0, MODAL_A2, MODAL_Y1, MODAL_Y2, MODAL_GAIN, MODAL_WORDS };
 enum { FOLLOW_A = 0, FOLLOW_R, FOLLOW_OUT, FOLLOW_WORDS };
+enum { OPER_INC = 0, OPER_POS, OPER_FREQ, OPER_AMP, OPER_ENV, OPER_WORDS = OPER_ENV + ENV_WORDS };
 enum { MAX_WORDS = 128, MAX_NODES = 64, MAX_OPS = 1024 };
 
 inline bool is_oscillator(int k) { return k == N_FSINE || k == N_SAW || k == N_PULSE || (k >= N_BSINE && k <= N_BPULSE); }
@@ -83,12 +85,13 @@ inline int node_words(int kind) {
 	case N_BUTTER1: return BW1_WORDS;
 	case N_MODAL: return MODAL_WORDS;
 	case N_FOLLOWPEAK: case N_FOLLOWRMS: return FOLLOW_WORDS;
+	case N_OPERATOR: return OPER_WORDS;
 	}
 	return 0;
 }
 inline const char* node_name(int kind) {
 	static const char* names[N_KINDS] = { "fsine", "saw", "pulse", "lpf", "env", "adsr", "param", "bsine", "bsaw", "btri", "bsquare", "bpulse",
-	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms" };
+	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator" };
 	return (kind >= 0 && kind < N_KINDS) ? names[kind] : "?";
 }
 
@@ -107,10 +110,11 @@ enum OpCode {
 	OP_STOPIF,      /* if (env/adsr node .finished()) stop();   klang.h:4094, 4276-4279               */
 	OP_STOP,        /* stop();                                                                        */
 	OP_SETPARAM,    /* N_PARAM node = a                    (a member written by process(): next sample reads it) */
+	OP_OPERATOR,    /* dst = operator node process()       modulator a (or -1: none), amp b (or -1: keep)   Operator::process klang.h:4164-4168 */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "operator" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -206,6 +210,7 @@ struct Program {
 			case OP_STOPIF: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); has_dst = false; break;
 			case OP_STOP: has_dst = false; break;
 			case OP_SETPARAM: if (k != N_PARAM) return bad("node is not a param"); need_a = true; has_dst = false; break;
+			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			default: return bad("unknown code");
 			}
 			if (need_a && !def(o.a)) return bad("operand a is not defined");

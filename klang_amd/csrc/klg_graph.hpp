@@ -129,6 +129,19 @@ inline std::string generate_source(const Program& g) {
 			end += W(FOLLOW_OUT, "f2u(" + n + ".out)");
 			mark(w0 + FOLLOW_OUT, 1);
 			break;
+		case N_OPERATOR: {
+			live += fmt(" FSine n%zu; float n%zua; Env n%zue; Pts4 n%zup; int n%zunp, n%zuls, n%zule;", i, i, i, i, i, i, i);
+			const int e0 = OPER_ENV;
+			begin += "\t\t" + n + ".inc = (int32_t)" + R(OPER_INC) + "; " + n + ".pos = " + R(OPER_POS) + "; " + n + "a = " + F(OPER_AMP) + ";\n";
+			begin += "\t\t" + n + "e.r_out = " + F(e0 + ENV_OUT) + "; " + n + "e.r_target = " + F(e0 + ENV_TARGET) + "; " + n + "e.r_rate = " + F(e0 + ENV_RATE) + "; " + n + "e.time = " + F(e0 + ENV_TIME) + "; env_unpack(" + n + "e, " + R(e0 + ENV_BITS) + "); "
+				+ n + "np = (int)" + R(e0 + ENV_NPOINTS) + "; " + n + "ls = (int)(" + R(e0 + ENV_LOOP) + " & 0xFFu); " + n + "le = (int)((" + R(e0 + ENV_LOOP) + " >> 8) & 0xFFu); "
+				+ n + "ls = " + n + "ls == 255 ? -1 : " + n + "ls; " + n + "le = " + n + "le == 255 ? -1 : " + n + "le;\n";
+			begin += "\t\t" + n + "p.x0 = " + F(e0 + ENV_PX) + "; " + n + "p.x1 = " + F(e0 + ENV_PX + 1) + "; " + n + "p.x2 = " + F(e0 + ENV_PX + 2) + "; " + n + "p.x3 = " + F(e0 + ENV_PX + 3) + "; "
+				+ n + "p.y0 = " + F(e0 + ENV_PY) + "; " + n + "p.y1 = " + F(e0 + ENV_PY + 1) + "; " + n + "p.y2 = " + F(e0 + ENV_PY + 2) + "; " + n + "p.y3 = " + F(e0 + ENV_PY + 3) + ";\n";
+			end += W(OPER_POS, n + ".pos") + W(OPER_AMP, "f2u(" + n + "a)")
+				+ W(e0 + ENV_OUT, "f2u(" + n + "e.r_out)") + W(e0 + ENV_TARGET, "f2u(" + n + "e.r_target)") + W(e0 + ENV_RATE, "f2u(" + n + "e.r_rate)") + W(e0 + ENV_TIME, "f2u(" + n + "e.time)") + W(e0 + ENV_BITS, "env_pack(" + n + "e)");
+			mark(w0 + OPER_POS, 1); mark(w0 + OPER_AMP, 1); mark(w0 + e0 + ENV_OUT, 5);
+		} break;
 		case N_PARAM:
 			live += fmt(" float n%zu;", i);
 			begin += "\t\t" + n + " = " + F(0) + ";\n";
@@ -177,6 +190,10 @@ inline std::string generate_source(const Program& g) {
 		case OP_STOPIF: body += "\t\tL.stage = (" + n + (k == N_ADSR ? ".e" : "") + ".stage == ENV_OFF) ? (int)ST_OFF : L.stage;\n"; break;
 		case OP_STOP: body += "\t\tL.stage = (int)ST_OFF;\n"; break;
 		case OP_SETPARAM: body += "\t\t" + n + " = " + a + ";\n"; break;
+		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
+			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";
+			body += d + "fsine_process(" + n + ", fsine_rel_offset(" + (o.a >= 0 ? a : std::string("0.f")) + ")) * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs) * " + n + "a);\n";
+			break;
 		}
 	}
 	std::string s;

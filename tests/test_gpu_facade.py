@@ -63,7 +63,8 @@ def test_own_dsl_patch_recorded_as_graph(binary, scenario, tmp_path):
     check(*run_facade(path, scenario, tmp_path), scenario)
 
 
-@pytest.mark.parametrize("binary,scenario", [("facade_graph_sub2b", "sub2b_poly"), ("facade_graph_supersaw", "supersaw_poly"), ("facade_graph_supersaw", "supersaw_ctl")])
+@pytest.mark.parametrize("binary,scenario", [("facade_graph_sub2b", "sub2b_poly"), ("facade_graph_supersaw", "supersaw_poly"), ("facade_graph_supersaw", "supersaw_ctl"),
+                                             ("facade_graph_fm", "fm3_poly"), ("facade_graph_fm", "fm3_ctl")])
 def test_shipped_k_files_recorded_as_graph(binary, scenario, tmp_path):
     path = os.path.join(ROOT, "oracle", "_ref", binary)
     if not os.path.exists(path):
