@@ -328,14 +328,14 @@ namespace Basic {
 		using Oscillator::set;
 		void reset() { if (gpu::no_set_while_recording("Basic oscillator reset()")) return; h.position = 0; }
 		void set(param f) override {
-			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Basic oscillator"), 0, false); return; }
-			h.frequency = f; h.increment = f * 2.f * pi.f / fs.f;
+			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Basic oscillator"), 0, false); frequency = f; return; }
+			h.frequency = f; h.increment = f * 2.f * pi.f / fs.f; frequency = f;
 		}
-		void set(param f, param phase) override { if (gpu::no_set_while_recording("Basic oscillator set(f, phase)")) return; h.set(f, phase, host_fs()); }
+		void set(param f, param phase) override { if (gpu::no_set_while_recording("Basic oscillator set(f, phase)")) return; h.set(f, phase, host_fs()); frequency = f; }
 		void set(param f, relative phase) override { set(f); set(phase); }
 		void set(relative phase) override { if (gpu::no_set_while_recording("Basic oscillator set(relative)")) return; h.offset = phase.value * (2 * pi); }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Basic oscillator"), 0, true); return; } device_only("Basic oscillator process()"); }
-		void pack(uint32_t* w) const override { using namespace klg::graph; w[BOSC_INC] = gpu::fbits(h.increment); w[BOSC_POS] = gpu::fbits(h.position); w[BOSC_OFFSET] = gpu::fbits(h.offset); w[BOSC_DUTY] = gpu::fbits(duty_); }
+		void pack(uint32_t* w) const override { using namespace klg::graph; w[BOSC_INC] = gpu::fbits(h.increment); w[BOSC_POS] = gpu::fbits(h.position); w[BOSC_OFFSET] = gpu::fbits(h.offset); w[BOSC_DUTY] = gpu::fbits(duty_); w[BOSC_FREQ] = gpu::fbits(h.frequency); }
 		void unpack(const uint32_t* w) override { using namespace klg::graph; std::memcpy(&h.increment, &w[BOSC_INC], 4); std::memcpy(&h.position, &w[BOSC_POS], 4); }
 	};
 	struct Sine : Osc { Sine() : Osc(klg::graph::N_BSINE) {} };
@@ -355,10 +355,11 @@ namespace Fast {
 		using Oscillator::set;
 		void reset() { if (gpu::no_set_while_recording("Fast::Sine::reset()")) return; h.pos = 0; }                        // klang.h:5136-5140
 		void set(param f) override {
-			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Fast::Sine"), 0, false); return; }   // per-sample set(f): vibrato / FM
+			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Fast::Sine"), 0, false); frequency = f; return; }   // per-sample set(f): vibrato / FM
 			if (f != h.frequency) { h.frequency = f; h.inc = klg::host::fast_increment(f, host_fs()); }
+			frequency = f;
 		}
-		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast::Sine::set(f, phase)")) return; h.set(f, phase, host_fs()); }
+		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast::Sine::set(f, phase)")) return; h.set(f, phase, host_fs()); frequency = f; }
 		void set(param f, relative phase) override { set(f); set(phase); }
 		void set(relative) override { device_only("Fast::Sine::set(relative) [phase modulation]"); }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast::Sine"), 0, true); return; } device_only("Fast::Sine::process()"); }
@@ -370,11 +371,12 @@ namespace Fast {
 		Osm(int wf, float duty) : h(duty), waveform(wf) { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Osm), wf ? klg::graph::N_PULSE : klg::graph::N_SAW, this); }
 		using Oscillator::set;
 		void set(param f) override {
-			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Fast oscillator"), 0, false); return; }
+			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Fast oscillator"), 0, false); frequency = f; return; }
 			if (h.frequency != f) { h.refresh(f, host_fs()); h.init(); }
+			frequency = f;
 		}
-		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase)")) return; h.set(f, phase, host_fs()); }
-		void set(param f, param phase, param duty) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase, duty)")) return; h.set(f, phase, duty, host_fs()); }
+		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase)")) return; h.set(f, phase, host_fs()); frequency = f; }
+		void set(param f, param phase, param duty) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase, duty)")) return; h.set(f, phase, duty, host_fs()); frequency = f; }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast oscillator"), 0, true); return; } device_only("Fast::Osm::process()"); }
 		void pack(uint32_t* w) const override { using namespace klg::graph; w[OSM_INC] = (uint32_t)h.inc; w[OSM_OFFSET] = h.offset; w[OSM_DUTY] = h.duty; w[OSM_DELTA] = gpu::fbits(h.delta); w[OSM_STATE] = (uint32_t)h.state; w[OSM_FREQ] = gpu::fbits(h.frequency); }
 		void unpack(const uint32_t* w) override { using namespace klg::graph; h.inc = (int32_t)w[OSM_INC]; h.offset = w[OSM_OFFSET]; h.state = (int)(w[OSM_STATE] & 3u); std::memcpy(&h.delta, &w[OSM_DELTA], 4); std::memcpy(&h.frequency, &w[OSM_FREQ], 4); }
@@ -732,6 +734,12 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 			std::vector<int> first_reg(R.objs.size(), -1);
 			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; first_reg[i] = sg->reg = R.emit(OP_PARAM, -1, -1, (int)i, 0, true); }
 			for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = R.emit(OP_CTL, -1, -1, -1, (uint32_t)c, true);
+			// `osc.frequency` read inside process(): the node's current frequency (what on() or a recorded set(f) left there)
+			std::vector<Oscillator*> oscs;
+			for (size_t i = 0; i < R.objs.size(); i++) if (is_oscillator(R.objs[i].kind) || R.objs[i].kind == N_OPERATOR) {
+				Oscillator* o = const_cast<Oscillator*>(dynamic_cast<const Oscillator*>(R.objs[i].packable));
+				if (o) { o->frequency.reg = R.emit(OP_FREQ, -1, -1, (int)i, 0, true); oscs.push_back(o); }
+			}
 			NOTEBASE* nb = t;
 			nb->process();
 			if (R.pending >= 0) R.fail("`if (env.finished())` may only guard stop() in a recorded process()");
@@ -742,13 +750,14 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 				sg->reg = -1;
 			}
 			for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = -1;
+			for (Oscillator* o : oscs) o->frequency.reg = -1;
 			R.recording = false;
 			gpu::rec = nullptr;
 			if (!R.error.empty()) { std::fprintf(stderr, "klang-mi355: cannot record %s::process() as a graph patch: %s\n", typeid(T).name(), R.error.c_str()); std::abort(); }
 			// ---- dead code: pure ops nobody reads, params nobody reads (and their write-backs), primitives nobody uses ----
 			std::vector<Op>& ops = R.prog.ops;
 			std::vector<char> keep(ops.size(), 1), used;
-			auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG; };
+			auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG; };
 			for (bool changed = true; changed;) {
 				changed = false;
 				used.assign(MAX_OPS + 1, 0); used[(size_t)R.prog.ret] = 1;

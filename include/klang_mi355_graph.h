@@ -43,7 +43,7 @@ enum NodeKind {
 	N_ENV = 4,      /* Envelope, <= 4 breakpoints       3867-4102           words: r_out r_target r_rate time bits npoints loop px[4] py[4] */
 	N_ADSR = 5,     /* ADSR                             4105-4137           words: r_out r_target r_rate time bits A AD S R */
 	N_PARAM = 6,    /* a signal / param member of the Note that process() reads (and may write)   words: value */
-	N_BSINE = 7, N_BSAW, N_BTRI, N_BSQUARE, N_BPULSE,   /* Generators::Basic::*   2849-2880, 4899-4944   words: increment, position, offset, duty */
+	N_BSINE = 7, N_BSAW, N_BTRI, N_BSQUARE, N_BPULSE,   /* Generators::Basic::*   2849-2880, 4899-4944   words: increment, position, offset, duty, frequency */
 	N_OPLPF = 12, N_OPHPF,   /* Filters::OnePole::LPF / HPF   5470-5543           words: b0 b1 a1 z out */
 	N_DCF = 14,     /* Filters::DCF                     5386-5397           words: r z out */
 	N_IIR1 = 15,    /* Filters::IIR<1>                  5434-5447           words: a b out */
@@ -58,7 +58,7 @@ enum { OSM_INC = 0, OSM_OFFSET, OSM_DUTY, OSM_DELTA, OSM_STATE, OSM_FREQ, OSM_WO
 enum { LPF_B0 = 0, LPF_B1, LPF_B2, LPF_A1, LPF_A2, LPF_Z0, LPF_Z1, LPF_F, LPF_Q, LPF_WORDS };
 enum { ENV_OUT = 0, ENV_TARGET, ENV_RATE, ENV_TIME, ENV_BITS, ENV_NPOINTS, ENV_LOOP /* start | end << 8, 0xFF = none (setLoop) */, ENV_PX, ENV_PY = ENV_PX + 4, ENV_WORDS = ENV_PY + 4 };
 enum { ADSR_OUT = 0, ADSR_TARGET, ADSR_RATE, ADSR_TIME, ADSR_BITS, ADSR_A, ADSR_AD, ADSR_S, ADSR_R, ADSR_WORDS };
-enum { BOSC_INC = 0, BOSC_POS, BOSC_OFFSET, BOSC_DUTY, BOSC_WORDS };
+enum { BOSC_INC = 0, BOSC_POS, BOSC_OFFSET, BOSC_DUTY, BOSC_FREQ, BOSC_WORDS };
 enum { OP1_B0 = 0, OP1_B1, OP1_A1, OP1_Z, OP1_OUT, OP1_WORDS };
 enum { DCF_R = 0, DCF_Z, DCF_OUT, DCF_WORDS };
 enum { IIR1_A = 0, IIR1_B, IIR1_OUT, IIR1_WORDS };
@@ -110,11 +110,12 @@ enum OpCode {
 	OP_STOPIF,      /* if (env/adsr node .finished()) stop();   klang.h:4094, 4276-4279               */
 	OP_STOP,        /* stop();                                                                        */
 	OP_SETPARAM,    /* N_PARAM node = a                    (a member written by process(): next sample reads it) */
+	OP_FREQ,        /* dst = oscillator node .frequency    (Oscillator::frequency klang.h:2856, as last set by on() or by oscset) */
 	OP_OPERATOR,    /* dst = operator node process()       modulator a (or -1: none), amp b (or -1: keep)   Operator::process klang.h:4164-4168 */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "operator" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "operator" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -210,6 +211,7 @@ struct Program {
 			case OP_STOPIF: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); has_dst = false; break;
 			case OP_STOP: has_dst = false; break;
 			case OP_SETPARAM: if (k != N_PARAM) return bad("node is not a param"); need_a = true; has_dst = false; break;
+			case OP_FREQ: if (!is_oscillator(k) && k != N_OPERATOR) return bad("node is not an oscillator"); break;
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			default: return bad("unknown code");
 			}

@@ -87,11 +87,11 @@ inline std::string generate_source(const Program& g) {
 			mark(w0 + ADSR_OUT, 5);
 			break;
 		case N_BSINE: case N_BSAW: case N_BTRI: case N_BSQUARE: case N_BPULSE:
-			live += fmt(" BOsc n%zu; float n%zud;", i, i);
-			begin += "\t\t" + n + ".increment = " + F(BOSC_INC) + "; " + n + ".position = " + F(BOSC_POS) + "; " + n + ".offset = " + F(BOSC_OFFSET) + "; " + n + "d = " + F(BOSC_DUTY) + ";\n";
+			live += fmt(" BOsc n%zu; float n%zud, n%zuf;", i, i, i);
+			begin += "\t\t" + n + ".increment = " + F(BOSC_INC) + "; " + n + ".position = " + F(BOSC_POS) + "; " + n + ".offset = " + F(BOSC_OFFSET) + "; " + n + "d = " + F(BOSC_DUTY) + "; " + n + "f = " + F(BOSC_FREQ) + ";\n";
 			end += W(BOSC_POS, "f2u(" + n + ".position)");
 			mark(w0 + BOSC_POS, 1);
-			if (retuned[i]) { end += W(BOSC_INC, "f2u(" + n + ".increment)"); mark(w0 + BOSC_INC, 1); }
+			if (retuned[i]) { end += W(BOSC_INC, "f2u(" + n + ".increment)") + W(BOSC_FREQ, "f2u(" + n + "f)"); mark(w0 + BOSC_INC, 1); mark(w0 + BOSC_FREQ, 1); }
 			break;
 		case N_OPLPF: case N_OPHPF:
 			live += fmt(" OnePole n%zu;", i);
@@ -130,9 +130,9 @@ inline std::string generate_source(const Program& g) {
 			mark(w0 + FOLLOW_OUT, 1);
 			break;
 		case N_OPERATOR: {
-			live += fmt(" FSine n%zu; float n%zua; Env n%zue; Pts4 n%zup; int n%zunp, n%zuls, n%zule;", i, i, i, i, i, i, i);
+			live += fmt(" FSine n%zu; float n%zua, n%zuf; Env n%zue; Pts4 n%zup; int n%zunp, n%zuls, n%zule;", i, i, i, i, i, i, i, i);
 			const int e0 = OPER_ENV;
-			begin += "\t\t" + n + ".inc = (int32_t)" + R(OPER_INC) + "; " + n + ".pos = " + R(OPER_POS) + "; " + n + "a = " + F(OPER_AMP) + ";\n";
+			begin += "\t\t" + n + ".inc = (int32_t)" + R(OPER_INC) + "; " + n + ".pos = " + R(OPER_POS) + "; " + n + "a = " + F(OPER_AMP) + "; " + n + "f = " + F(OPER_FREQ) + ";\n";
 			begin += "\t\t" + n + "e.r_out = " + F(e0 + ENV_OUT) + "; " + n + "e.r_target = " + F(e0 + ENV_TARGET) + "; " + n + "e.r_rate = " + F(e0 + ENV_RATE) + "; " + n + "e.time = " + F(e0 + ENV_TIME) + "; env_unpack(" + n + "e, " + R(e0 + ENV_BITS) + "); "
 				+ n + "np = (int)" + R(e0 + ENV_NPOINTS) + "; " + n + "ls = (int)(" + R(e0 + ENV_LOOP) + " & 0xFFu); " + n + "le = (int)((" + R(e0 + ENV_LOOP) + " >> 8) & 0xFFu); "
 				+ n + "ls = " + n + "ls == 255 ? -1 : " + n + "ls; " + n + "le = " + n + "le == 255 ? -1 : " + n + "le;\n";
@@ -172,7 +172,7 @@ inline std::string generate_source(const Program& g) {
 			body += d + e + ";\n";
 		} break;
 		case OP_OSCSET:
-			if (k >= N_BSINE && k <= N_BPULSE) body += "\t\t" + n + ".increment = " + a + " * 2.f * KLG_PI_F / c.fs.f;\n";   // Oscillator::set(f) klang.h:2862-2865
+			if (k >= N_BSINE && k <= N_BPULSE) body += "\t\t" + n + "f = " + a + "; " + n + ".increment = " + a + " * 2.f * KLG_PI_F / c.fs.f;\n";   // Oscillator::set(f) klang.h:2862-2865
 			else body += "\t\t" + std::string(k == N_FSINE ? "fsine_set_f(" : "osm_set_f(") + n + ", " + n + "f, " + a + ", c.fs.f);\n";
 			break;
 		case OP_LPF: {
@@ -190,6 +190,7 @@ inline std::string generate_source(const Program& g) {
 		case OP_STOPIF: body += "\t\tL.stage = (" + n + (k == N_ADSR ? ".e" : "") + ".stage == ENV_OFF) ? (int)ST_OFF : L.stage;\n"; break;
 		case OP_STOP: body += "\t\tL.stage = (int)ST_OFF;\n"; break;
 		case OP_SETPARAM: body += "\t\t" + n + " = " + a + ";\n"; break;
+		case OP_FREQ: body += d + n + "f;\n"; break;
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";
 			body += d + "fsine_process(" + n + ", fsine_rel_offset(" + (o.a >= 0 ? a : std::string("0.f")) + ")) * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs) * " + n + "a);\n";
