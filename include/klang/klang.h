@@ -208,9 +208,14 @@ inline param::param(Control& c) : signal(c.value) {}
 KLANG_CONTROL_OPS(+) KLANG_CONTROL_OPS(-) KLANG_CONTROL_OPS(*) KLANG_CONTROL_OPS(/)
 #undef KLANG_CONTROL_OPS
 inline Control Dial(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f) { Control c; c.name = name; c.min = mn; c.max = mx; c.initial = initial; c.value = initial; return c; }
+struct Group {                                          // klang.h:1853-1873: `{ Dial(..) }` or `{ "name", Dial(..), Dial(..) }`
+	const char* name; std::vector<Control> controls;
+	template<typename... C> Group(const char* n, C... c) : name(n), controls{ c... } {}
+	template<typename... C> Group(C... c) : name(""), controls{ c... } {}
+};
 struct Controls {
 	std::vector<Control> items; float cache[128] = { 0 };
-	void operator=(std::initializer_list<Control> l) { items.assign(l.begin(), l.end()); }
+	void operator=(std::initializer_list<Group> l) { items.clear(); for (const Group& g : l) for (const Control& c : g.controls) items.push_back(c); }   // klang.h:1895-1902
 	Control& operator[](int i) { return items[(size_t)i]; }
 	unsigned size() const { return (unsigned)items.size(); }
 	bool changed() { bool c = false; for (size_t i = 0; i < items.size(); i++) if (items[i].value.value != cache[i]) { cache[i] = items[i].value.value; c = true; } return c; }   // klang.h:1914
@@ -265,16 +270,14 @@ template<class S> inline S operator-(Output<S>& o, float x) { return S(o) - x; }
 template<class S> inline S operator/(Output<S>& o, float x) { return S(o) / x; }
 template<class S> inline S operator+(float x, Output<S>& o) { return S(o) + x; }
 template<class S> inline S operator*(float x, Output<S>& o) { return S(o) * x; }
-// object (op) signal, also for temporaries (`osc * (a++ + b++)`): read the object, then combine
-inline signal operator+(Output<signal>& o, const signal& x) { const signal& a = o; return a + x; }
-inline signal operator-(Output<signal>& o, const signal& x) { const signal& a = o; return a - x; }
-inline signal operator*(Output<signal>& o, const signal& x) { const signal& a = o; return a * x; }
-inline signal operator/(Output<signal>& o, const signal& x) { const signal& a = o; return a / x; }
-// signal (op) object: the object is read (its process() runs) and combined — better than either user conversion alone
-inline signal operator+(const signal& a, Output<signal>& o) { const signal& b = o; return a + b; }
-inline signal operator-(const signal& a, Output<signal>& o) { const signal& b = o; return a - b; }
-inline signal operator*(const signal& a, Output<signal>& o) { const signal& b = o; return a * b; }
-inline signal operator/(const signal& a, Output<signal>& o) { const signal& b = o; return a / b; }
+// object (op) signal, also for temporaries (`osc * (a++ + b++)`): read the object, then combine; and signal (op) object.
+// Templates on the signal side: only a signal / param / ... written as such takes part (an Operator or an ADSR on that side keeps
+// the meaning its own class gives the operator, e.g. `op * adsr` sets the operator's amp).
+#define KLANG_OBJECT_OPS(OP) \
+	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator OP(Output<signal>& o, const S& x) { const signal& a = o; return a OP static_cast<const signal&>(x); } \
+	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator OP(const S& a, Output<signal>& o) { const signal& b = o; return static_cast<const signal&>(a) OP b; }
+KLANG_OBJECT_OPS(+) KLANG_OBJECT_OPS(-) KLANG_OBJECT_OPS(*) KLANG_OBJECT_OPS(/)
+#undef KLANG_OBJECT_OPS
 template<class SIGNAL> struct Generator : Output<SIGNAL> {
 	template<typename... P> Output<SIGNAL>& operator()(P... p) { this->set(p...); return *this; }
 	using Output<SIGNAL>::operator>>;
@@ -560,6 +563,7 @@ template<class OSC> struct Operator : OSC, Input {
 	Operator& operator()(param f, relative phase) { OSC::set(f, phase); return *this; }
 	Operator& operator=(std::initializer_list<Envelope::Point> p) { env = p; return *this; }
 	Operator& operator*(signal a) { amp = a; return *this; }                     // (while recording, `a` may be a recorded value: the operator's amp operand)
+	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> Operator& operator*(const S& a) { amp = static_cast<const signal&>(a); return *this; }   // exact for param / Frequency / ...
 	Operator& operator>>(Operator& carrier) { carrier << *this; return carrier; }
 	void process() override {
 		if (gpu::Recorder* r = gpu::recording()) {
@@ -885,8 +889,8 @@ namespace Stereo {
 	};
 }
 
-namespace optimised { using namespace klang; using namespace Generators::Fast; using namespace Filters::Biquad; }
-namespace basic { using namespace klang; using namespace Generators::Basic; using namespace Filters::Biquad; }
+namespace optimised { using namespace klang; using namespace Generators::Fast; using namespace Modifiers; using namespace Filters; using namespace Filters::Biquad; }   // klang.h:6145-6152
+namespace basic { using namespace klang; using namespace Generators::Basic; using namespace Modifiers; using namespace Filters; using namespace Filters::Biquad; }       // klang.h:6136-6143
 namespace minimal { using namespace klang; }
 
 }  // namespace klang

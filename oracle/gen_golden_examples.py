@@ -51,13 +51,16 @@ def scenarios():
     out["ex_am"] = poly("ex_am", 32, [0, 1, 9, 31], off_base=8, ctl=[(0, 0.5), (1, 0.5)], ctl_events=[(4, 0, 1.7), (6, 1, 0.9)])
     out["ex_fmmod"] = poly("ex_fmmod", 32, [0, 1, 9, 31], off_base=8, ctl=[(0, 0.5), (1, 0.5)], ctl_events=[(4, 0, 2.1), (6, 1, 6.0)])
     out["ex_fm2"] = poly("ex_fm2", 32, [0, 1, 9, 31], off_base=8, ctl=[(0, 0.5), (1, 0.5), (2, 0.5)], ctl_events=[(4, 1, 3.0), (6, 2, 7.5)])
+    # Operators.k: grouped controls, three 3-point operator envelopes, `(.. >> op3) * adsr` (the ADSR becomes op3's amp), HPF
+    out["ex_operators"] = poly("ex_operators", 32, [0, 1, 9, 31], off_base=8, ctl=[(0, 1.0), (1, 0.5), (2, 1.0), (3, 4.296), (4, 2.0)], ctl_events=[(5, 1, 2.5), (7, 3, 1.0)])
     # OUR OWN patches (tests/patches/*.k; 16 notes, so the 20 note-ons also exercise voice stealing)
     out["own_basic_mix"] = poly("own_basic_mix", 48, [0, 1, 7, 8, 47], off_base=10, notes=16)
     out["own_filters_f2"] = poly("own_filters_f2", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
     out["own_modal_follow"] = poly("own_modal_follow", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
-                "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)]}
+                "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],
+                "ex_operators": [(0, 1.0), (1, 0.5), (2, 1.0), (3, 4.296), (4, 2.0)]}
     for name in list(out):
         src = out[name]
         s = Scenario(patch=src.patch, block=256, blocks=24, synths=1, notes=src.notes, dump=[0, 23])
