@@ -69,6 +69,7 @@ void klg_random_seed(unsigned seed);
  * v / notes_per_synth, slot v % notes_per_synth, one GPU lane per voice.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct klg_synth klg_synth;
+typedef struct klg_fx klg_fx;
 
 /* replaces: constructing the user's Synth subclass + notes.add<T>(n) (klang.h:4324-4331); klang::fs (1604) */
 klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_synth, float sample_rate, int max_block);
@@ -131,6 +132,12 @@ int klg_voices_upload(klg_synth* s, int n, const int* voices, const void* states
  * ------------------------------------------------------------------------------------------------ */
 klg_synth* klg_synth_create_graph(const char* program, int synths, int notes_per_synth, float sample_rate, int max_block);
 int klg_graph_check(const char* program, int want_source, char* out, size_t out_cap);
+/* The same for a recorded Effect::process() body (`kind effect 1|2` programs; replaces constructing `instances` copies of a
+ * user klang::Effect / Stereo::Effect, klang.h:4190-4216, 4703-4717).  `initial_record`: the record words of one freshly
+ * constructed instance (Program::words() x 4 bytes; NULL = zeros), every instance starts from it; Delay<SIZE> members become
+ * zero-filled rings in HBM.  The handle is used with klg_fx_set_control / klg_fx_process[_device] / klg_fx_destroy; io is
+ * [instances][channels][n]. */
+klg_fx* klg_fx_create_graph(const char* program, int instances, float sample_rate, int max_block, const void* initial_record);
 
 /* Measurement hooks used by bench.py: timing of the render kernel with HIP events recorded on the
  * stream the kernel is launched on.  klg_timing_begin() arms it, klg_timing_end() returns the number of
@@ -141,7 +148,6 @@ int klg_timing_end(klg_synth* s, int* launches, float* total_ms);
 /* ------------------------------------------------------------------------------------------------
  * Effect banks: `instances` independent Stereo::Effect objects (klang.h:4703-4717) of one patch.
  * ------------------------------------------------------------------------------------------------ */
-typedef struct klg_fx klg_fx;
 klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate, int max_block);
 void klg_fx_destroy(klg_fx* f);
 int klg_fx_set_control(klg_fx* f, int instance, int index, float value);

@@ -12,11 +12,13 @@
  *
  * Program text (one statement per line, '#' starts a comment):
  *     klgg 1
- *     ctl <count>                         number of controls of the synth (<= 8)
+ *     kind effect <channels>              optional: the body of an Effect::process() (1 = klang::Effect, 2 = Stereo::Effect) instead
+ *                                         of a Note's; one lane per effect instance, input samples via `in`, output via ret / ret2
+ *     ctl <count>                         number of controls of the synth / effect (<= 8)
  *     dial <i> <min> <max> <initial>      Dial(...) of control i              klang.h:1797-1800
- *     node <id> <kind>                    a primitive object of the Note, ids 0,1,2,... in order
+ *     node <id> <kind> [size]             a primitive object of the Note / Effect, ids 0,1,2,... in order (size: Delay<SIZE>)
  *     op <code> <dst> <a> <b> <node> <imm>   one op; unused fields are -1; imm = IEEE-754 bits (hex) of a constant
- *     ret <reg>                           the register holding `out` at the end of process()
+ *     ret <reg>                           the register holding `out` at the end of process()   (ret2 <l> <r> for a Stereo::Effect)
  *     end
  * Registers are single-assignment fp32 values.  Record layout: word 0 = flags (bits 0-1 NoteBase::stage), then the
  * words of node 0, node 1, ... in order (node_words()).
@@ -51,6 +53,9 @@ enum NodeKind {
 	N_MODAL = 17,   /* Modifiers::Modal                 5815-5859           words: a1 a2 y1 y2 gain */
 	N_FOLLOWPEAK = 18, N_FOLLOWRMS,   /* Envelope::Follower (Peak / RMS)  5862-5903   words: A R out */
 	N_OPERATOR = 20,   /* Operator<Fast::Sine>          4140-4180           words: inc pos frequency amp + the N_ENV words of its envelope */
+	N_DELAY = 21,   /* Delay<SIZE> (effects only)       3381-3512           words: none — a ring of SIZE floats per instance in HBM, position-major
+	                                                                        over the 64 instances of a wave; the write cursor is the sample counter */
+	N_SMOOTH = 22,  /* controls[i].smooth() in an effect   1715             words: smoothed */
 	N_KINDS
 };
 enum { FSINE_INC = 0, FSINE_POS, FSINE_FREQ, FSINE_WORDS };
@@ -86,12 +91,14 @@ inline int node_words(int kind) {
 	case N_MODAL: return MODAL_WORDS;
 	case N_FOLLOWPEAK: case N_FOLLOWRMS: return FOLLOW_WORDS;
 	case N_OPERATOR: return OPER_WORDS;
+	case N_DELAY: return 0;
+	case N_SMOOTH: return 1;
 	}
 	return 0;
 }
 inline const char* node_name(int kind) {
 	static const char* names[N_KINDS] = { "fsine", "saw", "pulse", "lpf", "env", "adsr", "param", "bsine", "bsaw", "btri", "bsquare", "bpulse",
-	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator" };
+	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator", "delay", "smooth" };
 	return (kind >= 0 && kind < N_KINDS) ? names[kind] : "?";
 }
 
@@ -111,11 +118,15 @@ enum OpCode {
 	OP_STOP,        /* stop();                                                                        */
 	OP_SETPARAM,    /* N_PARAM node = a                    (a member written by process(): next sample reads it) */
 	OP_FREQ,        /* dst = oscillator node .frequency    (Oscillator::frequency klang.h:2856, as last set by on() or by oscset) */
+	OP_IN,          /* dst = this sample of input channel imm            (effects: `in`, `in.l`, `in.r`)                       */
+	OP_DELAYIN,     /* a >> delay node                                  Delay::input klang.h:3396-3403                        */
+	OP_DELAYTAP,    /* dst = delay node (a)                             Delay::tap(float) klang.h:3412-3427                   */
+	OP_SMOOTH,      /* dst = smooth node: controls[imm].smooth()        Control::smooth klang.h:1715                          */
 	OP_OPERATOR,    /* dst = operator node process()       modulator a (or -1: none), amp b (or -1: keep)   Operator::process klang.h:4164-4168 */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "operator" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -126,8 +137,11 @@ struct Program {
 	int nctl = 0;
 	Dial dials[8] = {};
 	std::vector<int> nodes;      /* kind of node i */
+	std::vector<int> node_arg;   /* Delay<SIZE>: SIZE; else 0 */
 	std::vector<Op> ops;
-	int ret = -1;
+	int ret = -1, ret_r = -1;    /* ret_r: right channel of a Stereo::Effect */
+	int channels = 0;            /* 0 = synth note; 1 / 2 = effect with that many channels */
+	int arg(int node) const { return node < (int)node_arg.size() ? node_arg[(size_t)node] : 0; }
 
 	int words() const { int w = 1; for (int k : nodes) w += node_words(k); return w; }
 	int node_word0(int node) const { int w = 1; for (int i = 0; i < node; i++) w += node_words(nodes[(size_t)i]); return w; }
@@ -135,11 +149,16 @@ struct Program {
 	std::string text() const {
 		std::string s = "klgg 1\n";
 		char line[160];
+		if (channels) { snprintf(line, sizeof line, "kind effect %d\n", channels); s += line; }
 		snprintf(line, sizeof line, "ctl %d\n", nctl); s += line;
 		for (int i = 0; i < nctl; i++) { snprintf(line, sizeof line, "dial %d %.9g %.9g %.9g\n", i, dials[i].min, dials[i].max, dials[i].initial); s += line; }
-		for (size_t i = 0; i < nodes.size(); i++) { snprintf(line, sizeof line, "node %zu %s\n", i, node_name(nodes[i])); s += line; }
+		for (size_t i = 0; i < nodes.size(); i++) {
+			if (arg((int)i)) snprintf(line, sizeof line, "node %zu %s %d\n", i, node_name(nodes[i]), arg((int)i)); else snprintf(line, sizeof line, "node %zu %s\n", i, node_name(nodes[i]));
+			s += line;
+		}
 		for (const Op& o : ops) { snprintf(line, sizeof line, "op %s %d %d %d %d %08x\n", op_name(o.code), o.dst, o.a, o.b, o.node, o.imm); s += line; }
-		snprintf(line, sizeof line, "ret %d\nend\n", ret); s += line;
+		if (channels == 2) snprintf(line, sizeof line, "ret2 %d %d\nend\n", ret, ret_r); else snprintf(line, sizeof line, "ret %d\nend\n", ret);
+		s += line;
 		return s;
 	}
 
@@ -159,15 +178,17 @@ struct Program {
 			auto bad = [&](const char* why) { char m[200]; snprintf(m, sizeof m, "graph program line %d: %s: '%s'", lineno, why, ln.c_str()); return std::string(m); };
 			if (!strcmp(kw, "klgg")) { int v = 0; if (sscanf(rest, "%d", &v) != 1 || v != 1) return bad("unsupported version"); header = true; }
 			else if (!header) return bad("missing 'klgg 1' header");
+			else if (!strcmp(kw, "kind")) { char w[32]; if (sscanf(rest, "%31s %d", w, &channels) != 2 || strcmp(w, "effect") || channels < 1 || channels > 2) return bad("expected: kind effect 1|2"); }
 			else if (!strcmp(kw, "ctl")) { if (sscanf(rest, "%d", &nctl) != 1 || nctl < 0 || nctl > 8) return bad("ctl count must be 0..8"); }
 			else if (!strcmp(kw, "dial")) { int i; float a, b, c; if (sscanf(rest, "%d %g %g %g", &i, &a, &b, &c) != 4 || i < 0 || i >= nctl) return bad("bad dial"); dials[i] = { a, b, c }; }
 			else if (!strcmp(kw, "node")) {
-				int id; char kind[32];
-				if (sscanf(rest, "%d %31s", &id, kind) != 2 || id != (int)nodes.size()) return bad("nodes must be numbered 0,1,2,... in order");
+				int id, size = 0; char kind[32];
+				if (sscanf(rest, "%d %31s %d", &id, kind, &size) < 2 || id != (int)nodes.size()) return bad("nodes must be numbered 0,1,2,... in order");
 				int k = -1; for (int q = 0; q < N_KINDS; q++) if (!strcmp(kind, node_name(q))) k = q;
 				if (k < 0) return bad("unknown node kind");
 				if ((int)nodes.size() >= MAX_NODES) return bad("too many nodes");
-				nodes.push_back(k);
+				if (k == N_DELAY && (size < 2 || size > (1 << 24))) return bad("delay needs its SIZE (2 .. 2^24)");
+				nodes.push_back(k); node_arg.push_back(k == N_DELAY ? size : 0);
 			}
 			else if (!strcmp(kw, "op")) {
 				char code[32]; Op o; unsigned imm;
@@ -178,6 +199,7 @@ struct Program {
 				ops.push_back(o);
 			}
 			else if (!strcmp(kw, "ret")) { if (sscanf(rest, "%d", &ret) != 1) return bad("bad ret"); }
+			else if (!strcmp(kw, "ret2")) { if (sscanf(rest, "%d %d", &ret, &ret_r) != 2) return bad("bad ret2"); }
 			else if (!strcmp(kw, "end")) ended = true;
 			else return bad("unknown statement");
 		}
@@ -212,6 +234,10 @@ struct Program {
 			case OP_STOP: has_dst = false; break;
 			case OP_SETPARAM: if (k != N_PARAM) return bad("node is not a param"); need_a = true; has_dst = false; break;
 			case OP_FREQ: if (!is_oscillator(k) && k != N_OPERATOR) return bad("node is not an oscillator"); break;
+			case OP_IN: if (channels == 0 || (int)o.imm >= channels) return bad("`in` needs an effect program with that channel"); break;
+			case OP_DELAYIN: if (k != N_DELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
+			case OP_DELAYTAP: if (k != N_DELAY) return bad("node is not a delay"); need_a = true; break;
+			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); break;
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			default: return bad("unknown code");
 			}
@@ -225,6 +251,8 @@ struct Program {
 			}
 		}
 		if (!def(ret)) return "graph program: 'ret' names an undefined register";
+		if (channels == 2 && !def(ret_r)) return "graph program: 'ret2' names an undefined register";
+		if (channels == 0) for (int k : nodes) if (k == N_DELAY || k == N_SMOOTH) return "graph program: delay / smooth nodes need an effect program (kind effect)";
 		return "";
 	}
 };

@@ -137,11 +137,17 @@ class SynthBank:
 class FxBank:
     """`instances` independent Stereo::Effect objects of one patch (PingPong.k / Reverb.k)."""
 
-    def __init__(self, patch, instances, fs=48000.0, max_block=256):
+    def __init__(self, patch, instances, fs=48000.0, max_block=256, initial_record=None, channels=2):
         self._L = lib()
         self._h = None
-        pid = PATCH_IDS[patch] if isinstance(patch, str) else int(patch)
-        h = self._L.klg_fx_create(pid, int(instances), float(fs), int(max_block))
+        self.channels = 2
+        if isinstance(patch, str) and patch.lstrip().startswith("klgg"):       # a recorded Effect::process() body (`kind effect`)
+            rec = None if initial_record is None else np.ascontiguousarray(initial_record, dtype=np.uint32)
+            h = self._L.klg_fx_create_graph(patch.encode(), int(instances), float(fs), int(max_block), rec.ctypes.data_as(C.c_void_p) if rec is not None else None)
+            self.channels = int(channels)
+        else:
+            pid = PATCH_IDS[patch] if isinstance(patch, str) else int(patch)
+            h = self._L.klg_fx_create(pid, int(instances), float(fs), int(max_block))
         if not h:
             raise KlangError("klg_fx_create failed: " + self._L.klg_last_error().decode())
         self._h = h
@@ -163,8 +169,8 @@ class FxBank:
         return check(self._L.klg_fx_set_control(self._h, int(instance), int(index), float(value)), "klg_fx_set_control")
 
     def process(self, io):
-        """io: float32 [instances][2][n], processed in place."""
-        assert io.dtype == np.float32 and io.flags.c_contiguous and io.shape[:2] == (self.instances, 2)
+        """io: float32 [instances][channels][n], processed in place."""
+        assert io.dtype == np.float32 and io.flags.c_contiguous and io.shape[:2] == (self.instances, self.channels)
         check(self._L.klg_fx_process(self._h, _fp(io), io.shape[2]), "klg_fx_process")
         return io
 

@@ -20,6 +20,7 @@
 // oracle/... (test infrastructure) — citations are into the reference files.
 #pragma once
 #include "klg_device.hpp"
+#include "klg_kernels.hpp"
 
 #pragma clang fp contract(off)
 
@@ -647,6 +648,8 @@ struct Rv16Lds {
 	float CF[15][64];                           // per-instance constants only two waves per channel need: early LPF / HPF coefficients, dry/c1/c2/c3/wet
 };
 
+template<bool B> struct BoolTag { static constexpr bool value = B; };   // (std::true_type without <type_traits>: this header is also compiled by hipRTC)
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every ring-row
 // prefetch and ring store in flight twice per sample; the rings need no cross-wave ordering inside a block (a row written at
 // sample e is next read `time` >= 45 ms later, and only after the writer's in-order vmcnt has retired the store).
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 		wg_sync_lds();
 		if (o_on && ((o & (FX_CHUNK - 1)) == FX_CHUNK - 1 || o == n - 1)) { store_chunk(o >> 5); }
 	};
-	const std::true_type ramp; const std::false_type steady;
+	const BoolTag<true> ramp; const BoolTag<false> steady;
 	int t = -2;
 	for (; t <= 0 && t <= n; t++) { if (t & 1) step(ramp, t, B, A); else step(ramp, t, A, B); }      // even t: set A holds this iteration's rows
 	for (; t + 1 <= n - 4; t += 2) { step(steady, t, B, A); step(steady, t + 1, A, B); }                 // t is odd here
@@ -842,6 +845,67 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 		}
 	}
 #undef RVW
+}
+
+// =================================================================================================
+// Graph effects (include/klang_mi355_graph.h, `kind effect`): the recorded body of a user Effect::process()
+// =================================================================================================
+// One lane per effect instance, one wave per 64 instances (the shape of klg_fx_pingpong): record words in registers for
+// the block, the caller's [K][CH][n] block staged through the padded LDS tile, Delay<SIZE> members as position-major rings
+// in this group's ring tile.  P is generated by klg_graph.hpp: Rec / kStoreMask(2) / Live / begin / sample / end, kChannels.
+struct FxGraphArgs {
+	uint32_t* state; size_t kpad; int K;
+	float* rings; size_t ring_rows;          // rows (of 64 floats) per group of 64 instances: the sum of the Delay SIZEs
+	float* io; int n;
+	const float* controls;                   // [kpad][KLG_MAX_CTL]
+	SampleRate fs;
+	unsigned long long samples;              // samples processed before this block (every delay's write cursor derives from it)
+};
+struct FxCtx { SampleRate fs; const float* ctl; unsigned long long samples; float* ring; };   // ring: this lane's column of the group's tile
+
+template<class P>
+__global__ __launch_bounds__(FX_WG) void klg_fx_graph(const FxGraphArgs a) {
+	using Rec = typename P::Rec;
+	constexpr int W = sizeof(Rec) / 4, CH = P::kChannels;
+	__shared__ float tile[2 * FX_CHUNK * FX_LD];
+	const int lane = threadIdx.x, k0 = blockIdx.x * FX_WG, k = k0 + lane;
+	RecWords<Rec> rw;
+#pragma unroll
+	for (int w = 0; w < W; w++) rw.w[w] = a.state[(size_t)w * a.kpad + k];
+	Rec rec; rw.to(rec);
+	typename P::Live L;
+	FxCtx c;
+	c.fs = a.fs; c.ctl = a.controls + (size_t)k * KLG_MAX_CTL; c.samples = a.samples;
+	c.ring = a.rings + (size_t)blockIdx.x * a.ring_rows * FX_WG + lane;
+	P::begin(L, rec, c);
+	const int col = lane & 31, half = lane >> 5;
+	for (int s0 = 0; s0 < a.n; s0 += FX_CHUNK) {
+		const int cl = (a.n - s0 < FX_CHUNK) ? (a.n - s0) : FX_CHUNK;
+		for (int it = 0; it < 32 * CH; it++) {                       // 64 * CH rows of the [K][CH][n] block, two rows per access
+			const int row = 2 * it + half, inst = row / CH, ch = row % CH;
+			tile[(ch * FX_CHUNK + col) * FX_LD + inst] = (col < cl && k0 + inst < a.K) ? a.io[((size_t)(k0 + inst) * CH + ch) * a.n + s0 + col] : 0.f;
+		}
+		wave_sync();
+		for (int s = 0; s < cl; s++) {
+			const float in0 = tile[(0 * FX_CHUNK + s) * FX_LD + lane], in1 = CH > 1 ? tile[(1 * FX_CHUNK + s) * FX_LD + lane] : 0.f;
+			float out0 = 0.f, out1 = 0.f;
+			P::sample(L, c, in0, in1, out0, out1);
+			tile[(0 * FX_CHUNK + s) * FX_LD + lane] = out0;
+			if (CH > 1) tile[(1 * FX_CHUNK + s) * FX_LD + lane] = out1;
+		}
+		wave_sync();
+		for (int it = 0; it < 32 * CH; it++) {
+			const int row = 2 * it + half, inst = row / CH, ch = row % CH;
+			if (col < cl && k0 + inst < a.K) a.io[((size_t)(k0 + inst) * CH + ch) * a.n + s0 + col] = tile[(ch * FX_CHUNK + col) * FX_LD + inst];
+		}
+		wave_sync();
+	}
+	if (k < a.K) {
+		P::end(L, rec);
+		rw.from(rec);
+#pragma unroll
+		for (int w = 0; w < W; w++) if (patch_stores<P>(w)) a.state[(size_t)w * a.kpad + k] = rw.w[w];
+	}
 }
 
 // scatter host-side updates into the SoA state: upd = { k, word, value_bits } triples

@@ -26,15 +26,22 @@ struct klg_fx {
 	std::vector<RvHost> rv;
 	BiquadCoef pp_dc;
 	bool timing = false; std::vector<hipEvent_t> tev; int launches = 0;
+	// graph effects (klg_graph.hpp, `kind effect`): hipRTC code object, per-instance controls in HBM
+	const graphrt::Compiled* graph = nullptr;
+	hipModule_t module = nullptr; hipFunction_t graph_fn = nullptr;
+	int channels = 2;
+	float* d_controls = nullptr; std::vector<float> h_controls; bool controls_dirty = false;
 };
+enum { KLG_PATCH_FXGRAPH = 1001 };
 
 static inline int f2i(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 
 static void fx_free(klg_fx* f) {
 	if (!f) return;
 	if (f->stream) (void)hipStreamSynchronize(f->stream);
-	void* dev[] = { f->d_state, f->d_rings, f->d_rings2, f->d_io, f->d_upd };
+	void* dev[] = { f->d_state, f->d_rings, f->d_rings2, f->d_io, f->d_upd, f->d_controls };
 	for (void* p : dev) if (p) (void)hipFree(p);
+	if (f->module) (void)hipModuleUnload(f->module);
 	for (auto e : f->tev) (void)hipEventDestroy(e);
 	if (f->stream) (void)hipStreamDestroy(f->stream);
 	delete f;
@@ -95,9 +102,50 @@ extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate,
 	return f;
 }
 
+// replaces: constructing `instances` copies of a user Effect whose process() body was recorded (include/klang_mi355_graph.h,
+// `kind effect 1|2`).  `initial_record` (the program's record: Program::words() 32-bit words; NULL = zeros) is the state of one freshly
+// constructed instance; every instance starts from it.  Delay<SIZE> members become zero-filled rings in HBM.
+extern "C" klg_fx* klg_fx_create_graph(const char* program, int instances, float sample_rate, int max_block, const void* initial_record) {
+	RandGuard rg;
+	if (instances <= 0 || max_block <= 0 || max_block > MAX_BLOCK || !(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_fx_create_graph: bad arguments"); return nullptr; }
+	const graphrt::Compiled* c = nullptr;
+	const std::string err = graphrt::compile(program, &c);
+	if (!err.empty()) { fail(KLG_ERR_INVALID, "klg_fx_create_graph: %s", err.c_str()); return nullptr; }
+	if (!c->channels) { fail(KLG_ERR_INVALID, "klg_fx_create_graph: the program is a synth note body (no `kind effect` line): use klg_synth_create_graph"); return nullptr; }
+	graph::Program g; (void)g.parse(program);
+	if (klg_ensure_device()) return nullptr;
+	klg_fx* f = new klg_fx();
+	f->patch = KLG_PATCH_FXGRAPH; f->K = instances; f->max_block = max_block; f->graph = c; f->channels = c->channels;
+	f->kpad = ((size_t)instances + FX_WG - 1) / FX_WG * FX_WG;
+	f->fs = host::Fs(sample_rate);
+	f->nctl = g.nctl; f->words = c->words;
+	const size_t ring = (size_t)std::max<long long>(c->ring_rows, 1) * f->kpad;
+	bool ok = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) == hipSuccess;
+	ok = ok && hipMalloc(&f->d_state, (size_t)f->words * f->kpad * 4) == hipSuccess;
+	ok = ok && hipMalloc(&f->d_rings, ring * 4) == hipSuccess;
+	ok = ok && hipMalloc(&f->d_io, (size_t)f->kpad * f->channels * max_block * 4) == hipSuccess;
+	ok = ok && hipMalloc(&f->d_controls, f->kpad * KLG_MAX_CTL * 4) == hipSuccess;
+	ok = ok && hipMemset(f->d_rings, 0, ring * 4) == hipSuccess;                       // Delay() : buffer(SIZE + 1, 0)
+	ok = ok && hipModuleLoadData(&f->module, c->code.data()) == hipSuccess;
+	ok = ok && hipModuleGetFunction(&f->graph_fn, f->module, c->name[0].c_str()) == hipSuccess;
+	if (!ok) { fail(KLG_ERR_NOMEM, "klg_fx_create_graph: device allocation / module load failed (%zu ring bytes): %s", ring * 4, hipGetErrorString(hipGetLastError())); fx_free(f); return nullptr; }
+	std::vector<uint32_t> init((size_t)f->words * f->kpad, 0u);
+	if (initial_record) { const uint32_t* r = (const uint32_t*)initial_record; for (int w = 0; w < f->words; w++) std::fill(init.begin() + (size_t)w * f->kpad, init.begin() + (size_t)(w + 1) * f->kpad, r[w]); }
+	if (hipMemcpy(f->d_state, init.data(), init.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { fail(KLG_ERR_HIP, "klg_fx_create_graph: state upload failed"); fx_free(f); return nullptr; }
+	f->controls.resize((size_t)instances * std::max(1, f->nctl));
+	f->h_controls.assign(f->kpad * KLG_MAX_CTL, 0.f);
+	for (int k = 0; k < instances; k++) for (int i = 0; i < f->nctl; i++) {
+		f->controls[(size_t)k * f->nctl + i] = { g.dials[i].min, g.dials[i].max, g.dials[i].initial };
+		f->h_controls[(size_t)k * KLG_MAX_CTL + i] = g.dials[i].initial;
+	}
+	f->controls_dirty = true;
+	return f;
+}
+
 extern "C" void klg_fx_destroy(klg_fx* f) { if (f && g_device >= 0) (void)hipSetDevice(g_device); fx_free(f); }
 extern "C" size_t klg_fx_state_bytes(const klg_fx* f) {
 	if (!f) return 0;
+	if (f->graph) return (size_t)f->words * 4 + (size_t)f->graph->ring_rows * 4;
 	return (size_t)f->words * 4 + (f->patch == KLG_PATCH_PINGPONG ? (size_t)2 * 192000 * 4 : ((size_t)2 * RV_ESIZE + (size_t)16 * RV_FSIZE) * 4);
 }
 
@@ -105,6 +153,7 @@ extern "C" int klg_fx_set_control(klg_fx* f, int instance, int index, float valu
 	if (!f || instance < 0 || instance >= f->K || index < 0 || index >= f->nctl) return fail(KLG_ERR_INVALID, "klg_fx_set_control: instance %d / control %d out of range", instance, index);
 	host::ControlH& c = f->controls[(size_t)instance * f->nctl + index];
 	c.set(value);                                                                   // Control::set clamps (klang.h:1725-1728)
+	if (f->graph) { f->h_controls[(size_t)instance * KLG_MAX_CTL + index] = c.value; f->controls_dirty = true; return 0; }
 	if (f->patch == KLG_PATCH_PINGPONG) f->upd.push_back({ instance, index, f2i(c.value) });
 	else if (index < 5) f->upd.push_back({ instance, RV_CTL + index, f2i(c.value) });
 	return 0;
@@ -204,7 +253,31 @@ static int fx_flush_updates(klg_fx* f, hipStream_t st) {
 	return 0;
 }
 
+static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
+	if (f->controls_dirty) {
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipMemcpyAsync(f->d_controls, f->h_controls.data(), f->h_controls.size() * 4, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		f->controls_dirty = false;
+	}
+	if (f->timing) {
+		if ((int)f->tev.size() < 2 * (f->launches + 1)) { hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); f->tev.push_back(e0); f->tev.push_back(e1); }
+		HIP_TRY(hipEventRecord(f->tev[2 * f->launches], st));
+	}
+	FxGraphArgs a;
+	a.state = (uint32_t*)f->d_state; a.kpad = f->kpad; a.K = f->K; a.rings = f->d_rings; a.ring_rows = (size_t)f->graph->ring_rows;
+	a.io = d_io; a.n = n; a.controls = f->d_controls;
+	a.fs.f = f->fs.f; a.fs.w = f->fs.w; a.fs.timeInc = 1.0f / f->fs.f;
+	a.samples = f->samples;
+	void* params[] = { &a };
+	HIP_TRY(hipModuleLaunchKernel(f->graph_fn, (unsigned)(f->kpad / FX_WG), 1, 1, FX_WG, 1, 1, 0, st, params, nullptr));
+	if (f->timing) { HIP_TRY(hipEventRecord(f->tev[2 * f->launches + 1], st)); f->launches++; }
+	f->samples += (unsigned long long)n;
+	return 0;
+}
+
 static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
+	if (f->graph) return fx_enqueue_graph(f, d_io, n, st);
 	if (f->patch == KLG_PATCH_REVERB) for (int k = 0; k < f->K; k++) rv_prepare(f, k);
 	if (int rc = fx_flush_updates(f, st)) return rc;
 	if (f->timing) {
@@ -244,7 +317,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 extern "C" int klg_fx_process(klg_fx* f, float* io, int n) {
 	if (!f || !io || n <= 0 || n > f->max_block) return fail(KLG_ERR_INVALID, "klg_fx_process: bad arguments (n=%d)", n);
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
-	const size_t bytes = (size_t)f->K * 2 * n * 4;
+	const size_t bytes = (size_t)f->K * f->channels * n * 4;
 	HIP_TRY(hipMemcpyAsync(f->d_io, io, bytes, hipMemcpyHostToDevice, f->stream));
 	if (int rc = fx_enqueue(f, f->d_io, n, f->stream)) return rc;
 	HIP_TRY(hipMemcpyAsync(io, f->d_io, bytes, hipMemcpyDeviceToHost, f->stream));

@@ -32,9 +32,14 @@ inline std::string generate_source(const Program& g) {
 	const int NW = g.words();
 	std::vector<bool> swept(g.nodes.size(), false), written(g.nodes.size(), false), retuned(g.nodes.size(), false);
 	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; if (o.code == OP_OSCSET) retuned[(size_t)o.node] = true; }
+	const bool fx = g.channels > 0;
+	std::vector<long long> ring_off(g.nodes.size(), 0); std::vector<int> inputs(g.nodes.size(), 0);   // Delay nodes: first row in the group's ring tile, inputs per sample
+	{ long long rows = 0; for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == N_DELAY) { ring_off[i] = rows; rows += g.arg((int)i); } }
+	for (const Op& o : g.ops) if (o.code == OP_DELAYIN) inputs[(size_t)o.node]++;
+	auto ring = [&](int node) { return fmt("Ring{ c.ring + (size_t)%lldll * FX_WG, FX_WG, %d }", ring_off[(size_t)node], g.arg(node)); };
 	uint64_t mask[2] = { 1ull, 0ull };                                   // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
-	std::string live = "\tstruct Live { int stage;", begin, end, body;
+	std::string live = fx ? "\tstruct Live { int unused_;" : "\tstruct Live { int stage;", begin, end, body;
 	for (size_t i = 0; i < g.nodes.size(); i++) {
 		const int k = g.nodes[i], w0 = g.node_word0((int)i);
 		const std::string n = fmt("L.n%zu", i);
@@ -142,6 +147,15 @@ inline std::string generate_source(const Program& g) {
 				+ W(e0 + ENV_OUT, "f2u(" + n + "e.r_out)") + W(e0 + ENV_TARGET, "f2u(" + n + "e.r_target)") + W(e0 + ENV_RATE, "f2u(" + n + "e.r_rate)") + W(e0 + ENV_TIME, "f2u(" + n + "e.time)") + W(e0 + ENV_BITS, "env_pack(" + n + "e)");
 			mark(w0 + OPER_POS, 1); mark(w0 + OPER_AMP, 1); mark(w0 + e0 + ENV_OUT, 5);
 		} break;
+		case N_DELAY:
+			live += fmt(" int n%zupos;", i);
+			begin += "\t\t" + n + fmt("pos = (int)((c.samples * %dull) %% %dull);\n", inputs[i], g.arg((int)i));     // Delay::position: one step per input()
+			break;
+		case N_SMOOTH:
+			live += fmt(" float n%zu;", i);
+			begin += "\t\t" + n + " = " + F(0) + ";\n";
+			end += W(0, "f2u(" + n + ")"); mark(w0, 1);
+			break;
 		case N_PARAM:
 			live += fmt(" float n%zu;", i);
 			begin += "\t\t" + n + " = " + F(0) + ";\n";
@@ -191,6 +205,10 @@ inline std::string generate_source(const Program& g) {
 		case OP_STOP: body += "\t\tL.stage = (int)ST_OFF;\n"; break;
 		case OP_SETPARAM: body += "\t\t" + n + " = " + a + ";\n"; break;
 		case OP_FREQ: body += d + n + "f;\n"; break;
+		case OP_IN: body += d + (o.imm ? "in1" : "in0") + ";\n"; break;
+		case OP_DELAYIN: body += "\t\t{ const Ring q = " + ring(o.node) + "; q.wr(" + n + "pos, " + a + "); " + n + "pos = (" + n + fmt("pos + 1 == %d) ? 0 : ", g.arg(o.node)) + n + "pos + 1; }\n"; break;   // Delay::input klang.h:3396-3403
+		case OP_DELAYTAP: body += d + "delay_tap_float(" + ring(o.node) + ", " + n + "pos, " + a + ");\n"; break;
+		case OP_SMOOTH: body += "\t\t" + n + " = " + n + fmt(" * 0.999f + (1.f - 0.999f) * c.ctl[%u];\n", o.imm) + d + n + ";\n"; break;   // Control::smooth klang.h:1715
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";
 			body += d + "fsine_process(" + n + ", fsine_rel_offset(" + (o.a >= 0 ? a : std::string("0.f")) + ")) * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs) * " + n + "a);\n";
@@ -199,16 +217,26 @@ inline std::string generate_source(const Program& g) {
 	}
 	std::string s;
 	s += "// generated by klg_graph.hpp from a recorded klang process() body (include/klang_mi355_graph.h)\n";
-	s += "#include \"klg_kernels.hpp\"\n#pragma clang fp contract(off)\nnamespace klg {\n";
+	s += fx ? "#include \"klg_fx.hpp\"\n" : "#include \"klg_kernels.hpp\"\n";
+	s += "#pragma clang fp contract(off)\nnamespace klg {\n";
 	s += "__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }\n";
 	s += "struct PatchGen {\n";
 	s += fmt("\tstruct Rec { uint32_t w[%d]; };\n", NW);
 	s += fmt("\tstatic constexpr uint64_t kStoreMask = 0x%llxull;\n\tstatic constexpr uint64_t kStoreMask2 = 0x%llxull;\n", (unsigned long long)mask[0], (unsigned long long)mask[1]);
 	s += live;
-	s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {\n\t\tL.stage = (int)(r.w[0] & 3u);\n" + begin + "\t}\n";
-	s += "\tstatic __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {\n" + body + fmt("\t\treturn r%d;\n\t}\n", g.ret);
-	s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\tr.w[0] = (uint32_t)L.stage;\n" + end + "\t}\n";
-	s += "\tstatic __device__ __forceinline__ void release(Rec&, float) {}\n};\n}\n";
+	if (fx) {
+		s += fmt("\tstatic constexpr int kChannels = %d;\n", g.channels);
+		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const FxCtx& c) {\n\t\tL.unused_ = 0; (void)r; (void)c;\n" + begin + "\t}\n";
+		s += "\tstatic __device__ __forceinline__ void sample(Live& L, const FxCtx& c, float in0, float in1, float& out0, float& out1) {\n\t\t(void)in0; (void)in1;\n" + body
+			+ fmt("\t\tout0 = r%d;\n", g.ret) + (g.channels == 2 ? fmt("\t\tout1 = r%d;\n", g.ret_r) : std::string("\t\t(void)out1;\n")) + "\t}\n";
+		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\t(void)L; (void)r;\n" + end + "\t}\n};\n}\n";
+	}
+	else {
+		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {\n\t\tL.stage = (int)(r.w[0] & 3u);\n" + begin + "\t}\n";
+		s += "\tstatic __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {\n" + body + fmt("\t\treturn r%d;\n\t}\n", g.ret);
+		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\tr.w[0] = (uint32_t)L.stage;\n" + end + "\t}\n";
+		s += "\tstatic __device__ __forceinline__ void release(Rec&, float) {}\n};\n}\n";
+	}
 	return s;
 }
 
@@ -248,7 +276,7 @@ struct Rtc {
 	}
 };
 
-struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; };   // name[pv]
+struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; };   // name[pv] (effects: name[0] only)
 
 // directory holding klg_kernels.hpp etc.: next to the shared library (klang_amd/csrc), or $KLG_GRAPH_SRC
 inline std::string source_dir() {
@@ -277,11 +305,13 @@ inline std::string compile(const char* text, const Compiled** out) {
 	if (!rtc.load()) return rtc.error;
 	Compiled c;
 	c.source = generate_source(g);
-	c.words = g.words();
+	c.words = g.words(); c.channels = g.channels;
+	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY) c.ring_rows += g.arg((int)i);
 	void* prog = nullptr;
 	if (rtc.CreateProgram(&prog, c.source.c_str(), "klg_graph_patch.hip", 0, nullptr, nullptr) != 0) return "hiprtcCreateProgram failed";
 	const char* expr[2] = { "klg::klg_render<klg::PatchGen, false>", "klg::klg_render<klg::PatchGen, true>" };
-	rtc.AddNameExpression(prog, expr[0]); rtc.AddNameExpression(prog, expr[1]);
+	if (g.channels) expr[0] = expr[1] = "klg::klg_fx_graph<klg::PatchGen>";
+	rtc.AddNameExpression(prog, expr[0]); if (!g.channels) rtc.AddNameExpression(prog, expr[1]);
 	const std::string inc = "-I" + source_dir();
 	const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str() };
 	const int rc = rtc.CompileProgram(prog, 5, opts);

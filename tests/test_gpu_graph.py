@@ -67,3 +67,49 @@ def test_graph_program_errors_are_reported():
     import klang_amd
     with pytest.raises(klang_amd.KlangError, match="operand a is not defined"):
         klang_amd.SynthBank("klgg 1\nctl 0\nnode 0 lpf\nop lpf 1 0 -1 0 0\nret 1\nend\n", synths=1, notes=1)
+
+
+# ---- graph effects (`kind effect`): a hand-written program against a numpy model of the same arithmetic ----
+ECHO_PROGRAM = """klgg 1
+kind effect 1
+ctl 2
+dial 0 0.001 1 0.01
+dial 1 0 1 0.5
+node 0 delay 4800
+op in 0 -1 -1 -1 0
+op ctl 1 -1 -1 -1 0
+op const 2 -1 -1 -1 473b8000      # 48000.f
+op mul 3 1 2 -1 0                 # time = controls[0] * fs
+op ctl 4 -1 -1 -1 1
+op delayin -1 0 -1 0 0            # in >> delay
+op delaytap 5 3 -1 0 0            # delay(time)
+op mul 6 5 4 -1 0
+op add 7 0 6 -1 0                 # in + delay(time) * gain >> out
+ret 7
+end
+"""
+
+
+def test_graph_effect_echo_matches_numpy_model():
+    import klang_amd
+    K, N, B, SIZE = 70, 96, 12, 4800
+    bank = klang_amd.FxBank(ECHO_PROGRAM, K, max_block=N, channels=1)
+    rng = np.random.default_rng(8)
+    times = rng.uniform(0.002, 0.09, K).astype(np.float32); gains = rng.uniform(0, 1, K).astype(np.float32)
+    for k in range(K):
+        bank.set_control(k, 0, float(times[k])); bank.set_control(k, 1, float(gains[k]))
+    x = rng.uniform(-0.5, 0.5, (B, K, 1, N)).astype(np.float32)
+    ring = np.zeros((K, SIZE), np.float32); pos = 0
+    for b in range(B):
+        io = x[b].copy()
+        bank.process(io)
+        ref = np.zeros((K, N), np.float32)
+        for i in range(N):                                           # Delay::input then tap(float) klang.h:3396-3427, fp32 throughout
+            ring[:, pos] = x[b, :, 0, i]; pos = (pos + 1) % SIZE
+            read = np.float32(pos - 1) - times * np.float32(48000.0)
+            read = np.where(read < 0, read + np.float32(SIZE), read).astype(np.float32)
+            ii = read.astype(np.int32); frac = (read - ii.astype(np.float32)).astype(np.float32); jj = (ii + 1) % SIZE
+            a, c = ring[np.arange(K), ii], ring[np.arange(K), jj]
+            ref[:, i] = x[b, :, 0, i] + (a + frac * (c - a)).astype(np.float32) * gains
+        assert np.array_equal(io[:, 0].view(np.uint32), ref.view(np.uint32)), f"block {b}"
+    bank.close()
