@@ -80,17 +80,23 @@ namespace gpu {
 // a primitive that lives in a lane record: host mirror <-> its block of record words (include/klang_mi355_graph.h)
 struct Packable { virtual void pack(uint32_t* w) const = 0; virtual void unpack(const uint32_t* w) = 0; virtual ~Packable() {} };
 struct Recorder {
-	struct Obj { const void* addr; size_t size; int kind; const Packable* packable; };     // a primitive or a signal member seen while the prototype Note was constructed
+	struct Obj { const void* addr; size_t size; int kind; const Packable* packable; int arg; };     // a primitive or a signal member seen while the prototype Note / Effect was constructed (arg: Delay SIZE)
 	std::vector<Obj> objs;
 	bool constructing = false, recording = false;
 	klg::graph::Program prog;
 	int next_reg = 0, pending = -1;                              // pending: node whose finished() was just tested by an `if`
 	std::string error;
 	void fail(const std::string& what) { if (error.empty()) error = what; }
-	void note(const void* addr, size_t size, int kind, const Packable* p = nullptr) {
+	void note(const void* addr, size_t size, int kind, const Packable* p = nullptr, int arg = 0) {
 		for (Obj& o : objs) if (o.addr == addr) { o.kind = kind; o.size = size; if (p) o.packable = p; return; }       // ADSR refines the Envelope it derives from
-		objs.push_back({ addr, size, kind, p });
+		objs.push_back({ addr, size, kind, p, arg });
 	}
+	int smooth_node(const void* smoothed_signal) {               // controls[i].smooth() inside an effect: one state word per smoothed control
+		for (size_t i = 0; i < objs.size(); i++) if (objs[i].addr == smoothed_signal) return (int)i;
+		objs.push_back({ smoothed_signal, sizeof(float) * 2, klg::graph::N_SMOOTH, nullptr, 0 });
+		return (int)objs.size() - 1;
+	}
+	bool effect = false;                                         // recording an Effect::process() (in / delay / smooth are available)
 	int emit(int code, int a, int b, int node, uint32_t imm, bool has_dst) {
 		if (pending >= 0 && code != klg::graph::OP_STOPIF) fail("`if (env.finished())` may only guard stop() in a recorded process()");
 		klg::graph::Op o; o.code = code; o.a = a; o.b = b; o.node = node; o.imm = imm; o.dst = has_dst ? next_reg++ : -1;
@@ -161,12 +167,12 @@ struct relative : signal {};
 inline relative signal::operator+() const { relative r; r.value = value; r.reg = reg; return r; }
 inline signal& operator>>(float in, signal& dst) { dst.value = in; dst.reg = -1; return dst; }
 // (templates: only a signal / param / ... on the right takes part — `constant` and `Control` keep their float conversions)
-#define KLANG_SIGNAL_LEFT(T) \
-	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator+(T x, const S& s) { return signal::bin(klg::graph::OP_ADD, signal((float)x), s, (float)x + s.value); } \
-	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator-(T x, const S& s) { return signal::bin(klg::graph::OP_SUB, signal((float)x), s, (float)x - s.value); } \
-	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator*(T x, const S& s) { return signal::bin(klg::graph::OP_MUL, signal((float)x), s, (float)x * s.value); } \
-	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator/(T x, const S& s) { return signal::bin(klg::graph::OP_DIV, signal((float)x), s, (float)x / s.value); }
-KLANG_SIGNAL_LEFT(float) KLANG_SIGNAL_LEFT(double) KLANG_SIGNAL_LEFT(int)
+#define KLANG_SIGNAL_LEFT(OP, CODE) \
+	template<class T, class S, std::enable_if_t<(std::is_same_v<T, float> || std::is_same_v<T, int>) && std::is_base_of_v<signal, S>, int> = 0> \
+	inline signal operator OP(T x, const S& s) { return signal::bin(klg::graph::CODE, signal((float)x), s, (float)x OP s.value); }
+KLANG_SIGNAL_LEFT(+, OP_ADD) KLANG_SIGNAL_LEFT(-, OP_SUB) KLANG_SIGNAL_LEFT(*, OP_MUL) KLANG_SIGNAL_LEFT(/, OP_DIV)
+// (no `double` on the left: the reference has no such operators either, so `0.01 * sig` is built-in DOUBLE arithmetic through the
+//  float conversion and stays a double — on()/off() code keeps exactly those roundings; inside a recorded process() write 0.01f)
 #undef KLANG_SIGNAL_LEFT
 // param + param, Frequency * param, ...: both operands exactly as written (otherwise derived-to-base on one side ties with the
 // float conversion on the other and the call is ambiguous under ISO rules, which clang enforces)
@@ -189,12 +195,15 @@ struct param : signal {
 // ---- Control / Controls / Presets (klang.h:1654-1981; UI fields omitted) ----
 struct Control {
 	std::string name; float min = 0.f, max = 1.f, initial = 0.f;
-	signal value, smoothed;
+	signal value, smoothed; int index = 0;                   // index: position in its Controls (set by Controls::operator=)
 	operator signal&() { return value; }
 	operator param() const { return param(value); }
 	operator float() const { value.concrete_only("float conversion of a Control"); return value.value; }
 	signal smooth() {                                                                                        // klang.h:1715
-		if (gpu::Recorder* r = gpu::recording()) r->fail("Control::smooth() (per-synth state advanced per sample) is not supported in a recorded Note::process()");
+		if (gpu::Recorder* r = gpu::recording()) {
+			if (!r->effect) { r->fail("Control::smooth() (per-synth state advanced per sample) is not supported in a recorded Note::process()"); return smoothed; }
+			signal s(smoothed.value); s.reg = r->emit(klg::graph::OP_SMOOTH, -1, -1, r->smooth_node(&smoothed), (uint32_t)index, true); return s;   // one lane = one effect instance: its own smoothed state
+		}
 		smoothed = smoothed.value * 0.999f + (1.f - 0.999f) * value.value; return smoothed;
 	}
 	Control& set(float x) { value = (x < min) ? min : (max < x) ? max : x; return *this; }                    // klang.h:1725
@@ -215,7 +224,7 @@ struct Group {                                          // klang.h:1853-1873: `{
 };
 struct Controls {
 	std::vector<Control> items; float cache[128] = { 0 };
-	void operator=(std::initializer_list<Group> l) { items.clear(); for (const Group& g : l) for (const Control& c : g.controls) items.push_back(c); }   // klang.h:1895-1902
+	void operator=(std::initializer_list<Group> l) { items.clear(); for (const Group& g : l) for (const Control& c : g.controls) { items.push_back(c); items.back().index = (int)items.size() - 1; } }   // klang.h:1895-1902
 	Control& operator[](int i) { return items[(size_t)i]; }
 	unsigned size() const { return (unsigned)items.size(); }
 	bool changed() { bool c = false; for (size_t i = 0; i < items.size(); i++) if (items[i].value.value != cache[i]) { cache[i] = items[i].value.value; c = true; } return c; }   // klang.h:1914
@@ -241,6 +250,25 @@ struct SampleRate {
 };
 inline SampleRate fs(44100);       // ONE definition per program (the reference's is `static` per translation unit, F7)
 inline klg::host::Fs host_fs() { return klg::host::Fs(fs.f); }
+// `controls[0] * fs`, `mod * fs`: the sample rate is a plain number (its float conversion would un-record a recorded left side)
+// (R is deduced, so a plain float never converts into a SampleRate to get here)
+template<class S, class R, std::enable_if_t<std::is_base_of_v<signal, S> && std::is_same_v<R, SampleRate>, int> = 0> inline signal operator*(const S& a, const R& r) { return static_cast<const signal&>(a) * signal(r.f); }
+template<class S, class R, std::enable_if_t<std::is_base_of_v<signal, S> && std::is_same_v<R, SampleRate>, int> = 0> inline signal operator/(const S& a, const R& r) { return static_cast<const signal&>(a) / signal(r.f); }
+template<class R, std::enable_if_t<std::is_same_v<R, SampleRate>, int> = 0> inline signal operator*(Control& c, const R& r) { return c.value * signal(r.f); }
+template<class R, std::enable_if_t<std::is_same_v<R, SampleRate>, int> = 0> inline signal operator/(Control& c, const R& r) { return c.value / signal(r.f); }
+// Control (op) float / int and the mirror image inside a recorded process() keep the control a control read (same fp32 result as
+// the built-in; doubles stay with the built-in double arithmetic)
+#define KLANG_CONTROL_NUM(OP) \
+	template<class T, std::enable_if_t<std::is_same_v<T, float> || std::is_same_v<T, int>, int> = 0> inline signal operator OP(Control& c, T x) { return c.value OP signal((float)x); } \
+	template<class T, std::enable_if_t<std::is_same_v<T, float> || std::is_same_v<T, int>, int> = 0> inline signal operator OP(T x, Control& c) { return signal((float)x) OP c.value; }
+KLANG_CONTROL_NUM(+) KLANG_CONTROL_NUM(-) KLANG_CONTROL_NUM(*) KLANG_CONTROL_NUM(/)
+#undef KLANG_CONTROL_NUM
+// sqr / cube (klang.h:3067-3069: Function<float> objects; applied to a signal they are the same fp32 products)
+inline signal sqr(const signal& x) { return x * x; }
+inline signal cube(const signal& x) { return x * x * x; }
+// `x >> debug`: the plugin's debug scope (klang.h:3299); nothing to plot here
+struct DebugSink { template<class T> void operator<<(const T&) {} };
+inline thread_local DebugSink debug;
 
 // ---- Generator / Modifier protocol (klang.h:2180-2329): reading an object as a signal runs its process() ----
 namespace Generic {
