@@ -666,18 +666,60 @@ struct GraphLayout {
 	void pack(const void* note, uint32_t* w) const {
 		for (const Member& m : members) {
 			const char* obj = (const char*)note + m.offset;
-			if (m.kind == klg::graph::N_PARAM) w[m.word0] = fbits(reinterpret_cast<const signal*>(obj)->value);
+			if (m.kind == klg::graph::N_DELAY) continue;                           // no record words: the ring lives in HBM
+			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH) w[m.word0] = fbits(reinterpret_cast<const signal*>(obj)->value);
 			else reinterpret_cast<const Packable*>(obj)->pack(w + m.word0);
 		}
 	}
 	void unpack(void* note, const uint32_t* w) const {
 		for (const Member& m : members) {
 			char* obj = (char*)note + m.offset;
-			if (m.kind == klg::graph::N_PARAM) std::memcpy(&reinterpret_cast<signal*>(obj)->value, &w[m.word0], 4);
+			if (m.kind == klg::graph::N_DELAY) continue;
+			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH) std::memcpy(&reinterpret_cast<signal*>(obj)->value, &w[m.word0], 4);
 			else reinterpret_cast<Packable*>(obj)->unpack(w + m.word0);
 		}
 	}
 };
+}
+
+namespace gpu {
+// dead-code elimination, node numbering and member layout shared by the note and the effect recorder
+inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
+	using namespace klg::graph;
+	// ---- dead code: pure ops nobody reads, params nobody reads (and their write-backs), primitives nobody uses ----
+	std::vector<Op>& ops = R.prog.ops;
+	std::vector<char> keep(ops.size(), 1), used;
+	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG; };
+	for (bool changed = true; changed;) {
+		changed = false;
+		used.assign(MAX_OPS + 1, 0); used[(size_t)R.prog.ret] = 1; if (R.prog.ret_r >= 0) used[(size_t)R.prog.ret_r] = 1;
+		for (size_t i = ops.size(); i-- > 0;) {                         // registers are defined before use: one backward sweep
+			if (!keep[i]) continue;
+			const Op& o = ops[i];
+			if (pure(o.code) && !used[(size_t)o.dst]) { keep[i] = 0; changed = true; continue; }
+			if (o.a >= 0) used[(size_t)o.a] = 1;
+			if (o.b >= 0) used[(size_t)o.b] = 1;
+		}
+		std::vector<char> param_read(R.objs.size(), 0);
+		for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].code == OP_PARAM) param_read[(size_t)ops[i].node] = 1;
+		for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].code == OP_SETPARAM && !param_read[(size_t)ops[i].node]) { keep[i] = 0; changed = true; }
+	}
+	std::vector<int> node_id(R.objs.size(), -1);
+	std::vector<char> node_used(R.objs.size(), 0);
+	for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].node >= 0) node_used[(size_t)ops[i].node] = 1;
+	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) { node_id[i] = (int)R.prog.nodes.size(); R.prog.nodes.push_back(R.objs[i].kind); R.prog.node_arg.push_back(R.objs[i].arg); }
+	std::vector<Op> out_ops;
+	for (size_t i = 0; i < ops.size(); i++) if (keep[i]) { Op o = ops[i]; if (o.node >= 0) o.node = node_id[(size_t)o.node]; out_ops.push_back(o); }
+	ops = out_ops;
+	const std::string verr = R.prog.validate();
+	if (!verr.empty()) { std::fprintf(stderr, "klang-mi355: the recorded program is invalid: %s\n", verr.c_str()); std::abort(); }
+	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) {
+		const void* at = (R.objs[i].kind == N_PARAM || R.objs[i].kind == N_SMOOTH || !R.objs[i].packable) ? R.objs[i].addr : (const void*)R.objs[i].packable;
+		L.members.push_back({ (size_t)((const char*)at - lo), R.objs[i].kind, R.prog.node_word0(node_id[i]) });
+	}
+	L.program = R.prog.text();
+	L.words = R.prog.words();
+}
 }
 
 // ---- Controller / Plugin / Effect / NoteBase (klang.h:4182-4292) ----
@@ -786,39 +828,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 			R.recording = false;
 			gpu::rec = nullptr;
 			if (!R.error.empty()) { std::fprintf(stderr, "klang-mi355: cannot record %s::process() as a graph patch: %s\n", typeid(T).name(), R.error.c_str()); std::abort(); }
-			// ---- dead code: pure ops nobody reads, params nobody reads (and their write-backs), primitives nobody uses ----
-			std::vector<Op>& ops = R.prog.ops;
-			std::vector<char> keep(ops.size(), 1), used;
-			auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG; };
-			for (bool changed = true; changed;) {
-				changed = false;
-				used.assign(MAX_OPS + 1, 0); used[(size_t)R.prog.ret] = 1;
-				for (size_t i = ops.size(); i-- > 0;) {                         // registers are defined before use: one backward sweep
-					if (!keep[i]) continue;
-					const Op& o = ops[i];
-					if (pure(o.code) && !used[(size_t)o.dst]) { keep[i] = 0; changed = true; continue; }
-					if (o.a >= 0) used[(size_t)o.a] = 1;
-					if (o.b >= 0) used[(size_t)o.b] = 1;
-				}
-				std::vector<char> param_read(R.objs.size(), 0);
-				for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].code == OP_PARAM) param_read[(size_t)ops[i].node] = 1;
-				for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].code == OP_SETPARAM && !param_read[(size_t)ops[i].node]) { keep[i] = 0; changed = true; }
-			}
-			std::vector<int> node_id(R.objs.size(), -1);
-			std::vector<char> node_used(R.objs.size(), 0);
-			for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].node >= 0) node_used[(size_t)ops[i].node] = 1;
-			for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) { node_id[i] = (int)R.prog.nodes.size(); R.prog.nodes.push_back(R.objs[i].kind); }
-			std::vector<Op> out_ops;
-			for (size_t i = 0; i < ops.size(); i++) if (keep[i]) { Op o = ops[i]; if (o.node >= 0) o.node = node_id[(size_t)o.node]; out_ops.push_back(o); }
-			ops = out_ops;
-			const std::string verr = R.prog.validate();
-			if (!verr.empty()) { std::fprintf(stderr, "klang-mi355: recorded program of %s is invalid: %s\n", typeid(T).name(), verr.c_str()); std::abort(); }
-			for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) {
-				const void* at = R.objs[i].kind == N_PARAM ? R.objs[i].addr : (const void*)R.objs[i].packable;
-				L.members.push_back({ (size_t)((const char*)at - lo), R.objs[i].kind, R.prog.node_word0(node_id[i]) });
-			}
-			L.program = R.prog.text();
-			L.words = R.prog.words();
+			gpu::finish_program(R, lo, L);
 			if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", typeid(T).name(), L.program.c_str());
 			return t;
 		}
@@ -915,6 +925,113 @@ namespace Stereo {
 		virtual void process(float** buffers, int length, float* parameters = nullptr) { render(buffers, 2, length, parameters); }                 // klang.h:4830-4858
 		void output(float** buffers, int length, float* parameters = nullptr) { process(buffers, length, parameters); }                            // v0.7.2 template name
 	};
+}
+
+// =================================================================================================
+// Effects (klang.h:4190-4216 Effect, 4703-4717 Stereo::Effect): the DSL side, rendered as recorded graph effects
+// =================================================================================================
+// Delay<SIZE> (klang.h:3381-3512) inside a recorded Effect::process(): `x >> delay`, `delay << x`, `delay(time)`, `(x >> delay)(time)`.
+// The line itself lives in HBM (one ring per effect instance); on the host the object only takes part in the recording.
+template<int SIZE> struct Delay : Modifier {
+	Delay() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Delay), klg::graph::N_DELAY, nullptr, SIZE); }
+	using Generic::Input<signal>::input;
+	void input() override {
+		if (gpu::Recorder* r = gpu::recording()) { if (!r->effect) { r->fail("Delay is recorded in effects only"); return; } r->emit(klg::graph::OP_DELAYIN, r->reg_of(in), -1, r->node(this, "Delay"), 0, false); return; }
+		device_only("Delay::input()");
+	}
+	template<typename TIME> signal operator()(const TIME& delay) {                 // klang.h:3491-3509: tap(int) for integers, tap(float) otherwise
+		static_assert(!std::is_integral_v<TIME>, "klang-mi355: Delay::operator()(int) (the un-interpolated tap) is not recorded yet: pass a float / signal time");
+		if (gpu::Recorder* r = gpu::recording()) { signal t; if constexpr (std::is_arithmetic_v<TIME>) t = signal((float)delay); else t = signal(delay); signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(t), -1, r->node(this, "Delay"), 0, true); return s; }
+		device_only("Delay::operator()");
+	}
+	void process() override { if (gpu::Recorder* r = gpu::recording()) { r->fail("Delay::set(time) + `>> delay >> out` is not recorded yet: use delay(time)"); return; } device_only("Delay::process()"); }
+	unsigned int max() const { return SIZE; }
+};
+
+// klang::Effect: `in` and `out` are the Modifier's signals; process() is the per-sample body, prepare() runs on the host
+struct Effect : Plugin, Modifier {
+	enum { channels = 1 };
+	virtual void prepare() {}
+	virtual void process() override = 0;
+};
+namespace Stereo {
+	struct signal {                                                          // klang.h:4487-4558 (the operators the shipped effects use)
+		klang::signal l, r;
+		signal(klang::signal l_ = 0.f, klang::signal r_ = 0.f) : l(l_), r(r_) {}
+		signal operator+(const signal& x) const { return { l + x.l, r + x.r }; } signal operator-(const signal& x) const { return { l - x.l, r - x.r }; }
+		signal operator*(const signal& x) const { return { l * x.l, r * x.r }; } signal operator/(const signal& x) const { return { l / x.l, r / x.r }; }
+		signal operator*(const klang::signal& x) const { return { l * x, r * x }; } signal operator/(const klang::signal& x) const { return { l / x, r / x }; }
+		signal operator*(float x) const { return { l * x, r * x }; }
+	};
+	struct Effect : Plugin {
+		enum { channels = 2 };
+		Stereo::signal in, out;
+		virtual ~Effect() {}
+		virtual void prepare() {}
+		virtual void process() = 0;
+	};
+}
+namespace stereo = Stereo;
+
+namespace gpu {
+// `instances` copies of a user effect FX, rendered on the GPU.  The constructor builds ONE FX object with every primitive /
+// signal member announcing itself, runs prepare() and then process() once in recording mode (include/klang_mi355_graph.h,
+// `kind effect`), packs the object's state into the record every instance starts from and creates the bank.
+template<class FX> struct EffectBank {
+	FX* fx = nullptr; klg_fx* h = nullptr; GraphLayout layout; int instances; int channels = FX::channels;
+	explicit EffectBank(int instances_, int max_block = 1024) : instances(instances_) {
+		using namespace klg::graph;
+		Recorder R; R.effect = true; rec = &R;
+		R.constructing = true; fx = new FX(); R.constructing = false;
+		const char* lo = (const char*)fx; const char* hi = lo + sizeof(FX);
+		std::vector<Recorder::Obj> kept;
+		for (const auto& o : R.objs) {
+			const char* a = (const char*)o.addr;
+			if (a < lo || a >= hi) continue;
+			bool inside = false;
+			if (o.kind == N_PARAM) for (const auto& q : R.objs) if (q.kind != N_PARAM && a >= (const char*)q.addr && a < (const char*)q.addr + q.size) inside = true;
+			if (!inside) kept.push_back(o);
+		}
+		R.objs = kept;
+		Controls& ctl = fx->controls;
+		R.prog.channels = channels;
+		R.prog.nctl = (int)ctl.size() < 8 ? (int)ctl.size() : 8;
+		for (int c = 0; c < R.prog.nctl; c++) R.prog.dials[c] = { ctl[c].min, ctl[c].max, ctl[c].initial };
+		fx->prepare();                                                          // host side, before the state is packed
+		R.recording = true;
+		std::vector<int> first_reg(R.objs.size(), -1);
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; first_reg[i] = sg->reg = R.emit(OP_PARAM, -1, -1, (int)i, 0, true); }
+		for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = R.emit(OP_CTL, -1, -1, -1, (uint32_t)c, true);
+		std::vector<Oscillator*> oscs;
+		for (size_t i = 0; i < R.objs.size(); i++) if (is_oscillator(R.objs[i].kind)) if (Oscillator* o = const_cast<Oscillator*>(dynamic_cast<const Oscillator*>(R.objs[i].packable))) { o->frequency.reg = R.emit(OP_FREQ, -1, -1, (int)i, 0, true); oscs.push_back(o); }
+		signal* ins[2]; signal* outs[2];
+		if constexpr (FX::channels == 2) { ins[0] = &fx->in.l; ins[1] = &fx->in.r; outs[0] = &fx->out.l; outs[1] = &fx->out.r; }
+		else { ins[0] = ins[1] = &fx->in; outs[0] = outs[1] = &fx->out; }
+		for (int c = 0; c < channels; c++) ins[c]->reg = R.emit(OP_IN, -1, -1, -1, (uint32_t)c, true);      // `in` is this sample of the block
+		fx->process();
+		R.prog.ret = R.reg_of(*outs[0]);
+		if (channels == 2) R.prog.ret_r = R.reg_of(*outs[1]);
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
+			signal* sg = (signal*)R.objs[i].addr;
+			const bool io = sg == ins[0] || sg == ins[1];
+			if (!io && sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);
+			sg->reg = -1;
+		}
+		for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = -1;
+		for (Oscillator* o : oscs) o->frequency.reg = -1;
+		R.recording = false; rec = nullptr;
+		if (!R.error.empty()) { std::fprintf(stderr, "klang-mi355: cannot record %s::process() as a graph effect: %s\n", typeid(FX).name(), R.error.c_str()); std::abort(); }
+		finish_program(R, lo, layout);
+		if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", typeid(FX).name(), layout.program.c_str());
+		std::vector<uint32_t> words((size_t)layout.words, 0u);
+		layout.pack(fx, words.data());
+		h = klg_fx_create_graph(layout.program.c_str(), instances, fs.f, max_block, words.data());
+		if (!h) { std::fprintf(stderr, "klang-mi355: klg_fx_create_graph: %s\n", klg_last_error()); std::abort(); }
+	}
+	~EffectBank() { if (h) klg_fx_destroy(h); delete fx; }
+	void set(int instance, int control, float value) { if (klg_fx_set_control(h, instance, control, value)) { std::fprintf(stderr, "klang-mi355: %s\n", klg_last_error()); std::abort(); } }
+	void process(float* io /* [instances][channels][n] */, int n) { if (klg_fx_process(h, io, n)) { std::fprintf(stderr, "klang-mi355: klg_fx_process: %s\n", klg_last_error()); std::abort(); } }
+};
 }
 
 namespace optimised { using namespace klang; using namespace Generators::Fast; using namespace Modifiers; using namespace Filters; using namespace Filters::Biquad; }   // klang.h:6145-6152

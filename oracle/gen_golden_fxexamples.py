@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""oracle/gen_golden_fxexamples.py — TEST INFRASTRUCTURE.  Golden vectors for twelve shipped example EFFECTS that have no
+hand-written kernel: examples/{Gain/{Gain,Pan,RM,Tremolo}, Filtering/{EQ,IIR,WahWah}, Delay/{Echo,Feedback},
+Modulation/{Flanger,ModDelay,Chorus}}.k run through the genuine reference header (oracle/_ref/ref_fx_*).  They pin the
+recorded graph-effect path (klang::gpu::EffectBank + `kind effect` programs): tests/test_gpu_fx_facade.py.
+
+Run from the repo root in the build container:  python oracle/gen_golden_fxexamples.py
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from scenario_io import Scenario  # noqa: E402
+
+# name -> per-control (lo, hi) ranges the instances are spread over (inside the Dial ranges of the patch)
+FX = {
+    "fx_gain": [(0.0, 1.0)],
+    "fx_pan": [(0.0, 1.0)],
+    "fx_rm": [(1.0, 900.0), (0.0, 1.0)],
+    "fx_tremolo": [(0.5, 18.0), (0.0, 1.0)],
+    "fx_eq": [(0.0, 1.0), (0.0, 1.0), (0.0, 1.0)],
+    "fx_iir": [(0.05, 1.0)],
+    "fx_wahwah": [(300.0, 5000.0), (0.8, 8.0), (0.2, 6.0)],
+    "fx_echo": [(0.002, 0.02), (0.0, 0.9)],
+    "fx_feedback": [(0.002, 0.02), (0.0, 0.85)],
+    "fx_flanger": [(0.1, 4.0), (0.5, 9.0)],
+    "fx_moddelay": [(0.1, 4.0), (0.1, 0.9)],
+    "fx_chorus": [],
+}
+
+
+def scenarios():
+    rng = np.random.default_rng(20250929)
+    out = {}
+    for name, ranges in FX.items():
+        K = 9
+        s = Scenario(patch=name, block=128, blocks=24, instances=K, burst=2200, seed=int(rng.integers(1, 1 << 30)), dump=list(range(24)))
+        for k in range(K):
+            for c, (lo, hi) in enumerate(ranges):
+                s.control(0, k, c, float(rng.uniform(lo, hi)))
+        for k in range(0, K, 2):                                   # a control change mid-run on some instances
+            for c, (lo, hi) in enumerate(ranges[:2]):
+                s.control(9 + c, k, c, float(rng.uniform(lo, hi)))
+        s.sort()
+        out[name] = s
+    return out
+
+
+def main():
+    subprocess.run(["make", "-C", HERE, "ref"], check=True)
+    for name, s in scenarios().items():
+        scn = os.path.join(GOLD, name + ".scn")
+        s.save(scn)
+        tmp = f"/tmp/_ref_{name}.bin"
+        subprocess.run([os.path.join(HERE, "_ref", "ref_" + name), scn, tmp], check=True)
+        d = open(tmp, "rb").read()
+        magic, K, N, B, CH = (int(x) for x in np.frombuffer(d, np.int32, 5))
+        assert magic == 0x58474C4B
+        out = np.frombuffer(d, np.float32, B * K * CH * N, 20).reshape(B, K, CH, N)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), out=out)
+        print(f"{name}: ok ({os.path.getsize(os.path.join(GOLD, name + '.npz')) // 1024} KiB), peak {np.abs(out).max():.3f}, channels {CH}")
+
+
+if __name__ == "__main__":
+    main()

@@ -199,4 +199,40 @@ static int run_effect(const RefScenario& s, const char* outpath) {
 	return 0;
 }
 
+// Example effects (klang::Effect = 1 channel, Stereo::Effect = 2): every block is written.
+// Output: int32 magic 'KLGX', K, N, B, CH ; float32 [B][K][CH][N]
+template<class EFFECT, int CH>
+static int run_effect_example(const RefScenario& s, const char* outpath) {
+	klang::fs = klang::SampleRate(s.fs);
+	const int N = s.block, K = s.instances, B = s.blocks;
+	std::vector<EFFECT*> fx(K);
+	for (int k = 0; k < K; k++) {
+		fx[k] = new EFFECT();
+		for (auto& c : s.ctl) fx[k]->controls[c.first].set(c.second);
+	}
+	FILE* out = fopen(outpath, "wb");
+	if (!out) return 3;
+	const int hdr[5] = { 0x58474C4B, K, N, B, CH };
+	fwrite(hdr, sizeof(int), 5, out);
+	std::vector<float> io((size_t)K * CH * N);
+	size_t evi = 0;
+	for (int b = 0; b < B; b++) {
+		for (; evi < s.ev.size() && s.ev[evi].block <= b; evi++) {
+			const RefEvent& e = s.ev[evi];
+			if (e.type == 2) fx[e.synth]->controls[(int)e.a].set(e.b);
+		}
+		for (int k = 0; k < K; k++) {
+			float* ch[2] = { &io[((size_t)k * CH + 0) * N], &io[((size_t)k * CH + (CH - 1)) * N] };
+			for (int c = 0; c < CH; c++) for (int i = 0; i < N; i++) ch[c][i] = ref_fx_input(s.seed, k, c, (unsigned)(b * N + i), s.burst);
+			klang::Debug::Session session(nullptr, N, klang::Debug::Buffer::Effect);
+			if constexpr (CH == 1) { klang::buffer mono(ch[0], N); fx[k]->klang::Effect::process(mono); }
+			else { klang::buffer left(ch[0], N), right(ch[1], N); klang::Stereo::buffer st(left, right); fx[k]->klang::Stereo::Effect::process(st); }
+		}
+		fwrite(io.data(), sizeof(float), io.size(), out);
+	}
+	fclose(out);
+	for (auto* e : fx) delete e;
+	return 0;
+}
+
 #endif // REF_WITH_KLANG

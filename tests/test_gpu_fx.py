@@ -12,7 +12,7 @@ from scenario_io import Scenario
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FX_SCENARIOS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.scn")) if Scenario.load(p).instances > 0)
+FX_SCENARIOS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.scn")) if Scenario.load(p).instances > 0 and not os.path.basename(p).startswith("fx_"))   # fx_*: facade-only (test_gpu_fx_facade.py)
 TOL = 1e-5
 
 
