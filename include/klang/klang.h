@@ -439,8 +439,8 @@ namespace Biquad {
 		void set(param f) override { set(f, param(h.type == klg::host::BQ_APF ? 1.f : klg::host::ROOT2_INV)); }
 		void set(param f, param Q) override {
 			if (gpu::Recorder* r = gpu::recording()) {
-				if (h.type != klg::host::BQ_LPF) { r->fail("set(f, Q) inside process() is recorded for Biquad::LPF only"); return; }
-				const int rf = r->reg_of(f), rq = r->reg_of(Q); r->emit(klg::graph::OP_LPFSET, rf, rq, r->node(this, "Biquad::LPF"), 0, false); return;
+				if (h.type == klg::host::BQ_APF) { r->fail("Biquad::APF::set() inside process() / prepare() is not recorded (double-precision design)"); return; }
+				const int rf = r->reg_of(f), rq = r->reg_of(Q); r->emit(klg::graph::OP_LPFSET, rf, rq, r->node(this, "Biquad filter"), (uint32_t)h.type, false); return;
 			}
 			h.set(f, Q, host_fs());
 		}
@@ -709,8 +709,10 @@ inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].node >= 0) node_used[(size_t)ops[i].node] = 1;
 	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) { node_id[i] = (int)R.prog.nodes.size(); R.prog.nodes.push_back(R.objs[i].kind); R.prog.node_arg.push_back(R.objs[i].arg); }
 	std::vector<Op> out_ops;
-	for (size_t i = 0; i < ops.size(); i++) if (keep[i]) { Op o = ops[i]; if (o.node >= 0) o.node = node_id[(size_t)o.node]; out_ops.push_back(o); }
+	int kept_prepare = 0;
+	for (size_t i = 0; i < ops.size(); i++) if (keep[i]) { Op o = ops[i]; if (o.node >= 0) o.node = node_id[(size_t)o.node]; out_ops.push_back(o); if ((int)i < R.prog.prepare_ops) kept_prepare++; }
 	ops = out_ops;
+	R.prog.prepare_ops = kept_prepare;
 	const std::string verr = R.prog.validate();
 	if (!verr.empty()) { std::fprintf(stderr, "klang-mi355: the recorded program is invalid: %s\n", verr.c_str()); std::abort(); }
 	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) {
@@ -958,6 +960,7 @@ namespace Stereo {
 	struct signal {                                                          // klang.h:4487-4558 (the operators the shipped effects use)
 		klang::signal l, r;
 		signal(klang::signal l_ = 0.f, klang::signal r_ = 0.f) : l(l_), r(r_) {}
+		klang::signal& operator[](int c) { return c == 0 ? l : r; }                // klang.h:4530
 		signal operator+(const signal& x) const { return { l + x.l, r + x.r }; } signal operator-(const signal& x) const { return { l - x.l, r - x.r }; }
 		signal operator*(const signal& x) const { return { l * x.l, r * x.r }; } signal operator/(const signal& x) const { return { l / x.l, r / x.r }; }
 		signal operator*(const klang::signal& x) const { return { l * x, r * x }; } signal operator/(const klang::signal& x) const { return { l / x, r / x }; }
@@ -997,13 +1000,28 @@ template<class FX> struct EffectBank {
 		R.prog.channels = channels;
 		R.prog.nctl = (int)ctl.size() < 8 ? (int)ctl.size() : 8;
 		for (int c = 0; c < R.prog.nctl; c++) R.prog.dials[c] = { ctl[c].min, ctl[c].max, ctl[c].initial };
-		fx->prepare();                                                          // host side, before the state is packed
+		// prepare() is recorded too: it becomes the program's per-block prologue (`prepare <n>`), so `filter.set(controls[2])`
+		// follows each instance's own control.  Member params it assigns are written to the record and read back by process().
 		R.recording = true;
 		std::vector<int> first_reg(R.objs.size(), -1);
-		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; first_reg[i] = sg->reg = R.emit(OP_PARAM, -1, -1, (int)i, 0, true); }
-		for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = R.emit(OP_CTL, -1, -1, -1, (uint32_t)c, true);
-		std::vector<Oscillator*> oscs;
-		for (size_t i = 0; i < R.objs.size(); i++) if (is_oscillator(R.objs[i].kind)) if (Oscillator* o = const_cast<Oscillator*>(dynamic_cast<const Oscillator*>(R.objs[i].packable))) { o->frequency.reg = R.emit(OP_FREQ, -1, -1, (int)i, 0, true); oscs.push_back(o); }
+		std::vector<Oscillator*> oscs; std::vector<int> osc_node;
+		for (size_t i = 0; i < R.objs.size(); i++) if (is_oscillator(R.objs[i].kind)) if (Oscillator* o = const_cast<Oscillator*>(dynamic_cast<const Oscillator*>(R.objs[i].packable))) { oscs.push_back(o); osc_node.push_back((int)i); }
+		auto fresh_inputs = [&]() {                                              // control / member / frequency reads of the phase being recorded
+			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; first_reg[i] = sg->reg = R.emit(OP_PARAM, -1, -1, (int)i, 0, true); }
+			for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = R.emit(OP_CTL, -1, -1, -1, (uint32_t)c, true);
+			for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = R.emit(OP_FREQ, -1, -1, osc_node[q], 0, true);
+		};
+		auto write_back = [&](signal* skip0, signal* skip1) {
+			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
+				signal* sg = (signal*)R.objs[i].addr;
+				if (sg != skip0 && sg != skip1 && sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);
+			}
+		};
+		fresh_inputs();
+		fx->prepare();
+		write_back(nullptr, nullptr);
+		R.prog.prepare_ops = (int)R.prog.ops.size();
+		fresh_inputs();
 		signal* ins[2]; signal* outs[2];
 		if constexpr (FX::channels == 2) { ins[0] = &fx->in.l; ins[1] = &fx->in.r; outs[0] = &fx->out.l; outs[1] = &fx->out.r; }
 		else { ins[0] = ins[1] = &fx->in; outs[0] = outs[1] = &fx->out; }

@@ -18,6 +18,8 @@
  *     dial <i> <min> <max> <initial>      Dial(...) of control i              klang.h:1797-1800
  *     node <id> <kind> [size]             a primitive object of the Note / Effect, ids 0,1,2,... in order (size: Delay<SIZE>)
  *     op <code> <dst> <a> <b> <node> <imm>   one op; unused fields are -1; imm = IEEE-754 bits (hex) of a constant
+ *     prepare <n>                         optional (effects): the first n ops are Effect::prepare() (klang.h:4208-4211) — they run once per
+ *                                         block per instance, before the samples; their registers are not visible to the sample ops
  *     ret <reg>                           the register holding `out` at the end of process()   (ret2 <l> <r> for a Stereo::Effect)
  *     end
  * Registers are single-assignment fp32 values.  Record layout: word 0 = flags (bits 0-1 NoteBase::stage), then the
@@ -110,7 +112,7 @@ enum OpCode {
 	OP_OSC,         /* dst = oscillator node process()     Fast::Sine / OSM saw / OSM pulse / Basic::*   */
 	OP_OSCSET,      /* oscillator node .set(f = a)         Fast::Sine::set 5142-5147 / OSM::set 5217-5224 / Oscillator::set 2862 (per sample: vibrato, FM) */
 	OP_LPF,         /* dst = (a >> modifier node)          any modifier kind: Biquad::Filter::process 5605-5612, OnePole, DCF, IIR<1>, ... */
-	OP_LPFSET,      /* lpf node .set(f = a, Q = b)         Biquad::LPF::set klang.h:5575-5600, 5658   */
+	OP_LPFSET,      /* lpf node .set(f = a, Q = b)         Biquad::Filter::set klang.h:5575-5600 + the init() of type imm (0 LPF, 1 HPF, 2 / 3 BPF peak / skirt, 4 BRF, 6 Butterworth<2>) */
 	OP_ENV,         /* dst = env/adsr node ++              Envelope::operator++ klang.h:4013-4051     */
 	OP_ADD, OP_SUB, OP_MUL, OP_DIV,   /* dst = a op b      fp32, IEEE, no contraction                 */
 	OP_NEG,         /* dst = -a                                                                       */
@@ -141,6 +143,7 @@ struct Program {
 	std::vector<Op> ops;
 	int ret = -1, ret_r = -1;    /* ret_r: right channel of a Stereo::Effect */
 	int channels = 0;            /* 0 = synth note; 1 / 2 = effect with that many channels */
+	int prepare_ops = 0;         /* the first prepare_ops ops are the effect's prepare(): once per block */
 	int arg(int node) const { return node < (int)node_arg.size() ? node_arg[(size_t)node] : 0; }
 
 	int words() const { int w = 1; for (int k : nodes) w += node_words(k); return w; }
@@ -157,6 +160,7 @@ struct Program {
 			s += line;
 		}
 		for (const Op& o : ops) { snprintf(line, sizeof line, "op %s %d %d %d %d %08x\n", op_name(o.code), o.dst, o.a, o.b, o.node, o.imm); s += line; }
+		if (prepare_ops) { snprintf(line, sizeof line, "prepare %d\n", prepare_ops); s += line; }
 		if (channels == 2) snprintf(line, sizeof line, "ret2 %d %d\nend\n", ret, ret_r); else snprintf(line, sizeof line, "ret %d\nend\n", ret);
 		s += line;
 		return s;
@@ -199,6 +203,7 @@ struct Program {
 				ops.push_back(o);
 			}
 			else if (!strcmp(kw, "ret")) { if (sscanf(rest, "%d", &ret) != 1) return bad("bad ret"); }
+			else if (!strcmp(kw, "prepare")) { if (sscanf(rest, "%d", &prepare_ops) != 1 || prepare_ops < 0) return bad("bad prepare"); }
 			else if (!strcmp(kw, "ret2")) { if (sscanf(rest, "%d %d", &ret, &ret_r) != 2) return bad("bad ret2"); }
 			else if (!strcmp(kw, "end")) ended = true;
 			else return bad("unknown statement");
@@ -226,7 +231,7 @@ struct Program {
 			case OP_OSC: if (!is_oscillator(k)) return bad("node is not an oscillator"); break;
 			case OP_OSCSET: if (!is_oscillator(k)) return bad("node is not an oscillator"); need_a = true; has_dst = false; break;
 			case OP_LPF: if (!is_modifier(k)) return bad("node is not a modifier"); need_a = true; break;
-			case OP_LPFSET: if (k != N_LPF) return bad("node is not an lpf"); need_a = need_b = true; has_dst = false; break;
+			case OP_LPFSET: if (k != N_LPF) return bad("node is not an lpf"); if (o.imm == 5 || o.imm > 6) return bad("this biquad type cannot be set() on the device"); need_a = need_b = true; has_dst = false; break;
 			case OP_ENV: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); break;
 			case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: need_a = need_b = true; break;
 			case OP_NEG: need_a = true; break;
@@ -249,6 +254,14 @@ struct Program {
 				if (defined[(size_t)o.dst]) return bad("register assigned twice");
 				defined[(size_t)o.dst] = 1;
 			}
+		}
+		if (prepare_ops > (int)ops.size() || (prepare_ops && !channels)) return "graph program: 'prepare' needs an effect program and at most as many ops as there are";
+		{	/* sample ops may not read prepare() registers (prepare runs in another function of the generated patch) */
+			std::vector<char> pre; for (int i = 0; i < prepare_ops; i++) if (ops[(size_t)i].dst >= 0) { if ((int)pre.size() <= ops[(size_t)i].dst) pre.resize((size_t)ops[(size_t)i].dst + 1, 0); pre[(size_t)ops[(size_t)i].dst] = 1; }
+			auto is_pre = [&](int r) { return r >= 0 && r < (int)pre.size() && pre[(size_t)r]; };
+			for (size_t i = (size_t)prepare_ops; i < ops.size(); i++) if (is_pre(ops[i].a) || is_pre(ops[i].b)) return "graph program: a sample op reads a register of prepare()";
+			if (is_pre(ret) || is_pre(ret_r)) return "graph program: 'ret' names a register of prepare()";
+			for (int i = 0; i < prepare_ops; i++) { const int c = ops[(size_t)i].code; if (c == OP_IN || c == OP_DELAYIN || c == OP_DELAYTAP || c == OP_OSC || c == OP_LPF || c == OP_ENV || c == OP_SMOOTH || c == OP_OPERATOR) return "graph program: prepare() may only compute and set()"; }
 		}
 		if (!def(ret)) return "graph program: 'ret' names an undefined register";
 		if (channels == 2 && !def(ret_r)) return "graph program: 'ret2' names an undefined register";

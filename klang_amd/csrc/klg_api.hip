@@ -110,6 +110,7 @@ struct klg_synth {
 	const graphrt::Compiled* graph = nullptr;
 	hipModule_t module = nullptr;
 	hipFunction_t graph_fn[2] = { nullptr, nullptr };
+	hipError_t launch_error = hipSuccess;
 	// host mirrors
 	std::vector<host::ControlH> controls;        // [S][nctl]
 	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
@@ -247,7 +248,7 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 	if (s->graph) {                                       // hipRTC code object: klg_render<PatchGen, pv>
 		RenderArgs args = a;
 		void* params[] = { &args };
-		(void)hipModuleLaunchKernel(s->graph_fn[pv ? 1 : 0], (unsigned)s->grid, 1, 1, WG, 1, 1, 0, st, params, nullptr);
+		s->launch_error = hipModuleLaunchKernel(s->graph_fn[pv ? 1 : 0], (unsigned)s->grid, 1, 1, WG, 1, 1, 0, st, params, nullptr);
 		return;
 	}
 	if (s->patch == KLG_PATCH_SUB2A && s->x2) {           // two voices per lane, packed fp32 (klg_render_x2.hpp)
@@ -522,6 +523,7 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 		HIP_TRY(hipEventRecord(s->tev[2 * s->launches], st));
 	}
 	launch_render(s, a, per_voice, st);
+	if (s->launch_error != hipSuccess) { const hipError_t e = s->launch_error; s->launch_error = hipSuccess; return fail(KLG_ERR_HIP, "launching the compiled graph patch failed: %s", hipGetErrorString(e)); }
 	if (s->timing) { HIP_TRY(hipEventRecord(s->tev[2 * s->launches + 1], st)); s->launches++; }
 	hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
 	HIP_TRY(hipGetLastError());

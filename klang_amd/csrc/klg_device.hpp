@@ -259,6 +259,29 @@ __device__ __forceinline__ void biquad_lpf_set(Biquad& q, BiquadSweep& c, float 
 }
 
 // ---- Filters::OnePole klang.h:5470-5543 ----
+// The same for every Filters::Biquad type but the APF (its init() uses a double cos): TYPE as in host_dsl.hpp
+// (0 LPF, 1 HPF, 2 BPF constant peak, 3 BPF constant skirt, 4 BRF, 6 Butterworth::LPF<2>); klang.h:5658-5739, 5801-5811.
+template<int TYPE> __device__ __forceinline__ void biquad_set(Biquad& q, BiquadSweep& c, float f, float Q, float fs_w) {
+	if (Q < 0) Q = f / -Q;
+	if (c.f != f || c.Q != Q) {
+		c.f = f; c.Q = Q;
+		const float w = f * fs_w;
+		const float cos0 = glibc_cosf(w);
+		const float sin0 = glibc_sinf(w);
+		if (Q < 0.5f) Q = 0.5f;
+		const float a = sin0 / (2.f * Q);
+		const double a0 = (double)(1.f + a);
+		const float inv = (a0 == 0.0) ? 0.0f : (float)(1.0 / a0);
+		q.a1 = inv * (-2.f * cos0);
+		q.a2 = inv * (1.f - a);
+		if (TYPE == 0) { q.b2 = q.b0 = inv * (1.f - cos0) * 0.5f; q.b1 = inv * (1.f - cos0); }
+		else if (TYPE == 1) { q.b2 = q.b0 = inv * (1.f + cos0) * 0.5f; q.b1 = inv * -(1.f + cos0); }
+		else if (TYPE == 2) { q.b0 = inv * a; q.b1 = 0.f; q.b2 = inv * -a; }
+		else if (TYPE == 3) { q.b0 = inv * sin0 * 0.5f; q.b1 = 0.f; q.b2 = -q.b0; }
+		else if (TYPE == 4) { q.b1 = q.a1; q.b0 = q.b2 = inv; }
+		else { q.b0 = inv * ((1.f - cos0) / 2.f); q.b1 = inv * (1.f - cos0); q.b2 = inv * ((1.f - cos0) / 2.f); }
+	}
+}
 struct OnePole { float b0, b1, a1, z, out; };
 __device__ __forceinline__ float onepole_lpf_process(OnePole& q, float in) { q.out = q.b0 * in + q.a1 * q.out + KLG_DENORM; return q.out; }
 __device__ __forceinline__ float onepole_process(OnePole& q, float in) { q.out = q.b0 * in + q.b1 * q.z + q.a1 * q.out + KLG_DENORM; q.z = in; return q.out; }

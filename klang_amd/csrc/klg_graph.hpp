@@ -164,7 +164,10 @@ inline std::string generate_source(const Program& g) {
 		}
 	}
 	live += " };\n";
-	for (const Op& o : g.ops) {
+	std::string prologue;                                                // Effect::prepare(): once per block, at the end of begin()
+	for (size_t oi = 0; oi < g.ops.size(); oi++) {
+		const Op& o = g.ops[oi];
+		if ((int)oi == g.prepare_ops && g.prepare_ops) { prologue = body; body.clear(); }
 		const std::string d = fmt("\t\tconst float r%d = ", o.dst), n = fmt("L.n%d", o.node), a = fmt("r%d", o.a), b = fmt("r%d", o.b);
 		const int k = (o.node >= 0 && o.node < (int)g.nodes.size()) ? g.nodes[(size_t)o.node] : -1;
 		switch (o.code) {
@@ -194,7 +197,7 @@ inline std::string generate_source(const Program& g) {
 				: k == N_BUTTER1 ? "butter1_process" : k == N_MODAL ? "modal_process" : k == N_FOLLOWPEAK ? "follower_peak" : "follower_rms";
 			body += d + fn + "(" + n + ", " + a + ");\n";
 		} break;
-		case OP_LPFSET: body += "\t\tbiquad_lpf_set(" + n + ", " + n + "s, " + a + ", " + b + ", c.fs.w);\n"; break;
+		case OP_LPFSET: body += (o.imm == 0 ? "\t\tbiquad_lpf_set(" : fmt("\t\tbiquad_set<%u>(", o.imm)) + n + ", " + n + "s, " + a + ", " + b + ", c.fs.w);\n"; break;
 		case OP_ENV: body += d + (k == N_ADSR ? "adsr_process(" + n + ", c.fs)" : "env_process_rt(" + n + ", " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs)") + ";\n"; break;
 		case OP_ADD: body += d + a + " + " + b + ";\n"; break;
 		case OP_SUB: body += d + a + " - " + b + ";\n"; break;
@@ -215,6 +218,8 @@ inline std::string generate_source(const Program& g) {
 			break;
 		}
 	}
+	if (g.prepare_ops && (int)g.ops.size() == g.prepare_ops) { prologue = body; body.clear(); }
+	begin += prologue;
 	std::string s;
 	s += "// generated by klg_graph.hpp from a recorded klang process() body (include/klang_mi355_graph.h)\n";
 	s += fx ? "#include \"klg_fx.hpp\"\n" : "#include \"klg_kernels.hpp\"\n";

@@ -159,6 +159,7 @@ extern "C" int klg_selftest(int prim, const float* params, int n_params, const f
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	float *d_p = nullptr, *d_in = nullptr, *d_out = nullptr, *d_scratch = nullptr;
 	const size_t scratch = 1 << 20;
+	struct Free { float **a, **b, **c, **d; ~Free() { (void)hipFree(*a); (void)hipFree(*b); (void)hipFree(*c); (void)hipFree(*d); } } release = { &d_p, &d_in, &d_out, &d_scratch };   // also on the error returns of HIP_TRY
 	HIP_TRY(hipMalloc(&d_p, (size_t)std::max(n_params, 1) * 4)); HIP_TRY(hipMalloc(&d_in, (size_t)std::max(n_in, 1) * 4));
 	HIP_TRY(hipMalloc(&d_out, (size_t)n_out * 4)); HIP_TRY(hipMalloc(&d_scratch, scratch * 4));
 	HIP_TRY(hipMemcpy(d_p, params, (size_t)n_params * 4, hipMemcpyHostToDevice));
@@ -168,7 +169,6 @@ extern "C" int klg_selftest(int prim, const float* params, int n_params, const f
 	hipLaunchKernelGGL(klg::klg_selftest_kernel, dim3(1), dim3(64), 0, 0, a);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpy(out, d_out, (size_t)n_out * 4, hipMemcpyDeviceToHost));
-	(void)hipFree(d_p); (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_scratch);
 	return 0;
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""oracle/gen_golden_fxexamples.py — TEST INFRASTRUCTURE.  Golden vectors for twelve shipped example EFFECTS that have no
-hand-written kernel: examples/{Gain/{Gain,Pan,RM,Tremolo}, Filtering/{EQ,IIR,WahWah}, Delay/{Echo,Feedback},
+"""oracle/gen_golden_fxexamples.py — TEST INFRASTRUCTURE.  Golden vectors for thirteen shipped example EFFECTS that have no
+hand-written kernel: examples/{Gain/{Gain,Pan,RM,Tremolo}, Filtering/{EQ,IIR,WahWah}, Delay/{Echo,Feedback,Reverb},
 Modulation/{Flanger,ModDelay,Chorus}}.k run through the genuine reference header (oracle/_ref/ref_fx_*).  They pin the
 recorded graph-effect path (klang::gpu::EffectBank + `kind effect` programs): tests/test_gpu_fx_facade.py.
 
@@ -32,6 +32,9 @@ FX = {
     "fx_flanger": [(0.1, 4.0), (0.5, 9.0)],
     "fx_moddelay": [(0.1, 4.0), (0.1, 0.9)],
     "fx_chorus": [],
+    # Delay/Reverb.k: prepare() sets the damping LPF from a control every block (recorded as the per-block prologue),
+    # sixteen `param` members (tap times / gains) live in the record, two Delay<192000> (Reverb2.k computes a tap time in DOUBLE from a control, which a recorded fp32 program cannot express)
+    "fx_reverb1": [(0.05, 0.5), (0.02, 0.4), (500.0, 5000.0)],
 }
 
 
@@ -45,7 +48,7 @@ def scenarios():
             for c, (lo, hi) in enumerate(ranges):
                 s.control(0, k, c, float(rng.uniform(lo, hi)))
         for k in range(0, K, 2):                                   # a control change mid-run on some instances
-            for c, (lo, hi) in enumerate(ranges[:2]):
+            for c, (lo, hi) in list(enumerate(ranges))[-2:]:
                 s.control(9 + c, k, c, float(rng.uniform(lo, hi)))
         s.sort()
         out[name] = s
