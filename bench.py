@@ -73,6 +73,17 @@ def cpu_baseline(patch, block, budget_s=12.0):
             "sample": f"{patch}: 128 voices x {block} samples x {blocks} blocks, oracle/klang_oracle.c -O2 single thread, {os.cpu_count()} host cores present"}
 
 
+def valu_issue(patch, V, N, kern_s):
+    """VALU ISSUE-rate view of the sustain loop of klg_render_sub2a_x2 (the number that actually bounds this kernel): one wave =
+    128 voices; per sample its steady-state loop issues 37 instructions + 65 per 16-sample mix flush = 41 (counted in the ISA,
+    DESIGN.md section 3); a SIMD issues one wave64 VALU instruction per 4 cycles, 1024 SIMDs at the 2.4 GHz peak engine clock."""
+    if patch != "sub2a" or os.environ.get("KLG_RENDER_X1") == "1":
+        return {}
+    achieved = (V / 128.0) * N * 41.0 / kern_s
+    peak = 1024 * 2.4e9 / 4.0
+    return {"issue_rate_frac_est": achieved / peak, "wave_instr_per_wave_sample": 41, "issue_peak_wave_instr_per_s": peak}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,7 +224,7 @@ def main():
                          "kernel": ("klg_render_sub2a_x2<false>" if args.patch == "sub2a" and os.environ.get("KLG_RENDER_X1") != "1" else "klg_render<%s>" % args.patch), "kernel_ms": 1e3 * kern_s, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "synth patches keep voice state in registers: the binding unit is fp32 VALU issue, see `valu`",
                          "valu": {"achieved_tflops_est": flops, "peak_tflops": FP32_PEAK_TFLOPS, "frac": flops / FP32_PEAK_TFLOPS,
-                                  "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(args.patch, 0)}},
+                                  "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(args.patch, 0), **valu_issue(args.patch, V, N, kern_s)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.patch, N)
