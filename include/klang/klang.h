@@ -24,10 +24,12 @@
 //     (`osc(f * (1 + lfo * depth))`: vibrato / FM by set(f)), the Basic oscillators, Operator<Sine> chains (`op1 * I >> op2 >> out`),
 //     every Biquad type, OnePole, DCF, IIR<1>, Butterworth, Modal, Envelope::Follower (Biquad::LPF also set(f, Q) per sample), Envelope
 //     (<= 4 points, setLoop) and ADSR `++`, + - * / and unary minus on signals / params / controls / constants, `.out` of a
-//     member, signal and param members of the Note (read, and written for next-sample state), `>> out`, `out *= x`, and
-//     `if (env.finished()) stop();`.  Anything else (a signal forced to a plain float, other data-dependent branches,
-//     set(f, phase) / reset() inside process()) stops with a message naming the construct.
-// Effects (Stereo::Effect patches) are reached through klg_fx_* directly; their DSL façade is future work.
+//     member, signal and param members of the Note (read, and written for next-sample state), `>> out`, `out *= x`,
+//     `if (env.finished()) stop();`, and data-dependent `if` / `else if` / `&&` / `!` on comparisons of signals, params and controls
+//     (`if (in > 1) in = 1;`, `if (osc.frequency < fs.nyquist) out += osc / h;`): process() is then run once per outcome and the
+//     traces are merged into structured if / else / endif + phi ops (gpu::PathMerger).  Anything else (a signal forced to a plain
+//     float or int, set(f, phase) / reset() inside process()) stops with a message naming the construct.
+// Effects: klang::gpu::EffectBank<FX> records a user Effect / Stereo::Effect the same way (prepare() becomes the per-block prologue).
 //
 // Reference interface citations (file:line) are into nashaudio/klang's klang.h v0.7.8.
 #pragma once
@@ -37,7 +39,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <initializer_list>
+#include <map>
+#include <set>
 #include <string>
 #include <type_traits>
 #include <typeinfo>
@@ -97,6 +102,16 @@ struct Recorder {
 		return (int)objs.size() - 1;
 	}
 	bool effect = false;                                         // recording an Effect::process() (in / delay / smooth are available)
+	// data-dependent branches: process() is run once per outcome (record_paths below); `decisions` is the outcome list this run
+	// follows, runs past its end take `true`.  Each test leaves an OP_IF marker (imm = the outcome taken) in the trace.
+	std::vector<char> decisions; size_t decision_pos = 0; bool may_branch = false;
+	bool decide(int cond_reg) {
+		if (!may_branch) { fail("a data-dependent `if` is only supported in process() (not in prepare())"); return true; }
+		if (decision_pos >= decisions.size()) decisions.push_back(1);
+		const bool take = decisions[decision_pos++] != 0;
+		emit(klg::graph::OP_IF, cond_reg, -1, -1, take ? 1u : 0u, false);
+		return take;
+	}
 	int emit(int code, int a, int b, int node, uint32_t imm, bool has_dst) {
 		if (pending >= 0 && code != klg::graph::OP_STOPIF) fail("`if (env.finished())` may only guard stop() in a recorded process()");
 		klg::graph::Op o; o.code = code; o.a = a; o.b = b; o.node = node; o.imm = imm; o.dst = has_dst ? next_reg++ : -1;
@@ -104,6 +119,15 @@ struct Recorder {
 		return o.dst;
 	}
 	int reg_of(const signal& s);
+	// literals: an op where they are first needed — except while process() is traced once per branch outcome (PathMerger), where
+	// they live in a pool of their own (registers CONST_BASE + k), so that the traces of different outcomes line up op for op
+	enum { CONST_BASE = 1 << 24 };
+	bool pool_consts = false; std::vector<uint32_t> const_pool;
+	int const_reg(uint32_t bits) {
+		if (!pool_consts) return emit(klg::graph::OP_CONST, -1, -1, -1, bits, true);
+		for (size_t k = 0; k < const_pool.size(); k++) if (const_pool[k] == bits) return CONST_BASE + (int)k;
+		const_pool.push_back(bits); return CONST_BASE + (int)const_pool.size() - 1;
+	}
 	std::vector<int> node_of_obj;                               // objs index -> provisional node id (== objs index)
 	int node(const void* addr, const char* what) {
 		for (size_t i = 0; i < objs.size(); i++) if (objs[i].addr == addr) return (int)i;
@@ -119,6 +143,16 @@ inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline bool no_set_while_recording(const char* what) { if (Recorder* r = recording()) { r->fail(std::string(what) + " inside process() is not supported in a recorded graph (set it in on())"); return true; } return false; }
 // the value of `if (env.finished())`: a plain bool on the host, a recorded condition while recording
 struct Cond { bool value; int node; explicit operator bool() const { if (node >= 0 && recording()) { rec->pending = node; return true; } return value; } bool operator!() const { if (node >= 0 && recording()) { rec->fail("`!env.finished()` is not supported in a recorded process()"); } return !value; } };
+}
+
+namespace gpu {
+// `a < b` on signals: a plain bool outside a recording (or between two unrecorded values), a recorded condition inside one —
+// testing it (`if`, `&&`, `?:`) asks the recorder which way this run goes
+struct Pred {
+	bool value; int reg = -1;
+	explicit operator bool() const { if (reg >= 0) if (Recorder* r = recording()) return r->decide(reg); return value; }
+	Pred operator!() const;
+};
 }
 
 // ---- signal / relative / param (klang.h:1062-1200, 1357-1371) ----
@@ -161,8 +195,30 @@ struct signal {
 	void concrete_only(const char* what) const { if (reg >= 0) if (gpu::Recorder* r = gpu::recording()) r->fail(std::string(what) + " of a signal computed in process(): keep it a signal / param (a plain float cannot be recorded)"); }
 	operator const float() const { concrete_only("float conversion"); return value; }
 	operator float&() { concrete_only("float& conversion"); return value; }
+	// `if (mute)`: non-zero (the built-in float -> bool), recordable
+	static gpu::Pred cmp(uint32_t rel, const signal& a, const signal& b, bool concrete) {
+		gpu::Recorder* r = gpu::recording();
+		if (!r || (a.reg < 0 && b.reg < 0)) return gpu::Pred{ concrete, -1 };
+		const int ra = r->reg_of(a), rb = r->reg_of(b);
+		return gpu::Pred{ concrete, r->emit(klg::graph::OP_CMP, ra, rb, -1, rel, true) };
+	}
+	explicit operator bool() const { return (bool)cmp(5u, *this, signal(0.f), value != 0.f); }
+	explicit operator bool() { return (bool)cmp(5u, *this, signal(0.f), value != 0.f); }
 	relative operator+() const;
 };
+// comparisons (the reference compares through the float conversion; same result, but recordable).  Templates with exactly
+// deduced operand types, so that they never compete with the built-in comparisons of plain numbers.
+#define KLANG_SIGNAL_CMP(OP, REL) \
+	template<class A, class B, std::enable_if_t<std::is_base_of_v<signal, A> && std::is_base_of_v<signal, B>, int> = 0> inline gpu::Pred operator OP(const A& a, const B& b) { return signal::cmp(REL, a, b, a.value OP b.value); } \
+	template<class A, class T, std::enable_if_t<std::is_base_of_v<signal, A> && std::is_arithmetic_v<T>, int> = 0> inline gpu::Pred operator OP(const A& a, T b) { return signal::cmp(REL, a, signal((float)b), a.value OP (float)b); } \
+	template<class T, class B, std::enable_if_t<std::is_arithmetic_v<T> && std::is_base_of_v<signal, B>, int> = 0> inline gpu::Pred operator OP(T a, const B& b) { return signal::cmp(REL, signal((float)a), b, (float)a OP b.value); }
+KLANG_SIGNAL_CMP(<, 0u) KLANG_SIGNAL_CMP(>, 1u) KLANG_SIGNAL_CMP(<=, 2u) KLANG_SIGNAL_CMP(>=, 3u) KLANG_SIGNAL_CMP(==, 4u) KLANG_SIGNAL_CMP(!=, 5u)
+#undef KLANG_SIGNAL_CMP
+inline gpu::Pred gpu::Pred::operator!() const {
+	Recorder* r = reg >= 0 ? recording() : nullptr;
+	if (!r) return Pred{ !value, -1 };
+	return Pred{ !value, r->emit(klg::graph::OP_CMP, reg, r->const_reg(0u), -1, 4u, true) };   // !c  ==  (c == 0)
+}
 struct relative : signal {};
 inline relative signal::operator+() const { relative r; r.value = value; r.reg = reg; return r; }
 inline signal& operator>>(float in, signal& dst) { dst.value = in; dst.reg = -1; return dst; }
@@ -181,7 +237,7 @@ KLANG_SIGNAL_LEFT(+, OP_ADD) KLANG_SIGNAL_LEFT(-, OP_SUB) KLANG_SIGNAL_LEFT(*, O
 	inline signal operator OP(const A& a, const B& b) { return signal::bin(klg::graph::CODE, a, b, a.value OP b.value); }
 KLANG_SIGNAL_PAIR(+, OP_ADD) KLANG_SIGNAL_PAIR(-, OP_SUB) KLANG_SIGNAL_PAIR(*, OP_MUL) KLANG_SIGNAL_PAIR(/, OP_DIV)
 #undef KLANG_SIGNAL_PAIR
-inline int gpu::Recorder::reg_of(const signal& s) { return s.reg >= 0 ? s.reg : emit(klg::graph::OP_CONST, -1, -1, -1, gpu::fbits(s.value), true); }
+inline int gpu::Recorder::reg_of(const signal& s) { return s.reg >= 0 ? s.reg : const_reg(gpu::fbits(s.value)); }
 
 struct Control;
 struct param : signal {
@@ -216,7 +272,23 @@ inline param::param(Control& c) : signal(c.value) {}
 	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> inline signal operator OP(Control& c, const S& a) { return c.value OP static_cast<const signal&>(a); }
 KLANG_CONTROL_OPS(+) KLANG_CONTROL_OPS(-) KLANG_CONTROL_OPS(*) KLANG_CONTROL_OPS(/)
 #undef KLANG_CONTROL_OPS
+// comparisons of a control (recordable like those of a signal)
+#define KLANG_CONTROL_CMP(OP) \
+	template<class T, std::enable_if_t<std::is_arithmetic_v<T>, int> = 0> inline gpu::Pred operator OP(Control& c, T x) { return c.value OP x; } \
+	template<class T, std::enable_if_t<std::is_arithmetic_v<T>, int> = 0> inline gpu::Pred operator OP(T x, Control& c) { return x OP c.value; } \
+	template<class S, std::enable_if_t<std::is_base_of_v<signal, S>, int> = 0> inline gpu::Pred operator OP(Control& c, const S& s) { return c.value OP static_cast<const signal&>(s); } \
+	template<class S, std::enable_if_t<std::is_base_of_v<signal, S>, int> = 0> inline gpu::Pred operator OP(const S& s, Control& c) { return static_cast<const signal&>(s) OP c.value; }
+KLANG_CONTROL_CMP(<) KLANG_CONTROL_CMP(>) KLANG_CONTROL_CMP(<=) KLANG_CONTROL_CMP(>=) KLANG_CONTROL_CMP(==) KLANG_CONTROL_CMP(!=)
+#undef KLANG_CONTROL_CMP
 inline Control Dial(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f) { Control c; c.name = name; c.min = mn; c.max = mx; c.initial = initial; c.value = initial; return c; }
+// the other control kinds (klang.h:1801-1856): on this side of the boundary a control is its range and value
+inline Control Slider(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f) { return Dial(name, mn, mx, initial); }
+inline Control Meter(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f) { return Dial(name, mn, mx, initial); }
+inline Control Button(const char* name) { return Dial(name, 0.f, 1.f, 0.f); }
+inline Control Toggle(const char* name, bool initial = false) { return Dial(name, 0.f, 1.f, initial ? 1.f : 0.f); }
+template<typename... Options> inline Control Menu(const char* name, const Options... options) { return Dial(name, 0.f, (float)sizeof...(options) - 1.f, 0.f); }
+inline Control PitchBend() { return Dial("PITCH\nBEND", 0.f, 16384.f, 8192.f); }
+inline Control ModWheel() { return Dial("MOD\nWHEEL", 0.f, 127.f, 0.f); }
 struct Group {                                          // klang.h:1853-1873: `{ Dial(..) }` or `{ "name", Dial(..), Dial(..) }`
 	const char* name; std::vector<Control> controls;
 	template<typename... C> Group(const char* n, C... c) : name(n), controls{ c... } {}
@@ -683,13 +755,148 @@ struct GraphLayout {
 }
 
 namespace gpu {
+// ---- data-dependent branches: one run of process() per outcome, merged into structured if / else / endif + phi ops ----
+// `run` executes process() and its epilogue (write-backs, then the OP_OUT marker naming the output registers).  The first
+// trace takes `true` everywhere; at each OP_IF marker the other outcome is traced too, the two traces rejoin where their
+// tails become the same ops again (the longest common tail: merging more of the tail is always valid, the operands that
+// differ become phis), the parts in between are the two sides.  Sides may contain further branches (handled recursively).
+struct PathMerger {
+	using Op = klg::graph::Op;
+	enum { OP_OUT = klg::graph::OP_CODES };                       // recorder-internal: a = out (left), b = right or -1; becomes `ret`
+	Recorder& R; size_t base_ops; int base_reg; std::function<void()> run;
+	std::vector<Op> out; int next = 0, pseudo = 1 << 20, runs = 0;
+	PathMerger(Recorder& r, std::function<void()> f) : R(r), base_ops(r.prog.ops.size()), base_reg(r.next_reg), run(std::move(f)), next(r.next_reg) {}
+	std::vector<Op> trace(const std::vector<char>& D) {
+		R.prog.ops.resize(base_ops); R.next_reg = base_reg; R.decisions = D; R.decision_pos = 0; R.pending = -1;
+		if (++runs > 2048) { R.fail("process() has too many data-dependent branches to record"); return {}; }
+		run();
+		return std::vector<Op>(R.prog.ops.begin() + (std::ptrdiff_t)base_ops, R.prog.ops.end());
+	}
+	std::map<int, int> const_final;                               // pool index -> register of the final program
+	int map_reg(const std::map<int, int>& m, int r) {
+		if (r < base_reg) return r;                                   // -1, or a register of the common prologue
+		if (r >= Recorder::CONST_BASE) { const auto it = const_final.find(r - Recorder::CONST_BASE); if (it != const_final.end()) return it->second; return const_final[r - Recorder::CONST_BASE] = next++; }
+		const auto it = m.find(r);
+		if (it == m.end()) { R.fail("a value computed inside one side of an `if` is used after it in a way that cannot be merged"); return 0; }
+		return it->second;
+	}
+	void copy_op(const Op& o, std::map<int, int>& m) { Op q = o; q.a = map_reg(m, o.a); q.b = map_reg(m, o.b); if (o.dst >= 0) { q.dst = next++; m[o.dst] = q.dst; } out.push_back(q); }
+	static bool same(const Op& a, const Op& b) { return a.code == b.code && a.node == b.node && a.imm == b.imm && (a.dst >= 0) == (b.dst >= 0); }
+	// a trace: `cur` is rewritten as phis replace operands of its tail, `orig` keeps the registers as the run numbered them
+	// (two runs that share a prefix number it identically, so `orig` is what traces are compared on)
+	struct Trace { std::vector<Op> cur, orig; size_t size() const { return cur.size(); } };
+	// longest tail of T[from..) / F[from..) that is the same ops with corresponding operands; `occ` (optional) receives the
+	// operand occurrences (index into the tail, field 0 = a / 1 = b) whose values differ between the traces: the phis
+	// (p0: pseudo registers >= p0 are phis made inside the sides of this `if` — out of scope after it, so they need a phi too)
+	size_t common_tail(const Trace& T, const Trace& F, size_t from, int r_if, int p0, std::vector<std::pair<size_t, int>>* occ) {
+		size_t S = 0;
+		const size_t lim = std::min(T.size(), F.size()) - from;
+		while (S < lim && same(T.cur[T.size() - 1 - S], F.cur[F.size() - 1 - S])) S++;
+		for (;;) {
+			const size_t sT = T.size() - S, sF = F.size() - S;
+			std::map<int, int> def; std::set<int> fdef;
+			if (occ) occ->clear();
+			bool ok = true;
+			for (size_t k = 0; k < S && ok; k++) {
+				const Op& a = T.orig[sT + k]; const Op& b = F.orig[sF + k];
+				const int xs[2] = { a.a, a.b }, ys[2] = { b.a, b.b };
+				for (int f = 0; f < 2 && ok; f++) {
+					const int x = xs[f], y = ys[f];
+					if (x < 0 && y < 0) continue;
+					const bool dx = def.count(x) != 0, dy = fdef.count(y) != 0;
+					if ((x < 0) != (y < 0) || dx != dy || (dx && def[x] != y)) { S = S - k - 1; ok = false; break; }
+					if (dx) continue;
+					const int xc = f ? T.cur[sT + k].b : T.cur[sT + k].a, yc = f ? F.cur[sF + k].b : F.cur[sF + k].a;
+					if (x == y && (x < r_if || x >= Recorder::CONST_BASE) && !(xc >= p0 && xc < Recorder::CONST_BASE) && !(yc >= p0 && yc < Recorder::CONST_BASE)) continue;   // the same value, computed before the branch (or the same literal)
+					if (occ) occ->push_back({ k, f });
+				}
+				if (ok && a.dst >= 0) { def[a.dst] = b.dst; fdef.insert(b.dst); }
+			}
+			if (ok) return S;
+		}
+	}
+	void emit_range(Trace& T, size_t lo, size_t hi, std::map<int, int>& m) {
+		using namespace klg::graph;
+		for (size_t i = lo; i < hi && R.error.empty();) {
+			const Op o = T.cur[i];
+			if (o.code != OP_IF) { copy_op(o, m); i++; continue; }
+			std::vector<char> D;
+			for (size_t q = 0; q < i; q++) if (T.cur[q].code == OP_IF) D.push_back((char)T.cur[q].imm);
+			D.push_back(0);
+			Trace F; F.cur = trace(D); F.orig = F.cur;
+			if (!R.error.empty()) return;
+			bool prefix = F.size() > i && F.cur[i].code == OP_IF && F.cur[i].imm == 0 && o.imm == 1;
+			for (size_t q = 0; prefix && q < i; q++) prefix = same(T.orig[q], F.orig[q]) && T.orig[q].dst == F.orig[q].dst;
+			if (!prefix) { R.fail("process() does not record the same ops when run again (does it depend on random() or host state?)"); return; }
+			int r_if = base_reg;
+			for (size_t q = 0; q < i; q++) if (T.orig[q].dst >= r_if) r_if = T.orig[q].dst + 1;
+			const int p0 = pseudo;
+			const size_t S = common_tail(T, F, i + 1, r_if, p0, nullptr);
+			const size_t sT = T.size() - S, sF = F.size() - S;
+			if (std::getenv("KLANG_MI355_DEBUG_PATHS")) {
+				std::fprintf(stderr, "if at %zu: |T| %zu |F| %zu tail %zu -> sides T[%zu,%zu) F[%zu,%zu) hi %zu r_if %d\n", i, T.size(), F.size(), S, i + 1, sT, i + 1, sF, hi, r_if);
+				for (size_t q = i; q < std::min(T.size(), i + 14); q++) std::fprintf(stderr, "   T %s %d %d %d n%d %x | F %s %d %d %d n%d %x\n", op_name(T.orig[q].code), T.orig[q].dst, T.orig[q].a, T.orig[q].b, T.orig[q].node, T.orig[q].imm,
+					q < F.size() ? op_name(F.orig[q].code) : "-", q < F.size() ? F.orig[q].dst : 0, q < F.size() ? F.orig[q].a : 0, q < F.size() ? F.orig[q].b : 0, q < F.size() ? F.orig[q].node : 0, q < F.size() ? F.orig[q].imm : 0);
+			}
+			if (sT > hi) { R.fail("an `if` inside process() does not rejoin the code after it (early return?)"); return; }
+			Op c = o; c.a = map_reg(m, o.a); c.imm = 0; out.push_back(c);
+			std::map<int, int> mT = m, mF = m;
+			emit_range(T, i + 1, sT, mT);
+			Op e = o; e.code = OP_ELSE; e.a = -1; e.imm = 0; out.push_back(e);
+			emit_range(F, i + 1, sF, mF);
+			e.code = OP_ENDIF; out.push_back(e);
+			if (!R.error.empty()) return;
+			std::vector<std::pair<size_t, int>> occ;
+			if (common_tail(T, F, i + 1, r_if, p0, &occ) != S) { R.fail("internal: the branch join moved"); return; }
+			// after the join only what was visible before the `if` and the phis are: registers of the sides are out of scope
+			// (a later run that took the `if` side names its values by their raw registers: those map to a phi that merged them)
+			std::map<std::pair<int, int>, int> phi_of;                     // (then value, else value) -> pseudo register of the tail
+			for (const auto& oc : occ) {
+				Op& a = T.cur[sT + oc.first]; const Op& b = F.cur[sF + oc.first];
+				int& x = oc.second ? a.b : a.a; const int y = oc.second ? b.b : b.a;
+				const int x_raw = oc.second ? T.orig[sT + oc.first].b : T.orig[sT + oc.first].a;
+				const auto key = std::make_pair(x, y);
+				auto it = phi_of.find(key);
+				if (it == phi_of.end()) {
+					Op ph; ph.code = OP_PHI; ph.node = -1; ph.imm = 0; ph.a = map_reg(mT, x); ph.b = map_reg(mF, y); ph.dst = next++;
+					out.push_back(ph);
+					it = phi_of.emplace(key, pseudo++).first;
+					m[it->second] = ph.dst;
+					if (x_raw >= r_if && x_raw < Recorder::CONST_BASE) m[x_raw] = ph.dst;
+				}
+				x = it->second;
+			}
+			i = sT;
+		}
+	}
+	// records every path; on return R.prog.ops = prologue + the structured body, R.prog.ret / ret_r are set
+	void record() {
+		R.pool_consts = true;
+		Trace T; T.cur = trace({}); T.orig = T.cur;
+		if (!R.error.empty()) return;
+		std::map<int, int> m;
+		emit_range(T, 0, T.size(), m);
+		if (!R.error.empty()) return;
+		if (out.empty() || out.back().code != OP_OUT) { R.fail("internal: the recorded body does not end with its output"); return; }
+		R.prog.ret = out.back().a; R.prog.ret_r = out.back().b; out.pop_back();
+		for (const Op& q : out) if (q.code == OP_OUT) { R.fail("internal: output marker inside a branch"); return; }
+		R.prog.ops.resize(base_ops);
+		for (const auto& kv : const_final) { Op c; c.code = klg::graph::OP_CONST; c.dst = kv.second; c.a = c.b = c.node = -1; c.imm = R.const_pool[(size_t)kv.first]; R.prog.ops.push_back(c); }
+		R.prog.ops.insert(R.prog.ops.end(), out.begin(), out.end());
+		R.next_reg = next;
+		R.pool_consts = false;
+	}
+};
+}
+
+namespace gpu {
 // dead-code elimination, node numbering and member layout shared by the note and the effect recorder
 inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	using namespace klg::graph;
 	// ---- dead code: pure ops nobody reads, params nobody reads (and their write-backs), primitives nobody uses ----
 	std::vector<Op>& ops = R.prog.ops;
 	std::vector<char> keep(ops.size(), 1), used;
-	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG; };
+	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG || c == OP_CMP || c == OP_PHI; };
 	for (bool changed = true; changed;) {
 		changed = false;
 		used.assign(MAX_OPS + 1, 0); used[(size_t)R.prog.ret] = 1; if (R.prog.ret_r >= 0) used[(size_t)R.prog.ret_r] = 1;
@@ -714,7 +921,7 @@ inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	ops = out_ops;
 	R.prog.prepare_ops = kept_prepare;
 	const std::string verr = R.prog.validate();
-	if (!verr.empty()) { std::fprintf(stderr, "klang-mi355: the recorded program is invalid: %s\n", verr.c_str()); std::abort(); }
+	if (!verr.empty()) { std::fprintf(stderr, "klang-mi355: the recorded program is invalid: %s\n%s", verr.c_str(), R.prog.text().c_str()); std::abort(); }
 	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) {
 		const void* at = (R.objs[i].kind == N_PARAM || R.objs[i].kind == N_SMOOTH || !R.objs[i].packable) ? R.objs[i].addr : (const void*)R.objs[i].packable;
 		L.members.push_back({ (size_t)((const char*)at - lo), R.objs[i].kind, R.prog.node_word0(node_id[i]) });
@@ -817,14 +1024,25 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 				if (o) { o->frequency.reg = R.emit(OP_FREQ, -1, -1, (int)i, 0, true); oscs.push_back(o); }
 			}
 			NOTEBASE* nb = t;
-			nb->process();
-			if (R.pending >= 0) R.fail("`if (env.finished())` may only guard stop() in a recorded process()");
-			R.prog.ret = R.reg_of(nb->out);
-			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
-				signal* sg = (signal*)R.objs[i].addr;
-				if (sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);     // written by process(): the next sample reads it
-				sg->reg = -1;
-			}
+			std::vector<float> value0(R.objs.size(), 0.f); std::vector<int> freq_reg;
+			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) value0[i] = ((signal*)R.objs[i].addr)->value;
+			for (Oscillator* o : oscs) freq_reg.push_back(o->frequency.reg);
+			gpu::PathMerger paths(R, [&]() {                                 // one run of process(): every data-dependent `if` outcome gets its own (gpu::PathMerger)
+				for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = first_reg[i]; sg->value = value0[i]; }
+				for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = freq_reg[q];
+				R.may_branch = true;
+				nb->process();
+				R.may_branch = false;
+				if (R.pending >= 0) R.fail("`if (env.finished())` may only guard stop() in a recorded process()");
+				const int ret = R.reg_of(nb->out);
+				for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
+					signal* sg = (signal*)R.objs[i].addr;
+					if (sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);     // written by process(): the next sample reads it
+				}
+				R.emit(gpu::PathMerger::OP_OUT, ret, -1, -1, 0, false);
+			});
+			paths.record();
+			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = -1; sg->value = value0[i]; }
 			for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = -1;
 			for (Oscillator* o : oscs) o->frequency.reg = -1;
 			R.recording = false;
@@ -1026,15 +1244,27 @@ template<class FX> struct EffectBank {
 		if constexpr (FX::channels == 2) { ins[0] = &fx->in.l; ins[1] = &fx->in.r; outs[0] = &fx->out.l; outs[1] = &fx->out.r; }
 		else { ins[0] = ins[1] = &fx->in; outs[0] = outs[1] = &fx->out; }
 		for (int c = 0; c < channels; c++) ins[c]->reg = R.emit(OP_IN, -1, -1, -1, (uint32_t)c, true);      // `in` is this sample of the block
-		fx->process();
-		R.prog.ret = R.reg_of(*outs[0]);
-		if (channels == 2) R.prog.ret_r = R.reg_of(*outs[1]);
-		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
-			signal* sg = (signal*)R.objs[i].addr;
-			const bool io = sg == ins[0] || sg == ins[1];
-			if (!io && sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);
-			sg->reg = -1;
-		}
+		std::vector<float> value0(R.objs.size(), 0.f); std::vector<int> freq_reg, in_reg;
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) value0[i] = ((signal*)R.objs[i].addr)->value;
+		for (Oscillator* o : oscs) freq_reg.push_back(o->frequency.reg);
+		for (int c = 0; c < channels; c++) in_reg.push_back(ins[c]->reg);
+		PathMerger paths(R, [&]() {                                          // one run of process() per outcome of its data-dependent `if`s
+			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = first_reg[i]; sg->value = value0[i]; }
+			for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = freq_reg[q];
+			for (int c = 0; c < channels; c++) ins[c]->reg = in_reg[(size_t)c];
+			R.may_branch = true;
+			fx->process();
+			R.may_branch = false;
+			const int ret = R.reg_of(*outs[0]), ret_r = channels == 2 ? R.reg_of(*outs[1]) : -1;
+			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
+				signal* sg = (signal*)R.objs[i].addr;
+				const bool io = sg == ins[0] || sg == ins[1];
+				if (!io && sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);
+			}
+			R.emit(PathMerger::OP_OUT, ret, ret_r, -1, 0, false);
+		});
+		paths.record();
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = -1; sg->value = value0[i]; }
 		for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = -1;
 		for (Oscillator* o : oscs) o->frequency.reg = -1;
 		R.recording = false; rec = nullptr;

@@ -22,6 +22,11 @@
  *                                         block per instance, before the samples; their registers are not visible to the sample ops
  *     ret <reg>                           the register holding `out` at the end of process()   (ret2 <l> <r> for a Stereo::Effect)
  *     end
+ * Data-dependent branches of process() (`if (in > 1) in = 1;`, `if (osc.frequency < fs.nyquist) out += osc / h;`) are
+ * structured ops: `cmp` makes a 1.0 / 0.0 register, `if <a>` ... `else` ... `endif` brackets the two sides (registers
+ * assigned inside a side are not visible outside it), and the `phi` ops directly after an `endif` merge values:
+ * `phi dst a b` = a (a register visible at the end of the `if` side) when the condition held, else b (visible at the end of
+ * the `else` side).  The façade finds the sides by running process() once per branch outcome and merging the traces.
  * Registers are single-assignment fp32 values.  Record layout: word 0 = flags (bits 0-1 NoteBase::stage), then the
  * words of node 0, node 1, ... in order (node_words()).
  */
@@ -125,10 +130,15 @@ enum OpCode {
 	OP_DELAYTAP,    /* dst = delay node (a)                             Delay::tap(float) klang.h:3412-3427                   */
 	OP_SMOOTH,      /* dst = smooth node: controls[imm].smooth()        Control::smooth klang.h:1715                          */
 	OP_OPERATOR,    /* dst = operator node process()       modulator a (or -1: none), amp b (or -1: keep)   Operator::process klang.h:4164-4168 */
+	OP_CMP,         /* dst = (a REL b) ? 1.0 : 0.0         imm = relation: 0 <, 1 >, 2 <=, 3 >=, 4 ==, 5 !=  (IEEE: false on NaN except !=) */
+	OP_IF,          /* if (a != 0) {                       structured; the sides are scopes                   */
+	OP_ELSE,        /* } else {                                                                               */
+	OP_ENDIF,       /* }                                                                                      */
+	OP_PHI,         /* dst = condition of the `if` just closed ? a : b       only directly after `endif` (or another phi of it) */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -216,8 +226,13 @@ struct Program {
 	/* single assignment, defined-before-use, node kinds match their ops */
 	std::string validate() const {
 		if (words() > MAX_WORDS) return "graph program: the voice record exceeds 128 words";
-		std::vector<char> defined;
-		auto def = [&](int r) { return r >= 0 && r < (int)defined.size() && defined[(size_t)r]; };
+		std::vector<char> defined;                                 /* 1 = visible here, 2 = assigned in a branch side that has ended */
+		auto def = [&](int r) { return r >= 0 && r < (int)defined.size() && defined[(size_t)r] == 1; };
+		struct Side { std::vector<int> regs; bool in_else; std::vector<int> then_side; };
+		std::vector<Side> open;                                    /* the `if`s we are inside */
+		std::vector<int> then_regs, else_regs;                     /* of the `if` just closed: what its phis may name */
+		bool after_endif = false;
+		auto in_list = [](const std::vector<int>& l, int r) { for (int x : l) if (x == r) return true; return false; };
 		auto kind = [&](int n) { return (n >= 0 && n < (int)nodes.size()) ? nodes[(size_t)n] : -1; };
 		char m[160];
 		for (size_t i = 0; i < ops.size(); i++) {
@@ -244,8 +259,25 @@ struct Program {
 			case OP_DELAYTAP: if (k != N_DELAY) return bad("node is not a delay"); need_a = true; break;
 			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); break;
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
+			case OP_CMP: if (o.imm > 5u) return bad("unknown relation"); need_a = need_b = true; break;
+			case OP_IF: if ((int)i < prepare_ops) return bad("prepare() may not branch"); need_a = true; has_dst = false; open.push_back({ {}, false, {} }); break;
+			case OP_ELSE:
+				if (open.empty() || open.back().in_else) return bad("no open `if`");
+				has_dst = false; open.back().then_side = open.back().regs; for (int r : open.back().regs) defined[(size_t)r] = 2; open.back().regs.clear(); open.back().in_else = true; break;
+			case OP_ENDIF:
+				if (open.empty()) return bad("no open `if`");
+				has_dst = false;
+				if (!open.back().in_else) { then_regs = open.back().regs; else_regs.clear(); } else { then_regs = open.back().then_side; else_regs = open.back().regs; }
+				for (int r : open.back().regs) defined[(size_t)r] = 2;
+				open.pop_back(); break;
+			case OP_PHI:
+				if (!after_endif) return bad("a phi must directly follow `endif`");
+				if (!(def(o.a) || in_list(then_regs, o.a))) return bad("operand a is not visible at the end of the `if` side");
+				if (!(def(o.b) || in_list(else_regs, o.b))) return bad("operand b is not visible at the end of the `else` side");
+				break;
 			default: return bad("unknown code");
 			}
+			after_endif = o.code == OP_ENDIF || o.code == OP_PHI;
 			if (need_a && !def(o.a)) return bad("operand a is not defined");
 			if (need_b && !def(o.b)) return bad("operand b is not defined");
 			if (has_dst) {
@@ -253,8 +285,10 @@ struct Program {
 				if ((int)defined.size() <= o.dst) defined.resize((size_t)o.dst + 1, 0);
 				if (defined[(size_t)o.dst]) return bad("register assigned twice");
 				defined[(size_t)o.dst] = 1;
+				if (!open.empty()) open.back().regs.push_back(o.dst);
 			}
 		}
+		if (!open.empty()) return "graph program: an `if` is not closed";
 		if (prepare_ops > (int)ops.size() || (prepare_ops && !channels)) return "graph program: 'prepare' needs an effect program and at most as many ops as there are";
 		{	/* sample ops may not read prepare() registers (prepare runs in another function of the generated patch) */
 			std::vector<char> pre; for (int i = 0; i < prepare_ops; i++) if (ops[(size_t)i].dst >= 0) { if ((int)pre.size() <= ops[(size_t)i].dst) pre.resize((size_t)ops[(size_t)i].dst + 1, 0); pre[(size_t)ops[(size_t)i].dst] = 1; }

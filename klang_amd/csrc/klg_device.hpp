@@ -37,6 +37,21 @@ __device__ __forceinline__ uint32_t f2u_wrap(float x) {
 	return in_range ? (uint32_t)(int64_t)x : 0u;
 }
 
+// x / Y for a compile-time constant Y (bit pattern YBITS) in three VALU operations instead of the ~12 of the IEEE division
+// expansion: with r = RN(1/Y), q = RN(x*r), e = x - Y*q (exact in an fma), q + e*r rounds to the IEEE quotient.  Only divisors for
+// which this was checked against x / Y on ALL 2^32 float bit patterns (tools/verify_div_const.c: 0 mismatches) are accepted;
+// zeros, infinities and NaN take q, which is the IEEE result for them.
+template<uint32_t YBITS> struct DivConstChecked { static constexpr bool value = YBITS == 0x40e00000u /*7*/ || YBITS == 0x40400000u /*3*/ || YBITS == 0x40a00000u /*5*/
+	|| YBITS == 0x41100000u /*9*/ || YBITS == 0x40200000u /*2.5*/; };
+template<uint32_t YBITS> __device__ __forceinline__ float div_const(float x) {
+	static_assert(DivConstChecked<YBITS>::value, "divisor not in the exhaustively verified set");
+	const float y = u2f(YBITS), r = 1.0f / y;
+	const float q = x * r;
+	const float e = __builtin_fmaf(-y, q, x);
+	const float q2 = __builtin_fmaf(e, r, q);
+	return __builtin_amdgcn_class(x, 0x198) ? q2 : q;                      // -normal | -subnormal | +subnormal | +normal
+}
+
 // ---- Generators::Fast helpers ----
 __device__ __forceinline__ uint32_t fast_phase(float radians) {          // Fast::Phase::operator= klang.h:4993-4998
 	return f2u_wrap(radians * KLG_FINTMAX / KLG_TWO_PI);

@@ -164,6 +164,19 @@ inline std::string generate_source(const Program& g) {
 		}
 	}
 	live += " };\n";
+	std::map<int, uint32_t> const_of;                                    // single-assignment registers holding a literal
+	// structured branches: the phis that follow an `endif` are assigned at the end of each side of their `if`
+	std::vector<int> match_else(g.ops.size(), -1), match_endif(g.ops.size(), -1), if_of(g.ops.size(), -1);
+	{
+		std::vector<int> st;
+		for (size_t oi = 0; oi < g.ops.size(); oi++) {
+			const int c = g.ops[oi].code;
+			if (c == OP_IF) st.push_back((int)oi);
+			else if (c == OP_ELSE && !st.empty()) { match_else[(size_t)st.back()] = (int)oi; if_of[oi] = st.back(); }
+			else if (c == OP_ENDIF && !st.empty()) { match_endif[(size_t)st.back()] = (int)oi; if_of[oi] = st.back(); st.pop_back(); }
+		}
+	}
+	auto phis_of = [&](int if_index) { std::vector<const Op*> v; const int e = match_endif[(size_t)if_index]; for (size_t q = (size_t)e + 1; e >= 0 && q < g.ops.size() && g.ops[q].code == OP_PHI; q++) v.push_back(&g.ops[q]); return v; };
 	std::string prologue;                                                // Effect::prepare(): once per block, at the end of begin()
 	for (size_t oi = 0; oi < g.ops.size(); oi++) {
 		const Op& o = g.ops[oi];
@@ -171,7 +184,7 @@ inline std::string generate_source(const Program& g) {
 		const std::string d = fmt("\t\tconst float r%d = ", o.dst), n = fmt("L.n%d", o.node), a = fmt("r%d", o.a), b = fmt("r%d", o.b);
 		const int k = (o.node >= 0 && o.node < (int)g.nodes.size()) ? g.nodes[(size_t)o.node] : -1;
 		switch (o.code) {
-		case OP_CONST: body += d + fmt("u2f(0x%08xu);\n", o.imm); break;
+		case OP_CONST: body += d + fmt("u2f(0x%08xu);\n", o.imm); const_of[o.dst] = o.imm; break;
 		case OP_CTL: body += d + fmt("c.ctl[%u];\n", o.imm); break;
 		case OP_PARAM: body += d + n + ";\n"; break;
 		case OP_OSC: {
@@ -202,8 +215,28 @@ inline std::string generate_source(const Program& g) {
 		case OP_ADD: body += d + a + " + " + b + ";\n"; break;
 		case OP_SUB: body += d + a + " - " + b + ";\n"; break;
 		case OP_MUL: body += d + a + " * " + b + ";\n"; break;
-		case OP_DIV: body += d + a + " / " + b + ";\n"; break;
+		case OP_DIV: {                                              // constant divisors of the verified set: klg_device.hpp div_const
+			const auto cv = const_of.find(o.b);
+			const uint32_t y = cv == const_of.end() ? 0u : cv->second;
+			if (y == 0x40e00000u || y == 0x40400000u || y == 0x40a00000u || y == 0x41100000u || y == 0x40200000u) body += d + fmt("div_const<0x%08xu>(", y) + a + ");\n";
+			else body += d + a + " / " + b + ";\n";
+		} break;
 		case OP_NEG: body += d + "-" + a + ";\n"; break;
+		case OP_CMP: { static const char* rel[6] = { "<", ">", "<=", ">=", "==", "!=" }; body += d + "(" + a + " " + rel[o.imm <= 5u ? o.imm : 0u] + " " + b + ") ? 1.f : 0.f;\n"; } break;
+		case OP_IF:
+			for (const Op* ph : phis_of((int)oi)) body += fmt("\t\tfloat r%d;\n", ph->dst);
+			body += "\t\tif (" + a + " != 0.f) {\n";
+			break;
+		case OP_ELSE:
+			for (const Op* ph : phis_of(if_of[oi])) body += fmt("\t\tr%d = r%d;\n", ph->dst, ph->a);
+			body += "\t\t} else {\n";
+			break;
+		case OP_ENDIF:
+			if (match_else[(size_t)if_of[oi]] < 0) { for (const Op* ph : phis_of(if_of[oi])) body += fmt("\t\tr%d = r%d;\n", ph->dst, ph->a); body += "\t\t} else {\n"; }
+			for (const Op* ph : phis_of(if_of[oi])) body += fmt("\t\tr%d = r%d;\n", ph->dst, ph->b);
+			body += "\t\t}\n";
+			break;
+		case OP_PHI: break;                                         // assigned at the end of both sides (above)
 		case OP_STOPIF: body += "\t\tL.stage = (" + n + (k == N_ADSR ? ".e" : "") + ".stage == ENV_OFF) ? (int)ST_OFF : L.stage;\n"; break;
 		case OP_STOP: body += "\t\tL.stage = (int)ST_OFF;\n"; break;
 		case OP_SETPARAM: body += "\t\t" + n + " = " + a + ";\n"; break;

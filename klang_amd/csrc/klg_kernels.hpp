@@ -48,8 +48,13 @@ template<class P, class = void> struct StoreMask2 { static constexpr uint64_t va
 template<class P> struct StoreMask2<P, klg_void_t<decltype(P::kStoreMask2)>> { static constexpr uint64_t value = P::kStoreMask2; };
 template<class P> __device__ __forceinline__ constexpr bool patch_stores(int w) { return w < 64 ? ((P::kStoreMask >> (w & 63)) & 1ull) != 0 : ((StoreMask2<P>::value >> (w & 63)) & 1ull) != 0; }
 
+// a patch may pin its occupancy with `static constexpr int kWavesPerEu` (measured per patch: SuperSaw renders 8 % faster at 4
+// waves/SIMD with ~10 spilled registers than at the 3 the allocator picks on its own; FM and sub2 do not)
+template<class P, class = void> struct WavesPerEu { static constexpr int lo = 1, hi = 8; };
+template<class P> struct WavesPerEu<P, klg_void_t<decltype(P::kWavesPerEu)>> { static constexpr int lo = P::kWavesPerEu, hi = P::kWavesPerEu; };
+
 template<class P, bool PER_VOICE>
-__global__ __launch_bounds__(WG) void klg_render(const RenderArgs a) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P>::lo, WavesPerEu<P>::hi))) void klg_render(const RenderArgs a) {
 	using Rec = typename P::Rec;
 	constexpr int W = sizeof(Rec) / 4;
 	__shared__ float lds[WAVES * CHUNK * TILE_LD + MAX_BLOCK];

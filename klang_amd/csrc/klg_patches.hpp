@@ -167,6 +167,7 @@ struct PatchSuperSaw {
 	using Rec = rec::SuperSaw;                                                               // 37 words = 148 B read, 12 words written
 	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc[0].offset, 1) | KLG_W(Rec, osc[1].offset, 1) | KLG_W(Rec, osc[2].offset, 1)
 		| KLG_W(Rec, osc[3].offset, 1) | KLG_W(Rec, osc[4].offset, 1) | KLG_W(Rec, osc[5].offset, 1) | KLG_W(Rec, osc[6].offset, 1) | KLG_W(Rec, adsr.r_out, 4);
+	static constexpr int kWavesPerEu = 4;
 	struct Live { Osm osc[7]; Adsr adsr; int stage; };
 	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {
 		L.stage = (int)(r.flags & 3u);
@@ -177,7 +178,7 @@ struct PatchSuperSaw {
 	static __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {
 		float out = 0.f;
 #pragma unroll
-		for (int k = 0; k < 7; k++) out += osm_saw(L.osc[k]) / 7.f;
+		for (int k = 0; k < 7; k++) out += div_const<0x40e00000u>(osm_saw(L.osc[k]));   // `/ 7` SuperSaw.k:29
 		out *= adsr_process(L.adsr, c.fs);
 		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;

@@ -44,8 +44,7 @@ def scenarios():
     # Expression.k: per-sample vibrato (osc.set(f) from an LFO whose rate is itself an envelope), three 3/4-point envelopes,
     # swept LPF, random() in on() -> every note-on carries a seed
     out["ex_expression"] = poly("ex_expression", 64, [0, 1, 30, 31, 63], off_base=20, seeded=True)
-    # four more shipped examples: 32 Fast::Sine partials in a user Generator (Additive/Saw.k; Square.k and Nyquist.k branch on
-    # `osc.frequency < fs.nyquist` per sample, which a recorded graph cannot express), and AM / FM / FM2 whose carriers and
+    # four more shipped examples: 32 Fast::Sine partials in a user Generator (Additive/Saw.k), and AM / FM / FM2 whose carriers and
     # modulators are re-tuned per sample from `carrier.frequency` and the controls
     out["ex_addsaw"] = poly("ex_addsaw", 24, [0, 1, 23], off_base=8)
     out["ex_am"] = poly("ex_am", 32, [0, 1, 9, 31], off_base=8, ctl=[(0, 0.5), (1, 0.5)], ctl_events=[(4, 0, 1.7), (6, 1, 0.9)])
@@ -57,6 +56,16 @@ def scenarios():
     out["own_basic_mix"] = poly("own_basic_mix", 48, [0, 1, 7, 8, 47], off_base=10, notes=16)
     out["own_filters_f2"] = poly("own_filters_f2", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
     out["own_modal_follow"] = poly("own_modal_follow", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
+    # Additive/Nyquist.k and Square.k: `if (osc[o].frequency < fs.nyquist) out += osc[o] / h;` per partial and sample — a
+    # data-dependent branch per oscillator (the partial is neither summed NOR advanced above Nyquist); high pitches so that it bites
+    for nm in ("ex_nyquist", "ex_square"):
+        s = Scenario(patch=nm, block=256, blocks=16, synths=1, notes=32, dump=[0, 1, 15])
+        for k, p in enumerate(rng.choice(np.arange(60, 120), size=14, replace=False)):
+            s.on(0 if k < 8 else k - 6, 0, int(p), float(rng.uniform(0.25, 1.0)), -1)
+            s.off(5 + (k % 7), 0, int(p), 0.0)
+        s.sort()
+        out[nm] = s
+    out["own_branches"] = poly("own_branches", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 0, 0.1)])
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],
@@ -66,8 +75,8 @@ def scenarios():
         s = Scenario(patch=src.patch, block=256, blocks=24, synths=1, notes=src.notes, dump=[0, 23])
         for i, v in solo_ctl.get(name, []):
             s.ctl.append((i, float(np.float32(v))))
-        s.on(0, 0, 57, 0.8, 4242 if name == "ex_expression" else -1)
-        s.off(14, 0, 57, 0.0)
+        s.on(0, 0, 100 if name in ("ex_nyquist", "ex_square") else 57, 0.8, 4242 if name == "ex_expression" else -1)
+        s.off(14, 0, 100 if name in ("ex_nyquist", "ex_square") else 57, 0.0)
         out[name + "_solo"] = s
     return out
 

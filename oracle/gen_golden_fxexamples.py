@@ -35,7 +35,16 @@ FX = {
     # Delay/Reverb.k: prepare() sets the damping LPF from a control every block (recorded as the per-block prologue),
     # sixteen `param` members (tap times / gains) live in the record, two Delay<192000> (Reverb2.k computes a tap time in DOUBLE from a control, which a recorded fp32 program cannot express)
     "fx_reverb1": [(0.05, 0.5), (0.02, 0.4), (500.0, 5000.0)],
+    # data-dependent `if`s in process() (recorded once per outcome and merged into if / else / phi ops): a three-way clipper and a
+    # Toggle that selects the gain
+    "fx_clipping": [(1.0, 11.0)],
+    "fx_mute": [("choice", (0.0, 1.0))],
 }
+
+
+def draw(rng, lo, hi):
+    return float(rng.choice(hi)) if lo == "choice" else float(rng.uniform(lo, hi))
+
 
 
 def scenarios():
@@ -46,10 +55,10 @@ def scenarios():
         s = Scenario(patch=name, block=128, blocks=24, instances=K, burst=2200, seed=int(rng.integers(1, 1 << 30)), dump=list(range(24)))
         for k in range(K):
             for c, (lo, hi) in enumerate(ranges):
-                s.control(0, k, c, float(rng.uniform(lo, hi)))
+                s.control(0, k, c, draw(rng, lo, hi))
         for k in range(0, K, 2):                                   # a control change mid-run on some instances
             for c, (lo, hi) in list(enumerate(ranges))[-2:]:
-                s.control(9 + c, k, c, float(rng.uniform(lo, hi)))
+                s.control(9 + c, k, c, draw(rng, lo, hi))
         s.sort()
         out[name] = s
     return out

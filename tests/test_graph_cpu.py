@@ -64,6 +64,71 @@ def test_malformed_programs_are_rejected_with_a_reason(program, message):
     assert rc < 0 and message in msg, msg
 
 
+CLIPPER = """klgg 1
+kind effect 1
+ctl 1
+dial 0 1 11 1
+op ctl 0 -1 -1 -1 0
+op in 1 -1 -1 -1 0
+op mul 2 1 0 -1 0
+op const 3 -1 -1 -1 3f800000
+op const 4 -1 -1 -1 bf800000
+op cmp 5 2 3 -1 1            # in * gain > 1
+op if -1 5 -1 -1 0
+op else -1 -1 -1 -1 0
+op cmp 6 2 4 -1 0            # in * gain < -1
+op if -1 6 -1 -1 0
+op else -1 -1 -1 -1 0
+op endif -1 -1 -1 -1 0
+op phi 7 4 2 -1 0
+op endif -1 -1 -1 -1 0
+op phi 8 3 7 -1 0
+ret 8
+end
+"""
+
+
+def test_structured_branches_compile():
+    rc, src = check(CLIPPER, want_source=True)
+    assert rc == 0, src
+    for needle in ("const float r5 = (r2 > r3) ? 1.f : 0.f;", "float r8;", "if (r5 != 0.f) {", "r8 = r3;", "} else {", "float r7;", "r7 = r4;", "r7 = r2;", "r8 = r7;"):
+        assert needle in src, needle
+
+
+@pytest.mark.parametrize("program,message", [
+    (CLIPPER.replace("op phi 7 4 2 -1 0\n", "op add 9 2 2 -1 0\nop phi 7 4 2 -1 0\n"), "a phi must directly follow"),
+    (CLIPPER.replace("op endif -1 -1 -1 -1 0\nop phi 8 3 7 -1 0\n", ""), "not closed"),
+    (CLIPPER.replace("op else -1 -1 -1 -1 0\nop cmp 6", "op const 9 -1 -1 -1 0\nop else -1 -1 -1 -1 0\nop cmp 6").replace("ret 8", "ret 9"), "undefined register"),   # a side's register is not visible after it
+    (CLIPPER.replace("op phi 8 3 7 -1 0", "op phi 8 6 7 -1 0"), "not visible at the end of the `if` side"),   # r6 belongs to the else side
+    (CLIPPER.replace("op cmp 5 2 3 -1 1", "op cmp 5 2 3 -1 9"), "unknown relation"),
+    ("klgg 1\nctl 0\nop else -1 -1 -1 -1 0\nop const 0 -1 -1 -1 0\nret 0\nend\n", "no open `if`"),
+])
+def test_malformed_branches_are_rejected(program, message):
+    rc, msg = check(program)
+    assert rc < 0 and message in msg, msg
+
+
+def test_facade_records_branches_once_per_outcome_and_merges_them():
+    """tests/patches/branches.k: an else-if chain with `!` / `&&`, a nested `if`, an oscillator advanced on one side only, a
+    member written on both sides.  process() is run once per branch outcome; the traces are merged into if / else / endif + phi."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    exe = os.path.join(ROOT, "tests", "cpp", "_bin", "facade_graph_own_branches")
+    scn = os.path.join(ROOT, "tests", "golden", "own_branches_solo.scn")
+    r = subprocess.run([exe, scn, "/dev/null"], env=dict(os.environ, KLANG_MI355_DUMP_GRAPH="1", HIP_VISIBLE_DEVICES="-1"), capture_output=True, text=True)
+    err = r.stderr
+    text = err[err.index("klgg 1"):err.index("end\n") + 4]
+    ops = [ln.split()[1] for ln in text.splitlines() if ln.startswith("op ")]
+    assert ops.count("if") == ops.count("endif") == 6 and ops.count("phi") == 6, ops   # `a && b` is two nested ifs
+    assert ops.count("osc") == 3 and ops.count("setparam") == 1                          # each oscillator appears once: the sides were merged, not duplicated
+    lines = text.splitlines()
+    osc_b = next(i for i, ln in enumerate(lines) if ln.startswith("op osc") and ln.split()[5] == "1")
+    first_if = next(i for i, ln in enumerate(lines) if ln.startswith("op if"))
+    first_else = next(i for i, ln in enumerate(lines) if ln.startswith("op else"))
+    assert first_if < osc_b < first_else + 20                                              # Sine b is read inside the first `if` side only
+    rc, msg = check(text)
+    assert rc == 0, msg
+
+
 def test_facade_records_our_dsl_patch():
     """tests/patches/sub2a.k compiled against include/klang/klang.h with NO binding: notes.add<T>() records process().
     Without a GPU the run then stops at klg_synth_create_graph (no CPU fallback) — after printing the program."""
