@@ -312,7 +312,23 @@ struct Pitch : param {
 	static inline thread_local Conversion Frequency;
 	const Pitch* operator->() { Frequency = klg::host::pitch_to_frequency(value); return this; }             // klang.h:1568-1571
 };
-struct Amplitude : param { using param::param; Amplitude(float a = 1.f) : param(a) {} };
+// dB <-> linear (klang.h:1609-1652): `GAIN[o]->Amplitude`.  power(10, x) of the reference is ::exp(x * ln 10) on the float product,
+// evaluated in double (the global ::exp of <cmath>) and rounded once
+inline float db_to_amplitude(float db) { return (float)std::exp((double)((db * 0.05f) * 2.3025850929940456840179914546843642076011014886287729760333279009f)); }
+struct dB : param {
+	using param::param;
+	dB(float gain = 0.f) : param(gain) {}
+	static inline thread_local Conversion Amplitude;
+	const dB* operator->() const { value_only("dB -> Amplitude"); Amplitude = db_to_amplitude(value); return this; }
+	void value_only(const char* what) const { concrete_only(what); }
+};
+struct Amplitude : param {
+	using param::param;
+	Amplitude(float a = 1.f) : param(a) {}
+	Amplitude(const klang::dB& db) : param(db_to_amplitude(db.value)) { db.value_only("dB -> Amplitude"); }
+	static inline thread_local Conversion dB;
+	const Amplitude* operator->() const { concrete_only("Amplitude -> dB"); dB = 20.f * log10f(value); return this; }
+};
 typedef Amplitude Velocity;
 
 struct SampleRate {
@@ -421,6 +437,7 @@ inline DST& operator>>(const SRC& src, DST& dst) {
 struct Oscillator : Generator {
 	Frequency frequency = 1000.f;
 	using Generator::set;
+	virtual void reset() {}                                   // klang.h:2859 (a user Oscillator's own phase: it has none here, its members do)
 };
 namespace Generators {
 namespace Basic {

@@ -39,6 +39,8 @@ FX = {
     # Toggle that selects the gain
     "fx_clipping": [(1.0, 11.0)],
     "fx_mute": [("choice", (0.0, 1.0))],
+    # Filtering/Bands.k: two BPFs re-designed every sample from grouped controls
+    "fx_bands": [(10.0, 1000.0), (0.1, 10.0), (10.0, 1000.0), (0.1, 10.0)],
 }
 
 

@@ -73,7 +73,7 @@ def test_shipped_k_files_recorded_as_graph(binary, scenario, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter", "ex_expression",
-                                  "ex_addsaw", "ex_am", "ex_fmmod", "ex_fm2", "ex_operators", "ex_nyquist", "ex_square"])
+                                  "ex_addsaw", "ex_am", "ex_fmmod", "ex_fm2", "ex_operators", "ex_nyquist", "ex_square", "ex_resynthesis"])
 def test_example_synths_without_a_handwritten_kernel(name, tmp_path):
     """examples/Subtractive/{Breakpoint,Ramp,Release,Filter,Expression}.k of the reference, compiled unchanged: there is no kernel for
     them in the library, only the recorded graph.  Goldens: oracle/gen_golden_examples.py (genuine reference header)."""
@@ -94,7 +94,7 @@ def test_own_patches_for_the_other_node_kinds(name, tmp_path):
     check(*run_facade(path, name, tmp_path), name)
 
 
-SOLO = ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter", "ex_expression", "ex_addsaw", "ex_am", "ex_fmmod", "ex_fm2", "ex_operators", "ex_nyquist", "ex_square",
+SOLO = ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter", "ex_expression", "ex_addsaw", "ex_am", "ex_fmmod", "ex_fm2", "ex_operators", "ex_nyquist", "ex_square", "ex_resynthesis",
         "own_basic_mix", "own_filters_f2", "own_modal_follow", "own_branches"]
 
 
