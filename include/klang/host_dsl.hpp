@@ -71,6 +71,16 @@ struct FSineH {
 	}
 };
 
+// Fast::Sine::process on the host (klang.h:5093-5132, 5165-5171) — only to render a cycle into a Wavetable (klang.h:3646-3651);
+// audio-rate processing is the device's
+inline float fastsinp_host(uint32_t p) {
+	float x = (u2f((p >> 9) | 0x3f800000u) - 1.f) * (2.f * PI_F);
+	if (x > 4.71238899230957031f) x -= 2.f * PI_F;                 // 3.f / 2.f * pi.f
+	else if (x > 1.57079637050628662f) x = PI_F - x;              // pi.f / 2.f
+	const float x2 = x * x;
+	return (((-0.00018542f * x2 + 0.0083143f) * x2 - 0.16666f) * x2 + 1.0f) * x;
+}
+
 // ---- Generic::Oscillator set() side (klang.h:2862-2870) ----
 struct BOscH {
 	float frequency = 1000.f, increment = 0.f, position = 0.f, offset = 0.f;

@@ -22,6 +22,7 @@
 //     instead of computing — and the program is compiled for gfx950 by klg_synth_create_graph().  Supported in a
 //     recorded process(): Fast::{Sine,Saw,Triangle,Square,Pulse} with their frequency set in on() or per sample
 //     (`osc(f * (1 + lfo * depth))`: vibrato / FM by set(f)), the Basic oscillators, Operator<Sine> chains (`op1 * I >> op2 >> out`),
+//     Wavetable / Sample (samples in HBM, klg_table_upload) and Table<float, N> reads with a recorded index,
 //     every Biquad type, OnePole, DCF, IIR<1>, Butterworth, Modal, Envelope::Follower (Biquad::LPF also set(f, Q) per sample), Envelope
 //     (<= 4 points, setLoop) and ADSR `++`, + - * / and unary minus on signals / params / controls / constants, `.out` of a
 //     member, signal and param members of the Note (read, and written for next-sample state), `>> out`, `out *= x`,
@@ -119,6 +120,15 @@ struct Recorder {
 		return o.dst;
 	}
 	int reg_of(const signal& s);
+	// Table<float, SIZE> objects read with a recorded index: slot k (1-based, in order of first use) is uploaded as table id k
+	// right after the bank is created (before any Wavetable member uploads its samples)
+	struct StaticTable { const void* addr; std::vector<float> data; };
+	std::vector<StaticTable> static_tables;
+	uint32_t table_slot(const void* addr, const float* data, int n) {
+		for (size_t k = 0; k < static_tables.size(); k++) if (static_tables[k].addr == addr) return (uint32_t)k + 1u;
+		static_tables.push_back({ addr, std::vector<float>(data, data + n) });
+		return (uint32_t)static_tables.size();
+	}
 	// literals: an op where they are first needed — except while process() is traced once per branch outcome (PathMerger), where
 	// they live in a pool of their own (registers CONST_BASE + k), so that the traces of different outcomes line up op for op
 	enum { CONST_BASE = 1 << 24 };
@@ -438,6 +448,7 @@ struct Oscillator : Generator {
 	Frequency frequency = 1000.f;
 	using Generator::set;
 	virtual void reset() {}                                   // klang.h:2859 (a user Oscillator's own phase: it has none here, its members do)
+	virtual float host_process() { device_only("rendering this oscillator into a Wavetable on the host (supported: Fast::Sine, Basic::Sine / Saw / Triangle / Square)"); }
 };
 namespace Generators {
 namespace Basic {
@@ -455,6 +466,20 @@ namespace Basic {
 		void set(param f, relative phase) override { set(f); set(phase); }
 		void set(relative phase) override { if (gpu::no_set_while_recording("Basic oscillator set(relative)")) return; h.offset = phase.value * (2 * pi); }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Basic oscillator"), 0, true); return; } device_only("Basic oscillator process()"); }
+		float host_process() override {                                      // klang.h:4899-4944 (one cycle into a Wavetable)
+			using namespace klg::graph;
+			const float two_pi = 2.f * pi.f;
+			float y;
+			switch (kind) {
+			case N_BSINE: y = (float)std::sin((double)(h.position + h.offset)); break;
+			case N_BSAW: y = h.position * pi.inv - 1.f; break;
+			case N_BTRI: y = std::fabs(2.f * h.position * pi.inv - 2.f) - 1.f; break;
+			case N_BSQUARE: y = h.position > pi.f ? 1.f : -1.f; break;
+			default: device_only("rendering a Basic::Pulse into a Wavetable on the host");
+			}
+			if (!(h.increment >= two_pi)) { h.position += h.increment; if (h.position > two_pi) h.position -= two_pi; }
+			return y;
+		}
 		void pack(uint32_t* w) const override { using namespace klg::graph; w[BOSC_INC] = gpu::fbits(h.increment); w[BOSC_POS] = gpu::fbits(h.position); w[BOSC_OFFSET] = gpu::fbits(h.offset); w[BOSC_DUTY] = gpu::fbits(duty_); w[BOSC_FREQ] = gpu::fbits(h.frequency); }
 		void unpack(const uint32_t* w) override { using namespace klg::graph; std::memcpy(&h.increment, &w[BOSC_INC], 4); std::memcpy(&h.position, &w[BOSC_POS], 4); }
 	};
@@ -483,6 +508,7 @@ namespace Fast {
 		void set(param f, relative phase) override { set(f); set(phase); }
 		void set(relative) override { device_only("Fast::Sine::set(relative) [phase modulation]"); }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast::Sine"), 0, true); return; } device_only("Fast::Sine::process()"); }
+		float host_process() override { const float y = klg::host::fastsinp_host(h.pos); h.pos += (uint32_t)h.inc; return y; }   // klang.h:5165-5171
 		void pack(uint32_t* w) const override { w[klg::graph::FSINE_INC] = (uint32_t)h.inc; w[klg::graph::FSINE_POS] = h.pos; w[klg::graph::FSINE_FREQ] = gpu::fbits(h.frequency); }
 		void unpack(const uint32_t* w) override { h.inc = (int32_t)w[klg::graph::FSINE_INC]; h.pos = w[klg::graph::FSINE_POS]; std::memcpy(&h.frequency, &w[klg::graph::FSINE_FREQ], 4); }
 	};
@@ -714,6 +740,58 @@ template<typename TYPE> struct Result {
 	TYPE& operator++(int) { i++; return *++y; }
 };
 #define FUNCTION(type) (void(*)(type, klang::Result<type>&))[](type x, klang::Result<type>& y)
+// ---- Wavetable / Sample (klang.h:3626-3720): the samples live in HBM (klg_table_upload); a note's record names them by id ----
+namespace gpu { inline thread_local klg_synth* upload_target = nullptr; }   // the bank a voice record is being packed for (SynthCore sets it)
+class Wavetable : public Oscillator, public gpu::Packable {
+protected:
+	std::vector<signal> samples; int size;
+	float increment = 0.f, position = 0.f, offset = 0.f;
+	mutable int table_id = -1; mutable bool dirty = true;
+	void announce() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Wavetable), klg::graph::N_WAVETABLE, this); }
+public:
+	using Oscillator::set;
+	Wavetable(int size_ = 2048) : samples((size_t)size_), size(size_) { announce(); }
+	template<typename TYPE, std::enable_if_t<std::is_base_of_v<Oscillator, TYPE>, int> = 0>
+	Wavetable(TYPE oscillator, int size_ = 2048) : samples((size_t)size_), size(size_) { announce(); operator=(oscillator); }
+	signal& operator[](int index) { dirty = true; return samples[(size_t)index]; }
+	template<typename TYPE, std::enable_if_t<std::is_base_of_v<Oscillator, TYPE>, int> = 0>
+	Wavetable& operator=(TYPE& oscillator) {                                  // one cycle of the oscillator klang.h:3646-3651
+		oscillator.set(param(fs.f / (float)size));
+		for (int s = 0; s < size; s++) samples[(size_t)s] = oscillator.host_process();
+		dirty = true; return *this;
+	}
+	void set(param f) override {                                             // klang.h:3655-3658
+		if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Wavetable"), 0, false); frequency = f; return; }
+		frequency = f; increment = f * ((float)size / fs.f);
+	}
+	void set(param f, param phase) override { if (gpu::no_set_while_recording("Wavetable::set(f, phase)")) return; position = phase * float(size); set(f); }
+	void set(relative phase) override { if (gpu::no_set_while_recording("Wavetable::set(relative)")) return; offset = phase.value * float(size); }
+	void set(param f, relative phase) override { set(f); set(phase); }
+	void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Wavetable"), 0, true); return; } device_only("Wavetable::process()"); }
+	void pack(uint32_t* w) const override {
+		using namespace klg::graph;
+		if (dirty || table_id < 0) {
+			if (!gpu::upload_target) { std::fprintf(stderr, "klang-mi355: a Wavetable can only be packed for a GPU bank\n"); std::abort(); }
+			std::vector<float> f((size_t)size); for (int s = 0; s < size; s++) f[(size_t)s] = samples[(size_t)s].value;
+			table_id = klg_table_upload(gpu::upload_target, f.data(), size, 1);
+			if (table_id < 0) { std::fprintf(stderr, "klang-mi355: klg_table_upload: %s\n", klg_last_error()); std::abort(); }
+			dirty = false;
+		}
+		w[WT_INC] = gpu::fbits(increment); w[WT_POS] = gpu::fbits(position); w[WT_OFFSET] = gpu::fbits(offset); w[WT_FREQ] = gpu::fbits(frequency.value); w[WT_TABLE] = (uint32_t)table_id;
+	}
+	void unpack(const uint32_t* w) override { std::memcpy(&increment, &w[klg::graph::WT_INC], 4); std::memcpy(&position, &w[klg::graph::WT_POS], 4); }
+};
+// Sample (klang.h:3683-3720): plays an attached buffer at one sample per sample, whatever the frequency
+class Sample : public Wavetable {
+public:
+	Sample() : Wavetable(2) {}
+	Sample& operator=(const std::vector<float>& data) { samples.assign(data.begin(), data.end()); size = (int)data.size(); dirty = true; return *this; }
+	void set(param f) override { if (gpu::no_set_while_recording("Sample::set(f)")) return; frequency = f; increment = 1.f; }
+	void set(param f, param phase) override { if (gpu::no_set_while_recording("Sample::set(f, phase)")) return; position = phase * 44100.f; set(f); }
+	void set(relative phase) override { if (gpu::no_set_while_recording("Sample::set(relative)")) return; offset = phase.value * 44100.f; }
+	void set(param f, relative phase) override { set(f); set(phase); }
+};
+
 template<typename TYPE, int SIZE> struct Table {
 	TYPE items[SIZE] = {}; unsigned count = 0;
 	void add(const TYPE& v) { if (count < (unsigned)SIZE) items[count++] = v; }
@@ -721,6 +799,15 @@ template<typename TYPE, int SIZE> struct Table {
 	Table(void (*function)(TYPE x, Result<TYPE>& y)) { count = SIZE; Result<TYPE> y(items, 0); for (int x = 0; x < SIZE; x++) { function((TYPE)x, y); y.sum += items[x]; y++; } }
 	Table(std::initializer_list<TYPE> values) { for (TYPE v : values) add(v); }
 	TYPE operator[](int index) const { return items[index]; }
+	// a recorded index: the clamped linear read runs on the device (OP_TABREAD), the samples go to HBM with the bank
+	template<class S, std::enable_if_t<std::is_base_of_v<signal, S> && std::is_same_v<TYPE, float>, int> = 0>
+	signal operator[](const S& index) const {
+		gpu::Recorder* r = gpu::recording();
+		if (!r || index.reg < 0) return signal((*this)[(float)index.value]);
+		signal y((*this)[(float)index.value]);
+		y.reg = r->emit(klg::graph::OP_TABREAD, index.reg, -1, -1, r->table_slot(this, items, SIZE), true);
+		return y;
+	}
 	TYPE operator[](float index) const {
 		if (index < 0) return items[0];
 		if (index >= (SIZE - 1)) return items[SIZE - 1];
@@ -752,6 +839,7 @@ struct GraphLayout {
 	std::vector<Member> members;
 	std::string program;
 	int words = 0;
+	std::vector<std::vector<float>> tables;                        // tabread slot k + 1 -> samples (uploaded by the Synth when the bank is created)
 	void pack(const void* note, uint32_t* w) const {
 		for (const Member& m : members) {
 			const char* obj = (const char*)note + m.offset;
@@ -913,7 +1001,7 @@ inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	// ---- dead code: pure ops nobody reads, params nobody reads (and their write-backs), primitives nobody uses ----
 	std::vector<Op>& ops = R.prog.ops;
 	std::vector<char> keep(ops.size(), 1), used;
-	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG || c == OP_CMP || c == OP_PHI; };
+	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG || c == OP_CMP || c == OP_PHI || c == OP_TABREAD; };
 	for (bool changed = true; changed;) {
 		changed = false;
 		used.assign(MAX_OPS + 1, 0); used[(size_t)R.prog.ret] = 1; if (R.prog.ret_r >= 0) used[(size_t)R.prog.ret_r] = 1;
@@ -945,6 +1033,7 @@ inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	}
 	L.program = R.prog.text();
 	L.words = R.prog.words();
+	for (const auto& t : R.static_tables) L.tables.push_back(t.data);
 }
 }
 
@@ -1097,6 +1186,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		if (const gpu::GraphLayout* g = notes.items[0].graph) {              // recorded process(): compiled for gfx950 now (hipRTC)
 			gpu = klg_synth_create_graph(g->program.c_str(), 1, (int)notes.count, fs.f, 1024);
 			if (!gpu) fail("klg_synth_create_graph");
+			for (size_t k = 0; k < g->tables.size(); k++) if (klg_table_upload(gpu, g->tables[k].data(), (int)g->tables[k].size(), 0) != (int)k + 1) fail("klg_table_upload (Table read by process())");
 		}
 		else {
 			if (patch < 0) { std::fprintf(stderr, "klang-mi355: no GPU kernel is bound to this Note type\n"); std::abort(); }
@@ -1115,6 +1205,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		if (klg_voice_download(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_download");
 		if ((words[0] & 3u) != (uint32_t)klg::ST_OFF || s.note->stage != NOTEBASE::Off) { if (s.graph) s.graph->unpack(s.note, words.data()); else s.b.unpack(s.note, words.data()); }
 		event_code(s.note);
+		gpu::upload_target = gpu;                                      // a Wavetable member uploads its samples while packing
 		if (s.graph) s.graph->pack(s.note, words.data()); else s.b.pack(s.note, words.data());
 		words[0] = (words[0] & ~3u) | (uint32_t)s.note->stage;
 		if (klg_voice_upload(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_upload");

@@ -131,6 +131,13 @@ int klg_voices_upload(klg_synth* s, int n, const int* voices, const void* states
  * want_source != 0 a successful check returns the generated HIP source instead).
  * ------------------------------------------------------------------------------------------------ */
 klg_synth* klg_synth_create_graph(const char* program, int synths, int notes_per_synth, float sample_rate, int max_block);
+/* Sample tables of a graph bank.  replaces: the `buffer` a Wavetable / Sample owns (klang.h:3626-3720:
+ * `Wavetable(osc, 2048)` renders one cycle into it, `wavetable[i] = x` writes it, process() reads it with linear
+ * interpolation) and a Table<float, SIZE> read with a fractional index (3365-3377).  Copies n floats to HBM and returns the
+ * table's id (>= 1; < 0 = error): the value of a wavetable node's `table` record word, or the imm of a `tabread` op.  With
+ * dedup != 0 a table with exactly the same samples as an earlier one returns that one's id (a bank of notes built from the
+ * same oscillator shares ONE table).  Tables live as long as the bank. */
+int klg_table_upload(klg_synth* s, const float* samples, int n, int dedup);
 int klg_graph_check(const char* program, int want_source, char* out, size_t out_cap);
 /* The same for a recorded Effect::process() body (`kind effect 1|2` programs; replaces constructing `instances` copies of a
  * user klang::Effect / Stereo::Effect, klang.h:4190-4216, 4703-4717).  `initial_record`: the record words of one freshly

@@ -63,6 +63,8 @@ enum NodeKind {
 	N_DELAY = 21,   /* Delay<SIZE> (effects only)       3381-3512           words: none — a ring of SIZE floats per instance in HBM, position-major
 	                                                                        over the 64 instances of a wave; the write cursor is the sample counter */
 	N_SMOOTH = 22,  /* controls[i].smooth() in an effect   1715             words: smoothed */
+	N_WAVETABLE = 23,  /* Wavetable / Sample (synth notes)  3626-3720        words: increment position offset frequency table — `table` is the id
+	                                                                        klg_table_upload() returned for this note's samples (HBM; identical tables share an id) */
 	N_KINDS
 };
 enum { FSINE_INC = 0, FSINE_POS, FSINE_FREQ, FSINE_WORDS };
@@ -78,9 +80,10 @@ enum { BW1_B0 = 0, BW1_A1, BW1_Z, BW1_OUT, BW1_WORDS };
 enum { MODAL_A1 = 0, MODAL_A2, MODAL_Y1, MODAL_Y2, MODAL_GAIN, MODAL_WORDS };
 enum { FOLLOW_A = 0, FOLLOW_R, FOLLOW_OUT, FOLLOW_WORDS };
 enum { OPER_INC = 0, OPER_POS, OPER_FREQ, OPER_AMP, OPER_ENV, OPER_WORDS = OPER_ENV + ENV_WORDS };
+enum { WT_INC = 0, WT_POS, WT_OFFSET, WT_FREQ, WT_TABLE, WT_WORDS };
 enum { MAX_WORDS = 128, MAX_NODES = 64, MAX_OPS = 1024 };
 
-inline bool is_oscillator(int k) { return k == N_FSINE || k == N_SAW || k == N_PULSE || (k >= N_BSINE && k <= N_BPULSE); }
+inline bool is_oscillator(int k) { return k == N_FSINE || k == N_SAW || k == N_PULSE || (k >= N_BSINE && k <= N_BPULSE) || k == N_WAVETABLE; }
 inline bool is_modifier(int k) { return k == N_LPF || (k >= N_OPLPF && k <= N_FOLLOWRMS); }
 inline int node_words(int kind) {
 	switch (kind) {
@@ -100,12 +103,13 @@ inline int node_words(int kind) {
 	case N_OPERATOR: return OPER_WORDS;
 	case N_DELAY: return 0;
 	case N_SMOOTH: return 1;
+	case N_WAVETABLE: return WT_WORDS;
 	}
 	return 0;
 }
 inline const char* node_name(int kind) {
 	static const char* names[N_KINDS] = { "fsine", "saw", "pulse", "lpf", "env", "adsr", "param", "bsine", "bsaw", "btri", "bsquare", "bpulse",
-	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator", "delay", "smooth" };
+	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator", "delay", "smooth", "wavetable" };
 	return (kind >= 0 && kind < N_KINDS) ? names[kind] : "?";
 }
 
@@ -135,10 +139,11 @@ enum OpCode {
 	OP_ELSE,        /* } else {                                                                               */
 	OP_ENDIF,       /* }                                                                                      */
 	OP_PHI,         /* dst = condition of the `if` just closed ? a : b       only directly after `endif` (or another phi of it) */
+	OP_TABREAD,     /* dst = table imm [ a ]               Table<float, SIZE>::operator[](float): clamped, linear   klang.h:3365-3377; imm = table id (klg_table_upload) */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "tabread" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -260,6 +265,7 @@ struct Program {
 			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); break;
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			case OP_CMP: if (o.imm > 5u) return bad("unknown relation"); need_a = need_b = true; break;
+			case OP_TABREAD: if (channels) return bad("tables are only available to synth notes"); if (o.imm == 0u) return bad("table id 0 is reserved"); need_a = true; break;
 			case OP_IF: if ((int)i < prepare_ops) return bad("prepare() may not branch"); need_a = true; has_dst = false; open.push_back({ {}, false, {} }); break;
 			case OP_ELSE:
 				if (open.empty() || open.back().in_else) return bad("no open `if`");
@@ -300,6 +306,7 @@ struct Program {
 		if (!def(ret)) return "graph program: 'ret' names an undefined register";
 		if (channels == 2 && !def(ret_r)) return "graph program: 'ret2' names an undefined register";
 		if (channels == 0) for (int k : nodes) if (k == N_DELAY || k == N_SMOOTH) return "graph program: delay / smooth nodes need an effect program (kind effect)";
+		if (channels != 0) for (int k : nodes) if (k == N_WAVETABLE) return "graph program: wavetable nodes are only available to synth notes";
 		return "";
 	}
 };

@@ -125,6 +125,14 @@ class SynthBank:
         words = np.ascontiguousarray(words, dtype=np.uint32).reshape(len(voices), self.state_bytes // 4)
         check(self._L.klg_voices_upload(self._h, len(voices), voices.ctypes.data_as(C.POINTER(C.c_int)), words.ctypes.data_as(C.c_void_p)), "klg_voices_upload")
 
+    def table_upload(self, samples, dedup=True):
+        """Copies a sample table to HBM (graph banks); returns its id: a wavetable node's `table` word / a tabread op's imm."""
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        tid = self._L.klg_table_upload(self._h, samples.ctypes.data_as(C.POINTER(C.c_float)), samples.size, 1 if dedup else 0)
+        if tid < 0:
+            check(tid, "klg_table_upload")
+        return tid
+
     def timing_begin(self):
         check(self._L.klg_timing_begin(self._h), "klg_timing_begin")
 

@@ -5,6 +5,8 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../libklang_mi355.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared \
+# -Bsymbolic: the library binds its own C++ inline functions (the graph-program parser of include/klang_mi355_graph.h is
+# compiled into host programs too) instead of letting a host executable's copies interpose on them.
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wl,-Bsymbolic \
     -Wall -Wno-unused-function "$@" "$HERE/klg_api.hip" -o "$OUT"
 echo "built $OUT"

@@ -111,6 +111,10 @@ struct klg_synth {
 	hipModule_t module = nullptr;
 	hipFunction_t graph_fn[2] = { nullptr, nullptr };
 	hipError_t launch_error = hipSuccess;
+	// sample tables (klg_table_upload): id -> HBM copy; d_tables mirrors `tables` for the kernels
+	struct Table { float* d; std::vector<float> h; uint64_t hash; };
+	std::vector<Table> tables;
+	TableDesc* d_tables = nullptr; size_t d_tables_cap = 0; bool tables_dirty = false;
 	// host mirrors
 	std::vector<host::ControlH> controls;        // [S][nctl]
 	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
@@ -137,6 +141,8 @@ static void synth_free(klg_synth* s) {
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
 	void* dev[] = { s->d_state, s->d_controls, s->d_partials, s->d_mix, s->d_per_voice, s->d_scratch_rec, s->d_stage };
 	for (void* p : dev) if (p) (void)hipFree(p);
+	for (auto& t : s->tables) if (t.d) (void)hipFree(t.d);
+	if (s->d_tables) (void)hipFree(s->d_tables);
 	void* pinned[] = { s->h_stage, s->h_mix, s->h_flags, s->h_per_voice };
 	for (void* p : pinned) if (p) (void)hipHostFree(p);
 	if (s->stage_done) (void)hipEventDestroy(s->stage_done);
@@ -512,12 +518,15 @@ extern "C" int klg_get_control(klg_synth* s, int synth, int index, float* value)
 // ------------------------------------------------------------------------------------------------
 // block processing
 // ------------------------------------------------------------------------------------------------
+static int tables_sync(klg_synth* s);
 static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipStream_t st) {
 	if (int rc = flush_events(s, st)) return rc;
 	if (int rc = upload_controls(s, st)) return rc;
 	RenderArgs a;
 	a.state = s->d_state; a.stride = s->stride; a.voices = s->V; a.notes_per_synth = s->P; a.n = n;
 	a.controls = s->d_controls; a.fs = s->dfs; a.partials = s->d_partials; a.per_voice = per_voice ? s->d_per_voice : nullptr;
+	if (int rc = tables_sync(s)) return rc;
+	a.tables = s->d_tables;
 	if (s->timing) {
 		if ((int)s->tev.size() < 2 * (s->launches + 1)) { hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); s->tev.push_back(e0); s->tev.push_back(e1); }
 		HIP_TRY(hipEventRecord(s->tev[2 * s->launches], st));
@@ -616,6 +625,46 @@ extern "C" int klg_voices_upload(klg_synth* s, int n, const int* voices, const v
 		push_note_on(s, voices[i], w + (size_t)i * s->W);
 		s->voices[voices[i]].stage = (uint8_t)(w[(size_t)i * s->W] & 3u);
 	}
+	return 0;
+}
+
+// ---- sample tables (include/klang_mi355.h: klg_table_upload) ----
+static int table_add(klg_synth* s, const float* samples, int n) {
+	klg_synth::Table t; t.d = nullptr; t.h.assign(samples, samples + n);
+	uint64_t h = 1469598103934665603ull;
+	for (int i = 0; i < n; i++) { uint32_t u; memcpy(&u, &samples[i], 4); h = (h ^ u) * 1099511628211ull; }
+	t.hash = h;
+	if (hipMalloc((void**)&t.d, (size_t)n * sizeof(float)) != hipSuccess) return fail(KLG_ERR_HIP, "klg_table_upload: hipMalloc of %d floats failed", n);
+	if (hipMemcpy(t.d, samples, (size_t)n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t.d); return fail(KLG_ERR_HIP, "klg_table_upload: copy failed"); }
+	s->tables.push_back(std::move(t));
+	s->tables_dirty = true;
+	return (int)s->tables.size() - 1;
+}
+extern "C" int klg_table_upload(klg_synth* s, const float* samples, int n, int dedup) {
+	if (!s || !samples || n < 2 || n > (1 << 26)) return fail(KLG_ERR_INVALID, "klg_table_upload: bad arguments (2 .. 2^26 samples)");
+	if (s->patch != KLG_PATCH_GRAPH) return fail(KLG_ERR_INVALID, "klg_table_upload: only graph banks (klg_synth_create_graph) read tables");
+	RandGuard rg;
+	if (s->tables.empty()) { const float zero[2] = { 0.f, 0.f }; const int id0 = table_add(s, zero, 2); if (id0 < 0) return id0; }   // id 0: what an all-zero record reads
+	if (dedup) {
+		uint64_t h = 1469598103934665603ull;
+		for (int i = 0; i < n; i++) { uint32_t u; memcpy(&u, &samples[i], 4); h = (h ^ u) * 1099511628211ull; }
+		for (size_t k = 1; k < s->tables.size(); k++) if (s->tables[k].hash == h && (int)s->tables[k].h.size() == n && !memcmp(s->tables[k].h.data(), samples, (size_t)n * sizeof(float))) return (int)k;
+	}
+	return table_add(s, samples, n);
+}
+// the descriptor array the kernels index; re-uploaded (on the bank's stream order: synchronously, before the next launch) when a table was added
+static int tables_sync(klg_synth* s) {
+	if (!s->tables_dirty) return 0;
+	HIP_TRY(hipDeviceSynchronize());                       // rare (a new table): nothing in flight may still read the old array
+	if (s->tables.size() > s->d_tables_cap) {
+		if (s->d_tables) (void)hipFree(s->d_tables);
+		s->d_tables_cap = s->tables.size() * 2 + 8;
+		HIP_TRY(hipMalloc((void**)&s->d_tables, s->d_tables_cap * sizeof(TableDesc)));
+	}
+	std::vector<TableDesc> h(s->tables.size());
+	for (size_t k = 0; k < h.size(); k++) { h[k].p = s->tables[k].d; h[k].size = (int)s->tables[k].h.size(); h[k].pad_ = 0; }
+	HIP_TRY(hipMemcpy(s->d_tables, h.data(), h.size() * sizeof(TableDesc), hipMemcpyHostToDevice));
+	s->tables_dirty = false;
 	return 0;
 }
 

@@ -202,6 +202,37 @@ __device__ __forceinline__ float osm_pulse(Osm& o) {                        // p
 	return (o_up == n_up) ? y_same : (valid_edge ? y_edge : 0.f);
 }
 
+// ---- Wavetable / Sample klang.h:3626-3720 and Table<float, SIZE>::operator[](float) 3365-3377 ----
+// Tables live in HBM (klg_table_upload); a lane names its table by id, identical tables share one (so a bank of notes built
+// from the same oscillator reads ONE 8 KB table, which stays in the CU's L1 / L2).  Id 0 is a two-sample table of zeros:
+// what the dead lanes of a live wave (all-zero record) read.
+struct TableDesc { const float* p; int size; int pad_; };
+struct WTab { float inc, pos, off; uint32_t table; };
+// Oscillator::set(f) of a Wavetable klang.h:3655-3658: increment = frequency * (size / fs)
+__device__ __forceinline__ void wavetable_set_f(WTab& w, float& cached, float f, float fs, const TableDesc* tabs) { cached = f; w.inc = f * ((float)tabs[w.table].size / fs); }
+// Wavetable::process 3676-3679: position += { increment, size } (Phase::operator+=(increment) 1527-1534), then the linear read
+// buffer::operator[](float) 2070-2078.  (An index past the last sample — position == size exactly, or a phase offset pushing
+// it there — reads beyond the array in the reference; here it wraps to the start.)
+__device__ __forceinline__ float wavetable_process(WTab& w, const TableDesc* tabs) {
+	const TableDesc t = tabs[w.table];
+	const float size = (float)t.size;
+	if (!(w.inc >= size)) { w.pos += w.inc; if (w.pos > size) w.pos -= size; }
+	const float o = w.pos + w.off;
+	const float fl = floorf(o), frac = o - fl;
+	int i = (int)o;
+	i = (i >= t.size) ? i - t.size : i; i = (i < 0 || i >= t.size) ? 0 : i;
+	const int j = (i == t.size - 1) ? 0 : i + 1;
+	return t.p[i] * (1.f - frac) + t.p[j] * frac;
+}
+__device__ __forceinline__ float table_read(const TableDesc* tabs, uint32_t id, float index) {
+	const TableDesc t = tabs[id];
+	if (index < 0.f) return t.p[0];
+	if (index >= (float)(t.size - 1)) return t.p[t.size - 1];
+	const float x = floorf(index); const int i = (int)x;
+	const float dx = index - x, dy = t.p[i + 1] - t.p[i];
+	return t.p[i] + dx * dy;
+}
+
 // ---- Filters::Biquad klang.h:5550-5773 ----
 struct Biquad { float b0, b1, b2, a1, a2, z0, z1; };
 __device__ __forceinline__ float biquad_process(Biquad& q, float in) {      // TDF-II 5605-5612

@@ -147,6 +147,13 @@ inline std::string generate_source(const Program& g) {
 				+ W(e0 + ENV_OUT, "f2u(" + n + "e.r_out)") + W(e0 + ENV_TARGET, "f2u(" + n + "e.r_target)") + W(e0 + ENV_RATE, "f2u(" + n + "e.r_rate)") + W(e0 + ENV_TIME, "f2u(" + n + "e.time)") + W(e0 + ENV_BITS, "env_pack(" + n + "e)");
 			mark(w0 + OPER_POS, 1); mark(w0 + OPER_AMP, 1); mark(w0 + e0 + ENV_OUT, 5);
 		} break;
+		case N_WAVETABLE:
+			live += fmt(" WTab n%zu; float n%zuf;", i, i);
+			begin += "\t\t" + n + ".inc = " + F(WT_INC) + "; " + n + ".pos = " + F(WT_POS) + "; " + n + ".off = " + F(WT_OFFSET) + "; " + n + "f = " + F(WT_FREQ) + "; " + n + ".table = " + R(WT_TABLE) + ";\n";
+			end += W(WT_POS, "f2u(" + n + ".pos)");
+			mark(w0 + WT_POS, 1);
+			if (retuned[i]) { end += W(WT_INC, "f2u(" + n + ".inc)") + W(WT_FREQ, "f2u(" + n + "f)"); mark(w0 + WT_INC, 1); mark(w0 + WT_FREQ, 1); }
+			break;
 		case N_DELAY:
 			live += fmt(" int n%zupos;", i);
 			begin += "\t\t" + n + fmt("pos = (int)((c.samples * %dull) %% %dull);\n", inputs[i], g.arg((int)i));     // Delay::position: one step per input()
@@ -198,11 +205,13 @@ inline std::string generate_source(const Program& g) {
 			case N_BTRI: e = "basic_triangle(" + n + ")"; break;
 			case N_BSQUARE: e = "basic_square(" + n + ")"; break;
 			case N_BPULSE: e = "basic_pulse(" + n + ", " + n + "d)"; break;
+			case N_WAVETABLE: e = "wavetable_process(" + n + ", c.tables)"; break;
 			}
 			body += d + e + ";\n";
 		} break;
 		case OP_OSCSET:
-			if (k >= N_BSINE && k <= N_BPULSE) body += "\t\t" + n + "f = " + a + "; " + n + ".increment = " + a + " * 2.f * KLG_PI_F / c.fs.f;\n";   // Oscillator::set(f) klang.h:2862-2865
+			if (k == N_WAVETABLE) body += "\t\twavetable_set_f(" + n + ", " + n + "f, " + a + ", c.fs.f, c.tables);\n";
+			else if (k >= N_BSINE && k <= N_BPULSE) body += "\t\t" + n + "f = " + a + "; " + n + ".increment = " + a + " * 2.f * KLG_PI_F / c.fs.f;\n";   // Oscillator::set(f) klang.h:2862-2865
 			else body += "\t\t" + std::string(k == N_FSINE ? "fsine_set_f(" : "osm_set_f(") + n + ", " + n + "f, " + a + ", c.fs.f);\n";
 			break;
 		case OP_LPF: {
@@ -236,6 +245,7 @@ inline std::string generate_source(const Program& g) {
 			for (const Op* ph : phis_of(if_of[oi])) body += fmt("\t\tr%d = r%d;\n", ph->dst, ph->b);
 			body += "\t\t}\n";
 			break;
+		case OP_TABREAD: body += d + fmt("table_read(c.tables, %uu, ", o.imm) + a + ");\n"; break;
 		case OP_PHI: break;                                         // assigned at the end of both sides (above)
 		case OP_STOPIF: body += "\t\tL.stage = (" + n + (k == N_ADSR ? ".e" : "") + ".stage == ENV_OFF) ? (int)ST_OFF : L.stage;\n"; break;
 		case OP_STOP: body += "\t\tL.stage = (int)ST_OFF;\n"; break;

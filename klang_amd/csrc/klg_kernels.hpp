@@ -31,6 +31,7 @@ struct RenderArgs {
 	SampleRate fs;
 	float* partials;          // [gridDim.x][n]
 	float* per_voice;         // [voices][n] or null
+	const TableDesc* tables;  // [tables] or null (klg_table_upload)
 };
 
 // record <-> word planes.  Words are moved with static indices only (fully unrolled) and converted with
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		typename P::Live L;
 		BlockCtx ctx;
 		ctx.fs = a.fs;
+		ctx.tables = a.tables;
 		ctx.ctl = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
 		// Dead lanes of a live wave run the same instruction stream on an all-zero record (no per-sample exec
 		// masking); their output is forced to 0 at the tile write and their record is never stored.

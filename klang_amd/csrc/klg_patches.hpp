@@ -22,6 +22,7 @@ namespace klg {
 struct BlockCtx {
 	SampleRate fs;
 	const float* ctl;        // this voice's synth instance controls [KLG_MAX_CTL]
+	const TableDesc* tables; // klg_table_upload()ed sample tables (graph patches with Wavetable / Table reads), else null
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -63,6 +63,80 @@ def test_graph_sub2a_equals_handwritten_kernel():
     hand.close(); gen.close()
 
 
+WAVETABLE_PROGRAM = """klgg 1
+ctl 0
+node 0 wavetable
+node 1 param
+op osc 0 -1 -1 0 0           # Wavetable::process
+op param 1 -1 -1 1 0
+op mul 2 0 1 -1 0             # wavetable * scale (a param member) ...
+op tabread 3 2 -1 -1 2        # ... as a fractional index into table 2 (Table<float, SIZE>::operator[](float))
+op add 4 0 3 -1 0
+ret 4
+end
+"""
+
+
+def test_graph_wavetable_and_table_read_match_numpy_model():
+    """klg_table_upload + a wavetable node + a tabread op against the reference's arithmetic written out in numpy fp32:
+    Phase += {increment, size}; buffer[float] = s[i] * (1 - frac) + s[j] * frac (klang.h:2070-2078, 3676-3679) and the clamped
+    Table read s[i] + dx * (s[i + 1] - s[i]) (3365-3377).  Voices differ in table, increment, start position and scale."""
+    import klang_amd
+    f32 = np.float32
+    V, N, B = 70, 64, 5                                   # two waves, the second partly filled
+    bank = klang_amd.SynthBank(WAVETABLE_PROGRAM, synths=1, notes=V, max_block=N)
+    assert bank.state_bytes == (1 + 5 + 1) * 4
+    rng = np.random.default_rng(11)
+    sine = np.sin(2 * np.pi * np.arange(2048) / 2048).astype(f32)
+    shaper = np.tanh(np.linspace(-3, 3, 33)).astype(f32)
+    odd = rng.uniform(-1, 1, 100).astype(f32)
+    t_sine = bank.table_upload(sine)
+    t_shaper = bank.table_upload(shaper, dedup=False)
+    t_odd = bank.table_upload(odd)
+    assert (t_sine, t_shaper, t_odd) == (1, 2, 3)
+    assert bank.table_upload(sine.copy()) == 1 and bank.table_upload(sine.copy(), dedup=False) == 4   # same samples share an id unless asked not to
+    tables = {1: sine, 3: odd}
+    words = np.zeros((V, 7), np.uint32)
+    state = []
+    for v in range(V):
+        tid = 1 if v % 3 else 3
+        size = len(tables[tid])
+        inc = f32(rng.uniform(0.3, 0.49 * size)) if v else f32(2.0 * size)   # voice 0: increment >= size never advances (klang.h:1528)
+        pos = f32(rng.uniform(0, size - 1))
+        scale = f32(rng.uniform(0, 48))
+        words[v] = [1, inc.view(np.uint32), pos.view(np.uint32), 0, 0, tid, scale.view(np.uint32)]   # flags = Sustain
+        state.append([inc, pos, tid, scale])
+    bank.voices_upload(np.arange(V), words)
+    for block in range(B):
+        pv, _ = bank.process_voices(N)
+        want = np.zeros((V, N), f32)
+        for v, st in enumerate(state):
+            inc, pos, tid, scale = st
+            tab = tables[tid]; size = f32(len(tab))
+            for i in range(N):
+                if not inc >= size:
+                    pos = f32(pos + inc)
+                    if pos > size:
+                        pos = f32(pos - size)
+                fl = f32(np.floor(pos)); frac = f32(pos - fl)
+                a = int(pos); a = a - len(tab) if a >= len(tab) else a
+                b = 0 if a == len(tab) - 1 else a + 1
+                y = f32(f32(tab[a] * f32(f32(1) - frac)) + f32(tab[b] * frac))
+                idx = f32(y * scale)
+                if idx < 0:
+                    sh = shaper[0]
+                elif idx >= len(shaper) - 1:
+                    sh = shaper[-1]
+                else:
+                    x = f32(np.floor(idx)); k = int(x)
+                    sh = f32(shaper[k] + f32(f32(idx - x) * f32(shaper[k + 1] - shaper[k])))
+                want[v, i] = f32(y + sh)
+            st[1] = pos
+        assert np.array_equal(pv.view(np.uint32), want.view(np.uint32)), f"block {block}: max err {np.abs(pv - want).max()}"
+    assert np.abs(pv).max() > 0.5
+    bank.close()
+
+
 def test_graph_program_errors_are_reported():
     import klang_amd
     with pytest.raises(klang_amd.KlangError, match="operand a is not defined"):
