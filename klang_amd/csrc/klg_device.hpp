@@ -207,22 +207,29 @@ __device__ __forceinline__ float osm_pulse(Osm& o) {                        // p
 // from the same oscillator reads ONE 8 KB table, which stays in the CU's L1 / L2).  Id 0 is a two-sample table of zeros:
 // what the dead lanes of a live wave (all-zero record) read.
 struct TableDesc { const float* p; int size; int pad_; };
-struct WTab { float inc, pos, off; uint32_t table; };
+struct WTab { float inc, pos, off; const float* p; int size; };      // p / size: the lane's table, looked up once per block
+__device__ __forceinline__ void wavetable_load(WTab& w, const TableDesc* tabs, uint32_t id) { const TableDesc t = tabs[id]; w.p = t.p; w.size = t.size; }
 // Oscillator::set(f) of a Wavetable klang.h:3655-3658: increment = frequency * (size / fs)
-__device__ __forceinline__ void wavetable_set_f(WTab& w, float& cached, float f, float fs, const TableDesc* tabs) { cached = f; w.inc = f * ((float)tabs[w.table].size / fs); }
+__device__ __forceinline__ void wavetable_set_f(WTab& w, float& cached, float f, float fs) { cached = f; w.inc = f * ((float)w.size / fs); }
 // Wavetable::process 3676-3679: position += { increment, size } (Phase::operator+=(increment) 1527-1534), then the linear read
 // buffer::operator[](float) 2070-2078.  (An index past the last sample — position == size exactly, or a phase offset pushing
-// it there — reads beyond the array in the reference; here it wraps to the start.)
-__device__ __forceinline__ float wavetable_process(WTab& w, const TableDesc* tabs) {
-	const TableDesc t = tabs[w.table];
-	const float size = (float)t.size;
+// it there — reads beyond the array in the reference; here it wraps to the start.)  The two neighbours are one 8-byte
+// gather unless some lane of the wave sits on the last sample (whose neighbour is sample 0).
+__device__ __forceinline__ float wavetable_process(WTab& w) {
+	const float size = (float)w.size;
 	if (!(w.inc >= size)) { w.pos += w.inc; if (w.pos > size) w.pos -= size; }
 	const float o = w.pos + w.off;
 	const float fl = floorf(o), frac = o - fl;
 	int i = (int)o;
-	i = (i >= t.size) ? i - t.size : i; i = (i < 0 || i >= t.size) ? 0 : i;
-	const int j = (i == t.size - 1) ? 0 : i + 1;
-	return t.p[i] * (1.f - frac) + t.p[j] * frac;
+	i = (i >= w.size) ? i - w.size : i; i = (i < 0 || i >= w.size) ? 0 : i;
+	float a, b;
+	if (__ballot(i == w.size - 1) == 0ull) {
+		typedef float f2u_t __attribute__((ext_vector_type(2), aligned(4)));
+		const f2u_t ab = *reinterpret_cast<const f2u_t*>(w.p + i);
+		a = ab.x; b = ab.y;
+	}
+	else { a = w.p[i]; b = w.p[(i == w.size - 1) ? 0 : i + 1]; }
+	return a * (1.f - frac) + b * frac;
 }
 __device__ __forceinline__ float table_read(const TableDesc* tabs, uint32_t id, float index) {
 	const TableDesc t = tabs[id];

@@ -149,7 +149,7 @@ inline std::string generate_source(const Program& g) {
 		} break;
 		case N_WAVETABLE:
 			live += fmt(" WTab n%zu; float n%zuf;", i, i);
-			begin += "\t\t" + n + ".inc = " + F(WT_INC) + "; " + n + ".pos = " + F(WT_POS) + "; " + n + ".off = " + F(WT_OFFSET) + "; " + n + "f = " + F(WT_FREQ) + "; " + n + ".table = " + R(WT_TABLE) + ";\n";
+			begin += "\t\t" + n + ".inc = " + F(WT_INC) + "; " + n + ".pos = " + F(WT_POS) + "; " + n + ".off = " + F(WT_OFFSET) + "; " + n + "f = " + F(WT_FREQ) + "; wavetable_load(" + n + ", c.tables, " + R(WT_TABLE) + ");\n";
 			end += W(WT_POS, "f2u(" + n + ".pos)");
 			mark(w0 + WT_POS, 1);
 			if (retuned[i]) { end += W(WT_INC, "f2u(" + n + ".inc)") + W(WT_FREQ, "f2u(" + n + "f)"); mark(w0 + WT_INC, 1); mark(w0 + WT_FREQ, 1); }
@@ -205,12 +205,12 @@ inline std::string generate_source(const Program& g) {
 			case N_BTRI: e = "basic_triangle(" + n + ")"; break;
 			case N_BSQUARE: e = "basic_square(" + n + ")"; break;
 			case N_BPULSE: e = "basic_pulse(" + n + ", " + n + "d)"; break;
-			case N_WAVETABLE: e = "wavetable_process(" + n + ", c.tables)"; break;
+			case N_WAVETABLE: e = "wavetable_process(" + n + ")"; break;
 			}
 			body += d + e + ";\n";
 		} break;
 		case OP_OSCSET:
-			if (k == N_WAVETABLE) body += "\t\twavetable_set_f(" + n + ", " + n + "f, " + a + ", c.fs.f, c.tables);\n";
+			if (k == N_WAVETABLE) body += "\t\twavetable_set_f(" + n + ", " + n + "f, " + a + ", c.fs.f);\n";
 			else if (k >= N_BSINE && k <= N_BPULSE) body += "\t\t" + n + "f = " + a + "; " + n + ".increment = " + a + " * 2.f * KLG_PI_F / c.fs.f;\n";   // Oscillator::set(f) klang.h:2862-2865
 			else body += "\t\t" + std::string(k == N_FSINE ? "fsine_set_f(" : "osm_set_f(") + n + ", " + n + "f, " + a + ", c.fs.f);\n";
 			break;
@@ -280,7 +280,7 @@ inline std::string generate_source(const Program& g) {
 		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\t(void)L; (void)r;\n" + end + "\t}\n};\n}\n";
 	}
 	else {
-		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {\n\t\tL.stage = (int)(r.w[0] & 3u);\n" + begin + "\t}\n";
+		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx& c) {\n\t\tL.stage = (int)(r.w[0] & 3u); (void)c;\n" + begin + "\t}\n";
 		s += "\tstatic __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {\n" + body + fmt("\t\treturn r%d;\n\t}\n", g.ret);
 		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\tr.w[0] = (uint32_t)L.stage;\n" + end + "\t}\n";
 		s += "\tstatic __device__ __forceinline__ void release(Rec&, float) {}\n};\n}\n";
