@@ -273,6 +273,9 @@ struct Control {
 		smoothed = smoothed.value * 0.999f + (1.f - 0.999f) * value.value; return smoothed;
 	}
 	Control& set(float x) { value = (x < min) ? min : (max < x) ? max : x; return *this; }                    // klang.h:1725
+	float range() const { return max - min; }                                                                // klang.h:1719-1721: what a host's 0..1 parameter maps to
+	float normalised() const { const float v = value.value; return range() ? (v - min) / range() : (v < 0.f ? 0.f : (1.f < v ? 1.f : v)); }
+	void setNormalised(float norm) { value = norm * range() + min; }
 };
 inline param::param(Control& c) : signal(c.value) {}
 // signal (op) Control and Control (op) signal: the control's value (recorded as a control read inside a recorded process()).
@@ -457,7 +460,7 @@ namespace Basic {
 		klg::host::BOscH h; float duty_ = 0.5f; int kind;
 		explicit Osc(int k) : kind(k) { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Osc), k, this); }
 		using Oscillator::set;
-		void reset() { if (gpu::no_set_while_recording("Basic oscillator reset()")) return; h.position = 0; }
+		void reset() override { if (gpu::no_set_while_recording("Basic oscillator reset()")) return; h.position = 0; }
 		void set(param f) override {
 			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Basic oscillator"), 0, false); frequency = f; return; }
 			h.frequency = f; h.increment = f * 2.f * pi.f / fs.f; frequency = f;
@@ -498,7 +501,7 @@ namespace Fast {
 		klg::host::FSineH h;
 		Sine() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Sine), klg::graph::N_FSINE, this); }
 		using Oscillator::set;
-		void reset() { if (gpu::no_set_while_recording("Fast::Sine::reset()")) return; h.pos = 0; }                        // klang.h:5136-5140
+		void reset() override { if (gpu::no_set_while_recording("Fast::Sine::reset()")) return; h.pos = 0; }                        // klang.h:5136-5140
 		void set(param f) override {
 			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Fast::Sine"), 0, false); frequency = f; return; }   // per-sample set(f): vibrato / FM
 			if (f != h.frequency) { h.frequency = f; h.inc = klg::host::fast_increment(f, host_fs()); }
@@ -578,6 +581,7 @@ namespace Biquad {
 	struct DCF : Modifier, gpu::Packable {
 		float r = 0.995f, z = 0;
 		DCF() { if (gpu::Recorder* rr = gpu::constructing()) rr->note(this, sizeof(DCF), klg::graph::N_DCF, this); }
+		using Modifier::set;
 		void set(float r_) { r = r_; }
 		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "DCF"); return; } device_only("DCF::process()"); }
 		void pack(uint32_t* w) const override { w[klg::graph::DCF_R] = gpu::fbits(r); w[klg::graph::DCF_Z] = gpu::fbits(z); w[klg::graph::DCF_OUT] = gpu::fbits(out.value); }
