@@ -37,7 +37,19 @@ struct Sub2aX2 {
 	f2 r_out, r_target, r_rate, time, A, AD, S;
 	i2 estage, point, active;      // active: 0 / -1 mask
 	i2 stage;                      // NoteBase::stage
+	// derived from the envelope's stage / point / ramp, which only change on the rare path (sub2a_x2_derive refreshes them there)
+	f2 tinc, srate;                // time increment of this sample (timeInc at Sustain, else +0); signed ramp step
+	i2 special;                    // an idle ramp means work: Sustain before its last point, or Release
 };
+// Envelope::process klang.h:4018-4051 per sample: `time += timeInc` at Sustain; the ramp steps by +-rate towards its target (the
+// sign is fixed while a ramp runs: out only moves towards target); an idle ramp at a segment end / in Release takes the rare path.
+__device__ __forceinline__ void sub2a_x2_derive(Sub2aX2& L, const SampleRate& fs) {
+	const i2 sustain = (L.estage == (int)ENV_SUSTAIN);
+	L.tinc = sustain ? splat(fs.timeInc) : splat(0.f);                 // time >= 0: adding +0 leaves it bit for bit
+	L.special = (sustain & (L.point != 2)) | (L.estage == (int)ENV_RELEASE);
+	L.srate = (L.r_target > L.r_out) ? L.r_rate : -L.r_rate;
+	L.stage = (L.estage == (int)ENV_OFF) ? (i2)(int)ST_OFF : L.stage;  // if (adsr.finished()) stop();
+}
 
 __device__ __forceinline__ void sub2a_x2_begin(Sub2aX2& L, const u2 (&w)[sizeof(PatchSub2a::Rec) / 4]) {
 	// word order of PatchSub2a::Rec: flags | inc offset duty delta | b0 b1 b2 a1 a2 z0 z1 | r_out r_target r_rate time A AD S R
@@ -61,6 +73,7 @@ __device__ __forceinline__ void sub2a_x2_begin(Sub2aX2& L, const u2 (&w)[sizeof(
 	L.A = as_f2(w[16]); L.AD = as_f2(w[17]); L.S = as_f2(w[18]);
 }
 
+
 // rare path of one voice (element c): segment end / stage change, the scalar code of klg_device.hpp
 template<int c>
 __device__ __forceinline__ void sub2a_x2_rare(Sub2aX2& L, const SampleRate& fs) {
@@ -74,10 +87,11 @@ __device__ __forceinline__ void sub2a_x2_rare(Sub2aX2& L, const SampleRate& fs) 
 
 __device__ __forceinline__ f2 sub2a_x2_osc_filter(Sub2aX2& L) {
 	// ---- Fast::Saw (OSM, duty 0)  klang.h:5251-5302 ----
-	const f2 p = as_f2((L.offset >> 9) | 0x3f800000u) - 1.f;          // float(offset) - col, col == 0
+	// p = float(offset) - col with col == 0 is the 23-bit fraction m / 2^23 exactly, and only p + p is used below: the same
+	// bits under exponent 2 are 2 + 2p, and taking 2 off is exact — one operation instead of two, same value
+	const f2 pp = as_f2((L.offset >> 9) | 0x40000000u) - 2.f;
 	const i2 carry = L.offset < L.inc;
 	L.offset += L.inc;
-	const f2 pp = p + p;
 	const f2 y_lin = L.c2 * (pp - L.f) + 1.f;
 	const f2 y_wrap = L.nrcpf * (1.f + L.k2 * (pp + L.omf)) + 1.f;
 	const f2 osc = carry ? y_wrap : y_lin;
@@ -94,10 +108,9 @@ __device__ __forceinline__ f2 sub2a_x2_osc_filter(Sub2aX2& L) {
 __device__ __forceinline__ i2 sub2a_x2_quiet(const Sub2aX2& L) {
 	return ~L.active & (((L.estage == (int)ENV_SUSTAIN) & (L.point == 2)) | (L.estage == (int)ENV_OFF));
 }
-__device__ __forceinline__ f2 sub2a_x2_sample_quiet(Sub2aX2& L, const SampleRate& fs) {
+__device__ __forceinline__ f2 sub2a_x2_sample_quiet(Sub2aX2& L) {
 	const f2 y = sub2a_x2_osc_filter(L);
-	const i2 sustain = (L.estage == (int)ENV_SUSTAIN);
-	L.time = sustain ? (L.time + fs.timeInc) : L.time;                // Envelope::process, case Sustain: time += timeInc
+	L.time += L.tinc;                                                 // Envelope::process, case Sustain: time += timeInc
 	return y * L.r_out;                                               // out *= adsr++ (ramp idle: value unchanged)
 }
 
@@ -105,21 +118,19 @@ __device__ __forceinline__ f2 sub2a_x2_sample(Sub2aX2& L, const SampleRate& fs) 
 	const f2 y = sub2a_x2_osc_filter(L);
 	// ---- ADSR: Envelope::process fast path  klang.h:4018-4051 (see env_process) ----
 	const f2 env = L.r_out;
-	const i2 up = L.r_target > L.r_out;
-	const f2 nxt = L.r_out + (up ? L.r_rate : -L.r_rate);
+	const f2 nxt = L.r_out + L.srate;
 	f2 stepped;
 	stepped.x = __builtin_amdgcn_fmed3f(L.r_out.x, nxt.x, L.r_target.x);
 	stepped.y = __builtin_amdgcn_fmed3f(L.r_out.y, nxt.y, L.r_target.y);
 	L.r_out = L.active ? stepped : L.r_out;
 	L.active = L.active & (stepped != L.r_target);
-	const i2 sustain = (L.estage == (int)ENV_SUSTAIN);
-	L.time = sustain ? (L.time + fs.timeInc) : L.time;
-	const i2 rare = ~L.active & ((sustain & (L.point != 2)) | (L.estage == (int)ENV_RELEASE));
+	L.time += L.tinc;
+	const i2 rare = ~L.active & L.special;
 	if (__ballot((rare.x | rare.y) != 0) != 0ull) {
 		if (rare.x) sub2a_x2_rare<0>(L, fs);
 		if (rare.y) sub2a_x2_rare<1>(L, fs);
+		sub2a_x2_derive(L, fs);
 	}
-	L.stage = (L.estage == (int)ENV_OFF) ? (i2)(int)ST_OFF : L.stage;  // if (adsr.finished()) stop();
 	return y * env;                                                    // out *= adsr++
 }
 
@@ -165,20 +176,21 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
 		}
 		Sub2aX2 L;
 		sub2a_x2_begin(L, w);
+		sub2a_x2_derive(L, a.fs);
 		for (int c0 = 0; c0 < n; c0 += X2_CHUNK) {
 			const int cl = (n - c0 < X2_CHUNK) ? (n - c0) : X2_CHUNK;
 			const i2 quiet = sub2a_x2_quiet(L);
+			// (no `live ? y : 0` at the tile write: a dead lane runs on an all-zero record — b0 = 0 and r_out = 0 — whose
+			//  output is +0 by itself: osc = y_lin = 1, y = 0 * 1 + 0, 0 * 0)
 			if (__ballot((quiet.x & quiet.y) == 0) == 0ull) {         // every voice of the wave is quiet
-				for (int s = 0; s < cl; s++) {
-					const f2 y = sub2a_x2_sample_quiet(L, a.fs);
-					tile[s * X2_LD + lane] = live ? y : splat(0.f);
+				if (cl == X2_CHUNK) {
+#pragma unroll 4
+					for (int s = 0; s < X2_CHUNK; s++) tile[s * X2_LD + lane] = sub2a_x2_sample_quiet(L);
 				}
+				else for (int s = 0; s < cl; s++) tile[s * X2_LD + lane] = sub2a_x2_sample_quiet(L);
 			}
 			else {
-				for (int s = 0; s < cl; s++) {
-					const f2 y = sub2a_x2_sample(L, a.fs);
-					tile[s * X2_LD + lane] = live ? y : splat(0.f);
-				}
+				for (int s = 0; s < cl; s++) tile[s * X2_LD + lane] = sub2a_x2_sample(L, a.fs);
 			}
 			wave_sync();
 			if (PER_VOICE) {
