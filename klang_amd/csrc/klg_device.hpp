@@ -173,10 +173,11 @@ __device__ __forceinline__ float osm_saw(Osm& o) {                          // s
 // Saw() : Osm(&OSM::saw, 0.f) whose duty is never changed (patch invariant, e.g. config 2a): duty == 0 so
 // col = 0, c2 = -1, `offset < duty` is never true, state stays Down and only Down (0) / DownUpDown (4) occur.
 __device__ __forceinline__ float osm_saw_duty0(Osm& o) {
-	const float p = fast_phase_float(o.offset) - o.col;
+	// p = float(offset) - col with col == 0 is the 23-bit fraction exactly and only p + p is used: the same bits under exponent 2
+	// are 2 + 2p, and taking 2 off is exact — one operation less, the same value
+	const float pp = u2f((o.offset >> 9) | 0x40000000u) - 2.f;
 	const bool carry = o.offset < (uint32_t)o.inc;
 	o.offset += (uint32_t)o.inc;
-	const float pp = p + p;
 	const float y_lin = o.c2 * (pp - o.f) + 1.f;
 	const float y_wrap = -o.rcpf * (1.f + o.c2 * o.omf * (pp + o.omf)) + 1.f;
 	return carry ? y_wrap : y_lin;
