@@ -454,7 +454,21 @@ struct Oscillator : Generator {
 	virtual float host_process() { device_only("rendering this oscillator into a Wavetable on the host (supported: Fast::Sine, Basic::Sine / Saw / Triangle / Square)"); }
 };
 namespace Generators {
+	// White noise: one libc rand() per sample (klang.h:4947-4951 Basic, 5357-5366 Fast).  Recordable in an Effect (the bank draws the
+	// block's values on the host in the reference's call order); a Note's voices share ONE process-wide sequence: not recordable.
+	struct NoiseBase : Generator {
+		int kind;
+		explicit NoiseBase(int k) : kind(k) {}
+		void process() override {
+			if (gpu::Recorder* r = gpu::recording()) {
+				if (!r->effect) { r->fail("Noise in a Note::process(): every voice draws from one process-wide rand() sequence, which lanes cannot share"); return; }
+				out.reg = r->emit(klg::graph::OP_NOISE, -1, -1, -1, (uint32_t)kind, true); return;
+			}
+			device_only("Noise::process()");
+		}
+	};
 namespace Basic {
+	struct Noise : NoiseBase { Noise() : NoiseBase(0) {} };
 	// Generic::Oscillator set() (klang.h:2862-2880) + the five Basic waveforms (4899-4944); process() is device code
 	struct Osc : Oscillator, gpu::Packable {
 		klg::host::BOscH h; float duty_ = 0.5f; int kind;
@@ -497,6 +511,7 @@ namespace Basic {
 	};
 }
 namespace Fast {
+	struct Noise : NoiseBase { Noise() : NoiseBase(1) {} };
 	struct Sine : Oscillator, gpu::Packable {
 		klg::host::FSineH h;
 		Sine() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Sine), klg::graph::N_FSINE, this); }

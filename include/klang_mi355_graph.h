@@ -139,11 +139,14 @@ enum OpCode {
 	OP_ELSE,        /* } else {                                                                               */
 	OP_ENDIF,       /* }                                                                                      */
 	OP_PHI,         /* dst = condition of the `if` just closed ? a : b       only directly after `endif` (or another phi of it) */
+	OP_NOISE,       /* dst = Noise process()               imm 0: Generators::Basic::Noise klang.h:4947-4951, 1: Fast::Noise 5357-5366.  Both draw
+	                   from libc rand(): the bank draws the values on the host, per block, in the order the reference would call rand() with
+	                   its instances in one process (instance-major, then sample, then the ops in program order).  Effects only, never inside an `if` */
 	OP_TABREAD,     /* dst = table imm [ a ]               Table<float, SIZE>::operator[](float): clamped, linear   klang.h:3365-3377; imm = table id (klg_table_upload) */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "tabread" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "tabread" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -161,6 +164,7 @@ struct Program {
 	int prepare_ops = 0;         /* the first prepare_ops ops are the effect's prepare(): once per block */
 	int arg(int node) const { return node < (int)node_arg.size() ? node_arg[(size_t)node] : 0; }
 
+	int noise_calls() const { int k = 0; for (const Op& o : ops) if (o.code == OP_NOISE) k++; return k; }   /* rand() draws per sample */
 	int words() const { int w = 1; for (int k : nodes) w += node_words(k); return w; }
 	int node_word0(int node) const { int w = 1; for (int i = 0; i < node; i++) w += node_words(nodes[(size_t)i]); return w; }
 
@@ -265,6 +269,7 @@ struct Program {
 			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); break;
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			case OP_CMP: if (o.imm > 5u) return bad("unknown relation"); need_a = need_b = true; break;
+			case OP_NOISE: if (!channels) return bad("Noise draws from the process-wide rand(): only effect programs can order it"); if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;
 			case OP_TABREAD: if (channels) return bad("tables are only available to synth notes"); if (o.imm == 0u) return bad("table id 0 is reserved"); need_a = true; break;
 			case OP_IF: if ((int)i < prepare_ops) return bad("prepare() may not branch"); need_a = true; has_dst = false; open.push_back({ {}, false, {} }); break;
 			case OP_ELSE:

@@ -860,8 +860,9 @@ struct FxGraphArgs {
 	const float* controls;                   // [kpad][KLG_MAX_CTL]
 	SampleRate fs;
 	unsigned long long samples;              // samples processed before this block (every delay's write cursor derives from it)
+	const int* rand; int rand_per_instance;  // Noise: this block's rand() values, [K][n * draws per sample] (or null)
 };
-struct FxCtx { SampleRate fs; const float* ctl; unsigned long long samples; float* ring; };   // ring: this lane's column of the group's tile
+struct FxCtx { SampleRate fs; const float* ctl; unsigned long long samples; float* ring; const int* rand; };   // ring: this lane's column of the group's tile; rand: this instance's draws of the block
 
 template<class P>
 __global__ __launch_bounds__(FX_WG) void klg_fx_graph(const FxGraphArgs a) {
@@ -877,6 +878,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_graph(const FxGraphArgs a) {
 	FxCtx c;
 	c.fs = a.fs; c.ctl = a.controls + (size_t)k * KLG_MAX_CTL; c.samples = a.samples;
 	c.ring = a.rings + (size_t)blockIdx.x * a.ring_rows * FX_WG + lane;
+	c.rand = a.rand ? a.rand + (size_t)(k < a.K ? k : 0) * (size_t)a.rand_per_instance : nullptr;
 	P::begin(L, rec, c);
 	const int col = lane & 31, half = lane >> 5;
 	for (int s0 = 0; s0 < a.n; s0 += FX_CHUNK) {

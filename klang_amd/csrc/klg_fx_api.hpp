@@ -31,6 +31,9 @@ struct klg_fx {
 	hipModule_t module = nullptr; hipFunction_t graph_fn = nullptr;
 	int channels = 2;
 	float* d_controls = nullptr; std::vector<float> h_controls; bool controls_dirty = false;
+	// Noise ops: the block's rand() draws, staged through a small ring of pinned buffers (a slot is reused once its copy + kernel are done)
+	enum { RAND_SLOTS = 4 };
+	int* h_rand[RAND_SLOTS] = {}; int* d_rand[RAND_SLOTS] = {}; hipEvent_t rand_done[RAND_SLOTS] = {}; int rand_slot = 0;
 };
 enum { KLG_PATCH_FXGRAPH = 1001 };
 
@@ -43,6 +46,7 @@ static void fx_free(klg_fx* f) {
 	for (void* p : dev) if (p) (void)hipFree(p);
 	if (f->module) (void)hipModuleUnload(f->module);
 	for (auto e : f->tev) (void)hipEventDestroy(e);
+	for (int i = 0; i < klg_fx::RAND_SLOTS; i++) { if (f->h_rand[i]) (void)hipHostFree(f->h_rand[i]); if (f->d_rand[i]) (void)hipFree(f->d_rand[i]); if (f->rand_done[i]) (void)hipEventDestroy(f->rand_done[i]); }
 	if (f->stream) (void)hipStreamDestroy(f->stream);
 	delete f;
 }
@@ -269,8 +273,27 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
 	a.io = d_io; a.n = n; a.controls = f->d_controls;
 	a.fs.f = f->fs.f; a.fs.w = f->fs.w; a.fs.timeInc = 1.0f / f->fs.f;
 	a.samples = f->samples;
+	a.rand = nullptr; a.rand_per_instance = 0;
+	const int draws = f->graph->noise_calls;
+	int slot = -1;
+	if (draws > 0) {
+		// Generators::*::Noise call libc rand() once per sample (klang.h:4949, 5363): draw this block's values here, in the order the
+		// reference would with its `K` effect objects in one process — instance 0's whole block, then instance 1's, ...
+		slot = f->rand_slot; f->rand_slot = (slot + 1) % klg_fx::RAND_SLOTS;
+		const size_t per = (size_t)n * (size_t)draws, count = per * (size_t)f->K;
+		if (!f->h_rand[slot]) {
+			RandGuard rg;                                              // allocations must not disturb the stream the draws below come from
+			const size_t cap = (size_t)f->max_block * (size_t)draws * (size_t)f->K * sizeof(int);
+			HIP_TRY(hipHostMalloc((void**)&f->h_rand[slot], cap)); HIP_TRY(hipMalloc((void**)&f->d_rand[slot], cap)); HIP_TRY(hipEventCreateWithFlags(&f->rand_done[slot], hipEventDisableTiming));
+		}
+		else HIP_TRY(hipEventSynchronize(f->rand_done[slot]));
+		for (size_t i = 0; i < count; i++) f->h_rand[slot][i] = rand();
+		HIP_TRY(hipMemcpyAsync(f->d_rand[slot], f->h_rand[slot], count * sizeof(int), hipMemcpyHostToDevice, st));
+		a.rand = f->d_rand[slot]; a.rand_per_instance = (int)per;
+	}
 	void* params[] = { &a };
 	HIP_TRY(hipModuleLaunchKernel(f->graph_fn, (unsigned)(f->kpad / FX_WG), 1, 1, FX_WG, 1, 1, 0, st, params, nullptr));
+	if (slot >= 0) HIP_TRY(hipEventRecord(f->rand_done[slot], st));
 	if (f->timing) { HIP_TRY(hipEventRecord(f->tev[2 * f->launches + 1], st)); f->launches++; }
 	f->samples += (unsigned long long)n;
 	return 0;

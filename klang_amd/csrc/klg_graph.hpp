@@ -39,7 +39,8 @@ inline std::string generate_source(const Program& g) {
 	auto ring = [&](int node) { return fmt("Ring{ c.ring + (size_t)%lldll * FX_WG, FX_WG, %d }", ring_off[(size_t)node], g.arg(node)); };
 	uint64_t mask[2] = { 1ull, 0ull };                                   // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
-	std::string live = fx ? "\tstruct Live { int unused_;" : "\tstruct Live { int stage;", begin, end, body;
+	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { int stage;", begin, end, body;
+	const int noise_calls = g.noise_calls(); int noise_k = 0;
 	for (size_t i = 0; i < g.nodes.size(); i++) {
 		const int k = g.nodes[i], w0 = g.node_word0((int)i);
 		const std::string n = fmt("L.n%zu", i);
@@ -245,6 +246,7 @@ inline std::string generate_source(const Program& g) {
 			for (const Op* ph : phis_of(if_of[oi])) body += fmt("\t\tr%d = r%d;\n", ph->dst, ph->b);
 			body += "\t\t}\n";
 			break;
+		case OP_NOISE: body += d + (o.imm ? "fast_noise(" : "basic_noise(") + fmt("c.rand[L.sidx * %d + %d]);\n", noise_calls, noise_k++); break;
 		case OP_TABREAD: body += d + fmt("table_read(c.tables, %uu, ", o.imm) + a + ");\n"; break;
 		case OP_PHI: break;                                         // assigned at the end of both sides (above)
 		case OP_STOPIF: body += "\t\tL.stage = (" + n + (k == N_ADSR ? ".e" : "") + ".stage == ENV_OFF) ? (int)ST_OFF : L.stage;\n"; break;
@@ -274,9 +276,9 @@ inline std::string generate_source(const Program& g) {
 	s += live;
 	if (fx) {
 		s += fmt("\tstatic constexpr int kChannels = %d;\n", g.channels);
-		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const FxCtx& c) {\n\t\tL.unused_ = 0; (void)r; (void)c;\n" + begin + "\t}\n";
+		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const FxCtx& c) {\n\t\tL.unused_ = 0; L.sidx = 0; (void)r; (void)c;\n" + begin + "\t}\n";
 		s += "\tstatic __device__ __forceinline__ void sample(Live& L, const FxCtx& c, float in0, float in1, float& out0, float& out1) {\n\t\t(void)in0; (void)in1;\n" + body
-			+ fmt("\t\tout0 = r%d;\n", g.ret) + (g.channels == 2 ? fmt("\t\tout1 = r%d;\n", g.ret_r) : std::string("\t\t(void)out1;\n")) + "\t}\n";
+			+ fmt("\t\tout0 = r%d;\n", g.ret) + (g.channels == 2 ? fmt("\t\tout1 = r%d;\n", g.ret_r) : std::string("\t\t(void)out1;\n")) + "\t\tL.sidx++;\n\t}\n";
 		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\t(void)L; (void)r;\n" + end + "\t}\n};\n}\n";
 	}
 	else {
@@ -324,7 +326,7 @@ struct Rtc {
 	}
 };
 
-struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; };   // name[pv] (effects: name[0] only)
+struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; int noise_calls = 0; };   // name[pv] (effects: name[0] only)
 
 // directory holding klg_kernels.hpp etc.: next to the shared library (klang_amd/csrc), or $KLG_GRAPH_SRC
 inline std::string source_dir() {
@@ -355,6 +357,7 @@ inline std::string compile(const char* text, const Compiled** out) {
 	c.source = generate_source(g);
 	c.words = g.words(); c.channels = g.channels;
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY) c.ring_rows += g.arg((int)i);
+	c.noise_calls = g.noise_calls();
 	void* prog = nullptr;
 	if (rtc.CreateProgram(&prog, c.source.c_str(), "klg_graph_patch.hip", 0, nullptr, nullptr) != 0) return "hiprtcCreateProgram failed";
 	const char* expr[2] = { "klg::klg_render<klg::PatchGen, false>", "klg::klg_render<klg::PatchGen, true>" };

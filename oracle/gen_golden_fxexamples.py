@@ -41,6 +41,8 @@ FX = {
     "fx_mute": [("choice", (0.0, 1.0))],
     # Filtering/Bands.k: two BPFs re-designed every sample from grouped controls
     "fx_bands": [(10.0, 1000.0), (0.1, 10.0), (10.0, 1000.0), (0.1, 10.0)],
+    # Filtering/Objects.k: Noise (one libc rand() per sample, ONE sequence shared by the process's instances) through an LPF set in prepare()
+    "fx_objects": [(10.0, 1000.0), (0.1, 10.0)],
 }
 
 

@@ -108,6 +108,18 @@ def test_malformed_branches_are_rejected(program, message):
     assert rc < 0 and message in msg, msg
 
 
+def test_noise_is_an_effect_op_outside_branches():
+    ok = "klgg 1\nkind effect 1\nctl 0\nop noise 0 -1 -1 -1 1\nop noise 1 -1 -1 -1 0\nop add 2 0 1 -1 0\nret 2\nend\n"
+    rc, src = check(ok, want_source=True)
+    assert rc == 0, src
+    assert "fast_noise(c.rand[L.sidx * 2 + 0])" in src and "basic_noise(c.rand[L.sidx * 2 + 1])" in src and "L.sidx++;" in src
+    rc, msg = check(ok.replace("kind effect 1\n", ""))
+    assert rc < 0 and "only effect programs" in msg
+    branchy = "klgg 1\nkind effect 1\nctl 0\nop in 0 -1 -1 -1 0\nop cmp 1 0 0 -1 1\nop if -1 1 -1 -1 0\nop noise 2 -1 -1 -1 1\nop endif -1 -1 -1 -1 0\nret 0\nend\n"
+    rc, msg = check(branchy)
+    assert rc < 0 and "inside an `if`" in msg
+
+
 def test_facade_records_branches_once_per_outcome_and_merges_them():
     """tests/patches/branches.k: an else-if chain with `!` / `&&`, a nested `if`, an oscillator advanced on one side only, a
     member written on both sides.  process() is run once per branch outcome; the traces are merged into if / else / endif + phi."""
