@@ -1311,6 +1311,17 @@ namespace Stereo {
 		signal operator*(const klang::signal& x) const { return { l * x, r * x }; } signal operator/(const klang::signal& x) const { return { l / x, r / x }; }
 		signal operator*(float x) const { return { l * x, r * x }; }
 	};
+	// Stereo::Delay<SIZE> (klang.h:4646-4699): a left and a right Delay<SIZE> advanced together
+	template<int SIZE> struct Delay {
+		klang::Delay<SIZE> items[2]; klang::Delay<SIZE>& l; klang::Delay<SIZE>& r;
+		Delay() : l(items[0]), r(items[1]) {}
+		void operator<<(const signal& x) { x.l >> items[0]; x.r >> items[1]; }                  // `delay << out`: each line takes its channel
+		signal operator()(const signal& time) { return { items[0](time.l), items[1](time.r) }; }   // stereo time: a tap per side (klang.h:4692-4693)
+		template<typename TIME, std::enable_if_t<!std::is_same_v<TIME, signal>, int> = 0>
+		signal operator()(const TIME& time) { return { items[0](time), items[1](time) }; }
+		unsigned int max() const { return SIZE; }
+	};
+	inline signal& operator>>(const signal& x, signal& dst) { dst = x; return dst; }
 	struct Effect : Plugin {
 		enum { channels = 2 };
 		Stereo::signal in, out;

@@ -43,6 +43,8 @@ FX = {
     "fx_bands": [(10.0, 1000.0), (0.1, 10.0), (10.0, 1000.0), (0.1, 10.0)],
     # Filtering/Objects.k: Noise (one libc rand() per sample, ONE sequence shared by the process's instances) through an LPF set in prepare()
     "fx_objects": [(10.0, 1000.0), (0.1, 10.0)],
+    # Delay/PingPong.k: Stereo::Delay<192000> (two lines advanced together), stereo::signal arithmetic, cross-fed channels
+    "fx_dpingpong": [(0.002, 0.02), (0.3, 0.9), (0.002, 0.02), (0.0, 0.9)],
 }
 
 
