@@ -128,7 +128,9 @@ int klg_voices_upload(klg_synth* s, int n, const int* voices, const void* states
  * render kernel as the shipped patches.  on()/off() stay with the caller: note events arrive as voice records
  * (klg_voice_download / klg_voice_upload / klg_voices_upload); klg_note_on / klg_note_off are rejected for such a bank.
  * klg_graph_check compiles a program WITHOUT a device (0, or KLG_ERR_INVALID with the message in `out`; with
- * want_source != 0 a successful check returns the generated HIP source instead).
+ * want_source != 0 a successful check returns the generated HIP source instead; want_source == 2 asks for the
+ * two-voices-per-lane form, which klg_synth_create_graph picks by itself when every node / op of the program has a packed
+ * primitive and the kernel keeps both voices in registers — KLG_GRAPH_X1=1 in the environment forces one voice per lane).
  * ------------------------------------------------------------------------------------------------ */
 klg_synth* klg_synth_create_graph(const char* program, int synths, int notes_per_synth, float sample_rate, int max_block);
 /* Sample tables of a graph bank.  replaces: the `buffer` a Wavetable / Sample owns (klang.h:3626-3720:

@@ -209,9 +209,25 @@ extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_s
 extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, int notes_per_synth, float sample_rate, int max_block) {
 	RandGuard rg;                 // hipRTC / comgr draw temporary names from libc random(): the caller's klang::random(seed) stream must survive
 	const graphrt::Compiled* c = nullptr;
-	const std::string err = graphrt::compile(program, &c);
-	if (!err.empty()) { fail(KLG_ERR_INVALID, "klg_synth_create_graph: %s", err.c_str()); return nullptr; }
-	graph::Program g; (void)g.parse(program);
+	graph::Program g;
+	{ const std::string perr = g.parse(program); if (!perr.empty()) { fail(KLG_ERR_INVALID, "klg_synth_create_graph: %s", perr.c_str()); return nullptr; } }
+	// two voices per lane (packed fp32, klg_render_x2<P>) when every node / op of the program has a packed form and the kernel
+	// keeps both voices in registers; KLG_GRAPH_X1=1 forces one voice per lane (A/B tests)
+	const char* x1env = getenv("KLG_GRAPH_X1");
+	bool x2 = graphrt::x2_eligible(g) && !(x1env && x1env[0] == '1');
+	for (;;) {
+		const std::string err = graphrt::compile(program, &c, x2);
+		if (!err.empty()) { fail(KLG_ERR_INVALID, "klg_synth_create_graph: %s", err.c_str()); return nullptr; }
+		if (!x2) break;
+		if (klg_ensure_device()) return nullptr;
+		hipModule_t m = nullptr; hipFunction_t fn = nullptr; int scratch = 1;
+		const bool loaded = hipModuleLoadData(&m, c->code.data()) == hipSuccess && hipModuleGetFunction(&fn, m, c->name[0].c_str()) == hipSuccess
+			&& hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn) == hipSuccess;
+		if (m) (void)hipModuleUnload(m);
+		if (getenv("KLG_GRAPH_DEBUG")) fprintf(stderr, "klang-mi355: graph patch, two voices per lane: %s, scratch %d bytes per lane\n", loaded ? "loaded" : "failed to load", scratch);
+		if (loaded && scratch == 0) break;
+		x2 = false;                                                   // spills (or would not load): one voice per lane
+	}
 	PatchInfo pi = {};
 	pi.words = c->words; pi.ncontrols = g.nctl;
 	for (int i = 0; i < g.nctl; i++) pi.dials[i] = { g.dials[i].min, g.dials[i].max, g.dials[i].initial };
@@ -228,7 +244,7 @@ extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, in
 extern "C" int klg_graph_check(const char* program, int want_source, char* out, size_t out_cap) {
 	RandGuard rg;
 	const graphrt::Compiled* c = nullptr;
-	const std::string err = graphrt::compile(program, &c);
+	const std::string err = graphrt::compile(program, &c, want_source == 2);
 	const std::string& msg = err.empty() ? (want_source ? c->source : err) : err;
 	if (out && out_cap) { const size_t n = std::min(out_cap - 1, msg.size()); memcpy(out, msg.data(), n); out[n] = 0; }
 	return err.empty() ? 0 : fail(KLG_ERR_INVALID, "klg_graph_check: %s", err.c_str());
@@ -247,14 +263,14 @@ template<class P> static void launch_render_t(klg_synth* s, const RenderArgs& a,
 	else hipLaunchKernelGGL((klg_render<P, false>), dim3(s->grid), dim3(WG), 0, st, a);
 }
 static int render_grid(const klg_synth* s) {      // workgroups (= partial rows) of the render launch
-	if (s->patch == KLG_PATCH_SUB2A && s->x2) return std::min((int)((s->stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG), s->grid);
+	if ((s->patch == KLG_PATCH_SUB2A && s->x2) || (s->graph && s->graph->x2)) return std::min((int)((s->stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG), s->grid);
 	return s->grid;
 }
 static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_t st) {
 	if (s->graph) {                                       // hipRTC code object: klg_render<PatchGen, pv>
 		RenderArgs args = a;
 		void* params[] = { &args };
-		s->launch_error = hipModuleLaunchKernel(s->graph_fn[pv ? 1 : 0], (unsigned)s->grid, 1, 1, WG, 1, 1, 0, st, params, nullptr);
+		s->launch_error = hipModuleLaunchKernel(s->graph_fn[pv ? 1 : 0], (unsigned)render_grid(s), 1, 1, WG, 1, 1, 0, st, params, nullptr);
 		return;
 	}
 	if (s->patch == KLG_PATCH_SUB2A && s->x2) {           // two voices per lane, packed fp32 (klg_render_x2.hpp)

@@ -21,6 +21,7 @@
 #pragma once
 #include "klg_device.hpp"
 #include "klg_kernels.hpp"
+#include "klg_device_x2.hpp"     // the width-generic helpers a generated body uses (to_i, kf, f2u, ...)
 
 #pragma clang fp contract(off)
 
@@ -119,11 +120,6 @@ __device__ __forceinline__ void io_store_chunk(const float* tile, float* io, int
 		const int row = 2 * it + half, inst = row >> 1, ch = row & 1;
 		if (col < cl && k0 + inst < K) io[((size_t)(k0 + inst) * 2 + ch) * n + s0 + col] = tile[(ch * FX_CHUNK + col) * FX_LD + inst];
 	}
-}
-__device__ __forceinline__ void wave_sync() {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // =================================================================================================
@@ -863,6 +859,7 @@ struct FxGraphArgs {
 	const int* rand; int rand_per_instance;  // Noise: this block's rand() values, [K][n * draws per sample] (or null)
 };
 struct FxCtx { SampleRate fs; const float* ctl; unsigned long long samples; float* ring; const int* rand; };   // ring: this lane's column of the group's tile; rand: this instance's draws of the block
+__device__ __forceinline__ float ctl_read(const FxCtx& c, unsigned i) { return c.ctl[i]; }
 
 template<class P>
 __global__ __launch_bounds__(FX_WG) void klg_fx_graph(const FxGraphArgs a) {

@@ -27,8 +27,23 @@ inline std::string fmt(const char* f, ...) {
 	char b[512]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return std::string(b);
 }
 
-inline std::string generate_source(const Program& g) {
+// Can this program run two voices per lane?  Only node kinds / ops that have packed forms in klg_device_x2.hpp.
+inline bool x2_eligible(const Program& g) {
 	using namespace graph;
+	if (g.channels) return false;
+	for (int k : g.nodes) if (!(k == N_FSINE || k == N_SAW || k == N_PULSE || k == N_LPF || k == N_ENV || k == N_ADSR || k == N_PARAM)) return false;
+	for (const Op& o : g.ops) switch (o.code) {
+		case OP_CONST: case OP_CTL: case OP_PARAM: case OP_OSC: case OP_LPF: case OP_ENV: case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_NEG:
+		case OP_STOPIF: case OP_STOP: case OP_SETPARAM: break;
+		default: return false;
+	}
+	return true;
+}
+
+inline std::string generate_source(const Program& g, bool x2 = false) {
+	using namespace graph;
+	// type names of the generated body: one voice per lane, or two (the packed primitives overload the scalar names)
+	const std::string TF = x2 ? "f2" : "float", TI = x2 ? "i2" : "int", TU = x2 ? "u2" : "uint32_t", T2 = x2 ? "2" : "";
 	const int NW = g.words();
 	std::vector<bool> swept(g.nodes.size(), false), written(g.nodes.size(), false), retuned(g.nodes.size(), false);
 	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; if (o.code == OP_OSCSET) retuned[(size_t)o.node] = true; }
@@ -39,7 +54,7 @@ inline std::string generate_source(const Program& g) {
 	auto ring = [&](int node) { return fmt("Ring{ c.ring + (size_t)%lldll * FX_WG, FX_WG, %d }", ring_off[(size_t)node], g.arg(node)); };
 	uint64_t mask[2] = { 1ull, 0ull };                                   // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
-	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { int stage;", begin, end, body;
+	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { " + TI + " stage;", begin, end, body;
 	const int noise_calls = g.noise_calls(); int noise_k = 0;
 	for (size_t i = 0; i < g.nodes.size(); i++) {
 		const int k = g.nodes[i], w0 = g.node_word0((int)i);
@@ -49,22 +64,22 @@ inline std::string generate_source(const Program& g) {
 		auto W = [&](int off, const std::string& expr) { return fmt("\t\tr.w[%d] = ", w0 + off) + expr + ";\n"; };
 		switch (k) {
 		case N_FSINE:
-			live += fmt(" FSine n%zu; float n%zuf;", i, i);
-			begin += "\t\t" + n + ".inc = (int32_t)" + R(FSINE_INC) + "; " + n + ".pos = " + R(FSINE_POS) + "; " + n + "f = " + F(FSINE_FREQ) + ";\n";
+			live += " FSine" + T2 + fmt(" n%zu; ", i) + TF + fmt(" n%zuf;", i);
+			begin += "\t\t" + n + ".inc = to_i(" + R(FSINE_INC) + "); " + n + ".pos = " + R(FSINE_POS) + "; " + n + "f = " + F(FSINE_FREQ) + ";\n";
 			end += W(FSINE_POS, n + ".pos");
 			mark(w0 + FSINE_POS, 1);
-			if (retuned[i]) { end += W(FSINE_INC, "(uint32_t)" + n + ".inc") + W(FSINE_FREQ, "f2u(" + n + "f)"); mark(w0 + FSINE_INC, 1); mark(w0 + FSINE_FREQ, 1); }
+			if (retuned[i]) { end += W(FSINE_INC, "to_u(" + n + ".inc)") + W(FSINE_FREQ, "f2u(" + n + "f)"); mark(w0 + FSINE_INC, 1); mark(w0 + FSINE_FREQ, 1); }
 			break;
 		case N_SAW: case N_PULSE:
-			live += fmt(" Osm n%zu; float n%zuf;", i, i);
-			begin += "\t\t" + n + ".inc = (int32_t)" + R(OSM_INC) + "; " + n + ".offset = " + R(OSM_OFFSET) + "; " + n + ".duty = " + R(OSM_DUTY) + "; " + n + ".delta = " + F(OSM_DELTA) + "; "
-				+ n + ".state = (int)(" + R(OSM_STATE) + " & 3u); " + n + "f = " + F(OSM_FREQ) + "; osm_derive(" + n + ");\n";
-			end += W(OSM_OFFSET, n + ".offset") + W(OSM_STATE, "(uint32_t)" + n + ".state");
+			live += " Osm" + T2 + fmt(" n%zu; ", i) + TF + fmt(" n%zuf; bool n%zud0;", i, i);
+			begin += "\t\t" + n + ".inc = to_i(" + R(OSM_INC) + "); " + n + ".offset = " + R(OSM_OFFSET) + "; " + n + ".duty = " + R(OSM_DUTY) + "; " + n + ".delta = " + F(OSM_DELTA) + "; "
+				+ n + ".state = to_i(" + R(OSM_STATE) + " & 3u); " + n + "f = " + F(OSM_FREQ) + "; osm_derive(" + n + "); " + n + "d0 = osm_is_duty0(" + n + ");\n";
+			end += W(OSM_OFFSET, n + ".offset") + W(OSM_STATE, "to_u(" + n + ".state)");
 			mark(w0 + OSM_OFFSET, 1); mark(w0 + OSM_STATE, 1);
-			if (retuned[i]) { end += W(OSM_INC, "(uint32_t)" + n + ".inc") + W(OSM_DELTA, "f2u(" + n + ".delta)") + W(OSM_FREQ, "f2u(" + n + "f)"); mark(w0 + OSM_INC, 1); mark(w0 + OSM_DELTA, 1); mark(w0 + OSM_FREQ, 1); }
+			if (retuned[i]) { end += W(OSM_INC, "to_u(" + n + ".inc)") + W(OSM_DELTA, "f2u(" + n + ".delta)") + W(OSM_FREQ, "f2u(" + n + "f)"); mark(w0 + OSM_INC, 1); mark(w0 + OSM_DELTA, 1); mark(w0 + OSM_FREQ, 1); }
 			break;
 		case N_LPF:
-			live += fmt(" Biquad n%zu; BiquadSweep n%zus;", i, i);
+			live += " Biquad" + T2 + fmt(" n%zu;", i) + " BiquadSweep" + T2 + fmt(" n%zus;", i);
 			begin += "\t\t" + n + ".b0 = " + F(LPF_B0) + "; " + n + ".b1 = " + F(LPF_B1) + "; " + n + ".b2 = " + F(LPF_B2) + "; " + n + ".a1 = " + F(LPF_A1) + "; " + n + ".a2 = " + F(LPF_A2) + "; "
 				+ n + ".z0 = " + F(LPF_Z0) + "; " + n + ".z1 = " + F(LPF_Z1) + "; " + n + "s.f = " + F(LPF_F) + "; " + n + "s.Q = " + F(LPF_Q) + ";\n";
 			end += W(LPF_Z0, "f2u(" + n + ".z0)") + W(LPF_Z1, "f2u(" + n + ".z1)");
@@ -76,19 +91,18 @@ inline std::string generate_source(const Program& g) {
 			}
 			break;
 		case N_ENV:
-			live += fmt(" Env n%zu; Pts4 n%zup; int n%zunp, n%zuls, n%zule;", i, i, i, i, i);
+			live += (x2 ? std::string(" Env2") : std::string(" Env")) + fmt(" n%zu; ", i) + (x2 ? "Pts4x2" : "Pts4") + fmt(" n%zup; ", i) + TI + fmt(" n%zunp, n%zuls, n%zule;", i, i, i);
 			begin += "\t\t" + n + ".r_out = " + F(ENV_OUT) + "; " + n + ".r_target = " + F(ENV_TARGET) + "; " + n + ".r_rate = " + F(ENV_RATE) + "; " + n + ".time = " + F(ENV_TIME) + "; env_unpack(" + n + ", " + R(ENV_BITS) + "); "
-				+ n + "np = (int)" + R(ENV_NPOINTS) + "; " + n + "ls = (int)(" + R(ENV_LOOP) + " & 0xFFu); " + n + "le = (int)((" + R(ENV_LOOP) + " >> 8) & 0xFFu); "
-				+ n + "ls = " + n + "ls == 255 ? -1 : " + n + "ls; " + n + "le = " + n + "le == 255 ? -1 : " + n + "le;\n";
+				+ n + "np = to_i(" + R(ENV_NPOINTS) + "); " + n + "ls = loop_index(" + R(ENV_LOOP) + " & 0xFFu); " + n + "le = loop_index((" + R(ENV_LOOP) + " >> 8) & 0xFFu);\n";
 			begin += "\t\t" + n + "p.x0 = " + F(ENV_PX) + "; " + n + "p.x1 = " + F(ENV_PX + 1) + "; " + n + "p.x2 = " + F(ENV_PX + 2) + "; " + n + "p.x3 = " + F(ENV_PX + 3) + "; "
 				+ n + "p.y0 = " + F(ENV_PY) + "; " + n + "p.y1 = " + F(ENV_PY + 1) + "; " + n + "p.y2 = " + F(ENV_PY + 2) + "; " + n + "p.y3 = " + F(ENV_PY + 3) + ";\n";
 			end += W(ENV_OUT, "f2u(" + n + ".r_out)") + W(ENV_TARGET, "f2u(" + n + ".r_target)") + W(ENV_RATE, "f2u(" + n + ".r_rate)") + W(ENV_TIME, "f2u(" + n + ".time)") + W(ENV_BITS, "env_pack(" + n + ")");
 			mark(w0 + ENV_OUT, 5);
 			break;
 		case N_ADSR:
-			live += fmt(" Adsr n%zu;", i);
+			live += " Adsr" + T2 + fmt(" n%zu;", i);
 			begin += "\t\t" + n + ".e.r_out = " + F(ADSR_OUT) + "; " + n + ".e.r_target = " + F(ADSR_TARGET) + "; " + n + ".e.r_rate = " + F(ADSR_RATE) + "; " + n + ".e.time = " + F(ADSR_TIME) + "; env_unpack(" + n + ".e, " + R(ADSR_BITS) + ");\n";
-			begin += "\t\t" + n + ".p.x0 = 0.f; " + n + ".p.x1 = " + F(ADSR_A) + "; " + n + ".p.x2 = " + F(ADSR_AD) + "; " + n + ".p.y0 = 0.f; " + n + ".p.y1 = 1.f; " + n + ".p.y2 = " + F(ADSR_S) + "; " + n + ".R = " + F(ADSR_R) + ";\n";
+			begin += "\t\tadsr_set_points(" + n + ", " + F(ADSR_A) + ", " + F(ADSR_AD) + ", " + F(ADSR_S) + ", " + F(ADSR_R) + "); adsr_derive(" + n + ", c.fs);\n";
 			end += W(ADSR_OUT, "f2u(" + n + ".e.r_out)") + W(ADSR_TARGET, "f2u(" + n + ".e.r_target)") + W(ADSR_RATE, "f2u(" + n + ".e.r_rate)") + W(ADSR_TIME, "f2u(" + n + ".e.time)") + W(ADSR_BITS, "env_pack(" + n + ".e)");
 			mark(w0 + ADSR_OUT, 5);
 			break;
@@ -165,7 +179,7 @@ inline std::string generate_source(const Program& g) {
 			end += W(0, "f2u(" + n + ")"); mark(w0, 1);
 			break;
 		case N_PARAM:
-			live += fmt(" float n%zu;", i);
+			live += " " + TF + fmt(" n%zu;", i);
 			begin += "\t\t" + n + " = " + F(0) + ";\n";
 			if (written[i]) { end += W(0, "f2u(" + n + ")"); mark(w0, 1); }
 			break;
@@ -173,6 +187,7 @@ inline std::string generate_source(const Program& g) {
 	}
 	live += " };\n";
 	std::map<int, uint32_t> const_of;                                    // single-assignment registers holding a literal
+	int if_depth = 0; std::vector<std::string> stop_at_end;
 	// structured branches: the phis that follow an `endif` are assigned at the end of each side of their `if`
 	std::vector<int> match_else(g.ops.size(), -1), match_endif(g.ops.size(), -1), if_of(g.ops.size(), -1);
 	{
@@ -189,17 +204,17 @@ inline std::string generate_source(const Program& g) {
 	for (size_t oi = 0; oi < g.ops.size(); oi++) {
 		const Op& o = g.ops[oi];
 		if ((int)oi == g.prepare_ops && g.prepare_ops) { prologue = body; body.clear(); }
-		const std::string d = fmt("\t\tconst float r%d = ", o.dst), n = fmt("L.n%d", o.node), a = fmt("r%d", o.a), b = fmt("r%d", o.b);
+		const std::string d = "\t\tconst " + TF + fmt(" r%d = ", o.dst), n = fmt("L.n%d", o.node), a = fmt("r%d", o.a), b = fmt("r%d", o.b);
 		const int k = (o.node >= 0 && o.node < (int)g.nodes.size()) ? g.nodes[(size_t)o.node] : -1;
 		switch (o.code) {
-		case OP_CONST: body += d + fmt("u2f(0x%08xu);\n", o.imm); const_of[o.dst] = o.imm; break;
-		case OP_CTL: body += d + fmt("c.ctl[%u];\n", o.imm); break;
+		case OP_CONST: body += d + "kf<" + TF + fmt(">(0x%08xu);\n", o.imm); const_of[o.dst] = o.imm; break;
+		case OP_CTL: body += d + fmt("ctl_read(c, %uu);\n", o.imm); break;
 		case OP_PARAM: body += d + n + ";\n"; break;
 		case OP_OSC: {
 			std::string e;
 			switch (k) {
 			case N_FSINE: e = "fsine_process(" + n + ", 0u)"; break;
-			case N_SAW: e = (retuned[(size_t)o.node] ? "osm_saw(" : "osm_saw_auto(") + n + ")"; break;
+			case N_SAW: e = retuned[(size_t)o.node] ? "osm_saw(" + n + ")" : "(" + n + "d0 ? osm_saw_duty0(" + n + ") : osm_saw(" + n + "))"; break;   // d0: decided once per block (begin)
 			case N_PULSE: e = "osm_pulse(" + n + ")"; break;
 			case N_BSINE: e = "basic_sine(" + n + ")"; break;
 			case N_BSAW: e = "basic_saw(" + n + ")"; break;
@@ -234,6 +249,7 @@ inline std::string generate_source(const Program& g) {
 		case OP_NEG: body += d + "-" + a + ";\n"; break;
 		case OP_CMP: { static const char* rel[6] = { "<", ">", "<=", ">=", "==", "!=" }; body += d + "(" + a + " " + rel[o.imm <= 5u ? o.imm : 0u] + " " + b + ") ? 1.f : 0.f;\n"; } break;
 		case OP_IF:
+			if_depth++;
 			for (const Op* ph : phis_of((int)oi)) body += fmt("\t\tfloat r%d;\n", ph->dst);
 			body += "\t\tif (" + a + " != 0.f) {\n";
 			break;
@@ -249,8 +265,12 @@ inline std::string generate_source(const Program& g) {
 		case OP_NOISE: body += d + (o.imm ? "fast_noise(" : "basic_noise(") + fmt("c.rand[L.sidx * %d + %d]);\n", noise_calls, noise_k++); break;
 		case OP_TABREAD: body += d + fmt("table_read(c.tables, %uu, ", o.imm) + a + ");\n"; break;
 		case OP_PHI: break;                                         // assigned at the end of both sides (above)
-		case OP_STOPIF: body += "\t\tL.stage = (" + n + (k == N_ADSR ? ".e" : "") + ".stage == ENV_OFF) ? (int)ST_OFF : L.stage;\n"; break;
-		case OP_STOP: body += "\t\tL.stage = (int)ST_OFF;\n"; break;
+		case OP_STOPIF: {
+			// outside a branch the test may wait for the end of the block: an envelope that is Off stays Off, and the note's stage is only read there
+			const std::string t = "stage_off_if(env_is_off(" + n + (k == N_ADSR ? ".e" : "") + ".stage), ";
+			if (if_depth == 0 && !fx) stop_at_end.push_back(t); else body += "\t\tL.stage = " + t + "L.stage);\n";
+		} break;
+		case OP_STOP: body += "\t\tL.stage = stage_all_off(L.stage);\n"; break;
 		case OP_SETPARAM: body += "\t\t" + n + " = " + a + ";\n"; break;
 		case OP_FREQ: body += d + n + "f;\n"; break;
 		case OP_IN: body += d + (o.imm ? "in1" : "in0") + ";\n"; break;
@@ -267,11 +287,10 @@ inline std::string generate_source(const Program& g) {
 	begin += prologue;
 	std::string s;
 	s += "// generated by klg_graph.hpp from a recorded klang process() body (include/klang_mi355_graph.h)\n";
-	s += fx ? "#include \"klg_fx.hpp\"\n" : "#include \"klg_kernels.hpp\"\n";
+	s += fx ? "#include \"klg_fx.hpp\"\n" : "#include \"klg_render_x2.hpp\"\n";
 	s += "#pragma clang fp contract(off)\nnamespace klg {\n";
-	s += "__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }\n";
 	s += "struct PatchGen {\n";
-	s += fmt("\tstruct Rec { uint32_t w[%d]; };\n", NW);
+	s += "\tstruct Rec { " + TU + fmt(" w[%d]; };\n\tstatic constexpr int kWords = %d;\n", NW, NW);
 	s += fmt("\tstatic constexpr uint64_t kStoreMask = 0x%llxull;\n\tstatic constexpr uint64_t kStoreMask2 = 0x%llxull;\n", (unsigned long long)mask[0], (unsigned long long)mask[1]);
 	s += live;
 	if (fx) {
@@ -282,9 +301,12 @@ inline std::string generate_source(const Program& g) {
 		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\t(void)L; (void)r;\n" + end + "\t}\n};\n}\n";
 	}
 	else {
-		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx& c) {\n\t\tL.stage = (int)(r.w[0] & 3u); (void)c;\n" + begin + "\t}\n";
-		s += "\tstatic __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {\n" + body + fmt("\t\treturn r%d;\n\t}\n", g.ret);
-		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\tr.w[0] = (uint32_t)L.stage;\n" + end + "\t}\n";
+		const std::string ctx = x2 ? "BlockCtx2" : "BlockCtx";
+		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const " + ctx + "& c) {\n\t\tL.stage = to_i(r.w[0] & 3u); (void)c;\n" + begin + "\t}\n";
+		s += "\tstatic __device__ __forceinline__ " + TF + " sample(Live& L, const " + ctx + "& c) {\n" + body + fmt("\t\treturn r%d;\n\t}\n", g.ret);
+		std::string stage_expr = "L.stage";
+		for (const std::string& t : stop_at_end) stage_expr = t + stage_expr + ")";
+		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\tr.w[0] = to_u(" + stage_expr + ");\n" + end + "\t}\n";
 		s += "\tstatic __device__ __forceinline__ void release(Rec&, float) {}\n};\n}\n";
 	}
 	return s;
@@ -326,7 +348,7 @@ struct Rtc {
 	}
 };
 
-struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; int noise_calls = 0; };   // name[pv] (effects: name[0] only)
+struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; int noise_calls = 0; bool x2 = false; };   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
 
 // directory holding klg_kernels.hpp etc.: next to the shared library (klang_amd/csrc), or $KLG_GRAPH_SRC
 inline std::string source_dir() {
@@ -341,7 +363,7 @@ inline std::string source_dir() {
 }
 
 // program text -> code object (cached per process by program text).  Returns "" on success.
-inline std::string compile(const char* text, const Compiled** out) {
+inline std::string compile(const char* text, const Compiled** out, bool x2 = false) {
 	static std::mutex mu;
 	static std::map<std::string, Compiled> cache;
 	static Rtc rtc;
@@ -349,19 +371,21 @@ inline std::string compile(const char* text, const Compiled** out) {
 	Program g;
 	const std::string perr = g.parse(text);
 	if (!perr.empty()) return perr;
-	const std::string key = g.text();
+	if (x2 && !x2_eligible(g)) return "graph program: not every node / op has a two-voices-per-lane form";
+	const std::string key = (x2 ? "x2\n" : "") + g.text();
 	auto it = cache.find(key);
 	if (it != cache.end()) { *out = &it->second; return ""; }
 	if (!rtc.load()) return rtc.error;
 	Compiled c;
-	c.source = generate_source(g);
-	c.words = g.words(); c.channels = g.channels;
+	c.source = generate_source(g, x2);
+	c.words = g.words(); c.channels = g.channels; c.x2 = x2;
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY) c.ring_rows += g.arg((int)i);
 	c.noise_calls = g.noise_calls();
 	void* prog = nullptr;
 	if (rtc.CreateProgram(&prog, c.source.c_str(), "klg_graph_patch.hip", 0, nullptr, nullptr) != 0) return "hiprtcCreateProgram failed";
 	const char* expr[2] = { "klg::klg_render<klg::PatchGen, false>", "klg::klg_render<klg::PatchGen, true>" };
 	if (g.channels) expr[0] = expr[1] = "klg::klg_fx_graph<klg::PatchGen>";
+	if (x2) { expr[0] = "klg::klg_render_x2<klg::PatchGen, false>"; expr[1] = "klg::klg_render_x2<klg::PatchGen, true>"; }
 	rtc.AddNameExpression(prog, expr[0]); if (!g.channels) rtc.AddNameExpression(prog, expr[1]);
 	const std::string inc = "-I" + source_dir();
 	const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str() };

@@ -43,6 +43,13 @@ template<class REC> struct RecWords {
 	__device__ __forceinline__ void from(const REC& r) { __builtin_memcpy(w, &r, sizeof(REC)); }
 };
 
+// all lanes of the wave have written / may read the wave's LDS tile
+__device__ __forceinline__ void wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // records longer than 64 words (generated graph patches, klg_graph.hpp) name their second store mask kStoreMask2
 template<class...> using klg_void_t = void;
 template<class P, class = void> struct StoreMask2 { static constexpr uint64_t value = 0; };

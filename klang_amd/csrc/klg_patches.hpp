@@ -35,6 +35,7 @@ __device__ __forceinline__ void osm_load(Osm& o, const OsmRec& r, uint32_t state
 __device__ __forceinline__ void osm_store(const Osm& o, OsmRec& r) { r.inc = o.inc; r.offset = o.offset; r.duty = o.duty; r.delta = o.delta; }
 
 struct Adsr { Env e; Pts3 p; float R; };
+__device__ __forceinline__ void adsr_set_points(Adsr& a, float A, float AD, float S, float R) { a.p.x0 = 0.f; a.p.x1 = A; a.p.x2 = AD; a.p.y0 = 0.f; a.p.y1 = 1.f; a.p.y2 = S; a.R = R; }
 __device__ __forceinline__ void adsr_load(Adsr& a, const AdsrRec& r, uint32_t bits) {
 	a.e.r_out = r.r_out; a.e.r_target = r.r_target; a.e.r_rate = r.r_rate; a.e.time = r.time;
 	env_unpack(a.e, bits);

@@ -12,20 +12,13 @@
 // (conflict-free ds_write_b64 / ds_read_b64), lane (s = l & 15, q = l >> 4) sums a quarter row with packed adds.
 #pragma once
 #include "klg_kernels.hpp"
+#include "klg_device_x2.hpp"
 
 #pragma clang fp contract(off)
 
 namespace klg {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef int i2 __attribute__((ext_vector_type(2)));
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
-
 enum { X2_CHUNK = 16, X2_LD = 65, X2_VOICES_PER_WG = 2 * WG };
-
-__device__ __forceinline__ f2 as_f2(u2 v) { return __builtin_bit_cast(f2, v); }
-__device__ __forceinline__ u2 as_u2(f2 v) { return __builtin_bit_cast(u2, v); }
-__device__ __forceinline__ f2 splat(float x) { f2 r = { x, x }; return r; }
 
 struct Sub2aX2 {
 	using Rec = PatchSub2a::Rec;
@@ -229,6 +222,105 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
 				else if (live.y) a.state[(size_t)k * a.stride + v + 1] = val.y;
 			};
 			st(0, flags); st(2, offset); st(10, z0); st(11, z1); st(12, r_out); st(13, r_target); st(14, r_rate); st(15, time);
+		}
+	}
+	__syncthreads();
+	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = acc[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same shape for ANY patch written over the packed primitives of klg_device_x2.hpp: what a generated graph patch
+// (klg_graph.hpp) uses when its nodes all have packed forms.  P: Rec { u2 w[kWords]; }, Live, begin / sample / end over
+// BlockCtx2, kStoreMask / kStoreMask2 as for klg_render<P>.
+// ---------------------------------------------------------------------------------------------
+struct BlockCtx2 {
+	SampleRate fs;
+	const float* ctl0; const float* ctl1;     // the two voices' synth instances (they differ when notes_per_synth is odd)
+	const TableDesc* tables;
+};
+__device__ __forceinline__ float ctl_read(const BlockCtx& c, unsigned i) { return c.ctl[i]; }
+__device__ __forceinline__ f2 ctl_read(const BlockCtx2& c, unsigned i) { f2 r = { c.ctl0[i], c.ctl1[i] }; return r; }
+
+template<class P, bool PER_VOICE>
+__global__ __launch_bounds__(WG) void klg_render_x2(const RenderArgs a) {
+	constexpr int W = P::kWords;
+	__shared__ __attribute__((aligned(16))) float lds[WAVES * X2_CHUNK * X2_LD * 2 + MAX_BLOCK];
+	float* acc = lds + WAVES * X2_CHUNK * X2_LD * 2;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	f2* tile = reinterpret_cast<f2*>(lds) + wave * X2_CHUNK * X2_LD;
+	const int n = a.n;
+	for (int i = tid; i < n; i += WG) acc[i] = 0.f;
+	__syncthreads();
+
+	const int groups = (int)((a.stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG);
+	for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+		const int v0 = g * X2_VOICES_PER_WG + wave * 128;
+		const int v = v0 + 2 * lane;
+		const bool in_range = (size_t)v < a.stride;
+		typename P::Rec rec;
+		rec.w[0] = in_range ? *reinterpret_cast<const u2*>(a.state + v) : (u2)(unsigned)ST_OFF;
+		i2 live = ((rec.w[0] & 3u) != (unsigned)ST_OFF);
+		live.x = (v < a.voices) ? live.x : 0; live.y = (v + 1 < a.voices) ? live.y : 0;
+		const bool any_live = (live.x | live.y) != 0;
+		if (__ballot(any_live) == 0ull) {
+			if (PER_VOICE)
+				for (int j = 0; j < 128 && v0 + j < a.voices; j++)
+					for (int i = lane; i < n; i += 64) a.per_voice[(size_t)(v0 + j) * n + i] = 0.f;
+			continue;
+		}
+		rec.w[0] = live ? rec.w[0] : (u2)0u;
+#pragma unroll
+		for (int k = 1; k < W; k++) {
+			const u2 t = any_live ? *reinterpret_cast<const u2*>(a.state + (size_t)k * a.stride + v) : (u2)0u;
+			rec.w[k] = live ? t : (u2)0u;
+		}
+		typename P::Live L;
+		BlockCtx2 ctx;
+		ctx.fs = a.fs; ctx.tables = a.tables;
+		ctx.ctl0 = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
+		ctx.ctl1 = a.controls + (size_t)((v + 1 < a.voices ? v + 1 : 0) / a.notes_per_synth) * KLG_MAX_CTL;
+		P::begin(L, rec, ctx);
+		for (int c0 = 0; c0 < n; c0 += X2_CHUNK) {
+			const int cl = (n - c0 < X2_CHUNK) ? (n - c0) : X2_CHUNK;
+			for (int s = 0; s < cl; s++) {
+				const f2 y = P::sample(L, ctx);
+				tile[s * X2_LD + lane] = live ? y : splat(0.f);
+			}
+			wave_sync();
+			if (PER_VOICE) {
+				constexpr int Q = 64 / X2_CHUNK;
+				const int s = lane & (X2_CHUNK - 1), q = lane / X2_CHUNK;
+				const float* tf = reinterpret_cast<const float*>(tile);
+				for (int j = 0; j < 128 / Q; j++) {
+					const int vv = Q * j + q;
+					if (s < cl && v0 + vv < a.voices) a.per_voice[(size_t)(v0 + vv) * n + c0 + s] = tf[(s * X2_LD) * 2 + vv];
+				}
+			}
+			{
+				constexpr int Q = 64 / X2_CHUNK;
+				const int s = lane & (X2_CHUNK - 1), q = lane / X2_CHUNK;
+				f2 sum2 = splat(0.f);
+				if (s < cl) {
+					const f2* row = tile + s * X2_LD + q * (64 / Q);
+#pragma unroll
+					for (int j = 0; j < 64 / Q; j++) sum2 += row[j];
+				}
+				float sum = sum2.x + sum2.y;
+#pragma unroll
+				for (int m = X2_CHUNK; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
+				if (lane < cl) atomicAdd(&acc[c0 + lane], sum);
+			}
+			wave_sync();
+		}
+		if (any_live) {
+			P::end(L, rec);
+#pragma unroll
+			for (int k = 0; k < W; k++) if (patch_stores<P>(k)) {
+				u2* dst = reinterpret_cast<u2*>(a.state + (size_t)k * a.stride + v);
+				if (live.x && live.y) *dst = rec.w[k];
+				else if (live.x) a.state[(size_t)k * a.stride + v] = rec.w[k].x;
+				else if (live.y) a.state[(size_t)k * a.stride + v + 1] = rec.w[k].y;
+			}
 		}
 	}
 	__syncthreads();

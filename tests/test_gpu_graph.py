@@ -31,8 +31,13 @@ def sub2a_to_graph(r):
     return g
 
 
-def test_graph_sub2a_equals_handwritten_kernel():
+@pytest.mark.parametrize("lanes", ["two voices per lane", "one voice per lane"])
+def test_graph_sub2a_equals_handwritten_kernel(lanes, monkeypatch):
+    """The generated patch runs two voices per lane (packed primitives, klg_render_x2<P>) when every node has a packed form —
+    this program does — and one per lane with KLG_GRAPH_X1=1: both must equal the hand-written kernel bit for bit."""
     import klang_amd
+    if lanes == "one voice per lane":
+        monkeypatch.setenv("KLG_GRAPH_X1", "1")
     S, P, N = 3, 32, 192
     hand = klang_amd.SynthBank("sub2a", synths=S, notes=P, max_block=N)
     gen = klang_amd.SynthBank(SUB2A_PROGRAM, synths=S, notes=P, max_block=N)

@@ -44,7 +44,7 @@ def test_program_compiles_for_gfx950_without_a_device():
     assert rc == 0, src
     # the generated patch is built from the same device primitives as the hand-written ones
     for needle in ("struct PatchGen", "osm_pulse(L.n0)", "biquad_lpf_set(L.n3, L.n3s, r3, r4, c.fs.w)", "adsr_process(L.n1, c.fs)",
-                   "env_process_rt(L.n2", "c.ctl[0]", "L.n4 = r8;", "ENV_OFF) ? (int)ST_OFF : L.stage"):
+                   "env_process_rt(L.n2", "ctl_read(c, 0u)", "L.n4 = r8;", "stage_off_if(env_is_off(L.n1.e.stage), L.stage)"):
         assert needle in src, needle
     words = 1 + 6 + 9 + 15 + 9 + 1
     assert f"uint32_t w[{words}]" in src
