@@ -304,6 +304,20 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		const std::string ctx = x2 ? "BlockCtx2" : "BlockCtx";
 		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const " + ctx + "& c) {\n\t\tL.stage = to_i(r.w[0] & 3u); (void)c;\n" + begin + "\t}\n";
 		s += "\tstatic __device__ __forceinline__ " + TF + " sample(Live& L, const " + ctx + "& c) {\n" + body + fmt("\t\treturn r%d;\n\t}\n", g.ret);
+		if (x2) {
+			// the same body with every ADSR holding (adsr_hold): what klg_render_x2 runs for a chunk when quiet() says every envelope
+			// of the wave only has its Sustain clock to advance.  (Envelope nodes have no such form: their patches never are quiet.)
+			std::string quiet_test, qbody = body; bool has_env = false, has_adsr = false;
+			for (size_t i = 0; i < g.nodes.size(); i++) { if (g.nodes[i] == N_ENV) has_env = true; if (g.nodes[i] == N_ADSR) { has_adsr = true; quiet_test += fmt(" & adsr_quiet(L.n%zu)", i); } }
+			const bool quiet = has_adsr && !has_env;
+			for (size_t at = 0; quiet && (at = qbody.find("adsr_process(", at)) != std::string::npos;) {
+				const size_t close = qbody.find(", c.fs)", at);
+				qbody = qbody.substr(0, at) + "adsr_hold(" + qbody.substr(at + 13, close - (at + 13)) + ")" + qbody.substr(close + 7);
+			}
+			s += std::string("\tstatic constexpr bool kHasQuiet = ") + (quiet ? "true" : "false") + ";\n";
+			s += "\tstatic __device__ __forceinline__ bool quiet(const Live& L) {\n\t\t(void)L; const i2 q = (i2)(-1)" + (quiet ? quiet_test : std::string("")) + ";\n\t\treturn __ballot((q.x & q.y) == 0) == 0ull;\n\t}\n";
+			s += "\tstatic __device__ __forceinline__ f2 sample_quiet(Live& L, const " + ctx + "& c) {\n" + (quiet ? qbody : body) + fmt("\t\treturn r%d;\n\t}\n", g.ret);
+		}
 		std::string stage_expr = "L.stage";
 		for (const std::string& t : stop_at_end) stage_expr = t + stage_expr + ")";
 		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\tr.w[0] = to_u(" + stage_expr + ");\n" + end + "\t}\n";

@@ -282,9 +282,17 @@ __global__ __launch_bounds__(WG) void klg_render_x2(const RenderArgs a) {
 		P::begin(L, rec, ctx);
 		for (int c0 = 0; c0 < n; c0 += X2_CHUNK) {
 			const int cl = (n - c0 < X2_CHUNK) ? (n - c0) : X2_CHUNK;
-			for (int s = 0; s < cl; s++) {
-				const f2 y = P::sample(L, ctx);
-				tile[s * X2_LD + lane] = live ? y : splat(0.f);
+			if (P::kHasQuiet && P::quiet(L)) {                        // every envelope of the wave holds: the body without the envelope work
+				for (int s = 0; s < cl; s++) {
+					const f2 y = P::sample_quiet(L, ctx);
+					tile[s * X2_LD + lane] = live ? y : splat(0.f);
+				}
+			}
+			else {
+				for (int s = 0; s < cl; s++) {
+					const f2 y = P::sample(L, ctx);
+					tile[s * X2_LD + lane] = live ? y : splat(0.f);
+				}
 			}
 			wave_sync();
 			if (PER_VOICE) {
