@@ -200,7 +200,7 @@ __device__ __forceinline__ f2 adsr_process(Adsr2& a, const SampleRate& fs) {    
 // sustain point, or Off).  Only host events between blocks end that, so a wave whose envelopes are all quiet can run a
 // chunk with adsr_hold in place of adsr_process (klg_render_x2<P>, P::sample_quiet).
 __device__ __forceinline__ i2 adsr_quiet(const Adsr2& a) { return ~a.e.active & ~a.special; }
-__device__ __forceinline__ f2 adsr_hold(Adsr2& a) { a.e.time += a.tinc; return a.e.r_out; }
+__device__ __forceinline__ f2 adsr_hold(Adsr2& a, const SampleRate&) { a.e.time += a.tinc; return a.e.r_out; }
 __device__ __forceinline__ void adsr_set_points(Adsr2& a, f2 A, f2 AD, f2 S, f2 R) { a.A = A; a.AD = AD; a.S = S; a.R = R; }
 
 // x / Y for a constant Y of the verified set (div_const of klg_device.hpp), both voices

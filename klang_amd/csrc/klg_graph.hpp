@@ -304,19 +304,33 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		const std::string ctx = x2 ? "BlockCtx2" : "BlockCtx";
 		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const " + ctx + "& c) {\n\t\tL.stage = to_i(r.w[0] & 3u); (void)c;\n" + begin + "\t}\n";
 		s += "\tstatic __device__ __forceinline__ " + TF + " sample(Live& L, const " + ctx + "& c) {\n" + body + fmt("\t\treturn r%d;\n\t}\n", g.ret);
-		if (x2) {
-			// the same body with every ADSR holding (adsr_hold): what klg_render_x2 runs for a chunk when quiet() says every envelope
-			// of the wave only has its Sustain clock to advance.  (Envelope nodes have no such form: their patches never are quiet.)
-			std::string quiet_test, qbody = body; bool has_env = false, has_adsr = false;
-			for (size_t i = 0; i < g.nodes.size(); i++) { if (g.nodes[i] == N_ENV) has_env = true; if (g.nodes[i] == N_ADSR) { has_adsr = true; quiet_test += fmt(" & adsr_quiet(L.n%zu)", i); } }
-			const bool quiet = has_adsr && !has_env;
-			for (size_t at = 0; quiet && (at = qbody.find("adsr_process(", at)) != std::string::npos;) {
-				const size_t close = qbody.find(", c.fs)", at);
-				qbody = qbody.substr(0, at) + "adsr_hold(" + qbody.substr(at + 13, close - (at + 13)) + ")" + qbody.substr(close + 7);
+		{
+			// the same body with every ADSR holding (adsr_hold): what the render kernel runs for a chunk when quiet() says every envelope
+			// of the wave only has its Sustain clock to advance.  (Envelope nodes have no such form: their patches never are quiet; a
+			// body with branches keeps one form.)
+			std::string quiet_test, d0_test, qbody = body; bool has_env = false, has_adsr = false, has_if = false;
+			for (size_t i = 0; i < g.nodes.size(); i++) {
+				if (g.nodes[i] == N_ENV || g.nodes[i] == N_OPERATOR) has_env = true;
+				if (g.nodes[i] == N_ADSR) { has_adsr = true; quiet_test += fmt(" & adsr_quiet(L.n%zu)", i); }
+				if (g.nodes[i] == N_SAW && !retuned[i]) d0_test += fmt(" && L.n%zud0", i);
+			}
+			for (const Op& o : g.ops) if (o.code == OP_IF) has_if = true;
+			const bool quiet = has_adsr && !has_env && !has_if;
+			for (size_t at = 0; quiet && (at = qbody.find("adsr_process(", at)) != std::string::npos;) qbody.replace(at, 13, "adsr_hold(");
+			// ... and with every saw in its duty-0 form (the per-block decision n<k>d0 folded into the choice of body)
+			std::string fbody = qbody;
+			for (size_t at = 0; (at = fbody.find("d0 ? osm_saw_duty0(", at)) != std::string::npos;) {
+				const size_t open = fbody.rfind('(', at), colon = fbody.find(" : osm_saw(", at), close = fbody.find("))", colon);
+				const std::string call = fbody.substr(at + 5, colon - (at + 5));            // osm_saw_duty0(L.nK)
+				fbody.replace(open, close + 2 - open, call);
+				at = open;
 			}
 			s += std::string("\tstatic constexpr bool kHasQuiet = ") + (quiet ? "true" : "false") + ";\n";
-			s += "\tstatic __device__ __forceinline__ bool quiet(const Live& L) {\n\t\t(void)L; const i2 q = (i2)(-1)" + (quiet ? quiet_test : std::string("")) + ";\n\t\treturn __ballot((q.x & q.y) == 0) == 0ull;\n\t}\n";
-			s += "\tstatic __device__ __forceinline__ f2 sample_quiet(Live& L, const " + ctx + "& c) {\n" + (quiet ? qbody : body) + fmt("\t\treturn r%d;\n\t}\n", g.ret);
+			// 0: the full body; 1: every envelope of the wave holds; 2: ... and every saw is in its duty-0 form
+			if (x2) s += "\tstatic __device__ __forceinline__ int quiet(const Live& L) {\n\t\t(void)L; const i2 q = (i2)(-1)" + (quiet ? quiet_test : std::string("")) + ";\n\t\tif (__ballot((q.x & q.y) == 0) != 0ull) return 0;\n\t\treturn (true" + d0_test + ") ? 2 : 1;\n\t}\n";
+			else s += "\tstatic __device__ __forceinline__ int quiet(const Live& L) {\n\t\t(void)L; const bool q = true" + (quiet ? quiet_test : std::string("")) + ";\n\t\tif (__ballot(!q) != 0ull) return 0;\n\t\treturn (true" + d0_test + ") ? 2 : 1;\n\t}\n";
+			s += "\tstatic __device__ __forceinline__ " + TF + " sample_quiet(Live& L, const " + ctx + "& c) {\n" + (quiet ? qbody : body) + fmt("\t\treturn r%d;\n\t}\n", g.ret);
+			s += "\tstatic __device__ __forceinline__ " + TF + " sample_fast(Live& L, const " + ctx + "& c) {\n" + (quiet ? fbody : body) + fmt("\t\treturn r%d;\n\t}\n", g.ret);
 		}
 		std::string stage_expr = "L.stage";
 		for (const std::string& t : stop_at_end) stage_expr = t + stage_expr + ")";

@@ -61,6 +61,11 @@ template<class P> __device__ __forceinline__ constexpr bool patch_stores(int w) 
 template<class P, class = void> struct WavesPerEu { static constexpr int lo = 1, hi = 8; };
 template<class P> struct WavesPerEu<P, klg_void_t<decltype(P::kWavesPerEu)>> { static constexpr int lo = P::kWavesPerEu, hi = P::kWavesPerEu; };
 
+// a patch may offer a second body for chunks in which every envelope of the wave merely holds: `static constexpr bool kHasQuiet`,
+// `quiet(L)` (wave-uniform) and `sample_quiet(L, ctx)` (generated graph patches do, klg_graph.hpp)
+template<class P, class = void> struct HasQuiet { static constexpr bool value = false; };
+template<class P> struct HasQuiet<P, klg_void_t<decltype(P::kHasQuiet)>> { static constexpr bool value = P::kHasQuiet; };
+
 template<class P, bool PER_VOICE>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P>::lo, WavesPerEu<P>::hi))) void klg_render(const RenderArgs a) {
 	using Rec = typename P::Rec;
@@ -103,7 +108,17 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		P::begin(L, rec, ctx);
 		for (int c0 = 0; c0 < n; c0 += CHUNK) {
 			const int cl = (n - c0 < CHUNK) ? (n - c0) : CHUNK;
-			for (int s = 0; s < cl; s++) {
+			int quiet = 0;                                          // 0: full body, 1: envelopes holding, 2: ... and duty-0 saws (generated patches)
+			if constexpr (HasQuiet<P>::value) quiet = P::quiet(L);
+			if (quiet == 2) {
+				if constexpr (HasQuiet<P>::value)
+					for (int s = 0; s < cl; s++) { const float y = P::sample_fast(L, ctx); tile[s * TILE_LD + lane] = live ? y : 0.f; }
+			}
+			else if (quiet == 1) {
+				if constexpr (HasQuiet<P>::value)
+					for (int s = 0; s < cl; s++) { const float y = P::sample_quiet(L, ctx); tile[s * TILE_LD + lane] = live ? y : 0.f; }
+			}
+			else for (int s = 0; s < cl; s++) {
 				const float y = P::sample(L, ctx);
 				tile[s * TILE_LD + lane] = live ? y : 0.f;
 			}

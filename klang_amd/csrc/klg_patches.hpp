@@ -47,6 +47,10 @@ __device__ __forceinline__ void adsr_store(const Adsr& a, AdsrRec& r) {
 	r.r_out = a.e.r_out; r.r_target = a.e.r_target; r.r_rate = a.e.r_rate; r.time = a.e.time;
 }
 __device__ __forceinline__ float adsr_process(Adsr& a, const SampleRate& fs) { return env_process<3, true>(a.e, a.p, 3, fs); }
+// QUIET: the ramp is idle and no segment end is pending (holding at the sustain point, or Off) — only the Sustain clock runs,
+// and only host events between blocks end that.  adsr_hold is adsr_process for such a sample.
+__device__ __forceinline__ bool adsr_quiet(const Adsr& a) { return !a.e.active && ((a.e.stage == ENV_SUSTAIN && a.e.point == 2) || a.e.stage == ENV_OFF); }
+__device__ __forceinline__ float adsr_hold(Adsr& a, const SampleRate& fs) { a.e.time = (a.e.stage == ENV_SUSTAIN) ? (a.e.time + fs.timeInc) : a.e.time; return a.e.r_out; }
 // ADSR::release(time = 0, level = 0) klang.h:4131-4133 on the packed record (event kernel)
 __device__ __forceinline__ void adsr_release_rec(AdsrRec& r, uint32_t& bits, float fs) {
 	Env e; e.r_out = r.r_out; e.r_target = r.r_target; e.r_rate = r.r_rate; e.time = r.time; env_unpack(e, bits);

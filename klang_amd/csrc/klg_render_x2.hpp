@@ -282,11 +282,16 @@ __global__ __launch_bounds__(WG) void klg_render_x2(const RenderArgs a) {
 		P::begin(L, rec, ctx);
 		for (int c0 = 0; c0 < n; c0 += X2_CHUNK) {
 			const int cl = (n - c0 < X2_CHUNK) ? (n - c0) : X2_CHUNK;
-			if (P::kHasQuiet && P::quiet(L)) {                        // every envelope of the wave holds: the body without the envelope work
-				for (int s = 0; s < cl; s++) {
-					const f2 y = P::sample_quiet(L, ctx);
-					tile[s * X2_LD + lane] = live ? y : splat(0.f);
+			const int quiet = P::kHasQuiet ? P::quiet(L) : 0;         // 0: full body, 1: envelopes holding, 2: ... and duty-0 saws
+			if (quiet == 2) {
+				if (cl == X2_CHUNK) {
+#pragma unroll 4
+					for (int s = 0; s < X2_CHUNK; s++) { const f2 y = P::sample_fast(L, ctx); tile[s * X2_LD + lane] = live ? y : splat(0.f); }
 				}
+				else for (int s = 0; s < cl; s++) { const f2 y = P::sample_fast(L, ctx); tile[s * X2_LD + lane] = live ? y : splat(0.f); }
+			}
+			else if (quiet == 1) {
+				for (int s = 0; s < cl; s++) { const f2 y = P::sample_quiet(L, ctx); tile[s * X2_LD + lane] = live ? y : splat(0.f); }
 			}
 			else {
 				for (int s = 0; s < cl; s++) {
