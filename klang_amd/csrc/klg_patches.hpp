@@ -189,6 +189,17 @@ struct PatchSuperSaw {
 		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;
 	}
+	// chunks in which every ADSR of the wave merely holds (klg_render: HasQuiet): the envelope is its value, only the Sustain clock runs
+	static constexpr bool kHasQuiet = true;
+	static __device__ __forceinline__ int quiet(const Live& L) { return __ballot(!adsr_quiet(L.adsr)) == 0ull ? 1 : 0; }
+	static __device__ __forceinline__ float sample_quiet(Live& L, const BlockCtx& c) {
+		float out = 0.f;
+#pragma unroll
+		for (int k = 0; k < 7; k++) out += div_const<0x40e00000u>(osm_saw(L.osc[k]));
+		out *= adsr_hold(L.adsr, c.fs);
+		return out;
+	}
+	static __device__ __forceinline__ float sample_fast(Live& L, const BlockCtx& c) { return sample_quiet(L, c); }
 	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
 		uint32_t f = (uint32_t)L.stage | (env_pack(L.adsr.e) << 2);
 #pragma unroll
