@@ -108,6 +108,36 @@ def test_malformed_branches_are_rejected(program, message):
     assert rc < 0 and message in msg, msg
 
 
+SAW_LPF_ADSR = "klgg 1\nctl 0\nnode 0 saw\nnode 1 lpf\nnode 2 adsr\nop osc 0 -1 -1 0 0\nop lpf 1 0 -1 1 0\nop env 2 -1 -1 2 0\nop mul 3 1 2 -1 0\nop stopif -1 -1 -1 2 0\nret 3\nend\n"
+
+
+def check_mode(program, mode):
+    from klang_amd._lib import lib
+    buf = C.create_string_buffer(1 << 17)
+    rc = lib().klg_graph_check(program.encode(), mode, buf, len(buf))
+    return rc, buf.value.decode()
+
+
+def test_two_voices_per_lane_form_and_the_three_bodies():
+    """A program whose nodes all have packed forms also compiles with two voices per lane: the SAME body text over 2-vector
+    types, plus the bodies for chunks in which the envelopes hold (adsr_hold) and the saws are in their duty-0 form."""
+    rc1, one = check_mode(SAW_LPF_ADSR, 1)
+    rc2, two = check_mode(SAW_LPF_ADSR, 2)
+    assert rc1 == 0 and rc2 == 0, one + two
+    assert "struct Rec { uint32_t w[25]; }" in one and "struct Live { int stage; Osm n0;" in one and "klg_render_x2" not in one.split("namespace klg")[1]
+    assert "struct Rec { u2 w[25]; }" in two and "struct Live { i2 stage; Osm2 n0;" in two and "const BlockCtx2& c" in two
+    body = lambda src, name: src[src.index(name):].split("return r3;")[0].split("{\n", 1)[1]
+    for src, F in ((one, "float"), (two, "f2")):
+        assert body(src, F + " sample(") == body(src, F + " sample(")                                            # sanity
+        assert "adsr_process(L.n2, c.fs)" in body(src, F + " sample(") and "osm_saw(L.n0)" in body(src, F + " sample(")
+        assert "adsr_hold(L.n2, c.fs)" in body(src, F + " sample_quiet(") and "L.n0d0 ? osm_saw_duty0(L.n0)" in body(src, F + " sample_quiet(")
+        assert "adsr_hold(L.n2, c.fs)" in body(src, F + " sample_fast(") and "= osm_saw_duty0(L.n0);" in body(src, F + " sample_fast(")
+        assert "stage_off_if(env_is_off(L.n2.e.stage), L.stage)" in src.split("void end(")[1]                    # `if (adsr.finished()) stop();` once per block
+    assert body(one, "float sample(").replace("float", "f2") == body(two, "f2 sample(")                          # the same text, other types
+    rc, msg = check_mode(SUB2B_LIKE, 2)                                                                          # lpfset has no packed form
+    assert rc < 0 and "two-voices-per-lane" in msg
+
+
 def test_noise_is_an_effect_op_outside_branches():
     ok = "klgg 1\nkind effect 1\nctl 0\nop noise 0 -1 -1 -1 1\nop noise 1 -1 -1 -1 0\nop add 2 0 1 -1 0\nret 2\nend\n"
     rc, src = check(ok, want_source=True)

@@ -117,6 +117,23 @@ def test_wav_reader_decodes_pcm16_stereo(tmp_path):
         assert float(toks[7]) == pytest.approx(float(f[0]), rel=1e-6, abs=1e-9)
 
 
+def test_wav_reader_decodes_float32_and_pcm24(tmp_path):
+    x = np.linspace(-0.9, 0.9, 50).astype(np.float32)
+    def riff(fmt, bits, payload, ch=1, rate=48000):
+        hdr = b"WAVEfmt " + struct.pack("<IHHIIHH", 16, fmt, ch, rate, rate * ch * bits // 8, ch * bits // 8, bits) + b"LIST" + struct.pack("<I", 4) + b"abcd" + b"data" + struct.pack("<I", len(payload)) + payload
+        return b"RIFF" + struct.pack("<I", len(hdr)) + hdr
+    f32 = tmp_path / "f32.wav"
+    f32.write_bytes(riff(3, 32, x.tobytes()))                                  # IEEE float, with a LIST chunk before the data
+    out = subprocess.run([host("klang_render"), "--wav-info", str(f32)], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0] == "rate 48000 channels 1 frames 50" and float(out[1].split()[7]) == pytest.approx(-0.9, rel=1e-6)
+    q = np.round(x.astype(np.float64) * 8388607).astype(np.int32)
+    p24 = tmp_path / "p24.wav"
+    p24.write_bytes(riff(1, 24, b"".join(int(v).to_bytes(3, "little", signed=True) for v in q)))
+    out = subprocess.run([host("klang_render"), "--wav-info", str(p24)], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0] == "rate 48000 channels 1 frames 50"
+    assert float(out[1].split()[7]) == pytest.approx(q[0] / 8388608.0, rel=1e-6) and float(out[1].split()[5]) == pytest.approx(np.abs(q).max() / 8388608.0, rel=1e-6)
+
+
 def read_wav_f32(path):
     d = open(path, "rb").read()
     assert d[:4] == b"RIFF" and d[8:16] == b"WAVEfmt "
