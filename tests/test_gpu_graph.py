@@ -142,6 +142,78 @@ def test_graph_wavetable_and_table_read_match_numpy_model():
     bank.close()
 
 
+CTL_PROGRAM = """klgg 1
+ctl 2
+dial 0 0 1 0.5
+dial 1 0 2 1
+node 0 saw
+node 1 fsine
+node 2 adsr
+op osc 0 -1 -1 0 0
+op osc 1 -1 -1 1 0
+op ctl 2 -1 -1 -1 0
+op ctl 3 -1 -1 -1 1
+op mul 4 0 2 -1 0
+op mul 5 1 3 -1 0
+op add 6 4 5 -1 0
+op env 7 -1 -1 2 0
+op mul 8 6 7 -1 0
+op stopif -1 -1 -1 2 0
+ret 8
+end
+"""
+
+
+def test_graph_two_voices_per_lane_reads_each_voices_own_controls(monkeypatch):
+    """An odd number of notes per synth puts the two voices of a lane in DIFFERENT synth instances (different controls); duty != 0 on
+    some voices keeps the general saw form in play; an ADSR that finishes mid-run exercises the packed segment ends and stop."""
+    import klang_amd
+    S, P, N = 5, 3, 96
+    rng = np.random.default_rng(21)
+    def make(env):
+        if env:
+            monkeypatch.setenv("KLG_GRAPH_X1", "1")
+        else:
+            monkeypatch.delenv("KLG_GRAPH_X1", raising=False)
+        b = klang_amd.SynthBank(CTL_PROGRAM, synths=S, notes=P, max_block=N)
+        for sy in range(S):
+            b.set_control(sy, 0, 0.1 + 0.2 * sy); b.set_control(sy, 1, 1.9 - 0.3 * sy)
+        return b
+    one, two = make(True), make(False)
+    f = np.float32
+    words = np.zeros((S * P, 1 + 6 + 3 + 9), np.uint32)
+    for v in range(S * P):
+        inc = np.int32(rng.integers(1 << 20, 1 << 26)); delta = f((int(inc) >> 9 | 0x3f800000)); delta = np.uint32((int(inc) >> 9) | 0x3f800000).view(f) - f(1)
+        duty = np.uint32(0 if v % 2 else rng.integers(1 << 28, 1 << 31))
+        words[v, 0] = 1
+        words[v, 1:7] = [np.uint32(inc), np.uint32(rng.integers(0, 1 << 32)), duty, delta.view(np.uint32), 0, 0]
+        words[v, 7:10] = [np.uint32(rng.integers(1 << 20, 1 << 25)), np.uint32(rng.integers(0, 1 << 32)), 0]
+        A, AD, Sus, R = f(0.0005 * (1 + v % 3)), f(0.0015 * (1 + v % 3)), f(0.6), f(0.001)
+        # attack from 0: target 1 at time A (Envelope::setTargetTime: rate = |1 - 0| / ((A - 0) * fs)); ramp active, stage Sustain, point 0
+        words[v, 10:19] = [f(0).view(np.uint32), f(1).view(np.uint32), f(1.0 / (float(A) * 48000.0)).view(np.uint32), f(0).view(np.uint32), (0 | (0 << 2) | (1 << 5)),
+                           A.view(np.uint32), AD.view(np.uint32), Sus.view(np.uint32), R.view(np.uint32)]
+    for b in (one, two):
+        b.voices_upload(np.arange(S * P), words)
+    for block in range(6):
+        if block == 3:                                            # release half the voices the way ADSR::release does: stage Release, ramp to 0 over R
+            for b in (one, two):
+                for v in range(0, S * P, 2):
+                    w = b.voice_download(v).copy()
+                    out = w[10:11].view(f)[0]
+                    w[11] = f(0).view(np.uint32); w[12] = f(abs(0 - out) / (0.001 * 48000.0)).view(np.uint32); w[14] = (1 | (int(w[14]) & 0x1C) | (1 << 5))
+                    b.voice_upload(v, w)
+        a, _ = one.process_voices(N)
+        c, _ = two.process_voices(N)
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), f"block {block}: max err {np.abs(a - c).max()}"
+        assert np.array_equal(one.stages(), two.stages())
+        for v in range(S * P):
+            assert np.array_equal(one.voice_download(v), two.voice_download(v)), f"block {block} voice {v}"
+    assert np.abs(a).max() > 0.01 and (one.stages() == 3).sum() >= S * P // 2
+    per_synth = np.abs(a.reshape(S, P, N)).max(axis=(1, 2))
+    assert len(set(np.round(per_synth, 3))) > 1                    # the synths' different controls are audible
+    one.close(); two.close()
+
+
 def test_graph_program_errors_are_reported():
     import klang_amd
     with pytest.raises(klang_amd.KlangError, match="operand a is not defined"):
