@@ -28,6 +28,9 @@ namespace klg {
 struct SampleRate { float f, w, timeInc; };           // SampleRate klang.h:1593-1604; timeInc = 1.0f / fs (3976)
 
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+// (pos >> 9) | (EXP << 23) — the 23 top bits of a 32-bit phase under a float exponent — in ONE v_alignbit_b32: the low word of
+// ({EXP, pos} >> 9).  EXP = 0x7F: a float in [1, 2); EXP = 0x80: in [2, 4).
+template<uint32_t EXP> __device__ __forceinline__ uint32_t phase_mantissa(uint32_t pos) { return __builtin_amdgcn_alignbit(EXP, pos, 9u); }
 
 // float -> unsigned exactly as the pinned oracle build does it (clang, baseline x86-64: cvttss2si r64,
 // truncate to 32 bits; "integer indefinite" = 0 in the low word when out of range / NaN).  Reproduces the
@@ -57,7 +60,7 @@ __device__ __forceinline__ uint32_t fast_phase(float radians) {          // Fast
 	return f2u_wrap(radians * KLG_FINTMAX / KLG_TWO_PI);
 }
 __device__ __forceinline__ float fast_phase_float(uint32_t pos) {        // Fast::Phase::operator float 5004-5007
-	return u2f((pos >> 9) | 0x3f800000u) - 1.f;
+	return u2f(phase_mantissa<0x7Fu>(pos)) - 1.f;
 }
 __device__ __forceinline__ float fast_increment_float(int32_t amount) {  // Fast::Increment::operator float 4979-4983
 	return u2f((uint32_t)((amount >> 9) | 0x3f800000)) - 1.f;
@@ -67,7 +70,7 @@ __device__ __forceinline__ float polysin(float x) {                      // klan
 	return (((-0.00018542f * x2 + 0.0083143f) * x2 - 0.16666f) * x2 + 1.0f) * x;
 }
 __device__ __forceinline__ float fastsinp(uint32_t p) {                  // klang.h:5117-5132 (+ fast_modp 1424-1428)
-	float x = (u2f((p >> 9) | 0x3f800000u) - 1.f) * KLG_TWO_PI;
+	float x = (u2f(phase_mantissa<0x7Fu>(p)) - 1.f) * KLG_TWO_PI;
 	if (x > KLG_3HALF_PI) x -= KLG_TWO_PI;
 	else if (x > KLG_HALF_PI) x = KLG_PI_F - x;
 	return polysin(x);
@@ -175,7 +178,7 @@ __device__ __forceinline__ float osm_saw(Osm& o) {                          // s
 __device__ __forceinline__ float osm_saw_duty0(Osm& o) {
 	// p = float(offset) - col with col == 0 is the 23-bit fraction exactly and only p + p is used: the same bits under exponent 2
 	// are 2 + 2p, and taking 2 off is exact — one operation less, the same value
-	const float pp = u2f((o.offset >> 9) | 0x40000000u) - 2.f;
+	const float pp = u2f(phase_mantissa<0x80u>(o.offset)) - 2.f;
 	const bool carry = o.offset < (uint32_t)o.inc;
 	o.offset += (uint32_t)o.inc;
 	const float y_lin = o.c2 * (pp - o.f) + 1.f;

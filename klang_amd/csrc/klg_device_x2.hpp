@@ -19,6 +19,7 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 as_f2(u2 v) { return __builtin_bit_cast(f2, v); }
 __device__ __forceinline__ u2 as_u2(f2 v) { return __builtin_bit_cast(u2, v); }
 __device__ __forceinline__ f2 splat(float x) { f2 r = { x, x }; return r; }
+template<uint32_t EXP> __device__ __forceinline__ f2 phase_float2(u2 pos) { u2 m = { phase_mantissa<EXP>(pos.x), phase_mantissa<EXP>(pos.y) }; return as_f2(m); }   // see phase_mantissa
 
 // ---- helpers a generated body uses for both widths ----
 __device__ __forceinline__ f2 u2f(u2 v) { return as_f2(v); }
@@ -46,7 +47,7 @@ __device__ __forceinline__ i2 env_is_off(i2 stage) { return stage == (int)ENV_OF
 struct FSine2 { i2 inc; u2 pos; };
 __device__ __forceinline__ f2 polysin(f2 x) { const f2 x2 = x * x; return (((-0.00018542f * x2 + 0.0083143f) * x2 - 0.16666f) * x2 + 1.0f) * x; }
 __device__ __forceinline__ f2 fastsinp(u2 p) {
-	f2 x = (as_f2((p >> 9) | 0x3f800000u) - 1.f) * KLG_TWO_PI;
+	f2 x = (phase_float2<0x7Fu>(p) - 1.f) * KLG_TWO_PI;
 	x = (x > KLG_3HALF_PI) ? (x - KLG_TWO_PI) : ((x > KLG_HALF_PI) ? (KLG_PI_F - x) : x);
 	return polysin(x);
 }
@@ -60,7 +61,7 @@ __device__ __forceinline__ void osm_derive(Osm2& o) {                           
 	o.omf = 1.f - o.f;
 	o.rcpf = 1.f / o.f;
 	o.rcpf2 = 2.f * o.rcpf;
-	o.col = as_f2((o.duty >> 9) | 0x3f800000u) - 1.f;
+	o.col = phase_float2<0x7Fu>(o.duty) - 1.f;
 	o.c1 = 1.f / o.col;
 	o.c2 = -1.f / (1.0f - o.col);
 }
@@ -73,7 +74,7 @@ __device__ __forceinline__ i2 osm_tick(Osm2& o) {                               
 }
 __device__ __forceinline__ f2 sqrf(f2 x) { return x * x; }
 __device__ __forceinline__ f2 osm_saw(Osm2& o) {                                // saw() 5290-5302 (see the scalar osm_saw)
-	const f2 p = (as_f2((o.offset >> 9) | 0x3f800000u) - 1.f) - o.col;
+	const f2 p = (phase_float2<0x7Fu>(o.offset) - 1.f) - o.col;
 	const i2 tr = osm_tick(o);
 	const f2 f = o.f, omf = o.omf, rcpf = o.rcpf, c1 = o.c1, c2 = o.c2;
 	const i2 n_up = (tr & 1) != 0, o_up = (tr & 2) != 0, carry = (tr & 4) != 0;
@@ -90,7 +91,7 @@ __device__ __forceinline__ f2 osm_saw(Osm2& o) {                                
 	return (o_up == n_up) ? y_same : (valid_edge ? y_edge : splat(0.f));
 }
 __device__ __forceinline__ f2 osm_saw_duty0(Osm2& o) {
-	const f2 pp = as_f2((o.offset >> 9) | 0x40000000u) - 2.f;                   // 2p in one operation (see the scalar osm_saw_duty0)
+	const f2 pp = phase_float2<0x80u>(o.offset) - 2.f;                   // 2p in one operation (see the scalar osm_saw_duty0)
 	const u2 uinc = to_u(o.inc);
 	const i2 carry = o.offset < uinc;
 	o.offset += uinc;
@@ -107,7 +108,7 @@ __device__ __forceinline__ f2 osm_saw_auto(Osm2& o) {
 	return osm_saw(o);
 }
 __device__ __forceinline__ f2 osm_pulse(Osm2& o) {                              // pulse() 5304-5316
-	const f2 p = as_f2((o.offset >> 9) | 0x3f800000u) - 1.f;
+	const f2 p = phase_float2<0x7Fu>(o.offset) - 1.f;
 	const i2 tr = osm_tick(o);
 	const f2 rcpf2 = o.rcpf2, col = o.col;
 	const i2 n_up = (tr & 1) != 0, o_up = (tr & 2) != 0, carry = (tr & 4) != 0;

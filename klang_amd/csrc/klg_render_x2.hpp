@@ -58,7 +58,7 @@ __device__ __forceinline__ void sub2a_x2_begin(Sub2aX2& L, const u2 (&w)[sizeof(
 	L.omf = 1.f - L.f;
 	const f2 rcpf = 1.f / L.f;
 	L.nrcpf = -rcpf;
-	const f2 col = as_f2(((w[3] >> 9) | 0x3f800000u)) - 1.f;
+	const f2 col = phase_float2<0x7Fu>(w[3]) - 1.f;
 	L.c2 = -1.f / (1.0f - col);
 	L.k2 = L.c2 * L.omf;                           // `c2 * omf * (...)` associates left: (c2 * omf) is loop invariant
 	L.b0 = as_f2(w[5]); L.b1 = as_f2(w[6]); L.b2 = as_f2(w[7]); L.a1 = as_f2(w[8]); L.a2 = as_f2(w[9]); L.z0 = as_f2(w[10]); L.z1 = as_f2(w[11]);
@@ -82,7 +82,7 @@ __device__ __forceinline__ f2 sub2a_x2_osc_filter(Sub2aX2& L) {
 	// ---- Fast::Saw (OSM, duty 0)  klang.h:5251-5302 ----
 	// p = float(offset) - col with col == 0 is the 23-bit fraction m / 2^23 exactly, and only p + p is used below: the same
 	// bits under exponent 2 are 2 + 2p, and taking 2 off is exact — one operation instead of two, same value
-	const f2 pp = as_f2((L.offset >> 9) | 0x40000000u) - 2.f;
+	const f2 pp = phase_float2<0x80u>(L.offset) - 2.f;
 	const i2 carry = L.offset < L.inc;
 	L.offset += L.inc;
 	const f2 y_lin = L.c2 * (pp - L.f) + 1.f;
