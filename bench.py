@@ -75,14 +75,14 @@ def cpu_baseline(patch, block, budget_s=12.0):
 
 def valu_issue(patch, V, N, kern_s):
     """VALU ISSUE-rate view of the sustain loop of klg_render_sub2a_x2 (the number that actually bounds this kernel): one wave =
-    128 voices; per sample its steady-state loop issues 31.5 instructions (4x unrolled: 124 VALU + 2 ds_write2 per 4 samples)
-    + 65 per 16-sample mix flush = 35.6 (counted in the ISA); a SIMD issues one wave64 VALU instruction
+    128 voices; per sample its steady-state loop issues 27.75 instructions (4x unrolled: 109 VALU + 2 ds_write2 per 4 samples)
+    + 65 per 16-sample mix flush = 31.8 (counted in the ISA); a SIMD issues one wave64 VALU instruction
     per 4 cycles, 1024 SIMDs at the 2.4 GHz peak engine clock."""
     if patch != "sub2a" or os.environ.get("KLG_RENDER_X1") == "1":
         return {}
-    achieved = (V / 128.0) * N * 35.6 / kern_s
+    achieved = (V / 128.0) * N * 31.8 / kern_s
     peak = 1024 * 2.4e9 / 4.0
-    return {"issue_rate_frac_est": achieved / peak, "wave_instr_per_wave_sample": 35.6, "issue_peak_wave_instr_per_s": peak}
+    return {"issue_rate_frac_est": achieved / peak, "wave_instr_per_wave_sample": 31.8, "issue_peak_wave_instr_per_s": peak}
 
 
 def main():
