@@ -759,6 +759,16 @@ template<typename TYPE> struct Result {
 	TYPE& operator++(int) { i++; return *++y; }
 };
 #define FUNCTION(type) (void(*)(type, klang::Result<type>&))[](type x, klang::Result<type>& y)
+// klang::buffer (klang.h:1983-2136) as far as a host needs it here: a view of caller-owned samples (what a Sample attaches to)
+class buffer {
+	float* samples_;
+public:
+	const int size;
+	buffer(float* data, int size_) : samples_(data), size(size_) {}
+	float operator[](int i) const { return samples_[i]; }
+	const float* data() const { return samples_; }
+};
+
 // ---- Wavetable / Sample (klang.h:3626-3720): the samples live in HBM (klg_table_upload); a note's record names them by id ----
 namespace gpu { inline thread_local klg_synth* upload_target = nullptr; }   // the bank a voice record is being packed for (SynthCore sets it)
 class Wavetable : public Oscillator, public gpu::Packable {
@@ -804,6 +814,7 @@ public:
 class Sample : public Wavetable {
 public:
 	Sample() : Wavetable(2) {}
+	Sample& operator=(const klang::buffer& b) { samples.assign(b.data(), b.data() + b.size); size = b.size; dirty = true; return *this; }   // klang.h:3696-3700 (the samples are copied to HBM when the note is packed)
 	Sample& operator=(const std::vector<float>& data) { samples.assign(data.begin(), data.end()); size = (int)data.size(); dirty = true; return *this; }
 	void set(param f) override { if (gpu::no_set_while_recording("Sample::set(f)")) return; frequency = f; increment = 1.f; }
 	void set(param f, param phase) override { if (gpu::no_set_while_recording("Sample::set(f, phase)")) return; position = phase * 44100.f; set(f); }
