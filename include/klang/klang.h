@@ -265,6 +265,9 @@ struct Control {
 	operator signal&() { return value; }
 	operator param() const { return param(value); }
 	operator float() const { value.concrete_only("float conversion of a Control"); return value.value; }
+	// `const int p = controls[0];` (a Menu selecting a row of constants): truncation.  While recording it is a chain of data-dependent
+	// branches `v < min + 1 ? min : v < min + 2 ? min + 1 : ...` over the control's range, so every choice gets its own recorded path
+	operator int() const;
 	signal smooth() {                                                                                        // klang.h:1715
 		if (gpu::Recorder* r = gpu::recording()) {
 			if (!r->effect) { r->fail("Control::smooth() (per-synth state advanced per sample) is not supported in a recorded Note::process()"); return smoothed; }
@@ -278,6 +281,13 @@ struct Control {
 	void setNormalised(float norm) { value = norm * range() + min; }
 };
 inline param::param(Control& c) : signal(c.value) {}
+inline Control::operator int() const {
+	if (value.reg < 0 || !gpu::recording()) return (int)value.value;
+	const int lo = (int)min, hi = (int)max;
+	if (hi - lo > 15) { gpu::rec->fail("int conversion of a Control with more than 16 values inside process()"); return (int)value.value; }
+	for (int k = lo; k < hi; k++) if ((bool)signal::cmp(0u, value, signal((float)(k + 1)), value.value < (float)(k + 1))) return k;
+	return hi;
+}
 // signal (op) Control and Control (op) signal: the control's value (recorded as a control read inside a recorded process()).
 // Templates, so that only a signal / param / ... operand takes part (plain numbers keep the Control's float conversion).
 #define KLANG_CONTROL_OPS(OP) \
@@ -364,6 +374,13 @@ template<class R, std::enable_if_t<std::is_same_v<R, SampleRate>, int> = 0> inli
 	template<class T, std::enable_if_t<std::is_same_v<T, float> || std::is_same_v<T, int>, int> = 0> inline signal operator OP(T x, Control& c) { return signal((float)x) OP c.value; }
 KLANG_CONTROL_NUM(+) KLANG_CONTROL_NUM(-) KLANG_CONTROL_NUM(*) KLANG_CONTROL_NUM(/)
 #undef KLANG_CONTROL_NUM
+// double (op) Control: the built-in DOUBLE arithmetic on the control's float value, spelled out (the control also converts to int —
+// `const int p = controls[0];` — so the built-in candidates alone would be ambiguous)
+#define KLANG_CONTROL_DBL(OP) \
+	template<class T, std::enable_if_t<std::is_same_v<T, double>, int> = 0> inline double operator OP(T x, const Control& c) { return x OP (double)(float)c; } \
+	template<class T, std::enable_if_t<std::is_same_v<T, double>, int> = 0> inline double operator OP(const Control& c, T x) { return (double)(float)c OP x; }
+KLANG_CONTROL_DBL(+) KLANG_CONTROL_DBL(-) KLANG_CONTROL_DBL(*) KLANG_CONTROL_DBL(/)
+#undef KLANG_CONTROL_DBL
 // sqr / cube (klang.h:3067-3069: Function<float> objects; applied to a signal they are the same fp32 products)
 inline signal sqr(const signal& x) { return x * x; }
 inline signal cube(const signal& x) { return x * x * x; }

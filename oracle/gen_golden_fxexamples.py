@@ -45,7 +45,11 @@ FX = {
     "fx_objects": [(10.0, 1000.0), (0.1, 10.0)],
     # Delay/PingPong.k: Stereo::Delay<192000> (two lines advanced together), stereo::signal arithmetic, cross-fed channels
     "fx_dpingpong": [(0.002, 0.02), (0.3, 0.9), (0.002, 0.02), (0.0, 0.9)],
+    # Delay/Patterns.k: `const int p = controls[0];` (a Menu) picks a row of tap times / gains — an int conversion of a control inside
+    # process(): recorded as branches over the menu's values, merged into phis of the rows' constants.  Long enough for the 0.25 s tap.
+    "fx_patterns": [("choice", (0.0, 1.0, 2.0))],
 }
+SHAPE = {"fx_patterns": dict(K=4, blocks=110)}        # name -> instances / blocks (default 9 / 24)
 
 
 def draw(rng, lo, hi):
@@ -57,8 +61,8 @@ def scenarios():
     rng = np.random.default_rng(20250929)
     out = {}
     for name, ranges in FX.items():
-        K = 9
-        s = Scenario(patch=name, block=128, blocks=24, instances=K, burst=2200, seed=int(rng.integers(1, 1 << 30)), dump=list(range(24)))
+        K, B = SHAPE.get(name, {}).get("K", 9), SHAPE.get(name, {}).get("blocks", 24)
+        s = Scenario(patch=name, block=128, blocks=B, instances=K, burst=2200, seed=int(rng.integers(1, 1 << 30)), dump=list(range(B)))
         for k in range(K):
             for c, (lo, hi) in enumerate(ranges):
                 s.control(0, k, c, draw(rng, lo, hi))
