@@ -22,7 +22,8 @@
 //     instead of computing — and the program is compiled for gfx950 by klg_synth_create_graph().  Supported in a
 //     recorded process(): Fast::{Sine,Saw,Triangle,Square,Pulse} with their frequency set in on() or per sample
 //     (`osc(f * (1 + lfo * depth))`: vibrato / FM by set(f)), the Basic oscillators, Operator<Sine> chains (`op1 * I >> op2 >> out`),
-//     Wavetable / Sample (samples in HBM, klg_table_upload) and Table<float, N> reads with a recorded index,
+//     Wavetable / Sample (samples in HBM, klg_table_upload) and Table<float, N> reads with a recorded index, Delay<SIZE> members
+//     (a line per voice in HBM: set(time) / clear() in on(), `delay >> x`, `delay << out`, `delay(time)` in process()),
 //     every Biquad type, OnePole, DCF, IIR<1>, Butterworth, Modal, Envelope::Follower (Biquad::LPF also set(f, Q) per sample), Envelope
 //     (<= 4 points, setLoop) and ADSR `++`, + - * / and unary minus on signals / params / controls / constants, `.out` of a
 //     member, signal and param members of the Note (read, and written for next-sample state), `>> out`, `out *= x`,
@@ -168,8 +169,10 @@ struct Pred {
 // ---- signal / relative / param (klang.h:1062-1200, 1357-1371) ----
 // `reg` >= 0 only while a process() body is being recorded: the value lives in that register of the program.
 struct relative;
+struct Control;
 struct signal {
 	float value; int reg = -1;
+	signal(const Control& c);                                   // the control's value (a Control also converts to float and int: name the one meant)
 	signal(constant c) : value(c.f) { reg_member(); }
 	signal(const float v = 0.f) : value(v) { reg_member(); }
 	signal(const double v) : value((float)v) { reg_member(); }
@@ -281,6 +284,7 @@ struct Control {
 	void setNormalised(float norm) { value = norm * range() + min; }
 };
 inline param::param(Control& c) : signal(c.value) {}
+inline signal::signal(const Control& c) : value(c.value.value), reg(c.value.reg) {}
 inline Control::operator int() const {
 	if (value.reg < 0 || !gpu::recording()) return (int)value.value;
 	const int lo = (int)min, hi = (int)max;
@@ -895,6 +899,10 @@ struct GraphLayout {
 			else reinterpret_cast<const Packable*>(obj)->pack(w + m.word0);
 		}
 	}
+	// a note's delay line keeps its cursors across notes (the reference never resets Delay::position): read them back even from a voice that is Off
+	void unpack_delays(void* note, const uint32_t* w) const {
+		for (const Member& m : members) if (m.kind == klg::graph::N_NDELAY) reinterpret_cast<Packable*>((char*)note + m.offset)->unpack(w + m.word0);
+	}
 	void unpack(void* note, const uint32_t* w) const {
 		for (const Member& m : members) {
 			char* obj = (char*)note + m.offset;
@@ -906,6 +914,9 @@ struct GraphLayout {
 };
 }
 
+namespace gpu {                                                              // what a note's Delay::clear() needs to find its line: set by SynthCore around events
+inline thread_local int current_voice = -1; inline thread_local const void* current_note = nullptr; inline thread_local const GraphLayout* current_layout = nullptr;
+}
 namespace gpu {
 // ---- data-dependent branches: one run of process() per outcome, merged into structured if / else / endif + phi ops ----
 // `run` executes process() and its epilogue (write-backs, then the OP_OUT marker naming the output registers).  The first
@@ -1251,8 +1262,9 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		Slot& s = notes.items[(size_t)n];
 		if (klg_voice_download(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_download");
 		if ((words[0] & 3u) != (uint32_t)klg::ST_OFF || s.note->stage != NOTEBASE::Off) { if (s.graph) s.graph->unpack(s.note, words.data()); else s.b.unpack(s.note, words.data()); }
+		else if (s.graph) s.graph->unpack_delays(s.note, words.data());
+		gpu::upload_target = gpu; gpu::current_voice = n; gpu::current_note = s.note; gpu::current_layout = s.graph;   // Wavetable uploads / Delay::clear() of this voice
 		event_code(s.note);
-		gpu::upload_target = gpu;                                      // a Wavetable member uploads its samples while packing
 		if (s.graph) s.graph->pack(s.note, words.data()); else s.b.pack(s.note, words.data());
 		words[0] = (words[0] & ~3u) | (uint32_t)s.note->stage;
 		if (klg_voice_upload(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_upload");
@@ -1307,11 +1319,19 @@ namespace Stereo {
 // =================================================================================================
 // Delay<SIZE> (klang.h:3381-3512) inside a recorded Effect::process(): `x >> delay`, `delay << x`, `delay(time)`, `(x >> delay)(time)`.
 // The line itself lives in HBM (one ring per effect instance); on the host the object only takes part in the recording.
-template<int SIZE> struct Delay : Modifier {
-	Delay() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Delay), klg::graph::N_DELAY, nullptr, SIZE); }
+// Delay<SIZE> (klang.h:3381-3512).  In an Effect: a ring per instance, cursor = the sample counter.  In a Note (physical models): a
+// `notedelay` node — the line lives in HBM per voice, its cursors (write position, the read head of set() / process()) in the record.
+template<int SIZE> struct Delay : Modifier, gpu::Packable {
+	bool in_note = false;
+	float time = 1.f; int position = 0; struct { int position = 0; float fraction = 0.f; } last;      // host mirror (notes)
+	Delay() {
+		if (gpu::Recorder* r = gpu::constructing()) { in_note = !r->effect; r->note(this, sizeof(Delay), in_note ? klg::graph::N_NDELAY : klg::graph::N_DELAY, in_note ? this : nullptr, SIZE); }
+		else in_note = true;                                                        // every further Note of a recorded type
+	}
 	using Generic::Input<signal>::input;
+	using Modifier::set;
 	void input() override {
-		if (gpu::Recorder* r = gpu::recording()) { if (!r->effect) { r->fail("Delay is recorded in effects only"); return; } r->emit(klg::graph::OP_DELAYIN, r->reg_of(in), -1, r->node(this, "Delay"), 0, false); return; }
+		if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_DELAYIN, r->reg_of(in), -1, r->node(this, "Delay"), 0, false); return; }
 		device_only("Delay::input()");
 	}
 	template<typename TIME> signal operator()(const TIME& delay) {                 // klang.h:3491-3509: tap(int) for integers, tap(float) otherwise
@@ -1319,7 +1339,30 @@ template<int SIZE> struct Delay : Modifier {
 		if (gpu::Recorder* r = gpu::recording()) { signal t; if constexpr (std::is_arithmetic_v<TIME>) t = signal((float)delay); else t = signal(delay); signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(t), -1, r->node(this, "Delay"), 0, true); return s; }
 		device_only("Delay::operator()");
 	}
-	void process() override { if (gpu::Recorder* r = gpu::recording()) { r->fail("Delay::set(time) + `>> delay >> out` is not recorded yet: use delay(time)"); return; } device_only("Delay::process()"); }
+	void set(param samples) override {                                             // klang.h:3480-3489: place the read head `samples` behind the write cursor
+		if (gpu::no_set_while_recording("Delay::set(time)")) return;
+		time = samples.value < SIZE ? samples.value : (float)SIZE;
+		float read = static_cast<float>(position - 1) - time;
+		if (read < 0.f) read += SIZE;
+		last.position = static_cast<int>(read);
+		last.fraction = read - last.position;
+	}
+	void clear() {                                                                 // klang.h:3392-3394, on the voice's line in HBM
+		if (gpu::no_set_while_recording("Delay::clear()")) return;
+		if (!gpu::upload_target || gpu::current_voice < 0 || !gpu::current_layout) return;          // not attached to a voice yet: the line is still all zeros
+		int ordinal = 0; const size_t me = (size_t)((const char*)static_cast<const gpu::Packable*>(this) - (const char*)gpu::current_note);
+		for (const auto& m : gpu::current_layout->members) if (m.kind == klg::graph::N_NDELAY && m.offset < me) ordinal++;
+		if (klg_voice_delay_clear(gpu::upload_target, gpu::current_voice, ordinal)) { std::fprintf(stderr, "klang-mi355: klg_voice_delay_clear: %s\n", klg_last_error()); std::abort(); }
+	}
+	void process() override {
+		if (gpu::Recorder* r = gpu::recording()) {
+			if (!in_note) { r->fail("Delay::set(time) + `delay >> x` in an effect is not recorded yet: use delay(time)"); return; }
+			out.reg = r->emit(klg::graph::OP_DELAYOUT, -1, -1, r->node(this, "Delay"), 0, true); return;
+		}
+		device_only("Delay::process()");
+	}
+	void pack(uint32_t* w) const override { using namespace klg::graph; w[ND_POS] = (uint32_t)position; w[ND_LASTPOS] = (uint32_t)last.position; w[ND_LASTFRAC] = gpu::fbits(last.fraction); w[ND_TIME] = gpu::fbits(time); }
+	void unpack(const uint32_t* w) override { using namespace klg::graph; position = (int)w[ND_POS]; last.position = (int)w[ND_LASTPOS]; }
 	unsigned int max() const { return SIZE; }
 };
 

@@ -140,6 +140,11 @@ klg_synth* klg_synth_create_graph(const char* program, int synths, int notes_per
  * dedup != 0 a table with exactly the same samples as an earlier one returns that one's id (a bank of notes built from the
  * same oscillator shares ONE table).  Tables live as long as the bank. */
 int klg_table_upload(klg_synth* s, const float* samples, int n, int dedup);
+/* Note delays of a graph bank: a Delay<SIZE> member of the Note (klang.h:3381-3512; Karplus-Strong strings, waveguides) is a
+ * `notedelay` node — its SIZE samples per voice live in HBM, zero-filled at creation like a fresh Delay, its cursors in the
+ * voice record.  replaces: Delay::clear() (klang.h:3392-3394) of voice `voice`'s delay number `delay_index` (the program's
+ * delay nodes in node order); queued in order with the blocks. */
+int klg_voice_delay_clear(klg_synth* s, int voice, int delay_index);
 int klg_graph_check(const char* program, int want_source, char* out, size_t out_cap);
 /* The same for a recorded Effect::process() body (`kind effect 1|2` programs; replaces constructing `instances` copies of a
  * user klang::Effect / Stereo::Effect, klang.h:4190-4216, 4703-4717).  `initial_record`: the record words of one freshly

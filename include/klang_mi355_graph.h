@@ -65,6 +65,9 @@ enum NodeKind {
 	N_SMOOTH = 22,  /* controls[i].smooth() in an effect   1715             words: smoothed */
 	N_WAVETABLE = 23,  /* Wavetable / Sample (synth notes)  3626-3720        words: increment position offset frequency table — `table` is the id
 	                                                                        klg_table_upload() returned for this note's samples (HBM; identical tables share an id) */
+	N_NDELAY = 24,  /* Delay<SIZE> member of a NOTE (physical models: a delay line per voice)  3381-3512   words: position (write cursor),
+	                                                                        last.position, last.fraction (the read head of Delay::process, set by set()), time;
+	                                                                        the ring of SIZE floats per voice lives in HBM, position-major over the 64 voices of a wave */
 	N_KINDS
 };
 enum { FSINE_INC = 0, FSINE_POS, FSINE_FREQ, FSINE_WORDS };
@@ -81,6 +84,7 @@ enum { MODAL_A1 = 0, MODAL_A2, MODAL_Y1, MODAL_Y2, MODAL_GAIN, MODAL_WORDS };
 enum { FOLLOW_A = 0, FOLLOW_R, FOLLOW_OUT, FOLLOW_WORDS };
 enum { OPER_INC = 0, OPER_POS, OPER_FREQ, OPER_AMP, OPER_ENV, OPER_WORDS = OPER_ENV + ENV_WORDS };
 enum { WT_INC = 0, WT_POS, WT_OFFSET, WT_FREQ, WT_TABLE, WT_WORDS };
+enum { ND_POS = 0, ND_LASTPOS, ND_LASTFRAC, ND_TIME, ND_WORDS };
 enum { MAX_WORDS = 128, MAX_NODES = 64, MAX_OPS = 1024 };
 
 inline bool is_oscillator(int k) { return k == N_FSINE || k == N_SAW || k == N_PULSE || (k >= N_BSINE && k <= N_BPULSE) || k == N_WAVETABLE; }
@@ -104,12 +108,13 @@ inline int node_words(int kind) {
 	case N_DELAY: return 0;
 	case N_SMOOTH: return 1;
 	case N_WAVETABLE: return WT_WORDS;
+	case N_NDELAY: return ND_WORDS;
 	}
 	return 0;
 }
 inline const char* node_name(int kind) {
 	static const char* names[N_KINDS] = { "fsine", "saw", "pulse", "lpf", "env", "adsr", "param", "bsine", "bsaw", "btri", "bsquare", "bpulse",
-	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator", "delay", "smooth", "wavetable" };
+	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator", "delay", "smooth", "wavetable", "notedelay" };
 	return (kind >= 0 && kind < N_KINDS) ? names[kind] : "?";
 }
 
@@ -142,11 +147,12 @@ enum OpCode {
 	OP_NOISE,       /* dst = Noise process()               imm 0: Generators::Basic::Noise klang.h:4947-4951, 1: Fast::Noise 5357-5366.  Both draw
 	                   from libc rand(): the bank draws the values on the host, per block, in the order the reference would call rand() with
 	                   its instances in one process (instance-major, then sample, then the ops in program order).  Effects only, never inside an `if` */
+	OP_DELAYOUT,    /* dst = delay node process()          Delay::process 3470-3473: the read head set by set() (note delays)   */
 	OP_TABREAD,     /* dst = table imm [ a ]               Table<float, SIZE>::operator[](float): clamped, linear   klang.h:3365-3377; imm = table id (klg_table_upload) */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "tabread" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -210,8 +216,8 @@ struct Program {
 				int k = -1; for (int q = 0; q < N_KINDS; q++) if (!strcmp(kind, node_name(q))) k = q;
 				if (k < 0) return bad("unknown node kind");
 				if ((int)nodes.size() >= MAX_NODES) return bad("too many nodes");
-				if (k == N_DELAY && (size < 2 || size > (1 << 24))) return bad("delay needs its SIZE (2 .. 2^24)");
-				nodes.push_back(k); node_arg.push_back(k == N_DELAY ? size : 0);
+				if ((k == N_DELAY || k == N_NDELAY) && (size < 2 || size > (1 << 24))) return bad("delay needs its SIZE (2 .. 2^24)");
+				nodes.push_back(k); node_arg.push_back((k == N_DELAY || k == N_NDELAY) ? size : 0);
 			}
 			else if (!strcmp(kw, "op")) {
 				char code[32]; Op o; unsigned imm;
@@ -264,8 +270,9 @@ struct Program {
 			case OP_SETPARAM: if (k != N_PARAM) return bad("node is not a param"); need_a = true; has_dst = false; break;
 			case OP_FREQ: if (!is_oscillator(k) && k != N_OPERATOR) return bad("node is not an oscillator"); break;
 			case OP_IN: if (channels == 0 || (int)o.imm >= channels) return bad("`in` needs an effect program with that channel"); break;
-			case OP_DELAYIN: if (k != N_DELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
-			case OP_DELAYTAP: if (k != N_DELAY) return bad("node is not a delay"); need_a = true; break;
+			case OP_DELAYIN: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
+			case OP_DELAYTAP: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); need_a = true; break;
+			case OP_DELAYOUT: if (k != N_NDELAY) return bad("node is not a note delay"); break;
 			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); break;
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			case OP_CMP: if (o.imm > 5u) return bad("unknown relation"); need_a = need_b = true; break;
@@ -311,7 +318,7 @@ struct Program {
 		if (!def(ret)) return "graph program: 'ret' names an undefined register";
 		if (channels == 2 && !def(ret_r)) return "graph program: 'ret2' names an undefined register";
 		if (channels == 0) for (int k : nodes) if (k == N_DELAY || k == N_SMOOTH) return "graph program: delay / smooth nodes need an effect program (kind effect)";
-		if (channels != 0) for (int k : nodes) if (k == N_WAVETABLE) return "graph program: wavetable nodes are only available to synth notes";
+		if (channels != 0) for (int k : nodes) if (k == N_WAVETABLE || k == N_NDELAY) return "graph program: wavetable / notedelay nodes are only available to synth notes";
 		return "";
 	}
 };

@@ -115,6 +115,7 @@ struct klg_synth {
 	struct Table { float* d; std::vector<float> h; uint64_t hash; };
 	std::vector<Table> tables;
 	TableDesc* d_tables = nullptr; size_t d_tables_cap = 0; bool tables_dirty = false;
+	float* d_note_rings = nullptr;               // note delays of a graph patch: [stride / 64][ring_rows][64]
 	// host mirrors
 	std::vector<host::ControlH> controls;        // [S][nctl]
 	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
@@ -141,6 +142,7 @@ static void synth_free(klg_synth* s) {
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
 	void* dev[] = { s->d_state, s->d_controls, s->d_partials, s->d_mix, s->d_per_voice, s->d_scratch_rec, s->d_stage };
 	for (void* p : dev) if (p) (void)hipFree(p);
+	if (s->d_note_rings) (void)hipFree(s->d_note_rings);
 	for (auto& t : s->tables) if (t.d) (void)hipFree(t.d);
 	if (s->d_tables) (void)hipFree(s->d_tables);
 	void* pinned[] = { s->h_stage, s->h_mix, s->h_flags, s->h_per_voice };
@@ -241,6 +243,13 @@ extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, in
 	bool ok = hipModuleLoadData(&s->module, c->code.data()) == hipSuccess;
 	for (int i = 0; i < 2 && ok; i++) ok = hipModuleGetFunction(&s->graph_fn[i], s->module, c->name[i].c_str()) == hipSuccess;
 	if (!ok) { fail(KLG_ERR_HIP, "klg_synth_create_graph: loading the compiled patch failed: %s", hipGetErrorString(hipGetLastError())); synth_free(s); return nullptr; }
+	if (c->ring_rows > 0) {                                       // a delay line per voice and Delay member (zero-filled, like a fresh Delay)
+		const size_t bytes = s->stride * (size_t)c->ring_rows * sizeof(float);
+		if (bytes > (200ull << 30) || hipMalloc((void**)&s->d_note_rings, bytes) != hipSuccess || hipMemset(s->d_note_rings, 0, bytes) != hipSuccess) {
+			fail(KLG_ERR_HIP, "klg_synth_create_graph: %zu voices x %lld delay samples = %.1f GB of delay lines could not be allocated", s->stride, c->ring_rows, bytes / 1e9);
+			synth_free(s); return nullptr;
+		}
+	}
 	return s;
 }
 // Parse, generate and compile a graph program for gfx950 WITHOUT touching a device (build-time / CI check).
@@ -547,6 +556,7 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	a.controls = s->d_controls; a.fs = s->dfs; a.partials = s->d_partials; a.per_voice = per_voice ? s->d_per_voice : nullptr;
 	if (int rc = tables_sync(s)) return rc;
 	a.tables = s->d_tables;
+	a.rings = s->d_note_rings; a.ring_rows = s->graph ? (size_t)s->graph->ring_rows : 0;
 	if (s->timing) {
 		if ((int)s->tev.size() < 2 * (s->launches + 1)) { hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); s->tev.push_back(e0); s->tev.push_back(e1); }
 		HIP_TRY(hipEventRecord(s->tev[2 * s->launches], st));
@@ -645,6 +655,17 @@ extern "C" int klg_voices_upload(klg_synth* s, int n, const int* voices, const v
 		push_note_on(s, voices[i], w + (size_t)i * s->W);
 		s->voices[voices[i]].stage = (uint8_t)(w[(size_t)i * s->W] & 3u);
 	}
+	return 0;
+}
+
+// Delay::clear() of a note's delay line (klang.h:3392-3394), in stream order with the blocks
+extern "C" int klg_voice_delay_clear(klg_synth* s, int voice, int delay_index) {
+	if (!s || !s->graph || !s->d_note_rings) return fail(KLG_ERR_INVALID, "klg_voice_delay_clear: the bank has no note delays (graph %p, %lld ring rows, lines %p)", s ? (const void*)s->graph : nullptr, s && s->graph ? s->graph->ring_rows : -1ll, s ? (const void*)s->d_note_rings : nullptr);
+	if (voice < 0 || voice >= s->V || delay_index < 0 || delay_index >= (int)s->graph->delays.size()) return fail(KLG_ERR_INVALID, "klg_voice_delay_clear: voice %d / delay %d out of range", voice, delay_index);
+	const long long row0 = s->graph->delays[(size_t)delay_index].first; const int size = s->graph->delays[(size_t)delay_index].second;
+	float* col = s->d_note_rings + ((size_t)(voice >> 6) * (size_t)s->graph->ring_rows + (size_t)row0) * 64 + (size_t)(voice & 63);
+	hipLaunchKernelGGL(klg_ring_clear, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, s->stream, col, size);
+	HIP_TRY(hipGetLastError());
 	return 0;
 }
 

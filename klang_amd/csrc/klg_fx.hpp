@@ -22,6 +22,7 @@
 #include "klg_device.hpp"
 #include "klg_kernels.hpp"
 #include "klg_device_x2.hpp"     // the width-generic helpers a generated body uses (to_i, kf, f2u, ...)
+#include "klg_delay.hpp"
 
 #pragma clang fp contract(off)
 
@@ -31,59 +32,6 @@ enum { FX_WG = 64, FX_CHUNK = 32, FX_LD = 65 };
 
 struct BiquadCoef { float b0, b1, b2, a1, a2; };
 
-// ---- Delay<SIZE> on an interleaved ring (klang.h:3381-3512) ----
-struct Ring {
-	float* base;          // this wave's column: &rings[line][0][k]
-	size_t stride;        // Kpad
-	int size;
-	__device__ __forceinline__ float rd(int i) const { return base[(size_t)i * stride]; }
-	__device__ __forceinline__ void wr(int i, float v) const { base[(size_t)i * stride] = v; }
-};
-struct Tap { int position; float fraction; };
-__device__ __forceinline__ Tap delay_set(int position, int size, float samples) {      // Delay::set 3480-3489
-	const float time = samples < size ? samples : (float)size;
-	float read = (float)(position - 1) - time;
-	if (read < 0.f) read += size;
-	Tap t; t.position = (int)read; t.fraction = read - t.position;
-	return t;
-}
-__device__ __forceinline__ float delay_process(const Ring& r, Tap& t) {               // tap() 3461-3468 + process 3470-3473
-	const int i = t.position;
-	const int j = (i + 1 == r.size) ? 0 : i + 1;                                      // (i + 1) % SIZE for 0 <= i < SIZE
-	const float a = r.rd(i), b = r.rd(j);
-	const float out = a + t.fraction * (b - a);
-	t.position = j;
-	return out;
-}
-
-// Delay::tap(int) 3405-3410, tap(float) 3412-3427, lagrange(float) 3429-3458 — `position` is the write cursor
-__device__ __forceinline__ float delay_tap_int(const Ring& r, int position, int delay) {
-	int read = (position - 1) - delay;
-	if (read < 0) read += r.size;
-	return r.rd(read);
-}
-__device__ __forceinline__ float delay_tap_float(const Ring& r, int position, float delay) {
-	float read = (float)(position - 1) - delay;
-	if (read < 0.f) read += r.size;
-	const int i = (int)read;
-	const float fraction = read - i;
-	const int j = (i + 1) % r.size;
-	const float a = r.rd(i), b = r.rd(j);
-	return a + fraction * (b - a);
-}
-__device__ __forceinline__ float delay_lagrange(const Ring& r, int position, float delay) {
-	const int SIZE = r.size;
-	float read = (float)(position - 1) - delay;
-	if (read < 0.f) read += SIZE;
-	const int i = (int)read;
-	const float x = read - i;
-	const float y0 = r.rd((i - 1 + SIZE) % SIZE), y1 = r.rd(i), y2 = r.rd((i + 1) % SIZE), y3 = r.rd((i + 2) % SIZE);
-	const float c0 = (-x * (x - 1) * (x - 2)) / 6.0f;
-	const float c1 = ((x + 1) * (x - 1) * (x - 2)) / 2.0f;
-	const float c2 = (-x * (x + 1) * (x - 2)) / 2.0f;
-	const float c3 = (x * (x + 1) * (x - 1)) / 6.0f;
-	return c0 * y0 + c1 * y1 + c2 * y2 + c3 * y3;
-}
 // Stereo::Delay::tap(float) klang.h:4668-4681: both channels read at the LEFT line's cursor, a*(1-frac) + b*frac form
 __device__ __forceinline__ void stereo_delay_tap(const Ring& l, const Ring& r, int position, float delay, float& outl, float& outr) {
 	float read = (float)(position - 1) - delay;

@@ -49,9 +49,9 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; if (o.code == OP_OSCSET) retuned[(size_t)o.node] = true; }
 	const bool fx = g.channels > 0;
 	std::vector<long long> ring_off(g.nodes.size(), 0); std::vector<int> inputs(g.nodes.size(), 0);   // Delay nodes: first row in the group's ring tile, inputs per sample
-	{ long long rows = 0; for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == N_DELAY) { ring_off[i] = rows; rows += g.arg((int)i); } }
+	{ long long rows = 0; for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == N_DELAY || g.nodes[i] == N_NDELAY) { ring_off[i] = rows; rows += g.arg((int)i); } }
 	for (const Op& o : g.ops) if (o.code == OP_DELAYIN) inputs[(size_t)o.node]++;
-	auto ring = [&](int node) { return fmt("Ring{ c.ring + (size_t)%lldll * FX_WG, FX_WG, %d }", ring_off[(size_t)node], g.arg(node)); };
+	auto ring = [&](int node) { return fmt("Ring{ c.ring + (size_t)%lldll * 64, 64, %d }", ring_off[(size_t)node], g.arg(node)); };   // 64 == FX_WG: one row of a ring position per wave
 	uint64_t mask[2] = { 1ull, 0ull };                                   // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
 	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { " + TI + " stage;", begin, end, body;
@@ -169,6 +169,12 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			mark(w0 + WT_POS, 1);
 			if (retuned[i]) { end += W(WT_INC, "f2u(" + n + ".inc)") + W(WT_FREQ, "f2u(" + n + "f)"); mark(w0 + WT_INC, 1); mark(w0 + WT_FREQ, 1); }
 			break;
+		case N_NDELAY:                                                   // a note's delay line: its own write cursor and read head (klang.h:3386-3388, 3475-3478)
+			live += fmt(" int n%zupos; Tap n%zut; float n%zutime;", i, i, i);
+			begin += "\t\t" + n + "pos = (int)" + R(ND_POS) + "; " + n + "t.position = (int)" + R(ND_LASTPOS) + "; " + n + "t.fraction = " + F(ND_LASTFRAC) + "; " + n + "time = " + F(ND_TIME) + ";\n";
+			end += W(ND_POS, "(uint32_t)" + n + "pos") + W(ND_LASTPOS, "(uint32_t)" + n + "t.position");
+			mark(w0 + ND_POS, 2);
+			break;
 		case N_DELAY:
 			live += fmt(" int n%zupos;", i);
 			begin += "\t\t" + n + fmt("pos = (int)((c.samples * %dull) %% %dull);\n", inputs[i], g.arg((int)i));     // Delay::position: one step per input()
@@ -263,6 +269,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			body += "\t\t}\n";
 			break;
 		case OP_NOISE: body += d + (o.imm ? "fast_noise(" : "basic_noise(") + fmt("c.rand[L.sidx * %d + %d]);\n", noise_calls, noise_k++); break;
+		case OP_DELAYOUT: body += d + "delay_process(" + ring(o.node) + ", " + n + "t);\n"; break;
 		case OP_TABREAD: body += d + fmt("table_read(c.tables, %uu, ", o.imm) + a + ");\n"; break;
 		case OP_PHI: break;                                         // assigned at the end of both sides (above)
 		case OP_STOPIF: {
@@ -287,7 +294,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	begin += prologue;
 	std::string s;
 	s += "// generated by klg_graph.hpp from a recorded klang process() body (include/klang_mi355_graph.h)\n";
-	s += fx ? "#include \"klg_fx.hpp\"\n" : "#include \"klg_render_x2.hpp\"\n";
+	s += fx ? "#include \"klg_fx.hpp\"\n" : "#include \"klg_render_x2.hpp\"\n#include \"klg_delay.hpp\"\n";
 	s += "#pragma clang fp contract(off)\nnamespace klg {\n";
 	s += "struct PatchGen {\n";
 	s += "\tstruct Rec { " + TU + fmt(" w[%d]; };\n\tstatic constexpr int kWords = %d;\n", NW, NW);
@@ -376,7 +383,7 @@ struct Rtc {
 	}
 };
 
-struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; int noise_calls = 0; bool x2 = false; };   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
+struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; int noise_calls = 0; bool x2 = false; std::vector<std::pair<long long, int>> delays; };   // delays: (first ring row, SIZE) of each delay node in node order   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
 
 // directory holding klg_kernels.hpp etc.: next to the shared library (klang_amd/csrc), or $KLG_GRAPH_SRC
 inline std::string source_dir() {
@@ -407,7 +414,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	Compiled c;
 	c.source = generate_source(g, x2);
 	c.words = g.words(); c.channels = g.channels; c.x2 = x2;
-	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY) c.ring_rows += g.arg((int)i);
+	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY || g.nodes[i] == graph::N_NDELAY) { c.delays.push_back({ c.ring_rows, g.arg((int)i) }); c.ring_rows += g.arg((int)i); }
 	c.noise_calls = g.noise_calls();
 	void* prog = nullptr;
 	if (rtc.CreateProgram(&prog, c.source.c_str(), "klg_graph_patch.hip", 0, nullptr, nullptr) != 0) return "hiprtcCreateProgram failed";

@@ -68,6 +68,7 @@ def scenarios():
     # Additive/Resynthesis.k: six partials weighted by `GAIN[o]->Amplitude` (dB -> linear on the host), user Oscillator::reset()
     out["ex_resynthesis"] = poly("ex_resynthesis", 24, [0, 1, 23], off_base=8)
     out["own_branches"] = poly("own_branches", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 0, 0.1)])
+    out["own_pluck"] = poly("own_pluck", 48, [0, 1, 7, 8, 47], off_base=10, notes=16, ctl_events=[(12, 0, 0.98), (20, 1, 0.6)])
     out["own_sample"] = poly("own_sample", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
     out["own_wavetable"] = poly("own_wavetable", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
