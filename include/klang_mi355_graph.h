@@ -67,7 +67,7 @@ enum NodeKind {
 	                                                                        klg_table_upload() returned for this note's samples (HBM; identical tables share an id) */
 	N_NDELAY = 24,  /* Delay<SIZE> member of a NOTE (physical models: a delay line per voice)  3381-3512   words: position (write cursor),
 	                                                                        last.position, last.fraction (the read head of Delay::process, set by set()), time;
-	                                                                        the ring of SIZE floats per voice lives in HBM, position-major over the 64 voices of a wave */
+	                                                                        the SIZE floats of each voice's line are contiguous in HBM (voices' cursors never line up) */
 	N_KINDS
 };
 enum { FSINE_INC = 0, FSINE_POS, FSINE_FREQ, FSINE_WORDS };

@@ -115,7 +115,7 @@ struct klg_synth {
 	struct Table { float* d; std::vector<float> h; uint64_t hash; };
 	std::vector<Table> tables;
 	TableDesc* d_tables = nullptr; size_t d_tables_cap = 0; bool tables_dirty = false;
-	float* d_note_rings = nullptr;               // note delays of a graph patch: [stride / 64][ring_rows][64]
+	float* d_note_rings = nullptr;               // note delays of a graph patch: [stride][ring_rows], each voice's lines contiguous
 	// host mirrors
 	std::vector<host::ControlH> controls;        // [S][nctl]
 	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
@@ -663,9 +663,8 @@ extern "C" int klg_voice_delay_clear(klg_synth* s, int voice, int delay_index) {
 	if (!s || !s->graph || !s->d_note_rings) return fail(KLG_ERR_INVALID, "klg_voice_delay_clear: the bank has no note delays (graph %p, %lld ring rows, lines %p)", s ? (const void*)s->graph : nullptr, s && s->graph ? s->graph->ring_rows : -1ll, s ? (const void*)s->d_note_rings : nullptr);
 	if (voice < 0 || voice >= s->V || delay_index < 0 || delay_index >= (int)s->graph->delays.size()) return fail(KLG_ERR_INVALID, "klg_voice_delay_clear: voice %d / delay %d out of range", voice, delay_index);
 	const long long row0 = s->graph->delays[(size_t)delay_index].first; const int size = s->graph->delays[(size_t)delay_index].second;
-	float* col = s->d_note_rings + ((size_t)(voice >> 6) * (size_t)s->graph->ring_rows + (size_t)row0) * 64 + (size_t)(voice & 63);
-	hipLaunchKernelGGL(klg_ring_clear, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, s->stream, col, size);
-	HIP_TRY(hipGetLastError());
+	float* line = s->d_note_rings + (size_t)voice * (size_t)s->graph->ring_rows + (size_t)row0;
+	HIP_TRY(hipMemsetAsync(line, 0, (size_t)size * sizeof(float), s->stream));
 	return 0;
 }
 

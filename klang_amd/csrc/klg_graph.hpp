@@ -51,7 +51,10 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	std::vector<long long> ring_off(g.nodes.size(), 0); std::vector<int> inputs(g.nodes.size(), 0);   // Delay nodes: first row in the group's ring tile, inputs per sample
 	{ long long rows = 0; for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == N_DELAY || g.nodes[i] == N_NDELAY) { ring_off[i] = rows; rows += g.arg((int)i); } }
 	for (const Op& o : g.ops) if (o.code == OP_DELAYIN) inputs[(size_t)o.node]++;
-	auto ring = [&](int node) { return fmt("Ring{ c.ring + (size_t)%lldll * 64, 64, %d }", ring_off[(size_t)node], g.arg(node)); };   // 64 == FX_WG: one row of a ring position per wave
+	// effects: position-major rows of 64 instances (all instances share the cursor: one coalesced row per access).  notes: each voice's
+	// line is contiguous — voices start at different times and have different lengths, so their cursors never line up; a lane walking its
+	// own line re-uses each 64-byte sector for 16 samples (measured 8x over the position-major layout, tools/pluck_bench.py)
+	auto ring = [&](int node) { return fx ? fmt("Ring{ c.ring + (size_t)%lldll * 64, 64, %d }", ring_off[(size_t)node], g.arg(node)) : fmt("Ring{ c.ring + (size_t)%lldll, 1, %d }", ring_off[(size_t)node], g.arg(node)); };
 	uint64_t mask[2] = { 1ull, 0ull };                                   // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
 	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { " + TI + " stage;", begin, end, body;

@@ -32,7 +32,7 @@ struct RenderArgs {
 	float* partials;          // [gridDim.x][n]
 	float* per_voice;         // [voices][n] or null
 	const TableDesc* tables;  // [tables] or null (klg_table_upload)
-	float* rings;             // note delays: [stride / 64][ring_rows][64] (a generated patch's Delay members), or null
+	float* rings;             // note delays: [stride][ring_rows] — each voice's lines contiguous (a generated patch's Delay members), or null
 	size_t ring_rows;         // ring positions per voice = the sum of the patch's Delay SIZEs
 };
 
@@ -44,12 +44,6 @@ template<class REC> struct RecWords {
 	__device__ __forceinline__ void to(REC& r) const { __builtin_memcpy(&r, w, sizeof(REC)); }
 	__device__ __forceinline__ void from(const REC& r) { __builtin_memcpy(w, &r, sizeof(REC)); }
 };
-
-// Delay::clear() of one voice's line (klang.h:3392-3394): `col` = the voice's column at the line's first row (stride 64)
-__global__ void klg_ring_clear(float* col, int size) {
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < size) col[(size_t)i * 64] = 0.f;
-}
 
 // all lanes of the wave have written / may read the wave's LDS tile
 __device__ __forceinline__ void wave_sync() {
@@ -106,7 +100,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		BlockCtx ctx;
 		ctx.fs = a.fs;
 		ctx.tables = a.tables;
-		ctx.ring = a.rings ? a.rings + (size_t)(v >> 6) * a.ring_rows * 64 + (size_t)(v & 63) : nullptr;
+		ctx.ring = a.rings ? a.rings + (size_t)v * a.ring_rows : nullptr;                   // this voice's lines, contiguous
 		ctx.ctl = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
 		// Dead lanes of a live wave run the same instruction stream on an all-zero record (no per-sample exec
 		// masking); their output is forced to 0 at the tile write and their record is never stored.

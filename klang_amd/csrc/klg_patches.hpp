@@ -23,7 +23,7 @@ struct BlockCtx {
 	SampleRate fs;
 	const float* ctl;        // this voice's synth instance controls [KLG_MAX_CTL]
 	const TableDesc* tables; // klg_table_upload()ed sample tables (graph patches with Wavetable / Table reads), else null
-	float* ring;             // this voice's column of its wave's note-delay rows (stride 64), else null
+	float* ring;             // this voice's note-delay lines (contiguous), else null
 };
 
 // ---------------------------------------------------------------------------------------------
