@@ -146,6 +146,9 @@ int klg_table_upload(klg_synth* s, const float* samples, int n, int dedup);
  * delay nodes in node order); queued in order with the blocks. */
 int klg_voice_delay_clear(klg_synth* s, int voice, int delay_index);
 int klg_graph_check(const char* program, int want_source, char* out, size_t out_cap);
+/* How many voices one GPU lane renders in this bank: 2 for the packed Subtractive kernel and for graph patches that run packed,
+ * else 1.  (Diagnostics / tests; no reference counterpart.) */
+int klg_synth_voices_per_lane(const klg_synth* s);
 /* The same for a recorded Effect::process() body (`kind effect 1|2` programs; replaces constructing `instances` copies of a
  * user klang::Effect / Stereo::Effect, klang.h:4190-4216, 4703-4717).  `initial_record`: the record words of one freshly
  * constructed instance (Program::words() x 4 bytes; NULL = zeros), every instance starts from it; Delay<SIZE> members become

@@ -63,6 +63,7 @@ def load():
         "klg_voices_upload": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), vp]),
         "klg_table_upload": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int, C.c_int]),
         "klg_voice_delay_clear": (C.c_int, [vp, C.c_int, C.c_int]),
+        "klg_synth_voices_per_lane": (C.c_int, [vp]),
         "klg_synth_create_graph": (vp, [C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_int]),
         "klg_graph_check": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
         "klg_fx_create_graph": (vp, [C.c_char_p, C.c_int, C.c_float, C.c_int, vp]),

@@ -125,6 +125,10 @@ class SynthBank:
         words = np.ascontiguousarray(words, dtype=np.uint32).reshape(len(voices), self.state_bytes // 4)
         check(self._L.klg_voices_upload(self._h, len(voices), voices.ctypes.data_as(C.POINTER(C.c_int)), words.ctypes.data_as(C.c_void_p)), "klg_voices_upload")
 
+    @property
+    def voices_per_lane(self):
+        return self._L.klg_synth_voices_per_lane(self._h)
+
     def table_upload(self, samples, dedup=True):
         """Copies a sample table to HBM (graph banks); returns its id: a wavetable node's `table` word / a tabread op's imm."""
         samples = np.ascontiguousarray(samples, dtype=np.float32)

@@ -264,6 +264,7 @@ extern "C" int klg_graph_check(const char* program, int want_source, char* out, 
 }
 
 extern "C" void klg_synth_destroy(klg_synth* s) { if (s && g_device >= 0) (void)hipSetDevice(g_device); synth_free(s); }
+extern "C" int klg_synth_voices_per_lane(const klg_synth* s) { if (!s) return KLG_ERR_INVALID; return ((s->patch == KLG_PATCH_SUB2A && s->x2) || (s->graph && s->graph->x2)) ? 2 : 1; }
 extern "C" int klg_synth_voices(const klg_synth* s) { return s ? s->V : KLG_ERR_INVALID; }
 extern "C" int klg_synth_controls(const klg_synth* s) { return s ? s->nctl : KLG_ERR_INVALID; }
 extern "C" size_t klg_synth_state_bytes(const klg_synth* s) { return s ? (size_t)s->W * 4 : 0; }

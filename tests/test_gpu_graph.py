@@ -42,6 +42,7 @@ def test_graph_sub2a_equals_handwritten_kernel(lanes, monkeypatch):
     hand = klang_amd.SynthBank("sub2a", synths=S, notes=P, max_block=N)
     gen = klang_amd.SynthBank(SUB2A_PROGRAM, synths=S, notes=P, max_block=N)
     assert gen.state_bytes == 25 * 4 and gen.voices == hand.voices
+    assert gen.voices_per_lane == (1 if lanes == "one voice per lane" else 2) and hand.voices_per_lane == 2
     rng = np.random.default_rng(4)
     held = []
     def mirror(voices):
@@ -180,6 +181,7 @@ def test_graph_two_voices_per_lane_reads_each_voices_own_controls(monkeypatch):
             b.set_control(sy, 0, 0.1 + 0.2 * sy); b.set_control(sy, 1, 1.9 - 0.3 * sy)
         return b
     one, two = make(True), make(False)
+    assert one.voices_per_lane == 1 and two.voices_per_lane == 2
     f = np.float32
     words = np.zeros((S * P, 1 + 6 + 3 + 9), np.uint32)
     for v in range(S * P):
