@@ -303,6 +303,15 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	s += "\tstruct Rec { " + TU + fmt(" w[%d]; };\n\tstatic constexpr int kWords = %d;\n", NW, NW);
 	s += fmt("\tstatic constexpr uint64_t kStoreMask = 0x%llxull;\n\tstatic constexpr uint64_t kStoreMask2 = 0x%llxull;\n", (unsigned long long)mask[0], (unsigned long long)mask[1]);
 	s += live;
+	if (!fx) {
+		// delay lines in notes: a wave keeps 64 voices x (read head, tap, write) x one 64-byte sector live while it walks its lines; at full
+		// occupancy the waves of an XCD hold more live sectors than its 4 MB L2 and every access becomes an HBM sector.  One wave per SIMD
+		// keeps the live set in L2: 3.3e10 voice*samples/s at 1 Mi voices against 2.5e10 / 2.4e10 / 2.2e10 with 2 / 3 / 4 (measured,
+		// tools/pluck_bench.py; KLG_NDELAY_WAVES overrides)
+		bool nd = false; for (int k : g.nodes) if (k == N_NDELAY) nd = true;
+		const char* e = getenv("KLG_NDELAY_WAVES");
+		if (nd) s += fmt("\tstatic constexpr int kWavesPerEu = %d;\n", e ? atoi(e) : 1);
+	}
 	if (fx) {
 		s += fmt("\tstatic constexpr int kChannels = %d;\n", g.channels);
 		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const FxCtx& c) {\n\t\tL.unused_ = 0; L.sidx = 0; (void)r; (void)c;\n" + begin + "\t}\n";
