@@ -73,6 +73,36 @@ def cpu_baseline(patch, block, budget_s=12.0):
             "sample": f"{patch}: 128 voices x {block} samples x {blocks} blocks, oracle/klang_oracle.c -O2 single thread, {os.cpu_count()} host cores present"}
 
 
+def cpu_reference(patch, block, budget_s=10.0):
+    """The GENUINE reference header (oracle/_ref/ref_subtractive: /root/reference/klang.h compiled where it lies, the binary travels)
+    on one host core, same bounded workload: 128 voices x `block` samples x M blocks; wall time of the whole run (process start,
+    128 note-ons and writing the mixes included: < 1 %).  None when the binary is not there."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_subtractive")
+    if patch != "sub2a" or not os.path.exists(exe):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenario_io import Scenario
+
+    def run(blocks):
+        s = Scenario(patch="sub2a", block=block, blocks=blocks, synths=1, notes=128, dump=[])
+        rng = np.random.default_rng(20250314)
+        for p in rng.integers(36, 97, size=128):
+            s.on(0, 0, int(p), 0.8)
+        with tempfile.TemporaryDirectory() as d:
+            scn, out = os.path.join(d, "s.scn"), os.path.join(d, "o.bin")
+            s.save(scn)
+            t0 = time.perf_counter()
+            subprocess.run([exe, scn, out], check=True, stdout=subprocess.DEVNULL)
+            return time.perf_counter() - t0
+    probe = run(1000)
+    blocks = int(max(1000, min(40000, 1000 * budget_s / max(probe, 1e-3))))
+    dt = run(blocks)
+    return {"value": 128 * block * blocks / dt, "unit": "voice*samples/s", "cores": 1, "kind": "reference",
+            "sample": f"{patch}: 128 voices x {block} samples x {blocks} blocks, the reference's klang.h v0.7.8 (oracle/_ref/ref_subtractive, clang++ -O2) single thread, {os.cpu_count()} host cores present"}
+
+
 def valu_issue(patch, V, N, kern_s):
     """VALU ISSUE-rate view of the sustain loop of klg_render_sub2a_x2 (the number that actually bounds this kernel): one wave =
     128 voices; per sample its steady-state loop issues 27.75 instructions (4x unrolled: 109 VALU + 2 ds_write2 per 4 samples)
@@ -228,7 +258,9 @@ def main():
                                   "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(args.patch, 0), **valu_issue(args.patch, V, N, kern_s)}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.patch, N)
+            port = cpu_baseline(args.patch, N, budget_s=8.0)                 # the C restatement (oracle/klang_oracle.c)
+            ref = cpu_reference(args.patch, N, budget_s=8.0)                 # the genuine header, where its binary travelled
+            out["cpu_baseline"] = dict(ref, port_value=port["value"], port_sample=port["sample"]) if ref else port
         print(json.dumps(out))
     bank.close()
     if world > 1:
