@@ -259,7 +259,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline(args.patch, N, budget_s=8.0)                 # the C restatement (oracle/klang_oracle.c)
-            ref = cpu_reference(args.patch, N, budget_s=8.0)                 # the genuine header, where its binary travelled
+            try:
+                ref = cpu_reference(args.patch, N, budget_s=8.0)             # the genuine header, where its binary travelled
+            except Exception as e:                                          # a baseline must never cost the bench line
+                print(f"bench.py: reference baseline unavailable ({e}); reporting the port", file=sys.stderr)
+                ref = None
             out["cpu_baseline"] = dict(ref, port_value=port["value"], port_sample=port["sample"]) if ref else port
         print(json.dumps(out))
     bank.close()
