@@ -216,6 +216,22 @@ def test_graph_two_voices_per_lane_reads_each_voices_own_controls(monkeypatch):
     one.close(); two.close()
 
 
+def test_table_and_delay_entry_points_reject_misuse():
+    import klang_amd
+    from klang_amd._lib import KlangError
+    hand = klang_amd.SynthBank("sub2a", synths=1, notes=4, max_block=64)
+    with pytest.raises(KlangError, match="only graph banks"):
+        hand.table_upload(np.zeros(8, np.float32))
+    assert hand._L.klg_voice_delay_clear(hand._h, 0, 0) < 0 and b"no note delays" in hand._L.klg_last_error()
+    hand.close()
+    g = klang_amd.SynthBank(WAVETABLE_PROGRAM, synths=1, notes=4, max_block=64)
+    with pytest.raises(KlangError, match="bad arguments"):
+        g.table_upload(np.zeros(1, np.float32))                     # a table needs two samples
+    assert g._L.klg_voice_delay_clear(g._h, 0, 0) < 0               # this program has no delay
+    assert g.voices_per_lane == 1                                   # wavetable nodes have no packed form
+    g.close()
+
+
 def test_graph_program_errors_are_reported():
     import klang_amd
     with pytest.raises(klang_amd.KlangError, match="operand a is not defined"):

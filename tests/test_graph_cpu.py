@@ -138,6 +138,22 @@ def test_two_voices_per_lane_form_and_the_three_bodies():
     assert rc < 0 and "two-voices-per-lane" in msg
 
 
+def test_wavetable_and_notedelay_nodes_belong_to_synth_programs():
+    ok = "klgg 1\nctl 0\nnode 0 notedelay 4800\nnode 1 wavetable\nop delayout 0 -1 -1 0 0\nop osc 1 -1 -1 1 0\nop add 2 0 1 -1 0\nop delayin -1 2 -1 0 0\nop const 3 -1 -1 -1 42c80000\nop delaytap 4 3 -1 0 0\nop tabread 5 4 -1 -1 1\nop add 6 2 5 -1 0\nret 6\nend\n"
+    rc, src = check(ok, want_source=True)
+    assert rc == 0, src
+    for needle in ("delay_process(Ring{ c.ring + (size_t)0ll, 1, 4800 }, L.n0t)", "wavetable_process(L.n1)", "table_read(c.tables, 1u, r4)", "static constexpr int kWavesPerEu = 1;", "uint32_t w[10]"):
+        assert needle in src, needle
+    for bad, msg in ((ok.replace("klgg 1\n", "klgg 1\nkind effect 1\n"), "only available to synth notes"),
+                     (ok.replace("node 0 notedelay 4800", "node 0 notedelay"), "delay needs its SIZE"),
+                     (ok.replace("op delayout 0 -1 -1 0 0", "op delayout 0 -1 -1 1 0"), "not a note delay"),
+                     (ok.replace("tabread 5 4 -1 -1 1", "tabread 5 4 -1 -1 0"), "table id 0 is reserved")):
+        rc, m = check(bad)
+        assert rc < 0 and msg in m, m
+    rc, m = check_mode(ok, 2)
+    assert rc < 0 and "two-voices-per-lane" in m
+
+
 def test_noise_is_an_effect_op_outside_branches():
     ok = "klgg 1\nkind effect 1\nctl 0\nop noise 0 -1 -1 -1 1\nop noise 1 -1 -1 -1 0\nop add 2 0 1 -1 0\nret 2\nend\n"
     rc, src = check(ok, want_source=True)
