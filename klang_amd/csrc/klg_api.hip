@@ -222,14 +222,16 @@ extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, in
 		if (!err.empty()) { fail(KLG_ERR_INVALID, "klg_synth_create_graph: %s", err.c_str()); return nullptr; }
 		if (!x2) break;
 		if (klg_ensure_device()) return nullptr;
-		// worth it while both voices' state fits ~160 registers (3 waves per SIMD): the recorded sub2a needs 129; a patch of seven
+		// worth it only for the smallest patches (tools/graph_width_bench.py, profiles/r01o_graph_width_bench.jsonl): one saw + biquad + ADSR
+		// (127-129 registers) gains 10 %, two saws (160) already lose 3 %, seven (296) lose 17 % — and a saw in its general form (duty != 0)
+		// loses 25 % even in the smallest.  Hence <= 130 registers; a patch of seven
 		// general OSM oscillators needs 250+ and renders 1.6x SLOWER packed (recorded SuperSaw.k, tools/graph_bench_supersaw.py)
 		hipModule_t m = nullptr; hipFunction_t fn = nullptr; int scratch = 1, regs = 1 << 20;
 		const bool loaded = hipModuleLoadData(&m, c->code.data()) == hipSuccess && hipModuleGetFunction(&fn, m, c->name[0].c_str()) == hipSuccess
 			&& hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn) == hipSuccess && hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn) == hipSuccess;
 		if (m) (void)hipModuleUnload(m);
 		const char* force = getenv("KLG_GRAPH_X2");
-		const bool keep = loaded && scratch == 0 && (regs <= 160 || (force && force[0] == '1'));
+		const bool keep = loaded && scratch == 0 && (regs <= 130 || (force && force[0] == '1'));
 		if (getenv("KLG_GRAPH_DEBUG")) fprintf(stderr, "klang-mi355: graph patch, two voices per lane: %s, %d registers, scratch %d bytes per lane -> %s\n", loaded ? "loaded" : "failed to load", regs, scratch, keep ? "used" : "one voice per lane");
 		if (keep) break;
 		x2 = false;
