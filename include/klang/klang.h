@@ -203,6 +203,8 @@ struct signal {
 	signal operator+(T x) const { return *this + signal((float)x); } signal operator-(T x) const { return *this - signal((float)x); } \
 	signal operator*(T x) const { return *this * signal((float)x); } signal operator/(T x) const { return *this / signal((float)x); }
 	KLANG_SIGNAL_OPS(float) KLANG_SIGNAL_OPS(double) KLANG_SIGNAL_OPS(int)
+	signal operator+(constant c) const { return *this + signal(c.f); } signal operator-(constant c) const { return *this - signal(c.f); }   // `x * root2`: the constant's float (klang.h:93-111)
+	signal operator*(constant c) const { return *this * signal(c.f); } signal operator/(constant c) const { return *this / signal(c.f); }
 #undef KLANG_SIGNAL_OPS
 	// reading a recorded value as a plain float leaves the program: not representable
 	void concrete_only(const char* what) const { if (reg >= 0) if (gpu::Recorder* r = gpu::recording()) r->fail(std::string(what) + " of a signal computed in process(): keep it a signal / param (a plain float cannot be recorded)"); }
@@ -880,6 +882,11 @@ inline void klang_gpu_unpack(void*, const uint32_t*) {}
 	inline void klang_gpu_pack(const NOTE* n, uint32_t* w) { BINDER::pack(*n, w); } \
 	inline void klang_gpu_unpack(NOTE* n, const uint32_t* w) { BINDER::unpack(*n, w); }
 
+// the same for an Effect type and a klg_patch id of an effect kernel (KLG_PATCH_PINGPONG, KLG_PATCH_REVERB): gpu::EffectBank<FX> then
+// creates the bank with klg_fx_create instead of recording FX::process()
+inline int klang_gpu_fx_patch(const void*) { return -1; }
+#define KLANG_GPU_BIND_FX(FX, PATCH) inline int klang_gpu_fx_patch(const FX*) { return PATCH; }
+
 struct NoteBinding { int patch; void (*pack)(const void*, uint32_t*); void (*unpack)(void*, const uint32_t*); };
 
 // A recorded Note type: the program, and where each node's object sits inside a Note of that type (every instance of the
@@ -1411,6 +1418,14 @@ template<class FX> struct EffectBank {
 	FX* fx = nullptr; klg_fx* h = nullptr; GraphLayout layout; int instances; int channels = FX::channels;
 	explicit EffectBank(int instances_, int max_block = 1024) : instances(instances_) {
 		using namespace klg::graph;
+		// an effect type tied to a hand-written kernel (KLANG_GPU_BIND_FX: the shipped PingPong.k / Reverb.k) is not recorded
+		const int bound = klang_gpu_fx_patch((const FX*)nullptr);
+		if (bound >= 0 && !std::getenv("KLANG_MI355_FORCE_GRAPH")) {
+			fx = new FX();
+			h = klg_fx_create(bound, instances, fs.f, max_block);
+			if (!h) { std::fprintf(stderr, "klang-mi355: klg_fx_create: %s\n", klg_last_error()); std::abort(); }
+			return;
+		}
 		Recorder R; R.effect = true; rec = &R;
 		R.constructing = true; fx = new FX(); R.constructing = false;
 		const char* lo = (const char*)fx; const char* hi = lo + sizeof(FX);

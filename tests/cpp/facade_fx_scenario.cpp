@@ -7,6 +7,9 @@
 #include <vector>
 
 #include PATCH_FILE
+#ifdef FX_BIND_LINE
+FX_BIND_LINE
+#endif
 
 struct Ev { int block, type, inst; float a, b; long seed; };
 

@@ -17,6 +17,34 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 NAMES = ["fx_gain", "fx_pan", "fx_rm", "fx_tremolo", "fx_eq", "fx_iir", "fx_wahwah", "fx_echo", "fx_feedback", "fx_flanger", "fx_moddelay", "fx_chorus", "fx_reverb1", "fx_clipping", "fx_mute", "fx_bands", "fx_objects", "fx_dpingpong", "fx_patterns"]
 
 
+def run_effect(name, tmp_path):
+    exe = os.path.join(ROOT, "oracle", "_ref", "facade_" + name)
+    if not os.path.exists(exe):
+        pytest.skip("built only where the reference's .k files exist (build container); the binary travels in oracle/_ref/")
+    ref = np.load(os.path.join(GOLDEN, name + ".npz"))["out"]                  # [B][K][CH][N]
+    B, K, CH, N = ref.shape
+    s = Scenario.load(os.path.join(GOLDEN, name + ".scn"))
+    t = np.arange(B * N, dtype=np.uint64)
+    x = np.stack([np.stack([fx_input(s.seed, k, c, t, s.burst) for c in range(CH)]) for k in range(K)])    # [K][CH][B*N]
+    x = x.reshape(K, CH, B, N).transpose(2, 0, 1, 3).copy()
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    x.astype(np.float32).tofile(fin)
+    subprocess.run([exe, os.path.join(GOLDEN, name + ".scn"), str(fin), str(fout)], check=True)
+    return np.fromfile(fout, np.float32).reshape(B, K, CH, N), ref
+
+
+def test_shipped_pingpong_k_bound_to_its_kernel_through_the_effect_bank(tmp_path):
+    """examples/PingPong.k (BASELINE config 4), compiled UNCHANGED against the facade with `KLANG_GPU_BIND_FX(PingPong, KLG_PATCH_PINGPONG)`:
+    klang::gpu::EffectBank<PingPong> creates the bank with klg_fx_create (the hand-written kernel) instead of recording process() —
+    which writes controls and branches on std::abs of a signal, so it cannot be traced.  Nine instances, control changes mid-run,
+    against the genuine header."""
+    got, ref = run_effect("fx_toppingpong", tmp_path)
+    peak = np.abs(ref).max()
+    exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+    print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e}")
+    assert exact == 1.0, f"max abs err {np.abs(got - ref).max()} (peak {peak})"
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_example_effect_recorded_as_graph_is_bit_exact(name, tmp_path):
     exe = os.path.join(ROOT, "oracle", "_ref", "facade_" + name)
