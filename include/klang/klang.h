@@ -845,6 +845,13 @@ public:
 	void set(param f, relative phase) override { set(f); set(phase); }
 };
 
+// Array<T, N> (klang.h:1373-1444): a counted fixed-capacity array
+template<typename TYPE, int CAPACITY> struct Array {
+	TYPE items[CAPACITY] = {}; unsigned count = 0;
+	void add(const TYPE& v) { if (count < (unsigned)CAPACITY) items[count++] = v; }
+	TYPE& operator[](int i) { return items[i]; } const TYPE& operator[](int i) const { return items[i]; }
+	unsigned size() const { return count; }
+};
 template<typename TYPE, int SIZE> struct Table {
 	TYPE items[SIZE] = {}; unsigned count = 0;
 	void add(const TYPE& v) { if (count < (unsigned)SIZE) items[count++] = v; }
@@ -1388,6 +1395,28 @@ namespace Stereo {
 		signal operator*(const signal& x) const { return { l * x.l, r * x.r }; } signal operator/(const signal& x) const { return { l / x.l, r / x.r }; }
 		signal operator*(const klang::signal& x) const { return { l * x, r * x }; } signal operator/(const klang::signal& x) const { return { l / x, r / x }; }
 		signal operator*(float x) const { return { l * x, r * x }; }
+		signal(float x) : l(x), r(x) {} signal(int x) : l((float)x), r((float)x) {} signal(double x) : l((float)x), r((float)x) {}
+		signal& operator+=(const signal& x) { l = l + x.l; r = r + x.r; return *this; }
+	};
+	inline signal operator*(Control& c, const signal& x) { return { c.value * x.l, c.value * x.r }; }
+	// Stereo::Modifier / Stereo::Bank<T> (klang.h:4560-4645): the types the shipped Reverb.k is written in.  They are here so that the
+	// file compiles unchanged; a patch built from them is tied to its hand-written kernel (KLANG_GPU_BIND_FX) — their process() is
+	// never recorded.
+	struct Modifier {
+		Stereo::signal in, out;
+		virtual ~Modifier() {}
+		virtual void process() { out = in; }
+		void operator<<(const Stereo::signal& x) { in = x; process(); }
+		operator const Stereo::signal&() { return out; }
+		Stereo::signal operator*(const klang::signal& x) { return out * x; }
+	};
+	template<class TYPE> struct Bank {
+		TYPE items[2];
+		Stereo::signal out;
+		template<typename... P> void set(P... p) { items[0].set(p...); items[1].set(p...); }
+		void operator<<(const Stereo::signal& x) { x.l >> items[0]; x.r >> items[1]; out = { klang::signal(items[0]), klang::signal(items[1]) }; }
+		operator const Stereo::signal&() { return out; }
+		TYPE& operator[](int i) { return items[i]; }
 	};
 	// Stereo::Delay<SIZE> (klang.h:4646-4699): a left and a right Delay<SIZE> advanced together
 	template<int SIZE> struct Delay {
@@ -1409,6 +1438,23 @@ namespace Stereo {
 	};
 }
 namespace stereo = Stereo;
+namespace Mono { typedef klang::Modifier Modifier; typedef klang::Generator Generator; typedef klang::signal signal; }
+namespace mono = Mono;
+// signals<N> / Matrix (klang.h:1273-1337, 1446-1470): a row of signals and the 4 x 4 feedback matrix of Reverb.k
+struct Matrix { float v[4][4]; constexpr float operator()(int r, int c) const { return v[r][c]; } };
+template<int N> struct signals {
+	signal value[N];
+	template<typename... A, std::enable_if_t<sizeof...(A) == N, int> = 0> signals(A&... a) : value{ signal(a)... } {}
+	signals() {}
+	signal& operator[](int i) { return value[i]; } const signal& operator[](int i) const { return value[i]; }
+	signals operator+(const signal& x) const { signals s; for (int i = 0; i < N; i++) s.value[i] = value[i] + x; return s; }
+	signals operator>>(const Matrix& m) const {                   // Matrix::operator>> klang.h:1457-1466 (rows = outputs)
+		static_assert(N == 4, "Matrix is 4 x 4");
+		signals s;
+		for (int r = 0; r < 4; r++) s.value[r] = value[0] * m(r, 0) + value[1] * m(r, 1) + value[2] * m(r, 2) + value[3] * m(r, 3);
+		return s;
+	}
+};
 
 namespace gpu {
 // `instances` copies of a user effect FX, rendered on the GPU.  The constructor builds ONE FX object with every primitive /

@@ -45,6 +45,17 @@ def test_shipped_pingpong_k_bound_to_its_kernel_through_the_effect_bank(tmp_path
     assert exact == 1.0, f"max abs err {np.abs(got - ref).max()} (peak {peak})"
 
 
+def test_shipped_reverb_k_bound_to_its_kernel_through_the_effect_bank(tmp_path):
+    """examples/Reverb.k (the other config-4 patch: Stereo::Modifier, Array, Stereo::Bank, signals<4> >> Matrix), compiled UNCHANGED
+    against the facade and tied to klg_fx_create(KLG_PATCH_REVERB) with KLANG_GPU_BIND_FX.  Its prepare() re-seeds rand() and redraws the
+    tap tables whenever a control changed: the scenario changes controls mid-run."""
+    got, ref = run_effect("fx_topreverb", tmp_path)
+    peak = np.abs(ref).max()
+    exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+    print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e} (peak {peak:.3f})")
+    assert exact == 1.0, f"max abs err {np.abs(got - ref).max()} (peak {peak})"
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_example_effect_recorded_as_graph_is_bit_exact(name, tmp_path):
     exe = os.path.join(ROOT, "oracle", "_ref", "facade_" + name)
