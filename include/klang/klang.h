@@ -1350,11 +1350,11 @@ template<int SIZE> struct Delay : Modifier, gpu::Packable {
 	}
 	template<typename TIME> signal operator()(const TIME& delay) {                 // klang.h:3491-3509: tap(int) for integers, tap(float) otherwise
 		static_assert(!std::is_integral_v<TIME>, "klang-mi355: Delay::operator()(int) (the un-interpolated tap) is not recorded yet: pass a float / signal time");
-		if (gpu::Recorder* r = gpu::recording()) { signal t; if constexpr (std::is_arithmetic_v<TIME>) t = signal((float)delay); else t = signal(delay); signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(t), -1, r->node(this, "Delay"), 0, true); return s; }
+		if (gpu::Recorder* r = gpu::recording()) { signal t; if constexpr (std::is_arithmetic_v<TIME>) t = signal((float)delay); else t = signal(const_cast<TIME&>(delay)); signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(t), -1, r->node(this, "Delay"), 0, true); return s; }
 		device_only("Delay::operator()");
 	}
 	void set(param samples) override {                                             // klang.h:3480-3489: place the read head `samples` behind the write cursor
-		if (gpu::no_set_while_recording("Delay::set(time)")) return;
+		if (samples.reg >= 0 && gpu::no_set_while_recording("Delay::set(time) with a recorded time")) return;   // a plain number only moves the host mirror (its use, `delay >> x` in an effect, is what cannot be recorded)
 		time = samples.value < SIZE ? samples.value : (float)SIZE;
 		float read = static_cast<float>(position - 1) - time;
 		if (read < 0.f) read += SIZE;

@@ -51,6 +51,9 @@ FX = {
 }
 FX["fx_toppingpong"] = [(0.2, 0.9), (0.005, 0.03), (0.0, 0.6), (0.05, 0.9), (0.3, 1.5), (0.005, 0.03)]   # the shipped examples/PingPong.k (config 4): bound to the hand-written kernel, not recorded
 FX["fx_topreverb"] = [(0.0, 1.0), (0.0, 1.0), (0.0, 1.0), (0.0, 1.0), (0.3, 1.0), (2.0, 60.0), (0.1, 1.0), (0.05, 1.0), (0.05, 1.0), (0.0, 0.2)]   # the shipped examples/Reverb.k (config 4): bound to the hand-written kernel
+# examples/Chorus.k (top level): a Stereo::Effect of two Mono::Modifier channels (each holding a Controls&), five triangle-LFO modulated taps
+# per channel set up in the channels' prepare(), recorded as the per-block prologue
+FX["fx_topchorus"] = [(0.2, 1.0), (0.05, 1.5), (0.1, 0.5), (1.0, 5.5), (0.1, 0.5), (2.0, 20.0)]
 SHAPE = {"fx_patterns": dict(K=4, blocks=110)}        # name -> instances / blocks (default 9 / 24)
 
 
