@@ -31,7 +31,9 @@
 //     (`if (in > 1) in = 1;`, `if (osc.frequency < fs.nyquist) out += osc / h;`): process() is then run once per outcome and the
 //     traces are merged into structured if / else / endif + phi ops (gpu::PathMerger).  Anything else (a signal forced to a plain
 //     float or int, set(f, phase) / reset() inside process()) stops with a message naming the construct.
-// Effects: klang::gpu::EffectBank<FX> records a user Effect / Stereo::Effect the same way (prepare() becomes the per-block prologue).
+// Effects: klang::gpu::EffectBank<FX> records a user Effect / Stereo::Effect the same way (prepare() becomes the per-block prologue);
+//   an effect type tied to a hand-written kernel with KLANG_GPU_BIND_FX (the shipped PingPong.k / Reverb.k) is created with
+//   klg_fx_create instead.  Stereo::Modifier, Stereo::Bank, Array, signals<N> and Matrix exist so that Reverb.k compiles unchanged.
 //
 // Reference interface citations (file:line) are into nashaudio/klang's klang.h v0.7.8.
 #pragma once
