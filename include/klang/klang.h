@@ -37,6 +37,7 @@
 //
 // Reference interface citations (file:line) are into nashaudio/klang's klang.h v0.7.8.
 #pragma once
+#define KLANG_MI355 1              // this is the MI355X façade, not the reference header (what a host may test to add a KLANG_GPU_BIND line)
 
 #include <cmath>
 #include <cstdint>
@@ -49,7 +50,9 @@
 #include <set>
 #include <string>
 #include <type_traits>
+#include <typeindex>
 #include <typeinfo>
+#include <unordered_map>
 #include <vector>
 
 #include "../klang_mi355.h"
@@ -86,26 +89,48 @@ inline void random(const unsigned seed) { std::srand(seed); klg_random_seed(seed
 // =================================================================================================
 struct signal;
 namespace gpu {
+// Which objects are ALIVE: every primitive / signal noted into an owner's construction log (below) gets a serial here and takes it
+// out again in its destructor, so a log entry whose address has since been destroyed (or re-used by another object) is recognised
+// as dead and never touched.
+struct LiveMap { std::unordered_map<const void*, uint64_t> serial; uint64_t next = 1; };
+inline thread_local LiveMap* live = nullptr;
+inline void forget(const void* p) { live->serial.erase(p); }
 // a primitive that lives in a lane record: host mirror <-> its block of record words (include/klang_mi355_graph.h)
-struct Packable { virtual void pack(uint32_t* w) const = 0; virtual void unpack(const uint32_t* w) = 0; virtual ~Packable() {} };
-struct Recorder {
-	struct Obj { const void* addr; size_t size; int kind; const Packable* packable; int arg; };     // a primitive or a signal member seen while the prototype Note / Effect was constructed (arg: Delay SIZE)
-	std::vector<Obj> objs;
+struct Packable { virtual void pack(uint32_t* w) const = 0; virtual void unpack(const uint32_t* w) = 0; virtual ~Packable() { if (live) forget(this); } };
+struct Obj { const void* addr; size_t size; int kind; const Packable* packable; int arg; const void* key = nullptr; uint64_t serial = 0; };     // a primitive or a signal member seen while a Note / Effect was constructed (arg: Delay SIZE; key / serial: liveness)
+// Where construction is noted: the Recorder of a prototype built by notes.add<T>() / gpu::EffectBank<FX> (members = the address range of
+// the object), or the construction LOG every Plugin / Note owns — what lets Effect::process(buffer) and Note::process(buffer) find the
+// members of an object the HOST constructed (`PingPong pingpong;`), whose type the base class does not know.
+struct Sink {
+	std::vector<Obj> objs; bool effect = false, tracked = false;
+	void note(const void* addr, size_t size, int kind, const Packable* p = nullptr, int arg = 0, const void* key = nullptr) {
+		if (!key) key = p ? (const void*)p : addr;
+		uint64_t serial = 0;
+		if (tracked) { if (!live) live = new LiveMap(); auto it = live->serial.find(key); serial = it != live->serial.end() ? it->second : (live->serial[key] = live->next++); }
+		for (Obj& o : objs) if (o.addr == addr && (!tracked || o.serial == serial)) { o.kind = kind; o.size = size; if (p) o.packable = p; return; }       // ADSR refines the Envelope it derives from
+		objs.push_back({ addr, size, kind, p, arg, key, serial });
+	}
+	bool alive(const Obj& o) const { if (!tracked) return true; if (!live) return false; const auto it = live->serial.find(o.key); return it != live->serial.end() && it->second == o.serial; }
+};
+// The log of one owner (a Plugin or a Note): open from the owner's base-class constructor — which runs before the members of the
+// derived class are constructed — until the first thing that can only happen after construction (controls are assigned or read, an
+// event, a block, the next owner's constructor).
+struct ConstructionLog : Sink { ConstructionLog() { tracked = true; } };
+inline thread_local ConstructionLog* log_target = nullptr;
+inline thread_local int log_suppress = 0;                    // notes.add<T>() builds 128 notes of a type it has already recorded: nothing to log
+inline void close_log() { log_target = nullptr; }
+struct Recorder : Sink {
 	bool constructing = false, recording = false;
 	klg::graph::Program prog;
 	int next_reg = 0, pending = -1;                              // pending: node whose finished() was just tested by an `if`
 	std::string error;
 	void fail(const std::string& what) { if (error.empty()) error = what; }
-	void note(const void* addr, size_t size, int kind, const Packable* p = nullptr, int arg = 0) {
-		for (Obj& o : objs) if (o.addr == addr) { o.kind = kind; o.size = size; if (p) o.packable = p; return; }       // ADSR refines the Envelope it derives from
-		objs.push_back({ addr, size, kind, p, arg });
-	}
 	int smooth_node(const void* smoothed_signal) {               // controls[i].smooth() inside an effect: one state word per smoothed control
 		for (size_t i = 0; i < objs.size(); i++) if (objs[i].addr == smoothed_signal) return (int)i;
 		objs.push_back({ smoothed_signal, sizeof(float) * 2, klg::graph::N_SMOOTH, nullptr, 0 });
 		return (int)objs.size() - 1;
 	}
-	bool effect = false;                                         // recording an Effect::process() (in / delay / smooth are available)
+	// (Sink::effect: recording an Effect::process() — in / delay / smooth are available)
 	// data-dependent branches: process() is run once per outcome (record_paths below); `decisions` is the outcome list this run
 	// follows, runs past its end take `true`.  Each test leaves an OP_IF marker (imm = the outcome taken) in the trace.
 	std::vector<char> decisions; size_t decision_pos = 0; bool may_branch = false;
@@ -149,7 +174,7 @@ struct Recorder {
 	}
 };
 inline thread_local Recorder* rec = nullptr;
-inline Recorder* constructing() { return (rec && rec->constructing) ? rec : nullptr; }
+inline Sink* constructing() { return (rec && rec->constructing) ? static_cast<Sink*>(rec) : static_cast<Sink*>(log_target); }
 inline Recorder* recording() { return (rec && rec->recording) ? rec : nullptr; }
 inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 // host-side set()/reset()/release() calls inside a recorded process() would have to run per sample on the device
@@ -181,7 +206,8 @@ struct signal {
 	signal(const int v) : value((float)v) { reg_member(); }
 	signal(const signal&) = default;
 	signal& operator=(const signal&) = default;
-	void reg_member() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(signal), klg::graph::N_PARAM); }
+	~signal() { if (gpu::live) gpu::forget(this); }           // (host side only: a member signal noted in a construction log leaves the live map)
+	void reg_member() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(signal), klg::graph::N_PARAM); }
 	static signal bin(int code, const signal& a, const signal& b, float concrete) {
 		gpu::Recorder* r = gpu::recording();
 		if (!r || (a.reg < 0 && b.reg < 0)) return signal(concrete);
@@ -282,7 +308,8 @@ struct Control {
 		}
 		smoothed = smoothed.value * 0.999f + (1.f - 0.999f) * value.value; return smoothed;
 	}
-	Control& set(float x) { value = (x < min) ? min : (max < x) ? max : x; return *this; }                    // klang.h:1725
+	bool touched = true;                                     // set() since the last block a gpu::FxRunner sent the controls (a set() overwrites what the effect wrote, even with the same value)
+	Control& set(float x) { value = (x < min) ? min : (max < x) ? max : x; touched = true; return *this; }    // klang.h:1725
 	float range() const { return max - min; }                                                                // klang.h:1719-1721: what a host's 0..1 parameter maps to
 	float normalised() const { const float v = value.value; return range() ? (v - min) / range() : (v < 0.f ? 0.f : (1.f < v ? 1.f : v)); }
 	void setNormalised(float norm) { value = norm * range() + min; }
@@ -327,9 +354,12 @@ struct Group {                                          // klang.h:1853-1873: `{
 };
 struct Controls {
 	std::vector<Control> items; float cache[128] = { 0 };
-	void operator=(std::initializer_list<Group> l) { items.clear(); for (const Group& g : l) for (const Control& c : g.controls) { items.push_back(c); items.back().index = (int)items.size() - 1; } }   // klang.h:1895-1902
-	Control& operator[](int i) { return items[(size_t)i]; }
-	unsigned size() const { return (unsigned)items.size(); }
+	// (controls are assigned in the constructor BODY of a plugin and read by its host: either way every member of the plugin has been
+	//  constructed, so the owner's construction log ends here)
+	void operator=(std::initializer_list<Group> l) { gpu::close_log(); items.clear(); for (const Group& g : l) for (const Control& c : g.controls) { items.push_back(c); items.back().index = (int)items.size() - 1; } }   // klang.h:1895-1902
+	Control& operator[](int i) { gpu::close_log(); return items[(size_t)i]; }
+	const Control& operator[](int i) const { return items[(size_t)i]; }
+	unsigned size() const { gpu::close_log(); return (unsigned)items.size(); }
 	bool changed() { bool c = false; for (size_t i = 0; i < items.size(); i++) if (items[i].value.value != cache[i]) { cache[i] = items[i].value.value; c = true; } return c; }   // klang.h:1914
 };
 struct Preset { std::string name; std::vector<float> values; Preset(const char* n, std::initializer_list<double> v) : name(n) { for (double x : v) values.push_back((float)x); } };
@@ -497,7 +527,7 @@ namespace Basic {
 	// Generic::Oscillator set() (klang.h:2862-2880) + the five Basic waveforms (4899-4944); process() is device code
 	struct Osc : Oscillator, gpu::Packable {
 		klg::host::BOscH h; float duty_ = 0.5f; int kind;
-		explicit Osc(int k) : kind(k) { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Osc), k, this); }
+		explicit Osc(int k) : kind(k) { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Osc), k, this); }
 		using Oscillator::set;
 		void reset() override { if (gpu::no_set_while_recording("Basic oscillator reset()")) return; h.position = 0; }
 		void set(param f) override {
@@ -539,7 +569,7 @@ namespace Fast {
 	struct Noise : NoiseBase { Noise() : NoiseBase(1) {} };
 	struct Sine : Oscillator, gpu::Packable {
 		klg::host::FSineH h;
-		Sine() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Sine), klg::graph::N_FSINE, this); }
+		Sine() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Sine), klg::graph::N_FSINE, this); }
 		using Oscillator::set;
 		void reset() override { if (gpu::no_set_while_recording("Fast::Sine::reset()")) return; h.pos = 0; }                        // klang.h:5136-5140
 		void set(param f) override {
@@ -557,7 +587,7 @@ namespace Fast {
 	};
 	struct Osm : Oscillator, gpu::Packable {
 		klg::host::OsmH h; int waveform;             // 0 = saw family, 1 = pulse family
-		Osm(int wf, float duty) : h(duty), waveform(wf) { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Osm), wf ? klg::graph::N_PULSE : klg::graph::N_SAW, this); }
+		Osm(int wf, float duty) : h(duty), waveform(wf) { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Osm), wf ? klg::graph::N_PULSE : klg::graph::N_SAW, this); }
 		using Oscillator::set;
 		void set(param f) override {
 			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Fast oscillator"), 0, false); frequency = f; return; }
@@ -591,7 +621,7 @@ namespace Biquad {
 	// Biquad::Filter (klang.h:5550-5652): one host design per type, one type-independent process() on the device
 	struct Filter : Modifier, gpu::Packable {
 		klg::host::BiquadLpfH h;
-		explicit Filter(int type) { h.type = type; if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Filter), klg::graph::N_LPF, this); }
+		explicit Filter(int type) { h.type = type; if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Filter), klg::graph::N_LPF, this); }
 		void reset() { if (gpu::no_set_while_recording("Biquad filter reset()")) return; h.reset(); }
 		using Modifier::set;
 		void set(param f) override { set(f, param(h.type == klg::host::BQ_APF ? 1.f : klg::host::ROOT2_INV)); }
@@ -620,7 +650,7 @@ namespace Biquad {
 	// Filters::DCF klang.h:5386-5397
 	struct DCF : Modifier, gpu::Packable {
 		float r = 0.995f, z = 0;
-		DCF() { if (gpu::Recorder* rr = gpu::constructing()) rr->note(this, sizeof(DCF), klg::graph::N_DCF, this); }
+		DCF() { if (gpu::Sink* rr = gpu::constructing()) rr->note(this, sizeof(DCF), klg::graph::N_DCF, this); }
 		using Modifier::set;
 		void set(float r_) { r = r_; }
 		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "DCF"); return; } device_only("DCF::process()"); }
@@ -631,7 +661,7 @@ namespace Biquad {
 	template<int ORDER> struct IIR;
 	template<> struct IIR<1> : Modifier, gpu::Packable {
 		float a = 1, b = 0;
-		IIR() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(IIR<1>), klg::graph::N_IIR1, this); }
+		IIR() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(IIR<1>), klg::graph::N_IIR1, this); }
 		using Modifier::set;
 		void set(param coeff) override { if (gpu::no_set_while_recording("IIR<1>::set()")) return; a = coeff; b = 1.f - a; }
 		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "IIR<1>"); return; } device_only("IIR<1>::process()"); }
@@ -642,7 +672,7 @@ namespace OnePole {
 	// OnePole::Filter / LPF / HPF klang.h:5470-5543
 	struct Filter : Modifier, gpu::Packable {
 		klg::host::OnePoleH h;
-		explicit Filter(bool hpf) { h.hpf = hpf; if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Filter), hpf ? klg::graph::N_OPHPF : klg::graph::N_OPLPF, this); }
+		explicit Filter(bool hpf) { h.hpf = hpf; if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Filter), hpf ? klg::graph::N_OPHPF : klg::graph::N_OPLPF, this); }
 		void reset() { if (gpu::no_set_while_recording("OnePole reset()")) return; h.reset(); }
 		using Modifier::set;
 		void set(param f) override { if (gpu::no_set_while_recording("OnePole set(f)")) return; h.set(f, host_fs()); }
@@ -657,7 +687,7 @@ namespace Butterworth {
 	template<int ORDER> struct LPF;
 	template<> struct LPF<1> : Modifier, gpu::Packable {                        // klang.h:5786-5799
 		klg::host::Butter1H h;
-		LPF() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(LPF<1>), klg::graph::N_BUTTER1, this); }
+		LPF() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(LPF<1>), klg::graph::N_BUTTER1, this); }
 		using Modifier::set;
 		void set(param f) override { if (gpu::no_set_while_recording("Butterworth::LPF<1>::set()")) return; h.set(f, host_fs()); }
 		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "Butterworth::LPF<1>"); return; } device_only("Butterworth::LPF<1>::process()"); }
@@ -671,7 +701,7 @@ namespace Modifiers {
 	// Modifiers::Modal klang.h:5815-5859
 	struct Modal : Modifier, gpu::Packable {
 		klg::host::ModalH h;
-		Modal() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Modal), klg::graph::N_MODAL, this); }
+		Modal() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Modal), klg::graph::N_MODAL, this); }
 		using Modifier::set;
 		void set(param f, param decay) override { if (gpu::no_set_while_recording("Modal::set()")) return; h.set(f, decay, host_fs()); in = 0; out = 0; }
 		void set(param f, param decay, param gain) override { if (gpu::no_set_while_recording("Modal::set()")) return; h.set(f, decay, gain.value, host_fs()); in = 0; out = 0; }
@@ -688,7 +718,7 @@ struct Envelope : Generator, gpu::Packable {
 	struct Point { float x, y; Point() : x(0), y(0) {} template<class A, class B> Point(A a, B b) : x(float(a)), y(float(b)) {} };
 	enum Stage { Sustain, Release, Off };
 	klg::host::EnvH h;
-	void reg_member() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Envelope), klg::graph::N_ENV, this); }
+	void reg_member() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Envelope), klg::graph::N_ENV, this); }
 	Envelope() { reg_member(); const float one[2] = { 0.f, 1.f }; h.set_points(1, one, host_fs()); }
 	Envelope(std::initializer_list<Point> p) { reg_member(); assign(p); }
 	Envelope& operator=(std::initializer_list<Point> p) { assign(p); return *this; }
@@ -715,7 +745,7 @@ struct Envelope : Generator, gpu::Packable {
 };
 struct ADSR : Envelope {
 	klg::host::AdsrH a;
-	ADSR() { if (gpu::Recorder* r = gpu::constructing()) r->note(static_cast<Envelope*>(this), sizeof(ADSR), klg::graph::N_ADSR, this); set(0.5, 0.5, 1, 0.5); }
+	ADSR() { if (gpu::Sink* r = gpu::constructing()) r->note(static_cast<Envelope*>(this), sizeof(ADSR), klg::graph::N_ADSR, this); set(0.5, 0.5, 1, 0.5); }
 	using Envelope::set;
 	void set(param attack, param decay, param sustain, param release) override { if (gpu::no_set_while_recording("ADSR::set()")) return; a.set(attack, decay, sustain, release, host_fs()); h = a.env; }
 	void pack(uint32_t* w) const override {
@@ -729,12 +759,12 @@ struct ADSR : Envelope {
 // ---- Envelope::Follower (klang.h:5862-5903): the AR smoother with abs / square-sqrt around it ----
 struct Envelope::Follower : Modifier, gpu::Packable {
 	klg::host::FollowerArH ar; Mode mode = RMS;
-	Follower() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Follower), klg::graph::N_FOLLOWRMS, this); set(0.01f, 0.1f); }
+	Follower() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Follower), klg::graph::N_FOLLOWRMS, this); set(0.01f, 0.1f); }
 	using Modifier::set;
 	void set(param attack, param release) override { if (gpu::no_set_while_recording("Envelope::Follower::set()")) return; ar.set(attack, release, host_fs()); }
 	Follower& operator=(Mode m) {                                              // klang.h:5892-5895 (choose before the Synth is created: the mode is part of the recorded program)
 		mode = m;
-		if (gpu::Recorder* r = gpu::rec) r->note(this, sizeof(Follower), m == RMS ? klg::graph::N_FOLLOWRMS : klg::graph::N_FOLLOWPEAK, this);
+		if (gpu::Sink* r = gpu::rec ? static_cast<gpu::Sink*>(gpu::rec) : static_cast<gpu::Sink*>(gpu::log_target)) r->note(this, sizeof(Follower), m == RMS ? klg::graph::N_FOLLOWRMS : klg::graph::N_FOLLOWPEAK, this);
 		return *this;
 	}
 	void process() override { if (gpu::recording()) { gpu::record_modifier(this, "Envelope::Follower"); return; } device_only("Envelope::Follower::process()"); }
@@ -745,7 +775,7 @@ struct Envelope::Follower : Modifier, gpu::Packable {
 // ---- FM operator (klang.h:4140-4180) ----
 template<class OSC> struct Operator : OSC, Input {
 	Envelope env; Amplitude amp = 1.f;
-	Operator() { if (gpu::Recorder* r = gpu::constructing()) r->note(static_cast<OSC*>(this), sizeof(Operator), klg::graph::N_OPERATOR, static_cast<gpu::Packable*>(static_cast<OSC*>(this))); }
+	Operator() { if (gpu::Sink* r = gpu::constructing()) r->note(static_cast<OSC*>(this), sizeof(Operator), klg::graph::N_OPERATOR, static_cast<gpu::Packable*>(static_cast<OSC*>(this))); }
 	Operator& operator()(param f) { OSC::set(f); return *this; }
 	Operator& operator()(param f, relative phase) { OSC::set(f, phase); return *this; }
 	Operator& operator=(std::initializer_list<Envelope::Point> p) { env = p; return *this; }
@@ -784,16 +814,63 @@ template<typename TYPE> struct Result {
 	TYPE& operator++(int) { i++; return *++y; }
 };
 #define FUNCTION(type) (void(*)(type, klang::Result<type>&))[](type x, klang::Result<type>& y)
-// klang::buffer (klang.h:1983-2136) as far as a host needs it here: a view of caller-owned samples (what a Sample attaches to)
+// klang::buffer (klang.h:1983-2136): a cursor over caller-owned samples (`buffer(float*, int)`: what a host hands to
+// Effect::process(buffer) / Note::process(buffer)) or over an owned array padded to the next power of two (`buffer(int size)`).  In the
+// reference a signal IS a float, so the cursor hands out `signal&` into the sample array; here a signal also carries its recording
+// register, so element access goes through `sample`, a reference-like proxy with the same reads, writes and compound assignments
+// (`buffer++ = out`, `buffer += x`, `buffer[i] = y`, `signal s = buffer`).
 class buffer {
-	float* samples_;
+protected:
+	static constexpr unsigned capacity(unsigned n) { n--; n |= n >> 1; n |= n >> 2; n |= n >> 4; n |= n >> 8; n |= n >> 16; return n + 1; }    // klang.h:1986-1997
+	unsigned mask = 0xFFFFFFFFu; bool owned = false;
+	float* samples; float* ptr; float* end;
 public:
+	struct sample {                                                            // `signal&` of the reference: one element of the array
+		float* p;
+		operator signal() const { return signal(*p); }
+		operator float() const { return *p; }
+		sample& operator=(const signal& in) { *p = in.value; return *this; }
+		sample& operator=(const sample& in) { *p = *in.p; return *this; }
+		sample& operator=(float in) { *p = in; return *this; }
+		sample& operator+=(const signal& in) { *p += in.value; return *this; }
+		sample& operator-=(const signal& in) { *p -= in.value; return *this; }
+		sample& operator*=(const signal& in) { *p *= in.value; return *this; }
+		sample& operator/=(const signal& in) { *p /= in.value; return *this; }
+	};
+	typedef klang::signal signal;
 	const int size;
-	buffer(float* data, int size_) : samples_(data), size(size_) {}
-	float operator[](int i) const { return samples_[i]; }
-	const float* data() const { return samples_; }
+	buffer(float* data, int size_) : samples(data), size(size_) { rewind(); }                                            // klang.h:2007-2010 (not owned: mask stays all ones)
+	buffer(float* data, int size_, float initial) : samples(data), size(size_) { rewind(); set(initial); }
+	buffer(int size_ = 1, float initial = 0) : mask(capacity((unsigned)size_) - 1u), owned(true), samples(new float[capacity((unsigned)size_)]), size(size_) { rewind(); set(initial); }
+	// a copy is a view of the same samples at the same cursor (process(buffer) takes its buffer BY VALUE: every note restarts where the caller's cursor stands)
+	buffer(const buffer& b) : mask(b.mask), owned(false), samples(b.samples), ptr(b.ptr), end(b.end), size(b.size) {}
+	virtual ~buffer() { if (owned) delete[] samples; }
+	void attach(const buffer& b, int n = 0) { samples = b.samples; rewind(); end = samples + n; }
+	void rewind(int offset = 0) { ptr = samples + offset; end = samples + size; }                                       // klang.h:2035-2041
+	void clear() { std::memset(samples, 0, sizeof(float) * (size_t)size); }
+	void clear(int n) { std::memset(samples, 0, sizeof(float) * (size_t)(n < size ? n : size)); }
+	int offset() const { return int(samples - ptr); }                                                                   // (the reference's sign: klang.h:2051-2053)
+	void set(float value = 0) { if (value == 0) clear(); else for (int i = 0; i < size; i++) samples[i] = value; }
+	sample operator[](int i) { return sample{ &samples[(unsigned)i & mask] }; }                                         // klang.h:2062-2064 (masked)
+	float operator[](int i) const { return samples[i]; }                                                                // klang.h:2080-2082
+	signal operator[](float o) const {                                                                                  // klang.h:2070-2078 (linear read, wraps at size - 1)
+		const float f = std::floor(o), frac = o - f;
+		const int i = (int)o, j = (i == size - 1) ? 0 : i + 1;
+		return signal(samples[i] * (1.f - frac) + samples[j] * frac);
+	}
+	operator signal() const { return signal(*ptr); }                                                                    // klang.h:2084-2090
+	explicit operator double() const { return *ptr; }
+	bool finished() const { return ptr == end; }                                                                        // klang.h:2096
+	sample operator++(int) { return sample{ ptr++ }; }                                                                  // klang.h:2100-2102
+	sample operator=(const signal& in) { *ptr = in.value; return sample{ ptr }; }                                       // klang.h:2104-2106
+	sample operator+=(const signal& in) { *ptr += in.value; return sample{ ptr }; }
+	sample operator*=(const signal& in) { *ptr *= in.value; return sample{ ptr }; }
+	buffer& operator=(const buffer& in) { std::memcpy(samples, in.samples, (size_t)(size < in.size ? size : in.size) * sizeof(float)); return *this; }   // klang.h:2118-2121
+	buffer& operator<<(const signal& in) { *ptr = in.value; return *this; }
+	float* data() { return samples; } const float* data() const { return samples; }
+	float* cursor() const { return ptr; } int remaining() const { return int(end - ptr); }                              // (what the block entry points hand to the GPU)
+	void advance(int n) { ptr += n; }
 };
-
 // ---- Wavetable / Sample (klang.h:3626-3720): the samples live in HBM (klg_table_upload); a note's record names them by id ----
 namespace gpu { inline thread_local klg_synth* upload_target = nullptr; }   // the bank a voice record is being packed for (SynthCore sets it)
 class Wavetable : public Oscillator, public gpu::Packable {
@@ -801,7 +878,7 @@ protected:
 	std::vector<signal> samples; int size;
 	float increment = 0.f, position = 0.f, offset = 0.f;
 	mutable int table_id = -1; mutable bool dirty = true;
-	void announce() { if (gpu::Recorder* r = gpu::constructing()) r->note(this, sizeof(Wavetable), klg::graph::N_WAVETABLE, this); }
+	void announce() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Wavetable), klg::graph::N_WAVETABLE, this); }
 public:
 	using Oscillator::set;
 	Wavetable(int size_ = 2048) : samples((size_t)size_), size(size_) { announce(); }
@@ -894,7 +971,7 @@ inline void klang_gpu_unpack(void*, const uint32_t*) {}
 // the same for an Effect type and a klg_patch id of an effect kernel (KLG_PATCH_PINGPONG, KLG_PATCH_REVERB): gpu::EffectBank<FX> then
 // creates the bank with klg_fx_create instead of recording FX::process()
 inline int klang_gpu_fx_patch(const void*) { return -1; }
-#define KLANG_GPU_BIND_FX(FX, PATCH) inline int klang_gpu_fx_patch(const FX*) { return PATCH; }
+// (KLANG_GPU_BIND_FX is defined with the effect classes below: it also registers the type for Effect::process(buffer))
 
 struct NoteBinding { int patch; void (*pack)(const void*, uint32_t*); void (*unpack)(void*, const uint32_t*); };
 
@@ -1116,232 +1193,184 @@ struct Controller {
 protected:
 	virtual event control(int, float) {}
 	virtual event preset(int) {}
+	virtual event midi(int, int, int) {}
 public:
 	virtual ~Controller() {}
 	virtual void onControl(int index, float value) { control(index, value); }
 	virtual void onPreset(int index) { preset(index); }
+	virtual void onMIDI(int status, int byte1, int byte2) { midi(status, byte1, byte2); }                  // klang.h:4191
 };
-struct Plugin : Controller { Controls controls; Presets presets; };
-
-template<class SYNTH> class NoteBase : public Controller {
-	SYNTH* synth = nullptr;
-protected:
-	virtual event on(Pitch, Velocity) {}
-	virtual event off(Velocity = 0) { stage = Off; }
-public:
-	struct ControlsRef { Controls* c = nullptr; Control& operator[](int i) { return (*c)[i]; } unsigned size() { return c ? c->size() : 0; } } controls;
-	Pitch pitch; Velocity velocity;
-	enum Stage { Onset, Sustain, Release, Off } stage = Off;
-	void attach(SYNTH* s) { synth = s; controls.c = &s->controls; }
-	virtual void start(Pitch p, Velocity v) { stage = Onset; pitch = p; velocity = v; on(pitch, velocity); stage = Sustain; }    // klang.h:4257-4263
-	virtual bool release(Velocity v = 0) { if (stage == Off) return true; if (stage != Release) { stage = Release; off(v); } return stage == Off; }
-	virtual bool stop(Velocity = 0) {
-		if (gpu::Recorder* r = gpu::recording()) {                 // `if (adsr.finished()) stop();` / `stop();` in a recorded process()
-			if (r->pending >= 0) { const int n = r->pending; r->emit(klg::graph::OP_STOPIF, -1, -1, n, 0, false); r->pending = -1; }
-			else r->emit(klg::graph::OP_STOP, -1, -1, -1, 0, false);
-			return true;
-		}
-		stage = Off; return true;
-	}
-	bool finished() const { return stage == Off; }
+namespace gpu {
+// Every Plugin and every Note owns the log of its own construction (gpu::ConstructionLog): the base-class constructor below runs
+// BEFORE the members of the user's class are constructed, so from here on each primitive / signal member announces itself into
+// this log — which is how Effect::process(buffer) / Note::process(buffer) later find the members of an object that the HOST
+// constructed (`PingPong pingpong;` in a plugin processor), with no template parameter naming its type.
+struct Owner {
+	ConstructionLog log;
+	explicit Owner(bool effect) { log.effect = effect; if (!(rec && rec->constructing) && !log_suppress) log_target = &log; }
+	Owner(const Owner& o) { log.effect = o.log.effect; }                     // a copy has a log of its own (empty: its members were copied, not constructed)
+	Owner& operator=(const Owner&) { return *this; }
+	~Owner() { if (log_target == &log) log_target = nullptr; }
 };
+// the members among what a sink saw: inside [lo, hi) (a prototype built under a Recorder) or still alive (an owner's log); signals
+// inside a primitive belong to the primitive
+inline std::vector<Obj> member_objs(const Sink& sink, const char* lo, const char* hi) {
+	std::vector<Obj> in, kept;
+	for (const Obj& o : sink.objs) {
+		const char* a = (const char*)o.addr;
+		if (hi ? (a < lo || a >= hi) : !sink.alive(o)) continue;
+		in.push_back(o);
+	}
+	for (const Obj& o : in) {
+		const char* a = (const char*)o.addr;
+		bool inside = false;
+		if (o.kind == klg::graph::N_PARAM) for (const Obj& q : in) if (q.kind != klg::graph::N_PARAM && a >= (const char*)q.addr && a < (const char*)q.addr + q.size) inside = true;
+		if (!inside) kept.push_back(o);
+	}
+	return kept;
+}
+// effect types tied to a hand-written kernel, by dynamic type (what Effect::process(buffer) can look up from `*this`)
+inline std::map<std::type_index, int>& fx_bindings() { static std::map<std::type_index, int> m; return m; }
+inline bool register_fx(const std::type_info& t, int patch) { fx_bindings()[std::type_index(t)] = patch; return true; }
+inline int fx_binding(const std::type_info& t) { const auto it = fx_bindings().find(std::type_index(t)); return it == fx_bindings().end() ? -1 : it->second; }
+}
+#define KLANG_GPU_BIND_FX_CAT2(a, b) a##b
+#define KLANG_GPU_BIND_FX_CAT(a, b) KLANG_GPU_BIND_FX_CAT2(a, b)
+#define KLANG_GPU_BIND_FX(FX, PATCH) inline int klang_gpu_fx_patch(const FX*) { return PATCH; } \
+	static const bool KLANG_GPU_BIND_FX_CAT(klang_gpu_fx_registered_, __LINE__) = klang::gpu::register_fx(typeid(FX), PATCH);
 
-// =================================================================================================
-// Synth: host voice allocation + event dispatch; blocks rendered by libklang_mi355.so
-// =================================================================================================
-template<class NOTEBASE> struct SynthCore : Plugin {
-	struct Slot { NOTEBASE* note = nullptr; NoteBinding b = { -1, nullptr, nullptr }; const gpu::GraphLayout* graph = nullptr; };
-	struct NotesT {
-		SynthCore* owner; std::vector<Slot> items; unsigned noteOns = 0; unsigned noteStart[128] = { 0 };
-		unsigned count = 0;
-		std::vector<gpu::GraphLayout*> layouts;
-		template<class T> void add(int n) {
-			const bool bound = klang_gpu_patch((const T*)nullptr) >= 0 && !std::getenv("KLANG_MI355_FORCE_GRAPH");
-			const gpu::GraphLayout* layout = nullptr;
-			for (int i = 0; i < n && items.size() < 128; i++) {
-				T* t = nullptr;
-				if (!bound && !layout) { gpu::GraphLayout* l = new gpu::GraphLayout(); layouts.push_back(l); t = record<T>(*l); layout = l; }   // the prototype becomes note 0
-				else { t = new T(); t->attach(static_cast<typename T::synth_type*>(owner)); }
-				Slot s; s.note = t; s.graph = layout;
-				s.b.patch = bound ? klang_gpu_patch((const T*)t) : -1;
-				s.b.pack = [](const void* p, uint32_t* w) { klang_gpu_pack((const T*)p, w); };
-				s.b.unpack = [](void* p, const uint32_t* w) { klang_gpu_unpack((T*)p, w); };
-				items.push_back(s); count = (unsigned)items.size();
-			}
-		}
-		// Construct the prototype Note with every primitive / signal member announcing itself, run its process() once in
-		// recording mode, and turn what was recorded into a graph program + the member layout of the Note type.
-		template<class T> T* record(gpu::GraphLayout& L) {
-			using namespace klg::graph;
-			gpu::Recorder R;
-			gpu::rec = &R;
-			R.constructing = true;
-			T* t = new T();
-			R.constructing = false;
-			t->attach(static_cast<typename T::synth_type*>(owner));
-			const char* lo = (const char*)t; const char* hi = lo + sizeof(T);
-			std::vector<gpu::Recorder::Obj> kept;                            // members of THIS note; signals inside a primitive belong to the primitive
-			for (const auto& o : R.objs) {
-				const char* a = (const char*)o.addr;
-				if (a < lo || a >= hi) continue;
-				bool inside = false;
-				if (o.kind == N_PARAM) for (const auto& q : R.objs) if (q.kind != N_PARAM && a >= (const char*)q.addr && a < (const char*)q.addr + q.size) inside = true;
-				if (!inside) kept.push_back(o);
-			}
-			R.objs = kept;
-			Controls& ctl = owner->controls;
-			R.prog.nctl = (int)ctl.size() < 8 ? (int)ctl.size() : 8;
-			for (int c = 0; c < R.prog.nctl; c++) R.prog.dials[c] = { ctl[c].min, ctl[c].max, ctl[c].initial };
-			// ---- record ----
-			R.recording = true;
-			std::vector<int> first_reg(R.objs.size(), -1);
-			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; first_reg[i] = sg->reg = R.emit(OP_PARAM, -1, -1, (int)i, 0, true); }
-			for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = R.emit(OP_CTL, -1, -1, -1, (uint32_t)c, true);
-			// `osc.frequency` read inside process(): the node's current frequency (what on() or a recorded set(f) left there)
-			std::vector<Oscillator*> oscs;
-			for (size_t i = 0; i < R.objs.size(); i++) if (is_oscillator(R.objs[i].kind) || R.objs[i].kind == N_OPERATOR) {
-				Oscillator* o = const_cast<Oscillator*>(dynamic_cast<const Oscillator*>(R.objs[i].packable));
-				if (o) { o->frequency.reg = R.emit(OP_FREQ, -1, -1, (int)i, 0, true); oscs.push_back(o); }
-			}
-			NOTEBASE* nb = t;
-			std::vector<float> value0(R.objs.size(), 0.f); std::vector<int> freq_reg;
-			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) value0[i] = ((signal*)R.objs[i].addr)->value;
-			for (Oscillator* o : oscs) freq_reg.push_back(o->frequency.reg);
-			gpu::PathMerger paths(R, [&]() {                                 // one run of process(): every data-dependent `if` outcome gets its own (gpu::PathMerger)
-				for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = first_reg[i]; sg->value = value0[i]; }
-				for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = freq_reg[q];
-				R.may_branch = true;
-				nb->process();
-				R.may_branch = false;
-				if (R.pending >= 0) R.fail("`if (env.finished())` may only guard stop() in a recorded process()");
-				const int ret = R.reg_of(nb->out);
-				for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
-					signal* sg = (signal*)R.objs[i].addr;
-					if (sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);     // written by process(): the next sample reads it
-				}
-				R.emit(gpu::PathMerger::OP_OUT, ret, -1, -1, 0, false);
-			});
-			paths.record();
-			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = -1; sg->value = value0[i]; }
-			for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = -1;
-			for (Oscillator* o : oscs) o->frequency.reg = -1;
-			R.recording = false;
-			gpu::rec = nullptr;
-			if (!R.error.empty()) { std::fprintf(stderr, "klang-mi355: cannot record %s::process() as a graph patch: %s\n", typeid(T).name(), R.error.c_str()); std::abort(); }
-			gpu::finish_program(R, lo, L);
-			if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", typeid(T).name(), L.program.c_str());
-			return t;
-		}
-		NOTEBASE* operator[](int i) { return items[(size_t)i].note; }
-		int assign() {                                                       // Notes::assign klang.h:4336-4372
-			for (unsigned i = 0; i < count; i++) if (items[i].note->stage == NOTEBASE::Off) { noteStart[i] = noteOns++; return (int)i; }
-			int oldest = -1; unsigned oldest_start = 0;
-			for (unsigned i = 0; i < count; i++) if (items[i].note->stage == NOTEBASE::Release && (oldest == -1 || noteStart[i] < oldest_start)) { oldest = (int)i; oldest_start = noteStart[i]; }
-			if (oldest != -1) { noteStart[oldest] = noteOns++; return oldest; }
-			oldest = -1; oldest_start = 0;
-			for (unsigned i = 0; i < count; i++) if (oldest == -1 || noteStart[i] < oldest_start) { oldest = (int)i; oldest_start = noteStart[i]; }
-			noteStart[oldest] = noteOns++;
-			return oldest;
-		}
-		~NotesT() { for (auto& s : items) delete s.note; for (auto* l : layouts) delete l; }
-	} notes;
-	klg_synth* gpu = nullptr;
-	std::vector<uint32_t> words;
-	std::vector<uint8_t> stages;
+struct Plugin : Controller, gpu::Owner { Plugin() : gpu::Owner(true) {} Controls controls; Presets presets; };
 
-	SynthCore() { notes.owner = this; }
-	~SynthCore() { if (gpu) klg_synth_destroy(gpu); }
-
-	void fail(const char* what) { std::fprintf(stderr, "klang-mi355: %s: %s\n", what, klg_last_error()); std::abort(); }
-	void ensure_gpu() {
-		if (gpu) return;
-		if (!notes.count) { std::fprintf(stderr, "klang-mi355: Synth has no notes (call notes.add<T>(n))\n"); std::abort(); }
-		const int patch = notes.items[0].b.patch;
-		if (const gpu::GraphLayout* g = notes.items[0].graph) {              // recorded process(): compiled for gfx950 now (hipRTC)
-			gpu = klg_synth_create_graph(g->program.c_str(), 1, (int)notes.count, fs.f, 1024);
-			if (!gpu) fail("klg_synth_create_graph");
-			for (size_t k = 0; k < g->tables.size(); k++) if (klg_table_upload(gpu, g->tables[k].data(), (int)g->tables[k].size(), 0) != (int)k + 1) fail("klg_table_upload (Table read by process())");
-		}
-		else {
-			if (patch < 0) { std::fprintf(stderr, "klang-mi355: no GPU kernel is bound to this Note type\n"); std::abort(); }
-			gpu = klg_synth_create(patch, 1, (int)notes.count, fs.f, 1024);
-			if (!gpu) fail("klg_synth_create");
-		}
-		words.resize(klg_synth_state_bytes(gpu) / 4);
-		stages.resize(notes.count);
-		sync_controls();
-	}
-	void sync_controls() { for (unsigned c = 0; c < controls.size() && (int)c < klg_synth_controls(gpu); c++) klg_set_control(gpu, 0, (int)c, controls[(int)c].value.value); }
-	// host mirror <- lane ; run the event ; lane <- host mirror
-	template<class F> void with_voice(int n, F&& event_code) {
-		ensure_gpu();
-		Slot& s = notes.items[(size_t)n];
-		if (klg_voice_download(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_download");
-		if ((words[0] & 3u) != (uint32_t)klg::ST_OFF || s.note->stage != NOTEBASE::Off) { if (s.graph) s.graph->unpack(s.note, words.data()); else s.b.unpack(s.note, words.data()); }
-		else if (s.graph) s.graph->unpack_delays(s.note, words.data());
-		gpu::upload_target = gpu; gpu::current_voice = n; gpu::current_note = s.note; gpu::current_layout = s.graph;   // Wavetable uploads / Delay::clear() of this voice
-		event_code(s.note);
-		if (s.graph) s.graph->pack(s.note, words.data()); else s.b.pack(s.note, words.data());
-		words[0] = (words[0] & ~3u) | (uint32_t)s.note->stage;
-		if (klg_voice_upload(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_upload");
-	}
-	virtual event noteOn(int pitch, float velocity) {                        // klang.h:4423-4427
-		ensure_gpu(); refresh_stages();
-		const int n = notes.assign();
-		with_voice(n, [&](NOTEBASE* note) { note->start((float)pitch, velocity); });
-	}
-	virtual event noteOff(int pitch, float velocity) {                       // klang.h:4430-4434
-		ensure_gpu();
-		for (unsigned n = 0; n < notes.count; n++)
-			if (notes[(int)n]->pitch == pitch && notes[(int)n]->stage == NOTEBASE::Sustain)
-				with_voice((int)n, [&](NOTEBASE* note) { note->release(velocity); });
-	}
-	event onControl(int index, float value) override { control(index, value); if (gpu) sync_controls(); }
-	void refresh_stages() {
-		if (klg_voice_stages(gpu, stages.data(), (int)notes.count)) fail("klg_voice_stages");
-		for (unsigned n = 0; n < notes.count; n++) if (stages[n] == klg::ST_OFF) notes[(int)n]->stage = NOTEBASE::Off;    // `if (!note->process(..)) note->stop()`
-	}
-	void render(float* const* buffers, int channels, int length, float* parameters) {
-		ensure_gpu();
-		if (parameters) for (unsigned c = 0; c < controls.size(); c++) controls[(int)c].set(parameters[c]);
-		sync_controls();
-		if (klg_process(gpu, buffers, channels, length, nullptr)) fail("klg_process");
-		refresh_stages();
-		if (parameters) for (unsigned c = 0; c < controls.size(); c++) parameters[c] = controls[(int)c].value.value;
-	}
-};
-
-struct Synth;
-struct Note : NoteBase<Synth>, Generator { typedef Synth synth_type; virtual void process() override = 0; };
-struct Synth : SynthCore<Note> {
-	typedef klang::Note Note;
-	virtual void process(float* buffer, int length, float* parameters = nullptr) { float* b[1] = { buffer }; render(b, 1, length, parameters); }   // klang.h:4440-4466 (voices are SUMMED)
-};
-
-namespace Stereo {
-	struct Synth;
-	struct Note : NoteBase<Synth>, klang::Generator { typedef Synth synth_type; virtual void process() override = 0; };
-	namespace Mono { typedef Stereo::Note Note; }
-	struct Synth : SynthCore<Note> {
-		typedef Stereo::Note Note;
-		struct Mono { typedef Stereo::Note Note; };
-		virtual void process(float** buffers, int length, float* parameters = nullptr) { render(buffers, 2, length, parameters); }                 // klang.h:4830-4858
-		void output(float** buffers, int length, float* parameters = nullptr) { process(buffers, length, parameters); }                            // v0.7.2 template name
+namespace gpu {
+// ---- recording a Note's process() (+ prepare()) into a graph program ----
+// `objs`: the note's members (member_objs).  prepare() — host code that runs once per block in the reference (klang.h:4292-4296) —
+// becomes the program's per-block prologue, like an effect's.
+template<class NOTEBASE> inline void record_note(NOTEBASE* nb, std::vector<Obj> objs, Controls& ctl, const char* lo, GraphLayout& L, const char* type_name) {
+	using namespace klg::graph;
+	Recorder R; rec = &R;
+	R.objs = std::move(objs);
+	R.prog.nctl = (int)ctl.items.size() < 8 ? (int)ctl.items.size() : 8;
+	for (int c = 0; c < R.prog.nctl; c++) R.prog.dials[c] = { ctl.items[(size_t)c].min, ctl.items[(size_t)c].max, ctl.items[(size_t)c].initial };
+	R.recording = true;
+	std::vector<int> first_reg(R.objs.size(), -1);
+	// `osc.frequency` read inside process(): the node's current frequency (what on() or a recorded set(f) left there)
+	std::vector<Oscillator*> oscs; std::vector<int> osc_node;
+	for (size_t i = 0; i < R.objs.size(); i++) if (is_oscillator(R.objs[i].kind) || R.objs[i].kind == N_OPERATOR)
+		if (Oscillator* o = const_cast<Oscillator*>(dynamic_cast<const Oscillator*>(R.objs[i].packable))) { oscs.push_back(o); osc_node.push_back((int)i); }
+	auto fresh_inputs = [&]() {                                              // member / control / frequency reads of the phase being recorded
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; first_reg[i] = sg->reg = R.emit(OP_PARAM, -1, -1, (int)i, 0, true); }
+		for (int c = 0; c < R.prog.nctl; c++) ctl.items[(size_t)c].value.reg = R.emit(OP_CTL, -1, -1, -1, (uint32_t)c, true);
+		for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = R.emit(OP_FREQ, -1, -1, osc_node[q], 0, true);
 	};
+	fresh_inputs();
+	nb->prepare();
+	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; if (sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false); }
+	R.prog.prepare_ops = (int)R.prog.ops.size();
+	fresh_inputs();
+	std::vector<float> value0(R.objs.size(), 0.f); std::vector<int> freq_reg;
+	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) value0[i] = ((signal*)R.objs[i].addr)->value;
+	for (Oscillator* o : oscs) freq_reg.push_back(o->frequency.reg);
+	PathMerger paths(R, [&]() {                                          // one run of process(): every data-dependent `if` outcome gets its own (gpu::PathMerger)
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = first_reg[i]; sg->value = value0[i]; }
+		for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = freq_reg[q];
+		R.may_branch = true;
+		nb->run_process();
+		R.may_branch = false;
+		if (R.pending >= 0) R.fail("`if (env.finished())` may only guard stop() in a recorded process()");
+		const int ret = R.reg_of(nb->out);
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
+			signal* sg = (signal*)R.objs[i].addr;
+			if (sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);     // written by process(): the next sample reads it
+		}
+		R.emit(PathMerger::OP_OUT, ret, -1, -1, 0, false);
+	});
+	paths.record();
+	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = -1; sg->value = value0[i]; }
+	for (int c = 0; c < R.prog.nctl; c++) ctl.items[(size_t)c].value.reg = -1;
+	for (Oscillator* o : oscs) o->frequency.reg = -1;
+	R.recording = false;
+	rec = nullptr;
+	if (!R.error.empty()) { std::fprintf(stderr, "klang-mi355: cannot record %s::process() as a graph patch: %s\n", type_name, R.error.c_str()); std::abort(); }
+	finish_program(R, lo, L);
+	if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", type_name, L.program.c_str());
+}
+
+// ---- recording an Effect's prepare() + process() into a `kind effect` program ----
+// `identity` (optional) is set when the body is `out = in` and nothing else (the default Effect::process(), klang.h:4206: what a Synth
+// that has no post-processing of its own inherits) — no program is built then.
+inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, signal* const ins[2], signal* const outs[2], const std::function<void()>& prepare,
+                          const std::function<void()>& process, const char* lo, GraphLayout& layout, const char* type_name, bool* identity = nullptr) {
+	using namespace klg::graph;
+	Recorder R; R.effect = true; rec = &R;
+	R.objs = std::move(objs);
+	R.prog.channels = channels;
+	R.prog.nctl = (int)ctl.items.size() < 8 ? (int)ctl.items.size() : 8;
+	for (int c = 0; c < R.prog.nctl; c++) R.prog.dials[c] = { ctl.items[(size_t)c].min, ctl.items[(size_t)c].max, ctl.items[(size_t)c].initial };
+	// prepare() is recorded too: it becomes the program's per-block prologue (`prepare <n>`), so `filter.set(controls[2])`
+	// follows each instance's own control.  Member params it assigns are written to the record and read back by process().
+	R.recording = true;
+	std::vector<int> first_reg(R.objs.size(), -1);
+	std::vector<Oscillator*> oscs; std::vector<int> osc_node;
+	for (size_t i = 0; i < R.objs.size(); i++) if (is_oscillator(R.objs[i].kind)) if (Oscillator* o = const_cast<Oscillator*>(dynamic_cast<const Oscillator*>(R.objs[i].packable))) { oscs.push_back(o); osc_node.push_back((int)i); }
+	auto is_io = [&](const signal* sg) { return sg == ins[0] || sg == ins[1] || sg == outs[0] || sg == outs[1]; };
+	auto fresh_inputs = [&]() {                                              // control / member / frequency reads of the phase being recorded
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; first_reg[i] = sg->reg = R.emit(OP_PARAM, -1, -1, (int)i, 0, true); }
+		for (int c = 0; c < R.prog.nctl; c++) ctl.items[(size_t)c].value.reg = R.emit(OP_CTL, -1, -1, -1, (uint32_t)c, true);
+		for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = R.emit(OP_FREQ, -1, -1, osc_node[q], 0, true);
+	};
+	fresh_inputs();
+	prepare();
+	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; if (sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false); }
+	R.prog.prepare_ops = (int)R.prog.ops.size();
+	fresh_inputs();
+	for (int c = 0; c < channels; c++) ins[c]->reg = R.emit(OP_IN, -1, -1, -1, (uint32_t)c, true);      // `in` is this sample of the block
+	std::vector<float> value0(R.objs.size(), 0.f); std::vector<int> freq_reg, in_reg;
+	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) value0[i] = ((signal*)R.objs[i].addr)->value;
+	for (Oscillator* o : oscs) freq_reg.push_back(o->frequency.reg);
+	for (int c = 0; c < channels; c++) in_reg.push_back(ins[c]->reg);
+	PathMerger paths(R, [&]() {                                          // one run of process() per outcome of its data-dependent `if`s
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = first_reg[i]; sg->value = value0[i]; }
+		for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = freq_reg[q];
+		for (int c = 0; c < channels; c++) ins[c]->reg = in_reg[(size_t)c];
+		R.may_branch = true;
+		process();
+		R.may_branch = false;
+		const int ret = R.reg_of(*outs[0]), ret_r = channels == 2 ? R.reg_of(*outs[1]) : -1;
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
+			signal* sg = (signal*)R.objs[i].addr;
+			if (!(sg == ins[0] || sg == ins[1]) && sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);
+		}
+		R.emit(PathMerger::OP_OUT, ret, ret_r, -1, 0, false);
+	});
+	paths.record();
+	(void)is_io;
+	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = -1; sg->value = value0[i]; }
+	for (int c = 0; c < channels; c++) { ins[c]->reg = -1; outs[c]->reg = -1; }
+	for (int c = 0; c < R.prog.nctl; c++) ctl.items[(size_t)c].value.reg = -1;
+	for (Oscillator* o : oscs) o->frequency.reg = -1;
+	R.recording = false; rec = nullptr;
+	if (!R.error.empty()) { std::fprintf(stderr, "klang-mi355: cannot record %s::process() as a graph effect: %s\n", type_name, R.error.c_str()); std::abort(); }
+	if (identity) {
+		*identity = R.prog.ret == in_reg[0] && (channels < 2 || R.prog.ret_r == in_reg[1]);
+		for (const Op& o : R.prog.ops) if (o.code == OP_SETPARAM || o.code == OP_DELAYIN || o.code == OP_OSCSET || o.code == OP_LPFSET) *identity = false;
+		if (*identity) return;
+	}
+	finish_program(R, lo, layout);
+	if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", type_name, layout.program.c_str());
+}
 }
 
 // =================================================================================================
 // Effects (klang.h:4190-4216 Effect, 4703-4717 Stereo::Effect): the DSL side, rendered as recorded graph effects
 // =================================================================================================
-// Delay<SIZE> (klang.h:3381-3512) inside a recorded Effect::process(): `x >> delay`, `delay << x`, `delay(time)`, `(x >> delay)(time)`.
-// The line itself lives in HBM (one ring per effect instance); on the host the object only takes part in the recording.
-// Delay<SIZE> (klang.h:3381-3512).  In an Effect: a ring per instance, cursor = the sample counter.  In a Note (physical models): a
+// Delay<SIZE> (klang.h:3381-3512).  In an Effect: a ring per instance in HBM, cursor = the sample counter (`x >> delay`, `delay << x`,
+// `delay(time)`, `(x >> delay)(time)`); on the host the object only takes part in the recording.  In a Note (physical models): a
 // `notedelay` node — the line lives in HBM per voice, its cursors (write position, the read head of set() / process()) in the record.
 template<int SIZE> struct Delay : Modifier, gpu::Packable {
 	bool in_note = false;
 	float time = 1.f; int position = 0; struct { int position = 0; float fraction = 0.f; } last;      // host mirror (notes)
 	Delay() {
-		if (gpu::Recorder* r = gpu::constructing()) { in_note = !r->effect; r->note(this, sizeof(Delay), in_note ? klg::graph::N_NDELAY : klg::graph::N_DELAY, in_note ? this : nullptr, SIZE); }
+		if (gpu::Sink* r = gpu::constructing()) { in_note = !r->effect; r->note(this, sizeof(Delay), in_note ? klg::graph::N_NDELAY : klg::graph::N_DELAY, in_note ? this : nullptr, SIZE, static_cast<const gpu::Packable*>(this)); }
 		else in_note = true;                                                        // every further Note of a recorded type
 	}
 	using Generic::Input<signal>::input;
@@ -1382,11 +1411,78 @@ template<int SIZE> struct Delay : Modifier, gpu::Packable {
 	unsigned int max() const { return SIZE; }
 };
 
-// klang::Effect: `in` and `out` are the Modifier's signals; process() is the per-sample body, prepare() runs on the host
+namespace gpu {
+// One instance of an effect on the GPU, built the first time its owner hands it a block: the engine behind Effect::process(buffer),
+// Stereo::Effect::process(Stereo::buffer) and the post-processing pass of a Synth (klang.h:4208-4216, 4708-4716, 4451, 4851).
+// The effect's type is tied to a hand-written kernel (KLANG_GPU_BIND_FX: klg_fx_create) or its prepare() / process() are recorded
+// from the members its construction log names (klg_fx_create_graph); blocks then go through klg_fx_process.
+struct FxRunner {
+	klg_fx* h = nullptr; GraphLayout layout; bool built = false, identity = false; int channels = 1, cap = 1024;
+	std::vector<float> io, sent;
+	FxRunner() {}
+	FxRunner(const FxRunner&) {}
+	FxRunner& operator=(const FxRunner&) { return *this; }
+	~FxRunner() { if (h) klg_fx_destroy(h); }
+	[[noreturn]] static void die(const char* what) { std::fprintf(stderr, "klang-mi355: %s: %s\n", what, klg_last_error()); std::abort(); }
+	template<class FX> void build(FX* fx, Owner& owner, Controls& ctl, int channels_, signal* const ins[2], signal* const outs[2], bool may_be_identity) {
+		if (built) return;
+		built = true; channels = channels_;
+		close_log();
+		const int bound = fx_binding(typeid(*fx));
+		if (bound >= 0 && !std::getenv("KLANG_MI355_FORCE_GRAPH")) {
+			if (channels != 2) { std::fprintf(stderr, "klang-mi355: the effect kernels of the library are stereo\n"); std::abort(); }
+			h = klg_fx_create(bound, 1, fs.f, cap);
+			if (!h) die("klg_fx_create");
+			return;
+		}
+		const char* lo = (const char*)dynamic_cast<const void*>(fx);
+		record_effect(member_objs(owner.log, nullptr, nullptr), ctl, channels, ins, outs, [fx]() { fx->prepare(); }, [fx]() { fx->run_process(); }, lo, layout, typeid(*fx).name(), may_be_identity ? &identity : nullptr);
+		if (identity) return;
+		std::vector<uint32_t> words((size_t)layout.words, 0u);
+		layout.pack(lo, words.data());
+		h = klg_fx_create_graph(layout.program.c_str(), 1, fs.f, cap, words.data());
+		if (!h) die("klg_fx_create_graph");
+	}
+	// the host's control values -> the instance: whatever was set() since the last block (even to the same value: a set() overwrites
+	// what the effect itself may have written to the control, as in the reference) or differs from what was sent
+	void sync_controls(Controls& ctl) {
+		const int n = (int)ctl.items.size();
+		if ((int)sent.size() != n) sent.assign((size_t)n, std::nanf(""));
+		for (int c = 0; c < n; c++) {
+			Control& k = ctl.items[(size_t)c];
+			if (!k.touched && k.value.value == sent[(size_t)c]) continue;
+			if (klg_fx_set_control(h, 0, c, k.value.value)) die("klg_fx_set_control");
+			sent[(size_t)c] = k.value.value; k.touched = false;
+		}
+	}
+	void run(Controls& ctl, float* const* ch, int n) {                               // ch[channels][n], processed in place
+		if (identity || n <= 0) return;
+		sync_controls(ctl);
+		for (int at = 0; at < n; at += cap) {                                        // (prepare() runs once per klg_fx_process call: once per <= 1024 samples)
+			const int m = n - at < cap ? n - at : cap;
+			io.resize((size_t)channels * (size_t)m);
+			for (int c = 0; c < channels; c++) std::memcpy(&io[(size_t)c * (size_t)m], ch[c] + at, (size_t)m * sizeof(float));
+			if (klg_fx_process(h, io.data(), m)) die("klg_fx_process");
+			for (int c = 0; c < channels; c++) std::memcpy(ch[c] + at, &io[(size_t)c * (size_t)m], (size_t)m * sizeof(float));
+		}
+	}
+};
+}
+
+// klang::Effect (klang.h:4203-4217): `in` and `out` are the Modifier's signals; process() is the per-sample body (device code, recorded),
+// prepare() runs once per block; process(buffer) is the host's entry point — the whole block goes to the GPU.
 struct Effect : Plugin, Modifier {
 	enum { channels = 1 };
+	gpu::FxRunner gpu_fx;
 	virtual void prepare() {}
-	virtual void process() override = 0;
+	virtual void process() override { out = in; }                                  // klang.h:4206
+	void run_process() { this->process(); }
+	virtual void process(buffer buffer) {                                          // klang.h:4208-4216: prepare(); per sample { in = *buf; process(); *buf++ = out; }
+		signal* ins[2] = { &in, &in }; signal* outs[2] = { &out, &out };
+		gpu_fx.build(this, *this, controls, 1, ins, outs, false);
+		float* ch[1] = { buffer.cursor() };
+		gpu_fx.run(controls, ch, buffer.remaining());
+	}
 };
 namespace Stereo {
 	struct signal {                                                          // klang.h:4487-4558 (the operators the shipped effects use)
@@ -1399,8 +1495,47 @@ namespace Stereo {
 		signal operator*(float x) const { return { l * x, r * x }; }
 		signal(float x) : l(x), r(x) {} signal(int x) : l((float)x), r((float)x) {} signal(double x) : l((float)x), r((float)x) {}
 		signal& operator+=(const signal& x) { l = l + x.l; r = r + x.r; return *this; }
+		klang::signal mono() const { return (l + r) * 0.5f; }                      // klang.h:4556
 	};
 	inline signal operator*(Control& c, const signal& x) { return { c.value * x.l, c.value * x.r }; }
+	// Stereo::frame (klang.h:4487-4517): one sample of each channel of a Stereo::buffer, by reference
+	struct frame {
+		klang::buffer::sample l, r;
+		frame(klang::buffer::sample left, klang::buffer::sample right) : l(left), r(right) {}
+		frame& operator+=(const frame& x) { l += klang::signal(x.l); r += klang::signal(x.r); return *this; } frame& operator-=(const frame& x) { l -= klang::signal(x.l); r -= klang::signal(x.r); return *this; }
+		frame& operator*=(const frame& x) { l *= klang::signal(x.l); r *= klang::signal(x.r); return *this; } frame& operator/=(const frame& x) { l /= klang::signal(x.l); r /= klang::signal(x.r); return *this; }
+		frame& operator+=(const signal& x) { l += x.l; r += x.r; return *this; } frame& operator-=(const signal& x) { l -= x.l; r -= x.r; return *this; }
+		frame& operator*=(const signal& x) { l *= x.l; r *= x.r; return *this; } frame& operator/=(const signal& x) { l /= x.l; r /= x.r; return *this; }
+		frame& operator=(const signal& x) { l = x.l; r = x.r; return *this; }
+		frame& operator=(const klang::signal& x) { l = x; r = x; return *this; }
+		operator signal() const { return { klang::signal(l), klang::signal(r) }; }
+	};
+	// Stereo::buffer (klang.h:4578-4640): two mono buffers advanced in lock-step (`left` by reference, `right` a copy, as declared there)
+	struct buffer {
+		typedef Stereo::signal signal;
+		klang::buffer& left; klang::buffer right;
+		buffer(const buffer& b) : left(b.left), right(b.right) { rewind(); }
+		buffer(klang::buffer& l, klang::buffer& r) : left(l), right(r) { rewind(); }
+		operator const signal() const { return { klang::signal(left), klang::signal(right) }; }
+		operator frame() { return { klang::buffer::sample{ left.cursor() }, klang::buffer::sample{ right.cursor() } }; }
+		bool finished() const { return left.finished() && right.finished(); }
+		frame operator++(int) { return { left++, right++ }; }
+		frame operator=(const signal& in) { return { left = in.l, right = in.r }; }
+		buffer& operator=(const buffer& in) { left = in.left; right = in.right; return *this; }
+		buffer& operator+=(const signal& in) { left += in.l; right += in.r; return *this; }
+		buffer& operator=(const frame& in) { left = klang::signal(in.l); right = klang::signal(in.r); return *this; }
+		buffer& operator+=(const frame& in) { left += klang::signal(in.l); right += klang::signal(in.r); return *this; }
+		buffer& operator*=(const frame& in) { left *= klang::signal(in.l); right *= klang::signal(in.r); return *this; }
+		buffer& operator=(const klang::signal in) { left = in; right = in; return *this; }
+		buffer& operator+=(const klang::signal in) { left += in; right += in; return *this; }
+		buffer& operator*=(const klang::signal in) { left *= in; right *= in; return *this; }
+		frame operator[](int index) { return { left[index], right[index] }; }
+		signal operator[](int index) const { const klang::buffer& l = left; const klang::buffer& r = right; return { klang::signal(l[index]), klang::signal(r[index]) }; }
+		klang::buffer& channel(int index) { return index == 1 ? right : left; }
+		void clear() { left.clear(); right.clear(); }
+		void clear(int size) { left.clear(size); right.clear(size); }
+		void rewind() { left.rewind(); right.rewind(); }
+	};
 	// Stereo::Modifier / Stereo::Bank<T> (klang.h:4560-4645): the types the shipped Reverb.k is written in.  They are here so that the
 	// file compiles unchanged; a patch built from them is tied to its hand-written kernel (KLANG_GPU_BIND_FX) — their process() is
 	// never recorded.
@@ -1431,17 +1566,373 @@ namespace Stereo {
 		unsigned int max() const { return SIZE; }
 	};
 	inline signal& operator>>(const signal& x, signal& dst) { dst = x; return dst; }
+	// Stereo::Effect (klang.h:4703-4717)
 	struct Effect : Plugin {
 		enum { channels = 2 };
 		Stereo::signal in, out;
+		gpu::FxRunner gpu_fx;
 		virtual ~Effect() {}
 		virtual void prepare() {}
-		virtual void process() = 0;
+		virtual void process() { out = in; }                                       // klang.h:4707
+		void run_process() { this->process(); }
+		virtual void process(Stereo::buffer buffer) {                              // klang.h:4708-4716
+			klang::signal* ins[2] = { &in.l, &in.r }; klang::signal* outs[2] = { &out.l, &out.r };
+			gpu_fx.build(this, *this, controls, 2, ins, outs, false);
+			float* ch[2] = { buffer.left.cursor(), buffer.right.cursor() };
+			const int n = buffer.left.remaining() < buffer.right.remaining() ? buffer.left.remaining() : buffer.right.remaining();
+			gpu_fx.run(controls, ch, n);
+		}
 	};
 }
 namespace stereo = Stereo;
-namespace Mono { typedef klang::Modifier Modifier; typedef klang::Generator Generator; typedef klang::signal signal; }
+namespace Mono { typedef klang::Modifier Modifier; typedef klang::Generator Generator; typedef klang::signal signal; typedef klang::buffer buffer; }
 namespace mono = Mono;
+
+// =================================================================================================
+// Notes
+// =================================================================================================
+namespace gpu {
+// A note the host uses on its own (`MyNote note; note.start(p, v); if (!note.process(buffer)) note.stop();`, klang.h:4295-4306 and the
+// reference's README): a one-voice bank built from the note's construction log the first time it is needed.
+struct SoloVoice {
+	klg_synth* h = nullptr; GraphLayout layout; std::vector<uint32_t> words; std::vector<float> pv; Controls no_controls; bool rendered = false;
+	~SoloVoice() { if (h) klg_synth_destroy(h); }
+};
+template<class T> struct NoteHooks {                                       // does the Note type T define control() / preset() / midi() of its own?
+	struct Probe : T {
+		static constexpr bool control_() { return !std::is_same_v<decltype(&Probe::control), void (Controller::*)(int, float)>; }
+		static constexpr bool preset_() { return !std::is_same_v<decltype(&Probe::preset), void (Controller::*)(int)>; }
+		static constexpr bool midi_() { return !std::is_same_v<decltype(&Probe::midi), void (Controller::*)(int, int, int)>; }
+	};
+	static constexpr unsigned mask() { return (Probe::control_() ? 1u : 0u) | (Probe::preset_() ? 2u : 0u) | (Probe::midi_() ? 4u : 0u); }
+};
+}
+
+template<class SYNTH> class NoteBase : public Controller, public gpu::Owner {
+	SYNTH* synth = nullptr;
+protected:
+	virtual event on(Pitch, Velocity) {}
+	virtual event off(Velocity = 0) { stage = Off; }
+	SYNTH* getSynth() { return synth; }
+public:
+	struct ControlsRef { Controls* c = nullptr; Control& operator[](int i) { return (*c)[i]; } unsigned size() { return c ? c->size() : 0; } } controls;
+	Pitch pitch; Velocity velocity;
+	enum Stage { Onset, Sustain, Release, Off } stage = Off;
+	gpu::SoloVoice* solo = nullptr;                                         // only when the host drives this note by itself (no Synth)
+	NoteBase() : gpu::Owner(false) {}
+	virtual ~NoteBase() { delete solo; }
+	bool attached() const { return synth != nullptr; }
+	void attach(SYNTH* s) { synth = s; controls.c = &s->controls; init(); }      // klang.h:4245-4249
+	virtual void init() {}
+	virtual void solo_pull() {}                                             // lane -> host mirror / host mirror -> lane of a note used on its own
+	virtual void solo_push() {}
+	virtual void start(Pitch p, Velocity v) { if (!synth) solo_pull(); stage = Onset; pitch = p; velocity = v; on(pitch, velocity); stage = Sustain; if (!synth) solo_push(); }    // klang.h:4257-4263
+	virtual bool release(Velocity v = 0) {                                   // klang.h:4265-4275
+		if (stage == Off) return true;
+		if (stage != Release) { if (!synth) solo_pull(); stage = Release; off(v); if (!synth) solo_push(); }
+		return stage == Off;
+	}
+	virtual bool stop(Velocity = 0) {
+		if (gpu::Recorder* r = gpu::recording()) {                 // `if (adsr.finished()) stop();` / `stop();` in a recorded process()
+			if (r->pending >= 0) { const int n = r->pending; r->emit(klg::graph::OP_STOPIF, -1, -1, n, 0, false); r->pending = -1; }
+			else r->emit(klg::graph::OP_STOP, -1, -1, -1, 0, false);
+			return true;
+		}
+		stage = Off; if (!synth && solo) solo_push(); return true;
+	}
+	bool finished() const { return stage == Off; }
+	virtual void controlChange(int controller, int value) { midi(0xB0, controller, value); }   // klang.h:4289
+};
+
+namespace gpu {
+// the block of a note used on its own: record + create on first use, then one klg_process_voices per <= 1024 samples
+template<class NOTE> inline void solo_ensure(NOTE* note) {
+	if (note->solo) return;
+	close_log();
+	SoloVoice* s = note->solo = new SoloVoice();
+	const char* lo = (const char*)dynamic_cast<const void*>(note);
+	record_note(note, member_objs(note->log, nullptr, nullptr), s->no_controls, lo, s->layout, typeid(*note).name());
+	s->h = klg_synth_create_graph(s->layout.program.c_str(), 1, 1, fs.f, 1024);
+	if (!s->h) { std::fprintf(stderr, "klang-mi355: klg_synth_create_graph: %s\n", klg_last_error()); std::abort(); }
+	for (size_t k = 0; k < s->layout.tables.size(); k++) if (klg_table_upload(s->h, s->layout.tables[k].data(), (int)s->layout.tables[k].size(), 0) != (int)k + 1) { std::fprintf(stderr, "klang-mi355: klg_table_upload: %s\n", klg_last_error()); std::abort(); }
+	s->words.assign(klg_synth_state_bytes(s->h) / 4, 0u);
+}
+template<class NOTE> inline void solo_pull(NOTE* note) {
+	solo_ensure(note);
+	SoloVoice* s = note->solo; const char* lo = (const char*)dynamic_cast<const void*>(note);
+	if (klg_voice_download(s->h, 0, s->words.data(), s->words.size() * 4)) { std::fprintf(stderr, "klang-mi355: klg_voice_download: %s\n", klg_last_error()); std::abort(); }
+	if ((s->words[0] & 3u) != (uint32_t)klg::ST_OFF || note->stage != NOTE::Off) s->layout.unpack((void*)lo, s->words.data());
+	else s->layout.unpack_delays((void*)lo, s->words.data());
+	upload_target = s->h; current_voice = 0; current_note = lo; current_layout = &s->layout;
+}
+template<class NOTE> inline void solo_push(NOTE* note) {
+	solo_ensure(note);
+	SoloVoice* s = note->solo; const char* lo = (const char*)dynamic_cast<const void*>(note);
+	upload_target = s->h; current_voice = 0; current_note = lo; current_layout = &s->layout;
+	s->layout.pack(lo, s->words.data());
+	s->words[0] = (s->words[0] & ~3u) | (uint32_t)note->stage;
+	if (klg_voice_upload(s->h, 0, s->words.data(), s->words.size() * 4)) { std::fprintf(stderr, "klang-mi355: klg_voice_upload: %s\n", klg_last_error()); std::abort(); }
+}
+// renders the note's next n samples into s->pv and brings the note's stage back (a note the GPU stopped is Off)
+template<class NOTE> inline const float* solo_render(NOTE* note, int at, int m) {
+	(void)at;
+	SoloVoice* s = note->solo;
+	s->pv.resize((size_t)m);
+	if (klg_process_voices(s->h, s->pv.data(), nullptr, 0, m)) { std::fprintf(stderr, "klang-mi355: klg_process_voices: %s\n", klg_last_error()); std::abort(); }
+	uint8_t st = 0;
+	if (klg_voice_stages(s->h, &st, 1)) { std::fprintf(stderr, "klang-mi355: klg_voice_stages: %s\n", klg_last_error()); std::abort(); }
+	if (st == klg::ST_OFF) note->stage = NOTE::Off;
+	return s->pv.data();
+}
+[[noreturn]] inline void note_of_a_synth() {
+	std::fprintf(stderr, "klang-mi355: Note::process(buffer) on a note that belongs to a Synth: the Synth renders all its voices in one launch (Synth::process)\n"); std::abort();
+}
+}
+
+// =================================================================================================
+// Synth: host voice allocation + event dispatch; blocks rendered by libklang_mi355.so
+// =================================================================================================
+namespace gpu { enum MixMode { Sum = 0, LastActiveVoice = 1 }; }          // how the voices of a MONO Synth combine (see klang::Synth below)
+
+template<class NOTEBASE> struct SynthCore : Plugin {
+	struct Slot { NOTEBASE* note = nullptr; NoteBinding b = { -1, nullptr, nullptr }; const gpu::GraphLayout* graph = nullptr; };
+	struct NotesT {
+		SynthCore* owner; std::vector<Slot> items; unsigned noteOns = 0; unsigned noteStart[128] = { 0 };
+		unsigned count = 0;
+		std::vector<gpu::GraphLayout*> layouts;
+		const std::type_info* note_type = nullptr; unsigned hooks = 0;
+		template<class T> void add(int n) {
+			gpu::close_log();
+			// one Note type per Synth: the bank is ONE kernel over ONE record layout (the reference's Notes would take several)
+			if (note_type && *note_type != typeid(T)) { std::fprintf(stderr, "klang-mi355: notes.add<%s>() after notes.add<%s>(): a Synth renders ONE Note type (one kernel, one record layout); use a Synth per type\n", typeid(T).name(), note_type->name()); std::abort(); }
+			note_type = &typeid(T); hooks = gpu::NoteHooks<T>::mask();
+			const bool bound = klang_gpu_patch((const T*)nullptr) >= 0 && !std::getenv("KLANG_MI355_FORCE_GRAPH");
+			const gpu::GraphLayout* layout = items.empty() ? nullptr : items[0].graph;
+			for (int i = 0; i < n && items.size() < 128; i++) {
+				T* t = nullptr;
+				if (!bound && !layout) { gpu::GraphLayout* l = new gpu::GraphLayout(); layouts.push_back(l); t = record<T>(*l); layout = l; }   // the prototype becomes note 0
+				else { gpu::log_suppress++; t = new T(); gpu::log_suppress--; t->attach(static_cast<typename T::synth_type*>(owner)); }
+				Slot s; s.note = t; s.graph = layout;
+				s.b.patch = bound ? klang_gpu_patch((const T*)t) : -1;
+				s.b.pack = [](const void* p, uint32_t* w) { klang_gpu_pack((const T*)p, w); };
+				s.b.unpack = [](void* p, const uint32_t* w) { klang_gpu_unpack((T*)p, w); };
+				items.push_back(s); count = (unsigned)items.size();
+			}
+		}
+		// Construct the prototype Note with every primitive / signal member announcing itself, run its process() once in
+		// recording mode, and turn what was recorded into a graph program + the member layout of the Note type.
+		template<class T> T* record(gpu::GraphLayout& L) {
+			gpu::Recorder C;
+			gpu::rec = &C; C.constructing = true;
+			T* t = new T();
+			C.constructing = false; gpu::rec = nullptr;
+			t->attach(static_cast<typename T::synth_type*>(owner));
+			const char* lo = (const char*)t;
+			NOTEBASE* nb = t;
+			gpu::record_note(nb, gpu::member_objs(C, lo, lo + sizeof(T)), owner->controls, lo, L, typeid(T).name());
+			return t;
+		}
+		NOTEBASE* operator[](int i) { return items[(size_t)i].note; }
+		int assign() {                                                       // Notes::assign klang.h:4336-4372
+			for (unsigned i = 0; i < count; i++) if (items[i].note->stage == NOTEBASE::Off) { noteStart[i] = noteOns++; return (int)i; }
+			int oldest = -1; unsigned oldest_start = 0;
+			for (unsigned i = 0; i < count; i++) if (items[i].note->stage == NOTEBASE::Release && (oldest == -1 || noteStart[i] < oldest_start)) { oldest = (int)i; oldest_start = noteStart[i]; }
+			if (oldest != -1) { noteStart[oldest] = noteOns++; return oldest; }
+			oldest = -1; oldest_start = 0;
+			for (unsigned i = 0; i < count; i++) if (oldest == -1 || noteStart[i] < oldest_start) { oldest = (int)i; oldest_start = noteStart[i]; }
+			noteStart[oldest] = noteOns++;
+			return oldest;
+		}
+		~NotesT() { for (auto& s : items) delete s.note; for (auto* l : layouts) delete l; }
+	} notes;
+	klg_synth* gpu = nullptr;
+	std::vector<uint32_t> words;
+	std::vector<uint8_t> stages;
+	gpu::MixMode mix = gpu::Sum;
+	gpu::FxRunner post;                                                      // the Synth's own process() (post-processing of the mix), if it has one
+
+	SynthCore() { notes.owner = this; }
+	~SynthCore() { if (gpu) klg_synth_destroy(gpu); }
+
+	virtual bool mono_synth() const { return false; }
+	void fail(const char* what) { std::fprintf(stderr, "klang-mi355: %s: %s\n", what, klg_last_error()); std::abort(); }
+	void ensure_gpu() {
+		if (gpu) return;
+		gpu::close_log();
+		if (!notes.count) { std::fprintf(stderr, "klang-mi355: Synth has no notes (call notes.add<T>(n))\n"); std::abort(); }
+		const int patch = notes.items[0].b.patch;
+		if (const gpu::GraphLayout* g = notes.items[0].graph) {              // recorded process(): compiled for gfx950 now (hipRTC)
+			gpu = klg_synth_create_graph(g->program.c_str(), 1, (int)notes.count, fs.f, 1024);
+			if (!gpu) fail("klg_synth_create_graph");
+			for (size_t k = 0; k < g->tables.size(); k++) if (klg_table_upload(gpu, g->tables[k].data(), (int)g->tables[k].size(), 0) != (int)k + 1) fail("klg_table_upload (Table read by process())");
+		}
+		else {
+			if (patch < 0) { std::fprintf(stderr, "klang-mi355: no GPU kernel is bound to this Note type\n"); std::abort(); }
+			gpu = klg_synth_create(patch, 1, (int)notes.count, fs.f, 1024);
+			if (!gpu) fail("klg_synth_create");
+		}
+		if (const char* e = std::getenv("KLANG_MI355_MONO_MIX")) if (mono_synth() && (!std::strcmp(e, "last") || !std::strcmp(e, "reference"))) mix = gpu::LastActiveVoice;   // (no source change needed to get the reference's literal mono behaviour)
+		if (klg_synth_set_mix_mode(gpu, (int)mix)) fail("klg_synth_set_mix_mode");
+		words.resize(klg_synth_state_bytes(gpu) / 4);
+		stages.resize(notes.count);
+		sync_controls();
+	}
+	void sync_controls() { for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_set_control(gpu, 0, (int)c, controls.items[c].value.value); }
+	// host mirror <- lane ; run the event ; lane <- host mirror
+	template<class F> void with_voice(int n, F&& event_code) {
+		ensure_gpu();
+		Slot& s = notes.items[(size_t)n];
+		if (klg_voice_download(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_download");
+		if ((words[0] & 3u) != (uint32_t)klg::ST_OFF || s.note->stage != NOTEBASE::Off) { if (s.graph) s.graph->unpack(s.note, words.data()); else s.b.unpack(s.note, words.data()); }
+		else if (s.graph) s.graph->unpack_delays(s.note, words.data());
+		gpu::upload_target = gpu; gpu::current_voice = n; gpu::current_note = s.note; gpu::current_layout = s.graph;   // Wavetable uploads / Delay::clear() of this voice
+		event_code(s.note);
+		if (s.graph) s.graph->pack(s.note, words.data()); else s.b.pack(s.note, words.data());
+		words[0] = (words[0] & ~3u) | (uint32_t)s.note->stage;
+		if (klg_voice_upload(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_upload");
+	}
+	virtual event noteOn(int pitch, float velocity) {                        // klang.h:4423-4427
+		ensure_gpu(); refresh_stages();
+		const int n = notes.assign();
+		with_voice(n, [&](NOTEBASE* note) { note->start((float)pitch, velocity); });
+	}
+	virtual event noteOff(int pitch, float velocity) {                       // klang.h:4430-4434
+		ensure_gpu();
+		for (unsigned n = 0; n < notes.count; n++)
+			if (notes[(int)n]->pitch == pitch && notes[(int)n]->stage == NOTEBASE::Sustain)
+				with_voice((int)n, [&](NOTEBASE* note) { note->release(velocity); });
+	}
+	// events go to the synth and to every sounding note (klang.h:4399-4421, 4779-4811).  A note's own hook runs on the host mirror of
+	// its voice (lane -> host -> hook -> lane), and only for a Note type that defines the hook at all (gpu::NoteHooks).
+	template<class F> void to_sounding_notes(unsigned hook, F&& f) {
+		if (!(notes.hooks & hook) || !notes.count) return;
+		ensure_gpu(); refresh_stages();
+		for (unsigned n = 0; n < notes.count; n++) if (notes[(int)n]->stage != NOTEBASE::Off) with_voice((int)n, f);
+	}
+	event onControl(int index, float value) override { control(index, value); to_sounding_notes(1u, [&](NOTEBASE* note) { note->onControl(index, value); }); if (gpu) sync_controls(); }
+	event onPreset(int index) override { preset(index); to_sounding_notes(2u, [&](NOTEBASE* note) { note->onPreset(index); }); if (gpu) sync_controls(); }
+	event onMIDI(int status, int byte1, int byte2) override { midi(status, byte1, byte2); to_sounding_notes(4u, [&](NOTEBASE* note) { note->onMIDI(status, byte1, byte2); }); }
+	// MIDI input for external calls (templates/juce/synth/Source/klang.h:3921-3928)
+	virtual void input(int status, int byte1, int byte2) {
+		if (status == 0x90 && byte2 > 0) noteOn(byte1, byte2 / 127.f);
+		else if (status == 0x80 || (status == 0x90 && byte2 == 0)) noteOff(byte1, byte2 / 127.f);
+		else onMIDI(status, byte1, byte2);
+	}
+	void refresh_stages() {
+		if (klg_voice_stages(gpu, stages.data(), (int)notes.count)) fail("klg_voice_stages");
+		for (unsigned n = 0; n < notes.count; n++) if (stages[n] == klg::ST_OFF) notes[(int)n]->stage = NOTEBASE::Off;    // `if (!note->process(..)) note->stop()`
+	}
+	void render_voices(float* const* buffers, int channels, int length) {
+		ensure_gpu();
+		sync_controls();
+		if (klg_process(gpu, buffers, channels, length, nullptr)) fail("klg_process");
+		refresh_stages();
+	}
+};
+
+// klang::Note / klang::Synth (mono, klang.h:4292-4466).  A Synth is an Effect in the reference: its own process() post-processes the mix.
+struct Synth;
+struct Note : NoteBase<Synth>, Generator {
+	typedef Synth synth_type;
+	virtual void prepare() {}
+	virtual void process() override = 0;
+	void run_process() { this->process(); }
+	void solo_pull() override { gpu::solo_pull(this); }
+	void solo_push() override { gpu::solo_push(this); }
+	virtual bool process(buffer buffer) {                                    // klang.h:4295-4303: per sample { process(); buffer++ = out; } — a mono note OVERWRITES
+		if (attached()) gpu::note_of_a_synth();
+		gpu::solo_ensure(this);
+		if (!solo->rendered) { gpu::solo_push(this); solo->rendered = true; }
+		while (!buffer.finished()) {
+			const int m = buffer.remaining() < 1024 ? buffer.remaining() : 1024;
+			const float* y = gpu::solo_render(this, 0, m);
+			std::memcpy(buffer.cursor(), y, (size_t)m * sizeof(float));
+			buffer.advance(m);
+		}
+		return !finished();
+	}
+	virtual bool process(buffer* buffers) { return this->process(buffers[0]); }   // klang.h:4304-4306
+};
+struct Synth : SynthCore<Note> {
+	typedef klang::Note Note;
+	signal in = { 0.f }, out = { 0.f };
+	bool mono_synth() const override { return true; }
+	// post processing (klang.h:4438-4439): the Synth's own per-sample process() over the mixed block, identity unless overridden
+	virtual void prepare() {}
+	virtual void process() { out = in; }
+	void run_process() { this->process(); }
+	virtual void process(buffer buffer) {
+		signal* ins[2] = { &in, &in }; signal* outs[2] = { &out, &out };
+		post.build(this, *this, controls, 1, ins, outs, true);
+		float* ch[1] = { buffer.cursor() };
+		post.run(controls, ch, buffer.remaining());
+	}
+	// klang.h:4440-4466.  In the reference every sounding note OVERWRITES the block in turn (`buffer++ = out`, klang.h:4299), so what a
+	// mono Synth returns is its last sounding note alone: that is `mix = gpu::LastActiveVoice`.  The default here is the SUM of the voices
+	// (what Stereo::Synth does) — set `mix` before the first block / event to get the reference's literal behaviour.
+	virtual void process(float* buffer, int length, float* parameters = nullptr) {
+		if (parameters) for (unsigned c = 0; c < controls.items.size(); c++) controls.items[c].set(parameters[c]);
+		float* b[1] = { buffer }; render_voices(b, 1, length);
+		klang::buffer mono(buffer, length);
+		this->process(mono);
+		if (parameters) for (unsigned c = 0; c < controls.items.size(); c++) parameters[c] = controls.items[c].value.value;
+	}
+};
+
+namespace Stereo {
+	struct Synth;
+	// Stereo::Note / Stereo::Mono::Note (klang.h:4722-4757): the note's `out` is mono here and goes to both channels (Mono::Note's
+	// `L += out; R += out`); a note used on its own ADDS to the buffer, as there
+	struct Note : NoteBase<Synth>, klang::Generator {
+		typedef Synth synth_type;
+		virtual void prepare() {}
+		virtual void process() override = 0;
+		void run_process() { this->process(); }
+		void solo_pull() override { gpu::solo_pull(this); }
+		void solo_push() override { gpu::solo_push(this); }
+		virtual bool process(Stereo::buffer buffer) {                            // klang.h:4727-4734 / 4747-4756
+			if (attached()) gpu::note_of_a_synth();
+			gpu::solo_ensure(this);
+			if (!solo->rendered) { gpu::solo_push(this); solo->rendered = true; }
+			while (!buffer.finished()) {
+				int m = buffer.left.remaining() < buffer.right.remaining() ? buffer.left.remaining() : buffer.right.remaining();
+				if (m > 1024) m = 1024;
+				if (m <= 0) break;
+				const float* y = gpu::solo_render(this, 0, m);
+				float* l = buffer.left.cursor(); float* r = buffer.right.cursor();
+				for (int i = 0; i < m; i++) { l[i] += y[i]; r[i] += y[i]; }
+				buffer.left.advance(m); buffer.right.advance(m);
+			}
+			return !finished();
+		}
+		virtual bool process(klang::buffer* buffers) { Stereo::buffer b = { buffers[0], buffers[1] }; return this->process(b); }   // klang.h:4735-4738
+	};
+	namespace Mono { typedef Stereo::Note Note; }
+	struct Synth : SynthCore<Note> {
+		typedef Stereo::Note Note;
+		struct Mono { typedef Stereo::Note Note; };
+		Stereo::signal in, out;
+		virtual void prepare() {}
+		virtual void process() { out = in; }                                       // post processing (klang.h:4826-4827)
+		void run_process() { this->process(); }
+		virtual void process(Stereo::buffer buffer) {
+			klang::signal* ins[2] = { &in.l, &in.r }; klang::signal* outs[2] = { &out.l, &out.r };
+			post.build(this, *this, controls, 2, ins, outs, true);
+			float* ch[2] = { buffer.left.cursor(), buffer.right.cursor() };
+			post.run(controls, ch, buffer.left.remaining() < buffer.right.remaining() ? buffer.left.remaining() : buffer.right.remaining());
+		}
+		virtual void process(float** buffers, int length, float* parameters = nullptr) {   // klang.h:4830-4858
+			if (parameters) for (unsigned c = 0; c < controls.items.size(); c++) controls.items[c].set(parameters[c]);
+			render_voices(buffers, 2, length);
+			klang::buffer left(buffers[0], length), right(buffers[1], length);
+			Stereo::buffer both(left, right);
+			this->process(both);
+			if (parameters) for (unsigned c = 0; c < controls.items.size(); c++) parameters[c] = controls.items[c].value.value;
+		}
+		void output(float** buffers, int length, float* parameters = nullptr) { process(buffers, length, parameters); }                            // v0.7.2 template name (templates/juce/synth/Source/klang.h:3931)
+	};
+}
+
 // signals<N> / Matrix (klang.h:1273-1337, 1446-1470): a row of signals and the 4 x 4 feedback matrix of Reverb.k
 struct Matrix { float v[4][4]; constexpr float operator()(int r, int c) const { return v[r][c]; } };
 template<int N> struct signals {
@@ -1459,90 +1950,29 @@ template<int N> struct signals {
 };
 
 namespace gpu {
-// `instances` copies of a user effect FX, rendered on the GPU.  The constructor builds ONE FX object with every primitive /
-// signal member announcing itself, runs prepare() and then process() once in recording mode (include/klang_mi355_graph.h,
-// `kind effect`), packs the object's state into the record every instance starts from and creates the bank.
+// `instances` copies of a user effect FX, rendered on the GPU (bank scale: BASELINE config 4).  The constructor builds ONE FX object
+// with every primitive / signal member announcing itself, runs prepare() and then process() once in recording mode
+// (include/klang_mi355_graph.h, `kind effect`), packs the object's state into the record every instance starts from and creates the bank.
 template<class FX> struct EffectBank {
 	FX* fx = nullptr; klg_fx* h = nullptr; GraphLayout layout; int instances; int channels = FX::channels;
 	explicit EffectBank(int instances_, int max_block = 1024) : instances(instances_) {
-		using namespace klg::graph;
 		// an effect type tied to a hand-written kernel (KLANG_GPU_BIND_FX: the shipped PingPong.k / Reverb.k) is not recorded
 		const int bound = klang_gpu_fx_patch((const FX*)nullptr);
 		if (bound >= 0 && !std::getenv("KLANG_MI355_FORCE_GRAPH")) {
 			fx = new FX();
+			close_log();
 			h = klg_fx_create(bound, instances, fs.f, max_block);
 			if (!h) { std::fprintf(stderr, "klang-mi355: klg_fx_create: %s\n", klg_last_error()); std::abort(); }
 			return;
 		}
-		Recorder R; R.effect = true; rec = &R;
-		R.constructing = true; fx = new FX(); R.constructing = false;
-		const char* lo = (const char*)fx; const char* hi = lo + sizeof(FX);
-		std::vector<Recorder::Obj> kept;
-		for (const auto& o : R.objs) {
-			const char* a = (const char*)o.addr;
-			if (a < lo || a >= hi) continue;
-			bool inside = false;
-			if (o.kind == N_PARAM) for (const auto& q : R.objs) if (q.kind != N_PARAM && a >= (const char*)q.addr && a < (const char*)q.addr + q.size) inside = true;
-			if (!inside) kept.push_back(o);
-		}
-		R.objs = kept;
-		Controls& ctl = fx->controls;
-		R.prog.channels = channels;
-		R.prog.nctl = (int)ctl.size() < 8 ? (int)ctl.size() : 8;
-		for (int c = 0; c < R.prog.nctl; c++) R.prog.dials[c] = { ctl[c].min, ctl[c].max, ctl[c].initial };
-		// prepare() is recorded too: it becomes the program's per-block prologue (`prepare <n>`), so `filter.set(controls[2])`
-		// follows each instance's own control.  Member params it assigns are written to the record and read back by process().
-		R.recording = true;
-		std::vector<int> first_reg(R.objs.size(), -1);
-		std::vector<Oscillator*> oscs; std::vector<int> osc_node;
-		for (size_t i = 0; i < R.objs.size(); i++) if (is_oscillator(R.objs[i].kind)) if (Oscillator* o = const_cast<Oscillator*>(dynamic_cast<const Oscillator*>(R.objs[i].packable))) { oscs.push_back(o); osc_node.push_back((int)i); }
-		auto fresh_inputs = [&]() {                                              // control / member / frequency reads of the phase being recorded
-			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; first_reg[i] = sg->reg = R.emit(OP_PARAM, -1, -1, (int)i, 0, true); }
-			for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = R.emit(OP_CTL, -1, -1, -1, (uint32_t)c, true);
-			for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = R.emit(OP_FREQ, -1, -1, osc_node[q], 0, true);
-		};
-		auto write_back = [&](signal* skip0, signal* skip1) {
-			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
-				signal* sg = (signal*)R.objs[i].addr;
-				if (sg != skip0 && sg != skip1 && sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);
-			}
-		};
-		fresh_inputs();
-		fx->prepare();
-		write_back(nullptr, nullptr);
-		R.prog.prepare_ops = (int)R.prog.ops.size();
-		fresh_inputs();
+		Recorder C; C.effect = true; rec = &C;
+		C.constructing = true; fx = new FX(); C.constructing = false; rec = nullptr;
+		const char* lo = (const char*)fx;
 		signal* ins[2]; signal* outs[2];
 		if constexpr (FX::channels == 2) { ins[0] = &fx->in.l; ins[1] = &fx->in.r; outs[0] = &fx->out.l; outs[1] = &fx->out.r; }
 		else { ins[0] = ins[1] = &fx->in; outs[0] = outs[1] = &fx->out; }
-		for (int c = 0; c < channels; c++) ins[c]->reg = R.emit(OP_IN, -1, -1, -1, (uint32_t)c, true);      // `in` is this sample of the block
-		std::vector<float> value0(R.objs.size(), 0.f); std::vector<int> freq_reg, in_reg;
-		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) value0[i] = ((signal*)R.objs[i].addr)->value;
-		for (Oscillator* o : oscs) freq_reg.push_back(o->frequency.reg);
-		for (int c = 0; c < channels; c++) in_reg.push_back(ins[c]->reg);
-		PathMerger paths(R, [&]() {                                          // one run of process() per outcome of its data-dependent `if`s
-			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = first_reg[i]; sg->value = value0[i]; }
-			for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = freq_reg[q];
-			for (int c = 0; c < channels; c++) ins[c]->reg = in_reg[(size_t)c];
-			R.may_branch = true;
-			fx->process();
-			R.may_branch = false;
-			const int ret = R.reg_of(*outs[0]), ret_r = channels == 2 ? R.reg_of(*outs[1]) : -1;
-			for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
-				signal* sg = (signal*)R.objs[i].addr;
-				const bool io = sg == ins[0] || sg == ins[1];
-				if (!io && sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);
-			}
-			R.emit(PathMerger::OP_OUT, ret, ret_r, -1, 0, false);
-		});
-		paths.record();
-		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = -1; sg->value = value0[i]; }
-		for (int c = 0; c < R.prog.nctl; c++) ctl[c].value.reg = -1;
-		for (Oscillator* o : oscs) o->frequency.reg = -1;
-		R.recording = false; rec = nullptr;
-		if (!R.error.empty()) { std::fprintf(stderr, "klang-mi355: cannot record %s::process() as a graph effect: %s\n", typeid(FX).name(), R.error.c_str()); std::abort(); }
-		finish_program(R, lo, layout);
-		if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", typeid(FX).name(), layout.program.c_str());
+		FX* f = fx;
+		record_effect(member_objs(C, lo, lo + sizeof(FX)), fx->controls, channels, ins, outs, [f]() { f->prepare(); }, [f]() { f->run_process(); }, lo, layout, typeid(FX).name());
 		std::vector<uint32_t> words((size_t)layout.words, 0u);
 		layout.pack(fx, words.data());
 		h = klg_fx_create_graph(layout.program.c_str(), instances, fs.f, max_block, words.data());

@@ -102,6 +102,13 @@ int klg_process(klg_synth* s, float* const* out, int channels, int n, float* par
 /* Same block, additionally returning every voice's own n samples (per_voice[v*n + i], zeros for Off voices):
  * the quantity Note::process(buffer) writes (klang.h:4295-4303).  Parity/debug path. */
 int klg_process_voices(klg_synth* s, float* per_voice, float* const* out, int channels, int n);
+/* How the voices of one synth instance combine.  KLG_MIX_SUM (default): the block is the SUM of the sounding voices and is ADDED to the
+ * caller's samples — Stereo::Synth::process (klang.h:4842-4848; Stereo::Note::process `buffer++ += out`, 4731).
+ * KLG_MIX_LAST_ACTIVE: the mono klang::Synth::process(float*, int, float*) (klang.h:4450-4457) lets every sounding note OVERWRITE the
+ * block in note order (Note::process: `buffer++ = out`, 4299), so the block is the output of the LAST sounding note of the instance
+ * alone and REPLACES the caller's samples (they stay as they are while no note sounds).  Per-voice outputs are the same in both modes. */
+enum { KLG_MIX_SUM = 0, KLG_MIX_LAST_ACTIVE = 1 };
+int klg_synth_set_mix_mode(klg_synth* s, int mode);
 /* replaces: reading note->stage after the block (klang.h:4455-4456: `if (!note->process(..)) note->stop()`). */
 int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices);
 

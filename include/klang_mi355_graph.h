@@ -18,7 +18,7 @@
  *     dial <i> <min> <max> <initial>      Dial(...) of control i              klang.h:1797-1800
  *     node <id> <kind> [size]             a primitive object of the Note / Effect, ids 0,1,2,... in order (size: Delay<SIZE>)
  *     op <code> <dst> <a> <b> <node> <imm>   one op; unused fields are -1; imm = IEEE-754 bits (hex) of a constant
- *     prepare <n>                         optional (effects): the first n ops are Effect::prepare() (klang.h:4208-4211) — they run once per
+ *     prepare <n>                         optional: the first n ops are Effect::prepare() / Note::prepare() (klang.h:4208-4211) — they run once per
  *                                         block per instance, before the samples; their registers are not visible to the sample ops
  *     ret <reg>                           the register holding `out` at the end of process()   (ret2 <l> <r> for a Stereo::Effect)
  *     end
@@ -307,7 +307,7 @@ struct Program {
 			}
 		}
 		if (!open.empty()) return "graph program: an `if` is not closed";
-		if (prepare_ops > (int)ops.size() || (prepare_ops && !channels)) return "graph program: 'prepare' needs an effect program and at most as many ops as there are";
+		if (prepare_ops > (int)ops.size()) return "graph program: 'prepare' names more ops than there are";
 		{	/* sample ops may not read prepare() registers (prepare runs in another function of the generated patch) */
 			std::vector<char> pre; for (int i = 0; i < prepare_ops; i++) if (ops[(size_t)i].dst >= 0) { if ((int)pre.size() <= ops[(size_t)i].dst) pre.resize((size_t)ops[(size_t)i].dst + 1, 0); pre[(size_t)ops[(size_t)i].dst] = 1; }
 			auto is_pre = [&](int r) { return r >= 0 && r < (int)pre.size() && pre[(size_t)r]; };

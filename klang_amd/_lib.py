@@ -55,6 +55,7 @@ def load():
         "klg_get_control": (C.c_int, [vp, C.c_int, C.c_int, f32p]),
         "klg_process": (C.c_int, [vp, C.POINTER(f32p), C.c_int, C.c_int, f32p]),
         "klg_process_voices": (C.c_int, [vp, f32p, C.POINTER(f32p), C.c_int, C.c_int]),
+        "klg_synth_set_mix_mode": (C.c_int, [vp, C.c_int]),
         "klg_voice_stages": (C.c_int, [vp, u8p, C.c_int]),
         "klg_process_device": (C.c_int, [vp, vp, C.c_int, vp]),
         "klg_sync": (C.c_int, [vp]),

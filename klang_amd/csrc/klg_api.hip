@@ -105,6 +105,7 @@ struct klg_synth {
 	float *d_controls = nullptr, *d_partials = nullptr, *d_mix = nullptr, *d_per_voice = nullptr;
 	uint32_t* d_scratch_rec = nullptr;
 	int grid = 0;
+	int mix_mode = 0; int* d_solo = nullptr;      // klg_synth_set_mix_mode: KLG_MIX_LAST_ACTIVE keeps one voice per instance (d_solo[synths])
 	bool x2 = true;               // KLG_RENDER_X1=1 in the environment selects the one-voice-per-lane kernel (A/B tests)
 	// graph patches (klg_graph.hpp): the render kernels come from a hipRTC code object instead of this library
 	const graphrt::Compiled* graph = nullptr;
@@ -143,6 +144,7 @@ static void synth_free(klg_synth* s) {
 	void* dev[] = { s->d_state, s->d_controls, s->d_partials, s->d_mix, s->d_per_voice, s->d_scratch_rec, s->d_stage };
 	for (void* p : dev) if (p) (void)hipFree(p);
 	if (s->d_note_rings) (void)hipFree(s->d_note_rings);
+	if (s->d_solo) (void)hipFree(s->d_solo);
 	for (auto& t : s->tables) if (t.d) (void)hipFree(t.d);
 	if (s->d_tables) (void)hipFree(s->d_tables);
 	void* pinned[] = { s->h_stage, s->h_mix, s->h_flags, s->h_per_voice };
@@ -246,7 +248,7 @@ extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, in
 	for (int i = 0; i < 2 && ok; i++) ok = hipModuleGetFunction(&s->graph_fn[i], s->module, c->name[i].c_str()) == hipSuccess;
 	if (!ok) { fail(KLG_ERR_HIP, "klg_synth_create_graph: loading the compiled patch failed: %s", hipGetErrorString(hipGetLastError())); synth_free(s); return nullptr; }
 	if (c->ring_rows > 0) {                                       // a delay line per voice and Delay member (zero-filled, like a fresh Delay)
-		const size_t bytes = s->stride * (size_t)c->ring_rows * sizeof(float);
+		const size_t bytes = (s->stride + 1) * (size_t)c->ring_rows * sizeof(float);      // + the scratch line dead lanes of a live wave write to (klg_render)
 		if (bytes > (200ull << 30) || hipMalloc((void**)&s->d_note_rings, bytes) != hipSuccess || hipMemset(s->d_note_rings, 0, bytes) != hipSuccess) {
 			fail(KLG_ERR_HIP, "klg_synth_create_graph: %zu voices x %lld delay samples = %.1f GB of delay lines could not be allocated", s->stride, c->ring_rows, bytes / 1e9);
 			synth_free(s); return nullptr;
@@ -267,6 +269,19 @@ extern "C" int klg_graph_check(const char* program, int want_source, char* out, 
 
 extern "C" void klg_synth_destroy(klg_synth* s) { if (s && g_device >= 0) (void)hipSetDevice(g_device); synth_free(s); }
 extern "C" int klg_synth_voices_per_lane(const klg_synth* s) { if (!s) return KLG_ERR_INVALID; return ((s->patch == KLG_PATCH_SUB2A && s->x2) || (s->graph && s->graph->x2)) ? 2 : 1; }
+// replaces: the voice loop of the MONO Synth::process(float*, int, float*) (klang.h:4450-4457), see include/klang_mi355.h
+extern "C" int klg_synth_set_mix_mode(klg_synth* s, int mode) {
+	if (!s || (mode != KLG_MIX_SUM && mode != KLG_MIX_LAST_ACTIVE)) return fail(KLG_ERR_INVALID, "klg_synth_set_mix_mode: bad handle or mode %d", mode);
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (mode == KLG_MIX_LAST_ACTIVE && !s->d_solo) {
+		RandGuard rg;
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		HIP_TRY(hipMalloc((void**)&s->d_solo, (size_t)s->S * sizeof(int)));
+		if (s->patch == KLG_PATCH_SUB2A) s->x2 = false;             // the packed kernel has no per-voice mask at its tile write: one voice per lane in this mode
+	}
+	s->mix_mode = mode;
+	return 0;
+}
 extern "C" int klg_synth_voices(const klg_synth* s) { return s ? s->V : KLG_ERR_INVALID; }
 extern "C" int klg_synth_controls(const klg_synth* s) { return s ? s->nctl : KLG_ERR_INVALID; }
 extern "C" size_t klg_synth_state_bytes(const klg_synth* s) { return s ? (size_t)s->W * 4 : 0; }
@@ -275,8 +290,8 @@ extern "C" size_t klg_synth_state_bytes(const klg_synth* s) { return s ? (size_t
 // kernel dispatch by patch
 // ------------------------------------------------------------------------------------------------
 template<class P> static void launch_render_t(klg_synth* s, const RenderArgs& a, bool pv, hipStream_t st) {
-	if (pv) hipLaunchKernelGGL((klg_render<P, true>), dim3(s->grid), dim3(WG), 0, st, a);
-	else hipLaunchKernelGGL((klg_render<P, false>), dim3(s->grid), dim3(WG), 0, st, a);
+	if (pv) hipLaunchKernelGGL((klg_render<P, true>), dim3(s->grid), dim3(WG), render_lds_bytes(a.n), st, a);
+	else hipLaunchKernelGGL((klg_render<P, false>), dim3(s->grid), dim3(WG), render_lds_bytes(a.n), st, a);
 }
 static int render_grid(const klg_synth* s) {      // workgroups (= partial rows) of the render launch
 	if ((s->patch == KLG_PATCH_SUB2A && s->x2) || (s->graph && s->graph->x2)) return std::min((int)((s->stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG), s->grid);
@@ -286,13 +301,13 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 	if (s->graph) {                                       // hipRTC code object: klg_render<PatchGen, pv>
 		RenderArgs args = a;
 		void* params[] = { &args };
-		s->launch_error = hipModuleLaunchKernel(s->graph_fn[pv ? 1 : 0], (unsigned)render_grid(s), 1, 1, WG, 1, 1, 0, st, params, nullptr);
+		s->launch_error = hipModuleLaunchKernel(s->graph_fn[pv ? 1 : 0], (unsigned)render_grid(s), 1, 1, WG, 1, 1, render_lds_bytes(a.n), st, params, nullptr);
 		return;
 	}
 	if (s->patch == KLG_PATCH_SUB2A && s->x2) {           // two voices per lane, packed fp32 (klg_render_x2.hpp)
 		const dim3 g(render_grid(s)), b(WG);
-		if (pv) hipLaunchKernelGGL(klg_render_sub2a_x2<true>, g, b, 0, st, a);
-		else hipLaunchKernelGGL(klg_render_sub2a_x2<false>, g, b, 0, st, a);
+		if (pv) hipLaunchKernelGGL(klg_render_sub2a_x2<true>, g, b, render_lds_bytes(a.n), st, a);
+		else hipLaunchKernelGGL(klg_render_sub2a_x2<false>, g, b, render_lds_bytes(a.n), st, a);
 		return;
 	}
 	switch (s->patch) {
@@ -560,6 +575,11 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	if (int rc = tables_sync(s)) return rc;
 	a.tables = s->d_tables;
 	a.rings = s->d_note_rings; a.ring_rows = s->graph ? (size_t)s->graph->ring_rows : 0;
+	a.solo = nullptr;
+	if (s->mix_mode == KLG_MIX_LAST_ACTIVE) {                      // after this block's events: which voice of each instance is heard
+		hipLaunchKernelGGL(klg_select_last_active, dim3((s->S + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->d_state, s->S, s->P, s->d_solo);
+		a.solo = s->d_solo;
+	}
 	if (s->timing) {
 		if ((int)s->tev.size() < 2 * (s->launches + 1)) { hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); s->tev.push_back(e0); s->tev.push_back(e1); }
 		HIP_TRY(hipEventRecord(s->tev[2 * s->launches], st));
@@ -584,13 +604,22 @@ static int process_host(klg_synth* s, float* per_voice, float* const* out, int c
 		HIP_TRY(hipMalloc(&s->d_per_voice, (size_t)s->V * s->max_block * 4));
 		HIP_TRY(hipHostMalloc(&s->h_per_voice, (size_t)s->V * s->max_block * 4));
 	}
+	bool replace = false;                                          // KLG_MIX_LAST_ACTIVE: a sounding note overwrites the caller's samples (klang.h:4299)
+	if (s->mix_mode == KLG_MIX_LAST_ACTIVE) {
+		if (int rc = refresh_stages(s)) return rc;
+		for (int v = 0; v < s->V && !replace; v++) replace = s->voices[v].stage != ST_OFF;
+	}
 	HIP_TRY(hipMemsetAsync(s->d_mix, 0, (size_t)2 * n * 4, st));
 	if (int rc = enqueue_block(s, s->d_mix, n, per_voice != nullptr, st)) return rc;
 	HIP_TRY(hipMemcpyAsync(s->h_mix, s->d_mix, (size_t)2 * n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(s->h_flags, s->d_state, (size_t)s->V * 4, hipMemcpyDeviceToHost, st));
 	if (per_voice) HIP_TRY(hipMemcpyAsync(s->h_per_voice, s->d_per_voice, (size_t)s->V * n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
-	if (out) for (int c = 0; c < channels; c++) { float* dst = out[c]; const float* src = s->h_mix + (size_t)c * n; for (int i = 0; i < n; i++) dst[i] += src[i]; }
+	if (out) for (int c = 0; c < channels; c++) {
+		float* dst = out[c]; const float* src = s->h_mix + (size_t)c * n;
+		if (replace) std::memcpy(dst, src, (size_t)n * 4);
+		else if (s->mix_mode != KLG_MIX_LAST_ACTIVE) for (int i = 0; i < n; i++) dst[i] += src[i];
+	}
 	if (per_voice) std::memcpy(per_voice, s->h_per_voice, (size_t)s->V * n * 4);
 	for (int v = 0; v < s->V; v++) if ((s->h_flags[v] & 3u) == (uint32_t)ST_OFF) s->voices[v].stage = ST_OFF;
 	s->stages_dirty = false;

@@ -30,7 +30,7 @@ inline std::string fmt(const char* f, ...) {
 // Can this program run two voices per lane?  Only node kinds / ops that have packed forms in klg_device_x2.hpp.
 inline bool x2_eligible(const Program& g) {
 	using namespace graph;
-	if (g.channels) return false;
+	if (g.channels || g.prepare_ops) return false;
 	for (int k : g.nodes) if (!(k == N_FSINE || k == N_SAW || k == N_PULSE || k == N_LPF || k == N_ENV || k == N_ADSR || k == N_PARAM)) return false;
 	for (const Op& o : g.ops) switch (o.code) {
 		case OP_CONST: case OP_CTL: case OP_PARAM: case OP_OSC: case OP_LPF: case OP_ENV: case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_NEG:

@@ -7,8 +7,10 @@
 //                        registers, and writes back only the words that change.  Voice mix: every 32 samples a wave
 //                        transposes its 64x32 outputs through a padded LDS tile (stride 65 dwords: conflict-free
 //                        ds_write_b32 / ds_read_b32), each lane sums 32 voices for one sample, the two half-sums are
-//                        combined with one cross-lane exchange and accumulated into the workgroup's [n] LDS
-//                        accumulator with ds_add_f32.  The workgroup then writes its partial [n] row.
+//                        combined with one cross-lane exchange and added to the WAVE's own [n] row in LDS (dynamic LDS:
+//                        WAVES x n floats, so only the wave itself ever touches its row: no atomics, a fixed order).  The
+//                        workgroup then adds its four rows in wave order and writes its partial [n] row: the mix is
+//                        bit-reproducible from run to run.
 //   klg_reduce           partial rows -> the stereo block (ADDED to the destination, like the reference's `+=`).
 //
 // Workgroups are independent (no inter-workgroup communication inside a launch); groups of 256 voices are dealt
@@ -32,8 +34,9 @@ struct RenderArgs {
 	float* partials;          // [gridDim.x][n]
 	float* per_voice;         // [voices][n] or null
 	const TableDesc* tables;  // [tables] or null (klg_table_upload)
-	float* rings;             // note delays: [stride][ring_rows] — each voice's lines contiguous (a generated patch's Delay members), or null
+	float* rings;             // note delays: [stride + 1][ring_rows] (the last line is the dead lanes' scratch) — each voice's lines contiguous (a generated patch's Delay members), or null
 	size_t ring_rows;         // ring positions per voice = the sum of the patch's Delay SIZEs
+	const int* solo;          // KLG_MIX_LAST_ACTIVE: [synths] the one voice of each instance that is heard this block (-1: none), else null
 };
 
 // record <-> word planes.  Words are moved with static indices only (fully unrolled) and converted with
@@ -51,6 +54,11 @@ __device__ __forceinline__ void wave_sync() {
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// Dynamic LDS of the render kernels: [WAVES][n] floats, one mix row per wave (render_lds_bytes(n) at launch).
+extern __shared__ float klg_mix_rows[];
+__device__ __forceinline__ float mix_rows_sum(int i, int n) { return ((klg_mix_rows[i] + klg_mix_rows[n + i]) + klg_mix_rows[2 * n + i]) + klg_mix_rows[3 * n + i]; }   // fixed order
+__host__ __device__ inline unsigned render_lds_bytes(int n) { return (unsigned)(WAVES * n * sizeof(float)); }
 
 // records longer than 64 words (generated graph patches, klg_graph.hpp) name their second store mask kStoreMask2
 template<class...> using klg_void_t = void;
@@ -72,20 +80,24 @@ template<class P, bool PER_VOICE>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P>::lo, WavesPerEu<P>::hi))) void klg_render(const RenderArgs a) {
 	using Rec = typename P::Rec;
 	constexpr int W = sizeof(Rec) / 4;
-	__shared__ float lds[WAVES * CHUNK * TILE_LD + MAX_BLOCK];
-	float* acc = lds + WAVES * CHUNK * TILE_LD;
+	__shared__ float lds[WAVES * CHUNK * TILE_LD];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	float* tile = lds + wave * CHUNK * TILE_LD;
 	const int n = a.n;
+	float* acc = klg_mix_rows + wave * n;                    // this wave's own mix row
 
-	for (int i = tid; i < n; i += WG) acc[i] = 0.f;
-	__syncthreads();
+	for (int i = lane; i < n; i += 64) acc[i] = 0.f;
+	wave_sync();
 
 	const int groups = (int)(a.stride / WG);
 	for (int g = blockIdx.x; g < groups; g += gridDim.x) {
 		const int v = g * WG + tid;
 		uint32_t flags = (v < a.voices) ? a.state[v] : (uint32_t)ST_OFF;
 		const bool live = (flags & 3u) != (uint32_t)ST_OFF;
+		// the mono Synth of the reference lets each sounding note overwrite the block in turn (klang.h:4299, 4450-4457): only the last one is heard
+		const bool audible = live && (!a.solo || a.solo[v / a.notes_per_synth] == v);
+		const bool in_tile = PER_VOICE ? live : audible;         // the per-voice dump wants every voice's own samples: there the selection happens in the sum
+		const unsigned long long heard = __ballot(audible);
 		if (__ballot(live) == 0ull) {                        // whole wave silent: nothing to add
 			if (PER_VOICE) {
 				const int v0 = g * WG + wave * 64;
@@ -100,7 +112,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		BlockCtx ctx;
 		ctx.fs = a.fs;
 		ctx.tables = a.tables;
-		ctx.ring = a.rings ? a.rings + (size_t)v * a.ring_rows : nullptr;                   // this voice's lines, contiguous
+		// this voice's lines, contiguous.  Dead lanes of a live wave run the body too (on an all-zero record): their ring accesses go to the
+		// one scratch line behind the last voice's (line index `stride`), so an Off voice's own line keeps its contents like the reference's
+		ctx.ring = a.rings ? a.rings + (size_t)(live ? (size_t)v : a.stride) * a.ring_rows : nullptr;
 		ctx.ctl = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
 		// Dead lanes of a live wave run the same instruction stream on an all-zero record (no per-sample exec
 		// masking); their output is forced to 0 at the tile write and their record is never stored.
@@ -115,15 +129,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 			if constexpr (HasQuiet<P>::value) quiet = P::quiet(L);
 			if (quiet == 2) {
 				if constexpr (HasQuiet<P>::value)
-					for (int s = 0; s < cl; s++) { const float y = P::sample_fast(L, ctx); tile[s * TILE_LD + lane] = live ? y : 0.f; }
+					for (int s = 0; s < cl; s++) { const float y = P::sample_fast(L, ctx); tile[s * TILE_LD + lane] = in_tile ? y : 0.f; }
 			}
 			else if (quiet == 1) {
 				if constexpr (HasQuiet<P>::value)
-					for (int s = 0; s < cl; s++) { const float y = P::sample_quiet(L, ctx); tile[s * TILE_LD + lane] = live ? y : 0.f; }
+					for (int s = 0; s < cl; s++) { const float y = P::sample_quiet(L, ctx); tile[s * TILE_LD + lane] = in_tile ? y : 0.f; }
 			}
 			else for (int s = 0; s < cl; s++) {
 				const float y = P::sample(L, ctx);
-				tile[s * TILE_LD + lane] = live ? y : 0.f;
+				tile[s * TILE_LD + lane] = in_tile ? y : 0.f;
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
@@ -141,11 +155,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 				float sum = 0.f;
 				if (s < cl) {
 					const float* row = tile + s * TILE_LD + h * 32;
+					if (PER_VOICE && a.solo) { for (int j = 0; j < 32; j++) sum += ((heard >> (h * 32 + j)) & 1ull) ? row[j] : 0.f; }
+					else {
 #pragma unroll
-					for (int j = 0; j < 32; j++) sum += row[j];
+						for (int j = 0; j < 32; j++) sum += row[j];
+					}
 				}
 				sum += __shfl_xor(sum, 32);
-				if (lane < cl) atomicAdd(&acc[c0 + lane], sum);     // LDS ds_add_f32
+				if (lane < cl) acc[c0 + lane] += sum;               // the wave's own row: program order, no atomics
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
@@ -160,7 +177,17 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		}
 	}
 	__syncthreads();
-	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = acc[i];
+	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = mix_rows_sum(i, n);
+}
+
+// KLG_MIX_LAST_ACTIVE: the highest-numbered sounding note of every synth instance (the one whose block survives in the reference's
+// mono Synth::process, klang.h:4450-4457), after this block's events have been applied
+__global__ void klg_select_last_active(const uint32_t* __restrict__ flags, int synths, int notes_per_synth, int* __restrict__ solo) {
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= synths) return;
+	int sel = -1;
+	for (int p = 0; p < notes_per_synth; p++) if ((flags[(size_t)s * notes_per_synth + p] & 3u) != (uint32_t)ST_OFF) sel = s * notes_per_synth + p;
+	solo[s] = sel;
 }
 
 // partial rows [rows][n] -> mix[c][i] += sum  (Stereo::Mono::Note: L += out; R += out, klang.h:4751-4752).

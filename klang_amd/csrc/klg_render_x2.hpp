@@ -137,13 +137,13 @@ __device__ __forceinline__ void sub2a_x2_end(const Sub2aX2& L, u2& flags, u2& of
 template<bool PER_VOICE>
 __global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
 	constexpr int W = sizeof(PatchSub2a::Rec) / 4;
-	__shared__ __attribute__((aligned(16))) float lds[WAVES * X2_CHUNK * X2_LD * 2 + MAX_BLOCK];
-	float* acc = lds + WAVES * X2_CHUNK * X2_LD * 2;
+	__shared__ __attribute__((aligned(16))) float lds[WAVES * X2_CHUNK * X2_LD * 2];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	f2* tile = reinterpret_cast<f2*>(lds) + wave * X2_CHUNK * X2_LD;
 	const int n = a.n;
-	for (int i = tid; i < n; i += WG) acc[i] = 0.f;
-	__syncthreads();
+	float* acc = klg_mix_rows + wave * n;                    // this wave's own mix row (klg_kernels.hpp)
+	for (int i = lane; i < n; i += 64) acc[i] = 0.f;
+	wave_sync();
 
 	const int groups = (int)((a.stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG);
 	for (int g = blockIdx.x; g < groups; g += gridDim.x) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
 				float sum = sum2.x + sum2.y;
 #pragma unroll
 				for (int m = X2_CHUNK; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
-				if (lane < cl) atomicAdd(&acc[c0 + lane], sum);
+				if (lane < cl) acc[c0 + lane] += sum;
 			}
 			wave_sync();
 		}
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
 		}
 	}
 	__syncthreads();
-	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = acc[i];
+	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = mix_rows_sum(i, n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -244,13 +244,13 @@ __device__ __forceinline__ f2 ctl_read(const BlockCtx2& c, unsigned i) { f2 r = 
 template<class P, bool PER_VOICE>
 __global__ __launch_bounds__(WG) void klg_render_x2(const RenderArgs a) {
 	constexpr int W = P::kWords;
-	__shared__ __attribute__((aligned(16))) float lds[WAVES * X2_CHUNK * X2_LD * 2 + MAX_BLOCK];
-	float* acc = lds + WAVES * X2_CHUNK * X2_LD * 2;
+	__shared__ __attribute__((aligned(16))) float lds[WAVES * X2_CHUNK * X2_LD * 2];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	f2* tile = reinterpret_cast<f2*>(lds) + wave * X2_CHUNK * X2_LD;
 	const int n = a.n;
-	for (int i = tid; i < n; i += WG) acc[i] = 0.f;
-	__syncthreads();
+	float* acc = klg_mix_rows + wave * n;                    // this wave's own mix row (klg_kernels.hpp)
+	for (int i = lane; i < n; i += 64) acc[i] = 0.f;
+	wave_sync();
 
 	const int groups = (int)((a.stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG);
 	for (int g = blockIdx.x; g < groups; g += gridDim.x) {
@@ -274,6 +274,14 @@ __global__ __launch_bounds__(WG) void klg_render_x2(const RenderArgs a) {
 			const u2 t = any_live ? *reinterpret_cast<const u2*>(a.state + (size_t)k * a.stride + v) : (u2)0u;
 			rec.w[k] = live ? t : (u2)0u;
 		}
+		// KLG_MIX_LAST_ACTIVE (klg_kernels.hpp): only one voice of each synth instance is heard; the per-voice dump keeps every voice
+		i2 heard = live;
+		if (a.solo) {
+			heard.x = (live.x && a.solo[v / a.notes_per_synth] == v) ? -1 : 0;
+			heard.y = (live.y && a.solo[(v + 1) / a.notes_per_synth] == v + 1) ? -1 : 0;
+		}
+		const unsigned long long heard_x = __ballot(heard.x != 0), heard_y = __ballot(heard.y != 0);
+		if (PER_VOICE) heard = live;                              // the tile then holds every voice; the selection happens in the sum
 		typename P::Live L;
 		BlockCtx2 ctx;
 		ctx.fs = a.fs; ctx.tables = a.tables;
@@ -286,17 +294,17 @@ __global__ __launch_bounds__(WG) void klg_render_x2(const RenderArgs a) {
 			if (quiet == 2) {
 				if (cl == X2_CHUNK) {
 #pragma unroll 4
-					for (int s = 0; s < X2_CHUNK; s++) { const f2 y = P::sample_fast(L, ctx); tile[s * X2_LD + lane] = live ? y : splat(0.f); }
+					for (int s = 0; s < X2_CHUNK; s++) { const f2 y = P::sample_fast(L, ctx); tile[s * X2_LD + lane] = heard ? y : splat(0.f); }
 				}
-				else for (int s = 0; s < cl; s++) { const f2 y = P::sample_fast(L, ctx); tile[s * X2_LD + lane] = live ? y : splat(0.f); }
+				else for (int s = 0; s < cl; s++) { const f2 y = P::sample_fast(L, ctx); tile[s * X2_LD + lane] = heard ? y : splat(0.f); }
 			}
 			else if (quiet == 1) {
-				for (int s = 0; s < cl; s++) { const f2 y = P::sample_quiet(L, ctx); tile[s * X2_LD + lane] = live ? y : splat(0.f); }
+				for (int s = 0; s < cl; s++) { const f2 y = P::sample_quiet(L, ctx); tile[s * X2_LD + lane] = heard ? y : splat(0.f); }
 			}
 			else {
 				for (int s = 0; s < cl; s++) {
 					const f2 y = P::sample(L, ctx);
-					tile[s * X2_LD + lane] = live ? y : splat(0.f);
+					tile[s * X2_LD + lane] = heard ? y : splat(0.f);
 				}
 			}
 			wave_sync();
@@ -315,13 +323,18 @@ __global__ __launch_bounds__(WG) void klg_render_x2(const RenderArgs a) {
 				f2 sum2 = splat(0.f);
 				if (s < cl) {
 					const f2* row = tile + s * X2_LD + q * (64 / Q);
+					if (PER_VOICE && a.solo) {
+						for (int j = 0; j < 64 / Q; j++) { const int src = q * (64 / Q) + j; f2 t = row[j]; t.x = ((heard_x >> src) & 1ull) ? t.x : 0.f; t.y = ((heard_y >> src) & 1ull) ? t.y : 0.f; sum2 += t; }
+					}
+					else {
 #pragma unroll
-					for (int j = 0; j < 64 / Q; j++) sum2 += row[j];
+						for (int j = 0; j < 64 / Q; j++) sum2 += row[j];
+					}
 				}
 				float sum = sum2.x + sum2.y;
 #pragma unroll
 				for (int m = X2_CHUNK; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
-				if (lane < cl) atomicAdd(&acc[c0 + lane], sum);
+				if (lane < cl) acc[c0 + lane] += sum;
 			}
 			wave_sync();
 		}
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(WG) void klg_render_x2(const RenderArgs a) {
 		}
 	}
 	__syncthreads();
-	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = acc[i];
+	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = mix_rows_sum(i, n);
 }
 
 } // namespace klg
