@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py — voice*samples/s of the Subtractive patch (BASELINE.json metric) on N MI355X of one node.
+"""bench.py — voice*samples/s of the Subtractive patch (BASELINE.json metric) on N MI355X of one node, and every BASELINE config beside it.
 
-A "step" is one audio block (256 samples @ 48 kHz) of every voice resident on the GPU: one klg_render launch
-(+ the tiny partial-sum reduce) accumulating into a device-resident stereo block; with N > 1 the voices are
-sharded across ranks (independent voice ranges, weak scaling) and the only exchange is one RCCL all-reduce of
-the [2][256] stereo block per step (BASELINE.json north_star).  Inputs (voice state) are resident in HBM when the
-timed region starts.
+HEADLINE (`value`): SURVEY.md §8(d)'s config-2 event script — Saw >> LPF >> ADSR voices, 256-sample blocks @ 48 kHz, a 375-block (2 s) note
+life: note-on at block 0, note-off at block 150 + (v mod 64), the 0.255 s release, silence — played as a STEADY STATE: the bank is 375 voice
+groups, group g running the script g blocks late and starting over when it ends, so every block holds every phase of the script in the
+script's own proportions (inside a group all voices run in phase, so a wave sees exactly what it sees in the literal script: all-sustain,
+then 64 staggered releases, then silence).  A "step" is one block: the block's note events are applied from an event script resident in HBM
+(klg_script_*: every on() ran on the host before the timed region), then ONE klg_render launch + the partial-sum reduce accumulate the
+stereo block in HBM.  value = sounding voices x samples / time (SURVEY §8d "active voices").  With N > 1 every rank owns its own shard of
+voices (weak scaling) and the only exchange is one RCCL all-reduce of the [2][256] block per step.
 
-Prints ONE JSON line (driver contract) with the extra `roofline` and `cpu_baseline` objects.
+`configs` (N = 1 only): each BASELINE config at its own size, self-timed in the same run — cfg 2 at 1024 voices, cfg 3 (16384 SuperSaw
+voices), cfg 4 (4096 PingPong / 4096 Reverb instances, each with its own roofline), the cfg-5 per-GPU share (131072 FM4 voices) — the
+literal script at the headline size with its phases (all-ramping, sustain-only, staggered release), and the p99 real-time deadline test.
+
+Prints ONE JSON line (driver contract) with `roofline`, `cpu_baseline` and `configs`.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -22,27 +31,62 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_PEAK_TFLOPS = 157.3        # fp32 vector peak
+FP32_PEAK_TFLOPS = 157.3        # fp32 vector peak (packed FMA)
 FLOPS_PER_VOICE_SAMPLE = {"sub2a": 21, "sub2b": 120, "supersaw": 120, "fm4": 95, "fm3": 72, "sine": 12}   # SURVEY.md §8(d) estimates
 # algorithmic HBM bytes per voice per block: record read + words written back (klang_amd/csrc/klg_patches.hpp)
 STORE_WORDS = {"sub2a": 8, "sub2b": 19, "supersaw": 12, "fm3": 20, "fm4": 25, "sine": 2}
+FX_BYTES_PER_SAMPLE = {"pingpong": 32, "reverb": 312}     # SURVEY.md §8(d) algorithmic bytes per instance*sample
+NOTES = {"sub2a": 128, "sine": 128, "bsine": 128}          # note slots per Synth instance (others: 32)
+SCRIPT_BLOCKS, OFF_BLOCK, OFF_SPREAD = 375, 150, 64        # SURVEY §8(d) cfg 2: 2 s, note-off at 150 + (v mod 64)
+# blocks a voice still sounds after its note-off: ceil(release time * 48000 / 256) — sub2a 0.25 s + 5 ms = 12240 samples, SuperSaw.k 0.5 s + 5 ms, FM 1 s + 5 ms
+RELEASE_BLOCKS = {"sub2a": 48, "supersaw": 95, "fm3": 189, "fm4": 189}
+KERNEL_OF = {"sub2a": "klg_render_sub2a_x2", "supersaw": "klg_render<klg::PatchSuperSaw", "fm4": "klg_render<klg::PatchFM<4>", "fm3": "klg_render<klg::PatchFM<3>",
+             "pingpong": "klg_fx_pingpong_x", "reverb": "klg_fx_reverb16"}
 
 
-def pmc_traffic(patch, voices):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE x 2 per the
-    gfx950 half-count correction of MI355X_MICROARCH.md + WRITE_SIZE), or None when no matching profile exists."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        e = t.get(f"{patch}:{voices}")
-        return e["bytes_per_launch"] if e else None
-    except Exception:
-        return None
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the event script of SURVEY §8(d), as an HBM-resident klg_script
+# ---------------------------------------------------------------------------------------------------------------------------------
+def build_script(bank, groups, rng, cyclic):
+    """Voices [0, V) in `groups` equal contiguous groups; group g starts its note at block g * (375 // groups) ... (cyclic) or every
+    group at block 0 (literal script, groups == 1).  Returns (EventScript, sounding[b] = voices sounding during block b once settled)."""
+    import klang_amd
+    V, notes = bank.voices, bank.notes
+    pitches = rng.integers(36, 97, size=V).astype(np.int32)
+    vels = rng.uniform(0.25, 1.0, size=V).astype(np.float32)
+    owner = (np.arange(V) // notes).astype(np.int32)
+    records = bank.note_records(owner, pitches, vels)                       # every on() runs HERE, once (host)
+    script = klang_amd.EventScript(bank, SCRIPT_BLOCKS)
+    first = script.add_records(records)
+    v = np.arange(V, dtype=np.int64)
+    gs = V // groups
+    g = v // gs
+    start = (g * (SCRIPT_BLOCKS // groups)) % SCRIPT_BLOCKS if cyclic else np.zeros(V, np.int64)
+    off = start + OFF_BLOCK + (v % OFF_SPREAD)
+    if cyclic:
+        off %= SCRIPT_BLOCKS
+    script.note_on(start, v, first + v)
+    script.note_off(off, v)
+    script.commit()
+    # sounding voices per block: from note-on until RELEASE_BLOCKS blocks after the note-off (the block in which the envelope runs out is rendered)
+    life = OFF_BLOCK + (v % OFF_SPREAD) + RELEASE_BLOCKS[bank.patch]                     # blocks a voice sounds, counted from its note-on
+    sounding = np.zeros(SCRIPT_BLOCKS, np.int64)
+    for b in range(SCRIPT_BLOCKS):
+        local = (b - start) % SCRIPT_BLOCKS if cyclic else b - start
+        sounding[b] = int(((local >= 0) & (local < life)).sum())
+    return script, sounding
 
 
+def alg_bytes(patch, bank, live_voices, n):
+    return live_voices * (bank.state_bytes + 4 * STORE_WORDS.get(patch, bank.state_bytes // 4)) + 2 * n * 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# CPU baselines (reported beside the GPU number, N = 1 only)
+# ---------------------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(patch, block, budget_s=12.0):
     """The TEST-ONLY oracle (C restatement, bit-exact vs the reference header) timed on ONE host core on a
     bounded sample of the same workload: 128 voices (one Synth instance) x `block` samples x M blocks."""
-    import subprocess
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True, stdout=subprocess.DEVNULL)
     ko = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libklang_oracle.so"))
     ko.ko_bank_create.restype = C.c_void_p
@@ -51,7 +95,7 @@ def cpu_baseline(patch, block, budget_s=12.0):
     ko.ko_bank_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     ko.ko_patch_from_name.argtypes = [C.c_char_p]
     pid = ko.ko_patch_from_name(patch.encode())
-    notes = 128 if patch in ("sub2a", "sine", "bsine") else 32
+    notes = NOTES.get(patch, 32)
     synths = 128 // notes
     bank = ko.ko_bank_create(pid, synths, notes, C.c_float(48000.0))
     rng = np.random.default_rng(20250314)
@@ -70,15 +114,13 @@ def cpu_baseline(patch, block, budget_s=12.0):
             break
     dt = time.perf_counter() - t0
     return {"value": 128 * block * blocks / dt, "unit": "voice*samples/s", "cores": 1, "kind": "port",
-            "sample": f"{patch}: 128 voices x {block} samples x {blocks} blocks, oracle/klang_oracle.c -O2 single thread, {os.cpu_count()} host cores present"}
+            "sample": f"{patch}: 128 voices x {block} samples x {blocks} blocks, all sounding, oracle/klang_oracle.c -O2 single thread, {os.cpu_count()} host cores present"}
 
 
 def cpu_reference(patch, block, budget_s=10.0):
     """The GENUINE reference header (oracle/_ref/ref_subtractive: /root/reference/klang.h compiled where it lies, the binary travels)
     on one host core, same bounded workload: 128 voices x `block` samples x M blocks; wall time of the whole run (process start,
     128 note-ons and writing the mixes included: < 1 %).  None when the binary is not there."""
-    import subprocess
-    import tempfile
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_subtractive")
     if patch != "sub2a" or not os.path.exists(exe):
         return None
@@ -100,38 +142,233 @@ def cpu_reference(patch, block, budget_s=10.0):
     blocks = int(max(1000, min(40000, 1000 * budget_s / max(probe, 1e-3))))
     dt = run(blocks)
     return {"value": 128 * block * blocks / dt, "unit": "voice*samples/s", "cores": 1, "kind": "reference",
-            "sample": f"{patch}: 128 voices x {block} samples x {blocks} blocks, the reference's klang.h v0.7.8 (oracle/_ref/ref_subtractive, clang++ -O2) single thread, {os.cpu_count()} host cores present"}
+            "sample": f"{patch}: 128 voices x {block} samples x {blocks} blocks, all sounding, the reference's klang.h v0.7.8 (oracle/_ref/ref_subtractive, clang++ -O2) single thread, {os.cpu_count()} host cores present"}
 
 
-def valu_issue(patch, V, N, kern_s):
-    """VALU ISSUE-rate view of the sustain loop of klg_render_sub2a_x2 (the number that actually bounds this kernel): one wave =
-    128 voices; per sample its steady-state loop issues 27.75 instructions (4x unrolled: 109 VALU + 2 ds_write2 per 4 samples)
-    + 65 per 16-sample mix flush = 31.8 (counted in the ISA); a SIMD issues one wave64 VALU instruction
-    per 4 cycles, 1024 SIMDs at the 2.4 GHz peak engine clock."""
-    if patch != "sub2a" or os.environ.get("KLG_RENDER_X1") == "1":
-        return {}
-    achieved = (V / 128.0) * N * 31.8 / kern_s
+def valu_issue(wave_samples, kern_s, per_sample):
+    """VALU ISSUE-rate view of klg_render_sub2a_x2 (the unit that binds it): one wave = 128 voices; `per_sample` wave-instructions per
+    wave*sample (counted in the ISA); a SIMD issues one wave64 VALU instruction per 4 cycles, 1024 SIMDs at 2.4 GHz."""
     peak = 1024 * 2.4e9 / 4.0
-    return {"issue_rate_frac_est": achieved / peak, "wave_instr_per_wave_sample": 31.8, "issue_peak_wave_instr_per_s": peak}
+    return {"issue_rate_frac_est": wave_samples * per_sample / kern_s / peak, "wave_instr_per_wave_sample": per_sample, "issue_peak_wave_instr_per_s": peak}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# live HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around a child of this script
+# ---------------------------------------------------------------------------------------------------------------------------------
+def pmc_traffic_live(args, kernel_substr, timeout_s=240):
+    """bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024 (gfx950 FETCH_SIZE half-count, MI355X_MICROARCH.md §HBM), mean over the
+    child's steady-state launches of the named kernel; None if rocprofv3 is unavailable or anything goes wrong (never costs the bench line)."""
+    import csv
+    import glob
+    import shutil
+    if os.environ.get("KLG_BENCH_PMC", "1") == "0" or not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not run"
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="klg_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--voices", str(args.voices), "--block", str(args.block), "--patch", args.patch]
+            subprocess.run(cmd, check=True, timeout=timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        vals.append(float(r["Counter_Value"]))
+            shutil.rmtree(d, ignore_errors=True)
+            if not vals:
+                return None, f"no {counter} rows for {kernel_substr}"
+            vals = vals[len(vals) // 2:]                                # the child's settled blocks
+            got[counter] = sum(vals) / len(vals)
+        return (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in this run (2 passes, {len(vals)} launches each); (2*FETCH_SIZE + WRITE_SIZE) KB * 1024"
+    except Exception as e:                                              # noqa: BLE001
+        return None, f"pmc leg failed: {type(e).__name__}"
+
+
+def pmc_child(args):
+    """what rocprofv3 wraps: the headline steady state, few blocks (setup identical, so the kernel sees the same voice population)"""
+    import torch
+    import klang_amd
+    notes = NOTES.get(args.patch, 32)
+    V = groups_voices(args.voices)
+    bank = klang_amd.SynthBank(args.patch, synths=V // notes, notes=notes, max_block=args.block)
+    script, _ = build_script(bank, SCRIPT_BLOCKS, np.random.default_rng(20250314), cyclic=True)
+    mix = torch.zeros((2, args.block), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for b in range(SCRIPT_BLOCKS + 24):
+        mix.zero_(); script.play_device(b % SCRIPT_BLOCKS, mix.data_ptr(), args.block, st)
+    torch.cuda.synchronize()
+    bank.close()
+
+
+def groups_voices(voices):
+    """375 equal groups of whole workgroups (512 voices of the packed kernel)"""
+    gs = max(512, (voices // SCRIPT_BLOCKS) // 512 * 512)
+    return gs * SCRIPT_BLOCKS
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the other BASELINE configs, each at its own size (N = 1)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def run_literal_script(patch, voices, N, label, phases=False):
+    """the §8(d) script as written (every voice starts at block 0), 375 blocks through klg_script_play_device; value = sounding voices x samples / time"""
+    import torch
+    import klang_amd
+    notes = NOTES.get(patch, 32)
+    bank = klang_amd.SynthBank(patch, synths=max(1, voices // notes), notes=notes, max_block=N)
+    bank.random(12345)
+    script, sounding = build_script(bank, 1, np.random.default_rng(20250314), cyclic=False)
+    mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(SCRIPT_BLOCKS)]
+    mix.zero_(); torch.cuda.synchronize()
+    bank.timing_begin()
+    t0 = time.perf_counter()
+    for b in range(SCRIPT_BLOCKS):
+        ev[b][0].record()
+        mix.zero_(); script.play_device(b, mix.data_ptr(), N, st)
+        ev[b][1].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    launches, kms = bank.timing_end()
+    ms = np.array([a.elapsed_time(b) for a, b in ev])
+    alive = int((bank.stages() != 3).sum())
+    V = bank.voices
+    res = {"name": label, "workload": f"{patch}: {V} voices, SURVEY 8(d) script as written: note-on at block 0, note-off at block 150 + (v mod 64), {SCRIPT_BLOCKS} blocks of {N} samples, events from HBM",
+           "value": float(sounding.sum()) * N / dt, "unit": "voice*samples/s (sounding voices)", "ms_per_step": 1e3 * dt / SCRIPT_BLOCKS, "steps": SCRIPT_BLOCKS,
+           "kernel_ms_mean": kms / max(1, launches), "voices_sounding_mean": float(sounding.mean()), "voices_alive_at_end": alive,
+           "ms_per_block_sustain": float(np.median(ms[40:OFF_BLOCK])), "value_sustain_phase": V * N / (1e-3 * float(np.median(ms[40:OFF_BLOCK])))}
+    kern_s = 1e-3 * float(np.median(ms[40:OFF_BLOCK]))
+    ab = alg_bytes(patch, bank, V, N)
+    res["roofline"] = {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "kernel": KERNEL_OF.get(patch, patch), "phase": "sustain (block time incl. event kernel + reduce)", "algorithmic_bytes_per_launch": ab,
+                       "note": "voice state lives in registers: VALU-issue bound by design (DESIGN.md §3)"}
+    if phases:
+        res["phases_ms_per_block"] = {"attack_decay_all_ramping(1..21)": float(np.median(ms[1:22])), "sustain_only(40..149)": float(np.median(ms[40:OFF_BLOCK])),
+                                      "staggered_release(150..213)": float(np.median(ms[OFF_BLOCK:OFF_BLOCK + OFF_SPREAD])), "release_tail(214..260)": float(np.median(ms[214:261])),
+                                      "all_off(270..374)": float(np.median(ms[270:]))}
+        res["value_all_ramping_phase"] = V * N / (1e-3 * float(np.median(ms[1:22])))
+    script.close(); bank.close()
+    return res
+
+
+def run_fx(patch, K, N):
+    """cfg 4: K instances, 375 blocks (2 s): a white-noise burst for the first 4800 samples, then silence; io resident in HBM"""
+    import torch
+    import klang_amd
+    bank = klang_amd.FxBank(patch, K, max_block=N)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    burst_blocks = (4800 + N - 1) // N
+    inputs = torch.rand((burst_blocks, K, 2, N), device="cuda", generator=g) - 0.5
+    inputs[-1, :, :, 4800 - (burst_blocks - 1) * N:] = 0
+    io = torch.zeros((K, 2, N), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    bank.timing_begin()
+    t0 = time.perf_counter()
+    for b in range(SCRIPT_BLOCKS):
+        if b < burst_blocks:
+            io.copy_(inputs[b])
+        else:
+            io.zero_()
+        bank.process_device(io.data_ptr(), N, st)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    launches, kms = bank.timing_end()
+    kern_s = 1e-3 * kms / launches
+    ab = K * N * FX_BYTES_PER_SAMPLE[patch]
+    res = {"name": f"cfg4_{patch}_{K}", "workload": f"{K} x {patch.capitalize()}.k (Stereo::Effect), {SCRIPT_BLOCKS} blocks of {N} samples: noise burst 4800 samples then silence, io + {bank.state_bytes * K / 1e9:.1f} GB of delay lines resident in HBM",
+           "value": K * N * SCRIPT_BLOCKS / dt, "unit": "instance*samples/s", "ms_per_step": 1e3 * dt / SCRIPT_BLOCKS, "steps": SCRIPT_BLOCKS, "kernel_ms_mean": 1e3 * kern_s,
+           "finite": bool(torch.isfinite(io).all().item()),
+           "roofline": {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": KERNEL_OF[patch], "algorithmic_bytes_per_launch": ab, "bytes_per_instance_sample": FX_BYTES_PER_SAMPLE[patch]}}
+    bank.close()
+    return res
+
+
+def run_realtime(patch, voices, N, blocks=2000):
+    """max real-time voice count: block time <= N / 48000 s over >= 2000 consecutive blocks, p99, every block synchronised like a
+    real-time host would; sustain (2000 blocks) and the worst case (every voice in its release ramp) separately"""
+    import torch
+    import klang_amd
+    notes = NOTES.get(patch, 32)
+    base = 1 << 20
+    tmp = klang_amd.SynthBank(patch, synths=base // notes, notes=notes, max_block=N)
+    rng = np.random.default_rng(7)
+    pitches = rng.integers(36, 97, size=base).astype(np.int32)
+    rec = tmp.note_records((np.arange(base) // notes).astype(np.int32), pitches, np.full(base, 0.8, np.float32))
+    tmp.close()
+    bank = klang_amd.SynthBank(patch, synths=voices // notes, notes=notes, max_block=N)
+    V = bank.voices
+    script = klang_amd.EventScript(bank, 2)
+    first = script.add_records(rec)
+    v = np.arange(V, dtype=np.int64)
+    script.note_on(np.zeros(V, np.int64), v, first + (v % base))               # block 0: every voice starts
+    script.note_off(np.ones(V, np.int64), v)                                   # block 1 (played later): every voice is released
+    script.commit()
+    mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    mix.zero_(); script.play_device(0, mix.data_ptr(), N, st); torch.cuda.synchronize()
+    t = np.empty(blocks)
+    for b in range(blocks):
+        t0 = time.perf_counter()
+        mix.zero_(); bank.process_device(mix.data_ptr(), N, st); torch.cuda.synchronize()
+        t[b] = 1e3 * (time.perf_counter() - t0)
+    mix.zero_(); script.play_device(1, mix.data_ptr(), N, st); torch.cuda.synchronize()
+    r = np.empty(44)
+    for b in range(44):
+        t0 = time.perf_counter()
+        mix.zero_(); bank.process_device(mix.data_ptr(), N, st); torch.cuda.synchronize()
+        r[b] = 1e3 * (time.perf_counter() - t0)
+    deadline = 1e3 * N / 48000.0
+    res = {"name": "realtime_deadline", "workload": f"{patch}: {V} voices, {blocks} consecutive blocks of {N} samples, each block synchronised (host wall clock per block)",
+           "voices": V, "deadline_ms": deadline, "attack_decay_max_ms": float(t[:22].max()), "sustain_p50_ms": float(np.median(t[30:])), "p99_ms": float(np.percentile(t, 99)), "max_ms": float(t.max()),
+           "release_all_ramping_p99_ms": float(np.percentile(r, 99)), "release_max_ms": float(r.max()),
+           "realtime": bool(np.percentile(t, 99) <= deadline and np.percentile(r, 99) <= deadline), "unit": "ms per block", "value": float(np.percentile(t, 99))}
+    script.close(); bank.close()
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def respawn(args):
+    """`python bench.py --gpus N` invoked plainly: one process per GPU, launched here the way the driver would"""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("KLG_BENCH_ONE_GPU") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (KLG_BENCH_ONE_GPU=1 runs every rank on cuda:0 over gloo: a functional test, not a measurement)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=375)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--patch", default="sub2a")
-    ap.add_argument("--voices", type=int, default=1 << 22, help="voices per GPU (weak scaling); 4 Mi voices = 336 MB of lane records")
+    ap.add_argument("--voices", type=int, default=375 * 11264, help="voices per GPU (weak scaling), rounded to 375 groups of whole workgroups; 4,224,000 voices = 338 MB of lane records")
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="headline only (what ranks of an N > 1 run do anyway)")
+    ap.add_argument("--realtime-voices", type=int, default=1 << 24)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return respawn(args)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: klang_amd has no CPU path")
     # test hook: KLG_BENCH_ONE_GPU=1 runs every rank on cuda:0 with the gloo backend so the N > 1 code path (sharding,
@@ -148,19 +385,16 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import klang_amd
-    notes = 128 if args.patch in ("sub2a", "sine", "bsine") else 32
-    synths = max(1, args.voices // notes)
-    # weak scaling: every rank owns `synths` instances of the global bank (klang_amd/shard.py: contiguous ranges)
-    bank = klang_amd.ShardedSynthBank(args.patch, synths * world, notes, fs=48000.0, max_block=args.block, rank=rank, world=world, device=local_rank)
-    V, N = bank.voices, args.block
-
-    # synthetic MIDI / random-parameter workload: every voice sounding, uniform pitches 36..96
-    rng = np.random.default_rng(20250314 + rank)
-    pitches = rng.integers(36, 97, size=V)
-    vels = rng.uniform(0.25, 1.0, size=V)
+    patch, N = args.patch, args.block
+    notes = NOTES.get(patch, 32)
+    V = groups_voices(args.voices)
+    # weak scaling: every rank owns `V` voices of the global bank (klang_amd/shard.py: contiguous ranges of synth instances)
+    sharded = klang_amd.ShardedSynthBank(patch, (V // notes) * world, notes, fs=48000.0, max_block=N, rank=rank, world=world, device=local_rank)
+    bank = sharded.bank
+    assert bank.voices == V
     bank.random(rank + 1)
-    owner = bank.lo + np.arange(V) // notes
-    bank.note_on_many(owner, pitches, vels)
+    script, sounding = build_script(bank, SCRIPT_BLOCKS, np.random.default_rng(20250314 + rank), cyclic=True)
+
     # Throughput mode: blocks are pipelined through a small ring of output buffers, so the (2 KiB, latency-bound) all-reduce
     # of block i overlaps the render of block i+1; a buffer is reused only after its own all-reduce has completed.
     RING = 4
@@ -170,13 +404,16 @@ def main():
     state = {"i": 0}
 
     def step():
-        k = state["i"] % RING
+        i = state["i"]
+        k = i % RING
         state["i"] += 1
         if pending[k] is not None:
             pending[k].wait()                        # the current stream waits for that buffer's collective (issued RING steps ago)
             pending[k] = None
         mixes[k].zero_()
-        pending[k] = bank.process_device(mixes[k], N, stream, async_reduce=True)   # render + (world > 1) one RCCL all-reduce of the [2][N] block
+        script.play_device(i % SCRIPT_BLOCKS, mixes[k].data_ptr(), N, stream)      # this block's note events (from HBM), render, reduce
+        if world > 1:
+            pending[k] = dist.all_reduce(mixes[k], async_op=True)                 # ONE RCCL all-reduce of the [2][N] block
 
     def drain():
         for k in range(RING):
@@ -184,9 +421,8 @@ def main():
                 pending[k].wait()
                 pending[k] = None
 
-    # settle: run the attack + decay segments (0.01 s + 0.105 s = 22 blocks) untimed so the timed region measures
-    # the steady state of a sounding voice (sustain); the all-voices-ramping worst case is measured separately below
-    for _ in range(24):
+    # settle (untimed set-up, like loading the voices): one full cycle of the script brings every group to its place in the steady state
+    for _ in range(SCRIPT_BLOCKS):
         step()
     for _ in range(args.warmup):
         step()
@@ -195,7 +431,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    bank.bank.timing_begin()
+    first_timed = state["i"]
+    bank.timing_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -205,69 +442,80 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    launches, kernel_ms = bank.bank.timing_end()
+    launches, kernel_ms = bank.timing_end()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     checksum = float(mixes[(state["i"] - 1) % RING].abs().sum().item())
-
-    # worst case for the envelope code: every voice in its release ramp (not part of `value`)
-    bank.note_off_many(owner, pitches, np.zeros(V, np.float32))
-    step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    for _ in range(20):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt_release = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([dt_release], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_release = float(t.item())
+    alive_now = int((bank.stages() != 3).sum())
+    expect_alive = int(sounding[(state["i"] - 1) % SCRIPT_BLOCKS])
+    sounding_timed = float(sum(int(sounding[(first_timed + j) % SCRIPT_BLOCKS]) for j in range(args.steps)))
 
     if rank == 0:
-        total_voices = V * world
-        value = total_voices * N * args.steps / dt
+        value = world * sounding_timed * N / dt
         ms_per_step = 1e3 * dt / args.steps
         kern_s = 1e-3 * kernel_ms / max(1, launches)
-        rec_bytes = bank.bank.state_bytes
-        alg_bytes = V * (rec_bytes + 4 * STORE_WORDS.get(args.patch, rec_bytes // 4)) + 2 * N * 4
-        achieved = alg_bytes / kern_s / 1e9
-        flops = FLOPS_PER_VOICE_SAMPLE.get(args.patch, 0) * V * N / kern_s / 1e12
+        live_mean = sounding_timed / args.steps
+        ab = alg_bytes(patch, bank, live_mean, N)
+        achieved = ab / kern_s / 1e9
+        flops = FLOPS_PER_VOICE_SAMPLE.get(patch, 0) * live_mean * N / kern_s / 1e12
+        kernel_name = KERNEL_OF.get(patch, patch) if os.environ.get("KLG_RENDER_X1") != "1" else "klg_render<klg::PatchSub2a"
+        traffic, traffic_how = (None, "N > 1: not collected") if world > 1 else pmc_traffic_live(args, kernel_name)
         out = {
             "metric": "voice*samples/s @48kHz Subtractive",
             "value": value, "unit": "voice*samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.patch}: {V} voices/GPU (Saw>>Biquad LPF>>ADSR), {N}-sample blocks @48kHz, all voices sounding, stereo mix resident in HBM",
-                       "voices_per_gpu": V, "block": N, "parallelism": f"voice-shard x{world}" + (" + RCCL all-reduce of [2][%d] per block" % N if world > 1 else ""),
-                       "phase": "sustain (all voices held)", "value_all_voices_in_release_ramp": total_voices * N * 20 / dt_release,
-                       "realtime_voices_equiv": int(value / 48000.0), "realtime_voices_equiv_worst_case": int(total_voices * N * 20 / dt_release / 48000.0),
+            "config": {"workload": f"{patch}: {V} voices/GPU (Saw>>Biquad LPF>>ADSR) playing SURVEY 8(d)'s cfg-2 note script (375 blocks: on at 0, off at 150 + (v mod 64), 0.255 s release) as a steady state of 375 phase-shifted groups; {N}-sample blocks @48kHz; note events applied from an HBM-resident script; stereo mix resident in HBM",
+                       "voices_per_gpu": V, "voices_sounding_per_gpu_mean": live_mean, "block": N, "parallelism": f"voice-shard x{world}" + (" + RCCL all-reduce of [2][%d] per block" % N if world > 1 else ""),
+                       "value_counts": "sounding voices x samples / s (SURVEY 8d: active voices); resident voices x samples / s = %.6g" % (world * V * N * args.steps / dt),
+                       "voices_alive_after_last_block": alive_now, "voices_alive_expected": expect_alive,
                        "block_deadline_ms": 1e3 * N / 48000.0, "mix_checksum": checksum},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.patch, V),
-                         "kernel": ("klg_render_sub2a_x2<false>" if args.patch == "sub2a" and os.environ.get("KLG_RENDER_X1") != "1" else "klg_render<%s>" % args.patch), "kernel_ms": 1e3 * kern_s, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "synth patches keep voice state in registers: the binding unit is fp32 VALU issue, see `valu`",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_how,
+                         "kernel": kernel_name, "kernel_ms": 1e3 * kern_s, "algorithmic_bytes_per_launch": ab,
+                         "algorithmic_bytes": "sounding voices x (80 B record read + 32 B written back) + the [2][256] block; a silent voice costs its 4-byte flag word (not counted)",
+                         "note": "synth patches keep voice state in registers (north_star): the binding unit is fp32 VALU issue, see `valu`",
                          "valu": {"achieved_tflops_est": flops, "peak_tflops": FP32_PEAK_TFLOPS, "frac": flops / FP32_PEAK_TFLOPS,
-                                  "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(args.patch, 0), **valu_issue(args.patch, V, N, kern_s)}},
+                                  "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(patch, 0)}},
         }
+        if world == 1 and not args.no_configs:
+            script.close(); sharded.close(); bank = None
+            torch.cuda.empty_cache()
+            configs = []
+
+            def leg(fn, *a, **kw):
+                try:
+                    configs.append(fn(*a, **kw))
+                except Exception as e:                                       # noqa: BLE001  a side leg must never cost the bench line
+                    configs.append({"name": getattr(fn, "__name__", "leg") + str(a[:2]), "error": f"{type(e).__name__}: {e}"})
+                    print(f"bench.py: {fn.__name__}{a[:2]} failed: {e}", file=sys.stderr)
+            leg(run_literal_script, "sub2a", V, N, "cfg2_script_as_written_at_headline_size", phases=True)
+            leg(run_literal_script, "sub2a", 1024, N, "cfg2_1024_voices")
+            leg(run_literal_script, "supersaw", 16384, N, "cfg3_16384_supersaw_voices")
+            leg(run_fx, "pingpong", 4096, N)
+            leg(run_fx, "reverb", 4096, N)
+            leg(run_literal_script, "fm4", 131072, N, "cfg5_share_131072_fm4_voices")
+            leg(run_realtime, "sub2a", args.realtime_voices, N)
+            out["configs"] = configs
+            lit = configs[0]
+            if "phases_ms_per_block" in lit:
+                out["config"]["value_sustain_only"] = lit["value_sustain_phase"]
+                out["config"]["value_all_voices_ramping"] = lit["value_all_ramping_phase"]
+                out["config"]["value_script_as_written"] = lit["value"]
+                ws = V / 128.0 * N
+                out["roofline"]["valu"].update({"sustain_loop": valu_issue(ws, 1e-3 * lit["phases_ms_per_block"]["sustain_only(40..149)"], 31.8)})
         if world == 1 and not args.no_cpu_baseline:
-            port = cpu_baseline(args.patch, N, budget_s=8.0)                 # the C restatement (oracle/klang_oracle.c)
+            port = cpu_baseline(patch, N, budget_s=8.0)                      # the C restatement (oracle/klang_oracle.c)
             try:
-                ref = cpu_reference(args.patch, N, budget_s=8.0)             # the genuine header, where its binary travelled
-            except Exception as e:                                          # a baseline must never cost the bench line
+                ref = cpu_reference(patch, N, budget_s=8.0)                  # the genuine header, where its binary travelled
+            except Exception as e:                                          # noqa: BLE001  a baseline must never cost the bench line
                 print(f"bench.py: reference baseline unavailable ({e}); reporting the port", file=sys.stderr)
                 ref = None
             out["cpu_baseline"] = dict(ref, port_value=port["value"], port_sample=port["sample"]) if ref else port
         print(json.dumps(out))
-    bank.close()
     if world > 1:
+        script.close(); sharded.close()
         dist.destroy_process_group()
 
 

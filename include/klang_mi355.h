@@ -118,6 +118,34 @@ int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices);
 int klg_process_device(klg_synth* s, float* d_mix, int n, void* hip_stream);
 int klg_sync(klg_synth* s);
 
+/* ------------------------------------------------------------------------------------------------
+ * Event scripts resident in HBM — offline / throughput rendering of an event stream that is known in advance (a MIDI file, a benchmark
+ * script).  replaces: the host's per-block loop of noteOn / noteOff calls followed by process() (templates/juce/synth/Source/
+ * PluginProcessor.cpp:170-177; klang.h:4423-4434) — here every on() runs on the host ONCE, up front, and the blocks then play with no host
+ * work and no transfer between them.  Voices are addressed explicitly (the caller does the voice allocation a script implies).
+ *   klg_note_record      the patch's on() for (pitch, velocity) on instance `synth` -> the lane record it would upload; nothing is queued
+ *   klg_script_add_record / klg_script_note_on / klg_script_note_off   build the script: block b starts `voice` from pool record r /
+ *                        releases `voice` (the patch's off(), applied to the voice's state at that block, only if it is at Sustain)
+ *   klg_script_commit    sorts each block's events per voice (call order kept) and uploads records + index arrays to HBM
+ *   klg_script_play_device  block `block` of the script: its events are applied by the event kernel from HBM, then the bank renders n
+ *                        samples into d_mix ([2][n], accumulated) on hip_stream; asynchronous like klg_process_device
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct klg_script klg_script;
+int klg_note_record(klg_synth* s, int synth, int pitch, float velocity, void* record, size_t bytes);
+klg_script* klg_script_create(klg_synth* s, int blocks);
+void klg_script_destroy(klg_script* k);
+int klg_script_add_record(klg_script* k, const void* record, size_t bytes);
+int klg_script_note_on(klg_script* k, int block, int voice, int record_index);
+int klg_script_note_off(klg_script* k, int block, int voice);
+/* bulk forms: event i is (block[i], voice[i], record_index[i]); records are AoS, klg_synth_state_bytes() bytes each; klg_script_add_records
+ * returns the pool index of the first record */
+int klg_note_records(klg_synth* s, int n, const int* synth, const int* pitch, const float* velocity, void* records);
+int klg_script_add_records(klg_script* k, int n, const void* records);
+int klg_script_note_on_many(klg_script* k, int n, const int* block, const int* voice, const int* record_index);
+int klg_script_note_off_many(klg_script* k, int n, const int* block, const int* voice);
+int klg_script_commit(klg_script* k);
+int klg_script_play_device(klg_script* k, int block, float* d_mix, int n, void* hip_stream);
+
 /* Voice state transfer (checkpoint / debugging).  `state` is the patch's packed per-voice record of
  * klg_synth_state_bytes() bytes.  Replaces nothing in the reference (it has no checkpointing). */
 int klg_voice_download(klg_synth* s, int voice, void* state, size_t bytes);

@@ -59,6 +59,18 @@ def load():
         "klg_voice_stages": (C.c_int, [vp, u8p, C.c_int]),
         "klg_process_device": (C.c_int, [vp, vp, C.c_int, vp]),
         "klg_sync": (C.c_int, [vp]),
+        "klg_note_record": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, vp, C.c_size_t]),
+        "klg_script_create": (vp, [vp, C.c_int]),
+        "klg_script_destroy": (None, [vp]),
+        "klg_script_add_record": (C.c_int, [vp, vp, C.c_size_t]),
+        "klg_script_note_on": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "klg_script_note_off": (C.c_int, [vp, C.c_int, C.c_int]),
+        "klg_note_records": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), f32p, vp]),
+        "klg_script_add_records": (C.c_int, [vp, C.c_int, vp]),
+        "klg_script_note_on_many": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "klg_script_note_off_many": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "klg_script_commit": (C.c_int, [vp]),
+        "klg_script_play_device": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
         "klg_voice_download": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "klg_voice_upload": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "klg_voices_upload": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), vp]),

@@ -99,6 +99,18 @@ class SynthBank:
         check(self._L.klg_process_voices(self._h, _fp(pv), ptrs, ch, n), "klg_process_voices")
         return pv, out
 
+    def note_records(self, synths, pitches, velocities):
+        """the patch's on() for each (synth, pitch, velocity): uint32 [n][words], nothing queued (klg_note_records)"""
+        sy = np.ascontiguousarray(synths, dtype=np.int32); pi = np.ascontiguousarray(pitches, dtype=np.int32); ve = np.ascontiguousarray(velocities, dtype=np.float32)
+        assert sy.shape == pi.shape == ve.shape
+        out = np.empty((len(sy), self.state_bytes // 4), dtype=np.uint32)
+        ip = C.POINTER(C.c_int)
+        check(self._L.klg_note_records(self._h, len(sy), sy.ctypes.data_as(ip), pi.ctypes.data_as(ip), _fp(ve), out.ctypes.data_as(C.c_void_p)), "klg_note_records")
+        return out
+
+    def set_mix_mode(self, mode):
+        check(self._L.klg_synth_set_mix_mode(self._h, int(mode)), "klg_synth_set_mix_mode")
+
     def stages(self):
         st = np.empty(self.voices, dtype=np.uint8)
         check(self._L.klg_voice_stages(self._h, st.ctypes.data_as(C.POINTER(C.c_uint8)), self.voices), "klg_voice_stages")
@@ -144,6 +156,52 @@ class SynthBank:
         n, ms = C.c_int(), C.c_float()
         check(self._L.klg_timing_end(self._h, C.byref(n), C.byref(ms)), "klg_timing_end")
         return n.value, ms.value
+
+
+class EventScript:
+    """An event stream known in advance, resident in HBM (klg_script_*): every on() runs on the host once, up front; the blocks then
+    play with no host work between them.  Voices are addressed explicitly."""
+
+    def __init__(self, bank, blocks):
+        self._L = lib()
+        self.bank, self.blocks = bank, int(blocks)
+        self._k = self._L.klg_script_create(bank._h, self.blocks)
+        if not self._k:
+            raise KlangError("klg_script_create failed: " + self._L.klg_last_error().decode())
+
+    def close(self):
+        if self._k:
+            self._L.klg_script_destroy(self._k)
+            self._k = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_records(self, records):
+        """records: uint32 [n][words]; returns the pool index of the first"""
+        r = np.ascontiguousarray(records, dtype=np.uint32).reshape(-1, self.bank.state_bytes // 4)
+        return check(self._L.klg_script_add_records(self._k, len(r), r.ctypes.data_as(C.c_void_p)), "klg_script_add_records")
+
+    def note_on(self, blocks, voices, record_indices):
+        ip = C.POINTER(C.c_int)
+        b = np.ascontiguousarray(blocks, dtype=np.int32); v = np.ascontiguousarray(voices, dtype=np.int32); r = np.ascontiguousarray(record_indices, dtype=np.int32)
+        assert b.shape == v.shape == r.shape
+        check(self._L.klg_script_note_on_many(self._k, len(b), b.ctypes.data_as(ip), v.ctypes.data_as(ip), r.ctypes.data_as(ip)), "klg_script_note_on_many")
+
+    def note_off(self, blocks, voices):
+        ip = C.POINTER(C.c_int)
+        b = np.ascontiguousarray(blocks, dtype=np.int32); v = np.ascontiguousarray(voices, dtype=np.int32)
+        assert b.shape == v.shape
+        check(self._L.klg_script_note_off_many(self._k, len(b), b.ctypes.data_as(ip), v.ctypes.data_as(ip)), "klg_script_note_off_many")
+
+    def commit(self):
+        check(self._L.klg_script_commit(self._k), "klg_script_commit")
+
+    def play_device(self, block, d_mix_ptr, n, stream=None):
+        check(self._L.klg_script_play_device(self._k, int(block), C.c_void_p(int(d_mix_ptr)), int(n), C.c_void_p(int(stream)) if stream else None), "klg_script_play_device")
 
 
 class FxBank:

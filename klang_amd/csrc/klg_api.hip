@@ -129,6 +129,7 @@ struct klg_synth {
 	std::vector<Event> events;
 	std::vector<uint32_t> payload;
 	unsigned seq = 0;
+	uint32_t* record_sink = nullptr;             // klg_note_record
 	void* h_stage = nullptr; size_t h_stage_cap = 0;      // pinned
 	void* d_stage = nullptr; size_t d_stage_cap = 0;
 	hipEvent_t stage_done = nullptr;
@@ -403,14 +404,15 @@ static int refresh_stages(klg_synth* s) {
 // the patches' on() code (host) -> lane record
 // ------------------------------------------------------------------------------------------------
 static void push_note_on(klg_synth* s, int voice, const void* rec) {
-	const int idx = (int)(s->payload.size() / s->W);
 	const uint32_t* w = (const uint32_t*)rec;
+	if (s->record_sink) { std::memcpy(s->record_sink, w, (size_t)s->W * 4); return; }      // klg_note_record: the record goes to the caller, nothing is queued
+	const int idx = (int)(s->payload.size() / s->W);
 	s->payload.insert(s->payload.end(), w, w + s->W);
 	s->events.push_back({ voice, 0, idx, s->seq++ });
 }
 
-static void patch_on(klg_synth* s, int synth, int voice) {
-	HostVoice& hv = s->voices[voice];
+static void patch_on(klg_synth* s, int synth, int voice, HostVoice* scratch = nullptr) {
+	HostVoice& hv = scratch ? *scratch : s->voices[voice];
 	const host::Fs& fs = s->fs;
 	const host::ControlH* ctl = s->nctl ? &s->controls[(size_t)synth * s->nctl] : nullptr;
 	const float f = host::pitch_to_frequency(hv.pitch);          // const param f = pitch -> Frequency;
@@ -738,6 +740,132 @@ static int tables_sync(klg_synth* s) {
 	HIP_TRY(hipMemcpy(s->d_tables, h.data(), h.size() * sizeof(TableDesc), hipMemcpyHostToDevice));
 	s->tables_dirty = false;
 	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Event scripts resident in HBM (include/klang_mi355.h: klg_script_*): offline / throughput rendering of a known event stream
+// ------------------------------------------------------------------------------------------------
+extern "C" int klg_note_record(klg_synth* s, int synth, int pitch, float velocity, void* record, size_t bytes) {
+	if (!s || !record || synth < 0 || synth >= s->S || bytes != (size_t)s->W * 4) return fail(KLG_ERR_INVALID, "klg_note_record: bad arguments (record is %d bytes)", s ? s->W * 4 : 0);
+	if (s->graph) return fail(KLG_ERR_INVALID, "klg_note_record: %s", kGraphEvents);
+	HostVoice hv = s->voices[(size_t)synth * s->P];                // a scratch note of this instance (the oscillators' cached frequencies start as a fresh note's)
+	hv = HostVoice();
+	if (s->patch == KLG_PATCH_SUPERSAW) for (auto& o : hv.osm) o = host::OsmH(0.f);
+	hv.stage = ST_ONSET; hv.pitch = (float)pitch; hv.velocity = velocity;
+	s->record_sink = (uint32_t*)record;
+	patch_on(s, synth, synth * s->P, &hv);
+	s->record_sink = nullptr;
+	return 0;
+}
+
+struct klg_script {
+	klg_synth* s = nullptr; int blocks = 0; bool committed = false;
+	std::vector<std::vector<Event>> ev;                            // per block, in call order
+	std::vector<uint32_t> pool;                                    // note-on records, W words each (shared by every block that starts that note)
+	struct Slice { size_t first; int R, E; };                      // where block b's run / event arrays sit in d_index
+	std::vector<Slice> slices;
+	int* d_index = nullptr; uint32_t* d_pool = nullptr;
+};
+extern "C" klg_script* klg_script_create(klg_synth* s, int blocks) {
+	if (!s || blocks <= 0) { fail(KLG_ERR_INVALID, "klg_script_create: bad arguments"); return nullptr; }
+	klg_script* k = new klg_script(); k->s = s; k->blocks = blocks; k->ev.resize((size_t)blocks);
+	return k;
+}
+extern "C" void klg_script_destroy(klg_script* k) {
+	if (!k) return;
+	if (k->d_index) (void)hipFree(k->d_index);
+	if (k->d_pool) (void)hipFree(k->d_pool);
+	delete k;
+}
+extern "C" int klg_script_add_record(klg_script* k, const void* record, size_t bytes) {
+	if (!k || !record || k->committed || bytes != (size_t)k->s->W * 4) return fail(KLG_ERR_INVALID, "klg_script_add_record: bad arguments (record is %d bytes) or script already committed", k ? k->s->W * 4 : 0);
+	const uint32_t* w = (const uint32_t*)record;
+	k->pool.insert(k->pool.end(), w, w + k->s->W);
+	return (int)(k->pool.size() / (size_t)k->s->W) - 1;
+}
+extern "C" int klg_script_note_on(klg_script* k, int block, int voice, int record_index) {
+	if (!k || k->committed || block < 0 || block >= k->blocks || voice < 0 || voice >= k->s->V || record_index < 0 || (size_t)record_index >= k->pool.size() / (size_t)k->s->W)
+		return fail(KLG_ERR_INVALID, "klg_script_note_on: bad arguments or script already committed");
+	k->ev[(size_t)block].push_back({ voice, 0, record_index, (unsigned)k->ev[(size_t)block].size() });
+	return 0;
+}
+extern "C" int klg_script_note_off(klg_script* k, int block, int voice) {
+	if (!k || k->committed || block < 0 || block >= k->blocks || voice < 0 || voice >= k->s->V) return fail(KLG_ERR_INVALID, "klg_script_note_off: bad arguments or script already committed");
+	if (k->s->graph) return fail(KLG_ERR_INVALID, "klg_script_note_off: %s", kGraphEvents);
+	k->ev[(size_t)block].push_back({ voice, 1, -1, (unsigned)k->ev[(size_t)block].size() });
+	return 0;
+}
+// bulk forms (one call per array instead of one per event)
+extern "C" int klg_note_records(klg_synth* s, int n, const int* synth, const int* pitch, const float* velocity, void* records) {
+	if (!s || n < 0 || !synth || !pitch || !velocity || !records) return fail(KLG_ERR_INVALID, "klg_note_records: bad arguments");
+	for (int i = 0; i < n; i++) if (int rc = klg_note_record(s, synth[i], pitch[i], velocity[i], (uint32_t*)records + (size_t)i * s->W, (size_t)s->W * 4)) return rc;
+	return 0;
+}
+extern "C" int klg_script_add_records(klg_script* k, int n, const void* records) {
+	if (!k || n < 0 || !records || k->committed) return fail(KLG_ERR_INVALID, "klg_script_add_records: bad arguments or script already committed");
+	const int first = (int)(k->pool.size() / (size_t)k->s->W);
+	const uint32_t* w = (const uint32_t*)records;
+	k->pool.insert(k->pool.end(), w, w + (size_t)n * k->s->W);
+	return first;
+}
+extern "C" int klg_script_note_on_many(klg_script* k, int n, const int* block, const int* voice, const int* record_index) {
+	if (!k || n < 0 || !block || !voice || !record_index) return fail(KLG_ERR_INVALID, "klg_script_note_on_many: bad arguments");
+	for (int i = 0; i < n; i++) if (int rc = klg_script_note_on(k, block[i], voice[i], record_index[i])) return rc;
+	return 0;
+}
+extern "C" int klg_script_note_off_many(klg_script* k, int n, const int* block, const int* voice) {
+	if (!k || n < 0 || !block || !voice) return fail(KLG_ERR_INVALID, "klg_script_note_off_many: bad arguments");
+	for (int i = 0; i < n; i++) if (int rc = klg_script_note_off(k, block[i], voice[i])) return rc;
+	return 0;
+}
+// sort every block's events into per-voice runs (what flush_events does per block) and move everything to HBM, once
+extern "C" int klg_script_commit(klg_script* k) {
+	if (!k || k->committed) return fail(KLG_ERR_INVALID, "klg_script_commit: bad handle or already committed");
+	RandGuard rg;
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	std::vector<int> index;
+	k->slices.resize((size_t)k->blocks);
+	for (int b = 0; b < k->blocks; b++) {
+		std::vector<Event>& ev = k->ev[(size_t)b];
+		std::stable_sort(ev.begin(), ev.end(), [](const Event& a, const Event& c) { return a.voice != c.voice ? a.voice < c.voice : a.seq < c.seq; });
+		std::vector<int> rv, rf, rc;
+		for (size_t e = 0; e < ev.size(); e++) {
+			if (e == 0 || ev[e].voice != ev[e - 1].voice) { rv.push_back(ev[e].voice); rf.push_back((int)e); rc.push_back(0); }
+			rc.back()++;
+		}
+		k->slices[(size_t)b] = { index.size(), (int)rv.size(), (int)ev.size() };
+		index.insert(index.end(), rv.begin(), rv.end()); index.insert(index.end(), rf.begin(), rf.end()); index.insert(index.end(), rc.begin(), rc.end());
+		for (const Event& e : ev) index.push_back(e.type);
+		for (const Event& e : ev) index.push_back(e.payload);
+		std::vector<Event>().swap(ev);
+	}
+	if (!index.empty()) { HIP_TRY(hipMalloc((void**)&k->d_index, index.size() * 4)); HIP_TRY(hipMemcpy(k->d_index, index.data(), index.size() * 4, hipMemcpyHostToDevice)); }
+	if (!k->pool.empty()) { HIP_TRY(hipMalloc((void**)&k->d_pool, k->pool.size() * 4)); HIP_TRY(hipMemcpy(k->d_pool, k->pool.data(), k->pool.size() * 4, hipMemcpyHostToDevice)); }
+	std::vector<uint32_t>().swap(k->pool);
+	k->committed = true;
+	return 0;
+}
+// replaces: the host's per-block loop "pass this block's MIDI to the synth, then render" (templates/juce/synth/Source/PluginProcessor.cpp:170-177)
+// for a stream known in advance: block `block`'s events are applied from HBM (no host work, no transfer), then the block is rendered
+extern "C" int klg_script_play_device(klg_script* k, int block, float* d_mix, int n, void* hip_stream) {
+	if (!k || !k->committed || block < 0 || block >= k->blocks || !d_mix || n <= 0 || n > k->s->max_block) return fail(KLG_ERR_INVALID, "klg_script_play_device: bad arguments or script not committed");
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	klg_synth* s = k->s;
+	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
+	if (int rc = flush_events(s, st)) return rc;                    // anything queued interactively comes first
+	const klg_script::Slice& sl = k->slices[(size_t)block];
+	if (sl.E > 0) {
+		int* d = k->d_index + sl.first;
+		EventArgs a;
+		a.state = s->d_state; a.stride = s->stride;
+		a.run_voice = d; a.run_first = d + sl.R; a.run_count = d + 2 * sl.R; a.runs = sl.R;
+		a.ev_type = d + 3 * sl.R; a.ev_payload = d + 3 * sl.R + sl.E; a.payload = k->d_pool;
+		a.fs = s->fs.f;
+		launch_events(s, a, st);
+		HIP_TRY(hipGetLastError());
+		s->stages_dirty = true;
+	}
+	return enqueue_block(s, d_mix, n, false, st);
 }
 
 extern "C" int klg_timing_begin(klg_synth* s) { if (!s) return fail(KLG_ERR_INVALID, "NULL handle"); s->timing = true; s->launches = 0; return 0; }

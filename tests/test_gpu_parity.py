@@ -15,7 +15,7 @@ from scenario_io import Scenario
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SYNTH_SCENARIOS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.scn"))
-                         if Scenario.load(p).instances == 0 and not os.path.basename(p).startswith(("ex_", "own_", "fx_")))   # ex_*: facade-only (test_gpu_facade.py)
+                         if Scenario.load(p).instances == 0 and not os.path.basename(p).startswith(("ex_", "own_", "fx_", "host_")))   # ex_*: facade-only (test_gpu_facade.py)
 TOL = 1e-5
 
 
