@@ -194,7 +194,9 @@ def pmc_child(args):
     bank = klang_amd.SynthBank(args.patch, synths=V // notes, notes=notes, max_block=args.block)
     script, _ = build_script(bank, SCRIPT_BLOCKS, np.random.default_rng(20250314), cyclic=True)
     mix = torch.zeros((2, args.block), dtype=torch.float32, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
+    st = ts.cuda_stream
     for b in range(SCRIPT_BLOCKS + 24):
         mix.zero_(); script.play_device(b % SCRIPT_BLOCKS, mix.data_ptr(), args.block, st)
     torch.cuda.synchronize()
@@ -219,17 +221,20 @@ def run_literal_script(patch, voices, N, label, phases=False):
     bank.random(12345)
     script, sounding = build_script(bank, 1, np.random.default_rng(20250314), cyclic=False)
     mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(SCRIPT_BLOCKS)]
-    mix.zero_(); torch.cuda.synchronize()
-    bank.timing_begin()
-    t0 = time.perf_counter()
-    for b in range(SCRIPT_BLOCKS):
-        ev[b][0].record()
-        mix.zero_(); script.play_device(b, mix.data_ptr(), N, st)
-        ev[b][1].record()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    ts = torch.cuda.Stream()                                               # the library launches on THIS stream (a non-default handle), and so do the events
+    with torch.cuda.stream(ts):
+        st = ts.cuda_stream
+        mix.zero_(); torch.cuda.synchronize()
+        bank.timing_begin()
+        t0 = time.perf_counter()
+        for b in range(SCRIPT_BLOCKS):
+            ev[b][0].record()
+            mix.zero_(); script.play_device(b, mix.data_ptr(), N, st)
+            ev[b][1].record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     launches, kms = bank.timing_end()
     ms = np.array([a.elapsed_time(b) for a, b in ev])
     alive = int((bank.stages() != 3).sum())
@@ -262,18 +267,20 @@ def run_fx(patch, K, N):
     inputs = torch.rand((burst_blocks, K, 2, N), device="cuda", generator=g) - 0.5
     inputs[-1, :, :, 4800 - (burst_blocks - 1) * N:] = 0
     io = torch.zeros((K, 2, N), device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize()
-    bank.timing_begin()
-    t0 = time.perf_counter()
-    for b in range(SCRIPT_BLOCKS):
-        if b < burst_blocks:
-            io.copy_(inputs[b])
-        else:
-            io.zero_()
-        bank.process_device(io.data_ptr(), N, st)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        st = ts.cuda_stream
+        bank.timing_begin()
+        t0 = time.perf_counter()
+        for b in range(SCRIPT_BLOCKS):
+            if b < burst_blocks:
+                io.copy_(inputs[b])
+            else:
+                io.zero_()
+            bank.process_device(io.data_ptr(), N, st)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     launches, kms = bank.timing_end()
     kern_s = 1e-3 * kms / launches
     ab = K * N * FX_BYTES_PER_SAMPLE[patch]
@@ -307,7 +314,10 @@ def run_realtime(patch, voices, N, blocks=2000):
     script.note_off(np.ones(V, np.int64), v)                                   # block 1 (played later): every voice is released
     script.commit()
     mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    ts = torch.cuda.Stream()
+    torch.cuda.set_stream(ts)
+    st = ts.cuda_stream
     mix.zero_(); script.play_device(0, mix.data_ptr(), N, st); torch.cuda.synchronize()
     t = np.empty(blocks)
     for b in range(blocks):
@@ -354,7 +364,7 @@ def main():
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only (what ranks of an N > 1 run do anyway)")
-    ap.add_argument("--realtime-voices", type=int, default=1 << 24)
+    ap.add_argument("--realtime-voices", type=int, default=24 << 20)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -400,7 +410,10 @@ def main():
     RING = 4
     mixes = [torch.zeros((2, N), dtype=torch.float32, device="cuda") for _ in range(RING)]
     pending = [None] * RING
-    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    work_stream = torch.cuda.Stream()            # ONE stream for the clear, the library's launches and the collective (a non-default handle:
+    torch.cuda.set_stream(work_stream)           # the library takes it as is; the default stream's handle 0 would mean "the bank's own stream")
+    stream = work_stream.cuda_stream
     state = {"i": 0}
 
     def step():

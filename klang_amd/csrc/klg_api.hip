@@ -130,6 +130,7 @@ struct klg_synth {
 	std::vector<uint32_t> payload;
 	unsigned seq = 0;
 	uint32_t* record_sink = nullptr;             // klg_note_record
+	bool scripted = false;                       // a klg_script has played on this bank: note stages live on the device only
 	void* h_stage = nullptr; size_t h_stage_cap = 0;      // pinned
 	void* d_stage = nullptr; size_t d_stage_cap = 0;
 	hipEvent_t stage_done = nullptr;
@@ -395,7 +396,9 @@ static int refresh_stages(klg_synth* s) {
 	if (int rc = flush_events(s, s->stream)) return rc;
 	HIP_TRY(hipMemcpyAsync(s->h_flags, s->d_state, (size_t)s->V * 4, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
-	for (int v = 0; v < s->V; v++) if ((s->h_flags[v] & 3u) == (uint32_t)ST_OFF) s->voices[v].stage = ST_OFF;
+	// events of a klg_script are applied on the device only: for such a bank the lane's stage bits ARE the note's stage
+	if (s->scripted) for (int v = 0; v < s->V; v++) s->voices[v].stage = (uint8_t)(s->h_flags[v] & 3u);
+	else for (int v = 0; v < s->V; v++) if ((s->h_flags[v] & 3u) == (uint32_t)ST_OFF) s->voices[v].stage = ST_OFF;
 	s->stages_dirty = false;
 	return 0;
 }
@@ -623,7 +626,8 @@ static int process_host(klg_synth* s, float* per_voice, float* const* out, int c
 		else if (s->mix_mode != KLG_MIX_LAST_ACTIVE) for (int i = 0; i < n; i++) dst[i] += src[i];
 	}
 	if (per_voice) std::memcpy(per_voice, s->h_per_voice, (size_t)s->V * n * 4);
-	for (int v = 0; v < s->V; v++) if ((s->h_flags[v] & 3u) == (uint32_t)ST_OFF) s->voices[v].stage = ST_OFF;
+	if (s->scripted) for (int v = 0; v < s->V; v++) s->voices[v].stage = (uint8_t)(s->h_flags[v] & 3u);
+	else for (int v = 0; v < s->V; v++) if ((s->h_flags[v] & 3u) == (uint32_t)ST_OFF) s->voices[v].stage = ST_OFF;
 	s->stages_dirty = false;
 	if (parameters && s->nctl)                                   // sync update out (klang.h:4854-4857)
 		for (int i = 0; i < s->S; i++) for (int c = 0; c < s->nctl; c++) parameters[(size_t)i * s->nctl + c] = s->controls[(size_t)i * s->nctl + c].value;
@@ -863,7 +867,7 @@ extern "C" int klg_script_play_device(klg_script* k, int block, float* d_mix, in
 		a.fs = s->fs.f;
 		launch_events(s, a, st);
 		HIP_TRY(hipGetLastError());
-		s->stages_dirty = true;
+		s->stages_dirty = true; s->scripted = true;
 	}
 	return enqueue_block(s, d_mix, n, false, st);
 }

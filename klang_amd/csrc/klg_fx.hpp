@@ -83,7 +83,7 @@ struct PingPongArgs {
 	SampleRate fs;
 	BiquadCoef dc;              // dcfilter[k].set(50, 1) — PingPong.k:39-40, computed on the host
 	float c1_min, c1_max;
-	int ablate;                 // measurement only (KLG_FX_ABLATE): 1 = no ring reads, 2 = no ring writes, 4 = no io staging
+	int ablate;                 // measurement only (KLG_FX_ABLATE): 1 = no ring reads, 2 = no ring writes, 4 = no io staging, 8 = no control recurrences, 16 = no DC filters, 32 = full barriers
 };
 
 // The kernel works in sub-chunks of PP_SUB samples:
@@ -222,23 +222,29 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 // -------------------------------------------------------------------------------------------------
 // PingPong.k, eleven waves per 64 instances (the production kernel).
 //
-// Once every tap of a chunk lies further behind the write cursor than the chunk is long, the samples of the chunk no
-// longer depend on each other through the delay lines: only three short recurrences are sequential in time — the control
-// smoothing, and the two DC filters.  The kernel therefore cuts the block into chunks of PPX_CHUNK samples and runs
-// them through a three-stage pipeline, one stage per group of waves, one __syncthreads() per chunk:
-//   wave 0       CONTROL  of chunk j+1: Control::smooth x2, scratch detector, LFO, controls[1].set() -> delay time per sample
-//   waves 1..8   AUDIO    of chunk j:   wave w owns 4 consecutive samples: Delay::set, 24 ring rows in flight, interpolate,
-//                                       cross-feed, both ring writes; also fetches the io rows of chunk j+1
+// Once every tap of a chunk lies further behind the write cursor than three chunks are long, the samples of the chunk no
+// longer depend on each other — nor on the two chunks before — through the delay lines: only three short recurrences are
+// sequential in time — the control smoothing, and the two DC filters.  The kernel therefore cuts the block into chunks of
+// PPX_CHUNK samples and runs them through a pipeline, one stage per group of waves, one LDS-only barrier per chunk:
+//   wave 0       CONTROL  of chunk j+2: Control::smooth x2, scratch detector, LFO, controls[1].set() -> delay time per sample
+//   waves 1..8   FETCH    of chunk j+1: wave w owns 4 consecutive samples: Delay::set, 24 ring rows requested into registers
+//                AUDIO    of chunk j:   (rows requested one step ago) interpolate, cross-feed, both ring writes;
+//                                       also fetches the io rows of chunk j+1
 //   waves 9, 10  FILTER   of chunk j-1: out.l / out.r >> dcfilter over the chunk; the io rows of chunk j-2 are stored
-// A chunk with a near tap (delay < ~0.8 ms, or within a chunk of the full line) is walked in order by wave 1 alone.
-// Arithmetic and its order are those of klg_fx_pingpong (KLG_FX_PINGPONG1=1) and the reference, bit for bit.
+// The barrier between steps waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier): ring rows are requested a whole step before
+// they are used and ring stores are never waited for, so no step exposes an HBM round trip (a __syncthreads() would drain
+// vmcnt and expose one per step — that was 11 x ~3.5 us of the 43 us this kernel took per 256-sample block at 4096 instances).
+// A chunk with a near tap (delay < ~4.2 ms, or within three chunks of the full line) is walked in order by wave 1 alone, between
+// full barriers.  Arithmetic and its order are those of klg_fx_pingpong (KLG_FX_PINGPONG1=1) and the reference, bit for bit.
 enum { PPX_CHUNK = 32, PPX_AUDIO = 8, PPX_PER = PPX_CHUNK / PPX_AUDIO, PPX_WAVES = 1 + PPX_AUDIO + 2, PPX_THREADS = PPX_WAVES * 64 };
 
 struct PpxLds {
 	float tile[4][2][PPX_CHUNK][FX_LD];         // [chunk & 3][channel][sample][instance]: loaded, audio, filter, store
-	float D[2][PPX_CHUNK][64];                  // delay time (smoothed controls[1]) per sample, [chunk & 1]
-	int far[2];                                 // 1: every tap of the chunk is far from the write cursor
+	float D[3][PPX_CHUNK][64];                  // delay time (smoothed controls[1]) per sample, [chunk % 3]
+	int far[4];                                 // [chunk & 3] 1: every tap of the chunk is far from the write cursor
 };
+
+__device__ __forceinline__ void wg_sync_lds_pp() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongArgs a) {
 	__shared__ PpxLds S;
@@ -275,18 +281,24 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	const int fch = wv - (PPX_AUDIO + 1);
 	Biquad dc = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, 0.f, 0.f };
 	if (w_filter) { dc.z0 = PPW(PP_Z + 2 * fch); dc.z1 = PPW(PP_Z + 2 * fch + 1); }
+	// ring rows of the audio waves' four samples: requested in the step before the one that uses them
+	float pl[PPX_PER][3], pr[PPX_PER][3], fl[PPX_PER], fr[PPX_PER];
+#pragma unroll
+	for (int q = 0; q < PPX_PER; q++) { pl[q][0] = pl[q][1] = pl[q][2] = pr[q][0] = pr[q][1] = pr[q][2] = 0.f; fl[q] = fr[q] = 0.f; }
+	if (tid < 4) S.far[tid] = 1;
+	__syncthreads();
 
-	for (int j = -1; j <= nchunks + 1; j++) {
+	for (int j = -2; j <= nchunks + 1; j++) {
 		// ---------------- io rows of chunk j+1 (audio waves; landed in LDS at the end of the step) ----------------
 		const int jn = j + 1;
-		const bool load_next = w_audio && jn < nchunks;
+		const bool load_next = w_audio && jn >= 0 && jn < nchunks;
 		float iov[8];
 		// (the thread index is laundered through an empty asm once per step: otherwise every per-thread address and bounds
 		//  predicate below is loop-invariant, gets hoisted out of the chunk loop, and ~100 VGPRs stay live for the whole kernel)
 		int at = tid - 64; asm volatile("" : "+v"(at));
 		const int acol = at & 31, arow = at >> 5;                                  // 512 audio threads: 16 rows x 32 samples per pass, 8 passes
 		const int ns0 = jn * PPX_CHUNK, ncl = (n - ns0 < PPX_CHUNK) ? (n - ns0) : PPX_CHUNK;
-		if (load_next) {
+		if (load_next && !(a.ablate & 4)) {
 			const char* src = (const char*)(a.io + (size_t)k0 * 2 * n + ns0);
 #pragma unroll
 			for (int i = 0; i < 8; i++) {
@@ -294,12 +306,16 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				iov[i] = (acol < ncl && k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + acol) * 4u) : 0.f;
 			}
 		}
-		// ---------------- CONTROL of chunk j+1 ----------------
-		if (w_control && jn < nchunks) {
+		// ---------------- CONTROL of chunk j+2 ----------------
+		const int jc = j + 2;
+		if (w_control && jc < nchunks && (a.ablate & 8)) { for (int u = 0; u < PPX_CHUNK; u++) S.D[jc % 3][u][lane] = 0.25f; if (lane == 0) S.far[jc & 3] = 1; }
+		else if (w_control && jc < nchunks) {
+			const int cs0 = jc * PPX_CHUNK, ccl = (n - cs0 < PPX_CHUNK) ? (n - cs0) : PPX_CHUNK;
 			float dmin = 3.0e38f, dmax = 0.f;                                         // range of the delay time over the chunk
 			lfo.increment = lfo_inc;
+			float (*D)[64] = S.D[jc % 3];
 #pragma unroll 4
-			for (int u = 0; u < ncl; u++) {
+			for (int u = 0; u < ccl; u++) {
 				sm5 = sm5 * 0.999f + (1.f - 0.999f) * c5;                           // controls[5].smooth()  klang.h:1715
 				const float new_delay = sm5;
 				// (double)fabsf(d) > 0.001  <=>  fabsf(d) >= 0.001f: 0.001f is the smallest float above the double 0.001
@@ -317,54 +333,45 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 					c1 = (nc1 < a.c1_min) ? a.c1_min : (a.c1_max < nc1) ? a.c1_max : nc1;
 				}
 				else phase_advance(lfo.position, lfo_inc);                          // lfo * 0 * 5e-5 == +-0, c1 + (+-0) == c1 (c1 >= c1_min > 0) and c1 is already clamped
-				S.D[jn & 1][u][lane] = delay;
+				D[u][lane] = delay;
 				dmin = fminf(dmin, delay); dmax = fmaxf(dmax, delay);
 			}
-			// x -> 0.5f * x * fs and x -> x * fs are monotonic, so the extreme delays decide for the whole chunk
-			const bool far = 0.5f * dmin * a.fs.f >= (float)(PPX_CHUNK + 3) && dmax * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
+			// x -> 0.5f * x * fs and x -> x * fs are monotonic, so the extreme delays decide for the whole chunk.  The rows of chunk c are
+			// requested during step c - 1, and what is safely in memory by then is everything written up to chunk c - 3: a wave's ring stores
+			// of chunk c - 3 (step c - 3) are older than its row requests for chunk c - 2, whose results it consumed — vmcnt returns in order —
+			// in step c - 2, before the barrier that ends that step.  A far tap therefore stays three chunks behind the write cursor.
+			const bool far = 0.5f * dmin * a.fs.f >= (float)(3 * PPX_CHUNK + 3) && dmax * a.fs.f <= (float)(SIZE - 3 * PPX_CHUNK - 4);
 			const bool all_far = __ballot(k < a.K && !far) == 0ull;                 // padding lanes (zero state, zero delay) do not veto
-			if (lane == 0) S.far[jn & 1] = all_far ? 1 : 0;
+			if (lane == 0) S.far[jc & 3] = all_far ? 1 : 0;
 		}
-		// ---------------- AUDIO of chunk j ----------------
+		// ---------------- AUDIO of chunk j (rows requested in the previous step) ----------------
+		const bool far_j = j >= 0 && j < nchunks && S.far[j & 3] != 0, far_n = jn >= 0 && jn < nchunks && S.far[jn & 3] != 0;
 		if (w_audio && j >= 0 && j < nchunks) {
 			const int s0 = j * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
 			const int pos0 = (int)(((long long)a.position + s0) % SIZE);
 			float (*T)[PPX_CHUNK][FX_LD] = S.tile[j & 3];
-			if (S.far[j & 1]) {
+			if (far_j) {
 				const int u0 = (wv - 1) * PPX_PER;
-				Tap tl[PPX_PER], tr[PPX_PER];
-				float pl[PPX_PER][3], pr[PPX_PER][3];
-#pragma unroll
-				for (int q = 0; q < PPX_PER; q++) if (u0 + q < cl) {
-					const float delay = S.D[j & 1][u0 + q][lane];
-					const int pos = wrap(pos0 + u0 + q);
-					tl[q] = delay_set(pos, SIZE, delay * a.fs.f);                   // left.set(delay * fs)
-					tr[q] = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);            // right.set(0.5f * delay * fs)
-					const int i0 = tl[q].position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
-					const int j0 = tr[q].position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
-					pl[q][0] = ring_rd(0, i0); pl[q][1] = ring_rd(0, i1); pl[q][2] = ring_rd(0, i2);
-					pr[q][0] = ring_rd(1, j0); pr[q][1] = ring_rd(1, j1); pr[q][2] = ring_rd(1, j2);
-				}
 #pragma unroll
 				for (int q = 0; q < PPX_PER; q++) if (u0 + q < cl) {
 					const int u = u0 + q, pos = wrap(pos0 + u);
 					const float in_l = T[0][u][lane], in_r = T[1][u][lane];
 					// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
-					const float r1 = pr[q][0] + tr[q].fraction * (pr[q][1] - pr[q][0]);
-					ring_wr(0, pos, in_l + r1 * gain);
-					const float l1 = pl[q][0] + tl[q].fraction * (pl[q][1] - pl[q][0]);
-					const float l2 = pl[q][1] + tl[q].fraction * (pl[q][2] - pl[q][1]);
+					const float r1 = pr[q][0] + fr[q] * (pr[q][1] - pr[q][0]);
+					if (!(a.ablate & 2)) ring_wr(0, pos, in_l + r1 * gain);
+					const float l1 = pl[q][0] + fl[q] * (pl[q][1] - pl[q][0]);
+					const float l2 = pl[q][1] + fl[q] * (pl[q][2] - pl[q][1]);
 					T[0][u][lane] = dry * in_l + l1 * (1.f - dry);
 					// dry * in.r + (1.f - dry) * ((in.r + left * gain) >> right) >> out.r;   PingPong.k:67
-					ring_wr(1, pos, in_r + l2 * gain);
-					const float r2 = pr[q][1] + tr[q].fraction * (pr[q][2] - pr[q][1]);
+					if (!(a.ablate & 2)) ring_wr(1, pos, in_r + l2 * gain);
+					const float r2 = pr[q][1] + fr[q] * (pr[q][2] - pr[q][1]);
 					T[1][u][lane] = dry * in_r + r2 * (1.f - dry);
 				}
 			}
 			else if (wv == 1) {                                                     // a near tap: the chunk is walked in order by one wave
 				Ring left = { ring0 + lane, FX_WG, SIZE }, right = { ring0 + (size_t)SIZE * FX_WG + lane, FX_WG, SIZE };
 				for (int u = 0; u < cl; u++) {
-					const float delay = S.D[j & 1][u][lane];
+					const float delay = S.D[j % 3][u][lane];
 					const int pos = wrap(pos0 + u);
 					Tap tl = delay_set(pos, SIZE, delay * a.fs.f), tr = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);
 					const float in_l = T[0][u][lane], in_r = T[1][u][lane];
@@ -378,8 +385,25 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				}
 			}
 		}
+		// ---------------- FETCH of chunk j+1: its ring rows are requested now and used in the next step ----------------
+		if (w_audio && far_n && !(a.ablate & 1)) {
+			const int pos0n = (int)(((long long)a.position + ns0) % SIZE);
+			const int u0 = (wv - 1) * PPX_PER;
+#pragma unroll
+			for (int q = 0; q < PPX_PER; q++) if (u0 + q < ncl) {
+				const float delay = S.D[jn % 3][u0 + q][lane];
+				const int pos = wrap(pos0n + u0 + q);
+				const Tap tl = delay_set(pos, SIZE, delay * a.fs.f);                // left.set(delay * fs)
+				const Tap tr = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);         // right.set(0.5f * delay * fs)
+				const int i0 = tl.position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
+				const int j0 = tr.position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
+				fl[q] = tl.fraction; fr[q] = tr.fraction;
+				pl[q][0] = ring_rd(0, i0); pl[q][1] = ring_rd(0, i1); pl[q][2] = ring_rd(0, i2);
+				pr[q][0] = ring_rd(1, j0); pr[q][1] = ring_rd(1, j1); pr[q][2] = ring_rd(1, j2);
+			}
+		}
 		// ---------------- store of chunk j-2 (first: its write acknowledgements have the whole step to arrive), FILTER of chunk j-1 ----------------
-		if (w_filter && j >= 2) {
+		if (w_filter && j >= 2 && !(a.ablate & 4)) {
 			const int js = j - 2, s0 = js * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
 			float (*T)[FX_LD] = S.tile[js & 3][fch];
 			int sl = lane; asm volatile("" : "+v"(sl));
@@ -391,7 +415,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
 			}
 		}
-		if (w_filter && j >= 1 && j <= nchunks) {
+		if (w_filter && j >= 1 && j <= nchunks && !(a.ablate & 16)) {
 			const int jf = j - 1, s0 = jf * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
 			float (*T)[FX_LD] = S.tile[jf & 3][fch];
 			for (int b = 0; b < PPX_CHUNK; b += 8) {                                  // eight LDS reads in flight, then the (sequential) filter
@@ -404,11 +428,14 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				for (int u = 0; u < 8; u++) T[b + u][lane] = x[u];
 			}
 		}
-		if (load_next) {
+		if (load_next && !(a.ablate & 4)) {
 #pragma unroll
 			for (int i = 0; i < 8; i++) { const int row = arow + 16 * i; S.tile[jn & 3][row & 1][acol][row >> 1] = iov[i]; }
 		}
-		__syncthreads();
+		// a near chunk (this one, or the next) reads rows that were written moments ago, possibly by another wave: those steps end with
+		// a full barrier (stores retired and visible); all other steps only order the LDS traffic
+		const bool near_step = (j >= 0 && j < nchunks && !far_j) || (jn >= 0 && jn < nchunks && !far_n);
+		if (near_step || (a.ablate & 32)) __syncthreads(); else wg_sync_lds_pp();
 	}
 	if (k < a.K) {
 		float* Wr = a.state + k;

@@ -317,7 +317,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		a.dc = f->pp_dc; a.c1_min = PP_DIALS[1].min; a.c1_max = PP_DIALS[1].max;
 		{ const char* e = getenv("KLG_FX_ABLATE"); a.ablate = e ? atoi(e) : 0; }
 		static const bool single_wave = []() { const char* e = getenv("KLG_FX_PINGPONG1"); return e && e[0] == '1'; }();
-		if (single_wave || a.ablate) hipLaunchKernelGGL(klg_fx_pingpong, grid, block, 0, st, a);   // one wave per 64 instances (A/B reference, ablation)
+		if (single_wave) hipLaunchKernelGGL(klg_fx_pingpong, grid, block, 0, st, a);   // one wave per 64 instances (A/B reference)
 		else hipLaunchKernelGGL(klg_fx_pingpong_x, grid, dim3(PPX_THREADS), 0, st, a);             // control / audio / filter pipeline over eleven waves
 	}
 	else {
