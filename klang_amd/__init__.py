@@ -5,5 +5,5 @@ C-ABI of include/klang_mi355.h (libklang_mi355.so: C++ host logic + hand-written
 There is no CPU rendering path anywhere in this package.
 """
 from ._lib import KlangError, lib, LIB_PATH  # noqa: F401
-from .bank import SynthBank, FxBank, EventScript, PATCH_IDS  # noqa: F401
+from .bank import SynthBank, FxBank, EventScript, PATCH_IDS, init  # noqa: F401
 from .shard import ShardedSynthBank, shard_range, owner_of  # noqa: F401

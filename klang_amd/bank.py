@@ -15,6 +15,13 @@ def _fp(a):
     return a.ctypes.data_as(F32P)
 
 
+def init(devices):
+    """klg_init: the GPUs of this process.  One id = every bank on that GPU; several ids = synth banks created afterwards are sharded over
+    them inside the library (contiguous ranges of synth instances, one RCCL all-reduce of the stereo block per klg_process)."""
+    ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+    check(lib().klg_init(ids, len(devices)), "klg_init")
+
+
 class SynthBank:
     """`synths` instances of one patch, `notes` Note slots each; one GPU lane per voice."""
 

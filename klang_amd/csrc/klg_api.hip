@@ -5,6 +5,8 @@
 // Device side (klg_kernels.hpp): everything per sample.  There is no CPU rendering path.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -57,14 +59,21 @@ int klg_ensure_device() {
 	return 0;
 }
 
+// The devices of this process.  One id: every bank lives on that GPU (one process per GPU: what bench.py and torch.distributed hosts do).
+// Several ids: a synth bank created afterwards is SHARDED over them inside the library — contiguous ranges of synth instances, one
+// shard (state, stream, event queue) per device, and ONE RCCL all-reduce of the [2][n] stereo block per klg_process (§ multi-device banks
+// below).  The same id may be listed twice (two shards on one GPU: how the sharding logic is tested on a 1-GPU box; those shards are
+// combined by a device-side add instead of RCCL, which cannot put one GPU in a communicator twice).
+static std::vector<int> g_devices;
 extern "C" int klg_init(const int* device_ids, int n_devices) {
 	RandGuard rg;
-	if (!device_ids || n_devices != 1) return fail(KLG_ERR_INVALID, "klg_init: one device per process (got %d)", n_devices);
+	if (!device_ids || n_devices < 1 || n_devices > 64) return fail(KLG_ERR_INVALID, "klg_init: 1..64 devices (got %d)", n_devices);
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(KLG_ERR_NO_DEVICE, "no HIP device visible: libklang_mi355 has no CPU fallback");
-	if (device_ids[0] < 0 || device_ids[0] >= count) return fail(KLG_ERR_INVALID, "device id %d out of range (0..%d)", device_ids[0], count - 1);
+	for (int i = 0; i < n_devices; i++) if (device_ids[i] < 0 || device_ids[i] >= count) return fail(KLG_ERR_INVALID, "device id %d out of range (0..%d)", device_ids[i], count - 1);
 	if (hipSetDevice(device_ids[0]) != hipSuccess) return fail(KLG_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device_ids[0]);
 	g_device = device_ids[0];
+	g_devices.assign(device_ids, device_ids + n_devices);
 	return 0;
 }
 
@@ -105,6 +114,8 @@ struct klg_synth {
 	float *d_controls = nullptr, *d_partials = nullptr, *d_mix = nullptr, *d_per_voice = nullptr;
 	uint32_t* d_scratch_rec = nullptr;
 	int grid = 0;
+	struct Multi* multi = nullptr;               // a bank sharded over several devices (klg_init with more than one id): this handle only routes
+	int device = 0;                              // the GPU this bank (or shard) lives on
 	int mix_mode = 0; int* d_solo = nullptr;      // klg_synth_set_mix_mode: KLG_MIX_LAST_ACTIVE keeps one voice per instance (d_solo[synths])
 	bool x2 = true;               // KLG_RENDER_X1=1 in the environment selects the one-voice-per-lane kernel (A/B tests)
 	// graph patches (klg_graph.hpp): the render kernels come from a hipRTC code object instead of this library
@@ -158,6 +169,109 @@ static void synth_free(klg_synth* s) {
 	delete s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// multi-device banks (SURVEY.md §8e behind the C-ABI): klg_init(ids, n > 1), then every synth bank is sharded over the devices
+// ------------------------------------------------------------------------------------------------
+// RCCL, loaded on first use (a single-device process never needs it)
+struct Rccl {
+	void* lib = nullptr; std::string error;
+	int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+	int (*CommDestroy)(void* comm) = nullptr;
+	int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t stream) = nullptr;
+	int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+	bool load() {
+		if (lib) return true;
+		const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
+		for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+		if (!lib) { error = std::string("cannot load librccl.so: ") + dlerror(); return false; }
+		bool ok = true;
+		auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) { ok = false; error = std::string("librccl.so lacks ") + n; } return p; };
+		CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+		AllReduce = (decltype(AllReduce))sym("ncclAllReduce"); GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+		GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+		if (!ok) { dlclose(lib); lib = nullptr; }
+		return ok;
+	}
+};
+static Rccl g_rccl;
+enum { KLG_NCCL_FLOAT32 = 7, KLG_NCCL_SUM = 0 };                   // ncclFloat32, ncclSum (rccl.h)
+
+struct Multi {
+	std::vector<klg_synth*> shard; std::vector<int> first;          // shard i owns synth instances [first[i], first[i + 1])
+	std::vector<void*> comm; bool rccl = false;                     // one communicator per shard (distinct devices), else a device-side add
+	std::vector<hipEvent_t> done;                                   // same-device combine: shard i's block is ready
+	hipEvent_t combined = nullptr, consumed = nullptr;              // the previous block: shard blocks added into shard 0's / shard 0's block added into the caller's
+	bool have_combined = false, have_consumed = false;
+};
+__global__ void klg_add_block(float* dst, const float* src, int count) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < count) dst[i] += src[i]; }
+__global__ void klg_sub_block(float* dst, const float* src, int count) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < count) dst[i] -= src[i]; }
+
+// run `f` with shard i's device current (every single-device entry point binds to g_device)
+template<class F> static auto on_shard(klg_synth* r, size_t i, F&& f) {
+	const int keep = g_device; const std::vector<int> keep_list = g_devices;
+	g_device = r->multi->shard[i]->device; g_devices.assign(1, g_device);
+	(void)hipSetDevice(g_device);
+	auto rc = f(r->multi->shard[i]);
+	g_device = keep; g_devices = keep_list;
+	(void)hipSetDevice(g_device);
+	return rc;
+}
+static int shard_of_synth(const klg_synth* r, int synth, int* local) {
+	const Multi& m = *r->multi;
+	for (size_t i = 0; i + 1 < m.first.size(); i++) if (synth >= m.first[i] && synth < m.first[i + 1]) { *local = synth - m.first[i]; return (int)i; }
+	return -1;
+}
+static int shard_of_voice(const klg_synth* r, int voice, int* local) { int ls = 0; const int i = shard_of_synth(r, voice / r->P, &ls); if (i >= 0) *local = ls * r->P + voice % r->P; return i; }
+
+static void multi_free(klg_synth* r) {
+	if (!r || !r->multi) return;
+	Multi* m = r->multi;
+	for (size_t i = 0; i < m->shard.size(); i++) on_shard(r, i, [&](klg_synth* sh) { if (m->rccl && i < m->comm.size() && m->comm[i]) g_rccl.CommDestroy(m->comm[i]); klg_synth_destroy(sh); return 0; });
+	for (auto e : m->done) if (e) (void)hipEventDestroy(e);
+	if (m->combined) (void)hipEventDestroy(m->combined);
+	if (m->consumed) (void)hipEventDestroy(m->consumed);
+	delete m; r->multi = nullptr;
+	delete r;
+}
+// create: `make(synths)` is the ordinary single-device creator, run once per device with that device current
+template<class MAKE> static klg_synth* multi_create(int synths, int notes_per_synth, int max_block, MAKE&& make) {
+	const std::vector<int> devs = g_devices;
+	const int n = (int)std::min<size_t>(devs.size(), (size_t)synths);
+	klg_synth* r = new klg_synth();
+	r->multi = new Multi(); r->S = synths; r->P = notes_per_synth; r->V = synths * notes_per_synth; r->max_block = max_block; r->device = devs[0];
+	Multi& m = *r->multi;
+	const int base = synths / n, extra = synths % n;                // contiguous ranges; the first `extra` shards own one instance more
+	m.first.push_back(0);
+	const int keep = g_device;
+	for (int i = 0; i < n; i++) {
+		const int count = base + (i < extra ? 1 : 0);
+		g_device = devs[(size_t)i]; g_devices.assign(1, g_device);
+		klg_synth* sh = hipSetDevice(g_device) == hipSuccess ? make(count) : nullptr;
+		g_device = keep; g_devices = devs;
+		if (!sh) { const std::string why = g_err; multi_free(r); (void)hipSetDevice(keep); fail(KLG_ERR_NOMEM, "multi-device bank: shard %d on device %d: %s", i, devs[(size_t)i], why.c_str()); return nullptr; }
+		sh->device = devs[(size_t)i];
+		m.shard.push_back(sh); m.first.push_back(m.first.back() + count);
+	}
+	(void)hipSetDevice(keep);
+	r->patch = m.shard[0]->patch; r->W = m.shard[0]->W; r->nctl = m.shard[0]->nctl; r->fs = m.shard[0]->fs;
+	bool distinct = true;
+	for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (devs[(size_t)i] == devs[(size_t)j]) distinct = false;
+	if (distinct && n > 1) {                                        // ONE communicator clique over the shards' devices (RCCL over xGMI)
+		if (!g_rccl.load()) { const std::string why = g_rccl.error; multi_free(r); fail(KLG_ERR_HIP, "multi-device bank: %s", why.c_str()); return nullptr; }
+		m.comm.assign((size_t)n, nullptr);
+		const int rc = g_rccl.CommInitAll(m.comm.data(), n, devs.data());
+		if (rc != 0) { const std::string why = g_rccl.GetErrorString(rc); multi_free(r); fail(KLG_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", n, why.c_str()); return nullptr; }
+		m.rccl = true;
+	}
+	else for (int i = 0; i < n; i++) { hipEvent_t e = nullptr; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); m.done.push_back(e); }
+	return r;
+}
+
+static int multi_process_host(klg_synth* r, float* per_voice, float* const* out, int channels, int n, float* parameters);
+static int multi_process_device(klg_synth* r, float* d_mix, int n, void* hip_stream);
+
 enum { KLG_PATCH_GRAPH = 1000 };     // klg_synth::patch of a graph patch (not a klg_patch id)
 
 static klg_synth* synth_create_common(int patch_id, const PatchInfo* pi, int synths, int notes_per_synth, float sample_rate, int max_block) {
@@ -207,12 +321,14 @@ static klg_synth* synth_create_common(int patch_id, const PatchInfo* pi, int syn
 extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_synth, float sample_rate, int max_block) {
 	const PatchInfo* pi = patch_info(patch_id);
 	if (!pi || pi->words == 0) { fail(KLG_ERR_INVALID, "klg_synth_create: patch %d is not a synth patch", patch_id); return nullptr; }
+	if (g_devices.size() > 1 && synths > 0) return multi_create(synths, notes_per_synth, max_block, [&](int count) { return klg_synth_create(patch_id, count, notes_per_synth, sample_rate, max_block); });
 	return synth_create_common(patch_id, pi, synths, notes_per_synth, sample_rate, max_block);
 }
 
 // replaces: constructing a user Synth whose Note::process() is NOT one of the shipped patch ids: the recorded body
 // (include/klang_mi355_graph.h) is compiled for gfx950 with hipRTC and rendered by the same klg_render kernel.
 extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, int notes_per_synth, float sample_rate, int max_block) {
+	if (g_devices.size() > 1 && synths > 0) return multi_create(synths, notes_per_synth, max_block, [&](int count) { return klg_synth_create_graph(program, count, notes_per_synth, sample_rate, max_block); });
 	RandGuard rg;                 // hipRTC / comgr draw temporary names from libc random(): the caller's klang::random(seed) stream must survive
 	const graphrt::Compiled* c = nullptr;
 	graph::Program g;
@@ -269,11 +385,12 @@ extern "C" int klg_graph_check(const char* program, int want_source, char* out, 
 	return err.empty() ? 0 : fail(KLG_ERR_INVALID, "klg_graph_check: %s", err.c_str());
 }
 
-extern "C" void klg_synth_destroy(klg_synth* s) { if (s && g_device >= 0) (void)hipSetDevice(g_device); synth_free(s); }
-extern "C" int klg_synth_voices_per_lane(const klg_synth* s) { if (!s) return KLG_ERR_INVALID; return ((s->patch == KLG_PATCH_SUB2A && s->x2) || (s->graph && s->graph->x2)) ? 2 : 1; }
+extern "C" void klg_synth_destroy(klg_synth* s) { if (s && s->multi) { multi_free(s); return; } if (s && g_device >= 0) (void)hipSetDevice(g_device); synth_free(s); }
+extern "C" int klg_synth_voices_per_lane(const klg_synth* s) { if (!s) return KLG_ERR_INVALID; if (s->multi) return klg_synth_voices_per_lane(s->multi->shard[0]); return ((s->patch == KLG_PATCH_SUB2A && s->x2) || (s->graph && s->graph->x2)) ? 2 : 1; }
 // replaces: the voice loop of the MONO Synth::process(float*, int, float*) (klang.h:4450-4457), see include/klang_mi355.h
 extern "C" int klg_synth_set_mix_mode(klg_synth* s, int mode) {
 	if (!s || (mode != KLG_MIX_SUM && mode != KLG_MIX_LAST_ACTIVE)) return fail(KLG_ERR_INVALID, "klg_synth_set_mix_mode: bad handle or mode %d", mode);
+	if (s->multi) { for (size_t i = 0; i < s->multi->shard.size(); i++) if (int rc = on_shard(s, i, [&](klg_synth* sh) { return klg_synth_set_mix_mode(sh, mode); })) return rc; s->mix_mode = mode; return 0; }
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	if (mode == KLG_MIX_LAST_ACTIVE && !s->d_solo) {
 		RandGuard rg;
@@ -513,6 +630,7 @@ static int synth_assign(klg_synth* s, int synth) {
 static const char* const kGraphEvents = "graph patches keep on()/off() in the caller (the DSL facade): move voice records with klg_voice_download / klg_voice_upload / klg_voices_upload";
 extern "C" int klg_note_on(klg_synth* s, int synth, int pitch, float velocity) {
 	if (!s || synth < 0 || synth >= s->S) return fail(KLG_ERR_INVALID, "klg_note_on: bad handle or synth index %d", synth);
+	if (s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); return on_shard(s, (size_t)i, [&](klg_synth* sh) { return klg_note_on(sh, ls, pitch, velocity); }); }
 	if (s->graph) return fail(KLG_ERR_INVALID, "klg_note_on: %s", kGraphEvents);
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	if (int rc = refresh_stages(s)) return rc;
@@ -529,6 +647,7 @@ extern "C" int klg_note_on(klg_synth* s, int synth, int pitch, float velocity) {
 extern "C" int klg_note_off(klg_synth* s, int synth, int pitch, float velocity) {
 	(void)velocity;
 	if (!s || synth < 0 || synth >= s->S) return fail(KLG_ERR_INVALID, "klg_note_off: bad handle or synth index %d", synth);
+	if (s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); return on_shard(s, (size_t)i, [&](klg_synth* sh) { return klg_note_off(sh, ls, pitch, velocity); }); }
 	if (s->graph) return fail(KLG_ERR_INVALID, "klg_note_off: %s", kGraphEvents);
 	for (int i = 0; i < s->P; i++) {
 		const int voice = synth * s->P + i;
@@ -555,6 +674,7 @@ extern "C" int klg_note_off_many(klg_synth* s, int n, const int* synth, const in
 
 extern "C" int klg_set_control(klg_synth* s, int synth, int index, float value) {
 	if (!s || synth < 0 || synth >= s->S || index < 0 || index >= s->nctl) return fail(KLG_ERR_INVALID, "klg_set_control: synth %d / control %d out of range", synth, index);
+	if (s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); return klg_set_control(s->multi->shard[(size_t)i], ls, index, value); }
 	host::ControlH& c = s->controls[(size_t)synth * s->nctl + index];
 	c.set(value);
 	s->h_controls[(size_t)synth * KLG_MAX_CTL + index] = c.value;
@@ -563,6 +683,7 @@ extern "C" int klg_set_control(klg_synth* s, int synth, int index, float value) 
 }
 extern "C" int klg_get_control(klg_synth* s, int synth, int index, float* value) {
 	if (!s || !value || synth < 0 || synth >= s->S || index < 0 || index >= s->nctl) return fail(KLG_ERR_INVALID, "klg_get_control: out of range");
+	if (s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); return klg_get_control(s->multi->shard[(size_t)i], ls, index, value); }
 	*value = s->controls[(size_t)synth * s->nctl + index].value;
 	return 0;
 }
@@ -634,16 +755,122 @@ static int process_host(klg_synth* s, float* per_voice, float* const* out, int c
 	return 0;
 }
 
+
+// every shard renders its block into its own [2][n] (cleared first), then ONE all-reduce (RCCL) — or, for shards sharing a GPU, adds
+// on shard 0's stream — leaves the global block in shard 0's d_mix
+static int multi_render(klg_synth* r, int n, bool per_voice) {
+	Multi& m = *r->multi;
+	for (size_t i = 0; i < m.shard.size(); i++) {
+		const int rc = on_shard(r, i, [&](klg_synth* sh) -> int {
+			if (per_voice && !sh->d_per_voice) { HIP_TRY(hipMalloc(&sh->d_per_voice, (size_t)sh->V * sh->max_block * 4)); HIP_TRY(hipHostMalloc(&sh->h_per_voice, (size_t)sh->V * sh->max_block * 4)); }
+			// a shard's block buffer is free again once the previous block has been combined (and, for shard 0, handed to the caller)
+			if (m.have_combined) HIP_TRY(hipStreamWaitEvent(sh->stream, m.combined, 0));
+			if (i == 0 && m.have_consumed) HIP_TRY(hipStreamWaitEvent(sh->stream, m.consumed, 0));
+			HIP_TRY(hipMemsetAsync(sh->d_mix, 0, (size_t)2 * n * 4, sh->stream));
+			if (int e = enqueue_block(sh, sh->d_mix, n, per_voice, sh->stream)) return e;
+			if (!m.rccl) HIP_TRY(hipEventRecord(m.done[i], sh->stream));
+			return 0;
+		});
+		if (rc) return rc;
+	}
+	if (m.shard.size() == 1) return 0;
+	if (m.rccl) {
+		int rc = g_rccl.GroupStart();
+		for (size_t i = 0; i < m.shard.size() && rc == 0; i++) rc = g_rccl.AllReduce(m.shard[i]->d_mix, m.shard[i]->d_mix, (size_t)2 * n, KLG_NCCL_FLOAT32, KLG_NCCL_SUM, m.comm[i], m.shard[i]->stream);
+		const int rc2 = g_rccl.GroupEnd();
+		if (rc != 0 || rc2 != 0) return fail(KLG_ERR_HIP, "ncclAllReduce of the [2][%d] block failed: %s", n, g_rccl.GetErrorString(rc ? rc : rc2));
+		return 0;
+	}
+	return on_shard(r, 0, [&](klg_synth* s0) -> int {
+		for (size_t i = 1; i < m.shard.size(); i++) {
+			HIP_TRY(hipStreamWaitEvent(s0->stream, m.done[i], 0));
+			hipLaunchKernelGGL(klg_add_block, dim3((2 * n + 255) / 256), dim3(256), 0, s0->stream, s0->d_mix, (const float*)m.shard[i]->d_mix, 2 * n);
+		}
+		HIP_TRY(hipGetLastError());
+		if (!m.combined) HIP_TRY(hipEventCreateWithFlags(&m.combined, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(m.combined, s0->stream)); m.have_combined = true;
+		return 0;
+	});
+}
+static int multi_process_host(klg_synth* r, float* per_voice, float* const* out, int channels, int n, float* parameters) {
+	if (n <= 0 || n > r->max_block) return fail(KLG_ERR_INVALID, "klg_process: n=%d not in 1..max_block", n);
+	if (out && (channels < 1 || channels > 2)) return fail(KLG_ERR_INVALID, "klg_process: channels must be 1 or 2");
+	Multi& m = *r->multi;
+	if (parameters && r->nctl) for (int i = 0; i < r->S; i++) for (int c = 0; c < r->nctl; c++) klg_set_control(r, i, c, parameters[(size_t)i * r->nctl + c]);
+	bool replace = false;
+	if (r->mix_mode == KLG_MIX_LAST_ACTIVE) for (size_t i = 0; i < m.shard.size(); i++) {
+		if (int rc = on_shard(r, i, [&](klg_synth* sh) { return refresh_stages(sh); })) return rc;
+		for (int v = 0; v < m.shard[i]->V && !replace; v++) replace = m.shard[i]->voices[v].stage != ST_OFF;
+	}
+	if (int rc = multi_render(r, n, per_voice != nullptr)) return rc;
+	size_t v0 = 0;
+	for (size_t i = 0; i < m.shard.size(); i++) {
+		const int rc = on_shard(r, i, [&](klg_synth* sh) -> int {
+			if (i == 0) HIP_TRY(hipMemcpyAsync(sh->h_mix, sh->d_mix, (size_t)2 * n * 4, hipMemcpyDeviceToHost, sh->stream));
+			HIP_TRY(hipMemcpyAsync(sh->h_flags, sh->d_state, (size_t)sh->V * 4, hipMemcpyDeviceToHost, sh->stream));
+			if (per_voice) HIP_TRY(hipMemcpyAsync(sh->h_per_voice, sh->d_per_voice, (size_t)sh->V * n * 4, hipMemcpyDeviceToHost, sh->stream));
+			HIP_TRY(hipStreamSynchronize(sh->stream));
+			if (per_voice) std::memcpy(per_voice + v0 * (size_t)n, sh->h_per_voice, (size_t)sh->V * n * 4);
+			if (sh->scripted) for (int v = 0; v < sh->V; v++) sh->voices[v].stage = (uint8_t)(sh->h_flags[v] & 3u);
+			else for (int v = 0; v < sh->V; v++) if ((sh->h_flags[v] & 3u) == (uint32_t)ST_OFF) sh->voices[v].stage = ST_OFF;
+			sh->stages_dirty = false;
+			return 0;
+		});
+		if (rc) return rc;
+		v0 += (size_t)m.shard[i]->V;
+	}
+	const float* mix = m.shard[0]->h_mix;
+	if (out) for (int c = 0; c < channels; c++) {
+		float* dst = out[c]; const float* src = mix + (size_t)c * n;
+		if (replace) std::memcpy(dst, src, (size_t)n * 4);
+		else if (r->mix_mode != KLG_MIX_LAST_ACTIVE) for (int i = 0; i < n; i++) dst[i] += src[i];
+	}
+	if (parameters && r->nctl) for (int i = 0; i < r->S; i++) for (int c = 0; c < r->nctl; c++) klg_get_control(r, i, c, &parameters[(size_t)i * r->nctl + c]);
+	return 0;
+}
+// throughput entry: the global block is ADDED to the caller's d_mix (a buffer on the device of shard 0) on shard 0's stream order
+static int multi_process_device(klg_synth* r, float* d_mix, int n, void* hip_stream) {
+	if (!d_mix || n <= 0 || n > r->max_block) return fail(KLG_ERR_INVALID, "klg_process_device: bad arguments (n=%d)", n);
+	if (int rc = multi_render(r, n, false)) return rc;
+	return on_shard(r, 0, [&](klg_synth* s0) -> int {
+		hipStream_t user = hip_stream ? (hipStream_t)hip_stream : s0->stream;
+		Multi& m = *r->multi;
+		if (user != s0->stream) {                                    // the caller's stream continues after the combine
+			if (m.done.empty()) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m.done.push_back(e); }
+			HIP_TRY(hipEventRecord(m.done[0], s0->stream));
+			HIP_TRY(hipStreamWaitEvent(user, m.done[0], 0));
+		}
+		hipLaunchKernelGGL(klg_add_block, dim3((2 * n + 255) / 256), dim3(256), 0, user, d_mix, (const float*)s0->d_mix, 2 * n);
+		HIP_TRY(hipGetLastError());
+		if (user != s0->stream) {                                    // shard 0 may not clear its block before the caller's stream has read it
+			if (!m.consumed) HIP_TRY(hipEventCreateWithFlags(&m.consumed, hipEventDisableTiming));
+			HIP_TRY(hipEventRecord(m.consumed, user)); m.have_consumed = true;
+		}
+		return 0;
+	});
+}
+
 extern "C" int klg_process(klg_synth* s, float* const* out, int channels, int n, float* parameters) {
 	if (!out) return fail(KLG_ERR_INVALID, "klg_process: out is NULL");
+	if (s && s->multi) return multi_process_host(s, nullptr, out, channels, n, parameters);
 	return process_host(s, nullptr, out, channels, n, parameters);
 }
 extern "C" int klg_process_voices(klg_synth* s, float* per_voice, float* const* out, int channels, int n) {
 	if (!per_voice) return fail(KLG_ERR_INVALID, "klg_process_voices: per_voice is NULL");
+	if (s && s->multi) return multi_process_host(s, per_voice, out, channels, n, nullptr);
 	return process_host(s, per_voice, out, channels, n, nullptr);
 }
 extern "C" int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices) {
 	if (!s || !stages || n_voices < 0 || n_voices > s->V) return fail(KLG_ERR_INVALID, "klg_voice_stages: bad arguments");
+	if (s->multi) {
+		int v0 = 0;
+		for (size_t i = 0; i < s->multi->shard.size() && v0 < n_voices; i++) {
+			const int take = std::min(n_voices - v0, s->multi->shard[i]->V);
+			if (int rc = on_shard(s, i, [&](klg_synth* sh) { return klg_voice_stages(sh, stages + v0, take); })) return rc;
+			v0 += take;
+		}
+		return 0;
+	}
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	if (int rc = refresh_stages(s)) return rc;
 	for (int v = 0; v < n_voices; v++) stages[v] = s->voices[v].stage;
@@ -651,12 +878,14 @@ extern "C" int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices) {
 }
 
 extern "C" int klg_process_device(klg_synth* s, float* d_mix, int n, void* hip_stream) {
+	if (s && s->multi) return multi_process_device(s, d_mix, n, hip_stream);
 	if (!s || !d_mix || n <= 0 || n > s->max_block) return fail(KLG_ERR_INVALID, "klg_process_device: bad arguments (n=%d)", n);
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	return enqueue_block(s, d_mix, n, false, hip_stream ? (hipStream_t)hip_stream : s->stream);
 }
 extern "C" int klg_sync(klg_synth* s) {
 	if (!s) return fail(KLG_ERR_INVALID, "klg_sync: NULL handle");
+	if (s->multi) { for (size_t i = 0; i < s->multi->shard.size(); i++) if (int rc = on_shard(s, i, [&](klg_synth* sh) { return klg_sync(sh); })) return rc; return 0; }
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	HIP_TRY(hipDeviceSynchronize());
@@ -665,6 +894,7 @@ extern "C" int klg_sync(klg_synth* s) {
 
 extern "C" int klg_voice_download(klg_synth* s, int voice, void* state, size_t bytes) {
 	if (!s || !state || voice < 0 || voice >= s->V || bytes != (size_t)s->W * 4) return fail(KLG_ERR_INVALID, "klg_voice_download: bad arguments (record is %d bytes)", s ? s->W * 4 : 0);
+	if (s->multi) { int lv = 0; const int i = shard_of_voice(s, voice, &lv); return on_shard(s, (size_t)i, [&](klg_synth* sh) { return klg_voice_download(sh, lv, state, bytes); }); }
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	if (int rc = flush_events(s, s->stream)) return rc;
 	hipLaunchKernelGGL(klg_copy_record, dim3(1), dim3(128), 0, s->stream, s->d_state, s->stride, voice, s->d_scratch_rec, s->W, 0);
@@ -674,6 +904,7 @@ extern "C" int klg_voice_download(klg_synth* s, int voice, void* state, size_t b
 }
 extern "C" int klg_voice_upload(klg_synth* s, int voice, const void* state, size_t bytes) {
 	if (!s || !state || voice < 0 || voice >= s->V || bytes != (size_t)s->W * 4) return fail(KLG_ERR_INVALID, "klg_voice_upload: bad arguments (record is %d bytes)", s ? s->W * 4 : 0);
+	if (s->multi) { int lv = 0; const int i = shard_of_voice(s, voice, &lv); return on_shard(s, (size_t)i, [&](klg_synth* sh) { return klg_voice_upload(sh, lv, state, bytes); }); }
 	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
 	if (int rc = flush_events(s, s->stream)) return rc;
 	HIP_TRY(hipMemcpyAsync(s->d_scratch_rec, state, bytes, hipMemcpyHostToDevice, s->stream));
@@ -688,6 +919,10 @@ extern "C" int klg_voice_upload(klg_synth* s, int voice, const void* state, size
 extern "C" int klg_voices_upload(klg_synth* s, int n, const int* voices, const void* states) {
 	if (!s || n < 0 || !voices || !states) return fail(KLG_ERR_INVALID, "klg_voices_upload: bad arguments");
 	for (int i = 0; i < n; i++) if (voices[i] < 0 || voices[i] >= s->V) return fail(KLG_ERR_INVALID, "klg_voices_upload: voice %d out of range", voices[i]);
+	if (s->multi) {
+		for (int i = 0; i < n; i++) { int lv = 0; const int sh = shard_of_voice(s, voices[i], &lv); if (int rc = klg_voices_upload(s->multi->shard[(size_t)sh], 1, &lv, (const uint32_t*)states + (size_t)i * s->W)) return rc; }
+		return 0;
+	}
 	const uint32_t* w = (const uint32_t*)states;
 	for (int i = 0; i < n; i++) {
 		push_note_on(s, voices[i], w + (size_t)i * s->W);
@@ -698,6 +933,7 @@ extern "C" int klg_voices_upload(klg_synth* s, int n, const int* voices, const v
 
 // Delay::clear() of a note's delay line (klang.h:3392-3394), in stream order with the blocks
 extern "C" int klg_voice_delay_clear(klg_synth* s, int voice, int delay_index) {
+	if (s && s->multi) { int lv = 0; const int i = shard_of_voice(s, voice, &lv); if (i < 0) return fail(KLG_ERR_INVALID, "klg_voice_delay_clear: voice %d out of range", voice); return on_shard(s, (size_t)i, [&](klg_synth* sh) { return klg_voice_delay_clear(sh, lv, delay_index); }); }
 	if (!s || !s->graph || !s->d_note_rings) return fail(KLG_ERR_INVALID, "klg_voice_delay_clear: the bank has no note delays (graph %p, %lld ring rows, lines %p)", s ? (const void*)s->graph : nullptr, s && s->graph ? s->graph->ring_rows : -1ll, s ? (const void*)s->d_note_rings : nullptr);
 	if (voice < 0 || voice >= s->V || delay_index < 0 || delay_index >= (int)s->graph->delays.size()) return fail(KLG_ERR_INVALID, "klg_voice_delay_clear: voice %d / delay %d out of range", voice, delay_index);
 	const long long row0 = s->graph->delays[(size_t)delay_index].first; const int size = s->graph->delays[(size_t)delay_index].second;
@@ -720,6 +956,7 @@ static int table_add(klg_synth* s, const float* samples, int n) {
 }
 extern "C" int klg_table_upload(klg_synth* s, const float* samples, int n, int dedup) {
 	if (!s || !samples || n < 2 || n > (1 << 26)) return fail(KLG_ERR_INVALID, "klg_table_upload: bad arguments (2 .. 2^26 samples)");
+	if (s->multi) { int id = -1; for (size_t i = 0; i < s->multi->shard.size(); i++) { id = on_shard(s, i, [&](klg_synth* sh) { return klg_table_upload(sh, samples, n, dedup); }); if (id < 0) return id; } return id; }   // the same tables in the same order on every device: one id
 	if (s->patch != KLG_PATCH_GRAPH) return fail(KLG_ERR_INVALID, "klg_table_upload: only graph banks (klg_synth_create_graph) read tables");
 	RandGuard rg;
 	if (s->tables.empty()) { const float zero[2] = { 0.f, 0.f }; const int id0 = table_add(s, zero, 2); if (id0 < 0) return id0; }   // id 0: what an all-zero record reads
@@ -750,6 +987,7 @@ static int tables_sync(klg_synth* s) {
 // Event scripts resident in HBM (include/klang_mi355.h: klg_script_*): offline / throughput rendering of a known event stream
 // ------------------------------------------------------------------------------------------------
 extern "C" int klg_note_record(klg_synth* s, int synth, int pitch, float velocity, void* record, size_t bytes) {
+	if (s && s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); if (i < 0) return fail(KLG_ERR_INVALID, "klg_note_record: synth %d out of range", synth); return klg_note_record(s->multi->shard[(size_t)i], ls, pitch, velocity, record, bytes); }
 	if (!s || !record || synth < 0 || synth >= s->S || bytes != (size_t)s->W * 4) return fail(KLG_ERR_INVALID, "klg_note_record: bad arguments (record is %d bytes)", s ? s->W * 4 : 0);
 	if (s->graph) return fail(KLG_ERR_INVALID, "klg_note_record: %s", kGraphEvents);
 	HostVoice hv = s->voices[(size_t)synth * s->P];                // a scratch note of this instance (the oscillators' cached frequencies start as a fresh note's)
@@ -771,6 +1009,7 @@ struct klg_script {
 	int* d_index = nullptr; uint32_t* d_pool = nullptr;
 };
 extern "C" klg_script* klg_script_create(klg_synth* s, int blocks) {
+	if (s && s->multi) { fail(KLG_ERR_INVALID, "klg_script_create: event scripts are per device: create one bank + script per GPU (one process per GPU, as bench.py does)"); return nullptr; }
 	if (!s || blocks <= 0) { fail(KLG_ERR_INVALID, "klg_script_create: bad arguments"); return nullptr; }
 	klg_script* k = new klg_script(); k->s = s; k->blocks = blocks; k->ev.resize((size_t)blocks);
 	return k;
@@ -872,9 +1111,15 @@ extern "C" int klg_script_play_device(klg_script* k, int block, float* d_mix, in
 	return enqueue_block(s, d_mix, n, false, st);
 }
 
-extern "C" int klg_timing_begin(klg_synth* s) { if (!s) return fail(KLG_ERR_INVALID, "NULL handle"); s->timing = true; s->launches = 0; return 0; }
+extern "C" int klg_timing_begin(klg_synth* s) { if (!s) return fail(KLG_ERR_INVALID, "NULL handle");
+ if (s->multi) { for (klg_synth* sh : s->multi->shard) klg_timing_begin(sh); return 0; } s->timing = true; s->launches = 0; return 0; }
 extern "C" int klg_timing_end(klg_synth* s, int* launches, float* total_ms) {
 	if (!s || !launches || !total_ms) return fail(KLG_ERR_INVALID, "klg_timing_end: bad arguments");
+	if (s->multi) {                                                     // the slowest shard's render time (they run concurrently)
+		int l = 0; float ms = 0.f; *launches = 0; *total_ms = 0.f;
+		for (size_t i = 0; i < s->multi->shard.size(); i++) { if (int rc = on_shard(s, i, [&](klg_synth* sh) { return klg_timing_end(sh, &l, &ms); })) return rc; if (ms > *total_ms) { *total_ms = ms; *launches = l; } }
+		return 0;
+	}
 	HIP_TRY(hipDeviceSynchronize());
 	float total = 0.f;
 	for (int i = 0; i < s->launches; i++) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, s->tev[2 * i], s->tev[2 * i + 1])); total += ms; }

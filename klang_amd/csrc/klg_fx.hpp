@@ -83,7 +83,7 @@ struct PingPongArgs {
 	SampleRate fs;
 	BiquadCoef dc;              // dcfilter[k].set(50, 1) — PingPong.k:39-40, computed on the host
 	float c1_min, c1_max;
-	int ablate;                 // measurement only (KLG_FX_ABLATE): 1 = no ring reads, 2 = no ring writes, 4 = no io staging, 8 = no control recurrences, 16 = no DC filters, 32 = full barriers
+	int ablate;                 // measurement only (KLG_FX_ABLATE, the one-wave kernel): 1 = no ring reads, 2 = no ring writes, 4 = no io staging
 };
 
 // The kernel works in sub-chunks of PP_SUB samples:
@@ -222,29 +222,23 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 // -------------------------------------------------------------------------------------------------
 // PingPong.k, eleven waves per 64 instances (the production kernel).
 //
-// Once every tap of a chunk lies further behind the write cursor than three chunks are long, the samples of the chunk no
-// longer depend on each other — nor on the two chunks before — through the delay lines: only three short recurrences are
-// sequential in time — the control smoothing, and the two DC filters.  The kernel therefore cuts the block into chunks of
-// PPX_CHUNK samples and runs them through a pipeline, one stage per group of waves, one LDS-only barrier per chunk:
-//   wave 0       CONTROL  of chunk j+2: Control::smooth x2, scratch detector, LFO, controls[1].set() -> delay time per sample
-//   waves 1..8   FETCH    of chunk j+1: wave w owns 4 consecutive samples: Delay::set, 24 ring rows requested into registers
-//                AUDIO    of chunk j:   (rows requested one step ago) interpolate, cross-feed, both ring writes;
-//                                       also fetches the io rows of chunk j+1
+// Once every tap of a chunk lies further behind the write cursor than the chunk is long, the samples of the chunk no
+// longer depend on each other through the delay lines: only three short recurrences are sequential in time — the control
+// smoothing, and the two DC filters.  The kernel therefore cuts the block into chunks of PPX_CHUNK samples and runs
+// them through a three-stage pipeline, one stage per group of waves, one __syncthreads() per chunk:
+//   wave 0       CONTROL  of chunk j+1: Control::smooth x2, scratch detector, LFO, controls[1].set() -> delay time per sample
+//   waves 1..8   AUDIO    of chunk j:   wave w owns 4 consecutive samples: Delay::set, 24 ring rows in flight, interpolate,
+//                                       cross-feed, both ring writes; also fetches the io rows of chunk j+1
 //   waves 9, 10  FILTER   of chunk j-1: out.l / out.r >> dcfilter over the chunk; the io rows of chunk j-2 are stored
-// The barrier between steps waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier): ring rows are requested a whole step before
-// they are used and ring stores are never waited for, so no step exposes an HBM round trip (a __syncthreads() would drain
-// vmcnt and expose one per step — that was 11 x ~3.5 us of the 43 us this kernel took per 256-sample block at 4096 instances).
-// A chunk with a near tap (delay < ~4.2 ms, or within three chunks of the full line) is walked in order by wave 1 alone, between
-// full barriers.  Arithmetic and its order are those of klg_fx_pingpong (KLG_FX_PINGPONG1=1) and the reference, bit for bit.
+// A chunk with a near tap (delay < ~0.8 ms, or within a chunk of the full line) is walked in order by wave 1 alone.
+// Arithmetic and its order are those of klg_fx_pingpong (KLG_FX_PINGPONG1=1) and the reference, bit for bit.
 enum { PPX_CHUNK = 32, PPX_AUDIO = 8, PPX_PER = PPX_CHUNK / PPX_AUDIO, PPX_WAVES = 1 + PPX_AUDIO + 2, PPX_THREADS = PPX_WAVES * 64 };
 
 struct PpxLds {
 	float tile[4][2][PPX_CHUNK][FX_LD];         // [chunk & 3][channel][sample][instance]: loaded, audio, filter, store
-	float D[3][PPX_CHUNK][64];                  // delay time (smoothed controls[1]) per sample, [chunk % 3]
-	int far[4];                                 // [chunk & 3] 1: every tap of the chunk is far from the write cursor
+	float D[2][PPX_CHUNK][64];                  // delay time (smoothed controls[1]) per sample, [chunk & 1]
+	int far[2];                                 // 1: every tap of the chunk is far from the write cursor
 };
-
-__device__ __forceinline__ void wg_sync_lds_pp() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongArgs a) {
 	__shared__ PpxLds S;
@@ -281,24 +275,18 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	const int fch = wv - (PPX_AUDIO + 1);
 	Biquad dc = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, 0.f, 0.f };
 	if (w_filter) { dc.z0 = PPW(PP_Z + 2 * fch); dc.z1 = PPW(PP_Z + 2 * fch + 1); }
-	// ring rows of the audio waves' four samples: requested in the step before the one that uses them
-	float pl[PPX_PER][3], pr[PPX_PER][3], fl[PPX_PER], fr[PPX_PER];
-#pragma unroll
-	for (int q = 0; q < PPX_PER; q++) { pl[q][0] = pl[q][1] = pl[q][2] = pr[q][0] = pr[q][1] = pr[q][2] = 0.f; fl[q] = fr[q] = 0.f; }
-	if (tid < 4) S.far[tid] = 1;
-	__syncthreads();
 
-	for (int j = -2; j <= nchunks + 1; j++) {
+	for (int j = -1; j <= nchunks + 1; j++) {
 		// ---------------- io rows of chunk j+1 (audio waves; landed in LDS at the end of the step) ----------------
 		const int jn = j + 1;
-		const bool load_next = w_audio && jn >= 0 && jn < nchunks;
+		const bool load_next = w_audio && jn < nchunks;
 		float iov[8];
 		// (the thread index is laundered through an empty asm once per step: otherwise every per-thread address and bounds
 		//  predicate below is loop-invariant, gets hoisted out of the chunk loop, and ~100 VGPRs stay live for the whole kernel)
 		int at = tid - 64; asm volatile("" : "+v"(at));
 		const int acol = at & 31, arow = at >> 5;                                  // 512 audio threads: 16 rows x 32 samples per pass, 8 passes
 		const int ns0 = jn * PPX_CHUNK, ncl = (n - ns0 < PPX_CHUNK) ? (n - ns0) : PPX_CHUNK;
-		if (load_next && !(a.ablate & 4)) {
+		if (load_next) {
 			const char* src = (const char*)(a.io + (size_t)k0 * 2 * n + ns0);
 #pragma unroll
 			for (int i = 0; i < 8; i++) {
@@ -306,19 +294,39 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				iov[i] = (acol < ncl && k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + acol) * 4u) : 0.f;
 			}
 		}
-		// ---------------- CONTROL of chunk j+2 ----------------
-		const int jc = j + 2;
-		if (w_control && jc < nchunks && (a.ablate & 8)) { for (int u = 0; u < PPX_CHUNK; u++) S.D[jc % 3][u][lane] = 0.25f; if (lane == 0) S.far[jc & 3] = 1; }
-		else if (w_control && jc < nchunks) {
-			const int cs0 = jc * PPX_CHUNK, ccl = (n - cs0 < PPX_CHUNK) ? (n - cs0) : PPX_CHUNK;
+		// ---------------- CONTROL of chunk j+1 ----------------
+		if (w_control && jn < nchunks) {
 			float dmin = 3.0e38f, dmax = 0.f;                                         // range of the delay time over the chunk
 			lfo.increment = lfo_inc;
-			float (*D)[64] = S.D[jc % 3];
+			float (*D)[64] = S.D[jn & 1];
+			if (!any_vibrato) {
+				// No instance of the wave has vibrato (controls[2] == 0: `lfo * vibrato * 0.00005` is +-0, `controls[1] + (+-0)` is controls[1],
+				// which is already clamped): the LFO only advances its phase.  This serial chain — one wave, one dependent instruction after
+				// the other — paces the whole pipeline, so it is written without branches: ~16 operations per sample (it was ~45 with them).
+				const float k5 = (1.f - 0.999f) * c5;                              // (1.f - 0.999f) * value: the control does not change inside a block
+				const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);                      // Phase::operator+= klang.h:1518-1525
+				float pos = lfo.position;
+#pragma unroll 8
+				for (int u = 0; u < ncl; u++) {
+					sm5 = sm5 * 0.999f + k5;                                        // controls[5].smooth()  klang.h:1715
+					// (double)fabsf(d) > 0.001  <=>  fabsf(d) >= 0.001f: 0.001f is the smallest float above the double 0.001
+					const bool trig = fabsf(mdelay - sm5) >= 0.001f;
+					mdelay = trig ? sm5 : c5;
+					c1 = trig ? __builtin_amdgcn_fmed3f(sm5, a.c1_min, a.c1_max) : c1;   // controls[1].set(new_delay): the clamp is the median of (x, min, max)
+					pos = trig ? KLG_PI_F : pos;                                    // lfo.set(rate, pi)
+					sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                       // controls[1].smooth()
+					D[u][lane] = sm1;
+					const float p1 = pos + lfo_inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
+					pos = inc_ok ? p2 : pos;
+					dmin = __builtin_fminf(dmin, sm1); dmax = __builtin_fmaxf(dmax, sm1);
+				}
+				lfo.position = pos;
+			}
+			else
 #pragma unroll 4
-			for (int u = 0; u < ccl; u++) {
+			for (int u = 0; u < ncl; u++) {
 				sm5 = sm5 * 0.999f + (1.f - 0.999f) * c5;                           // controls[5].smooth()  klang.h:1715
 				const float new_delay = sm5;
-				// (double)fabsf(d) > 0.001  <=>  fabsf(d) >= 0.001f: 0.001f is the smallest float above the double 0.001
 				if (fabsf(mdelay - new_delay) >= 0.001f) {
 					mdelay = new_delay;
 					c1 = (new_delay < a.c1_min) ? a.c1_min : (a.c1_max < new_delay) ? a.c1_max : new_delay;   // controls[1].set()
@@ -327,51 +335,57 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				else mdelay = c5;
 				sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                           // controls[1].smooth()
 				const float delay = sm1;
-				if (any_vibrato) {
-					const float lfo_out = basic_sine(lfo);                          // fp64 sin only when some instance uses it
-					const float nc1 = c1 + lfo_out * vibrato * 0.00005f;
-					c1 = (nc1 < a.c1_min) ? a.c1_min : (a.c1_max < nc1) ? a.c1_max : nc1;
-				}
-				else phase_advance(lfo.position, lfo_inc);                          // lfo * 0 * 5e-5 == +-0, c1 + (+-0) == c1 (c1 >= c1_min > 0) and c1 is already clamped
+				const float lfo_out = basic_sine(lfo);                              // fp64 sin
+				const float nc1 = c1 + lfo_out * vibrato * 0.00005f;
+				c1 = (nc1 < a.c1_min) ? a.c1_min : (a.c1_max < nc1) ? a.c1_max : nc1;
 				D[u][lane] = delay;
 				dmin = fminf(dmin, delay); dmax = fmaxf(dmax, delay);
 			}
-			// x -> 0.5f * x * fs and x -> x * fs are monotonic, so the extreme delays decide for the whole chunk.  The rows of chunk c are
-			// requested during step c - 1, and what is safely in memory by then is everything written up to chunk c - 3: a wave's ring stores
-			// of chunk c - 3 (step c - 3) are older than its row requests for chunk c - 2, whose results it consumed — vmcnt returns in order —
-			// in step c - 2, before the barrier that ends that step.  A far tap therefore stays three chunks behind the write cursor.
-			const bool far = 0.5f * dmin * a.fs.f >= (float)(3 * PPX_CHUNK + 3) && dmax * a.fs.f <= (float)(SIZE - 3 * PPX_CHUNK - 4);
+			// x -> 0.5f * x * fs and x -> x * fs are monotonic, so the extreme delays decide for the whole chunk
+			const bool far = 0.5f * dmin * a.fs.f >= (float)(PPX_CHUNK + 3) && dmax * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
 			const bool all_far = __ballot(k < a.K && !far) == 0ull;                 // padding lanes (zero state, zero delay) do not veto
-			if (lane == 0) S.far[jc & 3] = all_far ? 1 : 0;
+			if (lane == 0) S.far[jn & 1] = all_far ? 1 : 0;
 		}
-		// ---------------- AUDIO of chunk j (rows requested in the previous step) ----------------
-		const bool far_j = j >= 0 && j < nchunks && S.far[j & 3] != 0, far_n = jn >= 0 && jn < nchunks && S.far[jn & 3] != 0;
+		// ---------------- AUDIO of chunk j ----------------
 		if (w_audio && j >= 0 && j < nchunks) {
 			const int s0 = j * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
 			const int pos0 = (int)(((long long)a.position + s0) % SIZE);
 			float (*T)[PPX_CHUNK][FX_LD] = S.tile[j & 3];
-			if (far_j) {
+			if (S.far[j & 1]) {
 				const int u0 = (wv - 1) * PPX_PER;
+				Tap tl[PPX_PER], tr[PPX_PER];
+				float pl[PPX_PER][3], pr[PPX_PER][3];
+#pragma unroll
+				for (int q = 0; q < PPX_PER; q++) if (u0 + q < cl) {
+					const float delay = S.D[j & 1][u0 + q][lane];
+					const int pos = wrap(pos0 + u0 + q);
+					tl[q] = delay_set(pos, SIZE, delay * a.fs.f);                   // left.set(delay * fs)
+					tr[q] = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);            // right.set(0.5f * delay * fs)
+					const int i0 = tl[q].position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
+					const int j0 = tr[q].position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
+					pl[q][0] = ring_rd(0, i0); pl[q][1] = ring_rd(0, i1); pl[q][2] = ring_rd(0, i2);
+					pr[q][0] = ring_rd(1, j0); pr[q][1] = ring_rd(1, j1); pr[q][2] = ring_rd(1, j2);
+				}
 #pragma unroll
 				for (int q = 0; q < PPX_PER; q++) if (u0 + q < cl) {
 					const int u = u0 + q, pos = wrap(pos0 + u);
 					const float in_l = T[0][u][lane], in_r = T[1][u][lane];
 					// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
-					const float r1 = pr[q][0] + fr[q] * (pr[q][1] - pr[q][0]);
-					if (!(a.ablate & 2)) ring_wr(0, pos, in_l + r1 * gain);
-					const float l1 = pl[q][0] + fl[q] * (pl[q][1] - pl[q][0]);
-					const float l2 = pl[q][1] + fl[q] * (pl[q][2] - pl[q][1]);
+					const float r1 = pr[q][0] + tr[q].fraction * (pr[q][1] - pr[q][0]);
+					ring_wr(0, pos, in_l + r1 * gain);
+					const float l1 = pl[q][0] + tl[q].fraction * (pl[q][1] - pl[q][0]);
+					const float l2 = pl[q][1] + tl[q].fraction * (pl[q][2] - pl[q][1]);
 					T[0][u][lane] = dry * in_l + l1 * (1.f - dry);
 					// dry * in.r + (1.f - dry) * ((in.r + left * gain) >> right) >> out.r;   PingPong.k:67
-					if (!(a.ablate & 2)) ring_wr(1, pos, in_r + l2 * gain);
-					const float r2 = pr[q][1] + fr[q] * (pr[q][2] - pr[q][1]);
+					ring_wr(1, pos, in_r + l2 * gain);
+					const float r2 = pr[q][1] + tr[q].fraction * (pr[q][2] - pr[q][1]);
 					T[1][u][lane] = dry * in_r + r2 * (1.f - dry);
 				}
 			}
 			else if (wv == 1) {                                                     // a near tap: the chunk is walked in order by one wave
 				Ring left = { ring0 + lane, FX_WG, SIZE }, right = { ring0 + (size_t)SIZE * FX_WG + lane, FX_WG, SIZE };
 				for (int u = 0; u < cl; u++) {
-					const float delay = S.D[j % 3][u][lane];
+					const float delay = S.D[j & 1][u][lane];
 					const int pos = wrap(pos0 + u);
 					Tap tl = delay_set(pos, SIZE, delay * a.fs.f), tr = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);
 					const float in_l = T[0][u][lane], in_r = T[1][u][lane];
@@ -385,25 +399,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				}
 			}
 		}
-		// ---------------- FETCH of chunk j+1: its ring rows are requested now and used in the next step ----------------
-		if (w_audio && far_n && !(a.ablate & 1)) {
-			const int pos0n = (int)(((long long)a.position + ns0) % SIZE);
-			const int u0 = (wv - 1) * PPX_PER;
-#pragma unroll
-			for (int q = 0; q < PPX_PER; q++) if (u0 + q < ncl) {
-				const float delay = S.D[jn % 3][u0 + q][lane];
-				const int pos = wrap(pos0n + u0 + q);
-				const Tap tl = delay_set(pos, SIZE, delay * a.fs.f);                // left.set(delay * fs)
-				const Tap tr = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);         // right.set(0.5f * delay * fs)
-				const int i0 = tl.position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
-				const int j0 = tr.position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
-				fl[q] = tl.fraction; fr[q] = tr.fraction;
-				pl[q][0] = ring_rd(0, i0); pl[q][1] = ring_rd(0, i1); pl[q][2] = ring_rd(0, i2);
-				pr[q][0] = ring_rd(1, j0); pr[q][1] = ring_rd(1, j1); pr[q][2] = ring_rd(1, j2);
-			}
-		}
 		// ---------------- store of chunk j-2 (first: its write acknowledgements have the whole step to arrive), FILTER of chunk j-1 ----------------
-		if (w_filter && j >= 2 && !(a.ablate & 4)) {
+		if (w_filter && j >= 2) {
 			const int js = j - 2, s0 = js * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
 			float (*T)[FX_LD] = S.tile[js & 3][fch];
 			int sl = lane; asm volatile("" : "+v"(sl));
@@ -415,7 +412,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
 			}
 		}
-		if (w_filter && j >= 1 && j <= nchunks && !(a.ablate & 16)) {
+		if (w_filter && j >= 1 && j <= nchunks) {
 			const int jf = j - 1, s0 = jf * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
 			float (*T)[FX_LD] = S.tile[jf & 3][fch];
 			for (int b = 0; b < PPX_CHUNK; b += 8) {                                  // eight LDS reads in flight, then the (sequential) filter
@@ -428,14 +425,11 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				for (int u = 0; u < 8; u++) T[b + u][lane] = x[u];
 			}
 		}
-		if (load_next && !(a.ablate & 4)) {
+		if (load_next) {
 #pragma unroll
 			for (int i = 0; i < 8; i++) { const int row = arow + 16 * i; S.tile[jn & 3][row & 1][acol][row >> 1] = iov[i]; }
 		}
-		// a near chunk (this one, or the next) reads rows that were written moments ago, possibly by another wave: those steps end with
-		// a full barrier (stores retired and visible); all other steps only order the LDS traffic
-		const bool near_step = (j >= 0 && j < nchunks && !far_j) || (jn >= 0 && jn < nchunks && !far_n);
-		if (near_step || (a.ablate & 32)) __syncthreads(); else wg_sync_lds_pp();
+		__syncthreads();
 	}
 	if (k < a.K) {
 		float* Wr = a.state + k;
@@ -471,6 +465,7 @@ struct ReverbArgs {
 	int epos;                   // early write cursor at block start
 	int fpos;                   // FilteredDelay write cursor at block start (advances 2 per sample)
 	float* io; int n;
+	int layout;                 // 0: rings tiled per 64 instances, position-major rows (klg_fx_reverb16); 1: every (instance, line) its own contiguous ring (klg_fx_reverb_q)
 };
 
 struct FDelay { Biquad f; float in, gain; Tap last; Ring ring; };
@@ -489,7 +484,9 @@ __device__ __forceinline__ void fd_load(FDelay& d, const ReverbArgs& a, int idx,
 	d.gain = s[(size_t)FD_GAIN * a.kpad];
 	d.f.b0 = s[(size_t)(FD_COEF + 0) * a.kpad]; d.f.b1 = s[(size_t)(FD_COEF + 1) * a.kpad]; d.f.b2 = s[(size_t)(FD_COEF + 2) * a.kpad];
 	d.f.a1 = s[(size_t)(FD_COEF + 3) * a.kpad]; d.f.a2 = s[(size_t)(FD_COEF + 4) * a.kpad];
-	d.ring.base = a.fd_rings + ((size_t)blockIdx.x * 16 + idx) * RV_FSIZE * FX_WG + threadIdx.x; d.ring.stride = FX_WG; d.ring.size = RV_FSIZE;
+	if (a.layout) { d.ring.base = a.fd_rings + ((size_t)k * 16 + idx) * RV_FSIZE; d.ring.stride = 1; }
+	else { d.ring.base = a.fd_rings + ((size_t)blockIdx.x * 16 + idx) * RV_FSIZE * FX_WG + threadIdx.x; d.ring.stride = FX_WG; }
+	d.ring.size = RV_FSIZE;
 }
 __device__ __forceinline__ void fd_store(const FDelay& d, const ReverbArgs& a, int idx, int k) {
 	float* s = a.state + (size_t)(RV_FD + idx * FD_WORDS) * a.kpad + k;
@@ -534,6 +531,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
 	const int ecount = __float_as_int(RVW(RV_ECOUNT));
 	float* etile = a.early_rings + (size_t)blockIdx.x * 2 * RV_ESIZE * FX_WG + lane;
 	Ring el = { etile, FX_WG, RV_ESIZE }, er = { etile + (size_t)RV_ESIZE * FX_WG, FX_WG, RV_ESIZE };
+	if (a.layout) { el.base = a.early_rings + (size_t)k * 2 * RV_ESIZE; er.base = el.base + RV_ESIZE; el.stride = er.stride = 1; }
 	FDelay mid0[4], mid1[4], late0[4], late1[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) { fd_load(mid0[j], a, 0 + j, k); fd_load(mid1[j], a, 4 + j, k); fd_load(late0[j], a, 8 + j, k); fd_load(late1[j], a, 12 + j, k); }
@@ -810,6 +808,196 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 		float* Wr = a.state + k;
 		Wr[(size_t)(fw + FD_Z0) * KP] = ff.z0; Wr[(size_t)(fw + FD_Z1) * KP] = ff.z1; Wr[(size_t)(fw + FD_IN) * KP] = fin;
 		Wr[(size_t)(fw + FD_LASTP) * KP] = __int_as_float((int)((foff - fring.lane4) / FROW));
+		if (efilter) {
+			Wr[(size_t)(RV_EZ + 2 * ech) * KP] = elz0; Wr[(size_t)(RV_EZ + 2 * ech + 1) * KP] = elz1;
+			Wr[(size_t)(RV_EZ + 4 + 2 * ech) * KP] = ehz0; Wr[(size_t)(RV_EZ + 4 + 2 * ech + 1) * KP] = ehz1;
+		}
+	}
+#undef RVW
+}
+
+// =================================================================================================
+// Reverb.k, one wave per FOUR instances (the production kernel)
+// =================================================================================================
+// klg_fx_reverb16 above spreads the graph of 64 instances over sixteen WAVES: the 16 FilteredDelays meet twice per sample through LDS and
+// two workgroup barriers, a 64-instance group is the unit of work, and a bank of 4096 instances is 64 workgroups on 64 of the 256 CUs —
+// 380 us per 256-sample block whatever the bank size below 16k, bound by barriers and by one CU's instruction issue.
+// This kernel spreads the graph of an instance over the LANES of a wave instead: lane = (instance i of 4) x (slot r of 16), and
+//   slot r = FilteredDelay r (LateReflections r / 4: mid[0], mid[1], late[0], late[1]; line r % 4)
+//          + the early-reflection products of channel r / 8 for taps r % 8, + 8, + 16
+//          + (r == 0 / 8) the early LPF >> HPF of the left / right channel, (r == 8 / 12) the left / right output sample.
+// The four delays of a LateReflections are the four lanes of a quad: the 4 x 4 feedback matrix and the output sum read their
+// neighbours with DPP quad_perm; the few values that cross quads (early sum -> mid input, mid sum -> late input, the output's
+// operands) travel by ds_bpermute.  A wave therefore runs its four instances with NO barrier and no LDS traffic but the io tile, a
+// bank of K instances is K / 4 independent waves (1024 for 4096 instances: every SIMD of the chip has one), and the stages still run
+// skewed (early: sample t + 2, mid: t + 1, late: t, output: t - 1) so that one iteration holds four independent dependency chains.
+// Delay lines: every (instance, line) has its own CONTIGUOUS ring (ReverbArgs::layout 1) — a lane streams through its own lines, each
+// 64-byte sector it touches is used completely (16 positions) before it moves on; rows are requested RVQ_PD samples ahead into a
+// rotating set of register slots, so a wave needs no second wave on its SIMD to hide HBM latency.
+// Arithmetic, operand order and summation order are exactly those of klg_fx_reverb / the reference (the three kernels are compared bit
+// for bit in tests/test_gpu_fx.py: KLG_FX_REVERB1=1 selects the single-lane kernel, KLG_FX_REVERB16=1 the sixteen-wave one).
+enum { RVQ_PD = 8 };
+
+__device__ __forceinline__ float lane_get(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
+template<int Q> __device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xF, 0xF, true)); }
+
+struct RvqSlot { float f1, f2, ea[3], eb[3], ef[3]; };      // rows of one sample: FilteredDelay rows last+1, last+2; per early tap the two rows and the fraction
+
+__global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
+	extern __shared__ float rvq_tile[];                       // [8][n]: row = instance * 2 + channel of the caller's block, in place
+	const int lane = threadIdx.x, inst = lane >> 4, r = lane & 15, rowbase = lane & 48;
+	const int k0 = blockIdx.x * 4, k = k0 + inst;
+	const size_t KP = a.kpad;
+	const float* W = a.state + k;
+#define RVW(w) W[(size_t)(w) * KP]
+	const int n = a.n;
+	for (int R = 0; R < 8; R++) {
+		const int ki = k0 + (R >> 1);
+		for (int c = lane; c < n; c += 64) rvq_tile[R * n + c] = (ki < a.K) ? a.io[((size_t)ki * 2 + (R & 1)) * n + c] : 0.f;
+	}
+	// ---- this lane's FilteredDelay ----
+	const int grp = r >> 2, kk = r & 3, cf = grp < 2 ? 1 : 0;               // mid[] works on sample t + 1, late[] on t
+	const int fw = RV_FD + r * FD_WORDS;
+	Biquad ff = { RVW(fw + FD_COEF + 0), RVW(fw + FD_COEF + 1), RVW(fw + FD_COEF + 2), RVW(fw + FD_COEF + 3), RVW(fw + FD_COEF + 4), RVW(fw + FD_Z0), RVW(fw + FD_Z1) };
+	float fin = RVW(fw + FD_IN);
+	const float fgain = RVW(fw + FD_GAIN), ffrac = RVW(fw + FD_LASTF);
+	const int flast = __float_as_int(RVW(fw + FD_LASTP));
+	float* const fline = a.fd_rings + ((size_t)k * 16 + r) * RV_FSIZE;     // this (instance, line)'s own ring
+	// row kk of the FDN matrix (Reverb.k:158-161): products are summed left to right
+	const float m0 = kk == 0 ? 0.f : kk == 3 ? 1.f : -1.f, m1 = kk == 1 ? 0.f : kk == 3 ? -1.f : 1.f, m2 = kk == 2 ? 0.f : kk == 1 ? -1.f : 1.f, m3 = kk == 3 ? 0.f : kk == 1 ? 1.f : -1.f;
+	// ---- this lane's share of the early reflections ----
+	const int ech = r >> 3, ej = r & 7;
+	const int ecount = __float_as_int(RVW(RV_ECOUNT));
+	float etime[3], egain[3]; bool has[3];
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+		const int d = ej + 8 * q;
+		has[q] = d < 20 && d < ecount;
+		etime[q] = has[q] ? RVW(RV_ETIMES + d) : 0.f;                           // a lane without the tap reads a valid row; its product is replaced by -0.0f
+		egain[q] = has[q] ? RVW((ech ? RV_EGR : RV_EGL) + d) : 0.f;
+	}
+	float* const eline = a.early_rings + ((size_t)k * 2 + ech) * RV_ESIZE;  // this (instance, channel)'s own early ring
+	const bool efilter = ej == 0;                                           // in >> lpf >> hpf >> delay for channel ech (Reverb.k:88)
+	const float lb0 = RVW(RV_ELPF + 0), lb1 = RVW(RV_ELPF + 1), lb2 = RVW(RV_ELPF + 2), la1 = RVW(RV_ELPF + 3), la2 = RVW(RV_ELPF + 4);
+	const float hb0 = RVW(RV_EHPF + 0), hb1 = RVW(RV_EHPF + 1), hb2 = RVW(RV_EHPF + 2), ha1 = RVW(RV_EHPF + 3), ha2 = RVW(RV_EHPF + 4);
+	float elz0 = RVW(RV_EZ + 2 * ech), elz1 = RVW(RV_EZ + 2 * ech + 1), ehz0 = RVW(RV_EZ + 4 + 2 * ech), ehz1 = RVW(RV_EZ + 4 + 2 * ech + 1);
+	const bool outlane = r == 8 || r == 12;                                 // the output sample of channel och (a lane of late[och]'s quad)
+	const int och = r == 12 ? 1 : 0;
+	const float dry = RVW(RV_CTL + 0), c1 = RVW(RV_CTL + 1), c2 = RVW(RV_CTL + 2), c3 = RVW(RV_CTL + 3), wet = RVW(RV_CTL + 4);
+	float* const in_e = rvq_tile + (inst * 2 + ech) * n;                     // the filter lane's input row
+	float* const io_o = rvq_tile + (inst * 2 + och) * n;                     // the output lane's row
+
+	// ---- row requests, RVQ_PD samples ahead ----
+	auto wrapf = [](int p) { return p >= RV_FSIZE ? p - RV_FSIZE : p; };
+	int fnext = flast + 2 * (cf - 2) + 1; if (fnext < 0) fnext += RV_FSIZE;    // row `last + 1` of the sample of iteration t = -2 (s = cf - 2)
+	int ewnext = a.epos % RV_ESIZE;                                         // early write cursor of the sample the next request is for (e = 0 first)
+	auto request = [&](RvqSlot& X) {
+		const int p1 = fnext, p2 = wrapf(p1 + 1);
+		X.f1 = fline[p1]; X.f2 = fline[p2];
+		fnext = wrapf(p2 + 1);
+		const int pos = ring_next(ewnext, RV_ESIZE);                             // cursor after Delay::input()  (Stereo::Delay::tap(float) klang.h:4668-4681)
+#pragma unroll
+		for (int q = 0; q < 3; q++) {
+			float read = (float)(pos - 1) - etime[q];
+			if (read < 0.f) read += RV_ESIZE;
+			X.ef[q] = read - floorf(read);
+			const int i0 = (int)read, j0 = (i0 == RV_ESIZE - 1) ? 0 : (i0 + 1);
+			X.ea[q] = eline[i0]; X.eb[q] = eline[j0];
+		}
+		ewnext = pos;
+	};
+	RvqSlot S[RVQ_PD];
+	float fr0;                                                              // row `last` of the FilteredDelay's current sample ( = row last + 2 of the previous one)
+	{ int p0 = flast + 2 * (cf - 2); if (p0 < 0) p0 += RV_FSIZE; fr0 = fline[p0]; }
+#pragma unroll
+	for (int u = 0; u < RVQ_PD; u++) request(S[u]);
+	wave_sync();                                                            // the io tile is in LDS
+
+	int fwpos = a.fpos % RV_FSIZE;                                          // FilteredDelay write cursor of this lane's sample (two inputs per sample)
+	int ewpos = a.epos % RV_ESIZE;
+	float r1_prev = 0.f, ssum_prev = 0.f, lr_prev = 0.f, hA = 0.f, hB = 0.f, hC = 0.f;
+
+	// One iteration: early stage of sample t + 2, mid[] of t + 1, late[] of t, output of t - 1.  G = guarded (the ramp-up / ramp-down
+	// iterations test which stages are active); the steady-state iterations run the same code without guards, and with no conditional
+	// memory operation the compiler's vmcnt bookkeeping stays exact: nothing waits for a row younger than RVQ_PD - 1 iterations.
+	auto step = [&](auto guarded, const int t, RvqSlot& X) {
+		constexpr bool G = decltype(guarded)::value;
+		const int e = t + 2, sfd = t + cf, o = t - 1;
+		const bool e_on = !G || e < n, fd_on = !G || (sfd >= 0 && sfd < n), o_on = !G || (o >= 0 && o < n);
+		// ---- the rows of this iteration's samples (requested RVQ_PD iterations ago), then the slot is requested again ----
+		float prod[3];
+#pragma unroll
+		for (int q = 0; q < 3; q++) prod[q] = has[q] ? (X.ea[q] * (1.f - X.ef[q]) + X.eb[q] * X.ef[q]) * egain[q] : -0.f;   // delay(times[d]) * gains[d]; x + (-0) == x
+		const float r0 = fr0, r1v = X.f1, r2v = X.f2;
+		const float fdt1 = r0 + ffrac * (r1v - r0), fdt2 = r1v + ffrac * (r2v - r1v);     // the two delay reads of this sample (Delay::operator>> klang.h:3491-3500)
+		request(X);
+		// ---- early stage, sample e ----
+		if (e_on && efilter) {                                              // EarlyReflections: in >> lpf >> hpf >> delay  Reverb.k:88
+			Biquad elpf = { lb0, lb1, lb2, la1, la2, elz0, elz1 }, ehpf = { hb0, hb1, hb2, ha1, ha2, ehz0, ehz1 };
+			eline[ewpos] = biquad_process(ehpf, biquad_process(elpf, in_e[e]));
+			elz0 = elpf.z0; elz1 = elpf.z1; ehz0 = ehpf.z0; ehz1 = ehpf.z1;
+		}
+		ewpos = ring_next(ewpos, RV_ESIZE);
+		// out = 0; for d < count: out += delay(times[d]) * gains[d]   Reverb.k:90-92 — the twenty products of this channel, gathered from
+		// the eight lanes that hold them, added in tap order (every lane of the channel's half-row ends up with the same sum)
+		float g[20];
+#pragma unroll
+		for (int d = 0; d < 20; d++) g[d] = lane_get(prod[d >> 3], rowbase + ech * 8 + (d & 7));
+		float r1_new = 0.f;
+#pragma unroll
+		for (int d = 0; d < 20; d++) r1_new = r1_new + g[d];
+		// ---- the FilteredDelay: mid[] on sample t + 1 (input: the early reflections of its channel), late[] on sample t (input: mid[]'s sum) ----
+		const float from_r1 = lane_get(r1_prev, rowbase + 8), from_mid = lane_get(ssum_prev, lane - 8);
+		const float lr_in = r < 4 ? r1_prev : r < 8 ? from_r1 : from_mid;
+		float ssum = 0.f;
+		if (fd_on) {
+			const float dl = biquad_process(ff, fdt1) * fgain;                // signals<4> delays = { delay[0..3] }: first process() — (in >> delay >> filter) * gain, Reverb.k:130-132
+			const float d0 = quad_bcast<0>(dl), d1 = quad_bcast<1>(dl), d2 = quad_bcast<2>(dl), d3 = quad_bcast<3>(dl);
+			const float fb = m0 * d0 + m1 * d1 + m2 * d2 + m3 * d3;           // (delays >> matrix): row kk, products summed left to right (klang.h:1462-1467)
+			const float fin_new = fb + lr_in;                                 // fb[k] = ... + in;  fb[k] >> delay[k]
+			typedef float f2s_t __attribute__((ext_vector_type(2)));
+			*reinterpret_cast<f2s_t*>(fline + fwpos) = f2s_t{ fin, fin_new };  // the two inputs of this sample (fwpos is even: both in one 8-byte store)
+			fin = fin_new;
+			const float o2 = biquad_process(ff, fdt2) * fgain;                // the `+` chain processes each FilteredDelay a second time
+			const float q0 = quad_bcast<0>(o2), q1 = quad_bcast<1>(o2), q2 = quad_bcast<2>(o2), q3 = quad_bcast<3>(o2);
+			ssum = q3 + (q2 + (q0 + q1));                                     // ((o0 + o1) + o2) + o3 as the reference's `+` chain associates
+			fwpos = (fwpos + 2 >= RV_FSIZE) ? fwpos + 2 - RV_FSIZE : fwpos + 2;
+		}
+		fr0 = r2v;                                                          // row last + 2 of this sample is row `last` of the next
+		// ---- output, sample o: Reflections::process + Reverb::process ----
+		if (o_on && outlane) {
+			const float refl = (hA * c1 + lr_prev * c2) + ssum_prev * c3;     // r1 (three iterations ago), r2 = this late[]'s input and r3 = its sum of the previous iteration
+			io_o[o] = io_o[o] * dry + refl * (och ? 0.f : wet);               // wet side is signals<2>{ wet, 0 }
+		}
+		const float r1_out = r < 12 ? lane_get(r1_new, rowbase) : r1_new;     // the output lanes' r1: channel 0 lives in lanes 0..7, channel 1 in 8..15
+		hA = hB; hB = hC; hC = r1_out;
+		r1_prev = r1_new; ssum_prev = ssum; lr_prev = lr_in;
+	};
+	const BoolTag<true> ramp; const BoolTag<false> steady;
+	// iteration t uses slot (t + 2) % RVQ_PD
+	int t = -2;
+	step(ramp, -2, S[0]); step(ramp, -1, S[1]); step(ramp, 0, S[2]);
+	t = 1;
+	for (; t + RVQ_PD - 1 <= n - 3; t += RVQ_PD) {
+		step(steady, t + 0, S[3]); step(steady, t + 1, S[4]); step(steady, t + 2, S[5]); step(steady, t + 3, S[6]);
+		step(steady, t + 4, S[7]); step(steady, t + 5, S[0]); step(steady, t + 6, S[1]); step(steady, t + 7, S[2]);
+	}
+	for (; t <= n; t++) {
+		switch ((t + 2) & (RVQ_PD - 1)) {
+		case 0: step(ramp, t, S[0]); break; case 1: step(ramp, t, S[1]); break; case 2: step(ramp, t, S[2]); break; case 3: step(ramp, t, S[3]); break;
+		case 4: step(ramp, t, S[4]); break; case 5: step(ramp, t, S[5]); break; case 6: step(ramp, t, S[6]); break; default: step(ramp, t, S[7]); break;
+		}
+	}
+	wave_sync();
+	for (int R = 0; R < 8; R++) {
+		const int ki = k0 + (R >> 1);
+		if (ki < a.K) for (int c = lane; c < n; c += 64) a.io[((size_t)ki * 2 + (R & 1)) * n + c] = rvq_tile[R * n + c];
+	}
+	// ---- write back what changed ----
+	if (k < a.K) {
+		float* Wr = a.state + k;
+		Wr[(size_t)(fw + FD_Z0) * KP] = ff.z0; Wr[(size_t)(fw + FD_Z1) * KP] = ff.z1; Wr[(size_t)(fw + FD_IN) * KP] = fin;
+		Wr[(size_t)(fw + FD_LASTP) * KP] = __int_as_float((int)(((long long)flast + 2ll * n) % RV_FSIZE));
 		if (efilter) {
 			Wr[(size_t)(RV_EZ + 2 * ech) * KP] = elz0; Wr[(size_t)(RV_EZ + 2 * ech + 1) * KP] = elz1;
 			Wr[(size_t)(RV_EZ + 4 + 2 * ech) * KP] = ehz0; Wr[(size_t)(RV_EZ + 4 + 2 * ech + 1) * KP] = ehz1;

@@ -25,6 +25,7 @@ struct klg_fx {
 	std::vector<FxUpdate> upd;
 	std::vector<RvHost> rv;
 	BiquadCoef pp_dc;
+	int rv_layout = 1;                                 // Reverb ring layout: 1 = a contiguous ring per (instance, line) [klg_fx_reverb_q], 0 = tiles of 64 instances [klg_fx_reverb16]
 	bool timing = false; std::vector<hipEvent_t> tev; int launches = 0;
 	// graph effects (klg_graph.hpp, `kind effect`): hipRTC code object, per-instance controls in HBM
 	const graphrt::Compiled* graph = nullptr;
@@ -102,7 +103,7 @@ extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate,
 		else if (c < 5) f->upd.push_back({ k, RV_CTL + c, f2i(dials[c].initial) });
 	}
 	if (pp) f->pp_dc = design_biquad(true, 50.f, 1.f, f->fs);                          // dcfilter[k].set(50, 1)  PingPong.k:39-40
-	else f->rv.resize(instances);
+	else { f->rv.resize(instances); if (const char* e = getenv("KLG_FX_REVERB16")) if (e[0] == '1') f->rv_layout = 0; }
 	return f;
 }
 
@@ -317,7 +318,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		a.dc = f->pp_dc; a.c1_min = PP_DIALS[1].min; a.c1_max = PP_DIALS[1].max;
 		{ const char* e = getenv("KLG_FX_ABLATE"); a.ablate = e ? atoi(e) : 0; }
 		static const bool single_wave = []() { const char* e = getenv("KLG_FX_PINGPONG1"); return e && e[0] == '1'; }();
-		if (single_wave) hipLaunchKernelGGL(klg_fx_pingpong, grid, block, 0, st, a);   // one wave per 64 instances (A/B reference)
+		if (single_wave || a.ablate) hipLaunchKernelGGL(klg_fx_pingpong, grid, block, 0, st, a);   // one wave per 64 instances (A/B reference, ablation)
 		else hipLaunchKernelGGL(klg_fx_pingpong_x, grid, dim3(PPX_THREADS), 0, st, a);             // control / audio / filter pipeline over eleven waves
 	}
 	else {
@@ -327,9 +328,12 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		a.fpos = (int)((2ull * f->samples) % (unsigned long long)RV_FSIZE);
 		a.io = d_io; a.n = n;
 		static const bool single_wave = []() { const char* e = getenv("KLG_FX_REVERB1"); return e && e[0] == '1'; }();
-		// klg_fx_reverb16 requests ring rows one sample ahead: safe while the shortest line (7 ms * 0.9) is a few samples long
-		if (single_wave || f->fs.f < 4000.f) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);   // one lane walks the whole graph (A/B reference)
-		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances
+		a.layout = f->rv_layout;
+		// the production kernels request ring rows ahead of their use (reverb_q: 8 samples = 16 positions; reverb16: one sample): safe while the
+		// shortest line (7 ms * 0.9) is longer than that
+		if (single_wave || f->fs.f < 16000.f) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);   // one lane walks the whole graph (A/B reference; either layout)
+		else if (f->rv_layout) hipLaunchKernelGGL(klg_fx_reverb_q, dim3((unsigned)(f->kpad / 4)), dim3(64), (size_t)8 * n * sizeof(float), st, a);   // one wave per four instances
+		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances (KLG_FX_REVERB16=1)
 	}
 	HIP_TRY(hipGetLastError());
 	if (f->timing) { HIP_TRY(hipEventRecord(f->tev[2 * f->launches + 1], st)); f->launches++; }

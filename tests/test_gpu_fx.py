@@ -90,3 +90,47 @@ def test_fx_silence_in_silence_out():
         bank.process(io)
     assert not np.any(io)
     bank.close()
+
+
+@pytest.mark.parametrize("env", [{"KLG_FX_REVERB16": "1"}, {"KLG_FX_REVERB1": "1"}])
+def test_reverb_kernels_agree_bit_for_bit(env, monkeypatch):
+    """Three kernels render Reverb.k: the production one (a wave per four instances, a contiguous ring per line), the sixteen-waves-per-64-
+    instances one (KLG_FX_REVERB16=1, position-major ring tiles) and the single-lane walk of the whole graph (KLG_FX_REVERB1=1).  70 instances
+    with different controls, a control change mid-run, odd block length: identical bits."""
+    def render():
+        s = Scenario(patch="reverb", block=200, blocks=20, instances=70, burst=2000, seed=21, dump=list(range(0, 20, 3)))
+        rng = np.random.default_rng(8)
+        for k in range(70):
+            s.control(0, k, 0, float(rng.uniform(0.0, 1.0)))
+            s.control(0, k, 2, float(rng.uniform(0.0, 1.0)))
+            s.control(0, k, 3, float(rng.uniform(0.0, 1.0)))
+            s.control(0, k, 6, float(rng.uniform(0.0, 1.0)))
+            s.control(0, k, 7, float(rng.uniform(0.1, 1.0)))
+        for k in range(0, 70, 4):
+            s.control(9, k, 5, 40.0)
+        s.sort()
+        return run_fx_scenario_gpu(s)["per_voice"]
+    ref = render()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = render()
+    assert np.abs(ref).max() > 0
+    assert np.array_equal(ref.view(np.uint32), other.view(np.uint32))
+
+
+def test_delay_lines_wrap_around(oracle_build):
+    """Run long enough for every ring to wrap (PingPong: 192000 samples; Reverb's FilteredDelay lines advance two positions per sample: 96000
+    samples, its early ring 21600): 1024-sample blocks, the oracle walks the same 200k samples."""
+    for patch, blocks, dump in (("pingpong", 196, [0, 186, 188, 190, 195]), ("reverb", 100, [0, 21, 22, 93, 94, 95, 99])):
+        s = Scenario(patch=patch, block=1024, blocks=blocks, instances=5, burst=400000, seed=3, dump=dump)
+        rng = np.random.default_rng(2)
+        for k in range(5):
+            if patch == "pingpong":
+                s.control(0, k, 1, float(rng.uniform(0.05, 0.3))); s.control(0, k, 5, float(rng.uniform(0.05, 0.3))); s.control(0, k, 0, 0.6)
+            else:
+                s.control(0, k, 2, 0.8); s.control(0, k, 3, 0.7); s.control(0, k, 6, float(rng.uniform(0.2, 1.0)))
+        ref = run_scenario_oracle(s, oracle_build)["per_voice"]
+        got = run_fx_scenario_gpu(s)["per_voice"]
+        err = rel_err(got, ref)
+        print(f"{patch} wrap: rel err {err:.3e}, bit-exact {100 * bit_exact_fraction(got, ref):.2f}%")
+        assert err <= TOL and np.abs(got).max() > 0
