@@ -1661,8 +1661,9 @@ template<class NOTE> inline void solo_pull(NOTE* note) {
 	solo_ensure(note);
 	SoloVoice* s = note->solo; const char* lo = (const char*)dynamic_cast<const void*>(note);
 	if (klg_voice_download(s->h, 0, s->words.data(), s->words.size() * 4)) { std::fprintf(stderr, "klang-mi355: klg_voice_download: %s\n", klg_last_error()); std::abort(); }
-	if ((s->words[0] & 3u) != (uint32_t)klg::ST_OFF || note->stage != NOTE::Off) s->layout.unpack((void*)lo, s->words.data());
-	else s->layout.unpack_delays((void*)lo, s->words.data());
+	bool used = (s->words[0] & 3u) != (uint32_t)klg::ST_OFF || note->stage != NOTE::Off;     // (see SynthCore::with_voice)
+	for (size_t w = 1; w < s->words.size() && !used; w++) used = s->words[w] != 0u;
+	if (used) s->layout.unpack((void*)lo, s->words.data());
 	upload_target = s->h; current_voice = 0; current_note = lo; current_layout = &s->layout;
 }
 template<class NOTE> inline void solo_push(NOTE* note) {
@@ -1783,8 +1784,12 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		ensure_gpu();
 		Slot& s = notes.items[(size_t)n];
 		if (klg_voice_download(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_download");
-		if ((words[0] & 3u) != (uint32_t)klg::ST_OFF || s.note->stage != NOTEBASE::Off) { if (s.graph) s.graph->unpack(s.note, words.data()); else s.b.unpack(s.note, words.data()); }
-		else if (s.graph) s.graph->unpack_delays(s.note, words.data());
+		// the lane's record -> the host mirror.  A note keeps ALL its member state from one note to the next in the reference (filter memories,
+		// oscillator phases, delay cursors: nothing is reset unless on() does it), so a slot that has sounded before is unpacked whatever its
+		// stage; only a slot that was never started — an all-zero record — leaves the freshly constructed object as it is
+		bool used = (words[0] & 3u) != (uint32_t)klg::ST_OFF || s.note->stage != NOTEBASE::Off;
+		for (size_t w = 1; w < words.size() && !used; w++) used = words[w] != 0u;
+		if (used) { if (s.graph) s.graph->unpack(s.note, words.data()); else s.b.unpack(s.note, words.data()); }
 		gpu::upload_target = gpu; gpu::current_voice = n; gpu::current_note = s.note; gpu::current_layout = s.graph;   // Wavetable uploads / Delay::clear() of this voice
 		event_code(s.note);
 		if (s.graph) s.graph->pack(s.note, words.data()); else s.b.pack(s.note, words.data());

@@ -473,6 +473,7 @@ struct FDelay { Biquad f; float in, gain; Tap last; Ring ring; };
 // FilteredDelay::process Reverb.k:130-132 : (in >> delay >> filter) * gain >> out
 __device__ __forceinline__ float fd_process(FDelay& d, int& wpos) {
 	d.ring.wr(wpos, d.in);
+	if (d.ring.stride == 1 && wpos < 32) d.ring.wr(wpos + RV_FSIZE, d.in);  // layout 1: the mirror tail of klg_fx_reverb_q
 	const float t = delay_process(d.ring, d.last);
 	return biquad_process(d.f, t) * d.gain;
 }
@@ -484,7 +485,7 @@ __device__ __forceinline__ void fd_load(FDelay& d, const ReverbArgs& a, int idx,
 	d.gain = s[(size_t)FD_GAIN * a.kpad];
 	d.f.b0 = s[(size_t)(FD_COEF + 0) * a.kpad]; d.f.b1 = s[(size_t)(FD_COEF + 1) * a.kpad]; d.f.b2 = s[(size_t)(FD_COEF + 2) * a.kpad];
 	d.f.a1 = s[(size_t)(FD_COEF + 3) * a.kpad]; d.f.a2 = s[(size_t)(FD_COEF + 4) * a.kpad];
-	if (a.layout) { d.ring.base = a.fd_rings + ((size_t)k * 16 + idx) * RV_FSIZE; d.ring.stride = 1; }
+	if (a.layout) { d.ring.base = a.fd_rings + ((size_t)k * 16 + idx) * (RV_FSIZE + 32); d.ring.stride = 1; }   // RV_FSTRIDE: the line + its mirror tail (klg_fx_reverb_q)
 	else { d.ring.base = a.fd_rings + ((size_t)blockIdx.x * 16 + idx) * RV_FSIZE * FX_WG + threadIdx.x; d.ring.stride = FX_WG; }
 	d.ring.size = RV_FSIZE;
 }
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
 	const int ecount = __float_as_int(RVW(RV_ECOUNT));
 	float* etile = a.early_rings + (size_t)blockIdx.x * 2 * RV_ESIZE * FX_WG + lane;
 	Ring el = { etile, FX_WG, RV_ESIZE }, er = { etile + (size_t)RV_ESIZE * FX_WG, FX_WG, RV_ESIZE };
-	if (a.layout) { el.base = a.early_rings + (size_t)k * 2 * RV_ESIZE; er.base = el.base + RV_ESIZE; el.stride = er.stride = 1; }
+	if (a.layout) { el.base = a.early_rings + (size_t)k * 2 * (RV_ESIZE + 16); er.base = el.base + (RV_ESIZE + 16); el.stride = er.stride = 1; }   // RV_ESTRIDE
 	FDelay mid0[4], mid1[4], late0[4], late1[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) { fd_load(mid0[j], a, 0 + j, k); fd_load(mid1[j], a, 4 + j, k); fd_load(late0[j], a, 8 + j, k); fd_load(late1[j], a, 12 + j, k); }
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
 			const float fl = biquad_process(ehpf[0], biquad_process(elpf[0], in_l));
 			const float fr = biquad_process(ehpf[1], biquad_process(elpf[1], in_r));
 			el.wr(epos, fl); er.wr(epos, fr);
+			if (a.layout && epos < 16) { el.wr(epos + RV_ESIZE, fl); er.wr(epos + RV_ESIZE, fr); }   // layout 1: mirror tail
 			epos = (epos + 1 == RV_ESIZE) ? 0 : epos + 1;
 			float r1l = 0.f, r1r = 0.f;
 			for (int d = 0; d < ecount; d++) {                                          // Stereo::Delay::tap(float) klang.h:4668-4681
@@ -617,7 +619,8 @@ struct Rv16Lds {
 	float CF[15][64];                           // per-instance constants only two waves per channel need: early LPF / HPF coefficients, dry/c1/c2/c3/wet
 };
 
-template<bool B> struct BoolTag { static constexpr bool value = B; };   // (std::true_type without <type_traits>: this header is also compiled by hipRTC)
+template<bool B> struct BoolTag { static constexpr bool value = B; };
+template<int I> struct IntTag { static constexpr int value = I; };   // (std::true_type without <type_traits>: this header is also compiled by hipRTC)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every ring-row
 // prefetch and ring store in flight twice per sample; the rings need no cross-wave ordering inside a block (a row written at
@@ -836,12 +839,29 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 // rotating set of register slots, so a wave needs no second wave on its SIMD to hide HBM latency.
 // Arithmetic, operand order and summation order are exactly those of klg_fx_reverb / the reference (the three kernels are compared bit
 // for bit in tests/test_gpu_fx.py: KLG_FX_REVERB1=1 selects the single-lane kernel, KLG_FX_REVERB16=1 the sixteen-wave one).
-enum { RVQ_PD = 8 };
+// Rows come in batches of RVQ_B samples per lane: 16 consecutive positions of its FilteredDelay line (four 16-byte loads) and, per early
+// tap, the 12 positions the batch's eight linear reads can touch (three 16-byte loads) — each 64-byte sector is requested once and
+// used completely, instead of once per sample per lane (which is what a per-sample 4-byte read per lane costs: the 64 lanes of a wave walk
+// 64 different lines, far more live sectors than a CU's L1 holds).  The batch after the current one is in flight while the current
+// one is computed.  So that a window never straddles the end of a ring, every line carries a MIRROR of its first positions behind
+// its last one (RV_FPAD / RV_EPAD floats, written together with the original).
+enum { RVQ_B = 8, RV_FPAD = 32, RV_EPAD = 16, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
 
 __device__ __forceinline__ float lane_get(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
 template<int Q> __device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xF, 0xF, true)); }
 
-struct RvqSlot { float f1, f2, ea[3], eb[3], ef[3]; };      // rows of one sample: FilteredDelay rows last+1, last+2; per early tap the two rows and the fraction
+// DPP row moves (a row = 16 lanes = one instance): row_shr:n — lane L takes lane L - n's value; row_shl:n — lane L takes lane L + n's
+template<int CTRL> __device__ __forceinline__ float dpp_take(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+enum { DPP_ROW_SHR1 = 0x111, DPP_ROW_SHL7 = 0x107 };
+
+typedef float rvq_f4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float rvq_f2 __attribute__((ext_vector_type(2), aligned(8)));
+struct RvqRows {
+	float F[2 * RVQ_B];                                     // FilteredDelay rows J + 1 .. J + 16 of the batch (J = 2 x its first sample; row J is carried over)
+	float E[3][RVQ_B + 2];                                  // per early tap: rows i_lo .. i_lo + 9 (i_lo = the first sample's read position)
+	int elo[3]; float efr[3];                               // ... i_lo and the first sample's fraction
+	bool regular;                                           // wave-uniform: every tap of every lane reads positions i_lo + u with that same fraction through the batch
+};
 
 __global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
 	extern __shared__ float rvq_tile[];                       // [8][n]: row = instance * 2 + channel of the caller's block, in place
@@ -862,7 +882,7 @@ __global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
 	float fin = RVW(fw + FD_IN);
 	const float fgain = RVW(fw + FD_GAIN), ffrac = RVW(fw + FD_LASTF);
 	const int flast = __float_as_int(RVW(fw + FD_LASTP));
-	float* const fline = a.fd_rings + ((size_t)k * 16 + r) * RV_FSIZE;     // this (instance, line)'s own ring
+	float* const fline = a.fd_rings + ((size_t)k * 16 + r) * RV_FSTRIDE;    // this (instance, line)'s own ring (+ mirror tail)
 	// row kk of the FDN matrix (Reverb.k:158-161): products are summed left to right
 	const float m0 = kk == 0 ? 0.f : kk == 3 ? 1.f : -1.f, m1 = kk == 1 ? 0.f : kk == 3 ? -1.f : 1.f, m2 = kk == 2 ? 0.f : kk == 1 ? -1.f : 1.f, m3 = kk == 3 ? 0.f : kk == 1 ? 1.f : -1.f;
 	// ---- this lane's share of the early reflections ----
@@ -873,10 +893,10 @@ __global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
 	for (int q = 0; q < 3; q++) {
 		const int d = ej + 8 * q;
 		has[q] = d < 20 && d < ecount;
-		etime[q] = has[q] ? RVW(RV_ETIMES + d) : 0.f;                           // a lane without the tap reads a valid row; its product is replaced by -0.0f
+		etime[q] = has[q] ? RVW(RV_ETIMES + d) : 0.f;                           // a lane without the tap reads valid rows; its product is replaced by -0.0f
 		egain[q] = has[q] ? RVW((ech ? RV_EGR : RV_EGL) + d) : 0.f;
 	}
-	float* const eline = a.early_rings + ((size_t)k * 2 + ech) * RV_ESIZE;  // this (instance, channel)'s own early ring
+	float* const eline = a.early_rings + ((size_t)k * 2 + ech) * RV_ESTRIDE;  // this (instance, channel)'s own early ring (+ mirror tail)
 	const bool efilter = ej == 0;                                           // in >> lpf >> hpf >> delay for channel ech (Reverb.k:88)
 	const float lb0 = RVW(RV_ELPF + 0), lb1 = RVW(RV_ELPF + 1), lb2 = RVW(RV_ELPF + 2), la1 = RVW(RV_ELPF + 3), la2 = RVW(RV_ELPF + 4);
 	const float hb0 = RVW(RV_EHPF + 0), hb1 = RVW(RV_EHPF + 1), hb2 = RVW(RV_EHPF + 2), ha1 = RVW(RV_EHPF + 3), ha2 = RVW(RV_EHPF + 4);
@@ -886,107 +906,216 @@ __global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
 	const float dry = RVW(RV_CTL + 0), c1 = RVW(RV_CTL + 1), c2 = RVW(RV_CTL + 2), c3 = RVW(RV_CTL + 3), wet = RVW(RV_CTL + 4);
 	float* const in_e = rvq_tile + (inst * 2 + ech) * n;                     // the filter lane's input row
 	float* const io_o = rvq_tile + (inst * 2 + och) * n;                     // the output lane's row
+	// the early sum of channel c ends in lane c * 8 + 3 of the row: mid[0] (lanes 0..3) and the left output lane (8) want channel 0's
+	const int r1_src = rowbase + ((r < 4 || r == 8) ? 3 : 11);
+	// wave-uniform cursors of the block: every instance has processed the same number of samples
+	const int epos0 = __builtin_amdgcn_readfirstlane(a.epos % RV_ESIZE), fpos0 = __builtin_amdgcn_readfirstlane(a.fpos % RV_FSIZE);
 
-	// ---- row requests, RVQ_PD samples ahead ----
-	auto wrapf = [](int p) { return p >= RV_FSIZE ? p - RV_FSIZE : p; };
-	int fnext = flast + 2 * (cf - 2) + 1; if (fnext < 0) fnext += RV_FSIZE;    // row `last + 1` of the sample of iteration t = -2 (s = cf - 2)
-	int ewnext = a.epos % RV_ESIZE;                                         // early write cursor of the sample the next request is for (e = 0 first)
-	auto request = [&](RvqSlot& X) {
-		const int p1 = fnext, p2 = wrapf(p1 + 1);
-		X.f1 = fline[p1]; X.f2 = fline[p2];
-		fnext = wrapf(p2 + 1);
-		const int pos = ring_next(ewnext, RV_ESIZE);                             // cursor after Delay::input()  (Stereo::Delay::tap(float) klang.h:4668-4681)
+	// ---- row requests, one batch ahead ----
+	// Stereo::Delay::tap(float) klang.h:4668-4681 for the sample whose early write cursor is `wpos`: the read position (integer part, fraction);
+	// `bin` = the exponents of the float before / after the wrap correction and whether it was applied (two samples with equal `bin` whose
+	// reads are k apart have integer parts exactly k apart and the same fraction: adding k inside one binade is exact)
+	auto tap_pos = [&](int wpos, float time, float& frac, unsigned& bin) __attribute__((always_inline)) {
+		const int pos = (wpos + 1 == RV_ESIZE) ? 0 : wpos + 1;                   // cursor after Delay::input()
+		float read = (float)(pos - 1) - time;
+		const unsigned pre = __float_as_uint(read) >> 23;
+		const bool neg = read < 0.f;
+		if (neg) read += RV_ESIZE;
+		frac = read - floorf(read);
+		bin = (pre << 10) | ((__float_as_uint(read) >> 23) << 1) | (neg ? 1u : 0u);
+		return (int)read;
+	};
+	int fnext = flast + 2 * (cf - 2) + 1; if (fnext < 0) fnext += RV_FSIZE;    // row J + 1 of the first batch (its first sample: s = cf - 2, iteration t = -2)
+	int ewb = epos0;                                                        // early write cursor of the first sample of the batch being requested (uniform)
+	auto request = [&](RvqRows& X) __attribute__((always_inline)) {
+#pragma unroll
+		for (int v = 0; v < 2 * RVQ_B / 4; v++) {
+			const rvq_f4 x = *reinterpret_cast<const rvq_f4*>(fline + fnext + 4 * v);   // (never past the mirror tail: fnext < RV_FSIZE, 16 rows)
+			X.F[4 * v] = x.x; X.F[4 * v + 1] = x.y; X.F[4 * v + 2] = x.z; X.F[4 * v + 3] = x.w;
+		}
+		fnext += 2 * RVQ_B; if (fnext >= RV_FSIZE) fnext -= RV_FSIZE;
+		const int ewl = (ewb + RVQ_B - 1 >= RV_ESIZE) ? ewb + RVQ_B - 1 - RV_ESIZE : ewb + RVQ_B - 1;   // ... of its last sample
+		bool reg = true;
 #pragma unroll
 		for (int q = 0; q < 3; q++) {
-			float read = (float)(pos - 1) - etime[q];
-			if (read < 0.f) read += RV_ESIZE;
-			X.ef[q] = read - floorf(read);
-			const int i0 = (int)read, j0 = (i0 == RV_ESIZE - 1) ? 0 : (i0 + 1);
-			X.ea[q] = eline[i0]; X.eb[q] = eline[j0];
+			float fr, fr7; unsigned b0, b7;
+			const int i0 = tap_pos(ewb, etime[q], fr, b0), i7 = tap_pos(ewl, etime[q], fr7, b7);
+			X.elo[q] = i0; X.efr[q] = fr;
+			reg = reg && b0 == b7 && i7 == i0 + (RVQ_B - 1) && __float_as_uint(fr) == __float_as_uint(fr7);
+			// rows i0 .. i0 + 9: every register a load writes is used (a dead component would be handed to a temporary right away — and the
+			// wave would wait for the load to land before it may overwrite it)
+#pragma unroll
+			for (int v = 0; v < 2; v++) {
+				const rvq_f4 x = *reinterpret_cast<const rvq_f4*>(eline + i0 + 4 * v);
+				X.E[q][4 * v] = x.x; X.E[q][4 * v + 1] = x.y; X.E[q][4 * v + 2] = x.z; X.E[q][4 * v + 3] = x.w;
+			}
+			{ typedef float rvq_f2u __attribute__((ext_vector_type(2), aligned(4))); const rvq_f2u x = *reinterpret_cast<const rvq_f2u*>(eline + i0 + 8); X.E[q][8] = x.x; X.E[q][9] = x.y; }
 		}
-		ewnext = pos;
+		X.regular = __ballot(!reg) == 0ull;
+		ewb += RVQ_B; if (ewb >= RV_ESIZE) ewb -= RV_ESIZE;
 	};
-	RvqSlot S[RVQ_PD];
+	RvqRows A, Bn;
 	float fr0;                                                              // row `last` of the FilteredDelay's current sample ( = row last + 2 of the previous one)
 	{ int p0 = flast + 2 * (cf - 2); if (p0 < 0) p0 += RV_FSIZE; fr0 = fline[p0]; }
-#pragma unroll
-	for (int u = 0; u < RVQ_PD; u++) request(S[u]);
+	request(A);
 	wave_sync();                                                            // the io tile is in LDS
 
-	int fwpos = a.fpos % RV_FSIZE;                                          // FilteredDelay write cursor of this lane's sample (two inputs per sample)
-	int ewpos = a.epos % RV_ESIZE;
 	float r1_prev = 0.f, ssum_prev = 0.f, lr_prev = 0.f, hA = 0.f, hB = 0.f, hC = 0.f;
+	float x_in = in_e[0], x_out = 0.f;                                      // the filter lane's next input sample / the output lane's next dry sample (read from the LDS tile one iteration ahead)
+	// What a steady batch WRITES is collected in registers and stored once per batch — 64 bytes per FilteredDelay line, 32 per early line:
+	// whole sectors instead of eight 8-byte (4-byte) pieces of one, each of which the memory system would otherwise merge on its own.
+	float Wf[2 * RVQ_B], We[RVQ_B];
+#pragma unroll
+	for (int j = 0; j < 2 * RVQ_B; j++) Wf[j] = 0.f;
+#pragma unroll
+	for (int j = 0; j < RVQ_B; j++) We[j] = 0.f;
 
-	// One iteration: early stage of sample t + 2, mid[] of t + 1, late[] of t, output of t - 1.  G = guarded (the ramp-up / ramp-down
-	// iterations test which stages are active); the steady-state iterations run the same code without guards, and with no conditional
-	// memory operation the compiler's vmcnt bookkeeping stays exact: nothing waits for a row younger than RVQ_PD - 1 iterations.
-	auto step = [&](auto guarded, const int t, RvqSlot& X) {
+	// One iteration: early stage of sample t + 2, mid[] of t + 1, late[] of t, output of t - 1; u = its place in the batch (compile-time: every
+	// row is a named register).  G = guarded (the batches at the edges of the block test which stages are active).
+	// A wave is alone on its SIMD at the bank sizes that matter, so nothing hides a wait: every cross-lane / LDS value is requested at the
+	// top of the iteration before the one that uses it, or at the top of this one with a long computation in between.
+	auto step = [&](auto guarded, auto place, const int t, const RvqRows& X) __attribute__((always_inline)) {
 		constexpr bool G = decltype(guarded)::value;
+		constexpr int u = decltype(place)::value;
 		const int e = t + 2, sfd = t + cf, o = t - 1;
 		const bool e_on = !G || e < n, fd_on = !G || (sfd >= 0 && sfd < n), o_on = !G || (o >= 0 && o < n);
-		// ---- the rows of this iteration's samples (requested RVQ_PD iterations ago), then the slot is requested again ----
+		const int ewpos = (epos0 + e >= RV_ESIZE) ? epos0 + e - RV_ESIZE : epos0 + e;                  // uniform: the early write cursor of sample e
+		// ---- requests whose answers are needed later in this iteration / in the next one ----
+		const float from_mid = lane_get(ssum_prev, lane - 8);                 // late[]'s input: mid[]'s sum of the previous iteration
+		const float x_in_now = x_in, x_out_now = x_out;
+		x_in = in_e[(!G || e + 1 < n) ? e + 1 : 0];                             // next iteration's samples
+		x_out = io_o[(!G || (o + 1 >= 0 && o + 1 < n)) ? o + 1 : 0];
+		// ---- early products of sample e: delay(times[d]) * gains[d] ----
 		float prod[3];
+		if (X.regular) {
 #pragma unroll
-		for (int q = 0; q < 3; q++) prod[q] = has[q] ? (X.ea[q] * (1.f - X.ef[q]) + X.eb[q] * X.ef[q]) * egain[q] : -0.f;   // delay(times[d]) * gains[d]; x + (-0) == x
-		const float r0 = fr0, r1v = X.f1, r2v = X.f2;
-		const float fdt1 = r0 + ffrac * (r1v - r0), fdt2 = r1v + ffrac * (r2v - r1v);     // the two delay reads of this sample (Delay::operator>> klang.h:3491-3500)
-		request(X);
-		// ---- early stage, sample e ----
-		if (e_on && efilter) {                                              // EarlyReflections: in >> lpf >> hpf >> delay  Reverb.k:88
-			Biquad elpf = { lb0, lb1, lb2, la1, la2, elz0, elz1 }, ehpf = { hb0, hb1, hb2, ha1, ha2, ehz0, ehz1 };
-			eline[ewpos] = biquad_process(ehpf, biquad_process(elpf, in_e[e]));
-			elz0 = elpf.z0; elz1 = elpf.z1; ehz0 = ehpf.z0; ehz1 = ehpf.z1;
+			for (int q = 0; q < 3; q++) prod[q] = has[q] ? (X.E[q][u] * (1.f - X.efr[q]) + X.E[q][u + 1] * X.efr[q]) * egain[q] : -0.f;
 		}
-		ewpos = ring_next(ewpos, RV_ESIZE);
-		// out = 0; for d < count: out += delay(times[d]) * gains[d]   Reverb.k:90-92 — the twenty products of this channel, gathered from
-		// the eight lanes that hold them, added in tap order (every lane of the channel's half-row ends up with the same sum)
-		float g[20];
+		else {
 #pragma unroll
-		for (int d = 0; d < 20; d++) g[d] = lane_get(prod[d >> 3], rowbase + ech * 8 + (d & 7));
-		float r1_new = 0.f;
+			for (int q = 0; q < 3; q++) {
+				float fr; unsigned bin; const int i0 = tap_pos(ewpos, etime[q], fr, bin);
+				int idx = i0 - X.elo[q]; if (idx < 0) idx += RV_ESIZE;          // the mirror tail continues the ring past its end
+				// the read position advances by one per sample up to float rounding: idx is u - 1, u or u + 1
+				const float em = X.E[q][u > 0 ? u - 1 : 0], e0 = X.E[q][u], e1 = X.E[q][u + 1], e2 = X.E[q][u + 2];   // (named values, then selects: a select of array ELEMENTS would become a run-time index)
+				const float ea = idx < u ? em : idx > u ? e1 : e0;
+				const float eb = idx < u ? e0 : idx > u ? e2 : e1;
+				prod[q] = has[q] ? (ea * (1.f - fr) + eb * fr) * egain[q] : -0.f;    // x + (-0) == x: a tap this instance does not have leaves the sum as it is
+			}
+		}
+		// out = 0; for d < count: out += delay(times[d]) * gains[d]   Reverb.k:90-92.  The twenty products of a channel sit in eight lanes (tap
+		// d in lane d % 8, slot d / 8); the running sum walks through them in tap order — one v_add_f32 with a DPP source per tap: the lane that
+		// holds tap d takes the sum from the lane that holds tap d - 1 — and ends in lane c * 8 + 3 (tap 19).  Other lanes compute don't-cares.
+		float acc = 0.f + prod[0];
 #pragma unroll
-		for (int d = 0; d < 20; d++) r1_new = r1_new + g[d];
+		for (int d = 1; d < 8; d++) acc = dpp_take<DPP_ROW_SHR1>(acc) + prod[0];
+		acc = dpp_take<DPP_ROW_SHL7>(acc) + prod[1];
+#pragma unroll
+		for (int d = 9; d < 16; d++) acc = dpp_take<DPP_ROW_SHR1>(acc) + prod[1];
+		acc = dpp_take<DPP_ROW_SHL7>(acc) + prod[2];
+#pragma unroll
+		for (int d = 17; d < 20; d++) acc = dpp_take<DPP_ROW_SHR1>(acc) + prod[2];
+		const float r1_new = lane_get(acc, r1_src);                             // the early sum of the channel THIS lane wants (mid[] input next iteration; output in three)
 		// ---- the FilteredDelay: mid[] on sample t + 1 (input: the early reflections of its channel), late[] on sample t (input: mid[]'s sum) ----
-		const float from_r1 = lane_get(r1_prev, rowbase + 8), from_mid = lane_get(ssum_prev, lane - 8);
-		const float lr_in = r < 4 ? r1_prev : r < 8 ? from_r1 : from_mid;
-		float ssum = 0.f;
+		float r0 = fr0; if constexpr (u > 0) r0 = X.F[2 * u - 1];
+		const float r1v = X.F[2 * u], r2v = X.F[2 * u + 1];
+		const float fdt1 = r0 + ffrac * (r1v - r0), fdt2 = r1v + ffrac * (r2v - r1v);     // the two delay reads of this sample (Delay::operator>> klang.h:3491-3500)
+		float ssum = 0.f, lr_in = 0.f;
 		if (fd_on) {
 			const float dl = biquad_process(ff, fdt1) * fgain;                // signals<4> delays = { delay[0..3] }: first process() — (in >> delay >> filter) * gain, Reverb.k:130-132
 			const float d0 = quad_bcast<0>(dl), d1 = quad_bcast<1>(dl), d2 = quad_bcast<2>(dl), d3 = quad_bcast<3>(dl);
 			const float fb = m0 * d0 + m1 * d1 + m2 * d2 + m3 * d3;           // (delays >> matrix): row kk, products summed left to right (klang.h:1462-1467)
+			lr_in = r < 8 ? r1_prev : from_mid;
 			const float fin_new = fb + lr_in;                                 // fb[k] = ... + in;  fb[k] >> delay[k]
-			typedef float f2s_t __attribute__((ext_vector_type(2)));
-			*reinterpret_cast<f2s_t*>(fline + fwpos) = f2s_t{ fin, fin_new };  // the two inputs of this sample (fwpos is even: both in one 8-byte store)
+			const int fbase = (fpos0 + 2 * t >= RV_FSIZE) ? fpos0 + 2 * t - RV_FSIZE : fpos0 + 2 * t;   // uniform: late[]'s write cursor (mid[] is one sample = 2 ahead)
+			int fwpos = fbase + 2 * cf; if (fwpos >= RV_FSIZE) fwpos -= RV_FSIZE; if (fwpos < 0) fwpos += RV_FSIZE;
+			if constexpr (G) {
+				const rvq_f2 pair = { fin, fin_new };                         // the two inputs of this sample (fwpos is even: both in one 8-byte store)
+				*reinterpret_cast<rvq_f2*>(fline + fwpos) = pair;
+				if (fbase < RV_FPAD || fbase + 2 >= RV_FSIZE || fbase < 0) { if (fwpos < RV_FPAD) *reinterpret_cast<rvq_f2*>(fline + fwpos + RV_FSIZE) = pair; }   // mirror (the outer test is uniform and almost never true)
+			}
+			else {
+				Wf[2 * u] = fin; Wf[2 * u + 1] = fin_new;                     // stored with the rest of the batch (flush below)
+				if constexpr (u == RVQ_B - 1) {
+					int w0 = fwpos - 2 * (RVQ_B - 1);                         // the batch's first position (this lane's)
+					const bool straight = fbase - 2 * (RVQ_B - 1) >= RV_FPAD && fbase + 4 < RV_FSIZE;   // uniform: no wrap and no mirror inside the batch, for mid[] and late[] lanes alike
+					if (straight) {
+#pragma unroll
+						for (int v = 0; v < 2 * RVQ_B / 4; v++) { const rvq_f4 x = { Wf[4 * v], Wf[4 * v + 1], Wf[4 * v + 2], Wf[4 * v + 3] }; *reinterpret_cast<rvq_f4*>(fline + w0 + 4 * v) = x; }
+					}
+					else {
+						if (w0 < 0) w0 += RV_FSIZE;
+#pragma unroll
+						for (int j = 0; j < RVQ_B; j++) {
+							int w = w0 + 2 * j; if (w >= RV_FSIZE) w -= RV_FSIZE;
+							const rvq_f2 pair = { Wf[2 * j], Wf[2 * j + 1] };
+							*reinterpret_cast<rvq_f2*>(fline + w) = pair;
+							if (w < RV_FPAD) *reinterpret_cast<rvq_f2*>(fline + w + RV_FSIZE) = pair;
+						}
+					}
+				}
+			}
 			fin = fin_new;
 			const float o2 = biquad_process(ff, fdt2) * fgain;                // the `+` chain processes each FilteredDelay a second time
 			const float q0 = quad_bcast<0>(o2), q1 = quad_bcast<1>(o2), q2 = quad_bcast<2>(o2), q3 = quad_bcast<3>(o2);
 			ssum = q3 + (q2 + (q0 + q1));                                     // ((o0 + o1) + o2) + o3 as the reference's `+` chain associates
-			fwpos = (fwpos + 2 >= RV_FSIZE) ? fwpos + 2 - RV_FSIZE : fwpos + 2;
 		}
-		fr0 = r2v;                                                          // row last + 2 of this sample is row `last` of the next
+		if constexpr (u == RVQ_B - 1) fr0 = r2v;                             // row last + 2 of the batch's last sample is row `last` of the next batch's first
+		// ---- early stage, sample e: in >> lpf >> hpf >> delay  Reverb.k:88 ----
+		if (e_on) {
+			if (efilter) {
+				Biquad elpf = { lb0, lb1, lb2, la1, la2, elz0, elz1 }, ehpf = { hb0, hb1, hb2, ha1, ha2, ehz0, ehz1 };
+				const float y = biquad_process(ehpf, biquad_process(elpf, x_in_now));
+				elz0 = elpf.z0; elz1 = elpf.z1; ehz0 = ehpf.z0; ehz1 = ehpf.z1;
+				if constexpr (G) {
+					eline[ewpos] = y;
+					if (ewpos < RV_EPAD) eline[ewpos + RV_ESIZE] = y;         // mirror (a uniform test)
+				}
+				else {
+					We[u] = y;
+					if constexpr (u == RVQ_B - 1) {
+						const int w0 = ewpos - (RVQ_B - 1);
+						if (w0 >= RV_EPAD && ewpos < RV_ESIZE) {                  // uniform: the batch neither wraps nor touches the mirrored head
+#pragma unroll
+							for (int v = 0; v < RVQ_B / 4; v++) { const rvq_f4 x = { We[4 * v], We[4 * v + 1], We[4 * v + 2], We[4 * v + 3] }; *reinterpret_cast<rvq_f4*>(eline + w0 + 4 * v) = x; }
+						}
+						else {
+#pragma unroll
+							for (int j = 0; j < RVQ_B; j++) {
+								int w = w0 + j; if (w < 0) w += RV_ESIZE;
+								eline[w] = We[j];
+								if (w < RV_EPAD) eline[w + RV_ESIZE] = We[j];
+							}
+						}
+					}
+				}
+			}
+		}
 		// ---- output, sample o: Reflections::process + Reverb::process ----
-		if (o_on && outlane) {
-			const float refl = (hA * c1 + lr_prev * c2) + ssum_prev * c3;     // r1 (three iterations ago), r2 = this late[]'s input and r3 = its sum of the previous iteration
-			io_o[o] = io_o[o] * dry + refl * (och ? 0.f : wet);               // wet side is signals<2>{ wet, 0 }
+		if (o_on) {
+			if (outlane) {
+				const float refl = (hA * c1 + lr_prev * c2) + ssum_prev * c3;     // r1 (three iterations ago), r2 = this late[]'s input and r3 = its sum of the previous iteration
+				io_o[o] = x_out_now * dry + refl * (och ? 0.f : wet);             // wet side is signals<2>{ wet, 0 }
+			}
 		}
-		const float r1_out = r < 12 ? lane_get(r1_new, rowbase) : r1_new;     // the output lanes' r1: channel 0 lives in lanes 0..7, channel 1 in 8..15
-		hA = hB; hB = hC; hC = r1_out;
+		hA = hB; hB = hC; hC = r1_new;
 		r1_prev = r1_new; ssum_prev = ssum; lr_prev = lr_in;
 	};
+	auto batch = [&](auto guarded, const int t0, const RvqRows& X) __attribute__((always_inline)) {
+		step(guarded, IntTag<0>(), t0 + 0, X); step(guarded, IntTag<1>(), t0 + 1, X); step(guarded, IntTag<2>(), t0 + 2, X); step(guarded, IntTag<3>(), t0 + 3, X);
+		step(guarded, IntTag<4>(), t0 + 4, X); step(guarded, IntTag<5>(), t0 + 5, X); step(guarded, IntTag<6>(), t0 + 6, X); step(guarded, IntTag<7>(), t0 + 7, X);
+	};
 	const BoolTag<true> ramp; const BoolTag<false> steady;
-	// iteration t uses slot (t + 2) % RVQ_PD
-	int t = -2;
-	step(ramp, -2, S[0]); step(ramp, -1, S[1]); step(ramp, 0, S[2]);
-	t = 1;
-	for (; t + RVQ_PD - 1 <= n - 3; t += RVQ_PD) {
-		step(steady, t + 0, S[3]); step(steady, t + 1, S[4]); step(steady, t + 2, S[5]); step(steady, t + 3, S[6]);
-		step(steady, t + 4, S[7]); step(steady, t + 5, S[0]); step(steady, t + 6, S[1]); step(steady, t + 7, S[2]);
+	// iterations t = -2 .. n in batches of eight; the rows of a batch are requested while the batch before it is computed
+	int t0 = -2;
+	request(Bn); __builtin_amdgcn_sched_barrier(0); batch(ramp, t0, A); t0 += RVQ_B;     // t = -2 .. 5  (the barrier: the rows are REQUESTED here, a batch before they are used)
+	for (; t0 + 2 * RVQ_B - 1 <= n - 3; t0 += 2 * RVQ_B) {                       // two steady batches per turn (t >= 1 and t + 2 < n throughout): A and Bn swap roles
+		request(A); __builtin_amdgcn_sched_barrier(0); batch(steady, t0, Bn);
+		request(Bn); __builtin_amdgcn_sched_barrier(0); batch(steady, t0 + RVQ_B, A);
 	}
-	for (; t <= n; t++) {
-		switch ((t + 2) & (RVQ_PD - 1)) {
-		case 0: step(ramp, t, S[0]); break; case 1: step(ramp, t, S[1]); break; case 2: step(ramp, t, S[2]); break; case 3: step(ramp, t, S[3]); break;
-		case 4: step(ramp, t, S[4]); break; case 5: step(ramp, t, S[5]); break; case 6: step(ramp, t, S[6]); break; default: step(ramp, t, S[7]); break;
-		}
+	for (; t0 <= n; t0 += 2 * RVQ_B) {                                          // the last batches, guarded (the roles of A and Bn stay compile-time: no array ever lives in memory)
+		request(A); __builtin_amdgcn_sched_barrier(0); batch(ramp, t0, Bn);
+		if (t0 + RVQ_B <= n) { request(Bn); __builtin_amdgcn_sched_barrier(0); batch(ramp, t0 + RVQ_B, A); }
 	}
 	wave_sync();
 	for (int R = 0; R < 8; R++) {

@@ -84,8 +84,8 @@ extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate,
 	const bool pp = patch_id == KLG_PATCH_PINGPONG;
 	f->nctl = pp ? 6 : 10;
 	f->words = pp ? (int)PP_WORDS : (int)RV_WORDS;
-	const size_t ring1 = pp ? (size_t)2 * 192000 * f->kpad : (size_t)2 * RV_ESIZE * f->kpad;
-	const size_t ring2 = pp ? 0 : (size_t)16 * RV_FSIZE * f->kpad;
+	const size_t ring1 = pp ? (size_t)2 * 192000 * f->kpad : (size_t)2 * RV_ESTRIDE * f->kpad;     // (Reverb: lines + the mirror tails of klg_fx_reverb_q)
+	const size_t ring2 = pp ? 0 : (size_t)16 * RV_FSTRIDE * f->kpad;
 	bool ok = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) == hipSuccess;
 	ok = ok && hipMalloc(&f->d_state, (size_t)f->words * f->kpad * 4) == hipSuccess;
 	ok = ok && hipMalloc(&f->d_rings, ring1 * 4) == hipSuccess;

@@ -99,7 +99,7 @@ __device__ __forceinline__ f2 sub2a_x2_osc_filter(Sub2aX2& L) {
 // and the voice either holds at the ADSR sustain point or is already Off.  Nothing inside a block can end that
 // state (only host events between blocks do), so a wave whose voices are all quiet runs the short loop below.
 __device__ __forceinline__ i2 sub2a_x2_quiet(const Sub2aX2& L) {
-	return ~L.active & (((L.estage == (int)ENV_SUSTAIN) & (L.point == 2)) | (L.estage == (int)ENV_OFF));
+	return (L.r_out == L.r_target) & (((L.estage == (int)ENV_SUSTAIN) & (L.point == 2)) | (L.estage == (int)ENV_OFF));
 }
 __device__ __forceinline__ f2 sub2a_x2_sample_quiet(Sub2aX2& L) {
 	const f2 y = sub2a_x2_osc_filter(L);
@@ -107,19 +107,30 @@ __device__ __forceinline__ f2 sub2a_x2_sample_quiet(Sub2aX2& L) {
 	return y * L.r_out;                                               // out *= adsr++ (ramp idle: value unchanged)
 }
 
+// one sample of a ramping voice WITHOUT the segment-end test (see the render loop)
+__device__ __forceinline__ f2 sub2a_x2_step(Sub2aX2& L) {
+	const f2 y = sub2a_x2_osc_filter(L);
+	const f2 env = L.r_out;
+	const f2 nxt = L.r_out + L.srate;
+	L.r_out.x = __builtin_amdgcn_fmed3f(env.x, nxt.x, L.r_target.x);
+	L.r_out.y = __builtin_amdgcn_fmed3f(env.y, nxt.y, L.r_target.y);
+	L.time += L.tinc;
+	return y * env;                                                    // out *= adsr++
+}
 __device__ __forceinline__ f2 sub2a_x2_sample(Sub2aX2& L, const SampleRate& fs) {
 	const f2 y = sub2a_x2_osc_filter(L);
 	// ---- ADSR: Envelope::process fast path  klang.h:4018-4051 (see env_process) ----
+	// Linear's `active` is exactly (out != target): setTarget sets it so (klang.h:3756), the ramp clears it when it clamps to the target
+	// (3795-3805), setValue makes both equal.  So the flag needs no register: the step is the median of (out, out +- rate, target) for
+	// every voice — an idle ramp has out == target and the median of (x, anything, x) is x — and "idle" is one compare.
 	const f2 env = L.r_out;
 	const f2 nxt = L.r_out + L.srate;
-	f2 stepped;
-	stepped.x = __builtin_amdgcn_fmed3f(L.r_out.x, nxt.x, L.r_target.x);
-	stepped.y = __builtin_amdgcn_fmed3f(L.r_out.y, nxt.y, L.r_target.y);
-	L.r_out = L.active ? stepped : L.r_out;
-	L.active = L.active & (stepped != L.r_target);
+	L.r_out.x = __builtin_amdgcn_fmed3f(env.x, nxt.x, L.r_target.x);
+	L.r_out.y = __builtin_amdgcn_fmed3f(env.y, nxt.y, L.r_target.y);
 	L.time += L.tinc;
-	const i2 rare = ~L.active & L.special;
+	const i2 rare = (L.r_out == L.r_target) & L.special;              // an idle ramp that means work: a segment end, or the end of the release
 	if (__ballot((rare.x | rare.y) != 0) != 0ull) {
+		L.active = L.r_out != L.r_target;
 		if (rare.x) sub2a_x2_rare<0>(L, fs);
 		if (rare.y) sub2a_x2_rare<1>(L, fs);
 		sub2a_x2_derive(L, fs);
@@ -128,7 +139,8 @@ __device__ __forceinline__ f2 sub2a_x2_sample(Sub2aX2& L, const SampleRate& fs) 
 }
 
 __device__ __forceinline__ void sub2a_x2_end(const Sub2aX2& L, u2& flags, u2& offset, u2& z0, u2& z1, u2& r_out, u2& r_target, u2& r_rate, u2& time) {
-	const u2 eb = __builtin_convertvector(L.estage, u2) | (__builtin_convertvector(L.point, u2) << 2) | ((__builtin_convertvector(L.active, u2) & 1u) << 5);
+	const i2 active = L.r_out != L.r_target;                                 // Linear::active (see sub2a_x2_sample)
+	const u2 eb = __builtin_convertvector(L.estage, u2) | (__builtin_convertvector(L.point, u2) << 2) | ((__builtin_convertvector(active, u2) & 1u) << 5);
 	flags = __builtin_convertvector(L.stage, u2) | (eb << 2);                 // osm state bits stay 0 (Down)
 	offset = L.offset; z0 = as_u2(L.z0); z1 = as_u2(L.z1);
 	r_out = as_u2(L.r_out); r_target = as_u2(L.r_target); r_rate = as_u2(L.r_rate); time = as_u2(L.time);
@@ -183,7 +195,27 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
 				else for (int s = 0; s < cl; s++) tile[s * X2_LD + lane] = sub2a_x2_sample_quiet(L);
 			}
 			else {
-				for (int s = 0; s < cl; s++) tile[s * X2_LD + lane] = sub2a_x2_sample(L, a.fs);
+				// Some voice of the wave is ramping.  The ramp step itself is three operations for everybody (sub2a_x2_step); what costs is the
+				// segment-end code: kept INSIDE the sample loop it makes every envelope register a phi of "came round the loop" and "came out of
+				// the rare path" — some twenty register moves per sample.  So the sample loop only DETECTS a segment end and leaves; the rare
+				// code runs between two runs of the loop.
+				int s = 0;
+				while (s < cl) {
+					i2 rare = (i2)0;
+#pragma unroll 4
+					for (; s < cl;) {
+						tile[s * X2_LD + lane] = sub2a_x2_step(L);
+						s++;
+						rare = (L.r_out == L.r_target) & L.special;               // an idle ramp that means work: a segment end, or the end of the release
+						if (__ballot((rare.x | rare.y) != 0) != 0ull) break;
+					}
+					if (__ballot((rare.x | rare.y) != 0) != 0ull) {
+						L.active = L.r_out != L.r_target;
+						if (rare.x) sub2a_x2_rare<0>(L, a.fs);
+						if (rare.y) sub2a_x2_rare<1>(L, a.fs);
+						sub2a_x2_derive(L, a.fs);
+					}
+				}
 			}
 			wave_sync();
 			if (PER_VOICE) {

@@ -71,6 +71,16 @@ def scenarios():
     out["own_pluck"] = poly("own_pluck", 48, [0, 1, 7, 8, 47], off_base=10, notes=16, ctl_events=[(12, 0, 0.98), (20, 1, 0.6)])
     out["own_sample"] = poly("own_sample", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
     out["own_wavetable"] = poly("own_wavetable", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
+    # pluck_keep.k: no Delay::clear() in on() — slots are started again after their note ran out (release 45 ms) and stolen while sounding
+    # (6 slots, 30 note-ons): every restart finds the line as the previous note left it
+    s = Scenario(patch="own_pluck_keep", block=256, blocks=72, synths=1, notes=6, dump=[0, 1, 13, 14, 40, 71])
+    for k in range(30):
+        p = int(rng.integers(40, 80)); b0 = 2 * k + (k % 3)
+        s.on(b0, 0, p, float(rng.uniform(0.4, 1.0)))
+        if k % 4 != 3:
+            s.off(b0 + 3 + (k % 5), 0, p, 0.0)
+    s.sort()
+    out["own_pluck_keep"] = s
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],
