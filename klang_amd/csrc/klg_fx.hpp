@@ -845,6 +845,8 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 // 64 different lines, far more live sectors than a CU's L1 holds).  The batch after the current one is in flight while the current
 // one is computed.  So that a window never straddles the end of a ring, every line carries a MIRROR of its first positions behind
 // its last one (RV_FPAD / RV_EPAD floats, written together with the original).
+enum { RVQ_MAX_INSTANCES = 8192 };       // banks up to this size run klg_fx_reverb_q (measured: profiles/r02_fx_sizes.md)
+enum { RVQ_WG = 64 };
 enum { RVQ_B = 8, RV_FPAD = 32, RV_EPAD = 16, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
 
 __device__ __forceinline__ float lane_get(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
@@ -863,10 +865,13 @@ struct RvqRows {
 	bool regular;                                           // wave-uniform: every tap of every lane reads positions i_lo + u with that same fraction through the batch
 };
 
-__global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
-	extern __shared__ float rvq_tile[];                       // [8][n]: row = instance * 2 + channel of the caller's block, in place
-	const int lane = threadIdx.x, inst = lane >> 4, r = lane & 15, rowbase = lane & 48;
-	const int k0 = blockIdx.x * 4, k = k0 + inst;
+// Launch shape: a workgroup is RVQ_WG / 64 independent waves that share nothing (no barrier, a private slice of the LDS tile each).
+__global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
+	extern __shared__ float rvq_tiles[];                      // per wave [9][n]: rows 0..7 = instance * 2 + channel of the caller's block, in place; row 8: where the lanes that are no output lane "write"
+	const int lane = threadIdx.x & 63, inst = lane >> 4, r = lane & 15, rowbase = lane & 48;
+	float* const rvq_tile = rvq_tiles + (threadIdx.x >> 6) * 9 * a.n;
+	const int k0 = (blockIdx.x * (RVQ_WG / 64) + (threadIdx.x >> 6)) * 4, k = k0 + inst;
+	if (k0 >= (int)a.kpad) return;
 	const size_t KP = a.kpad;
 	const float* W = a.state + k;
 #define RVW(w) W[(size_t)(w) * KP]
@@ -904,8 +909,10 @@ __global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
 	const bool outlane = r == 8 || r == 12;                                 // the output sample of channel och (a lane of late[och]'s quad)
 	const int och = r == 12 ? 1 : 0;
 	const float dry = RVW(RV_CTL + 0), c1 = RVW(RV_CTL + 1), c2 = RVW(RV_CTL + 2), c3 = RVW(RV_CTL + 3), wet = RVW(RV_CTL + 4);
+	const float wet_o = och ? 0.f : wet;
 	float* const in_e = rvq_tile + (inst * 2 + ech) * n;                     // the filter lane's input row
 	float* const io_o = rvq_tile + (inst * 2 + och) * n;                     // the output lane's row
+	float* const io_w = outlane ? io_o : rvq_tile + 8 * n;                  // ... and where a lane stores "its" output sample: an unconditional ds_write, no exec-mask branch in the sample loop
 	// the early sum of channel c ends in lane c * 8 + 3 of the row: mid[0] (lanes 0..3) and the left output lane (8) want channel 0's
 	const int r1_src = rowbase + ((r < 4 || r == 8) ? 3 : 11);
 	// wave-uniform cursors of the block: every instance has processed the same number of samples
@@ -974,8 +981,12 @@ __global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
 	// row is a named register).  G = guarded (the batches at the edges of the block test which stages are active).
 	// A wave is alone on its SIMD at the bank sizes that matter, so nothing hides a wait: every cross-lane / LDS value is requested at the
 	// top of the iteration before the one that uses it, or at the top of this one with a long computation in between.
-	auto step = [&](auto guarded, auto place, const int t, const RvqRows& X) __attribute__((always_inline)) {
+	// A steady batch is ONE basic block of eight samples (no lane-predicated branch, no per-sample uniform one: what only some lanes need is
+	// computed by all of them — a masked-off lane costs the same issue slot — and `regular` is tested once per batch), so the scheduler
+	// can fill the wait states of the DPP sum chain and the latency of one sample's LDS / bpermute answers with the arithmetic of its neighbours.
+	auto step = [&](auto guarded, auto reg_tag, auto place, const int t, const RvqRows& X, const float (&omf)[3]) __attribute__((always_inline)) {
 		constexpr bool G = decltype(guarded)::value;
+		constexpr bool REG = decltype(reg_tag)::value;
 		constexpr int u = decltype(place)::value;
 		const int e = t + 2, sfd = t + cf, o = t - 1;
 		const bool e_on = !G || e < n, fd_on = !G || (sfd >= 0 && sfd < n), o_on = !G || (o >= 0 && o < n);
@@ -986,10 +997,11 @@ __global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
 		x_in = in_e[(!G || e + 1 < n) ? e + 1 : 0];                             // next iteration's samples
 		x_out = io_o[(!G || (o + 1 >= 0 && o + 1 < n)) ? o + 1 : 0];
 		// ---- early products of sample e: delay(times[d]) * gains[d] ----
+		// (a tap this instance does not have: gain 0, the product is +-0 and leaves the sum — never -0 after `0.f +` — as it is)
 		float prod[3];
-		if (X.regular) {
+		if constexpr (REG) {
 #pragma unroll
-			for (int q = 0; q < 3; q++) prod[q] = has[q] ? (X.E[q][u] * (1.f - X.efr[q]) + X.E[q][u + 1] * X.efr[q]) * egain[q] : -0.f;
+			for (int q = 0; q < 3; q++) prod[q] = (X.E[q][u] * omf[q] + X.E[q][u + 1] * X.efr[q]) * egain[q];
 		}
 		else {
 #pragma unroll
@@ -1000,7 +1012,7 @@ __global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
 				const float em = X.E[q][u > 0 ? u - 1 : 0], e0 = X.E[q][u], e1 = X.E[q][u + 1], e2 = X.E[q][u + 2];   // (named values, then selects: a select of array ELEMENTS would become a run-time index)
 				const float ea = idx < u ? em : idx > u ? e1 : e0;
 				const float eb = idx < u ? e0 : idx > u ? e2 : e1;
-				prod[q] = has[q] ? (ea * (1.f - fr) + eb * fr) * egain[q] : -0.f;    // x + (-0) == x: a tap this instance does not have leaves the sum as it is
+				prod[q] = (ea * (1.f - fr) + eb * fr) * egain[q];
 			}
 		}
 		// out = 0; for d < count: out += delay(times[d]) * gains[d]   Reverb.k:90-92.  The twenty products of a channel sit in eight lanes (tap
@@ -1062,18 +1074,20 @@ __global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
 		}
 		if constexpr (u == RVQ_B - 1) fr0 = r2v;                             // row last + 2 of the batch's last sample is row `last` of the next batch's first
 		// ---- early stage, sample e: in >> lpf >> hpf >> delay  Reverb.k:88 ----
-		if (e_on) {
-			if (efilter) {
+		if (e_on) {                                                           // (every lane of the channel runs the filter on the same input: eight copies of one state)
+			{
 				Biquad elpf = { lb0, lb1, lb2, la1, la2, elz0, elz1 }, ehpf = { hb0, hb1, hb2, ha1, ha2, ehz0, ehz1 };
 				const float y = biquad_process(ehpf, biquad_process(elpf, x_in_now));
 				elz0 = elpf.z0; elz1 = elpf.z1; ehz0 = ehpf.z0; ehz1 = ehpf.z1;
 				if constexpr (G) {
-					eline[ewpos] = y;
-					if (ewpos < RV_EPAD) eline[ewpos + RV_ESIZE] = y;         // mirror (a uniform test)
+					if (efilter) {
+						eline[ewpos] = y;
+						if (ewpos < RV_EPAD) eline[ewpos + RV_ESIZE] = y;     // mirror (a uniform test)
+					}
 				}
 				else {
 					We[u] = y;
-					if constexpr (u == RVQ_B - 1) {
+					if constexpr (u == RVQ_B - 1) if (efilter) {
 						const int w0 = ewpos - (RVQ_B - 1);
 						if (w0 >= RV_EPAD && ewpos < RV_ESIZE) {                  // uniform: the batch neither wraps nor touches the mirrored head
 #pragma unroll
@@ -1093,17 +1107,21 @@ __global__ __launch_bounds__(64) void klg_fx_reverb_q(const ReverbArgs a) {
 		}
 		// ---- output, sample o: Reflections::process + Reverb::process ----
 		if (o_on) {
-			if (outlane) {
-				const float refl = (hA * c1 + lr_prev * c2) + ssum_prev * c3;     // r1 (three iterations ago), r2 = this late[]'s input and r3 = its sum of the previous iteration
-				io_o[o] = x_out_now * dry + refl * (och ? 0.f : wet);             // wet side is signals<2>{ wet, 0 }
-			}
+			const float refl = (hA * c1 + lr_prev * c2) + ssum_prev * c3;         // r1 (three iterations ago), r2 = this late[]'s input and r3 = its sum of the previous iteration
+			io_w[o] = x_out_now * dry + refl * wet_o;                             // wet side is signals<2>{ wet, 0 }
 		}
 		hA = hB; hB = hC; hC = r1_new;
 		r1_prev = r1_new; ssum_prev = ssum; lr_prev = lr_in;
 	};
+	auto batch_as = [&](auto guarded, auto reg, const int t0, const RvqRows& X) __attribute__((always_inline)) {
+		const float omf[3] = { 1.f - X.efr[0], 1.f - X.efr[1], 1.f - X.efr[2] };
+		step(guarded, reg, IntTag<0>(), t0 + 0, X, omf); step(guarded, reg, IntTag<1>(), t0 + 1, X, omf); step(guarded, reg, IntTag<2>(), t0 + 2, X, omf); step(guarded, reg, IntTag<3>(), t0 + 3, X, omf);
+		step(guarded, reg, IntTag<4>(), t0 + 4, X, omf); step(guarded, reg, IntTag<5>(), t0 + 5, X, omf); step(guarded, reg, IntTag<6>(), t0 + 6, X, omf); step(guarded, reg, IntTag<7>(), t0 + 7, X, omf);
+	};
 	auto batch = [&](auto guarded, const int t0, const RvqRows& X) __attribute__((always_inline)) {
-		step(guarded, IntTag<0>(), t0 + 0, X); step(guarded, IntTag<1>(), t0 + 1, X); step(guarded, IntTag<2>(), t0 + 2, X); step(guarded, IntTag<3>(), t0 + 3, X);
-		step(guarded, IntTag<4>(), t0 + 4, X); step(guarded, IntTag<5>(), t0 + 5, X); step(guarded, IntTag<6>(), t0 + 6, X); step(guarded, IntTag<7>(), t0 + 7, X);
+		constexpr bool G = decltype(guarded)::value;
+		if constexpr (G) batch_as(guarded, BoolTag<false>(), t0, X);             // the edges of the block take the general form (a position per tap and sample)
+		else { if (X.regular) batch_as(guarded, BoolTag<true>(), t0, X); else batch_as(guarded, BoolTag<false>(), t0, X); }
 	};
 	const BoolTag<true> ramp; const BoolTag<false> steady;
 	// iterations t = -2 .. n in batches of eight; the rows of a batch are requested while the batch before it is computed

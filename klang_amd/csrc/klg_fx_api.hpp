@@ -84,6 +84,13 @@ extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate,
 	const bool pp = patch_id == KLG_PATCH_PINGPONG;
 	f->nctl = pp ? 6 : 10;
 	f->words = pp ? (int)PP_WORDS : (int)RV_WORDS;
+	if (!pp) {
+		// Which Reverb kernel serves this bank: klg_fx_reverb_q is one independent wave per four instances — it fills the chip from 1024
+		// instances up and is the faster one while a SIMD holds one or two of its waves; klg_fx_reverb16 (sixteen waves per 64 instances,
+		// LDS + barriers) hides its latencies behind other workgroups and wins once every CU holds several.  KLG_FX_REVERB16=0/1 overrides.
+		f->rv_layout = instances <= RVQ_MAX_INSTANCES ? 1 : 0;
+		if (const char* e = getenv("KLG_FX_REVERB16")) { if (e[0] == '1') f->rv_layout = 0; else if (e[0] == '0') f->rv_layout = 1; }
+	}
 	const size_t ring1 = pp ? (size_t)2 * 192000 * f->kpad : (size_t)2 * RV_ESTRIDE * f->kpad;     // (Reverb: lines + the mirror tails of klg_fx_reverb_q)
 	const size_t ring2 = pp ? 0 : (size_t)16 * RV_FSTRIDE * f->kpad;
 	bool ok = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) == hipSuccess;
@@ -103,7 +110,7 @@ extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate,
 		else if (c < 5) f->upd.push_back({ k, RV_CTL + c, f2i(dials[c].initial) });
 	}
 	if (pp) f->pp_dc = design_biquad(true, 50.f, 1.f, f->fs);                          // dcfilter[k].set(50, 1)  PingPong.k:39-40
-	else { f->rv.resize(instances); if (const char* e = getenv("KLG_FX_REVERB16")) if (e[0] == '1') f->rv_layout = 0; }
+	else f->rv.resize(instances);
 	return f;
 }
 
@@ -332,7 +339,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		// the production kernels request ring rows ahead of their use (reverb_q: 8 samples = 16 positions; reverb16: one sample): safe while the
 		// shortest line (7 ms * 0.9) is longer than that
 		if (single_wave || f->fs.f < 16000.f) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);   // one lane walks the whole graph (A/B reference; either layout)
-		else if (f->rv_layout) hipLaunchKernelGGL(klg_fx_reverb_q, dim3((unsigned)(f->kpad / 4)), dim3(64), (size_t)8 * n * sizeof(float), st, a);   // one wave per four instances
+		else if (f->rv_layout) hipLaunchKernelGGL(klg_fx_reverb_q, dim3((unsigned)((f->kpad + 4 * (RVQ_WG / 64) - 1) / (4 * (RVQ_WG / 64)))), dim3(RVQ_WG), (size_t)(RVQ_WG / 64) * 9 * n * sizeof(float), st, a);   // one wave per four instances, four waves (a CU) per workgroup
 		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances (KLG_FX_REVERB16=1)
 	}
 	HIP_TRY(hipGetLastError());
