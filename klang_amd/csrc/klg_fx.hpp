@@ -825,61 +825,165 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 // klg_fx_reverb16 above spreads the graph of 64 instances over sixteen WAVES: the 16 FilteredDelays meet twice per sample through LDS and
 // two workgroup barriers, a 64-instance group is the unit of work, and a bank of 4096 instances is 64 workgroups on 64 of the 256 CUs —
 // 380 us per 256-sample block whatever the bank size below 16k, bound by barriers and by one CU's instruction issue.
-// This kernel spreads the graph of an instance over the LANES of a wave instead: lane = (instance i of 4) x (slot r of 16), and
-//   slot r = FilteredDelay r (LateReflections r / 4: mid[0], mid[1], late[0], late[1]; line r % 4)
-//          + the early-reflection products of channel r / 8 for taps r % 8, + 8, + 16
-//          + (r == 0 / 8) the early LPF >> HPF of the left / right channel, (r == 8 / 12) the left / right output sample.
-// The four delays of a LateReflections are the four lanes of a quad: the 4 x 4 feedback matrix and the output sum read their
-// neighbours with DPP quad_perm; the few values that cross quads (early sum -> mid input, mid sum -> late input, the output's
-// operands) travel by ds_bpermute.  A wave therefore runs its four instances with NO barrier and no LDS traffic but the io tile, a
-// bank of K instances is K / 4 independent waves (1024 for 4096 instances: every SIMD of the chip has one), and the stages still run
-// skewed (early: sample t + 2, mid: t + 1, late: t, output: t - 1) so that one iteration holds four independent dependency chains.
-// Delay lines: every (instance, line) has its own CONTIGUOUS ring (ReverbArgs::layout 1) — a lane streams through its own lines, each
-// 64-byte sector it touches is used completely (16 positions) before it moves on; rows are requested RVQ_PD samples ahead into a
-// rotating set of register slots, so a wave needs no second wave on its SIMD to hide HBM latency.
+// This kernel gives a wave four instances and runs a block in two phases:
+//
+//   1. The early reflections of the WHOLE block, lane = sample.  `out = sum delay(times[d]) * gains[d]` (Reverb.k:90-92) reads the early
+//      line `times[d]` samples back — further than a block is long (checked by the host: the shortest tap must be > n + 2 samples, else
+//      the single-lane kernel runs) — so none of the block's taps sees a sample the block itself writes: the sum of sample e depends on
+//      history only, and the 64 lanes of the wave compute 64 consecutive samples at once.  A lane walks the taps in the reference's order
+//      (same products, same left-to-right sum); the 64 lanes read 64 consecutive ring positions per tap: every cache line the load touches
+//      is used completely by that one instruction.  (The previous form of this kernel — tap = lane, a running DPP sum per sample — fetched
+//      a 128-byte line per tap for every eight samples: 3.3 x the ring bytes at 4096 instances, measured with FETCH_SIZE; that, not
+//      instruction issue, bounded it.)  The sums wait in LDS.
+//   2. The recursive part, lane = (instance i of 4) x (slot r of 16), one sample per iteration:
+//        slot r = FilteredDelay r (LateReflections r / 4: mid[0], mid[1], late[0], late[1]; line r % 4)
+//               + (r == 0 / 8) the early LPF >> HPF of the left / right channel (its output goes to the early line for LATER blocks),
+//               + (r == 8 / 12) the left / right output sample.
+//      The four delays of a LateReflections are the four lanes of a quad: the 4 x 4 feedback matrix and the output sum read their
+//      neighbours with DPP quad_perm; mid[]'s sum reaches late[] by ds_bpermute.  The stages run skewed (early filter: sample t + 2,
+//      mid: t + 1, late: t, output: t - 1) so that one iteration holds independent dependency chains; no barrier anywhere.
+// Delay lines: every (instance, line) has its own CONTIGUOUS ring (ReverbArgs::layout 1).  FilteredDelay rows come in batches of RVQ_B
+// samples per lane (16 consecutive positions: four 16-byte loads), requested a batch ahead; what a batch writes is collected in
+// registers and stored as whole 64-byte pieces.  So that a window never straddles the end of a ring, every line carries a MIRROR of
+// its first positions behind its last one (RV_FPAD / RV_EPAD floats, written together with the original).
 // Arithmetic, operand order and summation order are exactly those of klg_fx_reverb / the reference (the three kernels are compared bit
 // for bit in tests/test_gpu_fx.py: KLG_FX_REVERB1=1 selects the single-lane kernel, KLG_FX_REVERB16=1 the sixteen-wave one).
-// Rows come in batches of RVQ_B samples per lane: 16 consecutive positions of its FilteredDelay line (four 16-byte loads) and, per early
-// tap, the 12 positions the batch's eight linear reads can touch (three 16-byte loads) — each 64-byte sector is requested once and
-// used completely, instead of once per sample per lane (which is what a per-sample 4-byte read per lane costs: the 64 lanes of a wave walk
-// 64 different lines, far more live sectors than a CU's L1 holds).  The batch after the current one is in flight while the current
-// one is computed.  So that a window never straddles the end of a ring, every line carries a MIRROR of its first positions behind
-// its last one (RV_FPAD / RV_EPAD floats, written together with the original).
 enum { RVQ_MAX_INSTANCES = 8192 };       // banks up to this size run klg_fx_reverb_q (measured: profiles/r02_fx_sizes.md)
 enum { RVQ_WG = 64 };
 enum { RVQ_B = 8, RV_FPAD = 32, RV_EPAD = 16, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
+enum { RVQ_TILE_ROWS = 17 };             // LDS per wave, rows of n floats: 0..7 the caller's block (instance * 2 + channel), 8 scrap, 9..16 the early sums
 
 __device__ __forceinline__ float lane_get(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
 template<int Q> __device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xF, 0xF, true)); }
 
-// DPP row moves (a row = 16 lanes = one instance): row_shr:n — lane L takes lane L - n's value; row_shl:n — lane L takes lane L + n's
-template<int CTRL> __device__ __forceinline__ float dpp_take(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
-enum { DPP_ROW_SHR1 = 0x111, DPP_ROW_SHL7 = 0x107 };
-
 typedef float rvq_f4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float rvq_f2 __attribute__((ext_vector_type(2), aligned(8)));
+typedef float rvq_v4 __attribute__((ext_vector_type(4)));
+// FilteredDelay rows J + 1 .. J + 16 of a batch (J = 2 x its first sample; row J is carried over).  They are requested two batches ahead —
+// into ACCUMULATION registers, by hand: a load the compiler knows about lands in registers it manages, and under this kernel's
+// register pressure it splits such a live range with copies wherever it likes — also between the request and the wait, where they copy
+// what has not arrived.  a0 .. a47 (three sets of 16) are outside its allocation (it uses no AGPR here: checked in the build remarks);
+// rvq_await waits and moves a set into ordinary registers, which the compiler sees defined only there.
+// vmcnt: loads retire in order, so "at most N outstanding" with N = the loads requested since (two later batches = 8) is exact for the
+// rows whatever the ring stores in between do.  "memory" clobbers pin every other memory instruction on its side of both statements.
 struct RvqRows {
-	float F[2 * RVQ_B];                                     // FilteredDelay rows J + 1 .. J + 16 of the batch (J = 2 x its first sample; row J is carried over)
-	float E[3][RVQ_B + 2];                                  // per early tap: rows i_lo .. i_lo + 9 (i_lo = the first sample's read position)
-	int elo[3]; float efr[3];                               // ... i_lo and the first sample's fraction
-	bool regular;                                           // wave-uniform: every tap of every lane reads positions i_lo + u with that same fraction through the batch
+	float f[2 * RVQ_B];
+	template<int I> __device__ __forceinline__ float F() const { return f[I]; }
 };
+template<int SET> __device__ __forceinline__ void rvq_request(const float* p) {
+	if constexpr (SET == 0) {
+		asm volatile("global_load_dwordx4 a[0:3], %0, off\n\tglobal_load_dwordx4 a[4:7], %0, off offset:16\n\tglobal_load_dwordx4 a[8:11], %0, off offset:32\n\tglobal_load_dwordx4 a[12:15], %0, off offset:48" :: "v"(p) : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+	}
+	else if constexpr (SET == 1) {
+		asm volatile("global_load_dwordx4 a[16:19], %0, off\n\tglobal_load_dwordx4 a[20:23], %0, off offset:16\n\tglobal_load_dwordx4 a[24:27], %0, off offset:32\n\tglobal_load_dwordx4 a[28:31], %0, off offset:48" :: "v"(p) : "memory", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+	}
+	else {
+		asm volatile("global_load_dwordx4 a[32:35], %0, off\n\tglobal_load_dwordx4 a[36:39], %0, off offset:16\n\tglobal_load_dwordx4 a[40:43], %0, off offset:32\n\tglobal_load_dwordx4 a[44:47], %0, off offset:48" :: "v"(p) : "memory", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+	}
+}
+template<int SET, int N> __device__ __forceinline__ void rvq_await(RvqRows& X) {
+	if constexpr (SET == 0) {
+		asm volatile("s_waitcnt vmcnt(%16)\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\tv_accvgpr_read_b32 %8, a8\n\tv_accvgpr_read_b32 %9, a9\n\tv_accvgpr_read_b32 %10, a10\n\tv_accvgpr_read_b32 %11, a11\n\tv_accvgpr_read_b32 %12, a12\n\tv_accvgpr_read_b32 %13, a13\n\tv_accvgpr_read_b32 %14, a14\n\tv_accvgpr_read_b32 %15, a15" : "=v"(X.f[0]), "=v"(X.f[1]), "=v"(X.f[2]), "=v"(X.f[3]), "=v"(X.f[4]), "=v"(X.f[5]), "=v"(X.f[6]), "=v"(X.f[7]), "=v"(X.f[8]), "=v"(X.f[9]), "=v"(X.f[10]), "=v"(X.f[11]), "=v"(X.f[12]), "=v"(X.f[13]), "=v"(X.f[14]), "=v"(X.f[15]) : "n"(N) : "memory");
+	}
+	else if constexpr (SET == 1) {
+		asm volatile("s_waitcnt vmcnt(%16)\n\tv_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19\n\tv_accvgpr_read_b32 %4, a20\n\tv_accvgpr_read_b32 %5, a21\n\tv_accvgpr_read_b32 %6, a22\n\tv_accvgpr_read_b32 %7, a23\n\tv_accvgpr_read_b32 %8, a24\n\tv_accvgpr_read_b32 %9, a25\n\tv_accvgpr_read_b32 %10, a26\n\tv_accvgpr_read_b32 %11, a27\n\tv_accvgpr_read_b32 %12, a28\n\tv_accvgpr_read_b32 %13, a29\n\tv_accvgpr_read_b32 %14, a30\n\tv_accvgpr_read_b32 %15, a31" : "=v"(X.f[0]), "=v"(X.f[1]), "=v"(X.f[2]), "=v"(X.f[3]), "=v"(X.f[4]), "=v"(X.f[5]), "=v"(X.f[6]), "=v"(X.f[7]), "=v"(X.f[8]), "=v"(X.f[9]), "=v"(X.f[10]), "=v"(X.f[11]), "=v"(X.f[12]), "=v"(X.f[13]), "=v"(X.f[14]), "=v"(X.f[15]) : "n"(N) : "memory");
+	}
+	else {
+		asm volatile("s_waitcnt vmcnt(%16)\n\tv_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35\n\tv_accvgpr_read_b32 %4, a36\n\tv_accvgpr_read_b32 %5, a37\n\tv_accvgpr_read_b32 %6, a38\n\tv_accvgpr_read_b32 %7, a39\n\tv_accvgpr_read_b32 %8, a40\n\tv_accvgpr_read_b32 %9, a41\n\tv_accvgpr_read_b32 %10, a42\n\tv_accvgpr_read_b32 %11, a43\n\tv_accvgpr_read_b32 %12, a44\n\tv_accvgpr_read_b32 %13, a45\n\tv_accvgpr_read_b32 %14, a46\n\tv_accvgpr_read_b32 %15, a47" : "=v"(X.f[0]), "=v"(X.f[1]), "=v"(X.f[2]), "=v"(X.f[3]), "=v"(X.f[4]), "=v"(X.f[5]), "=v"(X.f[6]), "=v"(X.f[7]), "=v"(X.f[8]), "=v"(X.f[9]), "=v"(X.f[10]), "=v"(X.f[11]), "=v"(X.f[12]), "=v"(X.f[13]), "=v"(X.f[14]), "=v"(X.f[15]) : "n"(N) : "memory");
+	}
+}
 
 // Launch shape: a workgroup is RVQ_WG / 64 independent waves that share nothing (no barrier, a private slice of the LDS tile each).
 __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
-	extern __shared__ float rvq_tiles[];                      // per wave [9][n]: rows 0..7 = instance * 2 + channel of the caller's block, in place; row 8: where the lanes that are no output lane "write"
-	const int lane = threadIdx.x & 63, inst = lane >> 4, r = lane & 15, rowbase = lane & 48;
-	float* const rvq_tile = rvq_tiles + (threadIdx.x >> 6) * 9 * a.n;
+	extern __shared__ float rvq_tiles[];
+	const int lane = threadIdx.x & 63, inst = lane >> 4, r = lane & 15;
+	float* const rvq_tile = rvq_tiles + (threadIdx.x >> 6) * RVQ_TILE_ROWS * a.n;
 	const int k0 = (blockIdx.x * (RVQ_WG / 64) + (threadIdx.x >> 6)) * 4, k = k0 + inst;
 	if (k0 >= (int)a.kpad) return;
 	const size_t KP = a.kpad;
 	const float* W = a.state + k;
 #define RVW(w) W[(size_t)(w) * KP]
 	const int n = a.n;
-	for (int R = 0; R < 8; R++) {
+	// the caller's block of these four instances is one contiguous span of 8 n floats: 16-byte pieces, all requested before the first lands
+	const bool whole = k0 + 4 <= a.K && (n & 3) == 0;                       // (else: the bank's last wave, or an odd block length — element by element)
+	if (whole) {
+		const rvq_v4* src = reinterpret_cast<const rvq_v4*>(a.io + (size_t)k0 * 2 * n);
+		rvq_v4* dst = reinterpret_cast<rvq_v4*>(rvq_tile);
+		for (int c0 = 0; c0 < 2 * n; c0 += 8 * 64) {
+			rvq_v4 x[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) { const int c = c0 + j * 64 + lane; x[j] = src[c < 2 * n ? c : 0]; }
+#pragma unroll
+			for (int j = 0; j < 8; j++) { const int c = c0 + j * 64 + lane; if (c < 2 * n) dst[c] = x[j]; }
+		}
+	}
+	else for (int R = 0; R < 8; R++) {
 		const int ki = k0 + (R >> 1);
 		for (int c = lane; c < n; c += 64) rvq_tile[R * n + c] = (ki < a.K) ? a.io[((size_t)ki * 2 + (R & 1)) * n + c] : 0.f;
 	}
+	// wave-uniform cursors of the block: every instance has processed the same number of samples
+	const int epos0 = __builtin_amdgcn_readfirstlane(a.epos % RV_ESIZE), fpos0 = __builtin_amdgcn_readfirstlane(a.fpos % RV_FSIZE);
+
+	// =========== phase 1: the early sums of the block, lane = sample ===========
+	// EarlyReflections::process Reverb.k:90-92 with Stereo::Delay::tap(float) klang.h:4668-4681 (both channels read at one cursor).
+	float* const r1_rows = rvq_tile + 9 * n;
+	{
+		typedef float rvq_f2u __attribute__((ext_vector_type(2), aligned(4)));
+		struct Taps { rvq_f2u l[20], r[20]; float fr[20]; };                    // per tap: positions i0, i0 + 1 of both lines (one 8-byte load each) and the fraction
+		const int chunks = (n + 63) >> 6, groups = 4 * chunks;                  // a group = 64 consecutive samples of one instance
+		// the taps' words (time, left gain, right gain; count) of the four instances wait in lanes: tap d of instance i in lane 16 i + d (d < 16)
+		// of the first register, lane 16 i + d - 16 of the second; v_readlane hands one to the whole wave (no memory in the loop)
+		const int pd = lane & 15;
+		const float* Wp = a.state + (k0 + inst);
+		const float tA = Wp[(size_t)(RV_ETIMES + pd) * KP], glA = Wp[(size_t)(RV_EGL + pd) * KP], grA = Wp[(size_t)(RV_EGR + pd) * KP];
+		const float tB = Wp[(size_t)(RV_ETIMES + 16 + (pd & 3)) * KP], glB = Wp[(size_t)(RV_EGL + 16 + (pd & 3)) * KP], grB = Wp[(size_t)(RV_EGR + 16 + (pd & 3)) * KP];
+		const int cntv = __float_as_int(Wp[(size_t)RV_ECOUNT * KP]);
+		auto word = [&](float A, float B, int i, int d) __attribute__((always_inline)) {
+			return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d < 16 ? A : B), 16 * i + (d & 15)));
+		};
+		// the loads of a group are all in flight before its first sum, and the next group's loads are issued before this group's sums
+		auto issue = [&](int g, Taps& T) __attribute__((always_inline)) {
+			const int i = g / chunks, e = (g - i * chunks) * 64 + lane;         // instance k0 + i (uniform)
+			const int cnt = __builtin_amdgcn_readlane(cntv, 16 * i);
+			const float* el = a.early_rings + (size_t)(k0 + i) * 2 * RV_ESTRIDE;
+			const float* er = el + RV_ESTRIDE;
+			int wpos = epos0 + e; if (wpos >= RV_ESIZE) wpos -= RV_ESIZE;       // the early write cursor of sample e (lanes past the block's end compute a valid position and drop the result)
+			const int pos = (wpos + 1 == RV_ESIZE) ? 0 : wpos + 1;              // ... after Delay::input()
+			const float at = (float)(pos - 1);
+#pragma unroll
+			for (int d = 0; d < 20; d++) {
+				float read = at - word(tA, tB, i, d);                           // (a tap this instance does not have: whatever its words hold — zero or an earlier time — gives a valid position, and it is never summed)
+				if (read < 0.f) read += RV_ESIZE;
+				T.fr[d] = read - floorf(read);
+				const int i0 = (int)read;                                       // i0 + 1 may be RV_ESIZE: the mirror tail holds position 0 there
+				T.l[d] = *reinterpret_cast<const rvq_f2u*>(el + i0); T.r[d] = *reinterpret_cast<const rvq_f2u*>(er + i0);
+			}
+		};
+		auto finish = [&](int g, const Taps& T) __attribute__((always_inline)) {
+			const int i = g / chunks, e = (g - i * chunks) * 64 + lane;
+			const int cnt = __builtin_amdgcn_readlane(cntv, 16 * i);
+			float accl = 0.f, accr = 0.f;
+#pragma unroll
+			for (int d = 0; d < 20; d++) {
+				const float omf = 1.f - T.fr[d];
+				const float pl = (T.l[d].x * omf + T.l[d].y * T.fr[d]) * word(glA, glB, i, d);
+				const float pr = (T.r[d].x * omf + T.r[d].y * T.fr[d]) * word(grA, grB, i, d);
+				accl = d < cnt ? accl + pl : accl;                              // out += delay(times[d]) * gains[d], d < count
+				accr = d < cnt ? accr + pr : accr;
+			}
+			if (e < n) { r1_rows[(i * 2) * n + e] = accl; r1_rows[(i * 2 + 1) * n + e] = accr; }
+		};
+		Taps T0, T1;
+		issue(0, T0);
+		int g = 0;
+		for (; g + 2 < groups; g += 2) {                                        // (groups is a multiple of four)
+			issue(g + 1, T1); __builtin_amdgcn_sched_barrier(0); finish(g, T0);
+			issue(g + 2, T0); __builtin_amdgcn_sched_barrier(0); finish(g + 1, T1);
+		}
+		issue(g + 1, T1); __builtin_amdgcn_sched_barrier(0); finish(g, T0); finish(g + 1, T1);
+	}
+
+	// =========== phase 2: the recursive part, lane = (instance, slot) ===========
 	// ---- this lane's FilteredDelay ----
 	const int grp = r >> 2, kk = r & 3, cf = grp < 2 ? 1 : 0;               // mid[] works on sample t + 1, late[] on t
 	const int fw = RV_FD + r * FD_WORDS;
@@ -890,19 +994,10 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	float* const fline = a.fd_rings + ((size_t)k * 16 + r) * RV_FSTRIDE;    // this (instance, line)'s own ring (+ mirror tail)
 	// row kk of the FDN matrix (Reverb.k:158-161): products are summed left to right
 	const float m0 = kk == 0 ? 0.f : kk == 3 ? 1.f : -1.f, m1 = kk == 1 ? 0.f : kk == 3 ? -1.f : 1.f, m2 = kk == 2 ? 0.f : kk == 1 ? -1.f : 1.f, m3 = kk == 3 ? 0.f : kk == 1 ? 1.f : -1.f;
-	// ---- this lane's share of the early reflections ----
-	const int ech = r >> 3, ej = r & 7;
-	const int ecount = __float_as_int(RVW(RV_ECOUNT));
-	float etime[3], egain[3]; bool has[3];
-#pragma unroll
-	for (int q = 0; q < 3; q++) {
-		const int d = ej + 8 * q;
-		has[q] = d < 20 && d < ecount;
-		etime[q] = has[q] ? RVW(RV_ETIMES + d) : 0.f;                           // a lane without the tap reads valid rows; its product is replaced by -0.0f
-		egain[q] = has[q] ? RVW((ech ? RV_EGR : RV_EGL) + d) : 0.f;
-	}
+	// ---- the early filter of channel ech (every lane of the channel runs it on the same input: eight copies of one state; lane r % 8 == 0 stores) ----
+	const int ech = r >> 3;
 	float* const eline = a.early_rings + ((size_t)k * 2 + ech) * RV_ESTRIDE;  // this (instance, channel)'s own early ring (+ mirror tail)
-	const bool efilter = ej == 0;                                           // in >> lpf >> hpf >> delay for channel ech (Reverb.k:88)
+	const bool efilter = (r & 7) == 0;                                      // in >> lpf >> hpf >> delay for channel ech (Reverb.k:88)
 	const float lb0 = RVW(RV_ELPF + 0), lb1 = RVW(RV_ELPF + 1), lb2 = RVW(RV_ELPF + 2), la1 = RVW(RV_ELPF + 3), la2 = RVW(RV_ELPF + 4);
 	const float hb0 = RVW(RV_EHPF + 0), hb1 = RVW(RV_EHPF + 1), hb2 = RVW(RV_EHPF + 2), ha1 = RVW(RV_EHPF + 3), ha2 = RVW(RV_EHPF + 4);
 	float elz0 = RVW(RV_EZ + 2 * ech), elz1 = RVW(RV_EZ + 2 * ech + 1), ehz0 = RVW(RV_EZ + 4 + 2 * ech), ehz1 = RVW(RV_EZ + 4 + 2 * ech + 1);
@@ -913,62 +1008,25 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	float* const in_e = rvq_tile + (inst * 2 + ech) * n;                     // the filter lane's input row
 	float* const io_o = rvq_tile + (inst * 2 + och) * n;                     // the output lane's row
 	float* const io_w = outlane ? io_o : rvq_tile + 8 * n;                  // ... and where a lane stores "its" output sample: an unconditional ds_write, no exec-mask branch in the sample loop
-	// the early sum of channel c ends in lane c * 8 + 3 of the row: mid[0] (lanes 0..3) and the left output lane (8) want channel 0's
-	const int r1_src = rowbase + ((r < 4 || r == 8) ? 3 : 11);
-	// wave-uniform cursors of the block: every instance has processed the same number of samples
-	const int epos0 = __builtin_amdgcn_readfirstlane(a.epos % RV_ESIZE), fpos0 = __builtin_amdgcn_readfirstlane(a.fpos % RV_FSIZE);
+	// the early sum a lane wants: mid[c] (lanes 4c .. 4c + 3) of its own sample t + 1, the output lane of channel c (8 / 12) of sample t - 1
+	const float* const r1_row = r1_rows + (inst * 2 + ((r < 4 || r == 8) ? 0 : 1)) * n;
+	const int r1_at = r < 8 ? 1 : -1;
 
 	// ---- row requests, one batch ahead ----
-	// Stereo::Delay::tap(float) klang.h:4668-4681 for the sample whose early write cursor is `wpos`: the read position (integer part, fraction);
-	// `bin` = the exponents of the float before / after the wrap correction and whether it was applied (two samples with equal `bin` whose
-	// reads are k apart have integer parts exactly k apart and the same fraction: adding k inside one binade is exact)
-	auto tap_pos = [&](int wpos, float time, float& frac, unsigned& bin) __attribute__((always_inline)) {
-		const int pos = (wpos + 1 == RV_ESIZE) ? 0 : wpos + 1;                   // cursor after Delay::input()
-		float read = (float)(pos - 1) - time;
-		const unsigned pre = __float_as_uint(read) >> 23;
-		const bool neg = read < 0.f;
-		if (neg) read += RV_ESIZE;
-		frac = read - floorf(read);
-		bin = (pre << 10) | ((__float_as_uint(read) >> 23) << 1) | (neg ? 1u : 0u);
-		return (int)read;
-	};
 	int fnext = flast + 2 * (cf - 2) + 1; if (fnext < 0) fnext += RV_FSIZE;    // row J + 1 of the first batch (its first sample: s = cf - 2, iteration t = -2)
-	int ewb = epos0;                                                        // early write cursor of the first sample of the batch being requested (uniform)
-	auto request = [&](RvqRows& X) __attribute__((always_inline)) {
-#pragma unroll
-		for (int v = 0; v < 2 * RVQ_B / 4; v++) {
-			const rvq_f4 x = *reinterpret_cast<const rvq_f4*>(fline + fnext + 4 * v);   // (never past the mirror tail: fnext < RV_FSIZE, 16 rows)
-			X.F[4 * v] = x.x; X.F[4 * v + 1] = x.y; X.F[4 * v + 2] = x.z; X.F[4 * v + 3] = x.w;
-		}
+	auto request = [&](auto set) __attribute__((always_inline)) {
+		rvq_request<decltype(set)::value>(fline + fnext);                    // (never past the mirror tail: fnext < RV_FSIZE, 16 rows)
 		fnext += 2 * RVQ_B; if (fnext >= RV_FSIZE) fnext -= RV_FSIZE;
-		const int ewl = (ewb + RVQ_B - 1 >= RV_ESIZE) ? ewb + RVQ_B - 1 - RV_ESIZE : ewb + RVQ_B - 1;   // ... of its last sample
-		bool reg = true;
-#pragma unroll
-		for (int q = 0; q < 3; q++) {
-			float fr, fr7; unsigned b0, b7;
-			const int i0 = tap_pos(ewb, etime[q], fr, b0), i7 = tap_pos(ewl, etime[q], fr7, b7);
-			X.elo[q] = i0; X.efr[q] = fr;
-			reg = reg && b0 == b7 && i7 == i0 + (RVQ_B - 1) && __float_as_uint(fr) == __float_as_uint(fr7);
-			// rows i0 .. i0 + 9: every register a load writes is used (a dead component would be handed to a temporary right away — and the
-			// wave would wait for the load to land before it may overwrite it)
-#pragma unroll
-			for (int v = 0; v < 2; v++) {
-				const rvq_f4 x = *reinterpret_cast<const rvq_f4*>(eline + i0 + 4 * v);
-				X.E[q][4 * v] = x.x; X.E[q][4 * v + 1] = x.y; X.E[q][4 * v + 2] = x.z; X.E[q][4 * v + 3] = x.w;
-			}
-			{ typedef float rvq_f2u __attribute__((ext_vector_type(2), aligned(4))); const rvq_f2u x = *reinterpret_cast<const rvq_f2u*>(eline + i0 + 8); X.E[q][8] = x.x; X.E[q][9] = x.y; }
-		}
-		X.regular = __ballot(!reg) == 0ull;
-		ewb += RVQ_B; if (ewb >= RV_ESIZE) ewb -= RV_ESIZE;
 	};
-	RvqRows A, Bn;
+	const IntTag<0> A; const IntTag<1> Bn; const IntTag<2> Cn;              // three sets of accumulation registers in rotation: a batch's rows are requested TWO batches before it runs
 	float fr0;                                                              // row `last` of the FilteredDelay's current sample ( = row last + 2 of the previous one)
 	{ int p0 = flast + 2 * (cf - 2); if (p0 < 0) p0 += RV_FSIZE; fr0 = fline[p0]; }
 	request(A);
-	wave_sync();                                                            // the io tile is in LDS
+	wave_sync();                                                            // the io tile and the early sums are in LDS
 
-	float r1_prev = 0.f, ssum_prev = 0.f, lr_prev = 0.f, hA = 0.f, hB = 0.f, hC = 0.f;
-	float x_in = in_e[0], x_out = 0.f;                                      // the filter lane's next input sample / the output lane's next dry sample (read from the LDS tile one iteration ahead)
+	auto inside = [&](int s) { return s < 0 ? 0 : s >= n ? n - 1 : s; };
+	float ssum_prev = 0.f, lr_prev = 0.f;
+	float x_in = in_e[0], x_out = 0.f, r1_cur = r1_row[inside(-2 + r1_at)];  // the filter lane's next input sample / the output lane's next dry sample / the next early sum (LDS, read one iteration ahead)
 	// What a steady batch WRITES is collected in registers and stored once per batch — 64 bytes per FilteredDelay line, 32 per early line:
 	// whole sectors instead of eight 8-byte (4-byte) pieces of one, each of which the memory system would otherwise merge on its own.
 	float Wf[2 * RVQ_B], We[RVQ_B];
@@ -977,67 +1035,35 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 #pragma unroll
 	for (int j = 0; j < RVQ_B; j++) We[j] = 0.f;
 
-	// One iteration: early stage of sample t + 2, mid[] of t + 1, late[] of t, output of t - 1; u = its place in the batch (compile-time: every
+	// One iteration: early filter of sample t + 2, mid[] of t + 1, late[] of t, output of t - 1; u = its place in the batch (compile-time: every
 	// row is a named register).  G = guarded (the batches at the edges of the block test which stages are active).
 	// A wave is alone on its SIMD at the bank sizes that matter, so nothing hides a wait: every cross-lane / LDS value is requested at the
 	// top of the iteration before the one that uses it, or at the top of this one with a long computation in between.
-	// A steady batch is ONE basic block of eight samples (no lane-predicated branch, no per-sample uniform one: what only some lanes need is
-	// computed by all of them — a masked-off lane costs the same issue slot — and `regular` is tested once per batch), so the scheduler
-	// can fill the wait states of the DPP sum chain and the latency of one sample's LDS / bpermute answers with the arithmetic of its neighbours.
-	auto step = [&](auto guarded, auto reg_tag, auto place, const int t, const RvqRows& X, const float (&omf)[3]) __attribute__((always_inline)) {
+	// A steady batch is ONE basic block of eight samples (no lane-predicated branch: what only some lanes need is computed by all of
+	// them — a masked-off lane costs the same issue slot), so the scheduler can fill the latency of one sample's LDS / bpermute answers with
+	// the arithmetic of its neighbours.
+	auto step = [&](auto guarded, auto place, const int t, const RvqRows& X) __attribute__((always_inline)) {
 		constexpr bool G = decltype(guarded)::value;
-		constexpr bool REG = decltype(reg_tag)::value;
 		constexpr int u = decltype(place)::value;
 		const int e = t + 2, sfd = t + cf, o = t - 1;
 		const bool e_on = !G || e < n, fd_on = !G || (sfd >= 0 && sfd < n), o_on = !G || (o >= 0 && o < n);
 		const int ewpos = (epos0 + e >= RV_ESIZE) ? epos0 + e - RV_ESIZE : epos0 + e;                  // uniform: the early write cursor of sample e
 		// ---- requests whose answers are needed later in this iteration / in the next one ----
 		const float from_mid = lane_get(ssum_prev, lane - 8);                 // late[]'s input: mid[]'s sum of the previous iteration
-		const float x_in_now = x_in, x_out_now = x_out;
-		x_in = in_e[(!G || e + 1 < n) ? e + 1 : 0];                             // next iteration's samples
-		x_out = io_o[(!G || (o + 1 >= 0 && o + 1 < n)) ? o + 1 : 0];
-		// ---- early products of sample e: delay(times[d]) * gains[d] ----
-		// (a tap this instance does not have: gain 0, the product is +-0 and leaves the sum — never -0 after `0.f +` — as it is)
-		float prod[3];
-		if constexpr (REG) {
-#pragma unroll
-			for (int q = 0; q < 3; q++) prod[q] = (X.E[q][u] * omf[q] + X.E[q][u + 1] * X.efr[q]) * egain[q];
-		}
-		else {
-#pragma unroll
-			for (int q = 0; q < 3; q++) {
-				float fr; unsigned bin; const int i0 = tap_pos(ewpos, etime[q], fr, bin);
-				int idx = i0 - X.elo[q]; if (idx < 0) idx += RV_ESIZE;          // the mirror tail continues the ring past its end
-				// the read position advances by one per sample up to float rounding: idx is u - 1, u or u + 1
-				const float em = X.E[q][u > 0 ? u - 1 : 0], e0 = X.E[q][u], e1 = X.E[q][u + 1], e2 = X.E[q][u + 2];   // (named values, then selects: a select of array ELEMENTS would become a run-time index)
-				const float ea = idx < u ? em : idx > u ? e1 : e0;
-				const float eb = idx < u ? e0 : idx > u ? e2 : e1;
-				prod[q] = (ea * (1.f - fr) + eb * fr) * egain[q];
-			}
-		}
-		// out = 0; for d < count: out += delay(times[d]) * gains[d]   Reverb.k:90-92.  The twenty products of a channel sit in eight lanes (tap
-		// d in lane d % 8, slot d / 8); the running sum walks through them in tap order — one v_add_f32 with a DPP source per tap: the lane that
-		// holds tap d takes the sum from the lane that holds tap d - 1 — and ends in lane c * 8 + 3 (tap 19).  Other lanes compute don't-cares.
-		float acc = 0.f + prod[0];
-#pragma unroll
-		for (int d = 1; d < 8; d++) acc = dpp_take<DPP_ROW_SHR1>(acc) + prod[0];
-		acc = dpp_take<DPP_ROW_SHL7>(acc) + prod[1];
-#pragma unroll
-		for (int d = 9; d < 16; d++) acc = dpp_take<DPP_ROW_SHR1>(acc) + prod[1];
-		acc = dpp_take<DPP_ROW_SHL7>(acc) + prod[2];
-#pragma unroll
-		for (int d = 17; d < 20; d++) acc = dpp_take<DPP_ROW_SHR1>(acc) + prod[2];
-		const float r1_new = lane_get(acc, r1_src);                             // the early sum of the channel THIS lane wants (mid[] input next iteration; output in three)
+		const float x_in_now = x_in, x_out_now = x_out, r1_now = r1_cur;
+		x_in = in_e[G ? inside(e + 1) : e + 1];                                 // next iteration's samples
+		x_out = io_o[G ? inside(o + 1) : o + 1];
+		r1_cur = r1_row[G ? inside(t + 1 + r1_at) : t + 1 + r1_at];
 		// ---- the FilteredDelay: mid[] on sample t + 1 (input: the early reflections of its channel), late[] on sample t (input: mid[]'s sum) ----
-		float r0 = fr0; if constexpr (u > 0) r0 = X.F[2 * u - 1];
-		const float r1v = X.F[2 * u], r2v = X.F[2 * u + 1];
+		float r0 = fr0; if constexpr (u > 0) r0 = X.template F<(u > 0 ? 2 * u - 1 : 0)>();
+		const float r1v = X.template F<2 * u>(), r2v = X.template F<2 * u + 1>();
 		const float fdt1 = r0 + ffrac * (r1v - r0), fdt2 = r1v + ffrac * (r2v - r1v);     // the two delay reads of this sample (Delay::operator>> klang.h:3491-3500)
 		float ssum = 0.f, lr_in = 0.f;
 		if (fd_on) {
 			const float dl = biquad_process(ff, fdt1) * fgain;                // signals<4> delays = { delay[0..3] }: first process() — (in >> delay >> filter) * gain, Reverb.k:130-132
 			const float d0 = quad_bcast<0>(dl), d1 = quad_bcast<1>(dl), d2 = quad_bcast<2>(dl), d3 = quad_bcast<3>(dl);
 			const float fb = m0 * d0 + m1 * d1 + m2 * d2 + m3 * d3;           // (delays >> matrix): row kk, products summed left to right (klang.h:1462-1467)
-			lr_in = r < 8 ? r1_prev : from_mid;
+			lr_in = r < 8 ? r1_now : from_mid;
 			const float fin_new = fb + lr_in;                                 // fb[k] = ... + in;  fb[k] >> delay[k]
 			const int fbase = (fpos0 + 2 * t >= RV_FSIZE) ? fpos0 + 2 * t - RV_FSIZE : fpos0 + 2 * t;   // uniform: late[]'s write cursor (mid[] is one sample = 2 ahead)
 			int fwpos = fbase + 2 * cf; if (fwpos >= RV_FSIZE) fwpos -= RV_FSIZE; if (fwpos < 0) fwpos += RV_FSIZE;
@@ -1074,32 +1100,30 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 		}
 		if constexpr (u == RVQ_B - 1) fr0 = r2v;                             // row last + 2 of the batch's last sample is row `last` of the next batch's first
 		// ---- early stage, sample e: in >> lpf >> hpf >> delay  Reverb.k:88 ----
-		if (e_on) {                                                           // (every lane of the channel runs the filter on the same input: eight copies of one state)
-			{
-				Biquad elpf = { lb0, lb1, lb2, la1, la2, elz0, elz1 }, ehpf = { hb0, hb1, hb2, ha1, ha2, ehz0, ehz1 };
-				const float y = biquad_process(ehpf, biquad_process(elpf, x_in_now));
-				elz0 = elpf.z0; elz1 = elpf.z1; ehz0 = ehpf.z0; ehz1 = ehpf.z1;
-				if constexpr (G) {
-					if (efilter) {
-						eline[ewpos] = y;
-						if (ewpos < RV_EPAD) eline[ewpos + RV_ESIZE] = y;     // mirror (a uniform test)
-					}
+		if (e_on) {
+			Biquad elpf = { lb0, lb1, lb2, la1, la2, elz0, elz1 }, ehpf = { hb0, hb1, hb2, ha1, ha2, ehz0, ehz1 };
+			const float y = biquad_process(ehpf, biquad_process(elpf, x_in_now));
+			elz0 = elpf.z0; elz1 = elpf.z1; ehz0 = ehpf.z0; ehz1 = ehpf.z1;
+			if constexpr (G) {
+				if (efilter) {
+					eline[ewpos] = y;
+					if (ewpos < RV_EPAD) eline[ewpos + RV_ESIZE] = y;         // mirror (a uniform test)
 				}
-				else {
-					We[u] = y;
-					if constexpr (u == RVQ_B - 1) if (efilter) {
-						const int w0 = ewpos - (RVQ_B - 1);
-						if (w0 >= RV_EPAD && ewpos < RV_ESIZE) {                  // uniform: the batch neither wraps nor touches the mirrored head
+			}
+			else {
+				We[u] = y;
+				if constexpr (u == RVQ_B - 1) if (efilter) {
+					const int w0 = ewpos - (RVQ_B - 1);
+					if (w0 >= RV_EPAD && ewpos < RV_ESIZE) {                      // uniform: the batch neither wraps nor touches the mirrored head
 #pragma unroll
-							for (int v = 0; v < RVQ_B / 4; v++) { const rvq_f4 x = { We[4 * v], We[4 * v + 1], We[4 * v + 2], We[4 * v + 3] }; *reinterpret_cast<rvq_f4*>(eline + w0 + 4 * v) = x; }
-						}
-						else {
+						for (int v = 0; v < RVQ_B / 4; v++) { const rvq_f4 x = { We[4 * v], We[4 * v + 1], We[4 * v + 2], We[4 * v + 3] }; *reinterpret_cast<rvq_f4*>(eline + w0 + 4 * v) = x; }
+					}
+					else {
 #pragma unroll
-							for (int j = 0; j < RVQ_B; j++) {
-								int w = w0 + j; if (w < 0) w += RV_ESIZE;
-								eline[w] = We[j];
-								if (w < RV_EPAD) eline[w + RV_ESIZE] = We[j];
-							}
+						for (int j = 0; j < RVQ_B; j++) {
+							int w = w0 + j; if (w < 0) w += RV_ESIZE;
+							eline[w] = We[j];
+							if (w < RV_EPAD) eline[w + RV_ESIZE] = We[j];
 						}
 					}
 				}
@@ -1107,36 +1131,48 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 		}
 		// ---- output, sample o: Reflections::process + Reverb::process ----
 		if (o_on) {
-			const float refl = (hA * c1 + lr_prev * c2) + ssum_prev * c3;         // r1 (three iterations ago), r2 = this late[]'s input and r3 = its sum of the previous iteration
+			const float refl = (r1_now * c1 + lr_prev * c2) + ssum_prev * c3;     // r1 of sample o, r2 = this late[]'s input and r3 = its sum of the previous iteration
 			io_w[o] = x_out_now * dry + refl * wet_o;                             // wet side is signals<2>{ wet, 0 }
 		}
-		hA = hB; hB = hC; hC = r1_new;
-		r1_prev = r1_new; ssum_prev = ssum; lr_prev = lr_in;
+		ssum_prev = ssum; lr_prev = lr_in;
 	};
-	auto batch_as = [&](auto guarded, auto reg, const int t0, const RvqRows& X) __attribute__((always_inline)) {
-		const float omf[3] = { 1.f - X.efr[0], 1.f - X.efr[1], 1.f - X.efr[2] };
-		step(guarded, reg, IntTag<0>(), t0 + 0, X, omf); step(guarded, reg, IntTag<1>(), t0 + 1, X, omf); step(guarded, reg, IntTag<2>(), t0 + 2, X, omf); step(guarded, reg, IntTag<3>(), t0 + 3, X, omf);
-		step(guarded, reg, IntTag<4>(), t0 + 4, X, omf); step(guarded, reg, IntTag<5>(), t0 + 5, X, omf); step(guarded, reg, IntTag<6>(), t0 + 6, X, omf); step(guarded, reg, IntTag<7>(), t0 + 7, X, omf);
-	};
-	auto batch = [&](auto guarded, const int t0, const RvqRows& X) __attribute__((always_inline)) {
-		constexpr bool G = decltype(guarded)::value;
-		if constexpr (G) batch_as(guarded, BoolTag<false>(), t0, X);             // the edges of the block take the general form (a position per tap and sample)
-		else { if (X.regular) batch_as(guarded, BoolTag<true>(), t0, X); else batch_as(guarded, BoolTag<false>(), t0, X); }
+	auto batch = [&](auto guarded, auto younger, const int t0, auto set) __attribute__((always_inline)) {
+		RvqRows X;
+		rvq_await<decltype(set)::value, decltype(younger)::value>(X);
+		step(guarded, IntTag<0>(), t0 + 0, X); step(guarded, IntTag<1>(), t0 + 1, X); step(guarded, IntTag<2>(), t0 + 2, X); step(guarded, IntTag<3>(), t0 + 3, X);
+		step(guarded, IntTag<4>(), t0 + 4, X); step(guarded, IntTag<5>(), t0 + 5, X); step(guarded, IntTag<6>(), t0 + 6, X); step(guarded, IntTag<7>(), t0 + 7, X);
 	};
 	const BoolTag<true> ramp; const BoolTag<false> steady;
-	// iterations t = -2 .. n in batches of eight; the rows of a batch are requested while the batch before it is computed
+	// iterations t = -2 .. n in batches of eight; the rows of a batch are requested two batches ahead (a wave alone on its SIMD has nothing
+	// but distance to hide HBM latency with; a batch is about a microsecond).  The sched_barrier: the rows are REQUESTED there, not where used.
+	// (A request past the block's end reads rows that exist and are not used.)
+	const IntTag<8> y8; const IntTag<16> y16;                                   // what is certainly in flight behind a batch's rows (see RvqRows)
 	int t0 = -2;
-	request(Bn); __builtin_amdgcn_sched_barrier(0); batch(ramp, t0, A); t0 += RVQ_B;     // t = -2 .. 5  (the barrier: the rows are REQUESTED here, a batch before they are used)
-	for (; t0 + 2 * RVQ_B - 1 <= n - 3; t0 += 2 * RVQ_B) {                       // two steady batches per turn (t >= 1 and t + 2 < n throughout): A and Bn swap roles
-		request(A); __builtin_amdgcn_sched_barrier(0); batch(steady, t0, Bn);
-		request(Bn); __builtin_amdgcn_sched_barrier(0); batch(steady, t0 + RVQ_B, A);
+	request(Bn);
+	request(Cn); batch(ramp, y8, t0, A); t0 += RVQ_B;                           // t = -2 .. 5
+	if (t0 + 3 * RVQ_B - 1 <= n - 3) {                                          // three steady batches per turn (t >= 1 and t + 2 < n throughout): the sets swap roles
+		request(A); batch(steady, y8, t0, Bn);                                  // (behind a guarded batch — which may have stored nothing — only the requests count)
+		request(Bn); batch(steady, y8, t0 + RVQ_B, Cn);
+		request(Cn); batch(steady, y8, t0 + 2 * RVQ_B, A);
+		for (t0 += 3 * RVQ_B; t0 + 3 * RVQ_B - 1 <= n - 3; t0 += 3 * RVQ_B) {
+			request(A); batch(steady, y8, t0, Bn);
+			request(Bn); batch(steady, y8, t0 + RVQ_B, Cn);
+			request(Cn); batch(steady, y8, t0 + 2 * RVQ_B, A);
+		}
 	}
-	for (; t0 <= n; t0 += 2 * RVQ_B) {                                          // the last batches, guarded (the roles of A and Bn stay compile-time: no array ever lives in memory)
-		request(A); __builtin_amdgcn_sched_barrier(0); batch(ramp, t0, Bn);
-		if (t0 + RVQ_B <= n) { request(Bn); __builtin_amdgcn_sched_barrier(0); batch(ramp, t0 + RVQ_B, A); }
-	}
+	// the last batches, guarded (the roles of the sets stay compile-time: no array ever lives in memory); at most two of them could have been steady
+	if (t0 <= n) { request(A); batch(ramp, y8, t0, Bn); t0 += RVQ_B; }
+	if (t0 <= n) { request(Bn); batch(ramp, y8, t0, Cn); t0 += RVQ_B; }
+	if (t0 <= n) { request(Cn); batch(ramp, y8, t0, A); t0 += RVQ_B; }
+	if (t0 <= n) { request(A); batch(ramp, y8, t0, Bn); t0 += RVQ_B; }
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // (requests past the block's end land in accumulation registers nobody reads)
 	wave_sync();
-	for (int R = 0; R < 8; R++) {
+	if (whole) {
+		rvq_v4* dst = reinterpret_cast<rvq_v4*>(a.io + (size_t)k0 * 2 * n);
+		const rvq_v4* src = reinterpret_cast<const rvq_v4*>(rvq_tile);
+		for (int c = lane; c < 2 * n; c += 64) dst[c] = src[c];
+	}
+	else for (int R = 0; R < 8; R++) {
 		const int ki = k0 + (R >> 1);
 		if (ki < a.K) for (int c = lane; c < n; c += 64) a.io[((size_t)ki * 2 + (R & 1)) * n + c] = rvq_tile[R * n + c];
 	}

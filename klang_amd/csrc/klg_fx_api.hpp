@@ -337,9 +337,11 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		static const bool single_wave = []() { const char* e = getenv("KLG_FX_REVERB1"); return e && e[0] == '1'; }();
 		a.layout = f->rv_layout;
 		// the production kernels request ring rows ahead of their use (reverb_q: 8 samples = 16 positions; reverb16: one sample): safe while the
-		// shortest line (7 ms * 0.9) is longer than that
-		if (single_wave || f->fs.f < 16000.f) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);   // one lane walks the whole graph (A/B reference; either layout)
-		else if (f->rv_layout) hipLaunchKernelGGL(klg_fx_reverb_q, dim3((unsigned)((f->kpad + 4 * (RVQ_WG / 64) - 1) / (4 * (RVQ_WG / 64)))), dim3(RVQ_WG), (size_t)(RVQ_WG / 64) * 9 * n * sizeof(float), st, a);   // one wave per four instances, four waves (a CU) per workgroup
+		// shortest line (7 ms * 0.9) is longer than that.  reverb_q also computes a block's early sums before the block's early-line writes:
+		// right while every tap reads further back than the block is long — the shortest tap is (50 ms + ...) * random(0.9, 1.1) > 44.9 ms.
+		const bool taps_behind_block = (float)(n + 2) < 0.0449f * f->fs.f;
+		if (single_wave || f->fs.f < 16000.f || (f->rv_layout && !taps_behind_block)) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);   // one lane walks the whole graph (A/B reference; either layout)
+		else if (f->rv_layout) hipLaunchKernelGGL(klg_fx_reverb_q, dim3((unsigned)((f->kpad + 4 * (RVQ_WG / 64) - 1) / (4 * (RVQ_WG / 64)))), dim3(RVQ_WG), (size_t)(RVQ_WG / 64) * RVQ_TILE_ROWS * n * sizeof(float), st, a);   // one wave per four instances
 		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances (KLG_FX_REVERB16=1)
 	}
 	HIP_TRY(hipGetLastError());
