@@ -851,6 +851,7 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 enum { RVQ_MAX_INSTANCES = 8192 };       // banks up to this size run klg_fx_reverb_q (measured: profiles/r02_fx_sizes.md)
 enum { RVQ_WG = 64 };
 enum { RVQ_B = 8, RV_FPAD = 32, RV_EPAD = 16, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
+enum { RVQ_XQ_LD = 20, RVQ_XQ_FLOATS = 64 * RVQ_XQ_LD };  // the quarter exchange of the ring stores: 64 rows of 16 floats, padded
 enum { RVQ_TILE_ROWS = 17 };             // LDS per wave, rows of n floats: 0..7 the caller's block (instance * 2 + channel), 8 scrap, 9..16 the early sums
 
 __device__ __forceinline__ float lane_get(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
@@ -897,7 +898,7 @@ template<int SET, int N> __device__ __forceinline__ void rvq_await(RvqRows& X) {
 __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	extern __shared__ float rvq_tiles[];
 	const int lane = threadIdx.x & 63, inst = lane >> 4, r = lane & 15;
-	float* const rvq_tile = rvq_tiles + (threadIdx.x >> 6) * RVQ_TILE_ROWS * a.n;
+	float* const rvq_tile = rvq_tiles + (threadIdx.x >> 6) * (((RVQ_TILE_ROWS * a.n + 3) & ~3) + RVQ_XQ_FLOATS);
 	const int k0 = (blockIdx.x * (RVQ_WG / 64) + (threadIdx.x >> 6)) * 4, k = k0 + inst;
 	if (k0 >= (int)a.kpad) return;
 	const size_t KP = a.kpad;
@@ -992,6 +993,9 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	const float fgain = RVW(fw + FD_GAIN), ffrac = RVW(fw + FD_LASTF);
 	const int flast = __float_as_int(RVW(fw + FD_LASTP));
 	float* const fline = a.fd_rings + ((size_t)k * 16 + r) * RV_FSTRIDE;    // this (instance, line)'s own ring (+ mirror tail)
+	float* const fquad = a.fd_rings + ((size_t)k * 16 + (r & 12)) * RV_FSTRIDE + 4 * (r & 3);   // quarter r % 4 of a 64-byte piece of the quad's first line (see the steady batch's stores)
+	rvq_v4* const xq_mine = reinterpret_cast<rvq_v4*>(rvq_tile + ((RVQ_TILE_ROWS * n + 3) & ~3) + lane * RVQ_XQ_LD);                         // the quarter exchange: a lane's 16 floats, rows padded against bank conflicts
+	const rvq_v4* const xq_quad = reinterpret_cast<const rvq_v4*>(rvq_tile + ((RVQ_TILE_ROWS * n + 3) & ~3) + (lane & 60) * RVQ_XQ_LD + 4 * (r & 3));   // ... quarter r % 4 of the quad's lane 0 (lane v: + v rows)
 	// row kk of the FDN matrix (Reverb.k:158-161): products are summed left to right
 	const float m0 = kk == 0 ? 0.f : kk == 3 ? 1.f : -1.f, m1 = kk == 1 ? 0.f : kk == 3 ? -1.f : 1.f, m2 = kk == 2 ? 0.f : kk == 1 ? -1.f : 1.f, m3 = kk == 3 ? 0.f : kk == 1 ? 1.f : -1.f;
 	// ---- the early filter of channel ech (every lane of the channel runs it on the same input: eight copies of one state; lane r % 8 == 0 stores) ----
@@ -1013,23 +1017,47 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	const int r1_at = r < 8 ? 1 : -1;
 
 	// ---- row requests, one batch ahead ----
-	int fnext = flast + 2 * (cf - 2) + 1; if (fnext < 0) fnext += RV_FSIZE;    // row J + 1 of the first batch (its first sample: s = cf - 2, iteration t = -2)
+	// The batches sit on a grid: a steady batch's ring stores are whole aligned 64-byte (FilteredDelay: 16 positions) / 32-byte (early line:
+	// 8 positions) pieces — an unaligned piece is two partial sectors to the memory system, twice the write traffic (measured: WRITE_SIZE
+	// 2 x the bytes, and 60 of 160 us at 4096 instances).  Both cursors advance with the sample count (2 per sample / 1 per sample) and both
+	// ring sizes are multiples of the piece: a batch that starts at an iteration t with (fpos0 / 2 + t) % 8 == 0 has late[]'s first pair at
+	// a multiple of 16 and the early cursor at a multiple of 8.  t_s = the first such iteration >= 1 (steady batches need every stage
+	// active); two guarded batches before it cover the ramp-up t = -2 .. t_s - 1 (the first of them may have nothing to do).
+	const int t_s = ((8 - ((fpos0 >> 1) & 7)) & 7) ? ((8 - ((fpos0 >> 1) & 7)) & 7) : 8;
+	const int t_first = t_s - 2 * RVQ_B;
+	int fnext = flast + 2 * (t_first + cf) + 1; if (fnext < 0) fnext += RV_FSIZE;   // row J + 1 of the first batch (its first sample: s = t_first + cf)
 	auto request = [&](auto set) __attribute__((always_inline)) {
 		rvq_request<decltype(set)::value>(fline + fnext);                    // (never past the mirror tail: fnext < RV_FSIZE, 16 rows)
 		fnext += 2 * RVQ_B; if (fnext >= RV_FSIZE) fnext -= RV_FSIZE;
 	};
 	const IntTag<0> A; const IntTag<1> Bn; const IntTag<2> Cn;              // three sets of accumulation registers in rotation: a batch's rows are requested TWO batches before it runs
 	float fr0;                                                              // row `last` of the FilteredDelay's current sample ( = row last + 2 of the previous one)
-	{ int p0 = flast + 2 * (cf - 2); if (p0 < 0) p0 += RV_FSIZE; fr0 = fline[p0]; }
+	{ int p0 = flast + 2 * (t_first + cf); if (p0 < 0) p0 += RV_FSIZE; fr0 = fline[p0]; }
 	request(A);
 	wave_sync();                                                            // the io tile and the early sums are in LDS
 
 	auto inside = [&](int s) { return s < 0 ? 0 : s >= n ? n - 1 : s; };
 	float ssum_prev = 0.f, lr_prev = 0.f;
-	float x_in = in_e[0], x_out = 0.f, r1_cur = r1_row[inside(-2 + r1_at)];  // the filter lane's next input sample / the output lane's next dry sample / the next early sum (LDS, read one iteration ahead)
+	// What a batch reads from LDS — the filter lane's input samples, the output lane's dry samples, the early sums — is known for the whole
+	// block: a batch's 24 values are read while the batch before it runs (three sets in rotation, like the rows), so no iteration waits for LDS.
+	struct RvqLds { float xin[RVQ_B], xout[RVQ_B], r1[RVQ_B]; };
+	auto fetch = [&](auto guarded, RvqLds& L, const int tb) __attribute__((always_inline)) {   // for the batch of iterations tb .. tb + 7
+		constexpr bool G = decltype(guarded)::value;
+#pragma unroll
+		for (int u = 0; u < RVQ_B; u++) {
+			const int t = tb + u;
+			L.xin[u] = in_e[G ? inside(t + 2) : t + 2];                         // sample e = t + 2 (read ahead of the output samples written in place: o = t - 1)
+			L.xout[u] = io_o[G ? inside(t - 1) : t - 1];
+			L.r1[u] = r1_row[G ? inside(t + r1_at) : t + r1_at];
+		}
+	};
+	RvqLds LA, LB, LC;
 	// What a steady batch WRITES is collected in registers and stored once per batch — 64 bytes per FilteredDelay line, 32 per early line:
 	// whole sectors instead of eight 8-byte (4-byte) pieces of one, each of which the memory system would otherwise merge on its own.
-	float Wf[2 * RVQ_B], We[RVQ_B];
+	// late[] (cf = 0) collects the pairs of iterations u = 0 .. 7 — positions fbase(t0) .. + 15; mid[] writes one sample ahead, so the SAME
+	// positions hold ITS pairs of iterations u = -1 .. 6: it stores the previous iteration's pair (pp0, pp1) in slot u.  The early line's
+	// aligned eight are the samples of iterations u = -2 .. 5 (slot (u + 2) % 8, stored after u = 5).
+	float Wf[2 * RVQ_B], We[RVQ_B], pp0 = 0.f, pp1 = 0.f;
 #pragma unroll
 	for (int j = 0; j < 2 * RVQ_B; j++) Wf[j] = 0.f;
 #pragma unroll
@@ -1042,18 +1070,15 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	// A steady batch is ONE basic block of eight samples (no lane-predicated branch: what only some lanes need is computed by all of
 	// them — a masked-off lane costs the same issue slot), so the scheduler can fill the latency of one sample's LDS / bpermute answers with
 	// the arithmetic of its neighbours.
-	auto step = [&](auto guarded, auto place, const int t, const RvqRows& X) __attribute__((always_inline)) {
+	auto step = [&](auto guarded, auto place, const int t, const RvqRows& X, const RvqLds& L) __attribute__((always_inline)) {
 		constexpr bool G = decltype(guarded)::value;
 		constexpr int u = decltype(place)::value;
 		const int e = t + 2, sfd = t + cf, o = t - 1;
-		const bool e_on = !G || e < n, fd_on = !G || (sfd >= 0 && sfd < n), o_on = !G || (o >= 0 && o < n);
-		const int ewpos = (epos0 + e >= RV_ESIZE) ? epos0 + e - RV_ESIZE : epos0 + e;                  // uniform: the early write cursor of sample e
+		const bool e_on = !G || (e >= 0 && e < n), fd_on = !G || (sfd >= 0 && sfd < n), o_on = !G || (o >= 0 && o < n);
+		int ewpos = epos0 + e; if (ewpos >= RV_ESIZE) ewpos -= RV_ESIZE; if (ewpos < 0) ewpos += RV_ESIZE;   // uniform: the early write cursor of sample e
 		// ---- requests whose answers are needed later in this iteration / in the next one ----
-		const float from_mid = lane_get(ssum_prev, lane - 8);                 // late[]'s input: mid[]'s sum of the previous iteration
-		const float x_in_now = x_in, x_out_now = x_out, r1_now = r1_cur;
-		x_in = in_e[G ? inside(e + 1) : e + 1];                                 // next iteration's samples
-		x_out = io_o[G ? inside(o + 1) : o + 1];
-		r1_cur = r1_row[G ? inside(t + 1 + r1_at) : t + 1 + r1_at];
+		const float from_mid = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssum_prev), 0x118, 0xF, 0xF, true));   // late[]'s input: mid[]'s sum of the previous iteration (DPP row_shr:8 — lane L takes lane L - 8 of its row of 16)
+		const float x_in_now = L.xin[u], x_out_now = L.xout[u], r1_now = L.r1[u];
 		// ---- the FilteredDelay: mid[] on sample t + 1 (input: the early reflections of its channel), late[] on sample t (input: mid[]'s sum) ----
 		float r0 = fr0; if constexpr (u > 0) r0 = X.template F<(u > 0 ? 2 * u - 1 : 0)>();
 		const float r1v = X.template F<2 * u>(), r2v = X.template F<2 * u + 1>();
@@ -1073,26 +1098,29 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 				if (fbase < RV_FPAD || fbase + 2 >= RV_FSIZE || fbase < 0) { if (fwpos < RV_FPAD) *reinterpret_cast<rvq_f2*>(fline + fwpos + RV_FSIZE) = pair; }   // mirror (the outer test is uniform and almost never true)
 			}
 			else {
-				Wf[2 * u] = fin; Wf[2 * u + 1] = fin_new;                     // stored with the rest of the batch (flush below)
+				Wf[2 * u] = cf ? pp0 : fin; Wf[2 * u + 1] = cf ? pp1 : fin_new;   // stored with the rest of the batch (flush below)
 				if constexpr (u == RVQ_B - 1) {
-					int w0 = fwpos - 2 * (RVQ_B - 1);                         // the batch's first position (this lane's)
-					const bool straight = fbase - 2 * (RVQ_B - 1) >= RV_FPAD && fbase + 4 < RV_FSIZE;   // uniform: no wrap and no mirror inside the batch, for mid[] and late[] lanes alike
-					if (straight) {
+					const int w0 = fbase - 2 * (RVQ_B - 1);                   // uniform and a multiple of 16 (the grid): the batch's piece of every line, never across the ring's end
+					// A lane holds the 64 bytes of ITS line; stored as they are, every 16-byte quarter is a write request of its own to the L2
+					// (64 lanes, 64 lines: nothing to merge — 10.7 M requests per block at 4096 instances, the kernel's bound).  The four
+					// lanes of a quad swap quarters through LDS instead: store v of lane i is quarter i of the quad's line v, so a quad
+					// writes 64 contiguous bytes per instruction — one request.
 #pragma unroll
-						for (int v = 0; v < 2 * RVQ_B / 4; v++) { const rvq_f4 x = { Wf[4 * v], Wf[4 * v + 1], Wf[4 * v + 2], Wf[4 * v + 3] }; *reinterpret_cast<rvq_f4*>(fline + w0 + 4 * v) = x; }
-					}
-					else {
-						if (w0 < 0) w0 += RV_FSIZE;
+					for (int v = 0; v < 4; v++) { const rvq_v4 x = { Wf[4 * v], Wf[4 * v + 1], Wf[4 * v + 2], Wf[4 * v + 3] }; xq_mine[v] = x; }
+					wave_sync();
+					rvq_v4 quarter[4];
 #pragma unroll
-						for (int j = 0; j < RVQ_B; j++) {
-							int w = w0 + 2 * j; if (w >= RV_FSIZE) w -= RV_FSIZE;
-							const rvq_f2 pair = { Wf[2 * j], Wf[2 * j + 1] };
-							*reinterpret_cast<rvq_f2*>(fline + w) = pair;
-							if (w < RV_FPAD) *reinterpret_cast<rvq_f2*>(fline + w + RV_FSIZE) = pair;
-						}
+					for (int v = 0; v < 4; v++) quarter[v] = xq_quad[v * (RVQ_XQ_LD / 4)];
+					wave_sync();                                              // (the next batch's writes come after these reads)
+#pragma unroll
+					for (int v = 0; v < 4; v++) *reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0) = quarter[v];
+					if (w0 < RV_FPAD) {                                       // the mirrored head (two batches per lap of the ring)
+#pragma unroll
+						for (int v = 0; v < 4; v++) *reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0 + RV_FSIZE) = quarter[v];
 					}
 				}
 			}
+			pp0 = fin; pp1 = fin_new;
 			fin = fin_new;
 			const float o2 = biquad_process(ff, fdt2) * fgain;                // the `+` chain processes each FilteredDelay a second time
 			const float q0 = quad_bcast<0>(o2), q1 = quad_bcast<1>(o2), q2 = quad_bcast<2>(o2), q3 = quad_bcast<3>(o2);
@@ -1104,27 +1132,23 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 			Biquad elpf = { lb0, lb1, lb2, la1, la2, elz0, elz1 }, ehpf = { hb0, hb1, hb2, ha1, ha2, ehz0, ehz1 };
 			const float y = biquad_process(ehpf, biquad_process(elpf, x_in_now));
 			elz0 = elpf.z0; elz1 = elpf.z1; ehz0 = ehpf.z0; ehz1 = ehpf.z1;
+			We[(u + 2) & (RVQ_B - 1)] = y;
 			if constexpr (G) {
 				if (efilter) {
 					eline[ewpos] = y;
 					if (ewpos < RV_EPAD) eline[ewpos + RV_ESIZE] = y;         // mirror (a uniform test)
 				}
 			}
-			else {
-				We[u] = y;
-				if constexpr (u == RVQ_B - 1) if (efilter) {
-					const int w0 = ewpos - (RVQ_B - 1);
-					if (w0 >= RV_EPAD && ewpos < RV_ESIZE) {                      // uniform: the batch neither wraps nor touches the mirrored head
+			else if constexpr (u == RVQ_B - 3) {
+				if (efilter) {
+					const int w0 = ewpos - (RVQ_B - 1);                       // uniform and a multiple of 8 (the grid)
+					typedef float rvq_v4e __attribute__((ext_vector_type(4), aligned(16)));
+					rvq_v4e* const dst = reinterpret_cast<rvq_v4e*>(eline + w0);
 #pragma unroll
-						for (int v = 0; v < RVQ_B / 4; v++) { const rvq_f4 x = { We[4 * v], We[4 * v + 1], We[4 * v + 2], We[4 * v + 3] }; *reinterpret_cast<rvq_f4*>(eline + w0 + 4 * v) = x; }
-					}
-					else {
+					for (int v = 0; v < RVQ_B / 4; v++) { const rvq_v4e x = { We[4 * v], We[4 * v + 1], We[4 * v + 2], We[4 * v + 3] }; dst[v] = x; }
+					if (w0 < RV_EPAD) {
 #pragma unroll
-						for (int j = 0; j < RVQ_B; j++) {
-							int w = w0 + j; if (w < 0) w += RV_ESIZE;
-							eline[w] = We[j];
-							if (w < RV_EPAD) eline[w + RV_ESIZE] = We[j];
-						}
+						for (int j = 0; j < RVQ_B; j++) eline[w0 + j + RV_ESIZE] = We[j];
 					}
 				}
 			}
@@ -1136,35 +1160,54 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 		}
 		ssum_prev = ssum; lr_prev = lr_in;
 	};
-	auto batch = [&](auto guarded, auto younger, const int t0, auto set) __attribute__((always_inline)) {
+	// a batch: request the rows of the batch after next (into the set the previous batch has used), read the next batch's LDS values, run
+	auto batch = [&](auto guarded, auto guarded_next, const int t0, auto set, const RvqLds& L, auto set_req, RvqLds& Lnext) __attribute__((always_inline)) {
+		request(set_req);
+		fetch(guarded_next, Lnext, t0 + RVQ_B);
 		RvqRows X;
-		rvq_await<decltype(set)::value, decltype(younger)::value>(X);
-		step(guarded, IntTag<0>(), t0 + 0, X); step(guarded, IntTag<1>(), t0 + 1, X); step(guarded, IntTag<2>(), t0 + 2, X); step(guarded, IntTag<3>(), t0 + 3, X);
-		step(guarded, IntTag<4>(), t0 + 4, X); step(guarded, IntTag<5>(), t0 + 5, X); step(guarded, IntTag<6>(), t0 + 6, X); step(guarded, IntTag<7>(), t0 + 7, X);
+		rvq_await<decltype(set)::value, 8>(X);
+		step(guarded, IntTag<0>(), t0 + 0, X, L); step(guarded, IntTag<1>(), t0 + 1, X, L); step(guarded, IntTag<2>(), t0 + 2, X, L); step(guarded, IntTag<3>(), t0 + 3, X, L);
+		step(guarded, IntTag<4>(), t0 + 4, X, L); step(guarded, IntTag<5>(), t0 + 5, X, L); step(guarded, IntTag<6>(), t0 + 6, X, L); step(guarded, IntTag<7>(), t0 + 7, X, L);
 	};
 	const BoolTag<true> ramp; const BoolTag<false> steady;
 	// iterations t = -2 .. n in batches of eight; the rows of a batch are requested two batches ahead (a wave alone on its SIMD has nothing
 	// but distance to hide HBM latency with; a batch is about a microsecond).  The sched_barrier: the rows are REQUESTED there, not where used.
 	// (A request past the block's end reads rows that exist and are not used.)
-	const IntTag<8> y8; const IntTag<16> y16;                                   // what is certainly in flight behind a batch's rows (see RvqRows)
-	int t0 = -2;
-	request(Bn);
-	request(Cn); batch(ramp, y8, t0, A); t0 += RVQ_B;                           // t = -2 .. 5
+	int t0 = t_first;
+	request(Bn); fetch(ramp, LA, t0);
+	batch(ramp, ramp, t0, A, LA, Cn, LB); t0 += RVQ_B;                          // (iterations before t = -2 find every stage off)
+	batch(ramp, ramp, t0, Bn, LB, A, LC); t0 += RVQ_B;                          // ... up to t_s - 1
 	if (t0 + 3 * RVQ_B - 1 <= n - 3) {                                          // three steady batches per turn (t >= 1 and t + 2 < n throughout): the sets swap roles
-		request(A); batch(steady, y8, t0, Bn);                                  // (behind a guarded batch — which may have stored nothing — only the requests count)
-		request(Bn); batch(steady, y8, t0 + RVQ_B, Cn);
-		request(Cn); batch(steady, y8, t0 + 2 * RVQ_B, A);
-		for (t0 += 3 * RVQ_B; t0 + 3 * RVQ_B - 1 <= n - 3; t0 += 3 * RVQ_B) {
-			request(A); batch(steady, y8, t0, Bn);
-			request(Bn); batch(steady, y8, t0 + RVQ_B, Cn);
-			request(Cn); batch(steady, y8, t0 + 2 * RVQ_B, A);
+		for (; t0 + 6 * RVQ_B - 1 <= n - 3; t0 += 3 * RVQ_B) {                  // ... while a whole steady turn follows
+			batch(steady, steady, t0, Cn, LC, Bn, LA);
+			batch(steady, steady, t0 + RVQ_B, A, LA, Cn, LB);
+			batch(steady, steady, t0 + 2 * RVQ_B, Bn, LB, A, LC);
+		}
+		batch(steady, steady, t0, Cn, LC, Bn, LA);                              // the last steady turn: what follows it is guarded
+		batch(steady, steady, t0 + RVQ_B, A, LA, Cn, LB);
+		batch(steady, ramp, t0 + 2 * RVQ_B, Bn, LB, A, LC);
+		t0 += 3 * RVQ_B;
+		// what the steady batches still hold: mid[]'s pair of the last iteration, the early samples of the last two
+		{
+			int fb = fpos0 + 2 * (t0 - 1); while (fb >= RV_FSIZE) fb -= RV_FSIZE;                   // late[]'s cursor of iteration t0 - 1; mid[]'s is one sample ahead
+			int w = fb + 2; if (w >= RV_FSIZE) w -= RV_FSIZE;
+			if (cf) {
+				const rvq_f2 pair = { pp0, pp1 };
+				*reinterpret_cast<rvq_f2*>(fline + w) = pair;
+				if (w < RV_FPAD) *reinterpret_cast<rvq_f2*>(fline + w + RV_FSIZE) = pair;
+			}
+			int ew = epos0 + t0; while (ew >= RV_ESIZE) ew -= RV_ESIZE;                             // the early cursor of iteration t0 - 2 (sample t0), a multiple of 8
+			if (efilter) {
+				eline[ew] = We[0]; eline[ew + 1] = We[1];
+				if (ew < RV_EPAD) { eline[ew + RV_ESIZE] = We[0]; eline[ew + 1 + RV_ESIZE] = We[1]; }
+			}
 		}
 	}
 	// the last batches, guarded (the roles of the sets stay compile-time: no array ever lives in memory); at most two of them could have been steady
-	if (t0 <= n) { request(A); batch(ramp, y8, t0, Bn); t0 += RVQ_B; }
-	if (t0 <= n) { request(Bn); batch(ramp, y8, t0, Cn); t0 += RVQ_B; }
-	if (t0 <= n) { request(Cn); batch(ramp, y8, t0, A); t0 += RVQ_B; }
-	if (t0 <= n) { request(A); batch(ramp, y8, t0, Bn); t0 += RVQ_B; }
+	if (t0 <= n) { batch(ramp, ramp, t0, Cn, LC, Bn, LA); t0 += RVQ_B; }
+	if (t0 <= n) { batch(ramp, ramp, t0, A, LA, Cn, LB); t0 += RVQ_B; }
+	if (t0 <= n) { batch(ramp, ramp, t0, Bn, LB, A, LC); t0 += RVQ_B; }
+	if (t0 <= n) { batch(ramp, ramp, t0, Cn, LC, Bn, LA); t0 += RVQ_B; }
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // (requests past the block's end land in accumulation registers nobody reads)
 	wave_sync();
 	if (whole) {
