@@ -288,7 +288,7 @@ def run_fx(patch, K, N):
            "value": K * N * SCRIPT_BLOCKS / dt, "unit": "instance*samples/s", "ms_per_step": 1e3 * dt / SCRIPT_BLOCKS, "steps": SCRIPT_BLOCKS, "kernel_ms_mean": 1e3 * kern_s,
            "finite": bool(torch.isfinite(io).all().item()),
            "roofline": {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": KERNEL_OF[patch], "algorithmic_bytes_per_launch": ab, "bytes_per_instance_sample": FX_BYTES_PER_SAMPLE[patch]}}
+                        "kernel": ("klg_fx_reverb_q" if patch == "reverb" and K <= 8192 else KERNEL_OF[patch]), "algorithmic_bytes_per_launch": ab, "bytes_per_instance_sample": FX_BYTES_PER_SAMPLE[patch]}}
     bank.close()
     return res
 

@@ -24,6 +24,7 @@ struct klg_fx {
 	std::vector<host::ControlH> controls;              // [K][nctl]
 	std::vector<FxUpdate> upd;
 	std::vector<RvHost> rv;
+	std::vector<int> rv_touched; std::vector<unsigned char> rv_flag;   // Reverb instances whose dials were set since their last prepare() (Controls::changed() is only evaluated for those)
 	BiquadCoef pp_dc;
 	int rv_layout = 1;                                 // Reverb ring layout: 1 = a contiguous ring per (instance, line) [klg_fx_reverb_q], 0 = tiles of 64 instances [klg_fx_reverb16]
 	bool timing = false; std::vector<hipEvent_t> tev; int launches = 0;
@@ -110,7 +111,7 @@ extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate,
 		else if (c < 5) f->upd.push_back({ k, RV_CTL + c, f2i(dials[c].initial) });
 	}
 	if (pp) f->pp_dc = design_biquad(true, 50.f, 1.f, f->fs);                          // dcfilter[k].set(50, 1)  PingPong.k:39-40
-	else f->rv.resize(instances);
+	else { f->rv.resize(instances); f->rv_flag.assign(instances, 1); f->rv_touched.resize(instances); for (int k = 0; k < instances; k++) f->rv_touched[k] = k; }
 	return f;
 }
 
@@ -167,7 +168,10 @@ extern "C" int klg_fx_set_control(klg_fx* f, int instance, int index, float valu
 	c.set(value);                                                                   // Control::set clamps (klang.h:1725-1728)
 	if (f->graph) { f->h_controls[(size_t)instance * KLG_MAX_CTL + index] = c.value; f->controls_dirty = true; return 0; }
 	if (f->patch == KLG_PATCH_PINGPONG) f->upd.push_back({ instance, index, f2i(c.value) });
-	else if (index < 5) f->upd.push_back({ instance, RV_CTL + index, f2i(c.value) });
+	else {
+		if (index < 5) f->upd.push_back({ instance, RV_CTL + index, f2i(c.value) });
+		if (!f->rv_flag[instance]) { f->rv_flag[instance] = 1; f->rv_touched.push_back(instance); }
+	}
 	return 0;
 }
 
@@ -309,7 +313,11 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
 
 static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 	if (f->graph) return fx_enqueue_graph(f, d_io, n, st);
-	if (f->patch == KLG_PATCH_REVERB) for (int k = 0; k < f->K; k++) rv_prepare(f, k);
+	if (f->patch == KLG_PATCH_REVERB && !f->rv_touched.empty()) {                    // prepare(): `if (controls.changed())` Reverb.k:238 — a dial changes only through klg_fx_set_control
+		std::sort(f->rv_touched.begin(), f->rv_touched.end());                        // (instance order: every changed instance re-seeds and draws from rand())
+		for (int k : f->rv_touched) { rv_prepare(f, k); f->rv_flag[k] = 0; }
+		f->rv_touched.clear();
+	}
 	if (int rc = fx_flush_updates(f, st)) return rc;
 	if (f->timing) {
 		if ((int)f->tev.size() < 2 * (f->launches + 1)) { hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); f->tev.push_back(e0); f->tev.push_back(e1); }
@@ -323,7 +331,8 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		a.io = d_io; a.n = n;
 		a.fs.f = f->fs.f; a.fs.w = f->fs.w; a.fs.timeInc = 1.0f / f->fs.f;
 		a.dc = f->pp_dc; a.c1_min = PP_DIALS[1].min; a.c1_max = PP_DIALS[1].max;
-		{ const char* e = getenv("KLG_FX_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+		static const int ablate = []() { const char* e = getenv("KLG_FX_ABLATE"); return e ? atoi(e) : 0; }();
+		a.ablate = ablate;
 		static const bool single_wave = []() { const char* e = getenv("KLG_FX_PINGPONG1"); return e && e[0] == '1'; }();
 		if (single_wave || a.ablate) hipLaunchKernelGGL(klg_fx_pingpong, grid, block, 0, st, a);   // one wave per 64 instances (A/B reference, ablation)
 		else hipLaunchKernelGGL(klg_fx_pingpong_x, grid, dim3(PPX_THREADS), 0, st, a);             // control / audio / filter pipeline over eleven waves
