@@ -118,7 +118,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		ctx.ctl = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
 		// Dead lanes of a live wave run the same instruction stream on an all-zero record (no per-sample exec
 		// masking); their output is forced to 0 at the tile write and their record is never stored.
-		rw.w[0] = live ? flags : 0u;
+		rw.w[0] = live ? flags : (uint32_t)ST_OFF;                  // (a lane without a voice: an all-zero record whose note stage says Off)
 #pragma unroll
 		for (int w = 1; w < W; w++) rw.w[w] = live ? a.state[(size_t)w * a.stride + v] : 0u;
 		rw.to(rec);

@@ -175,17 +175,32 @@ struct PatchSuperSaw {
 	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc[0].offset, 1) | KLG_W(Rec, osc[1].offset, 1) | KLG_W(Rec, osc[2].offset, 1)
 		| KLG_W(Rec, osc[3].offset, 1) | KLG_W(Rec, osc[4].offset, 1) | KLG_W(Rec, osc[5].offset, 1) | KLG_W(Rec, osc[6].offset, 1) | KLG_W(Rec, adsr.r_out, 4);
 	static constexpr int kWavesPerEu = 4;
-	struct Live { Osm osc[7]; Adsr adsr; int stage; };
+	struct Live { Osm osc[7]; Adsr adsr; int stage; bool duty0; };
 	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {
 		L.stage = (int)(r.flags & 3u);
 		adsr_load(L.adsr, r.adsr, KLG_FLAG_GET(r.flags, 2, 6));
+		bool general = false;
 #pragma unroll
-		for (int k = 0; k < 7; k++) osm_load(L.osc[k], r.osc[k], KLG_FLAG_GET(r.flags, 8 + 2 * k, 2));
+		for (int k = 0; k < 7; k++) { osm_load(L.osc[k], r.osc[k], KLG_FLAG_GET(r.flags, 8 + 2 * k, 2)); general = general || L.osc[k].duty != 0u || L.osc[k].state != 0; }
+		// SuperSaw.k's oscillators are Saw() — Osm(&OSM::saw, 0.f), a duty nobody sets: while no voice of the wave has one (and every
+		// state machine rests in Down) the seven saws take the two-case form of osm_saw_duty0 instead of the general table (wave-uniform,
+		// decided once per block: nothing inside a block gives a saw a duty)
+		L.duty0 = __ballot(general) == 0ull;
+	}
+	static __device__ __forceinline__ float saws(Live& L) {
+		float out = 0.f;
+		if (L.duty0) {
+#pragma unroll
+			for (int k = 0; k < 7; k++) out += div_const<0x40e00000u>(osm_saw_duty0(L.osc[k]));   // `/ 7` SuperSaw.k:29
+		}
+		else {
+#pragma unroll
+			for (int k = 0; k < 7; k++) out += div_const<0x40e00000u>(osm_saw(L.osc[k]));
+		}
+		return out;
 	}
 	static __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {
-		float out = 0.f;
-#pragma unroll
-		for (int k = 0; k < 7; k++) out += div_const<0x40e00000u>(osm_saw(L.osc[k]));   // `/ 7` SuperSaw.k:29
+		float out = saws(L);
 		out *= adsr_process(L.adsr, c.fs);
 		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;
@@ -194,9 +209,7 @@ struct PatchSuperSaw {
 	static constexpr bool kHasQuiet = true;
 	static __device__ __forceinline__ int quiet(const Live& L) { return __ballot(!adsr_quiet(L.adsr)) == 0ull ? 1 : 0; }
 	static __device__ __forceinline__ float sample_quiet(Live& L, const BlockCtx& c) {
-		float out = 0.f;
-#pragma unroll
-		for (int k = 0; k < 7; k++) out += div_const<0x40e00000u>(osm_saw(L.osc[k]));
+		float out = saws(L);
 		out *= adsr_hold(L.adsr, c.fs);
 		return out;
 	}
@@ -257,6 +270,40 @@ struct PatchFM {
 		float out = m;
 		out *= adsr_process(L.adsr, c.fs) * 0.1f;
 		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
+		return out;
+	}
+	// An operator's Envelope that has run through its points is Off and stays at its last value until a host event (between blocks)
+	// restarts it: its per-sample work is `out = value`.  Chunks in which that holds for every operator of the wave run without the
+	// operator envelopes (klg_render: quiet() = 1), and without the ADSR's ramp too when every ADSR merely holds (= 2).
+	static constexpr bool kHasQuiet = true;
+	static __device__ __forceinline__ int quiet(const Live& L) {
+		bool busy = false;
+#pragma unroll
+		for (int k = 0; k < NOPS; k++) busy = busy || L.op[k].env.active || L.op[k].env.stage != ENV_OFF;
+		const bool sounding = L.stage != (int)ST_OFF;                      // (a lane without a voice, or whose note has ended, is heard by nobody: it does not veto)
+		if (__ballot(sounding && busy) != 0ull) return 0;
+		return __ballot(sounding && !adsr_quiet(L.adsr)) == 0ull ? 2 : 1;
+	}
+	static __device__ __forceinline__ float ops_frozen(Live& L) {
+		float m = 0.f;
+#pragma unroll
+		for (int k = 0; k < NOPS; k++) {
+			Op& o = L.op[k];
+			float y = fsine_process(o.osc, fsine_rel_offset(m));
+			y *= o.env.r_out * o.amp;                                      // env_process of an Off envelope returns its value and changes nothing
+			m = y;
+		}
+		return m;
+	}
+	static __device__ __forceinline__ float sample_quiet(Live& L, const BlockCtx& c) {
+		float out = ops_frozen(L);
+		out *= adsr_process(L.adsr, c.fs) * 0.1f;
+		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
+		return out;
+	}
+	static __device__ __forceinline__ float sample_fast(Live& L, const BlockCtx& c) {
+		float out = ops_frozen(L);
+		out *= adsr_hold(L.adsr, c.fs) * 0.1f;
 		return out;
 	}
 	static __device__ __forceinline__ void end(const Live& L, Rec& r) {

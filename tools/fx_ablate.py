@@ -19,7 +19,7 @@ print(json.dumps({"kernel_us": 1e3 * ms / n}))
 ''' % ROOT
 masks = [int(m) for m in sys.argv[1:]] or [0]
 BYTES = {"pingpong": 32, "reverb": 312}
-for patch, sizes in (("pingpong", (4096, 16384, 65536)), ("reverb", (1024, 2048, 4096, 8192, 16384))):
+for patch, sizes in (("pingpong", (4096, 16384, 65536)), ("reverb", (1024, 4096, 6144, 8192, 12288, 16384))):
     for K in sizes:
         for mask in (masks if patch == "pingpong" else [0]):
             out = subprocess.run([sys.executable, "-c", CHILD, str(K), patch], env=dict(os.environ, KLG_FX_ABLATE=str(mask)), capture_output=True, text=True)
