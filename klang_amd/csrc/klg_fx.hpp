@@ -898,7 +898,8 @@ template<int SET, int N> __device__ __forceinline__ void rvq_await(RvqRows& X) {
 __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	extern __shared__ float rvq_tiles[];
 	const int lane = threadIdx.x & 63, inst = lane >> 4, r = lane & 15;
-	float* const rvq_tile = rvq_tiles + (threadIdx.x >> 6) * (((RVQ_TILE_ROWS * a.n + 3) & ~3) + RVQ_XQ_FLOATS);
+	const int ns = ((a.n + 3) & ~3) + 4;                                    // LDS row stride: a block length of 64 k would put every row in the same banks (the eight rows are read side by side)
+	float* const rvq_tile = rvq_tiles + (threadIdx.x >> 6) * (RVQ_TILE_ROWS * ns + RVQ_XQ_FLOATS);
 	const int k0 = (blockIdx.x * (RVQ_WG / 64) + (threadIdx.x >> 6)) * 4, k = k0 + inst;
 	if (k0 >= (int)a.kpad) return;
 	const size_t KP = a.kpad;
@@ -910,24 +911,25 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	if (whole) {
 		const rvq_v4* src = reinterpret_cast<const rvq_v4*>(a.io + (size_t)k0 * 2 * n);
 		rvq_v4* dst = reinterpret_cast<rvq_v4*>(rvq_tile);
+		const int q4 = n >> 2;                                                  // 16-byte pieces per row
 		for (int c0 = 0; c0 < 2 * n; c0 += 8 * 64) {
 			rvq_v4 x[8];
 #pragma unroll
 			for (int j = 0; j < 8; j++) { const int c = c0 + j * 64 + lane; x[j] = src[c < 2 * n ? c : 0]; }
 #pragma unroll
-			for (int j = 0; j < 8; j++) { const int c = c0 + j * 64 + lane; if (c < 2 * n) dst[c] = x[j]; }
+			for (int j = 0; j < 8; j++) { const int c = c0 + j * 64 + lane; if (c < 2 * n) { const int R = c / q4; dst[R * (ns >> 2) + (c - R * q4)] = x[j]; } }
 		}
 	}
 	else for (int R = 0; R < 8; R++) {
 		const int ki = k0 + (R >> 1);
-		for (int c = lane; c < n; c += 64) rvq_tile[R * n + c] = (ki < a.K) ? a.io[((size_t)ki * 2 + (R & 1)) * n + c] : 0.f;
+		for (int c = lane; c < n; c += 64) rvq_tile[R * ns + c] = (ki < a.K) ? a.io[((size_t)ki * 2 + (R & 1)) * n + c] : 0.f;
 	}
 	// wave-uniform cursors of the block: every instance has processed the same number of samples
 	const int epos0 = __builtin_amdgcn_readfirstlane(a.epos % RV_ESIZE), fpos0 = __builtin_amdgcn_readfirstlane(a.fpos % RV_FSIZE);
 
 	// =========== phase 1: the early sums of the block, lane = sample ===========
 	// EarlyReflections::process Reverb.k:90-92 with Stereo::Delay::tap(float) klang.h:4668-4681 (both channels read at one cursor).
-	float* const r1_rows = rvq_tile + 9 * n;
+	float* const r1_rows = rvq_tile + 9 * ns;
 	{
 		typedef float rvq_f2u __attribute__((ext_vector_type(2), aligned(4)));
 		struct Taps { rvq_f2u l[20], r[20]; float fr[20]; };                    // per tap: positions i0, i0 + 1 of both lines (one 8-byte load each) and the fraction
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 				accl = d < cnt ? accl + pl : accl;                              // out += delay(times[d]) * gains[d], d < count
 				accr = d < cnt ? accr + pr : accr;
 			}
-			if (e < n) { r1_rows[(i * 2) * n + e] = accl; r1_rows[(i * 2 + 1) * n + e] = accr; }
+			if (e < n) { r1_rows[(i * 2) * ns + e] = accl; r1_rows[(i * 2 + 1) * ns + e] = accr; }
 		};
 		Taps T0, T1;
 		issue(0, T0);
@@ -994,8 +996,8 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	const int flast = __float_as_int(RVW(fw + FD_LASTP));
 	float* const fline = a.fd_rings + ((size_t)k * 16 + r) * RV_FSTRIDE;    // this (instance, line)'s own ring (+ mirror tail)
 	float* const fquad = a.fd_rings + ((size_t)k * 16 + (r & 12)) * RV_FSTRIDE + 4 * (r & 3);   // quarter r % 4 of a 64-byte piece of the quad's first line (see the steady batch's stores)
-	rvq_v4* const xq_mine = reinterpret_cast<rvq_v4*>(rvq_tile + ((RVQ_TILE_ROWS * n + 3) & ~3) + lane * RVQ_XQ_LD);                         // the quarter exchange: a lane's 16 floats, rows padded against bank conflicts
-	const rvq_v4* const xq_quad = reinterpret_cast<const rvq_v4*>(rvq_tile + ((RVQ_TILE_ROWS * n + 3) & ~3) + (lane & 60) * RVQ_XQ_LD + 4 * (r & 3));   // ... quarter r % 4 of the quad's lane 0 (lane v: + v rows)
+	rvq_v4* const xq_mine = reinterpret_cast<rvq_v4*>(rvq_tile + RVQ_TILE_ROWS * ns + lane * RVQ_XQ_LD);                         // the quarter exchange: a lane's 16 floats, rows padded against bank conflicts
+	const rvq_v4* const xq_quad = reinterpret_cast<const rvq_v4*>(rvq_tile + RVQ_TILE_ROWS * ns + (lane & 60) * RVQ_XQ_LD + 4 * (r & 3));   // ... quarter r % 4 of the quad's lane 0 (lane v: + v rows)
 	// row kk of the FDN matrix (Reverb.k:158-161): products are summed left to right
 	const float m0 = kk == 0 ? 0.f : kk == 3 ? 1.f : -1.f, m1 = kk == 1 ? 0.f : kk == 3 ? -1.f : 1.f, m2 = kk == 2 ? 0.f : kk == 1 ? -1.f : 1.f, m3 = kk == 3 ? 0.f : kk == 1 ? 1.f : -1.f;
 	// ---- the early filter of channel ech (every lane of the channel runs it on the same input: eight copies of one state; lane r % 8 == 0 stores) ----
@@ -1009,11 +1011,11 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	const int och = r == 12 ? 1 : 0;
 	const float dry = RVW(RV_CTL + 0), c1 = RVW(RV_CTL + 1), c2 = RVW(RV_CTL + 2), c3 = RVW(RV_CTL + 3), wet = RVW(RV_CTL + 4);
 	const float wet_o = och ? 0.f : wet;
-	float* const in_e = rvq_tile + (inst * 2 + ech) * n;                     // the filter lane's input row
-	float* const io_o = rvq_tile + (inst * 2 + och) * n;                     // the output lane's row
-	float* const io_w = outlane ? io_o : rvq_tile + 8 * n;                  // ... and where a lane stores "its" output sample: an unconditional ds_write, no exec-mask branch in the sample loop
+	float* const in_e = rvq_tile + (inst * 2 + ech) * ns;                     // the filter lane's input row
+	float* const io_o = rvq_tile + (inst * 2 + och) * ns;                     // the output lane's row
+	float* const io_w = outlane ? io_o : rvq_tile + 8 * ns;                  // ... and where a lane stores "its" output sample: an unconditional ds_write, no exec-mask branch in the sample loop
 	// the early sum a lane wants: mid[c] (lanes 4c .. 4c + 3) of its own sample t + 1, the output lane of channel c (8 / 12) of sample t - 1
-	const float* const r1_row = r1_rows + (inst * 2 + ((r < 4 || r == 8) ? 0 : 1)) * n;
+	const float* const r1_row = r1_rows + (inst * 2 + ((r < 4 || r == 8) ? 0 : 1)) * ns;
 	const int r1_at = r < 8 ? 1 : -1;
 
 	// ---- row requests, one batch ahead ----
@@ -1213,11 +1215,12 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	if (whole) {
 		rvq_v4* dst = reinterpret_cast<rvq_v4*>(a.io + (size_t)k0 * 2 * n);
 		const rvq_v4* src = reinterpret_cast<const rvq_v4*>(rvq_tile);
-		for (int c = lane; c < 2 * n; c += 64) dst[c] = src[c];
+		const int q4 = n >> 2;
+		for (int c = lane; c < 2 * n; c += 64) { const int R = c / q4; dst[c] = src[R * (ns >> 2) + (c - R * q4)]; }
 	}
 	else for (int R = 0; R < 8; R++) {
 		const int ki = k0 + (R >> 1);
-		if (ki < a.K) for (int c = lane; c < n; c += 64) a.io[((size_t)ki * 2 + (R & 1)) * n + c] = rvq_tile[R * n + c];
+		if (ki < a.K) for (int c = lane; c < n; c += 64) a.io[((size_t)ki * 2 + (R & 1)) * n + c] = rvq_tile[R * ns + c];
 	}
 	// ---- write back what changed ----
 	if (k < a.K) {

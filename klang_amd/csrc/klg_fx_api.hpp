@@ -350,7 +350,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		// right while every tap reads further back than the block is long — the shortest tap is (50 ms + ...) * random(0.9, 1.1) > 44.9 ms.
 		const bool taps_behind_block = (float)(n + 2) < 0.0449f * f->fs.f;
 		if (single_wave || f->fs.f < 16000.f || (f->rv_layout && !taps_behind_block)) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);   // one lane walks the whole graph (A/B reference; either layout)
-		else if (f->rv_layout) hipLaunchKernelGGL(klg_fx_reverb_q, dim3((unsigned)((f->kpad + 4 * (RVQ_WG / 64) - 1) / (4 * (RVQ_WG / 64)))), dim3(RVQ_WG), (size_t)(RVQ_WG / 64) * (((RVQ_TILE_ROWS * n + 3) & ~3) + RVQ_XQ_FLOATS) * sizeof(float), st, a);   // one wave per four instances
+		else if (f->rv_layout) hipLaunchKernelGGL(klg_fx_reverb_q, dim3((unsigned)((f->kpad + 4 * (RVQ_WG / 64) - 1) / (4 * (RVQ_WG / 64)))), dim3(RVQ_WG), (size_t)(RVQ_WG / 64) * (RVQ_TILE_ROWS * (((n + 3) & ~3) + 4) + RVQ_XQ_FLOATS) * sizeof(float), st, a);   // one wave per four instances
 		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances (KLG_FX_REVERB16=1)
 	}
 	HIP_TRY(hipGetLastError());
