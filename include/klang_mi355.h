@@ -54,8 +54,15 @@ enum { KLG_STAGE_ONSET = 0, KLG_STAGE_SUSTAIN = 1, KLG_STAGE_RELEASE = 2, KLG_ST
 const char* klg_last_error(void);
 int klg_version(void);
 
-/* Select the GPU this process renders on (one process per GPU).  device_ids[0] is used; n_devices
- * must be 1.  Without this call device 0 is used.  (No reference equivalent: the reference is CPU.) */
+/* Select the GPU(s) this process renders on.  n_devices == 1: every bank created afterwards lives on
+ * device_ids[0] (the one-process-per-GPU arrangement; without this call device 0 is used).
+ * n_devices in 2..64: every synth bank created afterwards SPANS the listed devices — its instances are
+ * dealt to them in contiguous ranges, note and control calls are routed by instance, and
+ * klg_process / klg_process_device render every share and combine the [channels][n] blocks with ONE
+ * ncclAllReduce (RCCL, loaded on first use) before returning the global mix; a device listed more than
+ * once gets as many shares, combined by a plain add.  Returns KLG_ERR_INVALID for n < 1 or n > 64 or an
+ * id the runtime does not know.  (No reference equivalent: the reference is CPU;
+ * this is what lets ONE Stereo::Synth::process(float**, int, float*) of klang.h:4830 cover a node.) */
 int klg_init(const int* device_ids, int n_devices);
 
 /* klang::random(seed) (klang.h:239): seeds the libc rand() stream the host-side on() code of
