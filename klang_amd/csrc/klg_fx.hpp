@@ -248,6 +248,9 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	const int SIZE = 192000, n = a.n;
 	const int nchunks = (n + PPX_CHUNK - 1) / PPX_CHUNK;
 	const bool w_control = wv == 0, w_audio = wv >= 1 && wv <= PPX_AUDIO, w_filter = wv > PPX_AUDIO;
+	// the control and filter waves are dependent chains that pace the pipeline; the audio waves share their SIMDs and mostly wait for
+	// memory: when both are ready, the chain issues first
+	if (!w_audio) __builtin_amdgcn_s_setprio(3);
 	const float* W = a.state + k;
 #define PPW(w) W[(size_t)(w) * a.kpad]
 	// ---- control wave state (PingPong.k:44-60) ----
