@@ -1,7 +1,10 @@
 // include/klang/host/wav.hpp — RIFF/WAVE writer and reader for the headless host.
 // replaces: File::WAV decode of the reference (klang.h:5991-6099, the data a Sample plays) and the audio device the JUCE
 // wrapper writes to.  Writer: 32-bit float or 16-bit PCM, interleaved.  Reader: PCM 8/16/24/32 and float 32/64, any channel
-// count, returned de-interleaved as floats in [-1, 1).
+// count, returned de-interleaved as floats in [-1, 1).  Mono PCM 8 / 16 / 32 and float 32 — everything File::WAV decodes — give
+// the reference's floats bit for bit (tests/test_host_render.py::test_wav_reader_matches_the_reference_decoder, fixtures from
+// oracle/gen_golden_wav.py); the reference hands a multi-channel file to its buffer as the first `frames` samples of the
+// INTERLEAVED stream (klang.h:6085-6095: `decode<T>(.., buffer.size)` with STEP 1), this reader de-interleaves instead.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -60,7 +63,7 @@ inline bool wav_read(const char* path, WavData& out) {
 		float x = 0.f;
 		if (fmt == 3 && bits == 32) std::memcpy(&x, p, 4);
 		else if (fmt == 3 && bits == 64) { double v; std::memcpy(&v, p, 8); x = (float)v; }
-		else if (bits == 8) x = ((int)p[0] - 128) / 128.f;
+		else if (bits == 8) x = ((float)p[0] - 128.f) * (1.f / 255.f);                       // as the reference decodes unsigned samples: (x - 2^7) / (2^8 - 1), klang.h:6070-6075
 		else if (bits == 16) x = (float)(int16_t)(p[0] | (p[1] << 8)) / 32768.f;
 		else if (bits == 24) x = (float)(((int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24)) >> 8) / 8388608.f;
 		else if (bits == 32) { int32_t v; std::memcpy(&v, p, 4); x = (float)((double)v / 2147483648.0); }

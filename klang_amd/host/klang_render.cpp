@@ -17,6 +17,7 @@
 //                       p selects presets[p]
 //     --events          print the merged, time-stamped MIDI messages and exit (no GPU needed)
 //   klang_render --wav-info file.wav      decode a WAV file (the reader a Sample's data comes through) and print its shape
+//   klang_render --wav-dump file.wav      ... and print channel 0 as the bit patterns of its floats
 // Events that fall inside a block are delivered before that block is rendered (as the reference's processBlock does: it
 // ignores the messages' sample offsets).
 #include <cmath>
@@ -47,6 +48,14 @@ int main(int argc, char** argv) {
 		if (!klang::host::wav_read(argv[2], w)) { std::fprintf(stderr, "%s: %s\n", argv[2], w.error.c_str()); return 1; }
 		std::printf("rate %d channels %zu frames %zu\n", w.sample_rate, w.channels.size(), w.channels.empty() ? (size_t)0 : w.channels[0].size());
 		for (size_t c = 0; c < w.channels.size(); c++) { double sum = 0, peak = 0; for (float x : w.channels[c]) { sum += x; peak = std::fabs(x) > peak ? std::fabs(x) : peak; } std::printf("channel %zu sum %.9g peak %.9g first %.9g\n", c, sum, peak, w.channels[c].empty() ? 0.0 : (double)w.channels[c][0]); }
+		return 0;
+	}
+	if (argc == 3 && std::string(argv[1]) == "--wav-dump") {                     // channel 0 as the bit patterns of its floats (parity with the reference's decoder)
+		klang::host::WavData w;
+		if (!klang::host::wav_read(argv[2], w)) { std::fprintf(stderr, "%s: %s\n", argv[2], w.error.c_str()); return 1; }
+		const std::vector<float> none; const std::vector<float>& c0 = w.channels.empty() ? none : w.channels[0];
+		std::printf("%zu\n", c0.size());
+		for (float x : c0) { unsigned u; std::memcpy(&u, &x, 4); std::printf("%08x\n", u); }
 		return 0;
 	}
 	for (int i = 1; i < argc; i++) {

@@ -134,6 +134,18 @@ def test_wav_reader_decodes_float32_and_pcm24(tmp_path):
     assert float(out[1].split()[7]) == pytest.approx(q[0] / 8388608.0, rel=1e-6) and float(out[1].split()[5]) == pytest.approx(np.abs(q).max() / 8388608.0, rel=1e-6)
 
 
+@pytest.mark.parametrize("name", ["u8", "s16", "s32", "f32"])
+def test_wav_reader_matches_the_reference_decoder(name):
+    """include/klang/host/wav.hpp against File::WAV of the genuine header (klang.h:5991-6099) on every encoding that decoder knows:
+    the committed files of tests/golden/wav/ were decoded by oracle/_ref/ref_wav (oracle/gen_golden_wav.py) — bit for bit."""
+    golden = os.path.join(ROOT, "tests", "golden")
+    want = np.load(os.path.join(golden, "wav_expected.npz"))[name]
+    lines = subprocess.run([host("klang_render"), "--wav-dump", os.path.join(golden, "wav", name + ".wav")], capture_output=True, text=True, check=True).stdout.split()
+    got = np.array([int(x, 16) for x in lines[1:]], dtype=np.uint32)
+    assert int(lines[0]) == len(want) == len(got)
+    assert np.array_equal(got, want)
+
+
 def read_wav_f32(path):
     d = open(path, "rb").read()
     assert d[:4] == b"RIFF" and d[8:16] == b"WAVEfmt "
