@@ -200,6 +200,27 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
 				// the rare path" — some twenty register moves per sample.  So the sample loop only DETECTS a segment end and leaves; the rare
 				// code runs between two runs of the loop.
 				int s = 0;
+				// Most chunks of a ramp cannot reach its end: a voice still further from its target than (chunk + 2) steps (plus what sixteen
+				// roundings of a value <= 2 can add up to) neither clamps nor goes idle inside the chunk, so the chunk runs the bare step with no
+				// per-sample test at all (a wave-uniform decision; voices whose idle ramp means nothing — holding at sustain, Off — do not count).
+				{
+					const f2 d = __builtin_elementwise_abs(L.r_target - L.r_out);
+					const f2 lim = __builtin_elementwise_abs(L.srate) * (float)(X2_CHUNK + 2) + 4e-6f;
+					const i2 may = ~(d > lim) & L.special;                            // (not `d <= lim`: a NaN — the rate of a zero-length segment — must count as "may")
+					if (cl == X2_CHUNK && __ballot((may.x | may.y) != 0) == 0ull) {
+						// ... and without the clamp: a ramp that cannot arrive steps by exactly its rate (the median of (out, out + rate, target) IS
+						// out + rate), an idle one by -0.0 (x + -0.0 == x for every x, either zero included)
+						const f2 step = (L.r_out != L.r_target) ? L.srate : splat(-0.f);
+#pragma unroll 4
+						for (; s < X2_CHUNK; s++) {
+							const f2 y = sub2a_x2_osc_filter(L);
+							const f2 env = L.r_out;
+							L.r_out = env + step;
+							L.time += L.tinc;
+							tile[s * X2_LD + lane] = y * env;                          // out *= adsr++
+						}
+					}
+				}
 				while (s < cl) {
 					i2 rare = (i2)0;
 #pragma unroll 4
