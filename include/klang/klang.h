@@ -24,7 +24,7 @@
 //     (`osc(f * (1 + lfo * depth))`: vibrato / FM by set(f)), the Basic oscillators, Operator<Sine> chains (`op1 * I >> op2 >> out`),
 //     Wavetable / Sample (samples in HBM, klg_table_upload) and Table<float, N> reads with a recorded index, Delay<SIZE> members
 //     (a line per voice in HBM: set(time) / clear() in on(), `delay >> x`, `delay << out`, `delay(time)` in process()),
-//     every Biquad type, OnePole, DCF, IIR<1>, Butterworth, Modal, Envelope::Follower (Biquad::LPF also set(f, Q) per sample), Envelope
+//     every Biquad type, OnePole, DCF, IIR<1>, IIR<2..8>, Butterworth, Modal, Envelope::Follower (Biquad::LPF also set(f, Q) per sample), Envelope
 //     (<= 4 points, setLoop) and ADSR `++`, + - * / and unary minus on signals / params / controls / constants, `.out` of a
 //     member, signal and param members of the Note (read, and written for next-sample state), `>> out`, `out *= x`,
 //     `if (env.finished()) stop();`, and data-dependent `if` / `else if` / `&&` / `!` on comparisons of signals, params and controls
@@ -657,8 +657,22 @@ namespace Biquad {
 		void pack(uint32_t* w) const override { w[klg::graph::DCF_R] = gpu::fbits(r); w[klg::graph::DCF_Z] = gpu::fbits(z); w[klg::graph::DCF_OUT] = gpu::fbits(out.value); }
 		void unpack(const uint32_t* w) override { std::memcpy(&z, &w[klg::graph::DCF_Z], 4); std::memcpy(&out.value, &w[klg::graph::DCF_OUT], 4); }
 	};
-	// Filters::IIR<1> klang.h:5434-5447 (the general IIR<ORDER> exists as a device primitive, not as a recorded node yet)
-	template<int ORDER> struct IIR;
+	// Filters::IIR<ORDER> klang.h:5399-5432: `out = in - sum a[i] * y[i]` over the last ORDER outputs (node kind iirn, ORDER 2..8)
+	template<int ORDER> struct IIR : Modifier, gpu::Packable {
+		static_assert(ORDER >= 2 && ORDER <= 8, "IIR<ORDER>: orders 2..8 are recorded (IIR<1> is its own node)");
+		float a[ORDER] = { };
+		float y[ORDER] = { };
+		IIR() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(IIR<ORDER>), klg::graph::N_IIRN, this, ORDER); }
+		template<typename... Coeffs> void set(Coeffs... coeffs) {
+			static_assert(sizeof...(coeffs) == ORDER, "Incorrect number of coefficients.");
+			if (gpu::no_set_while_recording("IIR<ORDER>::set()")) return;
+			const float c[ORDER] = { (float)coeffs... };
+			for (int i = 0; i < ORDER; i++) a[i] = c[i];
+		}
+		void process() override { if (gpu::recording()) { gpu::record_modifier(this, "IIR<ORDER>"); return; } device_only("IIR<ORDER>::process()"); }
+		void pack(uint32_t* w) const override { for (int i = 0; i < ORDER; i++) { w[i] = gpu::fbits(a[i]); w[ORDER + i] = gpu::fbits(y[i]); } }
+		void unpack(const uint32_t* w) override { for (int i = 0; i < ORDER; i++) std::memcpy(&y[i], &w[ORDER + i], 4); }
+	};
 	template<> struct IIR<1> : Modifier, gpu::Packable {
 		float a = 1, b = 0;
 		IIR() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(IIR<1>), klg::graph::N_IIR1, this); }

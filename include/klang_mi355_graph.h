@@ -68,6 +68,7 @@ enum NodeKind {
 	N_NDELAY = 24,  /* Delay<SIZE> member of a NOTE (physical models: a delay line per voice)  3381-3512   words: position (write cursor),
 	                                                                        last.position, last.fraction (the read head of Delay::process, set by set()), time;
 	                                                                        the SIZE floats of each voice's line are contiguous in HBM (voices' cursors never line up) */
+	N_IIRN = 25,    /* Filters::IIR<ORDER>, ORDER 2..8  5399-5432           words: a[ORDER] then y[ORDER] (the node's argument is ORDER) */
 	N_KINDS
 };
 enum { FSINE_INC = 0, FSINE_POS, FSINE_FREQ, FSINE_WORDS };
@@ -88,8 +89,8 @@ enum { ND_POS = 0, ND_LASTPOS, ND_LASTFRAC, ND_TIME, ND_WORDS };
 enum { MAX_WORDS = 128, MAX_NODES = 64, MAX_OPS = 1024 };
 
 inline bool is_oscillator(int k) { return k == N_FSINE || k == N_SAW || k == N_PULSE || (k >= N_BSINE && k <= N_BPULSE) || k == N_WAVETABLE; }
-inline bool is_modifier(int k) { return k == N_LPF || (k >= N_OPLPF && k <= N_FOLLOWRMS); }
-inline int node_words(int kind) {
+inline bool is_modifier(int k) { return k == N_LPF || (k >= N_OPLPF && k <= N_FOLLOWRMS) || k == N_IIRN; }
+inline int node_words(int kind, int arg = 0) {
 	switch (kind) {
 	case N_FSINE: return FSINE_WORDS;
 	case N_SAW: case N_PULSE: return OSM_WORDS;
@@ -109,12 +110,13 @@ inline int node_words(int kind) {
 	case N_SMOOTH: return 1;
 	case N_WAVETABLE: return WT_WORDS;
 	case N_NDELAY: return ND_WORDS;
+	case N_IIRN: return 2 * arg;
 	}
 	return 0;
 }
 inline const char* node_name(int kind) {
 	static const char* names[N_KINDS] = { "fsine", "saw", "pulse", "lpf", "env", "adsr", "param", "bsine", "bsaw", "btri", "bsquare", "bpulse",
-	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator", "delay", "smooth", "wavetable", "notedelay" };
+	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator", "delay", "smooth", "wavetable", "notedelay", "iirn" };
 	return (kind >= 0 && kind < N_KINDS) ? names[kind] : "?";
 }
 
@@ -171,8 +173,8 @@ struct Program {
 	int arg(int node) const { return node < (int)node_arg.size() ? node_arg[(size_t)node] : 0; }
 
 	int noise_calls() const { int k = 0; for (const Op& o : ops) if (o.code == OP_NOISE) k++; return k; }   /* rand() draws per sample */
-	int words() const { int w = 1; for (int k : nodes) w += node_words(k); return w; }
-	int node_word0(int node) const { int w = 1; for (int i = 0; i < node; i++) w += node_words(nodes[(size_t)i]); return w; }
+	int words() const { int w = 1; for (size_t i = 0; i < nodes.size(); i++) w += node_words(nodes[i], arg((int)i)); return w; }
+	int node_word0(int node) const { int w = 1; for (int i = 0; i < node; i++) w += node_words(nodes[(size_t)i], arg(i)); return w; }
 
 	std::string text() const {
 		std::string s = "klgg 1\n";
@@ -217,7 +219,8 @@ struct Program {
 				if (k < 0) return bad("unknown node kind");
 				if ((int)nodes.size() >= MAX_NODES) return bad("too many nodes");
 				if ((k == N_DELAY || k == N_NDELAY) && (size < 2 || size > (1 << 24))) return bad("delay needs its SIZE (2 .. 2^24)");
-				nodes.push_back(k); node_arg.push_back((k == N_DELAY || k == N_NDELAY) ? size : 0);
+				if (k == N_IIRN && (size < 2 || size > 8)) return bad("iirn needs its ORDER (2 .. 8)");
+				nodes.push_back(k); node_arg.push_back((k == N_DELAY || k == N_NDELAY || k == N_IIRN) ? size : 0);
 			}
 			else if (!strcmp(kw, "op")) {
 				char code[32]; Op o; unsigned imm;

@@ -134,6 +134,15 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			end += W(IIR1_OUT, "f2u(" + n + ".out)");
 			mark(w0 + IIR1_OUT, 1);
 			break;
+		case N_IIRN: {
+			const int order = g.arg((int)i);
+			live += fmt(" Iir<%d> n%zu;", order, i);
+			begin += "\t\t";
+			for (int q = 0; q < order; q++) begin += n + fmt(".a[%d] = ", q) + F(q) + "; " + n + fmt(".y[%d] = ", q) + F(order + q) + "; ";
+			begin += "\n";
+			for (int q = 0; q < order; q++) end += W(order + q, "f2u(" + n + fmt(".y[%d])", q));
+			mark(w0 + order, order);
+		} break;
 		case N_BUTTER1:
 			live += fmt(" Butter1 n%zu;", i);
 			begin += "\t\t" + n + ".b0 = " + F(BW1_B0) + "; " + n + ".a1 = " + F(BW1_A1) + "; " + n + ".z = " + F(BW1_Z) + "; " + n + ".out = " + F(BW1_OUT) + ";\n";
@@ -240,7 +249,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			else body += "\t\t" + std::string(k == N_FSINE ? "fsine_set_f(" : "osm_set_f(") + n + ", " + n + "f, " + a + ", c.fs.f);\n";
 			break;
 		case OP_LPF: {
-			const char* fn = k == N_LPF ? "biquad_process" : k == N_OPLPF ? "onepole_lpf_process" : k == N_OPHPF ? "onepole_process" : k == N_DCF ? "dcf_process" : k == N_IIR1 ? "iir1_process"
+			const char* fn = k == N_LPF ? "biquad_process" : k == N_OPLPF ? "onepole_lpf_process" : k == N_OPHPF ? "onepole_process" : k == N_DCF ? "dcf_process" : k == N_IIR1 ? "iir1_process" : k == N_IIRN ? "iir_process"
 				: k == N_BUTTER1 ? "butter1_process" : k == N_MODAL ? "modal_process" : k == N_FOLLOWPEAK ? "follower_peak" : "follower_rms";
 			body += d + fn + "(" + n + ", " + a + ");\n";
 		} break;
