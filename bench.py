@@ -271,6 +271,9 @@ def run_fx(patch, K, N):
     ts = torch.cuda.Stream()
     with torch.cuda.stream(ts):
         st = ts.cuda_stream
+        for _ in range(8):                       # untimed: silence in, silence out — the bank's 6-51 GB of zeroed delay lines are really there afterwards
+            bank.process_device(io.data_ptr(), N, st)
+        torch.cuda.synchronize()
         bank.timing_begin()
         t0 = time.perf_counter()
         for b in range(SCRIPT_BLOCKS):
