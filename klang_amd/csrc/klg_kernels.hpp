@@ -24,6 +24,7 @@
 namespace klg {
 
 enum { WG = 256, WAVES = 4, CHUNK = 32, TILE_LD = 65, MAX_BLOCK = 1024 };
+static_assert(CHUNK <= KLG_CHUNK_MAX, "a patch's quiet() looks KLG_CHUNK_MAX samples ahead");
 
 struct RenderArgs {
 	uint32_t* state;          // [W][stride]

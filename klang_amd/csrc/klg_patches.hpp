@@ -233,6 +233,7 @@ struct PatchSuperSaw {
 //   op1 * I1 >> op2 * I2 >> [op3 * I3 >>] opN >> out;  out *= adsr++ * 0.1f;
 // flags: [0:2) note | [2:8) adsr | [8+6k : 14+6k) operator k envelope ; meta: 2 bits npoints per operator
 // ---------------------------------------------------------------------------------------------
+enum { KLG_CHUNK_MAX = 32 };   // the longest chunk klg_render runs between two quiet() decisions (checked there)
 template<int NOPS>
 struct PatchFM {
 	using OpRec = klg::OpRec;                                                                // 10 words
@@ -240,8 +241,9 @@ struct PatchFM {
 	static constexpr uint64_t op_mask(int k) { return words(8 + 40 * (size_t)k + 4, 5); }   // pos, r_out, r_target, r_rate, time of operator k
 	static constexpr uint64_t kStoreMask = 1ull | op_mask(0) | op_mask(1) | op_mask(2) | (NOPS > 3 ? op_mask(3) : 0ull) | words(8 + 40 * (size_t)NOPS, 4);
 	struct Op { FSine osc; Env env; Pts2 p; int np; float amp; };
-	struct Live { Op op[NOPS]; Adsr adsr; int stage; };
+	struct Live { Op op[NOPS]; Adsr adsr; int stage; float step[NOPS + 1], tstep[NOPS + 1], tinc; };   // step / tstep: see quiet()
 	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx& c) {
+		L.tinc = c.fs.timeInc;
 		L.stage = (int)(r.flags & 3u);
 		adsr_load(L.adsr, r.adsr, KLG_FLAG_GET(r.flags, 2, 6));
 #pragma unroll
@@ -272,40 +274,45 @@ struct PatchFM {
 		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;
 	}
-	// An operator's Envelope that has run through its points is Off and stays at its last value until a host event (between blocks)
-	// restarts it: its per-sample work is `out = value`.  Chunks in which that holds for every operator of the wave run without the
-	// operator envelopes (klg_render: quiet() = 1), and without the ADSR's ramp too when every ADSR merely holds (= 2).
+	// Most chunks contain no envelope event at all: a ramp still further from its target than (chunk + 2) steps — plus what a chunk of
+	// roundings can add up to — neither clamps nor goes idle inside the chunk, and an idle envelope whose idleness means nothing (Off, or
+	// an ADSR holding at its sustain point) stays as it is.  When that holds for every envelope of every sounding voice of the wave
+	// (klg_render: quiet() = 2), the chunk runs `out = value; value += step; time += tstep` per envelope — two additions instead of the
+	// ramp's median, the activity bookkeeping and the wave-wide segment-end test.  The result is the same bits: the median of
+	// (out, out + rate, target) IS out + rate for a ramp that does not arrive, and an idle ramp steps by -0.0 (x + -0.0 == x).
 	static constexpr bool kHasQuiet = true;
-	static __device__ __forceinline__ int quiet(const Live& L) {
-		bool busy = false;
-#pragma unroll
-		for (int k = 0; k < NOPS; k++) busy = busy || L.op[k].env.active || L.op[k].env.stage != ENV_OFF;
-		const bool sounding = L.stage != (int)ST_OFF;                      // (a lane without a voice, or whose note has ended, is heard by nobody: it does not veto)
-		if (__ballot(sounding && busy) != 0ull) return 0;
-		return __ballot(sounding && !adsr_quiet(L.adsr)) == 0ull ? 2 : 1;
+	static __device__ __forceinline__ bool env_safe(const Env& e, bool settled, float& step, float& tstep, float tinc) {
+		const bool sustain = e.stage == ENV_SUSTAIN;
+		const float d = fabsf(e.r_target - e.r_out);
+		const float mag = fmaxf(1.f, fmaxf(fabsf(e.r_target), fabsf(e.r_out)));
+		const float lim = fabsf(e.r_rate) * (float)(KLG_CHUNK_MAX + 2) + mag * ((float)KLG_CHUNK_MAX * 2.4e-7f);
+		step = e.active ? ((e.r_target > e.r_out) ? e.r_rate : -e.r_rate) : -0.f;
+		tstep = sustain ? tinc : 0.f;
+		return e.active ? (d > lim) : !((sustain && !settled) || e.stage == ENV_RELEASE);      // (`d > lim` is false for a NaN / infinite rate: not safe)
 	}
-	static __device__ __forceinline__ float ops_frozen(Live& L) {
+	static __device__ __forceinline__ int quiet(Live& L) {
+		bool safe = true;
+#pragma unroll
+		for (int k = 0; k < NOPS; k++) safe = env_safe(L.op[k].env, false, L.step[k], L.tstep[k], L.tinc) && safe;
+		safe = env_safe(L.adsr.e, L.adsr.e.point == 2, L.step[NOPS], L.tstep[NOPS], L.tinc) && safe;
+		const bool sounding = L.stage != (int)ST_OFF;                      // (a lane without a voice, or whose note has ended, is heard by nobody: it does not veto)
+		return __ballot(sounding && !safe) == 0ull ? 2 : 0;
+	}
+	static __device__ __forceinline__ float env_glide(Env& e, float step, float tstep) { const float out = e.r_out; e.r_out = out + step; e.time += tstep; return out; }
+	static __device__ __forceinline__ float sample_fast(Live& L, const BlockCtx& c) {
 		float m = 0.f;
 #pragma unroll
 		for (int k = 0; k < NOPS; k++) {
 			Op& o = L.op[k];
 			float y = fsine_process(o.osc, fsine_rel_offset(m));
-			y *= o.env.r_out * o.amp;                                      // env_process of an Off envelope returns its value and changes nothing
+			y *= env_glide(o.env, L.step[k], L.tstep[k]) * o.amp;
 			m = y;
 		}
-		return m;
-	}
-	static __device__ __forceinline__ float sample_quiet(Live& L, const BlockCtx& c) {
-		float out = ops_frozen(L);
-		out *= adsr_process(L.adsr, c.fs) * 0.1f;
-		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
+		float out = m;
+		out *= env_glide(L.adsr.e, L.step[NOPS], L.tstep[NOPS]) * 0.1f;
 		return out;
 	}
-	static __device__ __forceinline__ float sample_fast(Live& L, const BlockCtx& c) {
-		float out = ops_frozen(L);
-		out *= adsr_hold(L.adsr, c.fs) * 0.1f;
-		return out;
-	}
+	static __device__ __forceinline__ float sample_quiet(Live& L, const BlockCtx& c) { return sample(L, c); }   // (level 1 is not used by this patch)
 	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
 		uint32_t f = (uint32_t)L.stage | (env_pack(L.adsr.e) << 2);
 #pragma unroll
