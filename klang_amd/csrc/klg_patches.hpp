@@ -123,14 +123,35 @@ struct PatchSub2a {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Event-free chunks.  Most chunks of a block contain no envelope EVENT: a ramp still further from its target than (chunk + 2) steps —
+// plus what a chunk of roundings can add up to — neither clamps nor goes idle inside the chunk, and an idle envelope whose idleness
+// means nothing (Off, or an ADSR holding at its sustain point) stays as it is.  When that holds for every envelope of every sounding
+// voice of a wave (a patch's quiet() = 2), the chunk runs `out = value; value += step; time += tstep` per envelope (env_glide) — two
+// additions instead of the ramp's median, the activity bookkeeping and the wave-wide segment-end test of env_process.  Same bits: the
+// median of (out, out + rate, target) IS out + rate for a ramp that does not arrive, and an idle ramp steps by -0.0 (x + -0.0 == x).
+// ---------------------------------------------------------------------------------------------
+enum { KLG_CHUNK_MAX = 32 };   // the longest chunk klg_render runs between two quiet() decisions (checked there)
+__device__ __forceinline__ bool env_safe(const Env& e, bool settled, float& step, float& tstep, float tinc) {
+	const bool sustain = e.stage == ENV_SUSTAIN;
+	const float d = fabsf(e.r_target - e.r_out);
+	const float mag = fmaxf(1.f, fmaxf(fabsf(e.r_target), fabsf(e.r_out)));
+	const float lim = fabsf(e.r_rate) * (float)(KLG_CHUNK_MAX + 2) + mag * ((float)KLG_CHUNK_MAX * 2.4e-7f);
+	step = e.active ? ((e.r_target > e.r_out) ? e.r_rate : -e.r_rate) : -0.f;
+	tstep = sustain ? tinc : 0.f;
+	return e.active ? (d > lim) : !((sustain && !settled) || e.stage == ENV_RELEASE);      // (`d > lim` is false for a NaN / infinite rate: not safe)
+}
+__device__ __forceinline__ float env_glide(Env& e, float step, float tstep) { const float out = e.r_out; e.r_out = out + step; e.time += tstep; return out; }
+
+// ---------------------------------------------------------------------------------------------
 // config 2b: the shipped subtractive.k (Square >> filter(env++, 10) >> out; out *= adsr)
 // flags: [0:2) note | [2:8) adsr | [8:14) env | [14:16) osm state
 // ---------------------------------------------------------------------------------------------
 struct PatchSub2b {
 	using Rec = rec::Sub2b;                                                                  // 1+4+8+10+9 = 32 words
 	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc.offset, 1) | KLG_W(Rec, adsr.r_out, 4) | KLG_W(Rec, env.r_out, 4) | KLG_W(Rec, filter, 9);
-	struct Live { Osm osc; Adsr adsr; Env env; Pts3 p; Biquad lpf; BiquadSweep sw; int stage; };
-	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {
+	struct Live { Osm osc; Adsr adsr; Env env; Pts3 p; Biquad lpf; BiquadSweep sw; int stage; float step[2], tstep[2], tinc; };
+	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx& c) {
+		L.tinc = c.fs.timeInc;
 		L.stage = (int)(r.flags & 3u);
 		adsr_load(L.adsr, r.adsr, KLG_FLAG_GET(r.flags, 2, 6));
 		L.env.r_out = r.env.r_out; L.env.r_target = r.env.r_target; L.env.r_rate = r.env.r_rate; L.env.time = r.env.time;
@@ -150,6 +171,21 @@ struct PatchSub2b {
 		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;
 	}
+	// event-free chunks (see env_safe above): the filter envelope and the ADSR glide
+	static constexpr bool kHasQuiet = true;
+	static __device__ __forceinline__ int quiet(Live& L) {
+		bool safe = env_safe(L.env, false, L.step[0], L.tstep[0], L.tinc);
+		safe = env_safe(L.adsr.e, L.adsr.e.point == 2, L.step[1], L.tstep[1], L.tinc) && safe;
+		return __ballot(L.stage != (int)ST_OFF && !safe) == 0ull ? 2 : 0;
+	}
+	static __device__ __forceinline__ float sample_fast(Live& L, const BlockCtx& c) {
+		const float fc = env_glide(L.env, L.step[0], L.tstep[0]);
+		biquad_lpf_set(L.lpf, L.sw, fc, 10.f, c.fs.w);
+		float out = biquad_process(L.lpf, osm_pulse(L.osc));
+		out *= env_glide(L.adsr.e, L.step[1], L.tstep[1]);
+		return out;
+	}
+	static __device__ __forceinline__ float sample_quiet(Live& L, const BlockCtx& c) { return sample(L, c); }   // (level 1 is not used by this patch)
 	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
 		osm_store(L.osc, r.osc);
 		adsr_store(L.adsr, r.adsr);
@@ -175,8 +211,9 @@ struct PatchSuperSaw {
 	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc[0].offset, 1) | KLG_W(Rec, osc[1].offset, 1) | KLG_W(Rec, osc[2].offset, 1)
 		| KLG_W(Rec, osc[3].offset, 1) | KLG_W(Rec, osc[4].offset, 1) | KLG_W(Rec, osc[5].offset, 1) | KLG_W(Rec, osc[6].offset, 1) | KLG_W(Rec, adsr.r_out, 4);
 	static constexpr int kWavesPerEu = 4;
-	struct Live { Osm osc[7]; Adsr adsr; int stage; bool duty0; };
-	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx&) {
+	struct Live { Osm osc[7]; Adsr adsr; int stage; bool duty0; float step, tstep, tinc; };
+	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx& c) {
+		L.tinc = c.fs.timeInc;
 		L.stage = (int)(r.flags & 3u);
 		adsr_load(L.adsr, r.adsr, KLG_FLAG_GET(r.flags, 2, 6));
 		bool general = false;
@@ -207,13 +244,22 @@ struct PatchSuperSaw {
 	}
 	// chunks in which every ADSR of the wave merely holds (klg_render: HasQuiet): the envelope is its value, only the Sustain clock runs
 	static constexpr bool kHasQuiet = true;
-	static __device__ __forceinline__ int quiet(const Live& L) { return __ballot(!adsr_quiet(L.adsr)) == 0ull ? 1 : 0; }
+	// ... and chunks without an envelope event (env_safe above): the ADSR glides (quiet() = 2)
+	static __device__ __forceinline__ int quiet(Live& L) {
+		if (__ballot(!adsr_quiet(L.adsr)) == 0ull) return 1;
+		const bool safe = env_safe(L.adsr.e, L.adsr.e.point == 2, L.step, L.tstep, L.tinc);
+		return __ballot(L.stage != (int)ST_OFF && !safe) == 0ull ? 2 : 0;
+	}
 	static __device__ __forceinline__ float sample_quiet(Live& L, const BlockCtx& c) {
 		float out = saws(L);
 		out *= adsr_hold(L.adsr, c.fs);
 		return out;
 	}
-	static __device__ __forceinline__ float sample_fast(Live& L, const BlockCtx& c) { return sample_quiet(L, c); }
+	static __device__ __forceinline__ float sample_fast(Live& L, const BlockCtx&) {
+		float out = saws(L);
+		out *= env_glide(L.adsr.e, L.step, L.tstep);
+		return out;
+	}
 	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
 		uint32_t f = (uint32_t)L.stage | (env_pack(L.adsr.e) << 2);
 #pragma unroll
@@ -233,7 +279,6 @@ struct PatchSuperSaw {
 //   op1 * I1 >> op2 * I2 >> [op3 * I3 >>] opN >> out;  out *= adsr++ * 0.1f;
 // flags: [0:2) note | [2:8) adsr | [8+6k : 14+6k) operator k envelope ; meta: 2 bits npoints per operator
 // ---------------------------------------------------------------------------------------------
-enum { KLG_CHUNK_MAX = 32 };   // the longest chunk klg_render runs between two quiet() decisions (checked there)
 template<int NOPS>
 struct PatchFM {
 	using OpRec = klg::OpRec;                                                                // 10 words
@@ -274,22 +319,8 @@ struct PatchFM {
 		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;
 	}
-	// Most chunks contain no envelope event at all: a ramp still further from its target than (chunk + 2) steps — plus what a chunk of
-	// roundings can add up to — neither clamps nor goes idle inside the chunk, and an idle envelope whose idleness means nothing (Off, or
-	// an ADSR holding at its sustain point) stays as it is.  When that holds for every envelope of every sounding voice of the wave
-	// (klg_render: quiet() = 2), the chunk runs `out = value; value += step; time += tstep` per envelope — two additions instead of the
-	// ramp's median, the activity bookkeeping and the wave-wide segment-end test.  The result is the same bits: the median of
-	// (out, out + rate, target) IS out + rate for a ramp that does not arrive, and an idle ramp steps by -0.0 (x + -0.0 == x).
+	// event-free chunks (see env_safe above): the five envelopes glide
 	static constexpr bool kHasQuiet = true;
-	static __device__ __forceinline__ bool env_safe(const Env& e, bool settled, float& step, float& tstep, float tinc) {
-		const bool sustain = e.stage == ENV_SUSTAIN;
-		const float d = fabsf(e.r_target - e.r_out);
-		const float mag = fmaxf(1.f, fmaxf(fabsf(e.r_target), fabsf(e.r_out)));
-		const float lim = fabsf(e.r_rate) * (float)(KLG_CHUNK_MAX + 2) + mag * ((float)KLG_CHUNK_MAX * 2.4e-7f);
-		step = e.active ? ((e.r_target > e.r_out) ? e.r_rate : -e.r_rate) : -0.f;
-		tstep = sustain ? tinc : 0.f;
-		return e.active ? (d > lim) : !((sustain && !settled) || e.stage == ENV_RELEASE);      // (`d > lim` is false for a NaN / infinite rate: not safe)
-	}
 	static __device__ __forceinline__ int quiet(Live& L) {
 		bool safe = true;
 #pragma unroll
@@ -298,7 +329,6 @@ struct PatchFM {
 		const bool sounding = L.stage != (int)ST_OFF;                      // (a lane without a voice, or whose note has ended, is heard by nobody: it does not veto)
 		return __ballot(sounding && !safe) == 0ull ? 2 : 0;
 	}
-	static __device__ __forceinline__ float env_glide(Env& e, float step, float tstep) { const float out = e.r_out; e.r_out = out + step; e.time += tstep; return out; }
 	static __device__ __forceinline__ float sample_fast(Live& L, const BlockCtx& c) {
 		float m = 0.f;
 #pragma unroll
