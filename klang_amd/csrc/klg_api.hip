@@ -19,6 +19,7 @@
 #include "klg_graph.hpp"
 #include "klg_fx.hpp"
 #include "klg_render_x2.hpp"
+#include "klg_render_lanes.hpp"
 
 #pragma clang fp contract(off)
 
@@ -118,6 +119,8 @@ struct klg_synth {
 	int device = 0;                              // the GPU this bank (or shard) lives on
 	int mix_mode = 0; int* d_solo = nullptr;      // klg_synth_set_mix_mode: KLG_MIX_LAST_ACTIVE keeps one voice per instance (d_solo[synths])
 	bool x2 = true;               // KLG_RENDER_X1=1 in the environment selects the one-voice-per-lane kernel (A/B tests)
+	bool lanes = false;           // SuperSaw banks that do not fill the chip: one oscillator per lane (klg_render_lanes.hpp); KLG_SUPERSAW_LANES=0 / 1 forces the choice
+	int grid_lanes = 0;
 	// graph patches (klg_graph.hpp): the render kernels come from a hipRTC code object instead of this library
 	const graphrt::Compiled* graph = nullptr;
 	hipModule_t module = nullptr;
@@ -293,7 +296,12 @@ static klg_synth* synth_create_common(int patch_id, const PatchInfo* pi, int syn
 	ok = ok && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_state, (size_t)s->W * s->stride * 4) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_controls, (size_t)s->S * KLG_MAX_CTL * 4) == hipSuccess;
-	ok = ok && hipMalloc(&s->d_partials, (size_t)s->grid * max_block * 4) == hipSuccess;
+	if (patch_id == KLG_PATCH_SUPERSAW) {
+		const char* e = getenv("KLG_SUPERSAW_LANES");
+		s->lanes = e ? e[0] == '1' : s->V <= KLG_LANES_MAX_VOICES;
+		s->grid_lanes = std::min((s->V + KLG_LANES_VOICES_PER_WG - 1) / KLG_LANES_VOICES_PER_WG, (ok ? prop.multiProcessorCount : 256) * 8);
+	}
+	ok = ok && hipMalloc(&s->d_partials, (size_t)std::max(s->grid, s->lanes ? s->grid_lanes : 0) * max_block * 4) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_mix, (size_t)2 * max_block * 4) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_scratch_rec, (size_t)std::max(64, s->W) * 4) == hipSuccess;
 	ok = ok && hipHostMalloc(&s->h_mix, (size_t)2 * max_block * 4) == hipSuccess;
@@ -413,6 +421,7 @@ template<class P> static void launch_render_t(klg_synth* s, const RenderArgs& a,
 	else hipLaunchKernelGGL((klg_render<P, false>), dim3(s->grid), dim3(WG), render_lds_bytes(a.n), st, a);
 }
 static int render_grid(const klg_synth* s) {      // workgroups (= partial rows) of the render launch
+	if (s->lanes) return s->grid_lanes;
 	if ((s->patch == KLG_PATCH_SUB2A && s->x2) || (s->graph && s->graph->x2)) return std::min((int)((s->stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG), s->grid);
 	return s->grid;
 }
@@ -427,6 +436,12 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 		const dim3 g(render_grid(s)), b(WG);
 		if (pv) hipLaunchKernelGGL(klg_render_sub2a_x2<true>, g, b, render_lds_bytes(a.n), st, a);
 		else hipLaunchKernelGGL(klg_render_sub2a_x2<false>, g, b, render_lds_bytes(a.n), st, a);
+		return;
+	}
+	if (s->lanes) {                                       // SuperSaw, one oscillator per lane (small banks)
+		const dim3 g(render_grid(s)), b(WG);
+		if (pv) hipLaunchKernelGGL(klg_render_supersaw_lanes<true>, g, b, render_lds_bytes(a.n), st, a);
+		else hipLaunchKernelGGL(klg_render_supersaw_lanes<false>, g, b, render_lds_bytes(a.n), st, a);
 		return;
 	}
 	switch (s->patch) {

@@ -150,3 +150,18 @@ def test_one_voice_per_lane_kernel_matches_too(name, monkeypatch):
     got = run_scenario_gpu(s)
     assert np.array_equal(got["stages"], ref["stages"])
     assert bit_exact_fraction(got["per_voice"], ref["per_voice"]) == 1.0
+
+
+@pytest.mark.parametrize("name", ["supersaw_ctl", "supersaw_poly"])
+@pytest.mark.parametrize("lanes", ["0", "1"])
+def test_both_supersaw_kernels_match(name, lanes, monkeypatch):
+    """SuperSaw banks of up to 65,536 voices run the oscillator-per-lane kernel (klg_render_lanes.hpp), larger ones the voice-per-lane
+    kernel; KLG_SUPERSAW_LANES forces the choice.  Both must reproduce the reference bit for bit per voice."""
+    if not os.path.exists(os.path.join(GOLDEN, name + ".scn")):
+        pytest.skip("no such fixture")
+    monkeypatch.setenv("KLG_SUPERSAW_LANES", lanes)
+    s = Scenario.load(os.path.join(GOLDEN, name + ".scn"))
+    ref = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = run_scenario_gpu(s)
+    assert np.array_equal(got["stages"], ref["stages"])
+    assert bit_exact_fraction(got["per_voice"], ref["per_voice"]) == 1.0
