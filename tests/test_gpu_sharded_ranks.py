@@ -1,0 +1,81 @@
+"""Two REAL ranks of klang_amd.ShardedSynthBank with the HIP bank: one process per rank, the global event
+stream given to both, one all-reduce of the [2][n] block per step — against a single-process bank with the same events.  With two GPUs the
+ranks take cuda:0 / cuda:1 and the `nccl` (RCCL) backend; on a one-GPU box both ranks share cuda:0 and reduce through `gloo`
+(KLG_BENCH_ONE_GPU's arrangement).  The summation order differs (two partial mixes), hence the mix tolerance of test_gpu_parity."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+RANK = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import klang_amd
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+two = torch.cuda.device_count() >= 2
+dev = rank if two else 0
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl" if two else "gloo", device_id=torch.device("cuda", dev) if two else None)
+S, P, N, B = 5, 16, 256, 12                                     # 5 synth instances: an uneven 3 + 2 split
+bank = klang_amd.ShardedSynthBank(%(patch)r, S, P, max_block=N, rank=rank, world=world, device=dev)
+rng = np.random.default_rng(11)
+events = [(int(rng.integers(0, 4)), int(rng.integers(0, S)), int(rng.integers(40, 90)), float(rng.uniform(0.3, 1.0)), int(rng.integers(1, 1 << 30))) for _ in range(40)]
+out = np.zeros((B, 2, N), np.float32)
+for b in range(B):
+    for (at, sy, p, vel, seed) in events:
+        if at == b: bank.note_on(sy, p, vel, seed=seed)
+        if at + 5 == b: bank.note_off(sy, p)
+    if b == 6 and %(patch)r == "supersaw": bank.set_control(1, 0, 0.5)
+    mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+    bank.bank.process_device(mix.data_ptr(), N, None)
+    torch.cuda.synchronize()
+    if two:
+        dist.all_reduce(mix)
+    else:
+        host = mix.cpu(); dist.all_reduce(host); mix = host
+    out[b] = mix.cpu().numpy()
+if rank == 0: np.save(sys.argv[1], out)
+dist.barrier(); bank.close(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("patch", ["sub2a", "supersaw"])
+def test_two_ranks_with_the_hip_bank_equal_one_bank(patch, tmp_path):
+    import klang_amd
+    script = tmp_path / "rank.py"
+    script.write_text(RANK % {"root": ROOT, "patch": patch})
+    res = tmp_path / "mix.npy"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+                        str(script), str(res)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(res)
+    # the same events on ONE bank
+    S, P, N, B = 5, 16, 256, 12
+    bank = klang_amd.SynthBank(patch, synths=S, notes=P, max_block=N)
+    rng = np.random.default_rng(11)
+    events = [(int(rng.integers(0, 4)), int(rng.integers(0, S)), int(rng.integers(40, 90)), float(rng.uniform(0.3, 1.0)), int(rng.integers(1, 1 << 30))) for _ in range(40)]
+    want = np.zeros((B, 2, N), np.float32)
+    for b in range(B):
+        for (at, sy, p, vel, seed) in events:
+            if at == b:
+                bank.random(seed); bank.note_on(sy, p, vel)
+            if at + 5 == b:
+                bank.note_off(sy, p)
+        if b == 6 and patch == "supersaw":
+            bank.set_control(1, 0, 0.5)
+        blk = np.zeros((2, N), np.float32)
+        bank.process(blk)
+        want[b] = blk
+    bank.close()
+    peak = float(np.max(np.abs(want)))
+    assert peak > 0.05
+    assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 1e-5 * peak * np.sqrt(S * P) * 4
