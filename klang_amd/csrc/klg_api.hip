@@ -753,7 +753,6 @@ static int process_host(klg_synth* s, float* per_voice, float* const* out, int c
 	HIP_TRY(hipMemsetAsync(s->d_mix, 0, (size_t)2 * n * 4, st));
 	if (int rc = enqueue_block(s, s->d_mix, n, per_voice != nullptr, st)) return rc;
 	HIP_TRY(hipMemcpyAsync(s->h_mix, s->d_mix, (size_t)2 * n * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(s->h_flags, s->d_state, (size_t)s->V * 4, hipMemcpyDeviceToHost, st));
 	if (per_voice) HIP_TRY(hipMemcpyAsync(s->h_per_voice, s->d_per_voice, (size_t)s->V * n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	if (out) for (int c = 0; c < channels; c++) {
@@ -762,9 +761,8 @@ static int process_host(klg_synth* s, float* per_voice, float* const* out, int c
 		else if (s->mix_mode != KLG_MIX_LAST_ACTIVE) for (int i = 0; i < n; i++) dst[i] += src[i];
 	}
 	if (per_voice) std::memcpy(per_voice, s->h_per_voice, (size_t)s->V * n * 4);
-	if (s->scripted) for (int v = 0; v < s->V; v++) s->voices[v].stage = (uint8_t)(s->h_flags[v] & 3u);
-	else for (int v = 0; v < s->V; v++) if ((s->h_flags[v] & 3u) == (uint32_t)ST_OFF) s->voices[v].stage = ST_OFF;
-	s->stages_dirty = false;
+	// (the note stages come back when somebody asks — klg_note_on's assign(), klg_voice_stages: refresh_stages() — not 4 bytes per voice
+	//  over PCIe after every block: a block's host traffic is its 2 KiB of mix)
 	if (parameters && s->nctl)                                   // sync update out (klang.h:4854-4857)
 		for (int i = 0; i < s->S; i++) for (int c = 0; c < s->nctl; c++) parameters[(size_t)i * s->nctl + c] = s->controls[(size_t)i * s->nctl + c].value;
 	return 0;
@@ -822,14 +820,10 @@ static int multi_process_host(klg_synth* r, float* per_voice, float* const* out,
 	for (size_t i = 0; i < m.shard.size(); i++) {
 		const int rc = on_shard(r, i, [&](klg_synth* sh) -> int {
 			if (i == 0) HIP_TRY(hipMemcpyAsync(sh->h_mix, sh->d_mix, (size_t)2 * n * 4, hipMemcpyDeviceToHost, sh->stream));
-			HIP_TRY(hipMemcpyAsync(sh->h_flags, sh->d_state, (size_t)sh->V * 4, hipMemcpyDeviceToHost, sh->stream));
 			if (per_voice) HIP_TRY(hipMemcpyAsync(sh->h_per_voice, sh->d_per_voice, (size_t)sh->V * n * 4, hipMemcpyDeviceToHost, sh->stream));
 			HIP_TRY(hipStreamSynchronize(sh->stream));
 			if (per_voice) std::memcpy(per_voice + v0 * (size_t)n, sh->h_per_voice, (size_t)sh->V * n * 4);
-			if (sh->scripted) for (int v = 0; v < sh->V; v++) sh->voices[v].stage = (uint8_t)(sh->h_flags[v] & 3u);
-			else for (int v = 0; v < sh->V; v++) if ((sh->h_flags[v] & 3u) == (uint32_t)ST_OFF) sh->voices[v].stage = ST_OFF;
-			sh->stages_dirty = false;
-			return 0;
+			return 0;                                                   // (the note stages stay on the device until asked for: refresh_stages)
 		});
 		if (rc) return rc;
 		v0 += (size_t)m.shard[i]->V;

@@ -17,7 +17,7 @@ for V in (1 << 16, 1 << 20):
     t0 = time.perf_counter(); steps = 50
     for _ in range(steps): bank.process(mix)
     dt = time.perf_counter() - t0
-    out.append(dict(path="klg_process (host buffers)", voices=V, ms_per_block=1e3 * dt / steps, voice_samples_per_s=V * N * steps / dt, d2h_bytes_per_block=2 * N * 4 + V * 4))
+    out.append(dict(path="klg_process (host buffers)", voices=V, ms_per_block=1e3 * dt / steps, voice_samples_per_s=V * N * steps / dt, d2h_bytes_per_block=2 * N * 4))
     bank.close()
 for K in (256, 4096):
     bank = klang_amd.FxBank("pingpong", K, max_block=N)
