@@ -234,17 +234,27 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 // Arithmetic and its order are those of klg_fx_pingpong (KLG_FX_PINGPONG1=1) and the reference, bit for bit.
 enum { PPX_CHUNK = 32, PPX_AUDIO = 8, PPX_PER = PPX_CHUNK / PPX_AUDIO, PPX_WAVES = 1 + PPX_AUDIO + 2, PPX_THREADS = PPX_WAVES * 64 };
 
-struct PpxLds {
-	float tile[4][2][PPX_CHUNK][FX_LD];         // [chunk & 3][channel][sample][instance]: loaded, audio, filter, store
-	float D[2][PPX_CHUNK][64];                  // delay time (smoothed controls[1]) per sample, [chunk & 1]
+template<int G> struct PpxLds {
+	float tile[4][2][PPX_CHUNK][G + 1];         // [chunk & 3][channel][sample][instance]: loaded, audio, filter, store
+	float D[2][PPX_CHUNK][G];                   // delay time (smoothed controls[1]) per sample, [chunk & 1]
 	int far[2];                                 // 1: every tap of the chunk is far from the write cursor
 };
 
+// G = instances per workgroup: 64 (a whole ring group: banks that fill the chip on their own), or 32 / 16 — a half / a quarter of a
+// ring group per workgroup.  The pipeline's time is the instruction count of a chunk on the ONE CU a workgroup runs on (DESIGN.md §3:
+// ~7.7 k instructions per 32-sample chunk at G = 64, most of them the audio stage's), and a bank of 4,096 instances is 64 such
+// workgroups on a chip of 256 CUs.  With G = 16 an audio wave's 64 lanes are 4 samples x 16 instances — its four samples side by
+// side instead of one after the other — so the audio stage is a quarter of the instructions and the bank covers every CU; the control
+// and filter waves run their recurrences on 16 lanes (a lane costs nothing, an instruction does).  The ring layout is the same.
+template<int G>
 __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongArgs a) {
-	__shared__ PpxLds S;
+	static_assert(G == 64 || G == 32 || G == 16, "instances per workgroup");
+	constexpr int SPW = 64 / G, PASSES = PPX_PER / SPW;                           // samples a wave holds side by side; passes over its PPX_PER samples
+	__shared__ PpxLds<G> S;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int k0 = blockIdx.x * FX_WG, k = k0 + lane;
+	const int li = lane & (G - 1), lq = lane / G;                                  // this lane's instance of the workgroup; its sample slot in an audio pass
+	const int k0 = blockIdx.x * G, k = k0 + li;
 	const int SIZE = 192000, n = a.n;
 	const int nchunks = (n + PPX_CHUNK - 1) / PPX_CHUNK;
 	const bool w_control = wv == 0, w_audio = wv >= 1 && wv <= PPX_AUDIO, w_filter = wv > PPX_AUDIO;
@@ -269,8 +279,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	// ---- audio wave state ----
 	float gain = 0.f, dry = 0.f;
 	if (w_audio) { gain = PPW(0); dry = PPW(4); }
-	float* ring0 = a.rings + (size_t)blockIdx.x * 2 * SIZE * FX_WG;                // this workgroup's ring tile: [2][SIZE][64]
-	const unsigned lane4 = (unsigned)lane * 4u, ROW = FX_WG * 4u;
+	float* ring0 = a.rings + (size_t)(k0 / FX_WG) * 2 * SIZE * FX_WG;              // this workgroup's ring tile: [2][SIZE][64] (G < 64: its 64-instance group's)
+	const unsigned lane4 = (unsigned)((k0 & (FX_WG - 1)) + li) * 4u, ROW = FX_WG * 4u;
 	auto ring_rd = [&](int line, int i) { return *(const float*)((const char*)(ring0 + (size_t)line * SIZE * FX_WG) + ((unsigned)i * ROW + lane4)); };
 	auto ring_wr = [&](int line, int i, float v) { *(float*)((char*)(ring0 + (size_t)line * SIZE * FX_WG) + ((unsigned)i * ROW + lane4)) = v; };
 	auto wrap = [&](int i) { return i >= SIZE ? i - SIZE : i; };
@@ -283,7 +293,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		// ---------------- io rows of chunk j+1 (audio waves; landed in LDS at the end of the step) ----------------
 		const int jn = j + 1;
 		const bool load_next = w_audio && jn < nchunks;
-		float iov[8];
+		constexpr int IOV = G * 2 * PPX_CHUNK / (PPX_AUDIO * 64);               // values of the caller's chunk per audio thread
+		float iov[IOV];
 		// (the thread index is laundered through an empty asm once per step: otherwise every per-thread address and bounds
 		//  predicate below is loop-invariant, gets hoisted out of the chunk loop, and ~100 VGPRs stay live for the whole kernel)
 		int at = tid - 64; asm volatile("" : "+v"(at));
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		if (load_next) {
 			const char* src = (const char*)(a.io + (size_t)k0 * 2 * n + ns0);
 #pragma unroll
-			for (int i = 0; i < 8; i++) {
+			for (int i = 0; i < IOV; i++) {
 				const int row = arow + 16 * i, inst = row >> 1;
 				iov[i] = (acol < ncl && k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + acol) * 4u) : 0.f;
 			}
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		if (w_control && jn < nchunks) {
 			float dmin = 3.0e38f, dmax = 0.f;                                         // range of the delay time over the chunk
 			lfo.increment = lfo_inc;
-			float (*D)[64] = S.D[jn & 1];
+			float (*D)[G] = S.D[jn & 1];
 			if (!any_vibrato) {
 				// No instance of the wave has vibrato (controls[2] == 0: `lfo * vibrato * 0.00005` is +-0, `controls[1] + (+-0)` is controls[1],
 				// which is already clamped): the LFO only advances its phase.  This serial chain — one wave, one dependent instruction after
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 					c1 = trig ? __builtin_amdgcn_fmed3f(sm5, a.c1_min, a.c1_max) : c1;   // controls[1].set(new_delay): the clamp is the median of (x, min, max)
 					pos = trig ? KLG_PI_F : pos;                                    // lfo.set(rate, pi)
 					sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                       // controls[1].smooth()
-					D[u][lane] = sm1;
+					D[u][li] = sm1;
 					const float p1 = pos + lfo_inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
 					pos = inc_ok ? p2 : pos;
 					dmin = __builtin_fminf(dmin, sm1); dmax = __builtin_fmaxf(dmax, sm1);
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				const float lfo_out = basic_sine(lfo);                              // fp64 sin
 				const float nc1 = c1 + lfo_out * vibrato * 0.00005f;
 				c1 = (nc1 < a.c1_min) ? a.c1_min : (a.c1_max < nc1) ? a.c1_max : nc1;
-				D[u][lane] = delay;
+				D[u][li] = delay;
 				dmin = fminf(dmin, delay); dmax = fmaxf(dmax, delay);
 			}
 			// x -> 0.5f * x * fs and x -> x * fs are monotonic, so the extreme delays decide for the whole chunk
@@ -353,15 +364,17 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		if (w_audio && j >= 0 && j < nchunks) {
 			const int s0 = j * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
 			const int pos0 = (int)(((long long)a.position + s0) % SIZE);
-			float (*T)[PPX_CHUNK][FX_LD] = S.tile[j & 3];
+			float (*T)[PPX_CHUNK][G + 1] = S.tile[j & 3];
 			if (S.far[j & 1]) {
-				const int u0 = (wv - 1) * PPX_PER;
-				Tap tl[PPX_PER], tr[PPX_PER];
-				float pl[PPX_PER][3], pr[PPX_PER][3];
+				// a wave's PPX_PER samples: SPW of them side by side in its lanes (lane = sample slot x instance), PASSES passes
+				const int u0 = (wv - 1) * PPX_PER + lq;
+				Tap tl[PASSES], tr[PASSES];
+				float pl[PASSES][3], pr[PASSES][3];
 #pragma unroll
-				for (int q = 0; q < PPX_PER; q++) if (u0 + q < cl) {
-					const float delay = S.D[j & 1][u0 + q][lane];
-					const int pos = wrap(pos0 + u0 + q);
+				for (int q = 0; q < PASSES; q++) if (u0 + q * SPW < cl) {
+					const int u = u0 + q * SPW;
+					const float delay = S.D[j & 1][u][li];
+					const int pos = wrap(pos0 + u);
 					tl[q] = delay_set(pos, SIZE, delay * a.fs.f);                   // left.set(delay * fs)
 					tr[q] = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);            // right.set(0.5f * delay * fs)
 					const int i0 = tl[q].position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
@@ -370,71 +383,74 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 					pr[q][0] = ring_rd(1, j0); pr[q][1] = ring_rd(1, j1); pr[q][2] = ring_rd(1, j2);
 				}
 #pragma unroll
-				for (int q = 0; q < PPX_PER; q++) if (u0 + q < cl) {
-					const int u = u0 + q, pos = wrap(pos0 + u);
-					const float in_l = T[0][u][lane], in_r = T[1][u][lane];
+				for (int q = 0; q < PASSES; q++) if (u0 + q * SPW < cl) {
+					const int u = u0 + q * SPW, pos = wrap(pos0 + u);
+					const float in_l = T[0][u][li], in_r = T[1][u][li];
 					// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
 					const float r1 = pr[q][0] + tr[q].fraction * (pr[q][1] - pr[q][0]);
 					ring_wr(0, pos, in_l + r1 * gain);
 					const float l1 = pl[q][0] + tl[q].fraction * (pl[q][1] - pl[q][0]);
 					const float l2 = pl[q][1] + tl[q].fraction * (pl[q][2] - pl[q][1]);
-					T[0][u][lane] = dry * in_l + l1 * (1.f - dry);
+					T[0][u][li] = dry * in_l + l1 * (1.f - dry);
 					// dry * in.r + (1.f - dry) * ((in.r + left * gain) >> right) >> out.r;   PingPong.k:67
 					ring_wr(1, pos, in_r + l2 * gain);
 					const float r2 = pr[q][1] + tr[q].fraction * (pr[q][2] - pr[q][1]);
-					T[1][u][lane] = dry * in_r + r2 * (1.f - dry);
+					T[1][u][li] = dry * in_r + r2 * (1.f - dry);
 				}
 			}
-			else if (wv == 1) {                                                     // a near tap: the chunk is walked in order by one wave
-				Ring left = { ring0 + lane, FX_WG, SIZE }, right = { ring0 + (size_t)SIZE * FX_WG + lane, FX_WG, SIZE };
+			else if (wv == 1 && lane < G) {                                         // a near tap: the chunk is walked in order by one wave, lane = instance
+				const int col = (k0 & (FX_WG - 1)) + li;
+				Ring left = { ring0 + col, FX_WG, SIZE }, right = { ring0 + (size_t)SIZE * FX_WG + col, FX_WG, SIZE };
 				for (int u = 0; u < cl; u++) {
-					const float delay = S.D[j & 1][u][lane];
+					const float delay = S.D[j & 1][u][li];
 					const int pos = wrap(pos0 + u);
 					Tap tl = delay_set(pos, SIZE, delay * a.fs.f), tr = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);
-					const float in_l = T[0][u][lane], in_r = T[1][u][lane];
+					const float in_l = T[0][u][li], in_r = T[1][u][li];
 					const float r1 = delay_process(right, tr);
 					left.wr(pos, in_l + r1 * gain);
 					const float l1 = delay_process(left, tl), l2 = delay_process(left, tl);
-					T[0][u][lane] = dry * in_l + l1 * (1.f - dry);
+					T[0][u][li] = dry * in_l + l1 * (1.f - dry);
 					right.wr(pos, in_r + l2 * gain);
 					const float r2 = delay_process(right, tr);
-					T[1][u][lane] = dry * in_r + r2 * (1.f - dry);
+					T[1][u][li] = dry * in_r + r2 * (1.f - dry);
 				}
 			}
 		}
 		// ---------------- store of chunk j-2 (first: its write acknowledgements have the whole step to arrive), FILTER of chunk j-1 ----------------
 		if (w_filter && j >= 2) {
 			const int js = j - 2, s0 = js * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
-			float (*T)[FX_LD] = S.tile[js & 3][fch];
+			float (*T)[G + 1] = S.tile[js & 3][fch];
 			int sl = lane; asm volatile("" : "+v"(sl));
 			const int col = sl & 31, half = sl >> 5;
 			char* dst = (char*)(a.io + (size_t)k0 * 2 * n + s0);
 #pragma unroll 8
-			for (int it = 0; it < 32; it++) {
+			for (int it = 0; it < G / 2; it++) {
 				const int inst = 2 * it + half;
 				if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
 			}
 		}
 		if (w_filter && j >= 1 && j <= nchunks) {
 			const int jf = j - 1, s0 = jf * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
-			float (*T)[FX_LD] = S.tile[jf & 3][fch];
+			float (*T)[G + 1] = S.tile[jf & 3][fch];
 			for (int b = 0; b < PPX_CHUNK; b += 8) {                                  // eight LDS reads in flight, then the (sequential) filter
 				float x[8];
 #pragma unroll
-				for (int u = 0; u < 8; u++) x[u] = T[b + u][lane];
+				for (int u = 0; u < 8; u++) x[u] = T[b + u][li];
 #pragma unroll
 				for (int u = 0; u < 8; u++) if (b + u < cl) x[u] = biquad_process(dc, x[u]);     // out >> dcfilter[ch] >> out
+				if (lane < G) {
 #pragma unroll
-				for (int u = 0; u < 8; u++) T[b + u][lane] = x[u];
+					for (int u = 0; u < 8; u++) T[b + u][li] = x[u];
+				}
 			}
 		}
 		if (load_next) {
 #pragma unroll
-			for (int i = 0; i < 8; i++) { const int row = arow + 16 * i; S.tile[jn & 3][row & 1][acol][row >> 1] = iov[i]; }
+			for (int i = 0; i < IOV; i++) { const int row = arow + 16 * i; S.tile[jn & 3][row & 1][acol][row >> 1] = iov[i]; }
 		}
 		__syncthreads();
 	}
-	if (k < a.K) {
+	if (k < a.K && lane < G) {
 		float* Wr = a.state + k;
 		if (w_control) {
 			Wr[(size_t)1 * a.kpad] = c1; Wr[(size_t)PP_SM1 * a.kpad] = sm1; Wr[(size_t)PP_SM5 * a.kpad] = sm5; Wr[(size_t)PP_DELAY * a.kpad] = mdelay;
