@@ -165,3 +165,34 @@ def test_both_supersaw_kernels_match(name, lanes, monkeypatch):
     got = run_scenario_gpu(s)
     assert np.array_equal(got["stages"], ref["stages"])
     assert bit_exact_fraction(got["per_voice"], ref["per_voice"]) == 1.0
+
+
+@pytest.mark.parametrize("patch,synths,notes,seeded", [
+    ("sub2a", 4, 128, False), ("sub2b", 8, 32, False), ("supersaw", 8, 32, True), ("fm3", 8, 32, False), ("fm4", 8, 32, False),
+])
+def test_against_oracle_through_whole_note_lives(patch, synths, notes, seeded, oracle_build):
+    """48 blocks (0.26 s) of notes that start at different blocks and are released at random ones: attack and decay ends, release ends and
+    operator-envelope segment ends fall INSIDE chunks everywhere — what the event-free chunk paths (env_safe / the packed kernel's bare
+    step) must hand to the full Envelope::process at exactly the right sample.  Per voice, against the C restatement."""
+    rng = np.random.default_rng(4321)
+    blocks = 48
+    s = Scenario(patch=patch, block=256, blocks=blocks, synths=synths, notes=notes, dump=list(range(blocks)))
+    for sy in range(synths):
+        for k in range(notes):
+            p = int(rng.integers(36, 97))
+            on = int(rng.integers(0, 20))
+            s.on(on, sy, p, float(rng.uniform(0.25, 1.0)), int(rng.integers(1, 2**31 - 1)) if seeded else -1)
+            if rng.uniform() < 0.8:
+                s.off(int(rng.integers(on + 1, blocks - 4)), sy, p, 0.0)
+    s.sort()
+    ref = run_scenario_oracle(s, oracle_build)
+    got = run_scenario_gpu(s)
+    assert np.array_equal(got["stages"], ref["stages"])
+    err = rel_err(got["per_voice"], ref["per_voice"])
+    print(f"{patch}: {s.voices} voices x {blocks} blocks, rel err {err:.3e}, bit-exact {100 * bit_exact_fraction(got['per_voice'], ref['per_voice']):.3f}%")
+    assert err <= TOL
+
+
+def test_whole_note_lives_on_the_voice_per_lane_supersaw_kernel_too(oracle_build, monkeypatch):
+    monkeypatch.setenv("KLG_SUPERSAW_LANES", "0")
+    test_against_oracle_through_whole_note_lives("supersaw", 8, 32, True, oracle_build)
