@@ -10,6 +10,7 @@
 
 #include <map>
 #include <mutex>
+#include <regex>
 #include <string>
 #include <vector>
 
@@ -57,7 +58,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	auto ring = [&](int node) { return fx ? fmt("Ring{ c.ring + (size_t)%lldll * 64, 64, %d }", ring_off[(size_t)node], g.arg(node)) : fmt("Ring{ c.ring + (size_t)%lldll, 1, %d }", ring_off[(size_t)node], g.arg(node)); };
 	uint64_t mask[2] = { 1ull, 0ull };                                   // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
-	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { " + TI + " stage;", begin, end, body;
+	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { " + TI + " stage; float tinc;", begin, end, body;
 	const int noise_calls = g.noise_calls(); int noise_k = 0;
 	for (size_t i = 0; i < g.nodes.size(); i++) {
 		const int k = g.nodes[i], w0 = g.node_word0((int)i);
@@ -95,6 +96,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			break;
 		case N_ENV:
 			live += (x2 ? std::string(" Env2") : std::string(" Env")) + fmt(" n%zu; ", i) + (x2 ? "Pts4x2" : "Pts4") + fmt(" n%zup; ", i) + TI + fmt(" n%zunp, n%zuls, n%zule;", i, i, i);
+			if (!x2) live += fmt(" float n%zugs, n%zugt;", i, i);                     // event-free chunks: this envelope's step and time step (quiet())
 			begin += "\t\t" + n + ".r_out = " + F(ENV_OUT) + "; " + n + ".r_target = " + F(ENV_TARGET) + "; " + n + ".r_rate = " + F(ENV_RATE) + "; " + n + ".time = " + F(ENV_TIME) + "; env_unpack(" + n + ", " + R(ENV_BITS) + "); "
 				+ n + "np = to_i(" + R(ENV_NPOINTS) + "); " + n + "ls = loop_index(" + R(ENV_LOOP) + " & 0xFFu); " + n + "le = loop_index((" + R(ENV_LOOP) + " >> 8) & 0xFFu);\n";
 			begin += "\t\t" + n + "p.x0 = " + F(ENV_PX) + "; " + n + "p.x1 = " + F(ENV_PX + 1) + "; " + n + "p.x2 = " + F(ENV_PX + 2) + "; " + n + "p.x3 = " + F(ENV_PX + 3) + "; "
@@ -104,6 +106,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			break;
 		case N_ADSR:
 			live += " Adsr" + T2 + fmt(" n%zu;", i);
+			if (!x2) live += fmt(" float n%zugs, n%zugt;", i, i);
 			begin += "\t\t" + n + ".e.r_out = " + F(ADSR_OUT) + "; " + n + ".e.r_target = " + F(ADSR_TARGET) + "; " + n + ".e.r_rate = " + F(ADSR_RATE) + "; " + n + ".e.time = " + F(ADSR_TIME) + "; env_unpack(" + n + ".e, " + R(ADSR_BITS) + ");\n";
 			begin += "\t\tadsr_set_points(" + n + ", " + F(ADSR_A) + ", " + F(ADSR_AD) + ", " + F(ADSR_S) + ", " + F(ADSR_R) + "); adsr_derive(" + n + ", c.fs);\n";
 			end += W(ADSR_OUT, "f2u(" + n + ".e.r_out)") + W(ADSR_TARGET, "f2u(" + n + ".e.r_target)") + W(ADSR_RATE, "f2u(" + n + ".e.r_rate)") + W(ADSR_TIME, "f2u(" + n + ".e.time)") + W(ADSR_BITS, "env_pack(" + n + ".e)");
@@ -162,7 +165,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			mark(w0 + FOLLOW_OUT, 1);
 			break;
 		case N_OPERATOR: {
-			live += fmt(" FSine n%zu; float n%zua, n%zuf; Env n%zue; Pts4 n%zup; int n%zunp, n%zuls, n%zule;", i, i, i, i, i, i, i, i);
+			live += fmt(" FSine n%zu; float n%zua, n%zuf; Env n%zue; Pts4 n%zup; int n%zunp, n%zuls, n%zule; float n%zugs, n%zugt;", i, i, i, i, i, i, i, i, i, i);
 			const int e0 = OPER_ENV;
 			begin += "\t\t" + n + ".inc = (int32_t)" + R(OPER_INC) + "; " + n + ".pos = " + R(OPER_POS) + "; " + n + "a = " + F(OPER_AMP) + "; " + n + "f = " + F(OPER_FREQ) + ";\n";
 			begin += "\t\t" + n + "e.r_out = " + F(e0 + ENV_OUT) + "; " + n + "e.r_target = " + F(e0 + ENV_TARGET) + "; " + n + "e.r_rate = " + F(e0 + ENV_RATE) + "; " + n + "e.time = " + F(e0 + ENV_TIME) + "; env_unpack(" + n + "e, " + R(e0 + ENV_BITS) + "); "
@@ -330,7 +333,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	}
 	else {
 		const std::string ctx = x2 ? "BlockCtx2" : "BlockCtx";
-		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const " + ctx + "& c) {\n\t\tL.stage = to_i(r.w[0] & 3u); (void)c;\n" + begin + "\t}\n";
+		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const " + ctx + "& c) {\n\t\tL.stage = to_i(r.w[0] & 3u); L.tinc = c.fs.timeInc;\n" + begin + "\t}\n";
 		s += "\tstatic __device__ __forceinline__ " + TF + " sample(Live& L, const " + ctx + "& c) {\n" + body + fmt("\t\treturn r%d;\n\t}\n", g.ret);
 		{
 			// the same body with every ADSR holding (adsr_hold): what the render kernel runs for a chunk when quiet() says every envelope
@@ -343,8 +346,24 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 				if (g.nodes[i] == N_SAW && !retuned[i]) d0_test += fmt(" && L.n%zud0", i);
 			}
 			for (const Op& o : g.ops) if (o.code == OP_IF) has_if = true;
-			const bool quiet = has_adsr && !has_env && !has_if;
-			for (size_t at = 0; quiet && (at = qbody.find("adsr_process(", at)) != std::string::npos;) qbody.replace(at, 13, "adsr_hold(");
+			// One voice per lane: EVENT-FREE chunks (klg_patches.hpp: env_safe / env_glide).  When no envelope of any sounding voice of the wave
+			// can reach a segment end inside the chunk, every ADSR / Envelope / Operator envelope is `out = value; value += step; time += tstep`
+			// — holding at sustain is the special case step = -0.0.  quiet() decides per chunk and leaves the steps in Live.
+			const bool glide = !x2 && (has_adsr || has_env) && !has_if;
+			const bool quiet = glide || (has_adsr && !has_env && !has_if);
+			std::string glide_test;
+			if (glide) {
+				for (size_t i = 0; i < g.nodes.size(); i++) {
+					const std::string n = fmt("L.n%zu", i);
+					if (g.nodes[i] == N_ADSR) glide_test += "\t\tsafe = env_safe(" + n + ".e, " + n + ".e.point == 2, " + n + "gs, " + n + "gt, L.tinc) && safe;\n";
+					else if (g.nodes[i] == N_ENV) glide_test += "\t\tsafe = env_safe(" + n + ", " + n + "ls >= 0 && " + n + "ls == " + n + "le && " + n + ".point == " + n + "ls && " + n + ".r_out == " + n + "p.y(" + n + "ls), " + n + "gs, " + n + "gt, L.tinc) && safe;\n";
+					else if (g.nodes[i] == N_OPERATOR) glide_test += "\t\tsafe = env_safe(" + n + "e, " + n + "ls >= 0 && " + n + "ls == " + n + "le && " + n + "e.point == " + n + "ls && " + n + "e.r_out == " + n + "p.y(" + n + "ls), " + n + "gs, " + n + "gt, L.tinc) && safe;\n";
+				}
+				qbody = std::regex_replace(qbody, std::regex("adsr_process\\((L\\.n[0-9]+), c\\.fs\\)"), "env_glide($1.e, $1gs, $1gt)");
+				qbody = std::regex_replace(qbody, std::regex("env_process_rt\\((L\\.n[0-9]+)e, [^)]*\\)"), "env_glide($1e, $1gs, $1gt)");
+				qbody = std::regex_replace(qbody, std::regex("env_process_rt\\((L\\.n[0-9]+), [^)]*\\)"), "env_glide($1, $1gs, $1gt)");
+			}
+			else for (size_t at = 0; quiet && (at = qbody.find("adsr_process(", at)) != std::string::npos;) qbody.replace(at, 13, "adsr_hold(");
 			// ... and with every saw in its duty-0 form (the per-block decision n<k>d0 folded into the choice of body)
 			std::string fbody = qbody;
 			for (size_t at = 0; (at = fbody.find("d0 ? osm_saw_duty0(", at)) != std::string::npos;) {
@@ -354,8 +373,9 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 				at = open;
 			}
 			s += std::string("\tstatic constexpr bool kHasQuiet = ") + (quiet ? "true" : "false") + ";\n";
-			// 0: the full body; 1: every envelope of the wave holds; 2: ... and every saw is in its duty-0 form
-			if (x2) s += "\tstatic __device__ __forceinline__ int quiet(const Live& L) {\n\t\t(void)L; const i2 q = (i2)(-1)" + (quiet ? quiet_test : std::string("")) + ";\n\t\tif (__ballot((q.x & q.y) == 0) != 0ull) return 0;\n\t\treturn (true" + d0_test + ") ? 2 : 1;\n\t}\n";
+			// 0: the full body; 1: every envelope of the wave holds (or glides); 2: ... and every saw is in its duty-0 form
+			if (glide) s += "\tstatic __device__ __forceinline__ int quiet(Live& L) {\n\t\tbool safe = true;\n" + glide_test + "\t\tif (__ballot(L.stage != (int)ST_OFF && !safe) != 0ull) return 0;\n\t\treturn (true" + d0_test + ") ? 2 : 1;\n\t}\n";
+			else if (x2) s += "\tstatic __device__ __forceinline__ int quiet(const Live& L) {\n\t\t(void)L; const i2 q = (i2)(-1)" + (quiet ? quiet_test : std::string("")) + ";\n\t\tif (__ballot((q.x & q.y) == 0) != 0ull) return 0;\n\t\treturn (true" + d0_test + ") ? 2 : 1;\n\t}\n";
 			else s += "\tstatic __device__ __forceinline__ int quiet(const Live& L) {\n\t\t(void)L; const bool q = true" + (quiet ? quiet_test : std::string("")) + ";\n\t\tif (__ballot(!q) != 0ull) return 0;\n\t\treturn (true" + d0_test + ") ? 2 : 1;\n\t}\n";
 			s += "\tstatic __device__ __forceinline__ " + TF + " sample_quiet(Live& L, const " + ctx + "& c) {\n" + (quiet ? qbody : body) + fmt("\t\treturn r%d;\n\t}\n", g.ret);
 			s += "\tstatic __device__ __forceinline__ " + TF + " sample_fast(Live& L, const " + ctx + "& c) {\n" + (quiet ? fbody : body) + fmt("\t\treturn r%d;\n\t}\n", g.ret);

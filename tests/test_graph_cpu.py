@@ -124,15 +124,18 @@ def test_two_voices_per_lane_form_and_the_three_bodies():
     rc1, one = check_mode(SAW_LPF_ADSR, 1)
     rc2, two = check_mode(SAW_LPF_ADSR, 2)
     assert rc1 == 0 and rc2 == 0, one + two
-    assert "struct Rec { uint32_t w[25]; }" in one and "struct Live { int stage; Osm n0;" in one and "klg_render_x2" not in one.split("namespace klg")[1]
-    assert "struct Rec { u2 w[25]; }" in two and "struct Live { i2 stage; Osm2 n0;" in two and "const BlockCtx2& c" in two
+    assert "struct Rec { uint32_t w[25]; }" in one and "struct Live { int stage; float tinc; Osm n0;" in one and "klg_render_x2" not in one.split("namespace klg")[1]
+    assert "struct Rec { u2 w[25]; }" in two and "struct Live { i2 stage; float tinc; Osm2 n0;" in two and "const BlockCtx2& c" in two
     body = lambda src, name: src[src.index(name):].split("return r3;")[0].split("{\n", 1)[1]
-    for src, F in ((one, "float"), (two, "f2")):
+    # one voice per lane: the quiet bodies are EVENT-FREE chunks (every envelope glides: holding at sustain is the step -0.0);
+    # two voices per lane: the ADSR holds (adsr_hold)
+    for src, F, env in ((one, "float", "env_glide(L.n2.e, L.n2gs, L.n2gt)"), (two, "f2", "adsr_hold(L.n2, c.fs)")):
         assert body(src, F + " sample(") == body(src, F + " sample(")                                            # sanity
         assert "adsr_process(L.n2, c.fs)" in body(src, F + " sample(") and "osm_saw(L.n0)" in body(src, F + " sample(")
-        assert "adsr_hold(L.n2, c.fs)" in body(src, F + " sample_quiet(") and "L.n0d0 ? osm_saw_duty0(L.n0)" in body(src, F + " sample_quiet(")
-        assert "adsr_hold(L.n2, c.fs)" in body(src, F + " sample_fast(") and "= osm_saw_duty0(L.n0);" in body(src, F + " sample_fast(")
+        assert env in body(src, F + " sample_quiet(") and "L.n0d0 ? osm_saw_duty0(L.n0)" in body(src, F + " sample_quiet(")
+        assert env in body(src, F + " sample_fast(") and "= osm_saw_duty0(L.n0);" in body(src, F + " sample_fast(")
         assert "stage_off_if(env_is_off(L.n2.e.stage), L.stage)" in src.split("void end(")[1]                    # `if (adsr.finished()) stop();` once per block
+    assert "env_safe(L.n2.e, L.n2.e.point == 2, L.n2gs, L.n2gt, L.tinc)" in one.split("int quiet(")[1]
     assert body(one, "float sample(").replace("float", "f2") == body(two, "f2 sample(")                          # the same text, other types
     rc, msg = check_mode(SUB2B_LIKE, 2)                                                                          # lpfset has no packed form
     assert rc < 0 and "two-voices-per-lane" in msg
