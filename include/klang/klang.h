@@ -509,14 +509,14 @@ struct Oscillator : Generator {
 	virtual float host_process() { device_only("rendering this oscillator into a Wavetable on the host (supported: Fast::Sine, Basic::Sine / Saw / Triangle / Square)"); }
 };
 namespace Generators {
-	// White noise: one libc rand() per sample (klang.h:4947-4951 Basic, 5357-5366 Fast).  Recordable in an Effect (the bank draws the
-	// block's values on the host in the reference's call order); a Note's voices share ONE process-wide sequence: not recordable.
+	// White noise: one libc rand() per sample (klang.h:4947-4951 Basic, 5357-5366 Fast).  Every Noise object of the process draws from the
+	// one libc sequence, so the bank draws each block's values on the host with rand() itself, in the reference's call order (an Effect
+	// bank: instance by instance; a Synth bank: sounding note by sounding note, each through the whole block), and the lanes index them.
 	struct NoiseBase : Generator {
 		int kind;
 		explicit NoiseBase(int k) : kind(k) {}
 		void process() override {
 			if (gpu::Recorder* r = gpu::recording()) {
-				if (!r->effect) { r->fail("Noise in a Note::process(): every voice draws from one process-wide rand() sequence, which lanes cannot share"); return; }
 				out.reg = r->emit(klg::graph::OP_NOISE, -1, -1, -1, (uint32_t)kind, true); return;
 			}
 			device_only("Noise::process()");

@@ -279,7 +279,7 @@ struct Program {
 			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); break;
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			case OP_CMP: if (o.imm > 5u) return bad("unknown relation"); need_a = need_b = true; break;
-			case OP_NOISE: if (!channels) return bad("Noise draws from the process-wide rand(): only effect programs can order it"); if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;
+			case OP_NOISE: if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;
 			case OP_TABREAD: if (channels) return bad("tables are only available to synth notes"); if (o.imm == 0u) return bad("table id 0 is reserved"); need_a = true; break;
 			case OP_IF: if ((int)i < prepare_ops) return bad("prepare() may not branch"); need_a = true; has_dst = false; open.push_back({ {}, false, {} }); break;
 			case OP_ELSE:

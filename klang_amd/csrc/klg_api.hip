@@ -131,6 +131,7 @@ struct klg_synth {
 	std::vector<Table> tables;
 	TableDesc* d_tables = nullptr; size_t d_tables_cap = 0; bool tables_dirty = false;
 	float* d_note_rings = nullptr;               // note delays of a graph patch: [stride][ring_rows], each voice's lines contiguous
+	int *d_rand = nullptr, *d_rand_base = nullptr; std::vector<int> h_rand, h_rand_base;   // Noise generators of a graph patch: the block's rand() draws (draw_noise)
 	// host mirrors
 	std::vector<host::ControlH> controls;        // [S][nctl]
 	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
@@ -157,7 +158,7 @@ struct klg_synth {
 static void synth_free(klg_synth* s) {
 	if (!s) return;
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
-	void* dev[] = { s->d_state, s->d_controls, s->d_partials, s->d_mix, s->d_per_voice, s->d_scratch_rec, s->d_stage };
+	void* dev[] = { s->d_state, s->d_controls, s->d_partials, s->d_mix, s->d_per_voice, s->d_scratch_rec, s->d_stage, s->d_rand, s->d_rand_base };
 	for (void* p : dev) if (p) (void)hipFree(p);
 	if (s->d_note_rings) (void)hipFree(s->d_note_rings);
 	if (s->d_solo) (void)hipFree(s->d_solo);
@@ -707,6 +708,32 @@ extern "C" int klg_get_control(klg_synth* s, int synth, int index, float* value)
 // block processing
 // ------------------------------------------------------------------------------------------------
 static int tables_sync(klg_synth* s);
+// Noise generators in a generated patch (klang.h:4947-4951, 5357-5366): every sounding note draws one libc rand() per generator and sample,
+// and the reference walks its notes one after the other — synth by synth, note slot by note slot, each through the whole block
+// (Synth::process 4842-4848, Note::process(buffer) 4295-4303: all n samples, also after a stop()).  So the block's draws are made HERE,
+// with rand() itself, in exactly that order, once the block's events are on the device and the note stages are back: voice v's values
+// start at rand_base[v].  (One device round trip per block: the price of a sequence that is shared by construction.)
+static int draw_noise(klg_synth* s, RenderArgs& a, int n, hipStream_t st) {
+	const int draws = s->graph->noise_calls;
+	HIP_TRY(hipMemcpyAsync(s->h_flags, s->d_state, (size_t)s->V * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const size_t per = (size_t)n * (size_t)draws;
+	if (!s->d_rand) {
+		RandGuard rg;                                                  // allocations must not disturb the stream the draws below come from
+		HIP_TRY(hipMalloc((void**)&s->d_rand, std::max<size_t>(1, (size_t)s->V) * (size_t)s->max_block * (size_t)draws * sizeof(int)));
+		HIP_TRY(hipMalloc((void**)&s->d_rand_base, (size_t)s->V * sizeof(int)));
+	}
+	s->h_rand_base.assign((size_t)s->V, 0);
+	size_t sounding = 0;
+	for (int v = 0; v < s->V; v++) if ((s->h_flags[v] & 3u) != (uint32_t)ST_OFF) s->h_rand_base[(size_t)v] = (int)(per * sounding++);
+	s->h_rand.resize(std::max<size_t>(per, per * sounding));          // (lanes without a sounding voice read the first voice's values and drop the result)
+	for (size_t i = 0; i < per * sounding; i++) s->h_rand[i] = rand();
+	HIP_TRY(hipMemcpyAsync(s->d_rand, s->h_rand.data(), s->h_rand.size() * sizeof(int), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(s->d_rand_base, s->h_rand_base.data(), (size_t)s->V * sizeof(int), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));                                 // pageable staging: reused by the next block
+	a.rand = s->d_rand; a.rand_base = s->d_rand_base;
+	return 0;
+}
 static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipStream_t st) {
 	if (int rc = flush_events(s, st)) return rc;
 	if (int rc = upload_controls(s, st)) return rc;
@@ -717,6 +744,8 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	a.tables = s->d_tables;
 	a.rings = s->d_note_rings; a.ring_rows = s->graph ? (size_t)s->graph->ring_rows : 0;
 	a.solo = nullptr;
+	a.rand = nullptr; a.rand_base = nullptr;
+	if (s->graph && s->graph->noise_calls > 0) if (int rc = draw_noise(s, a, n, st)) return rc;
 	if (s->mix_mode == KLG_MIX_LAST_ACTIVE) {                      // after this block's events: which voice of each instance is heard
 		hipLaunchKernelGGL(klg_select_last_active, dim3((s->S + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->d_state, s->S, s->P, s->d_solo);
 		a.solo = s->d_solo;

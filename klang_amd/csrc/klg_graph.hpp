@@ -58,7 +58,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	auto ring = [&](int node) { return fx ? fmt("Ring{ c.ring + (size_t)%lldll * 64, 64, %d }", ring_off[(size_t)node], g.arg(node)) : fmt("Ring{ c.ring + (size_t)%lldll, 1, %d }", ring_off[(size_t)node], g.arg(node)); };
 	uint64_t mask[2] = { 1ull, 0ull };                                   // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
-	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { " + TI + " stage; float tinc;", begin, end, body;
+	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { " + TI + " stage; float tinc;" + (g.noise_calls() ? " int sidx;" : ""), begin, end, body;
 	const int noise_calls = g.noise_calls(); int noise_k = 0;
 	for (size_t i = 0; i < g.nodes.size(); i++) {
 		const int k = g.nodes[i], w0 = g.node_word0((int)i);
@@ -315,6 +315,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	s += "\tstruct Rec { " + TU + fmt(" w[%d]; };\n\tstatic constexpr int kWords = %d;\n", NW, NW);
 	s += fmt("\tstatic constexpr uint64_t kStoreMask = 0x%llxull;\n\tstatic constexpr uint64_t kStoreMask2 = 0x%llxull;\n", (unsigned long long)mask[0], (unsigned long long)mask[1]);
 	s += live;
+	if (!fx && noise_calls) { begin += "\t\tL.sidx = 0;\n"; body += "\t\tL.sidx++;\n"; }   // a voice's draws of the block: [sample][Noise generator in process() order]
 	if (!fx) {
 		// delay lines in notes: a wave keeps 64 voices x (read head, tap, write) x one 64-byte sector live while it walks its lines; at full
 		// occupancy the waves of an XCD hold more live sectors than its 4 MB L2 and every access becomes an HBM sector.  One wave per SIMD

@@ -38,6 +38,8 @@ struct RenderArgs {
 	float* rings;             // note delays: [stride + 1][ring_rows] (the last line is the dead lanes' scratch) — each voice's lines contiguous (a generated patch's Delay members), or null
 	size_t ring_rows;         // ring positions per voice = the sum of the patch's Delay SIZEs
 	const int* solo;          // KLG_MIX_LAST_ACTIVE: [synths] the one voice of each instance that is heard this block (-1: none), else null
+	const int* rand;          // Noise generators of a generated patch: this block's libc rand() values, drawn on the host in the reference's call order
+	const int* rand_base;     // ... [voices] where a sounding voice's n * draws values start (lanes without a sounding voice read from 0), else null
 };
 
 // record <-> word planes.  Words are moved with static indices only (fully unrolled) and converted with
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		// one scratch line behind the last voice's (line index `stride`), so an Off voice's own line keeps its contents like the reference's
 		ctx.ring = a.rings ? a.rings + (size_t)(live ? (size_t)v : a.stride) * a.ring_rows : nullptr;
 		ctx.ctl = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
+		ctx.rand = a.rand ? a.rand + (live ? a.rand_base[v] : 0) : nullptr;
 		// Dead lanes of a live wave run the same instruction stream on an all-zero record (no per-sample exec
 		// masking); their output is forced to 0 at the tile write and their record is never stored.
 		rw.w[0] = live ? flags : (uint32_t)ST_OFF;                  // (a lane without a voice: an all-zero record whose note stage says Off)

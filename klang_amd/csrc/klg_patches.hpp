@@ -24,6 +24,7 @@ struct BlockCtx {
 	const float* ctl;        // this voice's synth instance controls [KLG_MAX_CTL]
 	const TableDesc* tables; // klg_table_upload()ed sample tables (graph patches with Wavetable / Table reads), else null
 	float* ring;             // this voice's note-delay lines (contiguous), else null
+	const int* rand;         // this voice's rand() draws of the block, [n][draws per sample] (a generated patch with Noise generators), else null
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -85,6 +85,9 @@ def scenarios():
     out["own_early_return"] = poly("own_early_return", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 0, 0.1)])
     # iirn.k: Filters::IIR<2> / IIR<3> (the general recursive filter) as recorded nodes
     out["own_iirn"] = poly("own_iirn", 40, [0, 1, 7, 8, 39], off_base=8, notes=16)
+    # noise_note.k: two Noise generators per note: the process-wide rand() sequence is shared by the sounding notes in slot order, so the
+    # staggered note-ons / note-offs move every later voice's draws
+    out["own_noise_note"] = poly("own_noise_note", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.6), (20, 0, 0.0)])
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],
