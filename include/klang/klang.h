@@ -303,8 +303,9 @@ struct Control {
 	operator int() const;
 	signal smooth() {                                                                                        // klang.h:1715
 		if (gpu::Recorder* r = gpu::recording()) {
-			if (!r->effect) { r->fail("Control::smooth() (per-synth state advanced per sample) is not supported in a recorded Note::process()"); return smoothed; }
-			signal s(smoothed.value); s.reg = r->emit(klg::graph::OP_SMOOTH, -1, -1, r->smooth_node(&smoothed), (uint32_t)index, true); return s;   // one lane = one effect instance: its own smoothed state
+			// an Effect: one lane = one instance, its own smoothed state.  A Note: the control is its Synth's and every sounding note advances
+			// it in turn — the bank hands each voice the value its block starts from (klg_set_control_smoothed, klang_mi355.h)
+			signal s(smoothed.value); s.reg = r->emit(klg::graph::OP_SMOOTH, -1, -1, r->smooth_node(&smoothed), (uint32_t)index, true); return s;
 		}
 		smoothed = smoothed.value * 0.999f + (1.f - 0.999f) * value.value; return smoothed;
 	}
@@ -993,7 +994,7 @@ struct NoteBinding { int patch; void (*pack)(const void*, uint32_t*); void (*unp
 // type has the same layout, so the offsets found on the prototype serve all of them).
 namespace gpu {
 struct GraphLayout {
-	struct Member { size_t offset; int kind; int word0; };        // offset: of the Packable subobject (primitives) or of the signal (params)
+	struct Member { size_t offset; int kind; int word0; bool shared = false; };   // offset: of the Packable subobject (primitives) or of the signal (params); shared: a Note's smoothed control — it lives in the Synth, the bank sets the word per block
 	std::vector<Member> members;
 	std::string program;
 	int words = 0;
@@ -1002,6 +1003,7 @@ struct GraphLayout {
 		for (const Member& m : members) {
 			const char* obj = (const char*)note + m.offset;
 			if (m.kind == klg::graph::N_DELAY) continue;                           // no record words: the ring lives in HBM
+			if (m.shared) { w[m.word0] = 0u; continue; }
 			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH) w[m.word0] = fbits(reinterpret_cast<const signal*>(obj)->value);
 			else reinterpret_cast<const Packable*>(obj)->pack(w + m.word0);
 		}
@@ -1013,7 +1015,7 @@ struct GraphLayout {
 	void unpack(void* note, const uint32_t* w) const {
 		for (const Member& m : members) {
 			char* obj = (char*)note + m.offset;
-			if (m.kind == klg::graph::N_DELAY) continue;
+			if (m.kind == klg::graph::N_DELAY || m.shared) continue;
 			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH) std::memcpy(&reinterpret_cast<signal*>(obj)->value, &w[m.word0], 4);
 			else reinterpret_cast<Packable*>(obj)->unpack(w + m.word0);
 		}
@@ -1194,7 +1196,7 @@ inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	if (!verr.empty()) { std::fprintf(stderr, "klang-mi355: the recorded program is invalid: %s\n%s", verr.c_str(), R.prog.text().c_str()); std::abort(); }
 	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) {
 		const void* at = (R.objs[i].kind == N_PARAM || R.objs[i].kind == N_SMOOTH || !R.objs[i].packable) ? R.objs[i].addr : (const void*)R.objs[i].packable;
-		L.members.push_back({ (size_t)((const char*)at - lo), R.objs[i].kind, R.prog.node_word0(node_id[i]) });
+		L.members.push_back({ (size_t)((const char*)at - lo), R.objs[i].kind, R.prog.node_word0(node_id[i]), R.objs[i].kind == N_SMOOTH && !R.effect });
 	}
 	L.program = R.prog.text();
 	L.words = R.prog.words();
@@ -1791,8 +1793,12 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		words.resize(klg_synth_state_bytes(gpu) / 4);
 		stages.resize(notes.count);
 		sync_controls();
+		push_smoothed();
 	}
 	void sync_controls() { for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_set_control(gpu, 0, (int)c, controls.items[c].value.value); }
+	// Control::smoothed (klang.h:1707): the bank advances it (every sounding note's smooth() calls, in order); the host objects follow
+	void push_smoothed() { for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_set_control_smoothed(gpu, 0, (int)c, controls.items[c].smoothed.value); }
+	void pull_smoothed() { for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_get_control_smoothed(gpu, 0, (int)c, &controls.items[c].smoothed.value); }
 	// host mirror <- lane ; run the event ; lane <- host mirror
 	template<class F> void with_voice(int n, F&& event_code) {
 		ensure_gpu();
@@ -1846,6 +1852,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		sync_controls();
 		if (klg_process(gpu, buffers, channels, length, nullptr)) fail("klg_process");
 		refresh_stages();
+		pull_smoothed();
 	}
 };
 

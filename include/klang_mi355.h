@@ -99,6 +99,12 @@ int klg_note_off_many(klg_synth* s, int n, const int* synth, const int* pitch, c
  * Synth::process (klang.h:4444-4447, 4836-4839) followed by Synth::onControl (4399-4404). */
 int klg_set_control(klg_synth* s, int synth, int index, float value);
 int klg_get_control(klg_synth* s, int synth, int index, float* value);
+/* replaces: Control::smoothed (klang.h:1707), the state `controls[index].smooth()` (1715) advances.  In a Synth the control belongs to
+ * the Synth and EVERY sounding note's process() advances it — note by note, each through the whole block (4842-4848) — so a bank whose
+ * recorded Note calls smooth() keeps the value here, per synth instance, and hands every sounding voice the value its block starts
+ * from.  set: what a host's Control starts with (or a preset load); get: the value after the last block. */
+int klg_set_control_smoothed(klg_synth* s, int synth, int index, float smoothed);
+int klg_get_control_smoothed(klg_synth* s, int synth, int index, float* smoothed);
 
 /* replaces: Stereo::Synth::process(float** buffers, int length, float* parameters) klang.h:4830-4858
  * (and mono Synth::process(float*, int, float*) 4440-4466 with channels == 1): pending events are applied,

@@ -62,7 +62,7 @@ enum NodeKind {
 	N_OPERATOR = 20,   /* Operator<Fast::Sine>          4140-4180           words: inc pos frequency amp + the N_ENV words of its envelope */
 	N_DELAY = 21,   /* Delay<SIZE> (effects only)       3381-3512           words: none — a ring of SIZE floats per instance in HBM, position-major
 	                                                                        over the 64 instances of a wave; the write cursor is the sample counter */
-	N_SMOOTH = 22,  /* controls[i].smooth() in an effect   1715             words: smoothed */
+	N_SMOOTH = 22,  /* controls[i].smooth()                1715             words: smoothed (an effect instance's own; a note's is set per block: the Synth's notes share the control) */
 	N_WAVETABLE = 23,  /* Wavetable / Sample (synth notes)  3626-3720        words: increment position offset frequency table — `table` is the id
 	                                                                        klg_table_upload() returned for this note's samples (HBM; identical tables share an id) */
 	N_NDELAY = 24,  /* Delay<SIZE> member of a NOTE (physical models: a delay line per voice)  3381-3512   words: position (write cursor),
@@ -320,7 +320,7 @@ struct Program {
 		}
 		if (!def(ret)) return "graph program: 'ret' names an undefined register";
 		if (channels == 2 && !def(ret_r)) return "graph program: 'ret2' names an undefined register";
-		if (channels == 0) for (int k : nodes) if (k == N_DELAY || k == N_SMOOTH) return "graph program: delay / smooth nodes need an effect program (kind effect)";
+		if (channels == 0) for (int k : nodes) if (k == N_DELAY) return "graph program: delay nodes need an effect program (kind effect); a Note's Delay member is a notedelay";
 		if (channels != 0) for (int k : nodes) if (k == N_WAVETABLE || k == N_NDELAY) return "graph program: wavetable / notedelay nodes are only available to synth notes";
 		return "";
 	}

@@ -87,6 +87,15 @@ class SynthBank:
         check(self._L.klg_get_control(self._h, int(synth), int(index), C.byref(v)), "klg_get_control")
         return v.value
 
+    def set_control_smoothed(self, synth, index, value):
+        """Control::smoothed (klang.h:1707): what `controls[index].smooth()` in a recorded Note advances — the Synth's, shared by its notes."""
+        return check(self._L.klg_set_control_smoothed(self._h, int(synth), int(index), float(value)), "klg_set_control_smoothed")
+
+    def get_control_smoothed(self, synth, index):
+        v = C.c_float()
+        check(self._L.klg_get_control_smoothed(self._h, int(synth), int(index), C.byref(v)), "klg_get_control_smoothed")
+        return v.value
+
     # --- blocks ---
     def process(self, out, parameters=None):
         """out: float32 [channels][n] (accumulated into, like Stereo::Synth::process)."""

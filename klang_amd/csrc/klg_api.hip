@@ -135,6 +135,7 @@ struct klg_synth {
 	// host mirrors
 	std::vector<host::ControlH> controls;        // [S][nctl]
 	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
+	std::vector<float> smoothed, h_smooth_start; // Control::smoothed of every control [S][nctl] (note_prepass); staging [V]
 	bool controls_dirty = true;
 	std::vector<HostVoice> voices;
 	std::vector<unsigned> noteOns;               // [S]
@@ -314,9 +315,11 @@ static klg_synth* synth_create_common(int patch_id, const PatchInfo* pi, int syn
 	std::fill(init.begin(), init.begin() + s->stride, (uint32_t)ST_OFF);
 	if (hipMemcpy(s->d_state, init.data(), init.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { fail(KLG_ERR_HIP, "state init copy failed"); synth_free(s); return nullptr; }
 	s->controls.resize((size_t)s->S * std::max(1, s->nctl));
+	s->smoothed.assign((size_t)s->S * std::max(1, s->nctl), 0.f);
 	s->h_controls.assign((size_t)s->S * KLG_MAX_CTL, 0.f);
 	for (int i = 0; i < s->S; i++) for (int c = 0; c < s->nctl; c++) {
 		s->controls[(size_t)i * s->nctl + c] = { pi->dials[c].min, pi->dials[c].max, pi->dials[c].initial };
+		s->smoothed[(size_t)i * s->nctl + c] = pi->dials[c].initial;
 		s->h_controls[(size_t)i * KLG_MAX_CTL + c] = pi->dials[c].initial;
 	}
 	s->voices.resize(s->V);
@@ -697,6 +700,18 @@ extern "C" int klg_set_control(klg_synth* s, int synth, int index, float value) 
 	s->controls_dirty = true;
 	return 0;
 }
+extern "C" int klg_set_control_smoothed(klg_synth* s, int synth, int index, float smoothed) {
+	if (!s || synth < 0 || synth >= s->S || index < 0 || index >= s->nctl) return fail(KLG_ERR_INVALID, "klg_set_control_smoothed: synth %d / control %d out of range", synth, index);
+	if (s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); return klg_set_control_smoothed(s->multi->shard[(size_t)i], ls, index, smoothed); }
+	s->smoothed[(size_t)synth * s->nctl + index] = smoothed;
+	return 0;
+}
+extern "C" int klg_get_control_smoothed(klg_synth* s, int synth, int index, float* smoothed) {
+	if (!s || !smoothed || synth < 0 || synth >= s->S || index < 0 || index >= s->nctl) return fail(KLG_ERR_INVALID, "klg_get_control_smoothed: out of range");
+	if (s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); return klg_get_control_smoothed(s->multi->shard[(size_t)i], ls, index, smoothed); }
+	*smoothed = s->smoothed[(size_t)synth * s->nctl + index];
+	return 0;
+}
 extern "C" int klg_get_control(klg_synth* s, int synth, int index, float* value) {
 	if (!s || !value || synth < 0 || synth >= s->S || index < 0 || index >= s->nctl) return fail(KLG_ERR_INVALID, "klg_get_control: out of range");
 	if (s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); return klg_get_control(s->multi->shard[(size_t)i], ls, index, value); }
@@ -708,15 +723,36 @@ extern "C" int klg_get_control(klg_synth* s, int synth, int index, float* value)
 // block processing
 // ------------------------------------------------------------------------------------------------
 static int tables_sync(klg_synth* s);
-// Noise generators in a generated patch (klang.h:4947-4951, 5357-5366): every sounding note draws one libc rand() per generator and sample,
-// and the reference walks its notes one after the other — synth by synth, note slot by note slot, each through the whole block
-// (Synth::process 4842-4848, Note::process(buffer) 4295-4303: all n samples, also after a stop()).  So the block's draws are made HERE,
-// with rand() itself, in exactly that order, once the block's events are on the device and the note stages are back: voice v's values
-// start at rand_base[v].  (One device round trip per block: the price of a sequence that is shared by construction.)
-static int draw_noise(klg_synth* s, RenderArgs& a, int n, hipStream_t st) {
+// What the notes of a reference Synth SHARE, and therefore see in the order Synth::process walks them — synth by synth, note slot by
+// note slot, each sounding note through the whole block (klang.h:4842-4848; Note::process(buffer) 4295-4303 runs all n samples, also
+// after a stop()).  Both are settled HERE, per block, once the block's events are on the device and the note stages are back (one
+// device round trip per block: the price of state that is shared by construction):
+//  * Noise generators (4947-4951, 5357-5366): one libc rand() per generator and sample.  The block's draws are made with rand() itself
+//    in exactly that order; voice v's values start at rand_base[v].
+//  * controls[i].smooth() (1715): the control is the Synth's, every sounding note advances it.  The chain smoothed = smoothed * 0.999f +
+//    (1.f - 0.999f) * value runs on the host through the sounding notes (it stops early at its fp32 fixed point, where a step changes
+//    nothing); each voice's record gets the value ITS block starts from, and the lane repeats the same operations per sample.
+static int note_prepass(klg_synth* s, RenderArgs& a, int n, hipStream_t st) {
 	const int draws = s->graph->noise_calls;
 	HIP_TRY(hipMemcpyAsync(s->h_flags, s->d_state, (size_t)s->V * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
+	auto sounding = [&](int v) { return (s->h_flags[v] & 3u) != (uint32_t)ST_OFF; };
+	for (const auto& sm : s->graph->smooths) {
+		s->h_smooth_start.resize((size_t)s->V);
+		for (int i = 0; i < s->S; i++) {
+			float x = s->smoothed[(size_t)i * s->nctl + sm.ctl];
+			const float k = (1.f - 0.999f) * s->controls[(size_t)i * s->nctl + sm.ctl].value;
+			for (int v = i * s->P; v < (i + 1) * s->P; v++) {
+				s->h_smooth_start[(size_t)v] = x;
+				if (!sounding(v)) continue;
+				for (long long t = (long long)n * sm.calls; t > 0; t--) { const float y = x * 0.999f + k; if (y == x) break; x = y; }
+			}
+			s->smoothed[(size_t)i * s->nctl + sm.ctl] = x;
+		}
+		HIP_TRY(hipMemcpyAsync(s->d_state + (size_t)sm.word * s->stride, s->h_smooth_start.data(), (size_t)s->V * 4, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipStreamSynchronize(st));                             // pageable staging: reused by the next node / block
+	}
+	if (draws == 0) return 0;
 	const size_t per = (size_t)n * (size_t)draws;
 	if (!s->d_rand) {
 		RandGuard rg;                                                  // allocations must not disturb the stream the draws below come from
@@ -724,10 +760,10 @@ static int draw_noise(klg_synth* s, RenderArgs& a, int n, hipStream_t st) {
 		HIP_TRY(hipMalloc((void**)&s->d_rand_base, (size_t)s->V * sizeof(int)));
 	}
 	s->h_rand_base.assign((size_t)s->V, 0);
-	size_t sounding = 0;
-	for (int v = 0; v < s->V; v++) if ((s->h_flags[v] & 3u) != (uint32_t)ST_OFF) s->h_rand_base[(size_t)v] = (int)(per * sounding++);
-	s->h_rand.resize(std::max<size_t>(per, per * sounding));          // (lanes without a sounding voice read the first voice's values and drop the result)
-	for (size_t i = 0; i < per * sounding; i++) s->h_rand[i] = rand();
+	size_t count = 0;
+	for (int v = 0; v < s->V; v++) if (sounding(v)) s->h_rand_base[(size_t)v] = (int)(per * count++);
+	s->h_rand.resize(std::max<size_t>(per, per * count));             // (lanes without a sounding voice read the first voice's values and drop the result)
+	for (size_t i = 0; i < per * count; i++) s->h_rand[i] = rand();
 	HIP_TRY(hipMemcpyAsync(s->d_rand, s->h_rand.data(), s->h_rand.size() * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(s->d_rand_base, s->h_rand_base.data(), (size_t)s->V * sizeof(int), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipStreamSynchronize(st));                                 // pageable staging: reused by the next block
@@ -745,7 +781,7 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	a.rings = s->d_note_rings; a.ring_rows = s->graph ? (size_t)s->graph->ring_rows : 0;
 	a.solo = nullptr;
 	a.rand = nullptr; a.rand_base = nullptr;
-	if (s->graph && s->graph->noise_calls > 0) if (int rc = draw_noise(s, a, n, st)) return rc;
+	if (s->graph && (s->graph->noise_calls > 0 || !s->graph->smooths.empty())) if (int rc = note_prepass(s, a, n, st)) return rc;
 	if (s->mix_mode == KLG_MIX_LAST_ACTIVE) {                      // after this block's events: which voice of each instance is heard
 		hipLaunchKernelGGL(klg_select_last_active, dim3((s->S + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->d_state, s->S, s->P, s->d_solo);
 		a.solo = s->d_solo;

@@ -425,7 +425,7 @@ struct Rtc {
 	}
 };
 
-struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; int noise_calls = 0; bool x2 = false; std::vector<std::pair<long long, int>> delays; };   // delays: (first ring row, SIZE) of each delay node in node order   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
+struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; int noise_calls = 0; struct Smooth { int word, ctl, calls; }; std::vector<Smooth> smooths; bool x2 = false; std::vector<std::pair<long long, int>> delays; };   // delays: (first ring row, SIZE) of each delay node in node order   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
 
 // directory holding klg_kernels.hpp etc.: next to the shared library (klang_amd/csrc), or $KLG_GRAPH_SRC
 inline std::string source_dir() {
@@ -458,6 +458,11 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	c.words = g.words(); c.channels = g.channels; c.x2 = x2;
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY || g.nodes[i] == graph::N_NDELAY) { c.delays.push_back({ c.ring_rows, g.arg((int)i) }); c.ring_rows += g.arg((int)i); }
 	c.noise_calls = g.noise_calls();
+	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_SMOOTH) {            // controls[ctl].smooth(): state word, control, calls per sample
+		Compiled::Smooth sm = { g.node_word0((int)i), -1, 0 };
+		for (const graph::Op& o : g.ops) if (o.code == graph::OP_SMOOTH && o.node == (int)i) { sm.ctl = (int)o.imm; sm.calls++; }
+		if (sm.calls) c.smooths.push_back(sm);
+	}
 	void* prog = nullptr;
 	if (rtc.CreateProgram(&prog, c.source.c_str(), "klg_graph_patch.hip", 0, nullptr, nullptr) != 0) return "hiprtcCreateProgram failed";
 	const char* expr[2] = { "klg::klg_render<klg::PatchGen, false>", "klg::klg_render<klg::PatchGen, true>" };

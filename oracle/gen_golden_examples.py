@@ -88,10 +88,13 @@ def scenarios():
     # noise_note.k: two Noise generators per note: the process-wide rand() sequence is shared by the sounding notes in slot order, so the
     # staggered note-ons / note-offs move every later voice's draws
     out["own_noise_note"] = poly("own_noise_note", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.6), (20, 0, 0.0)])
+    # smooth_note.k: controls[i].smooth() in a Note: the Synth's control is advanced by every sounding note in turn; dial moves mid-run
+    # (the chain is still converging while notes start and end around it), then long enough to reach its fixed point
+    out["own_smooth_note"] = poly("own_smooth_note", 40, [0, 1, 3, 4, 7, 8, 39], off_base=8, notes=16, ctl=[(0, 1000.0), (1, 0.8)], ctl_events=[(3, 0, 4000.0), (3, 1, 0.3), (7, 0, 300.0), (12, 1, 1.0)])
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],
-                "ex_operators": [(0, 1.0), (1, 0.5), (2, 1.0), (3, 4.296), (4, 2.0)], "own_early_return": [(0, 0.9)]}
+                "ex_operators": [(0, 1.0), (1, 0.5), (2, 1.0), (3, 4.296), (4, 2.0)], "own_early_return": [(0, 0.9)], "own_smooth_note": [(0, 2500.0), (1, 0.5)]}
     for name in list(out):
         src = out[name]
         s = Scenario(patch=src.patch, block=256, blocks=24, synths=1, notes=src.notes, dump=[0, 23])

@@ -206,3 +206,15 @@ def test_facade_records_our_dsl_patch():
     assert ops == ["osc", "lpf", "env", "mul", "stopif"], ops
     rc, msg = check(err[err.index("klgg 1"):err.index("end\n") + 4])
     assert rc == 0, msg
+
+
+def test_a_notes_smoothed_control_is_a_record_word_the_bank_sets_per_block():
+    """controls[i].smooth() in a Note (klang.h:1715): the control is the Synth's and every sounding note advances it in turn, so the
+    generated body repeats the reference's operations on a record word that klg_process fills with the value this voice's block starts
+    from (note_prepass, klg_api.hip).  Two calls per sample on one control are two steps; such a program runs one voice per lane."""
+    prog = "klgg 1\nctl 2\nnode 0 fsine\nnode 1 smooth\nop osc 0 -1 -1 0 0\nop smooth 1 -1 -1 1 1\nop smooth 2 -1 -1 1 1\nop mul 3 0 1 -1 0\nop mul 4 3 2 -1 0\nret 4\nend\n"
+    rc, src = check(prog, want_source=True)
+    assert rc == 0, src
+    assert src.count("L.n1 = L.n1 * 0.999f + (1.f - 0.999f) * c.ctl[1];") == 2 * 3 and "klg_render_x2<" not in src      # three bodies
+    rc, msg = check(prog.replace("op smooth 2 -1 -1 1 1", "op smooth 2 -1 -1 1 5"))
+    assert rc < 0 and "not a smoothed control" in msg
