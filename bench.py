@@ -246,7 +246,7 @@ def run_literal_script(patch, voices, N, label, phases=False):
     kern_s = 1e-3 * float(np.median(ms[40:OFF_BLOCK]))
     ab = alg_bytes(patch, bank, V, N)
     res["roofline"] = {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                       "kernel": ("klg_render_supersaw_lanes" if patch == "supersaw" and voices <= 65536 else KERNEL_OF.get(patch, patch)), "phase": "sustain (block time incl. event kernel + reduce)", "algorithmic_bytes_per_launch": ab,
+                       "kernel": ("klg_render_supersaw_pairs" if patch == "supersaw" and voices <= 131072 else KERNEL_OF.get(patch, patch)), "phase": "sustain (block time incl. event kernel + reduce)", "algorithmic_bytes_per_launch": ab,
                        "note": "voice state lives in registers: VALU-issue bound by design (DESIGN.md §3)"}
     if phases:
         res["phases_ms_per_block"] = {"attack_decay_all_ramping(1..21)": float(np.median(ms[1:22])), "sustain_only(40..149)": float(np.median(ms[40:OFF_BLOCK])),

@@ -119,7 +119,8 @@ struct klg_synth {
 	int device = 0;                              // the GPU this bank (or shard) lives on
 	int mix_mode = 0; int* d_solo = nullptr;      // klg_synth_set_mix_mode: KLG_MIX_LAST_ACTIVE keeps one voice per instance (d_solo[synths])
 	bool x2 = true;               // KLG_RENDER_X1=1 in the environment selects the one-voice-per-lane kernel (A/B tests)
-	bool lanes = false;           // SuperSaw banks that do not fill the chip: one oscillator per lane (klg_render_lanes.hpp); KLG_SUPERSAW_LANES=0 / 1 forces the choice
+	bool lanes = false;           // SuperSaw banks that do not fill the chip: an oscillator pair — or one oscillator — per lane (klg_render_lanes.hpp); KLG_SUPERSAW_LANES=0 / 1 / 2 forces the choice
+	bool pairs = false; int pairs_p = 1;   // ... the pair form (2; the default for such banks) and its sample slots per voice (KLG_SUPERSAW_PAIRS_P forces 1 / 2 / 4)
 	int grid_lanes = 0;
 	// graph patches (klg_graph.hpp): the render kernels come from a hipRTC code object instead of this library
 	const graphrt::Compiled* graph = nullptr;
@@ -300,8 +301,14 @@ static klg_synth* synth_create_common(int patch_id, const PatchInfo* pi, int syn
 	ok = ok && hipMalloc(&s->d_controls, (size_t)s->S * KLG_MAX_CTL * 4) == hipSuccess;
 	if (patch_id == KLG_PATCH_SUPERSAW) {
 		const char* e = getenv("KLG_SUPERSAW_LANES");
-		s->lanes = e ? e[0] == '1' : s->V <= KLG_LANES_MAX_VOICES;
-		s->grid_lanes = std::min((s->V + KLG_LANES_VOICES_PER_WG - 1) / KLG_LANES_VOICES_PER_WG, (ok ? prop.multiProcessorCount : 256) * 8);
+		s->lanes = e ? (e[0] == '1' || e[0] == '2') : s->V <= KLG_LANES_MAX_VOICES;
+		s->pairs = s->lanes && !(e && e[0] == '1');
+		// sample slots per voice: enough waves for four per SIMD (a 16,384-voice bank: 4096); a bank that has them anyway keeps one
+		const char* pe = getenv("KLG_SUPERSAW_PAIRS_P");
+		s->pairs_p = pe ? atoi(pe) : (s->V <= 16384 ? 4 : 1);     // measured: 16,384 voices 58 / 49 / 49 us with 1 / 2 / 4 slots, 32,768 voices 77 / 82 / 87
+		if (s->pairs_p != 1 && s->pairs_p != 2 && s->pairs_p != 4) s->pairs_p = 1;
+		const int per_wg = s->pairs ? 16 / s->pairs_p * WAVES : KLG_LANES_VOICES_PER_WG;
+		s->grid_lanes = std::min((s->V + per_wg - 1) / per_wg, (ok ? prop.multiProcessorCount : 256) * 8);
 	}
 	ok = ok && hipMalloc(&s->d_partials, (size_t)std::max(s->grid, s->lanes ? s->grid_lanes : 0) * max_block * 4) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_mix, (size_t)2 * max_block * 4) == hipSuccess;
@@ -442,7 +449,20 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 		else hipLaunchKernelGGL(klg_render_sub2a_x2<false>, g, b, render_lds_bytes(a.n), st, a);
 		return;
 	}
-	if (s->lanes) {                                       // SuperSaw, one oscillator per lane (small banks)
+	if (s->pairs) {                                       // SuperSaw, an oscillator pair per lane (small banks)
+		const dim3 g(render_grid(s)), b(WG);
+		const size_t lds = render_lds_bytes(a.n);
+		switch (s->pairs_p * 2 + (pv ? 1 : 0)) {
+		case 2: hipLaunchKernelGGL((klg_render_supersaw_pairs<1, false>), g, b, lds, st, a); break;
+		case 3: hipLaunchKernelGGL((klg_render_supersaw_pairs<1, true>), g, b, lds, st, a); break;
+		case 4: hipLaunchKernelGGL((klg_render_supersaw_pairs<2, false>), g, b, lds, st, a); break;
+		case 5: hipLaunchKernelGGL((klg_render_supersaw_pairs<2, true>), g, b, lds, st, a); break;
+		case 8: hipLaunchKernelGGL((klg_render_supersaw_pairs<4, false>), g, b, lds, st, a); break;
+		default: hipLaunchKernelGGL((klg_render_supersaw_pairs<4, true>), g, b, lds, st, a); break;
+		}
+		return;
+	}
+	if (s->lanes) {                                       // SuperSaw, one oscillator per lane (KLG_SUPERSAW_LANES=1)
 		const dim3 g(render_grid(s)), b(WG);
 		if (pv) hipLaunchKernelGGL(klg_render_supersaw_lanes<true>, g, b, render_lds_bytes(a.n), st, a);
 		else hipLaunchKernelGGL(klg_render_supersaw_lanes<false>, g, b, render_lds_bytes(a.n), st, a);

@@ -32,6 +32,16 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 // ({EXP, pos} >> 9).  EXP = 0x7F: a float in [1, 2); EXP = 0x80: in [2, 4).
 template<uint32_t EXP> __device__ __forceinline__ uint32_t phase_mantissa(uint32_t pos) { return __builtin_amdgcn_alignbit(EXP, pos, 9u); }
 
+// 2-vectors: fp32 multiplies / adds / fmas on them issue as ONE v_pk_* operation whose halves are ordinary IEEE operations (the packed
+// two-voices-per-lane primitives of klg_device_x2.hpp, and osm_saw_pair below: two oscillators of one voice)
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 as_f2(u2 v) { return __builtin_bit_cast(f2, v); }
+__device__ __forceinline__ u2 as_u2(f2 v) { return __builtin_bit_cast(u2, v); }
+__device__ __forceinline__ f2 splat(float x) { f2 r = { x, x }; return r; }
+template<uint32_t EXP> __device__ __forceinline__ f2 phase_float2(u2 pos) { u2 m = { phase_mantissa<EXP>(pos.x), phase_mantissa<EXP>(pos.y) }; return as_f2(m); }   // see phase_mantissa
+
 // float -> unsigned exactly as the pinned oracle build does it (clang, baseline x86-64: cvttss2si r64,
 // truncate to 32 bits; "integer indefinite" = 0 in the low word when out of range / NaN).  Reproduces the
 // wrap of negative FM phase offsets (F3, klang.h:4995-4996).

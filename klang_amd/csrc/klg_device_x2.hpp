@@ -12,14 +12,7 @@
 
 namespace klg {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef int i2 __attribute__((ext_vector_type(2)));
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f2 as_f2(u2 v) { return __builtin_bit_cast(f2, v); }
-__device__ __forceinline__ u2 as_u2(f2 v) { return __builtin_bit_cast(u2, v); }
-__device__ __forceinline__ f2 splat(float x) { f2 r = { x, x }; return r; }
-template<uint32_t EXP> __device__ __forceinline__ f2 phase_float2(u2 pos) { u2 m = { phase_mantissa<EXP>(pos.x), phase_mantissa<EXP>(pos.y) }; return as_f2(m); }   // see phase_mantissa
+// (f2 / i2 / u2, as_f2, as_u2, splat, phase_float2: klg_device.hpp)
 
 // ---- helpers a generated body uses for both widths ----
 __device__ __forceinline__ f2 u2f(u2 v) { return as_f2(v); }

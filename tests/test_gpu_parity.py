@@ -153,13 +153,16 @@ def test_one_voice_per_lane_kernel_matches_too(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["supersaw_ctl", "supersaw_poly"])
-@pytest.mark.parametrize("lanes", ["0", "1"])
-def test_both_supersaw_kernels_match(name, lanes, monkeypatch):
-    """SuperSaw banks of up to 65,536 voices run the oscillator-per-lane kernel (klg_render_lanes.hpp), larger ones the voice-per-lane
-    kernel; KLG_SUPERSAW_LANES forces the choice.  Both must reproduce the reference bit for bit per voice."""
+@pytest.mark.parametrize("lanes", ["0", "1", "2:1", "2:2", "2:4"])
+def test_all_supersaw_kernels_match(name, lanes, monkeypatch):
+    """SuperSaw banks of up to 131,072 voices run the oscillator-pair-per-lane kernel (klg_render_lanes.hpp; 1: its one-oscillator-per-lane
+    predecessor), larger ones the voice-per-lane kernel; KLG_SUPERSAW_LANES forces the choice, KLG_SUPERSAW_PAIRS_P the pair kernel's
+    sample slots per voice.  All must reproduce the reference bit for bit per voice."""
     if not os.path.exists(os.path.join(GOLDEN, name + ".scn")):
         pytest.skip("no such fixture")
-    monkeypatch.setenv("KLG_SUPERSAW_LANES", lanes)
+    monkeypatch.setenv("KLG_SUPERSAW_LANES", lanes[0])
+    if ":" in lanes:
+        monkeypatch.setenv("KLG_SUPERSAW_PAIRS_P", lanes[2])              # sample slots per voice of the pair kernel
     s = Scenario.load(os.path.join(GOLDEN, name + ".scn"))
     ref = np.load(os.path.join(GOLDEN, name + ".npz"))
     got = run_scenario_gpu(s)
@@ -196,3 +199,67 @@ def test_against_oracle_through_whole_note_lives(patch, synths, notes, seeded, o
 def test_whole_note_lives_on_the_voice_per_lane_supersaw_kernel_too(oracle_build, monkeypatch):
     monkeypatch.setenv("KLG_SUPERSAW_LANES", "0")
     test_against_oracle_through_whole_note_lives("supersaw", 8, 32, True, oracle_build)
+
+
+def test_supersaw_pair_kernel_rebuilds_oscillators_of_records_it_cannot_hold(monkeypatch):
+    """The pair form assumes what note_on makes: one duty for the two oscillators of a lane, increments and duties of at least 2^-23.
+    Hand-made records (klg_voice_upload) may be anything: a wave that holds one takes the scalar table per oscillator.  Same voices, same
+    odd records, through the voice-per-lane kernel and the pair kernel: equal bit for bit — samples and final records."""
+    import klang_amd
+    def run(lanes, p="1", N=256):
+        monkeypatch.setenv("KLG_SUPERSAW_LANES", lanes)
+        monkeypatch.setenv("KLG_SUPERSAW_PAIRS_P", p)
+        bank = klang_amd.SynthBank("supersaw", synths=2, notes=32, max_block=N)
+        rng = np.random.default_rng(11)
+        for sy in range(2):
+            for k in range(20):
+                bank.random(1000 + 32 * sy + k)
+                bank.note_on(sy, int(rng.integers(36, 97)), float(rng.uniform(0.3, 1.0)))
+        bank.process(np.zeros((2, N), np.float32))
+        for v, (osc, word, value) in {3: (1, 2, 0x30000000), 17: (4, 2, 0), 21: (6, 2, 300), 40: (2, 0, 200), 41: (5, 2, 0x08000000)}.items():
+            w = bank.voice_download(v)                                    # rec::SuperSaw: flags | 7 x (inc offset duty delta) | adsr
+            w[1 + 4 * osc + word] = value
+            if word == 0:
+                w[1 + 4 * osc + 3] = np.float32(0.0).view(np.uint32)      # delta follows the increment (an increment below 2^-23 of a cycle: 0)
+            bank.voice_upload(v, w)
+        pv = [bank.process_voices(N)[0].copy() for _ in range(4)]
+        recs = np.stack([bank.voice_download(v) for v in range(64)])
+        bank.close()
+        return np.stack(pv), recs
+    for n in (256, 37, 1):                                                # whole chunks; a ragged last iteration; a single sample
+        a, ra = run("0", N=n)
+        for p in ("1", "2", "4"):
+            b, rb = run("2", p, N=n)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (n, p)
+            assert np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32)), (n, p)
+            assert np.array_equal(ra, rb), (n, p)
+        assert np.abs(a[~np.isnan(a)]).max() > 0
+
+
+@pytest.mark.parametrize("p", ["1", "2", "4"])
+@pytest.mark.parametrize("n", [256, 37, 1])
+def test_supersaw_pair_kernel_block_lengths(p, n, monkeypatch):
+    """Ordinary records (note_on), odd block lengths: the pair kernel's sample slots against the voice-per-lane kernel, samples and records."""
+    import klang_amd
+    def run(lanes):
+        monkeypatch.setenv("KLG_SUPERSAW_LANES", lanes)
+        monkeypatch.setenv("KLG_SUPERSAW_PAIRS_P", p)
+        bank = klang_amd.SynthBank("supersaw", synths=3, notes=32, max_block=256)
+        rng = np.random.default_rng(5)
+        for sy in range(3):
+            for k in range(24):
+                bank.random(77 + 32 * sy + k)
+                bank.note_on(sy, int(rng.integers(36, 97)), float(rng.uniform(0.3, 1.0)))
+        out = []
+        for b in range(6):
+            if b == 3:
+                for sy in range(3):
+                    bank.set_control(sy, 1, 0.3)                          # Saw-Tri: the next note_on carries another duty
+                    bank.random(5); bank.note_on(sy, 60, 0.9)
+            out.append(bank.process_voices(n)[0].copy())
+        recs = np.stack([bank.voice_download(v) for v in range(96)])
+        bank.close()
+        return np.stack(out), recs
+    a, ra = run("0")
+    b, rb = run("2")
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(ra, rb) and np.abs(a).max() > 0
