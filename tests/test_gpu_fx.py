@@ -45,8 +45,10 @@ def test_fx_against_oracle_many_instances(patch, instances, blocks, oracle_build
     ref = run_scenario_oracle(s, oracle_build)["per_voice"]
     got = run_fx_scenario_gpu(s)["per_voice"]
     err = rel_err(got, ref)
-    print(f"{patch}: {instances} instances, rel err {err:.3e}, bit-exact {100 * bit_exact_fraction(got, ref):.2f}%")
+    exact = bit_exact_fraction(got, ref)
+    print(f"{patch}: {instances} instances, rel err {err:.3e}, bit-exact {100 * exact:.2f}%")
     assert err <= TOL
+    assert exact == 1.0          # an instance is one lane's (or one quad's) own arithmetic in the reference's order: nothing to round differently
 
 
 def test_pingpong_near_taps_and_vibrato(oracle_build):
