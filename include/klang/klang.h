@@ -530,12 +530,15 @@ namespace Basic {
 		klg::host::BOscH h; float duty_ = 0.5f; int kind;
 		explicit Osc(int k) : kind(k) { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Osc), k, this); }
 		using Oscillator::set;
-		void reset() override { if (gpu::no_set_while_recording("Basic oscillator reset()")) return; h.position = 0; }
+		void reset() override { if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, -1, -1, r->node(this, "Basic oscillator"), 2, false); return; } h.position = 0; }
 		void set(param f) override {
 			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Basic oscillator"), 0, false); frequency = f; return; }
 			h.frequency = f; h.increment = f * 2.f * pi.f / fs.f; frequency = f;
 		}
-		void set(param f, param phase) override { if (gpu::no_set_while_recording("Basic oscillator set(f, phase)")) return; h.set(f, phase, host_fs()); frequency = f; }
+		void set(param f, param phase) override {
+			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), r->reg_of(phase), r->node(this, "Basic oscillator"), 1, false); frequency = f; return; }   // per sample: re-phasing
+			h.set(f, phase, host_fs()); frequency = f;
+		}
 		void set(param f, relative phase) override { set(f); set(phase); }
 		void set(relative phase) override { if (gpu::no_set_while_recording("Basic oscillator set(relative)")) return; h.offset = phase.value * (2 * pi); }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Basic oscillator"), 0, true); return; } device_only("Basic oscillator process()"); }
@@ -572,13 +575,16 @@ namespace Fast {
 		klg::host::FSineH h;
 		Sine() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Sine), klg::graph::N_FSINE, this); }
 		using Oscillator::set;
-		void reset() override { if (gpu::no_set_while_recording("Fast::Sine::reset()")) return; h.pos = 0; }                        // klang.h:5136-5140
+		void reset() override { if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, -1, -1, r->node(this, "Fast::Sine"), 2, false); return; } h.pos = 0; }   // klang.h:5136-5140
 		void set(param f) override {
 			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), -1, r->node(this, "Fast::Sine"), 0, false); frequency = f; return; }   // per-sample set(f): vibrato / FM
 			if (f != h.frequency) { h.frequency = f; h.inc = klg::host::fast_increment(f, host_fs()); }
 			frequency = f;
 		}
-		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast::Sine::set(f, phase)")) return; h.set(f, phase, host_fs()); frequency = f; }
+		void set(param f, param phase) override {
+			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), r->reg_of(phase), r->node(this, "Fast::Sine"), 1, false); frequency = f; return; }
+			h.set(f, phase, host_fs()); frequency = f;
+		}
 		void set(param f, relative phase) override { set(f); set(phase); }
 		void set(relative) override { device_only("Fast::Sine::set(relative) [phase modulation]"); }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast::Sine"), 0, true); return; } device_only("Fast::Sine::process()"); }
@@ -595,7 +601,10 @@ namespace Fast {
 			if (h.frequency != f) { h.refresh(f, host_fs()); h.init(); }
 			frequency = f;
 		}
-		void set(param f, param phase) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase)")) return; h.set(f, phase, host_fs()); frequency = f; }
+		void set(param f, param phase) override {
+			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), r->reg_of(phase), r->node(this, "Fast oscillator"), 1, false); frequency = f; return; }   // per sample: hard sync
+			h.set(f, phase, host_fs()); frequency = f;
+		}
 		void set(param f, param phase, param duty) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase, duty)")) return; h.set(f, phase, duty, host_fs()); frequency = f; }
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast oscillator"), 0, true); return; } device_only("Fast::Osm::process()"); }
 		void pack(uint32_t* w) const override { using namespace klg::graph; w[OSM_INC] = (uint32_t)h.inc; w[OSM_OFFSET] = h.offset; w[OSM_DUTY] = h.duty; w[OSM_DELTA] = gpu::fbits(h.delta); w[OSM_STATE] = (uint32_t)h.state; w[OSM_FREQ] = gpu::fbits(h.frequency); }

@@ -126,7 +126,8 @@ enum OpCode {
 	OP_CTL,         /* dst = controls[imm]                 (the synth instance's control value)      */
 	OP_PARAM,       /* dst = value word of N_PARAM node                                               */
 	OP_OSC,         /* dst = oscillator node process()     Fast::Sine / OSM saw / OSM pulse / Basic::*   */
-	OP_OSCSET,      /* oscillator node .set(f = a)         Fast::Sine::set 5142-5147 / OSM::set 5217-5224 / Oscillator::set 2862 (per sample: vibrato, FM) */
+	OP_OSCSET,      /* oscillator node .set(f = a)         Fast::Sine::set 5142-5147 / OSM::set 5217-5224 / Oscillator::set 2862 (per sample: vibrato, FM);
+	                   imm 1: .set(f = a, phase = b) 5149-5153 / 5226-5234 / 2867-2870 (hard sync, re-phasing); imm 2: .reset() 5136-5140 / 2859 */
 	OP_LPF,         /* dst = (a >> modifier node)          any modifier kind: Biquad::Filter::process 5605-5612, OnePole, DCF, IIR<1>, ... */
 	OP_LPFSET,      /* lpf node .set(f = a, Q = b)         Biquad::Filter::set klang.h:5575-5600 + the init() of type imm (0 LPF, 1 HPF, 2 / 3 BPF peak / skirt, 4 BRF, 6 Butterworth<2>) */
 	OP_ENV,         /* dst = env/adsr node ++              Envelope::operator++ klang.h:4013-4051     */
@@ -262,7 +263,7 @@ struct Program {
 			case OP_CTL: if ((int)o.imm >= nctl) return bad("control index out of range"); break;
 			case OP_PARAM: if (k != N_PARAM) return bad("node is not a param"); break;
 			case OP_OSC: if (!is_oscillator(k)) return bad("node is not an oscillator"); break;
-			case OP_OSCSET: if (!is_oscillator(k)) return bad("node is not an oscillator"); need_a = true; has_dst = false; break;
+			case OP_OSCSET: if (!is_oscillator(k)) return bad("node is not an oscillator"); if (o.imm > 2u || (o.imm && k == N_WAVETABLE) || (o.imm == 2u && (k == N_SAW || k == N_PULSE))) return bad("this oscillator has no such set() / reset() on the device"); need_a = o.imm != 2u; need_b = o.imm == 1u; has_dst = false; break;
 			case OP_LPF: if (!is_modifier(k)) return bad("node is not a modifier"); need_a = true; break;
 			case OP_LPFSET: if (k != N_LPF) return bad("node is not an lpf"); if (o.imm == 5 || o.imm > 6) return bad("this biquad type cannot be set() on the device"); need_a = need_b = true; has_dst = false; break;
 			case OP_ENV: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); break;

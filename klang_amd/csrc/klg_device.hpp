@@ -97,6 +97,8 @@ __device__ __forceinline__ int32_t fast_increment_set(float f, float fs) {
 struct FSine { int32_t inc; uint32_t pos; };
 // Fast::Sine::set(frequency) klang.h:5142-5147: only when it differs from the cached Oscillator::frequency
 __device__ __forceinline__ void fsine_set_f(FSine& o, float& cached, float f, float fs) { if (f != cached) { cached = f; o.inc = fast_increment_set(f, fs); } }
+// set(frequency, phase) klang.h:5149-5153: position = phase (offset = 0: phase modulation is not a node feature), then set(frequency)
+__device__ __forceinline__ void fsine_set_fp(FSine& o, float& cached, float f, float phase, float fs) { o.pos = fast_phase(phase); fsine_set_f(o, cached, f, fs); }
 __device__ __forceinline__ float fsine_process(FSine& o, uint32_t off) {
 	const float y = fastsinp(o.pos + off);
 	o.pos += (uint32_t)o.inc;
@@ -154,6 +156,13 @@ __device__ __forceinline__ void osm_set_f(Osm& o, float& cached, float f, float 
 		o.state = ((uint32_t)(o.offset - (uint32_t)o.inc) < o.duty) ? 3 : 0;
 		osm_derive(o);
 	}
+}
+// OSM::set(frequency, phase) klang.h:5226-5234: increment and delta only when the frequency changes; the phase and init() always
+__device__ __forceinline__ void osm_set_fp(Osm& o, float& cached, float f, float phase, float fs) {
+	if (cached != f) { cached = f; o.inc = fast_increment_set(f, fs); o.delta = fast_increment_float(o.inc); }
+	o.offset = fast_phase(phase);
+	o.state = ((uint32_t)(o.offset - (uint32_t)o.inc) < o.duty) ? 3 : 0;
+	osm_derive(o);
 }
 __device__ __forceinline__ int osm_tick(Osm& o) {                           // klang.h:5251-5263
 	o.state = ((o.state << 1) | (o.offset < o.duty ? 1 : 0)) & 3;

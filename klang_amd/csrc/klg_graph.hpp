@@ -247,7 +247,12 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			body += d + e + ";\n";
 		} break;
 		case OP_OSCSET:
-			if (k == N_WAVETABLE) body += "\t\twavetable_set_f(" + n + ", " + n + "f, " + a + ", c.fs.f);\n";
+			if (o.imm == 2u) body += "\t\t" + n + (k == N_FSINE ? ".pos = 0u;\n" : ".position = 0.f;\n");                               // reset(): Fast::Sine 5136-5140 (= set(frequency, 0)), Oscillator 2859
+			else if (o.imm == 1u) {                                                                                                    // set(f, phase)
+				if (k >= N_BSINE && k <= N_BPULSE) body += "\t\t" + n + ".position = " + b + "; " + n + "f = " + a + "; " + n + ".increment = " + a + " * 2.f * KLG_PI_F / c.fs.f;\n";   // klang.h:2867-2870
+				else body += "\t\t" + std::string(k == N_FSINE ? "fsine_set_fp(" : "osm_set_fp(") + n + ", " + n + "f, " + a + ", " + b + ", c.fs.f);\n";
+			}
+			else if (k == N_WAVETABLE) body += "\t\twavetable_set_f(" + n + ", " + n + "f, " + a + ", c.fs.f);\n";
 			else if (k >= N_BSINE && k <= N_BPULSE) body += "\t\t" + n + "f = " + a + "; " + n + ".increment = " + a + " * 2.f * KLG_PI_F / c.fs.f;\n";   // Oscillator::set(f) klang.h:2862-2865
 			else body += "\t\t" + std::string(k == N_FSINE ? "fsine_set_f(" : "osm_set_f(") + n + ", " + n + "f, " + a + ", c.fs.f);\n";
 			break;

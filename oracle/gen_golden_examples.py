@@ -91,6 +91,8 @@ def scenarios():
     # smooth_note.k: controls[i].smooth() in a Note: the Synth's control is advanced by every sounding note in turn; dial moves mid-run
     # (the chain is still converging while notes start and end around it), then long enough to reach its fixed point
     out["own_smooth_note"] = poly("own_smooth_note", 40, [0, 1, 3, 4, 7, 8, 39], off_base=8, notes=16, ctl=[(0, 1000.0), (1, 0.8)], ctl_events=[(3, 0, 4000.0), (3, 1, 0.3), (7, 0, 300.0), (12, 1, 1.0)])
+    # hardsync.k: set(f, phase) / reset() on Fast::OSM, Fast::Sine and Basic::Sine oscillators from inside branches of process()
+    out["own_hardsync"] = poly("own_hardsync", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.7), (20, 0, 0.0)])
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],

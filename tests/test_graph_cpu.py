@@ -218,3 +218,16 @@ def test_a_notes_smoothed_control_is_a_record_word_the_bank_sets_per_block():
     assert src.count("L.n1 = L.n1 * 0.999f + (1.f - 0.999f) * c.ctl[1];") == 2 * 3 and "klg_render_x2<" not in src      # three bodies
     rc, msg = check(prog.replace("op smooth 2 -1 -1 1 1", "op smooth 2 -1 -1 1 5"))
     assert rc < 0 and "not a smoothed control" in msg
+
+
+def test_oscillators_can_be_rephased_per_sample():
+    """osc.set(f, phase) and osc.reset() inside process() (hard sync, re-phasing): `oscset` with imm 1 (a = f, b = phase) and imm 2."""
+    prog = ("klgg 1\nctl 0\nnode 0 saw\nnode 1 fsine\nnode 2 bsine\nop const 0 -1 -1 -1 1135869952\nop const 1 -1 -1 -1 0\n"
+            "op oscset -1 0 1 0 1\nop oscset -1 0 1 1 1\nop oscset -1 0 1 2 1\nop oscset -1 -1 -1 1 2\nop oscset -1 -1 -1 2 2\n"
+            "op osc 2 -1 -1 0 0\nop osc 3 -1 -1 1 0\nop osc 4 -1 -1 2 0\nop add 5 2 3 -1 0\nop add 6 5 4 -1 0\nret 6\nend\n")
+    rc, src = check(prog, want_source=True)
+    assert rc == 0, src
+    for needle in ("osm_set_fp(L.n0, L.n0f, r0, r1, c.fs.f)", "fsine_set_fp(L.n1, L.n1f, r0, r1, c.fs.f)", "L.n2.position = r1; L.n2f = r0;", "L.n1.pos = 0u;", "L.n2.position = 0.f;"):
+        assert needle in src, needle
+    rc, msg = check(prog.replace("op oscset -1 -1 -1 1 2", "op oscset -1 -1 -1 0 2"))       # a Fast::OSM oscillator has no reset() of its own
+    assert rc < 0 and "no such set() / reset()" in msg
