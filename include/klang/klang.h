@@ -130,10 +130,16 @@ struct Recorder : Sink {
 		objs.push_back({ smoothed_signal, sizeof(float) * 2, klg::graph::N_SMOOTH, nullptr, 0 });
 		return (int)objs.size() - 1;
 	}
+	int ctlvar_node(const void* control_value) {                  // controls[i].set(x) inside an effect's process(): the instance's own copy of the control
+		for (size_t i = 0; i < objs.size(); i++) if (objs[i].addr == control_value && objs[i].kind == klg::graph::N_CTLVAR) return (int)i;
+		objs.push_back({ control_value, sizeof(float) * 2, klg::graph::N_CTLVAR, nullptr, 0 });
+		return (int)objs.size() - 1;
+	}
 	// (Sink::effect: recording an Effect::process() — in / delay / smooth are available)
 	// data-dependent branches: process() is run once per outcome (record_paths below); `decisions` is the outcome list this run
 	// follows, runs past its end take `true`.  Each test leaves an OP_IF marker (imm = the outcome taken) in the trace.
 	std::vector<char> decisions; size_t decision_pos = 0; bool may_branch = false;
+	int run_id = 0;                                               // counts the traced runs of process() (PathMerger): what happened "earlier in this run"
 	bool decide(int cond_reg) {
 		if (!may_branch) { fail("a data-dependent `if` is only supported in process() (not in prepare())"); return true; }
 		if (decision_pos >= decisions.size()) decisions.push_back(1);
@@ -251,10 +257,22 @@ struct signal {
 };
 // comparisons (the reference compares through the float conversion; same result, but recordable).  Templates with exactly
 // deduced operand types, so that they never compete with the built-in comparisons of plain numbers.
+// `x > 0.001` with a double literal is a DOUBLE comparison of the converted float in the reference (klang.h:1115: the float conversion, then the
+// built-in operator).  The same decision on floats: with bf = (float)b, (double)x > b  <=>  x >= bf when bf rounded up, x > bf when it
+// rounded down (no float lies between b and bf) — likewise for the other three orderings.  (== / != against a double that is not a float
+// keep the float literal: never / always true in the reference.)
+inline gpu::Pred signal_cmp_double(uint32_t rel, const signal& x, double b, bool concrete) {
+	const float bf = (float)b;
+	if ((double)bf != b && rel < 4u) {
+		const bool up = (double)bf > b;                                     // rel: 0 <  1 >  2 <=  3 >=
+		rel = (rel == 1u || rel == 3u) ? (up ? 3u : 1u) : (up ? 0u : 2u);
+	}
+	return signal::cmp(rel, x, signal(bf), concrete);
+}
 #define KLANG_SIGNAL_CMP(OP, REL) \
 	template<class A, class B, std::enable_if_t<std::is_base_of_v<signal, A> && std::is_base_of_v<signal, B>, int> = 0> inline gpu::Pred operator OP(const A& a, const B& b) { return signal::cmp(REL, a, b, a.value OP b.value); } \
-	template<class A, class T, std::enable_if_t<std::is_base_of_v<signal, A> && std::is_arithmetic_v<T>, int> = 0> inline gpu::Pred operator OP(const A& a, T b) { return signal::cmp(REL, a, signal((float)b), a.value OP (float)b); } \
-	template<class T, class B, std::enable_if_t<std::is_arithmetic_v<T> && std::is_base_of_v<signal, B>, int> = 0> inline gpu::Pred operator OP(T a, const B& b) { return signal::cmp(REL, signal((float)a), b, (float)a OP b.value); }
+	template<class A, class T, std::enable_if_t<std::is_base_of_v<signal, A> && std::is_arithmetic_v<T>, int> = 0> inline gpu::Pred operator OP(const A& a, T b) { if constexpr (std::is_same_v<T, double>) return signal_cmp_double(REL, a, b, (double)a.value OP b); else return signal::cmp(REL, a, signal((float)b), a.value OP (float)b); } \
+	template<class T, class B, std::enable_if_t<std::is_arithmetic_v<T> && std::is_base_of_v<signal, B>, int> = 0> inline gpu::Pred operator OP(T a, const B& b) { if constexpr (std::is_same_v<T, double>) return signal_cmp_double(REL ^ (REL < 4u ? 1u : 0u), b, a, a OP (double)b.value); else return signal::cmp(REL, signal((float)a), b, (float)a OP b.value); }
 KLANG_SIGNAL_CMP(<, 0u) KLANG_SIGNAL_CMP(>, 1u) KLANG_SIGNAL_CMP(<=, 2u) KLANG_SIGNAL_CMP(>=, 3u) KLANG_SIGNAL_CMP(==, 4u) KLANG_SIGNAL_CMP(!=, 5u)
 #undef KLANG_SIGNAL_CMP
 inline gpu::Pred gpu::Pred::operator!() const {
@@ -282,6 +300,8 @@ KLANG_SIGNAL_PAIR(+, OP_ADD) KLANG_SIGNAL_PAIR(-, OP_SUB) KLANG_SIGNAL_PAIR(*, O
 #undef KLANG_SIGNAL_PAIR
 inline int gpu::Recorder::reg_of(const signal& s) { return s.reg >= 0 ? s.reg : const_reg(gpu::fbits(s.value)); }
 
+// std::abs / abs of a signal (PingPong.k:46 `std::abs(delay - new_delay) > 0.001`): fabsf of the float the reference converts it to — recordable
+inline signal abs(const signal& x) { gpu::Recorder* r = gpu::recording(); signal s(__builtin_fabsf(x.value)); if (r && x.reg >= 0) s.reg = r->emit(klg::graph::OP_ABS, x.reg, -1, -1, 0, true); return s; }
 struct Control;
 struct param : signal {
 	param(constant c) : signal(c.f) {}
@@ -311,6 +331,15 @@ struct Control {
 	}
 	bool touched = true;                                     // set() since the last block a gpu::FxRunner sent the controls (a set() overwrites what the effect wrote, even with the same value)
 	Control& set(float x) { value = (x < min) ? min : (max < x) ? max : x; touched = true; return *this; }    // klang.h:1725
+	// controls[i].set(x) with a value computed in process() (PingPong.k:48,60): recorded in an Effect — the control becomes state of the instance
+	Control& set(const signal& x) {
+		gpu::Recorder* r = gpu::recording();
+		if (!r) return set(x.value);
+		if (!r->effect) { r->fail("controls[i].set() inside a Note::process(): the control is the Synth's, shared by its notes"); return *this; }
+		const float v = (x.value < min) ? min : (max < x.value) ? max : x.value;
+		value.reg = r->emit(klg::graph::OP_SETCTL, r->reg_of(x), -1, r->ctlvar_node(&value), (uint32_t)index, true); value.value = v;
+		return *this;
+	}
 	float range() const { return max - min; }                                                                // klang.h:1719-1721: what a host's 0..1 parameter maps to
 	float normalised() const { const float v = value.value; return range() ? (v - min) / range() : (v < 0.f ? 0.f : (1.f < v ? 1.f : v)); }
 	void setNormalised(float norm) { value = norm * range() + min; }
@@ -1013,7 +1042,7 @@ struct GraphLayout {
 			const char* obj = (const char*)note + m.offset;
 			if (m.kind == klg::graph::N_DELAY) continue;                           // no record words: the ring lives in HBM
 			if (m.shared) { w[m.word0] = 0u; continue; }
-			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH) w[m.word0] = fbits(reinterpret_cast<const signal*>(obj)->value);
+			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH || m.kind == klg::graph::N_CTLVAR) w[m.word0] = fbits(reinterpret_cast<const signal*>(obj)->value);
 			else reinterpret_cast<const Packable*>(obj)->pack(w + m.word0);
 		}
 	}
@@ -1025,7 +1054,7 @@ struct GraphLayout {
 		for (const Member& m : members) {
 			char* obj = (char*)note + m.offset;
 			if (m.kind == klg::graph::N_DELAY || m.shared) continue;
-			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH) std::memcpy(&reinterpret_cast<signal*>(obj)->value, &w[m.word0], 4);
+			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH || m.kind == klg::graph::N_CTLVAR) std::memcpy(&reinterpret_cast<signal*>(obj)->value, &w[m.word0], 4);
 			else reinterpret_cast<Packable*>(obj)->unpack(w + m.word0);
 		}
 	}
@@ -1048,7 +1077,7 @@ struct PathMerger {
 	std::vector<Op> out; int next = 0, pseudo = 1 << 20, runs = 0;
 	PathMerger(Recorder& r, std::function<void()> f) : R(r), base_ops(r.prog.ops.size()), base_reg(r.next_reg), run(std::move(f)), next(r.next_reg) {}
 	std::vector<Op> trace(const std::vector<char>& D) {
-		R.prog.ops.resize(base_ops); R.next_reg = base_reg; R.decisions = D; R.decision_pos = 0; R.pending = -1;
+		R.prog.ops.resize(base_ops); R.next_reg = base_reg; R.decisions = D; R.decision_pos = 0; R.pending = -1; R.run_id++;
 		if (++runs > 2048) { R.fail("process() has too many data-dependent branches to record"); return {}; }
 		run();
 		return std::vector<Op>(R.prog.ops.begin() + (std::ptrdiff_t)base_ops, R.prog.ops.end());
@@ -1204,7 +1233,7 @@ inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	const std::string verr = R.prog.validate();
 	if (!verr.empty()) { std::fprintf(stderr, "klang-mi355: the recorded program is invalid: %s\n%s", verr.c_str(), R.prog.text().c_str()); std::abort(); }
 	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) {
-		const void* at = (R.objs[i].kind == N_PARAM || R.objs[i].kind == N_SMOOTH || !R.objs[i].packable) ? R.objs[i].addr : (const void*)R.objs[i].packable;
+		const void* at = (R.objs[i].kind == N_PARAM || R.objs[i].kind == N_SMOOTH || R.objs[i].kind == N_CTLVAR || !R.objs[i].packable) ? R.objs[i].addr : (const void*)R.objs[i].packable;
 		L.members.push_back({ (size_t)((const char*)at - lo), R.objs[i].kind, R.prog.node_word0(node_id[i]), R.objs[i].kind == N_SMOOTH && !R.effect });
 	}
 	L.program = R.prog.text();
@@ -1353,10 +1382,13 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) value0[i] = ((signal*)R.objs[i].addr)->value;
 	for (Oscillator* o : oscs) freq_reg.push_back(o->frequency.reg);
 	for (int c = 0; c < channels; c++) in_reg.push_back(ins[c]->reg);
+	std::vector<int> ctl_reg; std::vector<float> ctl_value;
+	for (int c = 0; c < R.prog.nctl; c++) { ctl_reg.push_back(ctl.items[(size_t)c].value.reg); ctl_value.push_back(ctl.items[(size_t)c].value.value); }
 	PathMerger paths(R, [&]() {                                          // one run of process() per outcome of its data-dependent `if`s
 		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = first_reg[i]; sg->value = value0[i]; }
 		for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = freq_reg[q];
 		for (int c = 0; c < channels; c++) ins[c]->reg = in_reg[(size_t)c];
+		for (int c = 0; c < R.prog.nctl; c++) { ctl.items[(size_t)c].value.reg = ctl_reg[(size_t)c]; ctl.items[(size_t)c].value.value = ctl_value[(size_t)c]; }   // (process() may write its controls)
 		R.may_branch = true;
 		process();
 		R.may_branch = false;
@@ -1371,7 +1403,7 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 	(void)is_io;
 	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = -1; sg->value = value0[i]; }
 	for (int c = 0; c < channels; c++) { ins[c]->reg = -1; outs[c]->reg = -1; }
-	for (int c = 0; c < R.prog.nctl; c++) ctl.items[(size_t)c].value.reg = -1;
+	for (int c = 0; c < R.prog.nctl; c++) { ctl.items[(size_t)c].value.reg = -1; ctl.items[(size_t)c].value.value = ctl_value[(size_t)c]; }
 	for (Oscillator* o : oscs) o->frequency.reg = -1;
 	R.recording = false; rec = nullptr;
 	if (!R.error.empty()) { std::fprintf(stderr, "klang-mi355: cannot record %s::process() as a graph effect: %s\n", type_name, R.error.c_str()); std::abort(); }
@@ -1392,7 +1424,7 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 // `delay(time)`, `(x >> delay)(time)`); on the host the object only takes part in the recording.  In a Note (physical models): a
 // `notedelay` node — the line lives in HBM per voice, its cursors (write position, the read head of set() / process()) in the record.
 template<int SIZE> struct Delay : Modifier, gpu::Packable {
-	bool in_note = false;
+	bool in_note = false; int head_set_in = -1;                                   // (the recorder's run in which set() placed the read head)
 	float time = 1.f; int position = 0; struct { int position = 0; float fraction = 0.f; } last;      // host mirror (notes)
 	Delay() {
 		if (gpu::Sink* r = gpu::constructing()) { in_note = !r->effect; r->note(this, sizeof(Delay), in_note ? klg::graph::N_NDELAY : klg::graph::N_DELAY, in_note ? this : nullptr, SIZE, static_cast<const gpu::Packable*>(this)); }
@@ -1410,7 +1442,9 @@ template<int SIZE> struct Delay : Modifier, gpu::Packable {
 		device_only("Delay::operator()");
 	}
 	void set(param samples) override {                                             // klang.h:3480-3489: place the read head `samples` behind the write cursor
-		if (samples.reg >= 0 && gpu::no_set_while_recording("Delay::set(time) with a recorded time")) return;   // a plain number only moves the host mirror (its use, `delay >> x` in an effect, is what cannot be recorded)
+		if (gpu::Recorder* r = gpu::recording()) {                                  // per sample: the read head follows a control / an LFO (PingPong.k:62-63)
+			r->emit(klg::graph::OP_DELAYSET, r->reg_of(samples), -1, r->node(this, "Delay"), 0, false); head_set_in = r->run_id; return;
+		}
 		time = samples.value < SIZE ? samples.value : (float)SIZE;
 		float read = static_cast<float>(position - 1) - time;
 		if (read < 0.f) read += SIZE;
@@ -1426,7 +1460,7 @@ template<int SIZE> struct Delay : Modifier, gpu::Packable {
 	}
 	void process() override {
 		if (gpu::Recorder* r = gpu::recording()) {
-			if (!in_note) { r->fail("Delay::set(time) + `delay >> x` in an effect is not recorded yet: use delay(time)"); return; }
+			if (!in_note && head_set_in != r->run_id) { r->fail("an effect's `delay >> x` (Delay::process) needs delay.set(time) earlier in the same process(): the read head is not kept from one sample to the next"); return; }
 			out.reg = r->emit(klg::graph::OP_DELAYOUT, -1, -1, r->node(this, "Delay"), 0, true); return;
 		}
 		device_only("Delay::process()");
@@ -1489,6 +1523,12 @@ struct FxRunner {
 			for (int c = 0; c < channels; c++) std::memcpy(&io[(size_t)c * (size_t)m], ch[c] + at, (size_t)m * sizeof(float));
 			if (klg_fx_process(h, io.data(), m)) die("klg_fx_process");
 			for (int c = 0; c < channels; c++) std::memcpy(ch[c] + at, &io[(size_t)c * (size_t)m], (size_t)m * sizeof(float));
+		}
+		// what the effect wrote to its own controls (PingPong.k:48,60) comes back to the host's Control objects, as in the reference
+		for (int c = 0; c < (int)ctl.items.size() && c < 8; c++) {
+			float v = 0.f;
+			if (klg_fx_get_control(h, 0, c, &v)) die("klg_fx_get_control");
+			if (v != ctl.items[(size_t)c].value.value) { ctl.items[(size_t)c].value.value = v; sent[(size_t)c] = v; }
 		}
 	}
 };
@@ -2010,6 +2050,7 @@ template<class FX> struct EffectBank {
 		record_effect(member_objs(C, lo, lo + sizeof(FX)), fx->controls, channels, ins, outs, [f]() { f->prepare(); }, [f]() { f->run_process(); }, lo, layout, typeid(FX).name());
 		std::vector<uint32_t> words((size_t)layout.words, 0u);
 		layout.pack(fx, words.data());
+		if (std::getenv("KLANG_MI355_DUMP_GRAPH")) { std::fprintf(stderr, "klang-mi355: initial record:"); for (uint32_t w : words) std::fprintf(stderr, " %08x", w); std::fprintf(stderr, "\n"); }
 		h = klg_fx_create_graph(layout.program.c_str(), instances, fs.f, max_block, words.data());
 		if (!h) { std::fprintf(stderr, "klang-mi355: klg_fx_create_graph: %s\n", klg_last_error()); std::abort(); }
 	}
@@ -2024,3 +2065,7 @@ namespace basic { using namespace klang; using namespace Generators::Basic; usin
 namespace minimal { using namespace klang; }
 
 }  // namespace klang
+
+// `std::abs(x)` of a signal: in the reference the signal converts to float and takes std::abs(float).  A recorded value has no float to
+// convert to, so the call is given the signal itself (an exact match beats the float conversion); same value, recordable.
+namespace std { inline klang::signal abs(const klang::signal& x) { return klang::abs(x); } }

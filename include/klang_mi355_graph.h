@@ -69,6 +69,9 @@ enum NodeKind {
 	                                                                        last.position, last.fraction (the read head of Delay::process, set by set()), time;
 	                                                                        the SIZE floats of each voice's line are contiguous in HBM (voices' cursors never line up) */
 	N_IIRN = 25,    /* Filters::IIR<ORDER>, ORDER 2..8  5399-5432           words: a[ORDER] then y[ORDER] (the node's argument is ORDER) */
+	N_CTLVAR = 26,  /* a control an EFFECT writes: controls[i].set(x) inside process() (Control::set 1725-1728; PingPong.k:48,60)
+	                                                                        words: value — the instance's own copy of the control: every read of controls[i]
+	                                                                        (and its smooth()) in the program takes it; klg_fx_set_control overwrites it */
 	N_KINDS
 };
 enum { FSINE_INC = 0, FSINE_POS, FSINE_FREQ, FSINE_WORDS };
@@ -111,12 +114,13 @@ inline int node_words(int kind, int arg = 0) {
 	case N_WAVETABLE: return WT_WORDS;
 	case N_NDELAY: return ND_WORDS;
 	case N_IIRN: return 2 * arg;
+	case N_CTLVAR: return 1;
 	}
 	return 0;
 }
 inline const char* node_name(int kind) {
 	static const char* names[N_KINDS] = { "fsine", "saw", "pulse", "lpf", "env", "adsr", "param", "bsine", "bsaw", "btri", "bsquare", "bpulse",
-	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator", "delay", "smooth", "wavetable", "notedelay", "iirn" };
+	                                      "oplpf", "ophpf", "dcf", "iir1", "butter1", "modal", "followpeak", "followrms", "operator", "delay", "smooth", "wavetable", "notedelay", "iirn", "ctlvar" };
 	return (kind >= 0 && kind < N_KINDS) ? names[kind] : "?";
 }
 
@@ -152,10 +156,14 @@ enum OpCode {
 	                   its instances in one process (instance-major, then sample, then the ops in program order).  Effects only, never inside an `if` */
 	OP_DELAYOUT,    /* dst = delay node process()          Delay::process 3470-3473: the read head set by set() (note delays)   */
 	OP_TABREAD,     /* dst = table imm [ a ]               Table<float, SIZE>::operator[](float): clamped, linear   klang.h:3365-3377; imm = table id (klg_table_upload) */
+	OP_SETCTL,      /* dst = ctlvar node = clamp(a)        controls[imm].set(a): (a < min) ? min : (max < a) ? max : a, the dial's range   Control::set klang.h:1725-1728 (effects) */
+	OP_DELAYSET,    /* delay node .set(samples = a)        Delay::set 3480-3489: the read head `samples` behind the write cursor.  An effect delay's
+	                   head lives for the sample only: every process() read (delayout) follows a set() of the same sample (the recorder checks it) */
+	OP_ABS,         /* dst = |a|                           std::abs of a signal: fabsf                                                               */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -276,11 +284,14 @@ struct Program {
 			case OP_IN: if (channels == 0 || (int)o.imm >= channels) return bad("`in` needs an effect program with that channel"); break;
 			case OP_DELAYIN: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
 			case OP_DELAYTAP: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); need_a = true; break;
-			case OP_DELAYOUT: if (k != N_NDELAY) return bad("node is not a note delay"); break;
+			case OP_DELAYOUT: if (k != N_NDELAY && k != N_DELAY) return bad("node is not a delay"); break;
+			case OP_DELAYSET: if (k != N_NDELAY && k != N_DELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
 			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); break;
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			case OP_CMP: if (o.imm > 5u) return bad("unknown relation"); need_a = need_b = true; break;
 			case OP_NOISE: if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;
+			case OP_SETCTL: if (k != N_CTLVAR) return bad("node is not a written control"); if (!channels) return bad("only an effect writes its controls"); if ((int)o.imm >= nctl) return bad("control index out of range"); need_a = true; break;
+			case OP_ABS: need_a = true; break;
 			case OP_TABREAD: if (channels) return bad("tables are only available to synth notes"); if (o.imm == 0u) return bad("table id 0 is reserved"); need_a = true; break;
 			case OP_IF: if ((int)i < prepare_ops) return bad("prepare() may not branch"); need_a = true; has_dst = false; open.push_back({ {}, false, {} }); break;
 			case OP_ELSE:

@@ -53,6 +53,7 @@ def load():
         "klg_note_off_many": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]),
         "klg_set_control": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),
         "klg_get_control": (C.c_int, [vp, C.c_int, C.c_int, f32p]),
+        "klg_fx_get_control": (C.c_int, [vp, C.c_int, C.c_int, f32p]),
         "klg_set_control_smoothed": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),
         "klg_get_control_smoothed": (C.c_int, [vp, C.c_int, C.c_int, f32p]),
         "klg_process": (C.c_int, [vp, C.POINTER(f32p), C.c_int, C.c_int, f32p]),

@@ -162,16 +162,36 @@ extern "C" size_t klg_fx_state_bytes(const klg_fx* f) {
 	return (size_t)f->words * 4 + (f->patch == KLG_PATCH_PINGPONG ? (size_t)2 * 192000 * 4 : ((size_t)2 * RV_ESIZE + (size_t)16 * RV_FSIZE) * 4);
 }
 
+static int fx_flush_updates(klg_fx* f, hipStream_t st);
 extern "C" int klg_fx_set_control(klg_fx* f, int instance, int index, float value) {
 	if (!f || instance < 0 || instance >= f->K || index < 0 || index >= f->nctl) return fail(KLG_ERR_INVALID, "klg_fx_set_control: instance %d / control %d out of range", instance, index);
 	host::ControlH& c = f->controls[(size_t)instance * f->nctl + index];
 	c.set(value);                                                                   // Control::set clamps (klang.h:1725-1728)
-	if (f->graph) { f->h_controls[(size_t)instance * KLG_MAX_CTL + index] = c.value; f->controls_dirty = true; return 0; }
+	if (f->graph) {
+		f->h_controls[(size_t)instance * KLG_MAX_CTL + index] = c.value; f->controls_dirty = true;
+		// a control the effect itself writes lives in the instance's record: a host set() overwrites the effect's value (klang.h:4211-4212)
+		if (f->graph->ctlvar_word[index] >= 0) f->upd.push_back({ instance, f->graph->ctlvar_word[index], f2i(c.value) });
+		return 0;
+	}
 	if (f->patch == KLG_PATCH_PINGPONG) f->upd.push_back({ instance, index, f2i(c.value) });
 	else {
 		if (index < 5) f->upd.push_back({ instance, RV_CTL + index, f2i(c.value) });
 		if (!f->rv_flag[instance]) { f->rv_flag[instance] = 1; f->rv_touched.push_back(instance); }
 	}
+	return 0;
+}
+// the control's value as the effect sees it: a control the effect writes itself (PingPong.k:48,60 controls[1].set(..)) is read back from the
+// instance's state — the parameter sync OUT of Effect::process(float*, int, float* parameters) klang.h:4213-4215
+extern "C" int klg_fx_get_control(klg_fx* f, int instance, int index, float* value) {
+	if (!f || !value || instance < 0 || instance >= f->K || index < 0 || index >= f->nctl) return fail(KLG_ERR_INVALID, "klg_fx_get_control: instance %d / control %d out of range", instance, index);
+	int word = -1;
+	if (f->graph) word = f->graph->ctlvar_word[index];
+	else if (f->patch == KLG_PATCH_PINGPONG && index == 1) word = 1;                  // klg_fx_pingpong*: state word 1 is controls[1]
+	if (word < 0) { *value = f->controls[(size_t)instance * f->nctl + index].value; return 0; }
+	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (int rc = fx_flush_updates(f, f->stream)) return rc;
+	HIP_TRY(hipStreamSynchronize(f->stream));
+	HIP_TRY(hipMemcpy(value, (const float*)f->d_state + (size_t)word * f->kpad + instance, sizeof(float), hipMemcpyDeviceToHost));
 	return 0;
 }
 
@@ -270,6 +290,7 @@ static int fx_flush_updates(klg_fx* f, hipStream_t st) {
 }
 
 static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
+	if (int rc = fx_flush_updates(f, st)) return rc;
 	if (f->controls_dirty) {
 		HIP_TRY(hipStreamSynchronize(st));
 		HIP_TRY(hipMemcpyAsync(f->d_controls, f->h_controls.data(), f->h_controls.size() * 4, hipMemcpyHostToDevice, st));

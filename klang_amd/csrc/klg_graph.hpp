@@ -7,6 +7,7 @@
 // first use (a process that never creates a graph patch does not need it).  Compiling needs no GPU.
 #pragma once
 #include <dlfcn.h>
+#include <cstring>
 
 #include <map>
 #include <mutex>
@@ -47,8 +48,13 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	const std::string TF = x2 ? "f2" : "float", TI = x2 ? "i2" : "int", TU = x2 ? "u2" : "uint32_t", T2 = x2 ? "2" : "";
 	const int NW = g.words();
 	std::vector<bool> swept(g.nodes.size(), false), written(g.nodes.size(), false), retuned(g.nodes.size(), false);
+	std::vector<bool> reset_head(g.nodes.size(), false);
+	for (const Op& o : g.ops) if (o.code == OP_DELAYSET) reset_head[(size_t)o.node] = true;
 	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; if (o.code == OP_OSCSET) retuned[(size_t)o.node] = true; }
 	const bool fx = g.channels > 0;
+	int ctlvar[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };                      // control index -> the ctlvar node holding the instance's own copy (controls the effect writes)
+	for (const Op& o : g.ops) if (o.code == OP_SETCTL) ctlvar[o.imm & 7u] = o.node;
+	auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
 	std::vector<long long> ring_off(g.nodes.size(), 0); std::vector<int> inputs(g.nodes.size(), 0);   // Delay nodes: first row in the group's ring tile, inputs per sample
 	{ long long rows = 0; for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == N_DELAY || g.nodes[i] == N_NDELAY) { ring_off[i] = rows; rows += g.arg((int)i); } }
 	for (const Op& o : g.ops) if (o.code == OP_DELAYIN) inputs[(size_t)o.node]++;
@@ -189,11 +195,13 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			begin += "\t\t" + n + "pos = (int)" + R(ND_POS) + "; " + n + "t.position = (int)" + R(ND_LASTPOS) + "; " + n + "t.fraction = " + F(ND_LASTFRAC) + "; " + n + "time = " + F(ND_TIME) + ";\n";
 			end += W(ND_POS, "(uint32_t)" + n + "pos") + W(ND_LASTPOS, "(uint32_t)" + n + "t.position");
 			mark(w0 + ND_POS, 2);
+			if (reset_head[i]) { end += W(ND_LASTFRAC, "f2u(" + n + "t.fraction)"); mark(w0 + ND_LASTFRAC, 1); }   // set() inside process()
 			break;
 		case N_DELAY:
-			live += fmt(" int n%zupos;", i);
-			begin += "\t\t" + n + fmt("pos = (int)((c.samples * %dull) %% %dull);\n", inputs[i], g.arg((int)i));     // Delay::position: one step per input()
+			live += fmt(" int n%zupos; Tap n%zut;", i, i);                   // (the read head of set() / process(): re-placed by a set() in every sample that reads it)
+			begin += "\t\t" + n + fmt("pos = (int)((c.samples * %dull) %% %dull); ", inputs[i], g.arg((int)i)) + n + "t.position = 0; " + n + "t.fraction = 0.f;\n";     // Delay::position: one step per input()
 			break;
+		case N_CTLVAR:
 		case N_SMOOTH:
 			live += fmt(" float n%zu;", i);
 			begin += "\t\t" + n + " = " + F(0) + ";\n";
@@ -229,7 +237,9 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		const int k = (o.node >= 0 && o.node < (int)g.nodes.size()) ? g.nodes[(size_t)o.node] : -1;
 		switch (o.code) {
 		case OP_CONST: body += d + "kf<" + TF + fmt(">(0x%08xu);\n", o.imm); const_of[o.dst] = o.imm; break;
-		case OP_CTL: body += d + fmt("ctl_read(c, %uu);\n", o.imm); break;
+		case OP_CTL: body += d + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d;\n", ctlvar[o.imm & 7u]) : fmt("ctl_read(c, %uu);\n", o.imm)); break;   // (a control the effect writes: its own copy)
+		case OP_SETCTL: body += d + "(" + a + fmt(" < u2f(0x%08xu)) ? u2f(0x%08xu) : (u2f(0x%08xu) < ", fbits(g.dials[o.imm & 7u].min), fbits(g.dials[o.imm & 7u].min), fbits(g.dials[o.imm & 7u].max)) + a + fmt(") ? u2f(0x%08xu) : ", fbits(g.dials[o.imm & 7u].max)) + a + ";\n\t\t" + n + fmt(" = r%d;\n", o.dst); break;   // Control::set klang.h:1725-1728
+		case OP_ABS: body += d + "__builtin_fabsf(" + a + ");\n"; break;
 		case OP_PARAM: body += d + n + ";\n"; break;
 		case OP_OSC: {
 			std::string e;
@@ -302,8 +312,9 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		case OP_FREQ: body += d + n + "f;\n"; break;
 		case OP_IN: body += d + (o.imm ? "in1" : "in0") + ";\n"; break;
 		case OP_DELAYIN: body += "\t\t{ const Ring q = " + ring(o.node) + "; q.wr(" + n + "pos, " + a + "); " + n + "pos = (" + n + fmt("pos + 1 == %d) ? 0 : ", g.arg(o.node)) + n + "pos + 1; }\n"; break;   // Delay::input klang.h:3396-3403
+		case OP_DELAYSET: body += "\t\t" + n + "t = delay_set(" + n + fmt("pos, %d, ", g.arg(o.node)) + a + ");\n"; break;   // Delay::set klang.h:3480-3489
 		case OP_DELAYTAP: body += d + "delay_tap_float(" + ring(o.node) + ", " + n + "pos, " + a + ");\n"; break;
-		case OP_SMOOTH: body += "\t\t" + n + " = " + n + fmt(" * 0.999f + (1.f - 0.999f) * c.ctl[%u];\n", o.imm) + d + n + ";\n"; break;   // Control::smooth klang.h:1715
+		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 7u]) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";
 			body += d + "fsine_process(" + n + ", fsine_rel_offset(" + (o.a >= 0 ? a : std::string("0.f")) + ")) * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs) * " + n + "a);\n";
@@ -430,7 +441,8 @@ struct Rtc {
 	}
 };
 
-struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; int noise_calls = 0; struct Smooth { int word, ctl, calls; }; std::vector<Smooth> smooths; bool x2 = false; std::vector<std::pair<long long, int>> delays; };   // delays: (first ring row, SIZE) of each delay node in node order   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
+struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; int noise_calls = 0; struct Smooth { int word, ctl, calls; }; std::vector<Smooth> smooths; int ctlvar_word[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };   // ctlvar_word[i]: the record word of control i's own copy (an effect that writes it), else -1
+	 bool x2 = false; std::vector<std::pair<long long, int>> delays; };   // delays: (first ring row, SIZE) of each delay node in node order   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
 
 // directory holding klg_kernels.hpp etc.: next to the shared library (klang_amd/csrc), or $KLG_GRAPH_SRC
 inline std::string source_dir() {
@@ -463,6 +475,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	c.words = g.words(); c.channels = g.channels; c.x2 = x2;
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY || g.nodes[i] == graph::N_NDELAY) { c.delays.push_back({ c.ring_rows, g.arg((int)i) }); c.ring_rows += g.arg((int)i); }
 	c.noise_calls = g.noise_calls();
+	for (const graph::Op& o : g.ops) if (o.code == graph::OP_SETCTL) c.ctlvar_word[o.imm & 7u] = g.node_word0(o.node);
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_SMOOTH) {            // controls[ctl].smooth(): state word, control, calls per sample
 		Compiled::Smooth sm = { g.node_word0((int)i), -1, 0 };
 		for (const graph::Op& o : g.ops) if (o.code == graph::OP_SMOOTH && o.node == (int)i) { sm.ctl = (int)o.imm; sm.calls++; }

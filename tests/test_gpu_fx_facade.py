@@ -35,14 +35,27 @@ def run_effect(name, tmp_path):
 
 def test_shipped_pingpong_k_bound_to_its_kernel_through_the_effect_bank(tmp_path):
     """examples/PingPong.k (BASELINE config 4), compiled UNCHANGED against the facade with `KLANG_GPU_BIND_FX(PingPong, KLG_PATCH_PINGPONG)`:
-    klang::gpu::EffectBank<PingPong> creates the bank with klg_fx_create (the hand-written kernel) instead of recording process() —
-    which writes controls and branches on std::abs of a signal, so it cannot be traced.  Nine instances, control changes mid-run,
+    klang::gpu::EffectBank<PingPong> creates the bank with klg_fx_create (the hand-written kernel) instead of recording process().
+    Nine instances, control changes mid-run,
     against the genuine header."""
     got, ref = run_effect("fx_toppingpong", tmp_path)
     peak = np.abs(ref).max()
     exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
     print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e}")
     assert exact == 1.0, f"max abs err {np.abs(got - ref).max()} (peak {peak})"
+
+
+def test_shipped_pingpong_k_recorded_as_a_graph(tmp_path, monkeypatch):
+    """The same unchanged examples/PingPong.k, RECORDED (KLANG_MI355_FORCE_GRAPH=1 ignores the binding): process() writes controls[1]
+    twice (`controls[1].set(..)`: the control becomes state of the instance), branches on `std::abs(delay - new_delay) > 0.001` (a double
+    comparison, decided exactly on floats), re-phases its LFO with set(rate, pi) on one side of the branch, places both read heads with
+    Delay::set(time) every sample and reads them with `right * gain` / `>> left`.  Nine instances, control changes mid-run, against the
+    genuine header — bit for bit, like the hand-written kernel."""
+    monkeypatch.setenv("KLANG_MI355_FORCE_GRAPH", "1")
+    got, ref = run_effect("fx_toppingpong", tmp_path)
+    exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+    print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e}")
+    assert exact == 1.0, f"max abs err {np.abs(got - ref).max()} (peak {np.abs(ref).max()})"
 
 
 def test_shipped_reverb_k_bound_to_its_kernel_through_the_effect_bank(tmp_path):

@@ -53,15 +53,21 @@ def assert_bits(got, ref):
     assert np.abs(got).max() > 0
 
 
-def test_effect_template_callback_with_shipped_pingpong_k(tmp_path):
+@pytest.mark.parametrize("how", ["kernel", "recorded"])
+def test_effect_template_callback_with_shipped_pingpong_k(tmp_path, how, monkeypatch):
     """The template's callback as written: every control set() from its parameter EVERY block (which resets the controls[1] that PingPong.k
     itself writes per sample), `pingpong.klang::Stereo::Effect::process(buffers)`.  Nine runs of the one-object host, one per scenario instance."""
+    if how == "recorded":                                            # the unchanged file recorded as a graph effect instead of tied to klg_fx_pingpong_x:
+        monkeypatch.setenv("KLANG_MI355_FORCE_GRAPH", "1")           # the host's set() overwrites the instance's own copy of the control it writes
     got = run_effect_host("facade_host_fx_toppingpong", "fx_toppingpong", tmp_path)
     assert_bits(got, np.load(os.path.join(GOLDEN, "host_fx_toppingpong.npz"))["out"])
 
 
-def test_effect_host_reproduces_the_effect_bank_fixture(tmp_path):
+@pytest.mark.parametrize("how", ["kernel", "recorded"])
+def test_effect_host_reproduces_the_effect_bank_fixture(tmp_path, how, monkeypatch):
     """The same host setting a control only in the block its parameter changes: the fixture of the 9-instance gpu::EffectBank test (fx_toppingpong.npz)."""
+    if how == "recorded":
+        monkeypatch.setenv("KLANG_MI355_FORCE_GRAPH", "1")
     got = run_effect_host("facade_host_fx_toppingpong", "fx_toppingpong", tmp_path, extra=("--set-on-change",))
     assert_bits(got, np.load(os.path.join(GOLDEN, "fx_toppingpong.npz"))["out"])
 

@@ -149,7 +149,7 @@ def test_wavetable_and_notedelay_nodes_belong_to_synth_programs():
         assert needle in src, needle
     for bad, msg in ((ok.replace("klgg 1\n", "klgg 1\nkind effect 1\n"), "only available to synth notes"),
                      (ok.replace("node 0 notedelay 4800", "node 0 notedelay"), "delay needs its SIZE"),
-                     (ok.replace("op delayout 0 -1 -1 0 0", "op delayout 0 -1 -1 1 0"), "not a note delay"),
+                     (ok.replace("op delayout 0 -1 -1 0 0", "op delayout 0 -1 -1 1 0"), "node is not a delay"),
                      (ok.replace("tabread 5 4 -1 -1 1", "tabread 5 4 -1 -1 0"), "table id 0 is reserved")):
         rc, m = check(bad)
         assert rc < 0 and msg in m, m
@@ -231,3 +231,18 @@ def test_oscillators_can_be_rephased_per_sample():
         assert needle in src, needle
     rc, msg = check(prog.replace("op oscset -1 -1 -1 1 2", "op oscset -1 -1 -1 0 2"))       # a Fast::OSM oscillator has no reset() of its own
     assert rc < 0 and "no such set() / reset()" in msg
+
+
+def test_an_effect_may_write_its_controls_take_abs_and_place_delay_heads_per_sample():
+    """What examples/PingPong.k needs of a recorded effect (tests/golden/pingpong_recorded.klgg is the whole program): `setctl` (controls[i].set(x):
+    the dial's clamp, the instance's own copy `ctlvar` that every later read and smooth() of the control takes), `abs`, `delayset` + `delayout`
+    on an effect's Delay (the read head of set(), advanced by every process())."""
+    prog = open(os.path.join(ROOT, "tests", "golden", "pingpong_recorded.klgg")).read()
+    rc, src = check(prog, want_source=True)
+    assert rc == 0, src
+    for needle in ("float n7;", "const float r14 = L.n7;", "__builtin_fabsf(r26)", "L.n7 = r30;", "(r25 < u2f(0x3a83126fu)) ? u2f(0x3a83126fu) : (u2f(0x3f800000u) < r25) ? u2f(0x3f800000u) : r25",
+                   "L.n8 = L.n8 * 0.999f + (1.f - 0.999f) * L.n7;", "L.n6 = L.n6 * 0.999f + (1.f - 0.999f) * c.ctl[5];", "L.n0t = delay_set(L.n0pos, 192000, r46);", "delay_process(Ring{",
+                   "osc.set" if False else "L.n2.position = r31;"):
+        assert needle in src, needle
+    rc, msg = check(prog.replace("kind effect 2\n", "").replace("ret2 67 68", "ret 67"))
+    assert rc < 0                                                                      # a Note does not write its Synth's controls (nor has it `in`)
