@@ -254,6 +254,12 @@ class FxBank:
     def set_control(self, instance, index, value):
         return check(self._L.klg_fx_set_control(self._h, int(instance), int(index), float(value)), "klg_fx_set_control")
 
+    def get_control(self, instance, index):
+        """The control as the effect left it (klg_fx_get_control): a control its process() writes comes back from the instance's state."""
+        v = C.c_float()
+        check(self._L.klg_fx_get_control(self._h, int(instance), int(index), C.byref(v)), "klg_fx_get_control")
+        return v.value
+
     def process(self, io):
         """io: float32 [instances][channels][n], processed in place."""
         assert io.dtype == np.float32 and io.flags.c_contiguous and io.shape[:2] == (self.instances, self.channels)

@@ -136,3 +136,33 @@ def test_delay_lines_wrap_around(oracle_build):
         err = rel_err(got, ref)
         print(f"{patch} wrap: rel err {err:.3e}, bit-exact {100 * bit_exact_fraction(got, ref):.2f}%")
         assert err <= TOL and np.abs(got).max() > 0
+
+
+def test_a_control_the_effect_writes_comes_back_and_the_hosts_set_wins():
+    """PingPong.k writes controls[1] every sample (`controls[1].set(new_delay)` while controls[5] glides, then the LFO's vibrato on top):
+    klg_fx_get_control returns the instance's value after the block — the same from the hand-written kernel and from the RECORDED program
+    (tests/golden/pingpong_recorded.klgg: the control is a `ctlvar` word of the record there) — and a klg_fx_set_control overwrites it."""
+    import klang_amd
+    prog = open(os.path.join(GOLDEN, "pingpong_recorded.klgg")).read()
+    rec = np.array([int(w, 16) for w in open(os.path.join(GOLDEN, "pingpong_recorded.rec")).read().split()], np.uint32)
+    K, N = 5, 256
+    banks = [klang_amd.FxBank("pingpong", K, max_block=N), klang_amd.FxBank(prog, K, max_block=N, initial_record=rec, channels=2)]
+    rng = np.random.default_rng(2)
+    x = (rng.uniform(-0.5, 0.5, size=(4, K, 2, N))).astype(np.float32)
+    seen = []
+    for bank in banks:
+        for k in range(K):
+            bank.set_control(k, 5, 0.1 + 0.15 * k)                     # controls[5] away from `delay`: the scratch branch writes controls[1]
+            bank.set_control(k, 2, 0.2 * k); bank.set_control(k, 3, 0.5)   # vibrato: controls[1] += lfo * ...
+        vals, outs = [], []
+        for b in range(4):
+            if b == 2:
+                bank.set_control(3, 1, 0.9)                            # the host's set() wins over what the effect wrote
+            io = x[b].copy(); bank.process(io); outs.append(io)
+            vals.append([bank.get_control(k, 1) for k in range(K)])
+        assert bank.get_control(0, 0) == 0.5                           # an ordinary control: the host's value
+        seen.append((np.array(vals, np.float32), np.stack(outs)))
+        bank.close()
+    (va, oa), (vb, ob) = seen
+    assert np.array_equal(va.view(np.uint32), vb.view(np.uint32)) and np.array_equal(oa.view(np.uint32), ob.view(np.uint32))
+    assert not np.allclose(va[0], 0.5) and len(set(va[-1].tolist())) > 1        # the effect moved them, each instance its own way
