@@ -1040,7 +1040,6 @@ struct GraphLayout {
 	void pack(const void* note, uint32_t* w) const {
 		for (const Member& m : members) {
 			const char* obj = (const char*)note + m.offset;
-			if (m.kind == klg::graph::N_DELAY) continue;                           // no record words: the ring lives in HBM
 			if (m.shared) { w[m.word0] = 0u; continue; }
 			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH || m.kind == klg::graph::N_CTLVAR) w[m.word0] = fbits(reinterpret_cast<const signal*>(obj)->value);
 			else reinterpret_cast<const Packable*>(obj)->pack(w + m.word0);
@@ -1053,7 +1052,7 @@ struct GraphLayout {
 	void unpack(void* note, const uint32_t* w) const {
 		for (const Member& m : members) {
 			char* obj = (char*)note + m.offset;
-			if (m.kind == klg::graph::N_DELAY || m.shared) continue;
+			if (m.shared) continue;
 			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH || m.kind == klg::graph::N_CTLVAR) std::memcpy(&reinterpret_cast<signal*>(obj)->value, &w[m.word0], 4);
 			else reinterpret_cast<Packable*>(obj)->unpack(w + m.word0);
 		}
@@ -1424,10 +1423,10 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 // `delay(time)`, `(x >> delay)(time)`); on the host the object only takes part in the recording.  In a Note (physical models): a
 // `notedelay` node — the line lives in HBM per voice, its cursors (write position, the read head of set() / process()) in the record.
 template<int SIZE> struct Delay : Modifier, gpu::Packable {
-	bool in_note = false; int head_set_in = -1;                                   // (the recorder's run in which set() placed the read head)
+	bool in_note = false;
 	float time = 1.f; int position = 0; struct { int position = 0; float fraction = 0.f; } last;      // host mirror (notes)
 	Delay() {
-		if (gpu::Sink* r = gpu::constructing()) { in_note = !r->effect; r->note(this, sizeof(Delay), in_note ? klg::graph::N_NDELAY : klg::graph::N_DELAY, in_note ? this : nullptr, SIZE, static_cast<const gpu::Packable*>(this)); }
+		if (gpu::Sink* r = gpu::constructing()) { in_note = !r->effect; r->note(this, sizeof(Delay), in_note ? klg::graph::N_NDELAY : klg::graph::N_DELAY, this, SIZE, static_cast<const gpu::Packable*>(this)); }
 		else in_note = true;                                                        // every further Note of a recorded type
 	}
 	using Generic::Input<signal>::input;
@@ -1443,7 +1442,7 @@ template<int SIZE> struct Delay : Modifier, gpu::Packable {
 	}
 	void set(param samples) override {                                             // klang.h:3480-3489: place the read head `samples` behind the write cursor
 		if (gpu::Recorder* r = gpu::recording()) {                                  // per sample: the read head follows a control / an LFO (PingPong.k:62-63)
-			r->emit(klg::graph::OP_DELAYSET, r->reg_of(samples), -1, r->node(this, "Delay"), 0, false); head_set_in = r->run_id; return;
+			r->emit(klg::graph::OP_DELAYSET, r->reg_of(samples), -1, r->node(this, "Delay"), 0, false); return;
 		}
 		time = samples.value < SIZE ? samples.value : (float)SIZE;
 		float read = static_cast<float>(position - 1) - time;
@@ -1460,13 +1459,16 @@ template<int SIZE> struct Delay : Modifier, gpu::Packable {
 	}
 	void process() override {
 		if (gpu::Recorder* r = gpu::recording()) {
-			if (!in_note && head_set_in != r->run_id) { r->fail("an effect's `delay >> x` (Delay::process) needs delay.set(time) earlier in the same process(): the read head is not kept from one sample to the next"); return; }
 			out.reg = r->emit(klg::graph::OP_DELAYOUT, -1, -1, r->node(this, "Delay"), 0, true); return;
 		}
 		device_only("Delay::process()");
 	}
-	void pack(uint32_t* w) const override { using namespace klg::graph; w[ND_POS] = (uint32_t)position; w[ND_LASTPOS] = (uint32_t)last.position; w[ND_LASTFRAC] = gpu::fbits(last.fraction); w[ND_TIME] = gpu::fbits(time); }
-	void unpack(const uint32_t* w) override { using namespace klg::graph; position = (int)w[ND_POS]; last.position = (int)w[ND_LASTPOS]; }
+	void pack(uint32_t* w) const override {
+		using namespace klg::graph;
+		if (!in_note) { w[ED_LASTPOS] = (uint32_t)last.position; w[ED_LASTFRAC] = gpu::fbits(last.fraction); return; }      // an effect's Delay: only its read head is state of the record
+		w[ND_POS] = (uint32_t)position; w[ND_LASTPOS] = (uint32_t)last.position; w[ND_LASTFRAC] = gpu::fbits(last.fraction); w[ND_TIME] = gpu::fbits(time);
+	}
+	void unpack(const uint32_t* w) override { using namespace klg::graph; if (!in_note) { last.position = (int)w[ED_LASTPOS]; return; } position = (int)w[ND_POS]; last.position = (int)w[ND_LASTPOS]; }
 	unsigned int max() const { return SIZE; }
 };
 

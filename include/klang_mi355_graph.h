@@ -60,8 +60,9 @@ enum NodeKind {
 	N_MODAL = 17,   /* Modifiers::Modal                 5815-5859           words: a1 a2 y1 y2 gain */
 	N_FOLLOWPEAK = 18, N_FOLLOWRMS,   /* Envelope::Follower (Peak / RMS)  5862-5903   words: A R out */
 	N_OPERATOR = 20,   /* Operator<Fast::Sine>          4140-4180           words: inc pos frequency amp + the N_ENV words of its envelope */
-	N_DELAY = 21,   /* Delay<SIZE> (effects only)       3381-3512           words: none — a ring of SIZE floats per instance in HBM, position-major
-	                                                                        over the 64 instances of a wave; the write cursor is the sample counter */
+	N_DELAY = 21,   /* Delay<SIZE> (effects only)       3381-3512           words: last.position, last.fraction (the read head that set() places and
+	                                                                        every process() advances) — the SIZE floats live in a ring per instance in HBM,
+	                                                                        position-major over the 64 instances of a wave; the write cursor is the sample counter */
 	N_SMOOTH = 22,  /* controls[i].smooth()                1715             words: smoothed (an effect instance's own; a note's is set per block: the Synth's notes share the control) */
 	N_WAVETABLE = 23,  /* Wavetable / Sample (synth notes)  3626-3720        words: increment position offset frequency table — `table` is the id
 	                                                                        klg_table_upload() returned for this note's samples (HBM; identical tables share an id) */
@@ -89,6 +90,7 @@ enum { FOLLOW_A = 0, FOLLOW_R, FOLLOW_OUT, FOLLOW_WORDS };
 enum { OPER_INC = 0, OPER_POS, OPER_FREQ, OPER_AMP, OPER_ENV, OPER_WORDS = OPER_ENV + ENV_WORDS };
 enum { WT_INC = 0, WT_POS, WT_OFFSET, WT_FREQ, WT_TABLE, WT_WORDS };
 enum { ND_POS = 0, ND_LASTPOS, ND_LASTFRAC, ND_TIME, ND_WORDS };
+enum { ED_LASTPOS = 0, ED_LASTFRAC, ED_WORDS };   /* an effect's Delay: the read head of set() / process() (Delay::last klang.h:3388) */
 enum { MAX_WORDS = 128, MAX_NODES = 64, MAX_OPS = 1024 };
 
 inline bool is_oscillator(int k) { return k == N_FSINE || k == N_SAW || k == N_PULSE || (k >= N_BSINE && k <= N_BPULSE) || k == N_WAVETABLE; }
@@ -109,7 +111,7 @@ inline int node_words(int kind, int arg = 0) {
 	case N_MODAL: return MODAL_WORDS;
 	case N_FOLLOWPEAK: case N_FOLLOWRMS: return FOLLOW_WORDS;
 	case N_OPERATOR: return OPER_WORDS;
-	case N_DELAY: return 0;
+	case N_DELAY: return ED_WORDS;
 	case N_SMOOTH: return 1;
 	case N_WAVETABLE: return WT_WORDS;
 	case N_NDELAY: return ND_WORDS;
@@ -157,8 +159,8 @@ enum OpCode {
 	OP_DELAYOUT,    /* dst = delay node process()          Delay::process 3470-3473: the read head set by set() (note delays)   */
 	OP_TABREAD,     /* dst = table imm [ a ]               Table<float, SIZE>::operator[](float): clamped, linear   klang.h:3365-3377; imm = table id (klg_table_upload) */
 	OP_SETCTL,      /* dst = ctlvar node = clamp(a)        controls[imm].set(a): (a < min) ? min : (max < a) ? max : a, the dial's range   Control::set klang.h:1725-1728 (effects) */
-	OP_DELAYSET,    /* delay node .set(samples = a)        Delay::set 3480-3489: the read head `samples` behind the write cursor.  An effect delay's
-	                   head lives for the sample only: every process() read (delayout) follows a set() of the same sample (the recorder checks it) */
+	OP_DELAYSET,    /* delay node .set(samples = a)        Delay::set 3480-3489: the read head `samples` behind the write cursor (in process(), or in an
+	                   effect's prepare(): placed once per block, then walked by every `delay >> x`) */
 	OP_ABS,         /* dst = |a|                           std::abs of a signal: fabsf                                                               */
 	OP_CODES
 };

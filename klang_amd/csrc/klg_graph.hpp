@@ -48,7 +48,8 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	const std::string TF = x2 ? "f2" : "float", TI = x2 ? "i2" : "int", TU = x2 ? "u2" : "uint32_t", T2 = x2 ? "2" : "";
 	const int NW = g.words();
 	std::vector<bool> swept(g.nodes.size(), false), written(g.nodes.size(), false), retuned(g.nodes.size(), false);
-	std::vector<bool> reset_head(g.nodes.size(), false);
+	std::vector<bool> reset_head(g.nodes.size(), false), head_used(g.nodes.size(), false);
+	for (const Op& o : g.ops) if (o.code == OP_DELAYSET || o.code == OP_DELAYOUT) head_used[(size_t)o.node] = true;
 	for (const Op& o : g.ops) if (o.code == OP_DELAYSET) reset_head[(size_t)o.node] = true;
 	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; if (o.code == OP_OSCSET) retuned[(size_t)o.node] = true; }
 	const bool fx = g.channels > 0;
@@ -198,8 +199,9 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			if (reset_head[i]) { end += W(ND_LASTFRAC, "f2u(" + n + "t.fraction)"); mark(w0 + ND_LASTFRAC, 1); }   // set() inside process()
 			break;
 		case N_DELAY:
-			live += fmt(" int n%zupos; Tap n%zut;", i, i);                   // (the read head of set() / process(): re-placed by a set() in every sample that reads it)
-			begin += "\t\t" + n + fmt("pos = (int)((c.samples * %dull) %% %dull); ", inputs[i], g.arg((int)i)) + n + "t.position = 0; " + n + "t.fraction = 0.f;\n";     // Delay::position: one step per input()
+			live += fmt(" int n%zupos; Tap n%zut;", i, i);                   // (t: the read head of set() / process(), kept in the record)
+			begin += "\t\t" + n + fmt("pos = (int)((c.samples * %dull) %% %dull); ", inputs[i], g.arg((int)i)) + n + "t.position = (int)" + R(ED_LASTPOS) + "; " + n + "t.fraction = " + F(ED_LASTFRAC) + ";\n";     // Delay::position: one step per input()
+			if (head_used[i]) { end += W(ED_LASTPOS, "(uint32_t)" + n + "t.position") + W(ED_LASTFRAC, "f2u(" + n + "t.fraction)"); mark(w0 + ED_LASTPOS, 2); }
 			break;
 		case N_CTLVAR:
 		case N_SMOOTH:

@@ -54,6 +54,8 @@ FX["fx_topreverb"] = [(0.0, 1.0), (0.0, 1.0), (0.0, 1.0), (0.0, 1.0), (0.3, 1.0)
 # examples/Chorus.k (top level): a Stereo::Effect of two Mono::Modifier channels (each holding a Controls&), five triangle-LFO modulated taps
 # per channel set up in the channels' prepare(), recorded as the per-block prologue
 FX["fx_topchorus"] = [(0.2, 1.0), (0.05, 1.5), (0.1, 0.5), (1.0, 5.5), (0.1, 0.5), (2.0, 20.0)]
+# tests/patches/fx_tape.k (OUR OWN effect): Delay::set in prepare() places the read head once per block, `signal echo = tape` walks it
+FX["fx_owntape"] = [(0.003, 0.04), (0.0, 0.9), (400.0, 6000.0)]
 SHAPE = {"fx_patterns": dict(K=4, blocks=110)}        # name -> instances / blocks (default 9 / 24)
 
 

@@ -17,8 +17,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 NAMES = ["fx_gain", "fx_pan", "fx_rm", "fx_tremolo", "fx_eq", "fx_iir", "fx_wahwah", "fx_echo", "fx_feedback", "fx_flanger", "fx_moddelay", "fx_chorus", "fx_reverb1", "fx_clipping", "fx_mute", "fx_bands", "fx_objects", "fx_dpingpong", "fx_patterns", "fx_topchorus"]
 
 
-def run_effect(name, tmp_path):
-    exe = os.path.join(ROOT, "oracle", "_ref", "facade_" + name)
+def run_effect(name, tmp_path, own=False):
+    exe = os.path.join(ROOT, "tests", "cpp", "_bin", "facade_" + name) if own else os.path.join(ROOT, "oracle", "_ref", "facade_" + name)
+    if own and not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
     if not os.path.exists(exe):
         pytest.skip("built only where the reference's .k files exist (build container); the binary travels in oracle/_ref/")
     ref = np.load(os.path.join(GOLDEN, name + ".npz"))["out"]                  # [B][K][CH][N]
@@ -87,3 +89,13 @@ def test_example_effect_recorded_as_graph_is_bit_exact(name, tmp_path):
     bad = np.argwhere(got.view(np.uint32) != ref.view(np.uint32))
     assert len(bad) == 0, f"{len(bad)} of {got.size} samples differ, first at {bad[0]}, max abs err {np.abs(got - ref).max()}"
     assert np.abs(got).max() > 0
+
+
+def test_own_effect_places_its_read_head_in_prepare_and_walks_it(tmp_path):
+    """tests/patches/fx_tape.k (ours): `tape.set(time * fs)` in prepare() — recorded as the per-block prologue — and `signal echo = tape` in
+    process(): Delay::process reads under the head that set() placed and moves it on.  The head (position, fraction) is state of the
+    instance's record from one sample and one block to the next.  Nine instances, dials changed mid-run, against the genuine header."""
+    got, ref = run_effect("fx_owntape", tmp_path, own=True)
+    exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+    print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e}")
+    assert exact == 1.0 and np.abs(ref).max() > 0.1
