@@ -289,7 +289,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	Biquad dc = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, 0.f, 0.f };
 	if (w_filter) { dc.z0 = PPW(PP_Z + 2 * fch); dc.z1 = PPW(PP_Z + 2 * fch + 1); }
 
-	for (int j = -1; j <= nchunks + 1; j++) {
+	for (int j = -1; j <= nchunks; j++) {
 		// ---------------- io rows of chunk j+1 (audio waves; landed in LDS at the end of the step) ----------------
 		const int jn = j + 1;
 		const bool load_next = w_audio && jn < nchunks;
@@ -416,19 +416,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				}
 			}
 		}
-		// ---------------- store of chunk j-2 (first: its write acknowledgements have the whole step to arrive), FILTER of chunk j-1 ----------------
-		if (w_filter && j >= 2) {
-			const int js = j - 2, s0 = js * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
-			float (*T)[G + 1] = S.tile[js & 3][fch];
-			int sl = lane; asm volatile("" : "+v"(sl));
-			const int col = sl & 31, half = sl >> 5;
-			char* dst = (char*)(a.io + (size_t)k0 * 2 * n + s0);
-#pragma unroll 8
-			for (int it = 0; it < G / 2; it++) {
-				const int inst = 2 * it + half;
-				if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
-			}
-		}
+		// ---------------- FILTER of chunk j-1, then its store (the filter wave's own rows: wave-level ordering is enough) ----------------
 		if (w_filter && j >= 1 && j <= nchunks) {
 			const int jf = j - 1, s0 = jf * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
 			float (*T)[G + 1] = S.tile[jf & 3][fch];
@@ -442,6 +430,15 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 #pragma unroll
 					for (int u = 0; u < 8; u++) T[b + u][li] = x[u];
 				}
+			}
+			wave_sync();
+			int sl = lane; asm volatile("" : "+v"(sl));
+			const int col = sl & 31, half = sl >> 5;
+			char* dst = (char*)(a.io + (size_t)k0 * 2 * n + s0);
+#pragma unroll 8
+			for (int it = 0; it < G / 2; it++) {
+				const int inst = 2 * it + half;
+				if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
 			}
 		}
 		if (load_next) {
