@@ -219,6 +219,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 	}
 }
 
+template<bool B> struct BoolTag { static constexpr bool value = B; };   // (std::true_type without <type_traits>: this header is also compiled by hipRTC)
 // -------------------------------------------------------------------------------------------------
 // PingPong.k, eleven waves per 64 instances (the production kernel).
 //
@@ -366,37 +367,43 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			const int pos0 = (int)(((long long)a.position + s0) % SIZE);
 			float (*T)[PPX_CHUNK][G + 1] = S.tile[j & 3];
 			if (S.far[j & 1]) {
-				// a wave's PPX_PER samples: SPW of them side by side in its lanes (lane = sample slot x instance), PASSES passes
+				// a wave's PPX_PER samples: SPW of them side by side in its lanes (lane = sample slot x instance), PASSES passes.  FULL (a whole chunk: every
+				// chunk but a block's ragged last) is a compile-time variant: with the per-pass bounds tests in place every pass ends in a join, and the
+				// joins cost a dozen 64-bit register copies per pass (the rows in flight are live across them)
+				auto far_chunk = [&](auto full_c) {
+					constexpr bool FULL = decltype(full_c)::value;
 				const int u0 = (wv - 1) * PPX_PER + lq;
-				Tap tl[PASSES], tr[PASSES];
-				float pl[PASSES][3], pr[PASSES][3];
+					Tap tl[PASSES], tr[PASSES];
+					float pl[PASSES][3], pr[PASSES][3];
 #pragma unroll
-				for (int q = 0; q < PASSES; q++) if (u0 + q * SPW < cl) {
-					const int u = u0 + q * SPW;
-					const float delay = S.D[j & 1][u][li];
-					const int pos = wrap(pos0 + u);
-					tl[q] = delay_set(pos, SIZE, delay * a.fs.f);                   // left.set(delay * fs)
-					tr[q] = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);            // right.set(0.5f * delay * fs)
-					const int i0 = tl[q].position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
-					const int j0 = tr[q].position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
-					pl[q][0] = ring_rd(0, i0); pl[q][1] = ring_rd(0, i1); pl[q][2] = ring_rd(0, i2);
-					pr[q][0] = ring_rd(1, j0); pr[q][1] = ring_rd(1, j1); pr[q][2] = ring_rd(1, j2);
-				}
+					for (int q = 0; q < PASSES; q++) if (FULL || u0 + q * SPW < cl) {
+						const int u = u0 + q * SPW;
+						const float delay = S.D[j & 1][u][li];
+						const int pos = wrap(pos0 + u);
+						tl[q] = delay_set(pos, SIZE, delay * a.fs.f);                   // left.set(delay * fs)
+						tr[q] = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);            // right.set(0.5f * delay * fs)
+						const int i0 = tl[q].position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
+						const int j0 = tr[q].position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
+						pl[q][0] = ring_rd(0, i0); pl[q][1] = ring_rd(0, i1); pl[q][2] = ring_rd(0, i2);
+						pr[q][0] = ring_rd(1, j0); pr[q][1] = ring_rd(1, j1); pr[q][2] = ring_rd(1, j2);
+					}
 #pragma unroll
-				for (int q = 0; q < PASSES; q++) if (u0 + q * SPW < cl) {
-					const int u = u0 + q * SPW, pos = wrap(pos0 + u);
-					const float in_l = T[0][u][li], in_r = T[1][u][li];
-					// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
-					const float r1 = pr[q][0] + tr[q].fraction * (pr[q][1] - pr[q][0]);
-					ring_wr(0, pos, in_l + r1 * gain);
-					const float l1 = pl[q][0] + tl[q].fraction * (pl[q][1] - pl[q][0]);
-					const float l2 = pl[q][1] + tl[q].fraction * (pl[q][2] - pl[q][1]);
-					T[0][u][li] = dry * in_l + l1 * (1.f - dry);
-					// dry * in.r + (1.f - dry) * ((in.r + left * gain) >> right) >> out.r;   PingPong.k:67
-					ring_wr(1, pos, in_r + l2 * gain);
-					const float r2 = pr[q][1] + tr[q].fraction * (pr[q][2] - pr[q][1]);
-					T[1][u][li] = dry * in_r + r2 * (1.f - dry);
-				}
+					for (int q = 0; q < PASSES; q++) if (FULL || u0 + q * SPW < cl) {
+						const int u = u0 + q * SPW, pos = wrap(pos0 + u);
+						const float in_l = T[0][u][li], in_r = T[1][u][li];
+						// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
+						const float r1 = pr[q][0] + tr[q].fraction * (pr[q][1] - pr[q][0]);
+						ring_wr(0, pos, in_l + r1 * gain);
+						const float l1 = pl[q][0] + tl[q].fraction * (pl[q][1] - pl[q][0]);
+						const float l2 = pl[q][1] + tl[q].fraction * (pl[q][2] - pl[q][1]);
+						T[0][u][li] = dry * in_l + l1 * (1.f - dry);
+						// dry * in.r + (1.f - dry) * ((in.r + left * gain) >> right) >> out.r;   PingPong.k:67
+						ring_wr(1, pos, in_r + l2 * gain);
+						const float r2 = pr[q][1] + tr[q].fraction * (pr[q][2] - pr[q][1]);
+						T[1][u][li] = dry * in_r + r2 * (1.f - dry);
+					}
+							};
+				if (cl == PPX_CHUNK) far_chunk(BoolTag<true>{}); else far_chunk(BoolTag<false>{});
 			}
 			else if (wv == 1 && lane < G) {                                         // a near tap: the chunk is walked in order by one wave, lane = instance
 				const int col = (k0 & (FX_WG - 1)) + li;
@@ -420,17 +427,21 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		if (w_filter && j >= 1 && j <= nchunks) {
 			const int jf = j - 1, s0 = jf * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
 			float (*T)[G + 1] = S.tile[jf & 3][fch];
-			for (int b = 0; b < PPX_CHUNK; b += 8) {                                  // eight LDS reads in flight, then the (sequential) filter
-				float x[8];
+			auto filter_chunk = [&](auto full_c) {                                    // (FULL: see far_chunk — a bounds test per sample is a join per sample)
+				constexpr bool FULL = decltype(full_c)::value;
+				for (int b = 0; b < PPX_CHUNK; b += 8) {                              // eight LDS reads in flight, then the (sequential) filter
+					float x[8];
 #pragma unroll
-				for (int u = 0; u < 8; u++) x[u] = T[b + u][li];
+					for (int u = 0; u < 8; u++) x[u] = T[b + u][li];
 #pragma unroll
-				for (int u = 0; u < 8; u++) if (b + u < cl) x[u] = biquad_process(dc, x[u]);     // out >> dcfilter[ch] >> out
-				if (lane < G) {
+					for (int u = 0; u < 8; u++) if (FULL || b + u < cl) x[u] = biquad_process(dc, x[u]);     // out >> dcfilter[ch] >> out
+					if (lane < G) {
 #pragma unroll
-					for (int u = 0; u < 8; u++) T[b + u][li] = x[u];
+						for (int u = 0; u < 8; u++) T[b + u][li] = x[u];
+					}
 				}
-			}
+			};
+			if (cl == PPX_CHUNK) filter_chunk(BoolTag<true>{}); else filter_chunk(BoolTag<false>{});
 			wave_sync();
 			int sl = lane; asm volatile("" : "+v"(sl));
 			const int col = sl & 31, half = sl >> 5;
@@ -635,7 +646,6 @@ struct Rv16Lds {
 	float CF[15][64];                           // per-instance constants only two waves per channel need: early LPF / HPF coefficients, dry/c1/c2/c3/wet
 };
 
-template<bool B> struct BoolTag { static constexpr bool value = B; };
 template<int I> struct IntTag { static constexpr int value = I; };   // (std::true_type without <type_traits>: this header is also compiled by hipRTC)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every ring-row
