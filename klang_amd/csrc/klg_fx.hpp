@@ -303,10 +303,16 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		const int ns0 = jn * PPX_CHUNK, ncl = (n - ns0 < PPX_CHUNK) ? (n - ns0) : PPX_CHUNK;
 		if (load_next) {
 			const char* src = (const char*)(a.io + (size_t)k0 * 2 * n + ns0);
+			if (ncl == PPX_CHUNK && k0 + G <= a.K) {                                  // a whole chunk of a whole group: no bounds to test
 #pragma unroll
-			for (int i = 0; i < IOV; i++) {
-				const int row = arow + 16 * i, inst = row >> 1;
-				iov[i] = (acol < ncl && k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + acol) * 4u) : 0.f;
+				for (int i = 0; i < IOV; i++) iov[i] = *(const float*)(src + (unsigned)((arow + 16 * i) * n + acol) * 4u);
+			}
+			else {
+#pragma unroll
+				for (int i = 0; i < IOV; i++) {
+					const int row = arow + 16 * i, inst = row >> 1;
+					iov[i] = (acol < ncl && k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + acol) * 4u) : 0.f;
+				}
 			}
 		}
 		// ---------------- CONTROL of chunk j+1 ----------------
@@ -321,8 +327,9 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				const float k5 = (1.f - 0.999f) * c5;                              // (1.f - 0.999f) * value: the control does not change inside a block
 				const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);                      // Phase::operator+= klang.h:1518-1525
 				float pos = lfo.position;
+				auto chain = [&](const int count) {
 #pragma unroll 8
-				for (int u = 0; u < ncl; u++) {
+				for (int u = 0; u < count; u++) {
 					sm5 = sm5 * 0.999f + k5;                                        // controls[5].smooth()  klang.h:1715
 					// (double)fabsf(d) > 0.001  <=>  fabsf(d) >= 0.001f: 0.001f is the smallest float above the double 0.001
 					const bool trig = fabsf(mdelay - sm5) >= 0.001f;
@@ -335,6 +342,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 					pos = inc_ok ? p2 : pos;
 					dmin = __builtin_fminf(dmin, sm1); dmax = __builtin_fmaxf(dmax, sm1);
 				}
+				};
+				if (ncl == PPX_CHUNK) chain(PPX_CHUNK); else chain(ncl);              // (a whole chunk: a constant trip count)
 				lfo.position = pos;
 			}
 			else
@@ -446,10 +455,16 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			int sl = lane; asm volatile("" : "+v"(sl));
 			const int col = sl & 31, half = sl >> 5;
 			char* dst = (char*)(a.io + (size_t)k0 * 2 * n + s0);
+			if (cl == PPX_CHUNK && k0 + G <= a.K) {
 #pragma unroll 8
-			for (int it = 0; it < G / 2; it++) {
-				const int inst = 2 * it + half;
-				if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
+				for (int it = 0; it < G / 2; it++) { const int inst = 2 * it + half; *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst]; }
+			}
+			else {
+#pragma unroll 8
+				for (int it = 0; it < G / 2; it++) {
+					const int inst = 2 * it + half;
+					if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
+				}
 			}
 		}
 		if (load_next) {
