@@ -141,3 +141,35 @@ def test_effect_bank_at_config_size(patch, blocks, oracle_build):
     reps = got.reshape(len(dump), K // C, C, 2, N)
     assert np.array_equal(reps.view(np.uint32), np.broadcast_to(reps[:, :1], reps.shape).view(np.uint32)), "a replica differs from its class representative"
     assert np.abs(got).max() > 0
+
+
+def test_recorded_pingpong_equals_its_kernel_at_config_size():
+    """Config 4's size, 4,096 instances: the shipped examples/PingPong.k RECORDED (tests/golden/pingpong_recorded.klgg + .rec, what the facade
+    records from the unchanged file) against its hand-written kernel klg_fx_pingpong_x on the same input, dials spread over their ranges on every
+    seventh instance (vibrato on, taps inside a chunk, the scratch branch writing controls[1]) — bit for bit, and the control the effect writes
+    comes back the same from both."""
+    import os
+    import klang_amd
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    prog = open(os.path.join(golden, "pingpong_recorded.klgg")).read()
+    rec = np.array([int(w, 16) for w in open(os.path.join(golden, "pingpong_recorded.rec")).read().split()], np.uint32)
+    K, N, B = 4096, 256, 6
+    rng = np.random.default_rng(41)
+    ctl = [(k, c, float(rng.uniform(lo, hi))) for k in range(0, K, 7) for c, lo, hi in ((0, 0.2, 0.9), (1, 0.002, 0.6), (2, 0.0, 1.0), (3, 0.01, 1.0), (4, 0.2, 1.5), (5, 0.0, 0.4))]
+    x = rng.uniform(-0.5, 0.5, size=(B, K, 2, N)).astype(np.float32)
+    x[4:] = 0
+    outs, written = [], []
+    for bank in (klang_amd.FxBank("pingpong", K, max_block=N), klang_amd.FxBank(prog, K, max_block=N, initial_record=rec, channels=2)):
+        for k, c, v in ctl:
+            bank.set_control(k, c, v)
+        res = []
+        for b in range(B):
+            io = x[b].copy()
+            bank.process(io)
+            res.append(io)
+        outs.append(np.stack(res))
+        written.append(np.array([bank.get_control(k, 1) for k in range(0, K, 97)], np.float32))
+        bank.close()
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), f"max abs diff {np.abs(outs[0] - outs[1]).max()}"
+    assert np.array_equal(written[0].view(np.uint32), written[1].view(np.uint32))
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0][5]).max() > 1e-3                # the echoes are still sounding after the input stopped
