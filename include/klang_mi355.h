@@ -217,7 +217,8 @@ klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate, int max_bl
 void klg_fx_destroy(klg_fx* f);
 int klg_fx_set_control(klg_fx* f, int instance, int index, float value);
 /* replaces: `parameters[c] = controls[c].value` after the block (Effect::process(float*, int, float*) klang.h:4213-4215): the value as the
- * effect left it — a control its process() writes (examples/PingPong.k:48,60) comes back from the instance's state. */
+ * effect left it — a control its process() writes (examples/PingPong.k:48,60) comes back from the instance's state (as of the blocks
+ * that have completed on the bank's own stream: after klg_fx_process, or klg_fx_sync following klg_fx_process_device). */
 int klg_fx_get_control(klg_fx* f, int instance, int index, float* value);
 /* replaces: Stereo::Effect::process(Stereo::buffer) klang.h:4708-4716 for every instance:
  * io[(k*2 + c)*n + i] is channel c of instance k, processed in place.  Host buffers, synchronous. */

@@ -288,7 +288,7 @@ struct Program {
 			case OP_DELAYTAP: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); need_a = true; break;
 			case OP_DELAYOUT: if (k != N_NDELAY && k != N_DELAY) return bad("node is not a delay"); break;
 			case OP_DELAYSET: if (k != N_NDELAY && k != N_DELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
-			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); break;
+			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); if (!channels && !open.empty()) return bad("a Note's controls[i].smooth() may not sit inside an `if`: the bank advances the Synth's control by a fixed number of steps per sounding note and sample"); break;
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			case OP_CMP: if (o.imm > 5u) return bad("unknown relation"); need_a = need_b = true; break;
 			case OP_NOISE: if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;

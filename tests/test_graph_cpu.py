@@ -218,6 +218,9 @@ def test_a_notes_smoothed_control_is_a_record_word_the_bank_sets_per_block():
     assert src.count("L.n1 = L.n1 * 0.999f + (1.f - 0.999f) * c.ctl[1];") == 2 * 3 and "klg_render_x2<" not in src      # three bodies
     rc, msg = check(prog.replace("op smooth 2 -1 -1 1 1", "op smooth 2 -1 -1 1 5"))
     assert rc < 0 and "not a smoothed control" in msg
+    branchy = "klgg 1\nctl 1\nnode 0 fsine\nnode 1 smooth\nop osc 0 -1 -1 0 0\nop cmp 1 0 0 -1 1\nop if -1 1 -1 -1 0\nop smooth 2 -1 -1 1 0\nop endif -1 -1 -1 -1 0\nret 0\nend\n"
+    rc, msg = check(branchy)
+    assert rc < 0 and "inside an `if`" in msg          # the chain through the sounding notes assumes one step per call and sample
 
 
 def test_oscillators_can_be_rephased_per_sample():
