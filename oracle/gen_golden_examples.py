@@ -93,6 +93,8 @@ def scenarios():
     out["own_smooth_note"] = poly("own_smooth_note", 40, [0, 1, 3, 4, 7, 8, 39], off_base=8, notes=16, ctl=[(0, 1000.0), (1, 0.8)], ctl_events=[(3, 0, 4000.0), (3, 1, 0.3), (7, 0, 300.0), (12, 1, 1.0)])
     # hardsync.k: set(f, phase) / reset() on Fast::OSM, Fast::Sine and Basic::Sine oscillators from inside branches of process()
     out["own_hardsync"] = poly("own_hardsync", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.7), (20, 0, 0.0)])
+    # vibstring.k: Delay::set(time) with a recorded time EVERY sample in a Note (the read head's position and fraction are written back)
+    out["own_vibstring"] = poly("own_vibstring", 48, [0, 1, 7, 8, 47], off_base=10, notes=16, ctl_events=[(12, 0, 0.98), (20, 1, 0.03)])
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],
