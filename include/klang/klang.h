@@ -518,6 +518,10 @@ struct Output : Generic::Output<signal> {};
 struct Generator : Generic::Generator<signal> {};
 struct Modifier : Generic::Modifier<signal> {};
 inline signal& operator+=(signal& s, Generic::Output<signal>& o) { s.value += signal(o).value; return s; }
+// Control (op) object (`controls[1] * lfo`): the control's value and the object's next output (the reference: Control -> signal&, then signal (op) object)
+#define KLANG_CONTROL_OBJECT_OPS(OP) inline signal operator OP(Control& c, Generic::Output<signal>& o) { const signal& b = o; return c.value OP b; }
+KLANG_CONTROL_OBJECT_OPS(+) KLANG_CONTROL_OBJECT_OPS(-) KLANG_CONTROL_OBJECT_OPS(*) KLANG_CONTROL_OBJECT_OPS(/)
+#undef KLANG_CONTROL_OBJECT_OPS
 
 // `a >> b`: b.input(a) when b is an Input, else plain assignment (klang.h:4868-4890)
 template<class SRC, class DST, typename = std::enable_if_t<!std::is_arithmetic_v<SRC>>>
