@@ -1440,7 +1440,10 @@ template<int SIZE> struct Delay : Modifier, gpu::Packable {
 		device_only("Delay::input()");
 	}
 	template<typename TIME> signal operator()(const TIME& delay) {                 // klang.h:3491-3509: tap(int) for integers, tap(float) otherwise
-		static_assert(!std::is_integral_v<TIME>, "klang-mi355: Delay::operator()(int) (the un-interpolated tap) is not recorded yet: pass a float / signal time");
+		if constexpr (std::is_integral_v<TIME>) {                                   // tap(int) klang.h:3405-3410: the sample `delay` positions back, no interpolation
+			if (gpu::Recorder* r = gpu::recording()) { signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(signal((float)delay)), -1, r->node(this, "Delay"), 1, true); return s; }
+			device_only("Delay::operator()");
+		}
 		if (gpu::Recorder* r = gpu::recording()) { signal t; if constexpr (std::is_arithmetic_v<TIME>) t = signal((float)delay); else t = signal(const_cast<TIME&>(delay)); signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(t), -1, r->node(this, "Delay"), 0, true); return s; }
 		device_only("Delay::operator()");
 	}

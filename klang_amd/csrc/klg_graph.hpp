@@ -315,7 +315,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		case OP_IN: body += d + (o.imm ? "in1" : "in0") + ";\n"; break;
 		case OP_DELAYIN: body += "\t\t{ const Ring q = " + ring(o.node) + "; q.wr(" + n + "pos, " + a + "); " + n + "pos = (" + n + fmt("pos + 1 == %d) ? 0 : ", g.arg(o.node)) + n + "pos + 1; }\n"; break;   // Delay::input klang.h:3396-3403
 		case OP_DELAYSET: body += "\t\t" + n + "t = delay_set(" + n + fmt("pos, %d, ", g.arg(o.node)) + a + ");\n"; break;   // Delay::set klang.h:3480-3489
-		case OP_DELAYTAP: body += d + "delay_tap_float(" + ring(o.node) + ", " + n + "pos, " + a + ");\n"; break;
+		case OP_DELAYTAP: body += d + (o.imm == 1u ? "delay_tap_int(" + ring(o.node) + ", " + n + "pos, (int)" + a + ");\n" : "delay_tap_float(" + ring(o.node) + ", " + n + "pos, " + a + ");\n"); break;   // imm 1: tap(int), klang.h:3405-3410
 		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 7u]) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";
