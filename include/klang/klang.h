@@ -1334,12 +1334,13 @@ template<class NOTEBASE> inline void record_note(NOTEBASE* nb, std::vector<Obj> 
 		nb->run_process();
 		R.may_branch = false;
 		if (R.pending >= 0) R.fail("`if (env.finished())` may only guard stop() in a recorded process()");
-		const int ret = R.reg_of(nb->out);
+		// `out` at the end of process(): one register, or two for a Stereo::Note whose out is {l, r} (klang.h:4721-4733) -> `ret2`
+		const int ret = R.reg_of(nb->out_channel(0)), ret_r = nb->out_channels() == 2 ? R.reg_of(nb->out_channel(1)) : -1;
 		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
 			signal* sg = (signal*)R.objs[i].addr;
 			if (sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);     // written by process(): the next sample reads it
 		}
-		R.emit(PathMerger::OP_OUT, ret, -1, -1, 0, false);
+		R.emit(PathMerger::OP_OUT, ret, ret_r, -1, 0, false);
 	});
 	paths.record();
 	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = -1; sg->value = value0[i]; }
@@ -1752,7 +1753,7 @@ template<class NOTE> inline void solo_push(NOTE* note) {
 template<class NOTE> inline const float* solo_render(NOTE* note, int at, int m) {
 	(void)at;
 	SoloVoice* s = note->solo;
-	s->pv.resize((size_t)m);
+	s->pv.resize((size_t)m * (size_t)klg_synth_note_channels(s->h));       // [channels][m] for a note with a stereo out
 	if (klg_process_voices(s->h, s->pv.data(), nullptr, 0, m)) { std::fprintf(stderr, "klang-mi355: klg_process_voices: %s\n", klg_last_error()); std::abort(); }
 	uint8_t st = 0;
 	if (klg_voice_stages(s->h, &st, 1)) { std::fprintf(stderr, "klang-mi355: klg_voice_stages: %s\n", klg_last_error()); std::abort(); }
@@ -1905,10 +1906,12 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		if (klg_voice_stages(gpu, stages.data(), (int)notes.count)) fail("klg_voice_stages");
 		for (unsigned n = 0; n < notes.count; n++) if (stages[n] == klg::ST_OFF) notes[(int)n]->stage = NOTEBASE::Off;    // `if (!note->process(..)) note->stop()`
 	}
+	float* per_voice_sink = nullptr;                                          // tests: every voice's own block ([voice][note channels][length]) is written here too
 	void render_voices(float* const* buffers, int channels, int length) {
 		ensure_gpu();
 		sync_controls();
-		if (klg_process(gpu, buffers, channels, length, nullptr)) fail("klg_process");
+		if (per_voice_sink) { if (klg_process_voices(gpu, per_voice_sink, buffers, channels, length)) fail("klg_process_voices"); }
+		else if (klg_process(gpu, buffers, channels, length, nullptr)) fail("klg_process");
 		refresh_stages();
 		pull_smoothed();
 	}
@@ -1921,6 +1924,7 @@ struct Note : NoteBase<Synth>, Generator {
 	virtual void prepare() {}
 	virtual void process() override = 0;
 	void run_process() { this->process(); }
+	signal& out_channel(int) { return out; } int out_channels() const { return 1; }
 	void solo_pull() override { gpu::solo_pull(this); }
 	void solo_push() override { gpu::solo_push(this); }
 	virtual bool process(buffer buffer) {                                    // klang.h:4295-4303: per sample { process(); buffer++ = out; } — a mono note OVERWRITES
@@ -1965,16 +1969,21 @@ struct Synth : SynthCore<Note> {
 
 namespace Stereo {
 	struct Synth;
-	// Stereo::Note / Stereo::Mono::Note (klang.h:4722-4757): the note's `out` is mono here and goes to both channels (Mono::Note's
-	// `L += out; R += out`); a note used on its own ADDS to the buffer, as there
-	struct Note : NoteBase<Synth>, klang::Generator {
+	// Stereo::Note (klang.h:4721-4739): `out` is a STEREO signal; a block is `process(); buffer++ += out;` — out.l is added to the left,
+	// out.r to the right channel.  On the device such a note renders two samples per sample (`ret2` of its recorded program).
+	// Stereo::Mono::Note (klang.h:4741-4757) keeps a mono `out` that goes to both channels (`left += out; right += out`).
+	struct Note : NoteBase<Synth> {
 		typedef Synth synth_type;
+		Stereo::signal out;
+		Note() { out.l.reg_member(); out.r.reg_member(); }                       // (members of `out`: what process() leaves there is what the next sample finds)
 		virtual void prepare() {}
-		virtual void process() override = 0;
+		virtual void process() = 0;
 		void run_process() { this->process(); }
+		virtual klang::signal& out_channel(int c) { return c ? out.r : out.l; }
+		virtual int out_channels() const { return 2; }
 		void solo_pull() override { gpu::solo_pull(this); }
 		void solo_push() override { gpu::solo_push(this); }
-		virtual bool process(Stereo::buffer buffer) {                            // klang.h:4727-4734 / 4747-4756
+		virtual bool process(Stereo::buffer buffer) {                            // klang.h:4727-4734 / 4747-4756: a note ADDS to the buffer
 			if (attached()) gpu::note_of_a_synth();
 			gpu::solo_ensure(this);
 			if (!solo->rendered) { gpu::solo_push(this); solo->rendered = true; }
@@ -1983,18 +1992,26 @@ namespace Stereo {
 				if (m > 1024) m = 1024;
 				if (m <= 0) break;
 				const float* y = gpu::solo_render(this, 0, m);
+				const float* yr = out_channels() == 2 ? y + m : y;                 // per-voice block of a stereo note: [2][m]
 				float* l = buffer.left.cursor(); float* r = buffer.right.cursor();
-				for (int i = 0; i < m; i++) { l[i] += y[i]; r[i] += y[i]; }
+				for (int i = 0; i < m; i++) { l[i] += y[i]; r[i] += yr[i]; }
 				buffer.left.advance(m); buffer.right.advance(m);
 			}
 			return !finished();
 		}
 		virtual bool process(klang::buffer* buffers) { Stereo::buffer b = { buffers[0], buffers[1] }; return this->process(b); }   // klang.h:4735-4738
 	};
-	namespace Mono { typedef Stereo::Note Note; }
+	namespace Mono {
+		struct Note : Stereo::Note, klang::Generator {
+			using klang::Generator::out;
+			void process() override = 0;
+			klang::signal& out_channel(int) override { return out; }
+			int out_channels() const override { return 1; }
+		};
+	}
 	struct Synth : SynthCore<Note> {
 		typedef Stereo::Note Note;
-		struct Mono { typedef Stereo::Note Note; };
+		struct Mono { typedef Stereo::Mono::Note Note; };
 		Stereo::signal in, out;
 		virtual void prepare() {}
 		virtual void process() { out = in; }                                       // post processing (klang.h:4826-4827)

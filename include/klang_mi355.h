@@ -84,6 +84,10 @@ void klg_synth_destroy(klg_synth* s);
 int klg_synth_voices(const klg_synth* s);
 int klg_synth_controls(const klg_synth* s);              /* controls.size() of the patch */
 size_t klg_synth_state_bytes(const klg_synth* s);        /* resident HBM bytes per voice */
+/* replaces: the choice of Note base class (klang.h:4721-4757).  1: a voice's `out` is one signal — klang::Note, or Stereo::Mono::Note whose
+ * process(Stereo::buffer) adds it to BOTH channels (4747-4756); 2: Stereo::Note, `out` is a stereo signal and `buffer++ += out` (4731) adds
+ * out.l to the left and out.r to the right channel (graph banks whose program ends in `ret2`). */
+int klg_synth_note_channels(const klg_synth* s);
 
 /* replaces: Synth::noteOn(int pitch, float velocity) klang.h:4423-4427 / 4813-4817 — Notes::assign()
  * voice allocation + NoteBase::start() + the patch's on() run on the HOST; the resulting lane state is
@@ -113,7 +117,8 @@ int klg_get_control_smoothed(klg_synth* s, int synth, int index, float* smoothed
  * copied in (clamped) before and out after the block.  Synchronous on return. */
 int klg_process(klg_synth* s, float* const* out, int channels, int n, float* parameters);
 /* Same block, additionally returning every voice's own n samples (per_voice[v*n + i], zeros for Off voices):
- * the quantity Note::process(buffer) writes (klang.h:4295-4303).  Parity/debug path. */
+ * the quantity Note::process(buffer) writes (klang.h:4295-4303).  A bank of stereo notes (klg_synth_note_channels() == 2) returns
+ * per_voice[(v*2 + c)*n + i]: what Stereo::Note::process(Stereo::buffer) adds to channel c (klang.h:4727-4733).  Parity/debug path. */
 int klg_process_voices(klg_synth* s, float* per_voice, float* const* out, int channels, int n);
 /* How the voices of one synth instance combine.  KLG_MIX_SUM (default): the block is the SUM of the sounding voices and is ADDED to the
  * caller's samples — Stereo::Synth::process (klang.h:4842-4848; Stereo::Note::process `buffer++ += out`, 4731).

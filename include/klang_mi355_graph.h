@@ -20,7 +20,9 @@
  *     op <code> <dst> <a> <b> <node> <imm>   one op; unused fields are -1; imm = IEEE-754 bits (hex) of a constant
  *     prepare <n>                         optional: the first n ops are Effect::prepare() / Note::prepare() (klang.h:4208-4211) — they run once per
  *                                         block per instance, before the samples; their registers are not visible to the sample ops
- *     ret <reg>                           the register holding `out` at the end of process()   (ret2 <l> <r> for a Stereo::Effect)
+ *     ret <reg>                           the register holding `out` at the end of process()   (ret2 <l> <r> for a Stereo::Effect, and for a
+ *                                         note whose `out` is a stereo signal — Stereo::Note, klang.h:4721-4733: `buffer++ += out` adds out.l to
+ *                                         the left and out.r to the right channel; such a bank renders two samples per voice and sample)
  *     end
  * Data-dependent branches of process() (`if (in > 1) in = 1;`, `if (osc.frequency < fs.nyquist) out += osc / h;`) are
  * structured ops: `cmp` makes a 1.0 / 0.0 register, `if <a>` ... `else` ... `endif` brackets the two sides (registers
@@ -178,7 +180,8 @@ struct Program {
 	std::vector<int> nodes;      /* kind of node i */
 	std::vector<int> node_arg;   /* Delay<SIZE>: SIZE; else 0 */
 	std::vector<Op> ops;
-	int ret = -1, ret_r = -1;    /* ret_r: right channel of a Stereo::Effect */
+	int ret = -1, ret_r = -1;    /* ret_r: right channel of a Stereo::Effect / of a Stereo::Note (a note program with ret2) */
+	bool stereo_note() const { return channels == 0 && ret_r >= 0; }
 	int channels = 0;            /* 0 = synth note; 1 / 2 = effect with that many channels */
 	int prepare_ops = 0;         /* the first prepare_ops ops are the effect's prepare(): once per block */
 	int arg(int node) const { return node < (int)node_arg.size() ? node_arg[(size_t)node] : 0; }
@@ -199,7 +202,7 @@ struct Program {
 		}
 		for (const Op& o : ops) { snprintf(line, sizeof line, "op %s %d %d %d %d %08x\n", op_name(o.code), o.dst, o.a, o.b, o.node, o.imm); s += line; }
 		if (prepare_ops) { snprintf(line, sizeof line, "prepare %d\n", prepare_ops); s += line; }
-		if (channels == 2) snprintf(line, sizeof line, "ret2 %d %d\nend\n", ret, ret_r); else snprintf(line, sizeof line, "ret %d\nend\n", ret);
+		if (channels == 2 || stereo_note()) snprintf(line, sizeof line, "ret2 %d %d\nend\n", ret, ret_r); else snprintf(line, sizeof line, "ret %d\nend\n", ret);
 		s += line;
 		return s;
 	}
@@ -333,7 +336,8 @@ struct Program {
 			for (int i = 0; i < prepare_ops; i++) { const int c = ops[(size_t)i].code; if (c == OP_IN || c == OP_DELAYIN || c == OP_DELAYTAP || c == OP_OSC || c == OP_LPF || c == OP_ENV || c == OP_SMOOTH || c == OP_OPERATOR) return "graph program: prepare() may only compute and set()"; }
 		}
 		if (!def(ret)) return "graph program: 'ret' names an undefined register";
-		if (channels == 2 && !def(ret_r)) return "graph program: 'ret2' names an undefined register";
+		if ((channels == 2 || stereo_note()) && !def(ret_r)) return "graph program: 'ret2' names an undefined register";
+		if (channels == 1 && ret_r >= 0) return "graph program: 'ret2' in a one-channel effect";
 		if (channels == 0) for (int k : nodes) if (k == N_DELAY) return "graph program: delay nodes need an effect program (kind effect); a Note's Delay member is a notedelay";
 		if (channels != 0) for (int k : nodes) if (k == N_WAVETABLE || k == N_NDELAY) return "graph program: wavetable / notedelay nodes are only available to synth notes";
 		return "";

@@ -46,6 +46,7 @@ def load():
         "klg_synth_destroy": (None, [vp]),
         "klg_synth_voices": (C.c_int, [vp]),
         "klg_synth_controls": (C.c_int, [vp]),
+        "klg_synth_note_channels": (C.c_int, [vp]),
         "klg_synth_state_bytes": (C.c_size_t, [vp]),
         "klg_note_on": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),
         "klg_note_off": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),

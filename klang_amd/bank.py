@@ -106,8 +106,13 @@ class SynthBank:
         check(self._L.klg_process(self._h, ptrs, ch, n, par), "klg_process")
         return out
 
+    @property
+    def note_channels(self):
+        """1: a voice's `out` is mono; 2: the bank renders Stereo::Notes with a stereo `out` (klg_synth_note_channels)"""
+        return int(self._L.klg_synth_note_channels(self._h))
+
     def process_voices(self, n, out=None):
-        pv = np.empty((self.voices, n), dtype=np.float32)
+        pv = np.empty((self.voices, n) if self.note_channels == 1 else (self.voices, 2, n), dtype=np.float32)
         if out is None:
             out = np.zeros((2, n), dtype=np.float32)
         ch = out.shape[0]

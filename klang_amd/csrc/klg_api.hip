@@ -84,7 +84,7 @@ extern "C" void klg_random_seed(unsigned seed) { srand(seed); }     // klang::ra
 // patch table
 // ------------------------------------------------------------------------------------------------
 struct DialDef { float min, max, initial; };
-struct PatchInfo { int words; int ncontrols; DialDef dials[KLG_MAX_CTL]; int fsines; };
+struct PatchInfo { int words; int ncontrols; DialDef dials[KLG_MAX_CTL]; int fsines; int note_channels; };   // note_channels: 0 / 1 = the notes' `out` is mono, 2 = stereo (graph patches with ret2)
 
 static const PatchInfo* patch_info(int id) {
 	static const PatchInfo T[KLG_PATCH_COUNT] = {
@@ -107,6 +107,7 @@ struct Event { int voice, type, payload; unsigned seq; };
 
 struct klg_synth {
 	int patch = 0, S = 0, P = 0, V = 0, W = 0, max_block = 0, nctl = 0;
+	int note_ch = 1;                             // channels of a voice's own output: 2 for banks of Stereo::Notes whose `out` is {l, r} (klang.h:4721-4733)
 	size_t stride = 0;
 	host::Fs fs;
 	SampleRate dfs;
@@ -261,7 +262,7 @@ template<class MAKE> static klg_synth* multi_create(int synths, int notes_per_sy
 		m.shard.push_back(sh); m.first.push_back(m.first.back() + count);
 	}
 	(void)hipSetDevice(keep);
-	r->patch = m.shard[0]->patch; r->W = m.shard[0]->W; r->nctl = m.shard[0]->nctl; r->fs = m.shard[0]->fs;
+	r->patch = m.shard[0]->patch; r->W = m.shard[0]->W; r->nctl = m.shard[0]->nctl; r->fs = m.shard[0]->fs; r->note_ch = m.shard[0]->note_ch;
 	bool distinct = true;
 	for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (devs[(size_t)i] == devs[(size_t)j]) distinct = false;
 	if (distinct && n > 1) {                                        // ONE communicator clique over the shards' devices (RCCL over xGMI)
@@ -288,7 +289,7 @@ static klg_synth* synth_create_common(int patch_id, const PatchInfo* pi, int syn
 	if (klg_ensure_device()) return nullptr;
 	klg_synth* s = new klg_synth();
 	s->patch = patch_id; s->S = synths; s->P = notes_per_synth; s->V = synths * notes_per_synth; s->W = pi->words;
-	s->max_block = max_block; s->nctl = pi->ncontrols;
+	s->max_block = max_block; s->nctl = pi->ncontrols; s->note_ch = pi->note_channels == 2 ? 2 : 1;
 	s->stride = ((size_t)s->V + WG - 1) / WG * WG;
 	s->fs = host::Fs(sample_rate);
 	s->dfs.f = s->fs.f; s->dfs.w = s->fs.w; s->dfs.timeInc = 1.0f / s->fs.f;
@@ -310,7 +311,7 @@ static klg_synth* synth_create_common(int patch_id, const PatchInfo* pi, int syn
 		const int per_wg = s->pairs ? 16 / s->pairs_p * WAVES : KLG_LANES_VOICES_PER_WG;
 		s->grid_lanes = std::min((s->V + per_wg - 1) / per_wg, (ok ? prop.multiProcessorCount : 256) * 8);
 	}
-	ok = ok && hipMalloc(&s->d_partials, (size_t)std::max(s->grid, s->lanes ? s->grid_lanes : 0) * max_block * 4) == hipSuccess;
+	ok = ok && hipMalloc(&s->d_partials, (size_t)std::max(s->grid, s->lanes ? s->grid_lanes : 0) * max_block * 4 * s->note_ch) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_mix, (size_t)2 * max_block * 4) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_scratch_rec, (size_t)std::max(64, s->W) * 4) == hipSuccess;
 	ok = ok && hipHostMalloc(&s->h_mix, (size_t)2 * max_block * 4) == hipSuccess;
@@ -376,7 +377,7 @@ extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, in
 		x2 = false;
 	}
 	PatchInfo pi = {};
-	pi.words = c->words; pi.ncontrols = g.nctl;
+	pi.words = c->words; pi.ncontrols = g.nctl; pi.note_channels = c->note_channels;
 	for (int i = 0; i < g.nctl; i++) pi.dials[i] = { g.dials[i].min, g.dials[i].max, g.dials[i].initial };
 	klg_synth* s = synth_create_common(KLG_PATCH_GRAPH, &pi, synths, notes_per_synth, sample_rate, max_block);
 	if (!s) return nullptr;
@@ -422,6 +423,7 @@ extern "C" int klg_synth_set_mix_mode(klg_synth* s, int mode) {
 }
 extern "C" int klg_synth_voices(const klg_synth* s) { return s ? s->V : KLG_ERR_INVALID; }
 extern "C" int klg_synth_controls(const klg_synth* s) { return s ? s->nctl : KLG_ERR_INVALID; }
+extern "C" int klg_synth_note_channels(const klg_synth* s) { return s ? s->note_ch : KLG_ERR_INVALID; }
 extern "C" size_t klg_synth_state_bytes(const klg_synth* s) { return s ? (size_t)s->W * 4 : 0; }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,7 +442,7 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 	if (s->graph) {                                       // hipRTC code object: klg_render<PatchGen, pv>
 		RenderArgs args = a;
 		void* params[] = { &args };
-		s->launch_error = hipModuleLaunchKernel(s->graph_fn[pv ? 1 : 0], (unsigned)render_grid(s), 1, 1, WG, 1, 1, render_lds_bytes(a.n), st, params, nullptr);
+		s->launch_error = hipModuleLaunchKernel(s->graph_fn[pv ? 1 : 0], (unsigned)render_grid(s), 1, 1, WG, 1, 1, render_lds_bytes(a.n, s->note_ch), st, params, nullptr);
 		return;
 	}
 	if (s->patch == KLG_PATCH_SUB2A && s->x2) {           // two voices per lane, packed fp32 (klg_render_x2.hpp)
@@ -813,7 +815,8 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	launch_render(s, a, per_voice, st);
 	if (s->launch_error != hipSuccess) { const hipError_t e = s->launch_error; s->launch_error = hipSuccess; return fail(KLG_ERR_HIP, "launching the compiled graph patch failed: %s", hipGetErrorString(e)); }
 	if (s->timing) { HIP_TRY(hipEventRecord(s->tev[2 * s->launches + 1], st)); s->launches++; }
-	hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
+	if (s->note_ch == 2) hipLaunchKernelGGL(klg_reduce_stereo, dim3((n + 31) / 32, 2), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
+	else hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
 	HIP_TRY(hipGetLastError());
 	s->stages_dirty = true;
 	return 0;
@@ -827,8 +830,8 @@ static int process_host(klg_synth* s, float* per_voice, float* const* out, int c
 		for (int i = 0; i < s->S; i++) for (int c = 0; c < s->nctl; c++) klg_set_control(s, i, c, parameters[(size_t)i * s->nctl + c]);
 	hipStream_t st = s->stream;
 	if (per_voice && !s->d_per_voice) {
-		HIP_TRY(hipMalloc(&s->d_per_voice, (size_t)s->V * s->max_block * 4));
-		HIP_TRY(hipHostMalloc(&s->h_per_voice, (size_t)s->V * s->max_block * 4));
+		HIP_TRY(hipMalloc(&s->d_per_voice, (size_t)s->V * s->max_block * 4 * s->note_ch));
+		HIP_TRY(hipHostMalloc(&s->h_per_voice, (size_t)s->V * s->max_block * 4 * s->note_ch));
 	}
 	bool replace = false;                                          // KLG_MIX_LAST_ACTIVE: a sounding note overwrites the caller's samples (klang.h:4299)
 	if (s->mix_mode == KLG_MIX_LAST_ACTIVE) {
@@ -838,14 +841,14 @@ static int process_host(klg_synth* s, float* per_voice, float* const* out, int c
 	HIP_TRY(hipMemsetAsync(s->d_mix, 0, (size_t)2 * n * 4, st));
 	if (int rc = enqueue_block(s, s->d_mix, n, per_voice != nullptr, st)) return rc;
 	HIP_TRY(hipMemcpyAsync(s->h_mix, s->d_mix, (size_t)2 * n * 4, hipMemcpyDeviceToHost, st));
-	if (per_voice) HIP_TRY(hipMemcpyAsync(s->h_per_voice, s->d_per_voice, (size_t)s->V * n * 4, hipMemcpyDeviceToHost, st));
+	if (per_voice) HIP_TRY(hipMemcpyAsync(s->h_per_voice, s->d_per_voice, (size_t)s->V * n * 4 * s->note_ch, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	if (out) for (int c = 0; c < channels; c++) {
 		float* dst = out[c]; const float* src = s->h_mix + (size_t)c * n;
 		if (replace) std::memcpy(dst, src, (size_t)n * 4);
 		else if (s->mix_mode != KLG_MIX_LAST_ACTIVE) for (int i = 0; i < n; i++) dst[i] += src[i];
 	}
-	if (per_voice) std::memcpy(per_voice, s->h_per_voice, (size_t)s->V * n * 4);
+	if (per_voice) std::memcpy(per_voice, s->h_per_voice, (size_t)s->V * n * 4 * s->note_ch);
 	// (the note stages come back when somebody asks — klg_note_on's assign(), klg_voice_stages: refresh_stages() — not 4 bytes per voice
 	//  over PCIe after every block: a block's host traffic is its 2 KiB of mix)
 	if (parameters && s->nctl)                                   // sync update out (klang.h:4854-4857)
@@ -860,7 +863,7 @@ static int multi_render(klg_synth* r, int n, bool per_voice) {
 	Multi& m = *r->multi;
 	for (size_t i = 0; i < m.shard.size(); i++) {
 		const int rc = on_shard(r, i, [&](klg_synth* sh) -> int {
-			if (per_voice && !sh->d_per_voice) { HIP_TRY(hipMalloc(&sh->d_per_voice, (size_t)sh->V * sh->max_block * 4)); HIP_TRY(hipHostMalloc(&sh->h_per_voice, (size_t)sh->V * sh->max_block * 4)); }
+			if (per_voice && !sh->d_per_voice) { HIP_TRY(hipMalloc(&sh->d_per_voice, (size_t)sh->V * sh->max_block * 4 * sh->note_ch)); HIP_TRY(hipHostMalloc(&sh->h_per_voice, (size_t)sh->V * sh->max_block * 4 * sh->note_ch)); }
 			// a shard's block buffer is free again once the previous block has been combined (and, for shard 0, handed to the caller)
 			if (m.have_combined) HIP_TRY(hipStreamWaitEvent(sh->stream, m.combined, 0));
 			if (i == 0 && m.have_consumed) HIP_TRY(hipStreamWaitEvent(sh->stream, m.consumed, 0));
@@ -905,9 +908,9 @@ static int multi_process_host(klg_synth* r, float* per_voice, float* const* out,
 	for (size_t i = 0; i < m.shard.size(); i++) {
 		const int rc = on_shard(r, i, [&](klg_synth* sh) -> int {
 			if (i == 0) HIP_TRY(hipMemcpyAsync(sh->h_mix, sh->d_mix, (size_t)2 * n * 4, hipMemcpyDeviceToHost, sh->stream));
-			if (per_voice) HIP_TRY(hipMemcpyAsync(sh->h_per_voice, sh->d_per_voice, (size_t)sh->V * n * 4, hipMemcpyDeviceToHost, sh->stream));
+			if (per_voice) HIP_TRY(hipMemcpyAsync(sh->h_per_voice, sh->d_per_voice, (size_t)sh->V * n * 4 * sh->note_ch, hipMemcpyDeviceToHost, sh->stream));
 			HIP_TRY(hipStreamSynchronize(sh->stream));
-			if (per_voice) std::memcpy(per_voice + v0 * (size_t)n, sh->h_per_voice, (size_t)sh->V * n * 4);
+			if (per_voice) std::memcpy(per_voice + v0 * (size_t)n * sh->note_ch, sh->h_per_voice, (size_t)sh->V * n * 4 * sh->note_ch);
 			return 0;                                                   // (the note stages stay on the device until asked for: refresh_stages)
 		});
 		if (rc) return rc;

@@ -32,7 +32,7 @@ inline std::string fmt(const char* f, ...) {
 // Can this program run two voices per lane?  Only node kinds / ops that have packed forms in klg_device_x2.hpp.
 inline bool x2_eligible(const Program& g) {
 	using namespace graph;
-	if (g.channels || g.prepare_ops) return false;
+	if (g.channels || g.prepare_ops || g.stereo_note()) return false;
 	for (int k : g.nodes) if (!(k == N_FSINE || k == N_SAW || k == N_PULSE || k == N_LPF || k == N_ENV || k == N_ADSR || k == N_PARAM)) return false;
 	for (const Op& o : g.ops) switch (o.code) {
 		case OP_CONST: case OP_CTL: case OP_PARAM: case OP_OSC: case OP_LPF: case OP_ENV: case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_NEG:
@@ -353,7 +353,11 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	else {
 		const std::string ctx = x2 ? "BlockCtx2" : "BlockCtx";
 		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const " + ctx + "& c) {\n\t\tL.stage = to_i(r.w[0] & 3u); L.tinc = c.fs.timeInc;\n" + begin + "\t}\n";
-		s += "\tstatic __device__ __forceinline__ " + TF + " sample(Live& L, const " + ctx + "& c) {\n" + body + fmt("\t\treturn r%d;\n\t}\n", g.ret);
+		// a Stereo::Note returns both channels of its `out` (klang.h:4721-4733)
+		const bool st = g.stereo_note();
+		const std::string RT = st ? "Out2" : TF, retline = st ? fmt("\t\treturn Out2{ r%d, r%d };\n\t}\n", g.ret, g.ret_r) : fmt("\t\treturn r%d;\n\t}\n", g.ret);
+		if (st) s += "\tstatic constexpr bool kStereo = true;\n";
+		s += "\tstatic __device__ __forceinline__ " + RT + " sample(Live& L, const " + ctx + "& c) {\n" + body + retline;
 		{
 			// the same body with every ADSR holding (adsr_hold): what the render kernel runs for a chunk when quiet() says every envelope
 			// of the wave only has its Sustain clock to advance.  (Envelope nodes have no such form: their patches never are quiet; a
@@ -396,8 +400,8 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			if (glide) s += "\tstatic __device__ __forceinline__ int quiet(Live& L) {\n\t\tbool safe = true;\n" + glide_test + "\t\tif (__ballot(L.stage != (int)ST_OFF && !safe) != 0ull) return 0;\n\t\treturn (true" + d0_test + ") ? 2 : 1;\n\t}\n";
 			else if (x2) s += "\tstatic __device__ __forceinline__ int quiet(const Live& L) {\n\t\t(void)L; const i2 q = (i2)(-1)" + (quiet ? quiet_test : std::string("")) + ";\n\t\tif (__ballot((q.x & q.y) == 0) != 0ull) return 0;\n\t\treturn (true" + d0_test + ") ? 2 : 1;\n\t}\n";
 			else s += "\tstatic __device__ __forceinline__ int quiet(const Live& L) {\n\t\t(void)L; const bool q = true" + (quiet ? quiet_test : std::string("")) + ";\n\t\tif (__ballot(!q) != 0ull) return 0;\n\t\treturn (true" + d0_test + ") ? 2 : 1;\n\t}\n";
-			s += "\tstatic __device__ __forceinline__ " + TF + " sample_quiet(Live& L, const " + ctx + "& c) {\n" + (quiet ? qbody : body) + fmt("\t\treturn r%d;\n\t}\n", g.ret);
-			s += "\tstatic __device__ __forceinline__ " + TF + " sample_fast(Live& L, const " + ctx + "& c) {\n" + (quiet ? fbody : body) + fmt("\t\treturn r%d;\n\t}\n", g.ret);
+			s += "\tstatic __device__ __forceinline__ " + RT + " sample_quiet(Live& L, const " + ctx + "& c) {\n" + (quiet ? qbody : body) + retline;
+			s += "\tstatic __device__ __forceinline__ " + RT + " sample_fast(Live& L, const " + ctx + "& c) {\n" + (quiet ? fbody : body) + retline;
 		}
 		std::string stage_expr = "L.stage";
 		for (const std::string& t : stop_at_end) stage_expr = t + stage_expr + ")";
@@ -443,7 +447,8 @@ struct Rtc {
 	}
 };
 
-struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; long long ring_rows = 0; int noise_calls = 0; struct Smooth { int word, ctl, calls; }; std::vector<Smooth> smooths; int ctlvar_word[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };   // ctlvar_word[i]: the record word of control i's own copy (an effect that writes it), else -1
+struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; int note_channels = 1;   // note_channels: 2 = the notes' `out` is stereo (ret2 in a note program)
+	 long long ring_rows = 0; int noise_calls = 0; struct Smooth { int word, ctl, calls; }; std::vector<Smooth> smooths; int ctlvar_word[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };   // ctlvar_word[i]: the record word of control i's own copy (an effect that writes it), else -1
 	 bool x2 = false; std::vector<std::pair<long long, int>> delays; };   // delays: (first ring row, SIZE) of each delay node in node order   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
 
 // directory holding klg_kernels.hpp etc.: next to the shared library (klang_amd/csrc), or $KLG_GRAPH_SRC
@@ -474,7 +479,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	if (!rtc.load()) return rtc.error;
 	Compiled c;
 	c.source = generate_source(g, x2);
-	c.words = g.words(); c.channels = g.channels; c.x2 = x2;
+	c.words = g.words(); c.channels = g.channels; c.x2 = x2; c.note_channels = g.stereo_note() ? 2 : 1;
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY || g.nodes[i] == graph::N_NDELAY) { c.delays.push_back({ c.ring_rows, g.arg((int)i) }); c.ring_rows += g.arg((int)i); }
 	c.noise_calls = g.noise_calls();
 	for (const graph::Op& o : g.ops) if (o.code == graph::OP_SETCTL) c.ctlvar_word[o.imm & 7u] = g.node_word0(o.node);

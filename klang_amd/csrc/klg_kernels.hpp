@@ -11,7 +11,11 @@
 //                        WAVES x n floats, so only the wave itself ever touches its row: no atomics, a fixed order).  The
 //                        workgroup then adds its four rows in wave order and writes its partial [n] row: the mix is
 //                        bit-reproducible from run to run.
-//   klg_reduce           partial rows -> the stereo block (ADDED to the destination, like the reference's `+=`).
+//                        A patch whose notes have a STEREO `out` (P::kStereo, Stereo::Note klang.h:4721-4733) renders the same way with
+//                        two samples per voice and sample: the tile's 32 rows are 16 samples x 2 channels, every wave owns two mix
+//                        rows, a workgroup writes two partial rows, per-voice output is [voice][2][n].
+//   klg_reduce           partial rows -> the stereo block (ADDED to the destination, like the reference's `+=`); klg_reduce_stereo
+//                        for banks of stereo notes (left rows to the left channel, right rows to the right).
 //
 // Workgroups are independent (no inter-workgroup communication inside a launch); groups of 256 voices are dealt
 // round-robin to workgroups (group g -> block g % gridDim.x), which with the observed block->XCD mapping spreads
@@ -58,10 +62,10 @@ __device__ __forceinline__ void wave_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Dynamic LDS of the render kernels: [WAVES][n] floats, one mix row per wave (render_lds_bytes(n) at launch).
+// Dynamic LDS of the render kernels: [WAVES][n] floats, one mix row per wave (render_lds_bytes(n) at launch); [WAVES][2][n] for stereo notes.
 extern __shared__ float klg_mix_rows[];
 __device__ __forceinline__ float mix_rows_sum(int i, int n) { return ((klg_mix_rows[i] + klg_mix_rows[n + i]) + klg_mix_rows[2 * n + i]) + klg_mix_rows[3 * n + i]; }   // fixed order
-__host__ __device__ inline unsigned render_lds_bytes(int n) { return (unsigned)(WAVES * n * sizeof(float)); }
+__host__ __device__ inline unsigned render_lds_bytes(int n, int note_channels = 1) { return (unsigned)(WAVES * n * note_channels * sizeof(float)); }
 
 // records longer than 64 words (generated graph patches, klg_graph.hpp) name their second store mask kStoreMask2
 template<class...> using klg_void_t = void;
@@ -79,17 +83,23 @@ template<class P> struct WavesPerEu<P, klg_void_t<decltype(P::kWavesPerEu)>> { s
 template<class P, class = void> struct HasQuiet { static constexpr bool value = false; };
 template<class P> struct HasQuiet<P, klg_void_t<decltype(P::kHasQuiet)>> { static constexpr bool value = P::kHasQuiet; };
 
+// a patch whose sample() returns both channels of a Stereo::Note's `out` (Out2): `static constexpr bool kStereo = true`
+template<class P, class = void> struct IsStereo { static constexpr bool value = false; };
+template<class P> struct IsStereo<P, klg_void_t<decltype(P::kStereo)>> { static constexpr bool value = P::kStereo; };
+
 template<class P, bool PER_VOICE>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P>::lo, WavesPerEu<P>::hi))) void klg_render(const RenderArgs a) {
 	using Rec = typename P::Rec;
+	constexpr bool ST = IsStereo<P>::value;                  // stereo notes: tile rows = (channel, sample of a 16-sample chunk)
+	constexpr int NC = ST ? 2 : 1, CH = ST ? CHUNK / 2 : CHUNK;
 	constexpr int W = sizeof(Rec) / 4;
 	__shared__ float lds[WAVES * CHUNK * TILE_LD];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	float* tile = lds + wave * CHUNK * TILE_LD;
 	const int n = a.n;
-	float* acc = klg_mix_rows + wave * n;                    // this wave's own mix row
+	float* acc = klg_mix_rows + wave * n * NC;               // this wave's own mix row(s): [channel][n]
 
-	for (int i = lane; i < n; i += 64) acc[i] = 0.f;
+	for (int i = lane; i < n * NC; i += 64) acc[i] = 0.f;
 	wave_sync();
 
 	const int groups = (int)(a.stride / WG);
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 			if (PER_VOICE) {
 				const int v0 = g * WG + wave * 64;
 				for (int j = 0; j < 64 && v0 + j < a.voices; j++)
-					for (int i = lane; i < n; i += 64) a.per_voice[(size_t)(v0 + j) * n + i] = 0.f;
+					for (int i = lane; i < n * NC; i += 64) a.per_voice[(size_t)(v0 + j) * n * NC + i] = 0.f;
 			}
 			continue;
 		}
@@ -127,38 +137,41 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		for (int w = 1; w < W; w++) rw.w[w] = live ? a.state[(size_t)w * a.stride + v] : 0u;
 		rw.to(rec);
 		P::begin(L, rec, ctx);
-		for (int c0 = 0; c0 < n; c0 += CHUNK) {
-			const int cl = (n - c0 < CHUNK) ? (n - c0) : CHUNK;
+		for (int c0 = 0; c0 < n; c0 += CH) {
+			const int cl = (n - c0 < CH) ? (n - c0) : CH;
 			int quiet = 0;                                          // 0: full body, 1: envelopes holding, 2: ... and duty-0 saws (generated patches)
 			if constexpr (HasQuiet<P>::value) quiet = P::quiet(L);
+			// one sample into the tile: row s (mono) / rows s and CH + s (stereo: left, right)
+			auto put = [&](int s, const auto y) {
+				if constexpr (ST) { tile[s * TILE_LD + lane] = in_tile ? y.l : 0.f; tile[(CH + s) * TILE_LD + lane] = in_tile ? y.r : 0.f; }
+				else tile[s * TILE_LD + lane] = in_tile ? y : 0.f;
+			};
 			if (quiet == 2) {
 				if constexpr (HasQuiet<P>::value)
-					for (int s = 0; s < cl; s++) { const float y = P::sample_fast(L, ctx); tile[s * TILE_LD + lane] = in_tile ? y : 0.f; }
+					for (int s = 0; s < cl; s++) put(s, P::sample_fast(L, ctx));
 			}
 			else if (quiet == 1) {
 				if constexpr (HasQuiet<P>::value)
-					for (int s = 0; s < cl; s++) { const float y = P::sample_quiet(L, ctx); tile[s * TILE_LD + lane] = in_tile ? y : 0.f; }
+					for (int s = 0; s < cl; s++) put(s, P::sample_quiet(L, ctx));
 			}
-			else for (int s = 0; s < cl; s++) {
-				const float y = P::sample(L, ctx);
-				tile[s * TILE_LD + lane] = in_tile ? y : 0.f;
-			}
+			else for (int s = 0; s < cl; s++) put(s, P::sample(L, ctx));
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			// lane -> (tile row r, half h of the 64 voices); row r holds sample s of channel c
+			const int r = lane & 31, h = lane >> 5, s = ST ? (r & (CH - 1)) : r, c = ST ? (r >> 4) : 0;
+			static_assert(!ST || CH == 16, "stereo rows are addressed as channel = row >> 4");
 			if (PER_VOICE) {
 				const int v0 = g * WG + wave * 64;
-				const int s = lane & 31, h = lane >> 5;
 				for (int j = 0; j < 32; j++) {
 					const int jj = 2 * j + h;
-					if (s < cl && v0 + jj < a.voices) a.per_voice[(size_t)(v0 + jj) * n + c0 + s] = tile[s * TILE_LD + jj];
+					if (s < cl && v0 + jj < a.voices) a.per_voice[((size_t)(v0 + jj) * NC + c) * n + c0 + s] = tile[r * TILE_LD + jj];
 				}
 			}
 			{
-				const int s = lane & 31, h = lane >> 5;
 				float sum = 0.f;
 				if (s < cl) {
-					const float* row = tile + s * TILE_LD + h * 32;
+					const float* row = tile + r * TILE_LD + h * 32;
 					if (PER_VOICE && a.solo) { for (int j = 0; j < 32; j++) sum += ((heard >> (h * 32 + j)) & 1ull) ? row[j] : 0.f; }
 					else {
 #pragma unroll
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 					}
 				}
 				sum += __shfl_xor(sum, 32);
-				if (lane < cl) acc[c0 + lane] += sum;               // the wave's own row: program order, no atomics
+				if (lane < 32 && s < cl) acc[c * n + c0 + s] += sum;    // the wave's own row(s): program order, no atomics
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
@@ -181,7 +194,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		}
 	}
 	__syncthreads();
-	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = mix_rows_sum(i, n);
+	// one partial row per workgroup ([2][n] for stereo notes: the waves' rows are [channel][n], so element i of a wave's block is the same (channel, sample) in all four)
+	for (int i = tid; i < n * NC; i += WG) a.partials[(size_t)blockIdx.x * n * NC + i] = mix_rows_sum(i, n * NC);
 }
 
 // KLG_MIX_LAST_ACTIVE: the highest-numbered sounding note of every synth instance (the one whose block survives in the reference's
@@ -212,6 +226,27 @@ __global__ __launch_bounds__(1024) void klg_reduce(const float* __restrict__ par
 #pragma unroll
 		for (int k = 0; k < 32; k++) t += part[k][sl];
 		for (int c = 0; c < channels; c++) mix[(size_t)c * n + s] += t;
+	}
+}
+
+// banks of stereo notes: partial rows [rows][2][n] -> mix[c][i] += sum of channel c's rows (`buffer++ += out` on an {l, r} frame, klang.h:4731);
+// with channels == 1 (a mono destination) only the left rows are taken
+__global__ __launch_bounds__(1024) void klg_reduce_stereo(const float* __restrict__ partials, int rows, int n, float* mix, int channels) {
+	__shared__ float part[32][33];
+	const int sl = threadIdx.x & 31, p = threadIdx.x >> 5;
+	const int s = blockIdx.x * 32 + sl, c = blockIdx.y;
+	float sum = 0.f;
+	if (s < n) {
+#pragma unroll 8
+		for (int r = p; r < rows; r += 32) sum += partials[((size_t)r * 2 + c) * n + s];
+	}
+	part[p][sl] = sum;
+	__syncthreads();
+	if (p == 0 && s < n && c < channels) {
+		float t = 0.f;
+#pragma unroll
+		for (int k = 0; k < 32; k++) t += part[k][sl];
+		mix[(size_t)c * n + s] += t;
 	}
 }
 

@@ -19,6 +19,9 @@ namespace klg {
 // record layouts: include/klang_mi355_records.h (shared with the host side and the DSL header)
 
 // Per-block view every patch body gets.
+// a Stereo::Note's sample (klang.h:4721-4733: `out` is a stereo signal, `buffer++ += out`): what sample() of a patch with kStereo returns
+struct Out2 { float l, r; };
+
 struct BlockCtx {
 	SampleRate fs;
 	const float* ctl;        // this voice's synth instance controls [KLG_MAX_CTL]

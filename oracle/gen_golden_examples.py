@@ -95,6 +95,11 @@ def scenarios():
     out["own_hardsync"] = poly("own_hardsync", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.7), (20, 0, 0.0)])
     # vibstring.k: Delay::set(time) with a recorded time EVERY sample in a Note (the read head's position and fraction are written back)
     out["own_vibstring"] = poly("own_vibstring", 48, [0, 1, 7, 8, 47], off_base=10, notes=16, ctl_events=[(12, 0, 0.98), (20, 1, 0.03)])
+    # TRUE stereo notes (Stereo::Note, klang.h:4721-4733: `out` is {l, r}, `buffer++ += out`): per-voice output per channel.
+    # stereo_note.k writes out.l / out.r differently from a pan param set in on() and two controls; synthx_shape.k is the note shape of
+    # examples/SynTHX.k (detuned saw partials, each on ONE channel drawn with random() in on() -> seeded note-ons)
+    out["own_stereo_note"] = poly("own_stereo_note", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 1, 0.2)])
+    out["own_synthx_shape"] = poly("own_synthx_shape", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, seeded=True, ctl=[(0, 0.02), (1, 0.015)], ctl_events=[(10, 1, 0.3)])
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],
@@ -104,7 +109,7 @@ def scenarios():
         s = Scenario(patch=src.patch, block=256, blocks=24, synths=1, notes=src.notes, dump=[0, 23])
         for i, v in solo_ctl.get(name, []):
             s.ctl.append((i, float(np.float32(v))))
-        s.on(0, 0, 100 if name in ("ex_nyquist", "ex_square") else 57, 0.8, 4242 if name == "ex_expression" else -1)
+        s.on(0, 0, 100 if name in ("ex_nyquist", "ex_square") else 57, 0.8, 4242 if name in ("ex_expression", "own_synthx_shape") else -1)
         s.off(14, 0, 100 if name in ("ex_nyquist", "ex_square") else 57, 0.0)
         out[name + "_solo"] = s
     return out

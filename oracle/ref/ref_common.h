@@ -27,6 +27,8 @@
 //   float32 [ndump][V][N]   per-voice block output (zeros for Off voices)
 //   float32 [B][2][N]       stereo mix = fp32 sum over voices in index order
 //   uint8   [B][V]          NoteBase::stage after each block
+// Synths whose notes have a STEREO `out` (Stereo::Note, klang.h:4721-4733; run_synth<.., 2>): magic 'KLGS' and
+//   float32 [ndump][V][2][N] per-voice block output, left then right; the mix sums each channel over the voices
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -93,6 +95,7 @@ static inline float ref_fx_input(unsigned seed, unsigned instance, unsigned ch, 
 
 // NOTE_KIND: 0 = klang::Note (mono, process(buffer) overwrites),
 //            1 = Stereo::Mono::Note (process(Stereo::buffer) accumulates L and R)
+//            2 = Stereo::Note with a stereo `out` (process(Stereo::buffer): `buffer++ += out`, klang.h:4727-4733)
 template<class SYNTH, int NOTE_KIND>
 static int run_synth(const RefScenario& s, const char* outpath) {
 	klang::fs = klang::SampleRate(s.fs);   // fs is static per TU (klang.h:1593-1604)
@@ -107,10 +110,11 @@ static int run_synth(const RefScenario& s, const char* outpath) {
 
 	FILE* out = fopen(outpath, "wb");
 	if (!out) return 3;
-	const int hdr[5] = { 0x4F474C4B, V, N, (int)s.dump.size(), B };
+	constexpr int NC = NOTE_KIND == 2 ? 2 : 1;              // channels of a voice's own output
+	const int hdr[5] = { NOTE_KIND == 2 ? 0x53474C4B : 0x4F474C4B, V, N, (int)s.dump.size(), B };
 	fwrite(hdr, sizeof(int), 5, out);
 
-	std::vector<float> voice((size_t)V * N), mix((size_t)B * 2 * N, 0.f), tmpL(N), tmpR(N);
+	std::vector<float> voice((size_t)V * N * NC), mix((size_t)B * 2 * N, 0.f), tmpL(N), tmpR(N);
 	std::vector<unsigned char> stages((size_t)B * V);
 
 	size_t evi = 0;
@@ -128,7 +132,7 @@ static int run_synth(const RefScenario& s, const char* outpath) {
 		for (int v = 0; v < V; v++) {
 			SYNTH* sy = synths[v / P];
 			auto* note = sy->notes[v % P];
-			float* dst = &voice[(size_t)v * N];
+			float* dst = &voice[(size_t)v * N * NC];
 			if (note->stage != SYNTH::Note::Off) {
 				klang::Debug::Session session(nullptr, N, klang::Debug::Buffer::Synth);
 				bool alive;
@@ -143,9 +147,10 @@ static int run_synth(const RefScenario& s, const char* outpath) {
 					klang::Stereo::buffer st(left, right);
 					alive = note->process(st);
 					for (int i = 0; i < N; i++) dst[i] = tmpL[i];   // Mono::Note writes L == R
+					if constexpr (NOTE_KIND == 2) for (int i = 0; i < N; i++) dst[N + i] = tmpR[i];
 				}
 				if (!alive) note->stop();
-				for (int i = 0; i < N; i++) { mixL[i] += dst[i]; mixR[i] += dst[i]; }
+				for (int i = 0; i < N; i++) { mixL[i] += dst[i]; mixR[i] += dst[(NC - 1) * N + i]; }
 			}
 			stages[(size_t)b * V + v] = (unsigned char)note->stage;
 		}

@@ -14,7 +14,10 @@ int main(int argc, char** argv) {
 	if (argc < 3) { fprintf(stderr, "usage: %s scenario out.bin\n", argv[0]); return 1; }
 	RefScenario s;
 	if (!ref_load(argv[1], s)) return 1;
-	if (s.patch == EXAMPLE_NAME) return run_synth<EXAMPLE_TYPE, 0>(s, argv[2]);
+#ifndef EXAMPLE_NOTE_KIND
+#define EXAMPLE_NOTE_KIND 0        // 2: the patch's notes are Stereo::Notes with a stereo `out` (ref_common.h)
+#endif
+	if (s.patch == EXAMPLE_NAME) return run_synth<EXAMPLE_TYPE, EXAMPLE_NOTE_KIND>(s, argv[2]);
 	fprintf(stderr, "unknown patch %s\n", s.patch.c_str());
 	return 1;
 }

@@ -1,6 +1,8 @@
 // tests/cpp/facade_scenario.cpp — drives a .k patch THROUGH THE DSL FAÇADE (include/klang/klang.h): the patch's own
 // on()/off() run on the host, blocks are rendered by libklang_mi355.so.  Reads a scenario (tests/scenario_io.py format,
 // one synth instance), writes the stereo mix per block + note stages:  int32 'KLGM', N, B, P ; float32 [B][2][N] ; uint8 [B][P]
+// and, built with -DDUMP_VOICES=<channels of a note's out>, every voice's own block of the scenario's dump blocks:
+// int32 ndump, NC ; float32 [ndump][P][NC][N]
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -18,7 +20,7 @@ int main(int argc, char** argv) {
 	if (argc < 3) { std::fprintf(stderr, "usage: %s scenario out.bin\n", argv[0]); return 1; }
 	FILE* f = std::fopen(argv[1], "r");
 	if (!f) return 1;
-	char tok[64]; int ver; float fsr = 48000.f; int block = 256, blocks = 1, notes = 1; std::vector<Ev> ev; std::vector<std::pair<int, float>> ctl;
+	char tok[64]; int ver; float fsr = 48000.f; int block = 256, blocks = 1, notes = 1; std::vector<Ev> ev; std::vector<int> dump; std::vector<std::pair<int, float>> ctl;
 	if (std::fscanf(f, "%63s %d", tok, &ver) != 2) return 1;
 	while (std::fscanf(f, "%63s", tok) == 1) {
 		std::string t(tok); int k; 
@@ -29,7 +31,7 @@ int main(int argc, char** argv) {
 		else if (t == "blocks") (void)!std::fscanf(f, "%d", &blocks);
 		else if (t == "synths") (void)!std::fscanf(f, "%d", &k);
 		else if (t == "notes") (void)!std::fscanf(f, "%d", &notes);
-		else if (t == "dump") { (void)!std::fscanf(f, "%d", &k); for (int i = 0; i < k; i++) { int d; (void)!std::fscanf(f, "%d", &d); } }
+		else if (t == "dump") { (void)!std::fscanf(f, "%d", &k); for (int i = 0; i < k; i++) { int d; (void)!std::fscanf(f, "%d", &d); dump.push_back(d); } }
 		else if (t == "ctl") { int i; float v; (void)!std::fscanf(f, "%d %f", &i, &v); ctl.push_back({ i, v }); }
 		else if (t == "ev") { Ev e; (void)!std::fscanf(f, "%d %d %d %f %f %ld", &e.block, &e.type, &e.synth, &e.a, &e.b, &e.seed); ev.push_back(e); }
 	}
@@ -40,6 +42,10 @@ int main(int argc, char** argv) {
 	const int N = block, B = blocks, P = (int)synth.notes.count;
 	std::vector<float> mix((size_t)B * 2 * N, 0.f);
 	std::vector<unsigned char> stages((size_t)B * P);
+#ifdef DUMP_VOICES
+	std::vector<float> pv((size_t)P * DUMP_VOICES * N), dumps;
+	synth.per_voice_sink = pv.data();
+#endif
 	size_t evi = 0;
 	for (int b = 0; b < B; b++) {
 		for (; evi < ev.size() && ev[evi].block <= b; evi++) {
@@ -61,10 +67,17 @@ int main(int argc, char** argv) {
 		synth.process(bufs, N);
 #endif
 		for (int p = 0; p < P; p++) stages[(size_t)b * P + p] = (unsigned char)synth.notes[p]->stage;
+#ifdef DUMP_VOICES
+		for (int d : dump) if (d == b) dumps.insert(dumps.end(), pv.begin(), pv.end());
+#endif
 	}
 	FILE* o = std::fopen(argv[2], "wb");
 	const int hdr[4] = { 0x4D474C4B, N, B, P };
 	std::fwrite(hdr, 4, 4, o); std::fwrite(mix.data(), 4, mix.size(), o); std::fwrite(stages.data(), 1, stages.size(), o);
+#ifdef DUMP_VOICES
+	const int vh[2] = { (int)(dumps.size() / pv.size()), DUMP_VOICES };
+	std::fwrite(vh, 4, 2, o); std::fwrite(dumps.data(), 4, dumps.size(), o);
+#endif
 	std::fclose(o);
 	return 0;
 }

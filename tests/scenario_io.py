@@ -104,6 +104,11 @@ def load_ref_output(path):
         mix = np.frombuffer(d, dtype=np.float32, count=B * 2 * N, offset=o).reshape(B, 2, N); o += B * 2 * N * 4
         st = np.frombuffer(d, dtype=np.uint8, count=B * V, offset=o).reshape(B, V)
         return dict(per_voice=pv, mix=mix, stages=st)
+    if magic == 0x53474C4B:      # 'KLGS' synth of stereo notes: per-voice output per channel
+        pv = np.frombuffer(d, dtype=np.float32, count=nd * V * 2 * N, offset=o).reshape(nd, V, 2, N); o += nd * V * 2 * N * 4
+        mix = np.frombuffer(d, dtype=np.float32, count=B * 2 * N, offset=o).reshape(B, 2, N); o += B * 2 * N * 4
+        st = np.frombuffer(d, dtype=np.uint8, count=B * V, offset=o).reshape(B, V)
+        return dict(per_voice=pv, mix=mix, stages=st)
     if magic == 0x46474C4B:      # 'KLGF' effect
         pv = np.frombuffer(d, dtype=np.float32, count=nd * V * 2 * N, offset=o).reshape(nd, V, 2, N)
         return dict(per_voice=pv)

@@ -24,6 +24,18 @@ def run_facade(binary, scenario, tmp_path):
     return mix, stages
 
 
+def run_facade_voices(binary, scenario, tmp_path):
+    """a driver built with -DDUMP_VOICES: additionally every voice's own block ([dump][P][NC][N]) of the scenario's dump blocks"""
+    mix, stages = run_facade(binary, scenario, tmp_path)
+    d = open(tmp_path / "facade.bin", "rb").read()
+    B, _, N = mix.shape
+    P = stages.shape[1]
+    o = 16 + B * 2 * N * 4 + B * P
+    nd, NC = (int(x) for x in np.frombuffer(d, np.int32, 2, o))
+    pv = np.frombuffer(d, np.float32, nd * P * NC * N, o + 8).reshape(nd, P, NC, N)
+    return mix, stages, pv
+
+
 def check(mix, stages, scenario):
     ref = np.load(os.path.join(GOLDEN, scenario + ".npz"))
     assert np.array_equal(stages, ref["stages"]), "note stages (voice allocation / lifecycle) differ from the reference"
@@ -112,3 +124,47 @@ def test_recorded_graph_single_voice_is_bit_exact(name, tmp_path):
     assert np.array_equal(stages, ref["stages"])
     assert np.array_equal(mix.view(np.uint32), ref["mix"].view(np.uint32)), f"max abs err {np.abs(mix - ref['mix']).max()}"
     assert np.abs(mix).max() > 0
+
+
+# ---- TRUE stereo notes: Stereo::Note with `out` = {l, r}, `buffer++ += out` (klang.h:4721-4733) ----
+STEREO = ["own_stereo_note", "own_synthx_shape"]
+
+
+def stereo_binary(name):
+    path = os.path.join(ROOT, "tests", "cpp", "_bin", "facade_graph_" + name)
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    return path
+
+
+@pytest.mark.parametrize("name", STEREO)
+def test_stereo_note_single_voice_is_bit_exact_per_channel(name, tmp_path):
+    """One Stereo::Note held and released through Stereo::Synth::process(float**, int): left and right differ, and each equals the genuine
+    header's channel BIT FOR BIT — in the mix and in the voice's own [2][n] block (klg_process_voices of a stereo-note bank)."""
+    mix, stages, pv = run_facade_voices(stereo_binary(name), name + "_solo", tmp_path)
+    ref = np.load(os.path.join(GOLDEN, name + "_solo.npz"))
+    assert ref["per_voice"].ndim == 4 and ref["per_voice"].shape[2] == 2
+    assert np.array_equal(stages, ref["stages"])
+    assert np.array_equal(mix.view(np.uint32), ref["mix"].view(np.uint32)), f"max abs err {np.abs(mix - ref['mix']).max()}"
+    assert np.array_equal(pv.view(np.uint32), ref["per_voice"].view(np.uint32))
+    assert np.abs(mix[:, 0]).max() > 0 and np.abs(mix[:, 1]).max() > 0
+    assert not np.array_equal(mix[:, 0], mix[:, 1]), "a true stereo note: the channels must differ"
+
+
+@pytest.mark.parametrize("name", STEREO)
+def test_stereo_notes_polyphonic(name, tmp_path):
+    """20 note-ons on 16 slots (voice stealing), control changes mid-run: every voice's left and right block is bit-exact against the genuine
+    header, the note stages are equal, and each channel of the mix is the sum of ITS channel of the voices (1e-5: summation order)."""
+    mix, stages, pv = run_facade_voices(stereo_binary(name), name, tmp_path)
+    ref = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert np.array_equal(stages, ref["stages"])
+    assert np.array_equal(pv.view(np.uint32), ref["per_voice"].view(np.uint32)), f"per-voice max abs err {np.abs(pv - ref['per_voice']).max()}"
+    peak = float(np.max(np.abs(ref["per_voice"])))
+    V = ref["stages"].shape[1]
+    want = ref["mix"] if "mix" in ref else ref["mix_dump"]
+    got = mix if "mix" in ref else mix[ref["dump"]]
+    assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 1e-5 * peak * np.sqrt(V) * 4
+    # the channels are mixed separately: left = sum of the voices' left blocks (fp64 model of the dump blocks)
+    model = ref["per_voice"].astype(np.float64).sum(axis=1)                       # [dump][2][N]
+    assert float(np.max(np.abs(mix[ref["dump"]] - model))) <= 1e-5 * peak * np.sqrt(V) * 4
+    assert float(np.max(np.abs(model[:, 0] - model[:, 1]))) > 0.01 * peak
