@@ -27,7 +27,8 @@ using namespace klg;
 
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int g_device = -1;
+static int g_device = -1;                      // the DEFAULT GPU of this process (klg_init's first id, else 0).  A bank remembers the GPU it was created
+                                               // on (klg_synth::device / klg_fx::device); nothing below ever swaps this value around a call.
 
 static int fail(int code, const char* fmt, ...) {
 	char buf[512];
@@ -50,13 +51,32 @@ struct RandGuard {
 	~RandGuard() { if (prev) setstate(prev); }
 };
 
-int klg_ensure_device() {
-	if (g_device >= 0) { if (hipSetDevice(g_device) != hipSuccess) return fail(KLG_ERR_NO_DEVICE, "hipSetDevice(%d) failed", g_device); return 0; }
+// the default device, resolved once (-1 + error: no GPU, and no CPU fallback)
+static int default_device() {
+	if (g_device >= 0) return g_device;
 	int count = 0;
-	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
-		return fail(KLG_ERR_NO_DEVICE, "no HIP device visible: libklang_mi355 has no CPU fallback");
-	if (hipSetDevice(0) != hipSuccess) return fail(KLG_ERR_NO_DEVICE, "hipSetDevice(0) failed");
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { fail(KLG_ERR_NO_DEVICE, "no HIP device visible: libklang_mi355 has no CPU fallback"); return -1; }
 	g_device = 0;
+	return 0;
+}
+// Scoped device binding: every entry point that touches a bank makes the BANK's GPU current for the calling thread (hipSetDevice is
+// per thread) and puts back what the thread had on the way out — two banks on two GPUs may be driven from two host threads, and a
+// host that shares the process (torch, another library) finds its current device untouched.
+struct DeviceGuard {
+	int prev = -1; bool ok = true;
+	explicit DeviceGuard(int dev) {
+		if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+		if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+		if (!ok) fail(KLG_ERR_NO_DEVICE, "hipSetDevice(%d) failed", dev);
+	}
+	~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+	DeviceGuard(const DeviceGuard&) = delete; DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define KLG_BIND(handle) DeviceGuard klg_bound_((handle)->device); if (!klg_bound_.ok) return KLG_ERR_NO_DEVICE
+// entry points without a handle (klg_selftest): the default device becomes (and stays) current
+int klg_ensure_device() {
+	if (default_device() < 0) return KLG_ERR_NO_DEVICE;
+	if (hipSetDevice(g_device) != hipSuccess) return fail(KLG_ERR_NO_DEVICE, "hipSetDevice(%d) failed", g_device);
 	return 0;
 }
 
@@ -72,8 +92,7 @@ extern "C" int klg_init(const int* device_ids, int n_devices) {
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(KLG_ERR_NO_DEVICE, "no HIP device visible: libklang_mi355 has no CPU fallback");
 	for (int i = 0; i < n_devices; i++) if (device_ids[i] < 0 || device_ids[i] >= count) return fail(KLG_ERR_INVALID, "device id %d out of range (0..%d)", device_ids[i], count - 1);
-	if (hipSetDevice(device_ids[0]) != hipSuccess) return fail(KLG_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device_ids[0]);
-	g_device = device_ids[0];
+	g_device = device_ids[0];                                     // banks created from now on; existing banks stay where they are
 	g_devices.assign(device_ids, device_ids + n_devices);
 	return 0;
 }
@@ -149,6 +168,7 @@ struct klg_synth {
 	unsigned seq = 0;
 	uint32_t* record_sink = nullptr;             // klg_note_record
 	bool scripted = false;                       // a klg_script has played on this bank: note stages live on the device only
+	std::vector<struct klg_script*> scripts;     // the event scripts compiled for this bank: invalidated when the bank is destroyed
 	void* h_stage = nullptr; size_t h_stage_cap = 0;      // pinned
 	void* d_stage = nullptr; size_t d_stage_cap = 0;
 	hipEvent_t stage_done = nullptr;
@@ -215,15 +235,10 @@ struct Multi {
 __global__ void klg_add_block(float* dst, const float* src, int count) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < count) dst[i] += src[i]; }
 __global__ void klg_sub_block(float* dst, const float* src, int count) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < count) dst[i] -= src[i]; }
 
-// run `f` with shard i's device current (every single-device entry point binds to g_device)
+// run `f` with shard i's device current for this thread (the shard's own entry points bind themselves; the raw HIP calls inside `f` need it)
 template<class F> static auto on_shard(klg_synth* r, size_t i, F&& f) {
-	const int keep = g_device; const std::vector<int> keep_list = g_devices;
-	g_device = r->multi->shard[i]->device; g_devices.assign(1, g_device);
-	(void)hipSetDevice(g_device);
-	auto rc = f(r->multi->shard[i]);
-	g_device = keep; g_devices = keep_list;
-	(void)hipSetDevice(g_device);
-	return rc;
+	DeviceGuard bound(r->multi->shard[i]->device);
+	return f(r->multi->shard[i]);
 }
 static int shard_of_synth(const klg_synth* r, int synth, int* local) {
 	const Multi& m = *r->multi;
@@ -242,7 +257,7 @@ static void multi_free(klg_synth* r) {
 	delete m; r->multi = nullptr;
 	delete r;
 }
-// create: `make(synths)` is the ordinary single-device creator, run once per device with that device current
+// create: `make(device, synths)` is the ordinary single-device creator, run once per device of the list
 template<class MAKE> static klg_synth* multi_create(int synths, int notes_per_synth, int max_block, MAKE&& make) {
 	const std::vector<int> devs = g_devices;
 	const int n = (int)std::min<size_t>(devs.size(), (size_t)synths);
@@ -251,17 +266,12 @@ template<class MAKE> static klg_synth* multi_create(int synths, int notes_per_sy
 	Multi& m = *r->multi;
 	const int base = synths / n, extra = synths % n;                // contiguous ranges; the first `extra` shards own one instance more
 	m.first.push_back(0);
-	const int keep = g_device;
 	for (int i = 0; i < n; i++) {
 		const int count = base + (i < extra ? 1 : 0);
-		g_device = devs[(size_t)i]; g_devices.assign(1, g_device);
-		klg_synth* sh = hipSetDevice(g_device) == hipSuccess ? make(count) : nullptr;
-		g_device = keep; g_devices = devs;
-		if (!sh) { const std::string why = g_err; multi_free(r); (void)hipSetDevice(keep); fail(KLG_ERR_NOMEM, "multi-device bank: shard %d on device %d: %s", i, devs[(size_t)i], why.c_str()); return nullptr; }
-		sh->device = devs[(size_t)i];
+		klg_synth* sh = make(devs[(size_t)i], count);
+		if (!sh) { const std::string why = g_err; multi_free(r); fail(KLG_ERR_NOMEM, "multi-device bank: shard %d on device %d: %s", i, devs[(size_t)i], why.c_str()); return nullptr; }
 		m.shard.push_back(sh); m.first.push_back(m.first.back() + count);
 	}
-	(void)hipSetDevice(keep);
 	r->patch = m.shard[0]->patch; r->W = m.shard[0]->W; r->nctl = m.shard[0]->nctl; r->fs = m.shard[0]->fs; r->note_ch = m.shard[0]->note_ch;
 	bool distinct = true;
 	for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (devs[(size_t)i] == devs[(size_t)j]) distinct = false;
@@ -281,20 +291,22 @@ static int multi_process_device(klg_synth* r, float* d_mix, int n, void* hip_str
 
 enum { KLG_PATCH_GRAPH = 1000 };     // klg_synth::patch of a graph patch (not a klg_patch id)
 
-static klg_synth* synth_create_common(int patch_id, const PatchInfo* pi, int synths, int notes_per_synth, float sample_rate, int max_block) {
+static klg_synth* synth_create_common(int device, int patch_id, const PatchInfo* pi, int synths, int notes_per_synth, float sample_rate, int max_block) {
 	if (synths <= 0 || notes_per_synth <= 0 || notes_per_synth > 128) { fail(KLG_ERR_INVALID, "klg_synth_create: synths=%d notes_per_synth=%d (1..128, Array<NOTE*,128>)", synths, notes_per_synth); return nullptr; }
 	if (max_block <= 0 || max_block > MAX_BLOCK) { fail(KLG_ERR_INVALID, "klg_synth_create: max_block %d not in 1..%d", max_block, (int)MAX_BLOCK); return nullptr; }
 	if (!(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_synth_create: bad sample rate"); return nullptr; }
 	RandGuard rg;
-	if (klg_ensure_device()) return nullptr;
+	DeviceGuard bound(device);
+	if (!bound.ok) return nullptr;
 	klg_synth* s = new klg_synth();
+	s->device = device;
 	s->patch = patch_id; s->S = synths; s->P = notes_per_synth; s->V = synths * notes_per_synth; s->W = pi->words;
 	s->max_block = max_block; s->nctl = pi->ncontrols; s->note_ch = pi->note_channels == 2 ? 2 : 1;
 	s->stride = ((size_t)s->V + WG - 1) / WG * WG;
 	s->fs = host::Fs(sample_rate);
 	s->dfs.f = s->fs.f; s->dfs.w = s->fs.w; s->dfs.timeInc = 1.0f / s->fs.f;
 	hipDeviceProp_t prop;
-	bool ok = hipGetDeviceProperties(&prop, g_device) == hipSuccess;
+	bool ok = hipGetDeviceProperties(&prop, device) == hipSuccess;
 	const int groups = (int)(s->stride / WG);
 	s->grid = std::min(groups, (ok ? prop.multiProcessorCount : 256) * 8);   // 2 x the 4 resident workgroups per CU (LDS-limited); more groups are strided
 	ok = ok && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
@@ -341,15 +353,23 @@ static klg_synth* synth_create_common(int patch_id, const PatchInfo* pi, int syn
 extern "C" klg_synth* klg_synth_create(int patch_id, int synths, int notes_per_synth, float sample_rate, int max_block) {
 	const PatchInfo* pi = patch_info(patch_id);
 	if (!pi || pi->words == 0) { fail(KLG_ERR_INVALID, "klg_synth_create: patch %d is not a synth patch", patch_id); return nullptr; }
-	if (g_devices.size() > 1 && synths > 0) return multi_create(synths, notes_per_synth, max_block, [&](int count) { return klg_synth_create(patch_id, count, notes_per_synth, sample_rate, max_block); });
-	return synth_create_common(patch_id, pi, synths, notes_per_synth, sample_rate, max_block);
+	if (default_device() < 0) return nullptr;
+	if (g_devices.size() > 1 && synths > 0) return multi_create(synths, notes_per_synth, max_block, [&](int device, int count) { return synth_create_common(device, patch_id, pi, count, notes_per_synth, sample_rate, max_block); });
+	return synth_create_common(g_device, patch_id, pi, synths, notes_per_synth, sample_rate, max_block);
 }
 
 // replaces: constructing a user Synth whose Note::process() is NOT one of the shipped patch ids: the recorded body
 // (include/klang_mi355_graph.h) is compiled for gfx950 with hipRTC and rendered by the same klg_render kernel.
+static klg_synth* synth_create_graph_on(int device, const char* program, int synths, int notes_per_synth, float sample_rate, int max_block);
 extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, int notes_per_synth, float sample_rate, int max_block) {
-	if (g_devices.size() > 1 && synths > 0) return multi_create(synths, notes_per_synth, max_block, [&](int count) { return klg_synth_create_graph(program, count, notes_per_synth, sample_rate, max_block); });
-	RandGuard rg;                 // hipRTC / comgr draw temporary names from libc random(): the caller's klang::random(seed) stream must survive
+	if (default_device() < 0) return nullptr;
+	if (g_devices.size() > 1 && synths > 0) return multi_create(synths, notes_per_synth, max_block, [&](int device, int count) { return synth_create_graph_on(device, program, count, notes_per_synth, sample_rate, max_block); });
+	return synth_create_graph_on(g_device, program, synths, notes_per_synth, sample_rate, max_block);
+}
+static klg_synth* synth_create_graph_on(int device, const char* program, int synths, int notes_per_synth, float sample_rate, int max_block) {
+	RandGuard rg;
+	DeviceGuard bound(device);
+	if (!bound.ok) return nullptr;                 // hipRTC / comgr draw temporary names from libc random(): the caller's klang::random(seed) stream must survive
 	const graphrt::Compiled* c = nullptr;
 	graph::Program g;
 	{ const std::string perr = g.parse(program); if (!perr.empty()) { fail(KLG_ERR_INVALID, "klg_synth_create_graph: %s", perr.c_str()); return nullptr; } }
@@ -361,7 +381,6 @@ extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, in
 		const std::string err = graphrt::compile(program, &c, x2);
 		if (!err.empty()) { fail(KLG_ERR_INVALID, "klg_synth_create_graph: %s", err.c_str()); return nullptr; }
 		if (!x2) break;
-		if (klg_ensure_device()) return nullptr;
 		// worth it only for the smallest patches (tools/graph_width_bench.py, profiles/r01o_graph_width_bench.jsonl): one saw + biquad + ADSR
 		// (127-129 registers) gains 10 %, two saws (160) already lose 3 %, seven (296) lose 17 % — and a saw in its general form (duty != 0)
 		// loses 25 % even in the smallest.  Hence <= 130 registers; a patch of seven
@@ -379,7 +398,7 @@ extern "C" klg_synth* klg_synth_create_graph(const char* program, int synths, in
 	PatchInfo pi = {};
 	pi.words = c->words; pi.ncontrols = g.nctl; pi.note_channels = c->note_channels;
 	for (int i = 0; i < g.nctl; i++) pi.dials[i] = { g.dials[i].min, g.dials[i].max, g.dials[i].initial };
-	klg_synth* s = synth_create_common(KLG_PATCH_GRAPH, &pi, synths, notes_per_synth, sample_rate, max_block);
+	klg_synth* s = synth_create_common(device, KLG_PATCH_GRAPH, &pi, synths, notes_per_synth, sample_rate, max_block);
 	if (!s) return nullptr;
 	s->graph = c;
 	bool ok = hipModuleLoadData(&s->module, c->code.data()) == hipSuccess;
@@ -405,13 +424,14 @@ extern "C" int klg_graph_check(const char* program, int want_source, char* out, 
 	return err.empty() ? 0 : fail(KLG_ERR_INVALID, "klg_graph_check: %s", err.c_str());
 }
 
-extern "C" void klg_synth_destroy(klg_synth* s) { if (s && s->multi) { multi_free(s); return; } if (s && g_device >= 0) (void)hipSetDevice(g_device); synth_free(s); }
+static void scripts_invalidate(klg_synth* s);
+extern "C" void klg_synth_destroy(klg_synth* s) { if (!s) return; if (s->multi) { multi_free(s); return; } DeviceGuard bound(s->device); scripts_invalidate(s); synth_free(s); }
 extern "C" int klg_synth_voices_per_lane(const klg_synth* s) { if (!s) return KLG_ERR_INVALID; if (s->multi) return klg_synth_voices_per_lane(s->multi->shard[0]); return ((s->patch == KLG_PATCH_SUB2A && s->x2) || (s->graph && s->graph->x2)) ? 2 : 1; }
 // replaces: the voice loop of the MONO Synth::process(float*, int, float*) (klang.h:4450-4457), see include/klang_mi355.h
 extern "C" int klg_synth_set_mix_mode(klg_synth* s, int mode) {
 	if (!s || (mode != KLG_MIX_SUM && mode != KLG_MIX_LAST_ACTIVE)) return fail(KLG_ERR_INVALID, "klg_synth_set_mix_mode: bad handle or mode %d", mode);
 	if (s->multi) { for (size_t i = 0; i < s->multi->shard.size(); i++) if (int rc = on_shard(s, i, [&](klg_synth* sh) { return klg_synth_set_mix_mode(sh, mode); })) return rc; s->mix_mode = mode; return 0; }
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	KLG_BIND(s);
 	if (mode == KLG_MIX_LAST_ACTIVE && !s->d_solo) {
 		RandGuard rg;
 		HIP_TRY(hipStreamSynchronize(s->stream));
@@ -673,7 +693,7 @@ extern "C" int klg_note_on(klg_synth* s, int synth, int pitch, float velocity) {
 	if (!s || synth < 0 || synth >= s->S) return fail(KLG_ERR_INVALID, "klg_note_on: bad handle or synth index %d", synth);
 	if (s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); return on_shard(s, (size_t)i, [&](klg_synth* sh) { return klg_note_on(sh, ls, pitch, velocity); }); }
 	if (s->graph) return fail(KLG_ERR_INVALID, "klg_note_on: %s", kGraphEvents);
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	KLG_BIND(s);
 	if (int rc = refresh_stages(s)) return rc;
 	const int slot = synth_assign(s, synth);
 	const int voice = synth * s->P + slot;
@@ -825,7 +845,7 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 static int process_host(klg_synth* s, float* per_voice, float* const* out, int channels, int n, float* parameters) {
 	if (!s || n <= 0 || n > s->max_block) return fail(KLG_ERR_INVALID, "klg_process: n=%d not in 1..max_block", n);
 	if (out && (channels < 1 || channels > 2)) return fail(KLG_ERR_INVALID, "klg_process: channels must be 1 or 2");
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	KLG_BIND(s);
 	if (parameters && s->nctl)                                   // sync parameters in (klang.h:4836-4839)
 		for (int i = 0; i < s->S; i++) for (int c = 0; c < s->nctl; c++) klg_set_control(s, i, c, parameters[(size_t)i * s->nctl + c]);
 	hipStream_t st = s->stream;
@@ -968,7 +988,7 @@ extern "C" int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices) {
 		}
 		return 0;
 	}
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	KLG_BIND(s);
 	if (int rc = refresh_stages(s)) return rc;
 	for (int v = 0; v < n_voices; v++) stages[v] = s->voices[v].stage;
 	return 0;
@@ -977,13 +997,13 @@ extern "C" int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices) {
 extern "C" int klg_process_device(klg_synth* s, float* d_mix, int n, void* hip_stream) {
 	if (s && s->multi) return multi_process_device(s, d_mix, n, hip_stream);
 	if (!s || !d_mix || n <= 0 || n > s->max_block) return fail(KLG_ERR_INVALID, "klg_process_device: bad arguments (n=%d)", n);
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	KLG_BIND(s);
 	return enqueue_block(s, d_mix, n, false, hip_stream ? (hipStream_t)hip_stream : s->stream);
 }
 extern "C" int klg_sync(klg_synth* s) {
 	if (!s) return fail(KLG_ERR_INVALID, "klg_sync: NULL handle");
 	if (s->multi) { for (size_t i = 0; i < s->multi->shard.size(); i++) if (int rc = on_shard(s, i, [&](klg_synth* sh) { return klg_sync(sh); })) return rc; return 0; }
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	KLG_BIND(s);
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	HIP_TRY(hipDeviceSynchronize());
 	return 0;
@@ -992,7 +1012,7 @@ extern "C" int klg_sync(klg_synth* s) {
 extern "C" int klg_voice_download(klg_synth* s, int voice, void* state, size_t bytes) {
 	if (!s || !state || voice < 0 || voice >= s->V || bytes != (size_t)s->W * 4) return fail(KLG_ERR_INVALID, "klg_voice_download: bad arguments (record is %d bytes)", s ? s->W * 4 : 0);
 	if (s->multi) { int lv = 0; const int i = shard_of_voice(s, voice, &lv); return on_shard(s, (size_t)i, [&](klg_synth* sh) { return klg_voice_download(sh, lv, state, bytes); }); }
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	KLG_BIND(s);
 	if (int rc = flush_events(s, s->stream)) return rc;
 	hipLaunchKernelGGL(klg_copy_record, dim3(1), dim3(128), 0, s->stream, s->d_state, s->stride, voice, s->d_scratch_rec, s->W, 0);
 	HIP_TRY(hipMemcpyAsync(state, s->d_scratch_rec, bytes, hipMemcpyDeviceToHost, s->stream));
@@ -1002,7 +1022,7 @@ extern "C" int klg_voice_download(klg_synth* s, int voice, void* state, size_t b
 extern "C" int klg_voice_upload(klg_synth* s, int voice, const void* state, size_t bytes) {
 	if (!s || !state || voice < 0 || voice >= s->V || bytes != (size_t)s->W * 4) return fail(KLG_ERR_INVALID, "klg_voice_upload: bad arguments (record is %d bytes)", s ? s->W * 4 : 0);
 	if (s->multi) { int lv = 0; const int i = shard_of_voice(s, voice, &lv); return on_shard(s, (size_t)i, [&](klg_synth* sh) { return klg_voice_upload(sh, lv, state, bytes); }); }
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	KLG_BIND(s);
 	if (int rc = flush_events(s, s->stream)) return rc;
 	HIP_TRY(hipMemcpyAsync(s->d_scratch_rec, state, bytes, hipMemcpyHostToDevice, s->stream));
 	hipLaunchKernelGGL(klg_copy_record, dim3(1), dim3(128), 0, s->stream, s->d_state, s->stride, voice, s->d_scratch_rec, s->W, 1);
@@ -1035,6 +1055,7 @@ extern "C" int klg_voice_delay_clear(klg_synth* s, int voice, int delay_index) {
 	if (voice < 0 || voice >= s->V || delay_index < 0 || delay_index >= (int)s->graph->delays.size()) return fail(KLG_ERR_INVALID, "klg_voice_delay_clear: voice %d / delay %d out of range", voice, delay_index);
 	const long long row0 = s->graph->delays[(size_t)delay_index].first; const int size = s->graph->delays[(size_t)delay_index].second;
 	float* line = s->d_note_rings + (size_t)voice * (size_t)s->graph->ring_rows + (size_t)row0;
+	KLG_BIND(s);
 	HIP_TRY(hipMemsetAsync(line, 0, (size_t)size * sizeof(float), s->stream));
 	return 0;
 }
@@ -1056,6 +1077,7 @@ extern "C" int klg_table_upload(klg_synth* s, const float* samples, int n, int d
 	if (s->multi) { int id = -1; for (size_t i = 0; i < s->multi->shard.size(); i++) { id = on_shard(s, i, [&](klg_synth* sh) { return klg_table_upload(sh, samples, n, dedup); }); if (id < 0) return id; } return id; }   // the same tables in the same order on every device: one id
 	if (s->patch != KLG_PATCH_GRAPH) return fail(KLG_ERR_INVALID, "klg_table_upload: only graph banks (klg_synth_create_graph) read tables");
 	RandGuard rg;
+	KLG_BIND(s);
 	if (s->tables.empty()) { const float zero[2] = { 0.f, 0.f }; const int id0 = table_add(s, zero, 2); if (id0 < 0) return id0; }   // id 0: what an all-zero record reads
 	if (dedup) {
 		uint64_t h = 1469598103934665603ull;
@@ -1109,28 +1131,39 @@ extern "C" klg_script* klg_script_create(klg_synth* s, int blocks) {
 	if (s && s->multi) { fail(KLG_ERR_INVALID, "klg_script_create: event scripts are per device: create one bank + script per GPU (one process per GPU, as bench.py does)"); return nullptr; }
 	if (!s || blocks <= 0) { fail(KLG_ERR_INVALID, "klg_script_create: bad arguments"); return nullptr; }
 	klg_script* k = new klg_script(); k->s = s; k->blocks = blocks; k->ev.resize((size_t)blocks);
+	s->scripts.push_back(k);
 	return k;
+}
+// a bank that is destroyed takes its scripts' device arrays with it and leaves them INVALID (k->s == NULL): every later klg_script_* call on
+// such a handle fails with KLG_ERR_INVALID instead of touching freed state; klg_script_destroy() still releases the handle itself
+static void scripts_invalidate(klg_synth* s) {
+	for (klg_script* k : s->scripts) { if (k->d_index) (void)hipFree(k->d_index); if (k->d_pool) (void)hipFree(k->d_pool); k->d_index = nullptr; k->d_pool = nullptr; k->s = nullptr; }
+	s->scripts.clear();
 }
 extern "C" void klg_script_destroy(klg_script* k) {
 	if (!k) return;
-	if (k->d_index) (void)hipFree(k->d_index);
-	if (k->d_pool) (void)hipFree(k->d_pool);
+	if (k->s) {
+		DeviceGuard bound(k->s->device);
+		if (k->d_index) (void)hipFree(k->d_index);
+		if (k->d_pool) (void)hipFree(k->d_pool);
+		auto& v = k->s->scripts; v.erase(std::remove(v.begin(), v.end(), k), v.end());
+	}
 	delete k;
 }
 extern "C" int klg_script_add_record(klg_script* k, const void* record, size_t bytes) {
-	if (!k || !record || k->committed || bytes != (size_t)k->s->W * 4) return fail(KLG_ERR_INVALID, "klg_script_add_record: bad arguments (record is %d bytes) or script already committed", k ? k->s->W * 4 : 0);
+	if (!k || !k->s || !record || k->committed || bytes != (size_t)k->s->W * 4) return fail(KLG_ERR_INVALID, "klg_script_add_record: bad arguments (record is %d bytes), script already committed, or its bank was destroyed", k && k->s ? k->s->W * 4 : 0);
 	const uint32_t* w = (const uint32_t*)record;
 	k->pool.insert(k->pool.end(), w, w + k->s->W);
 	return (int)(k->pool.size() / (size_t)k->s->W) - 1;
 }
 extern "C" int klg_script_note_on(klg_script* k, int block, int voice, int record_index) {
-	if (!k || k->committed || block < 0 || block >= k->blocks || voice < 0 || voice >= k->s->V || record_index < 0 || (size_t)record_index >= k->pool.size() / (size_t)k->s->W)
+	if (!k || !k->s || k->committed || block < 0 || block >= k->blocks || voice < 0 || voice >= k->s->V || record_index < 0 || (size_t)record_index >= k->pool.size() / (size_t)k->s->W)
 		return fail(KLG_ERR_INVALID, "klg_script_note_on: bad arguments or script already committed");
 	k->ev[(size_t)block].push_back({ voice, 0, record_index, (unsigned)k->ev[(size_t)block].size() });
 	return 0;
 }
 extern "C" int klg_script_note_off(klg_script* k, int block, int voice) {
-	if (!k || k->committed || block < 0 || block >= k->blocks || voice < 0 || voice >= k->s->V) return fail(KLG_ERR_INVALID, "klg_script_note_off: bad arguments or script already committed");
+	if (!k || !k->s || k->committed || block < 0 || block >= k->blocks || voice < 0 || voice >= k->s->V) return fail(KLG_ERR_INVALID, "klg_script_note_off: bad arguments, script already committed, or its bank was destroyed");
 	if (k->s->graph) return fail(KLG_ERR_INVALID, "klg_script_note_off: %s", kGraphEvents);
 	k->ev[(size_t)block].push_back({ voice, 1, -1, (unsigned)k->ev[(size_t)block].size() });
 	return 0;
@@ -1142,7 +1175,7 @@ extern "C" int klg_note_records(klg_synth* s, int n, const int* synth, const int
 	return 0;
 }
 extern "C" int klg_script_add_records(klg_script* k, int n, const void* records) {
-	if (!k || n < 0 || !records || k->committed) return fail(KLG_ERR_INVALID, "klg_script_add_records: bad arguments or script already committed");
+	if (!k || !k->s || n < 0 || !records || k->committed) return fail(KLG_ERR_INVALID, "klg_script_add_records: bad arguments, script already committed, or its bank was destroyed");
 	const int first = (int)(k->pool.size() / (size_t)k->s->W);
 	const uint32_t* w = (const uint32_t*)records;
 	k->pool.insert(k->pool.end(), w, w + (size_t)n * k->s->W);
@@ -1160,9 +1193,9 @@ extern "C" int klg_script_note_off_many(klg_script* k, int n, const int* block, 
 }
 // sort every block's events into per-voice runs (what flush_events does per block) and move everything to HBM, once
 extern "C" int klg_script_commit(klg_script* k) {
-	if (!k || k->committed) return fail(KLG_ERR_INVALID, "klg_script_commit: bad handle or already committed");
+	if (!k || !k->s || k->committed) return fail(KLG_ERR_INVALID, "klg_script_commit: bad handle, already committed, or the script's bank was destroyed");
 	RandGuard rg;
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	KLG_BIND(k->s);
 	std::vector<int> index;
 	k->slices.resize((size_t)k->blocks);
 	for (int b = 0; b < k->blocks; b++) {
@@ -1188,8 +1221,8 @@ extern "C" int klg_script_commit(klg_script* k) {
 // replaces: the host's per-block loop "pass this block's MIDI to the synth, then render" (templates/juce/synth/Source/PluginProcessor.cpp:170-177)
 // for a stream known in advance: block `block`'s events are applied from HBM (no host work, no transfer), then the block is rendered
 extern "C" int klg_script_play_device(klg_script* k, int block, float* d_mix, int n, void* hip_stream) {
-	if (!k || !k->committed || block < 0 || block >= k->blocks || !d_mix || n <= 0 || n > k->s->max_block) return fail(KLG_ERR_INVALID, "klg_script_play_device: bad arguments or script not committed");
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (!k || !k->s || !k->committed || block < 0 || block >= k->blocks || !d_mix || n <= 0 || n > k->s->max_block) return fail(KLG_ERR_INVALID, "klg_script_play_device: bad arguments, script not committed, or its bank was destroyed");
+	KLG_BIND(k->s);
 	klg_synth* s = k->s;
 	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
 	if (int rc = flush_events(s, st)) return rc;                    // anything queued interactively comes first
@@ -1217,6 +1250,7 @@ extern "C" int klg_timing_end(klg_synth* s, int* launches, float* total_ms) {
 		for (size_t i = 0; i < s->multi->shard.size(); i++) { if (int rc = on_shard(s, i, [&](klg_synth* sh) { return klg_timing_end(sh, &l, &ms); })) return rc; if (ms > *total_ms) { *total_ms = ms; *launches = l; } }
 		return 0;
 	}
+	KLG_BIND(s);
 	HIP_TRY(hipDeviceSynchronize());
 	float total = 0.f;
 	for (int i = 0; i < s->launches; i++) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, s->tev[2 * i], s->tev[2 * i + 1])); total += ms; }

@@ -13,8 +13,14 @@ struct RvHost {                                        // host mirror of one Rev
 	float e_length = 0.f, e_size = 0.f;                // EarlyReflections::length / size
 };
 
+// a bank sharded BY INSTANCE over the devices of klg_init (effects shard by instance, no collective): contiguous ranges,
+// one ordinary single-device bank per device; this handle only routes
+struct FxMulti { std::vector<struct klg_fx*> shard; std::vector<int> first; };   // shard i owns instances [first[i], first[i + 1])
+
 struct klg_fx {
 	int patch = 0, K = 0, max_block = 0, nctl = 0, words = 0;
+	int device = 0;                                    // the GPU this bank (or shard) lives on
+	FxMulti* multi = nullptr;
 	size_t kpad = 0;
 	host::Fs fs;
 	hipStream_t stream = nullptr;
@@ -43,6 +49,7 @@ static inline int f2i(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 
 static void fx_free(klg_fx* f) {
 	if (!f) return;
+	if (f->multi) { for (klg_fx* sh : f->multi->shard) { DeviceGuard bound(sh->device); fx_free(sh); } delete f->multi; delete f; return; }
 	if (f->stream) (void)hipStreamSynchronize(f->stream);
 	void* dev[] = { f->d_state, f->d_rings, f->d_rings2, f->d_io, f->d_upd, f->d_controls };
 	for (void* p : dev) if (p) (void)hipFree(p);
@@ -73,12 +80,43 @@ static BiquadCoef design_biquad(bool hpf, float f, float Q, const host::Fs& fs) 
 	return c;
 }
 
+// `make(device, instances)` = the single-device creator; the bank's instances are dealt to the devices in contiguous ranges
+template<class MAKE> static klg_fx* fx_multi_create(int instances, int max_block, MAKE&& make) {
+	const std::vector<int> devs = g_devices;
+	const int n = (int)std::min<size_t>(devs.size(), (size_t)instances);
+	klg_fx* r = new klg_fx(); r->multi = new FxMulti(); r->K = instances; r->max_block = max_block; r->device = devs[0];
+	const int base = instances / n, extra = instances % n;
+	r->multi->first.push_back(0);
+	for (int i = 0; i < n; i++) {
+		const int count = base + (i < extra ? 1 : 0);
+		klg_fx* sh = make(devs[(size_t)i], count);
+		if (!sh) { const std::string why = g_err; fx_free(r); fail(KLG_ERR_NOMEM, "multi-device effect bank: shard %d on device %d: %s", i, devs[(size_t)i], why.c_str()); return nullptr; }
+		r->multi->shard.push_back(sh); r->multi->first.push_back(r->multi->first.back() + count);
+	}
+	const klg_fx* s0 = r->multi->shard[0];
+	r->patch = s0->patch; r->nctl = s0->nctl; r->words = s0->words; r->channels = s0->channels; r->fs = s0->fs; r->graph = s0->graph;
+	return r;
+}
+static int fx_shard_of(const klg_fx* f, int instance, int* local) {
+	const FxMulti& m = *f->multi;
+	for (size_t i = 0; i + 1 < m.first.size(); i++) if (instance >= m.first[i] && instance < m.first[i + 1]) { *local = instance - m.first[i]; return (int)i; }
+	return -1;
+}
+
+static klg_fx* fx_create_on(int device, int patch_id, int instances, float sample_rate, int max_block);
 extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate, int max_block) {
 	if (patch_id != KLG_PATCH_PINGPONG && patch_id != KLG_PATCH_REVERB) { fail(KLG_ERR_INVALID, "klg_fx_create: patch %d is not an effect patch", patch_id); return nullptr; }
 	if (instances <= 0 || max_block <= 0 || max_block > MAX_BLOCK || !(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_fx_create: bad arguments"); return nullptr; }
+	if (default_device() < 0) return nullptr;
+	if (g_devices.size() > 1) return fx_multi_create(instances, max_block, [&](int device, int count) { return fx_create_on(device, patch_id, count, sample_rate, max_block); });
+	return fx_create_on(g_device, patch_id, instances, sample_rate, max_block);
+}
+static klg_fx* fx_create_on(int device, int patch_id, int instances, float sample_rate, int max_block) {
 	RandGuard rg;
-	if (klg_ensure_device()) return nullptr;
+	DeviceGuard bound(device);
+	if (!bound.ok) return nullptr;
 	klg_fx* f = new klg_fx();
+	f->device = device;
 	f->patch = patch_id; f->K = instances; f->max_block = max_block;
 	f->kpad = ((size_t)instances + FX_WG - 1) / FX_WG * FX_WG;
 	f->fs = host::Fs(sample_rate);
@@ -118,16 +156,24 @@ extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate,
 // replaces: constructing `instances` copies of a user Effect whose process() body was recorded (include/klang_mi355_graph.h,
 // `kind effect 1|2`).  `initial_record` (the program's record: Program::words() 32-bit words; NULL = zeros) is the state of one freshly
 // constructed instance; every instance starts from it.  Delay<SIZE> members become zero-filled rings in HBM.
+static klg_fx* fx_create_graph_on(int device, const char* program, int instances, float sample_rate, int max_block, const void* initial_record);
 extern "C" klg_fx* klg_fx_create_graph(const char* program, int instances, float sample_rate, int max_block, const void* initial_record) {
-	RandGuard rg;
 	if (instances <= 0 || max_block <= 0 || max_block > MAX_BLOCK || !(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_fx_create_graph: bad arguments"); return nullptr; }
+	if (default_device() < 0) return nullptr;
+	if (g_devices.size() > 1) return fx_multi_create(instances, max_block, [&](int device, int count) { return fx_create_graph_on(device, program, count, sample_rate, max_block, initial_record); });
+	return fx_create_graph_on(g_device, program, instances, sample_rate, max_block, initial_record);
+}
+static klg_fx* fx_create_graph_on(int device, const char* program, int instances, float sample_rate, int max_block, const void* initial_record) {
+	RandGuard rg;
+	DeviceGuard bound(device);
+	if (!bound.ok) return nullptr;
 	const graphrt::Compiled* c = nullptr;
 	const std::string err = graphrt::compile(program, &c);
 	if (!err.empty()) { fail(KLG_ERR_INVALID, "klg_fx_create_graph: %s", err.c_str()); return nullptr; }
 	if (!c->channels) { fail(KLG_ERR_INVALID, "klg_fx_create_graph: the program is a synth note body (no `kind effect` line): use klg_synth_create_graph"); return nullptr; }
 	graph::Program g; (void)g.parse(program);
-	if (klg_ensure_device()) return nullptr;
 	klg_fx* f = new klg_fx();
+	f->device = device;
 	f->patch = KLG_PATCH_FXGRAPH; f->K = instances; f->max_block = max_block; f->graph = c; f->channels = c->channels;
 	f->kpad = ((size_t)instances + FX_WG - 1) / FX_WG * FX_WG;
 	f->fs = host::Fs(sample_rate);
@@ -155,9 +201,10 @@ extern "C" klg_fx* klg_fx_create_graph(const char* program, int instances, float
 	return f;
 }
 
-extern "C" void klg_fx_destroy(klg_fx* f) { if (f && g_device >= 0) (void)hipSetDevice(g_device); fx_free(f); }
+extern "C" void klg_fx_destroy(klg_fx* f) { if (!f) return; DeviceGuard bound(f->device); fx_free(f); }
 extern "C" size_t klg_fx_state_bytes(const klg_fx* f) {
 	if (!f) return 0;
+	if (f->multi) return klg_fx_state_bytes(f->multi->shard[0]);
 	if (f->graph) return (size_t)f->words * 4 + (size_t)f->graph->ring_rows * 4;
 	return (size_t)f->words * 4 + (f->patch == KLG_PATCH_PINGPONG ? (size_t)2 * 192000 * 4 : ((size_t)2 * RV_ESIZE + (size_t)16 * RV_FSIZE) * 4);
 }
@@ -165,6 +212,7 @@ extern "C" size_t klg_fx_state_bytes(const klg_fx* f) {
 static int fx_flush_updates(klg_fx* f, hipStream_t st);
 extern "C" int klg_fx_set_control(klg_fx* f, int instance, int index, float value) {
 	if (!f || instance < 0 || instance >= f->K || index < 0 || index >= f->nctl) return fail(KLG_ERR_INVALID, "klg_fx_set_control: instance %d / control %d out of range", instance, index);
+	if (f->multi) { int li = 0; const int sh = fx_shard_of(f, instance, &li); return klg_fx_set_control(f->multi->shard[(size_t)sh], li, index, value); }
 	host::ControlH& c = f->controls[(size_t)instance * f->nctl + index];
 	c.set(value);                                                                   // Control::set clamps (klang.h:1725-1728)
 	if (f->graph) {
@@ -184,11 +232,12 @@ extern "C" int klg_fx_set_control(klg_fx* f, int instance, int index, float valu
 // instance's state — the parameter sync OUT of Effect::process(float*, int, float* parameters) klang.h:4213-4215
 extern "C" int klg_fx_get_control(klg_fx* f, int instance, int index, float* value) {
 	if (!f || !value || instance < 0 || instance >= f->K || index < 0 || index >= f->nctl) return fail(KLG_ERR_INVALID, "klg_fx_get_control: instance %d / control %d out of range", instance, index);
+	if (f->multi) { int li = 0; const int sh = fx_shard_of(f, instance, &li); return klg_fx_get_control(f->multi->shard[(size_t)sh], li, index, value); }
 	int word = -1;
 	if (f->graph) word = f->graph->ctlvar_word[index];
 	else if (f->patch == KLG_PATCH_PINGPONG && index == 1) word = 1;                  // klg_fx_pingpong*: state word 1 is controls[1]
 	if (word < 0) { *value = f->controls[(size_t)instance * f->nctl + index].value; return 0; }
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	KLG_BIND(f);
 	if (int rc = fx_flush_updates(f, f->stream)) return rc;
 	HIP_TRY(hipStreamSynchronize(f->stream));
 	HIP_TRY(hipMemcpy(value, (const float*)f->d_state + (size_t)word * f->kpad + instance, sizeof(float), hipMemcpyDeviceToHost));
@@ -390,7 +439,22 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 
 extern "C" int klg_fx_process(klg_fx* f, float* io, int n) {
 	if (!f || !io || n <= 0 || n > f->max_block) return fail(KLG_ERR_INVALID, "klg_fx_process: bad arguments (n=%d)", n);
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (f->multi) {
+		// every shard takes ITS instances' rows of the caller's [K][channels][n] block: enqueue on all devices, then wait for all (no collective:
+		// effect instances are independent).  Host work that is ordered across instances (Reverb's prepare(), Noise draws) runs shard by shard
+		// = in instance order, as in one bank.
+		const FxMulti& m = *f->multi;
+		for (size_t i = 0; i < m.shard.size(); i++) {
+			klg_fx* sh = m.shard[i]; DeviceGuard bound(sh->device); if (!bound.ok) return KLG_ERR_NO_DEVICE;
+			float* part = io + (size_t)m.first[i] * sh->channels * n; const size_t bytes = (size_t)sh->K * sh->channels * n * 4;
+			HIP_TRY(hipMemcpyAsync(sh->d_io, part, bytes, hipMemcpyHostToDevice, sh->stream));
+			if (int rc = fx_enqueue(sh, sh->d_io, n, sh->stream)) return rc;
+			HIP_TRY(hipMemcpyAsync(part, sh->d_io, bytes, hipMemcpyDeviceToHost, sh->stream));
+		}
+		for (klg_fx* sh : m.shard) { DeviceGuard bound(sh->device); HIP_TRY(hipStreamSynchronize(sh->stream)); }
+		return 0;
+	}
+	KLG_BIND(f);
 	const size_t bytes = (size_t)f->K * f->channels * n * 4;
 	HIP_TRY(hipMemcpyAsync(f->d_io, io, bytes, hipMemcpyHostToDevice, f->stream));
 	if (int rc = fx_enqueue(f, f->d_io, n, f->stream)) return rc;
@@ -400,18 +464,26 @@ extern "C" int klg_fx_process(klg_fx* f, float* io, int n) {
 }
 extern "C" int klg_fx_process_device(klg_fx* f, float* d_io, int n, void* hip_stream) {
 	if (!f || !d_io || n <= 0 || n > f->max_block) return fail(KLG_ERR_INVALID, "klg_fx_process_device: bad arguments (n=%d)", n);
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (f->multi) return fail(KLG_ERR_INVALID, "klg_fx_process_device: this bank is sharded over %zu devices (klg_init) and a device block lives on ONE of them: use klg_fx_process (host block), or one bank per GPU", f->multi->shard.size());
+	KLG_BIND(f);
 	return fx_enqueue(f, d_io, n, hip_stream ? (hipStream_t)hip_stream : f->stream);
 }
 extern "C" int klg_fx_sync(klg_fx* f) {
 	if (!f) return fail(KLG_ERR_INVALID, "klg_fx_sync: NULL handle");
-	if (klg_ensure_device()) return KLG_ERR_NO_DEVICE;
+	if (f->multi) { for (klg_fx* sh : f->multi->shard) if (int rc = klg_fx_sync(sh)) return rc; return 0; }
+	KLG_BIND(f);
 	HIP_TRY(hipDeviceSynchronize());
 	return 0;
 }
-extern "C" int klg_fx_timing_begin(klg_fx* f) { if (!f) return fail(KLG_ERR_INVALID, "NULL handle"); f->timing = true; f->launches = 0; return 0; }
+extern "C" int klg_fx_timing_begin(klg_fx* f) { if (!f) return fail(KLG_ERR_INVALID, "NULL handle"); if (f->multi) { for (klg_fx* sh : f->multi->shard) klg_fx_timing_begin(sh); return 0; } f->timing = true; f->launches = 0; return 0; }
 extern "C" int klg_fx_timing_end(klg_fx* f, int* launches, float* total_ms) {
 	if (!f || !launches || !total_ms) return fail(KLG_ERR_INVALID, "klg_fx_timing_end: bad arguments");
+	if (f->multi) {                                                     // the slowest shard (they run concurrently)
+		int l = 0; float ms = 0.f; *launches = 0; *total_ms = 0.f;
+		for (klg_fx* sh : f->multi->shard) { if (int rc = klg_fx_timing_end(sh, &l, &ms)) return rc; if (ms > *total_ms) { *total_ms = ms; *launches = l; } }
+		return 0;
+	}
+	KLG_BIND(f);
 	HIP_TRY(hipDeviceSynchronize());
 	float total = 0.f;
 	for (int i = 0; i < f->launches; i++) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, f->tev[2 * i], f->tev[2 * i + 1])); total += ms; }

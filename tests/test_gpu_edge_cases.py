@@ -116,3 +116,23 @@ def test_silent_bank_and_max_block():
     b.process(out)                                            # nothing sounding: the caller's buffer is left untouched (+= 0)
     assert np.all(out == 0.25) and np.all(b.stages() == 3)
     b.close()
+
+
+def test_script_outlives_its_bank_without_touching_freed_state():
+    """a klg_script keeps a pointer to its bank.  Destroying the bank first invalidates the script (its device arrays go with the
+    bank); every later klg_script_* call fails with an error instead of dereferencing freed memory, and klg_script_destroy still works."""
+    import torch
+    import klang_amd
+    bank = klang_amd.SynthBank("sub2a", synths=2, notes=8, max_block=64)
+    script = klang_amd.EventScript(bank, 4)
+    first = script.add_records(bank.note_records([0, 1], [60, 64], [0.8, 0.7]))
+    script.note_on([0, 1], [0, 9], [first, first + 1])
+    script.commit()
+    mix = torch.zeros((2, 64), dtype=torch.float32, device="cuda")
+    script.play_device(0, mix.data_ptr(), 64)
+    bank.sync()
+    assert float(mix.abs().sum()) > 0
+    bank.close()                                          # the bank goes first
+    with pytest.raises(klang_amd.KlangError, match="destroyed"):
+        script.play_device(1, mix.data_ptr(), 64)
+    script.close()                                        # and the handle can still be released

@@ -130,6 +130,13 @@ def test_recorded_graph_single_voice_is_bit_exact(name, tmp_path):
 STEREO = ["own_stereo_note", "own_synthx_shape"]
 
 
+def same_bits_or_both_zero(a, b):
+    """The fixture's per-voice block is what Stereo::Note::process ADDED to a zeroed buffer (`buffer++ += out`): where `out` is -0.0
+    (a note's first sample) the buffer holds 0.0 + -0.0 = +0.0, while klg_process_voices returns `out` itself.  The two zeros add the
+    same nothing; every other sample must be the same bits."""
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))))
+
+
 def stereo_binary(name):
     path = os.path.join(ROOT, "tests", "cpp", "_bin", "facade_graph_" + name)
     if not os.path.exists(path):
@@ -146,7 +153,7 @@ def test_stereo_note_single_voice_is_bit_exact_per_channel(name, tmp_path):
     assert ref["per_voice"].ndim == 4 and ref["per_voice"].shape[2] == 2
     assert np.array_equal(stages, ref["stages"])
     assert np.array_equal(mix.view(np.uint32), ref["mix"].view(np.uint32)), f"max abs err {np.abs(mix - ref['mix']).max()}"
-    assert np.array_equal(pv.view(np.uint32), ref["per_voice"].view(np.uint32))
+    assert same_bits_or_both_zero(pv, ref["per_voice"])
     assert np.abs(mix[:, 0]).max() > 0 and np.abs(mix[:, 1]).max() > 0
     assert not np.array_equal(mix[:, 0], mix[:, 1]), "a true stereo note: the channels must differ"
 
@@ -158,7 +165,7 @@ def test_stereo_notes_polyphonic(name, tmp_path):
     mix, stages, pv = run_facade_voices(stereo_binary(name), name, tmp_path)
     ref = np.load(os.path.join(GOLDEN, name + ".npz"))
     assert np.array_equal(stages, ref["stages"])
-    assert np.array_equal(pv.view(np.uint32), ref["per_voice"].view(np.uint32)), f"per-voice max abs err {np.abs(pv - ref['per_voice']).max()}"
+    assert same_bits_or_both_zero(pv, ref["per_voice"]), f"per-voice max abs err {np.abs(pv - ref['per_voice']).max()}"
     peak = float(np.max(np.abs(ref["per_voice"])))
     V = ref["stages"].shape[1]
     want = ref["mix"] if "mix" in ref else ref["mix_dump"]

@@ -35,7 +35,7 @@ def device_lists():
     return lists
 
 
-@pytest.mark.parametrize("patch,synths,notes", [("sub2a", 5, 16), ("supersaw", 7, 8)])
+@pytest.mark.parametrize("patch,synths,notes", [("sub2a", 5, 16), ("supersaw", 7, 8), ("fm4", 5, 8), ("fm3", 3, 4)])
 def test_sharded_bank_equals_single_device_bank(patch, synths, notes):
     """uneven split (5 instances over 2 / 3 shards, 7 over 2 / 3): per-voice outputs and note stages bit for bit, the mix within the
     summation-order bound (the shards' partial sums are added in another order)"""
@@ -82,5 +82,108 @@ def test_sharded_bank_device_entry_and_controls():
         a, b = run((0,)), run((0, 0))
         assert np.abs(a - 0.25).max() > 0
         assert float(np.abs(a - b).max()) <= 1e-5 * float(np.abs(a).max())
+    finally:
+        klang_amd.init([0])
+
+
+def test_fm4_share_of_config_5_over_two_shards(oracle_build):
+    """BASELINE config 5's shape on one box: 131,072 FM4 voices as TWO shards of 65,536 (klg_init([0, 0]); two GPUs: (0, 1) and RCCL) —
+    256 class instances against the oracle, every replica in either shard bit-exact with its class, the combined mix = the fp64 sum of all
+    voices (voices shard, one reduce of the [2][n] block)."""
+    import torch
+    import klang_amd
+    from klg_driver import rel_err, run_scenario_oracle
+    from test_gpu_fullsize import class_scenario, replicate
+    classes, notes, total = 128, 32, 4096                                 # 4,096 instances x 32 notes = 131,072 voices; 2,048 instances per shard
+    dump = [0, 2, 4]
+    small = class_scenario("fm4", classes, notes, 5, 256, 4242, False, dump)
+    ref = run_scenario_oracle(small, oracle_build)
+    big = replicate(small, total)
+    devs = [0, 1] if torch.cuda.device_count() >= 2 else [0, 0]
+    klang_amd.init(devs)
+    try:
+        got = run_scenario_gpu(big)
+    finally:
+        klang_amd.init([0])
+    pv = got["per_voice"]
+    Vc = small.voices
+    assert pv.shape[1] == total * notes
+    assert rel_err(pv[:, :Vc], ref["per_voice"]) <= 1e-5
+    assert np.array_equal(got["stages"][:, :Vc], ref["stages"])
+    reps = pv.reshape(len(dump), total // classes, Vc, -1)
+    assert np.array_equal(reps.view(np.uint32), np.broadcast_to(reps[:, :1], reps.shape).view(np.uint32)), "a replica (in either shard) differs from its class representative"
+    V = pv.shape[1]
+    for i, b in enumerate(dump):
+        want = pv[i].astype(np.float64).sum(axis=0)
+        peak = float(np.abs(pv[i]).max())
+        assert float(np.abs(got["mix"][b, 0] - want).max()) <= 4 * np.sqrt(V) * np.finfo(np.float32).eps * peak * np.sqrt(V)
+    assert float(np.abs(got["mix"]).max()) > 0
+
+
+@pytest.mark.parametrize("patch", ["pingpong", "reverb"])
+def test_effect_bank_is_sharded_by_instance(patch):
+    """effects shard BY INSTANCE, no collective.  Under klg_init with several ids an effect bank is dealt to the devices in
+    contiguous ranges (uneven: 70 instances over 2 / 3 shards); per-instance controls reach the owning shard; the result equals the
+    single-device bank bit for bit; the device entry refuses loudly (a device block lives on one GPU)."""
+    import klang_amd
+    K, N, B = 70, 128, 6
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-0.5, 0.5, size=(B, K, 2, N)).astype(np.float32)
+    x[3:] = 0
+    ctl = [(k, c, float(rng.uniform(0.05, 0.9))) for k in range(K) for c in ((0, 1, 5) if patch == "pingpong" else (2, 3, 6, 7))]
+
+    def run(devs):
+        klang_amd.init(list(devs))
+        bank = klang_amd.FxBank(patch, K, max_block=N)
+        for k, c, v in ctl:
+            bank.set_control(k, c, v)
+        out = []
+        for b in range(B):
+            if b == 2:
+                bank.set_control(K - 1, ctl[-1][1], 0.33)                  # a change mid-run, last instance (the last shard)
+            io = x[b].copy(); bank.process(io); out.append(io)
+        back = [bank.get_control(k, 1) for k in (0, K // 2, K - 1)]
+        if len(devs) > 1:
+            import torch
+            with pytest.raises(klang_amd.KlangError, match="sharded over"):
+                bank.process_device(torch.zeros((K, 2, N), device="cuda").data_ptr(), N)
+        bank.close()
+        return np.stack(out), back
+
+    try:
+        ref, ref_back = run((0,))
+        for devs in device_lists():
+            got, back = run(devs)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), devs
+            assert back == ref_back
+        assert np.abs(ref[4]).max() > 1e-4
+    finally:
+        klang_amd.init([0])
+
+
+def test_two_banks_driven_from_two_host_threads():
+    """One calling thread per handle is the contract (include/klang_mi355.h); two handles may be driven CONCURRENTLY.  The bank's device is
+    a field of the handle and is bound per call and per thread (no process-global device is swapped around a call): two threads, each
+    creating, playing and reading its own bank — one of them a sharded (0, 0) bank —, get what they get alone."""
+    import threading
+    import klang_amd
+    s = scenario("sub2a", 4, 8, 6)
+
+    def play(result, key):
+        result[key] = run_scenario_gpu(s)
+
+    klang_amd.init([0])
+    alone = run_scenario_gpu(s)
+    try:
+        klang_amd.init([0, 0])
+        sharded_alone = run_scenario_gpu(s)
+        res = {}
+        for rnd in range(3):
+            threads = [threading.Thread(target=play, args=(res, i)) for i in range(2)]
+            for t in threads: t.start()
+            for t in threads: t.join()
+            for i in range(2):
+                assert np.array_equal(res[i]["per_voice"].view(np.uint32), alone["per_voice"].view(np.uint32)), (rnd, i)
+                assert np.array_equal(res[i]["mix"].view(np.uint32), sharded_alone["mix"].view(np.uint32)), (rnd, i)
     finally:
         klang_amd.init([0])

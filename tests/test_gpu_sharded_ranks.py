@@ -47,7 +47,7 @@ dist.barrier(); bank.close(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("patch", ["sub2a", "supersaw"])
+@pytest.mark.parametrize("patch", ["sub2a", "supersaw", "fm4"])
 def test_two_ranks_with_the_hip_bank_equal_one_bank(patch, tmp_path):
     import klang_amd
     script = tmp_path / "rank.py"
@@ -79,3 +79,25 @@ def test_two_ranks_with_the_hip_bank_equal_one_bank(patch, tmp_path):
     peak = float(np.max(np.abs(want)))
     assert peak > 0.05
     assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 1e-5 * peak * np.sqrt(S * P) * 4
+
+
+def test_bench_py_two_ranks_end_to_end():
+    """`python bench.py --gpus 2`: bench.py spawns its own ranks (torch.distributed.run on 127.0.0.1), every rank builds its shard and its
+    event script, blocks go through the ring of four buffers with one asynchronous all-reduce each, rank 0 prints ONE JSON line.  On a
+    one-GPU box KLG_BENCH_ONE_GPU=1 puts both ranks on cuda:0 over gloo — a functional run of the N > 1 code path as a whole, not a measurement."""
+    import json
+    import torch
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 2:
+        env["KLG_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--voices", str(375 * 256)],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak"
+    assert np.isfinite(out["value"]) and out["value"] > 0
+    assert out["config"]["voices_alive_after_last_block"] == out["config"]["voices_alive_expected"]
+    assert out["config"]["mix_checksum"] > 0
+    assert "all-reduce" in out["config"]["parallelism"]
