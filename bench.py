@@ -49,7 +49,8 @@ KERNEL_OF = {"sub2a": "klg_render_sub2a_x2", "supersaw": "klg_render<klg::PatchS
 # ---------------------------------------------------------------------------------------------------------------------------------
 def build_script(bank, groups, rng, cyclic):
     """Voices [0, V) in `groups` equal contiguous groups; group g starts its note at block g * (375 // groups) ... (cyclic) or every
-    group at block 0 (literal script, groups == 1).  Returns (EventScript, sounding[b] = voices sounding during block b once settled)."""
+    group at block 0 (literal script, groups == 1).  Returns (EventScript, sounding[b] = voices sounding during block b once settled);
+    sounding.alive_after[b] = voices still sounding AFTER block b (a voice's last block is the one in which its envelope runs out)."""
     import klang_amd
     V, notes = bank.voices, bank.notes
     pitches = rng.integers(36, 97, size=V).astype(np.int32)
@@ -70,10 +71,14 @@ def build_script(bank, groups, rng, cyclic):
     script.commit()
     # sounding voices per block: from note-on until RELEASE_BLOCKS blocks after the note-off (the block in which the envelope runs out is rendered)
     life = OFF_BLOCK + (v % OFF_SPREAD) + RELEASE_BLOCKS[bank.patch]                     # blocks a voice sounds, counted from its note-on
-    sounding = np.zeros(SCRIPT_BLOCKS, np.int64)
+    class Sounding(np.ndarray):
+        pass
+    sounding = np.zeros(SCRIPT_BLOCKS, np.int64).view(Sounding)
+    sounding.alive_after = np.zeros(SCRIPT_BLOCKS, np.int64)
     for b in range(SCRIPT_BLOCKS):
         local = (b - start) % SCRIPT_BLOCKS if cyclic else b - start
         sounding[b] = int(((local >= 0) & (local < life)).sum())
+        sounding.alive_after[b] = int(((local >= 0) & (local < life - 1)).sum())
     return script, sounding
 
 
@@ -141,8 +146,62 @@ def cpu_reference(patch, block, budget_s=10.0):
     probe = run(1000)
     blocks = int(max(1000, min(40000, 1000 * budget_s / max(probe, 1e-3))))
     dt = run(blocks)
-    return {"value": 128 * block * blocks / dt, "unit": "voice*samples/s", "cores": 1, "kind": "reference",
+    return {"value": 128 * block * blocks / dt, "unit": "voice*samples/s", "cores": 1, "kind": "reference", "blocks": blocks,
             "sample": f"{patch}: 128 voices x {block} samples x {blocks} blocks, all sounding, the reference's klang.h v0.7.8 (oracle/_ref/ref_subtractive, clang++ -O2) single thread, {os.cpu_count()} host cores present"}
+
+
+def host_cores():
+    """(cpu ids to pin to: one per PHYSICAL core this process may use, note).  The GPU box's cgroup grants fewer CPUs than the host has
+    (DESIGN.md §7): the affinity mask and cpu.max are what count, not os.cpu_count()."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, picked = set(), []
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib); picked.append(c)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    if quota is not None and quota < len(picked):
+        picked = picked[:quota]
+    return picked, f"{os.cpu_count()} logical CPUs present, {len(allowed)} in this process's affinity mask, cgroup cpu.max {'= ' + str(quota) if quota else 'unlimited'}, {len(picked)} physical cores used"
+
+
+def cpu_reference_node(patch, block, blocks):
+    """SURVEY §8(d)(b) / north_star "timed on the node's own host cores (core count stated)": ONE pinned process of the genuine-header binary
+    per physical core this job may use, all started together, each rendering the single-core sample (128 sounding voices x `blocks` blocks);
+    value = all voice*samples / wall time of the slowest.  None when the binary is not there."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_subtractive")
+    if patch != "sub2a" or not os.path.exists(exe):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenario_io import Scenario
+    cores, note = host_cores()
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        for i, c in enumerate(cores):
+            s = Scenario(patch="sub2a", block=block, blocks=blocks, synths=1, notes=128, dump=[])
+            for pch in np.random.default_rng(20250314 + i).integers(36, 97, size=128):
+                s.on(0, 0, int(pch), 0.8)
+            s.save(os.path.join(d, f"s{i}.scn"))
+        t0 = time.perf_counter()
+        for i, c in enumerate(cores):
+            procs.append(subprocess.Popen([exe, os.path.join(d, f"s{i}.scn"), os.path.join(d, f"o{i}.bin")], stdout=subprocess.DEVNULL,
+                                          preexec_fn=(lambda c=c: os.sched_setaffinity(0, {c}))))
+        rc = [p.wait() for p in procs]
+        dt = time.perf_counter() - t0
+    if any(rc):
+        return None
+    total = len(cores) * 128 * block * blocks / dt
+    return {"value": total, "unit": "voice*samples/s", "cores": len(cores), "per_core": total / len(cores), "kind": "reference",
+            "sample": f"{patch}: one process per physical core, each 128 voices x {block} samples x {blocks} blocks, all sounding, the reference's klang.h v0.7.8 (oracle/_ref/ref_subtractive), pinned; {note}"}
 
 
 def valu_issue(wave_samples, kern_s, per_sample):
@@ -245,9 +304,12 @@ def run_literal_script(patch, voices, N, label, phases=False):
            "ms_per_block_sustain": float(np.median(ms[40:OFF_BLOCK])), "value_sustain_phase": V * N / (1e-3 * float(np.median(ms[40:OFF_BLOCK])))}
     kern_s = 1e-3 * float(np.median(ms[40:OFF_BLOCK]))
     ab = alg_bytes(patch, bank, V, N)
-    res["roofline"] = {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                       "kernel": ("klg_render_supersaw_pairs" if patch == "supersaw" and voices <= 131072 else KERNEL_OF.get(patch, patch)), "phase": "sustain (block time incl. event kernel + reduce)", "algorithmic_bytes_per_launch": ab,
-                       "note": "voice state lives in registers: VALU-issue bound by design (DESIGN.md §3)"}
+    tf = FLOPS_PER_VOICE_SAMPLE.get(patch, 0) * V * N / kern_s / 1e12
+    res["roofline"] = {"bound": "valu", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,
+                       "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(patch, 0),
+                       "kernel": ("klg_render_supersaw_pairs" if patch == "supersaw" and voices <= 131072 else KERNEL_OF.get(patch, patch)), "phase": "sustain (block time incl. event kernel + reduce)",
+                       "hbm": {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab},
+                       "note": "voice state lives in registers: VALU-issue bound by design (DESIGN.md §3); 157.3 TFLOP/s is the packed-FMA peak, separate mul / add (bit-parity) reach at most half"}
     if phases:
         res["phases_ms_per_block"] = {"attack_decay_all_ramping(1..21)": float(np.median(ms[1:22])), "sustain_only(40..149)": float(np.median(ms[40:OFF_BLOCK])),
                                       "staggered_release(150..213)": float(np.median(ms[OFF_BLOCK:OFF_BLOCK + OFF_SPREAD])), "release_tail(214..260)": float(np.median(ms[214:261])),
@@ -465,7 +527,7 @@ def main():
         dt = float(t.item())
     checksum = float(mixes[(state["i"] - 1) % RING].abs().sum().item())
     alive_now = int((bank.stages() != 3).sum())
-    expect_alive = int(sounding[(state["i"] - 1) % SCRIPT_BLOCKS])
+    expect_alive = int(sounding.alive_after[(state["i"] - 1) % SCRIPT_BLOCKS])
     sounding_timed = float(sum(int(sounding[(first_timed + j) % SCRIPT_BLOCKS]) for j in range(args.steps)))
 
     if rank == 0:
@@ -488,10 +550,15 @@ def main():
                        "value_counts": "sounding voices x samples / s (SURVEY 8d: active voices); resident voices x samples / s = %.6g" % (world * V * N * args.steps / dt),
                        "voices_alive_after_last_block": alive_now, "voices_alive_expected": expect_alive,
                        "block_deadline_ms": 1e3 * N / 48000.0, "mix_checksum": checksum},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_how,
-                         "kernel": kernel_name, "kernel_ms": 1e3 * kern_s, "algorithmic_bytes_per_launch": ab,
-                         "algorithmic_bytes": "sounding voices x (80 B record read + 32 B written back) + the [2][256] block; a silent voice costs its 4-byte flag word (not counted)",
-                         "note": "synth patches keep voice state in registers (north_star): the binding unit is fp32 VALU issue, see `valu`",
+            # what BINDS this kernel is fp32 VALU issue (voice state in registers, as north_star prescribes; PMC: VALU busy 82-85 % of the kernel's
+            # cycles, profiles/r02_pmc/pmc_sub2a_*.json), so that is the roofline's `bound` and `frac`; the HBM view of the same launch is the `hbm`
+            # sub-object (`traffic` = HBM bytes per launch from the PMC counters, as everywhere)
+            "roofline": {"bound": "valu", "achieved": flops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_how,
+                         "kernel": kernel_name, "kernel_ms": 1e3 * kern_s,
+                         "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(patch, 0),
+                         "peak_note": "157.3 TFLOP/s is the packed-FMA fp32 peak; bit-parity forbids contraction, so separate mul / add reach at most half of it (v_pk_mul_f32 / v_pk_add_f32) — see `valu.sustain_loop.issue_rate_frac_est` for the fraction of VALU ISSUE slots used",
+                         "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
+                                 "algorithmic_bytes": "sounding voices x (80 B record read + 32 B written back) + the [2][256] block; a silent voice costs its 4-byte flag word (not counted)"},
                          "valu": {"achieved_tflops_est": flops, "peak_tflops": FP32_PEAK_TFLOPS, "frac": flops / FP32_PEAK_TFLOPS,
                                   "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(patch, 0)}},
         }
@@ -529,6 +596,14 @@ def main():
                 print(f"bench.py: reference baseline unavailable ({e}); reporting the port", file=sys.stderr)
                 ref = None
             out["cpu_baseline"] = dict(ref, port_value=port["value"], port_sample=port["sample"]) if ref else port
+            if ref:                                                          # the same sample on every physical core the job may use, at once
+                try:
+                    node = cpu_reference_node(patch, N, ref["blocks"])
+                except Exception as e:                                      # noqa: BLE001
+                    print(f"bench.py: node baseline unavailable ({e})", file=sys.stderr)
+                    node = None
+                if node:
+                    out["cpu_baseline"]["node"] = node
         print(json.dumps(out))
     if world > 1:
         script.close(); sharded.close()

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -45,10 +46,14 @@ extern "C" int klg_version(void) { return 100; }
 // shifts the rand() sequence).  The reference's patches use that same global stream on the host (klang::random /
 // SuperSaw.k:17), so every entry point that may initialise the runtime or allocate runs under this guard: it parks
 // the caller's generator state and restores it on exit (rand() and random() share state in glibc).
+// (The generator state is process-wide: guards of two host threads must not interleave — the second would park the FIRST guard's
+// temporary buffer as "the caller's state" and put it back after that buffer is gone.  One guard at a time, re-entrant per thread.)
 struct RandGuard {
 	char buf[128]; char* prev;
-	RandGuard() { prev = initstate(1u, buf, sizeof buf); }
-	~RandGuard() { if (prev) setstate(prev); }
+	static std::recursive_mutex& mu() { static std::recursive_mutex m; return m; }
+	RandGuard() { mu().lock(); prev = initstate(1u, buf, sizeof buf); }
+	~RandGuard() { if (prev) setstate(prev); mu().unlock(); }
+	RandGuard(const RandGuard&) = delete; RandGuard& operator=(const RandGuard&) = delete;
 };
 
 // the default device, resolved once (-1 + error: no GPU, and no CPU fallback)

@@ -126,7 +126,7 @@ def test_effect_bank_is_sharded_by_instance(patch):
     contiguous ranges (uneven: 70 instances over 2 / 3 shards); per-instance controls reach the owning shard; the result equals the
     single-device bank bit for bit; the device entry refuses loudly (a device block lives on one GPU)."""
     import klang_amd
-    K, N, B = 70, 128, 6
+    K, N, B = (70, 128, 6) if patch == "pingpong" else (70, 256, 14)      # (Reverb.k's first early reflection arrives after 50 ms = 2,400 samples)
     rng = np.random.default_rng(3)
     x = rng.uniform(-0.5, 0.5, size=(B, K, 2, N)).astype(np.float32)
     x[3:] = 0
@@ -156,7 +156,7 @@ def test_effect_bank_is_sharded_by_instance(patch):
             got, back = run(devs)
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), devs
             assert back == ref_back
-        assert np.abs(ref[4]).max() > 1e-4
+        assert np.abs(ref[-1]).max() > 1e-4                                   # the input stopped after block 2: what sounds now came out of the rings
     finally:
         klang_amd.init([0])
 
