@@ -66,8 +66,41 @@ template<uint32_t YBITS> __device__ __forceinline__ float div_const(float x) {
 }
 
 // ---- Generators::Fast helpers ----
-__device__ __forceinline__ uint32_t fast_phase(float radians) {          // Fast::Phase::operator= klang.h:4993-4998
-	return f2u_wrap(radians * KLG_FINTMAX / KLG_TWO_PI);
+// Fast::Phase::operator=(float radians) klang.h:4993-4998: position = (uint32_t)(int64_t)(radians * FINTMAX / twoPi), the float -> unsigned
+// wrap of F3 (f2u_wrap).  Written here WITHOUT the IEEE division expansion (11 operations) and the 64-bit conversion (10): with
+// n = radians * FINTMAX, r = RN(1 / twoPi):  q = n * r;  e = fma(-twoPi, q, n);  q2 = fma(e, r, q)  is the IEEE quotient wherever the
+// conversion can see it (quotients of magnitude [1, 2^63); anything smaller truncates to 0, anything larger — infinities, NaN — wraps to
+// 0 either way), and the low word of trunc(|q2|) is cvt_u32(|q2| - floor(|q2| * 2^-32) * 2^32) (exact: one fma; v_cvt_u32_f32 truncates,
+// and gives 0 for the NaN that an infinite q2 leaves), negated for a negative q2.  tools/verify_fast_phase.c compares this composition
+// with f2u_wrap(n / twoPi) on ALL 2^32 floats n: 0 mismatches (the 3-operation quotient by itself differs from IEEE on 3.4 M of them —
+// all outside the range the conversion looks at).  10 VALU operations where the plain form has 23.
+__device__ __forceinline__ uint32_t cvt_u32_trunc(float x) { uint32_t u; asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(u) : "v"(x)); return u; }   // (the C cast is undefined for NaN; the instruction is not)
+__device__ __forceinline__ uint32_t fast_phase(float radians) {
+	const float n = radians * KLG_FINTMAX;
+	constexpr float r = 1.0f / KLG_TWO_PI;
+	const float q = n * r;
+	const float e = __builtin_fmaf(-KLG_TWO_PI, q, n);
+	const float q2 = __builtin_fmaf(e, r, q);
+	const float a = __builtin_fabsf(q2);
+	const float hi = __builtin_floorf(a * 2.3283064365386963e-10f);         // 2^-32
+	const float lo = __builtin_fmaf(hi, -4294967296.0f, a);
+	const uint32_t u = cvt_u32_trunc(lo);
+	const uint32_t s = (uint32_t)((int32_t)__float_as_uint(q2) >> 31);
+	return (u ^ s) - s;
+}
+// ... of two values at once (packed multiplies / fmas)
+__device__ __forceinline__ u2 fast_phase(f2 radians) {
+	const f2 n = radians * KLG_FINTMAX;
+	constexpr float r = 1.0f / KLG_TWO_PI;
+	const f2 q = n * r;
+	const f2 e = __builtin_elementwise_fma(splat(-KLG_TWO_PI), q, n);
+	const f2 q2 = __builtin_elementwise_fma(e, splat(r), q);
+	const f2 a = __builtin_elementwise_abs(q2);
+	const f2 hi = __builtin_elementwise_floor(a * 2.3283064365386963e-10f);
+	const f2 lo = __builtin_elementwise_fma(hi, splat(-4294967296.0f), a);
+	u2 u = { cvt_u32_trunc(lo.x), cvt_u32_trunc(lo.y) };
+	const u2 s = __builtin_bit_cast(u2, __builtin_bit_cast(i2, q2) >> 31);
+	return (u ^ s) - s;
 }
 __device__ __forceinline__ float fast_phase_float(uint32_t pos) {        // Fast::Phase::operator float 5004-5007
 	return u2f(phase_mantissa<0x7Fu>(pos)) - 1.f;
@@ -79,11 +112,22 @@ __device__ __forceinline__ float polysin(float x) {                      // klan
 	const float x2 = x * x;
 	return (((-0.00018542f * x2 + 0.0083143f) * x2 - 0.16666f) * x2 + 1.0f) * x;
 }
-__device__ __forceinline__ float fastsinp(uint32_t p) {                  // klang.h:5117-5132 (+ fast_modp 1424-1428)
-	float x = (u2f(phase_mantissa<0x7Fu>(p)) - 1.f) * KLG_TWO_PI;
-	if (x > KLG_3HALF_PI) x -= KLG_TWO_PI;
-	else if (x > KLG_HALF_PI) x = KLG_PI_F - x;
-	return polysin(x);
+// fastsinp klang.h:5117-5132 (+ fast_modp 1424-1428).  The quadrant fold `if (x > 3pi/2) x -= 2pi; else if (x > pi/2) x = pi - x;` of an
+// angle in [0, 2pi) is the MEDIAN of { x, pi - x, x - 2pi } — ordered (x-2pi, x, pi-x) in the first quadrant, (x-2pi, pi-x, x) in the middle
+// two, (pi-x, x-2pi, x) in the last — : one v_med3_f32 instead of two compares and two selects (or exec-masked branches), bit for bit on
+// all 2^23 phase mantissas (tools/verify_fastsinp_med3.c).
+__device__ __forceinline__ float fold_quadrant(float x) { return __builtin_amdgcn_fmed3f(x, KLG_PI_F - x, x - KLG_TWO_PI); }
+__device__ __forceinline__ float fastsinp(uint32_t p) {
+	const float x = (u2f(phase_mantissa<0x7Fu>(p)) - 1.f) * KLG_TWO_PI;
+	return polysin(fold_quadrant(x));
+}
+// ... of two phases at once (two voices of a lane, or two consecutive samples of one voice): the polynomial as packed operations
+__device__ __forceinline__ f2 polysin(f2 x) { const f2 x2 = x * x; return (((-0.00018542f * x2 + 0.0083143f) * x2 - 0.16666f) * x2 + 1.0f) * x; }
+__device__ __forceinline__ f2 fastsinp(u2 p) {
+	const f2 x = (phase_float2<0x7Fu>(p) - 1.f) * KLG_TWO_PI;
+	const f2 a = KLG_PI_F - x, b = x - KLG_TWO_PI;                     // (packed), then the median per half
+	f2 r; r.x = __builtin_amdgcn_fmed3f(x.x, a.x, b.x); r.y = __builtin_amdgcn_fmed3f(x.y, a.y, b.y);
+	return polysin(r);
 }
 
 // ---- Generators::Fast::Sine klang.h:5135-5172 (lane state: inc, pos; offset only lives inside a sample) ----

@@ -38,12 +38,7 @@ __device__ __forceinline__ i2 env_is_off(i2 stage) { return stage == (int)ENV_OF
 
 // ---- Generators::Fast::Sine klang.h:5093-5172 ----
 struct FSine2 { i2 inc; u2 pos; };
-__device__ __forceinline__ f2 polysin(f2 x) { const f2 x2 = x * x; return (((-0.00018542f * x2 + 0.0083143f) * x2 - 0.16666f) * x2 + 1.0f) * x; }
-__device__ __forceinline__ f2 fastsinp(u2 p) {
-	f2 x = (phase_float2<0x7Fu>(p) - 1.f) * KLG_TWO_PI;
-	x = (x > KLG_3HALF_PI) ? (x - KLG_TWO_PI) : ((x > KLG_HALF_PI) ? (KLG_PI_F - x) : x);
-	return polysin(x);
-}
+// (polysin(f2), fastsinp(u2): klg_device.hpp)
 __device__ __forceinline__ f2 fsine_process(FSine2& o, u2 off) { const f2 y = fastsinp(o.pos + off); o.pos += to_u(o.inc); return y; }
 __device__ __forceinline__ f2 fsine_process(FSine2& o, uint32_t off) { u2 v = { off, off }; return fsine_process(o, v); }
 

@@ -83,6 +83,11 @@ template<class P> struct WavesPerEu<P, klg_void_t<decltype(P::kWavesPerEu)>> { s
 template<class P, class = void> struct HasQuiet { static constexpr bool value = false; };
 template<class P> struct HasQuiet<P, klg_void_t<decltype(P::kHasQuiet)>> { static constexpr bool value = P::kHasQuiet; };
 
+// a patch may render TWO consecutive samples of an event-free chunk at once (`static constexpr bool kHasFast2`, `f2 sample_fast2(L, ctx)`:
+// packed operations across the sample pair, PatchFM)
+template<class P, class = void> struct HasFast2 { static constexpr bool value = false; };
+template<class P> struct HasFast2<P, klg_void_t<decltype(P::kHasFast2)>> { static constexpr bool value = P::kHasFast2; };
+
 // a patch whose sample() returns both channels of a Stereo::Note's `out` (Out2): `static constexpr bool kStereo = true`
 template<class P, class = void> struct IsStereo { static constexpr bool value = false; };
 template<class P> struct IsStereo<P, klg_void_t<decltype(P::kStereo)>> { static constexpr bool value = P::kStereo; };
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		ctx.ring = a.rings ? a.rings + (size_t)(live ? (size_t)v : a.stride) * a.ring_rows : nullptr;
 		ctx.ctl = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
 		ctx.rand = a.rand ? a.rand + (live ? a.rand_base[v] : 0) : nullptr;
+		ctx.rec = a.state + v; ctx.stride = a.stride;             // (v < stride always: a lane without a voice points at padding or at an Off voice's words, and nothing it computes is kept)
 		// Dead lanes of a live wave run the same instruction stream on an all-zero record (no per-sample exec
 		// masking); their output is forced to 0 at the tile write and their record is never stored.
 		rw.w[0] = live ? flags : (uint32_t)ST_OFF;                  // (a lane without a voice: an all-zero record whose note stage says Off)
@@ -147,7 +153,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 				else tile[s * TILE_LD + lane] = in_tile ? y : 0.f;
 			};
 			if (quiet == 2) {
-				if constexpr (HasQuiet<P>::value)
+				if constexpr (HasFast2<P>::value) {
+					int s = 0;
+					if constexpr (P::kFastN > 2) {
+						constexpr int PAIRS = P::kFastN / 2;
+						for (; s + 2 * PAIRS <= cl; s += 2 * PAIRS) {
+							f2 y[PAIRS]; P::template sample_fast_pairs<PAIRS>(L, y);
+#pragma unroll
+							for (int j = 0; j < PAIRS; j++) { put(s + 2 * j, y[j].x); put(s + 2 * j + 1, y[j].y); }
+						}
+					}
+					for (; s + 1 < cl; s += 2) { const f2 y = P::sample_fast2(L, ctx); put(s, y.x); put(s + 1, y.y); }
+					if (s < cl) put(s, P::sample_fast(L, ctx));
+				}
+				else if constexpr (HasQuiet<P>::value)
 					for (int s = 0; s < cl; s++) put(s, P::sample_fast(L, ctx));
 			}
 			else if (quiet == 1) {

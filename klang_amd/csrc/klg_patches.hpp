@@ -28,7 +28,18 @@ struct BlockCtx {
 	const TableDesc* tables; // klg_table_upload()ed sample tables (graph patches with Wavetable / Table reads), else null
 	float* ring;             // this voice's note-delay lines (contiguous), else null
 	const int* rand;         // this voice's rand() draws of the block, [n][draws per sample] (a generated patch with Noise generators), else null
+	const uint32_t* rec;     // this voice's record in HBM: word w at rec[w * stride] (what a patch reads only when a segment ends need not sit in registers: PtsLazy*)
+	size_t stride;
 };
+
+// Breakpoints read from the voice's record when (and only when) a segment ends: envelope points are constants of a note and
+// env_segment_end is rare, so they are L2 reads there instead of registers held through every sample.  x(i) / y(i) as Pts2 / Pts3.
+struct PtsLazy2 { const uint32_t* px; size_t stride;                              // px: the record word of px[0]; px[1], py[0], py[1] follow
+	__device__ __forceinline__ float x(int i) const { return u2f(px[(size_t)(i == 1 ? 1 : 0) * stride]); }
+	__device__ __forceinline__ float y(int i) const { return u2f(px[(size_t)(i == 1 ? 3 : 2) * stride]); } };
+struct PtsLazyAdsr { const uint32_t* a; size_t stride;                            // a: the record word of AdsrRec::A; AD, S follow — points (0,0) (A,1) (AD,S)
+	__device__ __forceinline__ float x(int i) const { return i == 0 ? 0.f : u2f(a[(size_t)(i == 2 ? 1 : 0) * stride]); }
+	__device__ __forceinline__ float y(int i) const { return i == 0 ? 0.f : (i == 1 ? 1.f : u2f(a[(size_t)2 * stride])); } };
 
 // ---------------------------------------------------------------------------------------------
 // helpers shared by the patch bodies
@@ -289,38 +300,46 @@ struct PatchFM {
 	using Rec = rec::FM<NOPS>;
 	static constexpr uint64_t op_mask(int k) { return words(8 + 40 * (size_t)k + 4, 5); }   // pos, r_out, r_target, r_rate, time of operator k
 	static constexpr uint64_t kStoreMask = 1ull | op_mask(0) | op_mask(1) | op_mask(2) | (NOPS > 3 ? op_mask(3) : 0ull) | words(8 + 40 * (size_t)NOPS, 4);
-	struct Op { FSine osc; Env env; Pts2 p; int np; float amp; };
-	struct Live { Op op[NOPS]; Adsr adsr; int stage; float step[NOPS + 1], tstep[NOPS + 1], tinc; };   // step / tstep: see quiet()
+	// (breakpoints, point counts and the ADSR's times are read from the record when a segment ends — PtsLazy2 / PtsLazyAdsr —: 23 registers
+	//  fewer through the sample loops, 4 waves per SIMD instead of 3)
+#ifdef KLG_FM_WAVES
+	static constexpr int kWavesPerEu = KLG_FM_WAVES;
+#endif
+	struct Op { FSine osc; Env env; float amp; };
+	struct Live { Op op[NOPS]; Env adsr; int stage; uint32_t meta; float step[NOPS + 1], tstep[NOPS + 1], tinc; };   // step / tstep: see quiet()
+	static constexpr int kOpWord0 = 2, kOpWords = 10, kAdsrWord0 = 2 + 10 * NOPS;      // rec::FM<NOPS> in words: flags, meta, op[NOPS], adsr
+	static __device__ __forceinline__ PtsLazy2 op_pts(const BlockCtx& c, int k) { return PtsLazy2{ c.rec + (size_t)(kOpWord0 + kOpWords * k + 6) * c.stride, c.stride }; }
+	static __device__ __forceinline__ PtsLazyAdsr adsr_pts(const BlockCtx& c) { return PtsLazyAdsr{ c.rec + (size_t)(kAdsrWord0 + 4) * c.stride, c.stride }; }
 	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx& c) {
 		L.tinc = c.fs.timeInc;
 		L.stage = (int)(r.flags & 3u);
-		adsr_load(L.adsr, r.adsr, KLG_FLAG_GET(r.flags, 2, 6));
+		L.meta = r.meta;
+		L.adsr.r_out = r.adsr.r_out; L.adsr.r_target = r.adsr.r_target; L.adsr.r_rate = r.adsr.r_rate; L.adsr.time = r.adsr.time;
+		env_unpack(L.adsr, KLG_FLAG_GET(r.flags, 2, 6));
 #pragma unroll
 		for (int k = 0; k < NOPS; k++) {
 			Op& o = L.op[k]; const OpRec& q = r.op[k];
 			o.osc.inc = q.inc; o.osc.pos = q.pos;
 			o.env.r_out = q.r_out; o.env.r_target = q.r_target; o.env.r_rate = q.r_rate; o.env.time = q.time;
 			env_unpack(o.env, KLG_FLAG_GET(r.flags, 8 + 6 * k, 6));
-			o.p.x0 = q.px[0]; o.p.x1 = q.px[1]; o.p.y0 = q.py[0]; o.p.y1 = q.py[1];
-			o.np = (int)KLG_FLAG_GET(r.meta, 2 * k, 2);
 			// `op * I` sets amp every sample from controls[1 + k] (FM.k:64-68); the last operator keeps amp = 1
 			o.amp = (k < NOPS - 1) ? c.ctl[1 + k] : 1.f;
 		}
 	}
 	// Operator::process klang.h:4164-4168
-	static __device__ __forceinline__ float op_process(Op& o, float in, const BlockCtx& c) {
+	static __device__ __forceinline__ float op_process(Op& o, int k, uint32_t meta, float in, const BlockCtx& c) {
 		const uint32_t off = fsine_rel_offset(in);                 // OSCILLATOR::set(+in)
 		float y = fsine_process(o.osc, off);
-		y *= env_process<2, false>(o.env, o.p, o.np, c.fs) * o.amp;
+		y *= env_process<2, false>(o.env, op_pts(c, k), (int)KLG_FLAG_GET(meta, 2 * k, 2), c.fs) * o.amp;
 		return y;
 	}
 	static __device__ __forceinline__ float sample(Live& L, const BlockCtx& c) {
 		float m = 0.f;
 #pragma unroll
-		for (int k = 0; k < NOPS; k++) m = op_process(L.op[k], m, c);
+		for (int k = 0; k < NOPS; k++) m = op_process(L.op[k], k, L.meta, m, c);
 		float out = m;
-		out *= adsr_process(L.adsr, c.fs) * 0.1f;
-		L.stage = (L.adsr.e.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
+		out *= env_process<3, true>(L.adsr, adsr_pts(c), 3, c.fs) * 0.1f;      // adsr_process
+		L.stage = (L.adsr.stage == ENV_OFF) ? (int)ST_OFF : L.stage;
 		return out;
 	}
 	// event-free chunks (see env_safe above): the five envelopes glide
@@ -329,7 +348,7 @@ struct PatchFM {
 		bool safe = true;
 #pragma unroll
 		for (int k = 0; k < NOPS; k++) safe = env_safe(L.op[k].env, false, L.step[k], L.tstep[k], L.tinc) && safe;
-		safe = env_safe(L.adsr.e, L.adsr.e.point == 2, L.step[NOPS], L.tstep[NOPS], L.tinc) && safe;
+		safe = env_safe(L.adsr, L.adsr.point == 2, L.step[NOPS], L.tstep[NOPS], L.tinc) && safe;
 		const bool sounding = L.stage != (int)ST_OFF;                      // (a lane without a voice, or whose note has ended, is heard by nobody: it does not veto)
 		return __ballot(sounding && !safe) == 0ull ? 2 : 0;
 	}
@@ -343,12 +362,55 @@ struct PatchFM {
 			m = y;
 		}
 		float out = m;
-		out *= env_glide(L.adsr.e, L.step[NOPS], L.tstep[NOPS]) * 0.1f;
+		out *= env_glide(L.adsr, L.step[NOPS], L.tstep[NOPS]) * 0.1f;
 		return out;
 	}
 	static __device__ __forceinline__ float sample_quiet(Live& L, const BlockCtx& c) { return sample(L, c); }   // (level 1 is not used by this patch)
+	// TWO consecutive samples of an event-free chunk, side by side in the halves of 2-vectors (klg_render: HasFast2).  Nothing of a sample
+	// depends on the sample before it except the oscillator positions (closed form: pos, pos + inc) and the gliding envelopes (two additions
+	// each, taken in order), so the operator chain of sample s + 1 runs beside that of sample s: sine polynomial, envelope and amp products,
+	// the modulation's Fast::Phase — as v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32.  Same operations per sample, same bits.
+	// kFastN samples per call: kFastN / 2 INDEPENDENT pair chains — a bank of config 5's size gives a SIMD two waves, and one chain is a
+	// serial dependence from the first operator's phase to the output (every packed operation waiting for the one before it); a second
+	// chain fills those slots.
+	static constexpr bool kHasFast2 = true;
+#ifndef KLG_FM_FASTN
+#define KLG_FM_FASTN 4
+#endif
+	static constexpr int kFastN = KLG_FM_FASTN;
+	template<int PAIRS>
+	static __device__ __forceinline__ void sample_fast_pairs(Live& L, f2 (&out)[PAIRS]) {
+		f2 m[PAIRS];
+#pragma unroll
+		for (int j = 0; j < PAIRS; j++) m[j] = splat(0.f);
+#pragma unroll
+		for (int k = 0; k < NOPS; k++) {
+			Op& o = L.op[k];
+			const uint32_t inc = (uint32_t)o.osc.inc;
+			const float st = L.step[k], ts = L.tstep[k];
+#pragma unroll
+			for (int j = 0; j < PAIRS; j++) {
+				u2 pos = { o.osc.pos, o.osc.pos + inc };
+				o.osc.pos += 2u * inc;
+				if (k > 0) pos += fast_phase(m[j] * KLG_TWO_PI);               // OSCILLATOR::set(+in): fsine_rel_offset (operator 0 is not modulated: offset 0)
+				f2 y = fastsinp(pos);
+				f2 ev; ev.x = o.env.r_out; ev.y = ev.x + st; o.env.r_out = ev.y + st;      // two steps of env_glide
+				o.env.time = (o.env.time + ts) + ts;
+				y *= ev * o.amp;
+				m[j] = y;
+			}
+		}
+		const float st = L.step[NOPS], ts = L.tstep[NOPS];
+#pragma unroll
+		for (int j = 0; j < PAIRS; j++) {
+			f2 av; av.x = L.adsr.r_out; av.y = av.x + st; L.adsr.r_out = av.y + st;
+			L.adsr.time = (L.adsr.time + ts) + ts;
+			out[j] = m[j] * (av * 0.1f);
+		}
+	}
+	static __device__ __forceinline__ f2 sample_fast2(Live& L, const BlockCtx&) { f2 y[1]; sample_fast_pairs<1>(L, y); return y[0]; }
 	static __device__ __forceinline__ void end(const Live& L, Rec& r) {
-		uint32_t f = (uint32_t)L.stage | (env_pack(L.adsr.e) << 2);
+		uint32_t f = (uint32_t)L.stage | (env_pack(L.adsr) << 2);
 #pragma unroll
 		for (int k = 0; k < NOPS; k++) {
 			const Op& o = L.op[k]; OpRec& q = r.op[k];
@@ -356,7 +418,7 @@ struct PatchFM {
 			q.r_out = o.env.r_out; q.r_target = o.env.r_target; q.r_rate = o.env.r_rate; q.time = o.env.time;
 			f |= env_pack(o.env) << (8 + 6 * k);
 		}
-		adsr_store(L.adsr, r.adsr);
+		r.adsr.r_out = L.adsr.r_out; r.adsr.r_target = L.adsr.r_target; r.adsr.r_rate = L.adsr.r_rate; r.adsr.time = L.adsr.time;
 		r.flags = f;
 	}
 	static __device__ __forceinline__ void release(Rec& r, float fs) {
