@@ -11,6 +11,14 @@
 namespace klg {
 
 // ---- Delay<SIZE> on an interleaved ring (klang.h:3381-3512) ----
+// THE PAD ELEMENT.  klang's Delay<SIZE> owns SIZE + 1 floats (`buffer(SIZE + 1, 0)`, klang.h:3391) and writes SIZE of them: element SIZE stays
+// 0 for ever.  It IS read, rarely: `read = (position - 1) - time; if (read < 0) read += SIZE;` is float arithmetic, and a `read` within half an
+// ulp below zero rounds to exactly SIZE (at SIZE = 192000 that is one cursor position in ~130 per crossing of the tap over the ring's start) —
+// the tap then takes buffer[SIZE] = 0 and buffer[(SIZE + 1) % SIZE] = buffer[1], and a walking read head continues at 1.  Every line here
+// therefore has SIZE + 1 elements as well (the pad is never written: zero-filled at creation), a Tap::position may be SIZE, and the successor
+// of index i is (i + 1) mod SIZE for 0 <= i <= SIZE — ring_succ below (two operations: the unsigned minimum of j and j - SIZE).
+// (Found by tests/test_gpu_fx.py::test_pingpong_with_stationary_controls: one of twenty instances hit that cursor position.)
+__device__ __forceinline__ int ring_succ(int i, int size) { const unsigned j = (unsigned)i + 1u; const unsigned w = j - (unsigned)size; return (int)(j < w ? j : w); }
 struct Ring {
 	float* base;          // this wave's column: &rings[line][0][k]
 	size_t stride;        // Kpad
@@ -28,7 +36,7 @@ __device__ __forceinline__ Tap delay_set(int position, int size, float samples) 
 }
 __device__ __forceinline__ float delay_process(const Ring& r, Tap& t) {               // tap() 3461-3468 + process 3470-3473
 	const int i = t.position;
-	const int j = (i + 1 == r.size) ? 0 : i + 1;                                      // (i + 1) % SIZE for 0 <= i < SIZE
+	const int j = ring_succ(i, r.size);                                               // (i + 1) % SIZE for 0 <= i <= SIZE (i == SIZE: the pad element)
 	const float a = r.rd(i), b = r.rd(j);
 	const float out = a + t.fraction * (b - a);
 	t.position = j;
@@ -39,6 +47,7 @@ __device__ __forceinline__ float delay_process(const Ring& r, Tap& t) {         
 __device__ __forceinline__ float delay_tap_int(const Ring& r, int position, int delay) {
 	int read = (position - 1) - delay;
 	if (read < 0) read += r.size;
+	read = read < 0 ? r.size : (read > r.size ? r.size : read);                       // a tap outside the line (delay < 0 or > SIZE: undefined in the reference) reads the pad, not a neighbour's line
 	return r.rd(read);
 }
 __device__ __forceinline__ float delay_tap_float(const Ring& r, int position, float delay) {

@@ -74,6 +74,7 @@ __device__ __forceinline__ void io_store_chunk(const float* tile, float* io, int
 // PingPong.k
 // =================================================================================================
 enum { PP_C0 = 0, PP_SM1 = 6, PP_SM5 = 7, PP_DELAY = 8, PP_LFO_POS = 9, PP_LFO_INC = 10, PP_Z = 11, PP_WORDS = 15 };
+enum { PP_SIZE = 192000, PP_ROWS = PP_SIZE + 1 };   // Delay<192000>: rows per line in HBM = SIZE + the pad row (klg_delay.hpp)
 
 struct PingPongArgs {
 	float* state; size_t kpad; int K;
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 	BOsc lfo; lfo.position = st[PP_LFO_POS]; lfo.increment = st[PP_LFO_INC]; lfo.offset = 0.f;
 	Biquad dcl = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, st[PP_Z + 0], st[PP_Z + 1] };
 	Biquad dcr = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, st[PP_Z + 2], st[PP_Z + 3] };
-	float* tile0 = a.rings + (size_t)blockIdx.x * 2 * SIZE * FX_WG + lane;               // this wave's ring tile
-	Ring left = { tile0, FX_WG, SIZE }, right = { tile0 + (size_t)SIZE * FX_WG, FX_WG, SIZE };
+	float* tile0 = a.rings + (size_t)blockIdx.x * 2 * PP_ROWS * FX_WG + lane;            // this wave's ring tile: [2][SIZE + 1][64] (row SIZE: the pad, klg_delay.hpp)
+	Ring left = { tile0, FX_WG, SIZE }, right = { tile0 + (size_t)PP_ROWS * FX_WG, FX_WG, SIZE };
 	int position = a.position;
 	// loop invariants of process() PingPong.k:44-60 (controls 0, 2, 3, 4, 5 only change between blocks)
 	const float rate = (c3 * c3) * 100.f;                                       // sqr(controls[3]) * 100.f
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 #pragma unroll
 				for (int u = 0; u < PP_SUB; u++) {
 					if (u < ul) {
-						const int i0 = tl[u].position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
-						const int j0 = tr[u].position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
+						const int i0 = tl[u].position, i1 = ring_succ(i0, SIZE), i2 = ring_succ(i1, SIZE);
+						const int j0 = tr[u].position, j1 = ring_succ(j0, SIZE), j2 = ring_succ(j1, SIZE);
 						if (a.ablate & 1) { pl[u][0] = pl[u][1] = pl[u][2] = 0.f; pr[u][0] = pr[u][1] = pr[u][2] = 0.f; }
 						else {
 							pl[u][0] = left.rd(i0); pl[u][1] = left.rd(i1); pl[u][2] = left.rd(i2);
@@ -277,13 +278,24 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		vibrato = (c2 * c2) * rate * 1.41421354f;                                  // sqr(controls[2]) * rate * root2
 		any_vibrato = __ballot(vibrato != 0.f) != 0ull;
 	}
+	// STATIONARY controls: once both smoothers sit at their fp32 fixed points (x * 0.999f + (1.f - 0.999f) * v == x: some ten thousand samples
+	// after a dial last moved), no scratch is detected and there is no vibrato, every sample of the block leaves sm5, mdelay (= controls[5]),
+	// controls[1] and sm1 exactly as it found them: the delay time of every sample IS sm1.  The serial chain that otherwise paces the pipeline
+	// (~16 dependent operations per sample on one wave: 2.3 k of a step's 4.0 k cycles) is then not run at all — the control wave fills both
+	// delay-time buffers once and only walks the LFO's phase (which nothing waits for).  Checked per block, wave-uniform, on the values themselves.
+	bool stationary = false;
+	if (w_control && !any_vibrato) {
+		const float k5 = (1.f - 0.999f) * c5;
+		const bool fixed = (sm5 * 0.999f + k5 == sm5) && !(fabsf(mdelay - sm5) >= 0.001f) && !(fabsf(c5 - sm5) >= 0.001f) && (sm1 * 0.999f + (1.f - 0.999f) * c1 == sm1);
+		stationary = __ballot(!fixed) == 0ull;
+	}
 	// ---- audio wave state ----
 	float gain = 0.f, dry = 0.f;
 	if (w_audio) { gain = PPW(0); dry = PPW(4); }
-	float* ring0 = a.rings + (size_t)(k0 / FX_WG) * 2 * SIZE * FX_WG;              // this workgroup's ring tile: [2][SIZE][64] (G < 64: its 64-instance group's)
+	float* ring0 = a.rings + (size_t)(k0 / FX_WG) * 2 * PP_ROWS * FX_WG;           // this workgroup's ring tile: [2][SIZE + 1][64] (G < 64: its 64-instance group's; row SIZE: the pad, klg_delay.hpp)
 	const unsigned lane4 = (unsigned)((k0 & (FX_WG - 1)) + li) * 4u, ROW = FX_WG * 4u;
-	auto ring_rd = [&](int line, int i) { return *(const float*)((const char*)(ring0 + (size_t)line * SIZE * FX_WG) + ((unsigned)i * ROW + lane4)); };
-	auto ring_wr = [&](int line, int i, float v) { *(float*)((char*)(ring0 + (size_t)line * SIZE * FX_WG) + ((unsigned)i * ROW + lane4)) = v; };
+	auto ring_rd = [&](int line, int i) { return *(const float*)((const char*)(ring0 + (size_t)line * PP_ROWS * FX_WG) + ((unsigned)i * ROW + lane4)); };
+	auto ring_wr = [&](int line, int i, float v) { *(float*)((char*)(ring0 + (size_t)line * PP_ROWS * FX_WG) + ((unsigned)i * ROW + lane4)) = v; };
 	auto wrap = [&](int i) { return i >= SIZE ? i - SIZE : i; };
 	// ---- filter wave state: dcfilter[ch].set(50, 1)  PingPong.k:39-40 ----
 	const int fch = wv - (PPX_AUDIO + 1);
@@ -320,7 +332,19 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			float dmin = 3.0e38f, dmax = 0.f;                                         // range of the delay time over the chunk
 			lfo.increment = lfo_inc;
 			float (*D)[G] = S.D[jn & 1];
-			if (!any_vibrato) {
+			if (stationary) {
+				if (jn < 2) {                                                            // both buffers, once: every later chunk finds them as they are
+#pragma unroll 8
+					for (int u = 0; u < PPX_CHUNK; u++) D[u][li] = sm1;
+					dmin = dmax = sm1;
+				}
+				mdelay = c5;                                                             // (no scratch: `else delay = controls[5]`)
+				const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);                            // the LFO keeps running: Phase::operator+= klang.h:1518-1525
+				float pos = lfo.position;
+				for (int u = 0; u < ncl; u++) { const float p1 = pos + lfo_inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1; pos = inc_ok ? p2 : pos; }
+				lfo.position = pos;
+			}
+			else if (!any_vibrato) {
 				// No instance of the wave has vibrato (controls[2] == 0: `lfo * vibrato * 0.00005` is +-0, `controls[1] + (+-0)` is controls[1],
 				// which is already clamped): the LFO only advances its phase.  This serial chain — one wave, one dependent instruction after
 				// the other — paces the whole pipeline, so it is written without branches: ~16 operations per sample (it was ~45 with them).
@@ -366,9 +390,11 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				dmin = fminf(dmin, delay); dmax = fmaxf(dmax, delay);
 			}
 			// x -> 0.5f * x * fs and x -> x * fs are monotonic, so the extreme delays decide for the whole chunk
-			const bool far = 0.5f * dmin * a.fs.f >= (float)(PPX_CHUNK + 3) && dmax * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
-			const bool all_far = __ballot(k < a.K && !far) == 0ull;                 // padding lanes (zero state, zero delay) do not veto
-			if (lane == 0) S.far[jn & 1] = all_far ? 1 : 0;
+			if (!stationary || jn < 2) {
+				const bool far = 0.5f * dmin * a.fs.f >= (float)(PPX_CHUNK + 3) && dmax * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
+				const bool all_far = __ballot(k < a.K && !far) == 0ull;             // padding lanes (zero state, zero delay) do not veto
+				if (lane == 0) S.far[jn & 1] = all_far ? 1 : 0;
+			}
 		}
 		// ---------------- AUDIO of chunk j ----------------
 		if (w_audio && j >= 0 && j < nchunks) {
@@ -391,8 +417,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 						const int pos = wrap(pos0 + u);
 						tl[q] = delay_set(pos, SIZE, delay * a.fs.f);                   // left.set(delay * fs)
 						tr[q] = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);            // right.set(0.5f * delay * fs)
-						const int i0 = tl[q].position, i1 = (i0 + 1 == SIZE) ? 0 : i0 + 1, i2 = (i1 + 1 == SIZE) ? 0 : i1 + 1;
-						const int j0 = tr[q].position, j1 = (j0 + 1 == SIZE) ? 0 : j0 + 1, j2 = (j1 + 1 == SIZE) ? 0 : j1 + 1;
+						const int i0 = tl[q].position, i1 = ring_succ(i0, SIZE), i2 = ring_succ(i1, SIZE);   // (a tap may sit on the pad row SIZE: klg_delay.hpp)
+						const int j0 = tr[q].position, j1 = ring_succ(j0, SIZE), j2 = ring_succ(j1, SIZE);
 						pl[q][0] = ring_rd(0, i0); pl[q][1] = ring_rd(0, i1); pl[q][2] = ring_rd(0, i2);
 						pr[q][0] = ring_rd(1, j0); pr[q][1] = ring_rd(1, j1); pr[q][2] = ring_rd(1, j2);
 					}
@@ -416,7 +442,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			}
 			else if (wv == 1 && lane < G) {                                         // a near tap: the chunk is walked in order by one wave, lane = instance
 				const int col = (k0 & (FX_WG - 1)) + li;
-				Ring left = { ring0 + col, FX_WG, SIZE }, right = { ring0 + (size_t)SIZE * FX_WG + col, FX_WG, SIZE };
+				Ring left = { ring0 + col, FX_WG, SIZE }, right = { ring0 + (size_t)PP_ROWS * FX_WG + col, FX_WG, SIZE };
 				for (int u = 0; u < cl; u++) {
 					const float delay = S.D[j & 1][u][li];
 					const int pos = wrap(pos0 + u);
@@ -508,6 +534,7 @@ struct ReverbArgs {
 	int fpos;                   // FilteredDelay write cursor at block start (advances 2 per sample)
 	float* io; int n;
 	int layout;                 // 0: rings tiled per 64 instances, position-major rows (klg_fx_reverb16); 1: every (instance, line) its own contiguous ring (klg_fx_reverb_q)
+	float* early_sums;          // layout 1: [kpad][2][n] the block's early-reflection sums (klg_fx_reverb_early writes them, klg_fx_reverb_q<true> reads them), else null
 };
 
 struct FDelay { Biquad f; float in, gain; Tap last; Ring ring; };
@@ -935,7 +962,56 @@ template<int SET, int N> __device__ __forceinline__ void rvq_await(RvqRows& X) {
 	}
 }
 
+// =================================================================================================
+// Reverb.k, the early-reflection sums of a block as a kernel of their own (lane = sample)
+// =================================================================================================
+// Phase 1 of klg_fx_reverb_q depends on HISTORY only (every tap reads the early line further back than a block is long), i.e. on nothing the
+// recursive part of the same block computes.  Inside that kernel it runs on a wave that is alone on its SIMD (304 registers), with nothing to
+// hide its load and issue latencies behind: a third of the kernel's instructions at half the issue rate.  Here the same sums are a plain
+// data-parallel launch — one lane per (instance, sample), sixteen waves per SIMD at 4,096 instances, tap words in scalar registers (the instance
+// is uniform per workgroup) — and the recursive kernel starts from them (klg_fx_reverb_q<true> copies them into its LDS rows).  Same
+// operations in the same order as phase 1 / EarlyReflections::process (Reverb.k:90-92, klang.h:4668-4681): bit-identical sums.
+// Because the sums of block b depend on samples >= 45 ms old only, this launch may also run BESIDE the recursive kernel of block b - 1 (the host
+// puts it on a second stream): the waves of this kernel fill the issue slots the lone recursive wave of a SIMD leaves empty.
+enum { RVE_WG = 256 };
+__global__ __launch_bounds__(RVE_WG) void klg_fx_reverb_early(const ReverbArgs a) {
+	const int k = blockIdx.y, e = blockIdx.x * RVE_WG + threadIdx.x, n = a.n;
+	if (k >= a.K) return;
+	const size_t KP = a.kpad;
+	const float* W = a.state + k;                                           // (uniform: the tap words are scalar loads)
+	const int cnt = __float_as_int(W[(size_t)RV_ECOUNT * KP]);
+	const int epos0 = a.epos % RV_ESIZE;
+	const float* el = a.early_rings + (size_t)k * 2 * RV_ESTRIDE;
+	const float* er = el + RV_ESTRIDE;
+	int wpos = epos0 + e; if (wpos >= RV_ESIZE) wpos -= RV_ESIZE;           // the early write cursor of sample e (lanes past the block's end compute a valid position and drop the result)
+	const int pos = (wpos + 1 == RV_ESIZE) ? 0 : wpos + 1;                  // ... after Delay::input()
+	const float at = (float)(pos - 1);
+	typedef float rve_f2u __attribute__((ext_vector_type(2), aligned(4)));
+	rve_f2u l[20], r[20]; float fr[20];
+#pragma unroll
+	for (int d = 0; d < 20; d++) {                                          // every load in flight before the first product (a tap past `cnt` repeats tap 0's address and is not summed)
+		const float t = W[(size_t)(RV_ETIMES + (d < cnt ? d : 0)) * KP];
+		float read = at - t;
+		if (read < 0.f) read += RV_ESIZE;
+		fr[d] = read - floorf(read);
+		const int i0 = (int)read;                                           // i0 + 1 may be RV_ESIZE: the mirror tail holds position 0 there
+		l[d] = *reinterpret_cast<const rve_f2u*>(el + i0); r[d] = *reinterpret_cast<const rve_f2u*>(er + i0);
+	}
+	float accl = 0.f, accr = 0.f;
+#pragma unroll
+	for (int d = 0; d < 20; d++) {
+		const float omf = 1.f - fr[d];
+		const float pl = (l[d].x * omf + l[d].y * fr[d]) * W[(size_t)(RV_EGL + d) * KP];
+		const float pr = (r[d].x * omf + r[d].y * fr[d]) * W[(size_t)(RV_EGR + d) * KP];
+		accl = d < cnt ? accl + pl : accl;                                  // out += delay(times[d]) * gains[d], d < count
+		accr = d < cnt ? accr + pr : accr;
+	}
+	if (e < n) { a.early_sums[((size_t)k * 2) * n + e] = accl; a.early_sums[((size_t)k * 2 + 1) * n + e] = accr; }
+}
+
 // Launch shape: a workgroup is RVQ_WG / 64 independent waves that share nothing (no barrier, a private slice of the LDS tile each).
+// PRE: the early sums were computed by klg_fx_reverb_early (a.early_sums) — phase 1 is a copy into the LDS rows.
+template<bool PRE>
 __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	extern __shared__ float rvq_tiles[];
 	const int lane = threadIdx.x & 63, inst = lane >> 4, r = lane & 15;
@@ -971,7 +1047,25 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	// =========== phase 1: the early sums of the block, lane = sample ===========
 	// EarlyReflections::process Reverb.k:90-92 with Stereo::Delay::tap(float) klang.h:4668-4681 (both channels read at one cursor).
 	float* const r1_rows = rvq_tile + 9 * ns;
-	{
+	if constexpr (PRE) {
+		if (whole) {                                                            // [k0 .. k0 + 3][2][n]: one contiguous span, like the caller's block
+			const rvq_v4* src = reinterpret_cast<const rvq_v4*>(a.early_sums + (size_t)k0 * 2 * n);
+			rvq_v4* dst = reinterpret_cast<rvq_v4*>(r1_rows);
+			const int q4 = n >> 2;
+			for (int c0 = 0; c0 < 2 * n; c0 += 8 * 64) {
+				rvq_v4 x[8];
+#pragma unroll
+				for (int j = 0; j < 8; j++) { const int c = c0 + j * 64 + lane; x[j] = src[c < 2 * n ? c : 0]; }
+#pragma unroll
+				for (int j = 0; j < 8; j++) { const int c = c0 + j * 64 + lane; if (c < 2 * n) { const int R = c / q4; dst[R * (ns >> 2) + (c - R * q4)] = x[j]; } }
+			}
+		}
+		else for (int R = 0; R < 8; R++) {
+			const int ki = k0 + (R >> 1);
+			for (int c = lane; c < n; c += 64) r1_rows[R * ns + c] = (ki < a.K) ? a.early_sums[((size_t)ki * 2 + (R & 1)) * n + c] : 0.f;
+		}
+	}
+	else {
 		typedef float rvq_f2u __attribute__((ext_vector_type(2), aligned(4)));
 		struct Taps { rvq_f2u l[20], r[20]; float fr[20]; };                    // per tap: positions i0, i0 + 1 of both lines (one 8-byte load each) and the fraction
 		const int chunks = (n + 63) >> 6, groups = 4 * chunks;                  // a group = 64 consecutive samples of one instance

@@ -25,6 +25,10 @@ struct klg_fx {
 	host::Fs fs;
 	hipStream_t stream = nullptr;
 	float *d_state = nullptr, *d_rings = nullptr, *d_rings2 = nullptr, *d_io = nullptr;
+	// Reverb (layout 1): the block's early-reflection sums [kpad][2][max_block] (klg_fx_reverb_early -> klg_fx_reverb_q<true>), two buffers in turn:
+	// block b + 1's sums are computed on `early_stream` while block b's recursive kernel runs (they depend on samples >= 45 ms old only)
+	float* d_early[2] = { nullptr, nullptr }; unsigned early_turn = 0; bool upd_flushed = false;
+	hipStream_t early_stream = nullptr; hipEvent_t early_ready = nullptr, q_done[2] = { nullptr, nullptr }, upd_done = nullptr; bool q_used[2] = { false, false };
 	int* d_upd = nullptr; size_t d_upd_cap = 0;
 	unsigned long long samples = 0;                    // samples processed so far (defines every write cursor)
 	std::vector<host::ControlH> controls;              // [K][nctl]
@@ -51,7 +55,9 @@ static void fx_free(klg_fx* f) {
 	if (!f) return;
 	if (f->multi) { for (klg_fx* sh : f->multi->shard) { DeviceGuard bound(sh->device); fx_free(sh); } delete f->multi; delete f; return; }
 	if (f->stream) (void)hipStreamSynchronize(f->stream);
-	void* dev[] = { f->d_state, f->d_rings, f->d_rings2, f->d_io, f->d_upd, f->d_controls };
+	void* dev[] = { f->d_state, f->d_rings, f->d_rings2, f->d_io, f->d_upd, f->d_controls, f->d_early[0], f->d_early[1] };
+	if (f->early_stream) { (void)hipStreamSynchronize(f->early_stream); (void)hipStreamDestroy(f->early_stream); }
+	for (hipEvent_t e : { f->early_ready, f->q_done[0], f->q_done[1], f->upd_done }) if (e) (void)hipEventDestroy(e);
 	for (void* p : dev) if (p) (void)hipFree(p);
 	if (f->module) (void)hipModuleUnload(f->module);
 	for (auto e : f->tev) (void)hipEventDestroy(e);
@@ -130,13 +136,18 @@ static klg_fx* fx_create_on(int device, int patch_id, int instances, float sampl
 		f->rv_layout = instances <= RVQ_MAX_INSTANCES ? 1 : 0;
 		if (const char* e = getenv("KLG_FX_REVERB16")) { if (e[0] == '1') f->rv_layout = 0; else if (e[0] == '0') f->rv_layout = 1; }
 	}
-	const size_t ring1 = pp ? (size_t)2 * 192000 * f->kpad : (size_t)2 * RV_ESTRIDE * f->kpad;     // (Reverb: lines + the mirror tails of klg_fx_reverb_q)
+	const size_t ring1 = pp ? (size_t)2 * PP_ROWS * f->kpad : (size_t)2 * RV_ESTRIDE * f->kpad;     // (Reverb: lines + the mirror tails of klg_fx_reverb_q)
 	const size_t ring2 = pp ? 0 : (size_t)16 * RV_FSTRIDE * f->kpad;
 	bool ok = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) == hipSuccess;
 	ok = ok && hipMalloc(&f->d_state, (size_t)f->words * f->kpad * 4) == hipSuccess;
 	ok = ok && hipMalloc(&f->d_rings, ring1 * 4) == hipSuccess;
 	ok = ok && (ring2 == 0 || hipMalloc(&f->d_rings2, ring2 * 4) == hipSuccess);
 	ok = ok && hipMalloc(&f->d_io, (size_t)f->kpad * 2 * max_block * 4) == hipSuccess;
+	if (!pp && f->rv_layout) {
+		for (int i = 0; i < 2; i++) ok = ok && hipMalloc(&f->d_early[i], (size_t)f->kpad * 2 * max_block * 4) == hipSuccess && hipEventCreateWithFlags(&f->q_done[i], hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipStreamCreateWithFlags(&f->early_stream, hipStreamNonBlocking) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&f->early_ready, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&f->upd_done, hipEventDisableTiming) == hipSuccess;
+	}
 	ok = ok && hipMemset(f->d_state, 0, (size_t)f->words * f->kpad * 4) == hipSuccess;
 	ok = ok && hipMemset(f->d_rings, 0, ring1 * 4) == hipSuccess;                      // Delay() : buffer(SIZE + 1, 0)
 	ok = ok && (ring2 == 0 || hipMemset(f->d_rings2, 0, ring2 * 4) == hipSuccess);
@@ -311,6 +322,7 @@ static void rv_prepare(klg_fx* f, int k) {
 }
 
 static int fx_flush_updates(klg_fx* f, hipStream_t st) {
+	f->upd_flushed = !f->upd.empty();
 	if (f->upd.empty()) return 0;
 	{	// several updates of one word in a batch: the LAST one wins (the scatter kernel has no ordering)
 		std::stable_sort(f->upd.begin(), f->upd.end(), [](const FxUpdate& a, const FxUpdate& b) { return a.k != b.k ? a.k < b.k : a.word < b.word; });
@@ -422,13 +434,38 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		a.fpos = (int)((2ull * f->samples) % (unsigned long long)RV_FSIZE);
 		a.io = d_io; a.n = n;
 		static const bool single_wave = []() { const char* e = getenv("KLG_FX_REVERB1"); return e && e[0] == '1'; }();
-		a.layout = f->rv_layout;
+		a.layout = f->rv_layout; a.early_sums = nullptr;
 		// the production kernels request ring rows ahead of their use (reverb_q: 8 samples = 16 positions; reverb16: one sample): safe while the
 		// shortest line (7 ms * 0.9) is longer than that.  reverb_q also computes a block's early sums before the block's early-line writes:
 		// right while every tap reads further back than the block is long — the shortest tap is (50 ms + ...) * random(0.9, 1.1) > 44.9 ms.
 		const bool taps_behind_block = (float)(n + 2) < 0.0449f * f->fs.f;
 		if (single_wave || f->fs.f < 16000.f || (f->rv_layout && !taps_behind_block)) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);   // one lane walks the whole graph (A/B reference; either layout)
-		else if (f->rv_layout) hipLaunchKernelGGL(klg_fx_reverb_q, dim3((unsigned)((f->kpad + 4 * (RVQ_WG / 64) - 1) / (4 * (RVQ_WG / 64)))), dim3(RVQ_WG), (size_t)(RVQ_WG / 64) * (RVQ_TILE_ROWS * (((n + 3) & ~3) + 4) + RVQ_XQ_FLOATS) * sizeof(float), st, a);   // one wave per four instances
+		else if (f->rv_layout) {
+			const dim3 qgrid((unsigned)((f->kpad + 4 * (RVQ_WG / 64) - 1) / (4 * (RVQ_WG / 64))));
+			const size_t qlds = (size_t)(RVQ_WG / 64) * (RVQ_TILE_ROWS * (((n + 3) & ~3) + 4) + RVQ_XQ_FLOATS) * sizeof(float);
+			// KLG_FX_REVERB_EARLY: 0 = the early sums inside klg_fx_reverb_q (phase 1 of the lone wave; the round-2 form), 1 = klg_fx_reverb_early ahead of it on
+			// the same stream, 2 (default) = on a second stream, beside the previous block's recursive kernel
+			static const int early_mode = []() { const char* e = getenv("KLG_FX_REVERB_EARLY"); return e ? atoi(e) : 2; }();
+			if (early_mode == 0 || !f->d_early[0]) hipLaunchKernelGGL(klg_fx_reverb_q<false>, qgrid, dim3(RVQ_WG), qlds, st, a);   // one wave per four instances
+			else {
+				const unsigned turn = f->early_turn++ & 1u;
+				a.early_sums = f->d_early[turn];
+				const dim3 egrid((unsigned)((n + RVE_WG - 1) / RVE_WG), (unsigned)f->K);
+				if (early_mode == 1) hipLaunchKernelGGL(klg_fx_reverb_early, egrid, dim3(RVE_WG), 0, st, a);
+				else {
+					// The sums of this block read early-line samples >= 45 ms old (the host checked taps_behind_block) and the tap words.  They wait (a) for
+					// state updates flushed on `st` in THIS call (a dial moved: rare), (b) for the recursive kernel that last read this buffer (two blocks
+					// ago) — and for nothing else on `st`: in a stream of blocks they run beside the previous block's recursive kernel.
+					if (f->upd_flushed) { HIP_TRY(hipEventRecord(f->upd_done, st)); HIP_TRY(hipStreamWaitEvent(f->early_stream, f->upd_done, 0)); }
+					if (f->q_used[turn]) HIP_TRY(hipStreamWaitEvent(f->early_stream, f->q_done[turn], 0));
+					hipLaunchKernelGGL(klg_fx_reverb_early, egrid, dim3(RVE_WG), 0, f->early_stream, a);
+					HIP_TRY(hipEventRecord(f->early_ready, f->early_stream));
+					HIP_TRY(hipStreamWaitEvent(st, f->early_ready, 0));
+				}
+				hipLaunchKernelGGL(klg_fx_reverb_q<true>, qgrid, dim3(RVQ_WG), qlds, st, a);
+				if (early_mode != 1) { HIP_TRY(hipEventRecord(f->q_done[turn], st)); f->q_used[turn] = true; }
+			}
+		}
 		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances (KLG_FX_REVERB16=1)
 	}
 	HIP_TRY(hipGetLastError());

@@ -57,7 +57,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	for (const Op& o : g.ops) if (o.code == OP_SETCTL) ctlvar[o.imm & 7u] = o.node;
 	auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
 	std::vector<long long> ring_off(g.nodes.size(), 0); std::vector<int> inputs(g.nodes.size(), 0);   // Delay nodes: first row in the group's ring tile, inputs per sample
-	{ long long rows = 0; for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == N_DELAY || g.nodes[i] == N_NDELAY) { ring_off[i] = rows; rows += g.arg((int)i); } }
+	{ long long rows = 0; for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == N_DELAY || g.nodes[i] == N_NDELAY) { ring_off[i] = rows; rows += g.arg((int)i) + 1; } }   // SIZE + 1: the pad element (klg_delay.hpp)
 	for (const Op& o : g.ops) if (o.code == OP_DELAYIN) inputs[(size_t)o.node]++;
 	// effects: position-major rows of 64 instances (all instances share the cursor: one coalesced row per access).  notes: each voice's
 	// line is contiguous — voices start at different times and have different lengths, so their cursors never line up; a lane walking its
@@ -480,7 +480,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	Compiled c;
 	c.source = generate_source(g, x2);
 	c.words = g.words(); c.channels = g.channels; c.x2 = x2; c.note_channels = g.stereo_note() ? 2 : 1;
-	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY || g.nodes[i] == graph::N_NDELAY) { c.delays.push_back({ c.ring_rows, g.arg((int)i) }); c.ring_rows += g.arg((int)i); }
+	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY || g.nodes[i] == graph::N_NDELAY) { c.delays.push_back({ c.ring_rows, g.arg((int)i) }); c.ring_rows += g.arg((int)i) + 1; }   // (+ the pad element of every line: klg_delay.hpp)
 	c.noise_calls = g.noise_calls();
 	for (const graph::Op& o : g.ops) if (o.code == graph::OP_SETCTL) c.ctlvar_word[o.imm & 7u] = g.node_word0(o.node);
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_SMOOTH) {            // controls[ctl].smooth(): state word, control, calls per sample

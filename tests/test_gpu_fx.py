@@ -166,3 +166,25 @@ def test_a_control_the_effect_writes_comes_back_and_the_hosts_set_wins():
     (va, oa), (vb, ob) = seen
     assert np.array_equal(va.view(np.uint32), vb.view(np.uint32)) and np.array_equal(oa.view(np.uint32), ob.view(np.uint32))
     assert not np.allclose(va[0], 0.5) and len(set(va[-1].tolist())) > 1        # the effect moved them, each instance its own way
+
+
+def test_pingpong_with_stationary_controls(oracle_build):
+    """Some ten thousand samples after a dial last moved both control smoothers sit at their fp32 fixed points; klg_fx_pingpong_x then skips the
+    serial control chain (every sample's delay time IS the smoothed value) and only walks the LFO phase.  160 blocks of 256 samples with the
+    dials set once (instances differ), then one dial moved at block 150 — in and out of the stationary state — against the oracle, bit for
+    bit, early blocks (converging), late blocks (stationary) and the blocks around the change."""
+    dump = [0, 1, 40, 100, 148, 149, 150, 151, 159]
+    s = Scenario(patch="pingpong", block=256, blocks=160, instances=20, burst=160 * 256, seed=11, dump=dump)
+    rng = np.random.default_rng(8)
+    for k in range(20):
+        s.control(0, k, 0, float(rng.uniform(0.2, 0.9)))
+        s.control(0, k, 1, float(rng.uniform(0.02, 0.6)))
+        s.control(0, k, 5, float(rng.uniform(0.02, 0.6)))
+        s.control(0, k, 4, float(rng.uniform(0.3, 1.0)))
+    for k in range(0, 20, 3):
+        s.control(150, k, 5, float(rng.uniform(0.02, 0.6)))
+    s.sort()
+    got = run_fx_scenario_gpu(s)["per_voice"]
+    ref = run_scenario_oracle(s, oracle_build)["per_voice"]
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"max abs err {np.abs(got - ref).max()}"
+    assert np.abs(got[-1]).max() > 1e-3
