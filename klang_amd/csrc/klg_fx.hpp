@@ -40,8 +40,14 @@ __device__ __forceinline__ void stereo_delay_tap(const Ring& l, const Ring& r, i
 	const float frac = read - f;
 	const int i = (int)read;
 	const int j = (i == l.size - 1) ? 0 : (i + 1);
-	outl = l.rd(i) * (1.f - frac) + l.rd(j) * frac;
-	outr = r.rd(i) * (1.f - frac) + r.rd(j) * frac;
+	// `read` within half an ulp below zero rounds to exactly SIZE (klg_delay.hpp, THE PAD ELEMENT).  The reference then reads buffer[SIZE] — the pad, 0 —
+	// and buffer[SIZE + 1], which lies beyond the buffer's `size` (inside its power-of-two allocation, never initialised): indeterminate there.
+	// Here that tap is 0 (both elements read as zeros), and no neighbouring line is touched.
+	const bool pad = i >= l.size;
+	const int ic = pad ? 0 : i, jc = pad ? 0 : j;
+	const float la = pad ? 0.f : l.rd(ic), lb = pad ? 0.f : l.rd(jc), ra = pad ? 0.f : r.rd(ic), rb = pad ? 0.f : r.rd(jc);
+	outl = la * (1.f - frac) + lb * frac;
+	outr = ra * (1.f - frac) + rb * frac;
 }
 
 // LDS staging of the [K][2][n] io block: tile[ch][sample][FX_LD]
@@ -761,8 +767,11 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 			float read = (float)(pos - 1) - etime[q];
 			if (read < 0.f) read += RV_ESIZE;
 			X.ef[q] = read - (float)floor((double)read);
-			const int i = (int)read, j = (i == RV_ESIZE - 1) ? 0 : (i + 1);
+			int i = (int)read, j = (i == RV_ESIZE - 1) ? 0 : (i + 1);
+			const bool pad = i == RV_ESIZE;                                           // (read rounded up to SIZE: stereo_delay_tap — the tap is 0; a wave-uniform, almost never taken branch)
+			if (__ballot(pad) != 0ull) { i = pad ? 0 : i; j = pad ? 0 : j; }
 			if (eload[q]) { X.ea[q] = ering.rd(i); X.eb[q] = ering.rd(j); }
+			if (__ballot(pad) != 0ull) { if (pad) { X.ea[q] = 0.f; X.eb[q] = 0.f; } }
 		}
 	};
 	int ewpos = a.epos % RV_ESIZE;              // early write cursor of sample e (advanced once per iteration)
@@ -996,6 +1005,7 @@ __global__ __launch_bounds__(RVE_WG) void klg_fx_reverb_early(const ReverbArgs a
 		fr[d] = read - floorf(read);
 		const int i0 = (int)read;                                           // i0 + 1 may be RV_ESIZE: the mirror tail holds position 0 there
 		l[d] = *reinterpret_cast<const rve_f2u*>(el + i0); r[d] = *reinterpret_cast<const rve_f2u*>(er + i0);
+		if (__ballot(i0 == RV_ESIZE) != 0ull) { if (i0 == RV_ESIZE) { l[d] = (rve_f2u)(0.f); r[d] = (rve_f2u)(0.f); } }   // read rounded up to SIZE (stereo_delay_tap): the tap is 0, not the mirror of positions 0 / 1
 	}
 	float accl = 0.f, accr = 0.f;
 #pragma unroll
@@ -1095,6 +1105,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 				T.fr[d] = read - floorf(read);
 				const int i0 = (int)read;                                       // i0 + 1 may be RV_ESIZE: the mirror tail holds position 0 there
 				T.l[d] = *reinterpret_cast<const rvq_f2u*>(el + i0); T.r[d] = *reinterpret_cast<const rvq_f2u*>(er + i0);
+				if (__ballot(i0 == RV_ESIZE) != 0ull) { if (i0 == RV_ESIZE) { T.l[d] = (rvq_f2u)(0.f); T.r[d] = (rvq_f2u)(0.f); } }   // read rounded up to SIZE (stereo_delay_tap): the tap is 0
 			}
 		};
 		auto finish = [&](int g, const Taps& T) __attribute__((always_inline)) {

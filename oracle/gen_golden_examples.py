@@ -15,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("KLG_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # KLG_GOLDEN_OUT: regenerate somewhere else (tests/test_golden_regen_cpu.py compares)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from scenario_io import load_ref_output, Scenario  # noqa: E402
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from scenario_io import Scenario, fx_input  # noqa: E402
 
-GOLDEN = os.path.join(ROOT, "tests", "golden")
+GOLDEN = os.environ.get("KLG_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # KLG_GOLDEN_OUT: regenerate somewhere else (tests/test_golden_regen_cpu.py compares)
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 

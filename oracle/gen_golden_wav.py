@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "..", "tests", "golden", "wav")
+GOLD = os.environ.get("KLG_GOLDEN_OUT") or os.path.join(HERE, "..", "tests", "golden")
+OUT = os.path.join(GOLD, "wav")
 os.makedirs(OUT, exist_ok=True)
 
 

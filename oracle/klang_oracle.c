@@ -509,6 +509,10 @@ void ko_stereo_delay_tap_float(const ko_delay* l, const ko_delay* r, float delay
 	delay = read - f;
 	const int i = (int)read;
 	const int j = (i == (SIZE - 1)) ? 0 : (i + 1);
+	/* `read` within half an ulp below zero rounds to exactly SIZE.  The reference then reads buffer[SIZE] (the pad of `buffer(SIZE + 1, 0)`, klang.h:3391:
+	 * 0) and buffer[SIZE + 1] — beyond the buffer's size, inside its power-of-two allocation, never initialised (klang.h:2018-2020, 2062): indeterminate in
+	 * the reference.  The restatement (and the device) DEFINE that corner: both elements read as 0. */
+	if (i >= SIZE) { *outl = 0.f * (1.f - delay) + 0.f * delay; *outr = *outl; return; }
 	*outl = l->buf[i] * (1.f - delay) + l->buf[j] * delay;
 	*outr = r->buf[i] * (1.f - delay) + r->buf[j] * delay;
 }
