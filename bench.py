@@ -298,10 +298,30 @@ def run_literal_script(patch, voices, N, label, phases=False):
     ms = np.array([a.elapsed_time(b) for a, b in ev])
     alive = int((bank.stages() != 3).sum())
     V = bank.voices
+    # the same 375 blocks as ONE library call (klg_script_render_device: the span cleared once, then one launch per block — for banks of a few
+    # workgroups the events and the voice sum are inside the render launch): what the blocks cost without a Python call between them
+    one_call = None
+    if voices <= 262144:
+        out = torch.zeros((SCRIPT_BLOCKS, 2, N), dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(ts):
+            script.render_device(0, SCRIPT_BLOCKS, out.data_ptr(), N, ts.cuda_stream)      # (warm: the voices play the script again from its block 0)
+            torch.cuda.synchronize()
+            bank.timing_begin()
+            t1 = time.perf_counter()
+            script.render_device(0, SCRIPT_BLOCKS, out.data_ptr(), N, ts.cuda_stream)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+        l1, kms1 = bank.timing_end()
+        one_call = {"ms_per_step": 1e3 * dt1 / SCRIPT_BLOCKS, "kernel_ms_mean": kms1 / max(1, l1), "value": float(sounding.sum()) * N / dt1,
+                    "what": "klg_script_render_device(0, 375): one clear of the [375][2][N] span, then per block ONE launch (events + render + voice sum), no host call between blocks",
+                    "mix_abs_sum": float(out.abs().sum().item())}
     res = {"name": label, "workload": f"{patch}: {V} voices, SURVEY 8(d) script as written: note-on at block 0, note-off at block 150 + (v mod 64), {SCRIPT_BLOCKS} blocks of {N} samples, events from HBM",
            "value": float(sounding.sum()) * N / dt, "unit": "voice*samples/s (sounding voices)", "ms_per_step": 1e3 * dt / SCRIPT_BLOCKS, "steps": SCRIPT_BLOCKS,
            "kernel_ms_mean": kms / max(1, launches), "voices_sounding_mean": float(sounding.mean()), "voices_alive_at_end": alive,
            "ms_per_block_sustain": float(np.median(ms[40:OFF_BLOCK])), "value_sustain_phase": V * N / (1e-3 * float(np.median(ms[40:OFF_BLOCK])))}
+    if one_call:
+        res["python_loop"] = {"ms_per_step": res["ms_per_step"], "value": res["value"], "kernel_ms_mean": res["kernel_ms_mean"], "what": "one Python -> C-ABI call per block (mix.zero_() + klg_script_play_device): host submission bound at this size"}
+        res.update(ms_per_step=one_call["ms_per_step"], value=one_call["value"], kernel_ms_mean=one_call["kernel_ms_mean"], one_call=one_call)
     kern_s = 1e-3 * float(np.median(ms[40:OFF_BLOCK]))
     ab = alg_bytes(patch, bank, V, N)
     tf = FLOPS_PER_VOICE_SAMPLE.get(patch, 0) * V * N / kern_s / 1e12

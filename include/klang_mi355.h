@@ -163,6 +163,11 @@ int klg_script_note_on_many(klg_script* k, int n, const int* block, const int* v
 int klg_script_note_off_many(klg_script* k, int n, const int* block, const int* voice);
 int klg_script_commit(klg_script* k);
 int klg_script_play_device(klg_script* k, int block, float* d_mix, int n, void* hip_stream);
+/* replaces: the host's whole block loop for a stream known in advance (offline rendering: PluginProcessor.cpp:170-177 called `blocks` times with
+ * cleared buffers): blocks first_block .. first_block + blocks - 1 of the script are rendered into d_out[b][2][n] (OVERWRITTEN: the library clears
+ * the whole span once, then every block adds its mix) on hip_stream, asynchronously.  One call = one clear + one launch per block for banks of a
+ * few workgroups (events and the voice sum inside the render launch), no host work between the blocks. */
+int klg_script_render_device(klg_script* k, int first_block, int blocks, float* d_out, int n, void* hip_stream);
 
 /* Voice state transfer (checkpoint / debugging).  `state` is the patch's packed per-voice record of
  * klg_synth_state_bytes() bytes.  Replaces nothing in the reference (it has no checkpointing). */

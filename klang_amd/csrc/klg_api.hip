@@ -142,6 +142,7 @@ struct klg_synth {
 	int grid = 0;
 	struct Multi* multi = nullptr;               // a bank sharded over several devices (klg_init with more than one id): this handle only routes
 	int device = 0;                              // the GPU this bank (or shard) lives on
+	unsigned* d_ticket = nullptr; bool fuse_reduce = false;   // banks of <= KLG_FUSE_MAX_ROWS workgroups: the last one to finish adds the partial rows to the mix (no klg_reduce launch)
 	int mix_mode = 0; int* d_solo = nullptr;      // klg_synth_set_mix_mode: KLG_MIX_LAST_ACTIVE keeps one voice per instance (d_solo[synths])
 	bool x2 = true;               // KLG_RENDER_X1=1 in the environment selects the one-voice-per-lane kernel (A/B tests)
 	bool lanes = false;           // SuperSaw banks that do not fill the chip: an oscillator pair — or one oscillator — per lane (klg_render_lanes.hpp); KLG_SUPERSAW_LANES=0 / 1 / 2 forces the choice
@@ -186,7 +187,7 @@ struct klg_synth {
 static void synth_free(klg_synth* s) {
 	if (!s) return;
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
-	void* dev[] = { s->d_state, s->d_controls, s->d_partials, s->d_mix, s->d_per_voice, s->d_scratch_rec, s->d_stage, s->d_rand, s->d_rand_base };
+	void* dev[] = { s->d_state, s->d_controls, s->d_partials, s->d_mix, s->d_per_voice, s->d_scratch_rec, s->d_stage, s->d_rand, s->d_rand_base, s->d_ticket };
 	for (void* p : dev) if (p) (void)hipFree(p);
 	if (s->d_note_rings) (void)hipFree(s->d_note_rings);
 	if (s->d_solo) (void)hipFree(s->d_solo);
@@ -330,6 +331,7 @@ static klg_synth* synth_create_common(int device, int patch_id, const PatchInfo*
 	}
 	ok = ok && hipMalloc(&s->d_partials, (size_t)std::max(s->grid, s->lanes ? s->grid_lanes : 0) * max_block * 4 * s->note_ch) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_mix, (size_t)2 * max_block * 4) == hipSuccess;
+	ok = ok && hipMalloc((void**)&s->d_ticket, sizeof(unsigned)) == hipSuccess && hipMemset(s->d_ticket, 0, sizeof(unsigned)) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_scratch_rec, (size_t)std::max(64, s->W) * 4) == hipSuccess;
 	ok = ok && hipHostMalloc(&s->h_mix, (size_t)2 * max_block * 4) == hipSuccess;
 	ok = ok && hipHostMalloc(&s->h_flags, s->stride * 4) == hipSuccess;
@@ -522,7 +524,10 @@ static void launch_events(klg_synth* s, const EventArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // events: host queue -> one staged H2D copy -> klg_apply_events
 // ------------------------------------------------------------------------------------------------
-static int flush_events(klg_synth* s, hipStream_t st) {
+// stages the queued events on the device and fills `a`; launches klg_apply_events unless the caller takes the run list into the render launch (`fused`)
+enum { KLG_FUSE_MAX_ROWS = 128, KLG_FUSE_MAX_RUNS = 2048 };     // one launch per block: partial rows the last workgroup still adds up quickly; event runs every workgroup can scan
+static int flush_events(klg_synth* s, hipStream_t st, EventArgs* fused = nullptr) {
+	if (fused) fused->runs = 0;
 	if (s->events.empty()) return 0;
 	std::stable_sort(s->events.begin(), s->events.end(), [](const Event& a, const Event& b) { return a.voice != b.voice ? a.voice < b.voice : a.seq < b.seq; });
 	const size_t E = s->events.size();
@@ -558,8 +563,8 @@ static int flush_events(klg_synth* s, hipStream_t st) {
 	a.run_voice = d; a.run_first = d + R; a.run_count = d + 2 * R; a.runs = (int)R;
 	a.ev_type = d + 3 * R; a.ev_payload = d + 3 * R + E; a.payload = (const uint32_t*)(d + 3 * R + 2 * E);
 	a.fs = s->fs.f;
-	launch_events(s, a, st);
-	HIP_TRY(hipGetLastError());
+	if (fused && a.runs <= KLG_FUSE_MAX_RUNS) *fused = a;
+	else { launch_events(s, a, st); HIP_TRY(hipGetLastError()); }
 	s->events.clear(); s->payload.clear();
 	return 0;
 }
@@ -817,8 +822,21 @@ static int note_prepass(klg_synth* s, RenderArgs& a, int n, hipStream_t st) {
 	a.rand = s->d_rand; a.rand_base = s->d_rand_base;
 	return 0;
 }
-static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipStream_t st) {
-	if (int rc = flush_events(s, st)) return rc;
+// does the render launch of this bank apply events / combine its partial rows itself (RenderArgs::ev / ticket)?  The kernels that can: klg_render<P>
+// (hand-written and generated patches, one voice per lane), klg_render_sub2a_x2, klg_render_supersaw_pairs.
+static bool fusing_kernel(const klg_synth* s) { return !(s->graph && s->graph->x2) && !(s->lanes && !s->pairs); }
+static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipStream_t st, const EventArgs* script_events = nullptr) {
+	const bool prepass = s->graph && (s->graph->noise_calls > 0 || !s->graph->smooths.empty());
+	const char* fuse_env = getenv("KLG_FUSE"); const bool fuse_off = fuse_env && fuse_env[0] == '0';   // KLG_FUSE=0: always the separate launches (A/B; read per block so that a test can flip it)
+	const bool small = !fuse_off && fusing_kernel(s) && render_grid(s) <= KLG_FUSE_MAX_ROWS;
+	const bool fuse_events = small && !prepass && s->mix_mode != KLG_MIX_LAST_ACTIVE;   // (those two read the note stages between the events and the render)
+	EventArgs ev; ev.runs = 0;
+	if (script_events) {                                            // a klg_script's block: anything queued interactively comes first, as a launch of its own
+		if (int rc = flush_events(s, st)) return rc;
+		if (fuse_events && script_events->runs <= KLG_FUSE_MAX_RUNS) ev = *script_events;
+		else if (script_events->runs > 0) { launch_events(s, *script_events, st); HIP_TRY(hipGetLastError()); }
+	}
+	else if (int rc = flush_events(s, st, fuse_events ? &ev : nullptr)) return rc;
 	if (int rc = upload_controls(s, st)) return rc;
 	RenderArgs a;
 	a.state = s->d_state; a.stride = s->stride; a.voices = s->V; a.notes_per_synth = s->P; a.n = n;
@@ -828,7 +846,8 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	a.rings = s->d_note_rings; a.ring_rows = s->graph ? (size_t)s->graph->ring_rows : 0;
 	a.solo = nullptr;
 	a.rand = nullptr; a.rand_base = nullptr;
-	if (s->graph && (s->graph->noise_calls > 0 || !s->graph->smooths.empty())) if (int rc = note_prepass(s, a, n, st)) return rc;
+	a.ev = ev; a.mix = d_mix; a.mix_channels = 2; a.ticket = small ? s->d_ticket : nullptr;
+	if (prepass) if (int rc = note_prepass(s, a, n, st)) return rc;
 	if (s->mix_mode == KLG_MIX_LAST_ACTIVE) {                      // after this block's events: which voice of each instance is heard
 		hipLaunchKernelGGL(klg_select_last_active, dim3((s->S + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->d_state, s->S, s->P, s->d_solo);
 		a.solo = s->d_solo;
@@ -840,7 +859,8 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	launch_render(s, a, per_voice, st);
 	if (s->launch_error != hipSuccess) { const hipError_t e = s->launch_error; s->launch_error = hipSuccess; return fail(KLG_ERR_HIP, "launching the compiled graph patch failed: %s", hipGetErrorString(e)); }
 	if (s->timing) { HIP_TRY(hipEventRecord(s->tev[2 * s->launches + 1], st)); s->launches++; }
-	if (s->note_ch == 2) hipLaunchKernelGGL(klg_reduce_stereo, dim3((n + 31) / 32, 2), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
+	if (a.ticket) {}                                                 // (the render launch's last workgroup added the rows)
+	else if (s->note_ch == 2) hipLaunchKernelGGL(klg_reduce_stereo, dim3((n + 31) / 32, 2), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
 	else hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
 	HIP_TRY(hipGetLastError());
 	s->stages_dirty = true;
@@ -1230,20 +1250,27 @@ extern "C" int klg_script_play_device(klg_script* k, int block, float* d_mix, in
 	KLG_BIND(k->s);
 	klg_synth* s = k->s;
 	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
-	if (int rc = flush_events(s, st)) return rc;                    // anything queued interactively comes first
 	const klg_script::Slice& sl = k->slices[(size_t)block];
+	EventArgs a; a.runs = 0;
 	if (sl.E > 0) {
 		int* d = k->d_index + sl.first;
-		EventArgs a;
 		a.state = s->d_state; a.stride = s->stride;
 		a.run_voice = d; a.run_first = d + sl.R; a.run_count = d + 2 * sl.R; a.runs = sl.R;
 		a.ev_type = d + 3 * sl.R; a.ev_payload = d + 3 * sl.R + sl.E; a.payload = k->d_pool;
 		a.fs = s->fs.f;
-		launch_events(s, a, st);
-		HIP_TRY(hipGetLastError());
 		s->stages_dirty = true; s->scripted = true;
 	}
-	return enqueue_block(s, d_mix, n, false, st);
+	return enqueue_block(s, d_mix, n, false, st, &a);               // (queued interactive events first, then this block's: as launches, or inside the render launch for small banks)
+}
+
+extern "C" int klg_script_render_device(klg_script* k, int first_block, int blocks, float* d_out, int n, void* hip_stream) {
+	if (!k || !k->s || !k->committed || first_block < 0 || blocks < 0 || first_block + blocks > k->blocks || !d_out || n <= 0 || n > k->s->max_block)
+		return fail(KLG_ERR_INVALID, "klg_script_render_device: bad arguments, script not committed, or its bank was destroyed");
+	KLG_BIND(k->s);
+	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : k->s->stream;
+	HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)blocks * 2 * n * sizeof(float), st));
+	for (int b = 0; b < blocks; b++) if (int rc = klg_script_play_device(k, first_block + b, d_out + (size_t)b * 2 * n, n, (void*)st)) return rc;
+	return 0;
 }
 
 extern "C" int klg_timing_begin(klg_synth* s) { if (!s) return fail(KLG_ERR_INVALID, "NULL handle");

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
 	const int ecount = __float_as_int(RVW(RV_ECOUNT));
 	float* etile = a.early_rings + (size_t)blockIdx.x * 2 * RV_ESIZE * FX_WG + lane;
 	Ring el = { etile, FX_WG, RV_ESIZE }, er = { etile + (size_t)RV_ESIZE * FX_WG, FX_WG, RV_ESIZE };
-	if (a.layout) { el.base = a.early_rings + (size_t)k * 2 * (RV_ESIZE + 16); er.base = el.base + (RV_ESIZE + 16); el.stride = er.stride = 1; }   // RV_ESTRIDE
+	if (a.layout) { el.base = a.early_rings + (size_t)k * 2 * (RV_ESIZE + 20); er.base = el.base + (RV_ESIZE + 20); el.stride = er.stride = 1; }   // RV_ESTRIDE
 	FDelay mid0[4], mid1[4], late0[4], late1[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) { fd_load(mid0[j], a, 0 + j, k); fd_load(mid1[j], a, 4 + j, k); fd_load(late0[j], a, 8 + j, k); fd_load(late1[j], a, 12 + j, k); }
@@ -927,7 +927,11 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 // for bit in tests/test_gpu_fx.py: KLG_FX_REVERB1=1 selects the single-lane kernel, KLG_FX_REVERB16=1 the sixteen-wave one).
 enum { RVQ_MAX_INSTANCES = 8192 };       // banks up to this size run klg_fx_reverb_q (measured: profiles/r02_fx_sizes.md)
 enum { RVQ_WG = 64 };
-enum { RVQ_B = 8, RV_FPAD = 32, RV_EPAD = 16, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
+// an early line in layout 1: [0, RV_ESIZE) the ring, then RV_EMIRROR floats mirroring positions 0 .. 15, then four floats that are ALWAYS ZERO (RV_EZERO): where a
+// tap whose read position rounded up to exactly RV_ESIZE is pointed (stereo_delay_tap: that tap reads the pad — zeros —; one compare and one select per tap,
+// no branch: a rarely-taken branch cost 9 VALU per tap in register copies at its join, profiles/r03_pmc/pmc_reverb_q_4096_padbranch.json)
+enum { RVQ_B = 8, RV_FPAD = 32, RV_EMIRROR = 16, RV_EZERO = RV_ESIZE + RV_EMIRROR, RV_EPAD = RV_EMIRROR + 4, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
+static_assert(RV_ESTRIDE % 4 == 0, "16-byte stores into an early line need 16-byte aligned line starts");
 enum { RVQ_XQ_LD = 20, RVQ_XQ_FLOATS = 64 * RVQ_XQ_LD };  // the quarter exchange of the ring stores: 64 rows of 16 floats, padded
 enum { RVQ_TILE_ROWS = 17 };             // LDS per wave, rows of n floats: 0..7 the caller's block (instance * 2 + channel), 8 scrap, 9..16 the early sums
 
@@ -1003,9 +1007,9 @@ __global__ __launch_bounds__(RVE_WG) void klg_fx_reverb_early(const ReverbArgs a
 		float read = at - t;
 		if (read < 0.f) read += RV_ESIZE;
 		fr[d] = read - floorf(read);
-		const int i0 = (int)read;                                           // i0 + 1 may be RV_ESIZE: the mirror tail holds position 0 there
+		int i0 = (int)read;                                                 // i0 + 1 may be RV_ESIZE: the mirror tail holds position 0 there
+		i0 = (i0 == RV_ESIZE) ? (int)RV_EZERO : i0;                         // read rounded up to SIZE (stereo_delay_tap): the tap reads zeros, not the mirror of positions 0 / 1
 		l[d] = *reinterpret_cast<const rve_f2u*>(el + i0); r[d] = *reinterpret_cast<const rve_f2u*>(er + i0);
-		if (__ballot(i0 == RV_ESIZE) != 0ull) { if (i0 == RV_ESIZE) { l[d] = (rve_f2u)(0.f); r[d] = (rve_f2u)(0.f); } }   // read rounded up to SIZE (stereo_delay_tap): the tap is 0, not the mirror of positions 0 / 1
 	}
 	float accl = 0.f, accr = 0.f;
 #pragma unroll
@@ -1103,9 +1107,9 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 				float read = at - word(tA, tB, i, d);                           // (a tap this instance does not have: whatever its words hold — zero or an earlier time — gives a valid position, and it is never summed)
 				if (read < 0.f) read += RV_ESIZE;
 				T.fr[d] = read - floorf(read);
-				const int i0 = (int)read;                                       // i0 + 1 may be RV_ESIZE: the mirror tail holds position 0 there
+				int i0 = (int)read;                                             // i0 + 1 may be RV_ESIZE: the mirror tail holds position 0 there
+				i0 = (i0 == RV_ESIZE) ? (int)RV_EZERO : i0;                     // read rounded up to SIZE (stereo_delay_tap): the tap reads zeros
 				T.l[d] = *reinterpret_cast<const rvq_f2u*>(el + i0); T.r[d] = *reinterpret_cast<const rvq_f2u*>(er + i0);
-				if (__ballot(i0 == RV_ESIZE) != 0ull) { if (i0 == RV_ESIZE) { T.l[d] = (rvq_f2u)(0.f); T.r[d] = (rvq_f2u)(0.f); } }   // read rounded up to SIZE (stereo_delay_tap): the tap is 0
 			}
 		};
 		auto finish = [&](int g, const Taps& T) __attribute__((always_inline)) {
@@ -1284,7 +1288,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 			if constexpr (G) {
 				if (efilter) {
 					eline[ewpos] = y;
-					if (ewpos < RV_EPAD) eline[ewpos + RV_ESIZE] = y;         // mirror (a uniform test)
+					if (ewpos < RV_EMIRROR) eline[ewpos + RV_ESIZE] = y;      // mirror (a uniform test)
 				}
 			}
 			else if constexpr (u == RVQ_B - 3) {
@@ -1294,7 +1298,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 					rvq_v4e* const dst = reinterpret_cast<rvq_v4e*>(eline + w0);
 #pragma unroll
 					for (int v = 0; v < RVQ_B / 4; v++) { const rvq_v4e x = { We[4 * v], We[4 * v + 1], We[4 * v + 2], We[4 * v + 3] }; dst[v] = x; }
-					if (w0 < RV_EPAD) {
+					if (w0 < RV_EMIRROR) {
 #pragma unroll
 						for (int j = 0; j < RVQ_B; j++) eline[w0 + j + RV_ESIZE] = We[j];
 					}
@@ -1347,7 +1351,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 			int ew = epos0 + t0; while (ew >= RV_ESIZE) ew -= RV_ESIZE;                             // the early cursor of iteration t0 - 2 (sample t0), a multiple of 8
 			if (efilter) {
 				eline[ew] = We[0]; eline[ew + 1] = We[1];
-				if (ew < RV_EPAD) { eline[ew + RV_ESIZE] = We[0]; eline[ew + 1 + RV_ESIZE] = We[1]; }
+				if (ew < RV_EMIRROR) { eline[ew + RV_ESIZE] = We[0]; eline[ew + 1 + RV_ESIZE] = We[1]; }
 			}
 		}
 	}

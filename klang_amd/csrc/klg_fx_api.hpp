@@ -443,9 +443,14 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		else if (f->rv_layout) {
 			const dim3 qgrid((unsigned)((f->kpad + 4 * (RVQ_WG / 64) - 1) / (4 * (RVQ_WG / 64))));
 			const size_t qlds = (size_t)(RVQ_WG / 64) * (RVQ_TILE_ROWS * (((n + 3) & ~3) + 4) + RVQ_XQ_FLOATS) * sizeof(float);
-			// KLG_FX_REVERB_EARLY: 0 = the early sums inside klg_fx_reverb_q (phase 1 of the lone wave; the round-2 form), 1 = klg_fx_reverb_early ahead of it on
-			// the same stream, 2 (default) = on a second stream, beside the previous block's recursive kernel
-			static const int early_mode = []() { const char* e = getenv("KLG_FX_REVERB_EARLY"); return e ? atoi(e) : 2; }();
+			// KLG_FX_REVERB_EARLY: 0 = the early sums inside klg_fx_reverb_q (phase 1 of the lone wave), 1 = klg_fx_reverb_early ahead of it on the same
+			// stream, 2 = on a second stream, beside the previous block's recursive kernel.  Measured (tools/reverb_modes.py, profiles/r03_reverb_modes.jsonl,
+			// us per 256-sample block, modes 0 / 1 / 2): 1,024 instances 82 / 71 / 78, 4,096: 138 / 145 / 151, 8,192: 257 / 284 / 286.  The sums are not
+			// instruction work that a fuller chip absorbs: they are 168 MB of the block's 302 MB of ring READS at 4,096 instances (20 taps x 2 lines x 257
+			// positions per instance), and from 4,096 instances on the recursive kernel already keeps the memory system busy — a second kernel only adds
+			// its own launch and an 8 MB round trip of the sums.  Below that the lone wave's phase 1 is latency-bound and the separate launch wins.
+			static const int forced_mode = []() { const char* e = getenv("KLG_FX_REVERB_EARLY"); return e ? atoi(e) : -1; }();
+			const int early_mode = forced_mode >= 0 ? forced_mode : (f->kpad <= 2048 ? 1 : 0);
 			if (early_mode == 0 || !f->d_early[0]) hipLaunchKernelGGL(klg_fx_reverb_q<false>, qgrid, dim3(RVQ_WG), qlds, st, a);   // one wave per four instances
 			else {
 				const unsigned turn = f->early_turn++ & 1u;

@@ -30,6 +30,15 @@ namespace klg {
 enum { WG = 256, WAVES = 4, CHUNK = 32, TILE_LD = 65, MAX_BLOCK = 1024 };
 static_assert(CHUNK <= KLG_CHUNK_MAX, "a patch's quiet() looks KLG_CHUNK_MAX samples ahead");
 
+// Events: runs[r] = {voice, first, count}; ev_type[e] (0 = note-on with payload ev_payload[e], 1 = note-off);
+// payload records are AoS [k][W] words as produced by the host-side on() code.
+struct EventArgs {
+	uint32_t* state; size_t stride;
+	const int* run_voice; const int* run_first; const int* run_count; int runs;
+	const int* ev_type; const int* ev_payload; const uint32_t* payload;
+	float fs;
+};
+
 struct RenderArgs {
 	uint32_t* state;          // [W][stride]
 	size_t stride;            // voices rounded up to WG
@@ -44,6 +53,12 @@ struct RenderArgs {
 	const int* solo;          // KLG_MIX_LAST_ACTIVE: [synths] the one voice of each instance that is heard this block (-1: none), else null
 	const int* rand;          // Noise generators of a generated patch: this block's libc rand() values, drawn on the host in the reference's call order
 	const int* rand_base;     // ... [voices] where a sounding voice's n * draws values start (lanes without a sounding voice read from 0), else null
+	// ONE LAUNCH PER BLOCK for banks of a few workgroups (a plugin's own synth: <= 128 notes, klang.h:4311), where three more launches cost as much as
+	// the render itself: (1) ev.runs > 0 — every workgroup first applies the block's event runs of ITS OWN voices (what klg_apply_events does as
+	// a launch); (2) ticket != null — the workgroup that finishes last adds all partial rows to `mix` in row order (what klg_reduce does as a
+	// launch; the order is fixed, so the mix stays bit-reproducible).  Both null / 0: the separate launches.
+	EventArgs ev;
+	float* mix; int mix_channels; unsigned* ticket;
 };
 
 // record <-> word planes.  Words are moved with static indices only (fully unrolled) and converted with
@@ -92,6 +107,44 @@ template<class P> struct HasFast2<P, klg_void_t<decltype(P::kHasFast2)>> { stati
 template<class P, class = void> struct IsStereo { static constexpr bool value = false; };
 template<class P> struct IsStereo<P, klg_void_t<decltype(P::kStereo)>> { static constexpr bool value = P::kStereo; };
 
+// ---- the fused launch (RenderArgs::ev / ticket) ----
+// (1) events: group g of `voices_per_group` voices is rendered by workgroup g % gridDim.x; that workgroup applies the runs of those voices first.
+//     A workgroup's stores are seen by its own later loads (one CU, one L1, __syncthreads() between them); no other workgroup touches these records.
+template<class P> __device__ __forceinline__ void fused_events(const RenderArgs& a, int voices_per_group) {
+	if (a.ev.runs == 0) return;
+	for (int r = threadIdx.x; r < a.ev.runs; r += blockDim.x) {
+		const int v = a.ev.run_voice[r];
+		if ((v / voices_per_group) % (int)gridDim.x == (int)blockIdx.x) apply_event_run<P>(a.ev, r);
+	}
+	__syncthreads();
+}
+// (2) the combine: every workgroup has written its partial row ([n * nc] floats); the one that draws the last ticket adds the rows to the mix.
+//     The hand-off is the guide's counter form (cdna_hip_programming.md §6 G16): all stores drained, ONE agent-scope release, then the relaxed
+//     ticket; the last arriver takes ONE agent-scope acquire and reads the rows with plain loads — correct wherever the workgroups ran (other CUs
+//     do not see this CU's L1, XCDs do not share an L2).  Rows are added in row order whoever is last: the mix is bit-reproducible.
+__device__ __forceinline__ void fused_combine(const RenderArgs& a, int n, int nc, int* lds_flag) {
+	if (!a.ticket) return;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const unsigned prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const int last = prev == gridDim.x - 1u;
+		if (last) { __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }   // (the next block's launch finds the counter at 0)
+		*lds_flag = last;
+	}
+	__syncthreads();
+	if (!*lds_flag) return;
+	const int rows = (int)gridDim.x, len = n * nc;
+	for (int i = threadIdx.x; i < len; i += blockDim.x) {
+		float t = 0.f;
+		for (int r = 0; r < rows; r++) t += a.partials[(size_t)r * len + i];
+		if (nc == 2) { if (i / n < a.mix_channels) a.mix[i] += t; }                                      // stereo notes: rows are [2][n], left to left, right to right
+		else for (int c = 0; c < a.mix_channels; c++) a.mix[(size_t)c * n + i] += t;              // a mono `out` goes to every channel (klg_reduce)
+	}
+}
+
 template<class P, bool PER_VOICE>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P>::lo, WavesPerEu<P>::hi))) void klg_render(const RenderArgs a) {
 	using Rec = typename P::Rec;
@@ -106,6 +159,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 
 	for (int i = lane; i < n * NC; i += 64) acc[i] = 0.f;
 	wave_sync();
+	fused_events<P>(a, WG);
 
 	const int groups = (int)(a.stride / WG);
 	for (int g = blockIdx.x; g < groups; g += gridDim.x) {
@@ -215,6 +269,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 	__syncthreads();
 	// one partial row per workgroup ([2][n] for stereo notes: the waves' rows are [channel][n], so element i of a wave's block is the same (channel, sample) in all four)
 	for (int i = tid; i < n * NC; i += WG) a.partials[(size_t)blockIdx.x * n * NC + i] = mix_rows_sum(i, n * NC);
+	fused_combine(a, n, NC, reinterpret_cast<int*>(lds));
 }
 
 // KLG_MIX_LAST_ACTIVE: the highest-numbered sounding note of every synth instance (the one whose block survives in the reference's
@@ -269,20 +324,17 @@ __global__ __launch_bounds__(1024) void klg_reduce_stereo(const float* __restric
 	}
 }
 
-// Events: runs[r] = {voice, first, count}; ev_type[e] (0 = note-on with payload ev_payload[e], 1 = note-off);
-// payload records are AoS [k][W] words as produced by the host-side on() code.
-struct EventArgs {
-	uint32_t* state; size_t stride;
-	const int* run_voice; const int* run_first; const int* run_count; int runs;
-	const int* ev_type; const int* ev_payload; const uint32_t* payload;
-	float fs;
-};
+template<class P> __device__ __forceinline__ void apply_event_run(const EventArgs& a, int r);
 template<class P>
 __global__ __launch_bounds__(64) void klg_apply_events(const EventArgs a) {
-	using Rec = typename P::Rec;
-	constexpr int W = sizeof(Rec) / 4;
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= a.runs) return;
+	apply_event_run<P>(a, r);
+}
+// one run = the events one voice received this block, in order
+template<class P> __device__ __forceinline__ void apply_event_run(const EventArgs& a, int r) {
+	using Rec = typename P::Rec;
+	constexpr int W = sizeof(Rec) / 4;
 	const int v = a.run_voice[r];
 	RecWords<Rec> rw;
 	bool loaded = false;

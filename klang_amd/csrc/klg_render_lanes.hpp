@@ -209,6 +209,7 @@ __global__ __launch_bounds__(WG) void klg_render_supersaw_pairs(const RenderArgs
 	float* acc = klg_mix_rows + wave * n;                                       // this wave's own mix row
 	for (int i = lane; i < n; i += 64) acc[i] = 0.f;
 	wave_sync();
+	fused_events<PatchSuperSaw>(a, VPWG);                                       // (small banks: this block's note events in the same launch, klg_kernels.hpp)
 
 	const int groups = (a.voices + VPWG - 1) / VPWG;
 	for (int g = blockIdx.x; g < groups; g += gridDim.x) {
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(WG) void klg_render_supersaw_pairs(const RenderArgs
 	}
 	__syncthreads();
 	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = mix_rows_sum(i, n);
+	fused_combine(a, n, 1, reinterpret_cast<int*>(lds));
 }
 
 }  // namespace klg

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
 	float* acc = klg_mix_rows + wave * n;                    // this wave's own mix row (klg_kernels.hpp)
 	for (int i = lane; i < n; i += 64) acc[i] = 0.f;
 	wave_sync();
+	fused_events<PatchSub2a>(a, X2_VOICES_PER_WG);            // (small banks: this block's note events in the same launch, klg_kernels.hpp)
 
 	const int groups = (int)((a.stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG);
 	for (int g = blockIdx.x; g < groups; g += gridDim.x) {
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_x2(const RenderArgs a) {
 	}
 	__syncthreads();
 	for (int i = tid; i < n; i += WG) a.partials[(size_t)blockIdx.x * n + i] = mix_rows_sum(i, n);
+	fused_combine(a, n, 1, reinterpret_cast<int*>(lds));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -136,3 +136,67 @@ def test_script_outlives_its_bank_without_touching_freed_state():
     with pytest.raises(klang_amd.KlangError, match="destroyed"):
         script.play_device(1, mix.data_ptr(), 64)
     script.close()                                        # and the handle can still be released
+
+
+@pytest.mark.parametrize("patch,synths,notes", [("sub2a", 4, 128), ("supersaw", 3, 32), ("fm4", 5, 32), ("sub2b", 2, 32)])
+def test_single_launch_blocks_equal_the_separate_launches(patch, synths, notes):
+    """Banks of a few workgroups render a block in ONE launch: the workgroups apply the block's note events of their own voices, the last one to
+    finish adds the partial rows to the mix (RenderArgs::ev / ticket).  KLG_FUSE=0 selects the separate klg_apply_events / klg_render / klg_reduce
+    launches: same per-voice samples and note stages bit for bit, the mix within the summation-order bound (rows are added in another order),
+    and the single-launch mix is bit-reproducible from run to run."""
+    import os
+    from klg_driver import run_scenario_gpu
+    from scenario_io import Scenario
+    s = Scenario(patch=patch, block=192, blocks=10, synths=synths, notes=notes, dump=list(range(10)))
+    rng = np.random.default_rng(5)
+    for b in range(8):
+        for _ in range(6):
+            sy, p = int(rng.integers(0, synths)), int(rng.integers(40, 90))
+            s.on(b, sy, p, float(rng.uniform(0.3, 1.0)), seed=int(rng.integers(1, 1 << 30)))
+            s.off(b + 2, sy, p)
+    s.sort()
+    try:
+        os.environ["KLG_FUSE"] = "0"
+        ref = run_scenario_gpu(s)
+        os.environ["KLG_FUSE"] = "1"
+        got = run_scenario_gpu(s)
+        again = run_scenario_gpu(s)
+    finally:
+        os.environ.pop("KLG_FUSE", None)
+    assert np.array_equal(got["stages"], ref["stages"])
+    assert np.array_equal(got["per_voice"].view(np.uint32), ref["per_voice"].view(np.uint32))
+    peak = float(np.abs(ref["per_voice"]).max())
+    assert peak > 0 and float(np.abs(got["mix"] - ref["mix"]).max()) <= 1e-5 * peak * np.sqrt(s.voices) * 4
+    assert np.array_equal(got["mix"].view(np.uint32), again["mix"].view(np.uint32))
+
+
+def test_script_rendered_in_one_call_equals_block_by_block():
+    """klg_script_render_device (the whole block loop of an offline render in one call) against klg_script_play_device per block into
+    cleared buffers: the same [blocks][2][n] bit for bit — for a bank that takes the single-launch path and one that does not."""
+    import torch
+    import klang_amd
+    for synths in (2, 80):                                   # 256 voices (one launch per block) / 10,240 voices (separate launches)
+        N, B = 128, 12
+        outs = []
+        for one_call in (False, True):
+            bank = klang_amd.SynthBank("sub2a", synths=synths, notes=128, max_block=N)
+            V = bank.voices
+            rng = np.random.default_rng(3)
+            script = klang_amd.EventScript(bank, B)
+            first = script.add_records(bank.note_records((np.arange(V) // 128).astype(np.int32), rng.integers(40, 90, size=V).astype(np.int32), rng.uniform(0.3, 1.0, size=V).astype(np.float32)))
+            v = np.arange(V)
+            script.note_on(v % 4, v, first + v)
+            script.note_off(5 + v % 3, v)
+            script.commit()
+            out = torch.full((B, 2, N), 7.0, dtype=torch.float32, device="cuda")
+            if one_call:
+                script.render_device(0, B, out.data_ptr(), N)
+            else:
+                out.zero_(); torch.cuda.synchronize()
+                for b in range(B):
+                    script.play_device(b, out[b].data_ptr(), N)
+            bank.sync(); torch.cuda.synchronize()
+            outs.append(out.cpu().numpy())
+            script.close(); bank.close()
+        assert np.abs(outs[0]).max() > 0
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), synths
