@@ -132,7 +132,11 @@ int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices);
 
 /* Throughput path: d_mix is a DEVICE pointer to [2][n] floats that the block is accumulated into on
  * `hip_stream` (a hipStream_t, or NULL for the handle's own stream); no host copies, no synchronisation.
- * klg_sync() waits for everything queued on the handle. */
+ * klg_sync() waits for everything queued on the handle.
+ * ONE EXCEPTION: a graph bank whose Note::process() draws Noise or calls controls[i].smooth() shares state between its notes in the order
+ * Synth::process walks them (klang.h:4842-4848: libc rand(), Control::smoothed); per block the library brings the note stages back, draws /
+ * advances on the host in that order and uploads the result — this entry (and klg_script_play_device) then SYNCHRONISES the stream two or three
+ * times per block and does O(sounding voices x n) host work.  Banks without those two ops never synchronise here. */
 int klg_process_device(klg_synth* s, float* d_mix, int n, void* hip_stream);
 int klg_sync(klg_synth* s);
 

@@ -158,7 +158,7 @@ struct klg_synth {
 	std::vector<Table> tables;
 	TableDesc* d_tables = nullptr; size_t d_tables_cap = 0; bool tables_dirty = false;
 	float* d_note_rings = nullptr;               // note delays of a graph patch: [stride][ring_rows], each voice's lines contiguous
-	int *d_rand = nullptr, *d_rand_base = nullptr; std::vector<int> h_rand, h_rand_base;   // Noise generators of a graph patch: the block's rand() draws (draw_noise)
+	int *d_rand = nullptr, *d_rand_base = nullptr; size_t d_rand_cap = 0; std::vector<int> h_rand, h_rand_base;   // Noise generators of a graph patch: the block's rand() draws (draw_noise)
 	// host mirrors
 	std::vector<host::ControlH> controls;        // [S][nctl]
 	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
@@ -806,14 +806,20 @@ static int note_prepass(klg_synth* s, RenderArgs& a, int n, hipStream_t st) {
 	}
 	if (draws == 0) return 0;
 	const size_t per = (size_t)n * (size_t)draws;
-	if (!s->d_rand) {
-		RandGuard rg;                                                  // allocations must not disturb the stream the draws below come from
-		HIP_TRY(hipMalloc((void**)&s->d_rand, std::max<size_t>(1, (size_t)s->V) * (size_t)s->max_block * (size_t)draws * sizeof(int)));
-		HIP_TRY(hipMalloc((void**)&s->d_rand_base, (size_t)s->V * sizeof(int)));
-	}
 	s->h_rand_base.assign((size_t)s->V, 0);
 	size_t count = 0;
 	for (int v = 0; v < s->V; v++) if (sounding(v)) s->h_rand_base[(size_t)v] = (int)(per * count++);
+	// the draws of the SOUNDING voices only: the device array grows with their high-water mark (a bank of a million slots of which a thousand sound
+	// holds a thousand voices' draws, not 4 GB per Noise generator)
+	const size_t need = std::max<size_t>(1, count) * (size_t)s->max_block * (size_t)draws;
+	if (!s->d_rand_base || need > s->d_rand_cap) {
+		RandGuard rg;                                                  // allocations must not disturb the stream the draws below come from
+		HIP_TRY(hipStreamSynchronize(st));
+		if (s->d_rand) (void)hipFree(s->d_rand);
+		s->d_rand_cap = need + need / 2;
+		HIP_TRY(hipMalloc((void**)&s->d_rand, s->d_rand_cap * sizeof(int)));
+		if (!s->d_rand_base) HIP_TRY(hipMalloc((void**)&s->d_rand_base, (size_t)s->V * sizeof(int)));
+	}
 	s->h_rand.resize(std::max<size_t>(per, per * count));             // (lanes without a sounding voice read the first voice's values and drop the result)
 	for (size_t i = 0; i < per * count; i++) s->h_rand[i] = rand();
 	HIP_TRY(hipMemcpyAsync(s->d_rand, s->h_rand.data(), s->h_rand.size() * sizeof(int), hipMemcpyHostToDevice, st));

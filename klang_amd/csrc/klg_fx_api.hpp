@@ -36,6 +36,7 @@ struct klg_fx {
 	std::vector<RvHost> rv;
 	std::vector<int> rv_touched; std::vector<unsigned char> rv_flag;   // Reverb instances whose dials were set since their last prepare() (Controls::changed() is only evaluated for those)
 	BiquadCoef pp_dc;
+	int lds_limit = 64 * 1024;                         // hipDeviceAttributeMaxSharedMemoryPerBlock of this bank's device (gfx950: 160 KB)
 	int rv_layout = 1;                                 // Reverb ring layout: 1 = a contiguous ring per (instance, line) [klg_fx_reverb_q], 0 = tiles of 64 instances [klg_fx_reverb16]
 	bool timing = false; std::vector<hipEvent_t> tev; int launches = 0;
 	// graph effects (klg_graph.hpp, `kind effect`): hipRTC code object, per-instance controls in HBM
@@ -127,6 +128,7 @@ static klg_fx* fx_create_on(int device, int patch_id, int instances, float sampl
 	f->kpad = ((size_t)instances + FX_WG - 1) / FX_WG * FX_WG;
 	f->fs = host::Fs(sample_rate);
 	const bool pp = patch_id == KLG_PATCH_PINGPONG;
+	{ int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) f->lds_limit = v; }
 	f->nctl = pp ? 6 : 10;
 	f->words = pp ? (int)PP_WORDS : (int)RV_WORDS;
 	if (!pp) {
@@ -439,7 +441,11 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		// shortest line (7 ms * 0.9) is longer than that.  reverb_q also computes a block's early sums before the block's early-line writes:
 		// right while every tap reads further back than the block is long — the shortest tap is (50 ms + ...) * random(0.9, 1.1) > 44.9 ms.
 		const bool taps_behind_block = (float)(n + 2) < 0.0449f * f->fs.f;
-		if (single_wave || f->fs.f < 16000.f || (f->rv_layout && !taps_behind_block)) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);   // one lane walks the whole graph (A/B reference; either layout)
+		// klg_fx_reverb_q stages the block in dynamic LDS (75 KB at n = 1024): more than a device grants (not on gfx950's 160 KB) -> the single-lane kernel, loudly once
+		const size_t q_lds = (size_t)(RVQ_WG / 64) * (RVQ_TILE_ROWS * (((n + 3) & ~3) + 4) + RVQ_XQ_FLOATS) * sizeof(float);
+		const bool lds_fits = q_lds <= (size_t)f->lds_limit;
+		if (f->rv_layout && !lds_fits) { static bool told = false; if (!told) { told = true; fprintf(stderr, "klang-mi355: klg_fx_reverb_q needs %zu bytes of LDS per workgroup for %d-sample blocks, the device grants %d: using the single-lane kernel\n", q_lds, n, f->lds_limit); } }
+		if (single_wave || f->fs.f < 16000.f || (f->rv_layout && (!taps_behind_block || !lds_fits))) hipLaunchKernelGGL(klg_fx_reverb, grid, block, 0, st, a);   // one lane walks the whole graph (A/B reference; either layout)
 		else if (f->rv_layout) {
 			const dim3 qgrid((unsigned)((f->kpad + 4 * (RVQ_WG / 64) - 1) / (4 * (RVQ_WG / 64))));
 			const size_t qlds = (size_t)(RVQ_WG / 64) * (RVQ_TILE_ROWS * (((n + 3) & ~3) + 4) + RVQ_XQ_FLOATS) * sizeof(float);

@@ -7,7 +7,7 @@ for a in sys.argv[1:]:
     if a.isdigit(): jobs.append((patch, int(a)))
     else: patch = a
 for patch, K in jobs:
-    N = 256
+    N = int(os.environ.get("KLG_FX_N", "256"))
     bank = klang_amd.FxBank(patch, K, max_block=N)
     g = torch.Generator(device="cuda").manual_seed(1)
     io = (torch.rand((K, 2, N), device="cuda", generator=g) - 0.5)
