@@ -304,16 +304,18 @@ def run_literal_script(patch, voices, N, label, phases=False):
     if voices <= 262144:
         out = torch.zeros((SCRIPT_BLOCKS, 2, N), dtype=torch.float32, device="cuda")
         with torch.cuda.stream(ts):
-            script.render_device(0, SCRIPT_BLOCKS, out.data_ptr(), N, ts.cuda_stream)      # (warm: the voices play the script again from its block 0)
+            script.render_device(0, SCRIPT_BLOCKS, out.data_ptr(), N, ts.cuda_stream)      # (warm: the voices play the script again from its block 0; the span's launches are captured as a hipGraph)
             torch.cuda.synchronize()
-            bank.timing_begin()
             t1 = time.perf_counter()
-            script.render_device(0, SCRIPT_BLOCKS, out.data_ptr(), N, ts.cuda_stream)
+            script.render_device(0, SCRIPT_BLOCKS, out.data_ptr(), N, ts.cuda_stream)      # the timed pass: the graph replayed
             torch.cuda.synchronize()
             dt1 = time.perf_counter() - t1
+            bank.timing_begin()                                                              # (kernel time: a third pass, launched one by one — event pairs cannot sit inside a replayed graph)
+            script.render_device(0, SCRIPT_BLOCKS, out.data_ptr(), N, ts.cuda_stream)
+            torch.cuda.synchronize()
         l1, kms1 = bank.timing_end()
         one_call = {"ms_per_step": 1e3 * dt1 / SCRIPT_BLOCKS, "kernel_ms_mean": kms1 / max(1, l1), "value": float(sounding.sum()) * N / dt1,
-                    "what": "klg_script_render_device(0, 375): one clear of the [375][2][N] span, then per block ONE launch (events + render + voice sum), no host call between blocks",
+                    "what": "klg_script_render_device(0, 375), its launches captured once as a hipGraph and replayed: one clear of the [375][2][N] span, then per block ONE launch for banks of a few workgroups (events + render + voice sum inside it; larger banks: events / render / reduce), no host call between blocks",
                     "mix_abs_sum": float(out.abs().sum().item())}
     res = {"name": label, "workload": f"{patch}: {V} voices, SURVEY 8(d) script as written: note-on at block 0, note-off at block 150 + (v mod 64), {SCRIPT_BLOCKS} blocks of {N} samples, events from HBM",
            "value": float(sounding.sum()) * N / dt, "unit": "voice*samples/s (sounding voices)", "ms_per_step": 1e3 * dt / SCRIPT_BLOCKS, "steps": SCRIPT_BLOCKS,
@@ -530,24 +532,55 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     first_timed = state["i"]
-    bank.timing_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()                                          # every block of the timed region is fully reduced inside the bracket
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    launches, kernel_ms = bank.timing_end()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    checksum = float(mixes[(state["i"] - 1) % RING].abs().sum().item())
+    # N = 1: the K timed blocks are submitted as spans of the script (klg_script_render_device: a span's launches — this block's events from HBM,
+    # render, reduce — captured as a hipGraph BEFORE the timed region, replayed inside it): K steps, no host call between them.  N > 1 keeps
+    # one call per block: every block ends in an all-reduce that torch.distributed issues.  KLG_BENCH_SPANS=0: one call per block at N = 1 too.
+    pieces, span_out = [], None
+    if world == 1 and os.environ.get("KLG_BENCH_SPANS", "1") != "0":
+        span_out = torch.zeros((args.steps, 2, N), dtype=torch.float32, device="cuda")
+        pos, left, off = first_timed % SCRIPT_BLOCKS, args.steps, 0
+        while left > 0:                                                       # [first, first + K) of the cyclic script, cut where it wraps
+            take = min(left, SCRIPT_BLOCKS - pos)
+            pieces.append((pos, take, span_out[off].data_ptr())); pos = (pos + take) % SCRIPT_BLOCKS; left -= take; off += take
+        if not all(script.capture_span(f, c, ptr, N, stream) for (f, c, ptr) in pieces):
+            pieces = []                                                       # (cannot be captured here: one call per block, as below)
+        torch.cuda.synchronize()
+    if pieces:
+        t0 = time.perf_counter()
+        for (f, c, ptr) in pieces:
+            script.render_device(f, c, ptr, N, stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        state["i"] += args.steps
+        checksum = float(span_out[-1].abs().sum().item())
+    else:
+        bank.timing_begin()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()                                          # every block of the timed region is fully reduced inside the bracket
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        launches, kernel_ms = bank.timing_end()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        checksum = float(mixes[(state["i"] - 1) % RING].abs().sum().item())
     alive_now = int((bank.stages() != 3).sum())
     expect_alive = int(sounding.alive_after[(state["i"] - 1) % SCRIPT_BLOCKS])
+    if pieces:                                           # the render kernel's own time (HIP events around each launch): the NEXT blocks of the same steady state, launched one by one
+        for _ in range(20):                              # (the chip idled through the read-back above: a few blocks before the events count)
+            step()
+        torch.cuda.synchronize()
+        bank.timing_begin()
+        for _ in range(max(60, min(args.steps, SCRIPT_BLOCKS))):
+            step()
+        torch.cuda.synchronize()
+        launches, kernel_ms = bank.timing_end()
     sounding_timed = float(sum(int(sounding[(first_timed + j) % SCRIPT_BLOCKS]) for j in range(args.steps)))
 
     if rank == 0:
@@ -569,7 +602,8 @@ def main():
                        "voices_per_gpu": V, "voices_sounding_per_gpu_mean": live_mean, "block": N, "parallelism": f"voice-shard x{world}" + (" + RCCL all-reduce of [2][%d] per block" % N if world > 1 else ""),
                        "value_counts": "sounding voices x samples / s (SURVEY 8d: active voices); resident voices x samples / s = %.6g" % (world * V * N * args.steps / dt),
                        "voices_alive_after_last_block": alive_now, "voices_alive_expected": expect_alive,
-                       "block_deadline_ms": 1e3 * N / 48000.0, "mix_checksum": checksum},
+                       "block_deadline_ms": 1e3 * N / 48000.0, "mix_checksum": checksum,
+                       "submission": ("the K timed blocks as %d span(s) of the script, each captured as a hipGraph before the timed region and replayed in it (klg_script_render_device)" % len(pieces)) if pieces else "one klg_script_play_device call per block"},
             # what BINDS this kernel is fp32 VALU issue (voice state in registers, as north_star prescribes; PMC: VALU busy 82-85 % of the kernel's
             # cycles, profiles/r02_pmc/pmc_sub2a_*.json), so that is the roofline's `bound` and `frac`; the HBM view of the same launch is the `hbm`
             # sub-object (`traffic` = HBM bytes per launch from the PMC counters, as everywhere)

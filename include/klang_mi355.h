@@ -172,6 +172,10 @@ int klg_script_play_device(klg_script* k, int block, float* d_mix, int n, void* 
  * the whole span once, then every block adds its mix) on hip_stream, asynchronously.  One call = one clear + one launch per block for banks of a
  * few workgroups (events and the voice sum inside the render launch), no host work between the blocks. */
 int klg_script_render_device(klg_script* k, int first_block, int blocks, float* d_out, int n, void* hip_stream);
+/* The span's launches are captured as a hipGraph the first time klg_script_render_device sees (span, n, d_out, stream) and replayed afterwards.
+ * klg_script_capture_span does the capture WITHOUT running anything (returns 0 when the span is — now or already — captured; an error when it
+ * cannot be: queued events or uploads pending, kernel timing on, KLG_GRAPH=0): the first real call is then a replay. */
+int klg_script_capture_span(klg_script* k, int first_block, int blocks, float* d_out, int n, void* hip_stream);
 
 /* Voice state transfer (checkpoint / debugging).  `state` is the patch's packed per-voice record of
  * klg_synth_state_bytes() bytes.  Replaces nothing in the reference (it has no checkpointing). */

@@ -76,6 +76,7 @@ def load():
         "klg_script_commit": (C.c_int, [vp]),
         "klg_script_play_device": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
         "klg_script_render_device": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp]),
+        "klg_script_capture_span": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp]),
         "klg_voice_download": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "klg_voice_upload": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "klg_voices_upload": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), vp]),

@@ -225,6 +225,10 @@ class EventScript:
         """blocks first_block .. + blocks - 1 into d_out[blocks][2][n] (overwritten), one call (klg_script_render_device)"""
         check(self._L.klg_script_render_device(self._k, int(first_block), int(blocks), C.c_void_p(int(d_out_ptr)), int(n), C.c_void_p(int(stream)) if stream else None), "klg_script_render_device")
 
+    def capture_span(self, first_block, blocks, d_out_ptr, n, stream=None):
+        """capture the span as a hipGraph without running it; False when it cannot be captured now (klg_script_capture_span)"""
+        return self._L.klg_script_capture_span(self._k, int(first_block), int(blocks), C.c_void_p(int(d_out_ptr)), int(n), C.c_void_p(int(stream)) if stream else None) == 0
+
     def play_device(self, block, d_mix_ptr, n, stream=None):
         check(self._L.klg_script_play_device(self._k, int(block), C.c_void_p(int(d_mix_ptr)), int(n), C.c_void_p(int(stream)) if stream else None), "klg_script_play_device")
 

@@ -1156,6 +1156,9 @@ struct klg_script {
 	std::vector<uint32_t> pool;                                    // note-on records, W words each (shared by every block that starts that note)
 	struct Slice { size_t first; int R, E; };                      // where block b's run / event arrays sit in d_index
 	std::vector<Slice> slices;
+	// klg_script_render_device: the launches of a span of blocks captured ONCE as a hipGraph and replayed (same span, block length, destination, stream)
+	struct Captured { int first, blocks, n; float* d_out; hipStream_t st; hipGraphExec_t exec; };
+	std::vector<Captured> graphs;
 	int* d_index = nullptr; uint32_t* d_pool = nullptr;
 };
 extern "C" klg_script* klg_script_create(klg_synth* s, int blocks) {
@@ -1167,14 +1170,16 @@ extern "C" klg_script* klg_script_create(klg_synth* s, int blocks) {
 }
 // a bank that is destroyed takes its scripts' device arrays with it and leaves them INVALID (k->s == NULL): every later klg_script_* call on
 // such a handle fails with KLG_ERR_INVALID instead of touching freed state; klg_script_destroy() still releases the handle itself
+static void script_drop_graphs(klg_script* k) { for (auto& g : k->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); k->graphs.clear(); }
 static void scripts_invalidate(klg_synth* s) {
-	for (klg_script* k : s->scripts) { if (k->d_index) (void)hipFree(k->d_index); if (k->d_pool) (void)hipFree(k->d_pool); k->d_index = nullptr; k->d_pool = nullptr; k->s = nullptr; }
+	for (klg_script* k : s->scripts) { script_drop_graphs(k); if (k->d_index) (void)hipFree(k->d_index); if (k->d_pool) (void)hipFree(k->d_pool); k->d_index = nullptr; k->d_pool = nullptr; k->s = nullptr; }
 	s->scripts.clear();
 }
 extern "C" void klg_script_destroy(klg_script* k) {
 	if (!k) return;
 	if (k->s) {
 		DeviceGuard bound(k->s->device);
+		script_drop_graphs(k);
 		if (k->d_index) (void)hipFree(k->d_index);
 		if (k->d_pool) (void)hipFree(k->d_pool);
 		auto& v = k->s->scripts; v.erase(std::remove(v.begin(), v.end(), k), v.end());
@@ -1269,15 +1274,48 @@ extern "C" int klg_script_play_device(klg_script* k, int block, float* d_mix, in
 	return enqueue_block(s, d_mix, n, false, st, &a);               // (queued interactive events first, then this block's: as launches, or inside the render launch for small banks)
 }
 
-extern "C" int klg_script_render_device(klg_script* k, int first_block, int blocks, float* d_out, int n, void* hip_stream) {
+static int script_render(klg_script* k, int first_block, int blocks, float* d_out, int n, void* hip_stream, bool capture_only) {
 	if (!k || !k->s || !k->committed || first_block < 0 || blocks < 0 || first_block + blocks > k->blocks || !d_out || n <= 0 || n > k->s->max_block)
 		return fail(KLG_ERR_INVALID, "klg_script_render_device: bad arguments, script not committed, or its bank was destroyed");
 	KLG_BIND(k->s);
-	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : k->s->stream;
-	HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)blocks * 2 * n * sizeof(float), st));
-	for (int b = 0; b < blocks; b++) if (int rc = klg_script_play_device(k, first_block + b, d_out + (size_t)b * 2 * n, n, (void*)st)) return rc;
+	klg_synth* s = k->s;
+	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
+	auto enqueue_span = [&]() -> int {
+		HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)blocks * 2 * n * sizeof(float), st));
+		for (int b = 0; b < blocks; b++) if (int rc = klg_script_play_device(k, first_block + b, d_out + (size_t)b * 2 * n, n, (void*)st)) return rc;
+		return 0;
+	};
+	// A span of a committed script is a fixed sequence of launches (the events come from HBM): captured once as a hipGraph, replayed afterwards — the
+	// per-launch submission cost and most of the gap between dependent launches go (what a bank of a few workgroups spends a fifth of its block on).
+	// Only when nothing the capture may not contain is pending: queued interactive events / control or table uploads (they synchronise), the
+	// per-block host pass of Noise / smooth() banks, kernel timing.  KLG_GRAPH=0: never.
+	const char* genv = getenv("KLG_GRAPH");
+	const bool prepass = s->graph && (s->graph->noise_calls > 0 || !s->graph->smooths.empty());
+	const bool can_graph = !(genv && genv[0] == '0') && blocks >= 2 && !s->timing && s->events.empty() && !s->controls_dirty && !s->tables_dirty && !prepass && s->mix_mode != KLG_MIX_LAST_ACTIVE;
+	if (!can_graph) return capture_only ? fail(KLG_ERR_INVALID, "klg_script_capture_span: nothing captured (pending events / uploads, kernel timing on, KLG_GRAPH=0, or a bank whose blocks need a host pass)") : enqueue_span();
+	for (const auto& g : k->graphs) if (g.first == first_block && g.blocks == blocks && g.n == n && g.d_out == d_out && g.st == st) {
+		if (capture_only) return 0;
+		HIP_TRY(hipGraphLaunch(g.exec, st)); s->stages_dirty = true; s->scripted = true; return 0;
+	}
+	const bool was_dirty = s->stages_dirty, was_scripted = s->scripted;
+	if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return capture_only ? fail(KLG_ERR_HIP, "klg_script_capture_span: the stream cannot be captured") : enqueue_span(); }
+	const int rc = enqueue_span();
+	hipGraph_t graph = nullptr;
+	const hipError_t ce = hipStreamEndCapture(st, &graph);
+	hipGraphExec_t exec = nullptr;
+	const bool ok = !rc && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec;
+	if (graph) (void)hipGraphDestroy(graph);
+	if (!ok) { (void)hipGetLastError(); if (capture_only) { s->stages_dirty = was_dirty; s->scripted = was_scripted; return fail(KLG_ERR_HIP, "klg_script_capture_span: capture failed"); } return rc ? rc : enqueue_span(); }
+	if (k->graphs.size() >= 8) script_drop_graphs(k);                // (a handful of spans at most: a render loop replays the same few)
+	k->graphs.push_back({ first_block, blocks, n, d_out, st, exec });
+	if (capture_only) { s->stages_dirty = was_dirty; s->scripted = was_scripted; return 0; }      // (nothing has run)
+	HIP_TRY(hipGraphLaunch(exec, st));
 	return 0;
 }
+extern "C" int klg_script_render_device(klg_script* k, int first_block, int blocks, float* d_out, int n, void* hip_stream) { return script_render(k, first_block, blocks, d_out, n, hip_stream, false); }
+// the capture without the run: a later klg_script_render_device of the same span on the same stream only replays (a host that wants its first timed
+// call free of the one-off capture / instantiation cost)
+extern "C" int klg_script_capture_span(klg_script* k, int first_block, int blocks, float* d_out, int n, void* hip_stream) { return script_render(k, first_block, blocks, d_out, n, hip_stream, true); }
 
 extern "C" int klg_timing_begin(klg_synth* s) { if (!s) return fail(KLG_ERR_INVALID, "NULL handle");
  if (s->multi) { for (klg_synth* sh : s->multi->shard) klg_timing_begin(sh); return 0; } s->timing = true; s->launches = 0; return 0; }

@@ -200,3 +200,40 @@ def test_script_rendered_in_one_call_equals_block_by_block():
             script.close(); bank.close()
         assert np.abs(outs[0]).max() > 0
         assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), synths
+
+
+def test_script_span_replayed_as_a_graph_equals_the_launches():
+    """klg_script_render_device captures a span's launches as a hipGraph the first time and replays it afterwards: the same span rendered three
+    times (capture + two replays, the voices replay the script from block 0 each time) gives the same bits every time, and the same as with
+    KLG_GRAPH=0 (plain launches)."""
+    import os
+    import torch
+    import klang_amd
+    N, B = 64, 16
+    outs = {}
+    for mode in ("graph", "plain"):
+        if mode == "plain":
+            os.environ["KLG_GRAPH"] = "0"
+        try:
+            bank = klang_amd.SynthBank("sub2a", synths=3, notes=128, max_block=N)
+            V = bank.voices
+            rng = np.random.default_rng(4)
+            script = klang_amd.EventScript(bank, B)
+            first = script.add_records(bank.note_records((np.arange(V) // 128).astype(np.int32), rng.integers(40, 90, size=V).astype(np.int32), rng.uniform(0.3, 1.0, size=V).astype(np.float32)))
+            v = np.arange(V)
+            script.note_on(np.zeros(V, np.int32), v, first + v)
+            script.note_off(6 + v % 3, v)
+            script.commit()
+            out = torch.zeros((B, 2, N), dtype=torch.float32, device="cuda")
+            res = []
+            for _ in range(3):
+                script.render_device(0, B, out.data_ptr(), N)
+                bank.sync(); torch.cuda.synchronize()
+                res.append(out.cpu().numpy().copy())
+            outs[mode] = res
+            script.close(); bank.close()
+        finally:
+            os.environ.pop("KLG_GRAPH", None)
+    assert np.abs(outs["graph"][0]).max() > 0
+    for r in outs["graph"][1:] + outs["plain"]:
+        assert np.array_equal(r.view(np.uint32), outs["graph"][0].view(np.uint32))
