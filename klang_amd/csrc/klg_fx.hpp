@@ -948,6 +948,7 @@ typedef float rvq_v4 __attribute__((ext_vector_type(4)));
 // rvq_await waits and moves a set into ordinary registers, which the compiler sees defined only there.
 // vmcnt: loads retire in order, so "at most N outstanding" with N = the loads requested since (two later batches = 8) is exact for the
 // rows whatever the ring stores in between do.  "memory" clobbers pin every other memory instruction on its side of both statements.
+template<int FD, int E, int O> struct RvqMode { static constexpr int fd = FD, e = E, o = O; };   // see `step` in klg_fx_reverb_q
 struct RvqRows {
 	float f[2 * RVQ_B];
 	template<int I> __device__ __forceinline__ float F() const { return f[I]; }
@@ -1222,11 +1223,19 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	// A steady batch is ONE basic block of eight samples (no lane-predicated branch: what only some lanes need is computed by all of
 	// them — a masked-off lane costs the same issue slot), so the scheduler can fill the latency of one sample's LDS / bpermute answers with
 	// the arithmetic of its neighbours.
-	auto step = [&](auto guarded, auto place, const int t, const RvqRows& X, const RvqLds& L) __attribute__((always_inline)) {
-		constexpr bool G = decltype(guarded)::value;
+	// A batch's MODE says, per stage, whether its lanes test if their sample lies inside the block and how what they write reaches the rings:
+	//   fd (FilteredDelays): 0 every lane runs, pairs collected, the 64-byte piece flushed at u = 7 (steady) | 1 tested, pairs stored one by one (an edge off the grid)
+	//                        | 2 tested, collected and flushed (an edge ON the grid: the piece is complete) | 3 tested, nothing stored (the iterations before an aligned block: only
+	//                        mid[]'s first pair exists, and it travels in pp to the next batch's slot 0)
+	//   e (early filter):    0 runs, collected, flushed at u = 5 | 1 tested, stored one by one | 2 tested, collected and flushed | 3 tested, collected only
+	//   o (output):          0 runs | 1 tested
+	// (8-byte pair stores are not merged on their way to memory: every one is a 32-byte write — 11 - 14 KB per instance and block at the edges,
+	//  profiles/r03_pmc/reverb_q_traffic_vs_block_length.jsonl; on the grid the edges are whole pieces too.)
+	auto step = [&](auto mode, auto place, const int t, const RvqRows& X, const RvqLds& L) __attribute__((always_inline)) {
+		constexpr int MFD = decltype(mode)::fd, ME = decltype(mode)::e, MO = decltype(mode)::o;
 		constexpr int u = decltype(place)::value;
 		const int e = t + 2, sfd = t + cf, o = t - 1;
-		const bool e_on = !G || (e >= 0 && e < n), fd_on = !G || (sfd >= 0 && sfd < n), o_on = !G || (o >= 0 && o < n);
+		const bool e_on = ME == 0 || (e >= 0 && e < n), fd_on = MFD == 0 || (sfd >= 0 && sfd < n), o_on = MO == 0 || (o >= 0 && o < n);
 		int ewpos = epos0 + e; if (ewpos >= RV_ESIZE) ewpos -= RV_ESIZE; if (ewpos < 0) ewpos += RV_ESIZE;   // uniform: the early write cursor of sample e
 		// ---- requests whose answers are needed later in this iteration / in the next one ----
 		const float from_mid = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssum_prev), 0x118, 0xF, 0xF, true));   // late[]'s input: mid[]'s sum of the previous iteration (DPP row_shr:8 — lane L takes lane L - 8 of its row of 16)
@@ -1236,47 +1245,49 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 		const float r1v = X.template F<2 * u>(), r2v = X.template F<2 * u + 1>();
 		const float fdt1 = r0 + ffrac * (r1v - r0), fdt2 = r1v + ffrac * (r2v - r1v);     // the two delay reads of this sample (Delay::operator>> klang.h:3491-3500)
 		float ssum = 0.f, lr_in = 0.f;
+		const int fbase = (fpos0 + 2 * t >= RV_FSIZE) ? fpos0 + 2 * t - RV_FSIZE : fpos0 + 2 * t;   // uniform: late[]'s write cursor (mid[] is one sample = 2 ahead)
+		float wa = pp0, wb = pp1;                                                // this slot's pair: mid[] (one sample ahead) stores the PREVIOUS iteration's, late[] this one's
 		if (fd_on) {
 			const float dl = biquad_process(ff, fdt1) * fgain;                // signals<4> delays = { delay[0..3] }: first process() — (in >> delay >> filter) * gain, Reverb.k:130-132
 			const float d0 = quad_bcast<0>(dl), d1 = quad_bcast<1>(dl), d2 = quad_bcast<2>(dl), d3 = quad_bcast<3>(dl);
 			const float fb = m0 * d0 + m1 * d1 + m2 * d2 + m3 * d3;           // (delays >> matrix): row kk, products summed left to right (klang.h:1462-1467)
 			lr_in = r < 8 ? r1_now : from_mid;
 			const float fin_new = fb + lr_in;                                 // fb[k] = ... + in;  fb[k] >> delay[k]
-			const int fbase = (fpos0 + 2 * t >= RV_FSIZE) ? fpos0 + 2 * t - RV_FSIZE : fpos0 + 2 * t;   // uniform: late[]'s write cursor (mid[] is one sample = 2 ahead)
-			int fwpos = fbase + 2 * cf; if (fwpos >= RV_FSIZE) fwpos -= RV_FSIZE; if (fwpos < 0) fwpos += RV_FSIZE;
-			if constexpr (G) {
+			if constexpr (MFD == 1) {
+				int fwpos = fbase + 2 * cf; if (fwpos >= RV_FSIZE) fwpos -= RV_FSIZE; if (fwpos < 0) fwpos += RV_FSIZE;
 				const rvq_f2 pair = { fin, fin_new };                         // the two inputs of this sample (fwpos is even: both in one 8-byte store)
 				*reinterpret_cast<rvq_f2*>(fline + fwpos) = pair;
 				if (fbase < RV_FPAD || fbase + 2 >= RV_FSIZE || fbase < 0) { if (fwpos < RV_FPAD) *reinterpret_cast<rvq_f2*>(fline + fwpos + RV_FSIZE) = pair; }   // mirror (the outer test is uniform and almost never true)
 			}
-			else {
-				Wf[2 * u] = cf ? pp0 : fin; Wf[2 * u + 1] = cf ? pp1 : fin_new;   // stored with the rest of the batch (flush below)
-				if constexpr (u == RVQ_B - 1) {
-					const int w0 = fbase - 2 * (RVQ_B - 1);                   // uniform and a multiple of 16 (the grid): the batch's piece of every line, never across the ring's end
-					// A lane holds the 64 bytes of ITS line; stored as they are, every 16-byte quarter is a write request of its own to the L2
-					// (64 lanes, 64 lines: nothing to merge — 10.7 M requests per block at 4096 instances, the kernel's bound).  The four
-					// lanes of a quad swap quarters through LDS instead: store v of lane i is quarter i of the quad's line v, so a quad
-					// writes 64 contiguous bytes per instruction — one request.
-#pragma unroll
-					for (int v = 0; v < 4; v++) { const rvq_v4 x = { Wf[4 * v], Wf[4 * v + 1], Wf[4 * v + 2], Wf[4 * v + 3] }; xq_mine[v] = x; }
-					wave_sync();
-					rvq_v4 quarter[4];
-#pragma unroll
-					for (int v = 0; v < 4; v++) quarter[v] = xq_quad[v * (RVQ_XQ_LD / 4)];
-					wave_sync();                                              // (the next batch's writes come after these reads)
-#pragma unroll
-					for (int v = 0; v < 4; v++) *reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0) = quarter[v];
-					if (w0 < RV_FPAD) {                                       // the mirrored head (two batches per lap of the ring)
-#pragma unroll
-						for (int v = 0; v < 4; v++) *reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0 + RV_FSIZE) = quarter[v];
-					}
-				}
-			}
+			wa = cf ? pp0 : fin; wb = cf ? pp1 : fin_new;
 			pp0 = fin; pp1 = fin_new;
 			fin = fin_new;
 			const float o2 = biquad_process(ff, fdt2) * fgain;                // the `+` chain processes each FilteredDelay a second time
 			const float q0 = quad_bcast<0>(o2), q1 = quad_bcast<1>(o2), q2 = quad_bcast<2>(o2), q3 = quad_bcast<3>(o2);
 			ssum = q3 + (q2 + (q0 + q1));                                     // ((o0 + o1) + o2) + o3 as the reference's `+` chain associates
+		}
+		if constexpr (MFD == 0 || MFD == 2) {                                 // every lane, also one whose own sample lies outside the block (mid[] in a block's last iteration: its slot is pp)
+			Wf[2 * u] = wa; Wf[2 * u + 1] = wb;                               // stored with the rest of the batch (flush below)
+			if constexpr (u == RVQ_B - 1) {
+				const int w0 = fbase - 2 * (RVQ_B - 1);                   // uniform and a multiple of 16 (the grid): the batch's piece of every line, never across the ring's end
+				// A lane holds the 64 bytes of ITS line; stored as they are, every 16-byte quarter is a write request of its own to the L2
+				// (64 lanes, 64 lines: nothing to merge — 10.7 M requests per block at 4096 instances, the kernel's bound).  The four
+				// lanes of a quad swap quarters through LDS instead: store v of lane i is quarter i of the quad's line v, so a quad
+				// writes 64 contiguous bytes per instruction — one request.
+#pragma unroll
+				for (int v = 0; v < 4; v++) { const rvq_v4 x = { Wf[4 * v], Wf[4 * v + 1], Wf[4 * v + 2], Wf[4 * v + 3] }; xq_mine[v] = x; }
+				wave_sync();
+				rvq_v4 quarter[4];
+#pragma unroll
+				for (int v = 0; v < 4; v++) quarter[v] = xq_quad[v * (RVQ_XQ_LD / 4)];
+				wave_sync();                                              // (the next batch's writes come after these reads)
+#pragma unroll
+				for (int v = 0; v < 4; v++) *reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0) = quarter[v];
+				if (w0 < RV_FPAD) {                                       // the mirrored head (two batches per lap of the ring)
+#pragma unroll
+					for (int v = 0; v < 4; v++) *reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0 + RV_FSIZE) = quarter[v];
+				}
+			}
 		}
 		if constexpr (u == RVQ_B - 1) fr0 = r2v;                             // row last + 2 of the batch's last sample is row `last` of the next batch's first
 		// ---- early stage, sample e: in >> lpf >> hpf >> delay  Reverb.k:88 ----
@@ -1285,13 +1296,13 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 			const float y = biquad_process(ehpf, biquad_process(elpf, x_in_now));
 			elz0 = elpf.z0; elz1 = elpf.z1; ehz0 = ehpf.z0; ehz1 = ehpf.z1;
 			We[(u + 2) & (RVQ_B - 1)] = y;
-			if constexpr (G) {
+			if constexpr (ME == 1) {
 				if (efilter) {
 					eline[ewpos] = y;
 					if (ewpos < RV_EMIRROR) eline[ewpos + RV_ESIZE] = y;      // mirror (a uniform test)
 				}
 			}
-			else if constexpr (u == RVQ_B - 3) {
+			else if constexpr (ME != 3 && u == RVQ_B - 3) {
 				if (efilter) {
 					const int w0 = ewpos - (RVQ_B - 1);                       // uniform and a multiple of 8 (the grid)
 					typedef float rvq_v4e __attribute__((ext_vector_type(4), aligned(16)));
@@ -1313,31 +1324,53 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 		ssum_prev = ssum; lr_prev = lr_in;
 	};
 	// a batch: request the rows of the batch after next (into the set the previous batch has used), read the next batch's LDS values, run
-	auto batch = [&](auto guarded, auto guarded_next, const int t0, auto set, const RvqLds& L, auto set_req, RvqLds& Lnext) __attribute__((always_inline)) {
+	auto batch = [&](auto mode, auto guarded_next, const int t0, auto set, const RvqLds& L, auto set_req, RvqLds& Lnext) __attribute__((always_inline)) {
 		request(set_req);
 		fetch(guarded_next, Lnext, t0 + RVQ_B);
 		RvqRows X;
 		rvq_await<decltype(set)::value, 8>(X);
-		step(guarded, IntTag<0>(), t0 + 0, X, L); step(guarded, IntTag<1>(), t0 + 1, X, L); step(guarded, IntTag<2>(), t0 + 2, X, L); step(guarded, IntTag<3>(), t0 + 3, X, L);
-		step(guarded, IntTag<4>(), t0 + 4, X, L); step(guarded, IntTag<5>(), t0 + 5, X, L); step(guarded, IntTag<6>(), t0 + 6, X, L); step(guarded, IntTag<7>(), t0 + 7, X, L);
+		step(mode, IntTag<0>(), t0 + 0, X, L); step(mode, IntTag<1>(), t0 + 1, X, L); step(mode, IntTag<2>(), t0 + 2, X, L); step(mode, IntTag<3>(), t0 + 3, X, L);
+		step(mode, IntTag<4>(), t0 + 4, X, L); step(mode, IntTag<5>(), t0 + 5, X, L); step(mode, IntTag<6>(), t0 + 6, X, L); step(mode, IntTag<7>(), t0 + 7, X, L);
 	};
-	const BoolTag<true> ramp; const BoolTag<false> steady;
+	const BoolTag<true> gfetch; const BoolTag<false> sfetch;                    // the next batch's LDS values: indices clamped to the block / as they are
+	const RvqMode<1, 1, 1> ramp; const RvqMode<0, 0, 0> steady;
+	const RvqMode<3, 3, 1> lead_in; const RvqMode<2, 2, 1> edge;               // the two kinds of edge batch of a block that starts and ends on the grid
 	// iterations t = -2 .. n in batches of eight; the rows of a batch are requested two batches ahead (a wave alone on its SIMD has nothing
 	// but distance to hide HBM latency with; a batch is about a microsecond).  The sched_barrier: the rows are REQUESTED there, not where used.
 	// (A request past the block's end reads rows that exist and are not used.)
 	int t0 = t_first;
-	request(Bn); fetch(ramp, LA, t0);
-	batch(ramp, ramp, t0, A, LA, Cn, LB); t0 += RVQ_B;                          // (iterations before t = -2 find every stage off)
-	batch(ramp, ramp, t0, Bn, LB, A, LC); t0 += RVQ_B;                          // ... up to t_s - 1
+	request(Bn); fetch(gfetch, LA, t0);
+	// A block that starts and ends ON the grid (both cursors at a multiple of the piece, a whole number of batches — the usual case: blocks of 64 / 256 /
+	// 1024 samples from a host that always asks for the same length) has no ragged edge: the batch of iterations -8 .. -1 only produces mid[]'s first pair
+	// and the early filter's first two samples (carried over in registers), the batches 0 .. 7 and n - 8 .. n - 1 hold complete pieces and store them whole.
+	const int steady_batches = n / RVQ_B - 2;
+	if (t_s == RVQ_B && n % RVQ_B == 0 && steady_batches >= 3 && steady_batches % 3 == 0) {
+		batch(lead_in, gfetch, t0, A, LA, Cn, LB); t0 += RVQ_B;                 // t = -8 .. -1
+		batch(edge, sfetch, t0, Bn, LB, A, LC); t0 += RVQ_B;                    // t = 0 .. 7: every FilteredDelay and early sample of the piece is inside the block; only the output of t = 0 is not
+		for (int turn = steady_batches / 3; turn > 1; turn--, t0 += 3 * RVQ_B) {
+			batch(steady, sfetch, t0, Cn, LC, Bn, LA);
+			batch(steady, sfetch, t0 + RVQ_B, A, LA, Cn, LB);
+			batch(steady, sfetch, t0 + 2 * RVQ_B, Bn, LB, A, LC);
+		}
+		batch(steady, sfetch, t0, Cn, LC, Bn, LA);
+		batch(steady, sfetch, t0 + RVQ_B, A, LA, Cn, LB);
+		batch(steady, gfetch, t0 + 2 * RVQ_B, Bn, LB, A, LC); t0 += 3 * RVQ_B;
+		batch(edge, gfetch, t0, Cn, LC, Bn, LA); t0 += RVQ_B;                   // t = n - 8 .. n - 1: mid[]'s last slot is the pair of t = n - 2, the early piece is complete at t = n - 3
+		batch(ramp, gfetch, t0, A, LA, Cn, LB); t0 += RVQ_B;                    // t = n: the last output sample
+		t0 = n + 1;
+	}
+	else {
+	batch(ramp, gfetch, t0, A, LA, Cn, LB); t0 += RVQ_B;                        // (iterations before t = -2 find every stage off)
+	batch(ramp, gfetch, t0, Bn, LB, A, LC); t0 += RVQ_B;                        // ... up to t_s - 1
 	if (t0 + 3 * RVQ_B - 1 <= n - 3) {                                          // three steady batches per turn (t >= 1 and t + 2 < n throughout): the sets swap roles
 		for (; t0 + 6 * RVQ_B - 1 <= n - 3; t0 += 3 * RVQ_B) {                  // ... while a whole steady turn follows
-			batch(steady, steady, t0, Cn, LC, Bn, LA);
-			batch(steady, steady, t0 + RVQ_B, A, LA, Cn, LB);
-			batch(steady, steady, t0 + 2 * RVQ_B, Bn, LB, A, LC);
+			batch(steady, sfetch, t0, Cn, LC, Bn, LA);
+			batch(steady, sfetch, t0 + RVQ_B, A, LA, Cn, LB);
+			batch(steady, sfetch, t0 + 2 * RVQ_B, Bn, LB, A, LC);
 		}
-		batch(steady, steady, t0, Cn, LC, Bn, LA);                              // the last steady turn: what follows it is guarded
-		batch(steady, steady, t0 + RVQ_B, A, LA, Cn, LB);
-		batch(steady, ramp, t0 + 2 * RVQ_B, Bn, LB, A, LC);
+		batch(steady, sfetch, t0, Cn, LC, Bn, LA);                              // the last steady turn: what follows it is guarded
+		batch(steady, sfetch, t0 + RVQ_B, A, LA, Cn, LB);
+		batch(steady, gfetch, t0 + 2 * RVQ_B, Bn, LB, A, LC);
 		t0 += 3 * RVQ_B;
 		// what the steady batches still hold: mid[]'s pair of the last iteration, the early samples of the last two
 		{
@@ -1356,10 +1389,11 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 		}
 	}
 	// the last batches, guarded (the roles of the sets stay compile-time: no array ever lives in memory); at most two of them could have been steady
-	if (t0 <= n) { batch(ramp, ramp, t0, Cn, LC, Bn, LA); t0 += RVQ_B; }
-	if (t0 <= n) { batch(ramp, ramp, t0, A, LA, Cn, LB); t0 += RVQ_B; }
-	if (t0 <= n) { batch(ramp, ramp, t0, Bn, LB, A, LC); t0 += RVQ_B; }
-	if (t0 <= n) { batch(ramp, ramp, t0, Cn, LC, Bn, LA); t0 += RVQ_B; }
+	if (t0 <= n) { batch(ramp, gfetch, t0, Cn, LC, Bn, LA); t0 += RVQ_B; }
+	if (t0 <= n) { batch(ramp, gfetch, t0, A, LA, Cn, LB); t0 += RVQ_B; }
+	if (t0 <= n) { batch(ramp, gfetch, t0, Bn, LB, A, LC); t0 += RVQ_B; }
+	if (t0 <= n) { batch(ramp, gfetch, t0, Cn, LC, Bn, LA); t0 += RVQ_B; }
+	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // (requests past the block's end land in accumulation registers nobody reads)
 	wave_sync();
 	if (whole) {
