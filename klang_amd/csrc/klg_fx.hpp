@@ -927,10 +927,13 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 // for bit in tests/test_gpu_fx.py: KLG_FX_REVERB1=1 selects the single-lane kernel, KLG_FX_REVERB16=1 the sixteen-wave one).
 enum { RVQ_MAX_INSTANCES = 8192 };       // banks up to this size run klg_fx_reverb_q (measured: profiles/r02_fx_sizes.md)
 enum { RVQ_WG = 64 };
-// an early line in layout 1: [0, RV_ESIZE) the ring, then RV_EMIRROR floats mirroring positions 0 .. 15, then four floats that are ALWAYS ZERO (RV_EZERO): where a
+#ifndef KLG_RVQ_ABLATE
+#define KLG_RVQ_ABLATE 0          // measurement builds only (tools/rvq_ablate.sh): 1 no FilteredDelay piece stores, 2 no early-line stores, 4 no output block, 8 no record write-back
+#endif
+// an early line in layout 1: [0, RV_ESIZE) the ring, then RV_EMIRROR floats mirroring positions 0 .. 15, then sixteen floats that are ALWAYS ZERO (RV_EZERO; sixteen, not two: a line's length stays a multiple of 128 bytes, so every line's 32-byte store pieces are whole sectors): where a
 // tap whose read position rounded up to exactly RV_ESIZE is pointed (stereo_delay_tap: that tap reads the pad — zeros —; one compare and one select per tap,
 // no branch: a rarely-taken branch cost 9 VALU per tap in register copies at its join, profiles/r03_pmc/pmc_reverb_q_4096_padbranch.json)
-enum { RVQ_B = 8, RV_FPAD = 32, RV_EMIRROR = 16, RV_EZERO = RV_ESIZE + RV_EMIRROR, RV_EPAD = RV_EMIRROR + 4, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
+enum { RVQ_B = 8, RV_FPAD = 32, RV_EMIRROR = 16, RV_EZERO = RV_ESIZE + RV_EMIRROR, RV_EPAD = RV_EMIRROR + 16, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
 static_assert(RV_ESTRIDE % 4 == 0, "16-byte stores into an early line need 16-byte aligned line starts");
 enum { RVQ_XQ_LD = 20, RVQ_XQ_FLOATS = 64 * RVQ_XQ_LD };  // the quarter exchange of the ring stores: 64 rows of 16 floats, padded
 enum { RVQ_TILE_ROWS = 17 };             // LDS per wave, rows of n floats: 0..7 the caller's block (instance * 2 + channel), 8 scrap, 9..16 the early sums
@@ -1274,6 +1277,10 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 				// (64 lanes, 64 lines: nothing to merge — 10.7 M requests per block at 4096 instances, the kernel's bound).  The four
 				// lanes of a quad swap quarters through LDS instead: store v of lane i is quarter i of the quad's line v, so a quad
 				// writes 64 contiguous bytes per instruction — one request.
+				// The stores are NONTEMPORAL: a piece is half of a 128-byte L2 line whose other half comes a batch later, and nobody
+				// reads either for milliseconds.  Kept as ordinary dirty lines under this kernel's read stream, a third of them went to memory twice
+				// (WRITE_SIZE 200 MB for 150 MB of distinct bytes at 4,096 instances; 154 MB with the hint — tools/rvq_ablate.sh,
+				// profiles/r03_pmc/reverb_q_writes.jsonl).
 #pragma unroll
 				for (int v = 0; v < 4; v++) { const rvq_v4 x = { Wf[4 * v], Wf[4 * v + 1], Wf[4 * v + 2], Wf[4 * v + 3] }; xq_mine[v] = x; }
 				wave_sync();
@@ -1282,7 +1289,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 				for (int v = 0; v < 4; v++) quarter[v] = xq_quad[v * (RVQ_XQ_LD / 4)];
 				wave_sync();                                              // (the next batch's writes come after these reads)
 #pragma unroll
-				for (int v = 0; v < 4; v++) *reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0) = quarter[v];
+				for (int v = 0; v < 4; v++) if (!(KLG_RVQ_ABLATE & 1)) __builtin_nontemporal_store(quarter[v], reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0));
 				if (w0 < RV_FPAD) {                                       // the mirrored head (two batches per lap of the ring)
 #pragma unroll
 					for (int v = 0; v < 4; v++) *reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0 + RV_FSIZE) = quarter[v];
@@ -1308,7 +1315,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 					typedef float rvq_v4e __attribute__((ext_vector_type(4), aligned(16)));
 					rvq_v4e* const dst = reinterpret_cast<rvq_v4e*>(eline + w0);
 #pragma unroll
-					for (int v = 0; v < RVQ_B / 4; v++) { const rvq_v4e x = { We[4 * v], We[4 * v + 1], We[4 * v + 2], We[4 * v + 3] }; dst[v] = x; }
+					for (int v = 0; v < RVQ_B / 4; v++) { const rvq_v4e x = { We[4 * v], We[4 * v + 1], We[4 * v + 2], We[4 * v + 3] }; if (!(KLG_RVQ_ABLATE & 2)) __builtin_nontemporal_store(x, dst + v); }
 					if (w0 < RV_EMIRROR) {
 #pragma unroll
 						for (int j = 0; j < RVQ_B; j++) eline[w0 + j + RV_ESIZE] = We[j];
@@ -1396,7 +1403,8 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // (requests past the block's end land in accumulation registers nobody reads)
 	wave_sync();
-	if (whole) {
+	if (KLG_RVQ_ABLATE & 4) {}
+	else if (whole) {
 		rvq_v4* dst = reinterpret_cast<rvq_v4*>(a.io + (size_t)k0 * 2 * n);
 		const rvq_v4* src = reinterpret_cast<const rvq_v4*>(rvq_tile);
 		const int q4 = n >> 2;
@@ -1407,7 +1415,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 		if (ki < a.K) for (int c = lane; c < n; c += 64) a.io[((size_t)ki * 2 + (R & 1)) * n + c] = rvq_tile[R * ns + c];
 	}
 	// ---- write back what changed ----
-	if (k < a.K) {
+	if (k < a.K && !(KLG_RVQ_ABLATE & 8)) {
 		float* Wr = a.state + k;
 		Wr[(size_t)(fw + FD_Z0) * KP] = ff.z0; Wr[(size_t)(fw + FD_Z1) * KP] = ff.z1; Wr[(size_t)(fw + FD_IN) * KP] = fin;
 		Wr[(size_t)(fw + FD_LASTP) * KP] = __int_as_float((int)(((long long)flast + 2ll * n) % RV_FSIZE));
