@@ -227,6 +227,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 }
 
 template<bool B> struct BoolTag { static constexpr bool value = B; };   // (std::true_type without <type_traits>: this header is also compiled by hipRTC)
+template<int I> struct IntTag { static constexpr int value = I; };
 // -------------------------------------------------------------------------------------------------
 // PingPong.k, eleven waves per 64 instances (the production kernel).
 //
@@ -239,13 +240,28 @@ template<bool B> struct BoolTag { static constexpr bool value = B; };   // (std:
 //                                       cross-feed, both ring writes; also fetches the io rows of chunk j+1
 //   waves 9, 10  FILTER   of chunk j-1: out.l / out.r >> dcfilter over the chunk; the io rows of chunk j-2 are stored
 // A chunk with a near tap (delay < ~0.8 ms, or within a chunk of the full line) is walked in order by wave 1 alone.
+//
+// REQUEST-AHEAD (round 3).  In the pipeline above the audio stage asks for its ring rows and waits for them inside its step: a memory round
+// trip — a microsecond and more — in every one of a block's ten steps, on a chip that a bank of 4,096 instances does not load enough to hide
+// it (one workgroup per CU).  Requesting a step earlier changes nothing (measured): a step's work is a quarter of the round trip.  So when the
+// whole block is known up front — the controls are STATIONARY (below), every tap lies more than P + 1 chunks behind the write cursor, the
+// block is whole chunks — the audio waves run P chunks ahead of themselves: in step j they use the rows of chunk j (requested in step j - P),
+// then request the rows of chunk j + P and the caller's rows of chunk j + P + 1; nothing requested in a step is waited for in it (the barrier
+// waits for LDS only, and the requests come back in the order they are used in).  P per workgroup width: what the registers hold.
 // Arithmetic and its order are those of klg_fx_pingpong (KLG_FX_PINGPONG1=1) and the reference, bit for bit.
+#ifndef KLG_PPX_VARIANT
+#define KLG_PPX_VARIANT 0         // measurement builds only: 1 the filter waves store their chunk (one step fewer), 2 the first requests wait for the decision
+#endif
+#ifndef KLG_PPX_ABLATE
+#define KLG_PPX_ABLATE 0          // measurement builds only (tools/ppx_ablate.sh): 1 no DC filter chain, 2 no output stores, 4 no ring requests, 8 no audio stage
+#endif
 enum { PPX_CHUNK = 32, PPX_AUDIO = 8, PPX_PER = PPX_CHUNK / PPX_AUDIO, PPX_WAVES = 1 + PPX_AUDIO + 2, PPX_THREADS = PPX_WAVES * 64 };
 
 template<int G> struct PpxLds {
 	float tile[4][2][PPX_CHUNK][G + 1];         // [chunk & 3][channel][sample][instance]: loaded, audio, filter, store
 	float D[2][PPX_CHUNK][G];                   // delay time (smoothed controls[1]) per sample, [chunk & 1]
 	int far[2];                                 // 1: every tap of the chunk is far from the write cursor
+	int deep;                                   // the block runs the request-ahead pipeline (see PPX_DEEP below)
 };
 
 // G = instances per workgroup: 64 (a whole ring group: banks that fill the chip on their own), or 32 / 16 — a half / a quarter of a
@@ -308,6 +324,196 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	Biquad dc = { a.dc.b0, a.dc.b1, a.dc.b2, a.dc.a1, a.dc.a2, 0.f, 0.f };
 	if (w_filter) { dc.z0 = PPW(PP_Z + 2 * fch); dc.z1 = PPW(PP_Z + 2 * fch + 1); }
 
+	// FILTER of chunk jf, then its store (the filter wave's own rows: wave-level ordering is enough)
+	auto filter_stage = [&](const int jf, auto store_c) __attribute__((always_inline)) {
+		const int s0 = jf * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
+		float (*T)[G + 1] = S.tile[jf & 3][fch];
+		auto filter_chunk = [&](auto full_c) {                                    // (FULL: see far_chunk — a bounds test per sample is a join per sample)
+			constexpr bool FULL = decltype(full_c)::value;
+			for (int b = 0; b < PPX_CHUNK; b += 8) {                              // eight LDS reads in flight, then the (sequential) filter
+				float x[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++) x[u] = T[b + u][li];
+#pragma unroll
+				for (int u = 0; u < 8; u++) if ((FULL || b + u < cl) && !(KLG_PPX_ABLATE & 1)) x[u] = biquad_process(dc, x[u]);     // out >> dcfilter[ch] >> out
+				if (lane < G) {
+#pragma unroll
+					for (int u = 0; u < 8; u++) T[b + u][li] = x[u];
+				}
+			}
+		};
+		if (cl == PPX_CHUNK) filter_chunk(BoolTag<true>{}); else filter_chunk(BoolTag<false>{});
+		if constexpr (!decltype(store_c)::value) return;                          // (the request-ahead pipeline: the audio waves store the chunk a step later)
+		wave_sync();
+		int sl = lane; asm volatile("" : "+v"(sl));
+		const int col = sl & 31, half = sl >> 5;
+		char* dst = (char*)(a.io + (size_t)k0 * 2 * n + s0);
+		if (KLG_PPX_ABLATE & 2) {}
+		else if (cl == PPX_CHUNK && k0 + G <= a.K) {
+#pragma unroll 8
+			for (int it = 0; it < G / 2; it++) { const int inst = 2 * it + half; *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst]; }
+		}
+		else {
+#pragma unroll 8
+			for (int it = 0; it < G / 2; it++) {
+				const int inst = 2 * it + half;
+				if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
+			}
+		}
+	};
+
+	// ---------------- the request-ahead pipeline (header comment) ----------------
+	constexpr int PPX_DEEP = G == 16 ? 4 : G == 32 ? 3 : 2;                   // chunks an audio wave runs ahead of itself
+	constexpr int P = PPX_DEEP;
+	constexpr int DIOV = G * 2 * PPX_CHUNK / (PPX_AUDIO * 64);                  // values of the caller's chunk per audio thread
+	float iov[P][DIOV];                                                         // the caller's rows of a chunk, requested P steps before they go to LDS
+	float rwl[P][PASSES][3], rwr[P][PASSES][3];                                 // a chunk's ring rows (left / right line), requested P steps before they are used
+	const bool whole_chunks = (n % PPX_CHUNK) == 0, whole_group = k0 + G <= a.K;
+	const float dly = (w_audio && whole_chunks) ? PPW(PP_SM1) : 0.f;            // this instance's delay time: every sample's, if the block turns out stationary
+		// the audio waves' part of step j; SLOT = j mod P (compile-time: the register arrays are indexed by constants only); nch = the block's chunks
+		auto audio_part = [&](auto slot_c, const int j, const int nch) __attribute__((always_inline)) {
+			constexpr int RS = decltype(slot_c)::value, IS = (RS + 1) % P;
+			int at = tid - 64; asm volatile("" : "+v"(at));                    // (see the general loop: keeps per-thread addresses out of loop-invariant registers)
+			const int acol = at & 31, arow = at >> 5;
+			const int jn = j + 1, js = j - 2;
+			if (js >= 0 && js < nch && !(KLG_PPX_ABLATE & 2) && !(KLG_PPX_VARIANT & 1)) {                 // the caller's rows of chunk j - 2 (filtered in the step before): to memory
+				char* dst = (char*)(a.io + (size_t)k0 * 2 * n + js * PPX_CHUNK);
+#pragma unroll
+				for (int i = 0; i < DIOV; i++) {
+					const int row = arow + 16 * i;
+					if (whole_group || k0 + (row >> 1) < a.K) *(float*)(dst + (unsigned)(row * n + acol) * 4u) = S.tile[js & 3][row & 1][acol][row >> 1];
+				}
+			}
+			if (jn >= 0 && jn < nch) {                                      // the caller's rows of chunk j + 1 (requested in step j - P): into LDS
+#pragma unroll
+				for (int i = 0; i < DIOV; i++) { const int row = arow + 16 * i; S.tile[jn & 3][row & 1][acol][row >> 1] = iov[IS][i]; }
+			}
+			const int u0 = (wv - 1) * PPX_PER + lq;
+			if (j >= 0 && j < nch && !(KLG_PPX_ABLATE & 8)) {                                        // AUDIO of chunk j: its rows were requested in step j - P
+				const int pos0 = (int)(((long long)a.position + j * PPX_CHUNK) % SIZE);
+				float (*T)[PPX_CHUNK][G + 1] = S.tile[j & 3];
+#pragma unroll
+				for (int q = 0; q < PASSES; q++) {
+					const int u = u0 + q * SPW, pos = wrap(pos0 + u);
+					const float in_l = T[0][u][li], in_r = T[1][u][li];
+					const float fl = delay_set(pos, SIZE, dly * a.fs.f).fraction, fr = delay_set(pos, SIZE, 0.5f * dly * a.fs.f).fraction;   // (as at the request: a dozen operations, not registers held for P steps)
+					// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
+					const float r1 = rwr[RS][q][0] + fr * (rwr[RS][q][1] - rwr[RS][q][0]);
+					ring_wr(0, pos, in_l + r1 * gain);
+					const float l1 = rwl[RS][q][0] + fl * (rwl[RS][q][1] - rwl[RS][q][0]);
+					const float l2 = rwl[RS][q][1] + fl * (rwl[RS][q][2] - rwl[RS][q][1]);
+					T[0][u][li] = dry * in_l + l1 * (1.f - dry);
+					// dry * in.r + (1.f - dry) * ((in.r + left * gain) >> right) >> out.r;   PingPong.k:67
+					ring_wr(1, pos, in_r + l2 * gain);
+					const float r2 = rwr[RS][q][1] + fr * (rwr[RS][q][2] - rwr[RS][q][1]);
+					T[1][u][li] = dry * in_r + r2 * (1.f - dry);
+				}
+			}
+			const int c = j + P;
+			if (c >= 0 && c < nch && !(KLG_PPX_ABLATE & 4)) {                                        // the ring rows of chunk j + P
+				const int pos1 = (int)(((long long)a.position + c * PPX_CHUNK) % SIZE);
+#pragma unroll
+				for (int q = 0; q < PASSES; q++) {
+					const int u = u0 + q * SPW, pos = wrap(pos1 + u);
+					const Tap tl = delay_set(pos, SIZE, dly * a.fs.f);              // left.set(delay * fs)
+					const Tap tr = delay_set(pos, SIZE, 0.5f * dly * a.fs.f);       // right.set(0.5f * delay * fs)
+					const int i0 = tl.position, i1 = ring_succ(i0, SIZE), i2 = ring_succ(i1, SIZE);   // (a tap may sit on the pad row SIZE: klg_delay.hpp)
+					const int j0 = tr.position, j1 = ring_succ(j0, SIZE), j2 = ring_succ(j1, SIZE);
+					rwl[RS][q][0] = ring_rd(0, i0); rwl[RS][q][1] = ring_rd(0, i1); rwl[RS][q][2] = ring_rd(0, i2);
+					rwr[RS][q][0] = ring_rd(1, j0); rwr[RS][q][1] = ring_rd(1, j1); rwr[RS][q][2] = ring_rd(1, j2);
+				}
+			}
+			const int c2 = j + P + 1;
+			if (c2 >= 0 && c2 < nch) {                                      // the caller's rows of chunk j + P + 1
+				const char* src = (const char*)(a.io + (size_t)k0 * 2 * n + c2 * PPX_CHUNK);
+				if (whole_group) {
+#pragma unroll
+					for (int i = 0; i < DIOV; i++) iov[IS][i] = *(const float*)(src + (unsigned)((arow + 16 * i) * n + acol) * 4u);
+				}
+				else {
+#pragma unroll
+					for (int i = 0; i < DIOV; i++) {
+						const int row = arow + 16 * i, inst = row >> 1;
+						iov[IS][i] = (k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + acol) * 4u) : 0.f;
+					}
+				}
+			}
+		};
+		// The first P steps only request — chunks 0 .. P - 1's ring rows, chunks 0 .. P's caller rows — and need nothing but this lane's own delay time:
+		// they are issued BEFORE the workgroup knows whether the block qualifies (the control wave's words are still on their way), so the
+		// decision costs no round trip of its own.  A block that does not qualify ignores what arrives (every address is a valid one).
+		auto first_requests = [&]() __attribute__((always_inline)) {
+			auto prologue = [&](auto self, auto t_c) __attribute__((always_inline)) {
+				constexpr int T = decltype(t_c)::value, J = T - P - 1;
+				if constexpr (T < P) { audio_part(IntTag<((J % P) + P) % P>{}, J, nchunks); self(self, IntTag<T + 1>{}); }
+			};
+			prologue(prologue, IntTag<0>{});
+		};
+		if (w_audio && whole_chunks && !(KLG_PPX_VARIANT & 2)) first_requests();
+		if (w_control) {
+			// (stationary: every sample's delay time is sm1.)  Rows of chunk c are requested while chunks c - P .. c - 1 are not written yet.
+			const bool far_deep = 0.5f * sm1 * a.fs.f >= (float)((P + 1) * PPX_CHUNK + 3) && sm1 * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
+			const bool ok = stationary && whole_chunks && __ballot(k < a.K && !far_deep) == 0ull;
+			if (lane == 0) S.deep = ok ? 1 : 0;
+		}
+		__syncthreads();
+	if (S.deep) {
+		if (w_control) mdelay = c5;                                             // (no scratch: `else delay = controls[5]`)
+		if (w_audio && (KLG_PPX_VARIANT & 2)) first_requests();
+		// the other waves' part: the LFO keeps running, a chunk per step (control: beside the filter waves, which are slower); FILTER of chunk j - 1
+		auto other_part = [&](const int j) __attribute__((always_inline)) {
+			if (w_control) {
+				const int cc = j - 1;
+				if (cc >= 0 && cc < nchunks) {
+					lfo.increment = lfo_inc;
+					const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);
+					float pos = lfo.position;
+					for (int u = 0; u < PPX_CHUNK; u++) { const float p1 = pos + lfo_inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1; pos = inc_ok ? p2 : pos; }
+					lfo.position = pos;
+				}
+			}
+			else if (j >= 1 && j <= nchunks) filter_stage(j - 1, BoolTag<(KLG_PPX_VARIANT & 1) != 0>{});
+		};
+		// Blocks of 4 / 8 / 16 chunks (128 / 256 / 512 samples): the audio waves' steps are written out one after the other — in straight-line code
+		// the compiler's wait before a use is exactly "everything requested since may still be under way"; through the loop below, with its
+		// guards, it waits for more than it has to (measured at 4,096 instances: 19.4 us with the loop).
+		auto audio_unrolled = [&](auto nch_c) __attribute__((always_inline)) {
+			constexpr int NCH = decltype(nch_c)::value;
+			auto run = [&](auto self, auto t_c) __attribute__((always_inline)) {
+				constexpr int T = decltype(t_c)::value, J = T - 1;
+				if constexpr (J <= NCH + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) {
+					audio_part(IntTag<((J % P) + P) % P>{}, J, NCH);
+					__syncthreads();
+					self(self, IntTag<T + 1>{});
+				}
+			};
+			run(run, IntTag<0>{});
+		};
+		const bool unrolled = nchunks == 4 || nchunks == 8 || nchunks == 16;
+		if (unrolled && w_audio) {
+			if (nchunks == 8) audio_unrolled(IntTag<8>{}); else if (nchunks == 4) audio_unrolled(IntTag<4>{}); else audio_unrolled(IntTag<16>{});
+		}
+		else if (unrolled) {
+			for (int j = -1; j <= nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1); j++) { other_part(j); __syncthreads(); }
+		}
+		else {
+			auto deep_step = [&](auto slot_c, const int j) __attribute__((always_inline)) {
+				if (w_audio) audio_part(slot_c, j, nchunks); else other_part(j);
+				__syncthreads();
+			};
+			int j = -1;
+			deep_step(IntTag<P - 1>{}, j); ++j;                                     // (-1 = P - 1 mod P)
+			for (;;) {
+				if (j > nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) break;
+				deep_step(IntTag<0>{}, j); ++j;
+				if (j > nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) break;
+				deep_step(IntTag<1 % P>{}, j); ++j;
+				if constexpr (P > 2) { if (j > nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) break; deep_step(IntTag<2 % P>{}, j); ++j; }
+				if constexpr (P > 3) { if (j > nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) break; deep_step(IntTag<3 % P>{}, j); ++j; }
+			}
+		}
+	}
+	else
 	for (int j = -1; j <= nchunks; j++) {
 		// ---------------- io rows of chunk j+1 (audio waves; landed in LDS at the end of the step) ----------------
 		const int jn = j + 1;
@@ -464,41 +670,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				}
 			}
 		}
-		// ---------------- FILTER of chunk j-1, then its store (the filter wave's own rows: wave-level ordering is enough) ----------------
-		if (w_filter && j >= 1 && j <= nchunks) {
-			const int jf = j - 1, s0 = jf * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
-			float (*T)[G + 1] = S.tile[jf & 3][fch];
-			auto filter_chunk = [&](auto full_c) {                                    // (FULL: see far_chunk — a bounds test per sample is a join per sample)
-				constexpr bool FULL = decltype(full_c)::value;
-				for (int b = 0; b < PPX_CHUNK; b += 8) {                              // eight LDS reads in flight, then the (sequential) filter
-					float x[8];
-#pragma unroll
-					for (int u = 0; u < 8; u++) x[u] = T[b + u][li];
-#pragma unroll
-					for (int u = 0; u < 8; u++) if (FULL || b + u < cl) x[u] = biquad_process(dc, x[u]);     // out >> dcfilter[ch] >> out
-					if (lane < G) {
-#pragma unroll
-						for (int u = 0; u < 8; u++) T[b + u][li] = x[u];
-					}
-				}
-			};
-			if (cl == PPX_CHUNK) filter_chunk(BoolTag<true>{}); else filter_chunk(BoolTag<false>{});
-			wave_sync();
-			int sl = lane; asm volatile("" : "+v"(sl));
-			const int col = sl & 31, half = sl >> 5;
-			char* dst = (char*)(a.io + (size_t)k0 * 2 * n + s0);
-			if (cl == PPX_CHUNK && k0 + G <= a.K) {
-#pragma unroll 8
-				for (int it = 0; it < G / 2; it++) { const int inst = 2 * it + half; *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst]; }
-			}
-			else {
-#pragma unroll 8
-				for (int it = 0; it < G / 2; it++) {
-					const int inst = 2 * it + half;
-					if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
-				}
-			}
-		}
+		// ---------------- FILTER of chunk j-1, then its store ----------------
+		if (w_filter && j >= 1 && j <= nchunks) filter_stage(j - 1, BoolTag<true>{});
 		if (load_next) {
 #pragma unroll
 			for (int i = 0; i < IOV; i++) { const int row = arow + 16 * i; S.tile[jn & 3][row & 1][acol][row >> 1] = iov[i]; }
@@ -694,7 +867,6 @@ struct Rv16Lds {
 	float CF[15][64];                           // per-instance constants only two waves per channel need: early LPF / HPF coefficients, dry/c1/c2/c3/wet
 };
 
-template<int I> struct IntTag { static constexpr int value = I; };   // (std::true_type without <type_traits>: this header is also compiled by hipRTC)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every ring-row
 // prefetch and ring store in flight twice per sample; the rings need no cross-wave ordering inside a block (a row written at

@@ -422,7 +422,8 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		// the pipeline's time is a workgroup's instruction count on its one CU: a quarter / a half of a ring group per workgroup while
 		// the bank does not fill the chip that way either (klg_fx_pingpong_x<G>; KLG_FX_PINGPONG_G = 16 / 32 / 64 forces the width)
 		else {
-			static const int forced = []() { const char* e = getenv("KLG_FX_PINGPONG_G"); return e ? atoi(e) : 0; }();
+			const char* const forced_env = getenv("KLG_FX_PINGPONG_G");                 // (read per launch: the tests switch it)
+			const int forced = forced_env ? atoi(forced_env) : 0;
 			const int G = forced == 16 || forced == 32 || forced == 64 ? forced : (f->kpad <= 4096 ? 16 : f->kpad <= 8192 ? 32 : 64);
 			if (G == 16) hipLaunchKernelGGL(klg_fx_pingpong_x<16>, dim3((unsigned)(f->kpad / 16)), dim3(PPX_THREADS), 0, st, a);
 			else if (G == 32) hipLaunchKernelGGL(klg_fx_pingpong_x<32>, dim3((unsigned)(f->kpad / 32)), dim3(PPX_THREADS), 0, st, a);

@@ -168,21 +168,29 @@ def test_a_control_the_effect_writes_comes_back_and_the_hosts_set_wins():
     assert not np.allclose(va[0], 0.5) and len(set(va[-1].tolist())) > 1        # the effect moved them, each instance its own way
 
 
-def test_pingpong_with_stationary_controls(oracle_build):
+@pytest.mark.parametrize("block,width", [(256, 0), (64, 16), (96, 32), (512, 64), (1024, 32), (256, 64), (80, 16)])
+def test_pingpong_with_stationary_controls(oracle_build, block, width, monkeypatch):
     """Some ten thousand samples after a dial last moved both control smoothers sit at their fp32 fixed points; klg_fx_pingpong_x then skips the
-    serial control chain (every sample's delay time IS the smoothed value) and only walks the LFO phase.  160 blocks of 256 samples with the
-    dials set once (instances differ), then one dial moved at block 150 — in and out of the stationary state — against the oracle, bit for
-    bit, early blocks (converging), late blocks (stationary) and the blocks around the change."""
-    dump = [0, 1, 40, 100, 148, 149, 150, 151, 159]
-    s = Scenario(patch="pingpong", block=256, blocks=160, instances=20, burst=160 * 256, seed=11, dump=dump)
+    serial control chain (every sample's delay time IS the smoothed value), only walks the LFO phase — and, when every tap also lies far enough
+    behind the write cursor and the block is whole chunks, runs its audio waves several chunks ahead of themselves (the request-ahead pipeline:
+    written out step by step for blocks of 4 / 8 / 16 chunks, a loop otherwise; 80 samples is not whole chunks and stays on the general path).
+    40,960 samples with the dials set once (instances differ, some delays too short to qualify), then one dial moved near the end — in and out
+    of the stationary state — against the oracle, bit for bit: early blocks (converging), late blocks (stationary), the blocks around the
+    change; every workgroup width (KLG_FX_PINGPONG_G)."""
+    if width: monkeypatch.setenv("KLG_FX_PINGPONG_G", str(width))
+    B = 40960 // block
+    change = B * 15 // 16
+    dump = sorted({0, 1, B // 4, B * 5 // 8, change - 2, change - 1, change, change + 1, B - 1})
+    s = Scenario(patch="pingpong", block=block, blocks=B, instances=20, burst=40960, seed=11, dump=dump)
     rng = np.random.default_rng(8)
     for k in range(20):
         s.control(0, k, 0, float(rng.uniform(0.2, 0.9)))
         s.control(0, k, 1, float(rng.uniform(0.02, 0.6)))
         s.control(0, k, 5, float(rng.uniform(0.02, 0.6)))
         s.control(0, k, 4, float(rng.uniform(0.3, 1.0)))
+    s.control(0, 3, 1, 0.003); s.control(0, 3, 5, 0.003)           # 3 ms: taps 72 samples behind the cursor — instance 3's workgroup cannot run ahead, the others do
     for k in range(0, 20, 3):
-        s.control(150, k, 5, float(rng.uniform(0.02, 0.6)))
+        s.control(change, k, 5, float(rng.uniform(0.02, 0.6)))
     s.sort()
     got = run_fx_scenario_gpu(s)["per_voice"]
     ref = run_scenario_oracle(s, oracle_build)["per_voice"]
