@@ -449,7 +449,11 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			};
 			prologue(prologue, IntTag<0>{});
 		};
-		if (w_audio && whole_chunks && !(KLG_PPX_VARIANT & 2)) first_requests();
+		// (not with vibrato — a block with an LFO on the delay time is never stationary, and its requests would only be in the way: the audio waves
+		//  see that in two words of their own instances)
+		bool may_qualify = w_audio && whole_chunks;
+		if (may_qualify) { const float c2 = PPW(2), c3 = PPW(3); may_qualify = __ballot((c2 * c2) * ((c3 * c3) * 100.f) * 1.41421354f != 0.f) == 0ull; }
+		if (may_qualify && !(KLG_PPX_VARIANT & 2)) first_requests();
 		if (w_control) {
 			// (stationary: every sample's delay time is sm1.)  Rows of chunk c are requested while chunks c - P .. c - 1 are not written yet.
 			const bool far_deep = 0.5f * sm1 * a.fs.f >= (float)((P + 1) * PPX_CHUNK + 3) && sm1 * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
