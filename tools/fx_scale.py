@@ -1,4 +1,5 @@
-"""tools/fx_scale.py [patch K K ...]... — effect kernel time vs instance count (HIP-event kernel time via klg_fx_timing_*)."""
+"""tools/fx_scale.py [patch K K ...]... — effect kernel time vs instance count (HIP-event kernel time via klg_fx_timing_*).  PingPong is warmed for 300 blocks
+(KLG_FX_WARM): the steady state of a plugin whose dials are not being turned (its control smoothers take some ten thousand samples to settle)."""
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, klang_amd
@@ -11,8 +12,8 @@ for patch, K in jobs:
     bank = klang_amd.FxBank(patch, K, max_block=N)
     g = torch.Generator(device="cuda").manual_seed(1)
     io = (torch.rand((K, 2, N), device="cuda", generator=g) - 0.5)
-    st = torch.cuda.current_stream().cuda_stream
-    for _ in range(4): bank.process_device(io.data_ptr(), N, st)
+    ts = torch.cuda.Stream(); torch.cuda.set_stream(ts); st = ts.cuda_stream       # (not the null stream: its implicit synchronisation shows up in the launch gaps)
+    for _ in range(int(os.environ.get("KLG_FX_WARM", "300" if patch == "pingpong" else "4"))): bank.process_device(io.data_ptr(), N, st)
     torch.cuda.synchronize(); bank.timing_begin(); t0 = time.perf_counter()
     steps = 20
     for _ in range(steps): bank.process_device(io.data_ptr(), N, st)
