@@ -96,7 +96,10 @@ struct LiveMap { std::unordered_map<const void*, uint64_t> serial; uint64_t next
 inline thread_local LiveMap* live = nullptr;
 inline void forget(const void* p) { live->serial.erase(p); }
 // a primitive that lives in a lane record: host mirror <-> its block of record words (include/klang_mi355_graph.h)
-struct Packable { virtual void pack(uint32_t* w) const = 0; virtual void unpack(const uint32_t* w) = 0; virtual ~Packable() { if (live) forget(this); } };
+struct Packable {
+	virtual void pack(uint32_t* w) const = 0; virtual void unpack(const uint32_t* w) = 0; virtual ~Packable() { if (live) forget(this); }
+	virtual void host_cursor(unsigned long long /*inputs so far*/) {}   // an effect's Delay: its write cursor, which on the device is derived from the sample count (a host-run prepare() places read heads against it)
+};
 struct Obj { const void* addr; size_t size; int kind; const Packable* packable; int arg; const void* key = nullptr; uint64_t serial = 0; };     // a primitive or a signal member seen while a Note / Effect was constructed (arg: Delay SIZE; key / serial: liveness)
 // Where construction is noted: the Recorder of a prototype built by notes.add<T>() / gpu::EffectBank<FX> (members = the address range of
 // the object), or the construction LOG every Plugin / Note owns — what lets Effect::process(buffer) and Note::process(buffer) find the
@@ -121,6 +124,7 @@ inline thread_local int log_suppress = 0;                    // notes.add<T>() b
 inline void close_log() { log_target = nullptr; }
 struct Recorder : Sink {
 	bool constructing = false, recording = false;
+	bool host_prepare = false;                                    // prepare() asked Controls::changed(): it stays HOST code (EffectBank runs it per instance and uploads what it changed)
 	klg::graph::Program prog;
 	int next_reg = 0, pending = -1;                              // pending: node whose finished() was just tested by an `if`
 	std::string error;
@@ -390,7 +394,9 @@ struct Controls {
 	Control& operator[](int i) { gpu::close_log(); return items[(size_t)i]; }
 	const Control& operator[](int i) const { return items[(size_t)i]; }
 	unsigned size() const { gpu::close_log(); return (unsigned)items.size(); }
-	bool changed() { bool c = false; for (size_t i = 0; i < items.size(); i++) if (items[i].value.value != cache[i]) { cache[i] = items[i].value.value; c = true; } return c; }   // klang.h:1914
+	// (while an effect's prepare() is being recorded: this prepare() is host code — tables drawn with rand(), loops over a count, caches compared with != —
+	//  and is not recorded at all; gpu::EffectBank runs it on a host mirror of every instance whose dials moved, see there)
+	bool changed() { if (gpu::Recorder* r = gpu::recording()) { r->host_prepare = true; return false; } bool c = false; for (size_t i = 0; i < items.size(); i++) if (items[i].value.value != cache[i]) { cache[i] = items[i].value.value; c = true; } return c; }   // klang.h:1914
 };
 struct Preset { std::string name; std::vector<float> values; Preset(const char* n, std::initializer_list<double> v) : name(n) { for (double x : v) values.push_back((float)x); } };
 struct Presets { std::vector<Preset> items; void operator=(std::initializer_list<Preset> l) { items.assign(l.begin(), l.end()); } };
@@ -982,10 +988,28 @@ public:
 };
 
 // Array<T, N> (klang.h:1373-1444): a counted fixed-capacity array
+// Array<TYPE, CAPACITY> (klang.h:245-330).  Its elements and its count are MEMBERS a recorded process() may read (`for (d = 0; d < times.count; d++)
+// out += delay(times[d]) * gains[d];` examples/Reverb.k:90-91): float elements are kept as params (a record word each), the count is a word too, and
+// `d < count` is a recorded comparison — one traced path per possible count, merged into nested ifs (PathMerger) — that is false outright at CAPACITY.
+template<int CAPACITY> struct ArrayCount {
+	param v;
+	ArrayCount() : v(0.f) {}
+	ArrayCount& operator=(unsigned n) { if (gpu::no_set_while_recording("Array::count = n")) return *this; v.value = (float)n; v.reg = -1; return *this; }
+	ArrayCount& operator=(int n) { return *this = (unsigned)n; }
+	ArrayCount& operator=(const ArrayCount& o) { return *this = (unsigned)o.v.value; }
+	ArrayCount& operator++() { return *this = (unsigned)v.value + 1u; }
+	unsigned operator++(int) { const unsigned n = (unsigned)v.value; *this = n + 1u; return n; }
+	operator unsigned() const { v.concrete_only("the integer value of an Array's count"); return (unsigned)v.value; }
+	template<class T, std::enable_if_t<std::is_integral_v<T>, int> = 0> friend gpu::Pred operator<(T d, const ArrayCount& c) {
+		if ((long long)d >= (long long)CAPACITY) return gpu::Pred{ false, -1 };
+		return (float)d < c.v;
+	}
+};
 template<typename TYPE, int CAPACITY> struct Array {
-	TYPE items[CAPACITY] = {}; unsigned count = 0;
-	void add(const TYPE& v) { if (count < (unsigned)CAPACITY) items[count++] = v; }
-	TYPE& operator[](int i) { return items[i]; } const TYPE& operator[](int i) const { return items[i]; }
+	using Item = std::conditional_t<std::is_same_v<TYPE, float>, param, TYPE>;
+	Item items[CAPACITY] = {}; ArrayCount<CAPACITY> count;
+	void add(const TYPE& v) { const unsigned n = count; if (n < (unsigned)CAPACITY) { items[n] = v; count = n + 1u; } }
+	Item& operator[](int i) { return items[i]; } const Item& operator[](int i) const { return items[i]; }
 	unsigned size() const { return count; }
 };
 template<typename TYPE, int SIZE> struct Table {
@@ -1041,6 +1065,8 @@ struct GraphLayout {
 	std::string program;
 	int words = 0;
 	std::vector<std::vector<float>> tables;                        // tabread slot k + 1 -> samples (uploaded by the Synth when the bank is created)
+	bool host_prepare = false;                                     // an effect whose prepare() stays host code (Controls::changed())
+	std::vector<int> delay_inputs;                                 // per member: an effect's Delay takes this many inputs per sample (its write cursor = samples x inputs, modulo SIZE)
 	void pack(const void* note, uint32_t* w) const {
 		for (const Member& m : members) {
 			const char* obj = (const char*)note + m.offset;
@@ -1417,6 +1443,9 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 		if (*identity) return;
 	}
 	finish_program(R, lo, layout);
+	layout.host_prepare = R.host_prepare;
+	layout.delay_inputs.assign(layout.members.size(), 0);             // (member j is node j of the finished program)
+	for (size_t i = (size_t)R.prog.prepare_ops; i < R.prog.ops.size(); i++) if (R.prog.ops[i].code == OP_DELAYIN && R.prog.ops[i].node >= 0 && (size_t)R.prog.ops[i].node < layout.delay_inputs.size()) layout.delay_inputs[(size_t)R.prog.ops[i].node]++;
 	if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", type_name, layout.program.c_str());
 }
 }
@@ -1448,6 +1477,11 @@ template<int SIZE> struct Delay : Modifier, gpu::Packable {
 		if (gpu::Recorder* r = gpu::recording()) { signal t; if constexpr (std::is_arithmetic_v<TIME>) t = signal((float)delay); else t = signal(const_cast<TIME&>(delay)); signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(t), -1, r->node(this, "Delay"), 0, true); return s; }
 		device_only("Delay::operator()");
 	}
+	// one channel of Stereo::Delay::tap(float) klang.h:4668-4681: its own interpolation form (a * (1 - f) + b * f), not Delay::tap(float)'s
+	template<typename TIME> signal tap_stereo_form(const TIME& delay) {
+		if (gpu::Recorder* r = gpu::recording()) { signal t; if constexpr (std::is_arithmetic_v<TIME>) t = signal((float)delay); else t = signal(const_cast<TIME&>(delay)); signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(t), -1, r->node(this, "Delay"), 2, true); return s; }
+		device_only("Stereo::Delay::operator()"); return signal();
+	}
 	void set(param samples) override {                                             // klang.h:3480-3489: place the read head `samples` behind the write cursor
 		if (gpu::Recorder* r = gpu::recording()) {                                  // per sample: the read head follows a control / an LFO (PingPong.k:62-63)
 			r->emit(klg::graph::OP_DELAYSET, r->reg_of(samples), -1, r->node(this, "Delay"), 0, false); return;
@@ -1477,6 +1511,7 @@ template<int SIZE> struct Delay : Modifier, gpu::Packable {
 		w[ND_POS] = (uint32_t)position; w[ND_LASTPOS] = (uint32_t)last.position; w[ND_LASTFRAC] = gpu::fbits(last.fraction); w[ND_TIME] = gpu::fbits(time);
 	}
 	void unpack(const uint32_t* w) override { using namespace klg::graph; if (!in_note) { last.position = (int)w[ED_LASTPOS]; return; } position = (int)w[ND_POS]; last.position = (int)w[ND_LASTPOS]; }
+	void host_cursor(unsigned long long inputs) override { if (!in_note) position = (int)(inputs % (unsigned long long)SIZE); }
 	unsigned int max() const { return SIZE; }
 };
 
@@ -1562,13 +1597,14 @@ struct Effect : Plugin, Modifier {
 namespace Stereo {
 	struct signal {                                                          // klang.h:4487-4558 (the operators the shipped effects use)
 		klang::signal l, r;
-		signal(klang::signal l_ = 0.f, klang::signal r_ = 0.f) : l(l_), r(r_) {}
+		signal(klang::signal l_ = 0.f, klang::signal r_ = 0.f) : l(l_), r(r_) { reg(); }
+		void reg() { l.reg_member(); r.reg_member(); }                             // (a member of an Effect — `Array<stereo::signal, 20> gains` — is state of its record: the channels were copy-constructed, which notes nothing)
 		klang::signal& operator[](int c) { return c == 0 ? l : r; }                // klang.h:4530
 		signal operator+(const signal& x) const { return { l + x.l, r + x.r }; } signal operator-(const signal& x) const { return { l - x.l, r - x.r }; }
 		signal operator*(const signal& x) const { return { l * x.l, r * x.r }; } signal operator/(const signal& x) const { return { l / x.l, r / x.r }; }
 		signal operator*(const klang::signal& x) const { return { l * x, r * x }; } signal operator/(const klang::signal& x) const { return { l / x, r / x }; }
 		signal operator*(float x) const { return { l * x, r * x }; }
-		signal(float x) : l(x), r(x) {} signal(int x) : l((float)x), r((float)x) {} signal(double x) : l((float)x), r((float)x) {}
+		signal(float x) : l(x), r(x) { reg(); } signal(int x) : l((float)x), r((float)x) { reg(); } signal(double x) : l((float)x), r((float)x) { reg(); }
 		signal& operator+=(const signal& x) { l = l + x.l; r = r + x.r; return *this; }
 		klang::signal mono() const { return (l + r) * 0.5f; }                      // klang.h:4556
 	};
@@ -1620,7 +1656,10 @@ namespace Stereo {
 		virtual void process() { out = in; }
 		void operator<<(const Stereo::signal& x) { in = x; process(); }
 		operator const Stereo::signal&() { return out; }
-		Stereo::signal operator*(const klang::signal& x) { return out * x; }
+		// `modifier * x` with x a signal / param: the reference's Modifier multiplies by ITS signal type, and x becomes a Stereo::signal through signals<2>'s variadic
+		// constructor (klang.h:1238-1241: value{ x }), i.e. { x, 0 } — the right channel is multiplied by 0 (examples/Reverb.k:271 `(in >> reflections) * wet`: the wet
+		// right channel is silent in the reference; reproduced, as the hand-written kernel does)
+		Stereo::signal operator*(const klang::signal& x) { return { out.l * x, out.r * klang::signal(0.f) }; }
 	};
 	template<class TYPE> struct Bank {
 		TYPE items[2];
@@ -1637,7 +1676,10 @@ namespace Stereo {
 		void operator<<(const signal& x) { x.l >> items[0]; x.r >> items[1]; }                  // `delay << out`: each line takes its channel
 		signal operator()(const signal& time) { return { items[0](time.l), items[1](time.r) }; }   // stereo time: a tap per side (klang.h:4692-4693)
 		template<typename TIME, std::enable_if_t<!std::is_same_v<TIME, signal>, int> = 0>
-		signal operator()(const TIME& time) { return { items[0](time), items[1](time) }; }
+		signal operator()(const TIME& time) {                                                   // klang.h:4686-4696: tap(int) for integers; otherwise Stereo::Delay::tap(float) — both lines at one cursor, its own interpolation form
+			if constexpr (std::is_integral_v<TIME>) return { items[0](time), items[1](time) };
+			else return { items[0].tap_stereo_form(time), items[1].tap_stereo_form(time) };
+		}
 		unsigned int max() const { return SIZE; }
 	};
 	inline signal& operator>>(const signal& x, signal& dst) { dst = x; return dst; }
@@ -2079,10 +2121,60 @@ template<class FX> struct EffectBank {
 		if (std::getenv("KLANG_MI355_DUMP_GRAPH")) { std::fprintf(stderr, "klang-mi355: initial record:"); for (uint32_t w : words) std::fprintf(stderr, " %08x", w); std::fprintf(stderr, "\n"); }
 		h = klg_fx_create_graph(layout.program.c_str(), instances, fs.f, max_block, words.data());
 		if (!h) { std::fprintf(stderr, "klang-mi355: klg_fx_create_graph: %s\n", klg_last_error()); std::abort(); }
+		device_controls = (int)fx->controls.items.size() < 8 ? (int)fx->controls.items.size() : 8;      // (record_effect: the controls a program knows)
 	}
-	~EffectBank() { if (h) klg_fx_destroy(h); delete fx; }
-	void set(int instance, int control, float value) { if (klg_fx_set_control(h, instance, control, value)) { std::fprintf(stderr, "klang-mi355: %s\n", klg_last_error()); std::abort(); } }
-	void process(float* io /* [instances][channels][n] */, int n) { if (klg_fx_process(h, io, n)) { std::fprintf(stderr, "klang-mi355: klg_fx_process: %s\n", klg_last_error()); std::abort(); } }
+	~EffectBank() { if (h) klg_fx_destroy(h); delete fx; for (FX* m : mirror) delete m; }
+	void set(int instance, int control, float value) {
+		if (layout.host_prepare) {                                // prepare() is host code: the dial goes to the instance's host mirror, prepare() runs before the next block
+			mirror_of(instance)->controls[control].set(value);
+			if (!dirty[(size_t)instance]) { dirty[(size_t)instance] = 1; touched.push_back(instance); }
+			if (control >= device_controls) return;                  // (a dial only prepare() reads: the program does not know it)
+		}
+		if (klg_fx_set_control(h, instance, control, value)) { std::fprintf(stderr, "klang-mi355: %s\n", klg_last_error()); std::abort(); }
+	}
+	void process(float* io /* [instances][channels][n] */, int n) {
+		if (layout.host_prepare) host_prepare();
+		if (klg_fx_process(h, io, n)) { std::fprintf(stderr, "klang-mi355: klg_fx_process: %s\n", klg_last_error()); std::abort(); }
+		samples += (unsigned long long)n;
+	}
+
+	// ---- an effect whose prepare() is HOST code (it asks Controls::changed(): examples/Reverb.k:238-241 — then reseeds rand(), draws tap tables in a
+	// loop over a count, compares cached values with !=, calls libm).  It stays host code, as in the reference: every instance has a host MIRROR (an FX
+	// object of its own, with its own Controls cache and member caches — what prepare() does depends on which dials moved since ITS last call); before a
+	// block, the mirror of every instance whose dials were set takes the instance's record as the device last left it (klg_fx_download_record), its
+	// Delays learn where their write cursors stand (samples x inputs per sample: Delay::set() places the read head against it), prepare() runs, and the
+	// words it changed are uploaded (klg_fx_upload_words).  process() is recorded once, from the prototype, and reads those members from the record. ----
+	std::vector<FX*> mirror; std::vector<char> dirty; std::vector<int> touched;
+	unsigned long long samples = 0; int device_controls = 0;
+	FX* mirror_of(int k) {
+		if (mirror.empty()) { mirror.assign((size_t)instances, nullptr); dirty.assign((size_t)instances, 0); }
+		if (!mirror[(size_t)k]) { mirror[(size_t)k] = new FX(); close_log(); }
+		return mirror[(size_t)k];
+	}
+	void host_prepare() {
+		if (mirror.empty()) { mirror_of(0); for (int k = 0; k < instances; k++) { dirty[(size_t)k] = 1; touched.push_back(k); } }   // the first block: every instance's prepare() finds its dials changed (klang.h:1914)
+		if (touched.empty()) return;
+		std::vector<uint32_t> before((size_t)layout.words), after((size_t)layout.words);
+		for (int k : touched) {
+			FX* m = mirror_of(k);
+			if (klg_fx_download_record(h, k, before.data(), before.size() * 4)) { std::fprintf(stderr, "klang-mi355: %s\n", klg_last_error()); std::abort(); }
+			layout.unpack(m, before.data());
+			for (size_t j = 0; j < layout.members.size(); j++) if (layout.members[j].kind == klg::graph::N_DELAY)
+				reinterpret_cast<Packable*>((char*)m + layout.members[j].offset)->host_cursor(samples * (unsigned long long)layout.delay_inputs[j]);
+			layout.pack(m, before.data());                          // (what the mirror holds — not everything a primitive keeps on the device has a host side: only what prepare() CHANGES goes back)
+			m->prepare();
+			layout.pack(m, after.data());
+			for (int w = 0; w < layout.words;) {
+				if (after[(size_t)w] == before[(size_t)w]) { w++; continue; }
+				int e = w + 1; while (e < layout.words && after[(size_t)e] != before[(size_t)e]) e++;
+				if (klg_fx_upload_words(h, k, w, e - w, after.data() + w)) { std::fprintf(stderr, "klang-mi355: %s\n", klg_last_error()); std::abort(); }
+				w = e;
+			}
+			if (std::getenv("KLANG_MI355_DUMP_GRAPH")) { int nchg = 0; for (int w = 0; w < layout.words; w++) nchg += after[(size_t)w] != before[(size_t)w]; std::fprintf(stderr, "klang-mi355: host prepare() of instance %d at sample %llu changed %d of %d words\n", k, samples, nchg, layout.words); }
+			dirty[(size_t)k] = 0;
+		}
+		touched.clear();
+	}
 };
 }
 

@@ -238,6 +238,13 @@ int klg_fx_set_control(klg_fx* f, int instance, int index, float value);
  * effect left it — a control its process() writes (examples/PingPong.k:48,60) comes back from the instance's state (as of the blocks
  * that have completed on the bank's own stream: after klg_fx_process, or klg_fx_sync following klg_fx_process_device). */
 int klg_fx_get_control(klg_fx* f, int instance, int index, float* value);
+/* An instance's record (graph effects: klg_fx_create_graph).  An effect whose prepare() is host code in the reference — Controls::changed(),
+ * libc rand() tables, loops over a count: examples/Reverb.k:238-241 with 23-56, 127-131 — keeps it host code: the facade (include/klang/klang.h,
+ * gpu::EffectBank) runs prepare() on its own mirror of the instance, starting from the record as the device last left it, and uploads the words
+ * prepare() changed; they are applied before the next block.  klg_fx_record_words: 32-bit words per record. */
+int klg_fx_record_words(const klg_fx* f);
+int klg_fx_download_record(klg_fx* f, int instance, void* words, size_t bytes);
+int klg_fx_upload_words(klg_fx* f, int instance, int first, int count, const void* values);
 /* replaces: Stereo::Effect::process(Stereo::buffer) klang.h:4708-4716 for every instance:
  * io[(k*2 + c)*n + i] is channel c of instance k, processed in place.  Host buffers, synchronous. */
 int klg_fx_process(klg_fx* f, float* io, int n);

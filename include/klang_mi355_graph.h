@@ -93,7 +93,7 @@ enum { OPER_INC = 0, OPER_POS, OPER_FREQ, OPER_AMP, OPER_ENV, OPER_WORDS = OPER_
 enum { WT_INC = 0, WT_POS, WT_OFFSET, WT_FREQ, WT_TABLE, WT_WORDS };
 enum { ND_POS = 0, ND_LASTPOS, ND_LASTFRAC, ND_TIME, ND_WORDS };
 enum { ED_LASTPOS = 0, ED_LASTFRAC, ED_WORDS };   /* an effect's Delay: the read head of set() / process() (Delay::last klang.h:3388) */
-enum { MAX_WORDS = 128, MAX_NODES = 64, MAX_OPS = 1024 };
+enum { MAX_WORDS = 512, MAX_NODES = 256, MAX_OPS = 16384 };   // (round 3: the shipped Reverb.k records — 16 FilteredDelays, 20 stereo taps — at ~330 words / ~3 k ops)
 
 inline bool is_oscillator(int k) { return k == N_FSINE || k == N_SAW || k == N_PULSE || (k >= N_BSINE && k <= N_BPULSE) || k == N_WAVETABLE; }
 inline bool is_modifier(int k) { return k == N_LPF || (k >= N_OPLPF && k <= N_FOLLOWRMS) || k == N_IIRN; }
@@ -147,7 +147,7 @@ enum OpCode {
 	OP_FREQ,        /* dst = oscillator node .frequency    (Oscillator::frequency klang.h:2856, as last set by on() or by oscset) */
 	OP_IN,          /* dst = this sample of input channel imm            (effects: `in`, `in.l`, `in.r`)                       */
 	OP_DELAYIN,     /* a >> delay node                                  Delay::input klang.h:3396-3403                        */
-	OP_DELAYTAP,    /* dst = delay node (a)                             Delay::tap(float) klang.h:3412-3427; imm 1: tap(int) 3405-3410 (a holds the integer) */
+	OP_DELAYTAP,    /* dst = delay node (a)                             Delay::tap(float) klang.h:3412-3427; imm 1: tap(int) 3405-3410 (a holds the integer); imm 2: one channel of Stereo::Delay::tap(float) 4668-4681 */
 	OP_SMOOTH,      /* dst = smooth node: controls[imm].smooth()        Control::smooth klang.h:1715                          */
 	OP_OPERATOR,    /* dst = operator node process()       modulator a (or -1: none), amp b (or -1: keep)   Operator::process klang.h:4164-4168 */
 	OP_CMP,         /* dst = (a REL b) ? 1.0 : 0.0         imm = relation: 0 <, 1 >, 2 <=, 3 >=, 4 ==, 5 !=  (IEEE: false on NaN except !=) */
@@ -257,7 +257,7 @@ struct Program {
 
 	/* single assignment, defined-before-use, node kinds match their ops */
 	std::string validate() const {
-		if (words() > MAX_WORDS) return "graph program: the voice record exceeds 128 words";
+		if (words() > MAX_WORDS) return "graph program: the voice record exceeds 512 words";
 		std::vector<char> defined;                                 /* 1 = visible here, 2 = assigned in a branch side that has ended */
 		auto def = [&](int r) { return r >= 0 && r < (int)defined.size() && defined[(size_t)r] == 1; };
 		struct Side { std::vector<int> regs; bool in_else; std::vector<int> then_side; };
@@ -288,7 +288,7 @@ struct Program {
 			case OP_FREQ: if (!is_oscillator(k) && k != N_OPERATOR) return bad("node is not an oscillator"); break;
 			case OP_IN: if (channels == 0 || (int)o.imm >= channels) return bad("`in` needs an effect program with that channel"); break;
 			case OP_DELAYIN: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
-			case OP_DELAYTAP: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); if (o.imm > 1u) return bad("unknown tap kind"); need_a = true; break;
+			case OP_DELAYTAP: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); if (o.imm > 2u) return bad("unknown tap kind"); need_a = true; break;
 			case OP_DELAYOUT: if (k != N_NDELAY && k != N_DELAY) return bad("node is not a delay"); break;
 			case OP_DELAYSET: if (k != N_NDELAY && k != N_DELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
 			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); if (!channels && !open.empty()) return bad("a Note's controls[i].smooth() may not sit inside an `if`: the bank advances the Synth's control by a fixed number of steps per sounding note and sample"); break;

@@ -55,6 +55,9 @@ def load():
         "klg_set_control": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),
         "klg_get_control": (C.c_int, [vp, C.c_int, C.c_int, f32p]),
         "klg_fx_get_control": (C.c_int, [vp, C.c_int, C.c_int, f32p]),
+        "klg_fx_record_words": (C.c_int, [vp]),
+        "klg_fx_download_record": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+        "klg_fx_upload_words": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
         "klg_set_control_smoothed": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),
         "klg_get_control_smoothed": (C.c_int, [vp, C.c_int, C.c_int, f32p]),
         "klg_process": (C.c_int, [vp, C.POINTER(f32p), C.c_int, C.c_int, f32p]),

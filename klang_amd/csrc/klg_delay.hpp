@@ -59,6 +59,20 @@ __device__ __forceinline__ float delay_tap_float(const Ring& r, int position, fl
 	const float a = r.rd(i), b = r.rd(j);
 	return a + fraction * (b - a);
 }
+// one channel of Stereo::Delay::tap(float) klang.h:4668-4681 — not the mono form: a * (1 - frac) + b * frac, frac against floor(read), the successor wraps at
+// SIZE - 1 (both lines of a Stereo::Delay stand at the same cursor).  `read` rounded up to exactly SIZE: the reference reads the pad and one element
+// past it (indeterminate there); that tap is 0 here (klg_fx.hpp stereo_delay_tap, oracle ko_stereo_delay_tap_float).
+__device__ __forceinline__ float delay_tap_stereo(const Ring& r, int position, float delay) {
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += r.size;
+	const float f = (float)floor((double)read);
+	const float frac = read - f;
+	const int i = (int)read;
+	const int j = (i == r.size - 1) ? 0 : (i + 1);
+	const bool pad = i >= r.size;
+	const float a = pad ? 0.f : r.rd(pad ? 0 : i), b = pad ? 0.f : r.rd(pad ? 0 : j);
+	return a * (1.f - frac) + b * frac;
+}
 __device__ __forceinline__ float delay_lagrange(const Ring& r, int position, float delay) {
 	const int SIZE = r.size;
 	float read = (float)(position - 1) - delay;

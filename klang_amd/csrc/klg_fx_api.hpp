@@ -241,6 +241,31 @@ extern "C" int klg_fx_set_control(klg_fx* f, int instance, int index, float valu
 	}
 	return 0;
 }
+// ---- an instance's record, for effects whose prepare() is HOST code (include/klang/klang.h EffectBank: Controls::changed(), rand() tables,
+// loops over a count — examples/Reverb.k:238-241): the facade runs prepare() on its own mirror of the instance, starting from the record as
+// the device last left it, and uploads the words prepare() changed ----
+extern "C" int klg_fx_record_words(const klg_fx* f) {
+	if (!f) return fail(KLG_ERR_INVALID, "klg_fx_record_words: null bank");
+	return f->multi ? klg_fx_record_words(f->multi->shard[0]) : f->words;
+}
+extern "C" int klg_fx_download_record(klg_fx* f, int instance, void* words, size_t bytes) {
+	if (!f || !words || instance < 0 || instance >= f->K) return fail(KLG_ERR_INVALID, "klg_fx_download_record: bad arguments");
+	if (f->multi) { int li = 0; const int sh = fx_shard_of(f, instance, &li); return klg_fx_download_record(f->multi->shard[(size_t)sh], li, words, bytes); }
+	if (bytes != (size_t)f->words * 4) return fail(KLG_ERR_INVALID, "klg_fx_download_record: the record is %d bytes", f->words * 4);
+	KLG_BIND(f);
+	if (int rc = fx_flush_updates(f, f->stream)) return rc;
+	HIP_TRY(hipStreamSynchronize(f->stream));
+	HIP_TRY(hipMemcpy2D(words, 4, (const float*)f->d_state + instance, f->kpad * sizeof(float), 4, (size_t)f->words, hipMemcpyDeviceToHost));   // word w of instance k: state[w][k]
+	return 0;
+}
+extern "C" int klg_fx_upload_words(klg_fx* f, int instance, int first, int count, const void* values) {
+	if (!f || !values || instance < 0 || instance >= f->K || first < 0 || count < 0) return fail(KLG_ERR_INVALID, "klg_fx_upload_words: bad arguments");
+	if (f->multi) { int li = 0; const int sh = fx_shard_of(f, instance, &li); return klg_fx_upload_words(f->multi->shard[(size_t)sh], li, first, count, values); }
+	if (first + count > f->words) return fail(KLG_ERR_INVALID, "klg_fx_upload_words: words %d .. %d of a record of %d", first, first + count - 1, f->words);
+	const int* v = (const int*)values;
+	for (int i = 0; i < count; i++) f->upd.push_back({ instance, first + i, v[i] });       // applied, in order, before the next block (klg_fx_apply_updates)
+	return 0;
+}
 // the control's value as the effect sees it: a control the effect writes itself (PingPong.k:48,60 controls[1].set(..)) is read back from the
 // instance's state — the parameter sync OUT of Effect::process(float*, int, float* parameters) klang.h:4213-4215
 extern "C" int klg_fx_get_control(klg_fx* f, int instance, int index, float* value) {

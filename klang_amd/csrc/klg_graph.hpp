@@ -63,7 +63,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	// line is contiguous — voices start at different times and have different lengths, so their cursors never line up; a lane walking its
 	// own line re-uses each 64-byte sector for 16 samples (measured 8x over the position-major layout, tools/pluck_bench.py)
 	auto ring = [&](int node) { return fx ? fmt("Ring{ c.ring + (size_t)%lldll * 64, 64, %d }", ring_off[(size_t)node], g.arg(node)) : fmt("Ring{ c.ring + (size_t)%lldll, 1, %d }", ring_off[(size_t)node], g.arg(node)); };
-	uint64_t mask[2] = { 1ull, 0ull };                                   // word 0 (flags) is always written back
+	uint64_t mask[graph::MAX_WORDS / 64] = { 1ull };                      // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
 	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { " + TI + " stage; float tinc;" + (g.noise_calls() ? " int sidx;" : ""), begin, end, body;
 	const int noise_calls = g.noise_calls(); int noise_k = 0;
@@ -315,7 +315,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		case OP_IN: body += d + (o.imm ? "in1" : "in0") + ";\n"; break;
 		case OP_DELAYIN: body += "\t\t{ const Ring q = " + ring(o.node) + "; q.wr(" + n + "pos, " + a + "); " + n + "pos = (" + n + fmt("pos + 1 == %d) ? 0 : ", g.arg(o.node)) + n + "pos + 1; }\n"; break;   // Delay::input klang.h:3396-3403
 		case OP_DELAYSET: body += "\t\t" + n + "t = delay_set(" + n + fmt("pos, %d, ", g.arg(o.node)) + a + ");\n"; break;   // Delay::set klang.h:3480-3489
-		case OP_DELAYTAP: body += d + (o.imm == 1u ? "delay_tap_int(" + ring(o.node) + ", " + n + "pos, (int)" + a + ");\n" : "delay_tap_float(" + ring(o.node) + ", " + n + "pos, " + a + ");\n"); break;   // imm 1: tap(int), klang.h:3405-3410
+		case OP_DELAYTAP: body += d + (o.imm == 1u ? "delay_tap_int(" + ring(o.node) + ", " + n + "pos, (int)" + a + ");\n" : (o.imm == 2u ? "delay_tap_stereo(" : "delay_tap_float(") + ring(o.node) + ", " + n + "pos, " + a + ");\n"); break;   // imm 1: tap(int), klang.h:3405-3410
 		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 7u]) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";
@@ -332,6 +332,11 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	s += "struct PatchGen {\n";
 	s += "\tstruct Rec { " + TU + fmt(" w[%d]; };\n\tstatic constexpr int kWords = %d;\n", NW, NW);
 	s += fmt("\tstatic constexpr uint64_t kStoreMask = 0x%llxull;\n\tstatic constexpr uint64_t kStoreMask2 = 0x%llxull;\n", (unsigned long long)mask[0], (unsigned long long)mask[1]);
+	if (NW > 128) {                                                       // longer records: one mask per 64 words (klg_kernels.hpp patch_stores)
+		s += "\tstatic __device__ __forceinline__ constexpr bool stores_word(int w) { constexpr uint64_t m[] = {";
+		for (int i = 0; i < (NW + 63) / 64; i++) s += fmt(" 0x%llxull,", (unsigned long long)mask[i]);
+		s += " }; return ((m[w >> 6] >> (w & 63)) & 1ull) != 0; }\n";
+	}
 	s += live;
 	if (!fx && noise_calls) { begin += "\t\tL.sidx = 0;\n"; body += "\t\tL.sidx++;\n"; }   // a voice's draws of the block: [sample][Noise generator in process() order]
 	if (!fx) {

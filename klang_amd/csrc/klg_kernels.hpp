@@ -86,7 +86,10 @@ __host__ __device__ inline unsigned render_lds_bytes(int n, int note_channels = 
 template<class...> using klg_void_t = void;
 template<class P, class = void> struct StoreMask2 { static constexpr uint64_t value = 0; };
 template<class P> struct StoreMask2<P, klg_void_t<decltype(P::kStoreMask2)>> { static constexpr uint64_t value = P::kStoreMask2; };
-template<class P> __device__ __forceinline__ constexpr bool patch_stores(int w) { return w < 64 ? ((P::kStoreMask >> (w & 63)) & 1ull) != 0 : ((StoreMask2<P>::value >> (w & 63)) & 1ull) != 0; }
+// ... and records longer than 128 words a function over one mask per 64 words (stores_word)
+template<class P, class = void> struct StoresWord { static __device__ __forceinline__ constexpr bool at(int w) { return w < 64 ? ((P::kStoreMask >> (w & 63)) & 1ull) != 0 : ((StoreMask2<P>::value >> (w & 63)) & 1ull) != 0; } };
+template<class P> struct StoresWord<P, klg_void_t<decltype(P::stores_word(0))>> { static __device__ __forceinline__ constexpr bool at(int w) { return P::stores_word(w); } };
+template<class P> __device__ __forceinline__ constexpr bool patch_stores(int w) { return StoresWord<P>::at(w); }
 
 // a patch may pin its occupancy with `static constexpr int kWavesPerEu` (measured per patch: SuperSaw renders 8 % faster at 4
 // waves/SIMD with ~10 spilled registers than at the 3 the allocator picks on its own; FM and sub2 do not)

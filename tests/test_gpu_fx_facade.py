@@ -71,6 +71,23 @@ def test_shipped_reverb_k_bound_to_its_kernel_through_the_effect_bank(tmp_path):
     assert exact == 1.0, f"max abs err {np.abs(got - ref).max()} (peak {peak})"
 
 
+def test_shipped_reverb_k_recorded_as_a_graph(tmp_path, monkeypatch):
+    """The same unchanged examples/Reverb.k, RECORDED (KLANG_MI355_FORCE_GRAPH=1 ignores the binding).  Its prepare() is host code and stays
+    host code (it asks Controls::changed(), reseeds rand(), draws the tap tables in a loop over a count, compares caches with !=): the
+    EffectBank keeps a host mirror per instance, runs prepare() on it when the instance's dials were set — from the record as the device last
+    left it, with every Delay's write cursor told to it — and uploads the words that changed (klg_fx_download_record / klg_fx_upload_words).
+    process() is recorded once: Stereo::Modifiers inside Modifiers, `Array<float, 20> times` / `Array<stereo::signal, 20> gains` read from the
+    record, `for (d = 0; d < times.count; d++)` as twenty nested recorded branches, Stereo::Bank<LPF / HPF>, sixteen FilteredDelays each processed
+    twice per sample, `signals<4> >> Matrix` — ~630 ops, 91 nodes, 273 record words.  Nine instances, dials changed mid-run (a change that
+    leaves the early reflections alone draws DIFFERENT random delays for the late ones than the first call did), bit for bit against the
+    genuine header — like the hand-written kernel."""
+    monkeypatch.setenv("KLANG_MI355_FORCE_GRAPH", "1")
+    got, ref = run_effect("fx_topreverb", tmp_path)
+    exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+    print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e} (peak {np.abs(ref).max():.3f})")
+    assert exact == 1.0, f"max abs err {np.abs(got - ref).max()}"
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_example_effect_recorded_as_graph_is_bit_exact(name, tmp_path):
     exe = os.path.join(ROOT, "oracle", "_ref", "facade_" + name)
