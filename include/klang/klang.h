@@ -1523,6 +1523,8 @@ namespace gpu {
 struct FxRunner {
 	klg_fx* h = nullptr; GraphLayout layout; bool built = false, identity = false; int channels = 1, cap = 1024;
 	std::vector<float> io, sent;
+	// an effect whose prepare() stays host code (Controls::changed(): see gpu::EffectBank) — here the host's own object is the mirror of the one instance
+	void* host_obj = nullptr; std::function<void()> host_prepare_fn; unsigned long long samples = 0; int device_controls = 8; std::vector<uint32_t> before, after;
 	FxRunner() {}
 	FxRunner(const FxRunner&) {}
 	FxRunner& operator=(const FxRunner&) { return *this; }
@@ -1546,6 +1548,23 @@ struct FxRunner {
 		layout.pack(lo, words.data());
 		h = klg_fx_create_graph(layout.program.c_str(), 1, fs.f, cap, words.data());
 		if (!h) die("klg_fx_create_graph");
+		device_controls = (int)ctl.items.size() < 8 ? (int)ctl.items.size() : 8;
+		if (layout.host_prepare) { host_obj = (void*)lo; host_prepare_fn = [fx]() { fx->prepare(); }; before.resize((size_t)layout.words); after.resize((size_t)layout.words); }
+	}
+	void host_prepare() {                                                            // (gpu::EffectBank::host_prepare, for the one instance the host object itself mirrors)
+		if (klg_fx_download_record(h, 0, before.data(), before.size() * 4)) die("klg_fx_download_record");
+		layout.unpack(host_obj, before.data());
+		for (size_t j = 0; j < layout.members.size(); j++) if (layout.members[j].kind == klg::graph::N_DELAY)
+			reinterpret_cast<Packable*>((char*)host_obj + layout.members[j].offset)->host_cursor(samples * (unsigned long long)layout.delay_inputs[j]);
+		layout.pack(host_obj, before.data());
+		host_prepare_fn();
+		layout.pack(host_obj, after.data());
+		for (int w = 0; w < layout.words;) {
+			if (after[(size_t)w] == before[(size_t)w]) { w++; continue; }
+			int e = w + 1; while (e < layout.words && after[(size_t)e] != before[(size_t)e]) e++;
+			if (klg_fx_upload_words(h, 0, w, e - w, after.data() + w)) die("klg_fx_upload_words");
+			w = e;
+		}
 	}
 	// the host's control values -> the instance: whatever was set() since the last block (even to the same value: a set() overwrites
 	// what the effect itself may have written to the control, as in the reference) or differs from what was sent
@@ -1555,6 +1574,7 @@ struct FxRunner {
 		for (int c = 0; c < n; c++) {
 			Control& k = ctl.items[(size_t)c];
 			if (!k.touched && k.value.value == sent[(size_t)c]) continue;
+			if (host_obj && c >= device_controls) { sent[(size_t)c] = k.value.value; k.touched = false; continue; }   // (a dial only the host-run prepare() reads)
 			if (klg_fx_set_control(h, 0, c, k.value.value)) die("klg_fx_set_control");
 			sent[(size_t)c] = k.value.value; k.touched = false;
 		}
@@ -1566,7 +1586,9 @@ struct FxRunner {
 			const int m = n - at < cap ? n - at : cap;
 			io.resize((size_t)channels * (size_t)m);
 			for (int c = 0; c < channels; c++) std::memcpy(&io[(size_t)c * (size_t)m], ch[c] + at, (size_t)m * sizeof(float));
+			if (host_obj) host_prepare();                                             // (Controls::changed() inside decides whether anything happens)
 			if (klg_fx_process(h, io.data(), m)) die("klg_fx_process");
+			samples += (unsigned long long)m;
 			for (int c = 0; c < channels; c++) std::memcpy(ch[c] + at, &io[(size_t)c * (size_t)m], (size_t)m * sizeof(float));
 		}
 		// what the effect wrote to its own controls (PingPong.k:48,60) comes back to the host's Control objects, as in the reference

@@ -72,11 +72,15 @@ def test_effect_host_reproduces_the_effect_bank_fixture(tmp_path, how, monkeypat
     assert_bits(got, np.load(os.path.join(GOLDEN, "fx_toppingpong.npz"))["out"])
 
 
-@pytest.mark.parametrize("binary,scn", [("facade_host_fx_topreverb", "fx_topreverb"), ("facade_host_fx_dpingpong", "fx_dpingpong"), ("facade_host_fx_echo", "fx_echo")])
-def test_effect_process_buffer_on_a_host_constructed_object(binary, scn, tmp_path):
-    """Reverb.k (tied to its kernel), Delay/PingPong.k (Stereo::Effect) and Delay/Echo.k (mono klang::Effect): the latter two are RECORDED from
-    the construction log of an object the host built itself (`Echo pingpong;`) — no template names the type.  These effects do not write
+@pytest.mark.parametrize("binary,scn,how", [("facade_host_fx_topreverb", "fx_topreverb", "kernel"), ("facade_host_fx_topreverb", "fx_topreverb", "recorded"),
+                                            ("facade_host_fx_dpingpong", "fx_dpingpong", "recorded"), ("facade_host_fx_echo", "fx_echo", "recorded")])
+def test_effect_process_buffer_on_a_host_constructed_object(binary, scn, how, tmp_path, monkeypatch):
+    """Reverb.k (tied to its kernel, and RECORDED: KLANG_MI355_FORCE_GRAPH — its prepare() is host code and runs on the host's own object, which
+    is the one instance's mirror: gpu::FxRunner::host_prepare), Delay/PingPong.k (Stereo::Effect) and Delay/Echo.k (mono klang::Effect): recorded
+    from the construction log of an object the host built itself (`Echo pingpong;`) — no template names the type.  These effects do not write
     their controls, so setting them every block changes nothing: the EffectBank fixtures apply."""
+    if how == "recorded" and binary == "facade_host_fx_topreverb":
+        monkeypatch.setenv("KLANG_MI355_FORCE_GRAPH", "1")
     got = run_effect_host(binary, scn, tmp_path)
     assert_bits(got, np.load(os.path.join(GOLDEN, scn + ".npz"))["out"])
 
