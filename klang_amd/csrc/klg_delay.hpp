@@ -53,7 +53,7 @@ __device__ __forceinline__ float delay_tap_int(const Ring& r, int position, int 
 __device__ __forceinline__ float delay_tap_float(const Ring& r, int position, float delay) {
 	float read = (float)(position - 1) - delay;
 	if (read < 0.f) read += r.size;
-	const int i = (int)read;
+	const int i = (int)read < 0 ? 0 : (int)read;                               // (a delay beyond SIZE leaves `read` negative: undefined in the reference, which indexes its buffer with it; here the tap stays inside this line)
 	const float fraction = read - i;
 	const int j = (i + 1) % r.size;
 	const float a = r.rd(i), b = r.rd(j);
@@ -69,7 +69,7 @@ __device__ __forceinline__ float delay_tap_stereo(const Ring& r, int position, f
 	const float frac = read - f;
 	const int i = (int)read;
 	const int j = (i == r.size - 1) ? 0 : (i + 1);
-	const bool pad = i >= r.size;
+	const bool pad = i >= r.size || i < 0;                                        // (i < 0: a delay beyond SIZE — undefined in the reference; the tap is 0 here and no other line is touched)
 	const float a = pad ? 0.f : r.rd(pad ? 0 : i), b = pad ? 0.f : r.rd(pad ? 0 : j);
 	return a * (1.f - frac) + b * frac;
 }
