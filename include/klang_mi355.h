@@ -132,6 +132,8 @@ int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices);
 
 /* Throughput path: d_mix is a DEVICE pointer to [2][n] floats that the block is accumulated into on
  * `hip_stream` (a hipStream_t, or NULL for the handle's own stream); no host copies, no synchronisation.
+ * (NULL is the handle's OWN stream, which is created non-blocking: work the caller has queued on the legacy default stream — a framework's clear of d_mix,
+ * say — is not ordered with it.  A caller whose buffers are produced on the default stream passes a stream of its own, or synchronises.)
  * klg_sync() waits for everything queued on the handle.
  * ONE EXCEPTION: a graph bank whose Note::process() draws Noise or calls controls[i].smooth() shares state between its notes in the order
  * Synth::process walks them (klang.h:4842-4848: libc rand(), Control::smoothed); per block the library brings the note stages back, draws /

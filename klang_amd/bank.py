@@ -138,6 +138,8 @@ class SynthBank:
         return st
 
     def process_device(self, d_mix_ptr, n, stream=None):
+        """stream: a hipStream_t handle; None / 0 = the bank's OWN stream, which is non-blocking — work queued on torch's default stream (a clear of the
+        mix, say) is not ordered with it: pass `torch.cuda.Stream().cuda_stream` and make that stream current, or synchronise first."""
         check(self._L.klg_process_device(self._h, C.c_void_p(int(d_mix_ptr)), int(n), C.c_void_p(int(stream)) if stream else None), "klg_process_device")
 
     def sync(self):

@@ -129,6 +129,7 @@ def test_script_outlives_its_bank_without_touching_freed_state():
     script.note_on([0, 1], [0, 9], [first, first + 1])
     script.commit()
     mix = torch.zeros((2, 64), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()                              # (no stream given = the bank's own, non-blocking stream: torch's fill on the default stream is not ordered with it)
     script.play_device(0, mix.data_ptr(), 64)
     bank.sync()
     assert float(mix.abs().sum()) > 0
@@ -189,6 +190,7 @@ def test_script_rendered_in_one_call_equals_block_by_block():
             script.note_off(5 + v % 3, v)
             script.commit()
             out = torch.full((B, 2, N), 7.0, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()                      # (the library's launches go to the bank's own stream: see above)
             if one_call:
                 script.render_device(0, B, out.data_ptr(), N)
             else:
@@ -225,6 +227,7 @@ def test_script_span_replayed_as_a_graph_equals_the_launches():
             script.note_off(6 + v % 3, v)
             script.commit()
             out = torch.zeros((B, 2, N), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
             res = []
             for _ in range(3):
                 script.render_device(0, B, out.data_ptr(), N)

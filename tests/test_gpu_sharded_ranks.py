@@ -35,6 +35,7 @@ for b in range(B):
         if at + 5 == b: bank.note_off(sy, p)
     if b == 6 and %(patch)r == "supersaw": bank.set_control(1, 0, 0.5)
     mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()                               # (no stream given = the bank's own, non-blocking stream: torch's fill on the default stream is not ordered with it)
     bank.bank.process_device(mix.data_ptr(), N, None)
     torch.cuda.synchronize()
     if two:

@@ -75,6 +75,7 @@ def gpu_synth(patch, voices, N, steps, warmup, release=False):
         bank.random(v + 1)
         bank.note_on(v // notes, int(pitches[v]), 0.8)
     mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+    torch.cuda.set_stream(torch.cuda.Stream())      # a stream of our own: handle 0 (torch's default) means "the bank's own stream" to the library, which torch's clears are not ordered with
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(warmup):
         mix.zero_(); bank.process_device(mix.data_ptr(), N, stream)
@@ -106,6 +107,7 @@ def gpu_fx(patch, K, N, steps, warmup):
     bank = klang_amd.FxBank(patch, K, max_block=N)
     g = torch.Generator(device="cuda").manual_seed(1)
     io = (torch.rand((K, 2, N), device="cuda", generator=g) - 0.5)
+    torch.cuda.set_stream(torch.cuda.Stream())      # a stream of our own: handle 0 (torch's default) means "the bank's own stream" to the library, which torch's clears are not ordered with
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(warmup):
         bank.process_device(io.data_ptr(), N, stream)

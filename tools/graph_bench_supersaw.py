@@ -32,6 +32,7 @@ def to_graph(r):
 
 def timed(bank, N, steps, warmup):
     mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+    torch.cuda.set_stream(torch.cuda.Stream())      # a stream of our own: handle 0 (torch's default) means "the bank's own stream" to the library, which torch's clears are not ordered with
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(warmup):
         mix.zero_(); bank.process_device(mix.data_ptr(), N, st)

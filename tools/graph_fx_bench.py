@@ -12,6 +12,7 @@ for K in [int(x) for x in sys.argv[1:]] or [4096, 65536]:
     bank = klang_amd.FxBank(prog, K, max_block=N, channels=1)
     g = torch.Generator(device="cuda").manual_seed(1)
     io = torch.rand((K, 1, N), device="cuda", generator=g) - 0.5
+    torch.cuda.set_stream(torch.cuda.Stream())      # a stream of our own: handle 0 (torch's default) means "the bank's own stream" to the library, which torch's clears are not ordered with
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(4): bank.process_device(io.data_ptr(), N, st)
     torch.cuda.synchronize(); bank.timing_begin(); t0 = time.perf_counter()

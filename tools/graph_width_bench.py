@@ -52,7 +52,7 @@ def run(k, duty, width, V=1 << 19, N=256):
     words[:, a] = f32(0.7).view(np.uint32); words[:, a + 1] = f32(0.7).view(np.uint32); words[:, a + 4] = 2 << 2; words[:, a + 7] = f32(0.7).view(np.uint32); words[:, a + 8] = f32(0.3).view(np.uint32)
     for c0 in range(0, V, 1 << 16):
         bank.voices_upload(np.arange(c0, c0 + (1 << 16), dtype=np.int32), words[c0:c0 + (1 << 16)])
-    mix = torch.zeros((2, N), dtype=torch.float32, device="cuda"); st = torch.cuda.current_stream().cuda_stream
+    mix = torch.zeros((2, N), dtype=torch.float32, device="cuda"); torch.cuda.set_stream(torch.cuda.Stream()); st = torch.cuda.current_stream().cuda_stream
     for _ in range(5):
         mix.zero_(); bank.process_device(mix.data_ptr(), N, st)
     torch.cuda.synchronize(); bank.timing_begin()

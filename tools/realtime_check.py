@@ -24,6 +24,7 @@ def main():
         pitches = rng.integers(36, 97, size=V); owner = np.arange(V) // notes
         bank.note_on_many(owner, pitches, np.full(V, 0.8, np.float32))
         mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+        torch.cuda.set_stream(torch.cuda.Stream())      # a stream of our own: handle 0 (torch's default) means "the bank's own stream" to the library, which torch's clears are not ordered with
         st = torch.cuda.current_stream().cuda_stream
         mix.zero_(); bank.process_device(mix.data_ptr(), N, st); torch.cuda.synchronize()      # block 0 also carries the event upload
         t = np.empty(a.blocks)

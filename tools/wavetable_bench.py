@@ -31,6 +31,7 @@ def run(V, T, size=2048, N=256, steps=50, warmup=5):
     for c0 in range(0, V, 1 << 16):
         bank.voices_upload(np.arange(c0, min(V, c0 + (1 << 16)), dtype=np.int32), words[c0:c0 + (1 << 16)])
     mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+    torch.cuda.set_stream(torch.cuda.Stream())      # a stream of our own: handle 0 (torch's default) means "the bank's own stream" to the library, which torch's clears are not ordered with
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(warmup):
         mix.zero_(); bank.process_device(mix.data_ptr(), N, st)
