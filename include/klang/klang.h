@@ -2192,6 +2192,7 @@ template<class FX> struct EffectBank {
 				if (klg_fx_upload_words(h, k, w, e - w, after.data() + w)) { std::fprintf(stderr, "klang-mi355: %s\n", klg_last_error()); std::abort(); }
 				w = e;
 			}
+			if (std::getenv("KLANG_MI355_DUMP_GRAPH") && k == 0 && samples == 0) { std::fprintf(stderr, "klang-mi355: prepared record:"); for (uint32_t w : after) std::fprintf(stderr, " %08x", w); std::fprintf(stderr, "\n"); }
 			if (std::getenv("KLANG_MI355_DUMP_GRAPH")) { int nchg = 0; for (int w = 0; w < layout.words; w++) nchg += after[(size_t)w] != before[(size_t)w]; std::fprintf(stderr, "klang-mi355: host prepare() of instance %d at sample %llu changed %d of %d words\n", k, samples, nchg, layout.words); }
 			dirty[(size_t)k] = 0;
 		}
