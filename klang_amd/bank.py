@@ -275,6 +275,20 @@ class FxBank:
         check(self._L.klg_fx_get_control(self._h, int(instance), int(index), C.byref(v)), "klg_fx_get_control")
         return v.value
 
+    def record_words(self):
+        return check(self._L.klg_fx_record_words(self._h), "klg_fx_record_words")
+
+    def download_record(self, instance):
+        """The instance's record as the device last left it (uint32 words): what a host-run prepare() starts from (klg_fx_download_record)."""
+        w = np.empty(self.record_words(), dtype=np.uint32)
+        check(self._L.klg_fx_download_record(self._h, int(instance), w.ctypes.data_as(C.c_void_p), w.nbytes), "klg_fx_download_record")
+        return w
+
+    def upload_words(self, instance, first, words):
+        """Overwrite words [first, first + len(words)) of the instance's record before the next block (klg_fx_upload_words)."""
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        check(self._L.klg_fx_upload_words(self._h, int(instance), int(first), int(w.size), w.ctypes.data_as(C.c_void_p)), "klg_fx_upload_words")
+
     def process(self, io):
         """io: float32 [instances][channels][n], processed in place."""
         assert io.dtype == np.float32 and io.flags.c_contiguous and io.shape[:2] == (self.instances, self.channels)

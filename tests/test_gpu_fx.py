@@ -196,3 +196,36 @@ def test_pingpong_with_stationary_controls(oracle_build, block, width, monkeypat
     ref = run_scenario_oracle(s, oracle_build)["per_voice"]
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"max abs err {np.abs(got - ref).max()}"
     assert np.abs(got[-1]).max() > 1e-3
+
+
+def test_record_download_and_word_upload():
+    """klg_fx_download_record / klg_fx_upload_words (what a host-run prepare() uses, include/klang/klang.h EffectBank::host_prepare): a record comes back
+    as the device last left it — the dials just set, state a block has changed — and uploaded words are what the next block starts from.  Instances
+    3 and 5 get the same dials and the same input and stay bit-equal; a DC-filter state word of 5 is overwritten (the filter sits behind the delay
+    lines: their contents stay equal) and its output leaves 3's; instance 3's record uploaded into 5 brings it back, bit for bit."""
+    import klang_amd
+    K, N = 8, 64
+    bank = klang_amd.FxBank("pingpong", K, max_block=N)
+    W = bank.record_words()
+    rng = np.random.default_rng(4)
+    for k in range(K):
+        kk = 3 if k == 5 else k
+        bank.set_control(k, 0, 0.3 + 0.05 * kk); bank.set_control(k, 1, 0.02 + 0.01 * kk); bank.set_control(k, 4, 0.3)
+    r0 = bank.download_record(3)
+    assert r0.size == W and np.float32(0.3 + 0.05 * 3) == r0[0:1].view(np.float32)[0] and np.float32(0.02 + 0.01 * 3) == r0[1:2].view(np.float32)[0]   # PingPong: word c is controls[c]
+    x = rng.uniform(-0.5, 0.5, size=(K, 2, N)).astype(np.float32)
+    x[5] = x[3]
+    for _ in range(60): a = bank.process(x.copy())
+    assert np.array_equal(a[5].view(np.uint32), a[3].view(np.uint32)) and not np.array_equal(a[3], x[3]) and not np.array_equal(a[4], a[3])
+    r3 = bank.download_record(3)
+    assert not np.array_equal(r3, r0) and np.array_equal(bank.download_record(5), r3)      # the smoothers, the LFO phase, the DC filters moved — alike in both
+    bank.upload_words(5, 11, np.array([0.25], np.float32).view(np.uint32))               # PP_Z: the left DC filter's first state word
+    with pytest.raises(klang_amd.KlangError):
+        bank.upload_words(5, W - 1, r3[:2])                    # past the end of the record
+    b = bank.process(x.copy())
+    assert not np.array_equal(b[5, 0], b[3, 0]) and np.array_equal(b[5, 1].view(np.uint32), b[3, 1].view(np.uint32))    # the left channel left, the right did not
+    bank.upload_words(5, 0, bank.download_record(3))           # instance 5 becomes instance 3 again
+    c = bank.process(x.copy())
+    assert np.array_equal(c[5].view(np.uint32), c[3].view(np.uint32))
+    assert np.array_equal(bank.download_record(5), bank.download_record(3))
+    bank.close()
