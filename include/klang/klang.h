@@ -207,8 +207,10 @@ struct Pred {
 // `reg` >= 0 only while a process() body is being recorded: the value lives in that register of the program.
 struct relative;
 struct Control;
+struct dsignal;
 struct signal {
 	float value; int reg = -1;
+	signal(const dsignal& d);                                   // (float) of a value computed in double (below)
 	signal(const Control& c);                                   // the control's value (a Control also converts to float and int: name the one meant)
 	signal(constant c) : value(c.f) { reg_member(); }
 	signal(const float v = 0.f) : value(v) { reg_member(); }
@@ -312,6 +314,7 @@ struct param : signal {
 	param(const float v = 0.f) : signal(v) {}
 	param(const signal& s) : signal(s) {}
 	param(signal& s) : signal(s) {}
+	param(const dsignal& d) : signal(d) {}
 	param(Control& c);
 };
 
@@ -435,6 +438,39 @@ struct SampleRate {
 };
 inline SampleRate fs(44100);       // ONE definition per program (the reference's is `static` per translation unit, F7)
 inline klg::host::Fs host_fs() { return klg::host::Fs(fs.f); }
+// ---- values the reference computes in DOUBLE from a control: `(controls[1] + 0.01232 * c) * fs` (examples/Delay/Reverb2.k:43) is Control -> float, float + double,
+// double * float -> a double, which Delay::operator()(double) turns into tap((float)x).  A Control (op) a DOUBLE operand — exactly double: ints and floats keep the
+// float arithmetic they have in the reference — yields a dsignal: a double on the host, a double REGISTER of the program while recording (f2d / dconst + dlow /
+// dadd / dsub / dmul / ddiv), rounded to float once, where the reference rounds (d2f: becoming a signal / param / delay time). ----
+struct dsignal {
+	double value = 0.; int reg = -1;
+	explicit dsignal(double v = 0.) : value(v) {}                              // (explicit: a plain number never turns into one on its own)
+	static int reg_of(gpu::Recorder* r, const dsignal& x) {
+		if (x.reg >= 0) return x.reg;
+		uint64_t u; std::memcpy(&u, &x.value, 8);
+		const int hi = r->emit(klg::graph::OP_DCONST, -1, -1, -1, (uint32_t)(u >> 32), true);
+		return (uint32_t)u ? r->emit(klg::graph::OP_DLOW, hi, -1, -1, (uint32_t)u, true) : hi;
+	}
+	static dsignal from(const signal& s) { dsignal d((double)s.value); if (s.reg >= 0) if (gpu::Recorder* r = gpu::recording()) d.reg = r->emit(klg::graph::OP_F2D, r->reg_of(s), -1, -1, 0, true); return d; }
+	static dsignal bin(int code, const dsignal& a, const dsignal& b, double concrete) {
+		dsignal d(concrete);
+		if (a.reg >= 0 || b.reg >= 0) if (gpu::Recorder* r = gpu::recording()) { const int ra = reg_of(r, a), rb = reg_of(r, b); d.reg = r->emit(code, ra, rb, -1, 0, true); }
+		return d;
+	}
+	operator double() const { if (reg >= 0 && gpu::recording()) gpu::rec->fail("a plain double out of a value computed in process(): keep it in the expression (or make it a signal / param)"); return value; }
+};
+inline signal::signal(const dsignal& d) : value((float)d.value) { if (d.reg >= 0) if (gpu::Recorder* r = gpu::recording()) reg = r->emit(klg::graph::OP_D2F, d.reg, -1, -1, 0, true); }
+#define KLANG_DSIGNAL_OPS(OP, CODE) \
+	template<class T, std::enable_if_t<std::is_same_v<T, double>, int> = 0> inline dsignal operator OP(Control& c, T x) { return dsignal::bin(klg::graph::CODE, dsignal::from(c.value), dsignal(x), (double)c.value.value OP x); } \
+	template<class T, std::enable_if_t<std::is_same_v<T, double>, int> = 0> inline dsignal operator OP(T x, Control& c) { return dsignal::bin(klg::graph::CODE, dsignal(x), dsignal::from(c.value), x OP (double)c.value.value); } \
+	inline dsignal operator OP(const dsignal& a, const dsignal& b) { return dsignal::bin(klg::graph::CODE, a, b, a.value OP b.value); } \
+	template<class T, std::enable_if_t<std::is_arithmetic_v<T>, int> = 0> inline dsignal operator OP(const dsignal& a, T x) { return dsignal::bin(klg::graph::CODE, a, dsignal((double)x), a.value OP (double)x); } \
+	template<class T, std::enable_if_t<std::is_arithmetic_v<T>, int> = 0> inline dsignal operator OP(T x, const dsignal& b) { return dsignal::bin(klg::graph::CODE, dsignal((double)x), b, (double)x OP b.value); } \
+	template<class S, std::enable_if_t<std::is_base_of_v<signal, S>, int> = 0> inline dsignal operator OP(const dsignal& a, const S& s) { return dsignal::bin(klg::graph::CODE, a, dsignal::from(s), a.value OP (double)s.value); } \
+	template<class S, std::enable_if_t<std::is_base_of_v<signal, S>, int> = 0> inline dsignal operator OP(const S& s, const dsignal& b) { return dsignal::bin(klg::graph::CODE, dsignal::from(s), b, (double)s.value OP b.value); } \
+	inline dsignal operator OP(const dsignal& a, const SampleRate& r) { return dsignal::bin(klg::graph::CODE, a, dsignal((double)r.f), a.value OP (double)r.f); }
+KLANG_DSIGNAL_OPS(+, OP_DADD) KLANG_DSIGNAL_OPS(-, OP_DSUB) KLANG_DSIGNAL_OPS(*, OP_DMUL) KLANG_DSIGNAL_OPS(/, OP_DDIV)
+#undef KLANG_DSIGNAL_OPS
 // `controls[0] * fs`, `mod * fs`: the sample rate is a plain number (its float conversion would un-record a recorded left side)
 // (R is deduced, so a plain float never converts into a SampleRate to get here)
 template<class S, class R, std::enable_if_t<std::is_base_of_v<signal, S> && std::is_same_v<R, SampleRate>, int> = 0> inline signal operator*(const S& a, const R& r) { return static_cast<const signal&>(a) * signal(r.f); }
@@ -1235,7 +1271,7 @@ inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	// ---- dead code: pure ops nobody reads, params nobody reads (and their write-backs), primitives nobody uses ----
 	std::vector<Op>& ops = R.prog.ops;
 	std::vector<char> keep(ops.size(), 1), used;
-	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG || c == OP_CMP || c == OP_PHI || c == OP_TABREAD; };
+	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG || c == OP_CMP || c == OP_PHI || c == OP_TABREAD || (c >= OP_F2D && c <= OP_D2F); };
 	for (bool changed = true; changed;) {
 		changed = false;
 		used.assign(MAX_OPS + 1, 0); used[(size_t)R.prog.ret] = 1; if (R.prog.ret_r >= 0) used[(size_t)R.prog.ret_r] = 1;
@@ -1474,7 +1510,7 @@ template<int SIZE> struct Delay : Modifier, gpu::Packable {
 			if (gpu::Recorder* r = gpu::recording()) { signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(signal((float)delay)), -1, r->node(this, "Delay"), 1, true); return s; }
 			device_only("Delay::operator()");
 		}
-		if (gpu::Recorder* r = gpu::recording()) { signal t; if constexpr (std::is_arithmetic_v<TIME>) t = signal((float)delay); else t = signal(const_cast<TIME&>(delay)); signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(t), -1, r->node(this, "Delay"), 0, true); return s; }
+		if (gpu::Recorder* r = gpu::recording()) { signal t; if constexpr (std::is_arithmetic_v<TIME>) t = signal((float)delay); else if constexpr (std::is_same_v<TIME, dsignal>) t = signal(delay); else t = signal(const_cast<TIME&>(delay)); signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(t), -1, r->node(this, "Delay"), 0, true); return s; }
 		device_only("Delay::operator()");
 	}
 	// one channel of Stereo::Delay::tap(float) klang.h:4668-4681: its own interpolation form (a * (1 - f) + b * f), not Delay::tap(float)'s

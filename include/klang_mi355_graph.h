@@ -164,10 +164,17 @@ enum OpCode {
 	OP_DELAYSET,    /* delay node .set(samples = a)        Delay::set 3480-3489: the read head `samples` behind the write cursor (in process(), or in an
 	                   effect's prepare(): placed once per block, then walked by every `delay >> x`) */
 	OP_ABS,         /* dst = |a|                           std::abs of a signal: fabsf                                                               */
+	/* DOUBLE registers: what `(controls[1] + 0.01232 * c) * fs` is in the reference (examples/Delay/Reverb2.k:43: Control -> float, float + double, double * float
+	 * -> double, then Delay::operator()(double) -> tap((float)x)).  A register is a double iff one of these defines it; only these and d2f read one; no phi */
+	OP_F2D,         /* dst(double) = (double) a                                                                                                        */
+	OP_DCONST,      /* dst(double) = the double whose HIGH word is imm (low word 0)                                                                    */
+	OP_DLOW,        /* dst(double) = a with its LOW word replaced by imm: a 64-bit literal is dconst + dlow (an op carries 32 immediate bits)          */
+	OP_DADD, OP_DSUB, OP_DMUL, OP_DDIV,   /* dst(double) = a OP b, both doubles                                                                          */
+	OP_D2F,         /* dst = (float) a   (round to nearest even)                                                                                       */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs", "f2d", "dconst", "dlow", "dadd", "dsub", "dmul", "ddiv", "d2f" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -266,11 +273,13 @@ struct Program {
 		bool after_endif = false;
 		auto in_list = [](const std::vector<int>& l, int r) { for (int x : l) if (x == r) return true; return false; };
 		auto kind = [&](int n) { return (n >= 0 && n < (int)nodes.size()) ? nodes[(size_t)n] : -1; };
+		std::vector<char> dbl;                                                    // registers that hold a double
+		auto is_dbl = [&](int r) { return r >= 0 && r < (int)dbl.size() && dbl[(size_t)r] != 0; };
 		char m[160];
 		for (size_t i = 0; i < ops.size(); i++) {
 			const Op& o = ops[i];
 			auto bad = [&](const char* why) { snprintf(m, sizeof m, "graph program op %zu (%s): %s", i, op_name(o.code), why); return std::string(m); };
-			bool need_a = false, need_b = false, has_dst = true; int k = kind(o.node);
+			bool need_a = false, need_b = false, has_dst = true, dst_dbl = false; int k = kind(o.node);
 			switch (o.code) {
 			case OP_CONST: break;
 			case OP_CTL: if ((int)o.imm >= nctl) return bad("control index out of range"); break;
@@ -297,6 +306,11 @@ struct Program {
 			case OP_NOISE: if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;
 			case OP_SETCTL: if (k != N_CTLVAR) return bad("node is not a written control"); if (!channels) return bad("only an effect writes its controls"); if ((int)o.imm >= nctl) return bad("control index out of range"); need_a = true; break;
 			case OP_ABS: need_a = true; break;
+			case OP_F2D: need_a = true; if (is_dbl(o.a)) return bad("operand a is already a double"); dst_dbl = true; break;
+			case OP_DCONST: dst_dbl = true; break;
+			case OP_DLOW: need_a = true; if (!is_dbl(o.a)) return bad("operand a is not a double"); dst_dbl = true; break;
+			case OP_DADD: case OP_DSUB: case OP_DMUL: case OP_DDIV: need_a = need_b = true; if (!is_dbl(o.a) || !is_dbl(o.b)) return bad("both operands must be doubles"); dst_dbl = true; break;
+			case OP_D2F: need_a = true; if (!is_dbl(o.a)) return bad("operand a is not a double"); break;
 			case OP_TABREAD: if (channels) return bad("tables are only available to synth notes"); if (o.imm == 0u) return bad("table id 0 is reserved"); need_a = true; break;
 			case OP_IF: if ((int)i < prepare_ops) return bad("prepare() may not branch"); need_a = true; has_dst = false; open.push_back({ {}, false, {} }); break;
 			case OP_ELSE:
@@ -318,11 +332,13 @@ struct Program {
 			after_endif = o.code == OP_ENDIF || o.code == OP_PHI;
 			if (need_a && !def(o.a)) return bad("operand a is not defined");
 			if (need_b && !def(o.b)) return bad("operand b is not defined");
+			if (!(o.code >= OP_F2D && o.code <= OP_D2F) && ((need_a && is_dbl(o.a)) || (need_b && is_dbl(o.b)) || (o.code == OP_PHI && (is_dbl(o.a) || is_dbl(o.b))))) return bad("a double register may only be read by dlow / dadd / dsub / dmul / ddiv / d2f");
 			if (has_dst) {
 				if (o.dst < 0 || o.dst >= MAX_OPS) return bad("bad destination register");
 				if ((int)defined.size() <= o.dst) defined.resize((size_t)o.dst + 1, 0);
 				if (defined[(size_t)o.dst]) return bad("register assigned twice");
 				defined[(size_t)o.dst] = 1;
+				if (dst_dbl) { if ((int)dbl.size() <= o.dst) dbl.resize((size_t)o.dst + 1, 0); dbl[(size_t)o.dst] = 1; }
 				if (!open.empty()) open.back().regs.push_back(o.dst);
 			}
 		}

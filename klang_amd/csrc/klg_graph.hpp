@@ -285,6 +285,15 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			else body += d + a + " / " + b + ";\n";
 		} break;
 		case OP_NEG: body += d + "-" + a + ";\n"; break;
+		// double registers (include/klang_mi355_graph.h): IEEE double arithmetic, contraction off like everything else
+		case OP_F2D: body += fmt("\t\tconst double r%d = (double)", o.dst) + a + ";\n"; break;
+		case OP_DCONST: body += fmt("\t\tconst double r%d = __longlong_as_double(0x%08x00000000ll);\n", o.dst, o.imm); break;
+		case OP_DLOW: body += fmt("\t\tconst double r%d = __longlong_as_double(__double_as_longlong(", o.dst) + a + fmt(") | 0x%08xll);\n", o.imm); break;
+		case OP_DADD: body += fmt("\t\tconst double r%d = ", o.dst) + a + " + " + b + ";\n"; break;
+		case OP_DSUB: body += fmt("\t\tconst double r%d = ", o.dst) + a + " - " + b + ";\n"; break;
+		case OP_DMUL: body += fmt("\t\tconst double r%d = ", o.dst) + a + " * " + b + ";\n"; break;
+		case OP_DDIV: body += fmt("\t\tconst double r%d = ", o.dst) + a + " / " + b + ";\n"; break;
+		case OP_D2F: body += d + "(float)" + a + ";\n"; break;
 		case OP_CMP: { static const char* rel[6] = { "<", ">", "<=", ">=", "==", "!=" }; body += d + "(" + a + " " + rel[o.imm <= 5u ? o.imm : 0u] + " " + b + ") ? 1.f : 0.f;\n"; } break;
 		case OP_IF:
 			if_depth++;

@@ -58,8 +58,13 @@ FX["fx_topchorus"] = [(0.2, 1.0), (0.05, 1.5), (0.1, 0.5), (1.0, 5.5), (0.1, 0.5
 FX["fx_owntape"] = [(0.003, 0.04), (0.0, 0.9), (400.0, 6000.0)]
 # tests/patches/fx_fdn.k (OUR OWN effect): four user Modifiers (Delay + LPF + gain), signals<4> >> Matrix, the rows fed back — Reverb.k's LateReflections' shape
 FX["fx_ownfdn"] = [(0.5, 3.0), (800.0, 10000.0), (0.05, 0.42), (0.2, 1.0)]
+# Delay/Reverb2.k: a tap time computed in DOUBLE from a control — `(controls[1] + 0.01232 * c) * fs` is float + double, double * float, then tap((float)x) — recorded as
+# double registers (f2d / dconst / dlow / dadd / dmul / d2f); two Delay<192000> per channel, eight constant taps, a damping LPF set in prepare().  (Added last: the
+# scenarios above keep their random draws.)
+FX["fx_reverb2"] = [(0.0, 0.5), (0.0, 0.4), (500.0, 5000.0)]
 SHAPE = {"fx_patterns": dict(K=4, blocks=110),       # name -> instances / blocks (default 9 / 24)
-         "fx_topreverb": dict(K=9, blocks=64)}         # 8,192 samples: the early reflections arrive after ~2,600, mid[] ~400 later, late[] ~1,000 after that
+         "fx_topreverb": dict(K=9, blocks=64),
+         "fx_reverb2": dict(K=9, blocks=40)}         # 8,192 samples: the early reflections arrive after ~2,600, mid[] ~400 later, late[] ~1,000 after that
 
 
 def draw(rng, lo, hi):
