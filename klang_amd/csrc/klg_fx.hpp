@@ -1113,7 +1113,7 @@ enum { RVQ_WG = 64 };
 // no branch: a rarely-taken branch cost 9 VALU per tap in register copies at its join, profiles/r03_pmc/pmc_reverb_q_4096_padbranch.json)
 enum { RVQ_B = 8, RV_FPAD = 32, RV_EMIRROR = 16, RV_EZERO = RV_ESIZE + RV_EMIRROR, RV_EPAD = RV_EMIRROR + 16, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
 static_assert(RV_ESTRIDE % 4 == 0, "16-byte stores into an early line need 16-byte aligned line starts");
-enum { RVQ_XQ_LD = 20, RVQ_XQ_FLOATS = 64 * RVQ_XQ_LD };  // the quarter exchange of the ring stores: 64 rows of 16 floats, padded
+enum { RVQ_XQ_LD = 36, RVQ_XQ_FLOATS = 64 * RVQ_XQ_LD };  // the quarter exchange of the ring stores: 64 rows of 32 floats (two batches' pieces: 128 bytes per line), padded
 enum { RVQ_TILE_ROWS = 17 };             // LDS per wave, rows of n floats: 0..7 the caller's block (instance * 2 + channel), 8 scrap, 9..16 the early sums
 
 __device__ __forceinline__ float lane_get(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
@@ -1408,6 +1408,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	//   fd (FilteredDelays): 0 every lane runs, pairs collected, the 64-byte piece flushed at u = 7 (steady) | 1 tested, pairs stored one by one (an edge off the grid)
 	//                        | 2 tested, collected and flushed (an edge ON the grid: the piece is complete) | 3 tested, nothing stored (the iterations before an aligned block: only
 	//                        mid[]'s first pair exists, and it travels in pp to the next batch's slot 0)
+	//                        | 4 / 5 every lane runs, 6 / 7 tested: the FIRST / SECOND batch of a PAIR whose two 64-byte pieces leave together as one aligned 128-byte piece (below)
 	//   e (early filter):    0 runs, collected, flushed at u = 5 | 1 tested, stored one by one | 2 tested, collected and flushed | 3 tested, collected only
 	//   o (output):          0 runs | 1 tested
 	// (8-byte pair stores are not merged on their way to memory: every one is a 32-byte write — 11 - 14 KB per instance and block at the edges,
@@ -1416,7 +1417,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 		constexpr int MFD = decltype(mode)::fd, ME = decltype(mode)::e, MO = decltype(mode)::o;
 		constexpr int u = decltype(place)::value;
 		const int e = t + 2, sfd = t + cf, o = t - 1;
-		const bool e_on = ME == 0 || (e >= 0 && e < n), fd_on = MFD == 0 || (sfd >= 0 && sfd < n), o_on = MO == 0 || (o >= 0 && o < n);
+		const bool e_on = ME == 0 || (e >= 0 && e < n), fd_on = MFD == 0 || MFD == 4 || MFD == 5 || (sfd >= 0 && sfd < n), o_on = MO == 0 || (o >= 0 && o < n);
 		int ewpos = epos0 + e; if (ewpos >= RV_ESIZE) ewpos -= RV_ESIZE; if (ewpos < 0) ewpos += RV_ESIZE;   // uniform: the early write cursor of sample e
 		// ---- requests whose answers are needed later in this iteration / in the next one ----
 		const float from_mid = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ssum_prev), 0x118, 0xF, 0xF, true));   // late[]'s input: mid[]'s sum of the previous iteration (DPP row_shr:8 — lane L takes lane L - 8 of its row of 16)
@@ -1474,6 +1475,34 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 				}
 			}
 		}
+		if constexpr (MFD >= 4) {
+			// PAIRS: a 64-byte piece is half of a 128-byte line, and the memory system moves this kernel's pattern — 65,536 lines, each touched one piece at a
+			// time — at 4.0 TB/s with 64-byte pieces and 5.0 TB/s with 128-byte ones (tools/calib/piece_bw.hip, profiles/r03_pmc/reverb_q_piece_size.jsonl).  The first
+			// batch of a pair leaves its lanes' sixteen floats in LDS; the second adds its own and the quad writes both halves of every line back to back.
+			Wf[2 * u] = wa; Wf[2 * u + 1] = wb;
+			if constexpr (u == RVQ_B - 1) {
+				constexpr int H = (MFD == 5 || MFD == 7) ? 1 : 0;
+#pragma unroll
+				for (int v = 0; v < 4; v++) { const rvq_v4 x = { Wf[4 * v], Wf[4 * v + 1], Wf[4 * v + 2], Wf[4 * v + 3] }; xq_mine[4 * H + v] = x; }
+				if constexpr (H == 1) {
+					const int w0 = fbase - 2 * (RVQ_B - 1) - 2 * RVQ_B;       // uniform and a multiple of 32: the pair's piece of every line
+					wave_sync();
+					rvq_v4 quarter[4][2];
+#pragma unroll
+					for (int v = 0; v < 4; v++) { quarter[v][0] = xq_quad[v * (RVQ_XQ_LD / 4)]; quarter[v][1] = xq_quad[v * (RVQ_XQ_LD / 4) + 4]; }
+					wave_sync();                                              // (the next pair's writes come after these reads)
+#pragma unroll
+					for (int v = 0; v < 4; v++) if (!(KLG_RVQ_ABLATE & 1)) {
+						__builtin_nontemporal_store(quarter[v][0], reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0));
+						__builtin_nontemporal_store(quarter[v][1], reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0 + 2 * RVQ_B));
+					}
+					if (w0 < RV_FPAD) {                                       // the mirrored head (once per lap of the ring)
+#pragma unroll
+						for (int v = 0; v < 4; v++) { *reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0 + RV_FSIZE) = quarter[v][0]; *reinterpret_cast<rvq_v4*>(fquad + (size_t)v * RV_FSTRIDE + w0 + 2 * RVQ_B + RV_FSIZE) = quarter[v][1]; }
+					}
+				}
+			}
+		}
 		if constexpr (u == RVQ_B - 1) fr0 = r2v;                             // row last + 2 of the batch's last sample is row `last` of the next batch's first
 		// ---- early stage, sample e: in >> lpf >> hpf >> delay  Reverb.k:88 ----
 		if (e_on) {
@@ -1520,6 +1549,7 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	const BoolTag<true> gfetch; const BoolTag<false> sfetch;                    // the next batch's LDS values: indices clamped to the block / as they are
 	const RvqMode<1, 1, 1> ramp; const RvqMode<0, 0, 0> steady;
 	const RvqMode<3, 3, 1> lead_in; const RvqMode<2, 2, 1> edge;               // the two kinds of edge batch of a block that starts and ends on the grid
+	const RvqMode<4, 0, 0> steady_1st; const RvqMode<5, 0, 0> steady_2nd; const RvqMode<6, 2, 1> edge_1st; const RvqMode<7, 2, 1> edge_2nd;   // ... whose pieces leave in pairs (128 bytes per line)
 	// iterations t = -2 .. n in batches of eight; the rows of a batch are requested two batches ahead (a wave alone on its SIMD has nothing
 	// but distance to hide HBM latency with; a batch is about a microsecond).  The sched_barrier: the rows are REQUESTED there, not where used.
 	// (A request past the block's end reads rows that exist and are not used.)
@@ -1529,7 +1559,43 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 	// 1024 samples from a host that always asks for the same length) has no ragged edge: the batch of iterations -8 .. -1 only produces mid[]'s first pair
 	// and the early filter's first two samples (carried over in registers), the batches 0 .. 7 and n - 8 .. n - 1 hold complete pieces and store them whole.
 	const int steady_batches = n / RVQ_B - 2;
-	if (t_s == RVQ_B && n % RVQ_B == 0 && steady_batches >= 3 && steady_batches % 3 == 0) {
+	if (t_s == RVQ_B && ((fpos0 >> 1) & (2 * RVQ_B - 1)) == 0 && n % (2 * RVQ_B) == 0 && steady_batches >= 2) {
+		// ... and on the grid of PAIRS (any block of a multiple of sixteen samples that starts on it): batch 0 (an edge) is the first of a pair, the steady batches
+		// alternate second / first — with the three register sets in rotation a turn is six batches, and what is left of them (none, two or four) is written out
+		// with the sets it finds —, the closing edge batch is a second.
+		const int turns = steady_batches / 6, rest = steady_batches - 6 * turns;        // rest: 0, 2 or 4 (an even number of batches)
+		batch(lead_in, gfetch, t0, A, LA, Cn, LB); t0 += RVQ_B;                 // t = -8 .. -1
+		batch(edge_1st, sfetch, t0, Bn, LB, A, LC); t0 += RVQ_B;                // t = 0 .. 7
+		for (int turn = turns; turn > 0; turn--, t0 += 6 * RVQ_B) {
+			batch(steady_2nd, sfetch, t0, Cn, LC, Bn, LA);
+			batch(steady_1st, sfetch, t0 + RVQ_B, A, LA, Cn, LB);
+			batch(steady_2nd, sfetch, t0 + 2 * RVQ_B, Bn, LB, A, LC);
+			batch(steady_1st, sfetch, t0 + 3 * RVQ_B, Cn, LC, Bn, LA);
+			batch(steady_2nd, sfetch, t0 + 4 * RVQ_B, A, LA, Cn, LB);
+			if (turn > 1 || rest) batch(steady_1st, sfetch, t0 + 5 * RVQ_B, Bn, LB, A, LC);
+			else batch(steady_1st, gfetch, t0 + 5 * RVQ_B, Bn, LB, A, LC);     // (what follows the last steady batch is guarded)
+		}
+		if (rest == 0) {
+			batch(edge_2nd, gfetch, t0, Cn, LC, Bn, LA);                        // t = n - 8 .. n - 1
+			batch(ramp, gfetch, t0 + RVQ_B, A, LA, Cn, LB);                     // t = n: the last output sample
+		}
+		else if (rest == 2) {
+			batch(steady_2nd, sfetch, t0, Cn, LC, Bn, LA);
+			batch(steady_1st, gfetch, t0 + RVQ_B, A, LA, Cn, LB);
+			batch(edge_2nd, gfetch, t0 + 2 * RVQ_B, Bn, LB, A, LC);
+			batch(ramp, gfetch, t0 + 3 * RVQ_B, Cn, LC, Bn, LA);
+		}
+		else {
+			batch(steady_2nd, sfetch, t0, Cn, LC, Bn, LA);
+			batch(steady_1st, sfetch, t0 + RVQ_B, A, LA, Cn, LB);
+			batch(steady_2nd, sfetch, t0 + 2 * RVQ_B, Bn, LB, A, LC);
+			batch(steady_1st, gfetch, t0 + 3 * RVQ_B, Cn, LC, Bn, LA);
+			batch(edge_2nd, gfetch, t0 + 4 * RVQ_B, A, LA, Cn, LB);
+			batch(ramp, gfetch, t0 + 5 * RVQ_B, Bn, LB, A, LC);
+		}
+		t0 = n + 1;
+	}
+	else if (t_s == RVQ_B && n % RVQ_B == 0 && steady_batches >= 3 && steady_batches % 3 == 0) {
 		batch(lead_in, gfetch, t0, A, LA, Cn, LB); t0 += RVQ_B;                 // t = -8 .. -1
 		batch(edge, sfetch, t0, Bn, LB, A, LC); t0 += RVQ_B;                    // t = 0 .. 7: every FilteredDelay and early sample of the piece is inside the block; only the output of t = 0 is not
 		for (int turn = steady_batches / 3; turn > 1; turn--, t0 += 3 * RVQ_B) {

@@ -84,6 +84,28 @@ def test_fx_block_size_independence():
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("block", [16, 32, 48, 64, 96, 128, 176, 256, 512, 1024, 40, 200])
+def test_reverb_block_lengths(block, oracle_build):
+    """klg_fx_reverb_q picks its way through a block by the block's length and where the rings' cursors stand: blocks of a multiple of sixteen samples
+    that start on the grid store their FilteredDelay pieces in PAIRS (128 bytes per line; six-batch turns plus none / two / four batches written out:
+    32 -> 2 steady batches, 48 -> 4, 64 -> 6, 96 -> 10, 128 -> 14, 176 -> 20, 256 -> 30, 512 -> 62, 1024 -> 126), a multiple of eight keeps whole 64-byte
+    pieces, anything else (40 after the first block, 200) the guarded general form.  Seven instances, ~7,200 samples (early reflections arrive after
+    ~2,400, the mid ones ~400 later), a dial changed on the way, against the oracle bit for bit."""
+    B = max(2, 7200 // block)
+    dump = sorted({0, 1, B // 2, B * 2 // 3, B - 2, B - 1})
+    s = Scenario(patch="reverb", block=block, blocks=B, instances=7, burst=2000, seed=31, dump=dump)
+    rng = np.random.default_rng(6)
+    for k in range(7):
+        s.control(0, k, 1, float(rng.uniform(0.3, 1.0))); s.control(0, k, 2, float(rng.uniform(0.2, 1.0))); s.control(0, k, 3, float(rng.uniform(0.2, 1.0)))
+        s.control(0, k, 5, float(rng.uniform(2.0, 40.0))); s.control(0, k, 6, float(rng.uniform(0.1, 1.0)))
+    s.control(B // 3, 2, 7, 0.4)
+    s.sort()
+    got = run_fx_scenario_gpu(s)["per_voice"]
+    ref = run_scenario_oracle(s, oracle_build)["per_voice"]
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"max abs err {np.abs(got - ref).max()}"
+    assert np.abs(got[-1]).max() > 1e-4
+
+
 def test_fx_silence_in_silence_out():
     import klang_amd
     bank = klang_amd.FxBank("reverb", 5, max_block=128)
