@@ -106,6 +106,33 @@ def test_reverb_block_lengths(block, oracle_build):
     assert np.abs(got[-1]).max() > 1e-4
 
 
+def test_reverb_is_independent_of_how_the_stream_is_cut():
+    """Property (GPU vs GPU): one stream of 6,144 samples through Reverb.k in blocks of 256 equals the same stream cut into a mixture of lengths —
+    which walks klg_fx_reverb_q through all of its ways in and out of a block (pairs, whole pieces, the guarded form) with the rings' cursors on
+    and off the store grids — bit for bit, for five instances with different dials."""
+    import klang_amd
+    K, total = 5, 6144
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-0.5, 0.5, size=(K, 2, total)).astype(np.float32)
+    x[:, :, 2500:] = 0
+    dials = [(k, c, float(rng.uniform(lo, hi))) for k in range(K) for c, lo, hi in ((1, 0.3, 1.0), (2, 0.2, 1.0), (3, 0.2, 1.0), (5, 2.0, 40.0), (6, 0.1, 1.0), (7, 0.05, 1.0))]
+    def render(cuts):
+        bank = klang_amd.FxBank("reverb", K, max_block=1024)
+        for k, c, v in dials: bank.set_control(k, c, v)
+        out, at = np.zeros_like(x), 0
+        for n in cuts:
+            io = np.ascontiguousarray(x[:, :, at:at + n]); bank.process(io); out[:, :, at:at + n] = io; at += n
+        assert at == total
+        bank.close()
+        return out
+    ref = render([256] * 24)
+    mixed = [256, 40, 256, 16, 200, 64, 8, 24, 512, 128, 48, 1024, 96, 32, 176, 1000, 264, 640, 368, 32, 64, 500, 140, 256]
+    assert sum(mixed) == total
+    got = render(mixed)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"max abs err {np.abs(got - ref).max()}"
+    assert np.abs(ref[:, :, 3000:]).max() > 1e-4
+
+
 def test_fx_silence_in_silence_out():
     import klang_amd
     bank = klang_amd.FxBank("reverb", 5, max_block=128)
