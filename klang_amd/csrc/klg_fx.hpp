@@ -1285,8 +1285,8 @@ __global__ __launch_bounds__(RVQ_WG) void klg_fx_reverb_q(const ReverbArgs a) {
 			const int pos = (wpos + 1 == RV_ESIZE) ? 0 : wpos + 1;              // ... after Delay::input()
 			const float at = (float)(pos - 1);
 #pragma unroll
-			for (int d = 0; d < 20; d++) {
-				float read = at - word(tA, tB, i, d);                           // (a tap this instance does not have: whatever its words hold — zero or an earlier time — gives a valid position, and it is never summed)
+			for (int d = 0; d < 20; d++) if (d < 10 || d < cnt) {               // (Reverb.k:26: ten to twenty taps by the room-size dial; a tap the instance does not have is neither fetched nor summed — the test is wave-uniform)
+				float read = at - word(tA, tB, i, d);
 				if (read < 0.f) read += RV_ESIZE;
 				T.fr[d] = read - floorf(read);
 				int i0 = (int)read;                                             // i0 + 1 may be RV_ESIZE: the mirror tail holds position 0 there
