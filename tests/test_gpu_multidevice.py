@@ -143,12 +143,15 @@ def test_effect_bank_is_sharded_by_instance(patch):
                 bank.set_control(K - 1, ctl[-1][1], 0.33)                  # a change mid-run, last instance (the last shard)
             io = x[b].copy(); bank.process(io); out.append(io)
         back = [bank.get_control(k, 1) for k in (0, K // 2, K - 1)]
+        recs = [bank.download_record(k) for k in (0, K // 2, K - 1)]              # an instance's record comes from the shard that owns it
+        bank.upload_words(K - 1, 0, recs[-1][:4])                                # ... and uploads go there (the same words back: nothing changes)
+        assert bank.record_words() == recs[0].size and np.array_equal(bank.download_record(K - 1), recs[-1])
         if len(devs) > 1:
             import torch
             with pytest.raises(klang_amd.KlangError, match="sharded over"):
                 bank.process_device(torch.zeros((K, 2, N), device="cuda").data_ptr(), N)
         bank.close()
-        return np.stack(out), back
+        return np.stack(out), (back, [r.tobytes() for r in recs])
 
     try:
         ref, ref_back = run((0,))
