@@ -710,6 +710,8 @@ enum {
 	RV_WORDS = RV_FD + 16 * FD_WORDS
 };
 enum { RV_ESIZE = 21600, RV_FSIZE = 192000 };
+// ring layout 1 (a contiguous ring per (instance, line): klg_fx_reverb_q, and klg_fx_reverb when it stands in for it): every line is followed by a tail — see klg_fx_reverb_q
+enum { RV_FPAD = 32, RV_EMIRROR = 16, RV_EZERO = RV_ESIZE + RV_EMIRROR, RV_EPAD = RV_EMIRROR + 16, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
 
 struct ReverbArgs {
 	float* state; size_t kpad; int K;
@@ -739,7 +741,7 @@ __device__ __forceinline__ void fd_load(FDelay& d, const ReverbArgs& a, int idx,
 	d.gain = s[(size_t)FD_GAIN * a.kpad];
 	d.f.b0 = s[(size_t)(FD_COEF + 0) * a.kpad]; d.f.b1 = s[(size_t)(FD_COEF + 1) * a.kpad]; d.f.b2 = s[(size_t)(FD_COEF + 2) * a.kpad];
 	d.f.a1 = s[(size_t)(FD_COEF + 3) * a.kpad]; d.f.a2 = s[(size_t)(FD_COEF + 4) * a.kpad];
-	if (a.layout) { d.ring.base = a.fd_rings + ((size_t)k * 16 + idx) * (RV_FSIZE + 32); d.ring.stride = 1; }   // RV_FSTRIDE: the line + its mirror tail (klg_fx_reverb_q)
+	if (a.layout) { d.ring.base = a.fd_rings + ((size_t)k * 16 + idx) * RV_FSTRIDE; d.ring.stride = 1; }   // the line + its mirror tail (klg_fx_reverb_q)
 	else { d.ring.base = a.fd_rings + ((size_t)blockIdx.x * 16 + idx) * RV_FSIZE * FX_WG + threadIdx.x; d.ring.stride = FX_WG; }
 	d.ring.size = RV_FSIZE;
 }
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
 	const int ecount = __float_as_int(RVW(RV_ECOUNT));
 	float* etile = a.early_rings + (size_t)blockIdx.x * 2 * RV_ESIZE * FX_WG + lane;
 	Ring el = { etile, FX_WG, RV_ESIZE }, er = { etile + (size_t)RV_ESIZE * FX_WG, FX_WG, RV_ESIZE };
-	if (a.layout) { el.base = a.early_rings + (size_t)k * 2 * (RV_ESIZE + 20); er.base = el.base + (RV_ESIZE + 20); el.stride = er.stride = 1; }   // RV_ESTRIDE
+	if (a.layout) { el.base = a.early_rings + (size_t)k * 2 * RV_ESTRIDE; er.base = el.base + RV_ESTRIDE; el.stride = er.stride = 1; }
 	FDelay mid0[4], mid1[4], late0[4], late1[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) { fd_load(mid0[j], a, 0 + j, k); fd_load(mid1[j], a, 4 + j, k); fd_load(late0[j], a, 8 + j, k); fd_load(late1[j], a, 12 + j, k); }
@@ -946,8 +948,8 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 			if (read < 0.f) read += RV_ESIZE;
 			X.ef[q] = read - (float)floor((double)read);
 			int i = (int)read, j = (i == RV_ESIZE - 1) ? 0 : (i + 1);
-			const bool pad = i == RV_ESIZE;                                           // (read rounded up to SIZE: stereo_delay_tap — the tap is 0; a wave-uniform, almost never taken branch)
-			if (__ballot(pad) != 0ull) { i = pad ? 0 : i; j = pad ? 0 : j; }
+			const bool pad = i == RV_ESIZE;                                           // (read rounded up to SIZE: stereo_delay_tap — the tap is 0; a wave-uniform, almost never taken branch.
+			if (__ballot(pad) != 0ull) { i = pad ? 0 : i; j = pad ? 0 : j; }          //  Selects on the loaded values instead were measured: 0.76 against 0.50 ms at 16,384 instances — they end the prefetch)
 			if (eload[q]) { X.ea[q] = ering.rd(i); X.eb[q] = ering.rd(j); }
 			if (__ballot(pad) != 0ull) { if (pad) { X.ea[q] = 0.f; X.eb[q] = 0.f; } }
 		}
@@ -1103,7 +1105,8 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 // its first positions behind its last one (RV_FPAD / RV_EPAD floats, written together with the original).
 // Arithmetic, operand order and summation order are exactly those of klg_fx_reverb / the reference (the three kernels are compared bit
 // for bit in tests/test_gpu_fx.py: KLG_FX_REVERB1=1 selects the single-lane kernel, KLG_FX_REVERB16=1 the sixteen-wave one).
-enum { RVQ_MAX_INSTANCES = 8192 };       // banks up to this size run klg_fx_reverb_q (measured: profiles/r02_fx_sizes.md)
+enum { RVQ_MAX_INSTANCES = 65536 };      // banks up to this size run klg_fx_reverb_q: every bank that fits (12.5 MB of rings per instance: ~22 k in 288 GB).  Round 2 drew the line at 8,192
+                                         // (profiles/r02_fx_sizes.md); since round 3's write-side work the kernel also wins above it — 16,384 instances: 0.467 against klg_fx_reverb16's 0.490 ms
 enum { RVQ_WG = 64 };
 #ifndef KLG_RVQ_ABLATE
 #define KLG_RVQ_ABLATE 0          // measurement builds only (tools/rvq_ablate.sh): 1 no FilteredDelay piece stores, 2 no early-line stores, 4 no output block, 8 no record write-back
@@ -1111,7 +1114,7 @@ enum { RVQ_WG = 64 };
 // an early line in layout 1: [0, RV_ESIZE) the ring, then RV_EMIRROR floats mirroring positions 0 .. 15, then sixteen floats that are ALWAYS ZERO (RV_EZERO; sixteen, not two: a line's length stays a multiple of 128 bytes, so every line's 32-byte store pieces are whole sectors): where a
 // tap whose read position rounded up to exactly RV_ESIZE is pointed (stereo_delay_tap: that tap reads the pad — zeros —; one compare and one select per tap,
 // no branch: a rarely-taken branch cost 9 VALU per tap in register copies at its join, profiles/r03_pmc/pmc_reverb_q_4096_padbranch.json)
-enum { RVQ_B = 8, RV_FPAD = 32, RV_EMIRROR = 16, RV_EZERO = RV_ESIZE + RV_EMIRROR, RV_EPAD = RV_EMIRROR + 16, RV_FSTRIDE = RV_FSIZE + RV_FPAD, RV_ESTRIDE = RV_ESIZE + RV_EPAD };
+enum { RVQ_B = 8 };
 static_assert(RV_ESTRIDE % 4 == 0, "16-byte stores into an early line need 16-byte aligned line starts");
 enum { RVQ_XQ_LD = 36, RVQ_XQ_FLOATS = 64 * RVQ_XQ_LD };  // the quarter exchange of the ring stores: 64 rows of 32 floats (two batches' pieces: 128 bytes per line), padded
 enum { RVQ_TILE_ROWS = 17 };             // LDS per wave, rows of n floats: 0..7 the caller's block (instance * 2 + channel), 8 scrap, 9..16 the early sums
