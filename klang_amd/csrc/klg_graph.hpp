@@ -509,8 +509,9 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	if (x2) { expr[0] = "klg::klg_render_x2<klg::PatchGen, false>"; expr[1] = "klg::klg_render_x2<klg::PatchGen, true>"; }
 	rtc.AddNameExpression(prog, expr[0]); if (!g.channels) rtc.AddNameExpression(prog, expr[1]);
 	const std::string inc = "-I" + source_dir();
-	const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str() };
-	const int rc = rtc.CompileProgram(prog, 5, opts);
+	const char* extra = getenv("KLG_RTC_EXTRA");                             // (measurement: one more compiler option for the generated kernels)
+	const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str(), extra };
+	const int rc = rtc.CompileProgram(prog, (extra && extra[0]) ? 6 : 5, opts);
 	if (rc != 0) {
 		size_t n = 0; rtc.GetProgramLogSize(prog, &n);
 		std::string log(n, '\0'); if (n) rtc.GetProgramLog(prog, &log[0]);
