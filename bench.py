@@ -632,6 +632,7 @@ def main():
             leg(run_literal_script, "supersaw", 16384, N, "cfg3_16384_supersaw_voices")
             leg(run_fx, "pingpong", 4096, N)
             leg(run_fx, "reverb", 4096, N)
+            leg(run_fx, "pingpong", 65536, N)                             # the same patch at bank scale: where config 4 meets north_star's "≥ 40 % of the HBM roofline" (100 GB of delay lines)
             leg(run_literal_script, "fm4", 131072, N, "cfg5_share_131072_fm4_voices")
             leg(run_realtime, "sub2a", args.realtime_voices, N)
             out["configs"] = configs
