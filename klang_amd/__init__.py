@@ -6,4 +6,4 @@ There is no CPU rendering path anywhere in this package.
 """
 from ._lib import KlangError, lib, LIB_PATH  # noqa: F401
 from .bank import SynthBank, FxBank, EventScript, PATCH_IDS, init  # noqa: F401
-from .shard import ShardedSynthBank, shard_range, owner_of  # noqa: F401
+from .shard import ShardedFxBank, ShardedSynthBank, shard_range, owner_of  # noqa: F401

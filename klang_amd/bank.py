@@ -238,10 +238,13 @@ class EventScript:
 class FxBank:
     """`instances` independent Stereo::Effect objects of one patch (PingPong.k / Reverb.k)."""
 
-    def __init__(self, patch, instances, fs=48000.0, max_block=256, initial_record=None, channels=2):
+    def __init__(self, patch, instances, fs=48000.0, max_block=256, initial_record=None, channels=2, device=None):
         self._L = lib()
         self._h = None
         self.channels = 2
+        if device is not None:
+            ids = (C.c_int * 1)(int(device))
+            check(self._L.klg_init(ids, 1), "klg_init")
         if isinstance(patch, str) and patch.lstrip().startswith("klgg"):       # a recorded Effect::process() body (`kind effect`)
             rec = None if initial_record is None else np.ascontiguousarray(initial_record, dtype=np.uint32)
             h = self._L.klg_fx_create_graph(patch.encode(), int(instances), float(fs), int(max_block), rec.ctypes.data_as(C.c_void_p) if rec is not None else None)

@@ -5,7 +5,7 @@ of the [2][n] stereo block per step, and only when the bank spans more than one 
 The renderer is injectable (`bank_factory`) so the partition / event-routing / reduce logic can be exercised on CPU
 with the gloo backend (tests/test_sharding_gloo.py); the product default is the HIP SynthBank.
 """
-from .bank import SynthBank
+from .bank import FxBank, SynthBank
 
 
 def shard_range(n_items, world, rank):
@@ -80,6 +80,46 @@ class ShardedSynthBank:
                     return dist.all_reduce(mix, async_op=True)
                 dist.all_reduce(mix)
         return None
+
+    def close(self):
+        self.bank.close()
+
+
+class ShardedFxBank:
+    """SURVEY.md §8e for effect banks: instances are independent (one Stereo::Effect object each in the reference), so they shard BY INSTANCE over the
+    ranks — contiguous ranges, like the synths above — and there is NO collective on the data path: a rank processes the rows of the caller's block that
+    belong to its instances and nobody else's.  Dials go to the rank that owns the instance.  (Inside one process the library shards a bank over the GPUs
+    of klg_init itself; this is the one-process-per-GPU form.)"""
+
+    def __init__(self, patch, instances, fs=48000.0, max_block=256, rank=0, world=1, device=None, bank_factory=None, **kw):
+        self.rank, self.world, self.instances = rank, world, instances
+        self.lo, self.hi = shard_range(instances, world, rank)
+        if self.hi <= self.lo:
+            raise ValueError(f"rank {rank} of {world} owns no effect instance (instances={instances})")
+        factory = bank_factory or (lambda *a, **k: FxBank(*a, device=device, **k))
+        self.bank = factory(patch, self.hi - self.lo, fs=fs, max_block=max_block, **kw)
+
+    def owns(self, instance):
+        return self.lo <= instance < self.hi
+
+    def set_control(self, instance, index, value):
+        if self.owns(instance):
+            self.bank.set_control(instance - self.lo, index, value)
+
+    def get_control(self, instance, index):
+        """The control as the owning rank's effect left it; None on the other ranks."""
+        return self.bank.get_control(instance - self.lo, index) if self.owns(instance) else None
+
+    def local(self, io):
+        """This rank's rows of a global [instances][channels][n] block (a view: processing it in place processes the caller's block)."""
+        return io[self.lo:self.hi]
+
+    def process(self, local_io):
+        """local_io: float32 [hi - lo][channels][n] — this rank's instances, processed in place (host buffers, synchronous)."""
+        return self.bank.process(local_io)
+
+    def process_device(self, d_local_io_ptr, n, stream=None):
+        return self.bank.process_device(d_local_io_ptr, n, stream)
 
     def close(self):
         self.bank.close()

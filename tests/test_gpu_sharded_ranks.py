@@ -102,3 +102,62 @@ def test_bench_py_two_ranks_end_to_end():
     assert out["config"]["voices_alive_after_last_block"] == out["config"]["voices_alive_expected"]
     assert out["config"]["mix_checksum"] > 0
     assert "all-reduce" in out["config"]["parallelism"]
+
+
+FX_RANK = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import klang_amd
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+two = torch.cuda.device_count() >= 2
+dev = rank if two else 0
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo")                                 # (only for the rendezvous and the final barrier: the effect path has no collective)
+K, N, B = 37, 256, 10                                           # 37 instances: 19 + 18
+bank = klang_amd.ShardedFxBank(%(patch)r, K, max_block=N, rank=rank, world=world, device=dev)
+rng = np.random.default_rng(23)
+dials = [(int(rng.integers(0, B)), int(rng.integers(0, K)), int(rng.integers(0, 3)), float(rng.uniform(.1, .9))) for _ in range(30)]
+out = np.zeros((B, bank.hi - bank.lo, 2, N), np.float32)
+ts = torch.cuda.Stream()
+with torch.cuda.stream(ts):
+    for b in range(B):
+        for (at, k, i, v) in dials:
+            if at == b: bank.set_control(k, i, v)
+        io = (rng.random((K, 2, N), dtype=np.float32) - 0.5).astype(np.float32)
+        d = torch.from_numpy(np.ascontiguousarray(bank.local(io))).cuda()
+        bank.process_device(d.data_ptr(), N, ts.cuda_stream)
+        ts.synchronize()
+        out[b] = d.cpu().numpy()
+np.save(sys.argv[1] + f".{rank}.npy", out)
+dist.barrier(); bank.close(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("patch", ["pingpong", "reverb"])
+def test_two_ranks_of_effect_instances_equal_one_bank(patch, tmp_path):
+    """SURVEY §8e for the effect banks: instances split 19 + 18 over two ranks, no collective; row for row the two ranks' output is the one bank's, bit for bit."""
+    import klang_amd
+    script = tmp_path / "fx_rank.py"
+    script.write_text(FX_RANK % {"root": ROOT, "patch": patch})
+    res = tmp_path / "fx"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29578",
+                        str(script), str(res)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.concatenate([np.load(f"{res}.{rk}.npy") for rk in range(2)], axis=1)
+    K, N, B = 37, 256, 10
+    bank = klang_amd.FxBank(patch, K, max_block=N)
+    rng = np.random.default_rng(23)
+    dials = [(int(rng.integers(0, B)), int(rng.integers(0, K)), int(rng.integers(0, 3)), float(rng.uniform(.1, .9))) for _ in range(30)]
+    for b in range(B):
+        for (at, k, i, v) in dials:
+            if at == b:
+                bank.set_control(k, i, v)
+        io = (rng.random((K, 2, N), dtype=np.float32) - 0.5).astype(np.float32)
+        bank.process(io)
+        assert np.array_equal(got[b].view(np.uint32), io.view(np.uint32)), (patch, b)
+    assert float(np.abs(got).max()) > 0.05
+    bank.close()
