@@ -224,9 +224,13 @@ int klg_synth_voices_per_lane(const klg_synth* s);
  * [instances][channels][n]. */
 klg_fx* klg_fx_create_graph(const char* program, int instances, float sample_rate, int max_block, const void* initial_record);
 
-/* Measurement hooks used by bench.py: timing of the render kernel with HIP events recorded on the
- * stream the kernel is launched on.  klg_timing_begin() arms it, klg_timing_end() returns the number of
- * render launches since begin and their summed duration in milliseconds. */
+/* Measurement hooks used by bench.py: timing of the render kernel with a pair of HIP events per launch, on the
+ * stream the kernel is launched on, ATTACHED TO THE DISPATCH (hipExtLaunchKernelGGL / hipExtModuleLaunchKernel:
+ * the kernel's own start and end, what rocprofv3's kernel trace reports — events recorded around the launch add
+ * 2 - 3 us of dispatch latency, which is nothing on a 0.38 ms launch and 15 % of a 17 us one).  klg_timing_begin()
+ * arms it, klg_timing_end() returns the number of render launches since begin and their summed duration in
+ * milliseconds.  klg_fx_timing_*: the same for an effect bank's kernel; a Reverb block is two kernels (the early
+ * sums of the block, klg_fx_reverb_q) and is timed by events recorded around the pair. */
 int klg_timing_begin(klg_synth* s);
 int klg_timing_end(klg_synth* s, int* launches, float* total_ms);
 

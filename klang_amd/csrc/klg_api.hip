@@ -4,6 +4,7 @@
 // controls, the patches' on()/off() code and event dispatch — all on the CPU, as in the reference.
 // Device side (klg_kernels.hpp): everything per sample.  There is no CPU rendering path.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <dlfcn.h>
 
@@ -21,6 +22,25 @@
 #include "klg_fx.hpp"
 #include "klg_render_x2.hpp"
 #include "klg_render_lanes.hpp"
+
+// Kernel timing (klg_timing_* / klg_fx_timing_*): the dominant kernel of a call is launched with its two events ATTACHED TO THE DISPATCH
+// (hipExtLaunchKernelGGL / hipExtModuleLaunchKernel): they hold the kernel's own start and end, what rocprofv3's kernel trace reads.  Events recorded
+// around the launch on the stream add the dispatch latency and the marker's completion — 2 - 3 us, which is 15 % of a 17 us PingPong block and made
+// a 1,024-voice bank's "kernel time" longer than its whole step.  Outside timing the two are null and the launch is an ordinary one.
+static thread_local hipEvent_t g_time0 = nullptr, g_time1 = nullptr;
+#define KLG_LAUNCH(kernel, grid, block, lds, st, ...) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, g_time0, g_time1, 0, __VA_ARGS__)
+static hipError_t klg_module_launch(hipFunction_t fn, unsigned groups, unsigned threads, unsigned lds, hipStream_t st, void** params) {
+	if (!g_time0) return hipModuleLaunchKernel(fn, groups, 1, 1, threads, 1, 1, lds, st, params, nullptr);
+	return hipExtModuleLaunchKernel(fn, groups * threads, 1, 1, threads, 1, 1, lds, st, params, nullptr, g_time0, g_time1, 0);
+}
+struct TimedLaunch {                                                // binds a handle's next pair of events to the launches made in its scope
+	template<class H> explicit TimedLaunch(H* h) {
+		if (!h->timing) return;
+		if ((int)h->tev.size() < 2 * (h->launches + 1)) { hipEvent_t e0 = nullptr, e1 = nullptr; if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return; h->tev.push_back(e0); h->tev.push_back(e1); }
+		g_time0 = h->tev[2 * h->launches]; g_time1 = h->tev[2 * h->launches + 1]; h->launches++;
+	}
+	~TimedLaunch() { g_time0 = g_time1 = nullptr; }
+};
 
 #pragma clang fp contract(off)
 
@@ -457,8 +477,8 @@ extern "C" size_t klg_synth_state_bytes(const klg_synth* s) { return s ? (size_t
 // kernel dispatch by patch
 // ------------------------------------------------------------------------------------------------
 template<class P> static void launch_render_t(klg_synth* s, const RenderArgs& a, bool pv, hipStream_t st) {
-	if (pv) hipLaunchKernelGGL((klg_render<P, true>), dim3(s->grid), dim3(WG), render_lds_bytes(a.n), st, a);
-	else hipLaunchKernelGGL((klg_render<P, false>), dim3(s->grid), dim3(WG), render_lds_bytes(a.n), st, a);
+	if (pv) KLG_LAUNCH((klg_render<P, true>), dim3(s->grid), dim3(WG), render_lds_bytes(a.n), st, a);
+	else KLG_LAUNCH((klg_render<P, false>), dim3(s->grid), dim3(WG), render_lds_bytes(a.n), st, a);
 }
 static int render_grid(const klg_synth* s) {      // workgroups (= partial rows) of the render launch
 	if (s->lanes) return s->grid_lanes;
@@ -469,32 +489,32 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 	if (s->graph) {                                       // hipRTC code object: klg_render<PatchGen, pv>
 		RenderArgs args = a;
 		void* params[] = { &args };
-		s->launch_error = hipModuleLaunchKernel(s->graph_fn[pv ? 1 : 0], (unsigned)render_grid(s), 1, 1, WG, 1, 1, render_lds_bytes(a.n, s->note_ch), st, params, nullptr);
+		s->launch_error = klg_module_launch(s->graph_fn[pv ? 1 : 0], (unsigned)render_grid(s), WG, (unsigned)render_lds_bytes(a.n, s->note_ch), st, params);
 		return;
 	}
 	if (s->patch == KLG_PATCH_SUB2A && s->x2) {           // two voices per lane, packed fp32 (klg_render_x2.hpp)
 		const dim3 g(render_grid(s)), b(WG);
-		if (pv) hipLaunchKernelGGL(klg_render_sub2a_x2<true>, g, b, render_lds_bytes(a.n), st, a);
-		else hipLaunchKernelGGL(klg_render_sub2a_x2<false>, g, b, render_lds_bytes(a.n), st, a);
+		if (pv) KLG_LAUNCH(klg_render_sub2a_x2<true>, g, b, render_lds_bytes(a.n), st, a);
+		else KLG_LAUNCH(klg_render_sub2a_x2<false>, g, b, render_lds_bytes(a.n), st, a);
 		return;
 	}
 	if (s->pairs) {                                       // SuperSaw, an oscillator pair per lane (small banks)
 		const dim3 g(render_grid(s)), b(WG);
 		const size_t lds = render_lds_bytes(a.n);
 		switch (s->pairs_p * 2 + (pv ? 1 : 0)) {
-		case 2: hipLaunchKernelGGL((klg_render_supersaw_pairs<1, false>), g, b, lds, st, a); break;
-		case 3: hipLaunchKernelGGL((klg_render_supersaw_pairs<1, true>), g, b, lds, st, a); break;
-		case 4: hipLaunchKernelGGL((klg_render_supersaw_pairs<2, false>), g, b, lds, st, a); break;
-		case 5: hipLaunchKernelGGL((klg_render_supersaw_pairs<2, true>), g, b, lds, st, a); break;
-		case 8: hipLaunchKernelGGL((klg_render_supersaw_pairs<4, false>), g, b, lds, st, a); break;
-		default: hipLaunchKernelGGL((klg_render_supersaw_pairs<4, true>), g, b, lds, st, a); break;
+		case 2: KLG_LAUNCH((klg_render_supersaw_pairs<1, false>), g, b, lds, st, a); break;
+		case 3: KLG_LAUNCH((klg_render_supersaw_pairs<1, true>), g, b, lds, st, a); break;
+		case 4: KLG_LAUNCH((klg_render_supersaw_pairs<2, false>), g, b, lds, st, a); break;
+		case 5: KLG_LAUNCH((klg_render_supersaw_pairs<2, true>), g, b, lds, st, a); break;
+		case 8: KLG_LAUNCH((klg_render_supersaw_pairs<4, false>), g, b, lds, st, a); break;
+		default: KLG_LAUNCH((klg_render_supersaw_pairs<4, true>), g, b, lds, st, a); break;
 		}
 		return;
 	}
 	if (s->lanes) {                                       // SuperSaw, one oscillator per lane (KLG_SUPERSAW_LANES=1)
 		const dim3 g(render_grid(s)), b(WG);
-		if (pv) hipLaunchKernelGGL(klg_render_supersaw_lanes<true>, g, b, render_lds_bytes(a.n), st, a);
-		else hipLaunchKernelGGL(klg_render_supersaw_lanes<false>, g, b, render_lds_bytes(a.n), st, a);
+		if (pv) KLG_LAUNCH(klg_render_supersaw_lanes<true>, g, b, render_lds_bytes(a.n), st, a);
+		else KLG_LAUNCH(klg_render_supersaw_lanes<false>, g, b, render_lds_bytes(a.n), st, a);
 		return;
 	}
 	switch (s->patch) {
@@ -858,13 +878,8 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 		hipLaunchKernelGGL(klg_select_last_active, dim3((s->S + 255) / 256), dim3(256), 0, st, (const uint32_t*)s->d_state, s->S, s->P, s->d_solo);
 		a.solo = s->d_solo;
 	}
-	if (s->timing) {
-		if ((int)s->tev.size() < 2 * (s->launches + 1)) { hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); s->tev.push_back(e0); s->tev.push_back(e1); }
-		HIP_TRY(hipEventRecord(s->tev[2 * s->launches], st));
-	}
-	launch_render(s, a, per_voice, st);
+	{ TimedLaunch timed(s); launch_render(s, a, per_voice, st); }
 	if (s->launch_error != hipSuccess) { const hipError_t e = s->launch_error; s->launch_error = hipSuccess; return fail(KLG_ERR_HIP, "launching the compiled graph patch failed: %s", hipGetErrorString(e)); }
-	if (s->timing) { HIP_TRY(hipEventRecord(s->tev[2 * s->launches + 1], st)); s->launches++; }
 	if (a.ticket) {}                                                 // (the render launch's last workgroup added the rows)
 	else if (s->note_ch == 2) hipLaunchKernelGGL(klg_reduce_stereo, dim3((n + 31) / 32, 2), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
 	else hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);

@@ -385,10 +385,6 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		HIP_TRY(hipStreamSynchronize(st));
 		f->controls_dirty = false;
 	}
-	if (f->timing) {
-		if ((int)f->tev.size() < 2 * (f->launches + 1)) { hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); f->tev.push_back(e0); f->tev.push_back(e1); }
-		HIP_TRY(hipEventRecord(f->tev[2 * f->launches], st));
-	}
 	FxGraphArgs a;
 	a.state = (uint32_t*)f->d_state; a.kpad = f->kpad; a.K = f->K; a.rings = f->d_rings; a.ring_rows = (size_t)f->graph->ring_rows;
 	a.io = d_io; a.n = n; a.controls = f->d_controls;
@@ -413,9 +409,8 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		a.rand = f->d_rand[slot]; a.rand_per_instance = (int)per;
 	}
 	void* params[] = { &a };
-	HIP_TRY(hipModuleLaunchKernel(f->graph_fn, (unsigned)(f->kpad / FX_WG), 1, 1, FX_WG, 1, 1, 0, st, params, nullptr));
+	{ TimedLaunch timed(f); HIP_TRY(klg_module_launch(f->graph_fn, (unsigned)(f->kpad / FX_WG), FX_WG, 0, st, params)); }
 	if (slot >= 0) HIP_TRY(hipEventRecord(f->rand_done[slot], st));
-	if (f->timing) { HIP_TRY(hipEventRecord(f->tev[2 * f->launches + 1], st)); f->launches++; }
 	f->samples += (unsigned long long)n;
 	return 0;
 }
@@ -428,12 +423,16 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		f->rv_touched.clear();
 	}
 	if (int rc = fx_flush_updates(f, st)) return rc;
-	if (f->timing) {
+	// kernel timing: PingPong is one launch, timed by events attached to its dispatch; a Reverb block is the early-sum kernel and klg_fx_reverb_q
+	// (the pair is what a block costs): events recorded around both on the stream
+	const bool bracket = f->timing && f->patch != KLG_PATCH_PINGPONG;
+	if (bracket) {
 		if ((int)f->tev.size() < 2 * (f->launches + 1)) { hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); f->tev.push_back(e0); f->tev.push_back(e1); }
 		HIP_TRY(hipEventRecord(f->tev[2 * f->launches], st));
 	}
 	const dim3 grid((unsigned)(f->kpad / FX_WG)), block(FX_WG);
 	if (f->patch == KLG_PATCH_PINGPONG) {
+		TimedLaunch timed(f);
 		PingPongArgs a;
 		a.state = f->d_state; a.kpad = f->kpad; a.K = f->K; a.rings = f->d_rings;
 		a.position = (int)(f->samples % 192000ull);
@@ -443,16 +442,16 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		static const int ablate = []() { const char* e = getenv("KLG_FX_ABLATE"); return e ? atoi(e) : 0; }();
 		a.ablate = ablate;
 		static const bool single_wave = []() { const char* e = getenv("KLG_FX_PINGPONG1"); return e && e[0] == '1'; }();
-		if (single_wave || a.ablate) hipLaunchKernelGGL(klg_fx_pingpong, grid, block, 0, st, a);   // one wave per 64 instances (A/B reference, ablation)
+		if (single_wave || a.ablate) KLG_LAUNCH(klg_fx_pingpong, grid, block, 0, st, a);   // one wave per 64 instances (A/B reference, ablation)
 		// the pipeline's time is a workgroup's instruction count on its one CU: a quarter / a half of a ring group per workgroup while
 		// the bank does not fill the chip that way either (klg_fx_pingpong_x<G>; KLG_FX_PINGPONG_G = 16 / 32 / 64 forces the width)
 		else {
 			const char* const forced_env = getenv("KLG_FX_PINGPONG_G");                 // (read per launch: the tests switch it)
 			const int forced = forced_env ? atoi(forced_env) : 0;
 			const int G = forced == 16 || forced == 32 || forced == 64 ? forced : (f->kpad <= 4096 ? 16 : f->kpad <= 8192 ? 32 : 64);
-			if (G == 16) hipLaunchKernelGGL(klg_fx_pingpong_x<16>, dim3((unsigned)(f->kpad / 16)), dim3(PPX_THREADS), 0, st, a);
-			else if (G == 32) hipLaunchKernelGGL(klg_fx_pingpong_x<32>, dim3((unsigned)(f->kpad / 32)), dim3(PPX_THREADS), 0, st, a);
-			else hipLaunchKernelGGL(klg_fx_pingpong_x<64>, grid, dim3(PPX_THREADS), 0, st, a);   // control / audio / filter pipeline over eleven waves
+			if (G == 16) KLG_LAUNCH(klg_fx_pingpong_x<16>, dim3((unsigned)(f->kpad / 16)), dim3(PPX_THREADS), 0, st, a);
+			else if (G == 32) KLG_LAUNCH(klg_fx_pingpong_x<32>, dim3((unsigned)(f->kpad / 32)), dim3(PPX_THREADS), 0, st, a);
+			else KLG_LAUNCH(klg_fx_pingpong_x<64>, grid, dim3(PPX_THREADS), 0, st, a);   // control / audio / filter pipeline over eleven waves
 		}
 	}
 	else {
@@ -506,7 +505,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances (KLG_FX_REVERB16=1)
 	}
 	HIP_TRY(hipGetLastError());
-	if (f->timing) { HIP_TRY(hipEventRecord(f->tev[2 * f->launches + 1], st)); f->launches++; }
+	if (bracket) { HIP_TRY(hipEventRecord(f->tev[2 * f->launches + 1], st)); f->launches++; }
 	f->samples += (unsigned long long)n;
 	return 0;
 }

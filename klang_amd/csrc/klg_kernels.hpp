@@ -113,6 +113,7 @@ template<class P> struct IsStereo<P, klg_void_t<decltype(P::kStereo)>> { static 
 // ---- the fused launch (RenderArgs::ev / ticket) ----
 // (1) events: group g of `voices_per_group` voices is rendered by workgroup g % gridDim.x; that workgroup applies the runs of those voices first.
 //     A workgroup's stores are seen by its own later loads (one CU, one L1, __syncthreads() between them); no other workgroup touches these records.
+template<class P> __device__ __forceinline__ void apply_event_run(const EventArgs& a, int r);
 template<class P> __device__ __forceinline__ void fused_events(const RenderArgs& a, int voices_per_group) {
 	if (a.ev.runs == 0) return;
 	for (int r = threadIdx.x; r < a.ev.runs; r += blockDim.x) {

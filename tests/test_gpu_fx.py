@@ -247,6 +247,36 @@ def test_pingpong_with_stationary_controls(oracle_build, block, width, monkeypat
     assert np.abs(got[-1]).max() > 1e-3
 
 
+@pytest.mark.parametrize("block,width", [(256, 0), (256, 16), (128, 32), (256, 64), (192, 16), (512, 64), (96, 32)])
+def test_pingpong_with_moving_dials(oracle_build, block, width, monkeypatch):
+    """Dials under automation: controls[1] / controls[5] of some instance move every few blocks, so the smoothers never settle and every block runs
+    klg_fx_pingpong_x's general pipeline (control chain one chunk ahead; whole and ragged last chunks; blocks of 3 .. 16 chunks).  A dial sent to 2 ms
+    brings near taps (a chunk walked in order by one wave) for as long as the smoothed delay is that short, a dial-5 move sets off the scratch detector
+    (controls[1].set, LFO reset) inside the chain.  70 instances (the second workgroup of every width is partly padding), EVERY block compared with
+    the oracle bit for bit.  (Written for a request-ahead variant of this path — control chain three chunks ahead, rows requested two steps early —
+    which passed it and was 4 % faster at 4,096 instances, 8 % slower at 16,384: not kept)"""
+    if width: monkeypatch.setenv("KLG_FX_PINGPONG_G", str(width))
+    B = 15360 // block
+    s = Scenario(patch="pingpong", block=block, blocks=B, instances=70, burst=15360, seed=5, dump=list(range(B)))
+    rng = np.random.default_rng(21)
+    for k in range(70):
+        s.control(0, k, 0, float(rng.uniform(0.2, 0.9)))
+        s.control(0, k, 1, float(rng.uniform(0.03, 0.6)))
+        s.control(0, k, 5, float(rng.uniform(0.03, 0.6)))
+        s.control(0, k, 4, float(rng.uniform(0.3, 1.0)))
+    for b in range(1, B):
+        for _ in range(3):
+            s.control(b, int(rng.integers(0, 70)), int(rng.choice([1, 5])), float(rng.uniform(0.03, 0.6)))
+    s.control(B // 3, 66, 1, 0.002); s.control(B // 3, 66, 5, 0.002)         # towards 2 ms: near taps in the second workgroup ...
+    s.control(2 * B // 3, 66, 1, 0.3); s.control(2 * B // 3, 66, 5, 0.3)     # ... and away again
+    s.sort()
+    got = run_fx_scenario_gpu(s)["per_voice"]
+    ref = run_scenario_oracle(s, oracle_build)["per_voice"]
+    bad = [b for b in range(B) if not np.array_equal(got[b].view(np.uint32), ref[b].view(np.uint32))]
+    assert not bad, f"blocks {bad[:8]} differ, max abs err {np.abs(got - ref).max()}"
+    assert np.abs(got[-1]).max() > 1e-3
+
+
 def test_record_download_and_word_upload():
     """klg_fx_download_record / klg_fx_upload_words (what a host-run prepare() uses, include/klang/klang.h EffectBank::host_prepare): a record comes back
     as the device last left it — the dials just set, state a block has changed — and uploaded words are what the next block starts from.  Instances

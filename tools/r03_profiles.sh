@@ -8,6 +8,10 @@ python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 KLG_BENCH_PMC=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-configs > $O/bench_profiled.json 2> $O/bench_profiled.err
 python $R/tools/kernel_summary.py $O/stats klg_render_sub2a_x2 375 20 375 > $O/kernel_summary.json 2>> $O/bench_profiled.err
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
+# every config's leg under the kernel trace: rocprofv3's average per kernel beside the legs' kernel_ms_mean (dispatch-attached HIP events) — they must agree
+KLG_BENCH_PMC=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_legs -- python $R/bench.py --no-cpu-baseline > $O/bench_legs_profiled.json 2> $O/bench_legs_profiled.err
+cp $(find $O/stats_legs -name "*kernel_stats.csv" | head -1) $O/bench_legs_kernel_stats.csv 2>/dev/null
+rm -rf $O/stats_legs
 python $R/tools/bench_all.py --cpu-budget 2 > $O/bench_all.json 2> $O/bench_all.err
 python $R/tools/fx_ablate.py > $O/fx_sizes.jsonl 2>&1
 python $R/tools/pingpong_steady.py > $O/pingpong_steady.jsonl 2>&1
