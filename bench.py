@@ -341,11 +341,15 @@ def run_literal_script(patch, voices, N, label, phases=False):
     return res
 
 
-def run_fx(patch, K, N):
-    """cfg 4: K instances, 375 blocks (2 s): a white-noise burst for the first 4800 samples, then silence; io resident in HBM"""
+def run_fx(patch, K, N, dials=None, tag=""):
+    """cfg 4: K instances, 375 blocks (2 s): a white-noise burst for the first 4800 samples, then silence; io resident in HBM.
+    dials: {index: value} set on every instance before the first block (default: the patch's own initial values)"""
     import torch
     import klang_amd
     bank = klang_amd.FxBank(patch, K, max_block=N)
+    for c, v in (dials or {}).items():
+        for k in range(K):
+            bank.set_control(k, c, v)
     g = torch.Generator(device="cuda").manual_seed(1)
     burst_blocks = (4800 + N - 1) // N
     inputs = torch.rand((burst_blocks, K, 2, N), device="cuda", generator=g) - 0.5
@@ -371,7 +375,7 @@ def run_fx(patch, K, N):
     launches, kms = bank.timing_end()
     kern_s = 1e-3 * kms / launches
     ab = K * N * FX_BYTES_PER_SAMPLE[patch]
-    res = {"name": f"cfg4_{patch}_{K}", "workload": f"{K} x {patch.capitalize()}.k (Stereo::Effect), {SCRIPT_BLOCKS} blocks of {N} samples: noise burst 4800 samples then silence, io + {bank.state_bytes * K / 1e9:.1f} GB of delay lines resident in HBM",
+    res = {"name": f"cfg4_{patch}_{K}{tag}", "workload": (f"dials {dials}: " if dials else "") + f"{K} x {patch.capitalize()}.k (Stereo::Effect), {SCRIPT_BLOCKS} blocks of {N} samples: noise burst 4800 samples then silence, io + {bank.state_bytes * K / 1e9:.1f} GB of delay lines resident in HBM",
            "value": K * N * SCRIPT_BLOCKS / dt, "unit": "instance*samples/s", "ms_per_step": 1e3 * dt / SCRIPT_BLOCKS, "steps": SCRIPT_BLOCKS, "kernel_ms_mean": 1e3 * kern_s,
            "finite": bool(torch.isfinite(io).all().item()),
            "roofline": {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -632,6 +636,7 @@ def main():
             leg(run_literal_script, "supersaw", 16384, N, "cfg3_16384_supersaw_voices")
             leg(run_fx, "pingpong", 4096, N)
             leg(run_fx, "reverb", 4096, N)
+            leg(run_fx, "pingpong", 4096, N, dials={2: 0.5, 3: 0.5}, tag="_vibrato")    # Scratch / Rate up (six of PingPong.k's eight presets have them up): the LFO's fp64 sine and a controls[1].set() per sample
             leg(run_fx, "pingpong", 65536, N)                             # the same patch at bank scale: where config 4 meets north_star's "≥ 40 % of the HBM roofline" (100 GB of delay lines)
             leg(run_literal_script, "fm4", 131072, N, "cfg5_share_131072_fm4_voices")
             leg(run_realtime, "sub2a", args.realtime_voices, N)

@@ -262,6 +262,7 @@ template<int G> struct PpxLds {
 	float D[2][PPX_CHUNK][G];                   // delay time (smoothed controls[1]) per sample, [chunk & 1]
 	int far[2];                                 // 1: every tap of the chunk is far from the write cursor
 	int deep;                                   // the block runs the request-ahead pipeline (see PPX_DEEP below)
+	float ph[G < 64 ? PPX_CHUNK : 1][G], sn[G < 64 ? PPX_CHUNK : 1][G];   // vibrato: the LFO's phases of the chunk and their sines (control wave, G < 64)
 };
 
 // G = instances per workgroup: 64 (a whole ring group: banks that fill the chip on their own), or 32 / 16 — a half / a quarter of a
@@ -588,24 +589,70 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				if (ncl == PPX_CHUNK) chain(PPX_CHUNK); else chain(ncl);              // (a whole chunk: a constant trip count)
 				lfo.position = pos;
 			}
-			else
+			else {
+				auto vibrato_serial = [&](int u) {
 #pragma unroll 4
-			for (int u = 0; u < ncl; u++) {
-				sm5 = sm5 * 0.999f + (1.f - 0.999f) * c5;                           // controls[5].smooth()  klang.h:1715
-				const float new_delay = sm5;
-				if (fabsf(mdelay - new_delay) >= 0.001f) {
-					mdelay = new_delay;
-					c1 = (new_delay < a.c1_min) ? a.c1_min : (a.c1_max < new_delay) ? a.c1_max : new_delay;   // controls[1].set()
-					lfo.position = KLG_PI_F;                                        // lfo.set(rate, pi)
+					for (; u < ncl; u++) {
+						sm5 = sm5 * 0.999f + (1.f - 0.999f) * c5;                           // controls[5].smooth()  klang.h:1715
+						const float new_delay = sm5;
+						if (fabsf(mdelay - new_delay) >= 0.001f) {
+							mdelay = new_delay;
+							c1 = (new_delay < a.c1_min) ? a.c1_min : (a.c1_max < new_delay) ? a.c1_max : new_delay;   // controls[1].set()
+							lfo.position = KLG_PI_F;                                        // lfo.set(rate, pi)
+						}
+						else mdelay = c5;
+						sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                           // controls[1].smooth()
+						const float delay = sm1;
+						const float lfo_out = basic_sine(lfo);                              // fp64 sin
+						const float nc1 = c1 + lfo_out * vibrato * 0.00005f;
+						c1 = (nc1 < a.c1_min) ? a.c1_min : (a.c1_max < nc1) ? a.c1_max : nc1;
+						D[u][li] = delay;
+						dmin = fminf(dmin, delay); dmax = fmaxf(dmax, delay);
+					}
+				};
+				if constexpr (G < 64) {
+					// The LFO's fp64 sine is most of this chain (~450 of a sample's ~640 cycles), and it depends on nothing but the LFO's phase, which only the
+					// scratch detector disturbs.  The control wave has 64 / G lanes per instance: the chunk's phases are walked first (three operations a
+					// sample), the sines are then taken 64 / G samples at a time side by side in the lanes, and the chain reads them from LDS.  A sample
+					// in which any instance's detector fires ends this: from there on the chunk is walked the plain way, every instance from its true phase.
+					constexpr int SLOTS = 64 / G;
+					const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);                          // Phase::operator+= klang.h:1518-1525
+					float pos = lfo.position;
+					for (int u = 0; u < ncl; u++) {
+						S.ph[u][li] = pos;                                                  // (the lanes of an instance hold the same state: they store the same value)
+						const float p1 = pos + lfo_inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
+						pos = inc_ok ? p2 : pos;
+					}
+					wave_sync();
+#pragma unroll
+					for (int u = lq; u < PPX_CHUNK; u += SLOTS) if (u < ncl) S.sn[u][li] = (float)sin_f64((double)(S.ph[u][li] + lfo.offset));   // Basic::Sine klang.h:4902
+					wave_sync();
+					// the chain, eight samples at a time without a branch: whether a detector fired is collected and looked at once per eight — if one did,
+					// the eight are walked again the plain way from the state they started with
+					int u = 0;
+					for (; u + 8 <= ncl; u += 8) {
+						float sv[8];
+#pragma unroll
+						for (int i = 0; i < 8; i++) sv[i] = S.sn[u + i][li] * vibrato * 0.00005f;
+						const float sm5_0 = sm5, mdelay_0 = mdelay, sm1_0 = sm1, c1_0 = c1, dmin_0 = dmin, dmax_0 = dmax;
+						bool fired = false;
+#pragma unroll
+						for (int i = 0; i < 8; i++) {
+							sm5 = sm5 * 0.999f + (1.f - 0.999f) * c5;                       // controls[5].smooth()  klang.h:1715
+							fired = fired || (fabsf(mdelay - sm5) >= 0.001f);              // the scratch detector
+							mdelay = c5;
+							sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                       // controls[1].smooth()
+							const float nc1 = c1 + sv[i];
+							c1 = __builtin_amdgcn_fmed3f(nc1, a.c1_min, a.c1_max);          // controls[1].set(): the clamp is the median of (x, min, max)
+							D[u + i][li] = sm1;
+							dmin = fminf(dmin, sm1); dmax = fmaxf(dmax, sm1);
+						}
+						if (__ballot(fired) != 0ull) { sm5 = sm5_0; mdelay = mdelay_0; sm1 = sm1_0; c1 = c1_0; dmin = dmin_0; dmax = dmax_0; break; }
+					}
+					lfo.position = (u < ncl) ? S.ph[u][li] : pos;
+					if (u < ncl) vibrato_serial(u);
 				}
-				else mdelay = c5;
-				sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                           // controls[1].smooth()
-				const float delay = sm1;
-				const float lfo_out = basic_sine(lfo);                              // fp64 sin
-				const float nc1 = c1 + lfo_out * vibrato * 0.00005f;
-				c1 = (nc1 < a.c1_min) ? a.c1_min : (a.c1_max < nc1) ? a.c1_max : nc1;
-				D[u][li] = delay;
-				dmin = fminf(dmin, delay); dmax = fmaxf(dmax, delay);
+				else vibrato_serial(0);
 			}
 			// x -> 0.5f * x * fs and x -> x * fs are monotonic, so the extreme delays decide for the whole chunk
 			if (!stationary || jn < 2) {

@@ -277,6 +277,34 @@ def test_pingpong_with_moving_dials(oracle_build, block, width, monkeypatch):
     assert np.abs(got[-1]).max() > 1e-3
 
 
+@pytest.mark.parametrize("block,width", [(256, 0), (256, 16), (192, 32), (256, 64), (80, 16)])
+def test_pingpong_vibrato_with_the_scratch_detector_firing(oracle_build, block, width, monkeypatch):
+    """Vibrato on (controls[2], controls[3] > 0): every sample takes the LFO's fp64 sine and writes controls[1].  With fewer than 64 instances per
+    workgroup the control wave walks a chunk's LFO phases first, takes the sines several samples at a time in its spare lanes and reads them back in
+    the chain; a controls[5] move sets off the scratch detector (`lfo.set(rate, pi)`) for some ten thousand samples, during which the chunk is walked
+    the plain way from the first firing sample on.  Some instances without vibrato in the same workgroup, blocks that are not whole chunks (80), the
+    single-slot width (64: the plain chain only); every block against the oracle, bit for bit."""
+    if width: monkeypatch.setenv("KLG_FX_PINGPONG_G", str(width))
+    B = 12288 // block
+    s = Scenario(patch="pingpong", block=block, blocks=B, instances=40, burst=12288, seed=9, dump=list(range(B)))
+    rng = np.random.default_rng(33)
+    for k in range(40):
+        s.control(0, k, 0, float(rng.uniform(0.2, 0.9)))
+        s.control(0, k, 1, float(rng.uniform(0.05, 0.6)))
+        s.control(0, k, 2, 0.0 if k % 5 == 4 else float(rng.uniform(0.1, 1.0)))
+        s.control(0, k, 3, float(rng.uniform(0.05, 1.0)))
+        s.control(0, k, 5, float(rng.uniform(0.05, 0.6)))
+    for b in (B // 4, B // 2, B // 2 + 1, 3 * B // 4):
+        for k in range(b % 3, 40, 3):
+            s.control(b, k, 5, float(rng.uniform(0.05, 0.6)))
+    s.sort()
+    got = run_fx_scenario_gpu(s)["per_voice"]
+    ref = run_scenario_oracle(s, oracle_build)["per_voice"]
+    bad = [b for b in range(B) if not np.array_equal(got[b].view(np.uint32), ref[b].view(np.uint32))]
+    assert not bad, f"blocks {bad[:8]} differ, max abs err {np.abs(got - ref).max()}"
+    assert np.abs(got[-1]).max() > 1e-3
+
+
 def test_record_download_and_word_upload():
     """klg_fx_download_record / klg_fx_upload_words (what a host-run prepare() uses, include/klang/klang.h EffectBank::host_prepare): a record comes back
     as the device last left it — the dials just set, state a block has changed — and uploaded words are what the next block starts from.  Instances
