@@ -216,6 +216,11 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			break;
 		}
 	}
+	if (fx) {                                                         // an effect's dials are the block's (klg_fx_set_control uploads them before the launch): read once, not in every sample
+		bool used[KLG_MAX_CTL] = {};
+		for (const Op& o : g.ops) if ((o.code == OP_CTL || o.code == OP_SMOOTH) && ctlvar[o.imm & 7u] < 0 && o.imm < (unsigned)KLG_MAX_CTL) used[o.imm] = true;
+		for (unsigned i = 0; i < (unsigned)KLG_MAX_CTL; i++) if (used[i]) { live += fmt(" float ctl%u;", i); begin += fmt("\t\tL.ctl%u = c.ctl[%u];\n", i, i); }
+	}
 	live += " };\n";
 	std::map<int, uint32_t> const_of;                                    // single-assignment registers holding a literal
 	int if_depth = 0; std::vector<std::string> stop_at_end;
@@ -239,7 +244,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		const int k = (o.node >= 0 && o.node < (int)g.nodes.size()) ? g.nodes[(size_t)o.node] : -1;
 		switch (o.code) {
 		case OP_CONST: body += d + "kf<" + TF + fmt(">(0x%08xu);\n", o.imm); const_of[o.dst] = o.imm; break;
-		case OP_CTL: body += d + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d;\n", ctlvar[o.imm & 7u]) : fmt("ctl_read(c, %uu);\n", o.imm)); break;   // (a control the effect writes: its own copy)
+		case OP_CTL: body += d + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d;\n", ctlvar[o.imm & 7u]) : fx ? fmt("L.ctl%u;\n", o.imm) : fmt("ctl_read(c, %uu);\n", o.imm)); break;   // (a control the effect writes: its own copy)
 		case OP_SETCTL: body += d + "(" + a + fmt(" < u2f(0x%08xu)) ? u2f(0x%08xu) : (u2f(0x%08xu) < ", fbits(g.dials[o.imm & 7u].min), fbits(g.dials[o.imm & 7u].min), fbits(g.dials[o.imm & 7u].max)) + a + fmt(") ? u2f(0x%08xu) : ", fbits(g.dials[o.imm & 7u].max)) + a + ";\n\t\t" + n + fmt(" = r%d;\n", o.dst); break;   // Control::set klang.h:1725-1728
 		case OP_ABS: body += d + "__builtin_fabsf(" + a + ");\n"; break;
 		case OP_PARAM: body += d + n + ";\n"; break;
@@ -325,7 +330,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		case OP_DELAYIN: body += "\t\t{ const Ring q = " + ring(o.node) + "; q.wr(" + n + "pos, " + a + "); " + n + "pos = (" + n + fmt("pos + 1 == %d) ? 0 : ", g.arg(o.node)) + n + "pos + 1; }\n"; break;   // Delay::input klang.h:3396-3403
 		case OP_DELAYSET: body += "\t\t" + n + "t = delay_set(" + n + fmt("pos, %d, ", g.arg(o.node)) + a + ");\n"; break;   // Delay::set klang.h:3480-3489
 		case OP_DELAYTAP: body += d + (o.imm == 1u ? "delay_tap_int(" + ring(o.node) + ", " + n + "pos, (int)" + a + ");\n" : (o.imm == 2u ? "delay_tap_stereo(" : "delay_tap_float(") + ring(o.node) + ", " + n + "pos, " + a + ");\n"); break;   // imm 1: tap(int), klang.h:3405-3410
-		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 7u]) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
+		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 7u]) : fx ? fmt("L.ctl%u", o.imm) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";
 			body += d + "fsine_process(" + n + ", fsine_rel_offset(" + (o.a >= 0 ? a : std::string("0.f")) + ")) * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs) * " + n + "a);\n";
