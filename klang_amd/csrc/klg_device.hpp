@@ -165,25 +165,28 @@ __device__ __forceinline__ void phase_advance(float& value, float inc) {  // Pha
 // [-pi/4, pi/4] (Sun's k_sin.c / k_cos.c polynomials, with the quarter trick of k_cos.c) — under an ulp in double, like glibc's.  What counts is
 // the value ROUNDED TO FLOAT: equal to glibc's for every float of [0, 2 pi] (exhaustive, 105 M arguments) and for 2e8 random arguments up to
 // +-9,000 (tools/verify_sin_f64.c, on the host: IEEE double is IEEE double).  |x| >= 1e4, NaN: the library's.
-__device__ __forceinline__ double sin_f64(double x) {
-	if (!(__builtin_fabs(x) < 1.0e4)) return sin(x);
+__device__ __forceinline__ double sin_f64_core(double x) {                // |x| < 1e4 is the caller's business (straight-line code: several can be in flight side by side)
 	const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
 	const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
 	const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
 	double r = __builtin_fma(-fn, 1.57079632679489655800e+00, x);
 	r = __builtin_fma(-fn, 6.12323399573676603587e-17, r);
 	const int n = (int)fn;
+	// odd k: cos(r), even: sin(r).  Both kernels run the same four Horner steps on their coefficients 2..6 — taken per lane, once — and differ in their tails
+	const bool odd = (n & 1) != 0;
+	const double K2 = odd ? C2 : S2, K3 = odd ? C3 : S3, K4 = odd ? C4 : S4, K5 = odd ? C5 : S5, K6 = odd ? C6 : S6;
 	const double z = r * r, v = z * r;
-	const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-	const double s = r + v * (S1 + z * rs);
-	const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+	const double h = K2 + z * (K3 + z * (K4 + z * (K5 + z * K6)));          // k_sin.c's r; k_cos.c's C2 + z * (...)
+	const double s = r + v * (S1 + z * h);
+	const double rc = z * (C1 + z * h);
 	const uint32_t hi = (uint32_t)((unsigned long long)__double_as_longlong(__builtin_fabs(r)) >> 32);
 	const double qx = hi < 0x3FD33333u ? 0.0 : hi > 0x3fe90000u ? 0.28125 : __longlong_as_double((long long)((unsigned long long)(hi - 0x00200000u) << 32));
 	const double hz = 0.5 * z - qx, a = 1.0 - qx;
 	const double c = a - (hz - z * rc);
-	const double res = (n & 1) ? c : s;
+	const double res = odd ? c : s;
 	return (n & 2) ? -res : res;
 }
+__device__ __forceinline__ double sin_f64(double x) { return (__builtin_fabs(x) < 1.0e4) ? sin_f64_core(x) : sin(x); }
 __device__ __forceinline__ float basic_sine(BOsc& o) {                    // double ::sin, rounded
 	const float y = (float)sin_f64((double)(o.position + o.offset));
 	phase_advance(o.position, o.increment);

@@ -610,7 +610,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 						dmin = fminf(dmin, delay); dmax = fmaxf(dmax, delay);
 					}
 				};
-				if constexpr (G < 64) {
+				if (G == 64 || __ballot(!(fabsf(lfo.position) < 1.0e4f)) != 0ull) vibrato_serial(0);   // (no spare lanes; or a phase no LFO walks to — an uploaded record: the plain way, with sin's range test)
+				else if constexpr (G < 64) {
 					// The LFO's fp64 sine is most of this chain (~450 of a sample's ~640 cycles), and it depends on nothing but the LFO's phase, which only the
 					// scratch detector disturbs.  The control wave has 64 / G lanes per instance: the chunk's phases are walked first (three operations a
 					// sample), the sines are then taken 64 / G samples at a time side by side in the lanes, and the chain reads them from LDS.  A sample
@@ -624,8 +625,15 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 						pos = inc_ok ? p2 : pos;
 					}
 					wave_sync();
+					// (four sines at a time, their chains side by side: the phases are in [0, 2 pi] and the control wave's LFO has no offset, so no range test stands between them)
 #pragma unroll
-					for (int u = lq; u < PPX_CHUNK; u += SLOTS) if (u < ncl) S.sn[u][li] = (float)sin_f64((double)(S.ph[u][li] + lfo.offset));   // Basic::Sine klang.h:4902
+					for (int u0 = lq; u0 < PPX_CHUNK; u0 += 4 * SLOTS) {
+						float y[4];
+#pragma unroll
+						for (int i = 0; i < 4; i++) { const int u = u0 + i * SLOTS; y[i] = (float)sin_f64_core((double)(S.ph[u < ncl ? u : ncl - 1][li] + lfo.offset)); }   // Basic::Sine klang.h:4902
+#pragma unroll
+						for (int i = 0; i < 4; i++) { const int u = u0 + i * SLOTS; if (u < ncl) S.sn[u][li] = y[i]; }
+					}
 					wave_sync();
 					// the chain, eight samples at a time without a branch: whether a detector fired is collected and looked at once per eight — if one did,
 					// the eight are walked again the plain way from the state they started with
@@ -652,7 +660,6 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 					lfo.position = (u < ncl) ? S.ph[u][li] : pos;
 					if (u < ncl) vibrato_serial(u);
 				}
-				else vibrato_serial(0);
 			}
 			// x -> 0.5f * x * fs and x -> x * fs are monotonic, so the extreme delays decide for the whole chunk
 			if (!stationary || jn < 2) {

@@ -16,17 +16,19 @@ static double klg_sin_f64(double x) {
 	double r = fma(-fn, 1.57079632679489655800e+00, x);
 	r = fma(-fn, 6.12323399573676603587e-17, r);
 	const int n = (int)fn;
+	const int odd = (n & 1) != 0;
+	const double K2 = odd ? C2 : S2, K3 = odd ? C3 : S3, K4 = odd ? C4 : S4, K5 = odd ? C5 : S5, K6 = odd ? C6 : S6;
 	const double z = r * r, v = z * r;
-	const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-	const double s = r + v * (S1 + z * rs);
-	const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+	const double h = K2 + z * (K3 + z * (K4 + z * (K5 + z * K6)));
+	const double s = r + v * (S1 + z * h);
+	const double rc = z * (C1 + z * h);
 	uint64_t b; const double ax = fabs(r); memcpy(&b, &ax, 8);
 	const uint32_t hi = (uint32_t)(b >> 32);
 	double qx;
 	if (hi < 0x3FD33333u) qx = 0.0; else if (hi > 0x3fe90000u) qx = 0.28125; else { const uint64_t q = (uint64_t)(hi - 0x00200000u) << 32; memcpy(&qx, &q, 8); }
 	const double hz = 0.5 * z - qx, a = 1.0 - qx;
 	const double c = a - (hz - z * rc);
-	double res = (n & 1) ? c : s;
+	double res = odd ? c : s;
 	return (n & 2) ? -res : res;
 }
 int main(int argc, char** argv) {
