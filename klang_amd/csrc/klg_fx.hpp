@@ -250,7 +250,7 @@ template<int I> struct IntTag { static constexpr int value = I; };
 // waits for LDS only, and the requests come back in the order they are used in).  P per workgroup width: what the registers hold.
 // Arithmetic and its order are those of klg_fx_pingpong (KLG_FX_PINGPONG1=1) and the reference, bit for bit.
 #ifndef KLG_PPX_VARIANT
-#define KLG_PPX_VARIANT 0         // measurement builds only: 1 the filter waves store their chunk (one step fewer), 2 the first requests wait for the decision
+#define KLG_PPX_VARIANT 0         // measurement builds only: 1 the filter waves store their chunk (one step fewer), 2 the first requests wait for the decision, 8 vibrato: no sines ahead
 #endif
 #ifndef KLG_PPX_ABLATE
 #define KLG_PPX_ABLATE 0          // measurement builds only (tools/ppx_ablate.sh): 1 no DC filter chain, 2 no output stores, 4 no ring requests, 8 no audio stage
@@ -262,7 +262,8 @@ template<int G> struct PpxLds {
 	float D[2][PPX_CHUNK][G];                   // delay time (smoothed controls[1]) per sample, [chunk & 1]
 	int far[2];                                 // 1: every tap of the chunk is far from the write cursor
 	int deep;                                   // the block runs the request-ahead pipeline (see PPX_DEEP below)
-	float ph[G < 64 ? PPX_CHUNK : 1][G], sn[G < 64 ? PPX_CHUNK : 1][G];   // vibrato: the LFO's phases of the chunk and their sines (control wave, G < 64)
+	int vibfast;                                // vibrato: the LFO's sines are taken by the audio waves, two chunks ahead of the chain
+	float ph[2][PPX_CHUNK + 1][G], sn[2][PPX_CHUNK][G];   // [chunk & 1]: the LFO's phase at every sample of the chunk (row PPX_CHUNK: after it), and their sines
 };
 
 // G = instances per workgroup: 64 (a whole ring group: banks that fill the chip on their own), or 32 / 16 — a half / a quarter of a
@@ -312,6 +313,30 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		const bool fixed = (sm5 * 0.999f + k5 == sm5) && !(fabsf(mdelay - sm5) >= 0.001f) && !(fabsf(c5 - sm5) >= 0.001f) && (sm1 * 0.999f + (1.f - 0.999f) * c1 == sm1);
 		stationary = __ballot(!fixed) == 0ull;
 	}
+	// ---- vibrato: the LFO's phases walked ahead (control wave), their sines (audio waves); see the control stage ----
+	float spec_pos = 0.f; int plain_chunk = -1;
+	auto prescan = [&](const int chunk) {
+		const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);                                  // Phase::operator+= klang.h:1518-1525
+		float (*PH)[G] = S.ph[chunk & 1];
+		float pos = spec_pos;
+		for (int u = 0; u < PPX_CHUNK; u++) {
+			PH[u][li] = pos;                                                            // (the lanes of an instance hold the same state: they store the same value)
+			const float p1 = pos + lfo_inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
+			pos = inc_ok ? p2 : pos;
+		}
+		PH[PPX_CHUNK][li] = pos;
+		spec_pos = pos;
+	};
+	auto sines = [&](const int chunk) {                                             // Basic::Sine klang.h:4902 on every phase of the chunk: 32 x G values over the 512 audio lanes
+		const float (*PH)[G] = S.ph[chunk & 1]; float (*SN)[G] = S.sn[chunk & 1];
+		constexpr int PER = PPX_CHUNK * G / (PPX_AUDIO * 64);
+		const int at = tid - 64;
+		float y[PER];
+#pragma unroll
+		for (int i = 0; i < PER; i++) { const int idx = at + i * PPX_AUDIO * 64; y[i] = (float)sin_f64_core((double)(PH[idx / G][idx % G] + 0.f)); }   // (position + offset; the control wave's LFO has none.  Phases are in [0, 2 pi]: no range test)
+#pragma unroll
+		for (int i = 0; i < PER; i++) { const int idx = at + i * PPX_AUDIO * 64; SN[idx / G][idx % G] = y[i]; }
+	};
 	// ---- audio wave state ----
 	float gain = 0.f, dry = 0.f;
 	if (w_audio) { gain = PPW(0); dry = PPW(4); }
@@ -462,8 +487,14 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			const bool far_deep = 0.5f * sm1 * a.fs.f >= (float)((P + 1) * PPX_CHUNK + 3) && sm1 * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
 			const bool ok = stationary && whole_chunks && __ballot(k < a.K && !far_deep) == 0ull;
 			if (lane == 0) S.deep = ok ? 1 : 0;
+			// vibrato (never stationary): a phase no LFO walks to (an uploaded record) keeps the plain chain, with sin's range test
+			const bool vf = any_vibrato && __ballot(!(fabsf(lfo.position) < 1.0e4f)) == 0ull && !(KLG_PPX_VARIANT & 8);
+			if (lane == 0) S.vibfast = vf ? 1 : 0;
+			if (vf) { spec_pos = lfo.position; prescan(0); prescan(1); }
 		}
 		__syncthreads();
+	const bool vibfast = S.vibfast != 0;
+	if (vibfast) { if (w_audio) sines(0); __syncthreads(); }                        // (chunk 1's are taken in step -1, chunk j + 2's in step j)
 	if (S.deep) {
 		if (w_control) mdelay = c5;                                             // (no scratch: `else delay = controls[5]`)
 		if (w_audio && (KLG_PPX_VARIANT & 2)) first_requests();
@@ -590,7 +621,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				lfo.position = pos;
 			}
 			else {
-				auto vibrato_serial = [&](int u) {
+				auto vibrato_serial = [&](int u) {                                     // -> a scratch detector fired (any instance of the wave)
+					bool fired = false;
 #pragma unroll 4
 					for (; u < ncl; u++) {
 						sm5 = sm5 * 0.999f + (1.f - 0.999f) * c5;                           // controls[5].smooth()  klang.h:1715
@@ -599,6 +631,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 							mdelay = new_delay;
 							c1 = (new_delay < a.c1_min) ? a.c1_min : (a.c1_max < new_delay) ? a.c1_max : new_delay;   // controls[1].set()
 							lfo.position = KLG_PI_F;                                        // lfo.set(rate, pi)
+							fired = true;
 						}
 						else mdelay = c5;
 						sm1 = sm1 * 0.999f + (1.f - 0.999f) * c1;                           // controls[1].smooth()
@@ -609,39 +642,26 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 						D[u][li] = delay;
 						dmin = fminf(dmin, delay); dmax = fmaxf(dmax, delay);
 					}
+					return __ballot(fired) != 0ull;
 				};
-				if (G == 64 || __ballot(!(fabsf(lfo.position) < 1.0e4f)) != 0ull) vibrato_serial(0);   // (no spare lanes; or a phase no LFO walks to — an uploaded record: the plain way, with sin's range test)
-				else if constexpr (G < 64) {
-					// The LFO's fp64 sine is most of this chain (~450 of a sample's ~640 cycles), and it depends on nothing but the LFO's phase, which only the
-					// scratch detector disturbs.  The control wave has 64 / G lanes per instance: the chunk's phases are walked first (three operations a
-					// sample), the sines are then taken 64 / G samples at a time side by side in the lanes, and the chain reads them from LDS.  A sample
-					// in which any instance's detector fires ends this: from there on the chunk is walked the plain way, every instance from its true phase.
-					constexpr int SLOTS = 64 / G;
-					const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);                          // Phase::operator+= klang.h:1518-1525
+				// The LFO's fp64 sine is most of this chain (~450 of a sample's ~640 cycles) and depends on nothing but the LFO's phase, which only the scratch
+				// detector disturbs.  So the phases are walked ahead on their own (prescan: three operations a sample, this wave, three chunks before the chain
+				// gets there), the AUDIO waves — 512 lanes that mostly wait for memory — take the sines of a whole chunk at once a step later (`sines`), and
+				// the chain reads them from LDS, eight samples at a time without a branch.  A detector that fires ends the speculation: the rest of the chunk
+				// and the next one (whose sines are already under way from the wrong phases) are walked the plain way, the phases restart from the true one.
+				auto respec = [&]() {                                                  // (true phase at the end of chunk jn -> the start of chunk jn + 2)
+					const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);
 					float pos = lfo.position;
-					for (int u = 0; u < ncl; u++) {
-						S.ph[u][li] = pos;                                                  // (the lanes of an instance hold the same state: they store the same value)
-						const float p1 = pos + lfo_inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
-						pos = inc_ok ? p2 : pos;
-					}
-					wave_sync();
-					// (four sines at a time, their chains side by side: the phases are in [0, 2 pi] and the control wave's LFO has no offset, so no range test stands between them)
-#pragma unroll
-					for (int u0 = lq; u0 < PPX_CHUNK; u0 += 4 * SLOTS) {
-						float y[4];
-#pragma unroll
-						for (int i = 0; i < 4; i++) { const int u = u0 + i * SLOTS; y[i] = (float)sin_f64_core((double)(S.ph[u < ncl ? u : ncl - 1][li] + lfo.offset)); }   // Basic::Sine klang.h:4902
-#pragma unroll
-						for (int i = 0; i < 4; i++) { const int u = u0 + i * SLOTS; if (u < ncl) S.sn[u][li] = y[i]; }
-					}
-					wave_sync();
-					// the chain, eight samples at a time without a branch: whether a detector fired is collected and looked at once per eight — if one did,
-					// the eight are walked again the plain way from the state they started with
+					for (int u = 0; u < PPX_CHUNK; u++) { const float p1 = pos + lfo_inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1; pos = inc_ok ? p2 : pos; }
+					spec_pos = pos; plain_chunk = jn + 1;
+				};
+				if (vibfast && jn != plain_chunk) {
+					float (*PH)[G] = S.ph[jn & 1]; float (*SN)[G] = S.sn[jn & 1];
 					int u = 0;
 					for (; u + 8 <= ncl; u += 8) {
 						float sv[8];
 #pragma unroll
-						for (int i = 0; i < 8; i++) sv[i] = S.sn[u + i][li] * vibrato * 0.00005f;
+						for (int i = 0; i < 8; i++) sv[i] = SN[u + i][li] * vibrato * 0.00005f;
 						const float sm5_0 = sm5, mdelay_0 = mdelay, sm1_0 = sm1, c1_0 = c1, dmin_0 = dmin, dmax_0 = dmax;
 						bool fired = false;
 #pragma unroll
@@ -657,9 +677,11 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 						}
 						if (__ballot(fired) != 0ull) { sm5 = sm5_0; mdelay = mdelay_0; sm1 = sm1_0; c1 = c1_0; dmin = dmin_0; dmax = dmax_0; break; }
 					}
-					lfo.position = (u < ncl) ? S.ph[u][li] : pos;
-					if (u < ncl) vibrato_serial(u);
+					lfo.position = PH[u][li];                                           // (row u: the phase sample u starts from; u == ncl: where the chunk ends)
+					if (u < ncl && vibrato_serial(u)) respec();                        // (a ragged last chunk's tail comes here too, without a firing)
 				}
+				else if (vibrato_serial(0) && vibfast) respec();
+				if (vibfast && jn + 2 < nchunks) prescan(jn + 2);
 			}
 			// x -> 0.5f * x * fs and x -> x * fs are monotonic, so the extreme delays decide for the whole chunk
 			if (!stationary || jn < 2) {
@@ -730,6 +752,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				}
 			}
 		}
+		if (vibfast && w_audio && j + 2 < nchunks) sines(j + 2);                    // vibrato: the sines the control chain reads two steps from now
 		// ---------------- FILTER of chunk j-1, then its store ----------------
 		if (w_filter && j >= 1 && j <= nchunks) filter_stage(j - 1, BoolTag<true>{});
 		if (load_next) {
