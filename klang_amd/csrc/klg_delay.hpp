@@ -59,6 +59,58 @@ __device__ __forceinline__ float delay_tap_float(const Ring& r, int position, fl
 	const float a = r.rd(i), b = r.rd(j);
 	return a + fraction * (b - a);
 }
+// HOISTED TAPS (generated effects, klg_graph.hpp).  In a recorded process() a tap's rows are loaded where the reference reads them — after the line's
+// input() of the sample, which waits for the OTHER line's tap: two or three dependent round trips to memory per sample (PingPong.k), eleven (Reverb.k).
+// The rows are known long before: the code generator requests them where their address is first computable (`h`: rows and values), and the tap at its own
+// place takes them if they are the rows it needs and no input() of the line has written one of them since (`hazard`: compared row by row) — else it reads
+// memory as before.  Same arithmetic on the same values.
+struct Rows2 { int i, j; };
+__device__ __forceinline__ float delay_process_h(const Ring& r, Tap& t, Rows2 h, float ha, float hb, bool hazard) {
+	const int i = t.position, j = ring_succ(i, r.size);
+	float a = ha, b = hb;
+	if (hazard || i != h.i || j != h.j) { a = r.rd(i); b = r.rd(j); }
+	const float out = a + t.fraction * (b - a);
+	t.position = j;
+	return out;
+}
+__device__ __forceinline__ Rows2 delay_tap_float_rows(int size, int position, float delay) {
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += size;
+	Rows2 h; h.i = (int)read < 0 ? 0 : (int)read; h.j = (h.i + 1) % size;
+	return h;
+}
+__device__ __forceinline__ float delay_tap_float_h(const Ring& r, int position, float delay, Rows2 h, float ha, float hb, bool hazard) {
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += r.size;
+	const int i = (int)read < 0 ? 0 : (int)read;
+	const float fraction = read - i;
+	const int j = (i + 1) % r.size;
+	float a = ha, b = hb;
+	if (hazard || i != h.i || j != h.j) { a = r.rd(i); b = r.rd(j); }
+	return a + fraction * (b - a);
+}
+__device__ __forceinline__ Rows2 delay_tap_stereo_rows(int size, int position, float delay) {
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += size;
+	const int i = (int)read, j = (i == size - 1) ? 0 : (i + 1);
+	const bool pad = i >= size || i < 0;
+	Rows2 h; h.i = pad ? 0 : i; h.j = pad ? 0 : j;
+	return h;
+}
+__device__ __forceinline__ float delay_tap_stereo_h(const Ring& r, int position, float delay, Rows2 h, float ha, float hb, bool hazard) {
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += r.size;
+	const float f = (float)floor((double)read);
+	const float frac = read - f;
+	const int i = (int)read;
+	const int j = (i == r.size - 1) ? 0 : (i + 1);
+	const bool pad = i >= r.size || i < 0;
+	const int ri = pad ? 0 : i, rj = pad ? 0 : j;
+	float va = ha, vb = hb;
+	if (hazard || ri != h.i || rj != h.j) { va = r.rd(ri); vb = r.rd(rj); }
+	const float a = pad ? 0.f : va, b = pad ? 0.f : vb;
+	return a * (1.f - frac) + b * frac;
+}
 // one channel of Stereo::Delay::tap(float) klang.h:4668-4681 — not the mono form: a * (1 - frac) + b * frac, frac against floor(read), the successor wraps at
 // SIZE - 1 (both lines of a Stereo::Delay stand at the same cursor).  `read` rounded up to exactly SIZE: the reference reads the pad and one element
 // past it (indeterminate there); that tap is 0 here (klg_fx.hpp stereo_delay_tap, oracle ko_stereo_delay_tap_float).

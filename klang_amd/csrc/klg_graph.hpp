@@ -236,10 +236,78 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		}
 	}
 	auto phis_of = [&](int if_index) { std::vector<const Op*> v; const int e = match_endif[(size_t)if_index]; for (size_t q = (size_t)e + 1; e >= 0 && q < g.ops.size() && g.ops[q].code == OP_PHI; q++) v.push_back(&g.ops[q]); return v; };
+	// ---- effects: taps requested where their rows are first known (klg_delay.hpp "HOISTED TAPS") ----
+	struct Hoist { int tap, at, m, k; std::vector<int> writes; };            // tap op, the op it is requested in front of, process() calls / input()s of the line in between
+	std::vector<Hoist> hoists; std::vector<int> hoist_of(g.ops.size(), -1);
+	std::vector<bool> names_row(g.ops.size(), false);                        // delayin ops whose row a later tap compares with
+	{
+		const char* he = getenv("KLG_FX_HOIST");
+		const int first = g.prepare_ops > 0 ? g.prepare_ops : 0;
+		std::vector<int> region(g.ops.size(), 0), region_start(1, first), stack(1, 0);
+		for (size_t oi = 0; oi < g.ops.size(); oi++) {                           // region of an op: the branch side it stands in (0: the top level)
+			const int c = g.ops[oi].code;
+			if (c == OP_IF) { region[oi] = stack.back(); stack.push_back((int)region_start.size()); region_start.push_back((int)oi + 1); }
+			else if (c == OP_ELSE && stack.size() > 1) { stack.pop_back(); region[oi] = stack.back(); stack.push_back((int)region_start.size()); region_start.push_back((int)oi + 1); }
+			else if (c == OP_ENDIF && stack.size() > 1) { stack.pop_back(); region[oi] = stack.back(); }
+			else region[oi] = stack.back();
+		}
+		std::vector<int> def_at(2 * g.ops.size() + 64, -1);
+		for (size_t oi = 0; oi < g.ops.size(); oi++) if (g.ops[oi].dst >= 0 && (size_t)g.ops[oi].dst < def_at.size()) def_at[(size_t)g.ops[oi].dst] = (int)oi;
+		if (fx && !(he && he[0] == '0')) for (size_t t = (size_t)first; t < g.ops.size(); t++) {
+			const Op& o = g.ops[t];
+			const bool out = o.code == OP_DELAYOUT, tapf = o.code == OP_DELAYTAP && (o.imm == 0u || o.imm == 2u);
+			if (!out && !tapf) continue;
+			if (o.node < 0 || g.nodes[(size_t)o.node] != N_DELAY) continue;
+			const int R = region[t];
+			int at = std::max(region_start[(size_t)R], first);
+			bool ok = true;
+			if (tapf) { const int dd = (o.a >= 0 && (size_t)o.a < def_at.size()) ? def_at[(size_t)o.a] : -1; if (dd >= (int)t) ok = false; else if (dd >= at) { if (region[(size_t)dd] != R) ok = false; at = dd + 1; if (g.ops[(size_t)dd].code == OP_PHI) { while (at < (int)t && g.ops[(size_t)at].code == OP_PHI) at++; } } }
+			if (out) for (int q = (int)t - 1; q >= at; q--) if (g.ops[(size_t)q].code == OP_DELAYSET && g.ops[(size_t)q].node == o.node) { if (region[(size_t)q] != R) ok = false; at = q + 1; break; }
+			Hoist h; h.tap = (int)t; h.at = at; h.m = 0; h.k = 0;
+			for (int q = at; ok && q < (int)t; q++) {
+				const Op& x = g.ops[(size_t)q];
+				if (x.node != o.node) continue;
+				if (x.code != OP_DELAYIN && x.code != OP_DELAYOUT && x.code != OP_DELAYSET) continue;
+				if (region[(size_t)q] != R) { ok = false; break; }                     // (a conditional input() / process() / set() of the line in between: not predicted)
+				if (x.code == OP_DELAYIN) { h.k++; h.writes.push_back(q); }
+				else if (x.code == OP_DELAYOUT) h.m++;
+				else ok = false;
+			}
+			if (!ok || (int)t - at < 2) continue;                                  // (nothing to request ahead of)
+			for (int w : h.writes) names_row[(size_t)w] = true;
+			hoist_of[t] = (int)hoists.size(); hoists.push_back(h);
+		}
+		// one tap a sample is one round trip a sample wherever it is requested — and requesting it early costs the compiler its own pairing of samples (the echo:
+		// 0.087 -> 0.109 ms); it is with several taps, each waiting behind an input() that waits for another tap, that the round trips add up
+		if (hoists.size() < 2) { hoists.clear(); std::fill(hoist_of.begin(), hoist_of.end(), -1); std::fill(names_row.begin(), names_row.end(), false); }
+	}
+	auto emit_hoists = [&](std::string& body, int at) {                       // the requests that stand in front of op `at`
+		for (size_t q = 0; q < hoists.size(); q++) if (hoists[q].at == at) {
+			const Hoist& h = hoists[q]; const Op& o = g.ops[(size_t)h.tap];
+			const std::string n = fmt("L.n%d", o.node), rg = ring(o.node);
+			const int SZ = g.arg(o.node);
+			if (o.code == OP_DELAYOUT) {
+				body += fmt("\t\tRows2 h%zu; h%zu.i = ", q, q) + n + "t.position;";
+				for (int i = 0; i < h.m; i++) body += fmt(" h%zu.i = ring_succ(h%zu.i, %d);", q, q, SZ);
+				body += fmt(" h%zu.j = ring_succ(h%zu.i, %d);\n", q, q, SZ);
+			}
+			else {
+				const std::string pos = h.k ? "((" + n + fmt("pos + %d) %% %d)", h.k, SZ) : n + "pos";
+				body += fmt("\t\tconst Rows2 h%zu = ", q) + (o.imm == 2u ? "delay_tap_stereo_rows(" : "delay_tap_float_rows(") + fmt("%d, ", SZ) + pos + fmt(", r%d);\n", o.a);
+			}
+			body += fmt("\t\tconst float h%zua = ", q) + rg + fmt(".rd(h%zu.i), h%zub = ", q, q) + rg + fmt(".rd(h%zu.j);\n", q);
+		}
+	};
+	auto hazard_of = [&](int q) {
+		std::string e = "false";
+		for (int w : hoists[(size_t)q].writes) e += fmt(" || h%d.i == wr%d || h%d.j == wr%d", q, w, q, w);
+		return e;
+	};
 	std::string prologue;                                                // Effect::prepare(): once per block, at the end of begin()
 	for (size_t oi = 0; oi < g.ops.size(); oi++) {
 		const Op& o = g.ops[oi];
 		if ((int)oi == g.prepare_ops && g.prepare_ops) { prologue = body; body.clear(); }
+		emit_hoists(body, (int)oi);
 		const std::string d = "\t\tconst " + TF + fmt(" r%d = ", o.dst), n = fmt("L.n%d", o.node), a = fmt("r%d", o.a), b = fmt("r%d", o.b);
 		const int k = (o.node >= 0 && o.node < (int)g.nodes.size()) ? g.nodes[(size_t)o.node] : -1;
 		switch (o.code) {
@@ -315,7 +383,10 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			body += "\t\t}\n";
 			break;
 		case OP_NOISE: body += d + (o.imm ? "fast_noise(" : "basic_noise(") + fmt("c.rand[L.sidx * %d + %d]);\n", noise_calls, noise_k++); break;
-		case OP_DELAYOUT: body += d + "delay_process(" + ring(o.node) + ", " + n + "t);\n"; break;
+		case OP_DELAYOUT:
+			if (hoist_of[oi] >= 0) body += d + "delay_process_h(" + ring(o.node) + ", " + n + fmt("t, h%d, h%da, h%db, ", hoist_of[oi], hoist_of[oi], hoist_of[oi]) + hazard_of(hoist_of[oi]) + ");\n";
+			else body += d + "delay_process(" + ring(o.node) + ", " + n + "t);\n";
+			break;
 		case OP_TABREAD: body += d + fmt("table_read(c.tables, %uu, ", o.imm) + a + ");\n"; break;
 		case OP_PHI: break;                                         // assigned at the end of both sides (above)
 		case OP_STOPIF: {
@@ -327,9 +398,13 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		case OP_SETPARAM: body += "\t\t" + n + " = " + a + ";\n"; break;
 		case OP_FREQ: body += d + n + "f;\n"; break;
 		case OP_IN: body += d + (o.imm ? "in1" : "in0") + ";\n"; break;
-		case OP_DELAYIN: body += "\t\t{ const Ring q = " + ring(o.node) + "; q.wr(" + n + "pos, " + a + "); " + n + "pos = (" + n + fmt("pos + 1 == %d) ? 0 : ", g.arg(o.node)) + n + "pos + 1; }\n"; break;   // Delay::input klang.h:3396-3403
+		case OP_DELAYIN:
+			if (names_row[oi]) body += fmt("\t\tconst int wr%zu = ", oi) + n + "pos;\n";     // (the row this input() writes: hoisted taps of the line compare theirs with it)
+			body += "\t\t{ const Ring q = " + ring(o.node) + "; q.wr(" + n + "pos, " + a + "); " + n + "pos = (" + n + fmt("pos + 1 == %d) ? 0 : ", g.arg(o.node)) + n + "pos + 1; }\n"; break;   // Delay::input klang.h:3396-3403
 		case OP_DELAYSET: body += "\t\t" + n + "t = delay_set(" + n + fmt("pos, %d, ", g.arg(o.node)) + a + ");\n"; break;   // Delay::set klang.h:3480-3489
-		case OP_DELAYTAP: body += d + (o.imm == 1u ? "delay_tap_int(" + ring(o.node) + ", " + n + "pos, (int)" + a + ");\n" : (o.imm == 2u ? "delay_tap_stereo(" : "delay_tap_float(") + ring(o.node) + ", " + n + "pos, " + a + ");\n"); break;   // imm 1: tap(int), klang.h:3405-3410
+		case OP_DELAYTAP:
+			if (hoist_of[oi] >= 0) { body += d + (o.imm == 2u ? "delay_tap_stereo_h(" : "delay_tap_float_h(") + ring(o.node) + ", " + n + "pos, " + a + fmt(", h%d, h%da, h%db, ", hoist_of[oi], hoist_of[oi], hoist_of[oi]) + hazard_of(hoist_of[oi]) + ");\n"; break; }
+			body += d + (o.imm == 1u ? "delay_tap_int(" + ring(o.node) + ", " + n + "pos, (int)" + a + ");\n" : (o.imm == 2u ? "delay_tap_stereo(" : "delay_tap_float(") + ring(o.node) + ", " + n + "pos, " + a + ");\n"); break;   // imm 1: tap(int), klang.h:3405-3410
 		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 7u]) : fx ? fmt("L.ctl%u", o.imm) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";

@@ -244,7 +244,7 @@ def test_an_effect_may_write_its_controls_take_abs_and_place_delay_heads_per_sam
     rc, src = check(prog, want_source=True)
     assert rc == 0, src
     for needle in ("float n7;", "const float r14 = L.n7;", "__builtin_fabsf(r26)", "L.n7 = r30;", "(r25 < u2f(0x3a83126fu)) ? u2f(0x3a83126fu) : (u2f(0x3f800000u) < r25) ? u2f(0x3f800000u) : r25",
-                   "L.n8 = L.n8 * 0.999f + (1.f - 0.999f) * L.n7;", "L.n6 = L.n6 * 0.999f + (1.f - 0.999f) * L.ctl5;", "L.ctl5 = c.ctl[5];", "L.n0t = delay_set(L.n0pos, 192000, r46);", "delay_process(Ring{",
+                   "L.n8 = L.n8 * 0.999f + (1.f - 0.999f) * L.n7;", "L.n6 = L.n6 * 0.999f + (1.f - 0.999f) * L.ctl5;", "L.ctl5 = c.ctl[5];", "L.n0t = delay_set(L.n0pos, 192000, r46);", "Rows2 h1; h1.i = L.n0t.position;", "delay_process_h(Ring{",
                    "osc.set" if False else "L.n2.position = r31;"):
         assert needle in src, needle
     rc, msg = check(prog.replace("kind effect 2\n", "").replace("ret2 67 68", "ret 67"))
