@@ -277,13 +277,14 @@ def test_pingpong_with_moving_dials(oracle_build, block, width, monkeypatch):
     assert np.abs(got[-1]).max() > 1e-3
 
 
-@pytest.mark.parametrize("block,width", [(256, 0), (256, 16), (192, 32), (256, 64), (80, 16)])
+@pytest.mark.parametrize("block,width", [(256, 0), (256, 16), (192, 32), (256, 64), (80, 16), (40, 32), (8, 0)])
 def test_pingpong_vibrato_with_the_scratch_detector_firing(oracle_build, block, width, monkeypatch):
     """Vibrato on (controls[2], controls[3] > 0): every sample takes the LFO's fp64 sine and writes controls[1].  With fewer than 64 instances per
     workgroup the control wave walks a chunk's LFO phases first, takes the sines several samples at a time in its spare lanes and reads them back in
     the chain; a controls[5] move sets off the scratch detector (`lfo.set(rate, pi)`) for some ten thousand samples, during which the chunk is walked
-    the plain way from the first firing sample on.  Some instances without vibrato in the same workgroup, blocks that are not whole chunks (80), the
-    single-slot width (64: the plain chain only); every block against the oracle, bit for bit."""
+    the plain way from the first firing sample on (round 3, final form: the phases are walked three chunks ahead and the AUDIO waves take the sines, at
+    every width).  Some instances without vibrato in the same workgroup, blocks that are not whole chunks (80, 40) or shorter than the chain's groups
+    of eight (8); every block against the oracle, bit for bit."""
     if width: monkeypatch.setenv("KLG_FX_PINGPONG_G", str(width))
     B = 12288 // block
     s = Scenario(patch="pingpong", block=block, blocks=B, instances=40, burst=12288, seed=9, dump=list(range(B)))
