@@ -277,9 +277,29 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			for (int w : h.writes) names_row[(size_t)w] = true;
 			hoist_of[t] = (int)hoists.size(); hoists.push_back(h);
 		}
-		// one tap a sample is one round trip a sample wherever it is requested — and requesting it early costs the compiler its own pairing of samples (the echo:
-		// 0.087 -> 0.109 ms); it is with several taps, each waiting behind an input() that waits for another tap, that the round trips add up
-		if (hoists.size() < 2) { hoists.clear(); std::fill(hoist_of.begin(), hoist_of.end(), -1); std::fill(names_row.begin(), names_row.end(), false); }
+		// A tap is worth requesting early when something it would otherwise stand behind WAITS for another tap: an input() in between whose value comes from a
+		// tap of this sample (PingPong.k's cross-feed; a feedback matrix).  Where no such input() lies in between the round trip is paid once wherever the request
+		// stands, and requesting early only costs the compiler its own pairing of samples (the echo: 0.087 -> 0.109 ms) — those taps stay where they are.
+		{
+			std::vector<bool> dep(def_at.size(), false), node_dep(g.nodes.size(), false), waits(g.ops.size(), false);
+			for (size_t oi = (size_t)first; oi < g.ops.size(); oi++) {
+				const Op& x = g.ops[oi];
+				auto D = [&](int r) { return r >= 0 && (size_t)r < dep.size() && dep[(size_t)r]; };
+				bool dd = D(x.a) || D(x.b) || x.code == OP_DELAYOUT || x.code == OP_DELAYTAP;
+				if (x.node >= 0 && (size_t)x.node < node_dep.size()) { if (x.code == OP_SETPARAM || x.code == OP_SETCTL) node_dep[(size_t)x.node] = node_dep[(size_t)x.node] || D(x.a); else if (node_dep[(size_t)x.node]) dd = true; }
+				if (x.dst >= 0 && (size_t)x.dst < dep.size()) dep[(size_t)x.dst] = dd;
+				if (x.code == OP_DELAYIN && D(x.a)) waits[oi] = true;
+			}
+			std::vector<Hoist> kept; std::fill(hoist_of.begin(), hoist_of.end(), -1); std::fill(names_row.begin(), names_row.end(), false);
+			for (const Hoist& h : hoists) {
+				bool behind = false;
+				for (int q = h.at; q < h.tap; q++) if (waits[(size_t)q]) behind = true;
+				if (!behind) continue;
+				for (int w : h.writes) names_row[(size_t)w] = true;
+				hoist_of[(size_t)h.tap] = (int)kept.size(); kept.push_back(h);
+			}
+			hoists.swap(kept);
+		}
 	}
 	auto emit_hoists = [&](std::string& body, int at) {                       // the requests that stand in front of op `at`
 		for (size_t q = 0; q < hoists.size(); q++) if (hoists[q].at == at) {
