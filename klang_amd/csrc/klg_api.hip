@@ -177,6 +177,7 @@ struct klg_synth {
 	struct Table { float* d; std::vector<float> h; uint64_t hash; };
 	std::vector<Table> tables;
 	TableDesc* d_tables = nullptr; size_t d_tables_cap = 0; bool tables_dirty = false;
+	unsigned args_gen = 0;                      // bumped whenever a device pointer that RenderArgs carries may have changed (tables_sync, mix mode): captured spans of an older generation are dropped, not replayed
 	float* d_note_rings = nullptr;               // note delays of a graph patch: [stride][ring_rows], each voice's lines contiguous
 	int *d_rand = nullptr, *d_rand_base = nullptr; size_t d_rand_cap = 0; std::vector<int> h_rand, h_rand_base;   // Noise generators of a graph patch: the block's rand() draws (draw_noise)
 	// host mirrors
@@ -465,7 +466,7 @@ extern "C" int klg_synth_set_mix_mode(klg_synth* s, int mode) {
 		HIP_TRY(hipMalloc((void**)&s->d_solo, (size_t)s->S * sizeof(int)));
 		if (s->patch == KLG_PATCH_SUB2A) s->x2 = false;             // the packed kernel has no per-voice mask at its tile write: one voice per lane in this mode
 	}
-	s->mix_mode = mode;
+	s->mix_mode = mode; s->args_gen++;
 	return 0;
 }
 extern "C" int klg_synth_voices(const klg_synth* s) { return s ? s->V : KLG_ERR_INVALID; }
@@ -863,6 +864,10 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 		else if (script_events->runs > 0) { launch_events(s, *script_events, st); HIP_TRY(hipGetLastError()); }
 	}
 	else if (int rc = flush_events(s, st, fuse_events ? &ev : nullptr)) return rc;
+	// Event runs handed to the render launch (`ev`) have left the host queue.  If this block bails out before that launch is issued (a control / table
+	// upload failed, the generated kernel could not be launched), they still take effect: applied by a klg_apply_events launch of their own.
+	struct FusedEvents { klg_synth* s; const EventArgs* ev; hipStream_t st; bool consumed;
+		~FusedEvents() { if (!consumed && ev->runs > 0) { launch_events(s, *ev, st); (void)hipGetLastError(); } } } fused_events = { s, &ev, st, false };
 	if (int rc = upload_controls(s, st)) return rc;
 	RenderArgs a;
 	a.state = s->d_state; a.stride = s->stride; a.voices = s->V; a.notes_per_synth = s->P; a.n = n;
@@ -880,6 +885,7 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	}
 	{ TimedLaunch timed(s); launch_render(s, a, per_voice, st); }
 	if (s->launch_error != hipSuccess) { const hipError_t e = s->launch_error; s->launch_error = hipSuccess; return fail(KLG_ERR_HIP, "launching the compiled graph patch failed: %s", hipGetErrorString(e)); }
+	fused_events.consumed = true;
 	if (a.ticket) {}                                                 // (the render launch's last workgroup added the rows)
 	else if (s->note_ch == 2) hipLaunchKernelGGL(klg_reduce_stereo, dim3((n + 31) / 32, 2), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
 	else hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
@@ -1145,6 +1151,7 @@ static int tables_sync(klg_synth* s) {
 	for (size_t k = 0; k < h.size(); k++) { h[k].p = s->tables[k].d; h[k].size = (int)s->tables[k].h.size(); h[k].pad_ = 0; }
 	HIP_TRY(hipMemcpy(s->d_tables, h.data(), h.size() * sizeof(TableDesc), hipMemcpyHostToDevice));
 	s->tables_dirty = false;
+	s->args_gen++;                                        // (a captured span holds the old d_tables pointer in its kernel parameters)
 	return 0;
 }
 
@@ -1172,7 +1179,7 @@ struct klg_script {
 	struct Slice { size_t first; int R, E; };                      // where block b's run / event arrays sit in d_index
 	std::vector<Slice> slices;
 	// klg_script_render_device: the launches of a span of blocks captured ONCE as a hipGraph and replayed (same span, block length, destination, stream)
-	struct Captured { int first, blocks, n; float* d_out; hipStream_t st; hipGraphExec_t exec; };
+	struct Captured { int first, blocks, n; float* d_out; hipStream_t st; hipGraphExec_t exec; unsigned gen; };   // gen: the bank's args_gen at capture time
 	std::vector<Captured> graphs;
 	int* d_index = nullptr; uint32_t* d_pool = nullptr;
 };
@@ -1308,6 +1315,7 @@ static int script_render(klg_script* k, int first_block, int blocks, float* d_ou
 	const bool prepass = s->graph && (s->graph->noise_calls > 0 || !s->graph->smooths.empty());
 	const bool can_graph = !(genv && genv[0] == '0') && blocks >= 2 && !s->timing && s->events.empty() && !s->controls_dirty && !s->tables_dirty && !prepass && s->mix_mode != KLG_MIX_LAST_ACTIVE;
 	if (!can_graph) return capture_only ? fail(KLG_ERR_INVALID, "klg_script_capture_span: nothing captured (pending events / uploads, kernel timing on, KLG_GRAPH=0, or a bank whose blocks need a host pass)") : enqueue_span();
+	if (!k->graphs.empty() && k->graphs.front().gen != s->args_gen) script_drop_graphs(k);   // the bank's device pointers moved since these were captured (a table upload re-allocated d_tables, the mix mode changed): never replay them
 	for (const auto& g : k->graphs) if (g.first == first_block && g.blocks == blocks && g.n == n && g.d_out == d_out && g.st == st) {
 		if (capture_only) return 0;
 		HIP_TRY(hipGraphLaunch(g.exec, st)); s->stages_dirty = true; s->scripted = true; return 0;
@@ -1322,7 +1330,7 @@ static int script_render(klg_script* k, int first_block, int blocks, float* d_ou
 	if (graph) (void)hipGraphDestroy(graph);
 	if (!ok) { (void)hipGetLastError(); if (capture_only) { s->stages_dirty = was_dirty; s->scripted = was_scripted; return fail(KLG_ERR_HIP, "klg_script_capture_span: capture failed"); } return rc ? rc : enqueue_span(); }
 	if (k->graphs.size() >= 8) script_drop_graphs(k);                // (a handful of spans at most: a render loop replays the same few)
-	k->graphs.push_back({ first_block, blocks, n, d_out, st, exec });
+	k->graphs.push_back({ first_block, blocks, n, d_out, st, exec, s->args_gen });
 	if (capture_only) { s->stages_dirty = was_dirty; s->scripted = was_scripted; return 0; }      // (nothing has run)
 	HIP_TRY(hipGraphLaunch(exec, st));
 	return 0;

@@ -29,6 +29,7 @@ struct klg_fx {
 	// block b + 1's sums are computed on `early_stream` while block b's recursive kernel runs (they depend on samples >= 45 ms old only)
 	float* d_early[2] = { nullptr, nullptr }; unsigned early_turn = 0; bool upd_flushed = false;
 	hipStream_t early_stream = nullptr; hipEvent_t early_ready = nullptr, q_done[2] = { nullptr, nullptr }, upd_done = nullptr; bool q_used[2] = { false, false };
+	bool early_alloc_failed = false; int rv_prev_n = 1 << 30; hipStream_t rv_prev_stream = nullptr;   // (mode 2: length and stream of the previous Reverb block)
 	int* d_upd = nullptr; size_t d_upd_cap = 0;
 	unsigned long long samples = 0;                    // samples processed so far (defines every write cursor)
 	std::vector<host::ControlH> controls;              // [K][nctl]
@@ -145,11 +146,6 @@ static klg_fx* fx_create_on(int device, int patch_id, int instances, float sampl
 	ok = ok && hipMalloc(&f->d_rings, ring1 * 4) == hipSuccess;
 	ok = ok && (ring2 == 0 || hipMalloc(&f->d_rings2, ring2 * 4) == hipSuccess);
 	ok = ok && hipMalloc(&f->d_io, (size_t)f->kpad * 2 * max_block * 4) == hipSuccess;
-	if (!pp && f->rv_layout) {
-		for (int i = 0; i < 2; i++) ok = ok && hipMalloc(&f->d_early[i], (size_t)f->kpad * 2 * max_block * 4) == hipSuccess && hipEventCreateWithFlags(&f->q_done[i], hipEventDisableTiming) == hipSuccess;
-		ok = ok && hipStreamCreateWithFlags(&f->early_stream, hipStreamNonBlocking) == hipSuccess;
-		ok = ok && hipEventCreateWithFlags(&f->early_ready, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&f->upd_done, hipEventDisableTiming) == hipSuccess;
-	}
 	ok = ok && hipMemset(f->d_state, 0, (size_t)f->words * f->kpad * 4) == hipSuccess;
 	ok = ok && hipMemset(f->d_rings, 0, ring1 * 4) == hipSuccess;                      // Delay() : buffer(SIZE + 1, 0)
 	ok = ok && (ring2 == 0 || hipMemset(f->d_rings2, 0, ring2 * 4) == hipSuccess);
@@ -415,6 +411,24 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
 	return 0;
 }
 
+// the early-sum buffers, second stream and events of KLG_FX_REVERB_EARLY modes 1 / 2: allocated the first time such a mode is selected (banks above 2,048
+// instances default to mode 0 and never pay the 2 x kpad x 2 x max_block floats: 256 MB at 16,384 instances)
+static bool rv_early_alloc(klg_fx* f) {
+	if (f->d_early[0] && f->d_early[1] && f->early_stream && f->early_ready && f->upd_done && f->q_done[0] && f->q_done[1]) return true;
+	if (f->early_alloc_failed) return false;
+	RandGuard rg;
+	bool ok = true;
+	for (int i = 0; i < 2; i++) {
+		if (!f->d_early[i]) ok = ok && hipMalloc(&f->d_early[i], (size_t)f->kpad * 2 * f->max_block * 4) == hipSuccess;
+		if (!f->q_done[i]) ok = ok && hipEventCreateWithFlags(&f->q_done[i], hipEventDisableTiming) == hipSuccess;
+	}
+	if (!f->early_stream) ok = ok && hipStreamCreateWithFlags(&f->early_stream, hipStreamNonBlocking) == hipSuccess;
+	if (!f->early_ready) ok = ok && hipEventCreateWithFlags(&f->early_ready, hipEventDisableTiming) == hipSuccess;
+	if (!f->upd_done) ok = ok && hipEventCreateWithFlags(&f->upd_done, hipEventDisableTiming) == hipSuccess;
+	if (!ok) { (void)hipGetLastError(); f->early_alloc_failed = true; }
+	return ok;
+}
+
 static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 	if (f->graph) return fx_enqueue_graph(f, d_io, n, st);
 	if (f->patch == KLG_PATCH_REVERB && !f->rv_touched.empty()) {                    // prepare(): `if (controls.changed())` Reverb.k:238 — a dial changes only through klg_fx_set_control
@@ -481,8 +495,14 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 			// positions per instance), and from 4,096 instances on the recursive kernel already keeps the memory system busy — a second kernel only adds
 			// its own launch and an 8 MB round trip of the sums.  Below that the lone wave's phase 1 is latency-bound and the separate launch wins.
 			static const int forced_mode = []() { const char* e = getenv("KLG_FX_REVERB_EARLY"); return e ? atoi(e) : -1; }();
-			const int early_mode = forced_mode >= 0 ? forced_mode : (f->kpad <= 2048 ? 1 : 0);
-			if (early_mode == 0 || !f->d_early[0]) hipLaunchKernelGGL(klg_fx_reverb_q<false>, qgrid, dim3(RVQ_WG), qlds, st, a);   // one wave per four instances
+			int early_mode = forced_mode >= 0 ? forced_mode : (f->kpad <= 2048 ? 1 : 0);
+			if (early_mode != 0 && (f->K > 65535 || !rv_early_alloc(f))) early_mode = 0;   // (klg_fx_reverb_early's grid has one row of workgroups per instance: gridDim.y <= 65535)
+			// Mode 2 runs THIS block's sums beside the PREVIOUS block's recursive kernel, which is still writing the previous block's early-line samples: nothing
+			// the sums read may be that young — the previous block's length counts too — and the previous block must have gone to the same stream (the only
+			// ordering mode 2 keeps is q_done of two blocks ago).  Otherwise: the same kernels on one stream (mode 1).
+			if (early_mode == 2 && (f->rv_prev_stream != st || !((float)(f->rv_prev_n + n + 2) < 0.0449f * f->fs.f))) early_mode = 1;
+			f->rv_prev_n = n; f->rv_prev_stream = st;
+			if (early_mode == 0) hipLaunchKernelGGL(klg_fx_reverb_q<false>, qgrid, dim3(RVQ_WG), qlds, st, a);   // one wave per four instances
 			else {
 				const unsigned turn = f->early_turn++ & 1u;
 				a.early_sums = f->d_early[turn];
@@ -499,7 +519,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 					HIP_TRY(hipStreamWaitEvent(st, f->early_ready, 0));
 				}
 				hipLaunchKernelGGL(klg_fx_reverb_q<true>, qgrid, dim3(RVQ_WG), qlds, st, a);
-				if (early_mode != 1) { HIP_TRY(hipEventRecord(f->q_done[turn], st)); f->q_used[turn] = true; }
+				HIP_TRY(hipEventRecord(f->q_done[turn], st)); f->q_used[turn] = true;       // (recorded in mode 1 as well: a later mode-2 block's sums wait for the last reader of this buffer whichever mode it ran in)
 			}
 		}
 		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances (KLG_FX_REVERB16=1)
