@@ -223,6 +223,13 @@ int klg_synth_voices_per_lane(const klg_synth* s);
  * zero-filled rings in HBM.  The handle is used with klg_fx_set_control / klg_fx_process[_device] / klg_fx_destroy; io is
  * [instances][channels][n]. */
 klg_fx* klg_fx_create_graph(const char* program, int instances, float sample_rate, int max_block, const void* initial_record);
+/* How a graph effect bank runs its recorded body (diagnostics / tests; no reference counterpart).  Returns 1 for the SAMPLE-PARALLEL form
+ * (klang_amd/csrc/klg_graph_staged.hpp: a workgroup takes *instances_per_workgroup instances x *samples_per_chunk samples of the block at a time —
+ * the parts of Effect::process() (klang.h:4208-4216 runs it sample after sample) that do not depend on the previous sample with a lane per
+ * (sample, instance), the recurrences in sample order on a lane per instance, *levels barrier-separated steps per chunk, *lds_values values handed
+ * between them through LDS), 0 for one lane per instance walking the samples in order — `why` then says what the body has that the staged form
+ * does not handle —, < 0 on a bad handle.  Any output pointer may be NULL.  KLG_FX_STAGED=0 in the environment keeps every bank on the second form. */
+int klg_fx_graph_form(const klg_fx* f, int* instances_per_workgroup, int* samples_per_chunk, int* levels, int* lds_values, char* why, size_t why_cap);
 
 /* Measurement hooks used by bench.py: timing of the render kernel with a pair of HIP events per launch, on the
  * stream the kernel is launched on, ATTACHED TO THE DISPATCH (hipExtLaunchKernelGGL / hipExtModuleLaunchKernel:

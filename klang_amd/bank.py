@@ -278,6 +278,13 @@ class FxBank:
         check(self._L.klg_fx_get_control(self._h, int(instance), int(index), C.byref(v)), "klg_fx_get_control")
         return v.value
 
+    def graph_form(self):
+        """How a graph effect bank runs its body: dict(staged, instances_per_workgroup, samples_per_chunk, levels, lds_values, why) (klg_fx_graph_form)."""
+        g, c, lv, sl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        why = C.create_string_buffer(512)
+        rc = check(self._L.klg_fx_graph_form(self._h, C.byref(g), C.byref(c), C.byref(lv), C.byref(sl), why, len(why)), "klg_fx_graph_form")
+        return dict(staged=bool(rc), instances_per_workgroup=g.value, samples_per_chunk=c.value, levels=lv.value, lds_values=sl.value, why=why.value.decode())
+
     def record_words(self):
         return check(self._L.klg_fx_record_words(self._h), "klg_fx_record_words")
 

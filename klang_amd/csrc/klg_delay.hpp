@@ -125,6 +125,54 @@ __device__ __forceinline__ float delay_tap_stereo(const Ring& r, int position, f
 	const float a = pad ? 0.f : r.rd(pad ? 0 : i), b = pad ? 0.f : r.rd(pad ? 0 : j);
 	return a * (1.f - frac) + b * frac;
 }
+// STAGED EFFECTS (klg_graph_staged.hpp): a chunk of C samples of an instance is computed with samples side by side, every ring read of the chunk before any of
+// its ring writes.  That is the reference's result exactly when no read of the chunk touches a row the chunk itself writes — rows w0 .. w0 + wn - 1 (mod SIZE) of
+// the line: a tap that close behind the cursor would have to see this chunk's input()s, one almost SIZE behind would have to see the OLD value of a row a later
+// sample overwrites.  Each read reports whether it did (`bad`); the chunk is then walked again in sample order by the plain body, before anything was written.
+// The arithmetic is that of delay_process / delay_tap_float / delay_tap_stereo / delay_tap_int above, on the same rows.
+struct RingWindow { int w0, wn; };
+__device__ __forceinline__ bool ring_in_window(int row, int size, RingWindow w) { int d = row - w.w0; d = d < 0 ? d + size : d; return row < size && d < w.wn; }
+__device__ __forceinline__ int ring_walk(int p, int m, int size) {                  // the read head after m process() calls: ring_succ applied m times (m < SIZE)
+	if (m == 0) return p;
+	int q = (p == size ? 0 : p) + m;
+	return q >= size ? q - size : q;
+}
+__device__ __forceinline__ float staged_process(const Ring& r, int position, float fraction, RingWindow w, int& bad) {
+	const int i = position, j = ring_succ(i, r.size);
+	bad |= (int)(ring_in_window(i, r.size, w) || ring_in_window(j, r.size, w));
+	const float a = r.rd(i), b = r.rd(j);
+	return a + fraction * (b - a);
+}
+__device__ __forceinline__ float staged_tap_int(const Ring& r, int position, int delay, RingWindow w, int& bad) {
+	int read = (position - 1) - delay;
+	if (read < 0) read += r.size;
+	read = read < 0 ? r.size : (read > r.size ? r.size : read);
+	bad |= (int)ring_in_window(read, r.size, w);
+	return r.rd(read);
+}
+__device__ __forceinline__ float staged_tap_float(const Ring& r, int position, float delay, RingWindow w, int& bad) {
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += r.size;
+	const int i = (int)read < 0 ? 0 : (int)read;
+	const float fraction = read - i;
+	const int j = (i + 1) % r.size;
+	bad |= (int)(ring_in_window(i, r.size, w) || ring_in_window(j, r.size, w));
+	const float a = r.rd(i), b = r.rd(j);
+	return a + fraction * (b - a);
+}
+__device__ __forceinline__ float staged_tap_stereo(const Ring& r, int position, float delay, RingWindow w, int& bad) {
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += r.size;
+	const float f = (float)floor((double)read);
+	const float frac = read - f;
+	const int i = (int)read;
+	const int j = (i == r.size - 1) ? 0 : (i + 1);
+	const bool pad = i >= r.size || i < 0;
+	const int ri = pad ? 0 : i, rj = pad ? 0 : j;
+	bad |= (int)(!pad && (ring_in_window(ri, r.size, w) || ring_in_window(rj, r.size, w)));
+	const float a = pad ? 0.f : r.rd(ri), b = pad ? 0.f : r.rd(rj);
+	return a * (1.f - frac) + b * frac;
+}
 __device__ __forceinline__ float delay_lagrange(const Ring& r, int position, float delay) {
 	const int SIZE = r.size;
 	float read = (float)(position - 1) - delay;

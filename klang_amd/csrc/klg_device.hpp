@@ -192,6 +192,10 @@ __device__ __forceinline__ float basic_sine(BOsc& o) {                    // dou
 	phase_advance(o.position, o.increment);
 	return y;
 }
+// the two halves of basic_sine for code that runs them in different places (the staged effect kernel of klg_graph_staged.hpp: the phase walk is the
+// oscillator's state and stays in sample order, the sine of each sample's argument is taken with samples side by side): same operations, same values
+__device__ __forceinline__ float basic_sine_arg(BOsc& o) { const float x = o.position + o.offset; phase_advance(o.position, o.increment); return x; }
+__device__ __forceinline__ float basic_sine_of(float x) { return (float)sin_f64((double)x); }
 __device__ __forceinline__ float basic_saw(BOsc& o) { const float y = o.position * KLG_PI_INV - 1.f; phase_advance(o.position, o.increment); return y; }
 __device__ __forceinline__ float basic_triangle(BOsc& o) { const float y = fabsf(2.f * o.position * KLG_PI_INV - 2.f) - 1.f; phase_advance(o.position, o.increment); return y; }
 __device__ __forceinline__ float basic_square(BOsc& o) { const float y = o.position > KLG_PI_F ? 1.f : -1.f; phase_advance(o.position, o.increment); return y; }

@@ -42,7 +42,7 @@ struct klg_fx {
 	bool timing = false; std::vector<hipEvent_t> tev; int launches = 0;
 	// graph effects (klg_graph.hpp, `kind effect`): hipRTC code object, per-instance controls in HBM
 	const graphrt::Compiled* graph = nullptr;
-	hipModule_t module = nullptr; hipFunction_t graph_fn = nullptr;
+	hipModule_t module = nullptr; hipFunction_t graph_fn = nullptr, staged_fn = nullptr;   // staged_fn: klg_fx_staged of the same code object, when the body has a sample-parallel form
 	int channels = 2;
 	float* d_controls = nullptr; std::vector<float> h_controls; bool controls_dirty = false;
 	// Noise ops: the block's rand() draws, staged through a small ring of pinned buffers (a slot is reused once its copy + kernel are done)
@@ -196,6 +196,7 @@ static klg_fx* fx_create_graph_on(int device, const char* program, int instances
 	ok = ok && hipMemset(f->d_rings, 0, ring * 4) == hipSuccess;                       // Delay() : buffer(SIZE + 1, 0)
 	ok = ok && hipModuleLoadData(&f->module, c->code.data()) == hipSuccess;
 	ok = ok && hipModuleGetFunction(&f->graph_fn, f->module, c->name[0].c_str()) == hipSuccess;
+	if (ok && c->staged && hipModuleGetFunction(&f->staged_fn, f->module, "klg_fx_staged") != hipSuccess) { (void)hipGetLastError(); f->staged_fn = nullptr; }   // the sample-parallel form of the same body (klg_graph_staged.hpp)
 	if (!ok) { fail(KLG_ERR_NOMEM, "klg_fx_create_graph: device allocation / module load failed (%zu ring bytes): %s", ring * 4, hipGetErrorString(hipGetLastError())); fx_free(f); return nullptr; }
 	std::vector<uint32_t> init((size_t)f->words * f->kpad, 0u);
 	if (initial_record) { const uint32_t* r = (const uint32_t*)initial_record; for (int w = 0; w < f->words; w++) std::fill(init.begin() + (size_t)w * f->kpad, init.begin() + (size_t)(w + 1) * f->kpad, r[w]); }
@@ -210,6 +211,19 @@ static klg_fx* fx_create_graph_on(int device, const char* program, int instances
 	return f;
 }
 
+// replaces nothing (diagnostics): how a graph effect bank runs its recorded body
+extern "C" int klg_fx_graph_form(const klg_fx* f, int* instances_per_workgroup, int* samples_per_chunk, int* levels, int* lds_values, char* why, size_t why_cap) {
+	if (!f) return fail(KLG_ERR_INVALID, "klg_fx_graph_form: NULL handle");
+	if (f->multi) return klg_fx_graph_form(f->multi->shard[0], instances_per_workgroup, samples_per_chunk, levels, lds_values, why, why_cap);
+	if (!f->graph) return fail(KLG_ERR_INVALID, "klg_fx_graph_form: not a graph effect bank (klg_fx_create_graph)");
+	const bool staged = f->staged_fn != nullptr;
+	if (instances_per_workgroup) *instances_per_workgroup = staged ? f->graph->staged_G : FX_WG;
+	if (samples_per_chunk) *samples_per_chunk = staged ? f->graph->staged_C : 1;
+	if (levels) *levels = staged ? f->graph->staged_levels : 1;
+	if (lds_values) *lds_values = staged ? f->graph->staged_slots : 0;
+	if (why && why_cap) { snprintf(why, why_cap, "%s", staged ? "" : f->graph->staged_why.c_str()); }
+	return staged ? 1 : 0;
+}
 extern "C" void klg_fx_destroy(klg_fx* f) { if (!f) return; DeviceGuard bound(f->device); fx_free(f); }
 extern "C" size_t klg_fx_state_bytes(const klg_fx* f) {
 	if (!f) return 0;
@@ -405,7 +419,10 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		a.rand = f->d_rand[slot]; a.rand_per_instance = (int)per;
 	}
 	void* params[] = { &a };
-	{ TimedLaunch timed(f); HIP_TRY(klg_module_launch(f->graph_fn, (unsigned)(f->kpad / FX_WG), FX_WG, 0, st, params)); }
+	// G instances x C samples per workgroup, level by level (klg_graph_staged.hpp) — or, for a body that has no such form (Compiled::staged_why), one lane per
+	// instance walking the samples in order.  Same bits either way (tests/test_gpu_fx_facade.py runs both).
+	if (f->staged_fn) { TimedLaunch timed(f); HIP_TRY(klg_module_launch(f->staged_fn, (unsigned)(f->kpad / (size_t)f->graph->staged_G), (unsigned)f->graph->staged_threads, (unsigned)f->graph->staged_lds, st, params)); }
+	else { TimedLaunch timed(f); HIP_TRY(klg_module_launch(f->graph_fn, (unsigned)(f->kpad / FX_WG), FX_WG, 0, st, params)); }
 	if (slot >= 0) HIP_TRY(hipEventRecord(f->rand_done[slot], st));
 	f->samples += (unsigned long long)n;
 	return 0;

@@ -15,12 +15,19 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+#include <cstdarg>
+#include <functional>
+
 #include "../../include/klang_mi355_graph.h"
 
 namespace klg { namespace graphrt {
 
 using graph::Program;
 using graph::Op;
+} }
+#include "klg_graph_staged.hpp"
+namespace klg { namespace graphrt {
 
 // ------------------------------------------------------------------------------------------------
 // source generation
@@ -42,7 +49,7 @@ inline bool x2_eligible(const Program& g) {
 	return true;
 }
 
-inline std::string generate_source(const Program& g, bool x2 = false) {
+inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan* staged = nullptr) {
 	using namespace graph;
 	// type names of the generated body: one voice per lane, or two (the packed primitives overload the scalar names)
 	const std::string TF = x2 ? "f2" : "float", TI = x2 ? "i2" : "int", TU = x2 ? "u2" : "uint32_t", T2 = x2 ? "2" : "";
@@ -66,9 +73,15 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	uint64_t mask[graph::MAX_WORDS / 64] = { 1ull };                      // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
 	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { " + TI + " stage; float tinc;" + (g.noise_calls() ? " int sidx;" : ""), begin, end, body;
-	const int noise_calls = g.noise_calls(); int noise_k = 0;
+	const int noise_calls = g.noise_calls();
+	std::vector<int> noise_index(g.ops.size(), 0);                          // OP_NOISE: which of the sample's draws (program order)
+	{ int nk = 0; for (size_t oi = 0; oi < g.ops.size(); oi++) if (g.ops[oi].code == OP_NOISE) noise_index[oi] = nk++; }
+	std::vector<std::string> node_begin(g.nodes.size()), node_end(g.nodes.size());   // each node's share of begin() / end() (the staged effect kernel loads and commits nodes one by one)
+	std::string ctl_begin;
 	for (size_t i = 0; i < g.nodes.size(); i++) {
 		const int k = g.nodes[i], w0 = g.node_word0((int)i);
+		const size_t begin_at = begin.size(), end_at = end.size();
+		struct Slice { std::string& from; size_t at; std::string& to; ~Slice() { to = from.substr(at); } } slice_b = { begin, begin_at, node_begin[i] }, slice_e = { end, end_at, node_end[i] };
 		const std::string n = fmt("L.n%zu", i);
 		auto R = [&](int off) { return fmt("r.w[%d]", w0 + off); };
 		auto F = [&](int off) { return fmt("u2f(r.w[%d])", w0 + off); };
@@ -219,10 +232,12 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	if (fx) {                                                         // an effect's dials are the block's (klg_fx_set_control uploads them before the launch): read once, not in every sample
 		bool used[KLG_MAX_CTL] = {};
 		for (const Op& o : g.ops) if ((o.code == OP_CTL || o.code == OP_SMOOTH) && ctlvar[o.imm & 7u] < 0 && o.imm < (unsigned)KLG_MAX_CTL) used[o.imm] = true;
-		for (unsigned i = 0; i < (unsigned)KLG_MAX_CTL; i++) if (used[i]) { live += fmt(" float ctl%u;", i); begin += fmt("\t\tL.ctl%u = c.ctl[%u];\n", i, i); }
+		for (unsigned i = 0; i < (unsigned)KLG_MAX_CTL; i++) if (used[i]) { live += fmt(" float ctl%u;", i); ctl_begin += fmt("\t\tL.ctl%u = c.ctl[%u];\n", i, i); }
+		begin += ctl_begin;
 	}
 	live += " };\n";
 	std::map<int, uint32_t> const_of;                                    // single-assignment registers holding a literal
+	for (const Op& o : g.ops) if (o.code == OP_CONST) const_of[o.dst] = o.imm;
 	int if_depth = 0; std::vector<std::string> stop_at_end;
 	// structured branches: the phis that follow an `endif` are assigned at the end of each side of their `if`
 	std::vector<int> match_else(g.ops.size(), -1), match_endif(g.ops.size(), -1), if_of(g.ops.size(), -1);
@@ -324,14 +339,15 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		return e;
 	};
 	std::string prologue;                                                // Effect::prepare(): once per block, at the end of begin()
-	for (size_t oi = 0; oi < g.ops.size(); oi++) {
+	// one op's statement(s) appended to `body`.  assign: `r<dst> = ...` into a register declared elsewhere instead of `const float r<dst> = ...`
+	// (the staged effect kernel declares registers that live across its phases, or inside a branch, up front)
+	auto emit_op = [&](size_t oi, std::string& body, bool assign) {
 		const Op& o = g.ops[oi];
-		if ((int)oi == g.prepare_ops && g.prepare_ops) { prologue = body; body.clear(); }
-		emit_hoists(body, (int)oi);
-		const std::string d = "\t\tconst " + TF + fmt(" r%d = ", o.dst), n = fmt("L.n%d", o.node), a = fmt("r%d", o.a), b = fmt("r%d", o.b);
+		const std::string d = assign ? fmt("\t\tr%d = ", o.dst) : "\t\tconst " + TF + fmt(" r%d = ", o.dst), n = fmt("L.n%d", o.node), a = fmt("r%d", o.a), b = fmt("r%d", o.b);
+		const std::string dd = assign ? fmt("\t\tr%d = ", o.dst) : fmt("\t\tconst double r%d = ", o.dst);
 		const int k = (o.node >= 0 && o.node < (int)g.nodes.size()) ? g.nodes[(size_t)o.node] : -1;
 		switch (o.code) {
-		case OP_CONST: body += d + "kf<" + TF + fmt(">(0x%08xu);\n", o.imm); const_of[o.dst] = o.imm; break;
+		case OP_CONST: body += d + "kf<" + TF + fmt(">(0x%08xu);\n", o.imm); break;
 		case OP_CTL: body += d + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d;\n", ctlvar[o.imm & 7u]) : fx ? fmt("L.ctl%u;\n", o.imm) : fmt("ctl_read(c, %uu);\n", o.imm)); break;   // (a control the effect writes: its own copy)
 		case OP_SETCTL: body += d + "(" + a + fmt(" < u2f(0x%08xu)) ? u2f(0x%08xu) : (u2f(0x%08xu) < ", fbits(g.dials[o.imm & 7u].min), fbits(g.dials[o.imm & 7u].min), fbits(g.dials[o.imm & 7u].max)) + a + fmt(") ? u2f(0x%08xu) : ", fbits(g.dials[o.imm & 7u].max)) + a + ";\n\t\t" + n + fmt(" = r%d;\n", o.dst); break;   // Control::set klang.h:1725-1728
 		case OP_ABS: body += d + "__builtin_fabsf(" + a + ");\n"; break;
@@ -379,13 +395,13 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 		} break;
 		case OP_NEG: body += d + "-" + a + ";\n"; break;
 		// double registers (include/klang_mi355_graph.h): IEEE double arithmetic, contraction off like everything else
-		case OP_F2D: body += fmt("\t\tconst double r%d = (double)", o.dst) + a + ";\n"; break;
-		case OP_DCONST: body += fmt("\t\tconst double r%d = __longlong_as_double(0x%08x00000000ll);\n", o.dst, o.imm); break;
-		case OP_DLOW: body += fmt("\t\tconst double r%d = __longlong_as_double(__double_as_longlong(", o.dst) + a + fmt(") | 0x%08xll);\n", o.imm); break;
-		case OP_DADD: body += fmt("\t\tconst double r%d = ", o.dst) + a + " + " + b + ";\n"; break;
-		case OP_DSUB: body += fmt("\t\tconst double r%d = ", o.dst) + a + " - " + b + ";\n"; break;
-		case OP_DMUL: body += fmt("\t\tconst double r%d = ", o.dst) + a + " * " + b + ";\n"; break;
-		case OP_DDIV: body += fmt("\t\tconst double r%d = ", o.dst) + a + " / " + b + ";\n"; break;
+		case OP_F2D: body += dd + "(double)" + a + ";\n"; break;
+		case OP_DCONST: body += dd + fmt("__longlong_as_double(0x%08x00000000ll);\n", o.imm); break;
+		case OP_DLOW: body += dd + "__longlong_as_double(__double_as_longlong(" + a + fmt(") | 0x%08xll);\n", o.imm); break;
+		case OP_DADD: body += dd + a + " + " + b + ";\n"; break;
+		case OP_DSUB: body += dd + a + " - " + b + ";\n"; break;
+		case OP_DMUL: body += dd + a + " * " + b + ";\n"; break;
+		case OP_DDIV: body += dd + a + " / " + b + ";\n"; break;
 		case OP_D2F: body += d + "(float)" + a + ";\n"; break;
 		case OP_CMP: { static const char* rel[6] = { "<", ">", "<=", ">=", "==", "!=" }; body += d + "(" + a + " " + rel[o.imm <= 5u ? o.imm : 0u] + " " + b + ") ? 1.f : 0.f;\n"; } break;
 		case OP_IF:
@@ -402,7 +418,7 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			for (const Op* ph : phis_of(if_of[oi])) body += fmt("\t\tr%d = r%d;\n", ph->dst, ph->b);
 			body += "\t\t}\n";
 			break;
-		case OP_NOISE: body += d + (o.imm ? "fast_noise(" : "basic_noise(") + fmt("c.rand[L.sidx * %d + %d]);\n", noise_calls, noise_k++); break;
+		case OP_NOISE: body += d + (o.imm ? "fast_noise(" : "basic_noise(") + fmt("c.rand[L.sidx * %d + %d]);\n", noise_calls, noise_index[oi]); break;
 		case OP_DELAYOUT:
 			if (hoist_of[oi] >= 0) body += d + "delay_process_h(" + ring(o.node) + ", " + n + fmt("t, h%d, h%da, h%db, ", hoist_of[oi], hoist_of[oi], hoist_of[oi]) + hazard_of(hoist_of[oi]) + ");\n";
 			else body += d + "delay_process(" + ring(o.node) + ", " + n + "t);\n";
@@ -431,8 +447,14 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 			body += d + "fsine_process(" + n + ", fsine_rel_offset(" + (o.a >= 0 ? a : std::string("0.f")) + ")) * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs) * " + n + "a);\n";
 			break;
 		}
+	};
+	for (size_t oi = 0; oi < g.ops.size(); oi++) {
+		if ((int)oi == g.prepare_ops && g.prepare_ops) { prologue = body; body.clear(); }
+		emit_hoists(body, (int)oi);
+		emit_op(oi, body, false);
 	}
 	if (g.prepare_ops && (int)g.ops.size() == g.prepare_ops) { prologue = body; body.clear(); }
+	const std::string begin_core = begin;                                 // (effects: begin() without the per-block prologue — what a chunk walked by the plain body inside the staged kernel starts from)
 	begin += prologue;
 	std::string s;
 	s += "// generated by klg_graph.hpp from a recorded klang process() body (include/klang_mi355_graph.h)\n";
@@ -460,9 +482,23 @@ inline std::string generate_source(const Program& g, bool x2 = false) {
 	if (fx) {
 		s += fmt("\tstatic constexpr int kChannels = %d;\n", g.channels);
 		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const FxCtx& c) {\n\t\tL.unused_ = 0; L.sidx = 0; (void)r; (void)c;\n" + begin + "\t}\n";
+		s += "\tstatic __device__ __forceinline__ void begin_core(Live& L, const Rec& r, const FxCtx& c) {\n\t\tL.unused_ = 0; L.sidx = 0; (void)r; (void)c;\n" + begin_core + "\t}\n";
 		s += "\tstatic __device__ __forceinline__ void sample(Live& L, const FxCtx& c, float in0, float in1, float& out0, float& out1) {\n\t\t(void)in0; (void)in1;\n" + body
 			+ fmt("\t\tout0 = r%d;\n", g.ret) + (g.channels == 2 ? fmt("\t\tout1 = r%d;\n", g.ret_r) : std::string("\t\t(void)out1;\n")) + "\t\tL.sidx++;\n\t}\n";
-		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\t(void)L; (void)r;\n" + end + "\t}\n};\n}\n";
+		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\t(void)L; (void)r;\n" + end + "\t}\n};\n";
+		// the sample-parallel form of the same body (klg_graph_staged.hpp), when the program has one: KLG_FX_STAGED=0 never, KLG_FX_STAGED_G / _C force the shape
+		if (staged) {
+			const char* se = getenv("KLG_FX_STAGED"), *ge = getenv("KLG_FX_STAGED_G"), *ce = getenv("KLG_FX_STAGED_C");
+			if (se && se[0] == '0') { staged->ok = false; staged->why = "KLG_FX_STAGED=0"; }
+			else {
+				StagedInput in;
+				in.g = &g; in.emit_op = emit_op; in.node_begin = &node_begin; in.node_end = &node_end; in.ctl_begin = ctl_begin; in.ring_off = &ring_off; in.inputs = &inputs; in.ctlvar = ctlvar;
+				in.G = ge ? atoi(ge) : 0; in.C = ce ? atoi(ce) : 0;
+				*staged = plan_staged(in);
+				if (staged->ok) s += staged->source;
+			}
+		}
+		s += "}\n";
 	}
 	else {
 		const std::string ctx = x2 ? "BlockCtx2" : "BlockCtx";
@@ -563,7 +599,8 @@ struct Rtc {
 
 struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; int note_channels = 1;   // note_channels: 2 = the notes' `out` is stereo (ret2 in a note program)
 	 long long ring_rows = 0; int noise_calls = 0; struct Smooth { int word, ctl, calls; }; std::vector<Smooth> smooths; int ctlvar_word[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };   // ctlvar_word[i]: the record word of control i's own copy (an effect that writes it), else -1
-	 bool x2 = false; std::vector<std::pair<long long, int>> delays; };   // delays: (first ring row, SIZE) of each delay node in node order   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
+	 bool x2 = false; std::vector<std::pair<long long, int>> delays;
+	 bool staged = false; std::string staged_why; int staged_G = 0, staged_C = 0, staged_threads = 0, staged_lds = 0, staged_levels = 0, staged_slots = 0; };   // staged: the code object also holds klg_fx_staged (klg_graph_staged.hpp)   // delays: (first ring row, SIZE) of each delay node in node order   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
 
 // directory holding klg_kernels.hpp etc.: next to the shared library (klang_amd/csrc), or $KLG_GRAPH_SRC
 inline std::string source_dir() {
@@ -587,12 +624,15 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	const std::string perr = g.parse(text);
 	if (!perr.empty()) return perr;
 	if (x2 && !x2_eligible(g)) return "graph program: not every node / op has a two-voices-per-lane form";
-	const std::string key = (x2 ? "x2\n" : "") + g.text();
+	auto envs = [](const char* n) { const char* e = getenv(n); return std::string(e ? e : ""); };
+	const std::string key = (x2 ? "x2\n" : "") + (g.channels ? "staged " + envs("KLG_FX_STAGED") + "," + envs("KLG_FX_STAGED_G") + "," + envs("KLG_FX_STAGED_C") + "," + envs("KLG_FX_STAGED_LDS") + "\n" : std::string()) + g.text();
 	auto it = cache.find(key);
 	if (it != cache.end()) { *out = &it->second; return ""; }
 	if (!rtc.load()) return rtc.error;
 	Compiled c;
-	c.source = generate_source(g, x2);
+	StagedPlan plan;
+	c.source = generate_source(g, x2, g.channels ? &plan : nullptr);
+	c.staged = plan.ok; c.staged_why = plan.why; c.staged_G = plan.G; c.staged_C = plan.C; c.staged_threads = plan.threads; c.staged_lds = plan.lds_bytes; c.staged_levels = plan.levels; c.staged_slots = plan.slots;
 	c.words = g.words(); c.channels = g.channels; c.x2 = x2; c.note_channels = g.stereo_note() ? 2 : 1;
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY || g.nodes[i] == graph::N_NDELAY) { c.delays.push_back({ c.ring_rows, g.arg((int)i) }); c.ring_rows += g.arg((int)i) + 1; }   // (+ the pad element of every line: klg_delay.hpp)
 	c.noise_calls = g.noise_calls();

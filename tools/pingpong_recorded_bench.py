@@ -32,8 +32,12 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream())                   # one stream for torch's work and the library's launches
     for K, dials in [(int(x), d) for x in (sys.argv[1:] or [4096, 16384]) for d in ("default", "random")]:
         rng = np.random.default_rng(3)
+        def recorded(staged):
+            os.environ["KLG_FX_STAGED"] = "1" if staged else "0"          # (read when the program is compiled; the two forms are cached separately)
+            return klang_amd.FxBank(PROGRAM, K, max_block=N, initial_record=initial_record(), channels=2)
         banks = {"hand-written klg_fx_pingpong_x": klang_amd.FxBank("pingpong", K, max_block=N),
-                 "recorded graph (klg_fx_graph)": klang_amd.FxBank(PROGRAM, K, max_block=N, initial_record=initial_record(), channels=2)}
+                 "recorded graph (klg_fx_graph)": recorded(True), "recorded graph, one lane per instance": recorded(False)}
+        form = banks["recorded graph (klg_fx_graph)"].graph_form()
         ctl = [] if dials == "default" else [(k, c, float(rng.uniform(lo, hi))) for k in range(0, K, 7) for c, lo, hi in ((0, 0.2, 0.9), (1, 0.01, 0.6), (2, 0.0, 1.0), (3, 0.01, 1.0), (5, 0.0, 0.4))]
         outs = {}
         for name, bank in banks.items():
@@ -54,8 +58,11 @@ def main():
         if not same and os.environ.get("KLG_BENCH_DEBUG"):
             d = (a.view(torch.int32) != b.view(torch.int32)).nonzero()
             print("differing", len(d), "of", a.numel(), "first", d[:5].tolist(), "max abs", float((a - b).abs().max()), "values", [(float(a[tuple(i)]), float(b[tuple(i)])) for i in d[:5]], file=sys.stderr)
+        c = outs["recorded graph, one lane per instance"]
+        same_lane = bool(torch.equal(a.view(torch.int32), c.view(torch.int32)))
         hand, rec = outs["hand-written klg_fx_pingpong_x ms"], outs["recorded graph (klg_fx_graph) ms"]
-        print(json.dumps(dict(effect="examples/PingPong.k", K=K, N=N, dials=dials, bit_identical=same, peak=float(a.abs().max()), hand_written_kernel_ms=hand, recorded_kernel_ms=rec,
+        print(json.dumps(dict(effect="examples/PingPong.k", K=K, N=N, dials=dials, bit_identical=same, one_lane_form_bit_identical=same_lane, form=form, peak=float(a.abs().max()), hand_written_kernel_ms=hand, recorded_kernel_ms=rec,
+                              recorded_one_lane_per_instance_ms=outs["recorded graph, one lane per instance ms"],
                               recorded_vs_hand=rec / hand, hand_alg_TBps=K * N * 32 / (hand * 1e-3) / 1e12, recorded_alg_TBps=K * N * 32 / (rec * 1e-3) / 1e12)), flush=True)
 
 

@@ -28,11 +28,22 @@ def main():
     for K in [int(x) for x in sys.argv[1:]] or [256, 1024]:
         io = torch.rand((K, 2, N), device="cuda") - 0.5
         out = {"K": K, "record_words": int(RECORD.size)}
+        def recorded(staged):
+            os.environ["KLG_FX_STAGED"] = "1" if staged else "0"          # (read when the program is compiled; the two forms are cached separately)
+            return klang_amd.FxBank(PROGRAM, K, max_block=N, initial_record=RECORD, channels=2)
+        res = {}
         for name, make in (("hand_written_ms", lambda: klang_amd.FxBank("reverb", K, max_block=N)),
-                           ("recorded_graph_ms", lambda: klang_amd.FxBank(PROGRAM, K, max_block=N, initial_record=RECORD, channels=2))):
+                           ("recorded_graph_ms", lambda: recorded(True)), ("recorded_one_lane_per_instance_ms", lambda: recorded(False))):
+            if name == "recorded_one_lane_per_instance_ms" and os.environ.get("KLG_BENCH_SKIP_PLAIN"): continue
             bank = make()
+            if name == "recorded_graph_ms": out["form"] = bank.graph_form()
+            x = io.clone()
+            for _ in range(6): bank.process_device(x.data_ptr(), N, torch.cuda.current_stream().cuda_stream)   # six blocks of the bank's own output fed back: what the forms are compared on
+            torch.cuda.synchronize(); res[name] = x.clone()
             out[name] = timed(bank, io.clone(), N)
             bank.close(); torch.cuda.empty_cache()
+        if "recorded_one_lane_per_instance_ms" in res: out["forms_bit_identical"] = bool(torch.equal(res["recorded_graph_ms"].view(torch.int32), res["recorded_one_lane_per_instance_ms"].view(torch.int32)))
+        out["recorded_equals_hand_written"] = bool(torch.equal(res["recorded_graph_ms"].view(torch.int32), res["hand_written_ms"].view(torch.int32)))
         out["ratio"] = out["recorded_graph_ms"] / out["hand_written_ms"]
         print(json.dumps(out), flush=True)
 
