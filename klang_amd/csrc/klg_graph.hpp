@@ -349,7 +349,11 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		switch (o.code) {
 		case OP_CONST: body += d + "kf<" + TF + fmt(">(0x%08xu);\n", o.imm); break;
 		case OP_CTL: body += d + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d;\n", ctlvar[o.imm & 7u]) : fx ? fmt("L.ctl%u;\n", o.imm) : fmt("ctl_read(c, %uu);\n", o.imm)); break;   // (a control the effect writes: its own copy)
-		case OP_SETCTL: body += d + "(" + a + fmt(" < u2f(0x%08xu)) ? u2f(0x%08xu) : (u2f(0x%08xu) < ", fbits(g.dials[o.imm & 7u].min), fbits(g.dials[o.imm & 7u].min), fbits(g.dials[o.imm & 7u].max)) + a + fmt(") ? u2f(0x%08xu) : ", fbits(g.dials[o.imm & 7u].max)) + a + ";\n\t\t" + n + fmt(" = r%d;\n", o.dst); break;   // Control::set klang.h:1725-1728
+		case OP_SETCTL: {                                                  // Control::set klang.h:1725-1728: (x < min) ? min : (max < x) ? max : x — as two selects (min < max: at most one of the tests holds; a NaN passes both)
+			const uint32_t mn = fbits(g.dials[o.imm & 7u].min), mx = fbits(g.dials[o.imm & 7u].max);
+			body += fmt("\t\tconst float r%dh = (u2f(0x%08xu) < ", o.dst, mx) + a + fmt(") ? u2f(0x%08xu) : ", mx) + a + ";\n";
+			body += d + "(" + a + fmt(" < u2f(0x%08xu)) ? u2f(0x%08xu) : r%dh;\n\t\t", mn, mn, o.dst) + n + fmt(" = r%d;\n", o.dst);
+		} break;
 		case OP_ABS: body += d + "__builtin_fabsf(" + a + ");\n"; break;
 		case OP_PARAM: body += d + n + ";\n"; break;
 		case OP_OSC: {
@@ -625,7 +629,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	if (!perr.empty()) return perr;
 	if (x2 && !x2_eligible(g)) return "graph program: not every node / op has a two-voices-per-lane form";
 	auto envs = [](const char* n) { const char* e = getenv(n); return std::string(e ? e : ""); };
-	const std::string key = (x2 ? "x2\n" : "") + (g.channels ? "staged " + envs("KLG_FX_STAGED") + "," + envs("KLG_FX_STAGED_G") + "," + envs("KLG_FX_STAGED_C") + "," + envs("KLG_FX_STAGED_LDS") + "\n" : std::string()) + g.text();
+	const std::string key = (x2 ? "x2\n" : "") + (g.channels ? "staged " + envs("KLG_FX_STAGED") + "," + envs("KLG_FX_STAGED_G") + "," + envs("KLG_FX_STAGED_C") + "," + envs("KLG_FX_STAGED_LDS") + "," + envs("KLG_FX_STAGED_SKIP") + "," + envs("KLG_FX_STAGED_STAMP") + "," + envs("KLG_FX_STAGED_PIPE") + "\n" : std::string()) + g.text();
 	auto it = cache.find(key);
 	if (it != cache.end()) { *out = &it->second; return ""; }
 	if (!rtc.load()) return rtc.error;

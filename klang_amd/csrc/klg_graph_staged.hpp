@@ -26,7 +26,8 @@ namespace klg { namespace graphrt {
 
 struct StagedPlan {
 	bool ok = false; std::string why;
-	int G = 16, C = 32, threads = 0, lds_bytes = 0, levels = 0, slots = 0, serial_ops = 0, parallel_ops = 0;
+	int G = 16, C = 32, threads = 0, lds_bytes = 0, levels = 0, slots = 0, serial_ops = 0, parallel_ops = 0; bool pipelined = false;
+	std::string prefix_commit;                                           // (scratch of plan_staged)
 	std::string source;                                                  // the kernel (appended to the generated translation unit, inside namespace klg)
 };
 
@@ -204,39 +205,61 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		if (v.code == OP_NOISE || v.code == OP_IN) return refuse("input inside a serial component");
 	}
 
-	// ---- levels (even: parallel, odd: serial) ----
-	std::vector<int> level((size_t)NV, 0);
-	std::vector<int> clevel((size_t)ncomp, -1);
+	// ---- the control path runs a chunk AHEAD ----
+	// Ops that nothing of the chunk's audio reaches — no ring read, no `in`, no input() upstream of them: dial smoothers, LFOs, the delay times they set — form the
+	// PREFIX; the rest is the SUFFIX.  While the suffix levels of chunk c run, the prefix levels of chunk c + 1 run beside them (serial components on other waves,
+	// parallel ones in the same lanes): a chunk then costs the longer of the two level sequences, not their sum.  No rollback is needed when chunk c fails its ring
+	// check and is walked by the plain body: the prefix of chunk c + 1 depends on nothing that walk computes differently (it is the same arithmetic on the same
+	// state), so what was computed ahead stays valid.  The prefix keeps its own copy of the records (end of chunk x in copy x & 1), handed to the architectural
+	// copy when chunk x is complete.
 	std::vector<std::vector<int>> pred((size_t)NV);
 	for (int u = 0; u < NV; u++) for (int w : succ[(size_t)u]) pred[(size_t)w].push_back(u);
+	std::vector<char> pfx((size_t)NV, 0);
+	bool pipelined = false;
+	{
+		std::vector<char> sfx((size_t)NV, 0); std::vector<int> work;
+		for (int i = 0; i < NV; i++) { const int c = V[(size_t)i].code; if (comp[(size_t)i] >= 0 && (c == OP_DELAYOUT || c == OP_DELAYTAP || c == OP_DELAYIN || c == OP_IN)) { sfx[(size_t)i] = 1; work.push_back(i); } }
+		while (!work.empty()) { const int u = work.back(); work.pop_back(); for (int w : succ[(size_t)u]) if (!sfx[(size_t)w]) { sfx[(size_t)w] = 1; work.push_back(w); } }
+		bool serial_prefix = false, any_suffix = false;
+		for (int i = 0; i < NV; i++) if (comp[(size_t)i] >= 0) { if (!sfx[(size_t)i]) { pfx[(size_t)i] = 1; if (cserial[(size_t)comp[(size_t)i]]) serial_prefix = true; } else any_suffix = true; }
+		const char* pe = getenv("KLG_FX_STAGED_PIPE");
+		pipelined = serial_prefix && any_suffix && !(pe && pe[0] == '0');
+		if (!pipelined) std::fill(pfx.begin(), pfx.end(), 0);
+	}
+	auto cpfx = [&](int c, const std::vector<std::vector<int>>& members) { return !members[(size_t)c].empty() && pfx[(size_t)members[(size_t)c][0]]; };
+
+	// ---- levels (even: parallel, odd: serial), counted inside each of the two groups ----
+	std::vector<int> level((size_t)NV, 0);
+	std::vector<int> clevel((size_t)ncomp, -1);
 	std::vector<std::vector<int>> members((size_t)ncomp);
 	for (int i = 0; i < NV; i++) if (comp[(size_t)i] >= 0) members[(size_t)comp[(size_t)i]].push_back(i);
-	int guard_level = -2;
+	int guard_level = -2, pmax = -1;
 	for (int c = ncomp - 1; c >= 0; c--) {                                       // topological order
-		const bool ser = cserial[(size_t)c] != 0;
+		const bool ser = cserial[(size_t)c] != 0, pf = cpfx(c, members);
 		int lv = ser ? 1 : 0;
 		for (int m : members[(size_t)c]) for (int p : pred[(size_t)m]) {
-			const int pc = comp[(size_t)p]; if (pc == c) continue;
+			const int pc = comp[(size_t)p]; if (pc == c || cpfx(pc, members) != pf) continue;   // (what the prefix hands to the suffix was computed an iteration earlier)
 			const int pl = clevel[(size_t)pc]; const bool pser = cserial[(size_t)pc] != 0;
 			lv = std::max(lv, (ser == pser) ? pl : pl + 1);
 		}
 		clevel[(size_t)c] = lv;
+		if (pf) pmax = std::max(pmax, lv);
 		for (int m : members[(size_t)c]) { level[(size_t)m] = lv; const int code = V[(size_t)m].code; if (code == OP_DELAYTAP || code == OP_DELAYOUT) guard_level = std::max(guard_level, lv); }
 	}
 	// ring writes only after every ring read of the chunk has been issued and checked
 	for (int i = 0; i < NV; i++) if (V[(size_t)i].code == OP_DELAYIN) { level[(size_t)i] = std::max(level[(size_t)i], guard_level + 2); clevel[(size_t)comp[(size_t)i]] = level[(size_t)i]; }
 	int max_level = 0;
-	for (int i = 0; i < NV; i++) if (comp[(size_t)i] >= 0) max_level = std::max(max_level, level[(size_t)i]);
+	for (int i = 0; i < NV; i++) if (comp[(size_t)i] >= 0 && !pfx[(size_t)i]) max_level = std::max(max_level, level[(size_t)i]);
 	const int out_level = (max_level + 1) & ~1;                                  // the level that writes `out` into the tile and commits the delay heads (parallel)
 	const int last_level = std::max(out_level, guard_level + 2);
-	// ---- serial components -> strands (those of one level that feed each other stay together) -> waves ----
+	// ---- serial components -> strands (those of one level and group that feed each other stay together) -> waves ----
 	std::vector<int> strand((size_t)ncomp, -1);
 	{
 		std::vector<int> parent((size_t)ncomp); for (int c = 0; c < ncomp; c++) parent[(size_t)c] = c;
 		std::function<int(int)> find = [&](int x) { while (parent[(size_t)x] != x) { parent[(size_t)x] = parent[(size_t)parent[(size_t)x]]; x = parent[(size_t)x]; } return x; };
 		for (int u = 0; u < NV; u++) for (int w : succ[(size_t)u]) {
 			const int a = comp[(size_t)u], b = comp[(size_t)w];
-			if (a != b && cserial[(size_t)a] && cserial[(size_t)b] && clevel[(size_t)a] == clevel[(size_t)b]) parent[(size_t)find(a)] = find(b);
+			if (a != b && cserial[(size_t)a] && cserial[(size_t)b] && clevel[(size_t)a] == clevel[(size_t)b] && cpfx(a, members) == cpfx(b, members)) parent[(size_t)find(a)] = find(b);
 		}
 		for (int c = 0; c < ncomp; c++) if (cserial[(size_t)c]) strand[(size_t)c] = find(c);
 	}
@@ -246,50 +269,82 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 	// the plan for a given chunk length: waves, slots, LDS bytes; the source is generated once the chunk length fits the LDS budget
 	for (;; C /= 2) {
 		if (C < 8) return refuse("the values that cross levels do not fit the LDS budget at any chunk length");
-		const int NT = G * C, NWV = NT / 64;
-		if (NT < 64 || NT > 1024 || (NT & 63)) return refuse("G x C must be 64 .. 1024 lanes");
-		// strands of a level -> waves, heaviest first onto the lightest wave
+		// The serial loops get waves of their own (NSW of them, after the NTP = G x C lanes of the parallel levels): a loop of the control path then runs BESIDE the
+		// audio path's parallel level of the same interval — which mostly waits for its ring rows — instead of after it on one of its waves.
+		// In interval k the audio path runs its level k and the control path (of the next chunk) its level k + poff: poff = 1 when the control path has nothing on
+		// level 0 (the usual case: its level 0 would be arithmetic on dials, and that is invariant), so that its serial levels meet the audio path's parallel ones.
+		int poff = 0;
+		if (pipelined) { bool l0 = false; for (int i = 0; i < NV; i++) if (comp[(size_t)i] >= 0 && pfx[(size_t)i] && level[(size_t)i] == 0) l0 = true; poff = l0 ? 0 : 1; }
+		const int NTP = G * C;
+		if (NTP < 64 || NTP > 1024 || (NTP & 63)) return refuse("G x C must be 64 .. 1024 lanes");
+		int NSW = 1;
+		for (int lv = 1; lv <= std::max(max_level, pmax); lv += 2) for (int grp = 0; grp < 2; grp++) {
+			std::vector<int> st; for (int c = 0; c < ncomp; c++) if (cserial[(size_t)c] && clevel[(size_t)c] == lv && (cpfx(c, members) ? 1 : 0) == grp) st.push_back(strand[(size_t)c]);
+			std::sort(st.begin(), st.end()); st.erase(std::unique(st.begin(), st.end()), st.end());
+			NSW = std::max(NSW, (int)st.size());
+		}
+		if (const char* e = getenv("KLG_FX_STAGED_SW")) NSW = std::max(1, atoi(e));
+		NSW = std::min(NSW, std::min(4, (1024 - NTP) / 64));
+		// (only a pipelined plan has anything to run beside a serial loop: without one the loops take the waves of the parallel levels — more waves would only cost
+		// registers: the recorded Reverb.k with 8 + 4 waves per workgroup spilled and ran 1.7 x slower than with 4)
+		const bool own_waves = pipelined && NSW >= 1;
+		const int NT = own_waves ? NTP + 64 * NSW : NTP, NWV = own_waves ? NSW : NTP / 64;
+		// strands of a level -> serial waves, heaviest first onto the lightest wave; where both groups have loops in one interval the audio path takes the lower half
 		std::vector<int> wave_of((size_t)ncomp, 0);
-		for (int lv = 1; lv <= max_level; lv += 2) {
-			std::map<int, int> weight;
-			for (int c = 0; c < ncomp; c++) if (cserial[(size_t)c] && clevel[(size_t)c] == lv) weight[strand[(size_t)c]] += csize[(size_t)c];
-			std::vector<std::pair<int, int>> order; for (const auto& kv : weight) order.push_back({ kv.second, kv.first });
-			std::sort(order.begin(), order.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
-			std::vector<int> load((size_t)NWV, 0); std::map<int, int> wave_of_strand;
-			for (const auto& o : order) { int best = 0; for (int w = 1; w < NWV; w++) if (load[(size_t)w] < load[(size_t)best]) best = w; load[(size_t)best] += o.first; wave_of_strand[o.second] = best; }
-			for (int c = 0; c < ncomp; c++) if (cserial[(size_t)c] && clevel[(size_t)c] == lv) wave_of[(size_t)c] = wave_of_strand[strand[(size_t)c]];
+		for (int lv = 1; lv <= std::max(max_level, pmax); lv += 2) {
+			for (int grp = 0; grp < 2; grp++) {
+				bool mine = false, other = false;                                      // the other group's serial level of the same interval
+				const int olv = grp ? lv - poff : lv + poff;
+				for (int c = 0; c < ncomp; c++) if (cserial[(size_t)c]) { const int cg = cpfx(c, members) ? 1 : 0; if (cg == grp && clevel[(size_t)c] == lv) mine = true; if (pipelined && cg != grp && clevel[(size_t)c] == olv) other = true; }
+				if (!mine) continue;
+				const bool split = other && NWV >= 2;
+				const int w0 = (split && grp == 1) ? NWV / 2 : 0, w1 = (split && grp == 0) ? NWV / 2 : NWV;
+				std::map<int, int> weight;
+				for (int c = 0; c < ncomp; c++) if (cserial[(size_t)c] && clevel[(size_t)c] == lv && (cpfx(c, members) ? 1 : 0) == grp) weight[strand[(size_t)c]] += csize[(size_t)c];
+				std::vector<std::pair<int, int>> order; for (const auto& kv : weight) order.push_back({ kv.second, kv.first });
+				std::sort(order.begin(), order.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
+				std::vector<int> load((size_t)NWV, 0); std::map<int, int> wave_of_strand;
+				for (const auto& o : order) { int best = w0; for (int w = w0 + 1; w < w1; w++) if (load[(size_t)w] < load[(size_t)best]) best = w; load[(size_t)best] += o.first; wave_of_strand[o.second] = best; }
+				for (int c = 0; c < ncomp; c++) if (cserial[(size_t)c] && clevel[(size_t)c] == lv && (cpfx(c, members) ? 1 : 0) == grp) wave_of[(size_t)c] = wave_of_strand[strand[(size_t)c]];
+			}
 		}
 		auto ser_of = [&](int i) { return comp[(size_t)i] >= 0 && cserial[(size_t)comp[(size_t)i]] != 0; };
 		auto wave_of_op = [&](int i) { return comp[(size_t)i] >= 0 ? wave_of[(size_t)comp[(size_t)i]] : -1; };
+		auto live_op = [&](int i) { return !is_struct(V[(size_t)i].code) && !inv[(size_t)i] && comp[(size_t)i] >= 0; };
+		// is op i one of (group, level, wave)?  wave -1: the parallel ops of the level
+		auto in_block = [&](int i, bool pf, int lv, int wave) { return live_op(i) && (pfx[(size_t)i] != 0) == pf && level[(size_t)i] == lv && ((wave >= 0) == ser_of(i)) && (wave < 0 || wave_of_op(i) == wave); };
 		// ---- where each register lives ----
-		struct Reg { int def = -1; bool slot = false, chunk = false; int last = -1; int slot_id = -1; };
+		// chunk: a lane's own register across levels of its group; xrot: parallel prefix -> parallel suffix (computed an iteration ahead, handed over at the top of the
+		// loop); slot: through LDS — a prefix value in two buffers (the chunk's parity), a suffix value in a slot that is reused once it is dead
+		struct Reg { int def = -1; bool slot = false, chunk = false, xrot = false; int last = -1; int slot_id = -1; };
 		std::vector<Reg> regs((size_t)maxreg + 2);
-		auto use = [&](int r, int at_level, bool at_ser, int at_wave) {
+		auto use = [&](int r, bool at_pf, int at_level, bool at_ser, int at_wave) {
 			if (r < 0 || (size_t)r >= regs.size()) return;
 			const int d = def_at[(size_t)r]; if (d < 0 || inv[(size_t)d]) return;  // (a prepare() register cannot be named here: Program::validate)
 			Reg& R = regs[(size_t)r]; R.def = d;
-			const int dl = level[(size_t)d]; const bool dser = ser_of(d);
+			const int dl = level[(size_t)d]; const bool dser = ser_of(d), dpf = pfx[(size_t)d] != 0;
+			if (dpf != at_pf) { if (!dser && !at_ser) R.xrot = true; else { R.slot = true; R.last = 1 << 20; } return; }
 			if (!dser && !at_ser) { if (at_level != dl) R.chunk = true; }
 			else if (dser && at_ser && dl == at_level && wave_of_op(d) == at_wave) {}
 			else { R.slot = true; R.last = std::max(R.last, at_level); }
 		};
 		for (int i = 0; i < NV; i++) {
 			const VOp& v = V[(size_t)i];
-			if (is_struct(v.code) || inv[(size_t)i]) continue;
-			const bool s = ser_of(i); const int lv = level[(size_t)i], w = s ? wave_of_op(i) : -1;
-			if (v.a >= 0) use(v.a, lv, s, w);
-			if (v.b >= 0) use(v.b, lv, s, w);
-			for (const auto& pe : v.path) use(V[(size_t)pe.first].a, lv, s, w);
-			if (v.code == OP_PHI && phi_if[(size_t)i] >= 0) use(V[(size_t)phi_if[(size_t)i]].a, lv, s, w);
+			if (!live_op(i)) continue;
+			const bool s = ser_of(i), pf = pfx[(size_t)i] != 0; const int lv = level[(size_t)i], w = s ? wave_of_op(i) : -1;
+			if (v.a >= 0) use(v.a, pf, lv, s, w);
+			if (v.b >= 0) use(v.b, pf, lv, s, w);
+			for (const auto& pe : v.path) use(V[(size_t)pe.first].a, pf, lv, s, w);
+			if (v.code == OP_PHI && phi_if[(size_t)i] >= 0) use(V[(size_t)phi_if[(size_t)i]].a, pf, lv, s, w);
 		}
-		use(g.ret, out_level, false, -1);
-		if (CH == 2) use(g.ret_r, out_level, false, -1);
+		use(g.ret, false, out_level, false, -1);
+		if (CH == 2) use(g.ret_r, false, out_level, false, -1);
 		for (size_t r = 0; r < regs.size(); r++) if (regs[r].slot && is_dbl[r]) return refuse("a double register would have to cross levels");
-		// slots: intervals [def level, last use level], reused when disjoint
-		int nslots = 0;
+		// slots: suffix values by interval [def level, last use level], reused when disjoint; prefix values one (double-buffered) slot each
+		int nslots = 0, npslots = 0;
 		{
 			std::vector<int> order;
-			for (size_t r = 0; r < regs.size(); r++) if (regs[r].slot) order.push_back((int)r);
+			for (size_t r = 0; r < regs.size(); r++) if (regs[r].slot) { if (pfx[(size_t)regs[r].def]) regs[r].slot_id = npslots++; else order.push_back((int)r); }
 			std::sort(order.begin(), order.end(), [&](int x, int y) { const int lx = level[(size_t)regs[(size_t)x].def], ly = level[(size_t)regs[(size_t)y].def]; return lx != ly ? lx < ly : x < y; });
 			std::vector<int> free_after;                                            // per slot: the level after which it is free
 			for (int r : order) {
@@ -301,7 +356,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			}
 			nslots = (int)free_after.size();
 		}
-		const long long lds_words = (long long)NW * G + (long long)CH * C * G + (long long)nslots * C * G + 4;
+		const long long lds_words = (long long)NW * G * (pipelined ? 3 : 1) + (long long)CH * C * G + (long long)(nslots + 2 * npslots) * C * G + 4;
 		const char* le = getenv("KLG_FX_STAGED_LDS");
 		const long long budget = le ? atoll(le) : 100 * 1024;                 // (gfx950 grants a workgroup up to 160 KB)
 		if (lds_words * 4 > budget) { if (in.C > 0) return refuse("the requested chunk length does not fit the LDS budget"); continue; }
@@ -311,8 +366,13 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		auto F = [](const char* f, ...) { char b[1024]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return std::string(b); };
 		auto ring = [&](int node) { return F("Ring{ c.ring + (size_t)%lldll * 64, 64, %d }", (*in.ring_off)[(size_t)node], g.arg(node)); };
 		auto ty = [&](int r) { return std::string(is_dbl[(size_t)r] ? "double" : "float"); };
-		// registers that must be declared ahead of their defining statement at the level they are defined in (inside a branch there)
 		auto in_branch = [&](int i) { return !V[(size_t)i].path.empty(); };
+		// where a register's LDS copy is, for code of group `pf` (the prefix works on the NEXT chunk: the other parity)
+		auto slot_ref = [&](int r, bool reader_pf) {
+			const Reg& R = regs[(size_t)r];
+			if (pfx[(size_t)R.def]) return F("SLP(%d, %s)", R.slot_id, reader_pf ? "parn" : "parc");
+			return F("SL(%d)", R.slot_id);
+		};
 		// the statement(s) of virtual op i, in the context (L, c) it is emitted in
 		auto op_text = [&](int i, bool assign) {
 			const VOp& v = V[(size_t)i];
@@ -338,14 +398,49 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			}
 			return b;
 		};
-		// ops of one (level, wave) in program order, with the branches they stand in re-opened around them
-		auto emit_ops = [&](int lv, int wave /* -1: parallel */, const std::string& slot_index, std::string& out, const std::vector<char>& predeclared) {
+		// A serial loop pays for every branch of its body in every sample (exec-mask bookkeeping and a jump on a chain nothing overlaps).  What stands inside a
+		// recorded `if` there is mostly plain arithmetic into single-assignment registers — only read under the same condition, or by a phi: computed
+		// unconditionally — and assignments to state (`L.x = e`: a member, a control, an oscillator's set()): `L.x = cond ? e : L.x`.  Statements of any other shape
+		// (a call that takes a node by reference: a filter, an oscillator step) keep their branch.  Returns false when the op's text has such a statement.
+		auto predicated = [&](const std::string& text, const std::string& cond, std::string& out) {
+			std::string res; size_t at = 0;
+			while (at < text.size()) {
+				size_t e = text.find(";\n", at); if (e == std::string::npos) return false;
+				std::string st = text.substr(at, e - at); at = e + 2;
+				// (several statements may share a line: `a = x; b = y;\n`)
+				std::vector<std::string> parts; { size_t b = 0; for (;;) { const size_t q = st.find("; ", b); if (q == std::string::npos) { parts.push_back(st.substr(b)); break; } parts.push_back(st.substr(b, q - b)); b = q + 2; } }
+				for (std::string p : parts) {
+					const size_t ns = p.find_first_not_of(" \t"); if (ns == std::string::npos) continue; p = p.substr(ns);
+					const size_t eq = p.find(" = "); if (eq == std::string::npos) return false;
+					const std::string lhs = p.substr(0, eq), rhs = p.substr(eq + 3);
+					if (rhs.find("(L.n") != std::string::npos || rhs.find("SL(") != std::string::npos) return false;
+					if (lhs.rfind("L.", 0) == 0) res += "\t\t" + lhs + " = (" + cond + ") ? (" + rhs + ") : " + lhs + ";\n";
+					else if (lhs.rfind("const float r", 0) == 0 || lhs.rfind("const double r", 0) == 0 || (lhs[0] == 'r' && lhs.find_first_not_of("0123456789", 1) == std::string::npos)) res += "\t\t" + p + ";\n";
+					else return false;
+				}
+			}
+			out += res; return true;
+		};
+		// ops of one block in program order, with the branches they stand in re-opened around them
+		auto emit_ops = [&](bool pf, int lv, int wave /* -1: parallel */, const std::string& slot_index, std::string& out, const std::vector<char>& predeclared) {
 			std::vector<std::pair<int, int>> open;
 			auto close_to = [&](size_t keep) { while (open.size() > keep) { out += "\t\t}\n"; open.pop_back(); } };
+			static const bool ifconv = []() { const char* e = getenv("KLG_FX_STAGED_IFCONV"); return !(e && e[0] == '0'); }();
 			for (int i = 0; i < NV; i++) {
 				const VOp& v = V[(size_t)i];
-				if (is_struct(v.code) || inv[(size_t)i] || level[(size_t)i] != lv) continue;
-				if ((wave >= 0) != ser_of(i) || (wave >= 0 && wave_of_op(i) != wave)) continue;
+				if (!in_block(i, pf, lv, wave)) continue;
+				if (wave >= 0 && ifconv && !v.path.empty() && v.code != V_OSCEVAL) {      // a serial loop: without the branch where the op allows it
+					const bool has_dst = v.dst >= 0 && v.code != OP_OSCSET && v.code != OP_LPFSET && v.code != OP_SETPARAM && v.code != OP_DELAYIN && v.code != OP_DELAYSET;
+					std::string cond;
+					for (const auto& pe : v.path) cond += (cond.empty() ? "" : " && ") + F("%s(r%d != 0.f)", pe.second ? "!" : "", V[(size_t)pe.first].a);
+					std::string conv;
+					if (predicated(op_text(i, has_dst && predeclared[(size_t)v.dst] != 0), cond, conv)) {
+						close_to(0);
+						out += conv;
+						if (has_dst && regs[(size_t)v.dst].slot) out += "\t\t" + slot_ref(v.dst, pf) + F("[%s] = r%d;\n", slot_index.c_str(), v.dst);
+						continue;
+					}
+				}
 				size_t common = 0;
 				while (common < open.size() && common < v.path.size() && open[common] == v.path[common]) common++;
 				close_to(common);
@@ -353,70 +448,159 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 				const bool has_dst = v.dst >= 0 && v.code != OP_OSCSET && v.code != OP_LPFSET && v.code != OP_SETPARAM && v.code != OP_DELAYIN && v.code != OP_DELAYSET;
 				const bool assign = has_dst && predeclared[(size_t)v.dst] != 0;
 				out += op_text(i, assign);
-				if (has_dst && regs[(size_t)v.dst].slot) out += F("\t\tSL(%d)[%s] = r%d;\n", regs[(size_t)v.dst].slot_id, slot_index.c_str(), v.dst);
+				if (has_dst && regs[(size_t)v.dst].slot) out += "\t\t" + slot_ref(v.dst, pf) + F("[%s] = r%d;\n", slot_index.c_str(), v.dst);
 			}
 			close_to(0);
 		};
-		// registers an op of (level, wave) reads that come from elsewhere
-		auto inputs_of = [&](int lv, int wave, std::vector<int>& from_slot) {
+		// every register the block reads (operands, branch conditions, phi conditions) -> f(r)
+		auto for_reads = [&](bool pf, int lv, int wave, const std::function<void(int)>& f) {
+			for (int i = 0; i < NV; i++) {
+				const VOp& v = V[(size_t)i];
+				if (!in_block(i, pf, lv, wave)) continue;
+				f(v.a); f(v.b);
+				for (const auto& pe : v.path) f(V[(size_t)pe.first].a);
+				if (v.code == OP_PHI) f(V[(size_t)phi_if[(size_t)i]].a);
+			}
+			if (!pf && wave < 0 && lv == out_level) { f(g.ret); if (CH == 2) f(g.ret_r); }
+		};
+		// registers the block reads from LDS
+		auto inputs_of = [&](bool pf, int lv, int wave, std::vector<int>& from_slot) {
 			std::vector<char> seen(regs.size(), 0);
-			auto want = [&](int r) {
+			for_reads(pf, lv, wave, [&](int r) {
 				if (r < 0 || (size_t)r >= regs.size() || seen[(size_t)r]) return;
 				const int d = def_at[(size_t)r]; if (d < 0 || inv[(size_t)d]) return;
-				const bool here = level[(size_t)d] == lv && ((wave >= 0) == ser_of(d)) && (wave < 0 || wave_of_op(d) == wave);
-				if (here) return;
-				if (wave < 0 && !ser_of(d)) return;                                   // parallel -> parallel: the lane's own register
+				if (in_block(d, pf, lv, wave)) return;
+				if (wave < 0 && !ser_of(d)) return;                                   // parallel -> parallel: a register of the lane (chunk / xrot)
 				seen[(size_t)r] = 1; from_slot.push_back(r);
-			};
-			for (int i = 0; i < NV; i++) {
-				const VOp& v = V[(size_t)i];
-				if (is_struct(v.code) || inv[(size_t)i] || level[(size_t)i] != lv || (wave >= 0) != ser_of(i) || (wave >= 0 && wave_of_op(i) != wave)) continue;
-				want(v.a); want(v.b);
-				for (const auto& pe : v.path) want(V[(size_t)pe.first].a);
-				if (v.code == OP_PHI) want(V[(size_t)phi_if[(size_t)i]].a);
-			}
-			if (wave < 0 && lv == out_level) { want(g.ret); if (CH == 2) want(g.ret_r); }
+			});
 		};
-
-		// the block invariants the ops of (level, wave) read, in program order
-		auto inv_prelude = [&](int lv, int wave) {
+		// the block invariants the block reads, in program order
+		auto inv_prelude = [&](bool pf, int lv, int wave) {
 			std::vector<char> need((size_t)NV, 0);
 			auto want = [&](int r) { const int d = (r >= 0 && (size_t)r < def_at.size()) ? def_at[(size_t)r] : -1; if (d >= 0 && inv[(size_t)d]) need[(size_t)d] = 1; };
-			for (int i = 0; i < NV; i++) {
-				const VOp& v = V[(size_t)i];
-				if (is_struct(v.code) || inv[(size_t)i] || level[(size_t)i] != lv || (wave >= 0) != ser_of(i) || (wave >= 0 && wave_of_op(i) != wave)) continue;
-				want(v.a); want(v.b);
-				for (const auto& pe : v.path) want(V[(size_t)pe.first].a);
-				if (v.code == OP_PHI) want(V[(size_t)phi_if[(size_t)i]].a);
-			}
-			if (wave < 0 && lv == out_level) { want(g.ret); if (CH == 2) want(g.ret_r); }
+			for_reads(pf, lv, wave, want);
 			for (int i = NV - 1; i >= 0; i--) if (need[(size_t)i]) { want(V[(size_t)i].a); want(V[(size_t)i].b); }     // operands come earlier in program order
 			std::string t;
 			for (int i = 0; i < NV; i++) if (need[(size_t)i]) t += op_text(i, false);
 			return t;
 		};
+		const char* skip_env = getenv("KLG_FX_STAGED_SKIP");                         // (measurement only: a bit mask of suffix levels whose code is left out — the result is wrong, the time is what the others cost)
+		const unsigned skip_mask = skip_env ? (unsigned)strtoul(skip_env, nullptr, 0) : 0u;
+		std::vector<std::string> deferred;                                          // commits of suffix serial levels at or below the guard
+		// ---- one block of code: the parallel ops of (group, level), or the serial loops of (group, level), one per wave that has work ----
+		bool first_pass = true;                                                      // (the control path's blocks are generated twice: for chunk 0 ahead of the loop, and inside it)
+		auto block = [&](bool pf, int lv) {
+			std::string code;
+			const char* cond = pf ? "pre" : "ok";
+			if (!pf && lv < 32 && ((skip_mask >> lv) & 1u)) return code;
+			if (!(lv & 1)) {
+				std::vector<int> from_slot; inputs_of(pf, lv, -1, from_slot);
+				std::vector<char> predecl(regs.size(), 0);
+				std::string decl, body;
+				if (pf) {                                                              // the prefix works on the next chunk: its own cursor positions, its registers under their plain names
+					decl += "\t\tLq.sidx = s0 + C + ps;\n";
+					std::vector<char> dn(NN, 0);
+					for (int i = 0; i < NV; i++) if (in_block(i, pf, lv, -1) && V[(size_t)i].code == OP_DELAYSET) dn[(size_t)V[(size_t)i].node] = 1;
+					for (size_t nd = 0; nd < NN; nd++) if (dn[nd]) decl += F("\t\tconst int d%zup0 = (int)((d%zub + (unsigned)(s0 + C + ps) * %du) %% %du); Tap& d%zut = xn_d%zut;\n", nd, nd, k_in[nd], g.arg((int)nd), nd, nd);
+					std::vector<char> bound(regs.size(), 0);
+					auto bind = [&](int r) {
+						if (r < 0 || (size_t)r >= regs.size() || bound[(size_t)r]) return;
+						const Reg& R = regs[(size_t)r]; if (R.def < 0 || !pfx[(size_t)R.def] || ser_of(R.def) || !(R.chunk || R.xrot)) return;
+						bound[(size_t)r] = 1; predecl[(size_t)r] = 1;
+						decl += "\t\t" + ty(r) + F("& r%d = %s_r%d; (void)r%d;\n", r, R.xrot ? "xn" : "pc", r, r);
+					};
+					for_reads(pf, lv, -1, bind);
+					for (int i = 0; i < NV; i++) if (in_block(i, pf, lv, -1) && V[(size_t)i].dst >= 0 && def_at[(size_t)V[(size_t)i].dst] == i) bind(V[(size_t)i].dst);
+				}
+				for (int r : from_slot) decl += "\t\tconst float " + F("r%d = ", r) + slot_ref(r, pf) + "[t];\n";
+				decl += inv_prelude(pf, lv, -1);
+				for (int i = 0; i < NV; i++) if (in_block(i, pf, lv, -1) && V[(size_t)i].dst >= 0 && (size_t)V[(size_t)i].dst < regs.size() && def_at[(size_t)V[(size_t)i].dst] == i) {
+					const int r = V[(size_t)i].dst;
+					if (predecl[(size_t)r]) continue;
+					if (!pf && regs[(size_t)r].chunk) predecl[(size_t)r] = 1;                          // (declared at the top of the chunk)
+					else if (in_branch(i)) { predecl[(size_t)r] = 1; decl += "\t\t" + ty(r) + F(" r%d = 0; (void)r%d;\n", r, r); }
+				}
+				emit_ops(pf, lv, -1, "t", body, predecl);
+				if (!pf) {
+					if (lv > guard_level && !deferred.empty()) { for (const std::string& d : deferred) code += d; deferred.clear(); }
+					if (lv == guard_level) body += "\t\tif (bad) *flag = 1;\n";
+					if (lv == out_level) {
+						body += F("\t\ttile[(0 * C + ps) * G + pg] = r%d;\n", g.ret);
+						if (CH == 2) body += F("\t\ttile[(1 * C + ps) * G + pg] = r%d;\n", g.ret_r);
+					}
+					if (lv == last_level) {                                                  // the read heads as the chunk leaves them (Delay::last)
+						for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY && head_used[nd]) {
+							const int SZ = g.arg((int)nd), w0 = g.node_word0((int)nd);
+							if (set_at[nd] >= 0) body += F("\t\tif (ps == C - 1) { srec[%d * G + pg] = (uint32_t)ring_walk(d%zut.position, %d, %d); srec[%d * G + pg] = f2u(d%zut.fraction); }\n", w0 + ED_LASTPOS, nd, outs[nd], SZ, w0 + ED_LASTFRAC, nd);
+							else if (outs[nd] > 0) body += F("\t\tif (ps == 0) srec[%d * G + pg] = (uint32_t)ring_walk(d%zuh.position, C * %d, %d);\n", w0 + ED_LASTPOS, nd, outs[nd], SZ);
+						}
+					}
+				}
+				if (!decl.empty() || !body.empty()) code += F("\t\tif (%s && t < NTP) { auto& L = %s; const FxCtx& c = cp; (void)L; (void)c;\n", cond, pf ? "Lq" : "Lp") + decl + body + "\t\t}\n";
+			}
+			else {
+				for (int w = 0; w < NWV; w++) {
+					std::vector<int> mine;
+					for (int i = 0; i < NV; i++) if (in_block(i, pf, lv, w)) mine.push_back(i);
+					if (mine.empty()) continue;
+					std::vector<char> node_here(NN, 0);
+					for (int i : mine) { int ns[2]; const int n = nodes_of(V[(size_t)i], ns); for (int q = 0; q < n; q++) node_here[(size_t)ns[q]] = 1; }
+					std::string load, commit, loop, decl;
+					for (size_t nd = 0; nd < NN; nd++) if (node_here[nd]) { load += (*in.node_begin)[nd]; commit += (*in.node_end)[nd]; }
+					std::vector<int> from_slot; inputs_of(pf, lv, w, from_slot);
+					std::vector<char> predecl(regs.size(), 0);
+					// the loop's inputs are fetched U samples at a time in front of the U samples that use them: one LDS round trip per batch instead of one (or more)
+					// in every sample of a chain nothing else overlaps (a power of two, so that it divides C; a long loop body — many components side by side —
+					// hides the round trip by itself and stays as it is)
+					int U = 8; while (U > 1 && U * (int)from_slot.size() > 64) U /= 2;
+					if (mine.size() > 48 || U > C) U = 1;
+					std::string fetch;
+					for (int r : from_slot) { fetch += F("\t\tfloat i%d[%d];\n#pragma unroll\n\t\tfor (int u = 0; u < %d; u++) i%d[u] = ", r, U, U, r) + slot_ref(r, pf) + "[(sb + u) * G + ln];\n"; decl += "\t\tconst " + ty(r) + F(" r%d = i%d[u];\n", r, r); }
+					for (int i : mine) if (V[(size_t)i].dst >= 0 && in_branch(i) && def_at[(size_t)V[(size_t)i].dst] == i) { const int r = V[(size_t)i].dst; predecl[(size_t)r] = 1; decl += "\t\t" + ty(r) + F(" r%d = 0; (void)r%d;\n", r, r); }
+					emit_ops(pf, lv, w, "q", loop, predecl);
+					if (first_pass) P.serial_ops += (int)mine.size();
+					// the suffix works on the architectural records; the prefix on its own two copies: from the one its previous chunk left, into the other
+					const std::string from = pf ? "srecp + (parn ^ 1) * (NW * G)" : "srec", to = pf ? "srecp + parn * (NW * G)" : "srec";
+					code += F("\t\tif (%s && sw == %d && ln < G) { auto& L = Ls; const FxCtx& c = cs; (void)L; (void)c;\n\t\t{ const StagedRec r = { { %s + ln } }; (void)r;\n", cond, w, from.c_str()) + load + "\t\t}\n" + inv_prelude(pf, lv, w);
+					code += F("\t\tfor (int sb = 0; sb < C; sb += %d) {\n", U) + fetch + F("#pragma unroll\n\t\tfor (int u = 0; u < %d; u++) { const int q = (sb + u) * G + ln; (void)q;\n", U) + decl + loop + "\t\t}\n\t\t}\n";
+					const std::string cm = F("\t\t{ StagedRec r = { { %s + ln } }; (void)r;\n", to.c_str()) + commit + "\t\t}\n";
+					if (pf || lv > guard_level) code += cm + "\t\t}\n";
+					else { code += "\t\t}\n"; deferred.push_back(F("\t\tif (ok && sw == %d && ln < G) { auto& L = Ls; (void)L;\n", w) + cm + "\t\t}\n"); }
+					if (pf && first_pass) {                                                // ... and, once its chunk is complete, from its copy to the architectural one
+						P.prefix_commit += F("\t\tif (ok && sw == %d && ln < G) { auto& L = Ls; (void)L;\n\t\t{ const StagedRec r = { { srecp + parc * (NW * G) + ln } }; (void)r;\n", w) + load + "\t\t}\n\t\t{ StagedRec r = { { srec + ln } }; (void)r;\n" + commit + "\t\t}\n\t\t}\n";
+					}
+				}
+			}
+			return code;
+		};
 
-		s += F("\n// ---- the staged form (klg_graph_staged.hpp): %d instances x %d samples per workgroup, %d levels, %d values through LDS ----\n", G, C, last_level + 1, nslots);
+		s += F("\n// ---- the staged form (klg_graph_staged.hpp): %d instances x %d samples per workgroup, %d levels%s, %d values through LDS ----\n", G, C, last_level + 1, pipelined ? F(" beside the %d of the next chunk's control path", pmax + 1).c_str() : "", nslots + npslots);
 		s += "__device__ __forceinline__ int ring_at(int p0, int j, int size) { const int p = p0 + j; return p >= size ? p - size : p; }\n";
 		s += "struct StagedWords { uint32_t* p; __device__ __forceinline__ uint32_t& operator[](int i) const { return p[i * " + std::to_string(G) + "]; } };\n";
 		s += "struct StagedRec { StagedWords w; };\n";
 		s += F("extern \"C\" __global__ __launch_bounds__(%d) void klg_fx_staged(const FxGraphArgs a) {\n", NT);
-		s += F("\tconstexpr int G = %d, C = %d, NT = %d, NW = %d, CH = %d;\n", G, C, NT, NW, CH);
+		s += F("\tconstexpr int G = %d, C = %d, NTP = %d, NT = %d, NW = %d, CH = %d, SW0 = %d;\n", G, C, NTP, NT, NW, CH, own_waves ? NTP / 64 : 0);
+		const char* stamp_env = getenv("KLG_FX_STAGED_STAMP");                       // (measurement only: workgroup 0 prints what its chunks spent between the barriers, 10 ns units: top of chunk, each level, tail)
+		const bool stamp = stamp_env && stamp_env[0] == '1';
 		s += "\tusing P = PatchGen;\n\textern __shared__ float lds[];\n";
+		if (stamp) s += "\tconst long long tstart = wall_clock64();\n";
 		s += "\tuint32_t* const srec = reinterpret_cast<uint32_t*>(lds);                 // [NW][G]: the G records between chunks\n";
-		s += "\tfloat* const tile = lds + NW * G;                                         // [CH][C][G]: the caller's block, chunk by chunk\n";
+		s += F("\tuint32_t* const srecp = srec + NW * G;                                    // [2][NW][G]: the control path's own copies (it runs a chunk ahead)%s\n", pipelined ? "" : " — unused");
+		s += F("\tfloat* const tile = lds + NW * G * %d;                                    // [CH][C][G]: the caller's block, chunk by chunk\n", pipelined ? 3 : 1);
 		s += "\tfloat* const slots = tile + CH * C * G;                                   // [slots][C][G]: values that cross levels\n";
-		s += F("\tint* const flag = reinterpret_cast<int*>(slots + %d * C * G);\n", nslots);
-		s += "#define SL(k) (slots + (k) * (C * G))\n";
-		s += "\tconst int t = threadIdx.x, ps = t / G, pg = t % G, wv = t >> 6, ln = t & 63, k0 = blockIdx.x * G;\n";
+		s += F("\tfloat* const pslots = slots + %d * C * G;                                 // [slots][2][C][G]: those of the control path, by the parity of their chunk\n", nslots);
+		s += F("\tint* const flag = reinterpret_cast<int*>(pslots + %d * C * G);\n", 2 * npslots);
+		s += "#define SL(k) (slots + (k) * (C * G))\n#define SLP(k, par) (pslots + ((k) * 2 + (par)) * (C * G))\n";
+		s += "\tconst int t = threadIdx.x, tp = t < NTP ? t : 0, ps = tp / G, pg = tp % G, wv = t >> 6, sw = wv - SW0, ln = t & 63, k0 = blockIdx.x * G;   // sw: which wave of the serial levels\n";
 		s += "\tconst int sg = ln < G ? ln : 0;                                           // the instance a lane of a serial level works for\n";
+		s += "\t(void)srecp; (void)pslots;\n";
 		s += "\tfor (int i = t; i < NW * G; i += NT) srec[i] = a.state[(size_t)(i / G) * a.kpad + k0 + (i % G)];\n";
 		s += "\tFxCtx cp, cs;\n\tcp.fs = cs.fs = a.fs; cp.samples = cs.samples = a.samples;\n";
 		s += "\tcp.ctl = a.controls + (size_t)(k0 + pg) * KLG_MAX_CTL; cs.ctl = a.controls + (size_t)(k0 + sg) * KLG_MAX_CTL;\n";
 		s += "\tfloat* const ring0 = a.rings + (size_t)(k0 / 64) * a.ring_rows * 64 + (k0 % 64);\n\tcp.ring = ring0 + pg; cs.ring = ring0 + sg;\n";
 		s += "\tcp.rand = a.rand ? a.rand + (size_t)(k0 + pg < a.K ? k0 + pg : 0) * (size_t)a.rand_per_instance : nullptr;\n";
 		s += "\tcs.rand = a.rand ? a.rand + (size_t)(k0 + sg < a.K ? k0 + sg : 0) * (size_t)a.rand_per_instance : nullptr;\n";
-		s += "\tP::Live Lp, Ls;\n\tLp.unused_ = 0; Lp.sidx = 0; Ls.unused_ = 0; Ls.sidx = 0;\n";
+		s += "\tP::Live Lp, Lq, Ls;\n\tLp.unused_ = 0; Lp.sidx = 0; Lq.unused_ = 0; Lq.sidx = 0; Ls.unused_ = 0; Ls.sidx = 0;\n";
 		s += "\t__syncthreads();\n";
 		// the plain body over [from, from + count) of the block, on one lane per instance (wave 0): prepare() at the head of the block, chunks whose check failed, a ragged tail
 		s += "\tauto plain = [&](int from, int count, bool with_prepare) {\n";
@@ -427,97 +611,82 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "\t\t\tP::sample(L, c, in0, in1, out0, out1);\n\t\t\ttile[(0 * C + q) * G + ln] = out0;\n\t\t\tif (CH > 1) tile[(1 * C + q) * G + ln] = out1;\n\t\t}\n";
 		s += "\t\tP::end(L, rec);\n#pragma unroll\n\t\tfor (int w = 0; w < NW; w++) if (patch_stores<P>(w)) srec[w * G + ln] = rec.w[w];\n\t};\n";
 		if (g.prepare_ops > 0) s += "\tplain(0, 0, true);                                                           // Effect::prepare(): once per block\n\t__syncthreads();\n";
+		if (pipelined) s += "\tfor (int i = t; i < NW * G; i += NT) { srecp[i] = srec[i]; srecp[NW * G + i] = srec[i]; }\n\t__syncthreads();\n";
 		// what the lanes hold for the whole block: the dials, the members process() only reads
 		{
-			std::string pb, sb;
+			std::string pb;
 			for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_PARAM && !written[nd]) pb += (*in.node_begin)[nd];
 			s += "\t{ auto& L = Lp; const FxCtx& c = cp; const StagedRec r = { { srec + pg } }; (void)L; (void)c; (void)r;\n" + in.ctl_begin + pb + "\t}\n";
+			s += "\t{ auto& L = Lq; const FxCtx& c = cp; const StagedRec r = { { srec + pg } }; (void)L; (void)c; (void)r;\n" + in.ctl_begin + pb + "\t}\n";
 			s += "\t{ auto& L = Ls; const FxCtx& c = cs; const StagedRec r = { { srec + sg } }; (void)L; (void)c; (void)r;\n" + in.ctl_begin + pb + "\t}\n";
 		}
+		// registers handed from the control path to the audio path: computed during the previous iteration (xn), taken at the top of this one (xc)
+		std::string xdecl, xrot, pcdecl, cdecl;
+		for (size_t r = 0; r < regs.size(); r++) if (regs[r].def >= 0 && !ser_of(regs[r].def)) {
+			const bool dpf = pfx[(size_t)regs[r].def] != 0;
+			if (dpf && regs[r].xrot) { xdecl += "\t" + ty((int)r) + F(" xn_r%zu = 0, xc_r%zu = 0; (void)xc_r%zu;\n", r, r, r); xrot += F("\t\txc_r%zu = xn_r%zu;\n", r, r); cdecl += "\t\tconst " + ty((int)r) + F(" r%zu = xc_r%zu; (void)r%zu;\n", r, r, r); }
+			else if (dpf && regs[r].chunk) pcdecl += "\t\t" + ty((int)r) + F(" pc_r%zu = 0; (void)pc_r%zu;\n", r, r);
+			else if (!dpf && regs[r].chunk) cdecl += "\t\t" + ty((int)r) + F(" r%zu = 0; (void)r%zu;\n", r, r);
+		}
+		for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY && set_at[nd] >= 0 && pfx[(size_t)set_at[nd]]) { xdecl += F("\tTap xn_d%zut = { 0, 0.f }, xc_d%zut = { 0, 0.f }; (void)xc_d%zut;\n", nd, nd, nd); xrot += F("\t\txc_d%zut = xn_d%zut;\n", nd, nd); }
+		s += xdecl;
+		// every Delay's write cursor is the sample counter (one step per input()): where it stands at the start of the block (64-bit once), 32-bit from there
+		for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY) s += F("\tconst unsigned d%zub = (unsigned)((a.samples * %dull) %% %dull);\n", nd, k_in[nd], g.arg((int)nd));
+		// the caller's rows of a chunk (a row's C samples are contiguous in the caller's block: G * CH * C = CH * NT values, CH per thread) are requested a chunk
+		// ahead and put into the tile at the top of their chunk
+		s += "\tfloat nx[CH];\n";
+		s += "\tauto fetch = [&](int s0) {\n#pragma unroll\n\t\tfor (int j = 0; j < CH; j++) { const int i = tp + j * NTP, row = i / C, q = i % C, gi = row / CH, ch = row % CH;\n";
+		s += "\t\t\tnx[j] = (t < NTP && s0 + q < a.n && k0 + gi < a.K) ? a.io[((size_t)(k0 + gi) * CH + ch) * a.n + s0 + q] : 0.f; }\n\t};\n";
+		s += "\tfetch(0);\n";
+		if (pipelined) {                                                           // the control path of chunk 0
+			s += "\t{ const int s0 = -C; const bool pre = a.n >= C; const int parn = 0; (void)parn;\n" + pcdecl;
+			for (int lv = 0; lv <= pmax; lv++) { const std::string code = block(true, lv); if (code.empty()) continue; s += F("\t\t// ---- control path of chunk 0, level %d ----\n", lv) + code + "\t\t__syncthreads();\n"; }
+			s += "\t}\n";
+			first_pass = false;
+		}
+		if (stamp) s += "\tlong long tacc[16] = { 0 }; const long long thead = wall_clock64() - tstart; long long tprev = wall_clock64();\n";
 		s += "\tfor (int s0 = 0; s0 < a.n; s0 += C) {\n\t\tconst int cl = (a.n - s0 < C) ? (a.n - s0) : C;\n";
-		// the caller's rows of this chunk -> tile (a row's C samples are contiguous in the caller's block)
-		s += "\t\tfor (int i = t; i < G * CH * C; i += NT) { const int row = i / C, q = i % C, gi = row / CH, ch = row % CH;\n";
-		s += "\t\t\ttile[(ch * C + q) * G + gi] = (q < cl && k0 + gi < a.K) ? a.io[((size_t)(k0 + gi) * CH + ch) * a.n + s0 + q] : 0.f; }\n";
+		s += "#pragma unroll\n\t\tfor (int j = 0; j < CH; j++) { const int i = tp + j * NTP, row = i / C, q = i % C, gi = row / CH, ch = row % CH; if (t < NTP) tile[(ch * C + q) * G + gi] = nx[j]; }\n";
 		s += "\t\tif (t == 0) *flag = 0;\n\t\t__syncthreads();\n";
+		s += "\t\tif (s0 + C < a.n) fetch(s0 + C);\n";
 		s += "\t\tbool ok = cl == C;\n\t\tint bad = 0; (void)bad;\n";
+		s += "\t\tconst bool pre = s0 + 2 * C <= a.n; const int parc = (s0 / C) & 1, parn = parc ^ 1; (void)pre; (void)parc; (void)parn;\n";
 		s += "\t\tconst float in0 = tile[(0 * C + ps) * G + pg], in1 = CH > 1 ? tile[(1 * C + ps) * G + pg] : 0.f; (void)in0; (void)in1;\n";
 		s += "\t\tLp.sidx = s0 + ps;\n";
+		s += xrot + pcdecl;
 		// delay lines: this lane's cursor at the start of its sample, the rows the chunk writes, the head
 		for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY) {
 			const int SZ = g.arg((int)nd), w0 = g.node_word0((int)nd);
-			s += F("\t\tconst int d%zup0 = (int)(((a.samples + (unsigned long long)(s0 + ps)) * %dull) %% %dull); (void)d%zup0;\n", nd, k_in[nd], SZ, nd);
-			s += F("\t\tconst RingWindow d%zuw = { (int)(((a.samples + (unsigned long long)s0) * %dull) %% %dull), %d * C }; (void)d%zuw;\n", nd, k_in[nd], SZ, k_in[nd], nd);
-			if (set_at[nd] >= 0) s += F("\t\tTap d%zut = { 0, 0.f }; (void)d%zut;\n", nd, nd);
+			s += F("\t\tconst int d%zup0 = (int)((d%zub + (unsigned)(s0 + ps) * %du) %% %du); (void)d%zup0;\n", nd, nd, k_in[nd], SZ, nd);
+			s += F("\t\tconst RingWindow d%zuw = { (int)((d%zub + (unsigned)s0 * %du) %% %du), %d * C }; (void)d%zuw;\n", nd, nd, k_in[nd], SZ, k_in[nd], nd);
+			if (set_at[nd] >= 0 && pfx[(size_t)set_at[nd]]) s += F("\t\tconst Tap d%zut = xc_d%zut; (void)d%zut;\n", nd, nd, nd);
+			else if (set_at[nd] >= 0) s += F("\t\tTap d%zut = { 0, 0.f }; (void)d%zut;\n", nd, nd);
 			else if (outs[nd] > 0) s += F("\t\tconst Tap d%zuh = { (int)srec[%d * G + pg], u2f(srec[%d * G + pg]) };\n", nd, w0 + ED_LASTPOS, w0 + ED_LASTFRAC);
 		}
-		// registers that live across levels of a lane
-		for (size_t r = 0; r < regs.size(); r++) if (regs[r].def >= 0 && regs[r].chunk) s += "\t\t" + ty((int)r) + F(" r%zu = 0; (void)r%zu;\n", r, r);
-		std::vector<std::string> deferred;                                          // commits of serial levels at or below the guard
+		s += cdecl;
 		bool guard_emitted = guard_level < 0;
-		for (int lv = 0; lv <= last_level; lv++) {
+		if (stamp) s += "\t\t{ const long long now = wall_clock64(); tacc[0] += now - tprev; tprev = now; }\n";
+		for (int lv = 0; lv <= std::max(last_level, pipelined ? pmax - poff : -1); lv++) {
 			std::string code;
-			if (!(lv & 1)) {                                                           // ---- a parallel level ----
-				std::vector<int> from_slot; inputs_of(lv, -1, from_slot);
-				std::vector<char> pre(regs.size(), 0);
-				std::string decl, body;
-				for (int r : from_slot) decl += "\t\tconst float " + F("r%d = SL(%d)[t];\n", r, regs[(size_t)r].slot_id);
-				decl += inv_prelude(lv, -1);
-				for (int i = 0; i < NV; i++) if (!is_struct(V[(size_t)i].code) && !inv[(size_t)i] && level[(size_t)i] == lv && !ser_of(i) && V[(size_t)i].dst >= 0 && (size_t)V[(size_t)i].dst < regs.size()) {
-					const int r = V[(size_t)i].dst;
-					if (regs[(size_t)r].chunk && regs[(size_t)r].def == i) pre[(size_t)r] = 1;
-					else if (in_branch(i) && def_at[(size_t)r] == i) { pre[(size_t)r] = 1; decl += "\t\t" + ty(r) + F(" r%d = 0; (void)r%d;\n", r, r); }
-				}
-				emit_ops(lv, -1, "t", body, pre);
-				if (lv > guard_level && !deferred.empty()) { for (const std::string& d : deferred) body += d; deferred.clear(); }
-				if (lv == guard_level) body += "\t\tif (bad) *flag = 1;\n";
-				if (lv == out_level) {
-					body += F("\t\ttile[(0 * C + ps) * G + pg] = r%d;\n", g.ret);
-					if (CH == 2) body += F("\t\ttile[(1 * C + ps) * G + pg] = r%d;\n", g.ret_r);
-				}
-				if (lv == last_level) {                                                  // the read heads as the chunk leaves them (Delay::last)
-					for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY && head_used[nd]) {
-						const int SZ = g.arg((int)nd), w0 = g.node_word0((int)nd);
-						if (set_at[nd] >= 0) body += F("\t\tif (ps == C - 1) { srec[%d * G + pg] = (uint32_t)ring_walk(d%zut.position, %d, %d); srec[%d * G + pg] = f2u(d%zut.fraction); }\n", w0 + ED_LASTPOS, nd, outs[nd], SZ, w0 + ED_LASTFRAC, nd);
-						else if (outs[nd] > 0) body += F("\t\tif (ps == 0) srec[%d * G + pg] = (uint32_t)ring_walk(d%zuh.position, C * %d, %d);\n", w0 + ED_LASTPOS, nd, outs[nd], SZ);
-					}
-				}
-				if (!decl.empty() || !body.empty()) code += "\t\tif (ok) { auto& L = Lp; const FxCtx& c = cp; (void)L; (void)c;\n" + decl + body + "\t\t}\n";
-			}
-			else {                                                                     // ---- a serial level: one loop per wave that has work ----
-				for (int w = 0; w < NWV; w++) {
-					std::vector<int> mine;
-					for (int i = 0; i < NV; i++) if (!is_struct(V[(size_t)i].code) && !inv[(size_t)i] && level[(size_t)i] == lv && ser_of(i) && wave_of_op(i) == w) mine.push_back(i);
-					if (mine.empty()) continue;
-					std::vector<char> node_here(NN, 0);
-					for (int i : mine) { int ns[2]; const int n = nodes_of(V[(size_t)i], ns); for (int q = 0; q < n; q++) node_here[(size_t)ns[q]] = 1; }
-					std::string load, commit, loop, decl;
-					for (size_t nd = 0; nd < NN; nd++) if (node_here[nd]) { load += (*in.node_begin)[nd]; commit += (*in.node_end)[nd]; }
-					std::vector<int> from_slot; inputs_of(lv, w, from_slot);
-					std::vector<char> pre(regs.size(), 0);
-					for (int r : from_slot) decl += "\t\tconst " + ty(r) + F(" r%d = SL(%d)[q];\n", r, regs[(size_t)r].slot_id);
-					for (int i : mine) if (V[(size_t)i].dst >= 0 && in_branch(i) && def_at[(size_t)V[(size_t)i].dst] == i) { const int r = V[(size_t)i].dst; pre[(size_t)r] = 1; decl += "\t\t" + ty(r) + F(" r%d = 0; (void)r%d;\n", r, r); }
-					emit_ops(lv, w, "q", loop, pre);
-					P.serial_ops += (int)mine.size();
-					code += F("\t\tif (ok && wv == %d && ln < G) { auto& L = Ls; const FxCtx& c = cs; const StagedRec r = { { srec + ln } }; (void)L; (void)c; (void)r;\n", w) + load + inv_prelude(lv, w);
-					code += "\t\tfor (int sq = 0; sq < C; sq++) { const int q = sq * G + ln; (void)q;\n" + decl + loop + "\t\t}\n";
-					const std::string cm = F("\t\tif (ok && wv == %d && ln < G) { auto& L = Ls; StagedRec r = { { srec + ln } }; (void)L; (void)r;\n", w) + commit + "\t\t}\n";
-					if (lv > guard_level) code += commit + "\t\t}\n"; else { code += "\t\t}\n"; deferred.push_back(cm); }
-				}
-			}
-			if (code.empty() && !(lv == guard_level)) continue;
-			s += F("\t\t// ---- level %d (%s) ----\n", lv, (lv & 1) ? "serial" : "parallel") + code;
-			if (lv < last_level || true) s += "\t\t__syncthreads();\n";
+			if (lv <= last_level) code += block(false, lv);
+			if (pipelined && lv + poff <= pmax) code += block(true, lv + poff);
+			if (code.empty() && lv != guard_level) continue;
+			s += F("\t\t// ---- interval %d ----\n", lv) + code + "\t\t__syncthreads();\n";
+			if (stamp) s += F("\t\t{ const long long now = wall_clock64(); tacc[%d] += now - tprev; tprev = now; }\n", lv + 1);
 			if (lv == guard_level && !guard_emitted) { s += "\t\tok = ok && *flag == 0;                                                   // every ring read of the chunk lies outside the rows the chunk writes\n"; guard_emitted = true; }
 		}
-		if (!deferred.empty()) { for (const std::string& d : deferred) s += d; s += "\t\t__syncthreads();\n"; }
+		{ std::string rest; for (const std::string& d : deferred) rest += d; deferred.clear(); rest += P.prefix_commit; if (!rest.empty()) s += rest + "\t\t__syncthreads();\n"; }
 		s += "\t\tif (!ok) { plain(s0, cl, false); __syncthreads(); }\n";
 		s += "\t\tfor (int i = t; i < G * CH * C; i += NT) { const int row = i / C, q = i % C, gi = row / CH, ch = row % CH;\n";
 		s += "\t\t\tif (q < cl && k0 + gi < a.K) a.io[((size_t)(k0 + gi) * CH + ch) * a.n + s0 + q] = tile[(ch * C + q) * G + gi]; }\n";
-		s += "\t\t__syncthreads();\n\t}\n";
+		s += "\t\t__syncthreads();\n";
+		if (stamp) s += "\t\t{ const long long now = wall_clock64(); tacc[15] += now - tprev; tprev = now; }\n";
+		s += "\t}\n";
+		if (stamp) s += "\tif (t == 0 && blockIdx.x == 0) { printf(\"staged stamps (10 ns): head %lld |\", thead); for (int i = 0; i < 16; i++) printf(\" %lld\", tacc[i]); printf(\"\\n\"); }\n";
 		s += "\tfor (int i = t; i < NW * G; i += NT) if (k0 + (i % G) < a.K && patch_stores<P>(i / G)) a.state[(size_t)(i / G) * a.kpad + k0 + (i % G)] = srec[i];\n";
-		s += "#undef SL\n}\n";
-		for (int i = 0; i < NV; i++) if (!is_struct(V[(size_t)i].code) && !inv[(size_t)i] && !ser_of(i)) P.parallel_ops++;
-		P.ok = true; P.G = G; P.C = C; P.threads = NT; P.lds_bytes = (int)(lds_words * 4); P.levels = last_level + 1; P.slots = nslots; P.source = s;
+		s += "#undef SL\n#undef SLP\n}\n";
+		for (int i = 0; i < NV; i++) if (live_op(i) && !ser_of(i)) P.parallel_ops++;
+		P.ok = true; P.G = G; P.C = C; P.threads = NT; P.lds_bytes = (int)(lds_words * 4); P.levels = last_level + 1; P.slots = nslots + npslots; P.pipelined = pipelined; P.source = s;
 		return P;
 	}
 }
