@@ -263,6 +263,13 @@ int klg_fx_upload_words(klg_fx* f, int instance, int first, int count, const voi
 int klg_fx_process(klg_fx* f, float* io, int n);
 /* Device-resident variant (d_io device pointer, asynchronous on hip_stream). */
 int klg_fx_process_device(klg_fx* f, float* d_io, int n, void* hip_stream);
+/* replaces: the host's block loop around an effect for a stream known in advance — Stereo::Effect::process(Stereo::buffer) (klang.h:4708-4716) called
+ * `blocks` times by templates/juce/effect/Source/PluginProcessor.cpp:153-178 (offline rendering, a benchmark).  d_io is a DEVICE buffer
+ * [blocks][instances][channels][n], processed in place, asynchronously on hip_stream; dials keep the values they have at the call (a host that moves a
+ * dial ends the span there).  Same bits as `blocks` calls of klg_fx_process_device.  One launch per span where the kernel can walk the blocks itself
+ * (PingPong.k's pipeline across the block boundaries — blocks of a multiple of 32 samples —, the staged form of a recorded effect with prepare() at the head
+ * of every block); otherwise the blocks' launches back to back without host work in between (Reverb.k: its kernel stages a whole block in LDS). */
+int klg_fx_render_device(klg_fx* f, float* d_io, int blocks, int n, void* hip_stream);
 int klg_fx_sync(klg_fx* f);
 size_t klg_fx_state_bytes(const klg_fx* f);
 int klg_fx_timing_begin(klg_fx* f);

@@ -99,6 +99,7 @@ def load():
         "klg_fx_set_control": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),
         "klg_fx_process": (C.c_int, [vp, f32p, C.c_int]),
         "klg_fx_process_device": (C.c_int, [vp, vp, C.c_int, vp]),
+        "klg_fx_render_device": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
         "klg_fx_sync": (C.c_int, [vp]),
         "klg_fx_state_bytes": (C.c_size_t, [vp]),
         "klg_fx_timing_begin": (C.c_int, [vp]),

@@ -308,6 +308,10 @@ class FxBank:
     def process_device(self, d_io_ptr, n, stream=None):
         check(self._L.klg_fx_process_device(self._h, C.c_void_p(int(d_io_ptr)), int(n), C.c_void_p(int(stream)) if stream else None), "klg_fx_process_device")
 
+    def render_device(self, d_io_ptr, blocks, n, stream=None):
+        """a span of `blocks` blocks: d_io [blocks][instances][channels][n] on the device, in place (klg_fx_render_device)"""
+        check(self._L.klg_fx_render_device(self._h, C.c_void_p(int(d_io_ptr)), int(blocks), int(n), C.c_void_p(int(stream)) if stream else None), "klg_fx_render_device")
+
     def sync(self):
         check(self._L.klg_fx_sync(self._h), "klg_fx_sync")
 

@@ -87,6 +87,10 @@ struct PingPongArgs {
 	float* rings;               // [kpad/64][2][192000][64]
 	int position;               // write cursor of both lines at block start (samples processed % 192000)
 	float* io; int n;
+	// a SPAN of blocks in one launch (klg_fx_render_device): n = blocks * nb samples, the caller's buffer is [blocks][K][2][nb] — block b's rows start block_stride
+	// floats after block b - 1's.  prepare() (PingPong.k:37-41) only sets the DC filters, and no dial can move inside a span, so a span IS one long block whose
+	// rows are cut into pieces: the pipeline runs across the block boundaries.  nb == 0: one block of n samples (klg_fx_pingpong_x only; nb a multiple of a chunk)
+	int nb; size_t block_stride;
 	SampleRate fs;
 	BiquadCoef dc;              // dcfilter[k].set(50, 1) — PingPong.k:39-40, computed on the host
 	float c1_min, c1_max;
@@ -282,6 +286,9 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	const int li = lane & (G - 1), lq = lane / G;                                  // this lane's instance of the workgroup; its sample slot in an audio pass
 	const int k0 = blockIdx.x * G, k = k0 + li;
 	const int SIZE = 192000, n = a.n;
+	const int nb = a.nb > 0 ? a.nb : n;                                            // the length of a row of the caller's buffer (a span: one block's)
+	// where the caller's rows of this workgroup's first instance stand for sample s of the span (s a multiple of the chunk: a chunk never straddles two blocks)
+	auto io_rows = [&](const int s) { const int b = s / nb; return (char*)(a.io + (size_t)b * a.block_stride + (size_t)k0 * 2 * nb + (s - b * nb)); };
 	const int nchunks = (n + PPX_CHUNK - 1) / PPX_CHUNK;
 	const bool w_control = wv == 0, w_audio = wv >= 1 && wv <= PPX_AUDIO, w_filter = wv > PPX_AUDIO;
 	// the control and filter waves are dependent chains that pace the pipeline; the audio waves share their SIMDs and mostly wait for
@@ -375,17 +382,17 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		wave_sync();
 		int sl = lane; asm volatile("" : "+v"(sl));
 		const int col = sl & 31, half = sl >> 5;
-		char* dst = (char*)(a.io + (size_t)k0 * 2 * n + s0);
+		char* dst = io_rows(s0);
 		if (KLG_PPX_ABLATE & 2) {}
 		else if (cl == PPX_CHUNK && k0 + G <= a.K) {
 #pragma unroll 8
-			for (int it = 0; it < G / 2; it++) { const int inst = 2 * it + half; *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst]; }
+			for (int it = 0; it < G / 2; it++) { const int inst = 2 * it + half; *(float*)(dst + (unsigned)((inst * 2 + fch) * nb + col) * 4u) = T[col][inst]; }
 		}
 		else {
 #pragma unroll 8
 			for (int it = 0; it < G / 2; it++) {
 				const int inst = 2 * it + half;
-				if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * n + col) * 4u) = T[col][inst];
+				if (col < cl && k0 + inst < a.K) *(float*)(dst + (unsigned)((inst * 2 + fch) * nb + col) * 4u) = T[col][inst];
 			}
 		}
 	};
@@ -405,11 +412,11 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			const int acol = at & 31, arow = at >> 5;
 			const int jn = j + 1, js = j - 2;
 			if (js >= 0 && js < nch && !(KLG_PPX_ABLATE & 2) && !(KLG_PPX_VARIANT & 1)) {                 // the caller's rows of chunk j - 2 (filtered in the step before): to memory
-				char* dst = (char*)(a.io + (size_t)k0 * 2 * n + js * PPX_CHUNK);
+				char* dst = io_rows(js * PPX_CHUNK);
 #pragma unroll
 				for (int i = 0; i < DIOV; i++) {
 					const int row = arow + 16 * i;
-					if (whole_group || k0 + (row >> 1) < a.K) *(float*)(dst + (unsigned)(row * n + acol) * 4u) = S.tile[js & 3][row & 1][acol][row >> 1];
+					if (whole_group || k0 + (row >> 1) < a.K) *(float*)(dst + (unsigned)(row * nb + acol) * 4u) = S.tile[js & 3][row & 1][acol][row >> 1];
 				}
 			}
 			if (jn >= 0 && jn < nch) {                                      // the caller's rows of chunk j + 1 (requested in step j - P): into LDS
@@ -453,16 +460,16 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			}
 			const int c2 = j + P + 1;
 			if (c2 >= 0 && c2 < nch) {                                      // the caller's rows of chunk j + P + 1
-				const char* src = (const char*)(a.io + (size_t)k0 * 2 * n + c2 * PPX_CHUNK);
+				const char* src = io_rows(c2 * PPX_CHUNK);
 				if (whole_group) {
 #pragma unroll
-					for (int i = 0; i < DIOV; i++) iov[IS][i] = *(const float*)(src + (unsigned)((arow + 16 * i) * n + acol) * 4u);
+					for (int i = 0; i < DIOV; i++) iov[IS][i] = *(const float*)(src + (unsigned)((arow + 16 * i) * nb + acol) * 4u);
 				}
 				else {
 #pragma unroll
 					for (int i = 0; i < DIOV; i++) {
 						const int row = arow + 16 * i, inst = row >> 1;
-						iov[IS][i] = (k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + acol) * 4u) : 0.f;
+						iov[IS][i] = (k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * nb + acol) * 4u) : 0.f;
 					}
 				}
 			}
@@ -564,16 +571,16 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		const int acol = at & 31, arow = at >> 5;                                  // 512 audio threads: 16 rows x 32 samples per pass, 8 passes
 		const int ns0 = jn * PPX_CHUNK, ncl = (n - ns0 < PPX_CHUNK) ? (n - ns0) : PPX_CHUNK;
 		if (load_next) {
-			const char* src = (const char*)(a.io + (size_t)k0 * 2 * n + ns0);
+			const char* src = io_rows(ns0);
 			if (ncl == PPX_CHUNK && k0 + G <= a.K) {                                  // a whole chunk of a whole group: no bounds to test
 #pragma unroll
-				for (int i = 0; i < IOV; i++) iov[i] = *(const float*)(src + (unsigned)((arow + 16 * i) * n + acol) * 4u);
+				for (int i = 0; i < IOV; i++) iov[i] = *(const float*)(src + (unsigned)((arow + 16 * i) * nb + acol) * 4u);
 			}
 			else {
 #pragma unroll
 				for (int i = 0; i < IOV; i++) {
 					const int row = arow + 16 * i, inst = row >> 1;
-					iov[i] = (acol < ncl && k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + acol) * 4u) : 0.f;
+					iov[i] = (acol < ncl && k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * nb + acol) * 4u) : 0.f;
 				}
 			}
 		}
@@ -1767,6 +1774,8 @@ struct FxGraphArgs {
 	SampleRate fs;
 	unsigned long long samples;              // samples processed before this block (every delay's write cursor derives from it)
 	const int* rand; int rand_per_instance;  // Noise: this block's rand() values, [K][n * draws per sample] (or null)
+	int blocks; size_t block_stride;         // klg_fx_staged only (klg_fx_render_device): a span of `blocks` blocks of n samples in one launch, block b's [K][CH][n] rows
+	                                         // block_stride floats after block b - 1's; prepare() at the head of every block as in Effect::process(buffer).  0 / 1: one block
 };
 struct FxCtx { SampleRate fs; const float* ctl; unsigned long long samples; float* ring; const int* rand; };   // ring: this lane's column of the group's tile; rand: this instance's draws of the block
 __device__ __forceinline__ float ctl_read(const FxCtx& c, unsigned i) { return c.ctl[i]; }

@@ -387,7 +387,7 @@ static int fx_flush_updates(klg_fx* f, hipStream_t st) {
 	return 0;
 }
 
-static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
+static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st, int blocks = 1) {
 	if (int rc = fx_flush_updates(f, st)) return rc;
 	if (f->controls_dirty) {
 		HIP_TRY(hipStreamSynchronize(st));
@@ -401,6 +401,7 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
 	a.fs.f = f->fs.f; a.fs.w = f->fs.w; a.fs.timeInc = 1.0f / f->fs.f;
 	a.samples = f->samples;
 	a.rand = nullptr; a.rand_per_instance = 0;
+	a.blocks = blocks; a.block_stride = (size_t)f->K * (size_t)f->channels * (size_t)n;      // (blocks > 1: fx_span_in_one_launch() said so)
 	const int draws = f->graph->noise_calls;
 	int slot = -1;
 	if (draws > 0) {
@@ -424,8 +425,17 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st) {
 	if (f->staged_fn) { TimedLaunch timed(f); HIP_TRY(klg_module_launch(f->staged_fn, (unsigned)(f->kpad / (size_t)f->graph->staged_G), (unsigned)f->graph->staged_threads, (unsigned)f->graph->staged_lds, st, params)); }
 	else { TimedLaunch timed(f); HIP_TRY(klg_module_launch(f->graph_fn, (unsigned)(f->kpad / FX_WG), FX_WG, 0, st, params)); }
 	if (slot >= 0) HIP_TRY(hipEventRecord(f->rand_done[slot], st));
-	f->samples += (unsigned long long)n;
+	f->samples += (unsigned long long)n * (unsigned long long)blocks;
 	return 0;
+}
+// Can a span of blocks of n samples go out as ONE launch?  The staged form of a recorded effect walks the blocks itself (prepare() at the head of each; not with
+// Noise: the draws are made per block on the host).  PingPong's pipelined kernel takes the span as one long block (PingPong.k's prepare() only sets the DC filters
+// and no dial moves inside a span): blocks of whole chunks.  Reverb's kernel stages a whole block in LDS: it stays a launch (two) per block.
+static bool fx_span_in_one_launch(const klg_fx* f, int n) {
+	if (f->graph) return f->staged_fn != nullptr && f->graph->noise_calls == 0;
+	if (f->patch != KLG_PATCH_PINGPONG) return false;
+	const char* e1 = getenv("KLG_FX_PINGPONG1"); const char* e2 = getenv("KLG_FX_ABLATE");
+	return n % PPX_CHUNK == 0 && !(e1 && e1[0] == '1') && !(e2 && atoi(e2));
 }
 
 // the early-sum buffers, second stream and events of KLG_FX_REVERB_EARLY modes 1 / 2: allocated the first time such a mode is selected (banks above 2,048
@@ -446,8 +456,8 @@ static bool rv_early_alloc(klg_fx* f) {
 	return ok;
 }
 
-static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
-	if (f->graph) return fx_enqueue_graph(f, d_io, n, st);
+static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st, int blocks = 1) {
+	if (f->graph) return fx_enqueue_graph(f, d_io, n, st, blocks);
 	if (f->patch == KLG_PATCH_REVERB && !f->rv_touched.empty()) {                    // prepare(): `if (controls.changed())` Reverb.k:238 — a dial changes only through klg_fx_set_control
 		std::sort(f->rv_touched.begin(), f->rv_touched.end());                        // (instance order: every changed instance re-seeds and draws from rand())
 		for (int k : f->rv_touched) { rv_prepare(f, k); f->rv_flag[k] = 0; }
@@ -467,7 +477,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 		PingPongArgs a;
 		a.state = f->d_state; a.kpad = f->kpad; a.K = f->K; a.rings = f->d_rings;
 		a.position = (int)(f->samples % 192000ull);
-		a.io = d_io; a.n = n;
+		a.io = d_io; a.n = n * blocks; a.nb = blocks > 1 ? n : 0; a.block_stride = (size_t)f->K * 2 * (size_t)n;
 		a.fs.f = f->fs.f; a.fs.w = f->fs.w; a.fs.timeInc = 1.0f / f->fs.f;
 		a.dc = f->pp_dc; a.c1_min = PP_DIALS[1].min; a.c1_max = PP_DIALS[1].max;
 		static const int ablate = []() { const char* e = getenv("KLG_FX_ABLATE"); return e ? atoi(e) : 0; }();
@@ -543,7 +553,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st) {
 	}
 	HIP_TRY(hipGetLastError());
 	if (bracket) { HIP_TRY(hipEventRecord(f->tev[2 * f->launches + 1], st)); f->launches++; }
-	f->samples += (unsigned long long)n;
+	f->samples += (unsigned long long)n * (unsigned long long)blocks;
 	return 0;
 }
 
@@ -577,6 +587,23 @@ extern "C" int klg_fx_process_device(klg_fx* f, float* d_io, int n, void* hip_st
 	if (f->multi) return fail(KLG_ERR_INVALID, "klg_fx_process_device: this bank is sharded over %zu devices (klg_init) and a device block lives on ONE of them: use klg_fx_process (host block), or one bank per GPU", f->multi->shard.size());
 	KLG_BIND(f);
 	return fx_enqueue(f, d_io, n, hip_stream ? (hipStream_t)hip_stream : f->stream);
+}
+// replaces: the host's block loop around an effect for a stream known in advance (templates/juce/effect/Source/PluginProcessor.cpp:153-178 called `blocks`
+// times: offline rendering, a benchmark): see include/klang_mi355.h
+extern "C" int klg_fx_render_device(klg_fx* f, float* d_io, int blocks, int n, void* hip_stream) {
+	if (!f || !d_io || blocks <= 0 || n <= 0 || n > f->max_block) return fail(KLG_ERR_INVALID, "klg_fx_render_device: bad arguments (blocks=%d, n=%d)", blocks, n);
+	if (f->multi) return fail(KLG_ERR_INVALID, "klg_fx_render_device: this bank is sharded over %zu devices (klg_init) and a device buffer lives on ONE of them: one bank per GPU", f->multi->shard.size());
+	KLG_BIND(f);
+	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : f->stream;
+	const size_t stride = (size_t)f->K * (size_t)f->channels * (size_t)n;
+	if (blocks > 1 && fx_span_in_one_launch(f, n)) {
+		// (the cursor arithmetic of a launch is 32-bit from the start of its span: spans of at most 2^20 samples per launch)
+		const int per = std::max(1, (1 << 20) / n);
+		for (int b = 0; b < blocks; b += per) if (int rc = fx_enqueue(f, d_io + (size_t)b * stride, n, st, std::min(per, blocks - b))) return rc;
+		return 0;
+	}
+	for (int b = 0; b < blocks; b++) if (int rc = fx_enqueue(f, d_io + (size_t)b * stride, n, st)) return rc;
+	return 0;
 }
 extern "C" int klg_fx_sync(klg_fx* f) {
 	if (!f) return fail(KLG_ERR_INVALID, "klg_fx_sync: NULL handle");

@@ -596,6 +596,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "\t(void)srecp; (void)pslots;\n";
 		s += "\tfor (int i = t; i < NW * G; i += NT) srec[i] = a.state[(size_t)(i / G) * a.kpad + k0 + (i % G)];\n";
 		s += "\tFxCtx cp, cs;\n\tcp.fs = cs.fs = a.fs; cp.samples = cs.samples = a.samples;\n";
+		s += "\tunsigned long long samples0 = a.samples; float* io = a.io;                // of the block being processed (a span: klg_fx_render_device)\n";
 		s += "\tcp.ctl = a.controls + (size_t)(k0 + pg) * KLG_MAX_CTL; cs.ctl = a.controls + (size_t)(k0 + sg) * KLG_MAX_CTL;\n";
 		s += "\tfloat* const ring0 = a.rings + (size_t)(k0 / 64) * a.ring_rows * 64 + (k0 % 64);\n\tcp.ring = ring0 + pg; cs.ring = ring0 + sg;\n";
 		s += "\tcp.rand = a.rand ? a.rand + (size_t)(k0 + pg < a.K ? k0 + pg : 0) * (size_t)a.rand_per_instance : nullptr;\n";
@@ -605,11 +606,13 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		// the plain body over [from, from + count) of the block, on one lane per instance (wave 0): prepare() at the head of the block, chunks whose check failed, a ragged tail
 		s += "\tauto plain = [&](int from, int count, bool with_prepare) {\n";
 		s += "\t\tif (wv != 0 || ln >= G) return;\n\t\tP::Rec rec;\n#pragma unroll\n\t\tfor (int w = 0; w < NW; w++) rec.w[w] = srec[w * G + ln];\n";
-		s += "\t\tP::Live L; FxCtx c = cs; c.samples = a.samples + (unsigned long long)from;\n";
+		s += "\t\tP::Live L; FxCtx c = cs; c.samples = samples0 + (unsigned long long)from;\n";
 		s += "\t\tif (with_prepare) P::begin(L, rec, c); else P::begin_core(L, rec, c);\n\t\tL.sidx = from;\n";
 		s += "\t\tfor (int q = 0; q < count; q++) {\n\t\t\tconst float in0 = tile[(0 * C + q) * G + ln], in1 = CH > 1 ? tile[(1 * C + q) * G + ln] : 0.f;\n\t\t\tfloat out0 = 0.f, out1 = 0.f;\n";
 		s += "\t\t\tP::sample(L, c, in0, in1, out0, out1);\n\t\t\ttile[(0 * C + q) * G + ln] = out0;\n\t\t\tif (CH > 1) tile[(1 * C + q) * G + ln] = out1;\n\t\t}\n";
 		s += "\t\tP::end(L, rec);\n#pragma unroll\n\t\tfor (int w = 0; w < NW; w++) if (patch_stores<P>(w)) srec[w * G + ln] = rec.w[w];\n\t};\n";
+		s += "\tconst int nblk = a.blocks > 1 ? a.blocks : 1;\n\tfor (int blk = 0; blk < nblk; blk++) {                                          // Effect::process(buffer), block after block (klang.h:4208-4216)\n";
+		s += "\tsamples0 = a.samples + (unsigned long long)blk * (unsigned long long)a.n; io = a.io + (size_t)blk * a.block_stride; cp.samples = cs.samples = samples0;\n";
 		if (g.prepare_ops > 0) s += "\tplain(0, 0, true);                                                           // Effect::prepare(): once per block\n\t__syncthreads();\n";
 		if (pipelined) s += "\tfor (int i = t; i < NW * G; i += NT) { srecp[i] = srec[i]; srecp[NW * G + i] = srec[i]; }\n\t__syncthreads();\n";
 		// what the lanes hold for the whole block: the dials, the members process() only reads
@@ -631,12 +634,12 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY && set_at[nd] >= 0 && pfx[(size_t)set_at[nd]]) { xdecl += F("\tTap xn_d%zut = { 0, 0.f }, xc_d%zut = { 0, 0.f }; (void)xc_d%zut;\n", nd, nd, nd); xrot += F("\t\txc_d%zut = xn_d%zut;\n", nd, nd); }
 		s += xdecl;
 		// every Delay's write cursor is the sample counter (one step per input()): where it stands at the start of the block (64-bit once), 32-bit from there
-		for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY) s += F("\tconst unsigned d%zub = (unsigned)((a.samples * %dull) %% %dull);\n", nd, k_in[nd], g.arg((int)nd));
+		for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY) s += F("\tconst unsigned d%zub = (unsigned)((samples0 * %dull) %% %dull);\n", nd, k_in[nd], g.arg((int)nd));
 		// the caller's rows of a chunk (a row's C samples are contiguous in the caller's block: G * CH * C = CH * NT values, CH per thread) are requested a chunk
 		// ahead and put into the tile at the top of their chunk
 		s += "\tfloat nx[CH];\n";
 		s += "\tauto fetch = [&](int s0) {\n#pragma unroll\n\t\tfor (int j = 0; j < CH; j++) { const int i = tp + j * NTP, row = i / C, q = i % C, gi = row / CH, ch = row % CH;\n";
-		s += "\t\t\tnx[j] = (t < NTP && s0 + q < a.n && k0 + gi < a.K) ? a.io[((size_t)(k0 + gi) * CH + ch) * a.n + s0 + q] : 0.f; }\n\t};\n";
+		s += "\t\t\tnx[j] = (t < NTP && s0 + q < a.n && k0 + gi < a.K) ? io[((size_t)(k0 + gi) * CH + ch) * a.n + s0 + q] : 0.f; }\n\t};\n";
 		s += "\tfetch(0);\n";
 		if (pipelined) {                                                           // the control path of chunk 0
 			s += "\t{ const int s0 = -C; const bool pre = a.n >= C; const int parn = 0; (void)parn;\n" + pcdecl;
@@ -678,11 +681,13 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		{ std::string rest; for (const std::string& d : deferred) rest += d; deferred.clear(); rest += P.prefix_commit; if (!rest.empty()) s += rest + "\t\t__syncthreads();\n"; }
 		s += "\t\tif (!ok) { plain(s0, cl, false); __syncthreads(); }\n";
 		s += "\t\tfor (int i = t; i < G * CH * C; i += NT) { const int row = i / C, q = i % C, gi = row / CH, ch = row % CH;\n";
-		s += "\t\t\tif (q < cl && k0 + gi < a.K) a.io[((size_t)(k0 + gi) * CH + ch) * a.n + s0 + q] = tile[(ch * C + q) * G + gi]; }\n";
+		s += "\t\t\tif (q < cl && k0 + gi < a.K) io[((size_t)(k0 + gi) * CH + ch) * a.n + s0 + q] = tile[(ch * C + q) * G + gi]; }\n";
 		s += "\t\t__syncthreads();\n";
 		if (stamp) s += "\t\t{ const long long now = wall_clock64(); tacc[15] += now - tprev; tprev = now; }\n";
 		s += "\t}\n";
+
 		if (stamp) s += "\tif (t == 0 && blockIdx.x == 0) { printf(\"staged stamps (10 ns): head %lld |\", thead); for (int i = 0; i < 16; i++) printf(\" %lld\", tacc[i]); printf(\"\\n\"); }\n";
+		s += "\t}                                                                          // (the next block of the span)\n";
 		s += "\tfor (int i = t; i < NW * G; i += NT) if (k0 + (i % G) < a.K && patch_stores<P>(i / G)) a.state[(size_t)(i / G) * a.kpad + k0 + (i % G)] = srec[i];\n";
 		s += "#undef SL\n#undef SLP\n}\n";
 		for (int i = 0; i < NV; i++) if (live_op(i) && !ser_of(i)) P.parallel_ops++;

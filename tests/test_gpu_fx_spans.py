@@ -1,0 +1,92 @@
+"""klg_fx_render_device: a span of blocks of an effect bank in one call — the host's block loop around Stereo::Effect::process(Stereo::buffer)
+(templates/juce/effect/Source/PluginProcessor.cpp:153-178 called once per block) for a stream known in advance.  Whatever the library does with the span
+(PingPong's pipeline running across the block boundaries in ONE launch, the staged form of a recorded effect walking the blocks itself with prepare() at the
+head of each, Reverb's launches back to back) the samples and the state it leaves are those of block-by-block calls, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import klang_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# an effect of our own whose prepare() is NOT idempotent: `tape.set(controls[0] * 2400)` places the read head once per block (the per-block prologue),
+# process() is `in >> tape; out = in + tape` — Delay::process walks the head.  A span must re-place the head at every block boundary.
+TAPE = """klgg 1
+kind effect 1
+ctl 1
+dial 0 0 1 0.5
+node 0 delay 4800
+op ctl 0 -1 -1 -1 00000000
+op const 1 -1 -1 -1 45160000
+op mul 2 0 1 -1 00000000
+op delayset -1 2 -1 0 00000000
+op in 3 -1 -1 -1 00000000
+op delayin -1 3 -1 0 00000000
+op delayout 4 -1 -1 0 00000000
+op add 5 3 4 -1 00000000
+prepare 4
+ret 5
+end
+"""
+
+
+def recorded(name):
+    prog = open(os.path.join(GOLDEN, name + ".klgg")).read()
+    rec = np.array([int(w, 16) for w in open(os.path.join(GOLDEN, name + ".rec")).read().split()], np.uint32)
+    return prog, rec
+
+
+def make(kind, K, n):
+    if kind == "pingpong":
+        return klang_amd.FxBank("pingpong", K, max_block=n), 2
+    if kind == "reverb":
+        return klang_amd.FxBank("reverb", K, max_block=n), 2
+    if kind == "pingpong_recorded":
+        prog, rec = recorded("pingpong_recorded")
+        return klang_amd.FxBank(prog, K, max_block=n, initial_record=rec, channels=2), 2
+    if kind == "tape":
+        return klang_amd.FxBank(TAPE, K, max_block=n, channels=1), 1
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,n,spans", [("pingpong", 256, (1, 5, 3, 8)), ("pingpong", 96, (4, 7)), ("pingpong", 100, (3, 3)), ("pingpong", 512, (2, 3)),
+                                          ("pingpong_recorded", 256, (4, 3)), ("pingpong_recorded", 80, (5, 2)), ("reverb", 256, (3, 2)), ("tape", 64, (6, 3)), ("tape", 50, (4, 2))])
+def test_a_span_of_blocks_equals_block_by_block(kind, n, spans):
+    K = 70
+    rng = np.random.default_rng(7)
+    a, CH = make(kind, K, n)
+    b, _ = make(kind, K, n)
+    if kind.startswith("pingpong"):
+        for k in range(0, K, 3):
+            for bank in (a, b):
+                bank.set_control(k, 5, 0.01 + 0.005 * k); bank.set_control(k, 1, 0.01 + 0.005 * k); bank.set_control(k, 0, 0.3 + 0.008 * k)
+                if k % 9 == 0: bank.set_control(k, 2, 0.6)
+    elif kind == "reverb":                                                       # (Direct up: the first reflection is 50 ms = ten blocks away)
+        for k in range(K):
+            for bank in (a, b): bank.set_control(k, 0, 0.3 + 0.01 * k); bank.set_control(k, 2, 0.5); bank.set_control(k, 3, 0.4)
+    elif kind == "tape":
+        for k in range(K):
+            for bank in (a, b): bank.set_control(k, 0, 0.02 + 0.013 * k)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for si, blocks in enumerate(spans):
+            x = (torch.from_numpy(rng.random((blocks, K, CH, n), dtype=np.float32)) - 0.5).cuda() * (1.0 if si < len(spans) - 1 else 0.25)
+            ya, yb = x.clone(), x.clone()
+            a.render_device(ya.data_ptr(), blocks, n, st.cuda_stream)
+            for blk in range(blocks):
+                b.process_device(yb[blk].data_ptr(), n, st.cuda_stream)
+            st.synchronize()
+            bad = (ya.view(torch.int32) != yb.view(torch.int32)).nonzero()
+            assert len(bad) == 0, f"span {si} ({blocks} blocks of {n}): {len(bad)} samples differ, first [block, instance, channel, sample] {bad[0].tolist()}"
+            assert float(ya.abs().max()) > 1e-3
+            if kind.startswith("pingpong") and si == 0:                           # a dial moved between two spans
+                for bank in (a, b): bank.set_control(1, 5, 0.31); bank.set_control(1, 1, 0.31)
+    if kind in ("pingpong_recorded", "tape"):                                    # ... and the same state afterwards
+        for k in (0, 1, K - 1):
+            assert np.array_equal(a.download_record(k), b.download_record(k))
+    a.close(); b.close()
