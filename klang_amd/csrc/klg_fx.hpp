@@ -406,12 +406,15 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	const bool whole_chunks = (n % PPX_CHUNK) == 0, whole_group = k0 + G <= a.K;
 	const float dly = (w_audio && whole_chunks) ? PPW(PP_SM1) : 0.f;            // this instance's delay time: every sample's, if the block turns out stationary
 		// the audio waves' part of step j; SLOT = j mod P (compile-time: the register arrays are indexed by constants only); nch = the block's chunks
-		auto audio_part = [&](auto slot_c, const int j, const int nch) __attribute__((always_inline)) {
+		// STEADY (a span's inner steps, 2 <= j <= nch - P - 2: every chunk the step touches exists): no test of j at all — through run-time guards every part of
+		// a step ends in a join, and behind a join the compiler waits for everything that is under way
+		auto audio_part = [&](auto slot_c, auto steady_c, const int j, const int nch) __attribute__((always_inline)) {
 			constexpr int RS = decltype(slot_c)::value, IS = (RS + 1) % P;
+			constexpr bool ST = decltype(steady_c)::value;
 			int at = tid - 64; asm volatile("" : "+v"(at));                    // (see the general loop: keeps per-thread addresses out of loop-invariant registers)
 			const int acol = at & 31, arow = at >> 5;
 			const int jn = j + 1, js = j - 2;
-			if (js >= 0 && js < nch && !(KLG_PPX_ABLATE & 2) && !(KLG_PPX_VARIANT & 1)) {                 // the caller's rows of chunk j - 2 (filtered in the step before): to memory
+			if ((ST || (js >= 0 && js < nch)) && !(KLG_PPX_ABLATE & 2) && !(KLG_PPX_VARIANT & 1)) {       // the caller's rows of chunk j - 2 (filtered in the step before): to memory
 				char* dst = io_rows(js * PPX_CHUNK);
 #pragma unroll
 				for (int i = 0; i < DIOV; i++) {
@@ -419,12 +422,12 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 					if (whole_group || k0 + (row >> 1) < a.K) *(float*)(dst + (unsigned)(row * nb + acol) * 4u) = S.tile[js & 3][row & 1][acol][row >> 1];
 				}
 			}
-			if (jn >= 0 && jn < nch) {                                      // the caller's rows of chunk j + 1 (requested in step j - P): into LDS
+			if (ST || (jn >= 0 && jn < nch)) {                              // the caller's rows of chunk j + 1 (requested in step j - P): into LDS
 #pragma unroll
 				for (int i = 0; i < DIOV; i++) { const int row = arow + 16 * i; S.tile[jn & 3][row & 1][acol][row >> 1] = iov[IS][i]; }
 			}
 			const int u0 = (wv - 1) * PPX_PER + lq;
-			if (j >= 0 && j < nch && !(KLG_PPX_ABLATE & 8)) {                                        // AUDIO of chunk j: its rows were requested in step j - P
+			if ((ST || (j >= 0 && j < nch)) && !(KLG_PPX_ABLATE & 8)) {                              // AUDIO of chunk j: its rows were requested in step j - P
 				const int pos0 = (int)(((long long)a.position + j * PPX_CHUNK) % SIZE);
 				float (*T)[PPX_CHUNK][G + 1] = S.tile[j & 3];
 #pragma unroll
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				}
 			}
 			const int c = j + P;
-			if (c >= 0 && c < nch && !(KLG_PPX_ABLATE & 4)) {                                        // the ring rows of chunk j + P
+			if ((ST || (c >= 0 && c < nch)) && !(KLG_PPX_ABLATE & 4)) {                              // the ring rows of chunk j + P
 				const int pos1 = (int)(((long long)a.position + c * PPX_CHUNK) % SIZE);
 #pragma unroll
 				for (int q = 0; q < PASSES; q++) {
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				}
 			}
 			const int c2 = j + P + 1;
-			if (c2 >= 0 && c2 < nch) {                                      // the caller's rows of chunk j + P + 1
+			if (ST || (c2 >= 0 && c2 < nch)) {                              // the caller's rows of chunk j + P + 1
 				const char* src = io_rows(c2 * PPX_CHUNK);
 				if (whole_group) {
 #pragma unroll
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		auto first_requests = [&]() __attribute__((always_inline)) {
 			auto prologue = [&](auto self, auto t_c) __attribute__((always_inline)) {
 				constexpr int T = decltype(t_c)::value, J = T - P - 1;
-				if constexpr (T < P) { audio_part(IntTag<((J % P) + P) % P>{}, J, nchunks); self(self, IntTag<T + 1>{}); }
+				if constexpr (T < P) { audio_part(IntTag<((J % P) + P) % P>{}, BoolTag<false>{}, J, nchunks); self(self, IntTag<T + 1>{}); }
 			};
 			prologue(prologue, IntTag<0>{});
 		};
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			auto run = [&](auto self, auto t_c) __attribute__((always_inline)) {
 				constexpr int T = decltype(t_c)::value, J = T - 1;
 				if constexpr (J <= NCH + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) {
-					audio_part(IntTag<((J % P) + P) % P>{}, J, NCH);
+					audio_part(IntTag<((J % P) + P) % P>{}, BoolTag<false>{}, J, NCH);
 					__syncthreads();
 					self(self, IntTag<T + 1>{});
 				}
@@ -542,19 +545,29 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			for (int j = -1; j <= nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1); j++) { other_part(j); __syncthreads(); }
 		}
 		else {
-			auto deep_step = [&](auto slot_c, const int j) __attribute__((always_inline)) {
-				if (w_audio) audio_part(slot_c, j, nchunks); else other_part(j);
+			auto deep_step = [&](auto slot_c, auto steady_c, const int j) __attribute__((always_inline)) {
+				if (w_audio) audio_part(slot_c, steady_c, j, nchunks); else other_part(j);
 				__syncthreads();
 			};
+			const int jend = nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1);
 			int j = -1;
-			deep_step(IntTag<P - 1>{}, j); ++j;                                     // (-1 = P - 1 mod P)
-			for (;;) {
-				if (j > nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) break;
-				deep_step(IntTag<0>{}, j); ++j;
-				if (j > nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) break;
-				deep_step(IntTag<1 % P>{}, j); ++j;
-				if constexpr (P > 2) { if (j > nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) break; deep_step(IntTag<2 % P>{}, j); ++j; }
-				if constexpr (P > 3) { if (j > nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) break; deep_step(IntTag<3 % P>{}, j); ++j; }
+			deep_step(IntTag<P - 1>{}, BoolTag<false>{}, j); ++j;                   // (-1 = P - 1 mod P)
+			// a group of P steps, slots 0 .. P - 1 (j is a multiple of P at its head); guarded: leaves where the block ends
+			auto group = [&](auto steady_c) __attribute__((always_inline)) -> bool {
+				constexpr bool ST = decltype(steady_c)::value;
+				if (!ST && j > jend) return false;
+				deep_step(IntTag<0>{}, steady_c, j); ++j;
+				if (!ST && j > jend) return false;
+				deep_step(IntTag<1 % P>{}, steady_c, j); ++j;
+				if constexpr (P > 2) { if (!ST && j > jend) return false; deep_step(IntTag<2 % P>{}, steady_c, j); ++j; }
+				if constexpr (P > 3) { if (!ST && j > jend) return false; deep_step(IntTag<3 % P>{}, steady_c, j); ++j; }
+				return true;
+			};
+			// the head of the span with its guards (steps 0 .. P - 1), the inner steps in groups without any (every chunk a step of theirs touches
+			// exists: 2 <= j, j + P - 1 <= nchunks - P - 2), the tail with guards again
+			if (group(BoolTag<false>{})) {
+				while (j + P - 1 <= nchunks - P - 2) group(BoolTag<true>{});
+				while (group(BoolTag<false>{})) {}
 			}
 		}
 	}
