@@ -214,7 +214,7 @@ def valu_issue(wave_samples, kern_s, per_sample):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # live HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around a child of this script
 # ---------------------------------------------------------------------------------------------------------------------------------
-def pmc_traffic_live(args, kernel_substr, timeout_s=240):
+def pmc_traffic_live(args, kernel_substr, timeout_s=240, child_args=None, blocks_per_launch=1):
     """bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024 (gfx950 FETCH_SIZE half-count, MI355X_MICROARCH.md §HBM), mean over the
     child's steady-state launches of the named kernel; None if rocprofv3 is unavailable or anything goes wrong (never costs the bench line)."""
     import csv
@@ -227,7 +227,7 @@ def pmc_traffic_live(args, kernel_substr, timeout_s=240):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="klg_pmc_", dir="/tmp")
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--pmc-child", "--voices", str(args.voices), "--block", str(args.block), "--patch", args.patch]
+                   "--pmc-child"] + (child_args if child_args is not None else ["--voices", str(args.voices), "--block", str(args.block), "--patch", args.patch])
             subprocess.run(cmd, check=True, timeout=timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -239,15 +239,40 @@ def pmc_traffic_live(args, kernel_substr, timeout_s=240):
                 return None, f"no {counter} rows for {kernel_substr}"
             vals = vals[len(vals) // 2:]                                # the child's settled blocks
             got[counter] = sum(vals) / len(vals)
-        return (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in this run (2 passes, {len(vals)} launches each); (2*FETCH_SIZE + WRITE_SIZE) KB * 1024"
+        return (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0 / blocks_per_launch, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in this run (2 passes, {len(vals)} launches each" + (f" of {blocks_per_launch} blocks" if blocks_per_launch > 1 else "") + "); (2*FETCH_SIZE + WRITE_SIZE) KB * 1024"
     except Exception as e:                                              # noqa: BLE001
         return None, f"pmc leg failed: {type(e).__name__}"
+
+
+PMC_FX_SPAN = 16                 # blocks per span in the effect legs' counter children
+
+
+def pmc_child_fx(spec, N):
+    """what rocprofv3 wraps for an effect leg: `patch:K[:ctl=value,...]` — the bank with its dials at rest (the spans before the counted ones let a
+    PingPong's smoothers converge), spans of PMC_FX_SPAN blocks through klg_fx_render_device"""
+    import torch
+    import klang_amd
+    parts = spec.split(":")
+    patch, K = parts[0], int(parts[1])
+    bank = klang_amd.FxBank(patch, K, max_block=N)
+    for kv in (parts[2].split(",") if len(parts) > 2 and parts[2] else []):
+        c, v = kv.split("=")
+        for k in range(K):
+            bank.set_control(k, int(c), float(v))
+    io = (torch.rand((PMC_FX_SPAN, K, 2, N), device="cuda") - 0.5) * 0.1
+    ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
+    for _ in range(12):                                                    # 8 spans to settle, the later half of the rest is what counts
+        bank.render_device(io.data_ptr(), PMC_FX_SPAN, N, ts.cuda_stream)
+    torch.cuda.synchronize()
+    bank.close()
 
 
 def pmc_child(args):
     """what rocprofv3 wraps: the headline steady state, few blocks (setup identical, so the kernel sees the same voice population)"""
     import torch
     import klang_amd
+    if args.pmc_fx:
+        return pmc_child_fx(args.pmc_fx, args.block)
     notes = NOTES.get(args.patch, 32)
     V = groups_voices(args.voices)
     bank = klang_amd.SynthBank(args.patch, synths=V // notes, notes=notes, max_block=args.block)
@@ -341,9 +366,11 @@ def run_literal_script(patch, voices, N, label, phases=False):
     return res
 
 
-def run_fx(patch, K, N, dials=None, tag=""):
+def run_fx(patch, K, N, dials=None, tag="", args=None):
     """cfg 4: K instances, 375 blocks (2 s): a white-noise burst for the first 4800 samples, then silence; io resident in HBM.
-    dials: {index: value} set on every instance before the first block (default: the patch's own initial values)"""
+    The blocks are submitted as SPANS (klg_fx_render_device: the host knows all its blocks — the effect template's callback,
+    templates/juce/effect/Source/PluginProcessor.cpp:153-178, called span after span): the span's [blocks][K][2][N] buffer is filled (burst or
+    silence) inside the timed region, then processed in place.  dials: {index: value} set on every instance before the first block."""
     import torch
     import klang_amd
     bank = klang_amd.FxBank(patch, K, max_block=N)
@@ -354,40 +381,55 @@ def run_fx(patch, K, N, dials=None, tag=""):
     burst_blocks = (4800 + N - 1) // N
     inputs = torch.rand((burst_blocks, K, 2, N), device="cuda", generator=g) - 0.5
     inputs[-1, :, :, 4800 - (burst_blocks - 1) * N:] = 0
-    io = torch.zeros((K, 2, N), device="cuda")
+    block_bytes = K * 2 * N * 4
+    span = next(d for d in (75, 25, 15, 5, 3, 1) if d * block_bytes <= (2 << 30) or d == 1)   # a divisor of the script's fifth (75 blocks), <= 2 GB of io per span
+    io = torch.zeros((span, K, 2, N), device="cuda")
     torch.cuda.synchronize()
     ts = torch.cuda.Stream()
     with torch.cuda.stream(ts):
         st = ts.cuda_stream
-        for _ in range(8):                       # untimed: silence in, silence out — the bank's 6-51 GB of zeroed delay lines are really there afterwards
-            bank.process_device(io.data_ptr(), N, st)
+        bank.render_device(io.data_ptr(), min(span, 8), N, st)   # untimed: silence in, silence out — the bank's 6-51 GB of zeroed delay lines are really there afterwards
         torch.cuda.synchronize()
         bank.timing_begin()
         t0 = time.perf_counter()
         head = SCRIPT_BLOCKS // 5                    # the kernel's time is collected in two parts: the first fifth of the script (a PingPong's dial smoothers are
-        for b in range(SCRIPT_BLOCKS):               # still on their way for ~40 blocks after construction: its general pipeline), and the rest (dials at rest)
-            if b == head:
+        b0 = 0                                       # still on their way for ~40 blocks after construction: its general pipeline), and the rest (dials at rest).
+        while b0 < SCRIPT_BLOCKS:                    # Whether a PingPong launch may run its request-ahead pipeline is decided per launch, on the dials as the launch finds
+            if b0 == head:                           # them: the first fifth goes in spans of a third (a launch that starts while a smoother still moves stays general)
                 head_launches, head_ms = bank.timing_end()      # (reads the events of finished launches: synchronises the stream once, inside the timed region — counted in dt)
                 bank.timing_begin()
-            if b < burst_blocks:
-                io.copy_(inputs[b])
-            else:
-                io.zero_()
-            bank.process_device(io.data_ptr(), N, st)
+            take = min(span if b0 >= head else max(1, span // 3), SCRIPT_BLOCKS - b0, (head - b0) if b0 < head else SCRIPT_BLOCKS)
+            io[:take].zero_()                                               # the host's next input: silence ...
+            if b0 < burst_blocks:
+                nb = min(take, burst_blocks - b0); io[:nb].copy_(inputs[b0:b0 + nb])   # ... or the burst
+            bank.render_device(io.data_ptr(), take, N, st)
+            b0 += take
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     rest_launches, rest_ms = bank.timing_end()
-    launches, kms = head_launches + rest_launches, head_ms + rest_ms
-    kern_s = 1e-3 * kms / launches
-    rest_s = 1e-3 * rest_ms / rest_launches
+    kern_s = 1e-3 * (head_ms + rest_ms) / SCRIPT_BLOCKS                     # per BLOCK (a PingPong span is one launch, a Reverb block one or two)
+    rest_s = 1e-3 * rest_ms / (SCRIPT_BLOCKS - head)
     ab = K * N * FX_BYTES_PER_SAMPLE[patch]
-    res = {"name": f"cfg4_{patch}_{K}{tag}", "workload": (f"dials {dials}: " if dials else "") + f"{K} x {patch.capitalize()}.k (Stereo::Effect), {SCRIPT_BLOCKS} blocks of {N} samples: noise burst 4800 samples then silence, io + {bank.state_bytes * K / 1e9:.1f} GB of delay lines resident in HBM",
-           "value": K * N * SCRIPT_BLOCKS / dt, "unit": "instance*samples/s", "ms_per_step": 1e3 * dt / SCRIPT_BLOCKS, "steps": SCRIPT_BLOCKS, "kernel_ms_mean": 1e3 * kern_s,
-           "finite": bool(torch.isfinite(io).all().item()),
-           "roofline": {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": ("klg_fx_reverb_q" if patch == "reverb" and K <= 8192 else KERNEL_OF[patch]), "algorithmic_bytes_per_launch": ab, "bytes_per_instance_sample": FX_BYTES_PER_SAMPLE[patch],
-                        "after_the_first_fifth": {"kernel_ms_mean": 1e3 * rest_s, "frac": ab / rest_s / 1e9 / HBM_PEAK_GBS, "launches": rest_launches,
-                                                  "note": "the same launches without the script's first 75 blocks, in which a freshly constructed PingPong's dial smoothers are still converging"}}}
+    kernel = ("klg_fx_reverb_q" if patch == "reverb" and K <= 8192 else KERNEL_OF[patch])
+    traffic, how = None, "not collected"
+    if args is not None and os.environ.get("KLG_BENCH_PMC_FX", "1") != "0":
+        spec = f"{patch}:{K}:" + ",".join(f"{c}={v}" for c, v in (dials or {}).items())
+        one_launch = patch == "pingpong"
+        traffic, how = pmc_traffic_live(args, kernel, timeout_s=180, child_args=["--pmc-fx", spec, "--block", str(N)], blocks_per_launch=PMC_FX_SPAN if one_launch else 1)
+    roof = {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": how,
+            "kernel": kernel, "algorithmic_bytes_per_launch": ab, "bytes_per_instance_sample": FX_BYTES_PER_SAMPLE[patch], "per": "block of %d samples (a PingPong span of %d blocks is ONE launch: its duration / %d)" % (N, span, span),
+            "after_the_first_fifth": {"kernel_ms_mean": 1e3 * rest_s, "frac": ab / rest_s / 1e9 / HBM_PEAK_GBS, "launches": rest_launches,
+                                      "note": "the same blocks without the script's first 75, in which a freshly constructed PingPong's dial smoothers are still converging"}}
+    if patch == "reverb":
+        # what the algorithm really moves: SURVEY's 312 B count every FilteredDelay once per sample; Reverb.k processes each TWICE (Reverb.k:150-168):
+        # reads 20 taps x 2 lines x 4 B + 16 lines x 2 heads x 4 B + io 8 B = 296 B, writes 2 x 4 B + 16 lines x 2 inputs x 4 B + io 8 B = 144 B
+        db = K * N * 440
+        roof["distinct_bytes_per_launch"] = db
+        roof["distinct_bytes_per_instance_sample"] = 440
+        roof["frac_on_distinct_bytes"] = db / kern_s / 1e9 / HBM_PEAK_GBS
+    res = {"name": f"cfg4_{patch}_{K}{tag}", "workload": (f"dials {dials}: " if dials else "") + f"{K} x {patch.capitalize()}.k (Stereo::Effect), {SCRIPT_BLOCKS} blocks of {N} samples in spans of {span} (klg_fx_render_device): noise burst 4800 samples then silence, io + {bank.state_bytes * K / 1e9:.1f} GB of delay lines resident in HBM",
+           "value": K * N * SCRIPT_BLOCKS / dt, "unit": "instance*samples/s", "ms_per_step": 1e3 * dt / SCRIPT_BLOCKS, "steps": SCRIPT_BLOCKS, "kernel_ms_mean": 1e3 * kern_s, "blocks_per_span": span,
+           "finite": bool(torch.isfinite(io).all().item()), "roofline": roof}
     bank.close()
     return res
 
@@ -465,6 +507,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="headline only (what ranks of an N > 1 run do anyway)")
     ap.add_argument("--realtime-voices", type=int, default=32 << 20, help="the deadline test: 32 Mi voices pass (p99 4.4 ms, every block under 5.33 ms); 36 Mi have blocks over the deadline")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-fx", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
@@ -584,15 +627,31 @@ def main():
         checksum = float(mixes[(state["i"] - 1) % RING].abs().sum().item())
     alive_now = int((bank.stages() != 3).sum())
     expect_alive = int(sounding.alive_after[(state["i"] - 1) % SCRIPT_BLOCKS])
-    if pieces:                                           # the render kernel's own time (HIP events around each launch): the NEXT blocks of the same steady state, launched one by one
-        for _ in range(20):                              # (the chip idled through the read-back above: a few blocks before the events count)
-            step()
+    aux_ms_per_step, pass2_ms_per_step = None, None
+    if pieces:
+        # The kernels' own durations come from the NEXT K blocks of the same steady state (every block of the cyclic script sees the same population),
+        # submitted the same way — as spans of the script — with kernel timing armed: events attached to every dispatch; a span is then one call that
+        # launches its blocks back to back instead of a graph replay.  Render kernel: klg_timing_end; the blocks' event kernel and reduce: klg_timing_end_aux.
+        def cut(pos, count):
+            out, off = [], 0
+            while count > 0:
+                take = min(count, SCRIPT_BLOCKS - pos)
+                out.append((pos, take, span_out[off].data_ptr())); pos = (pos + take) % SCRIPT_BLOCKS; count -= take; off += take
+            return out
+        for (f, c, ptr) in cut(state["i"] % SCRIPT_BLOCKS, args.steps):     # (the chip idled through the read-back above: K blocks untimed)
+            script.render_device(f, c, ptr, N, stream)
+        state["i"] += args.steps
         torch.cuda.synchronize()
         bank.timing_begin()
-        for _ in range(max(60, min(args.steps, SCRIPT_BLOCKS))):
-            step()
+        t2 = time.perf_counter()
+        for (f, c, ptr) in cut(state["i"] % SCRIPT_BLOCKS, args.steps):
+            script.render_device(f, c, ptr, N, stream)
         torch.cuda.synchronize()
+        pass2_ms_per_step = 1e3 * (time.perf_counter() - t2) / args.steps
+        aux_launches, aux_ms = bank.timing_end_aux()
         launches, kernel_ms = bank.timing_end()
+        aux_ms_per_step = aux_ms / args.steps
+        state["i"] += args.steps
     sounding_timed = float(sum(int(sounding[(first_timed + j) % SCRIPT_BLOCKS]) for j in range(args.steps)))
 
     if rank == 0:
@@ -621,6 +680,11 @@ def main():
             # sub-object (`traffic` = HBM bytes per launch from the PMC counters, as everywhere)
             "roofline": {"bound": "valu", "achieved": flops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_how,
                          "kernel": kernel_name, "kernel_ms": 1e3 * kern_s,
+                         "kernel_ms_source": ("HIP events attached to the dispatches of the next K blocks of the same steady state, submitted as spans like the timed ones (launches back to back instead of a graph replay)" if pieces else "HIP events attached to the dispatches of the timed blocks"),
+                         "step_kernels_ms": (1e3 * kern_s + aux_ms_per_step) if aux_ms_per_step is not None else None,
+                         "step_kernels": "render + this block's event kernel + the voice-mix reduce (klg_timing_end + klg_timing_end_aux)",
+                         "ms_per_step_of_the_timing_pass": pass2_ms_per_step,
+                         "kernels_fit_step": (bool(1e3 * kern_s + aux_ms_per_step <= ms_per_step) if aux_ms_per_step is not None else None),
                          "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(patch, 0),
                          "peak_note": "157.3 TFLOP/s is the packed-FMA fp32 peak; bit-parity forbids contraction, so separate mul / add reach at most half of it (v_pk_mul_f32 / v_pk_add_f32) — see `valu.sustain_loop.issue_rate_frac_est` for the fraction of VALU ISSUE slots used",
                          "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
@@ -642,10 +706,10 @@ def main():
             leg(run_literal_script, "sub2a", V, N, "cfg2_script_as_written_at_headline_size", phases=True)
             leg(run_literal_script, "sub2a", 1024, N, "cfg2_1024_voices")
             leg(run_literal_script, "supersaw", 16384, N, "cfg3_16384_supersaw_voices")
-            leg(run_fx, "pingpong", 4096, N)
-            leg(run_fx, "reverb", 4096, N)
-            leg(run_fx, "pingpong", 4096, N, dials={2: 0.5, 3: 0.5}, tag="_vibrato")    # Scratch / Rate up (six of PingPong.k's eight presets have them up): the LFO's fp64 sine and a controls[1].set() per sample
-            leg(run_fx, "pingpong", 65536, N)                             # the same patch at bank scale: where config 4 meets north_star's "≥ 40 % of the HBM roofline" (100 GB of delay lines)
+            leg(run_fx, "pingpong", 4096, N, args=args)
+            leg(run_fx, "reverb", 4096, N, args=args)
+            leg(run_fx, "pingpong", 4096, N, dials={2: 0.5, 3: 0.5}, tag="_vibrato", args=args)    # Scratch / Rate up (six of PingPong.k's eight presets have them up): the LFO's fp64 sine and a controls[1].set() per sample
+            leg(run_fx, "pingpong", 65536, N, args=args)                             # the same patch at bank scale: where config 4 meets north_star's "≥ 40 % of the HBM roofline" (100 GB of delay lines)
             leg(run_literal_script, "fm4", 131072, N, "cfg5_share_131072_fm4_voices")
             leg(run_realtime, "sub2a", args.realtime_voices, N)
             out["configs"] = configs

@@ -240,6 +240,9 @@ int klg_fx_graph_form(const klg_fx* f, int* instances_per_workgroup, int* sample
  * sums of the block, klg_fx_reverb_q) and is timed by events recorded around the pair. */
 int klg_timing_begin(klg_synth* s);
 int klg_timing_end(klg_synth* s, int* launches, float* total_ms);
+/* ... and, while timing is armed, the same for a block's OTHER kernels — the event kernel and the voice-mix reduce (none for small banks, whose render launch
+ * does both): launches and summed duration since klg_timing_begin.  Call it before klg_timing_end.  (What lets bench.py check that the kernels of a step fit the step.) */
+int klg_timing_end_aux(klg_synth* s, int* launches, float* total_ms);
 
 /* ------------------------------------------------------------------------------------------------
  * Effect banks: `instances` independent Stereo::Effect objects (klang.h:4703-4717) of one patch.

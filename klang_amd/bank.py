@@ -175,6 +175,12 @@ class SynthBank:
     def timing_begin(self):
         check(self._L.klg_timing_begin(self._h), "klg_timing_begin")
 
+    def timing_end_aux(self):
+        """(launches, ms) of the blocks' event kernels and reduces since timing_begin (klg_timing_end_aux); before timing_end"""
+        n, ms = C.c_int(), C.c_float()
+        check(self._L.klg_timing_end_aux(self._h, C.byref(n), C.byref(ms)), "klg_timing_end_aux")
+        return n.value, ms.value
+
     def timing_end(self):
         n, ms = C.c_int(), C.c_float()
         check(self._L.klg_timing_end(self._h, C.byref(n), C.byref(ms)), "klg_timing_end")

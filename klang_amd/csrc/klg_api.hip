@@ -41,6 +41,14 @@ struct TimedLaunch {                                                // binds a h
 	}
 	~TimedLaunch() { g_time0 = g_time1 = nullptr; }
 };
+struct TimedAux {                                                   // the same for a block's OTHER launches (its event kernel, the voice-mix reduce): a second list of events
+	template<class H> explicit TimedAux(H* h) {
+		if (!h->timing) return;
+		if ((int)h->tev_aux.size() < 2 * (h->launches_aux + 1)) { hipEvent_t e0 = nullptr, e1 = nullptr; if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return; h->tev_aux.push_back(e0); h->tev_aux.push_back(e1); }
+		g_time0 = h->tev_aux[2 * h->launches_aux]; g_time1 = h->tev_aux[2 * h->launches_aux + 1]; h->launches_aux++;
+	}
+	~TimedAux() { g_time0 = g_time1 = nullptr; }
+};
 
 #pragma clang fp contract(off)
 
@@ -202,7 +210,7 @@ struct klg_synth {
 	// pinned readback
 	float* h_mix = nullptr; uint32_t* h_flags = nullptr; float* h_per_voice = nullptr;
 	// timing
-	bool timing = false; std::vector<hipEvent_t> tev; int launches = 0;
+	bool timing = false; std::vector<hipEvent_t> tev, tev_aux; int launches = 0, launches_aux = 0;   // (aux: the block's event kernel and reduce, klg_timing_end_aux)
 };
 
 static void synth_free(klg_synth* s) {
@@ -219,6 +227,7 @@ static void synth_free(klg_synth* s) {
 	if (s->stage_done) (void)hipEventDestroy(s->stage_done);
 	if (s->module) (void)hipModuleUnload(s->module);
 	for (auto e : s->tev) (void)hipEventDestroy(e);
+	for (auto e : s->tev_aux) (void)hipEventDestroy(e);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	delete s;
 }
@@ -251,6 +260,12 @@ struct Rccl {
 };
 static Rccl g_rccl;
 enum { KLG_NCCL_FLOAT32 = 7, KLG_NCCL_SUM = 0 };                   // ncclFloat32, ncclSum (rccl.h)
+// The library is not LINKED against RCCL (librccl.so is loaded on the first multi-device bank: a one-GPU host needs none), so the two enumerators are spelled
+// out above — and checked against the header at build time wherever the header is:
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+static_assert((int)ncclFloat32 == (int)KLG_NCCL_FLOAT32 && (int)ncclSum == (int)KLG_NCCL_SUM, "rccl.h's ncclFloat32 / ncclSum are not the values klg_api.hip passes to ncclAllReduce");
+#endif
 
 struct Multi {
 	std::vector<klg_synth*> shard; std::vector<int> first;          // shard i owns synth instances [first[i], first[i + 1])
@@ -530,15 +545,16 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 }
 static void launch_events(klg_synth* s, const EventArgs& a, hipStream_t st) {
 	const dim3 g((a.runs + 63) / 64), b(64);
-	if (s->graph) { hipLaunchKernelGGL(klg_apply_records, g, b, 0, st, a, s->W); return; }
+	TimedAux timed(s);
+	if (s->graph) { KLG_LAUNCH(klg_apply_records, g, b, 0, st, a, s->W); return; }
 	switch (s->patch) {
-	case KLG_PATCH_SINE: hipLaunchKernelGGL(klg_apply_events<PatchSine>, g, b, 0, st, a); break;
-	case KLG_PATCH_BSINE: hipLaunchKernelGGL(klg_apply_events<PatchBSine>, g, b, 0, st, a); break;
-	case KLG_PATCH_SUB2A: hipLaunchKernelGGL(klg_apply_events<PatchSub2a>, g, b, 0, st, a); break;
-	case KLG_PATCH_SUB2B: hipLaunchKernelGGL(klg_apply_events<PatchSub2b>, g, b, 0, st, a); break;
-	case KLG_PATCH_SUPERSAW: hipLaunchKernelGGL(klg_apply_events<PatchSuperSaw>, g, b, 0, st, a); break;
-	case KLG_PATCH_FM3: hipLaunchKernelGGL(klg_apply_events<PatchFM<3>>, g, b, 0, st, a); break;
-	case KLG_PATCH_FM4: hipLaunchKernelGGL(klg_apply_events<PatchFM<4>>, g, b, 0, st, a); break;
+	case KLG_PATCH_SINE: KLG_LAUNCH(klg_apply_events<PatchSine>, g, b, 0, st, a); break;
+	case KLG_PATCH_BSINE: KLG_LAUNCH(klg_apply_events<PatchBSine>, g, b, 0, st, a); break;
+	case KLG_PATCH_SUB2A: KLG_LAUNCH(klg_apply_events<PatchSub2a>, g, b, 0, st, a); break;
+	case KLG_PATCH_SUB2B: KLG_LAUNCH(klg_apply_events<PatchSub2b>, g, b, 0, st, a); break;
+	case KLG_PATCH_SUPERSAW: KLG_LAUNCH(klg_apply_events<PatchSuperSaw>, g, b, 0, st, a); break;
+	case KLG_PATCH_FM3: KLG_LAUNCH(klg_apply_events<PatchFM<3>>, g, b, 0, st, a); break;
+	case KLG_PATCH_FM4: KLG_LAUNCH(klg_apply_events<PatchFM<4>>, g, b, 0, st, a); break;
 	}
 }
 
@@ -887,8 +903,8 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	if (s->launch_error != hipSuccess) { const hipError_t e = s->launch_error; s->launch_error = hipSuccess; return fail(KLG_ERR_HIP, "launching the compiled graph patch failed: %s", hipGetErrorString(e)); }
 	fused_events.consumed = true;
 	if (a.ticket) {}                                                 // (the render launch's last workgroup added the rows)
-	else if (s->note_ch == 2) hipLaunchKernelGGL(klg_reduce_stereo, dim3((n + 31) / 32, 2), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
-	else hipLaunchKernelGGL(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2);
+	else if (s->note_ch == 2) { TimedAux timed(s); KLG_LAUNCH(klg_reduce_stereo, dim3((n + 31) / 32, 2), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2); }
+	else { TimedAux timed(s); KLG_LAUNCH(klg_reduce, dim3((n + 31) / 32), dim3(1024), 0, st, (const float*)s->d_partials, render_grid(s), n, d_mix, 2); }
 	HIP_TRY(hipGetLastError());
 	s->stages_dirty = true;
 	return 0;
@@ -1341,7 +1357,18 @@ extern "C" int klg_script_render_device(klg_script* k, int first_block, int bloc
 extern "C" int klg_script_capture_span(klg_script* k, int first_block, int blocks, float* d_out, int n, void* hip_stream) { return script_render(k, first_block, blocks, d_out, n, hip_stream, true); }
 
 extern "C" int klg_timing_begin(klg_synth* s) { if (!s) return fail(KLG_ERR_INVALID, "NULL handle");
- if (s->multi) { for (klg_synth* sh : s->multi->shard) klg_timing_begin(sh); return 0; } s->timing = true; s->launches = 0; return 0; }
+ if (s->multi) { for (klg_synth* sh : s->multi->shard) klg_timing_begin(sh); return 0; } s->timing = true; s->launches = 0; s->launches_aux = 0; return 0; }
+// the block's OTHER kernels since klg_timing_begin (the event kernel, the voice-mix reduce): launches and summed duration; call before klg_timing_end
+extern "C" int klg_timing_end_aux(klg_synth* s, int* launches, float* total_ms) {
+	if (!s || !launches || !total_ms) return fail(KLG_ERR_INVALID, "klg_timing_end_aux: bad arguments");
+	if (s->multi) return klg_timing_end_aux(s->multi->shard[0], launches, total_ms);
+	KLG_BIND(s);
+	HIP_TRY(hipDeviceSynchronize());
+	float total = 0.f;
+	for (int i = 0; i < s->launches_aux; i++) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, s->tev_aux[2 * i], s->tev_aux[2 * i + 1])); total += ms; }
+	*launches = s->launches_aux; *total_ms = total;
+	return 0;
+}
 extern "C" int klg_timing_end(klg_synth* s, int* launches, float* total_ms) {
 	if (!s || !launches || !total_ms) return fail(KLG_ERR_INVALID, "klg_timing_end: bad arguments");
 	if (s->multi) {                                                     // the slowest shard's render time (they run concurrently)

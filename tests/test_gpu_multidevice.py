@@ -120,6 +120,45 @@ def test_fm4_share_of_config_5_over_two_shards(oracle_build):
     assert float(np.abs(got["mix"]).max()) > 0
 
 
+def test_config_5_at_its_literal_size_over_eight_shards(oracle_build):
+    """BASELINE config 5 as written — 1,048,576 FM4 voices over 8 GPUs, one reduce of the stereo block — on whatever this box has: klg_init with EIGHT ids
+    (the GPUs there are, repeated: eight shares of 131,072 voices each; a device listed twice combines by a plain add, distinct devices by the one
+    ncclAllReduce).  256 class instances against the oracle, every one of the 128 replicas of a class — they lie in all eight shards — bit-exact with its
+    class, note stages equal, the combined mix = the fp64 sum of all voices.  The first 8-GPU run must not be the first 8-way execution."""
+    import torch
+    import klang_amd
+    from klg_driver import rel_err, run_scenario_oracle
+    from test_gpu_fullsize import class_scenario, replicate
+    classes, notes, total = 256, 32, 32768                                # 32,768 instances x 32 notes = 1,048,576 voices; 4,096 instances = 131,072 voices per shard
+    dump = [0, 3]
+    small = class_scenario("fm4", classes, notes, 5, 256, 777, False, dump)
+    ref = run_scenario_oracle(small, oracle_build)
+    big = replicate(small, total)
+    have = max(1, torch.cuda.device_count())
+    devs = [i % have for i in range(8)]
+    klang_amd.init(devs)
+    try:
+        got = run_scenario_gpu(big)
+    finally:
+        klang_amd.init([0])
+    pv = got["per_voice"]
+    Vc = small.voices
+    assert pv.shape[1] == total * notes == 1 << 20
+    assert rel_err(pv[:, :Vc], ref["per_voice"]) <= 1e-5
+    assert np.array_equal(got["stages"][:, :Vc], ref["stages"])
+    reps = pv.reshape(len(dump), total // classes, Vc, -1)
+    for r in range(1, total // classes):                                  # (replica r lies in shard r * 8 // 128)
+        assert np.array_equal(reps[:, r].view(np.uint32), reps[:, 0].view(np.uint32)), f"replica {r} (shard {r * 8 // (total // classes)}) differs from its class representative"
+    st = got["stages"].reshape(got["stages"].shape[0], total // classes, Vc)
+    assert (st == st[:, :1]).all(), "note stages differ between replicas"
+    V = pv.shape[1]
+    for i, b in enumerate(dump):
+        want = pv[i].astype(np.float64).sum(axis=0)
+        peak = float(np.abs(pv[i]).max())
+        assert float(np.abs(got["mix"][b, 0] - want).max()) <= 4 * np.sqrt(V) * np.finfo(np.float32).eps * peak * np.sqrt(V)
+    assert float(np.abs(got["mix"]).max()) > 0
+
+
 @pytest.mark.parametrize("patch", ["pingpong", "reverb"])
 def test_effect_bank_is_sharded_by_instance(patch):
     """effects shard BY INSTANCE, no collective.  Under klg_init with several ids an effect bank is dealt to the devices in

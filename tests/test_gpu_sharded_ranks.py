@@ -104,6 +104,27 @@ def test_bench_py_two_ranks_end_to_end():
     assert "all-reduce" in out["config"]["parallelism"]
 
 
+def test_bench_py_eight_ranks_end_to_end():
+    """`python bench.py --gpus 8` as the driver's scaling run launches it, end to end, before there is an 8-GPU node to run it on: eight ranks (on a box with
+    fewer GPUs all on cuda:0 over gloo, KLG_BENCH_ONE_GPU=1: a functional run of the 8-way path, not a measurement), eight shards with their scripts, the
+    ring of four buffers, one asynchronous all-reduce per block, ONE JSON line from rank 0 whose aggregate counts all eight shards."""
+    import json
+    import torch
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 8:
+        env["KLG_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--voices", str(375 * 256)],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert np.isfinite(out["value"]) and out["value"] > 0
+    assert out["config"]["voices_alive_after_last_block"] == out["config"]["voices_alive_expected"]
+    assert out["config"]["mix_checksum"] > 0 and "x8" in out["config"]["parallelism"]
+
+
 FX_RANK = r'''
 import os, sys
 import numpy as np

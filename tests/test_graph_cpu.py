@@ -34,7 +34,7 @@ end
 
 def check(program, want_source=False):
     from klang_amd._lib import lib
-    buf = C.create_string_buffer(1 << 17)
+    buf = C.create_string_buffer(1 << 22)
     rc = lib().klg_graph_check(program.encode(), 1 if want_source else 0, buf, len(buf))
     return rc, buf.value.decode()
 
@@ -243,9 +243,56 @@ def test_an_effect_may_write_its_controls_take_abs_and_place_delay_heads_per_sam
     prog = open(os.path.join(ROOT, "tests", "golden", "pingpong_recorded.klgg")).read()
     rc, src = check(prog, want_source=True)
     assert rc == 0, src
-    for needle in ("float n7;", "const float r14 = L.n7;", "__builtin_fabsf(r26)", "L.n7 = r30;", "(r25 < u2f(0x3a83126fu)) ? u2f(0x3a83126fu) : (u2f(0x3f800000u) < r25) ? u2f(0x3f800000u) : r25",
+    for needle in ("float n7;", "const float r14 = L.n7;", "__builtin_fabsf(r26)", "L.n7 = r30;", "const float r30h = (u2f(0x3f800000u) < r25) ? u2f(0x3f800000u) : r25;", "(r25 < u2f(0x3a83126fu)) ? u2f(0x3a83126fu) : r30h;",
                    "L.n8 = L.n8 * 0.999f + (1.f - 0.999f) * L.n7;", "L.n6 = L.n6 * 0.999f + (1.f - 0.999f) * L.ctl5;", "L.ctl5 = c.ctl[5];", "L.n0t = delay_set(L.n0pos, 192000, r46);", "Rows2 h1; h1.i = L.n0t.position;", "delay_process_h(Ring{",
                    "osc.set" if False else "L.n2.position = r31;"):
         assert needle in src, needle
     rc, msg = check(prog.replace("kind effect 2\n", "").replace("ret2 67 68", "ret 67"))
     assert rc < 0                                                                      # a Note does not write its Synth's controls (nor has it `in`)
+
+
+def test_the_recorded_config_4_effects_get_a_staged_form():
+    """klang_amd/csrc/klg_graph_staged.hpp on the CPU (hipRTC needs no GPU): the recorded PingPong.k and Reverb.k both get the sample-parallel kernel beside
+    klg_fx_graph<P> — PingPong.k with its control path (the dial smoothers, the scratch detector, the LFO's phase, the delay times) a chunk ahead of the audio
+    path, the LFO's sine taken per (sample, instance), the DC filters as serial loops; Reverb.k's twenty biquads as serial loops between two parallel levels.
+    KLG_FX_STAGED=0 leaves the one-lane kernel alone."""
+    for name, needles in (("pingpong_recorded", ("extern \"C\" __global__", "klg_fx_staged", "beside the", "basic_sine_of(", "basic_sine_arg(L.n2)", "staged_process(Ring{", "xc_d0t = xn_d0t;", "plain(s0, cl, false)")),
+                          ("reverb_recorded", ("klg_fx_staged", "staged_tap_stereo(Ring{", "biquad_process(L.n", "if (bad) *flag = 1;", "plain(s0, cl, false)"))):
+        prog = open(os.path.join(ROOT, "tests", "golden", name + ".klgg")).read()
+        rc, src = check(prog, want_source=True)
+        assert rc == 0, src
+        for needle in needles:
+            assert needle in src, (name, needle)
+    os.environ["KLG_FX_STAGED"] = "0"
+    try:
+        rc, src = check(open(os.path.join(ROOT, "tests", "golden", "pingpong_recorded.klgg")).read(), want_source=True)
+        assert rc == 0 and "klg_fx_staged" not in src
+    finally:
+        del os.environ["KLG_FX_STAGED"]
+
+
+def test_a_conditional_delay_input_keeps_the_one_lane_kernel():
+    """What the staged form refuses: an input() of a Delay inside an `if` (its write cursor would depend on the samples).  The program still compiles — as
+    klg_fx_graph<P> only."""
+    prog = """klgg 1
+kind effect 1
+ctl 1
+dial 0 0 1 0.5
+node 0 delay 4800
+op in 0 -1 -1 -1 00000000
+op ctl 1 -1 -1 -1 00000000
+op const 2 -1 -1 -1 3f000000
+op cmp 3 1 2 -1 00000001
+op if -1 3 -1 -1 00000000
+op delayin -1 0 -1 0 00000000
+op endif -1 -1 -1 -1 00000000
+op const 4 -1 -1 -1 42c80000
+op delaytap 5 4 -1 0 00000000
+op add 6 0 5 -1 00000000
+ret 6
+end
+"""
+    rc, src = check(prog, want_source=True)
+    assert rc == 0, src
+    assert "klg_fx_graph" in src or "struct PatchGen" in src
+    assert "klg_fx_staged" not in src

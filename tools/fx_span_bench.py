@@ -19,12 +19,12 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream())
     st = torch.cuda.current_stream().cuda_stream
     for effect in (sys.argv[2:] or ["pingpong", "pingpong_recorded", "reverb"]):
-        for B in (1, 4, 16, 64):
+        for B in [int(x) for x in os.environ.get("FX_SPAN_BLOCKS", "1,4,16,64").split(",")]:
             if effect == "pingpong_recorded":
                 prog, rec = recorded("pingpong_recorded"); bank = klang_amd.FxBank(prog, K, max_block=N, initial_record=rec, channels=2)
             else:
                 bank = klang_amd.FxBank(effect, K, max_block=N)
-            io = (torch.rand((B, K, 2, N), device="cuda") - 0.5) * 0.1
+            io = (torch.rand((B, K, 2, N), device="cuda") - 0.5) * (0.0 if os.environ.get("FX_SPAN_SILENCE") else 0.1)
             for _ in range(max(2, 128 // B)): bank.render_device(io.data_ptr(), B, N, st)      # converge
             reps = max(4, 256 // B)
             torch.cuda.synchronize(); bank.timing_begin()
