@@ -100,18 +100,18 @@ struct Packable {
 	virtual void pack(uint32_t* w) const = 0; virtual void unpack(const uint32_t* w) = 0; virtual ~Packable() { if (live) forget(this); }
 	virtual void host_cursor(unsigned long long /*inputs so far*/) {}   // an effect's Delay: its write cursor, which on the device is derived from the sample count (a host-run prepare() places read heads against it)
 };
-struct Obj { const void* addr; size_t size; int kind; const Packable* packable; int arg; const void* key = nullptr; uint64_t serial = 0; };     // a primitive or a signal member seen while a Note / Effect was constructed (arg: Delay SIZE; key / serial: liveness)
+struct Obj { const void* addr; size_t size; int kind; const Packable* packable; int arg; const void* key = nullptr; uint64_t serial = 0; const int* live_arg = nullptr; };   // live_arg: a Delay<0>'s run-time SIZE, read when the program is finished (resize() may come after the constructor)     // a primitive or a signal member seen while a Note / Effect was constructed (arg: Delay SIZE; key / serial: liveness)
 // Where construction is noted: the Recorder of a prototype built by notes.add<T>() / gpu::EffectBank<FX> (members = the address range of
 // the object), or the construction LOG every Plugin / Note owns — what lets Effect::process(buffer) and Note::process(buffer) find the
 // members of an object the HOST constructed (`PingPong pingpong;`), whose type the base class does not know.
 struct Sink {
 	std::vector<Obj> objs; bool effect = false, tracked = false;
-	void note(const void* addr, size_t size, int kind, const Packable* p = nullptr, int arg = 0, const void* key = nullptr) {
+	void note(const void* addr, size_t size, int kind, const Packable* p = nullptr, int arg = 0, const void* key = nullptr, const int* live_arg = nullptr) {
 		if (!key) key = p ? (const void*)p : addr;
 		uint64_t serial = 0;
 		if (tracked) { if (!live) live = new LiveMap(); auto it = live->serial.find(key); serial = it != live->serial.end() ? it->second : (live->serial[key] = live->next++); }
 		for (Obj& o : objs) if (o.addr == addr && (!tracked || o.serial == serial)) { o.kind = kind; o.size = size; if (p) o.packable = p; return; }       // ADSR refines the Envelope it derives from
-		objs.push_back({ addr, size, kind, p, arg, key, serial });
+		objs.push_back({ addr, size, kind, p, arg, key, serial, live_arg });
 	}
 	bool alive(const Obj& o) const { if (!tracked) return true; if (!live) return false; const auto it = live->serial.find(o.key); return it != live->serial.end() && it->second == o.serial; }
 };
@@ -1289,7 +1289,7 @@ inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	std::vector<int> node_id(R.objs.size(), -1);
 	std::vector<char> node_used(R.objs.size(), 0);
 	for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].node >= 0) node_used[(size_t)ops[i].node] = 1;
-	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) { node_id[i] = (int)R.prog.nodes.size(); R.prog.nodes.push_back(R.objs[i].kind); R.prog.node_arg.push_back(R.objs[i].arg); }
+	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) { node_id[i] = (int)R.prog.nodes.size(); R.prog.nodes.push_back(R.objs[i].kind); R.prog.node_arg.push_back(R.objs[i].live_arg ? *R.objs[i].live_arg : R.objs[i].arg); }
 	std::vector<Op> out_ops;
 	int kept_prepare = 0;
 	for (size_t i = 0; i < ops.size(); i++) if (keep[i]) { Op o = ops[i]; if (o.node >= 0) o.node = node_id[(size_t)o.node]; out_ops.push_back(o); if ((int)i < R.prog.prepare_ops) kept_prepare++; }
@@ -1492,12 +1492,33 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 // Delay<SIZE> (klang.h:3381-3512).  In an Effect: a ring per instance in HBM, cursor = the sample counter (`x >> delay`, `delay << x`,
 // `delay(time)`, `(x >> delay)(time)`); on the host the object only takes part in the recording.  In a Note (physical models): a
 // `notedelay` node — the line lives in HBM per voice, its cursors (write position, the read head of set() / process()) in the record.
-template<int SIZE> struct Delay : Modifier, gpu::Packable {
+// Delay<0> (klang.h:3515-3624): the same object with a run-time SIZE, given by resize(samples).  On the GPU a line's SIZE fixes its ring in HBM when the bank is
+// created: resize() belongs where the reference's examples have it — the constructor, or the first prepare() — and the size is read when the recording is
+// finished; a resize() to ANOTHER size afterwards (the reference reallocates a cleared buffer) is refused loudly.
+namespace gpu {
+template<int N> struct DelaySize { static constexpr int SIZE = N; const int* live_size() const { return nullptr; } };
+template<> struct DelaySize<0> {
+	int SIZE = 0; bool sized = false;
+	const int* live_size() const { return &SIZE; }
+	void resize(int samples) {
+		if (samples == SIZE) return;
+		if (sized) { std::fprintf(stderr, "klang-mi355: Delay<0>::resize(%d) of a line that was sized to %d samples: on the GPU a line keeps the ring it was given\n", samples, SIZE); std::abort(); }
+		SIZE = samples; sized = true;
+	}
+};
+}
+template<int SIZE_> struct Delay : Modifier, gpu::Packable, gpu::DelaySize<SIZE_> {
+	using gpu::DelaySize<SIZE_>::SIZE;
 	bool in_note = false;
 	float time = 1.f; int position = 0; struct { int position = 0; float fraction = 0.f; } last;      // host mirror (notes)
 	Delay() {
-		if (gpu::Sink* r = gpu::constructing()) { in_note = !r->effect; r->note(this, sizeof(Delay), in_note ? klg::graph::N_NDELAY : klg::graph::N_DELAY, this, SIZE, static_cast<const gpu::Packable*>(this)); }
+		if (gpu::Sink* r = gpu::constructing()) { in_note = !r->effect; r->note(this, sizeof(Delay), in_note ? klg::graph::N_NDELAY : klg::graph::N_DELAY, this, SIZE, static_cast<const gpu::Packable*>(this), this->live_size()); }
 		else in_note = true;                                                        // every further Note of a recorded type
+	}
+	// Delay::lagrange(float) klang.h:3429-3458: third-order Lagrange interpolation over the four samples around the read position
+	template<typename TIME> signal lagrange(const TIME& delay) {
+		if (gpu::Recorder* r = gpu::recording()) { signal t; if constexpr (std::is_arithmetic_v<TIME>) t = signal((float)delay); else t = signal(const_cast<TIME&>(delay)); signal s; s.reg = r->emit(klg::graph::OP_DELAYTAP, r->reg_of(t), -1, r->node(this, "Delay"), 3, true); return s; }
+		device_only("Delay::lagrange()"); return signal();
 	}
 	using Generic::Input<signal>::input;
 	using Modifier::set;

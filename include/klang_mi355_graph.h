@@ -147,7 +147,7 @@ enum OpCode {
 	OP_FREQ,        /* dst = oscillator node .frequency    (Oscillator::frequency klang.h:2856, as last set by on() or by oscset) */
 	OP_IN,          /* dst = this sample of input channel imm            (effects: `in`, `in.l`, `in.r`)                       */
 	OP_DELAYIN,     /* a >> delay node                                  Delay::input klang.h:3396-3403                        */
-	OP_DELAYTAP,    /* dst = delay node (a)                             Delay::tap(float) klang.h:3412-3427; imm 1: tap(int) 3405-3410 (a holds the integer); imm 2: one channel of Stereo::Delay::tap(float) 4668-4681 */
+	OP_DELAYTAP,    /* dst = delay node (a)                             Delay::tap(float) klang.h:3412-3427; imm 1: tap(int) 3405-3410 (a holds the integer); imm 2: one channel of Stereo::Delay::tap(float) 4668-4681; imm 3: lagrange(float) 3429-3458 (effects) */
 	OP_SMOOTH,      /* dst = smooth node: controls[imm].smooth()        Control::smooth klang.h:1715                          */
 	OP_OPERATOR,    /* dst = operator node process()       modulator a (or -1: none), amp b (or -1: keep)   Operator::process klang.h:4164-4168 */
 	OP_CMP,         /* dst = (a REL b) ? 1.0 : 0.0         imm = relation: 0 <, 1 >, 2 <=, 3 >=, 4 ==, 5 !=  (IEEE: false on NaN except !=) */
@@ -297,7 +297,7 @@ struct Program {
 			case OP_FREQ: if (!is_oscillator(k) && k != N_OPERATOR) return bad("node is not an oscillator"); break;
 			case OP_IN: if (channels == 0 || (int)o.imm >= channels) return bad("`in` needs an effect program with that channel"); break;
 			case OP_DELAYIN: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
-			case OP_DELAYTAP: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); if (o.imm > 2u) return bad("unknown tap kind"); need_a = true; break;
+			case OP_DELAYTAP: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); if (o.imm > 3u || (o.imm == 3u && k != N_DELAY)) return bad("unknown tap kind"); need_a = true; break;
 			case OP_DELAYOUT: if (k != N_NDELAY && k != N_DELAY) return bad("node is not a delay"); break;
 			case OP_DELAYSET: if (k != N_NDELAY && k != N_DELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
 			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); if (!channels && !open.empty()) return bad("a Note's controls[i].smooth() may not sit inside an `if`: the bank advances the Synth's control by a fixed number of steps per sounding note and sample"); break;

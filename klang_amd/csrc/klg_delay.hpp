@@ -173,11 +173,26 @@ __device__ __forceinline__ float staged_tap_stereo(const Ring& r, int position, 
 	const float a = pad ? 0.f : r.rd(ri), b = pad ? 0.f : r.rd(rj);
 	return a * (1.f - frac) + b * frac;
 }
+__device__ __forceinline__ float staged_lagrange(const Ring& r, int position, float delay, RingWindow w, int& bad) {   // delay_lagrange below + the check of its four rows
+	const int SIZE = r.size;
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += SIZE;
+	int i = (int)read; i = i < 0 ? 0 : (i > SIZE ? SIZE : i);
+	const float x = read - i;
+	const int i0 = (i - 1 + SIZE) % SIZE, i2 = (i + 1) % SIZE, i3 = (i + 2) % SIZE;
+	bad |= (int)(ring_in_window(i0, SIZE, w) || ring_in_window(i, SIZE, w) || ring_in_window(i2, SIZE, w) || ring_in_window(i3, SIZE, w));
+	const float y0 = r.rd(i0), y1 = r.rd(i), y2 = r.rd(i2), y3 = r.rd(i3);
+	const float c0 = (-x * (x - 1) * (x - 2)) / 6.0f;
+	const float c1 = ((x + 1) * (x - 1) * (x - 2)) / 2.0f;
+	const float c2 = (-x * (x + 1) * (x - 2)) / 2.0f;
+	const float c3 = (x * (x + 1) * (x - 1)) / 6.0f;
+	return c0 * y0 + c1 * y1 + c2 * y2 + c3 * y3;
+}
 __device__ __forceinline__ float delay_lagrange(const Ring& r, int position, float delay) {
 	const int SIZE = r.size;
 	float read = (float)(position - 1) - delay;
 	if (read < 0.f) read += SIZE;
-	const int i = (int)read;
+	int i = (int)read; i = i < 0 ? 0 : (i > SIZE ? SIZE : i);                      // (a delay beyond the line is undefined in the reference; here the tap stays inside this line; i == SIZE: the pad element, as in tap(float))
 	const float x = read - i;
 	const float y0 = r.rd((i - 1 + SIZE) % SIZE), y1 = r.rd(i), y2 = r.rd((i + 1) % SIZE), y3 = r.rd((i + 2) % SIZE);
 	const float c0 = (-x * (x - 1) * (x - 2)) / 6.0f;

@@ -444,7 +444,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		case OP_DELAYSET: body += "\t\t" + n + "t = delay_set(" + n + fmt("pos, %d, ", g.arg(o.node)) + a + ");\n"; break;   // Delay::set klang.h:3480-3489
 		case OP_DELAYTAP:
 			if (hoist_of[oi] >= 0) { body += d + (o.imm == 2u ? "delay_tap_stereo_h(" : "delay_tap_float_h(") + ring(o.node) + ", " + n + "pos, " + a + fmt(", h%d, h%da, h%db, ", hoist_of[oi], hoist_of[oi], hoist_of[oi]) + hazard_of(hoist_of[oi]) + ");\n"; break; }
-			body += d + (o.imm == 1u ? "delay_tap_int(" + ring(o.node) + ", " + n + "pos, (int)" + a + ");\n" : (o.imm == 2u ? "delay_tap_stereo(" : "delay_tap_float(") + ring(o.node) + ", " + n + "pos, " + a + ");\n"); break;   // imm 1: tap(int), klang.h:3405-3410
+			body += d + (o.imm == 1u ? "delay_tap_int(" + ring(o.node) + ", " + n + "pos, (int)" + a + ");\n" : (o.imm == 3u ? "delay_lagrange(" : o.imm == 2u ? "delay_tap_stereo(" : "delay_tap_float(") + ring(o.node) + ", " + n + "pos, " + a + ");\n"); break;   // imm 1: tap(int), klang.h:3405-3410; 3: lagrange(float) 3429-3458
 		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 7u]) : fx ? fmt("L.ctl%u", o.imm) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";

@@ -392,7 +392,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 				break;
 			case OP_DELAYTAP:
 				if (v.imm == 1u) b += d + "staged_tap_int(" + ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", (int)r%d, d%dw, bad);\n", v.a, v.node);
-				else b += d + (v.imm == 2u ? "staged_tap_stereo(" : "staged_tap_float(") + ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", r%d, d%dw, bad);\n", v.a, v.node);
+				else b += d + (v.imm == 3u ? "staged_lagrange(" : v.imm == 2u ? "staged_tap_stereo(" : "staged_tap_float(") + ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", r%d, d%dw, bad);\n", v.a, v.node);
 				break;
 			default: in.emit_op((size_t)v.orig, b, assign); break;
 			}

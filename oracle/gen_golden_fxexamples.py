@@ -62,6 +62,8 @@ FX["fx_ownfdn"] = [(0.5, 3.0), (800.0, 10000.0), (0.05, 0.42), (0.2, 1.0)]
 # double registers (f2d / dconst / dlow / dadd / dmul / d2f); two Delay<192000> per channel, eight constant taps, a damping LPF set in prepare().  (Added last: the
 # scenarios above keep their random draws.)
 FX["fx_reverb2"] = [(0.0, 0.5), (0.0, 0.4), (500.0, 5000.0)]
+# tests/patches/fx_comb.k (OUR OWN effect, added after everything else): a Delay<0> sized with resize() read with tap(float), Delay::lagrange() on a Delay<2400>
+FX["fx_owncomb"] = [(0.6, 19.0), (0.0, 0.85), (0.0, 1.0)]
 SHAPE = {"fx_patterns": dict(K=4, blocks=110),       # name -> instances / blocks (default 9 / 24)
          "fx_topreverb": dict(K=9, blocks=64),
          "fx_reverb2": dict(K=9, blocks=40)}         # 8,192 samples: the early reflections arrive after ~2,600, mid[] ~400 later, late[] ~1,000 after that

@@ -127,3 +127,13 @@ def test_own_fdn_effect_with_user_modifiers_signals4_and_matrix(tmp_path):
     exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
     print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e}")
     assert exact == 1.0 and np.abs(ref).max() > 0.1
+
+
+def test_own_comb_effect_with_a_resizable_delay_and_a_lagrange_tap(tmp_path):
+    """tests/patches/fx_comb.k (ours): a `Delay<0>` — the resizable line of klang.h:3515-3624, sized with resize(9600) in the constructor: the node's SIZE is
+    read when the recording is finished — as a feedback comb read with tap(float), and `pre.lagrange(t)` (klang.h:3429-3458: four rows, third-order
+    weights) on a Delay<2400>.  Nine instances, dials changed mid-run, bit for bit against the genuine header."""
+    got, ref = run_effect("fx_owncomb", tmp_path, own=True)
+    exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+    print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e}")
+    assert exact == 1.0 and np.abs(ref).max() > 0.1
