@@ -248,6 +248,10 @@ int klg_timing_end_aux(klg_synth* s, int* launches, float* total_ms);
  * Effect banks: `instances` independent Stereo::Effect objects (klang.h:4703-4717) of one patch.
  * ------------------------------------------------------------------------------------------------ */
 klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate, int max_block);
+/* The same on a NAMED device, whatever klg_init() selected and without changing it: one bank on one GPU — a rank's share of a sharded effect bank
+ * (klang_amd/shard.py), several banks of one process on different GPUs.  `program` != NULL: a recorded effect (klg_fx_create_graph's program and
+ * initial_record), else patch_id as for klg_fx_create.  (No reference counterpart: the reference constructs its effects on the CPU.) */
+klg_fx* klg_fx_create_on(int device, int patch_id, const char* program, int instances, float sample_rate, int max_block, const void* initial_record);
 void klg_fx_destroy(klg_fx* f);
 int klg_fx_set_control(klg_fx* f, int instance, int index, float value);
 /* replaces: `parameters[c] = controls[c].value` after the block (Effect::process(float*, int, float*) klang.h:4213-4215): the value as the

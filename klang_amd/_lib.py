@@ -96,6 +96,7 @@ def load():
         "klg_selftest": (C.c_int, [C.c_int, f32p, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_int]),
         "klg_selftest_host": (C.c_int, [C.c_int, f32p, C.c_int, C.c_float, f32p, C.c_int]),
         "klg_fx_create": (vp, [C.c_int, C.c_int, C.c_float, C.c_int]),
+        "klg_fx_create_on": (vp, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_float, C.c_int, vp]),
         "klg_fx_destroy": (None, [vp]),
         "klg_fx_set_control": (C.c_int, [vp, C.c_int, C.c_int, C.c_float]),
         "klg_fx_process": (C.c_int, [vp, f32p, C.c_int]),

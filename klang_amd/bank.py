@@ -248,16 +248,21 @@ class FxBank:
         self._L = lib()
         self._h = None
         self.channels = 2
-        if device is not None:
-            ids = (C.c_int * 1)(int(device))
-            check(self._L.klg_init(ids, 1), "klg_init")
+        # device: THIS bank's GPU (klg_fx_create_on) — the process-wide selection of klg_init(), and every other bank's device, stay as they are
         if isinstance(patch, str) and patch.lstrip().startswith("klgg"):       # a recorded Effect::process() body (`kind effect`)
             rec = None if initial_record is None else np.ascontiguousarray(initial_record, dtype=np.uint32)
-            h = self._L.klg_fx_create_graph(patch.encode(), int(instances), float(fs), int(max_block), rec.ctypes.data_as(C.c_void_p) if rec is not None else None)
+            recp = rec.ctypes.data_as(C.c_void_p) if rec is not None else None
+            if device is not None:
+                h = self._L.klg_fx_create_on(int(device), -1, patch.encode(), int(instances), float(fs), int(max_block), recp)
+            else:
+                h = self._L.klg_fx_create_graph(patch.encode(), int(instances), float(fs), int(max_block), recp)
             self.channels = int(channels)
         else:
             pid = PATCH_IDS[patch] if isinstance(patch, str) else int(patch)
-            h = self._L.klg_fx_create(pid, int(instances), float(fs), int(max_block))
+            if device is not None:
+                h = self._L.klg_fx_create_on(int(device), pid, None, int(instances), float(fs), int(max_block), None)
+            else:
+                h = self._L.klg_fx_create(pid, int(instances), float(fs), int(max_block))
         if not h:
             raise KlangError("klg_fx_create failed: " + self._L.klg_last_error().decode())
         self._h = h

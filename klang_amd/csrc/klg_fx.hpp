@@ -268,6 +268,9 @@ template<int G> struct PpxLds {
 	int deep;                                   // the block runs the request-ahead pipeline (see PPX_DEEP below)
 	int vibfast;                                // vibrato: the LFO's sines are taken by the audio waves, two chunks ahead of the chain
 	float ph[2][PPX_CHUNK + 1][G], sn[2][PPX_CHUNK][G];   // [chunk & 1]: the LFO's phase at every sample of the chunk (row PPX_CHUNK: after it), and their sines
+	// a chunk with a NEAR tap (G <= 32; G = 64 has no room and keeps the walk through memory): the six ring values of every sample as they stood before the
+	// chunk, and what the chunk itself has written so far — the walk in sample order then waits for LDS, not for memory
+	float nv[G <= 32 ? PPX_CHUNK : 1][6][G], nw[2][G <= 32 ? PPX_CHUNK : 1][G];
 };
 
 // G = instances per workgroup: 64 (a whole ring group: banks that fill the chip on their own), or 32 / 16 — a half / a quarter of a
@@ -707,15 +710,22 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			if (!stationary || jn < 2) {
 				const bool far = 0.5f * dmin * a.fs.f >= (float)(PPX_CHUNK + 3) && dmax * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
 				const bool all_far = __ballot(k < a.K && !far) == 0ull;             // padding lanes (zero state, zero delay) do not veto
-				if (lane == 0) S.far[jn & 1] = all_far ? 1 : 0;
+				// HALF-far: every tap further behind the cursor than HALF a chunk is long (+ 3) — the shortest delay the dial allows, 1 ms, is there at 44.1 / 48 kHz
+				// (right tap: 22 / 24 samples; PingPong.k's preset "Doctor Who?").  The chunk is then two half-chunks that are each far: audio waves 1 - 4 take
+				// samples 0 - 15, a barrier, waves 5 - 8 samples 16 - 31 (flag 2)
+				const bool half = 0.5f * dmin * a.fs.f >= (float)(PPX_CHUNK / 2 + 3) && dmax * a.fs.f <= (float)(SIZE - PPX_CHUNK / 2 - 4);
+				const bool all_half = __ballot(k < a.K && !half) == 0ull;
+				if (lane == 0) S.far[jn & 1] = all_far ? 1 : all_half ? 2 : 0;
 			}
 		}
 		// ---------------- AUDIO of chunk j ----------------
-		if (w_audio && j >= 0 && j < nchunks) {
+		const bool audio_now = j >= 0 && j < nchunks;
+		const int farj = audio_now ? S.far[j & 1] : 1;                             // (workgroup-uniform: written a step ago, behind that step's barrier)
+		auto audio_stage = [&]() __attribute__((always_inline)) {
 			const int s0 = j * PPX_CHUNK, cl = (n - s0 < PPX_CHUNK) ? (n - s0) : PPX_CHUNK;
 			const int pos0 = (int)(((long long)a.position + s0) % SIZE);
 			float (*T)[PPX_CHUNK][G + 1] = S.tile[j & 3];
-			if (S.far[j & 1]) {
+			if (farj != 0) {
 				// a wave's PPX_PER samples: SPW of them side by side in its lanes (lane = sample slot x instance), PASSES passes.  FULL (a whole chunk: every
 				// chunk but a block's ragged last) is a compile-time variant: with the per-pass bounds tests in place every pass ends in a join, and the
 				// joins cost a dozen 64-bit register copies per pass (the rows in flight are live across them)
@@ -754,6 +764,59 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 							};
 				if (cl == PPX_CHUNK) far_chunk(BoolTag<true>{}); else far_chunk(BoolTag<false>{});
 			}
+			else if (G <= 32 && wv == 1) {
+				// A NEAR TAP (a delay under ~0.75 ms — PingPong.k's preset "Doctor Who?" sits there — or one within a chunk of the whole line): the chunk is
+				// walked in sample order by one wave, lane = instance.  Through memory that walk is three dependent round trips per sample (a tap may read what
+				// the sample before wrote): 40 us per chunk.  Here the wave first fetches, for every sample of the chunk, its six ring values AS THEY STAND
+				// BEFORE THE CHUNK (all in flight together, 64 / G samples per pass); the walk then takes a value from what the chunk has written so far
+				// (LDS) whenever its row is one of those, else the fetched one — the same values the reference reads — and waits for LDS only.
+				{
+					constexpr int NSPW = 64 / G;
+#pragma unroll
+					for (int p0 = 0; p0 < PPX_CHUNK; p0 += NSPW) {
+						const int u = p0 + lq;
+						if (u < cl) {
+							const float delay = S.D[j & 1][u][li];
+							const int pos = wrap(pos0 + u);
+							const Tap tl = delay_set(pos, SIZE, delay * a.fs.f), tr = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);
+							const int i0 = tl.position, i1 = ring_succ(i0, SIZE), i2 = ring_succ(i1, SIZE);
+							const int j0 = tr.position, j1 = ring_succ(j0, SIZE), j2 = ring_succ(j1, SIZE);
+							S.nv[u][0][li] = ring_rd(0, i0); S.nv[u][1][li] = ring_rd(0, i1); S.nv[u][2][li] = ring_rd(0, i2);
+							S.nv[u][3][li] = ring_rd(1, j0); S.nv[u][4][li] = ring_rd(1, j1); S.nv[u][5][li] = ring_rd(1, j2);
+						}
+					}
+				}
+				wave_sync();
+				if (lane < G) {
+					// row `row` of `line` as sample u finds it: written by this chunk (its first `upto` samples) or as fetched
+					auto seen = [&](const int line, const int row, const float fetched, const int upto) {
+						int d = row - pos0; d = d < 0 ? d + SIZE : d;
+						const bool mine = row < SIZE && d < upto;
+						const float w = S.nw[line][mine ? d : 0][li];
+						return mine ? w : fetched;
+					};
+					for (int u = 0; u < cl; u++) {
+						const float delay = S.D[j & 1][u][li];
+						const int pos = wrap(pos0 + u);
+						const Tap tl = delay_set(pos, SIZE, delay * a.fs.f), tr = delay_set(pos, SIZE, 0.5f * delay * a.fs.f);
+						const int i0 = tl.position, i1 = ring_succ(i0, SIZE), i2 = ring_succ(i1, SIZE);
+						const int j0 = tr.position, j1 = ring_succ(j0, SIZE), j2 = ring_succ(j1, SIZE);
+						const float in_l = T[0][u][li], in_r = T[1][u][li];
+						const float ra = seen(1, j0, S.nv[u][3][li], u), rb = seen(1, j1, S.nv[u][4][li], u);
+						const float r1 = ra + tr.fraction * (rb - ra);                          // right * gain: Delay::process under the head
+						const float wl = in_l + r1 * gain;
+						S.nw[0][u][li] = wl; ring_wr(0, pos, wl);                             // (in.l + right * gain) >> left
+						const float la = seen(0, i0, S.nv[u][0][li], u + 1), lb = seen(0, i1, S.nv[u][1][li], u + 1), lc = seen(0, i2, S.nv[u][2][li], u + 1);
+						const float l1 = la + tl.fraction * (lb - la), l2 = lb + tl.fraction * (lc - lb);
+						T[0][u][li] = dry * in_l + l1 * (1.f - dry);
+						const float wr = in_r + l2 * gain;
+						S.nw[1][u][li] = wr; ring_wr(1, pos, wr);                             // (in.r + left * gain) >> right
+						const float rb2 = seen(1, j1, S.nv[u][4][li], u + 1), rc = seen(1, j2, S.nv[u][5][li], u + 1);
+						const float r2 = rb2 + tr.fraction * (rc - rb2);
+						T[1][u][li] = dry * in_r + r2 * (1.f - dry);
+					}
+				}
+			}
 			else if (wv == 1 && lane < G) {                                         // a near tap: the chunk is walked in order by one wave, lane = instance
 				const int col = (k0 & (FX_WG - 1)) + li;
 				Ring left = { ring0 + col, FX_WG, SIZE }, right = { ring0 + (size_t)PP_ROWS * FX_WG + col, FX_WG, SIZE };
@@ -771,7 +834,11 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 					T[1][u][li] = dry * in_r + r2 * (1.f - dry);
 				}
 			}
-		}
+		};
+		// far: every audio wave its samples at once.  Half-far (farj == 2): waves 1 .. 4 (samples 0 - 15), then — behind a barrier of the whole workgroup, so that
+		// what they wrote is there — waves 5 .. 8 (samples 16 - 31).  Near (0): wave 1 walks the chunk
+		if (w_audio && audio_now && !(farj == 2 && wv > PPX_AUDIO / 2)) audio_stage();
+		if (farj == 2) { __syncthreads(); if (w_audio && wv > PPX_AUDIO / 2) audio_stage(); }
 		if (vibfast && w_audio && j + 2 < nchunks) sines(j + 2);                    // vibrato: the sines the control chain reads two steps from now
 		// ---------------- FILTER of chunk j-1, then its store ----------------
 		if (w_filter && j >= 1 && j <= nchunks) filter_stage(j - 1, BoolTag<true>{});

@@ -119,6 +119,18 @@ extern "C" klg_fx* klg_fx_create(int patch_id, int instances, float sample_rate,
 	if (g_devices.size() > 1) return fx_multi_create(instances, max_block, [&](int device, int count) { return fx_create_on(device, patch_id, count, sample_rate, max_block); });
 	return fx_create_on(g_device, patch_id, instances, sample_rate, max_block);
 }
+// the same on a NAMED device, whatever klg_init() said: one bank on one GPU (a rank of a sharded effect bank; several banks of one process on different GPUs).
+// `program` non-NULL: a recorded effect (klg_fx_create_graph's arguments), else patch_id as for klg_fx_create
+static klg_fx* fx_create_graph_on(int device, const char* program, int instances, float sample_rate, int max_block, const void* initial_record);
+extern "C" klg_fx* klg_fx_create_on(int device, int patch_id, const char* program, int instances, float sample_rate, int max_block, const void* initial_record) {
+	if (instances <= 0 || max_block <= 0 || max_block > MAX_BLOCK || !(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_fx_create_on: bad arguments"); return nullptr; }
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); fail(KLG_ERR_NO_DEVICE, "klg_fx_create_on: no HIP device visible: libklang_mi355 has no CPU fallback"); return nullptr; }
+	if (device < 0 || device >= count) { fail(KLG_ERR_INVALID, "klg_fx_create_on: device %d of %d", device, count); return nullptr; }
+	if (program) return fx_create_graph_on(device, program, instances, sample_rate, max_block, initial_record);
+	if (patch_id != KLG_PATCH_PINGPONG && patch_id != KLG_PATCH_REVERB) { fail(KLG_ERR_INVALID, "klg_fx_create_on: patch %d is not an effect patch", patch_id); return nullptr; }
+	return fx_create_on(device, patch_id, instances, sample_rate, max_block);
+}
 static klg_fx* fx_create_on(int device, int patch_id, int instances, float sample_rate, int max_block) {
 	RandGuard rg;
 	DeviceGuard bound(device);
@@ -165,7 +177,6 @@ static klg_fx* fx_create_on(int device, int patch_id, int instances, float sampl
 // replaces: constructing `instances` copies of a user Effect whose process() body was recorded (include/klang_mi355_graph.h,
 // `kind effect 1|2`).  `initial_record` (the program's record: Program::words() 32-bit words; NULL = zeros) is the state of one freshly
 // constructed instance; every instance starts from it.  Delay<SIZE> members become zero-filled rings in HBM.
-static klg_fx* fx_create_graph_on(int device, const char* program, int instances, float sample_rate, int max_block, const void* initial_record);
 extern "C" klg_fx* klg_fx_create_graph(const char* program, int instances, float sample_rate, int max_block, const void* initial_record) {
 	if (instances <= 0 || max_block <= 0 || max_block > MAX_BLOCK || !(sample_rate > 0.f)) { fail(KLG_ERR_INVALID, "klg_fx_create_graph: bad arguments"); return nullptr; }
 	if (default_device() < 0) return nullptr;

@@ -73,6 +73,33 @@ def test_pingpong_near_taps_and_vibrato(oracle_build):
     assert err <= TOL
 
 
+@pytest.mark.parametrize("fs,width", [(32000.0, "16"), (32000.0, "32"), (32000.0, "64"), (44100.0, "16"), (96000.0, "16")])
+def test_pingpong_near_taps_at_other_sample_rates(fs, width, oracle_build, monkeypatch):
+    """How a chunk with a short delay is run depends on the delay IN SAMPLES: at 44.1 / 48 kHz the shortest delay the dial allows (1 ms: the right tap 22 / 24
+    samples behind the cursor) leaves every tap further back than half a chunk — two half-chunks, a barrier between them (the "half-far" form); at 32 kHz
+    (16 samples) the chunk is walked in sample order by one wave, through LDS for workgroups of 16 / 32 instances, through memory for 64; at 96 kHz 1 ms is
+    48 samples: far.  Every form against the oracle, delays that cross the thresholds while the smoothed control glides, vibrato on some."""
+    monkeypatch.setenv("KLG_FX_PINGPONG_G", width)
+    K = 70
+    s = Scenario(patch="pingpong", block=192, blocks=14, instances=K, burst=2500, seed=23, dump=list(range(0, 14, 2)), fs=fs)
+    rng = np.random.default_rng(int(fs) + int(width))
+    for k in range(K):
+        s.control(0, k, 0, float(rng.uniform(0.3, 0.95)))
+        s.control(0, k, 1, float(rng.choice([0.001, 0.0011, 0.0013, 0.0016, 0.002, 0.004, 0.3])))
+        s.control(0, k, 5, float(rng.choice([0.0, 0.001, 0.0015, 0.003, 0.2])))
+        s.control(0, k, 2, float(rng.choice([0.0, 0.0, 0.7])))
+        s.control(0, k, 3, float(rng.uniform(0.01, 1.0)))
+        s.control(0, k, 4, float(rng.uniform(0.0, 1.0)))
+    for k in range(0, K, 3):                                   # glide from short to long and back
+        s.control(5, k, 1, 0.4); s.control(5, k, 5, 0.4)
+        s.control(9, k, 1, 0.001); s.control(9, k, 5, 0.0)
+    ref = run_scenario_oracle(s, oracle_build)["per_voice"]
+    got = run_fx_scenario_gpu(s)["per_voice"]
+    exact = bit_exact_fraction(got, ref)
+    print(f"pingpong near taps at {fs:.0f} Hz, {width} instances per workgroup: bit-exact {100 * exact:.2f}%")
+    assert exact == 1.0 and np.abs(ref).max() > 0.05
+
+
 def test_fx_block_size_independence():
     """Property: 4 x 64-sample blocks == 1 x 256-sample block, bit for bit (PingPong, GPU vs GPU)."""
     def render(block, blocks):
