@@ -188,7 +188,11 @@ static klg_fx* fx_create_graph_on(int device, const char* program, int instances
 	DeviceGuard bound(device);
 	if (!bound.ok) return nullptr;
 	const graphrt::Compiled* c = nullptr;
-	const std::string err = graphrt::compile(program, &c);
+	// instances per workgroup of the staged form, by bank size (measured with the recorded PingPong.k, tools/staged_sweep.py: 4,096 instances 55 us at 16 per
+	// workgroup, 16,384: 0.23 ms at 16, 0.17 at 32, 0.12 at 64; 65,536: 0.91 / 0.65 / 0.48 — a serial level costs a workgroup the same whatever its width, so a
+	// bank that fills the chip anyway takes the widest): the widths of klg_fx_pingpong_x
+	const size_t kp = ((size_t)instances + FX_WG - 1) / FX_WG * FX_WG;
+	const std::string err = graphrt::compile(program, &c, false, kp <= 4096 ? 16 : kp <= 8192 ? 32 : 64);
 	if (!err.empty()) { fail(KLG_ERR_INVALID, "klg_fx_create_graph: %s", err.c_str()); return nullptr; }
 	if (!c->channels) { fail(KLG_ERR_INVALID, "klg_fx_create_graph: the program is a synth note body (no `kind effect` line): use klg_synth_create_graph"); return nullptr; }
 	graph::Program g; (void)g.parse(program);

@@ -49,7 +49,7 @@ inline bool x2_eligible(const Program& g) {
 	return true;
 }
 
-inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan* staged = nullptr) {
+inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan* staged = nullptr, int staged_G = 0) {
 	using namespace graph;
 	// type names of the generated body: one voice per lane, or two (the packed primitives overload the scalar names)
 	const std::string TF = x2 ? "f2" : "float", TI = x2 ? "i2" : "int", TU = x2 ? "u2" : "uint32_t", T2 = x2 ? "2" : "";
@@ -497,8 +497,18 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			else {
 				StagedInput in;
 				in.g = &g; in.emit_op = emit_op; in.node_begin = &node_begin; in.node_end = &node_end; in.ctl_begin = ctl_begin; in.ring_off = &ring_off; in.inputs = &inputs; in.ctlvar = ctlvar;
-				in.G = ge ? atoi(ge) : 0; in.C = ce ? atoi(ce) : 0;
-				*staged = plan_staged(in);
+				// instances per workgroup: the caller's choice by bank size (klg_fx_create_graph), the chunk that goes with it (a wider workgroup takes a shorter chunk:
+				// 512 lanes for the parallel levels either way); a plan that does not fit at one width is tried at the next narrower one
+				int G = ge ? atoi(ge) : (staged_G ? staged_G : 16);
+				for (;;) {
+					StagedInput tryin = in; tryin.G = G;
+					if (ce) tryin.C = atoi(ce); else { tryin.C = G >= 64 ? 8 : G == 32 ? 16 : 32; tryin.C_is_a_preference = true; }
+					*staged = plan_staged(tryin);
+					// (a wide workgroup is worth it for bodies whose serial levels dominate — PingPong.k; one that only fits with a chunk shorter than its width's
+					//  own — the recorded Reverb.k: 68 values through LDS — is better off narrow and long: 2.5 ms at 16 x 32 against 3.9 at 32 x 8, 16,384 instances)
+					if (ge || G <= 16 || (staged->ok && staged->C >= tryin.C)) break;
+					G /= 2;
+				}
 				if (staged->ok) s += staged->source;
 			}
 		}
@@ -619,7 +629,7 @@ inline std::string source_dir() {
 }
 
 // program text -> code object (cached per process by program text).  Returns "" on success.
-inline std::string compile(const char* text, const Compiled** out, bool x2 = false) {
+inline std::string compile(const char* text, const Compiled** out, bool x2 = false, int staged_G = 0) {
 	static std::mutex mu;
 	static std::map<std::string, Compiled> cache;
 	static Rtc rtc;
@@ -629,13 +639,13 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	if (!perr.empty()) return perr;
 	if (x2 && !x2_eligible(g)) return "graph program: not every node / op has a two-voices-per-lane form";
 	auto envs = [](const char* n) { const char* e = getenv(n); return std::string(e ? e : ""); };
-	const std::string key = (x2 ? "x2\n" : "") + (g.channels ? "staged " + envs("KLG_FX_STAGED") + "," + envs("KLG_FX_STAGED_G") + "," + envs("KLG_FX_STAGED_C") + "," + envs("KLG_FX_STAGED_LDS") + "," + envs("KLG_FX_STAGED_SKIP") + "," + envs("KLG_FX_STAGED_STAMP") + "," + envs("KLG_FX_STAGED_PIPE") + "\n" : std::string()) + g.text();
+	const std::string key = (x2 ? "x2\n" : "") + (g.channels ? "staged G" + std::to_string(staged_G) + " " + envs("KLG_FX_STAGED") + "," + envs("KLG_FX_STAGED_G") + "," + envs("KLG_FX_STAGED_C") + "," + envs("KLG_FX_STAGED_LDS") + "," + envs("KLG_FX_STAGED_SKIP") + "," + envs("KLG_FX_STAGED_STAMP") + "," + envs("KLG_FX_STAGED_PIPE") + "\n" : std::string()) + g.text();
 	auto it = cache.find(key);
 	if (it != cache.end()) { *out = &it->second; return ""; }
 	if (!rtc.load()) return rtc.error;
 	Compiled c;
 	StagedPlan plan;
-	c.source = generate_source(g, x2, g.channels ? &plan : nullptr);
+	c.source = generate_source(g, x2, g.channels ? &plan : nullptr, staged_G);
 	c.staged = plan.ok; c.staged_why = plan.why; c.staged_G = plan.G; c.staged_C = plan.C; c.staged_threads = plan.threads; c.staged_lds = plan.lds_bytes; c.staged_levels = plan.levels; c.staged_slots = plan.slots;
 	c.words = g.words(); c.channels = g.channels; c.x2 = x2; c.note_channels = g.stereo_note() ? 2 : 1;
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY || g.nodes[i] == graph::N_NDELAY) { c.delays.push_back({ c.ring_rows, g.arg((int)i) }); c.ring_rows += g.arg((int)i) + 1; }   // (+ the pad element of every line: klg_delay.hpp)

@@ -39,6 +39,7 @@ struct StagedInput {
 	const std::vector<long long>* ring_off; const std::vector<int>* inputs;
 	const int* ctlvar;                                                   // control index -> ctlvar node or -1
 	int G, C;                                                            // requested width / chunk (0: choose)
+	bool C_is_a_preference = false;                                      // C: where the search for a chunk length that fits the LDS budget starts (else: that length or none)
 };
 
 inline StagedPlan plan_staged(const StagedInput& in) {
@@ -358,8 +359,8 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		}
 		const long long lds_words = (long long)NW * G * (pipelined ? 3 : 1) + (long long)CH * C * G + (long long)(nslots + 2 * npslots) * C * G + 4;
 		const char* le = getenv("KLG_FX_STAGED_LDS");
-		const long long budget = le ? atoll(le) : 100 * 1024;                 // (gfx950 grants a workgroup up to 160 KB)
-		if (lds_words * 4 > budget) { if (in.C > 0) return refuse("the requested chunk length does not fit the LDS budget"); continue; }
+		const long long budget = le ? atoll(le) : 160 * 1024;                 // gfx950 grants a workgroup up to 160 KB; a plan that needs most of it (the recorded Reverb.k: 68 values x 32 samples x 16 instances) is one workgroup of 8 waves per CU — measured 0.61 against 0.83 ms at 4,096 instances, 2.5 against 4.4 ms at 16,384, with half the chunk
+		if (lds_words * 4 > budget) { if (in.C > 0 && !in.C_is_a_preference) return refuse("the requested chunk length does not fit the LDS budget"); continue; }
 
 		// =========================================================== source ===========================================================
 		std::string s;
