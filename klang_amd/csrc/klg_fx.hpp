@@ -1873,7 +1873,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_graph(const FxGraphArgs a) {
 	typename P::Live L;
 	FxCtx c;
 	c.fs = a.fs; c.ctl = a.controls + (size_t)k * KLG_MAX_CTL; c.samples = a.samples;
-	c.ring = a.rings + (size_t)blockIdx.x * a.ring_rows * FX_WG + lane;
+	c.ring = a.rings + (size_t)(k / P::kRingRow) * a.ring_rows * P::kRingRow + (k % P::kRingRow);     // (rows of 64 instances: blockIdx.x * ring_rows * 64 + lane)
 	c.rand = a.rand ? a.rand + (size_t)(k < a.K ? k : 0) * (size_t)a.rand_per_instance : nullptr;
 	P::begin(L, rec, c);
 	const int col = lane & 31, half = lane >> 5;

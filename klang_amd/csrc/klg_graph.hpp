@@ -69,7 +69,13 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 	// effects: position-major rows of 64 instances (all instances share the cursor: one coalesced row per access).  notes: each voice's
 	// line is contiguous — voices start at different times and have different lengths, so their cursors never line up; a lane walking its
 	// own line re-uses each 64-byte sector for 16 samples (measured 8x over the position-major layout, tools/pluck_bench.py)
-	auto ring = [&](int node) { return fx ? fmt("Ring{ c.ring + (size_t)%lldll * 64, 64, %d }", ring_off[(size_t)node], g.arg(node)) : fmt("Ring{ c.ring + (size_t)%lldll, 1, %d }", ring_off[(size_t)node], g.arg(node)); };
+	// Effects: position-major rows of `ring_row` instances.  64 (a wave of klg_fx_graph<P>) unless the body has a staged form (klg_graph_staged.hpp): then a row is as
+	// wide as the staged kernel's workgroup (16 / 32 / 64 instances) — a workgroup owns its rows, and a chunk's 32 positions of a line are 32 consecutive rows:
+	// contiguous memory.  (With 64-wide rows four 16-instance workgroups share every row and each fetches the 128-byte lines around its 64 bytes: the recorded
+	// Reverb.k at 4,096 instances moved 2.28 GB per launch for 0.45 GB of algorithmic bytes.  Every instance's lines contiguous — the notes' layout — was
+	// measured too: fewer bytes, but 288 distant regions per workgroup instead of 18, and 0.82 ms instead of 0.63.)  `ring_row` is decided below, before any op is emitted.
+	int ring_row = 64;
+	auto ring = [&](int node) { return fx ? fmt("Ring{ c.ring + (size_t)%lldll * %d, %d, %d }", ring_off[(size_t)node], ring_row, ring_row, g.arg(node)) : fmt("Ring{ c.ring + (size_t)%lldll, 1, %d }", ring_off[(size_t)node], g.arg(node)); };
 	uint64_t mask[graph::MAX_WORDS / 64] = { 1ull };                      // word 0 (flags) is always written back
 	auto mark = [&](int w, int n) { for (int i = w; i < w + n; i++) mask[i >> 6] |= 1ull << (i & 63); };
 	std::string live = fx ? "\tstruct Live { int unused_; int sidx;" : "\tstruct Live { " + TI + " stage; float tinc;" + (g.noise_calls() ? " int sidx;" : ""), begin, end, body;
@@ -452,6 +458,29 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			break;
 		}
 	};
+	auto staged_plan = [&](bool dry) {
+		StagedPlan plan;
+		const char* se = getenv("KLG_FX_STAGED"), *ge = getenv("KLG_FX_STAGED_G"), *ce = getenv("KLG_FX_STAGED_C");
+		if (se && se[0] == '0') { plan.ok = false; plan.why = "KLG_FX_STAGED=0"; return plan; }
+		StagedInput in;
+		in.g = &g; in.node_begin = &node_begin; in.node_end = &node_end; in.ctl_begin = ctl_begin; in.ring_off = &ring_off; in.inputs = &inputs; in.ctlvar = ctlvar;
+		if (dry) in.emit_op = [](size_t, std::string&, bool) {}; else in.emit_op = emit_op;
+		// instances per workgroup: the caller's choice by bank size (klg_fx_create_graph), the chunk that goes with it (a wider workgroup takes a shorter chunk:
+		// 512 lanes for the parallel levels either way); a plan that does not fit at one width is tried at the next narrower one
+		int G = ge ? atoi(ge) : (staged_G ? staged_G : 16);
+		for (;;) {
+			StagedInput tryin = in; tryin.G = G;
+			if (ce) tryin.C = atoi(ce); else { tryin.C = G >= 64 ? 8 : G == 32 ? 16 : 32; tryin.C_is_a_preference = true; }
+			plan = plan_staged(tryin);
+			// (a wide workgroup is worth it for bodies whose serial levels dominate — PingPong.k; one that only fits with a chunk shorter than its width's
+			//  own — the recorded Reverb.k: 68 values through LDS — is better off narrow and long: 2.5 ms at 16 x 32 against 3.9 at 32 x 8, 16,384 instances)
+			if (ge || G <= 16 || (plan.ok && plan.C >= tryin.C)) break;
+			G /= 2;
+		}
+		return plan;
+	};
+	bool has_staged = false;
+	if (fx && staged) { const StagedPlan dry = staged_plan(true); has_staged = dry.ok; if (dry.ok) ring_row = dry.G; }   // the ring layout of BOTH kernels of this code object follows from the staged form's width
 	for (size_t oi = 0; oi < g.ops.size(); oi++) {
 		if ((int)oi == g.prepare_ops && g.prepare_ops) { prologue = body; body.clear(); }
 		emit_hoists(body, (int)oi);
@@ -485,6 +514,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 	}
 	if (fx) {
 		s += fmt("\tstatic constexpr int kChannels = %d;\n", g.channels);
+		s += fmt("\tstatic constexpr int kRingRow = %d;              // instances per row of the position-major delay lines (FxCtx::ring = the instance's column of its group's tile)\n", ring_row);
 		s += "\tstatic __device__ __forceinline__ void begin(Live& L, const Rec& r, const FxCtx& c) {\n\t\tL.unused_ = 0; L.sidx = 0; (void)r; (void)c;\n" + begin + "\t}\n";
 		s += "\tstatic __device__ __forceinline__ void begin_core(Live& L, const Rec& r, const FxCtx& c) {\n\t\tL.unused_ = 0; L.sidx = 0; (void)r; (void)c;\n" + begin_core + "\t}\n";
 		s += "\tstatic __device__ __forceinline__ void sample(Live& L, const FxCtx& c, float in0, float in1, float& out0, float& out1) {\n\t\t(void)in0; (void)in1;\n" + body
@@ -492,25 +522,9 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\t(void)L; (void)r;\n" + end + "\t}\n};\n";
 		// the sample-parallel form of the same body (klg_graph_staged.hpp), when the program has one: KLG_FX_STAGED=0 never, KLG_FX_STAGED_G / _C force the shape
 		if (staged) {
-			const char* se = getenv("KLG_FX_STAGED"), *ge = getenv("KLG_FX_STAGED_G"), *ce = getenv("KLG_FX_STAGED_C");
-			if (se && se[0] == '0') { staged->ok = false; staged->why = "KLG_FX_STAGED=0"; }
-			else {
-				StagedInput in;
-				in.g = &g; in.emit_op = emit_op; in.node_begin = &node_begin; in.node_end = &node_end; in.ctl_begin = ctl_begin; in.ring_off = &ring_off; in.inputs = &inputs; in.ctlvar = ctlvar;
-				// instances per workgroup: the caller's choice by bank size (klg_fx_create_graph), the chunk that goes with it (a wider workgroup takes a shorter chunk:
-				// 512 lanes for the parallel levels either way); a plan that does not fit at one width is tried at the next narrower one
-				int G = ge ? atoi(ge) : (staged_G ? staged_G : 16);
-				for (;;) {
-					StagedInput tryin = in; tryin.G = G;
-					if (ce) tryin.C = atoi(ce); else { tryin.C = G >= 64 ? 8 : G == 32 ? 16 : 32; tryin.C_is_a_preference = true; }
-					*staged = plan_staged(tryin);
-					// (a wide workgroup is worth it for bodies whose serial levels dominate — PingPong.k; one that only fits with a chunk shorter than its width's
-					//  own — the recorded Reverb.k: 68 values through LDS — is better off narrow and long: 2.5 ms at 16 x 32 against 3.9 at 32 x 8, 16,384 instances)
-					if (ge || G <= 16 || (staged->ok && staged->C >= tryin.C)) break;
-					G /= 2;
-				}
-				if (staged->ok) s += staged->source;
-			}
+			*staged = staged_plan(false);
+			if (staged->ok != has_staged || (staged->ok && staged->G != ring_row)) { staged->ok = false; staged->why = "the plan changed between its two passes"; }     // (cannot happen: the plan does not depend on the ops' text)
+			if (staged->ok) s += staged->source;
 		}
 		s += "}\n";
 	}

@@ -365,7 +365,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		// =========================================================== source ===========================================================
 		std::string s;
 		auto F = [](const char* f, ...) { char b[1024]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return std::string(b); };
-		auto ring = [&](int node) { return F("Ring{ c.ring + (size_t)%lldll * 64, 64, %d }", (*in.ring_off)[(size_t)node], g.arg(node)); };
+		auto ring = [&](int node) { return F("Ring{ c.ring + (size_t)%lldll * %d, %d, %d }", (*in.ring_off)[(size_t)node], G, G, g.arg(node)); };   // rows of G instances: this workgroup's own (PatchGen::kRingRow)
 		auto ty = [&](int r) { return std::string(is_dbl[(size_t)r] ? "double" : "float"); };
 		auto in_branch = [&](int i) { return !V[(size_t)i].path.empty(); };
 		// where a register's LDS copy is, for code of group `pf` (the prefix works on the NEXT chunk: the other parity)
@@ -374,6 +374,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			if (pfx[(size_t)R.def]) return F("SLP(%d, %s)", R.slot_id, reader_pf ? "parn" : "parc");
 			return F("SL(%d)", R.slot_id);
 		};
+		std::string inst = "pg";                                                   // which instance the code being generated works for: a lane of a parallel level (pg) or of a serial loop (ln)
 		// the statement(s) of virtual op i, in the context (L, c) it is emitted in
 		auto op_text = [&](int i, bool assign) {
 			const VOp& v = V[(size_t)i];
@@ -382,6 +383,9 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			const int SZ = v.node >= 0 ? g.arg(v.node) : 0;
 			auto pos = [&](int j) { return j ? F("ring_at(d%dp0, %d, %d)", v.node, j, SZ) : F("d%dp0", v.node); };
 			switch (v.code) {
+			case OP_PARAM:                                                           // a member process() only reads: from the LDS copy of the records where it is needed — as fields of the
+				if (!written[(size_t)v.node]) { b += d + F("u2f(srec[%d * G + %s]);\n", g.node_word0(v.node), inst.c_str()); break; }   // lanes' Live structs the recorded Reverb.k's 77 of them were held (three times) for the whole block: 1,123 spilled registers, 3.7 KB of scratch per lane, 5 x the algorithmic traffic
+				in.emit_op((size_t)v.orig, b, assign); break;
 			case V_OSCARG: b += d + F("basic_sine_arg(L.n%d);\n", v.node); break;
 			case V_OSCEVAL: b += d + F("basic_sine_of(r%d);\n", v.a); break;
 			case OP_PHI: b += d + F("(r%d != 0.f) ? r%d : r%d;\n", V[(size_t)phi_if[(size_t)i]].a, v.a, v.b); break;
@@ -494,6 +498,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			std::string code;
 			const char* cond = pf ? "pre" : "ok";
 			if (!pf && lv < 32 && ((skip_mask >> lv) & 1u)) return code;
+			inst = (lv & 1) ? "ln" : "pg";
 			if (!(lv & 1)) {
 				std::vector<int> from_slot; inputs_of(pf, lv, -1, from_slot);
 				std::vector<char> predecl(regs.size(), 0);
@@ -599,7 +604,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "\tFxCtx cp, cs;\n\tcp.fs = cs.fs = a.fs; cp.samples = cs.samples = a.samples;\n";
 		s += "\tunsigned long long samples0 = a.samples; float* io = a.io;                // of the block being processed (a span: klg_fx_render_device)\n";
 		s += "\tcp.ctl = a.controls + (size_t)(k0 + pg) * KLG_MAX_CTL; cs.ctl = a.controls + (size_t)(k0 + sg) * KLG_MAX_CTL;\n";
-		s += "\tfloat* const ring0 = a.rings + (size_t)(k0 / 64) * a.ring_rows * 64 + (k0 % 64);\n\tcp.ring = ring0 + pg; cs.ring = ring0 + sg;\n";
+		s += "\tfloat* const ring0 = a.rings + (size_t)blockIdx.x * a.ring_rows * G;             // this workgroup's ring tile: [line][position][G]\n\tcp.ring = ring0 + pg; cs.ring = ring0 + sg;\n";
 		s += "\tcp.rand = a.rand ? a.rand + (size_t)(k0 + pg < a.K ? k0 + pg : 0) * (size_t)a.rand_per_instance : nullptr;\n";
 		s += "\tcs.rand = a.rand ? a.rand + (size_t)(k0 + sg < a.K ? k0 + sg : 0) * (size_t)a.rand_per_instance : nullptr;\n";
 		s += "\tP::Live Lp, Lq, Ls;\n\tLp.unused_ = 0; Lp.sidx = 0; Lq.unused_ = 0; Lq.sidx = 0; Ls.unused_ = 0; Ls.sidx = 0;\n";
@@ -618,8 +623,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		if (pipelined) s += "\tfor (int i = t; i < NW * G; i += NT) { srecp[i] = srec[i]; srecp[NW * G + i] = srec[i]; }\n\t__syncthreads();\n";
 		// what the lanes hold for the whole block: the dials, the members process() only reads
 		{
-			std::string pb;
-			for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_PARAM && !written[nd]) pb += (*in.node_begin)[nd];
+			const std::string pb;                                                     // (members process() only reads are taken from the LDS records where they are used: op_text)
 			s += "\t{ auto& L = Lp; const FxCtx& c = cp; const StagedRec r = { { srec + pg } }; (void)L; (void)c; (void)r;\n" + in.ctl_begin + pb + "\t}\n";
 			s += "\t{ auto& L = Lq; const FxCtx& c = cp; const StagedRec r = { { srec + pg } }; (void)L; (void)c; (void)r;\n" + in.ctl_begin + pb + "\t}\n";
 			s += "\t{ auto& L = Ls; const FxCtx& c = cs; const StagedRec r = { { srec + sg } }; (void)L; (void)c; (void)r;\n" + in.ctl_begin + pb + "\t}\n";
@@ -650,6 +654,11 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		}
 		if (stamp) s += "\tlong long tacc[16] = { 0 }; const long long thead = wall_clock64() - tstart; long long tprev = wall_clock64();\n";
 		s += "\tfor (int s0 = 0; s0 < a.n; s0 += C) {\n\t\tconst int cl = (a.n - s0 < C) ? (a.n - s0) : C;\n";
+		// The thread index is laundered through an empty asm once per chunk: otherwise every per-lane LDS address of the chunk's body (a value's slot + this lane's
+		// place in it: the slots lie beyond an instruction's 16-bit offset) is loop-invariant, gets hoisted out of the chunk loop and then spilled — the recorded
+		// Reverb.k's kernel held ~500 of them in scratch (3.7 KB per lane; 1,123 spilled registers) and moved 5 x its algorithmic bytes
+		s += "\t\tint tv = threadIdx.x; asm volatile(\"\" : \"+v\"(tv));\n";
+		s += "\t\tconst int t = tv, tp = t < NTP ? t : 0, ps = tp / G, pg = tp % G, wv = t >> 6, sw = wv - SW0, ln = t & 63; (void)ps; (void)pg; (void)sw; (void)ln; (void)wv;\n";
 		s += "#pragma unroll\n\t\tfor (int j = 0; j < CH; j++) { const int i = tp + j * NTP, row = i / C, q = i % C, gi = row / CH, ch = row % CH; if (t < NTP) tile[(ch * C + q) * G + gi] = nx[j]; }\n";
 		s += "\t\tif (t == 0) *flag = 0;\n\t\t__syncthreads();\n";
 		s += "\t\tif (s0 + C < a.n) fetch(s0 + C);\n";
