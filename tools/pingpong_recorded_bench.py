@@ -35,12 +35,15 @@ def main():
         def recorded(staged):
             os.environ["KLG_FX_STAGED"] = "1" if staged else "0"          # (read when the program is compiled; the two forms are cached separately)
             return klang_amd.FxBank(PROGRAM, K, max_block=N, initial_record=initial_record(), channels=2)
-        banks = {"hand-written klg_fx_pingpong_x": klang_amd.FxBank("pingpong", K, max_block=N),
-                 "recorded graph (klg_fx_graph)": recorded(True), "recorded graph, one lane per instance": recorded(False)}
-        form = banks["recorded graph (klg_fx_graph)"].graph_form()
+        # one bank at a time (65,536 instances are 100 GB of rings each)
+        banks = {"hand-written klg_fx_pingpong_x": lambda: klang_amd.FxBank("pingpong", K, max_block=N),
+                 "recorded graph (klg_fx_graph)": lambda: recorded(True), "recorded graph, one lane per instance": lambda: recorded(False)}
+        form = None
         ctl = [] if dials == "default" else [(k, c, float(rng.uniform(lo, hi))) for k in range(0, K, 7) for c, lo, hi in ((0, 0.2, 0.9), (1, 0.01, 0.6), (2, 0.0, 1.0), (3, 0.01, 1.0), (5, 0.0, 0.4))]
         outs = {}
-        for name, bank in banks.items():
+        for name, make in banks.items():
+            bank = make()
+            if name == "recorded graph (klg_fx_graph)": form = bank.graph_form()
             for k, c, v in ctl: bank.set_control(k, c, v)
             g = torch.Generator(device="cuda").manual_seed(1)
             res = []
@@ -52,7 +55,8 @@ def main():
             outs[name] = torch.stack(res)
             io = torch.zeros((K, 2, N), device="cuda")
             outs[name + " ms"] = timed(bank, io, N)
-            bank.close()
+            bank.close(); del bank
+            torch.cuda.empty_cache()
         a, b = outs["hand-written klg_fx_pingpong_x"], outs["recorded graph (klg_fx_graph)"]
         same = bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
         if not same and os.environ.get("KLG_BENCH_DEBUG"):
