@@ -204,6 +204,12 @@ def cpu_reference_node(patch, block, blocks):
             "sample": f"{patch}: one process per physical core, each 128 voices x {block} samples x {blocks} blocks, all sounding, the reference's klang.h v0.7.8 (oracle/_ref/ref_subtractive), pinned; {note}"}
 
 
+# VALU wave-instructions per voice*sample of the two other synth kernels, from their counters (SQ_INSTS_VALU per launch / voices x samples;
+# they do not depend on the data: the sustain loop's paths are wave-uniform)
+VALU_INSTR_PER_VOICE_SAMPLE = {"fm4": (48537600 / (131072 * 256), "profiles/r04_pmc/pmc_fm4.json: SQ_INSTS_VALU 48,537,600 per launch of 131,072 voices x 256 samples"),
+                               "supersaw": (22462464 / (16384 * 256), "profiles/r04_pmc/pmc_supersaw_pairs.json: SQ_INSTS_VALU 22,462,464 per launch of klg_render_supersaw_pairs<4>, 16,384 voices x 256 samples")}
+
+
 def valu_issue(wave_samples, kern_s, per_sample):
     """VALU ISSUE-rate view of klg_render_sub2a_x2 (the unit that binds it): one wave = 128 voices; `per_sample` wave-instructions per
     wave*sample (counted in the ISA); a SIMD issues one wave64 VALU instruction per 4 cycles, 1024 SIMDs at 2.4 GHz."""
@@ -369,6 +375,11 @@ def run_literal_script(patch, voices, N, label, phases=False):
                        "kernel": ("klg_render_supersaw_pairs" if patch == "supersaw" and voices <= 131072 else KERNEL_OF.get(patch, patch)), "phase": "sustain (block time incl. event kernel + reduce)",
                        "hbm": {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab},
                        "note": "voice state lives in registers: VALU-issue bound by design (DESIGN.md §3); 157.3 TFLOP/s is the packed-FMA peak, separate mul / add (bit-parity) reach at most half"}
+    if patch in VALU_INSTR_PER_VOICE_SAMPLE and V == {"fm4": 131072, "supersaw": 16384}[patch]:
+        per, src = VALU_INSTR_PER_VOICE_SAMPLE[patch]
+        peak = 1024 * 2.4e9 / 4.0
+        res["roofline"]["valu"] = {"issue_rate_frac_est": V * N * per / kern_s / peak, "over": "the sustain phase's block time (incl. the reduce: understated by a few percent)", "wave_instr_per_voice_sample": per, "issue_peak_wave_instr_per_s": peak, "counted": src,
+                                   "reading": "the fraction of the chip's VALU issue slots (one wave64 instruction per SIMD and 4 cycles) the render kernel's own instructions fill; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the same file is that figure PER WAVE (several waves share a SIMD's slots)"}
     if phases:
         res["phases_ms_per_block"] = {"attack_decay_all_ramping(1..21)": float(np.median(ms[1:22])), "sustain_only(40..149)": float(np.median(ms[40:OFF_BLOCK])),
                                       "staggered_release(150..213)": float(np.median(ms[OFF_BLOCK:OFF_BLOCK + OFF_SPREAD])), "release_tail(214..260)": float(np.median(ms[214:261])),
