@@ -126,7 +126,7 @@ struct Recorder : Sink {
 	bool constructing = false, recording = false;
 	bool host_prepare = false;                                    // prepare() asked Controls::changed(): it stays HOST code (EffectBank runs it per instance and uploads what it changed)
 	klg::graph::Program prog;
-	int next_reg = 0, pending = -1;                              // pending: node whose finished() was just tested by an `if`
+	int next_reg = 0;
 	std::string error;
 	void fail(const std::string& what) { if (error.empty()) error = what; }
 	int smooth_node(const void* smoothed_signal) {               // controls[i].smooth() inside an effect: one state word per smoothed control
@@ -152,7 +152,6 @@ struct Recorder : Sink {
 		return take;
 	}
 	int emit(int code, int a, int b, int node, uint32_t imm, bool has_dst) {
-		if (pending >= 0 && code != klg::graph::OP_STOPIF) fail("`if (env.finished())` may only guard stop() in a recorded process()");
 		klg::graph::Op o; o.code = code; o.a = a; o.b = b; o.node = node; o.imm = imm; o.dst = has_dst ? next_reg++ : -1;
 		prog.ops.push_back(o);
 		return o.dst;
@@ -189,8 +188,6 @@ inline Recorder* recording() { return (rec && rec->recording) ? rec : nullptr; }
 inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 // host-side set()/reset()/release() calls inside a recorded process() would have to run per sample on the device
 inline bool no_set_while_recording(const char* what) { if (Recorder* r = recording()) { r->fail(std::string(what) + " inside process() is not supported in a recorded graph (set it in on())"); return true; } return false; }
-// the value of `if (env.finished())`: a plain bool on the host, a recorded condition while recording
-struct Cond { bool value; int node; explicit operator bool() const { if (node >= 0 && recording()) { rec->pending = node; return true; } return value; } bool operator!() const { if (node >= 0 && recording()) { rec->fail("`!env.finished()` is not supported in a recorded process()"); } return !value; } };
 }
 
 namespace gpu {
@@ -632,7 +629,7 @@ namespace Basic {
 			return y;
 		}
 		void pack(uint32_t* w) const override { using namespace klg::graph; w[BOSC_INC] = gpu::fbits(h.increment); w[BOSC_POS] = gpu::fbits(h.position); w[BOSC_OFFSET] = gpu::fbits(h.offset); w[BOSC_DUTY] = gpu::fbits(duty_); w[BOSC_FREQ] = gpu::fbits(h.frequency); }
-		void unpack(const uint32_t* w) override { using namespace klg::graph; std::memcpy(&h.increment, &w[BOSC_INC], 4); std::memcpy(&h.position, &w[BOSC_POS], 4); }
+		void unpack(const uint32_t* w) override { using namespace klg::graph; std::memcpy(&h.increment, &w[BOSC_INC], 4); std::memcpy(&h.position, &w[BOSC_POS], 4); std::memcpy(&duty_, &w[BOSC_DUTY], 4); }
 	};
 	struct Sine : Osc { Sine() : Osc(klg::graph::N_BSINE) {} };
 	struct Saw : Osc { Saw() : Osc(klg::graph::N_BSAW) {} };
@@ -641,7 +638,11 @@ namespace Basic {
 	struct Pulse : Osc {
 		Pulse() : Osc(klg::graph::N_BPULSE) {}
 		using Osc::set;
-		void set(param f, param phase, param duty) override { Osc::set(f, phase); duty_ = duty; }           // klang.h:4932-4935
+		void set(param f, param phase, param duty) override {                                             // klang.h:4932-4935
+			Osc::set(f, phase);
+			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(duty), -1, r->node(this, "Basic oscillator"), 3, false); return; }
+			duty_ = duty;
+		}
 	};
 }
 namespace Fast {
@@ -680,10 +681,13 @@ namespace Fast {
 			if (gpu::Recorder* r = gpu::recording()) { r->emit(klg::graph::OP_OSCSET, r->reg_of(f), r->reg_of(phase), r->node(this, "Fast oscillator"), 1, false); frequency = f; return; }   // per sample: hard sync
 			h.set(f, phase, host_fs()); frequency = f;
 		}
-		void set(param f, param phase, param duty) override { if (gpu::no_set_while_recording("Fast oscillator set(f, phase, duty)")) return; h.set(f, phase, duty, host_fs()); frequency = f; }
+		void set(param f, param phase, param duty) override {                  // klang.h:5236-5244; per sample (PWM): set(f, phase) then setDuty — the second init() recomputes all of the first
+			if (gpu::Recorder* r = gpu::recording()) { const int n = r->node(this, "Fast oscillator"); r->emit(klg::graph::OP_OSCSET, r->reg_of(f), r->reg_of(phase), n, 1, false); r->emit(klg::graph::OP_OSCSET, r->reg_of(duty), -1, n, 3, false); frequency = f; return; }
+			h.set(f, phase, duty, host_fs()); frequency = f;
+		}
 		void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_OSC, -1, -1, r->node(this, "Fast oscillator"), 0, true); return; } device_only("Fast::Osm::process()"); }
 		void pack(uint32_t* w) const override { using namespace klg::graph; w[OSM_INC] = (uint32_t)h.inc; w[OSM_OFFSET] = h.offset; w[OSM_DUTY] = h.duty; w[OSM_DELTA] = gpu::fbits(h.delta); w[OSM_STATE] = (uint32_t)h.state; w[OSM_FREQ] = gpu::fbits(h.frequency); }
-		void unpack(const uint32_t* w) override { using namespace klg::graph; h.inc = (int32_t)w[OSM_INC]; h.offset = w[OSM_OFFSET]; h.state = (int)(w[OSM_STATE] & 3u); std::memcpy(&h.delta, &w[OSM_DELTA], 4); std::memcpy(&h.frequency, &w[OSM_FREQ], 4); }
+		void unpack(const uint32_t* w) override { using namespace klg::graph; h.inc = (int32_t)w[OSM_INC]; h.offset = w[OSM_OFFSET]; h.duty = w[OSM_DUTY]; h.state = (int)(w[OSM_STATE] & 3u); std::memcpy(&h.delta, &w[OSM_DELTA], 4); std::memcpy(&h.frequency, &w[OSM_FREQ], 4); }
 	};
 	struct Saw : Osm { Saw() : Osm(0, 0.f) {} };
 	struct Triangle : Osm { Triangle() : Osm(0, 1.f) {} };
@@ -828,7 +832,9 @@ struct Envelope : Generator, gpu::Packable {
 	}
 	virtual void release(float time, float level = 0.f) { if (gpu::no_set_while_recording("Envelope::release()")) return; h.stage = klg::ENV_RELEASE; h.set_target(time, level, 0.f, host_fs()); }   // klang.h:3961-3966
 	void setLoop(int startPoint, int endPoint) { if (gpu::no_set_while_recording("Envelope::setLoop()")) return; h.set_loop(startPoint, endPoint); }   // klang.h:3923-3926
-	gpu::Cond finished() const { gpu::Recorder* r = gpu::recording(); return gpu::Cond{ h.stage == klg::ENV_OFF, r ? r->node(this, "Envelope") : -1 }; }
+	// klang.h:4094.  In a recorded process() the test is a VALUE (envoff): `if (env.finished()) stop();`, `if (env.finished()) { ...; stop(); return; }`,
+	// `!env.finished()`, `env.finished() && x > y` all record; the plain stop() idiom is folded back into `stopif` (gpu::fold_stop_idiom)
+	gpu::Pred finished() const { if (gpu::Recorder* r = gpu::recording()) return gpu::Pred{ h.stage == klg::ENV_OFF, r->emit(klg::graph::OP_ENVOFF, -1, -1, r->node(this, "Envelope"), 0, true) }; return gpu::Pred{ h.stage == klg::ENV_OFF, -1 }; }
 	signal& operator++(int) { this->process(); return out; }
 	void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_ENV, -1, -1, r->node(this, "Envelope"), 0, true); return; } device_only("Envelope::process()"); }
 	void pack(uint32_t* w) const override {
@@ -1142,7 +1148,7 @@ struct PathMerger {
 	std::vector<Op> out; int next = 0, pseudo = 1 << 20, runs = 0;
 	PathMerger(Recorder& r, std::function<void()> f) : R(r), base_ops(r.prog.ops.size()), base_reg(r.next_reg), run(std::move(f)), next(r.next_reg) {}
 	std::vector<Op> trace(const std::vector<char>& D) {
-		R.prog.ops.resize(base_ops); R.next_reg = base_reg; R.decisions = D; R.decision_pos = 0; R.pending = -1; R.run_id++;
+		R.prog.ops.resize(base_ops); R.next_reg = base_reg; R.decisions = D; R.decision_pos = 0; R.run_id++;
 		if (++runs > 2048) { R.fail("process() has too many data-dependent branches to record"); return {}; }
 		run();
 		return std::vector<Op>(R.prog.ops.begin() + (std::ptrdiff_t)base_ops, R.prog.ops.end());
@@ -1266,12 +1272,27 @@ struct PathMerger {
 
 namespace gpu {
 // dead-code elimination, node numbering and member layout shared by the note and the effect recorder
+// `if (env.finished()) stop();` (klang.h:4276-4279 in every shipped note) arrives as envoff / if / stop / else / endif: one `stopif` — which a body
+// without other branches may test once per block instead of per sample, and which has a two-voices-per-lane form (klg_graph.hpp)
+inline void fold_stop_idiom(std::vector<klg::graph::Op>& ops) {
+	using namespace klg::graph;
+	for (size_t i = 0; i + 4 < ops.size(); i++) {
+		if (ops[i].code != OP_ENVOFF || ops[i + 1].code != OP_IF || ops[i + 1].a != ops[i].dst || ops[i + 2].code != OP_STOP || ops[i + 3].code != OP_ELSE || ops[i + 4].code != OP_ENDIF) continue;
+		if (i + 5 < ops.size() && ops[i + 5].code == OP_PHI) continue;
+		bool read = false;
+		for (size_t q = 0; q < ops.size() && !read; q++) if (q != i + 1 && (ops[q].a == ops[i].dst || ops[q].b == ops[i].dst)) read = true;
+		if (read) continue;
+		Op s = ops[i]; s.code = OP_STOPIF; s.dst = -1; s.a = s.b = -1; s.imm = 0;
+		ops[i] = s; ops.erase(ops.begin() + (std::ptrdiff_t)i + 1, ops.begin() + (std::ptrdiff_t)i + 5);
+	}
+}
 inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	using namespace klg::graph;
+	fold_stop_idiom(R.prog.ops);
 	// ---- dead code: pure ops nobody reads, params nobody reads (and their write-backs), primitives nobody uses ----
 	std::vector<Op>& ops = R.prog.ops;
 	std::vector<char> keep(ops.size(), 1), used;
-	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG || c == OP_CMP || c == OP_PHI || c == OP_TABREAD || (c >= OP_F2D && c <= OP_D2F); };
+	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG || c == OP_CMP || c == OP_ENVOFF || c == OP_PHI || c == OP_TABREAD || (c >= OP_F2D && c <= OP_D2F); };
 	for (bool changed = true; changed;) {
 		changed = false;
 		used.assign(MAX_OPS + 1, 0); used[(size_t)R.prog.ret] = 1; if (R.prog.ret_r >= 0) used[(size_t)R.prog.ret_r] = 1;
@@ -1361,6 +1382,17 @@ inline int fx_binding(const std::type_info& t) { const auto it = fx_bindings().f
 struct Plugin : Controller, gpu::Owner { Plugin() : gpu::Owner(true) {} Controls controls; Presets presets; };
 
 namespace gpu {
+// a member's write-back whose value is the member's own read at the top of the sample (process() did not write it on any path): nothing to store
+inline void drop_idle_writebacks(Recorder& R, const std::vector<int>& first_reg) {
+	std::vector<klg::graph::Op>& ops = R.prog.ops;
+	size_t w = (size_t)R.prog.prepare_ops;
+	for (size_t q = w; q < ops.size(); q++) {
+		const klg::graph::Op& o = ops[q];
+		if (o.code == klg::graph::OP_SETPARAM && o.node >= 0 && (size_t)o.node < first_reg.size() && o.a == first_reg[(size_t)o.node]) continue;
+		ops[w++] = o;
+	}
+	ops.resize(w);
+}
 // ---- recording a Note's process() (+ prepare()) into a graph program ----
 // `objs`: the note's members (member_objs).  prepare() — host code that runs once per block in the reference (klang.h:4292-4296) —
 // becomes the program's per-block prologue, like an effect's.
@@ -1395,16 +1427,16 @@ template<class NOTEBASE> inline void record_note(NOTEBASE* nb, std::vector<Obj> 
 		R.may_branch = true;
 		nb->run_process();
 		R.may_branch = false;
-		if (R.pending >= 0) R.fail("`if (env.finished())` may only guard stop() in a recorded process()");
 		// `out` at the end of process(): one register, or two for a Stereo::Note whose out is {l, r} (klang.h:4721-4733) -> `ret2`
 		const int ret = R.reg_of(nb->out_channel(0)), ret_r = nb->out_channels() == 2 ? R.reg_of(nb->out_channel(1)) : -1;
 		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
 			signal* sg = (signal*)R.objs[i].addr;
-			if (sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);     // written by process(): the next sample reads it
-		}
+			R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);     // written by process(): the next sample reads it.  (EVERY member, also one this run left alone: the runs of
+		}                                                                     // different branch outcomes then end in the same ops and rejoin right after the `if` — drop_idle_writebacks removes the rest)
 		R.emit(PathMerger::OP_OUT, ret, ret_r, -1, 0, false);
 	});
 	paths.record();
+	drop_idle_writebacks(R, first_reg);
 	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = -1; sg->value = value0[i]; }
 	for (int c = 0; c < R.prog.nctl; c++) ctl.items[(size_t)c].value.reg = -1;
 	for (Oscillator* o : oscs) o->frequency.reg = -1;
@@ -1461,11 +1493,12 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 		const int ret = R.reg_of(*outs[0]), ret_r = channels == 2 ? R.reg_of(*outs[1]) : -1;
 		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) {
 			signal* sg = (signal*)R.objs[i].addr;
-			if (!(sg == ins[0] || sg == ins[1]) && sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);
+			if (!(sg == ins[0] || sg == ins[1])) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false);     // (every member: see record_note)
 		}
 		R.emit(PathMerger::OP_OUT, ret, ret_r, -1, 0, false);
 	});
 	paths.record();
+	drop_idle_writebacks(R, first_reg);
 	(void)is_io;
 	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; sg->reg = -1; sg->value = value0[i]; }
 	for (int c = 0; c < channels; c++) { ins[c]->reg = -1; outs[c]->reg = -1; }
@@ -1830,8 +1863,7 @@ public:
 	}
 	virtual bool stop(Velocity = 0) {
 		if (gpu::Recorder* r = gpu::recording()) {                 // `if (adsr.finished()) stop();` / `stop();` in a recorded process()
-			if (r->pending >= 0) { const int n = r->pending; r->emit(klg::graph::OP_STOPIF, -1, -1, n, 0, false); r->pending = -1; }
-			else r->emit(klg::graph::OP_STOP, -1, -1, -1, 0, false);
+			r->emit(klg::graph::OP_STOP, -1, -1, -1, 0, false);
 			return true;
 		}
 		stage = Off; if (!synth && solo) solo_push(); return true;

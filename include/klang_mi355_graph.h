@@ -135,7 +135,8 @@ enum OpCode {
 	OP_PARAM,       /* dst = value word of N_PARAM node                                               */
 	OP_OSC,         /* dst = oscillator node process()     Fast::Sine / OSM saw / OSM pulse / Basic::*   */
 	OP_OSCSET,      /* oscillator node .set(f = a)         Fast::Sine::set 5142-5147 / OSM::set 5217-5224 / Oscillator::set 2862 (per sample: vibrato, FM);
-	                   imm 1: .set(f = a, phase = b) 5149-5153 / 5226-5234 / 2867-2870 (hard sync, re-phasing); imm 2: .reset() 5136-5140 / 2859 */
+	                   imm 1: .set(f = a, phase = b) 5149-5153 / 5226-5234 / 2867-2870 (hard sync, re-phasing); imm 2: .reset() 5136-5140 / 2859;
+	                   imm 3: duty = a — OSM::setDuty 5246-5249 / Basic::Pulse::duty 4936: `set(f, phase, duty)` per sample (PWM) is oscset 1 followed by oscset 3 */
 	OP_LPF,         /* dst = (a >> modifier node)          any modifier kind: Biquad::Filter::process 5605-5612, OnePole, DCF, IIR<1>, ... */
 	OP_LPFSET,      /* lpf node .set(f = a, Q = b)         Biquad::Filter::set klang.h:5575-5600 + the init() of type imm (0 LPF, 1 HPF, 2 / 3 BPF peak / skirt, 4 BRF, 6 Butterworth<2>) */
 	OP_ENV,         /* dst = env/adsr node ++              Envelope::operator++ klang.h:4013-4051     */
@@ -171,10 +172,12 @@ enum OpCode {
 	OP_DLOW,        /* dst(double) = a with its LOW word replaced by imm: a 64-bit literal is dconst + dlow (an op carries 32 immediate bits)          */
 	OP_DADD, OP_DSUB, OP_DMUL, OP_DDIV,   /* dst(double) = a OP b, both doubles                                                                          */
 	OP_D2F,         /* dst = (float) a   (round to nearest even)                                                                                       */
+	OP_ENVOFF,      /* dst = env/adsr node .finished() ? 1.0 : 0.0     Envelope::finished klang.h:4094 (stage == Off) as a VALUE: `if (adsr.finished()) { ...; stop(); return; }`,
+	                   `!adsr.finished()`, `finished() && x > y` — the recorder turns the plain `if (env.finished()) stop();` back into stopif                 */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs", "f2d", "dconst", "dlow", "dadd", "dsub", "dmul", "ddiv", "d2f" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs", "f2d", "dconst", "dlow", "dadd", "dsub", "dmul", "ddiv", "d2f", "envoff" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -285,7 +288,7 @@ struct Program {
 			case OP_CTL: if ((int)o.imm >= nctl) return bad("control index out of range"); break;
 			case OP_PARAM: if (k != N_PARAM) return bad("node is not a param"); break;
 			case OP_OSC: if (!is_oscillator(k)) return bad("node is not an oscillator"); break;
-			case OP_OSCSET: if (!is_oscillator(k)) return bad("node is not an oscillator"); if (o.imm > 2u || (o.imm && k == N_WAVETABLE) || (o.imm == 2u && (k == N_SAW || k == N_PULSE))) return bad("this oscillator has no such set() / reset() on the device"); need_a = o.imm != 2u; need_b = o.imm == 1u; has_dst = false; break;
+			case OP_OSCSET: if (!is_oscillator(k)) return bad("node is not an oscillator"); if (o.imm > 3u || (o.imm && k == N_WAVETABLE) || (o.imm == 2u && (k == N_SAW || k == N_PULSE)) || (o.imm == 3u && !(k == N_SAW || k == N_PULSE || k == N_BPULSE))) return bad("this oscillator has no such set() / reset() on the device"); need_a = o.imm != 2u; need_b = o.imm == 1u; has_dst = false; break;
 			case OP_LPF: if (!is_modifier(k)) return bad("node is not a modifier"); need_a = true; break;
 			case OP_LPFSET: if (k != N_LPF) return bad("node is not an lpf"); if (o.imm == 5 || o.imm > 6) return bad("this biquad type cannot be set() on the device"); need_a = need_b = true; has_dst = false; break;
 			case OP_ENV: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); break;
@@ -311,6 +314,7 @@ struct Program {
 			case OP_DLOW: need_a = true; if (!is_dbl(o.a)) return bad("operand a is not a double"); dst_dbl = true; break;
 			case OP_DADD: case OP_DSUB: case OP_DMUL: case OP_DDIV: need_a = need_b = true; if (!is_dbl(o.a) || !is_dbl(o.b)) return bad("both operands must be doubles"); dst_dbl = true; break;
 			case OP_D2F: need_a = true; if (!is_dbl(o.a)) return bad("operand a is not a double"); break;
+			case OP_ENVOFF: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); break;
 			case OP_TABREAD: if (channels) return bad("tables are only available to synth notes"); if (o.imm == 0u) return bad("table id 0 is reserved"); need_a = true; break;
 			case OP_IF: if ((int)i < prepare_ops) return bad("prepare() may not branch"); need_a = true; has_dst = false; open.push_back({ {}, false, {} }); break;
 			case OP_ELSE:

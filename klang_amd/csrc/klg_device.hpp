@@ -241,6 +241,13 @@ __device__ __forceinline__ void osm_set_fp(Osm& o, float& cached, float f, float
 	o.state = ((uint32_t)(o.offset - (uint32_t)o.inc) < o.duty) ? 3 : 0;
 	osm_derive(o);
 }
+// OSM::setDuty klang.h:5246-5249: duty = duty * (2 pi) as a phase, then init() (the state from the phase, the coefficients from the duty).
+// `set(f, phase, duty)` 5236-5244 is set(f, phase) without its init() followed by this: the second init() recomputes everything the first one did
+__device__ __forceinline__ void osm_set_duty(Osm& o, float duty) {
+	o.duty = fast_phase(duty * (2.f * KLG_PI_F));
+	o.state = ((uint32_t)(o.offset - (uint32_t)o.inc) < o.duty) ? 3 : 0;
+	osm_derive(o);
+}
 __device__ __forceinline__ int osm_tick(Osm& o) {                           // klang.h:5251-5263
 	o.state = ((o.state << 1) | (o.offset < o.duty ? 1 : 0)) & 3;
 	const int tr = o.state | (o.offset < (uint32_t)o.inc ? 4 : 0);

@@ -54,11 +54,11 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 	// type names of the generated body: one voice per lane, or two (the packed primitives overload the scalar names)
 	const std::string TF = x2 ? "f2" : "float", TI = x2 ? "i2" : "int", TU = x2 ? "u2" : "uint32_t", T2 = x2 ? "2" : "";
 	const int NW = g.words();
-	std::vector<bool> swept(g.nodes.size(), false), written(g.nodes.size(), false), retuned(g.nodes.size(), false);
+	std::vector<bool> swept(g.nodes.size(), false), written(g.nodes.size(), false), retuned(g.nodes.size(), false), dutied(g.nodes.size(), false);   // dutied: a duty set per sample (oscset 3) is written back
 	std::vector<bool> reset_head(g.nodes.size(), false), head_used(g.nodes.size(), false);
 	for (const Op& o : g.ops) if (o.code == OP_DELAYSET || o.code == OP_DELAYOUT) head_used[(size_t)o.node] = true;
 	for (const Op& o : g.ops) if (o.code == OP_DELAYSET) reset_head[(size_t)o.node] = true;
-	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; if (o.code == OP_OSCSET) retuned[(size_t)o.node] = true; }
+	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; if (o.code == OP_OSCSET) { retuned[(size_t)o.node] = true; if (o.imm == 3u) dutied[(size_t)o.node] = true; } }
 	const bool fx = g.channels > 0;
 	int ctlvar[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };                      // control index -> the ctlvar node holding the instance's own copy (controls the effect writes)
 	for (const Op& o : g.ops) if (o.code == OP_SETCTL) ctlvar[o.imm & 7u] = o.node;
@@ -107,6 +107,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			end += W(OSM_OFFSET, n + ".offset") + W(OSM_STATE, "to_u(" + n + ".state)");
 			mark(w0 + OSM_OFFSET, 1); mark(w0 + OSM_STATE, 1);
 			if (retuned[i]) { end += W(OSM_INC, "to_u(" + n + ".inc)") + W(OSM_DELTA, "f2u(" + n + ".delta)") + W(OSM_FREQ, "f2u(" + n + "f)"); mark(w0 + OSM_INC, 1); mark(w0 + OSM_DELTA, 1); mark(w0 + OSM_FREQ, 1); }
+			if (dutied[i]) { end += W(OSM_DUTY, n + ".duty"); mark(w0 + OSM_DUTY, 1); }
 			break;
 		case N_LPF:
 			live += " Biquad" + T2 + fmt(" n%zu;", i) + " BiquadSweep" + T2 + fmt(" n%zus;", i);
@@ -144,6 +145,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			end += W(BOSC_POS, "f2u(" + n + ".position)");
 			mark(w0 + BOSC_POS, 1);
 			if (retuned[i]) { end += W(BOSC_INC, "f2u(" + n + ".increment)") + W(BOSC_FREQ, "f2u(" + n + "f)"); mark(w0 + BOSC_INC, 1); mark(w0 + BOSC_FREQ, 1); }
+			if (dutied[i]) { end += W(BOSC_DUTY, "f2u(" + n + "d)"); mark(w0 + BOSC_DUTY, 1); }
 			break;
 		case N_OPLPF: case N_OPHPF:
 			live += fmt(" OnePole n%zu;", i);
@@ -378,7 +380,8 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			body += d + e + ";\n";
 		} break;
 		case OP_OSCSET:
-			if (o.imm == 2u) body += "\t\t" + n + (k == N_FSINE ? ".pos = 0u;\n" : ".position = 0.f;\n");                               // reset(): Fast::Sine 5136-5140 (= set(frequency, 0)), Oscillator 2859
+			if (o.imm == 3u) body += k == N_BPULSE ? "\t\t" + n + "d = " + a + ";\n" : "\t\tosm_set_duty(" + n + ", " + a + ");\n";   // Basic::Pulse::duty 4936 / OSM::setDuty 5246-5249
+			else if (o.imm == 2u) body += "\t\t" + n + (k == N_FSINE ? ".pos = 0u;\n" : ".position = 0.f;\n");                               // reset(): Fast::Sine 5136-5140 (= set(frequency, 0)), Oscillator 2859
 			else if (o.imm == 1u) {                                                                                                    // set(f, phase)
 				if (k >= N_BSINE && k <= N_BPULSE) body += "\t\t" + n + ".position = " + b + "; " + n + "f = " + a + "; " + n + ".increment = " + a + " * 2.f * KLG_PI_F / c.fs.f;\n";   // klang.h:2867-2870
 				else body += "\t\t" + std::string(k == N_FSINE ? "fsine_set_fp(" : "osm_set_fp(") + n + ", " + n + "f, " + a + ", " + b + ", c.fs.f);\n";
@@ -413,6 +416,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		case OP_DMUL: body += dd + a + " * " + b + ";\n"; break;
 		case OP_DDIV: body += dd + a + " / " + b + ";\n"; break;
 		case OP_D2F: body += d + "(float)" + a + ";\n"; break;
+		case OP_ENVOFF: body += d + "env_is_off(" + n + (k == N_ADSR ? ".e" : "") + ".stage) ? 1.f : 0.f;\n"; break;     // Envelope::finished klang.h:4094
 		case OP_CMP: { static const char* rel[6] = { "<", ">", "<=", ">=", "==", "!=" }; body += d + "(" + a + " " + rel[o.imm <= 5u ? o.imm : 0u] + " " + b + ") ? 1.f : 0.f;\n"; } break;
 		case OP_IF:
 			if_depth++;

@@ -100,6 +100,11 @@ def scenarios():
     # examples/SynTHX.k (detuned saw partials, each on ONE channel drawn with random() in on() -> seeded note-ons)
     out["own_stereo_note"] = poly("own_stereo_note", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 1, 0.2)])
     out["own_synthx_shape"] = poly("own_synthx_shape", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, seeded=True, ctl=[(0, 0.02), (1, 0.015)], ctl_events=[(10, 1, 0.3)])
+    # (added in round 4, after every earlier draw of `rng`: the older scenarios keep their notes)
+    # finish_body.k: `finished()` as a value — stop() + return inside one branch, `!finished()`, `finished() && x < 0`; the second envelope's length follows a control
+    out["own_finish_body"] = poly("own_finish_body", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 0, 0.05)])
+    # pwm.k: set(f, phase, duty) on Fast::Pulse / Fast::Saw / Basic::Pulse from inside branches of process()
+    out["own_pwm"] = poly("own_pwm", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 0, 0.1)])
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],

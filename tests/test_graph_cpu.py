@@ -236,6 +236,49 @@ def test_oscillators_can_be_rephased_per_sample():
     assert rc < 0 and "no such set() / reset()" in msg
 
 
+def test_a_duty_can_be_set_per_sample_and_finished_is_a_value():
+    """`oscset` imm 3 (duty = a: OSM::setDuty klang.h:5246-5249, Basic::Pulse::duty 4936 — `set(f, phase, duty)` is oscset 1 then oscset 3) and `envoff`
+    (Envelope::finished() as a value, klang.h:4094): generated text, and what the validator refuses."""
+    prog = ("klgg 1\nctl 0\nnode 0 pulse\nnode 1 bpulse\nnode 2 adsr\nop const 0 -1 -1 -1 1135869952\nop const 1 -1 -1 -1 0\nop const 2 -1 -1 -1 1050253722\n"
+            "op oscset -1 0 1 0 1\nop oscset -1 2 -1 0 3\nop oscset -1 0 1 1 1\nop oscset -1 2 -1 1 3\n"
+            "op osc 3 -1 -1 0 0\nop osc 4 -1 -1 1 0\nop add 5 3 4 -1 0\nop env 6 -1 -1 2 0\nop mul 7 5 6 -1 0\n"
+            "op envoff 8 -1 -1 2 0\nop if -1 8 -1 -1 0\nop stop -1 -1 -1 -1 0\nop else -1 -1 -1 -1 0\nop endif -1 -1 -1 -1 0\nret 7\nend\n")
+    rc, src = check(prog, want_source=True)
+    assert rc == 0, src
+    for needle in ("osm_set_duty(L.n0, r2);", "L.n1d = r2;", "env_is_off(L.n2.e.stage) ? 1.f : 0.f;", "L.stage = stage_all_off(L.stage);"):
+        assert needle in src, needle
+    assert "f2u(L.n1d)" in src and "L.n0.duty" in src                                          # the duties are written back
+    rc, msg = check(prog.replace("node 0 pulse", "node 0 fsine"))                               # a Fast::Sine has no duty
+    assert rc < 0 and "no such set() / reset()" in msg
+    rc, msg = check(prog.replace("op envoff 8 -1 -1 2 0", "op envoff 8 -1 -1 0 0"))
+    assert rc < 0 and "not an envelope" in msg
+
+
+def test_facade_folds_the_stop_idiom_and_records_finished_as_a_value():
+    """tests/patches/finish_body.k: `if (adsr.finished()) { ...; stop(); return; }`, `!shape.finished()`, `shape.finished() && x < 0` record as envoff +
+    structured branches; tests/patches/pwm.k: `if (adsr.finished()) stop();` is still ONE stopif, set(f, phase, duty) is oscset 1 + oscset 3, and the
+    common tail after the outer `if` is there once (every member is written back on every path, idle write-backs dropped afterwards)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    def program(name):
+        exe = os.path.join(ROOT, "tests", "cpp", "_bin", "facade_graph_own_" + name)
+        r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", f"own_{name}_solo.scn"), "/dev/null"], env=dict(os.environ, KLANG_MI355_DUMP_GRAPH="1", HIP_VISIBLE_DEVICES="-1"), capture_output=True, text=True)
+        text = r.stderr[r.stderr.index("klgg 1"):r.stderr.index("end\n") + 4]
+        return text, [ln.split() for ln in text.splitlines() if ln.startswith("op ")]
+    text, ops = program("finish_body")
+    codes = [o[1] for o in ops]
+    assert codes.count("envoff") == 3 and codes.count("stop") == 1 and "stopif" not in codes, codes
+    assert codes.index("envoff") + 1 == codes.index("if") and codes[codes.index("if") + 1] == "stop"          # stop() is the `if` side, the rest of the body its `else`
+    rc, msg = check(text)
+    assert rc == 0, msg
+    text, ops = program("pwm")
+    codes = [o[1] for o in ops]
+    assert codes.count("stopif") == 1 and "envoff" not in codes and codes.count("osc") == 5 and codes.count("env") == 1, codes
+    sets = [(o[5], int(o[6], 16)) for o in ops if o[1] == "oscset"]
+    assert sets == [("2", 1), ("2", 3), ("1", 1), ("1", 3), ("3", 1), ("3", 3)], sets
+    rc, msg = check(text)
+    assert rc == 0, msg
+
+
 def test_an_effect_may_write_its_controls_take_abs_and_place_delay_heads_per_sample():
     """What examples/PingPong.k needs of a recorded effect (tests/golden/pingpong_recorded.klgg is the whole program): `setctl` (controls[i].set(x):
     the dial's clamp, the instance's own copy `ctlvar` that every later read and smooth() of the control takes), `abs`, `delayset` + `delayout`
