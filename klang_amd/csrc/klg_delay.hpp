@@ -137,30 +137,41 @@ __device__ __forceinline__ int ring_walk(int p, int m, int size) {              
 	int q = (p == size ? 0 : p) + m;
 	return q >= size ? q - size : q;
 }
-__device__ __forceinline__ float staged_process(const Ring& r, int position, float fraction, RingWindow w, int& bad) {
+// Every read comes in two halves — `_fetch` finds the rows, checks them and ISSUES the loads, `_finish` is the arithmetic on what they return — so that a
+// level of the staged kernel can issue all its taps' loads before it waits for the first of them (klg_graph_staged.hpp: one memory round trip per level
+// instead of one per tap).  The whole functions are finish(fetch()): the same operations in the same order either way.
+struct TapFetch { float a, b, c, d, f; bool pad; };
+__device__ __forceinline__ TapFetch staged_process_fetch(const Ring& r, int position, float fraction, RingWindow w, int& bad) {
 	const int i = position, j = ring_succ(i, r.size);
 	bad |= (int)(ring_in_window(i, r.size, w) || ring_in_window(j, r.size, w));
-	const float a = r.rd(i), b = r.rd(j);
-	return a + fraction * (b - a);
+	TapFetch t; t.a = r.rd(i); t.b = r.rd(j); t.c = t.d = 0.f; t.f = fraction; t.pad = false;
+	return t;
 }
-__device__ __forceinline__ float staged_tap_int(const Ring& r, int position, int delay, RingWindow w, int& bad) {
+__device__ __forceinline__ float staged_process_finish(const TapFetch& t) { return t.a + t.f * (t.b - t.a); }
+__device__ __forceinline__ float staged_process(const Ring& r, int position, float fraction, RingWindow w, int& bad) { return staged_process_finish(staged_process_fetch(r, position, fraction, w, bad)); }
+__device__ __forceinline__ TapFetch staged_tap_int_fetch(const Ring& r, int position, int delay, RingWindow w, int& bad) {
 	int read = (position - 1) - delay;
 	if (read < 0) read += r.size;
 	read = read < 0 ? r.size : (read > r.size ? r.size : read);
 	bad |= (int)ring_in_window(read, r.size, w);
-	return r.rd(read);
+	TapFetch t; t.a = r.rd(read); t.b = t.c = t.d = t.f = 0.f; t.pad = false;
+	return t;
 }
-__device__ __forceinline__ float staged_tap_float(const Ring& r, int position, float delay, RingWindow w, int& bad) {
+__device__ __forceinline__ float staged_tap_int_finish(const TapFetch& t) { return t.a; }
+__device__ __forceinline__ float staged_tap_int(const Ring& r, int position, int delay, RingWindow w, int& bad) { return staged_tap_int_finish(staged_tap_int_fetch(r, position, delay, w, bad)); }
+__device__ __forceinline__ TapFetch staged_tap_float_fetch(const Ring& r, int position, float delay, RingWindow w, int& bad) {
 	float read = (float)(position - 1) - delay;
 	if (read < 0.f) read += r.size;
 	const int i = (int)read < 0 ? 0 : (int)read;
 	const float fraction = read - i;
 	const int j = (i + 1) % r.size;
 	bad |= (int)(ring_in_window(i, r.size, w) || ring_in_window(j, r.size, w));
-	const float a = r.rd(i), b = r.rd(j);
-	return a + fraction * (b - a);
+	TapFetch t; t.a = r.rd(i); t.b = r.rd(j); t.c = t.d = 0.f; t.f = fraction; t.pad = false;
+	return t;
 }
-__device__ __forceinline__ float staged_tap_stereo(const Ring& r, int position, float delay, RingWindow w, int& bad) {
+__device__ __forceinline__ float staged_tap_float_finish(const TapFetch& t) { return t.a + t.f * (t.b - t.a); }
+__device__ __forceinline__ float staged_tap_float(const Ring& r, int position, float delay, RingWindow w, int& bad) { return staged_tap_float_finish(staged_tap_float_fetch(r, position, delay, w, bad)); }
+__device__ __forceinline__ TapFetch staged_tap_stereo_fetch(const Ring& r, int position, float delay, RingWindow w, int& bad) {
 	float read = (float)(position - 1) - delay;
 	if (read < 0.f) read += r.size;
 	const float f = (float)floor((double)read);
@@ -170,10 +181,12 @@ __device__ __forceinline__ float staged_tap_stereo(const Ring& r, int position, 
 	const bool pad = i >= r.size || i < 0;
 	const int ri = pad ? 0 : i, rj = pad ? 0 : j;
 	bad |= (int)(!pad && (ring_in_window(ri, r.size, w) || ring_in_window(rj, r.size, w)));
-	const float a = pad ? 0.f : r.rd(ri), b = pad ? 0.f : r.rd(rj);
-	return a * (1.f - frac) + b * frac;
+	TapFetch t; t.a = r.rd(ri); t.b = r.rd(rj); t.c = t.d = 0.f; t.f = frac; t.pad = pad;      // (a pad tap reads row 0 and drops it: no branch around the loads)
+	return t;
 }
-__device__ __forceinline__ float staged_lagrange(const Ring& r, int position, float delay, RingWindow w, int& bad) {   // delay_lagrange below + the check of its four rows
+__device__ __forceinline__ float staged_tap_stereo_finish(const TapFetch& t) { const float a = t.pad ? 0.f : t.a, b = t.pad ? 0.f : t.b; return a * (1.f - t.f) + b * t.f; }
+__device__ __forceinline__ float staged_tap_stereo(const Ring& r, int position, float delay, RingWindow w, int& bad) { return staged_tap_stereo_finish(staged_tap_stereo_fetch(r, position, delay, w, bad)); }
+__device__ __forceinline__ TapFetch staged_lagrange_fetch(const Ring& r, int position, float delay, RingWindow w, int& bad) {   // delay_lagrange below + the check of its four rows
 	const int SIZE = r.size;
 	float read = (float)(position - 1) - delay;
 	if (read < 0.f) read += SIZE;
@@ -181,13 +194,18 @@ __device__ __forceinline__ float staged_lagrange(const Ring& r, int position, fl
 	const float x = read - i;
 	const int i0 = (i - 1 + SIZE) % SIZE, i2 = (i + 1) % SIZE, i3 = (i + 2) % SIZE;
 	bad |= (int)(ring_in_window(i0, SIZE, w) || ring_in_window(i, SIZE, w) || ring_in_window(i2, SIZE, w) || ring_in_window(i3, SIZE, w));
-	const float y0 = r.rd(i0), y1 = r.rd(i), y2 = r.rd(i2), y3 = r.rd(i3);
+	TapFetch t; t.a = r.rd(i0); t.b = r.rd(i); t.c = r.rd(i2); t.d = r.rd(i3); t.f = x; t.pad = false;
+	return t;
+}
+__device__ __forceinline__ float staged_lagrange_finish(const TapFetch& t) {
+	const float x = t.f, y0 = t.a, y1 = t.b, y2 = t.c, y3 = t.d;
 	const float c0 = (-x * (x - 1) * (x - 2)) / 6.0f;
 	const float c1 = ((x + 1) * (x - 1) * (x - 2)) / 2.0f;
 	const float c2 = (-x * (x + 1) * (x - 2)) / 2.0f;
 	const float c3 = (x * (x + 1) * (x - 1)) / 6.0f;
 	return c0 * y0 + c1 * y1 + c2 * y2 + c3 * y3;
 }
+__device__ __forceinline__ float staged_lagrange(const Ring& r, int position, float delay, RingWindow w, int& bad) { return staged_lagrange_finish(staged_lagrange_fetch(r, position, delay, w, bad)); }
 __device__ __forceinline__ float delay_lagrange(const Ring& r, int position, float delay) {
 	const int SIZE = r.size;
 	float read = (float)(position - 1) - delay;

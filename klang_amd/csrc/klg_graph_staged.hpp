@@ -376,10 +376,15 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		};
 		std::string inst = "pg";                                                   // which instance the code being generated works for: a lane of a parallel level (pg) or of a serial loop (ln)
 		// the statement(s) of virtual op i, in the context (L, c) it is emitted in
-		auto op_text = [&](int i, bool assign) {
+		// tap_mode (ring reads only): 0 the whole read; 1 its first half — rows found, checked, loads issued into tf<i> —; 2 the arithmetic on what they returned
+		auto op_text = [&](int i, bool assign, int tap_mode = 0) {
 			const VOp& v = V[(size_t)i];
 			std::string b;
-			const std::string d = assign ? F("\t\tr%d = ", v.dst) : "\t\tconst " + ty(std::max(v.dst, 0)) + F(" r%d = ", v.dst);
+			std::string d = assign ? F("\t\tr%d = ", v.dst) : "\t\tconst " + ty(std::max(v.dst, 0)) + F(" r%d = ", v.dst);
+			if (tap_mode && (v.code == OP_DELAYOUT || v.code == OP_DELAYTAP)) {
+				const char* fn = v.code == OP_DELAYOUT ? "staged_process" : v.imm == 1u ? "staged_tap_int" : v.imm == 3u ? "staged_lagrange" : v.imm == 2u ? "staged_tap_stereo" : "staged_tap_float";
+				if (tap_mode == 2) return d + fn + F("_finish(tf%d);\n", i);
+			}
 			const int SZ = v.node >= 0 ? g.arg(v.node) : 0;
 			auto pos = [&](int j) { return j ? F("ring_at(d%dp0, %d, %d)", v.node, j, SZ) : F("d%dp0", v.node); };
 			switch (v.code) {
@@ -392,12 +397,14 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			case OP_DELAYIN: b += "\t\t{ const Ring q = " + ring(v.node) + "; q.wr(" + pos(in_index[(size_t)i]) + F(", r%d); }\n", v.a); break;
 			case OP_DELAYSET: b += F("\t\td%dt = delay_set(", v.node) + pos(in_index[(size_t)i]) + F(", %d, r%d);\n", SZ, v.a); break;
 			case OP_DELAYOUT:
-				if (set_at[(size_t)v.node] >= 0) b += d + "staged_process(" + ring(v.node) + F(", ring_walk(d%dt.position, %d, %d), d%dt.fraction, d%dw, bad);\n", v.node, out_index[(size_t)i], SZ, v.node, v.node);
-				else b += d + "staged_process(" + ring(v.node) + F(", ring_walk(d%dh.position, ps * %d + %d, %d), d%dh.fraction, d%dw, bad);\n", v.node, outs[(size_t)v.node], out_index[(size_t)i], SZ, v.node, v.node);
+				if (tap_mode == 1) d = F("\t\ttf%d = ", i);
+				if (set_at[(size_t)v.node] >= 0) b += d + (tap_mode == 1 ? "staged_process_fetch(" : "staged_process(") + ring(v.node) + F(", ring_walk(d%dt.position, %d, %d), d%dt.fraction, d%dw, bad);\n", v.node, out_index[(size_t)i], SZ, v.node, v.node);
+				else b += d + (tap_mode == 1 ? "staged_process_fetch(" : "staged_process(") + ring(v.node) + F(", ring_walk(d%dh.position, ps * %d + %d, %d), d%dh.fraction, d%dw, bad);\n", v.node, outs[(size_t)v.node], out_index[(size_t)i], SZ, v.node, v.node);
 				break;
 			case OP_DELAYTAP:
-				if (v.imm == 1u) b += d + "staged_tap_int(" + ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", (int)r%d, d%dw, bad);\n", v.a, v.node);
-				else b += d + (v.imm == 3u ? "staged_lagrange(" : v.imm == 2u ? "staged_tap_stereo(" : "staged_tap_float(") + ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", r%d, d%dw, bad);\n", v.a, v.node);
+				if (tap_mode == 1) d = F("\t\ttf%d = ", i);
+				if (v.imm == 1u) b += d + (tap_mode == 1 ? "staged_tap_int_fetch(" : "staged_tap_int(") + ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", (int)r%d, d%dw, bad);\n", v.a, v.node);
+				else b += d + std::string(v.imm == 3u ? "staged_lagrange" : v.imm == 2u ? "staged_tap_stereo" : "staged_tap_float") + (tap_mode == 1 ? "_fetch(" : "(") + ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", r%d, d%dw, bad);\n", v.a, v.node);
 				break;
 			default: in.emit_op((size_t)v.orig, b, assign); break;
 			}
@@ -431,6 +438,98 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			std::vector<std::pair<int, int>> open;
 			auto close_to = [&](size_t keep) { while (open.size() > keep) { out += "\t\t}\n"; open.pop_back(); } };
 			static const bool ifconv = []() { const char* e = getenv("KLG_FX_STAGED_IFCONV"); return !(e && e[0] == '0'); }();
+			const bool batch_taps = []() { const char* e = getenv("KLG_FX_STAGED_BATCH"); return !(e && e[0] == '0'); }();   // (read per plan: the compile cache is keyed by it)
+			// A parallel level's ring reads, many under way at a time.  Written one after the other, every read is two loads, a wait for both and the
+			// interpolation — a memory round trip per tap, fifty in a row in the recorded Reverb.k's first level.  Nothing in a parallel level has a side effect
+			// another op of the level could see, so its ops may run in any order their operands allow: a read's first half (rows, check, loads: tf<i>) is emitted
+			// where the read stands, its second half (the arithmetic) and everything that needs it wait until 2 x BATCH reads are under way; then the oldest
+			// BATCH are finished — behind a compiler barrier that keeps the loads above it — and what waited for them follows.
+			if (wave < 0 && batch_taps) {
+				std::vector<int> here; bool any_tap = false;
+				auto is_tap = [&](int i) { return V[(size_t)i].code == OP_DELAYOUT || V[(size_t)i].code == OP_DELAYTAP; };
+				for (int i = 0; i < NV; i++) if (in_block(i, pf, lv, wave)) { here.push_back(i); if (is_tap(i)) any_tap = true; }
+				if (any_tap) {
+					const int BATCH = []() { const char* e = getenv("KLG_FX_STAGED_BATCH"); const int b = e ? atoi(e) : 0; return b >= 2 ? b : 6; }();
+					std::vector<char> inblk((size_t)NV, 0), done((size_t)NV, 0);
+					for (int i : here) inblk[(size_t)i] = 1;
+					auto ready = [&](int i) {
+						const VOp& v = V[(size_t)i];
+						bool ok = true;
+						auto rd = [&](int r) { const int j = (r >= 0 && (size_t)r < def_at.size()) ? def_at[(size_t)r] : -1; if (j >= 0 && inblk[(size_t)j] && !done[(size_t)j]) ok = false; };
+						rd(v.a); rd(v.b);
+						for (const auto& pe : v.path) rd(V[(size_t)pe.first].a);
+						if (v.code == OP_PHI && phi_if[(size_t)i] >= 0) rd(V[(size_t)phi_if[(size_t)i]].a);
+						if (v.code == OP_DELAYOUT && v.node >= 0 && set_at[(size_t)v.node] >= 0) { const int sa = set_at[(size_t)v.node]; if (inblk[(size_t)sa] && !done[(size_t)sa]) ok = false; }   // (the head a process() walks is what set() left: d<n>t)
+						return ok;
+					};
+					for (int i : here) if (is_tap(i)) out += F("\t\tTapFetch tf%d;\n", i);
+					auto stmt = [&](int i, const std::string& text) {
+						const VOp& v = V[(size_t)i];
+						size_t common = 0;
+						while (common < open.size() && common < v.path.size() && open[common] == v.path[common]) common++;
+						close_to(common);
+						for (size_t q = common; q < v.path.size(); q++) { out += F("\t\tif (%s(r%d != 0.f)) {\n", v.path[q].second ? "!" : "", V[(size_t)v.path[q].first].a); open.push_back(v.path[q]); }
+						out += text;
+					};
+					auto has_dst_of = [&](const VOp& v) { return v.dst >= 0 && v.code != OP_OSCSET && v.code != OP_LPFSET && v.code != OP_SETPARAM && v.code != OP_DELAYIN && v.code != OP_DELAYSET; };
+					// A read inside a recorded `if` is taken OUTSIDE it: what is assigned under a branch and used behind the join lives in scratch (a store and a wait
+					// per load).  Every row a read computes is a row of its line whatever its operand holds; only its check counts under the branch's condition alone.
+					auto cond_of = [&](const VOp& v) { std::string c; for (const auto& pe : v.path) c += (c.empty() ? "" : " && ") + F("%s(r%d != 0.f)", pe.second ? "!" : "", V[(size_t)pe.first].a); return c; };
+					auto fetch = [&](int i) {
+						const VOp& v = V[(size_t)i];
+						close_to(0);
+						if (v.path.empty()) { out += op_text(i, false, 1); return; }
+						std::string text = op_text(i, false, 1);
+						const size_t at = text.rfind(", bad)");
+						if (at != std::string::npos) text.replace(at, 6, ", badl)");
+						out += "\t\t{ int badl = 0;\n" + text + "\t\tbad |= (" + cond_of(v) + ") ? badl : 0; }\n";
+					};
+					auto finish = [&](int i) {
+						const VOp& v = V[(size_t)i];
+						const bool assign = predeclared[(size_t)v.dst] != 0;
+						std::string text = op_text(i, assign, 2);
+						if (regs[(size_t)v.dst].slot) text += "\t\t" + slot_ref(v.dst, pf) + F("[%s] = r%d;\n", slot_index.c_str(), v.dst);
+						close_to(0);
+						out += text;
+						done[(size_t)i] = 1;
+					};
+					auto plain_op = [&](int i) {
+						const VOp& v = V[(size_t)i];
+						const bool has_dst = has_dst_of(v), assign = has_dst && predeclared[(size_t)v.dst] != 0;
+						std::string text = op_text(i, assign);
+						if (has_dst && regs[(size_t)v.dst].slot) text += "\t\t" + slot_ref(v.dst, pf) + F("[%s] = r%d;\n", slot_index.c_str(), v.dst);
+						stmt(i, text);
+						done[(size_t)i] = 1;
+					};
+					const std::string fence = "\t\tasm volatile(\"\" ::: \"memory\");                                       // (the loads above are not moved below this line)\n";
+					std::vector<int> pending, waiting;                                         // reads under way (oldest first); ops whose operands are not there yet (program order)
+					auto take = [&](int i) { if (is_tap(i)) { fetch(i); pending.push_back(i); } else plain_op(i); };
+					auto drain = [&](size_t n) {
+						if (n > pending.size()) n = pending.size();
+						if (n) { close_to(0); out += fence; for (size_t q = 0; q < n; q++) finish(pending[q]); pending.erase(pending.begin(), pending.begin() + (std::ptrdiff_t)n); }
+						for (bool moved = true; moved;) {                                        // what waited for them, in program order (a read among it goes under way)
+							moved = false;
+							for (size_t q = 0; q < waiting.size();) {
+								if (pending.size() >= 2 * (size_t)BATCH && is_tap(waiting[q])) { q++; continue; }
+								if (ready(waiting[q])) { const int i = waiting[q]; waiting.erase(waiting.begin() + (std::ptrdiff_t)q); take(i); moved = true; }
+								else q++;
+							}
+						}
+					};
+					for (int i : here) {
+						if (waiting.empty() ? ready(i) : (is_tap(i) && ready(i))) take(i);       // (an op behind a waiting one waits too unless it is a read: consumers keep their order)
+						else waiting.push_back(i);
+						if (pending.size() >= 2 * (size_t)BATCH) drain((size_t)BATCH);
+					}
+					while (!pending.empty() || !waiting.empty()) {
+						const size_t before = pending.size() + waiting.size();
+						drain(pending.size() > (size_t)BATCH ? (size_t)BATCH : pending.size());
+						if (pending.size() + waiting.size() == before && pending.empty()) break;   // (cannot happen: the ops of a block are in def-before-use order)
+					}
+					close_to(0);
+					return;
+				}
+			}
 			for (int i = 0; i < NV; i++) {
 				const VOp& v = V[(size_t)i];
 				if (!in_block(i, pf, lv, wave)) continue;
