@@ -141,15 +141,30 @@ __device__ __forceinline__ int ring_walk(int p, int m, int size) {              
 // level of the staged kernel can issue all its taps' loads before it waits for the first of them (klg_graph_staged.hpp: one memory round trip per level
 // instead of one per tap).  The whole functions are finish(fetch()): the same operations in the same order either way.
 struct TapFetch { float a, b, c, d, f; bool pad; };
-__device__ __forceinline__ TapFetch staged_process_fetch(const Ring& r, int position, float fraction, RingWindow w, int& bad) {
+// a line of the staged kernel's ring tile: rows of `stride4` bytes from a wave-uniform base, this lane's column `col4` bytes into a row — 32-bit offsets
+// (a workgroup's tile is < 4 GB): one operation per address where a per-lane 64-bit pointer takes three
+struct RingS {
+	const char* base; unsigned col4, stride4; int size;
+	__device__ __forceinline__ float rd(int i) const { return *(const float*)(base + ((unsigned)i * stride4 + col4)); }
+	__device__ __forceinline__ void wr(int i, float v) const { *(float*)(const_cast<char*>(base) + ((unsigned)i * stride4 + col4)) = v; }
+};
+// rows i and ring_succ(i) of a read, checked together: i in [w0 - 1, w0 + wn) (mod SIZE) is exactly "i or its successor lies in the window"; the pad row
+// (i == SIZE: zeros, its successor row 0 or 1) counts as row 0 — a check that says "maybe" where it need not only sends the chunk to the plain body
+__device__ __forceinline__ bool ring_pair_in_window(int i, int size, RingWindow w) {
+	const int ii = i >= size ? 0 : i;
+	int d = ii - w.w0 + 1;
+	d = d < 0 ? d + size : (d >= size ? d - size : d);
+	return d < w.wn + 1;
+}
+template<class RG> __device__ __forceinline__ TapFetch staged_process_fetch(const RG& r, int position, float fraction, RingWindow w, int& bad) {
 	const int i = position, j = ring_succ(i, r.size);
-	bad |= (int)(ring_in_window(i, r.size, w) || ring_in_window(j, r.size, w));
+	bad |= (int)ring_pair_in_window(i, r.size, w);
 	TapFetch t; t.a = r.rd(i); t.b = r.rd(j); t.c = t.d = 0.f; t.f = fraction; t.pad = false;
 	return t;
 }
 __device__ __forceinline__ float staged_process_finish(const TapFetch& t) { return t.a + t.f * (t.b - t.a); }
-__device__ __forceinline__ float staged_process(const Ring& r, int position, float fraction, RingWindow w, int& bad) { return staged_process_finish(staged_process_fetch(r, position, fraction, w, bad)); }
-__device__ __forceinline__ TapFetch staged_tap_int_fetch(const Ring& r, int position, int delay, RingWindow w, int& bad) {
+template<class RG> __device__ __forceinline__ float staged_process(const RG& r, int position, float fraction, RingWindow w, int& bad) { return staged_process_finish(staged_process_fetch(r, position, fraction, w, bad)); }
+template<class RG> __device__ __forceinline__ TapFetch staged_tap_int_fetch(const RG& r, int position, int delay, RingWindow w, int& bad) {
 	int read = (position - 1) - delay;
 	if (read < 0) read += r.size;
 	read = read < 0 ? r.size : (read > r.size ? r.size : read);
@@ -158,35 +173,35 @@ __device__ __forceinline__ TapFetch staged_tap_int_fetch(const Ring& r, int posi
 	return t;
 }
 __device__ __forceinline__ float staged_tap_int_finish(const TapFetch& t) { return t.a; }
-__device__ __forceinline__ float staged_tap_int(const Ring& r, int position, int delay, RingWindow w, int& bad) { return staged_tap_int_finish(staged_tap_int_fetch(r, position, delay, w, bad)); }
-__device__ __forceinline__ TapFetch staged_tap_float_fetch(const Ring& r, int position, float delay, RingWindow w, int& bad) {
+template<class RG> __device__ __forceinline__ float staged_tap_int(const RG& r, int position, int delay, RingWindow w, int& bad) { return staged_tap_int_finish(staged_tap_int_fetch(r, position, delay, w, bad)); }
+template<class RG> __device__ __forceinline__ TapFetch staged_tap_float_fetch(const RG& r, int position, float delay, RingWindow w, int& bad) {
 	float read = (float)(position - 1) - delay;
 	if (read < 0.f) read += r.size;
 	const int i = (int)read < 0 ? 0 : (int)read;
 	const float fraction = read - i;
-	const int j = (i + 1) % r.size;
-	bad |= (int)(ring_in_window(i, r.size, w) || ring_in_window(j, r.size, w));
+	const int j = (i + 1 >= r.size) ? i + 1 - r.size : i + 1;                         // (i + 1) % SIZE for 0 <= i <= SIZE
+	bad |= (int)ring_pair_in_window(i, r.size, w);                                   // (i == SIZE: the pad row and row 1 — checked as rows 0 and 1)
 	TapFetch t; t.a = r.rd(i); t.b = r.rd(j); t.c = t.d = 0.f; t.f = fraction; t.pad = false;
 	return t;
 }
 __device__ __forceinline__ float staged_tap_float_finish(const TapFetch& t) { return t.a + t.f * (t.b - t.a); }
-__device__ __forceinline__ float staged_tap_float(const Ring& r, int position, float delay, RingWindow w, int& bad) { return staged_tap_float_finish(staged_tap_float_fetch(r, position, delay, w, bad)); }
-__device__ __forceinline__ TapFetch staged_tap_stereo_fetch(const Ring& r, int position, float delay, RingWindow w, int& bad) {
+template<class RG> __device__ __forceinline__ float staged_tap_float(const RG& r, int position, float delay, RingWindow w, int& bad) { return staged_tap_float_finish(staged_tap_float_fetch(r, position, delay, w, bad)); }
+template<class RG> __device__ __forceinline__ TapFetch staged_tap_stereo_fetch(const RG& r, int position, float delay, RingWindow w, int& bad) {
 	float read = (float)(position - 1) - delay;
 	if (read < 0.f) read += r.size;
-	const float f = (float)floor((double)read);
+	const float f = __builtin_floorf(read);                                         // == (float)floor((double)read): the floor of a float is a float
 	const float frac = read - f;
 	const int i = (int)read;
 	const int j = (i == r.size - 1) ? 0 : (i + 1);
 	const bool pad = i >= r.size || i < 0;
 	const int ri = pad ? 0 : i, rj = pad ? 0 : j;
-	bad |= (int)(!pad && (ring_in_window(ri, r.size, w) || ring_in_window(rj, r.size, w)));
+	bad |= (int)(!pad && ring_pair_in_window(ri, r.size, w));
 	TapFetch t; t.a = r.rd(ri); t.b = r.rd(rj); t.c = t.d = 0.f; t.f = frac; t.pad = pad;      // (a pad tap reads row 0 and drops it: no branch around the loads)
 	return t;
 }
 __device__ __forceinline__ float staged_tap_stereo_finish(const TapFetch& t) { const float a = t.pad ? 0.f : t.a, b = t.pad ? 0.f : t.b; return a * (1.f - t.f) + b * t.f; }
-__device__ __forceinline__ float staged_tap_stereo(const Ring& r, int position, float delay, RingWindow w, int& bad) { return staged_tap_stereo_finish(staged_tap_stereo_fetch(r, position, delay, w, bad)); }
-__device__ __forceinline__ TapFetch staged_lagrange_fetch(const Ring& r, int position, float delay, RingWindow w, int& bad) {   // delay_lagrange below + the check of its four rows
+template<class RG> __device__ __forceinline__ float staged_tap_stereo(const RG& r, int position, float delay, RingWindow w, int& bad) { return staged_tap_stereo_finish(staged_tap_stereo_fetch(r, position, delay, w, bad)); }
+template<class RG> __device__ __forceinline__ TapFetch staged_lagrange_fetch(const RG& r, int position, float delay, RingWindow w, int& bad) {   // delay_lagrange below + the check of its four rows
 	const int SIZE = r.size;
 	float read = (float)(position - 1) - delay;
 	if (read < 0.f) read += SIZE;
@@ -205,7 +220,7 @@ __device__ __forceinline__ float staged_lagrange_finish(const TapFetch& t) {
 	const float c3 = (x * (x + 1) * (x - 1)) / 6.0f;
 	return c0 * y0 + c1 * y1 + c2 * y2 + c3 * y3;
 }
-__device__ __forceinline__ float staged_lagrange(const Ring& r, int position, float delay, RingWindow w, int& bad) { return staged_lagrange_finish(staged_lagrange_fetch(r, position, delay, w, bad)); }
+template<class RG> __device__ __forceinline__ float staged_lagrange(const RG& r, int position, float delay, RingWindow w, int& bad) { return staged_lagrange_finish(staged_lagrange_fetch(r, position, delay, w, bad)); }
 __device__ __forceinline__ float delay_lagrange(const Ring& r, int position, float delay) {
 	const int SIZE = r.size;
 	float read = (float)(position - 1) - delay;

@@ -365,7 +365,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		// =========================================================== source ===========================================================
 		std::string s;
 		auto F = [](const char* f, ...) { char b[1024]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return std::string(b); };
-		auto ring = [&](int node) { return F("Ring{ c.ring + (size_t)%lldll * %d, %d, %d }", (*in.ring_off)[(size_t)node], G, G, g.arg(node)); };   // rows of G instances: this workgroup's own (PatchGen::kRingRow)
+		auto ring = [&](int node) { return F("RingS{ (const char*)(ring0 + (size_t)%lldll * %d), (unsigned)pg * 4u, %du, %d }", (*in.ring_off)[(size_t)node], G, G * 4, g.arg(node)); };   // rows of G instances: this workgroup's own (PatchGen::kRingRow); a wave-uniform base + 32-bit offsets (klg_delay.hpp RingS)
 		auto ty = [&](int r) { return std::string(is_dbl[(size_t)r] ? "double" : "float"); };
 		auto in_branch = [&](int i) { return !V[(size_t)i].path.empty(); };
 		// where a register's LDS copy is, for code of group `pf` (the prefix works on the NEXT chunk: the other parity)
@@ -394,7 +394,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			case V_OSCARG: b += d + F("basic_sine_arg(L.n%d);\n", v.node); break;
 			case V_OSCEVAL: b += d + F("basic_sine_of(r%d);\n", v.a); break;
 			case OP_PHI: b += d + F("(r%d != 0.f) ? r%d : r%d;\n", V[(size_t)phi_if[(size_t)i]].a, v.a, v.b); break;
-			case OP_DELAYIN: b += "\t\t{ const Ring q = " + ring(v.node) + "; q.wr(" + pos(in_index[(size_t)i]) + F(", r%d); }\n", v.a); break;
+			case OP_DELAYIN: b += "\t\t{ const RingS q = " + ring(v.node) + "; q.wr(" + pos(in_index[(size_t)i]) + F(", r%d); }\n", v.a); break;
 			case OP_DELAYSET: b += F("\t\td%dt = delay_set(", v.node) + pos(in_index[(size_t)i]) + F(", %d, r%d);\n", SZ, v.a); break;
 			case OP_DELAYOUT:
 				if (tap_mode == 1) d = F("\t\ttf%d = ", i);
@@ -449,7 +449,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 				auto is_tap = [&](int i) { return V[(size_t)i].code == OP_DELAYOUT || V[(size_t)i].code == OP_DELAYTAP; };
 				for (int i = 0; i < NV; i++) if (in_block(i, pf, lv, wave)) { here.push_back(i); if (is_tap(i)) any_tap = true; }
 				if (any_tap) {
-					const int BATCH = []() { const char* e = getenv("KLG_FX_STAGED_BATCH"); const int b = e ? atoi(e) : 0; return b >= 2 ? b : 6; }();
+					const int BATCH = []() { const char* e = getenv("KLG_FX_STAGED_BATCH"); const int b = e ? atoi(e) : 0; return b >= 2 ? b : 8; }();
 					std::vector<char> inblk((size_t)NV, 0), done((size_t)NV, 0);
 					for (int i : here) inblk[(size_t)i] = 1;
 					auto ready = [&](int i) {
