@@ -23,6 +23,7 @@ python $R/tools/pingpong_dials_bench.py 4096 > $O/pingpong_dials.jsonl 2>&1
 ( python $R/tools/staged_stamp.py pingpong 4096 2>&1 | grep stamps | tail -1; KLG_FX_STAGED_PIPE=0 python $R/tools/staged_stamp.py pingpong 4096 2>&1 | grep stamps | tail -1; python $R/tools/staged_stamp.py reverb 4096 2>&1 | grep stamps | tail -1 ) > $O/staged_stamps.txt
 ( cd $R && python -m pytest tests/test_gpu_fx_staged.py -m gpu -q -s -k which_example 2>&1 | grep -E "staged:|one lane per instance:|passed|failed" ) > $O/staged_forms.txt
 python $R/tools/bench_all.py --cpu-budget 2 > $O/bench_all.json 2> $O/bench_all.err
+python $R/tools/staged_examples_bench.py 4096 65536 2>&1 | grep -v amdgpu.ids > $O/staged_examples.jsonl
 SQ1=SQ_WAVES,SQ_WAVE_CYCLES,SQ_BUSY_CYCLES,SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_INSTS_VMEM_RD,SQ_INSTS_VMEM_WR
 SQ2=SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_LDS,SQ_WAIT_INST_ANY,SQ_WAIT_ANY,SQ_ACTIVE_INST_ANY,SQ_WAIT_INST_LDS,SQ_ACTIVE_INST_SCA,SQ_LDS_BANK_CONFLICT
 # the staged kernels of the two recorded config-4 effects, and the hand-written ones as they run now (PingPong: 64-block spans)
