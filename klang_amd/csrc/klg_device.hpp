@@ -421,25 +421,43 @@ __device__ __forceinline__ void biquad_lpf_set(Biquad& q, BiquadSweep& c, float 
 // ---- Filters::OnePole klang.h:5470-5543 ----
 // The same for every Filters::Biquad type but the APF (its init() uses a double cos): TYPE as in host_dsl.hpp
 // (0 LPF, 1 HPF, 2 BPF constant peak, 3 BPF constant skirt, 4 BRF, 6 Butterworth::LPF<2>); klang.h:5658-5739, 5801-5811.
+// set(f, Q) in two halves — what it computes from (f, Q) alone, and what it does to the filter — so that the staged effect kernel (klg_graph_staged.hpp)
+// can take the cosine, the sine and the divisions of every sample of a chunk side by side and leave only the comparison with the cached (f, Q) and the five
+// assignments in the filter's sample-ordered loop.  biquad_set is apply(coefs()): the same operations in the same order either way.
+struct BiquadCoefs { float b0, b1, b2, a1, a2; };
+__device__ __forceinline__ float biquad_q(float f, float Q) { return Q < 0 ? f / -Q : Q; }            // what set() caches beside f (klang.h:5585)
+template<int TYPE> __device__ __forceinline__ BiquadCoefs biquad_coefs(float f, float Q /* biquad_q(f, Q) */, float fs_w) {
+	BiquadCoefs q;
+	const float w = f * fs_w;
+	const float cos0 = glibc_cosf(w);
+	const float sin0 = glibc_sinf(w);
+	if (Q < 0.5f) Q = 0.5f;
+	const float a = sin0 / (2.f * Q);
+	const double a0 = (double)(1.f + a);
+	const float inv = (a0 == 0.0) ? 0.0f : (float)(1.0 / a0);
+	q.a1 = inv * (-2.f * cos0);
+	q.a2 = inv * (1.f - a);
+	if (TYPE == 0) { q.b2 = q.b0 = inv * (1.f - cos0) * 0.5f; q.b1 = inv * (1.f - cos0); }
+	else if (TYPE == 1) { q.b2 = q.b0 = inv * (1.f + cos0) * 0.5f; q.b1 = inv * -(1.f + cos0); }
+	else if (TYPE == 2) { q.b0 = inv * a; q.b1 = 0.f; q.b2 = inv * -a; }
+	else if (TYPE == 3) { q.b0 = inv * sin0 * 0.5f; q.b1 = 0.f; q.b2 = -q.b0; }
+	else if (TYPE == 4) { q.b1 = q.a1; q.b0 = q.b2 = inv; }
+	else { q.b0 = inv * ((1.f - cos0) / 2.f); q.b1 = inv * (1.f - cos0); q.b2 = inv * ((1.f - cos0) / 2.f); }
+	return q;
+}
+template<int TYPE, int K> __device__ __forceinline__ float biquad_coef(float f, float Q, float fs_w) {  // one of them (the calls of a sample stand side by side: the compiler shares the rest)
+	const BiquadCoefs q = biquad_coefs<TYPE>(f, Q, fs_w);
+	return K == 0 ? q.b0 : K == 1 ? q.b1 : K == 2 ? q.b2 : K == 3 ? q.a1 : q.a2;
+}
+__device__ __forceinline__ void biquad_apply(Biquad& q, BiquadSweep& c, float f, float Q /* biquad_q */, float b0, float b1, float b2, float a1, float a2) {
+	if (c.f != f || c.Q != Q) { c.f = f; c.Q = Q; q.b0 = b0; q.b1 = b1; q.b2 = b2; q.a1 = a1; q.a2 = a2; }
+}
 template<int TYPE> __device__ __forceinline__ void biquad_set(Biquad& q, BiquadSweep& c, float f, float Q, float fs_w) {
-	if (Q < 0) Q = f / -Q;
+	Q = biquad_q(f, Q);
 	if (c.f != f || c.Q != Q) {
+		const BiquadCoefs k = biquad_coefs<TYPE>(f, Q, fs_w);
 		c.f = f; c.Q = Q;
-		const float w = f * fs_w;
-		const float cos0 = glibc_cosf(w);
-		const float sin0 = glibc_sinf(w);
-		if (Q < 0.5f) Q = 0.5f;
-		const float a = sin0 / (2.f * Q);
-		const double a0 = (double)(1.f + a);
-		const float inv = (a0 == 0.0) ? 0.0f : (float)(1.0 / a0);
-		q.a1 = inv * (-2.f * cos0);
-		q.a2 = inv * (1.f - a);
-		if (TYPE == 0) { q.b2 = q.b0 = inv * (1.f - cos0) * 0.5f; q.b1 = inv * (1.f - cos0); }
-		else if (TYPE == 1) { q.b2 = q.b0 = inv * (1.f + cos0) * 0.5f; q.b1 = inv * -(1.f + cos0); }
-		else if (TYPE == 2) { q.b0 = inv * a; q.b1 = 0.f; q.b2 = inv * -a; }
-		else if (TYPE == 3) { q.b0 = inv * sin0 * 0.5f; q.b1 = 0.f; q.b2 = -q.b0; }
-		else if (TYPE == 4) { q.b1 = q.a1; q.b0 = q.b2 = inv; }
-		else { q.b0 = inv * ((1.f - cos0) / 2.f); q.b1 = inv * (1.f - cos0); q.b2 = inv * ((1.f - cos0) / 2.f); }
+		q.b0 = k.b0; q.b1 = k.b1; q.b2 = k.b2; q.a1 = k.a1; q.a2 = k.a2;
 	}
 }
 struct OnePole { float b0, b1, a1, z, out; };

@@ -52,15 +52,36 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 	if (N - first < 1) return refuse("no sample ops");
 
 	// ---- virtual ops: the sample ops, with Basic::Sine's process() split into its phase walk (state) and the sine of the argument (pure) ----
-	enum { V_OSCARG = OP_CODES + 1, V_OSCEVAL };
-	struct VOp { int code, dst, a, b, node; uint32_t imm; int orig; std::vector<std::pair<int, int>> path; int parent_if = -1; };   // path: (vop index of the `if`, side 0 then / 1 else), outermost first
+	// ... and a biquad's set(f, Q) into what it computes from (f, Q) alone — the cached Q, five coefficients: pure, V_LPFQ / V_LPFCOEF — and what it does to the
+	// filter (V_LPFAPPLY: compare with the cached pair, assign): a cutoff swept per sample (WahWah.k) leaves its cosf / sinf / divisions out of the filter's loop
+	enum { V_OSCARG = OP_CODES + 1, V_OSCEVAL, V_LPFQ, V_LPFCOEF, V_LPFAPPLY };
+	struct VOp { int code, dst, a, b, node; uint32_t imm; int orig; std::vector<std::pair<int, int>> path; int parent_if = -1; std::vector<int> x; };   // x: further operands (V_LPFAPPLY: the five coefficients)   // path: (vop index of the `if`, side 0 then / 1 else), outermost first
 	std::vector<VOp> V;
 	int maxreg = -1;
 	for (const Op& o : g.ops) maxreg = std::max(maxreg, std::max(o.dst, std::max(o.a, o.b)));
-	std::vector<char> is_dbl((size_t)maxreg + 2 + (size_t)N, 0);
+	std::vector<char> is_dbl((size_t)maxreg + 2 + 8 * (size_t)N, 0);
 	for (const Op& o : g.ops) if (o.code == OP_F2D || o.code == OP_DCONST || o.code == OP_DLOW || (o.code >= OP_DADD && o.code <= OP_DDIV)) is_dbl[(size_t)o.dst] = 1;
 	std::vector<bool> written(g.nodes.size(), false);
 	for (int i = first; i < N; i++) if (g.ops[(size_t)i].code == OP_SETPARAM) written[(size_t)g.ops[(size_t)i].node] = true;
+	// (which registers are block invariants, on the recorded ops: a set(f, Q) of dials only stays one op — its test against the cached pair is all a sample costs)
+	std::vector<char> reg_inv((size_t)maxreg + 2, 0);
+	{
+		int depth = 0;
+		auto ri = [&](int r) { return r >= 0 && reg_inv[(size_t)r] != 0; };
+		for (int i = first; i < N; i++) {
+			const Op& o = g.ops[(size_t)i];
+			if (o.code == OP_IF) depth++; else if (o.code == OP_ENDIF) depth--;
+			if (o.dst < 0) continue;
+			switch (o.code) {
+			case OP_CONST: case OP_DCONST: reg_inv[(size_t)o.dst] = 1; break;
+			case OP_CTL: reg_inv[(size_t)o.dst] = in.ctlvar[o.imm & 7u] < 0; break;
+			case OP_PARAM: reg_inv[(size_t)o.dst] = !written[(size_t)o.node]; break;
+			case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_CMP: case OP_DADD: case OP_DSUB: case OP_DMUL: case OP_DDIV: reg_inv[(size_t)o.dst] = depth == 0 && ri(o.a) && ri(o.b); break;
+			case OP_NEG: case OP_ABS: case OP_F2D: case OP_D2F: case OP_DLOW: reg_inv[(size_t)o.dst] = depth == 0 && ri(o.a); break;
+			default: break;
+			}
+		}
+	}
 	{
 		std::vector<std::pair<int, int>> path;
 		for (int i = first; i < N; i++) {
@@ -73,6 +94,13 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			if (o.code == OP_OSC && o.node >= 0 && g.nodes[(size_t)o.node] == N_BSINE) {
 				VOp arg = v; arg.code = V_OSCARG; arg.dst = ++maxreg; V.push_back(arg);
 				v.code = V_OSCEVAL; v.a = arg.dst; v.node = -1; V.push_back(v);
+				continue;
+			}
+			if (o.code == OP_LPFSET && o.node >= 0 && !(o.a >= 0 && o.b >= 0 && reg_inv[(size_t)o.a] && reg_inv[(size_t)o.b])) {
+				VOp q = v; q.code = V_LPFQ; q.node = -1; q.dst = ++maxreg; V.push_back(q);
+				VOp ap = v; ap.code = V_LPFAPPLY; ap.b = q.dst; ap.dst = -1;
+				for (int k = 0; k < 5; k++) { VOp c = v; c.code = V_LPFCOEF; c.node = -1; c.b = q.dst; c.dst = ++maxreg; c.imm = o.imm | ((uint32_t)k << 8); V.push_back(c); ap.x.push_back(c.dst); }
+				V.push_back(ap);
 				continue;
 			}
 			V.push_back(v);
@@ -127,6 +155,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		case OP_PARAM: inv[(size_t)i] = !written[(size_t)v.node]; break;
 		case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_CMP: case OP_DADD: case OP_DSUB: case OP_DMUL: case OP_DDIV: inv[(size_t)i] = v.path.empty() && opinv(v.a) && opinv(v.b); break;
 		case OP_NEG: case OP_ABS: case OP_F2D: case OP_D2F: case OP_DLOW: inv[(size_t)i] = v.path.empty() && opinv(v.a); break;
+		case V_LPFQ: case V_LPFCOEF: inv[(size_t)i] = v.path.empty() && opinv(v.a) && opinv(v.b); break;   // (dials only: once per chunk by whoever needs them)
 		}
 	}
 
@@ -134,7 +163,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 	auto nodes_of = [&](const VOp& v, int out[2]) {
 		int n = 0;
 		switch (v.code) {
-		case OP_OSC: case V_OSCARG: case OP_OSCSET: case OP_FREQ: case OP_LPF: case OP_LPFSET: case OP_ENV: case OP_OPERATOR: case OP_SETCTL: out[n++] = v.node; break;
+		case OP_OSC: case V_OSCARG: case OP_OSCSET: case OP_FREQ: case OP_LPF: case OP_LPFSET: case V_LPFAPPLY: case OP_ENV: case OP_OPERATOR: case OP_SETCTL: out[n++] = v.node; break;
 		case OP_SMOOTH: out[n++] = v.node; if (in.ctlvar[v.imm & 7u] >= 0) out[n++] = in.ctlvar[v.imm & 7u]; break;
 		case OP_CTL: if (in.ctlvar[v.imm & 7u] >= 0) out[n++] = in.ctlvar[v.imm & 7u]; break;
 		case OP_PARAM: case OP_SETPARAM: if (written[(size_t)v.node]) out[n++] = v.node; break;
@@ -154,6 +183,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		if (v.code == OP_OPERATOR) { ua = v.a >= 0; ub = v.b >= 0; }
 		if (ua) edge(def(v.a), i);
 		if (ub) edge(def(v.b), i);
+		for (int r : v.x) edge(def(r), i);
 		for (const auto& pe : v.path) edge(def(V[(size_t)pe.first].a), i);                     // control: the conditions of every enclosing branch
 		if (v.code == OP_PHI && phi_if[(size_t)i] >= 0) edge(def(V[(size_t)phi_if[(size_t)i]].a), i);
 		if (v.code == OP_DELAYOUT && set_at[(size_t)v.node] >= 0) edge(set_at[(size_t)v.node], i);   // the head this process() walks
@@ -335,6 +365,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			const bool s = ser_of(i), pf = pfx[(size_t)i] != 0; const int lv = level[(size_t)i], w = s ? wave_of_op(i) : -1;
 			if (v.a >= 0) use(v.a, pf, lv, s, w);
 			if (v.b >= 0) use(v.b, pf, lv, s, w);
+			for (int r : v.x) use(r, pf, lv, s, w);
 			for (const auto& pe : v.path) use(V[(size_t)pe.first].a, pf, lv, s, w);
 			if (v.code == OP_PHI && phi_if[(size_t)i] >= 0) use(V[(size_t)phi_if[(size_t)i]].a, pf, lv, s, w);
 		}
@@ -393,6 +424,9 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 				in.emit_op((size_t)v.orig, b, assign); break;
 			case V_OSCARG: b += d + F("basic_sine_arg(L.n%d);\n", v.node); break;
 			case V_OSCEVAL: b += d + F("basic_sine_of(r%d);\n", v.a); break;
+			case V_LPFQ: b += d + F("biquad_q(r%d, r%d);\n", v.a, v.b); break;
+			case V_LPFCOEF: b += d + F("biquad_coef<%u, %u>(r%d, r%d, c.fs.w);\n", v.imm & 0xffu, v.imm >> 8, v.a, v.b); break;
+			case V_LPFAPPLY: b += F("\t\tbiquad_apply(L.n%d, L.n%ds, r%d, r%d, r%d, r%d, r%d, r%d, r%d);\n", v.node, v.node, v.a, v.b, v.x[0], v.x[1], v.x[2], v.x[3], v.x[4]); break;
 			case OP_PHI: b += d + F("(r%d != 0.f) ? r%d : r%d;\n", V[(size_t)phi_if[(size_t)i]].a, v.a, v.b); break;
 			case OP_DELAYIN: b += "\t\t{ const RingS q = " + ring(v.node) + "; q.wr(" + pos(in_index[(size_t)i]) + F(", r%d); }\n", v.a); break;
 			case OP_DELAYSET: b += F("\t\td%dt = delay_set(", v.node) + pos(in_index[(size_t)i]) + F(", %d, r%d);\n", SZ, v.a); break;
@@ -457,6 +491,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 						bool ok = true;
 						auto rd = [&](int r) { const int j = (r >= 0 && (size_t)r < def_at.size()) ? def_at[(size_t)r] : -1; if (j >= 0 && inblk[(size_t)j] && !done[(size_t)j]) ok = false; };
 						rd(v.a); rd(v.b);
+						for (int r : v.x) rd(r);
 						for (const auto& pe : v.path) rd(V[(size_t)pe.first].a);
 						if (v.code == OP_PHI && phi_if[(size_t)i] >= 0) rd(V[(size_t)phi_if[(size_t)i]].a);
 						if (v.code == OP_DELAYOUT && v.node >= 0 && set_at[(size_t)v.node] >= 0) { const int sa = set_at[(size_t)v.node]; if (inblk[(size_t)sa] && !done[(size_t)sa]) ok = false; }   // (the head a process() walks is what set() left: d<n>t)
@@ -562,6 +597,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 				const VOp& v = V[(size_t)i];
 				if (!in_block(i, pf, lv, wave)) continue;
 				f(v.a); f(v.b);
+				for (int r : v.x) f(r);
 				for (const auto& pe : v.path) f(V[(size_t)pe.first].a);
 				if (v.code == OP_PHI) f(V[(size_t)phi_if[(size_t)i]].a);
 			}
@@ -583,7 +619,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			std::vector<char> need((size_t)NV, 0);
 			auto want = [&](int r) { const int d = (r >= 0 && (size_t)r < def_at.size()) ? def_at[(size_t)r] : -1; if (d >= 0 && inv[(size_t)d]) need[(size_t)d] = 1; };
 			for_reads(pf, lv, wave, want);
-			for (int i = NV - 1; i >= 0; i--) if (need[(size_t)i]) { want(V[(size_t)i].a); want(V[(size_t)i].b); }     // operands come earlier in program order
+			for (int i = NV - 1; i >= 0; i--) if (need[(size_t)i]) { want(V[(size_t)i].a); want(V[(size_t)i].b); for (int r : V[(size_t)i].x) want(r); }     // operands come earlier in program order
 			std::string t;
 			for (int i = 0; i < NV; i++) if (need[(size_t)i]) t += op_text(i, false);
 			return t;
