@@ -140,7 +140,7 @@ __device__ __forceinline__ int ring_walk(int p, int m, int size) {              
 // Every read comes in two halves — `_fetch` finds the rows, checks them and ISSUES the loads, `_finish` is the arithmetic on what they return — so that a
 // level of the staged kernel can issue all its taps' loads before it waits for the first of them (klg_graph_staged.hpp: one memory round trip per level
 // instead of one per tap).  The whole functions are finish(fetch()): the same operations in the same order either way.
-struct TapFetch { float a, b, c, d, f; bool pad; };
+struct TapFetch { float a, b, c, d, f; bool pad; float la, lb; bool na, nb; };   // la / lb, na / nb: a row the chunk itself has written by then, from the chunk's own copy (staged_tap_float_fetch_near)
 // a line of the staged kernel's ring tile: rows of `stride4` bytes from a wave-uniform base, this lane's column `col4` bytes into a row — 32-bit offsets
 // (a workgroup's tile is < 4 GB): one operation per address where a per-lane 64-bit pointer takes three
 struct RingS {
@@ -185,6 +185,26 @@ template<class RG> __device__ __forceinline__ TapFetch staged_tap_float_fetch(co
 	return t;
 }
 __device__ __forceinline__ float staged_tap_float_finish(const TapFetch& t) { return t.a + t.f * (t.b - t.a); }
+// A line whose input() takes the effect's `in` itself (`in >> delay; ... delay(t)`: Flanger, Chorus, ModDelay) needs no check at all.  What a tap may read of
+// this chunk is known before the chunk starts: row w0 + m holds sample m's input — the chunk's copy of `in`, `mine[m * ld]` —, visible to the tap of sample s
+// when m < `vis` (= s, + 1 when the input() stands before the tap in the sample); every other row is read from the ring, which holds what it held before the
+// chunk until the chunk's last level (also rows a LATER sample overwrites: the tap wants their old value).  One input() per sample.
+template<class RG> __device__ __forceinline__ TapFetch staged_tap_float_fetch_near(const RG& r, int position, float delay, int w0, int vis, const float* mine, int ld) {
+	float read = (float)(position - 1) - delay;
+	if (read < 0.f) read += r.size;
+	const int i = (int)read < 0 ? 0 : (int)read;
+	const float fraction = read - i;
+	const int j = (i + 1 >= r.size) ? i + 1 - r.size : i + 1;
+	int di = i - w0; di = di < 0 ? di + r.size : di;
+	int dj = j - w0; dj = dj < 0 ? dj + r.size : dj;
+	TapFetch t; t.c = t.d = 0.f; t.f = fraction; t.pad = false;
+	t.na = i < r.size && di < vis; t.nb = dj < vis;
+	t.a = r.rd(i); t.b = r.rd(j);
+	t.la = mine[(t.na ? di : 0) * ld]; t.lb = mine[(t.nb ? dj : 0) * ld];
+	return t;
+}
+__device__ __forceinline__ float staged_tap_float_finish_near(const TapFetch& t) { const float a = t.na ? t.la : t.a, b = t.nb ? t.lb : t.b; return a + t.f * (b - a); }
+template<class RG> __device__ __forceinline__ float staged_tap_float_near(const RG& r, int position, float delay, int w0, int vis, const float* mine, int ld) { return staged_tap_float_finish_near(staged_tap_float_fetch_near(r, position, delay, w0, vis, mine, ld)); }
 template<class RG> __device__ __forceinline__ float staged_tap_float(const RG& r, int position, float delay, RingWindow w, int& bad) { return staged_tap_float_finish(staged_tap_float_fetch(r, position, delay, w, bad)); }
 template<class RG> __device__ __forceinline__ TapFetch staged_tap_stereo_fetch(const RG& r, int position, float delay, RingWindow w, int& bad) {
 	float read = (float)(position - 1) - delay;

@@ -142,6 +142,20 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		if (v.code == OP_DELAYSET) { if (set_at[(size_t)v.node] >= 0 || outs[(size_t)v.node] > 0) return refuse("a Delay that is set() twice per sample, or after its process()"); set_at[(size_t)v.node] = i; }
 	}
 	for (size_t d = 0; d < NN; d++) if (g.nodes[d] == N_DELAY && (k_in[d] * in.C >= g.arg((int)d) || outs[d] * 1024 >= g.arg((int)d))) return refuse("a Delay shorter than a chunk's inputs");
+	// lines that take the effect's own input (`in >> delay`, one input() per sample): what a tap may read of its own chunk is the chunk's `in`, known up front —
+	// such a tap needs no check and never sends its chunk to the plain body (klg_delay.hpp staged_tap_float_fetch_near): near_ch[line] = the channel, or -1
+	std::vector<int> near_ch(NN, -1);
+	bool any_near = false;
+	{
+		const char* e = getenv("KLG_FX_STAGED_NEAR");
+		if (!(e && e[0] == '0')) for (int i = 0; i < NV; i++) {
+			const VOp& v = V[(size_t)i];
+			if (v.code != OP_DELAYIN || v.node < 0 || k_in[(size_t)v.node] != 1) continue;
+			const int d = (v.a >= 0 && (size_t)v.a < def_at.size()) ? def_at[(size_t)v.a] : -1;
+			if (d >= 0 && V[(size_t)d].code == OP_IN && V[(size_t)d].path.empty()) near_ch[(size_t)v.node] = (int)V[(size_t)d].imm;
+		}
+		for (int i = 0; i < NV; i++) { const VOp& v = V[(size_t)i]; if (v.code == OP_DELAYTAP && v.imm == 0u && v.node >= 0 && near_ch[(size_t)v.node] >= 0) any_near = true; }
+	}
 
 	// ---- block invariants: literals, dials, members process() only reads, and plain arithmetic on those outside any branch.  They belong to no level: whoever
 	// needs one computes it (a lane of a parallel level once per chunk, a serial loop in front of its samples) — nothing of them travels through LDS ----
@@ -388,7 +402,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			}
 			nslots = (int)free_after.size();
 		}
-		const long long lds_words = (long long)NW * G * (pipelined ? 3 : 1) + (long long)CH * C * G + (long long)(nslots + 2 * npslots) * C * G + 4;
+		const long long lds_words = (long long)NW * G * (pipelined ? 3 : 1) + (long long)CH * C * G * (any_near ? 2 : 1) + (long long)(nslots + 2 * npslots) * C * G + 4;   // (any_near: a second copy of the chunk's `in`)
 		const char* le = getenv("KLG_FX_STAGED_LDS");
 		const long long budget = le ? atoll(le) : 160 * 1024;                 // gfx950 grants a workgroup up to 160 KB; a plan that needs most of it (the recorded Reverb.k: 68 values x 32 samples x 16 instances) is one workgroup of 8 waves per CU — measured 0.61 against 0.83 ms at 4,096 instances, 2.5 against 4.4 ms at 16,384, with half the chunk
 		if (lds_words * 4 > budget) { if (in.C > 0 && !in.C_is_a_preference) return refuse("the requested chunk length does not fit the LDS budget"); continue; }
@@ -414,7 +428,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			std::string d = assign ? F("\t\tr%d = ", v.dst) : "\t\tconst " + ty(std::max(v.dst, 0)) + F(" r%d = ", v.dst);
 			if (tap_mode && (v.code == OP_DELAYOUT || v.code == OP_DELAYTAP)) {
 				const char* fn = v.code == OP_DELAYOUT ? "staged_process" : v.imm == 1u ? "staged_tap_int" : v.imm == 3u ? "staged_lagrange" : v.imm == 2u ? "staged_tap_stereo" : "staged_tap_float";
-				if (tap_mode == 2) return d + fn + F("_finish(tf%d);\n", i);
+				if (tap_mode == 2 && !(v.code == OP_DELAYTAP && v.imm == 0u && near_ch[(size_t)v.node] >= 0)) return d + fn + F("_finish(tf%d);\n", i);
 			}
 			const int SZ = v.node >= 0 ? g.arg(v.node) : 0;
 			auto pos = [&](int j) { return j ? F("ring_at(d%dp0, %d, %d)", v.node, j, SZ) : F("d%dp0", v.node); };
@@ -436,6 +450,13 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 				else b += d + (tap_mode == 1 ? "staged_process_fetch(" : "staged_process(") + ring(v.node) + F(", ring_walk(d%dh.position, ps * %d + %d, %d), d%dh.fraction, d%dw, bad);\n", v.node, outs[(size_t)v.node], out_index[(size_t)i], SZ, v.node, v.node);
 				break;
 			case OP_DELAYTAP:
+				if (v.imm == 0u && near_ch[(size_t)v.node] >= 0) {                      // a line fed by `in`: no check (see near_ch)
+					const std::string args = ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", r%d, d%dw.w0, ps + %d, incopy + (%d * C) * G + pg, G);\n", v.a, v.node, in_index[(size_t)i], near_ch[(size_t)v.node]);
+					if (tap_mode == 2) b += d + F("staged_tap_float_finish_near(tf%d);\n", i);
+					else if (tap_mode == 1) b += F("\t\ttf%d = staged_tap_float_fetch_near(", i) + args;
+					else b += d + "staged_tap_float_near(" + args;
+					break;
+				}
 				if (tap_mode == 1) d = F("\t\ttf%d = ", i);
 				if (v.imm == 1u) b += d + (tap_mode == 1 ? "staged_tap_int_fetch(" : "staged_tap_int(") + ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", (int)r%d, d%dw, bad);\n", v.a, v.node);
 				else b += d + std::string(v.imm == 3u ? "staged_lagrange" : v.imm == 2u ? "staged_tap_stereo" : "staged_tap_float") + (tap_mode == 1 ? "_fetch(" : "(") + ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", r%d, d%dw, bad);\n", v.a, v.node);
@@ -730,7 +751,8 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += F("\tfloat* const tile = lds + NW * G * %d;                                    // [CH][C][G]: the caller's block, chunk by chunk\n", pipelined ? 3 : 1);
 		s += "\tfloat* const slots = tile + CH * C * G;                                   // [slots][C][G]: values that cross levels\n";
 		s += F("\tfloat* const pslots = slots + %d * C * G;                                 // [slots][2][C][G]: those of the control path, by the parity of their chunk\n", nslots);
-		s += F("\tint* const flag = reinterpret_cast<int*>(pslots + %d * C * G);\n", 2 * npslots);
+		s += F("\tfloat* const incopy = pslots + %d * C * G;                                  // [CH][C][G]: the chunk's `in` as it came (the tile is overwritten by the outputs)%s\n", 2 * npslots, any_near ? "" : " — unused");
+		s += F("\tint* const flag = reinterpret_cast<int*>(incopy + %d);\n\t(void)incopy;\n", any_near ? CH * C * G : 0);
 		s += "#define SL(k) (slots + (k) * (C * G))\n#define SLP(k, par) (pslots + ((k) * 2 + (par)) * (C * G))\n";
 		s += "\tconst int t = threadIdx.x, tp = t < NTP ? t : 0, ps = tp / G, pg = tp % G, wv = t >> 6, sw = wv - SW0, ln = t & 63, k0 = blockIdx.x * G;   // sw: which wave of the serial levels\n";
 		s += "\tconst int sg = ln < G ? ln : 0;                                           // the instance a lane of a serial level works for\n";
@@ -794,7 +816,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		// Reverb.k's kernel held ~500 of them in scratch (3.7 KB per lane; 1,123 spilled registers) and moved 5 x its algorithmic bytes
 		s += "\t\tint tv = threadIdx.x; asm volatile(\"\" : \"+v\"(tv));\n";
 		s += "\t\tconst int t = tv, tp = t < NTP ? t : 0, ps = tp / G, pg = tp % G, wv = t >> 6, sw = wv - SW0, ln = t & 63; (void)ps; (void)pg; (void)sw; (void)ln; (void)wv;\n";
-		s += "#pragma unroll\n\t\tfor (int j = 0; j < CH; j++) { const int i = tp + j * NTP, row = i / C, q = i % C, gi = row / CH, ch = row % CH; if (t < NTP) tile[(ch * C + q) * G + gi] = nx[j]; }\n";
+		s += "#pragma unroll\n\t\tfor (int j = 0; j < CH; j++) { const int i = tp + j * NTP, row = i / C, q = i % C, gi = row / CH, ch = row % CH; if (t < NTP) { tile[(ch * C + q) * G + gi] = nx[j];" + std::string(any_near ? " incopy[(ch * C + q) * G + gi] = nx[j];" : "") + " } }\n";
 		s += "\t\tif (t == 0) *flag = 0;\n\t\t__syncthreads();\n";
 		s += "\t\tif (s0 + C < a.n) fetch(s0 + C);\n";
 		s += "\t\tbool ok = cl == C;\n\t\tint bad = 0; (void)bad;\n";

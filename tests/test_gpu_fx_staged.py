@@ -176,3 +176,46 @@ def test_staged_reverb_equals_one_lane_per_instance(monkeypatch):
         if bi >= 12: tail = max(tail, float(np.abs(a).max()))
     assert peak > 1e-2 and tail > 1e-5, f"peak {peak}, tail {tail}: the reflections (50 ms and later) should sound after the input has stopped"
     staged.close(); lane.close()
+
+
+@pytest.mark.parametrize("name", ["fx_flanger", "fx_topchorus"])
+def test_staged_taps_of_a_line_fed_by_in_may_sit_inside_their_own_chunk(name, tmp_path, monkeypatch, capfd):
+    """`in >> delay; ... delay(t)` with t swept down to zero (Flanger.k, the shipped Chorus.k): what such a tap reads of its own chunk is the chunk's `in`, taken from
+    the chunk's copy in LDS (staged_tap_float_fetch_near) — no ring check, no chunk handed to the plain body.  The staged form against one lane per instance,
+    70 instances with their own dials (delays from zero to tens of milliseconds), dials moved mid-run, ragged and one-sample blocks; and once more with the
+    path switched off (KLG_FX_STAGED_NEAR=0: the same chunks fail their check and are walked by the plain body)."""
+    monkeypatch.setenv("KLANG_MI355_FORCE_GRAPH", "1"); monkeypatch.setenv("KLANG_MI355_DUMP_GRAPH", "1")
+    capfd.readouterr()
+    run_effect(name, tmp_path)
+    err = capfd.readouterr().err
+    m = re.search(r"^klgg 1\n.*?^end\n", err, re.S | re.M)
+    assert m, "no program in the facade's dump"
+    prog = m.group(0)
+    r = re.search(r"initial record:((?: [0-9a-f]{8})+)", err)
+    rec = np.array([int(w, 16) for w in r.group(1).split()], np.uint32) if r else None
+    ch = 2 if "kind effect 2" in prog else 1
+    dials = [tuple(float(x) for x in ln.split()[2:5]) for ln in prog.splitlines() if ln.startswith("dial ")]
+    K = 70
+    banks = []
+    for staged, near in (("1", "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("KLG_FX_STAGED", staged); monkeypatch.setenv("KLG_FX_STAGED_NEAR", near)
+        banks.append(klang_amd.FxBank(prog, K, max_block=256, initial_record=rec, channels=ch))
+    assert banks[0].graph_form()["staged"] and banks[1].graph_form()["staged"] and not banks[2].graph_form()["staged"]
+    rng = np.random.default_rng(17)
+    def move(ks):
+        for k in ks:
+            for c, (lo, hi, _) in enumerate(dials):
+                v = float(lo + (hi - lo) * rng.uniform(0.0, 1.0) ** 2)                  # (squared: many small delays / depths)
+                for b in banks: b.set_control(int(k), c, v)
+    move(range(K))
+    peak = 0.0
+    for bi, n in enumerate([256, 37, 1, 100, 256, 33, 256, 250, 7, 256, 256, 31, 256, 256]):
+        if bi in (4, 9): move(rng.choice(K, 20, replace=False))
+        x = ((rng.random((K, ch, n), dtype=np.float32) - 0.5) * (1.0 if bi < 11 else 0.0)).astype(np.float32)
+        outs = [b.process(x.copy()) for b in banks]
+        for what, o in zip(("with the chunk's own copy", "with the path switched off"), outs[:2]):
+            bad = np.argwhere(bits(o) != bits(outs[2]))
+            assert len(bad) == 0, f"block {bi} (n = {n}): staged {what} differs from one lane per instance in {len(bad)} samples, first {bad[0]}"
+        peak = max(peak, float(np.abs(outs[0]).max()))
+    assert peak > 1e-2
+    for b in banks: b.close()
