@@ -56,8 +56,8 @@ FX["fx_topreverb"] = [(0.0, 1.0), (0.0, 1.0), (0.0, 1.0), (0.0, 1.0), (0.3, 1.0)
 FX["fx_topchorus"] = [(0.2, 1.0), (0.05, 1.5), (0.1, 0.5), (1.0, 5.5), (0.1, 0.5), (2.0, 20.0)]
 # tests/patches/fx_tape.k (OUR OWN effect): Delay::set in prepare() places the read head once per block, `signal echo = tape` walks it
 FX["fx_owntape"] = [(0.003, 0.04), (0.0, 0.9), (400.0, 6000.0)]
-# tests/patches/fx_fdn.k (OUR OWN effect): four user Modifiers (Delay + LPF + gain), signals<4> >> Matrix, the rows fed back — Reverb.k's LateReflections' shape
-FX["fx_ownfdn"] = [(0.5, 3.0), (800.0, 10000.0), (0.05, 0.42), (0.2, 1.0)]
+# tests/patches/fx_fdn.k (OUR OWN effect): four user Modifiers (drive, Delay, HPF), signals<4> >> a Hadamard Matrix, the rows fed back, every Modifier processed twice per sample
+FX["fx_ownfdn"] = [(0.5, 3.0), (20.0, 900.0), (0.02, 0.24), (0.2, 1.0)]
 # Delay/Reverb2.k: a tap time computed in DOUBLE from a control — `(controls[1] + 0.01232 * c) * fs` is float + double, double * float, then tap((float)x) — recorded as
 # double registers (f2d / dconst / dlow / dadd / dmul / d2f); two Delay<192000> per channel, eight constant taps, a damping LPF set in prepare().  (Added last: the
 # scenarios above keep their random draws.)

@@ -119,10 +119,10 @@ def test_own_effect_places_its_read_head_in_prepare_and_walks_it(tmp_path):
 
 
 def test_own_fdn_effect_with_user_modifiers_signals4_and_matrix(tmp_path):
-    """tests/patches/fx_fdn.k (ours): the shape of the shipped Reverb.k's LateReflections (Reverb.k:117-169) as a recorded effect — four user
-    Modifiers (Delay<9600> + LPF + gain) read into a `signals<4>`, `delays >> matrix` (klang.h:1446-1470: rows of products summed left to right),
-    `+ in`, every row fed back into its delay and the delays processed a second time by the `+` chain; the delay times and the damping follow
-    dials in prepare() (the per-block prologue).  Nine instances, dials changed mid-run, bit for bit against the genuine header."""
+    """tests/patches/fx_fdn.k (ours): a four-line feedback network of user Modifiers as a recorded effect — each `Tank` is `in * drive >> line >> damp`
+    (a Delay<7200> and an HPF), the four read into a `signals<4>`, `taps >> mix` with a Hadamard Matrix (klang.h:1446-1470: rows of products summed left
+    to right), `+ in`, every row sent back into its tank — which the `+` chain processes a second time in the same sample; delay times, corner and
+    drive follow dials in prepare() (the per-block prologue).  Nine instances, dials changed mid-run, bit for bit against the genuine header."""
     got, ref = run_effect("fx_ownfdn", tmp_path, own=True)
     exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
     print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e}")
