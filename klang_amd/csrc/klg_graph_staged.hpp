@@ -335,7 +335,18 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		const bool own_waves = pipelined && NSW >= 1;
 		const int NT = own_waves ? NTP + 64 * NSW : NTP, NWV = own_waves ? NSW : NTP / 64;
 		// strands of a level -> serial waves, heaviest first onto the lightest wave; where both groups have loops in one interval the audio path takes the lower half
+		auto ser_of_comp = [&](int c) { return c >= 0 && cserial[(size_t)c] != 0; };
+		auto F = [](const char* f, ...) { char b[1024]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return std::string(b); };
 		std::vector<int> wave_of((size_t)ncomp, 0);
+		// PACKS.  A serial loop runs on G of a wave's 64 lanes, and an instruction costs its four cycles whatever the lanes: strands of one level that are the SAME
+		// code on different nodes (Reverb.k's sixteen damping filters, Chorus.k's ten LFOs, an equaliser's bands) run as ONE loop with 64 / G of them side by side
+		// in the lanes — lane = (strand of the pack, instance) —: the text is the first strand's, what differs (the nodes' record words, the LDS slots of what
+		// comes in and goes out) is chosen by the lane's quarter.  A strand qualifies when it has no branch, no invariant operand, and nothing per-instance but
+		// its nodes (no control, no Noise).  op_sub: -1 a strand on its own, p >= 0 the first strand of pack p (what is emitted), -2 the others.
+		struct Pack { int lv = 0; bool pf = false; int wave = 0; std::vector<std::vector<int>> ops; };
+		std::vector<Pack> packs;
+		std::vector<int> op_sub((size_t)NV, -1);
+		const int QPACK = []() { const char* e = getenv("KLG_FX_STAGED_PACK"); return !(e && e[0] == '0'); }() ? 64 / G : 1;
 		for (int lv = 1; lv <= std::max(max_level, pmax); lv += 2) {
 			for (int grp = 0; grp < 2; grp++) {
 				bool mine = false, other = false;                                      // the other group's serial level of the same interval
@@ -346,10 +357,60 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 				const int w0 = (split && grp == 1) ? NWV / 2 : 0, w1 = (split && grp == 0) ? NWV / 2 : NWV;
 				std::map<int, int> weight;
 				for (int c = 0; c < ncomp; c++) if (cserial[(size_t)c] && clevel[(size_t)c] == lv && (cpfx(c, members) ? 1 : 0) == grp) weight[strand[(size_t)c]] += csize[(size_t)c];
-				std::vector<std::pair<int, int>> order; for (const auto& kv : weight) order.push_back({ kv.second, kv.first });
+				// packs of this (level, group): strands with the same signature, 64 / G at a time
+				std::map<int, int> unit_of;                                            // strand -> the strand whose wave it shares (its pack's first)
+				std::vector<size_t> new_packs;
+				if (QPACK >= 2) {
+					std::map<int, std::vector<int>> sops;
+					for (int i = 0; i < NV; i++) { const int c = comp[(size_t)i]; if (c >= 0 && cserial[(size_t)c] && clevel[(size_t)c] == lv && (cpfx(c, members) ? 1 : 0) == grp && !is_struct(V[(size_t)i].code) && !inv[(size_t)i]) sops[strand[(size_t)c]].push_back(i); }
+					std::map<std::string, std::vector<int>> by_sig;
+					for (const auto& kv : sops) {
+						const std::vector<int>& ops = kv.second;
+						std::map<int, int> posof; for (size_t q = 0; q < ops.size(); q++) posof[ops[q]] = (int)q;
+						std::string sig; bool ok = true;
+						for (int i : ops) {
+							const VOp& v = V[(size_t)i];
+							switch (v.code) {
+							case OP_OSC: case V_OSCARG: case OP_OSCSET: case OP_LPF: case V_LPFAPPLY: case OP_ENV: case OP_OPERATOR: case OP_PARAM: case OP_SETPARAM: case OP_FREQ:
+							case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_NEG: case OP_ABS: case OP_CMP: break;
+							default: ok = false;
+							}
+							if (!v.path.empty()) ok = false;
+							if (!ok) break;
+							sig += F("|%d,%u,%d,%d,%d", v.code, v.imm, v.node >= 0 ? g.nodes[(size_t)v.node] : -1, v.node >= 0 ? g.arg(v.node) : 0, v.dst >= 0 ? 1 : 0);
+							std::vector<int> rs = { v.a, v.b }; rs.insert(rs.end(), v.x.begin(), v.x.end());
+							for (int r : rs) {
+								if (r < 0) { sig += ",-"; continue; }
+								const int d = (size_t)r < def_at.size() ? def_at[(size_t)r] : -1;
+								if (d < 0 || inv[(size_t)d] || is_dbl[(size_t)r]) { ok = false; break; }
+								const auto it = posof.find(d);
+								if (it != posof.end()) sig += F(",i%d", it->second);
+								else sig += F(",e%d%d", pfx[(size_t)d] ? 1 : 0, ser_of_comp(comp[(size_t)d]) ? 1 : 0);
+							}
+						}
+						if (ok && !ops.empty()) by_sig[sig].push_back(kv.first);
+					}
+					for (const auto& kv : by_sig) {
+						const std::vector<int>& st = kv.second;
+						for (size_t b0 = 0; b0 + 1 < st.size(); b0 += (size_t)QPACK) {
+							const size_t n = std::min((size_t)QPACK, st.size() - b0);
+							if (n < 2) break;
+							Pack pk; pk.lv = lv; pk.pf = grp != 0;
+							for (size_t q = 0; q < n; q++) { pk.ops.push_back(sops[st[b0 + q]]); unit_of[st[b0 + q]] = st[b0]; }
+							new_packs.push_back(packs.size()); packs.push_back(pk);
+						}
+					}
+				}
+				std::vector<std::pair<int, int>> order; for (const auto& kv : weight) { const auto u = unit_of.find(kv.first); if (u == unit_of.end() || u->second == kv.first) order.push_back({ kv.second, kv.first }); }
 				std::sort(order.begin(), order.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
 				std::vector<int> load((size_t)NWV, 0); std::map<int, int> wave_of_strand;
 				for (const auto& o : order) { int best = w0; for (int w = w0 + 1; w < w1; w++) if (load[(size_t)w] < load[(size_t)best]) best = w; load[(size_t)best] += o.first; wave_of_strand[o.second] = best; }
+				for (const auto& u : unit_of) wave_of_strand[u.first] = wave_of_strand[u.second];
+				for (size_t pi : new_packs) {
+					Pack& pk = packs[pi];
+					pk.wave = wave_of_strand[strand[(size_t)comp[(size_t)pk.ops[0][0]]]];
+					for (size_t q = 0; q < pk.ops.size(); q++) for (int i : pk.ops[q]) op_sub[(size_t)i] = q == 0 ? (int)pi : -2;
+				}
 				for (int c = 0; c < ncomp; c++) if (cserial[(size_t)c] && clevel[(size_t)c] == lv && (cpfx(c, members) ? 1 : 0) == grp) wave_of[(size_t)c] = wave_of_strand[strand[(size_t)c]];
 			}
 		}
@@ -357,7 +418,8 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		auto wave_of_op = [&](int i) { return comp[(size_t)i] >= 0 ? wave_of[(size_t)comp[(size_t)i]] : -1; };
 		auto live_op = [&](int i) { return !is_struct(V[(size_t)i].code) && !inv[(size_t)i] && comp[(size_t)i] >= 0; };
 		// is op i one of (group, level, wave)?  wave -1: the parallel ops of the level
-		auto in_block = [&](int i, bool pf, int lv, int wave) { return live_op(i) && (pfx[(size_t)i] != 0) == pf && level[(size_t)i] == lv && ((wave >= 0) == ser_of(i)) && (wave < 0 || wave_of_op(i) == wave); };
+		int cur_sub = -1;                                                          // which serial ops a block is being generated for: -1 the strands on their own, p the pack p (its first strand)
+		auto in_block = [&](int i, bool pf, int lv, int wave) { return live_op(i) && (pfx[(size_t)i] != 0) == pf && level[(size_t)i] == lv && ((wave >= 0) == ser_of(i)) && (wave < 0 || (wave_of_op(i) == wave && op_sub[(size_t)i] == cur_sub)); };
 		// ---- where each register lives ----
 		// chunk: a lane's own register across levels of its group; xrot: parallel prefix -> parallel suffix (computed an iteration ahead, handed over at the top of the
 		// loop); slot: through LDS — a prefix value in two buffers (the chunk's parity), a suffix value in a slot that is reused once it is dead
@@ -409,12 +471,13 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 
 		// =========================================================== source ===========================================================
 		std::string s;
-		auto F = [](const char* f, ...) { char b[1024]; va_list ap; va_start(ap, f); vsnprintf(b, sizeof b, f, ap); va_end(ap); return std::string(b); };
 		auto ring = [&](int node) { return F("RingS{ (const char*)(ring0 + (size_t)%lldll * %d), (unsigned)pg * 4u, %du, %d }", (*in.ring_off)[(size_t)node], G, G * 4, g.arg(node)); };   // rows of G instances: this workgroup's own (PatchGen::kRingRow); a wave-uniform base + 32-bit offsets (klg_delay.hpp RingS)
 		auto ty = [&](int r) { return std::string(is_dbl[(size_t)r] ? "double" : "float"); };
 		auto in_branch = [&](int i) { return !V[(size_t)i].path.empty(); };
 		// where a register's LDS copy is, for code of group `pf` (the prefix works on the NEXT chunk: the other parity)
+		std::map<int, std::string> slot_override;                                  // a pack's loop: the slot of (its first strand's) register r, by the lane's quarter
 		auto slot_ref = [&](int r, bool reader_pf) {
+			if (!slot_override.empty()) { const auto it = slot_override.find(r); if (it != slot_override.end()) return it->second; }
 			const Reg& R = regs[(size_t)r];
 			if (pfx[(size_t)R.def]) return F("SLP(%d, %s)", R.slot_id, reader_pf ? "parn" : "parc");
 			return F("SL(%d)", R.slot_id);
@@ -702,14 +765,62 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			}
 			else {
 				for (int w = 0; w < NWV; w++) {
+				std::vector<int> subs = { -1 };
+				for (size_t pi = 0; pi < packs.size(); pi++) if (packs[pi].lv == lv && packs[pi].pf == pf && packs[pi].wave == w) subs.push_back((int)pi);
+				for (int sub : subs) {
+					cur_sub = sub; slot_override.clear();
 					std::vector<int> mine;
 					for (int i = 0; i < NV; i++) if (in_block(i, pf, lv, w)) mine.push_back(i);
 					if (mine.empty()) continue;
+					const Pack* pk = sub >= 0 ? &packs[(size_t)sub] : nullptr;
+					const int K = pk ? (int)pk->ops.size() : 1;
+					const std::string li = pk ? "gi" : "ln";                               // the instance a lane works for
+					auto qsel = [&](const std::vector<long long>& v) {                      // a number by the lane's quarter
+						bool same = true; for (long long x : v) if (x != v[0]) same = false;
+						if (same) return F("%lld", v[0]);
+						std::string t = F("%lld", v.back());
+						for (size_t q = v.size() - 1; q-- > 0;) t = F("(qq == %zu ? %lld : ", q, v[q]) + t + ")";
+						return t;
+					};
 					std::vector<char> node_here(NN, 0);
 					for (int i : mine) { int ns[2]; const int n = nodes_of(V[(size_t)i], ns); for (int q = 0; q < n; q++) node_here[(size_t)ns[q]] = 1; }
-					std::string load, commit, loop, decl;
-					for (size_t nd = 0; nd < NN; nd++) if (node_here[nd]) { load += (*in.node_begin)[nd]; commit += (*in.node_end)[nd]; }
+					std::string load, commit, loop, decl, pack_decl;
+					if (pk) {
+						pack_decl += "\t\tconst int qq = ln / G, gi = ln - qq * G; (void)qq; (void)gi;\n";
+						// the corresponding nodes of the pack's other strands: by position in the op lists
+						std::vector<std::vector<long long>> w0s(NN);
+						for (size_t pos = 0; pos < pk->ops[0].size(); pos++) {
+							int n0[2]; const int c0 = nodes_of(V[(size_t)pk->ops[0][pos]], n0);
+							for (int q = 0; q < c0; q++) if (w0s[(size_t)n0[q]].empty()) for (int m = 0; m < K; m++) { int nm[2]; nodes_of(V[(size_t)pk->ops[(size_t)m][pos]], nm); w0s[(size_t)n0[q]].push_back((long long)g.node_word0(nm[q]) - (long long)g.node_word0(n0[q])); }
+						}
+						auto shifted = [&](std::string text, size_t nd) {                     // r.w[N] -> r.w[N + dw<nd>]
+							const std::string key = "r.w[";
+							for (size_t at = 0; (at = text.find(key, at)) != std::string::npos;) { const size_t e = text.find(']', at); text.insert(e, F(" + dw%zu", nd)); at = e; }
+							return text;
+						};
+						for (size_t nd = 0; nd < NN; nd++) if (node_here[nd]) { pack_decl += F("\t\tconst int dw%zu = ", nd) + qsel(w0s[nd]) + F("; (void)dw%zu;\n", nd); load += shifted((*in.node_begin)[nd], nd); commit += shifted((*in.node_end)[nd], nd); }
+					}
+					else for (size_t nd = 0; nd < NN; nd++) if (node_here[nd]) { load += (*in.node_begin)[nd]; commit += (*in.node_end)[nd]; }
 					std::vector<int> from_slot; inputs_of(pf, lv, w, from_slot);
+					if (pk) {
+						// the slots of what comes in and goes out, by quarter: the same operand / result of the same op in every strand of the pack
+						auto slots_of = [&](int r, size_t pos, int field /* 0 a, 1 b, 2.. x, -1 dst */) {
+							std::vector<long long> ids; bool dpf = false;
+							for (int m = 0; m < K; m++) {
+								const VOp& vm = V[(size_t)pk->ops[(size_t)m][pos]];
+								const int rm = field < 0 ? vm.dst : field == 0 ? vm.a : field == 1 ? vm.b : vm.x[(size_t)field - 2];
+								ids.push_back(regs[(size_t)rm].slot_id); dpf = pfx[(size_t)regs[(size_t)rm].def] != 0;
+							}
+							if (dpf) slot_override[r] = F("(pslots + ((%s) * 2 + %s) * (C * G))", qsel(ids).c_str(), pf ? "parn" : "parc");
+							else slot_override[r] = F("(slots + (%s) * (C * G))", qsel(ids).c_str());
+						};
+						for (size_t pos = 0; pos < pk->ops[0].size(); pos++) {
+							const VOp& v0 = V[(size_t)pk->ops[0][pos]];
+							std::vector<int> rs = { v0.a, v0.b }; rs.insert(rs.end(), v0.x.begin(), v0.x.end());
+							for (size_t f = 0; f < rs.size(); f++) if (rs[f] >= 0 && std::find(from_slot.begin(), from_slot.end(), rs[f]) != from_slot.end() && !slot_override.count(rs[f])) slots_of(rs[f], pos, (int)f);
+							if (v0.dst >= 0 && regs[(size_t)v0.dst].slot && def_at[(size_t)v0.dst] == pk->ops[0][pos]) slots_of(v0.dst, pos, -1);
+						}
+					}
 					std::vector<char> predecl(regs.size(), 0);
 					// the loop's inputs are fetched U samples at a time in front of the U samples that use them: one LDS round trip per batch instead of one (or more)
 					// in every sample of a chain nothing else overlaps (a power of two, so that it divides C; a long loop body — many components side by side —
@@ -717,20 +828,23 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 					int U = 8; while (U > 1 && U * (int)from_slot.size() > 64) U /= 2;
 					if (mine.size() > 48 || U > C) U = 1;
 					std::string fetch;
-					for (int r : from_slot) { fetch += F("\t\tfloat i%d[%d];\n#pragma unroll\n\t\tfor (int u = 0; u < %d; u++) i%d[u] = ", r, U, U, r) + slot_ref(r, pf) + "[(sb + u) * G + ln];\n"; decl += "\t\tconst " + ty(r) + F(" r%d = i%d[u];\n", r, r); }
+					for (int r : from_slot) { fetch += F("\t\tfloat i%d[%d];\n#pragma unroll\n\t\tfor (int u = 0; u < %d; u++) i%d[u] = ", r, U, U, r) + slot_ref(r, pf) + "[(sb + u) * G + " + li + "];\n"; decl += "\t\tconst " + ty(r) + F(" r%d = i%d[u];\n", r, r); }
 					for (int i : mine) if (V[(size_t)i].dst >= 0 && in_branch(i) && def_at[(size_t)V[(size_t)i].dst] == i) { const int r = V[(size_t)i].dst; predecl[(size_t)r] = 1; decl += "\t\t" + ty(r) + F(" r%d = 0; (void)r%d;\n", r, r); }
 					emit_ops(pf, lv, w, "q", loop, predecl);
-					if (first_pass) P.serial_ops += (int)mine.size();
+					if (first_pass) P.serial_ops += (int)mine.size() * K;
 					// the suffix works on the architectural records; the prefix on its own two copies: from the one its previous chunk left, into the other
 					const std::string from = pf ? "srecp + (parn ^ 1) * (NW * G)" : "srec", to = pf ? "srecp + parn * (NW * G)" : "srec";
-					code += F("\t\tif (%s && sw == %d && ln < G) { auto& L = Ls; const FxCtx& c = cs; (void)L; (void)c;\n\t\t{ const StagedRec r = { { %s + ln } }; (void)r;\n", cond, w, from.c_str()) + load + "\t\t}\n" + inv_prelude(pf, lv, w);
-					code += F("\t\tfor (int sb = 0; sb < C; sb += %d) {\n", U) + fetch + F("#pragma unroll\n\t\tfor (int u = 0; u < %d; u++) { const int q = (sb + u) * G + ln; (void)q;\n", U) + decl + loop + "\t\t}\n\t\t}\n";
-					const std::string cm = F("\t\t{ StagedRec r = { { %s + ln } }; (void)r;\n", to.c_str()) + commit + "\t\t}\n";
+					const std::string lanes = F("ln < %d", G * K);
+					code += F("\t\tif (%s && sw == %d && %s) { auto& L = Ls; const FxCtx& c = cs; (void)L; (void)c;\n", cond, w, lanes.c_str()) + pack_decl + F("\t\t{ const StagedRec r = { { %s + %s } }; (void)r;\n", from.c_str(), li.c_str()) + load + "\t\t}\n" + inv_prelude(pf, lv, w);
+					code += F("\t\tfor (int sb = 0; sb < C; sb += %d) {\n", U) + fetch + F("#pragma unroll\n\t\tfor (int u = 0; u < %d; u++) { const int q = (sb + u) * G + %s; (void)q;\n", U, li.c_str()) + decl + loop + "\t\t}\n\t\t}\n";
+					const std::string cm = F("\t\t{ StagedRec r = { { %s + %s } }; (void)r;\n", to.c_str(), li.c_str()) + commit + "\t\t}\n";
 					if (pf || lv > guard_level) code += cm + "\t\t}\n";
-					else { code += "\t\t}\n"; deferred.push_back(F("\t\tif (ok && sw == %d && ln < G) { auto& L = Ls; (void)L;\n", w) + cm + "\t\t}\n"); }
+					else { code += "\t\t}\n"; deferred.push_back(F("\t\tif (ok && sw == %d && %s) { auto& L = Ls; (void)L;\n", w, lanes.c_str()) + pack_decl + cm + "\t\t}\n"); }
 					if (pf && first_pass) {                                                // ... and, once its chunk is complete, from its copy to the architectural one
-						P.prefix_commit += F("\t\tif (ok && sw == %d && ln < G) { auto& L = Ls; (void)L;\n\t\t{ const StagedRec r = { { srecp + parc * (NW * G) + ln } }; (void)r;\n", w) + load + "\t\t}\n\t\t{ StagedRec r = { { srec + ln } }; (void)r;\n" + commit + "\t\t}\n\t\t}\n";
+						P.prefix_commit += F("\t\tif (ok && sw == %d && %s) { auto& L = Ls; (void)L;\n", w, lanes.c_str()) + pack_decl + F("\t\t{ const StagedRec r = { { srecp + parc * (NW * G) + %s } }; (void)r;\n", li.c_str()) + load + F("\t\t}\n\t\t{ StagedRec r = { { srec + %s } }; (void)r;\n", li.c_str()) + commit + "\t\t}\n\t\t}\n";
 					}
+				}
+				cur_sub = -1; slot_override.clear();
 				}
 			}
 			return code;

@@ -314,6 +314,15 @@ def test_the_recorded_config_4_effects_get_a_staged_form():
         assert rc == 0 and "klg_fx_staged" not in src
     finally:
         del os.environ["KLG_FX_STAGED"]
+    # Reverb.k's sixteen damping filters are the same code on different nodes: four of them side by side in a wave's lanes (lane = strand x instance), what differs by quarter
+    rc, src = check(open(os.path.join(ROOT, "tests", "golden", "reverb_recorded.klgg")).read(), want_source=True)
+    assert rc == 0 and "const int qq = ln / G, gi = ln - qq * G;" in src and "ln < 64) {" in src and "(qq == 0 ? 0 : (qq == 1 ? 13 : (qq == 2 ? 26 : 39)))" in src
+    os.environ["KLG_FX_STAGED_PACK"] = "0"
+    try:
+        rc, src = check(open(os.path.join(ROOT, "tests", "golden", "reverb_recorded.klgg")).read(), want_source=True)
+        assert rc == 0 and "const int qq = ln / G" not in src
+    finally:
+        del os.environ["KLG_FX_STAGED_PACK"]
     os.environ["KLG_FX_STAGED_BATCH"] = "0"
     try:
         rc, src = check(open(os.path.join(ROOT, "tests", "golden", "reverb_recorded.klgg")).read(), want_source=True)
