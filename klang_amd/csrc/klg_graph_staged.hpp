@@ -447,6 +447,12 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		}
 		use(g.ret, false, out_level, false, -1);
 		if (CH == 2) use(g.ret_r, false, out_level, false, -1);
+		// a pack's strands store the same results: where one strand's result crosses levels, every strand's does (a slot each; one nobody reads is written all the same)
+		for (const Pack& pk : packs) for (size_t pos = 0; pos < pk.ops[0].size(); pos++) {
+			bool any = false; int last = -1;
+			for (const auto& ops : pk.ops) { const int r = V[(size_t)ops[pos]].dst; if (r >= 0 && def_at[(size_t)r] == ops[pos] && regs[(size_t)r].slot) { any = true; last = std::max(last, regs[(size_t)r].last); } }
+			if (any) for (const auto& ops : pk.ops) { const int r = V[(size_t)ops[pos]].dst; if (r >= 0 && def_at[(size_t)r] == ops[pos]) { Reg& R = regs[(size_t)r]; R.def = ops[pos]; R.slot = true; R.last = std::max(R.last, last); } }
+		}
 		for (size_t r = 0; r < regs.size(); r++) if (regs[r].slot && is_dbl[r]) return refuse("a double register would have to cross levels");
 		// slots: suffix values by interval [def level, last use level], reused when disjoint; prefix values one (double-buffered) slot each
 		int nslots = 0, npslots = 0;
