@@ -17,7 +17,7 @@ def initial_record():
     return np.array([int(w, 16) for w in open(os.path.join(ROOT, "tests", "golden", "pingpong_recorded.rec")).read().split()], np.uint32)
 
 
-def timed(bank, io, N, steps=40, warmup=10):
+def timed(bank, io, N, steps=40, warmup=int(os.environ.get("KLG_BENCH_WARM", "10"))):
     st = torch.cuda.current_stream().cuda_stream                  # (main() makes a non-default stream current: handle 0 would mean "the bank's own stream")
     for _ in range(warmup): bank.process_device(io.data_ptr(), N, st)
     torch.cuda.synchronize(); bank.timing_begin()
