@@ -470,9 +470,13 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			}
 			nslots = (int)free_after.size();
 		}
-		const long long lds_words = (long long)NW * G * (pipelined ? 3 : 1) + (long long)CH * C * G * (any_near ? 2 : 1) + (long long)(nslots + 2 * npslots) * C * G + 4;   // (any_near: a second copy of the chunk's `in`)
+		long long lds_words = (long long)NW * G * (pipelined ? 3 : 1) + (long long)CH * C * G * (any_near ? 2 : 1) + (long long)(nslots + 2 * npslots) * C * G + 4;   // (any_near: a second copy of the chunk's `in`)
 		const char* le = getenv("KLG_FX_STAGED_LDS");
-		const long long budget = le ? atoll(le) : 160 * 1024;                 // gfx950 grants a workgroup up to 160 KB; a plan that needs most of it (the recorded Reverb.k: 68 values x 32 samples x 16 instances) is one workgroup of 8 waves per CU — measured 0.61 against 0.83 ms at 4,096 instances, 2.5 against 4.4 ms at 16,384, with half the chunk
+		const long long budget = le ? atoll(le) : 160 * 1024;
+		// two tiles, by the parity of the chunk, where they fit: a chunk's results leave from one while the next chunk's input lands in the other — no barrier between them
+		const char* te = getenv("KLG_FX_STAGED_TILES");
+		const bool two_tiles = !(te && te[0] == '1') && (lds_words + (long long)CH * C * G) * 4 <= budget;
+		if (two_tiles) lds_words += (long long)CH * C * G;                 // gfx950 grants a workgroup up to 160 KB; a plan that needs most of it (the recorded Reverb.k: 68 values x 32 samples x 16 instances) is one workgroup of 8 waves per CU — measured 0.61 against 0.83 ms at 4,096 instances, 2.5 against 4.4 ms at 16,384, with half the chunk
 		if (lds_words * 4 > budget) { if (in.C > 0 && !in.C_is_a_preference) return refuse("the requested chunk length does not fit the LDS budget"); continue; }
 
 		// =========================================================== source ===========================================================
@@ -868,8 +872,9 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		if (stamp) s += "\tconst long long tstart = wall_clock64();\n";
 		s += "\tuint32_t* const srec = reinterpret_cast<uint32_t*>(lds);                 // [NW][G]: the G records between chunks\n";
 		s += F("\tuint32_t* const srecp = srec + NW * G;                                    // [2][NW][G]: the control path's own copies (it runs a chunk ahead)%s\n", pipelined ? "" : " — unused");
-		s += F("\tfloat* const tile = lds + NW * G * %d;                                    // [CH][C][G]: the caller's block, chunk by chunk\n", pipelined ? 3 : 1);
-		s += "\tfloat* const slots = tile + CH * C * G;                                   // [slots][C][G]: values that cross levels\n";
+		s += F("\tfloat* const tile0 = lds + NW * G * %d;                                   // [%d][CH][C][G]: the caller's block, chunk by chunk (two: by the chunk's parity)\n", pipelined ? 3 : 1, two_tiles ? 2 : 1);
+		s += "\tfloat* tile = tile0; int tile_turn = 0; (void)tile_turn;\n";
+		s += F("\tfloat* const slots = tile0 + %d * CH * C * G;                              // [slots][C][G]: values that cross levels\n", two_tiles ? 2 : 1);
 		s += F("\tfloat* const pslots = slots + %d * C * G;                                 // [slots][2][C][G]: those of the control path, by the parity of their chunk\n", nslots);
 		s += F("\tfloat* const incopy = pslots + %d * C * G;                                  // [CH][C][G]: the chunk's `in` as it came (the tile is overwritten by the outputs)%s\n", 2 * npslots, any_near ? "" : " — unused");
 		s += F("\tint* const flag = reinterpret_cast<int*>(incopy + %d);\n\t(void)incopy;\n", any_near ? CH * C * G : 0);
@@ -934,6 +939,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		// The thread index is laundered through an empty asm once per chunk: otherwise every per-lane LDS address of the chunk's body (a value's slot + this lane's
 		// place in it: the slots lie beyond an instruction's 16-bit offset) is loop-invariant, gets hoisted out of the chunk loop and then spilled — the recorded
 		// Reverb.k's kernel held ~500 of them in scratch (3.7 KB per lane; 1,123 spilled registers) and moved 5 x its algorithmic bytes
+		if (two_tiles) s += "\t\ttile = tile0 + (tile_turn & 1) * (CH * C * G); tile_turn++;          // (counted across the blocks of a span)\n";
 		s += "\t\tint tv = threadIdx.x; asm volatile(\"\" : \"+v\"(tv));\n";
 		s += "\t\tconst int t = tv, tp = t < NTP ? t : 0, ps = tp / G, pg = tp % G, wv = t >> 6, sw = wv - SW0, ln = t & 63; (void)ps; (void)pg; (void)sw; (void)ln; (void)wv;\n";
 		s += "#pragma unroll\n\t\tfor (int j = 0; j < CH; j++) { const int i = tp + j * NTP, row = i / C, q = i % C, gi = row / CH, ch = row % CH; if (t < NTP) { tile[(ch * C + q) * G + gi] = nx[j];" + std::string(any_near ? " incopy[(ch * C + q) * G + gi] = nx[j];" : "") + " } }\n";
@@ -969,7 +975,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "\t\tif (!ok) { plain(s0, cl, false); __syncthreads(); }\n";
 		s += "\t\tfor (int i = t; i < G * CH * C; i += NT) { const int row = i / C, q = i % C, gi = row / CH, ch = row % CH;\n";
 		s += "\t\t\tif (q < cl && k0 + gi < a.K) io[((size_t)(k0 + gi) * CH + ch) * a.n + s0 + q] = tile[(ch * C + q) * G + gi]; }\n";
-		s += "\t\t__syncthreads();\n";
+		if (!two_tiles) s += "\t\t__syncthreads();\n";                            // (two tiles: the next chunk's input goes to the other one, and this one is not touched before the barriers of that chunk)
 		if (stamp) s += "\t\t{ const long long now = wall_clock64(); tacc[15] += now - tprev; tprev = now; }\n";
 		s += "\t}\n";
 
