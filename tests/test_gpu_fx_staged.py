@@ -219,3 +219,73 @@ def test_staged_taps_of_a_line_fed_by_in_may_sit_inside_their_own_chunk(name, tm
         peak = max(peak, float(np.abs(outs[0]).max()))
     assert peak > 1e-2
     for b in banks: b.close()
+
+
+@pytest.mark.parametrize("shape", ["32,16", "64,8", "16,16", "32,32"])
+def test_staged_reverb_workgroup_shapes(shape, monkeypatch):
+    """Recorded Reverb.k in the other workgroup shapes a bank's size selects (8,192 instances: 32 x 16 — packs of two strands; 16,384 and up: 64 x 8 — no
+    packs; and two more): the staged form against one lane per instance, 130 instances (a last workgroup that is not full), per-instance dials,
+    a ragged block.  KLG_FX_STAGED_LDS lifts the budget where a shape needs more than the default plan would take."""
+    prog = open(os.path.join(GOLDEN, "reverb_recorded.klgg")).read()
+    rec = np.array([int(w, 16) for w in open(os.path.join(GOLDEN, "reverb_recorded.rec")).read().split()], np.uint32)
+    g, c = shape.split(",")
+    K = 130
+    monkeypatch.setenv("KLG_FX_STAGED", "1"); monkeypatch.setenv("KLG_FX_STAGED_G", g); monkeypatch.setenv("KLG_FX_STAGED_C", c)
+    staged = klang_amd.FxBank(prog, K, max_block=256, initial_record=rec, channels=2)
+    form = staged.graph_form()
+    if not form["staged"]:
+        staged.close()
+        pytest.skip("this shape does not fit the LDS budget: " + form["why"])
+    assert form["instances_per_workgroup"] == int(g) and form["samples_per_chunk"] == int(c), form
+    monkeypatch.setenv("KLG_FX_STAGED", "0")
+    lane = klang_amd.FxBank(prog, K, max_block=256, initial_record=rec, channels=2)
+    rng = np.random.default_rng(23)
+    for k in range(K):
+        for ctl in range(5):
+            v = float(rng.uniform(0.0, 1.0))
+            staged.set_control(k, ctl, v); lane.set_control(k, ctl, v)
+    peak = 0.0
+    for bi, n in enumerate([256, 200, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256]):
+        x = ((rng.random((K, 2, n), dtype=np.float32) - 0.5) * (1.0 if bi < 4 else 0.0)).astype(np.float32)
+        a, b = staged.process(x.copy()), lane.process(x.copy())
+        bad = np.argwhere(bits(a) != bits(b))
+        assert len(bad) == 0, f"block {bi} (n = {n}): {len(bad)} samples differ, first {bad[0]}"
+        peak = max(peak, float(np.abs(a).max()))
+    assert peak > 1e-2
+    staged.close(); lane.close()
+
+
+@pytest.mark.parametrize("shape", ["32,16", "64,8", "16,16"])
+def test_staged_chorus_workgroup_shapes(shape, tmp_path, monkeypatch, capfd):
+    """The shipped Chorus.k (ten LFO strands: packs of four / two / none by workgroup width; ten taps of lines fed by `in`; a prepare() prologue) in the shapes
+    larger banks select: staged against one lane per instance, 130 instances, dials per instance, a ragged block."""
+    monkeypatch.setenv("KLANG_MI355_FORCE_GRAPH", "1"); monkeypatch.setenv("KLANG_MI355_DUMP_GRAPH", "1")
+    capfd.readouterr()
+    run_effect("fx_topchorus", tmp_path)
+    err = capfd.readouterr().err
+    prog = re.search(r"^klgg 1\n.*?^end\n", err, re.S | re.M).group(0)
+    r = re.search(r"initial record:((?: [0-9a-f]{8})+)", err)
+    rec = np.array([int(w, 16) for w in r.group(1).split()], np.uint32) if r else None
+    dials = [tuple(float(x) for x in ln.split()[2:5]) for ln in prog.splitlines() if ln.startswith("dial ")]
+    g, c = shape.split(",")
+    K = 130
+    monkeypatch.setenv("KLG_FX_STAGED", "1"); monkeypatch.setenv("KLG_FX_STAGED_G", g); monkeypatch.setenv("KLG_FX_STAGED_C", c)
+    staged = klang_amd.FxBank(prog, K, max_block=256, initial_record=rec, channels=2)
+    form = staged.graph_form()
+    assert form["staged"] and form["instances_per_workgroup"] == int(g) and form["samples_per_chunk"] == int(c), form
+    monkeypatch.setenv("KLG_FX_STAGED", "0")
+    lane = klang_amd.FxBank(prog, K, max_block=256, initial_record=rec, channels=2)
+    rng = np.random.default_rng(29)
+    for k in range(K):
+        for ctl, (lo, hi, _) in enumerate(dials):
+            v = float(lo + (hi - lo) * rng.uniform(0.0, 1.0))
+            staged.set_control(k, ctl, v); lane.set_control(k, ctl, v)
+    peak = 0.0
+    for bi, n in enumerate([256, 200, 256, 256, 7, 256, 256]):
+        x = ((rng.random((K, 2, n), dtype=np.float32) - 0.5) * (1.0 if bi < 5 else 0.0)).astype(np.float32)
+        a, b = staged.process(x.copy()), lane.process(x.copy())
+        bad = np.argwhere(bits(a) != bits(b))
+        assert len(bad) == 0, f"block {bi} (n = {n}): {len(bad)} samples differ, first {bad[0]}"
+        peak = max(peak, float(np.abs(a).max()))
+    assert peak > 1e-2
+    staged.close(); lane.close()
