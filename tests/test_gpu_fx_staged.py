@@ -221,11 +221,11 @@ def test_staged_taps_of_a_line_fed_by_in_may_sit_inside_their_own_chunk(name, tm
     for b in banks: b.close()
 
 
-@pytest.mark.parametrize("shape", ["32,16", "64,8", "16,16", "32,32"])
+@pytest.mark.parametrize("shape", ["16,16", "16,8"])
 def test_staged_reverb_workgroup_shapes(shape, monkeypatch):
-    """Recorded Reverb.k in the other workgroup shapes a bank's size selects (8,192 instances: 32 x 16 — packs of two strands; 16,384 and up: 64 x 8 — no
-    packs; and two more): the staged form against one lane per instance, 130 instances (a last workgroup that is not full), per-instance dials,
-    a ragged block.  KLG_FX_STAGED_LDS lifts the budget where a shape needs more than the default plan would take."""
+    """Recorded Reverb.k with shorter chunks (its 68 values through LDS only fit 16-instance workgroups: every bank size runs it 16 x 32; wider shapes are
+    covered by the shipped Chorus.k below): the staged form against one lane per instance, 130 instances (a last workgroup that is not full),
+    per-instance dials, a ragged block."""
     prog = open(os.path.join(GOLDEN, "reverb_recorded.klgg")).read()
     rec = np.array([int(w, 16) for w in open(os.path.join(GOLDEN, "reverb_recorded.rec")).read().split()], np.uint32)
     g, c = shape.split(",")
