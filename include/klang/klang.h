@@ -81,7 +81,8 @@ constexpr constant root2 = { 1.4142135623730950488016887242097 };
 
 template<typename T1, typename T2> inline T1 max(T1 a, T2 b) { return a > b ? a : (T1)b; }                              // klang.h:224 (returns the FIRST type)
 template<typename T1, typename T2> inline T1 min(T1 a, T2 b) { return a < b ? a : (T1)b; }                              // klang.h:223
-template<typename T> inline T random(const T mn, const T mx) { return std::rand() * ((mx - mn) / (T)RAND_MAX) + mn; }   // klang.h:236
+// (klg_rand_sync: Noise generators draw from the same sequence on the device; the C library gets it back before host code draws — include/klang_mi355.h)
+template<typename T> inline T random(const T mn, const T mx) { klg_rand_sync(); return std::rand() * ((mx - mn) / (T)RAND_MAX) + mn; }   // klang.h:236
 inline void random(const unsigned seed) { std::srand(seed); klg_random_seed(seed); }                                     // klang.h:239
 
 // =================================================================================================
@@ -583,8 +584,9 @@ struct Oscillator : Generator {
 };
 namespace Generators {
 	// White noise: one libc rand() per sample (klang.h:4947-4951 Basic, 5357-5366 Fast).  Every Noise object of the process draws from the
-	// one libc sequence, so the bank draws each block's values on the host with rand() itself, in the reference's call order (an Effect
-	// bank: instance by instance; a Synth bank: sounding note by sounding note, each through the whole block), and the lanes index them.
+	// one libc sequence: the bank produces each block's values ON THE DEVICE from that sequence's state (glibc's generator restated with jump-ahead,
+	// klang_amd/csrc/klg_rand.hpp) in the reference's call order (an Effect bank: instance by instance; a Synth bank: sounding note by sounding
+	// note, each through the whole block), and the lanes index them.
 	struct NoiseBase : Generator {
 		int kind;
 		explicit NoiseBase(int k) : kind(k) {}

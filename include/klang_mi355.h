@@ -66,8 +66,25 @@ int klg_version(void);
 int klg_init(const int* device_ids, int n_devices);
 
 /* klang::random(seed) (klang.h:239): seeds the libc rand() stream the host-side on() code of
- * SuperSaw-style patches draws detune from (SuperSaw.k:17). */
+ * SuperSaw-style patches draws detune from (SuperSaw.k:17) — and that every Noise generator draws
+ * from once per sample (klang.h:4949, 5363). */
 void klg_random_seed(unsigned seed);
+
+/* The reference has ONE rand() sequence per process, shared by host code (klang::random in on() /
+ * prepare()) and by Generators::{Basic,Fast}::Noise::process() (klang.h:4947-4951, 5357-5366).  This
+ * library produces the Noise draws ON THE DEVICE (glibc's generator restated with jump-ahead:
+ * klang_amd/csrc/klg_rand.hpp): while banks with Noise generators are being processed the sequence
+ * lives in device memory and no block waits for the host.  Host code that is about to call rand() /
+ * klang::random(a, b) itself calls klg_rand_sync() first: the C library's generator is set to where
+ * the device has got to (waits for the last enqueued Noise block; a no-op when no Noise bank has run
+ * since the last call).  The library's own host-side draws and include/klang/klang.h's random() do. */
+int klg_rand_sync(void);
+
+/* `ranks` x `per` consecutive values of that sequence into device memory, d_out[i * rstride + r] =
+ * the (r * per + i)-th rand() from where the sequence stands (rstride >= ranks) — what `ranks` Noise
+ * objects drawing `per` values one after the other (klang.h:4842-4848) would get; the sequence moves
+ * on by ranks * per.  Enqueued on `hip_stream`; what the banks' own Noise path uses. */
+int klg_rand_fill_device(int* d_out, size_t rstride, unsigned ranks, int per, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Synth banks.  One klg_synth = `synths` independent instances of klang::Synth / Stereo::Synth

@@ -8,7 +8,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libklang_mi355.so")
+LIB_PATH = os.environ.get("KLANG_MI355_LIB") or os.path.join(HERE, "libklang_mi355.so")   # (KLANG_MI355_LIB: another build of the same library, for A/B measurements: tools/noise_bench.py)
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "klang_mi355.h")
 
 
@@ -42,6 +42,8 @@ def load():
         "klg_version": (C.c_int, []),
         "klg_init": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
         "klg_random_seed": (None, [C.c_uint]),
+        "klg_rand_sync": (C.c_int, []),
+        "klg_rand_fill_device": (C.c_int, [vp, C.c_size_t, C.c_uint, C.c_int, vp]),
         "klg_synth_create": (vp, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
         "klg_synth_destroy": (None, [vp]),
         "klg_synth_voices": (C.c_int, [vp]),
@@ -109,6 +111,8 @@ def load():
     }
     for name in declared_symbols():
         if not hasattr(lib, name):
+            if os.environ.get("KLANG_MI355_LIB"):      # an older build under A/B measurement: it simply lacks the newer entries
+                continue
             raise KlangError(f"libklang_mi355.so does not export {name} declared in include/klang_mi355.h")
         if name not in sig:
             raise KlangError(f"klang_amd/_lib.py has no signature for {name}")

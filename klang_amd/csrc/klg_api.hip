@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -18,6 +19,7 @@
 #include "../../include/klang_mi355.h"
 #include "../../include/klang/host_dsl.hpp"
 #include "klg_kernels.hpp"
+#include "klg_rand_dev.hpp"
 #include "klg_graph.hpp"
 #include "klg_fx.hpp"
 #include "klg_render_x2.hpp"
@@ -130,7 +132,106 @@ extern "C" int klg_init(const int* device_ids, int n_devices) {
 	return 0;
 }
 
-extern "C" void klg_random_seed(unsigned seed) { srand(seed); }     // klang::random(seed) klang.h:239
+// ------------------------------------------------------------------------------------------------
+// where the rand() stream lives (klg_rand_dev.hpp)
+// ------------------------------------------------------------------------------------------------
+// The reference has ONE rand() sequence per process: klang::random(seed) seeds it, a patch's on() draws detune from it on the host (SuperSaw.k:17),
+// Reverb.k's prepare() re-seeds it and draws its tap tables, and every Noise generator draws from it once per sample (klang.h:4949, 5363).  Here the
+// per-sample draws happen on the device.  The stream is therefore in one of two places: in the C library (host code draws with rand() itself), or on a
+// device as 31 words that the Noise kernels advance block after block with no host round trip.  It moves to a device when a block with Noise
+// generators is enqueued, from device to device in the order shards are processed, and back into the C library — one 124-byte copy, after the last
+// Noise block has finished — when host code is about to draw: the library's own host draws call rng_to_host() first, the DSL facade's
+// klang::random() calls klg_rand_sync().
+struct RngChain {
+	bool on_device = false; int device = -1;
+	std::map<int, uint32_t*> d_state;                              // per device: 32 words
+	std::map<int, hipEvent_t> last; hipStream_t last_stream = nullptr;   // after the last launch that used the state on that device
+	std::map<std::pair<int, unsigned long long>, uint32_t*> tables;    // (device, per) -> klg_rand::jump_table(per) in HBM
+};
+static RngChain g_rng;
+// the stream's state in device memory of `device`, current as of what has been enqueued, with `st` ordered behind whoever used it last
+static int rng_acquire(int device, hipStream_t st, uint32_t** state) {
+	std::lock_guard<std::recursive_mutex> lock(RandGuard::mu());
+	RngChain& g = g_rng;
+	if (!g.d_state.count(device)) {
+		RandGuard rg;
+		uint32_t* p = nullptr; hipEvent_t e = nullptr;
+		HIP_TRY(hipMalloc((void**)&p, 32 * sizeof(uint32_t))); HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		g.d_state[device] = p; g.last[device] = e;
+	}
+	uint32_t* const mine = g.d_state[device];
+	if (!g.on_device) {
+		klg_rand::State s;
+		if (!klg_rand::libc_state(s)) return fail(KLG_ERR_INVALID, "the C library's rand() is not running its default generator (initstate() with a small state?): the Noise generators have no stream to continue");
+		RandStateArg arg; std::memcpy(arg.x, s.x, sizeof arg.x);
+		hipLaunchKernelGGL(klg_rand_set, dim3(1), dim3(64), 0, st, mine, arg);
+		HIP_TRY(hipGetLastError());
+	}
+	else if (g.device != device) {
+		HIP_TRY(hipStreamWaitEvent(st, g.last[g.device], 0));
+		HIP_TRY(hipMemcpyPeerAsync(mine, device, g.d_state[g.device], g.device, klg_rand::DEG * sizeof(uint32_t), st));
+	}
+	else if (g.last_stream != st) HIP_TRY(hipStreamWaitEvent(st, g.last[device], 0));
+	g.on_device = true; g.device = device; g.last_stream = st;
+	*state = mine;
+	return 0;
+}
+static int rng_release(int device, hipStream_t st) {                // after the launches that read / advanced the state
+	std::lock_guard<std::recursive_mutex> lock(RandGuard::mu());
+	HIP_TRY(hipEventRecord(g_rng.last[device], st));
+	return 0;
+}
+static int rng_table(int device, unsigned long long per, const uint32_t** table) {
+	std::lock_guard<std::recursive_mutex> lock(RandGuard::mu());
+	auto it = g_rng.tables.find({ device, per });
+	if (it == g_rng.tables.end()) {
+		RandGuard rg;
+		const std::vector<uint32_t> t = klg_rand::jump_table(per);
+		uint32_t* d = nullptr;
+		HIP_TRY(hipMalloc((void**)&d, t.size() * 4)); HIP_TRY(hipMemcpy(d, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+		it = g_rng.tables.emplace(std::make_pair(device, per), d).first;
+	}
+	*table = it->second;
+	return 0;
+}
+// host code is about to call rand(): the C library gets the stream back (waits for the last Noise block)
+static int rng_to_host() {
+	std::lock_guard<std::recursive_mutex> lock(RandGuard::mu());
+	RngChain& g = g_rng;
+	if (!g.on_device) return 0;
+	DeviceGuard bound(g.device); if (!bound.ok) return KLG_ERR_NO_DEVICE;
+	klg_rand::State s;
+	HIP_TRY(hipEventSynchronize(g.last[g.device]));
+	HIP_TRY(hipMemcpy(s.x, g.d_state[g.device], sizeof s.x, hipMemcpyDeviceToHost));
+	klg_rand::libc_set_state(s);
+	g.on_device = false;
+	return 0;
+}
+extern "C" int klg_rand_sync(void) { return rng_to_host(); }
+extern "C" void klg_random_seed(unsigned seed) {                   // klang::random(seed) klang.h:239
+	{ std::lock_guard<std::recursive_mutex> lock(RandGuard::mu()); g_rng.on_device = false; }      // (whatever a device held is superseded)
+	srand(seed);
+}
+// `ranks` x `per` draws of the stream, in order, into device memory: out[i * rstride + r] = the (r * per + i)-th rand() from here — what `ranks` Noise
+// objects processing `per / draws` samples one after the other would draw (klang.h:4842-4848)
+static int rng_fill(int device, hipStream_t st, int* d_out, size_t rstride, const unsigned* d_count, unsigned ranks_bound, unsigned count_imm, int per) {
+	uint32_t* state = nullptr; const uint32_t* table = nullptr;
+	if (int rc = rng_table(device, (unsigned long long)per, &table)) return rc;
+	if (int rc = rng_acquire(device, st, &state)) return rc;
+	RandFillArgs f; f.state = state; f.table = table; f.count = d_count; f.count_imm = count_imm; f.per = per; f.out = d_out; f.rstride = rstride;
+	if (ranks_bound > 0) hipLaunchKernelGGL(klg_rand_fill, dim3((ranks_bound + 255u) / 256u), dim3(256), 0, st, f);
+	hipLaunchKernelGGL(klg_rand_advance, dim3(1), dim3(64), 0, st, state, table, d_count, count_imm);
+	HIP_TRY(hipGetLastError());
+	return rng_release(device, st);
+}
+extern "C" int klg_rand_fill_device(int* d_out, size_t rstride, unsigned ranks, int per, void* hip_stream) {
+	if (!d_out || per <= 0 || rstride < ranks || ranks >= (1u << 30)) return fail(KLG_ERR_INVALID, "klg_rand_fill_device: bad arguments");
+	if (default_device() < 0) return KLG_ERR_NO_DEVICE;
+	int device = g_device;
+	{ hipPointerAttribute_t at; if (hipPointerGetAttributes(&at, d_out) == hipSuccess) device = at.device; else (void)hipGetLastError(); }
+	DeviceGuard bound(device); if (!bound.ok) return KLG_ERR_NO_DEVICE;
+	return rng_fill(device, (hipStream_t)hip_stream, d_out, rstride, nullptr, ranks, ranks, per);
+}
 
 // ------------------------------------------------------------------------------------------------
 // patch table
@@ -187,11 +288,16 @@ struct klg_synth {
 	TableDesc* d_tables = nullptr; size_t d_tables_cap = 0; bool tables_dirty = false;
 	unsigned args_gen = 0;                      // bumped whenever a device pointer that RenderArgs carries may have changed (tables_sync, mix mode): captured spans of an older generation are dropped, not replayed
 	float* d_note_rings = nullptr;               // note delays of a graph patch: [stride][ring_rows], each voice's lines contiguous
-	int *d_rand = nullptr, *d_rand_base = nullptr; size_t d_rand_cap = 0; std::vector<int> h_rand, h_rand_base;   // Noise generators of a graph patch: the block's rand() draws (draw_noise)
+	// Noise generators of a graph patch (note_prepass): the block's draws [n * draws][rand_cap ranks], every voice's rank, the rank kernels' workspace,
+	// the pinned word they report (block number, count) in, and what the host's capacity bound is made of
+	int *d_rand = nullptr, *d_rank = nullptr; size_t rand_cap = 0; unsigned* d_rank_groups = nullptr; unsigned long long* h_rank_feedback = nullptr;
+	enum { ONS_RING = 64 };
+	unsigned rank_seq = 0; unsigned long long ons_total = 0, ons_at[ONS_RING] = {};   // voice records sent to the bank so far; ... when block `seq` was enqueued
+	float* d_smoothed = nullptr; bool smoothed_host_newer = false, smoothed_device_newer = false;   // Control::smoothed [S][nctl] on the device (klg_note_smooth)
 	// host mirrors
 	std::vector<host::ControlH> controls;        // [S][nctl]
 	std::vector<float> h_controls;               // [S][KLG_MAX_CTL]
-	std::vector<float> smoothed, h_smooth_start; // Control::smoothed of every control [S][nctl] (note_prepass); staging [V]
+	std::vector<float> smoothed;                 // Control::smoothed of every control [S][nctl]: the host's copy (klg_set / get_control_smoothed; the device's is d_smoothed)
 	bool controls_dirty = true;
 	std::vector<HostVoice> voices;
 	std::vector<unsigned> noteOns;               // [S]
@@ -216,13 +322,13 @@ struct klg_synth {
 static void synth_free(klg_synth* s) {
 	if (!s) return;
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
-	void* dev[] = { s->d_state, s->d_controls, s->d_partials, s->d_mix, s->d_per_voice, s->d_scratch_rec, s->d_stage, s->d_rand, s->d_rand_base, s->d_ticket };
+	void* dev[] = { s->d_state, s->d_controls, s->d_partials, s->d_mix, s->d_per_voice, s->d_scratch_rec, s->d_stage, s->d_rand, s->d_rank, s->d_rank_groups, s->d_smoothed, s->d_ticket };
 	for (void* p : dev) if (p) (void)hipFree(p);
 	if (s->d_note_rings) (void)hipFree(s->d_note_rings);
 	if (s->d_solo) (void)hipFree(s->d_solo);
 	for (auto& t : s->tables) if (t.d) (void)hipFree(t.d);
 	if (s->d_tables) (void)hipFree(s->d_tables);
-	void* pinned[] = { s->h_stage, s->h_mix, s->h_flags, s->h_per_voice };
+	void* pinned[] = { s->h_stage, s->h_mix, s->h_flags, s->h_per_voice, s->h_rank_feedback };
 	for (void* p : pinned) if (p) (void)hipHostFree(p);
 	if (s->stage_done) (void)hipEventDestroy(s->stage_done);
 	if (s->module) (void)hipModuleUnload(s->module);
@@ -635,6 +741,7 @@ static void push_note_on(klg_synth* s, int voice, const void* rec) {
 	const uint32_t* w = (const uint32_t*)rec;
 	if (s->record_sink) { std::memcpy(s->record_sink, w, (size_t)s->W * 4); return; }      // klg_note_record: the record goes to the caller, nothing is queued
 	const int idx = (int)(s->payload.size() / s->W);
+	s->ons_total++;
 	s->payload.insert(s->payload.end(), w, w + s->W);
 	s->events.push_back({ voice, 0, idx, s->seq++ });
 }
@@ -678,6 +785,7 @@ static void patch_on(klg_synth* s, int synth, int voice, HostVoice* scratch = nu
 		push_note_on(s, voice, &r);
 	} break;
 	case KLG_PATCH_SUPERSAW: {                                    // SuperSaw.k:12-19
+		(void)rng_to_host();                                       // (random() below draws from the C library: the stream comes home if a Noise bank holds it)
 		const float detune = (float)(0.01 * (double)ctl[2].value * (double)f);
 		PatchSuperSaw::Rec r;
 		uint32_t flags = ST_SUSTAIN;
@@ -789,15 +897,27 @@ extern "C" int klg_set_control(klg_synth* s, int synth, int index, float value) 
 	s->controls_dirty = true;
 	return 0;
 }
+// Control::smoothed lives on the device once a block has run klg_note_smooth: the host's copy is refreshed when somebody asks
+static int smoothed_pull(klg_synth* s) {
+	if (!s->smoothed_device_newer || !s->d_smoothed) return 0;
+	KLG_BIND(s);
+	HIP_TRY(hipStreamSynchronize(s->stream)); HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(s->smoothed.data(), s->d_smoothed, s->smoothed.size() * 4, hipMemcpyDeviceToHost));
+	s->smoothed_device_newer = false;
+	return 0;
+}
 extern "C" int klg_set_control_smoothed(klg_synth* s, int synth, int index, float smoothed) {
 	if (!s || synth < 0 || synth >= s->S || index < 0 || index >= s->nctl) return fail(KLG_ERR_INVALID, "klg_set_control_smoothed: synth %d / control %d out of range", synth, index);
 	if (s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); return klg_set_control_smoothed(s->multi->shard[(size_t)i], ls, index, smoothed); }
+	if (int rc = smoothed_pull(s)) return rc;
 	s->smoothed[(size_t)synth * s->nctl + index] = smoothed;
+	s->smoothed_host_newer = true;
 	return 0;
 }
 extern "C" int klg_get_control_smoothed(klg_synth* s, int synth, int index, float* smoothed) {
 	if (!s || !smoothed || synth < 0 || synth >= s->S || index < 0 || index >= s->nctl) return fail(KLG_ERR_INVALID, "klg_get_control_smoothed: out of range");
 	if (s->multi) { int ls = 0; const int i = shard_of_synth(s, synth, &ls); return klg_get_control_smoothed(s->multi->shard[(size_t)i], ls, index, smoothed); }
+	if (int rc = smoothed_pull(s)) return rc;
 	*smoothed = s->smoothed[(size_t)synth * s->nctl + index];
 	return 0;
 }
@@ -814,55 +934,72 @@ extern "C" int klg_get_control(klg_synth* s, int synth, int index, float* value)
 static int tables_sync(klg_synth* s);
 // What the notes of a reference Synth SHARE, and therefore see in the order Synth::process walks them — synth by synth, note slot by
 // note slot, each sounding note through the whole block (klang.h:4842-4848; Note::process(buffer) 4295-4303 runs all n samples, also
-// after a stop()).  Both are settled HERE, per block, once the block's events are on the device and the note stages are back (one
-// device round trip per block: the price of state that is shared by construction):
-//  * Noise generators (4947-4951, 5357-5366): one libc rand() per generator and sample.  The block's draws are made with rand() itself
-//    in exactly that order; voice v's values start at rand_base[v].
-//  * controls[i].smooth() (1715): the control is the Synth's, every sounding note advances it.  The chain smoothed = smoothed * 0.999f +
-//    (1.f - 0.999f) * value runs on the host through the sounding notes (it stops early at its fp32 fixed point, where a step changes
-//    nothing); each voice's record gets the value ITS block starts from, and the lane repeats the same operations per sample.
+// after a stop()).  Both are settled HERE, per block, once the block's events are on the device — by kernels on the block's own stream,
+// with no copy to the host and no wait (klg_rand_dev.hpp):
+//  * Noise generators (4947-4951, 5357-5366): one libc rand() per generator and sample, from the process's one sequence.  klg_rand_rank
+//    numbers the sounding voices in that order, klg_rand_fill produces rank r's n * draws values from the stream's state on the device
+//    (stored [index][rank]; voice v reads column rank[v]), klg_rand_advance moves the state past the block.
+//  * controls[i].smooth() (1715): the control is the Synth's, every sounding note advances it: klg_note_smooth, a lane per instance.
+// The one thing the host decides is how many ranks the draw buffer must hold.  It never asks: the rank kernel leaves (block number, count) in a
+// pinned word the host reads whenever it comes by; a later block can need at most that count + every voice record that went to the bank since.
+// Only when that bound exceeds the buffer does the host wait for the exact count of THIS block (and grow the buffer if it must).
 static int note_prepass(klg_synth* s, RenderArgs& a, int n, hipStream_t st) {
 	const int draws = s->graph->noise_calls;
-	HIP_TRY(hipMemcpyAsync(s->h_flags, s->d_state, (size_t)s->V * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	auto sounding = [&](int v) { return (s->h_flags[v] & 3u) != (uint32_t)ST_OFF; };
-	for (const auto& sm : s->graph->smooths) {
-		s->h_smooth_start.resize((size_t)s->V);
-		for (int i = 0; i < s->S; i++) {
-			float x = s->smoothed[(size_t)i * s->nctl + sm.ctl];
-			const float k = (1.f - 0.999f) * s->controls[(size_t)i * s->nctl + sm.ctl].value;
-			for (int v = i * s->P; v < (i + 1) * s->P; v++) {
-				s->h_smooth_start[(size_t)v] = x;
-				if (!sounding(v)) continue;
-				for (long long t = (long long)n * sm.calls; t > 0; t--) { const float y = x * 0.999f + k; if (y == x) break; x = y; }
-			}
-			s->smoothed[(size_t)i * s->nctl + sm.ctl] = x;
-		}
-		HIP_TRY(hipMemcpyAsync(s->d_state + (size_t)sm.word * s->stride, s->h_smooth_start.data(), (size_t)s->V * 4, hipMemcpyHostToDevice, st));
-		HIP_TRY(hipStreamSynchronize(st));                             // pageable staging: reused by the next node / block
+	if (!s->graph->smooths.empty()) {
+		const size_t words = (size_t)s->S * (size_t)std::max(1, s->nctl);
+		if (!s->d_smoothed) { RandGuard rg; HIP_TRY(hipMalloc((void**)&s->d_smoothed, words * 4)); s->smoothed_host_newer = true; }
+		if (s->smoothed_host_newer) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipMemcpy(s->d_smoothed, s->smoothed.data(), words * 4, hipMemcpyHostToDevice)); s->smoothed_host_newer = false; }
+		SmoothArgs q;
+		q.state = s->d_state; q.stride = s->stride; q.synths = s->S; q.notes_per_synth = s->P; q.n = n; q.nctl = std::max(1, s->nctl);
+		q.controls = s->d_controls; q.smoothed = s->d_smoothed; q.count = 0;
+		for (const auto& sm : s->graph->smooths) if (q.count < KLG_MAX_CTL) { q.sm[q.count].word = sm.word; q.sm[q.count].ctl = sm.ctl; q.sm[q.count].calls = sm.calls; q.count++; }
+		{ TimedAux timed(s); KLG_LAUNCH(klg_note_smooth, dim3((unsigned)((s->S + 63) / 64)), dim3(64), 0, st, q); }
+		HIP_TRY(hipGetLastError());
+		s->smoothed_device_newer = true;
 	}
 	if (draws == 0) return 0;
-	const size_t per = (size_t)n * (size_t)draws;
-	s->h_rand_base.assign((size_t)s->V, 0);
-	size_t count = 0;
-	for (int v = 0; v < s->V; v++) if (sounding(v)) s->h_rand_base[(size_t)v] = (int)(per * count++);
-	// the draws of the SOUNDING voices only: the device array grows with their high-water mark (a bank of a million slots of which a thousand sound
-	// holds a thousand voices' draws, not 4 GB per Noise generator)
-	const size_t need = std::max<size_t>(1, count) * (size_t)s->max_block * (size_t)draws;
-	if (!s->d_rand_base || need > s->d_rand_cap) {
-		RandGuard rg;                                                  // allocations must not disturb the stream the draws below come from
-		HIP_TRY(hipStreamSynchronize(st));
-		if (s->d_rand) (void)hipFree(s->d_rand);
-		s->d_rand_cap = need + need / 2;
-		HIP_TRY(hipMalloc((void**)&s->d_rand, s->d_rand_cap * sizeof(int)));
-		if (!s->d_rand_base) HIP_TRY(hipMalloc((void**)&s->d_rand_base, (size_t)s->V * sizeof(int)));
+	const int groups = (s->V + RANK_WG - 1) / RANK_WG;
+	if (!s->d_rank) {
+		RandGuard rg;                                                  // (allocations must not disturb the C library's generator)
+		HIP_TRY(hipMalloc((void**)&s->d_rank, (size_t)s->V * sizeof(int)));
+		HIP_TRY(hipMalloc((void**)&s->d_rank_groups, ((size_t)groups + 1) * sizeof(unsigned)));
+		HIP_TRY(hipHostMalloc((void**)&s->h_rank_feedback, sizeof(unsigned long long)));
+		*s->h_rank_feedback = 0ull;
 	}
-	s->h_rand.resize(std::max<size_t>(per, per * count));             // (lanes without a sounding voice read the first voice's values and drop the result)
-	for (size_t i = 0; i < per * count; i++) s->h_rand[i] = rand();
-	HIP_TRY(hipMemcpyAsync(s->d_rand, s->h_rand.data(), s->h_rand.size() * sizeof(int), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(s->d_rand_base, s->h_rand_base.data(), (size_t)s->V * sizeof(int), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipStreamSynchronize(st));                                 // pageable staging: reused by the next block
-	a.rand = s->d_rand; a.rand_base = s->d_rand_base;
+	const unsigned seq = ++s->rank_seq;                                // (block numbers start at 1: a feedback word of 0 = nothing reported yet)
+	s->ons_at[seq % klg_synth::ONS_RING] = s->ons_total;
+	RankArgs r;
+	r.flags = s->d_state; r.voices = s->V; r.rank = s->d_rank; r.block_counts = s->d_rank_groups; r.count = s->d_rank_groups + groups; r.feedback = s->h_rank_feedback; r.seq = seq;
+	{
+		TimedAux timed(s);
+		if (groups == 1) KLG_LAUNCH(klg_rand_rank, dim3(1), dim3(RANK_WG), 0, st, r, 1);
+		else {
+			KLG_LAUNCH(klg_rand_count, dim3((unsigned)groups), dim3(RANK_WG), 0, st, r);
+			hipLaunchKernelGGL(klg_rand_scan, dim3(1), dim3(RANK_WG), 0, st, r, groups);
+			hipLaunchKernelGGL(klg_rand_rank, dim3((unsigned)groups), dim3(RANK_WG), 0, st, r, 0);
+		}
+	}
+	HIP_TRY(hipGetLastError());
+	// how many ranks can this block have?
+	const unsigned long long fb = *(volatile unsigned long long*)s->h_rank_feedback;
+	const unsigned seen_seq = (unsigned)(fb >> 32), seen_count = (unsigned)fb;
+	size_t bound = (size_t)s->V;
+	if (seen_seq != 0 && seq - seen_seq < (unsigned)klg_synth::ONS_RING) bound = std::min<size_t>(bound, (size_t)seen_count + (size_t)(s->ons_total - s->ons_at[seen_seq % klg_synth::ONS_RING]));
+	if (bound > s->rand_cap) {
+		HIP_TRY(hipStreamSynchronize(st));                             // (rare: the first block, a burst of note-ons beyond everything seen so far)
+		const size_t exact = (size_t)(unsigned)*(volatile unsigned long long*)s->h_rank_feedback;
+		bound = exact;
+		if (exact > s->rand_cap) {
+			RandGuard rg;
+			if (s->d_rand) (void)hipFree(s->d_rand);
+			s->d_rand = nullptr;
+			s->rand_cap = std::min<size_t>(((size_t)s->V + 255) / 256 * 256, (std::max<size_t>(exact + exact / 2, 1024) + 255) / 256 * 256);
+			const size_t bytes = s->rand_cap * (size_t)(s->max_block + KLG_NZ_GROUP) * (size_t)draws * sizeof(int);   // (+ the rows the last group of a block reads ahead: klg_render nz_stage)
+			if (hipMalloc((void**)&s->d_rand, bytes) != hipSuccess) { s->rand_cap = 0; return fail(KLG_ERR_NOMEM, "the Noise generators' draws of %zu sounding voices x %d samples x %d generators (%.2f GB) could not be allocated", exact, s->max_block, draws, bytes / 1e9); }
+		}
+	}
+	if (int rc = rng_fill(s->device, st, s->d_rand, s->rand_cap, r.count, (unsigned)std::min(bound, s->rand_cap), 0u, n * draws)) return rc;
+	a.rand = s->d_rand; a.rand_base = s->d_rank; a.rstride = s->rand_cap;
 	return 0;
 }
 // does the render launch of this bank apply events / combine its partial rows itself (RenderArgs::ev / ticket)?  The kernels that can: klg_render<P>
@@ -876,6 +1013,7 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	EventArgs ev; ev.runs = 0;
 	if (script_events) {                                            // a klg_script's block: anything queued interactively comes first, as a launch of its own
 		if (int rc = flush_events(s, st)) return rc;
+		s->ons_total += (unsigned long long)script_events->runs;
 		if (fuse_events && script_events->runs <= KLG_FUSE_MAX_RUNS) ev = *script_events;
 		else if (script_events->runs > 0) { launch_events(s, *script_events, st); HIP_TRY(hipGetLastError()); }
 	}
@@ -892,7 +1030,7 @@ static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipS
 	a.tables = s->d_tables;
 	a.rings = s->d_note_rings; a.ring_rows = s->graph ? (size_t)s->graph->ring_rows : 0;
 	a.solo = nullptr;
-	a.rand = nullptr; a.rand_base = nullptr;
+	a.rand = nullptr; a.rand_base = nullptr; a.rstride = 0;
 	a.ev = ev; a.mix = d_mix; a.mix_channels = 2; a.ticket = small ? s->d_ticket : nullptr;
 	if (prepass) if (int rc = note_prepass(s, a, n, st)) return rc;
 	if (s->mix_mode == KLG_MIX_LAST_ACTIVE) {                      // after this block's events: which voice of each instance is heard
@@ -1096,6 +1234,7 @@ extern "C" int klg_voice_upload(klg_synth* s, int voice, const void* state, size
 	hipLaunchKernelGGL(klg_copy_record, dim3(1), dim3(128), 0, s->stream, s->d_state, s->stride, voice, s->d_scratch_rec, s->W, 1);
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->voices[voice].stage = (uint8_t)(((const uint32_t*)state)[0] & 3u);
+	s->ons_total++;
 	return 0;
 }
 

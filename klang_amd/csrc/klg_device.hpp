@@ -203,7 +203,7 @@ __device__ __forceinline__ float basic_pulse(BOsc& o, float duty) { const float 
 
 // ---- Noise klang.h:4947-4951 (Basic), 5357-5366 (Fast) ----
 // The reference draws from libc rand(), one global sequential stream shared by every voice (F5).  The device
-// functions are the pure arithmetic applied to a rand() result; the stream itself is produced on the host
+// functions are the pure arithmetic applied to a rand() result; the stream itself is produced by klg_rand_fill (klg_rand_dev.hpp)
 // (glibc) and injected, which keeps the reference's exact sequence.
 __device__ __forceinline__ float basic_noise(int r) { return (float)r * 2.f / 2147483648.0f - 1.f; }   // RAND_MAX = 2^31 - 1 -> (float) 2^31
 __device__ __forceinline__ float fast_noise(int r) { return u2f((((uint32_t)r & 0x7FFFu) << 1) | 0x43800000u) - 257.f; }

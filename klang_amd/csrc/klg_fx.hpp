@@ -1853,11 +1853,11 @@ struct FxGraphArgs {
 	const float* controls;                   // [kpad][KLG_MAX_CTL]
 	SampleRate fs;
 	unsigned long long samples;              // samples processed before this block (every delay's write cursor derives from it)
-	const int* rand; int rand_per_instance;  // Noise: this block's rand() values, [K][n * draws per sample] (or null)
+	const int* rand; size_t rstride;         // Noise: the span's rand() values [n * draws per sample][rstride], column = block * K + instance (or null): klg_rand_fill
 	int blocks; size_t block_stride;         // klg_fx_staged only (klg_fx_render_device): a span of `blocks` blocks of n samples in one launch, block b's [K][CH][n] rows
 	                                         // block_stride floats after block b - 1's; prepare() at the head of every block as in Effect::process(buffer).  0 / 1: one block
 };
-struct FxCtx { SampleRate fs; const float* ctl; unsigned long long samples; float* ring; const int* rand; };   // ring: this lane's column of the group's tile; rand: this instance's draws of the block
+struct FxCtx { SampleRate fs; const float* ctl; unsigned long long samples; float* ring; const int* rand; size_t rstride; };   // ring: this lane's column of the group's tile; rand: this instance's column of the block's draws
 __device__ __forceinline__ float ctl_read(const FxCtx& c, unsigned i) { return c.ctl[i]; }
 
 template<class P>
@@ -1874,7 +1874,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_graph(const FxGraphArgs a) {
 	FxCtx c;
 	c.fs = a.fs; c.ctl = a.controls + (size_t)k * KLG_MAX_CTL; c.samples = a.samples;
 	c.ring = a.rings + (size_t)(k / P::kRingRow) * a.ring_rows * P::kRingRow + (k % P::kRingRow);     // (rows of 64 instances: blockIdx.x * ring_rows * 64 + lane)
-	c.rand = a.rand ? a.rand + (size_t)(k < a.K ? k : 0) * (size_t)a.rand_per_instance : nullptr;
+	c.rand = a.rand ? a.rand + (size_t)(k < a.K ? k : 0) : nullptr; c.rstride = a.rstride;
 	P::begin(L, rec, c);
 	const int col = lane & 31, half = lane >> 5;
 	for (int s0 = 0; s0 < a.n; s0 += FX_CHUNK) {

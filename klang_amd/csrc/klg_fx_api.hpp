@@ -45,9 +45,8 @@ struct klg_fx {
 	hipModule_t module = nullptr; hipFunction_t graph_fn = nullptr, staged_fn = nullptr;   // staged_fn: klg_fx_staged of the same code object, when the body has a sample-parallel form
 	int channels = 2;
 	float* d_controls = nullptr; std::vector<float> h_controls; bool controls_dirty = false;
-	// Noise ops: the block's rand() draws, staged through a small ring of pinned buffers (a slot is reused once its copy + kernel are done)
-	enum { RAND_SLOTS = 4 };
-	int* h_rand[RAND_SLOTS] = {}; int* d_rand[RAND_SLOTS] = {}; hipEvent_t rand_done[RAND_SLOTS] = {}; int rand_slot = 0;
+	// Noise ops: the span's rand() draws [n * draws][blocks * K], produced on the device (klg_rand_fill); rand_done: the last launch that read them
+	int* d_rand = nullptr; size_t rand_cap = 0; hipEvent_t rand_done = nullptr; hipStream_t rand_stream = nullptr;
 };
 enum { KLG_PATCH_FXGRAPH = 1001 };
 
@@ -63,7 +62,8 @@ static void fx_free(klg_fx* f) {
 	for (void* p : dev) if (p) (void)hipFree(p);
 	if (f->module) (void)hipModuleUnload(f->module);
 	for (auto e : f->tev) (void)hipEventDestroy(e);
-	for (int i = 0; i < klg_fx::RAND_SLOTS; i++) { if (f->h_rand[i]) (void)hipHostFree(f->h_rand[i]); if (f->d_rand[i]) (void)hipFree(f->d_rand[i]); if (f->rand_done[i]) (void)hipEventDestroy(f->rand_done[i]); }
+	if (f->d_rand) (void)hipFree(f->d_rand);
+	if (f->rand_done) (void)hipEventDestroy(f->rand_done);
 	if (f->stream) (void)hipStreamDestroy(f->stream);
 	delete f;
 }
@@ -320,7 +320,7 @@ static void rv_prepare(klg_fx* f, int k) {
 	bool changed = false;                                                           // Controls::changed() klang.h:1914-1923
 	for (int i = 0; i < 10; i++) if (c[i].value != h.cache[i]) { h.cache[i] = c[i].value; changed = true; }
 	if (!changed) return;
-	srand(272839);                                                                  // random(272839)  Reverb.k:239
+	klg_random_seed(272839);                                                        // random(272839)  Reverb.k:239 (whatever stream a device held is superseded: klg_api.hip RngChain)
 	const float length = c[5].value, size = c[6].value;
 	float dampening1 = c[7].value, dampening2 = c[8].value;
 	const host::Fs& fs = f->fs;
@@ -415,39 +415,41 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st, int b
 	a.io = d_io; a.n = n; a.controls = f->d_controls;
 	a.fs.f = f->fs.f; a.fs.w = f->fs.w; a.fs.timeInc = 1.0f / f->fs.f;
 	a.samples = f->samples;
-	a.rand = nullptr; a.rand_per_instance = 0;
+	a.rand = nullptr; a.rstride = 0;
 	a.blocks = blocks; a.block_stride = (size_t)f->K * (size_t)f->channels * (size_t)n;      // (blocks > 1: fx_span_in_one_launch() said so)
 	const int draws = f->graph->noise_calls;
-	int slot = -1;
 	if (draws > 0) {
-		// Generators::*::Noise call libc rand() once per sample (klang.h:4949, 5363): draw this block's values here, in the order the
-		// reference would with its `K` effect objects in one process — instance 0's whole block, then instance 1's, ...
-		slot = f->rand_slot; f->rand_slot = (slot + 1) % klg_fx::RAND_SLOTS;
-		const size_t per = (size_t)n * (size_t)draws, count = per * (size_t)f->K;
-		if (!f->h_rand[slot]) {
-			RandGuard rg;                                              // allocations must not disturb the stream the draws below come from
-			const size_t cap = (size_t)f->max_block * (size_t)draws * (size_t)f->K * sizeof(int);
-			HIP_TRY(hipHostMalloc((void**)&f->h_rand[slot], cap)); HIP_TRY(hipMalloc((void**)&f->d_rand[slot], cap)); HIP_TRY(hipEventCreateWithFlags(&f->rand_done[slot], hipEventDisableTiming));
+		// Generators::*::Noise call libc rand() once per sample (klang.h:4949, 5363), and the reference's `K` effect objects of one process would draw in the order
+		// they are processed — instance 0's whole block, then instance 1's, ... block after block: (block, instance) is the rank, n * draws values each, produced on
+		// the device from the stream's state (klg_rand_fill): no host draw, no copy.
+		const size_t ranks = (size_t)f->K * (size_t)blocks, rstride = (ranks + 63) / 64 * 64, need = rstride * (size_t)n * (size_t)draws;
+		if (need > f->rand_cap) {
+			RandGuard rg;                                                  // (allocations must not disturb the C library's generator)
+			HIP_TRY(hipStreamSynchronize(st));
+			if (f->rand_done) HIP_TRY(hipEventSynchronize(f->rand_done)); else HIP_TRY(hipEventCreateWithFlags(&f->rand_done, hipEventDisableTiming));
+			if (f->d_rand) (void)hipFree(f->d_rand);
+			f->d_rand = nullptr; f->rand_cap = 0;
+			if (hipMalloc((void**)&f->d_rand, need * sizeof(int)) != hipSuccess) return fail(KLG_ERR_NOMEM, "the Noise generators' draws (%zu instances x blocks, %d samples, %d generators: %.2f GB) could not be allocated", ranks, n, draws, need * 4 / 1e9);
+			f->rand_cap = need;
 		}
-		else HIP_TRY(hipEventSynchronize(f->rand_done[slot]));
-		for (size_t i = 0; i < count; i++) f->h_rand[slot][i] = rand();
-		HIP_TRY(hipMemcpyAsync(f->d_rand[slot], f->h_rand[slot], count * sizeof(int), hipMemcpyHostToDevice, st));
-		a.rand = f->d_rand[slot]; a.rand_per_instance = (int)per;
+		else if (f->rand_stream != st) HIP_TRY(hipStreamWaitEvent(st, f->rand_done, 0));   // (the buffer's last reader ran on another stream)
+		if (int rc = rng_fill(f->device, st, f->d_rand, rstride, nullptr, (unsigned)ranks, (unsigned)ranks, n * draws)) return rc;
+		a.rand = f->d_rand; a.rstride = rstride;
 	}
 	void* params[] = { &a };
 	// G instances x C samples per workgroup, level by level (klg_graph_staged.hpp) — or, for a body that has no such form (Compiled::staged_why), one lane per
 	// instance walking the samples in order.  Same bits either way (tests/test_gpu_fx_facade.py runs both).
 	if (f->staged_fn) { TimedLaunch timed(f); HIP_TRY(klg_module_launch(f->staged_fn, (unsigned)(f->kpad / (size_t)f->graph->staged_G), (unsigned)f->graph->staged_threads, (unsigned)f->graph->staged_lds, st, params)); }
 	else { TimedLaunch timed(f); HIP_TRY(klg_module_launch(f->graph_fn, (unsigned)(f->kpad / FX_WG), FX_WG, 0, st, params)); }
-	if (slot >= 0) HIP_TRY(hipEventRecord(f->rand_done[slot], st));
+	if (draws > 0) { HIP_TRY(hipEventRecord(f->rand_done, st)); f->rand_stream = st; }
 	f->samples += (unsigned long long)n * (unsigned long long)blocks;
 	return 0;
 }
-// Can a span of blocks of n samples go out as ONE launch?  The staged form of a recorded effect walks the blocks itself (prepare() at the head of each; not with
-// Noise: the draws are made per block on the host).  PingPong's pipelined kernel takes the span as one long block (PingPong.k's prepare() only sets the DC filters
+// Can a span of blocks of n samples go out as ONE launch?  The staged form of a recorded effect walks the blocks itself (prepare() at the head of each; a
+// span's Noise draws are made by one klg_rand_fill ahead of it).  PingPong's pipelined kernel takes the span as one long block (PingPong.k's prepare() only sets the DC filters
 // and no dial moves inside a span): blocks of whole chunks.  Reverb's kernel stages a whole block in LDS: it stays a launch (two) per block.
 static bool fx_span_in_one_launch(const klg_fx* f, int n) {
-	if (f->graph) return f->staged_fn != nullptr && f->graph->noise_calls == 0;
+	if (f->graph) return f->staged_fn != nullptr;
 	if (f->patch != KLG_PATCH_PINGPONG) return false;
 	const char* e1 = getenv("KLG_FX_PINGPONG1"); const char* e2 = getenv("KLG_FX_ABLATE");
 	return n % PPX_CHUNK == 0 && !(e1 && e1[0] == '1') && !(e2 && atoi(e2));
@@ -613,7 +615,8 @@ extern "C" int klg_fx_render_device(klg_fx* f, float* d_io, int blocks, int n, v
 	const size_t stride = (size_t)f->K * (size_t)f->channels * (size_t)n;
 	if (blocks > 1 && fx_span_in_one_launch(f, n)) {
 		// (the cursor arithmetic of a launch is 32-bit from the start of its span: spans of at most 2^20 samples per launch)
-		const int per = std::max(1, (1 << 20) / n);
+		int per = std::max(1, (1 << 20) / n);
+		if (f->graph && f->graph->noise_calls > 0) per = (int)std::max<size_t>(1, std::min<size_t>((size_t)per, ((size_t)64 << 20) / ((size_t)n * (size_t)f->graph->noise_calls * (size_t)f->K)));   // (... and their draws in at most 256 MB)
 		for (int b = 0; b < blocks; b += per) if (int rc = fx_enqueue(f, d_io + (size_t)b * stride, n, st, std::min(per, blocks - b))) return rc;
 		return 0;
 	}

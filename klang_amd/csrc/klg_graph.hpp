@@ -432,7 +432,10 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			for (const Op* ph : phis_of(if_of[oi])) body += fmt("\t\tr%d = r%d;\n", ph->dst, ph->b);
 			body += "\t\t}\n";
 			break;
-		case OP_NOISE: body += d + (o.imm ? "fast_noise(" : "basic_noise(") + fmt("c.rand[L.sidx * %d + %d]);\n", noise_calls, noise_index[oi]); break;
+		case OP_NOISE:                                                    // effects: straight from the block's draws; notes: from the wave's LDS copy of this group of samples (klg_render)
+			if (fx) body += d + (o.imm ? "fast_noise(" : "basic_noise(") + fmt("c.rand[(size_t)(L.sidx * %d + %d) * c.rstride]);\n", noise_calls, noise_index[oi]);
+			else body += d + (o.imm ? "fast_noise(" : "basic_noise(") + fmt("c.nz[((L.sidx & (KLG_NZ_GROUP - 1)) * %d + %d) * 64]);\n", noise_calls, noise_index[oi]);
+			break;
 		case OP_DELAYOUT:
 			if (hoist_of[oi] >= 0) body += d + "delay_process_h(" + ring(o.node) + ", " + n + fmt("t, h%d, h%da, h%db, ", hoist_of[oi], hoist_of[oi], hoist_of[oi]) + hazard_of(hoist_of[oi]) + ");\n";
 			else body += d + "delay_process(" + ring(o.node) + ", " + n + "t);\n";
@@ -506,7 +509,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		s += " }; return ((m[w >> 6] >> (w & 63)) & 1ull) != 0; }\n";
 	}
 	s += live;
-	if (!fx && noise_calls) { begin += "\t\tL.sidx = 0;\n"; body += "\t\tL.sidx++;\n"; }   // a voice's draws of the block: [sample][Noise generator in process() order]
+	if (!fx && noise_calls) { begin += "\t\tL.sidx = 0;\n"; body += "\t\tL.sidx++;\n"; s += fmt("\tstatic constexpr int kNoiseDraws = %d;\n", noise_calls); }   // a voice's draws of the block: [sample][Noise generator in process() order]
 	if (!fx) {
 		// delay lines in notes: a wave keeps 64 voices x (read head, tap, write) x one 64-byte sector live while it walks its lines; at full
 		// occupancy the waves of an XCD hold more live sectors than its 4 MB L2 and every access becomes an HBM sector.  One wave per SIMD

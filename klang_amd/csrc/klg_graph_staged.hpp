@@ -887,8 +887,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "\tunsigned long long samples0 = a.samples; float* io = a.io;                // of the block being processed (a span: klg_fx_render_device)\n";
 		s += "\tcp.ctl = a.controls + (size_t)(k0 + pg) * KLG_MAX_CTL; cs.ctl = a.controls + (size_t)(k0 + sg) * KLG_MAX_CTL;\n";
 		s += "\tfloat* const ring0 = a.rings + (size_t)blockIdx.x * a.ring_rows * G;             // this workgroup's ring tile: [line][position][G]\n\tcp.ring = ring0 + pg; cs.ring = ring0 + sg;\n";
-		s += "\tcp.rand = a.rand ? a.rand + (size_t)(k0 + pg < a.K ? k0 + pg : 0) * (size_t)a.rand_per_instance : nullptr;\n";
-		s += "\tcs.rand = a.rand ? a.rand + (size_t)(k0 + sg < a.K ? k0 + sg : 0) * (size_t)a.rand_per_instance : nullptr;\n";
+		s += "\tcp.rand = cs.rand = nullptr; cp.rstride = cs.rstride = a.rstride;\n";
 		s += "\tP::Live Lp, Lq, Ls;\n\tLp.unused_ = 0; Lp.sidx = 0; Lq.unused_ = 0; Lq.sidx = 0; Ls.unused_ = 0; Ls.sidx = 0;\n";
 		s += "\t__syncthreads();\n";
 		// the plain body over [from, from + count) of the block, on one lane per instance (wave 0): prepare() at the head of the block, chunks whose check failed, a ragged tail
@@ -901,6 +900,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "\t\tP::end(L, rec);\n#pragma unroll\n\t\tfor (int w = 0; w < NW; w++) if (patch_stores<P>(w)) srec[w * G + ln] = rec.w[w];\n\t};\n";
 		s += "\tconst int nblk = a.blocks > 1 ? a.blocks : 1;\n\tfor (int blk = 0; blk < nblk; blk++) {                                          // Effect::process(buffer), block after block (klang.h:4208-4216)\n";
 		s += "\tsamples0 = a.samples + (unsigned long long)blk * (unsigned long long)a.n; io = a.io + (size_t)blk * a.block_stride; cp.samples = cs.samples = samples0;\n";
+		s += "\tif (a.rand) { cp.rand = a.rand + (size_t)blk * (size_t)a.K + (size_t)(k0 + pg < a.K ? k0 + pg : 0); cs.rand = a.rand + (size_t)blk * (size_t)a.K + (size_t)(k0 + sg < a.K ? k0 + sg : 0); }   // this block's columns of the span's draws\n";
 		if (g.prepare_ops > 0) s += "\tplain(0, 0, true);                                                           // Effect::prepare(): once per block\n\t__syncthreads();\n";
 		if (pipelined) s += "\tfor (int i = t; i < NW * G; i += NT) { srecp[i] = srec[i]; srecp[NW * G + i] = srec[i]; }\n\t__syncthreads();\n";
 		// what the lanes hold for the whole block: the dials, the members process() only reads

@@ -51,8 +51,9 @@ struct RenderArgs {
 	float* rings;             // note delays: [stride + 1][ring_rows] (the last line is the dead lanes' scratch) — each voice's lines contiguous (a generated patch's Delay members), or null
 	size_t ring_rows;         // ring positions per voice = the sum of the patch's Delay SIZEs
 	const int* solo;          // KLG_MIX_LAST_ACTIVE: [synths] the one voice of each instance that is heard this block (-1: none), else null
-	const int* rand;          // Noise generators of a generated patch: this block's libc rand() values, drawn on the host in the reference's call order
-	const int* rand_base;     // ... [voices] where a sounding voice's n * draws values start (lanes without a sounding voice read from 0), else null
+	const int* rand;          // Noise generators of a generated patch: this block's rand() values [n * draws][rstride ranks], produced on the device in the reference's call order (klg_rand_dev.hpp)
+	const int* rand_base;     // ... [voices] a sounding voice's rank = its column (lanes without a sounding voice read column 0), else null
+	size_t rstride;
 	// ONE LAUNCH PER BLOCK for banks of a few workgroups (a plugin's own synth: <= 128 notes, klang.h:4311), where three more launches cost as much as
 	// the render itself: (1) ev.runs > 0 — every workgroup first applies the block's event runs of ITS OWN voices (what klg_apply_events does as
 	// a launch); (2) ticket != null — the workgroup that finishes last adds all partial rows to `mix` in row order (what klg_reduce does as a
@@ -105,6 +106,10 @@ template<class P> struct HasQuiet<P, klg_void_t<decltype(P::kHasQuiet)>> { stati
 // packed operations across the sample pair, PatchFM)
 template<class P, class = void> struct HasFast2 { static constexpr bool value = false; };
 template<class P> struct HasFast2<P, klg_void_t<decltype(P::kHasFast2)>> { static constexpr bool value = P::kHasFast2; };
+
+// a patch with Noise generators: `static constexpr int kNoiseDraws` = rand() draws per sample (generated patches)
+template<class P, class = void> struct NoiseDraws { static constexpr int value = 0; };
+template<class P> struct NoiseDraws<P, klg_void_t<decltype(P::kNoiseDraws)>> { static constexpr int value = P::kNoiseDraws; };
 
 // a patch whose sample() returns both channels of a Stereo::Note's `out` (Out2): `static constexpr bool kStereo = true`
 template<class P, class = void> struct IsStereo { static constexpr bool value = false; };
@@ -160,6 +165,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 	float* tile = lds + wave * CHUNK * TILE_LD;
 	const int n = a.n;
 	float* acc = klg_mix_rows + wave * n * NC;               // this wave's own mix row(s): [channel][n]
+	// Noise generators: the draws of KLG_NZ_GROUP samples at a time, from the block's [index][rank] array into the wave's [index][lane] LDS copy — the group's
+	// loads are all under way together (one memory round trip per group; read one by one where they are used, each sample waits out its own)
+	constexpr int ND = NoiseDraws<P>::value;
+	__shared__ int nz_lds[ND > 0 ? WAVES * KLG_NZ_GROUP * ND * 64 : 1];
+	static_assert(CH % KLG_NZ_GROUP == 0, "a chunk is a whole number of Noise groups");
 
 	for (int i = lane; i < n * NC; i += 64) acc[i] = 0.f;
 	wave_sync();
@@ -192,7 +202,22 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 		// one scratch line behind the last voice's (line index `stride`), so an Off voice's own line keeps its contents like the reference's
 		ctx.ring = a.rings ? a.rings + (size_t)(live ? (size_t)v : a.stride) * a.ring_rows : nullptr;
 		ctx.ctl = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
-		ctx.rand = a.rand ? a.rand + (live ? a.rand_base[v] : 0) : nullptr;
+		ctx.rand = a.rand ? a.rand + (live ? a.rand_base[v] : 0) : nullptr; ctx.rstride = a.rstride;
+		ctx.nz = nz_lds + wave * (KLG_NZ_GROUP * (ND > 0 ? ND : 1) * 64) + lane;
+		int* const nz_mine = nz_lds + wave * (KLG_NZ_GROUP * (ND > 0 ? ND : 1) * 64) + lane;
+		// (only this lane ever touches its column, LDS operations of a wave complete in order: no barrier.  The last group of a block reads up to
+		//  KLG_NZ_GROUP - 1 samples' rows beyond the block: the array has that many spare rows, klg_api.hip note_prepass)
+		auto nz_stage = [&](int sample) {
+			if constexpr (ND > 0) {
+				if ((sample & (KLG_NZ_GROUP - 1)) != 0) return;
+				const int* src = ctx.rand + (size_t)sample * ND * a.rstride;
+				int t[KLG_NZ_GROUP * ND];
+#pragma unroll
+				for (int i = 0; i < KLG_NZ_GROUP * ND; i++) t[i] = src[(size_t)i * a.rstride];
+#pragma unroll
+				for (int i = 0; i < KLG_NZ_GROUP * ND; i++) nz_mine[i * 64] = t[i];
+			}
+		};
 		ctx.rec = a.state + v; ctx.stride = a.stride;             // (v < stride always: a lane without a voice points at padding or at an Off voice's words, and nothing it computes is kept)
 		// Dead lanes of a live wave run the same instruction stream on an all-zero record (no per-sample exec
 		// masking); their output is forced to 0 at the tile write and their record is never stored.
@@ -225,13 +250,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WavesPerEu<P
 					if (s < cl) put(s, P::sample_fast(L, ctx));
 				}
 				else if constexpr (HasQuiet<P>::value)
-					for (int s = 0; s < cl; s++) put(s, P::sample_fast(L, ctx));
+					for (int s = 0; s < cl; s++) { nz_stage(c0 + s); put(s, P::sample_fast(L, ctx)); }
 			}
 			else if (quiet == 1) {
 				if constexpr (HasQuiet<P>::value)
-					for (int s = 0; s < cl; s++) put(s, P::sample_quiet(L, ctx));
+					for (int s = 0; s < cl; s++) { nz_stage(c0 + s); put(s, P::sample_quiet(L, ctx)); }
 			}
-			else for (int s = 0; s < cl; s++) put(s, P::sample(L, ctx));
+			else for (int s = 0; s < cl; s++) { nz_stage(c0 + s); put(s, P::sample(L, ctx)); }
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -22,12 +22,15 @@ namespace klg {
 // a Stereo::Note's sample (klang.h:4721-4733: `out` is a stereo signal, `buffer++ += out`): what sample() of a patch with kStereo returns
 struct Out2 { float l, r; };
 
+enum { KLG_NZ_GROUP = 8 };   // Noise draws are fetched this many samples at a time (one dependent memory round trip per group instead of one per sample)
+
 struct BlockCtx {
 	SampleRate fs;
 	const float* ctl;        // this voice's synth instance controls [KLG_MAX_CTL]
 	const TableDesc* tables; // klg_table_upload()ed sample tables (graph patches with Wavetable / Table reads), else null
 	float* ring;             // this voice's note-delay lines (contiguous), else null
-	const int* rand;         // this voice's rand() draws of the block, [n][draws per sample] (a generated patch with Noise generators), else null
+	const int* rand; size_t rstride;   // this voice's column of the block's rand() draws: rand[(sample * draws per sample + generator) * rstride] (a generated patch with Noise generators), else null
+	const int* nz;           // ... and the lane's column of the wave's LDS copy of the current KLG_NZ_GROUP samples' draws: nz[((sample % KLG_NZ_GROUP) * draws per sample + generator) * 64] (klg_render stages them)
 	const uint32_t* rec;     // this voice's record in HBM: word w at rec[w * stride] (what a patch reads only when a segment ends need not sit in registers: PtsLazy*)
 	size_t stride;
 };

@@ -90,3 +90,62 @@ def test_a_span_of_blocks_equals_block_by_block(kind, n, spans):
         for k in (0, 1, K - 1):
             assert np.array_equal(a.download_record(k), b.download_record(k))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("kind,width", [("pingpong", 16), ("pingpong", 32), ("pingpong", 64), ("pingpong_recorded", 0)])
+def test_stationary_spans_after_convergence(kind, width, oracle_build, monkeypatch):
+    """The path the cfg-4 bench legs time: a span on a bank whose dials have been still for so long that both Control::smooth chains sit at their fp32 fixed
+    points (klang.h:1708, 1715: some ten thousand samples from a fresh object) — klg_fx_pingpong_x then takes the span as ONE launch whose request-ahead
+    pipeline runs across the block boundaries, in groups of steps without run-time guards (klg_fx.hpp; for the recorded PingPong.k: the staged kernel walking
+    the blocks).  Two banks, 80 blocks of 256 block by block on both; then spans of 24 and 64 blocks on one, the same blocks one by one on the other: bit for
+    bit, every block; and blocks of both spans against the oracle.  70 instances: in one workgroup an instance at 3 ms (taps too near to run ahead), in another
+    one at 1 ms — the shortest the dial allows: half-far chunks — and 1.5 / 2 ms; the other workgroups run ahead.  Every workgroup width."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from klg_driver import run_scenario_oracle
+    from scenario_io import Scenario, fx_input
+    if width: monkeypatch.setenv("KLG_FX_PINGPONG_G", str(width))
+    K, n, warm, spans = 70, 256, 80, (24, 64)
+    B = warm + sum(spans)
+    dump = [0, warm - 1, warm, warm + 5, warm + spans[0] - 1, warm + spans[0], warm + spans[0] + 40, B - 1]
+    s = Scenario(patch="pingpong", block=n, blocks=B, instances=K, burst=B * n, seed=23, dump=dump)
+    rng = np.random.default_rng(17)
+    near = {3: 0.003, 17: 0.001, 40: 0.0015, 41: 0.002}
+    for k in range(K):
+        s.control(0, k, 0, float(rng.uniform(0.2, 0.9)))
+        t = near.get(k, float(rng.uniform(0.02, 0.6)))
+        s.control(0, k, 1, t if k in near else float(rng.uniform(0.02, 0.6)))
+        s.control(0, k, 5, t)
+        s.control(0, k, 4, float(rng.uniform(0.3, 1.0)))
+    s.sort()
+    a, CH = make(kind, K, n)
+    b, _ = make(kind, K, n)
+    for bank in (a, b):
+        for (_blk, _ty, inst, idx, val, _seed) in s.ev:
+            bank.set_control(inst, int(idx), val)
+    t = np.arange(B * n, dtype=np.uint64)
+    x = np.empty((K, 2, B * n), np.float32)
+    for k in range(K):
+        for ch in range(2):
+            x[k, ch] = fx_input(s.seed, k, ch, t, s.burst)
+    x = np.ascontiguousarray(x.reshape(K, 2, B, n).transpose(2, 0, 1, 3))          # [block][instance][channel][n]
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ya, yb = torch.from_numpy(x).cuda(), torch.from_numpy(x).cuda()
+        for blk in range(warm):
+            a.process_device(ya[blk].data_ptr(), n, st.cuda_stream); b.process_device(yb[blk].data_ptr(), n, st.cuda_stream)
+        at = warm
+        for blocks in spans:
+            a.render_device(ya[at].data_ptr(), blocks, n, st.cuda_stream)
+            for blk in range(at, at + blocks):
+                b.process_device(yb[blk].data_ptr(), n, st.cuda_stream)
+            at += blocks
+        st.synchronize()
+    bad = (ya.view(torch.int32) != yb.view(torch.int32)).nonzero()
+    assert len(bad) == 0, f"{len(bad)} samples differ between spans and single blocks, first [block, instance, channel, sample] {bad[0].tolist()}"
+    ref = run_scenario_oracle(s, oracle_build)["per_voice"]                         # [dumped block][instance][channel][n]
+    got = ya.cpu().numpy()[dump]
+    wrong = [dump[i] for i in range(len(dump)) if not np.array_equal(got[i].view(np.uint32), ref[i].view(np.uint32))]
+    assert not wrong, f"blocks {wrong} differ from the oracle, max abs err {np.abs(got - ref).max()}"
+    assert np.abs(got[-1]).max() > 1e-3
+    a.close(); b.close()

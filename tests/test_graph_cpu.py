@@ -161,12 +161,12 @@ def test_noise_draws_are_indexed_per_sample_and_stay_outside_branches():
     ok = "klgg 1\nkind effect 1\nctl 0\nop noise 0 -1 -1 -1 1\nop noise 1 -1 -1 -1 0\nop add 2 0 1 -1 0\nret 2\nend\n"
     rc, src = check(ok, want_source=True)
     assert rc == 0, src
-    assert "fast_noise(c.rand[L.sidx * 2 + 0])" in src and "basic_noise(c.rand[L.sidx * 2 + 1])" in src and "L.sidx++;" in src
+    assert "fast_noise(c.rand[(size_t)(L.sidx * 2 + 0) * c.rstride])" in src and "basic_noise(c.rand[(size_t)(L.sidx * 2 + 1) * c.rstride])" in src and "L.sidx++;" in src
     # ... and a Note's: its voice's draws of the block are [sample][generator]; the three bodies all count samples; one voice per lane
     rc, src = check(ok.replace("kind effect 1\n", ""), want_source=True)
     assert rc == 0, src
     assert "struct Live { int stage; float tinc; int sidx;" in src and "L.sidx = 0;" in src and src.count("L.sidx++;") == 3
-    assert "fast_noise(c.rand[L.sidx * 2 + 0])" in src and "klg_render_x2<" not in src
+    assert "fast_noise(c.nz[((L.sidx & (KLG_NZ_GROUP - 1)) * 2 + 0) * 64])" in src and "kNoiseDraws = 2" in src and "klg_render_x2<" not in src
     branchy = "klgg 1\nkind effect 1\nctl 0\nop in 0 -1 -1 -1 0\nop cmp 1 0 0 -1 1\nop if -1 1 -1 -1 0\nop noise 2 -1 -1 -1 1\nop endif -1 -1 -1 -1 0\nret 0\nend\n"
     rc, msg = check(branchy)
     assert rc < 0 and "inside an `if`" in msg
