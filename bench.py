@@ -36,6 +36,7 @@ FLOPS_PER_VOICE_SAMPLE = {"sub2a": 21, "sub2b": 120, "supersaw": 120, "fm4": 95,
 # algorithmic HBM bytes per voice per block: record read + words written back (klang_amd/csrc/klg_patches.hpp)
 STORE_WORDS = {"sub2a": 8, "sub2b": 19, "supersaw": 12, "fm3": 20, "fm4": 25, "sine": 2}
 FX_BYTES_PER_SAMPLE = {"pingpong": 32, "reverb": 312}     # SURVEY.md §8(d) algorithmic bytes per instance*sample
+PATCH_ID = {"sine": 0, "bsine": 1, "sub2a": 2, "sub2b": 3, "supersaw": 4, "fm3": 5, "fm4": 6}          # include/klang_mi355.h klg_patch
 NOTES = {"sub2a": 128, "sine": 128, "bsine": 128}          # note slots per Synth instance (others: 32)
 SCRIPT_BLOCKS, OFF_BLOCK, OFF_SPREAD = 375, 150, 64        # SURVEY §8(d) cfg 2: 2 s, note-off at 150 + (v mod 64)
 # blocks a voice still sounds after its note-off: ceil(release time * 48000 / 256) — sub2a 0.25 s + 5 ms = 12240 samples, SuperSaw.k 0.5 s + 5 ms, FM 1 s + 5 ms
@@ -391,7 +392,7 @@ def run_literal_script(patch, voices, N, label, phases=False):
     return res
 
 
-def run_fx(patch, K, N, dials=None, tag="", args=None):
+def run_fx(patch, K, N, dials=None, tag="", args=None, per_block=False):
     """cfg 4: K instances, 375 blocks (2 s): a white-noise burst for the first 4800 samples, then silence; io resident in HBM.
     The blocks are submitted as SPANS (klg_fx_render_device: the host knows all its blocks — the effect template's callback,
     templates/juce/effect/Source/PluginProcessor.cpp:153-178, called span after span): the span's [blocks][K][2][N] buffer is filled (burst or
@@ -413,6 +414,8 @@ def run_fx(patch, K, N, dials=None, tag="", args=None):
     span = next(d for d in (75, 25, 15, 5, 3, 1) if d * block_bytes <= (2 << 30) or d == 1)   # the script's first fifth (75 blocks): spans of a third of this (below)
     # the other four fifths: as few spans as 4 GB of io allow (a host that renders offline hands over what it has; 4,096 instances: all 300 blocks in one call)
     rest_span = next(d for d in (300, 150, 75, 25, 15, 5, 3, 1) if d * block_bytes <= (4 << 30) or d == 1)
+    if per_block:                                    # one block per call, as a real-time host hands them over (klg_fx_process_device: nothing runs across a block boundary)
+        span = rest_span = 1
     io = torch.zeros((rest_span, K, 2, N), device="cuda")
     torch.cuda.synchronize()
     ts = torch.cuda.Stream()
@@ -432,7 +435,10 @@ def run_fx(patch, K, N, dials=None, tag="", args=None):
             io[:take].zero_()                                               # the host's next input: silence ...
             if b0 < burst_blocks:
                 nb = min(take, burst_blocks - b0); io[:nb].copy_(inputs[b0:b0 + nb])   # ... or the burst
-            bank.render_device(io.data_ptr(), take, N, st)
+            if per_block:
+                bank.process_device(io.data_ptr(), N, st)
+            else:
+                bank.render_device(io.data_ptr(), take, N, st)
             b0 += take
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -442,9 +448,9 @@ def run_fx(patch, K, N, dials=None, tag="", args=None):
     ab = K * N * FX_BYTES_PER_SAMPLE[patch]
     kernel = ("klg_fx_reverb_q" if patch == "reverb" and K <= 8192 else KERNEL_OF[patch])
     traffic, how = None, "not collected"
-    if args is not None and os.environ.get("KLG_BENCH_PMC_FX", "1") != "0":
-        spec = f"{patch}:{K}:" + ("random7" if dials == "random7" else ",".join(f"{c}={v}" for c, v in (dials or {}).items()))
-        one_launch = patch == "pingpong"
+    spec = f"{patch}:{K}:" + ("random7" if dials == "random7" else ",".join(f"{c}={v}" for c, v in (dials or {}).items()))
+    one_launch = patch == "pingpong"
+    if args is not None and os.environ.get("KLG_BENCH_PMC_FX", "1") != "0" and not per_block:
         traffic, how = pmc_traffic_live(args, kernel, timeout_s=180, child_args=["--pmc-fx", spec, "--block", str(N)], blocks_per_launch=PMC_FX_SPAN if one_launch else 1)
     roof = {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": how,
             "kernel": kernel, "algorithmic_bytes_per_launch": ab, "bytes_per_instance_sample": FX_BYTES_PER_SAMPLE[patch], "per": "block of %d samples (a PingPong span of %d blocks is ONE launch: its duration / %d)" % (N, rest_span, rest_span),
@@ -460,6 +466,65 @@ def run_fx(patch, K, N, dials=None, tag="", args=None):
     res = {"name": f"cfg4_{patch}_{K}{tag}", "workload": (("one instance in seven with random dials: " if dials == "random7" else f"dials {dials}: ") if dials else "") + f"{K} x {patch.capitalize()}.k (Stereo::Effect), {SCRIPT_BLOCKS} blocks of {N} samples in spans of {span} (klg_fx_render_device): noise burst 4800 samples then silence, io + {bank.state_bytes * K / 1e9:.1f} GB of delay lines resident in HBM",
            "value": K * N * SCRIPT_BLOCKS / dt, "unit": "instance*samples/s", "ms_per_step": 1e3 * dt / SCRIPT_BLOCKS, "steps": SCRIPT_BLOCKS, "kernel_ms_mean": 1e3 * kern_s, "blocks_per_span": rest_span, "blocks_per_span_in_the_first_fifth": max(1, span // 3),
            "finite": bool(torch.isfinite(io).all().item()), "roofline": roof}
+    bank.close()
+    return res
+
+NOISE_NOTE_PROGRAM = """klgg 1
+ctl 0
+node 0 lpf
+op noise 0 -1 -1 -1 1
+op lpf 1 0 -1 0 0
+op noise 2 -1 -1 -1 0
+op const 3 -1 -1 -1 3dcccccd
+op mul 4 2 3 -1 0
+op add 5 1 4 -1 0
+ret 5
+end
+"""
+
+
+def run_noise_notes(voices, N, blocks=200):
+    """Notes with Noise generators (SURVEY §8 a9; klang.h:4947-4951, 5357-5366): `hiss >> lpf` + `grit * 0.1` — a Fast::Noise through a biquad and a Basic::Noise,
+    two rand() draws per voice and sample, all voices sounding.  The draws come from the C library's sequence continued ON THE DEVICE (klg_rand_fill), in the order
+    Synth::process walks the notes.  ms per block as a real-time host sees it (a call and a wait per block) and queued back to back."""
+    import torch
+    import klang_amd
+    P = 128
+    bank = klang_amd.SynthBank(NOISE_NOTE_PROGRAM, synths=max(1, voices // P), notes=min(P, voices), max_block=N)
+    V, W = bank.voices, bank.state_bytes // 4
+    words = np.zeros((V, W), np.uint32)
+    words[:, 0] = 1
+    words[:, 1:6] = np.array([0.02, 0.04, 0.02, -1.56, 0.64], np.float32).view(np.uint32)
+    bank.voices_upload(np.arange(V, dtype=np.int32), words)
+    bank.random(1)
+    mix = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        st = ts.cuda_stream
+        for _ in range(5):
+            mix.zero_(); bank.process_device(mix.data_ptr(), N, st)
+        torch.cuda.synchronize()
+        w = np.empty(blocks)
+        for b in range(blocks):
+            t0 = time.perf_counter()
+            mix.zero_(); bank.process_device(mix.data_ptr(), N, st); torch.cuda.synchronize()
+            w[b] = 1e3 * (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        for _ in range(blocks):
+            mix.zero_(); bank.process_device(mix.data_ptr(), N, st)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        bank.timing_begin()
+        for _ in range(blocks):
+            mix.zero_(); bank.process_device(mix.data_ptr(), N, st)
+        torch.cuda.synchronize()
+        aux_l, aux_ms = bank.timing_end_aux()
+        l, kms = bank.timing_end()
+    res = {"name": f"noise_note_{V}", "workload": f"{V} notes of Fast::Noise >> LPF + Basic::Noise (2 rand() per voice and sample, drawn on the device in Synth::process order), {blocks} blocks of {N} samples",
+           "value": V * N * blocks / dt, "unit": "voice*samples/s", "ms_per_step": 1e3 * dt / blocks, "steps": blocks, "kernel_ms_mean": kms / max(1, l),
+           "ms_per_block_with_wait_median": float(np.median(w)), "ms_per_block_with_wait_max": float(w.max()), "aux_kernels_ms_per_block": aux_ms / blocks,
+           "draws_per_s": 2.0 * V * N * blocks / dt, "finite": bool(torch.isfinite(mix).all().item()),
+           "round_4": "the same bank with round 4's library (rand() on the host + a device round trip per block): 5.14 ms per block at 1,024 voices, 82 ms at 16,384 (profiles/r05/noise_bench_ab_first.jsonl, same box)"}
     bank.close()
     return res
 
@@ -490,25 +555,50 @@ def run_realtime(patch, voices, N, blocks=2000, name="realtime_deadline"):
     torch.cuda.set_stream(ts)
     st = ts.cuda_stream
     mix.zero_(); script.play_device(0, mix.data_ptr(), N, st); torch.cuda.synchronize()
-    t = np.empty(blocks)
-    for b in range(blocks):
-        t0 = time.perf_counter()
-        mix.zero_(); bank.process_device(mix.data_ptr(), N, st); torch.cuda.synchronize()
-        t[b] = 1e3 * (time.perf_counter() - t0)
-    mix.zero_(); script.play_device(1, mix.data_ptr(), N, st); torch.cuda.synchronize()
-    r = np.empty(44)
-    for b in range(44):
-        t0 = time.perf_counter()
-        mix.zero_(); bank.process_device(mix.data_ptr(), N, st); torch.cuda.synchronize()
-        r[b] = 1e3 * (time.perf_counter() - t0)
+    import gc
+    gc_was = gc.isenabled()
+    gc.collect(); gc.disable()                                                 # (the interpreter's collector must not run inside a timed block)
+    try:
+        t = np.empty(blocks)
+        for b in range(blocks):
+            t0 = time.perf_counter()
+            mix.zero_(); bank.process_device(mix.data_ptr(), N, st); torch.cuda.synchronize()
+            t[b] = 1e3 * (time.perf_counter() - t0)
+        mix.zero_(); script.play_device(1, mix.data_ptr(), N, st); torch.cuda.synchronize()
+        r = np.empty(44)
+        for b in range(44):
+            t0 = time.perf_counter()
+            mix.zero_(); bank.process_device(mix.data_ptr(), N, st); torch.cuda.synchronize()
+            r[b] = 1e3 * (time.perf_counter() - t0)
+    finally:
+        if gc_was:
+            gc.enable()
     deadline = 1e3 * N / 48000.0
+    order = np.argsort(-t)[:10]
     res = {"name": name, "workload": f"{patch}: {V} voices, {blocks} consecutive blocks of {N} samples, each block synchronised (host wall clock per block)",
            "voices": V, "deadline_ms": deadline, "attack_decay_max_ms": float(t[:22].max()), "sustain_p50_ms": float(np.median(t[30:])), "p99_ms": float(np.percentile(t, 99)), "max_ms": float(t.max()),
+           "worst_block": int(order[0]), "ten_largest": [[int(i), float(t[i])] for i in order],
            "release_all_ramping_p99_ms": float(np.percentile(r, 99)), "release_max_ms": float(r.max()),
            "worst_block_ms": float(max(t.max(), r.max())), "worst_block_frac_of_deadline": float(max(t.max(), r.max()) / deadline),
            "every_block_within_90_percent_of_the_deadline": bool(max(t.max(), r.max()) <= 0.9 * deadline),
-           "realtime": bool(np.percentile(t, 99) <= deadline and np.percentile(r, 99) <= deadline), "unit": "ms per block", "value": float(np.percentile(t, 99))}
+           "realtime": bool(np.percentile(t, 99) <= deadline and np.percentile(r, 99) <= deadline), "unit": "ms per block", "value": float(np.percentile(t, 99)),
+           "host": "this Python process (ctypes call + torch.cuda.synchronize per block, garbage collector off)"}
     script.close(); bank.close()
+    del mix
+    torch.cuda.empty_cache()
+    # the same loop from a host that is not an interpreter (klang_amd/host/klang_deadline.cpp: pinned, memory locked, nothing allocates in the loop)
+    exe = os.path.join(ROOT, "klang_amd", "host", "klang_deadline")
+    if os.path.exists(exe) and patch in PATCH_ID:
+        try:
+            p = subprocess.run([exe, "--voices", str(V), "--blocks", str(blocks), "--n", str(N), "--patch", str(PATCH_ID[patch]), "--notes", str(notes)], capture_output=True, text=True, timeout=900)
+            res["c_host"] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else {"error": (p.stderr or p.stdout)[-300:]}
+        except Exception as e:                                                # noqa: BLE001
+            res["c_host"] = {"error": f"{type(e).__name__}: {e}"}
+        c = res["c_host"]
+        if "max_ms" in c:                                                     # the claim is about the product's own host loop; the interpreter's figures stay beside it
+            res["every_block_within_90_percent_of_the_deadline_python_loop"] = res["every_block_within_90_percent_of_the_deadline"]
+            res["every_block_within_90_percent_of_the_deadline"] = bool(c["every_block_within_90_percent_of_the_deadline"])
+            res["every_block_within_90_percent_of_the_deadline_source"] = "c_host (klang_deadline: C++ loop over klg_process_device + hipStreamSynchronize, pinned, memory locked)"
     return res
 
 
@@ -754,7 +844,27 @@ def main():
             leg(run_realtime, "sub2a", args.realtime_voices, N)
             # ... and the largest bank (to the nearest 4 Mi voices) whose WORST block — attack, sustain or the all-voices release — stays within 90 % of the deadline
             leg(run_realtime, "sub2a", args.realtime_margin_voices, N, name="realtime_deadline_with_margin")
+            leg(run_fx, "pingpong", 4096, N, tag="_block_by_block", per_block=True)   # the same bank handed over one block per call (a real-time host): nothing runs across a block boundary
+            leg(run_noise_notes, 16384, N)
             out["configs"] = configs
+            # every leg's roofline in the object the driver keeps: name -> [frac of the bound's peak, kernel ms per block, HBM traffic / algorithmic bytes (PMC) or null,
+            # frac on the distinct bytes (Reverb) or null]; the deadline legs and the Noise leg beside them
+            legs = {}
+            for c in configs:
+                r = c.get("roofline")
+                if r:
+                    ab_leg = r.get("algorithmic_bytes_per_launch") or (r.get("hbm") or {}).get("algorithmic_bytes_per_launch")
+                    legs[c["name"]] = [round(r["frac"], 4), round(c.get("kernel_ms_mean", float("nan")), 5), (round(r["traffic"] / ab_leg, 3) if r.get("traffic") and ab_leg else None),
+                                       (round(r["frac_on_distinct_bytes"], 4) if "frac_on_distinct_bytes" in r else None)]
+            out["roofline"]["legs"] = legs
+            out["roofline"]["legs_columns"] = ["frac (of HBM peak for cfg4_*, of fp32 peak otherwise)", "kernel ms per block", "PMC traffic / algorithmic bytes", "frac on distinct bytes"]
+            out["deadline"] = {c["name"]: {"voices": c["voices"], "p99_ms": round(c["p99_ms"], 3), "max_ms": round(c["max_ms"], 3), "worst_block": c["worst_block"], "release_max_ms": round(c["release_max_ms"], 3),
+                                           "within_90_percent": c["every_block_within_90_percent_of_the_deadline"],
+                                           "c_host": {k: c["c_host"].get(k) for k in ("p99_ms", "max_ms", "worst_block", "release_max_ms", "every_block_within_90_percent_of_the_deadline", "error") if k in c.get("c_host", {})}}
+                               for c in configs if c.get("name", "").startswith("realtime") and "p99_ms" in c}
+            for c in configs:
+                if c.get("name", "").startswith("noise_note") and "value" in c:
+                    out["noise"] = {"name": c["name"], "ms_per_block_with_wait_median": round(c["ms_per_block_with_wait_median"], 4), "ms_per_block_queued": round(c["ms_per_step"], 4), "kernel_ms": round(c["kernel_ms_mean"], 4), "round_4_ms_per_block": 82.0}
             lit = configs[0]
             if "phases_ms_per_block" in lit:
                 out["config"]["value_sustain_only"] = lit["value_sustain_phase"]
@@ -778,7 +888,35 @@ def main():
                     node = None
                 if node:
                     out["cpu_baseline"]["node"] = node
-        print(json.dumps(out))
+        # ONE line on stdout, short enough for a log's tail: the headline with every leg's roofline (`roofline.legs`), the deadline and Noise summaries.  The legs in
+        # full (`configs`) go to gpurun_out/bench_full.json (KLG_BENCH_FULL names another file; the copies under profiles/ come from there).
+        full_path = os.environ.get("KLG_BENCH_FULL") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+        try:
+            os.makedirs(os.path.dirname(full_path), exist_ok=True)
+            with open(full_path, "w") as f:
+                json.dump(out, f)
+            out["full_record"] = os.path.relpath(full_path, ROOT)
+        except OSError as e:
+            print(f"bench.py: could not write {full_path}: {e}", file=sys.stderr)
+        compact = {k: v for k, v in out.items() if k != "configs"}
+        r = dict(compact["roofline"])
+        for k in ("kernel_ms_source", "step_kernels", "peak_note", "valu"):
+            r.pop(k, None)
+        if "hbm" in r:
+            r["hbm"] = {k: r["hbm"][k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch") if k in r["hbm"]}
+        compact["roofline"] = r
+        cfg = dict(compact["config"])
+        for k in ("value_counts", "submission"):
+            cfg.pop(k, None)
+        compact["config"] = cfg
+        if "cpu_baseline" in compact:
+            cb = dict(compact["cpu_baseline"])
+            for k in ("port_sample", "binary", "note"):
+                cb.pop(k, None)
+            if isinstance(cb.get("node"), dict):
+                cb["node"] = {k: cb["node"][k] for k in ("value", "unit", "cores", "kind") if k in cb["node"]}
+            compact["cpu_baseline"] = cb
+        print(json.dumps(compact))
     if world > 1:
         script.close(); sharded.close()
         dist.destroy_process_group()

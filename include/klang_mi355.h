@@ -152,10 +152,10 @@ int klg_voice_stages(klg_synth* s, uint8_t* stages, int n_voices);
  * (NULL is the handle's OWN stream, which is created non-blocking: work the caller has queued on the legacy default stream — a framework's clear of d_mix,
  * say — is not ordered with it.  A caller whose buffers are produced on the default stream passes a stream of its own, or synchronises.)
  * klg_sync() waits for everything queued on the handle.
- * ONE EXCEPTION: a graph bank whose Note::process() draws Noise or calls controls[i].smooth() shares state between its notes in the order
- * Synth::process walks them (klang.h:4842-4848: libc rand(), Control::smoothed); per block the library brings the note stages back, draws /
- * advances on the host in that order and uploads the result — this entry (and klg_script_play_device) then SYNCHRONISES the stream two or three
- * times per block and does O(sounding voices x n) host work.  Banks without those two ops never synchronise here. */
+ * A graph bank whose Note::process() draws Noise or calls controls[i].smooth() shares state between its notes in the order Synth::process walks
+ * them (klang.h:4842-4848: libc rand(), Control::smoothed): that order is settled per block by kernels on the same stream (the sounding voices'
+ * ranks, the rand() values from the sequence's state on the device, the smoothing chain: klang_amd/csrc/klg_rand_dev.hpp) — no copy to the host, no
+ * wait.  (The host waits only when the buffer of draws must grow: a block with more sounding voices than any before it.) */
 int klg_process_device(klg_synth* s, float* d_mix, int n, void* hip_stream);
 int klg_sync(klg_synth* s);
 

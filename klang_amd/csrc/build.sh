@@ -12,3 +12,6 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Wl,-Bsymbolic \
     -Wall -Wno-unused-function "$@" "$HERE/klg_api.hip" -o "$OUT"
 echo "built $OUT"
+# the deadline-measurement host (klang_amd/host/klang_deadline.cpp): a C++ real-time loop over the C-ABI, for bench.py's deadline legs
+"$HIPCC" -O2 -std=c++17 -Wall "$HERE/../host/klang_deadline.cpp" -I"$HERE/../../include" -L"$HERE/.." -lklang_mi355 -Wl,-rpath,'$ORIGIN/..' -o "$HERE/../host/klang_deadline"
+echo "built $HERE/../host/klang_deadline"

@@ -211,7 +211,11 @@ static klg_fx* fx_create_graph_on(int device, const char* program, int instances
 	ok = ok && hipMemset(f->d_rings, 0, ring * 4) == hipSuccess;                       // Delay() : buffer(SIZE + 1, 0)
 	ok = ok && hipModuleLoadData(&f->module, c->code.data()) == hipSuccess;
 	ok = ok && hipModuleGetFunction(&f->graph_fn, f->module, c->name[0].c_str()) == hipSuccess;
-	if (ok && c->staged && hipModuleGetFunction(&f->staged_fn, f->module, "klg_fx_staged") != hipSuccess) { (void)hipGetLastError(); f->staged_fn = nullptr; }   // the sample-parallel form of the same body (klg_graph_staged.hpp)
+	{ int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) f->lds_limit = v; }
+	// the sample-parallel form of the same body (klg_graph_staged.hpp): planned for gfx950's 160 KB of LDS — a device that grants a workgroup less keeps the one-lane-per-instance
+	// kernel of the same code object (same bits, klg_fx_graph<P> with kRingRow = the plan's G), as does a kernel that cannot be given its dynamic LDS
+	if (ok && c->staged && c->staged_lds <= f->lds_limit && hipModuleGetFunction(&f->staged_fn, f->module, "klg_fx_staged") != hipSuccess) { (void)hipGetLastError(); f->staged_fn = nullptr; }
+	if (ok && c->staged && !f->staged_fn && c->staged_lds > f->lds_limit) fprintf(stderr, "klang-mi355: the staged form of this effect needs %d bytes of LDS per workgroup, the device grants %d: one lane per instance\n", c->staged_lds, f->lds_limit);
 	if (!ok) { fail(KLG_ERR_NOMEM, "klg_fx_create_graph: device allocation / module load failed (%zu ring bytes): %s", ring * 4, hipGetErrorString(hipGetLastError())); fx_free(f); return nullptr; }
 	std::vector<uint32_t> init((size_t)f->words * f->kpad, 0u);
 	if (initial_record) { const uint32_t* r = (const uint32_t*)initial_record; for (int w = 0; w < f->words; w++) std::fill(init.begin() + (size_t)w * f->kpad, init.begin() + (size_t)(w + 1) * f->kpad, r[w]); }
@@ -439,7 +443,17 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st, int b
 	void* params[] = { &a };
 	// G instances x C samples per workgroup, level by level (klg_graph_staged.hpp) — or, for a body that has no such form (Compiled::staged_why), one lane per
 	// instance walking the samples in order.  Same bits either way (tests/test_gpu_fx_facade.py runs both).
-	if (f->staged_fn) { TimedLaunch timed(f); HIP_TRY(klg_module_launch(f->staged_fn, (unsigned)(f->kpad / (size_t)f->graph->staged_G), (unsigned)f->graph->staged_threads, (unsigned)f->graph->staged_lds, st, params)); }
+	if (f->staged_fn) {
+		TimedLaunch timed(f);
+		const hipError_t e = klg_module_launch(f->staged_fn, (unsigned)(f->kpad / (size_t)f->graph->staged_G), (unsigned)f->graph->staged_threads, (unsigned)f->graph->staged_lds, st, params);
+		if (e != hipSuccess && blocks <= 1) {                              // (the launch was refused — its LDS, its registers —: nothing ran; the other kernel of the code object renders the same bits)
+			(void)hipGetLastError();
+			fprintf(stderr, "klang-mi355: launching the staged form failed (%s): one lane per instance from here on\n", hipGetErrorString(e));
+			f->staged_fn = nullptr;
+			HIP_TRY(klg_module_launch(f->graph_fn, (unsigned)(f->kpad / FX_WG), FX_WG, 0, st, params));
+		}
+		else HIP_TRY(e);
+	}
 	else { TimedLaunch timed(f); HIP_TRY(klg_module_launch(f->graph_fn, (unsigned)(f->kpad / FX_WG), FX_WG, 0, st, params)); }
 	if (draws > 0) { HIP_TRY(hipEventRecord(f->rand_done, st)); f->rand_stream = st; }
 	f->samples += (unsigned long long)n * (unsigned long long)blocks;

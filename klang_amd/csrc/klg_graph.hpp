@@ -7,6 +7,9 @@
 // first use (a process that never creates a graph patch does not need it).  Compiling needs no GPU.
 #pragma once
 #include <dlfcn.h>
+#include <dirent.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstring>
 
 #include <map>
@@ -610,6 +613,7 @@ struct Rtc {
 	int (*GetCode)(void*, char*) = nullptr;
 	int (*GetLoweredName)(void*, const char*, const char**) = nullptr;
 	int (*DestroyProgram)(void**) = nullptr;
+	int (*Version)(int*, int*) = nullptr;
 	std::string error;
 	bool load() {
 		if (lib) return true;
@@ -627,6 +631,7 @@ struct Rtc {
 		GetCode = (decltype(GetCode))sym("hiprtcGetCode");
 		GetLoweredName = (decltype(GetLoweredName))sym("hiprtcGetLoweredName");
 		DestroyProgram = (decltype(DestroyProgram))sym("hiprtcDestroyProgram");
+		Version = (decltype(Version))dlsym(lib, "hiprtcVersion");
 		if (!ok) { dlclose(lib); lib = nullptr; }
 		return ok;
 	}
@@ -647,6 +652,71 @@ inline std::string source_dir() {
 		return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/csrc";
 	}
 	return "klang_amd/csrc";
+}
+
+// ---- code objects on disk -----------------------------------------------------------------------------------------------------------------
+// hipRTC takes ~2 s per program; a plug-in host that instantiates Reverb.k pays that on every start unless the code object of an earlier process is
+// still good.  It is when NOTHING that went into it has changed: the generated source (which carries the program and every switch that shapes it), the
+// headers it includes (every *.hpp next to the library + the two record / graph headers: their bytes are hashed), the compiler (hiprtcVersion) and its options.
+// Files: $KLG_CACHE_DIR, else $XDG_CACHE_HOME/klang_mi355, else $HOME/.cache/klang_mi355; KLG_CACHE=0 turns the cache off.  A file that does not verify
+// (magic, sizes, the stored hash of its own payload) is ignored and rewritten.  Written to a temporary name and renamed: concurrent processes are safe.
+inline uint64_t fnv1a(const void* data, size_t n, uint64_t h = 1469598103934665603ull) { const unsigned char* p = (const unsigned char*)data; for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; } return h; }
+inline std::string cache_dir() {
+	const char* off = getenv("KLG_CACHE"); if (off && off[0] == '0') return "";
+	std::string d;
+	if (const char* e = getenv("KLG_CACHE_DIR")) d = e;
+	else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/klang_mi355";
+	else if (const char* h = getenv("HOME")) d = std::string(h) + "/.cache/klang_mi355";
+	if (d.empty()) return "";
+	std::string cur;
+	for (size_t i = 0; i <= d.size(); i++) if (i == d.size() || d[i] == '/') { cur = d.substr(0, i); if (!cur.empty()) (void)mkdir(cur.c_str(), 0755); }
+	return access(d.c_str(), W_OK) == 0 ? d : "";
+}
+inline uint64_t headers_hash() {
+	static const uint64_t h = []() {
+		uint64_t x = 1469598103934665603ull;
+		const std::string dir = source_dir();
+		std::vector<std::string> files;
+		if (DIR* dp = opendir(dir.c_str())) { while (dirent* e = readdir(dp)) { const std::string n = e->d_name; if (n.size() > 4 && n.substr(n.size() - 4) == ".hpp") files.push_back(dir + "/" + n); } closedir(dp); }
+		files.push_back(dir + "/../../include/klang_mi355_records.h"); files.push_back(dir + "/../../include/klang_mi355_graph.h");
+		std::sort(files.begin(), files.end());
+		for (const std::string& f : files) if (FILE* fp = fopen(f.c_str(), "rb")) { char buf[65536]; size_t n; x = fnv1a(f.data() + dir.size(), f.size() - dir.size(), x); while ((n = fread(buf, 1, sizeof buf, fp)) > 0) x = fnv1a(buf, n, x); fclose(fp); }
+		return x;
+	}();
+	return h;
+}
+inline std::string cache_file(const Rtc& rtc, const std::string& source, const std::string& options) {
+	const std::string dir = cache_dir();
+	if (dir.empty()) return "";
+	int major = 0, minor = 0; if (rtc.Version) (void)rtc.Version(&major, &minor);
+	uint64_t a = fnv1a(source.data(), source.size()), b = fnv1a(source.data(), source.size(), 0x9E3779B97F4A7C15ull);
+	a = fnv1a(options.data(), options.size(), a); const uint64_t hh = headers_hash(); a = fnv1a(&hh, sizeof hh, a); a = fnv1a(&major, sizeof major, a); a = fnv1a(&minor, sizeof minor, a);
+	char name[96]; snprintf(name, sizeof name, "/%016llx%016llx_%zu.klgco", (unsigned long long)a, (unsigned long long)b, source.size());
+	return dir + name;
+}
+inline bool cache_load(const std::string& path, Compiled& c) {
+	FILE* fp = path.empty() ? nullptr : fopen(path.c_str(), "rb");
+	if (!fp) return false;
+	bool ok = false;
+	char magic[8] = {}; uint64_t sizes[3] = {}, sum = 0;
+	if (fread(magic, 1, 8, fp) == 8 && memcmp(magic, "KLGCO01\n", 8) == 0 && fread(sizes, 8, 3, fp) == 3 && sizes[0] < 4096 && sizes[1] < 4096 && sizes[2] > 0 && sizes[2] < (1ull << 30)) {
+		std::string n0(sizes[0], '\0'), n1(sizes[1], '\0'); std::vector<char> code(sizes[2]);
+		if (fread(&n0[0], 1, n0.size(), fp) == n0.size() && fread(&n1[0], 1, n1.size(), fp) == n1.size() && fread(code.data(), 1, code.size(), fp) == code.size() && fread(&sum, 8, 1, fp) == 1
+		    && sum == fnv1a(code.data(), code.size(), fnv1a(n1.data(), n1.size(), fnv1a(n0.data(), n0.size())))) { c.name[0] = n0; c.name[1] = n1; c.code.swap(code); ok = true; }
+	}
+	fclose(fp);
+	return ok;
+}
+inline void cache_store(const std::string& path, const Compiled& c) {
+	if (path.empty()) return;
+	const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+	FILE* fp = fopen(tmp.c_str(), "wb");
+	if (!fp) return;
+	const uint64_t sizes[3] = { c.name[0].size(), c.name[1].size(), c.code.size() };
+	const uint64_t sum = fnv1a(c.code.data(), c.code.size(), fnv1a(c.name[1].data(), c.name[1].size(), fnv1a(c.name[0].data(), c.name[0].size())));
+	const bool ok = fwrite("KLGCO01\n", 1, 8, fp) == 8 && fwrite(sizes, 8, 3, fp) == 3 && fwrite(c.name[0].data(), 1, sizes[0], fp) == sizes[0] && fwrite(c.name[1].data(), 1, sizes[1], fp) == sizes[1]
+		&& fwrite(c.code.data(), 1, sizes[2], fp) == sizes[2] && fwrite(&sum, 8, 1, fp) == 1;
+	if (fclose(fp) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
 }
 
 // program text -> code object (cached per process by program text).  Returns "" on success.
@@ -677,6 +747,14 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 		for (const graph::Op& o : g.ops) if (o.code == graph::OP_SMOOTH && o.node == (int)i) { sm.ctl = (int)o.imm; sm.calls++; }
 		if (sm.calls) c.smooths.push_back(sm);
 	}
+	const char* const extra_opt = getenv("KLG_RTC_EXTRA");
+	const std::string disk = cache_file(rtc, c.source, std::string("--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off ") + (extra_opt ? extra_opt : ""));
+	if (cache_load(disk, c)) {
+		if (getenv("KLG_GRAPH_DEBUG")) fprintf(stderr, "klang-mi355: code object from %s\n", disk.c_str());
+		auto ins = cache.emplace(key, std::move(c));
+		*out = &ins.first->second;
+		return "";
+	}
 	void* prog = nullptr;
 	if (rtc.CreateProgram(&prog, c.source.c_str(), "klg_graph_patch.hip", 0, nullptr, nullptr) != 0) return "hiprtcCreateProgram failed";
 	const char* expr[2] = { "klg::klg_render<klg::PatchGen, false>", "klg::klg_render<klg::PatchGen, true>" };
@@ -698,6 +776,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	for (int i = 0; i < 2; i++) { const char* ln = nullptr; rtc.GetLoweredName(prog, expr[i], &ln); c.name[i] = ln ? ln : ""; }
 	rtc.DestroyProgram(&prog);
 	if (c.name[0].empty() || c.name[1].empty()) return "hipRTC: lowered kernel names not found";
+	cache_store(disk, c);
 	auto ins = cache.emplace(key, std::move(c));
 	*out = &ins.first->second;
 	return "";

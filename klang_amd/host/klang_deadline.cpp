@@ -1,0 +1,92 @@
+// klang_amd/host/klang_deadline.cpp — the real-time deadline, measured from a host that is not an interpreter.
+// replaces (as a measurement host): the audio callback of templates/juce/synth/Source/PluginProcessor.cpp:153-182 — one block per callback, the host
+// waits for the block before it returns.  V voices of a hand-written patch (default sub2a) all started in block 0 from an HBM-resident script
+// (klg_script_*), then `blocks` consecutive blocks of n samples, each: clear the [2][n] mix, klg_process_device, hipStreamSynchronize — timed with
+// CLOCK_MONOTONIC around the three; then every voice released and 44 more blocks (all voices in their release ramp: the worst case).  The process
+// is pinned to one core and its memory locked; nothing allocates inside the loop.  Prints ONE JSON line: p50 / p99 / max, the index of the worst
+// block and the ten largest block times with their indices (so that a spike can be told from a pattern).
+// Build: hipcc -O2 -std=c++17 klang_deadline.cpp -I../../include -L.. -lklang_mi355 -Wl,-rpath,'$ORIGIN/..' -o klang_deadline   (klang_amd/csrc/build.sh does)
+// Run:   klang_deadline [--voices V] [--blocks B] [--n N] [--patch id] [--notes P] [--cpu c]
+#include <hip/hip_runtime.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <time.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <klang_mi355.h>
+
+static double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec; }
+#define DIE(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); return 1; } while (0)
+#define KLG(call) do { if ((call) < 0) DIE("%s failed: %s", #call, klg_last_error()); } while (0)
+#define HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) DIE("%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+int main(int argc, char** argv) {
+	long long V = 1 << 20; int blocks = 2000, n = 256, patch = KLG_PATCH_SUB2A, notes = 32, cpu = -1;
+	for (int i = 1; i + 1 < argc; i += 2) {
+		if (!strcmp(argv[i], "--voices")) V = atoll(argv[i + 1]); else if (!strcmp(argv[i], "--blocks")) blocks = atoi(argv[i + 1]);
+		else if (!strcmp(argv[i], "--n")) n = atoi(argv[i + 1]); else if (!strcmp(argv[i], "--patch")) patch = atoi(argv[i + 1]);
+		else if (!strcmp(argv[i], "--notes")) notes = atoi(argv[i + 1]); else if (!strcmp(argv[i], "--cpu")) cpu = atoi(argv[i + 1]);
+		else DIE("unknown option %s", argv[i]);
+	}
+	if (cpu < 0) cpu = sched_getcpu();
+	cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpu, &set);
+	const bool pinned = sched_setaffinity(0, sizeof set, &set) == 0;
+	const int base = 1 << 20;                                                // distinct note records (pitch by voice); voices beyond share them
+	klg_synth* bank = klg_synth_create(patch, (int)(V / notes), notes, 48000.f, n);
+	if (!bank) DIE("klg_synth_create: %s", klg_last_error());
+	V = klg_synth_voices(bank);
+	const size_t W = klg_synth_state_bytes(bank) / 4;
+	klg_script* script = klg_script_create(bank, 2);
+	if (!script) DIE("klg_script_create: %s", klg_last_error());
+	{
+		const int R = (int)std::min<long long>(base, V);
+		std::vector<int> sy((size_t)R), pi((size_t)R); std::vector<float> ve((size_t)R, 0.8f); std::vector<uint32_t> rec((size_t)R * W);
+		unsigned x = 2463534242u;
+		for (int i = 0; i < R; i++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; sy[(size_t)i] = (int)((i / notes) % (V / notes)); pi[(size_t)i] = 36 + (int)(x % 61u); }
+		KLG(klg_note_records(bank, R, sy.data(), pi.data(), ve.data(), rec.data()));
+		const int first = klg_script_add_records(script, R, rec.data());
+		if (first < 0) DIE("klg_script_add_records: %s", klg_last_error());
+		std::vector<int> blk((size_t)V, 0), vo((size_t)V), ri((size_t)V);
+		for (long long v = 0; v < V; v++) { vo[(size_t)v] = (int)v; ri[(size_t)v] = first + (int)(v % R); }
+		KLG(klg_script_note_on_many(script, (int)V, blk.data(), vo.data(), ri.data()));
+		std::fill(blk.begin(), blk.end(), 1);
+		KLG(klg_script_note_off_many(script, (int)V, blk.data(), vo.data()));
+		KLG(klg_script_commit(script));
+	}
+	float* d_mix = nullptr; hipStream_t st = nullptr;
+	HIP(hipMalloc((void**)&d_mix, (size_t)2 * n * sizeof(float)));
+	HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	std::vector<double> t((size_t)blocks), r(44);
+	const bool locked = mlockall(MCL_CURRENT | MCL_FUTURE) == 0;
+	auto block = [&](int script_block) -> int {
+		HIP(hipMemsetAsync(d_mix, 0, (size_t)2 * n * sizeof(float), st));
+		if (script_block >= 0) KLG(klg_script_play_device(script, script_block, d_mix, n, st)); else KLG(klg_process_device(bank, d_mix, n, st));
+		HIP(hipStreamSynchronize(st));
+		return 0;
+	};
+	if (block(0)) return 1;
+	for (int b = 0; b < blocks; b++) { const double t0 = now_ms(); if (block(-1)) return 1; t[(size_t)b] = now_ms() - t0; }
+	if (block(1)) return 1;
+	for (int b = 0; b < 44; b++) { const double t0 = now_ms(); if (block(-1)) return 1; r[(size_t)b] = now_ms() - t0; }
+	std::vector<float> mix((size_t)2 * n);
+	HIP(hipMemcpy(mix.data(), d_mix, mix.size() * sizeof(float), hipMemcpyDeviceToHost));
+	bool finite = true; for (float f : mix) finite = finite && f == f && f - f == 0.f;
+	std::vector<int> order((size_t)blocks);
+	for (int i = 0; i < blocks; i++) order[(size_t)i] = i;
+	std::sort(order.begin(), order.end(), [&](int a, int b) { return t[(size_t)a] > t[(size_t)b]; });
+	std::vector<double> s = t; std::sort(s.begin(), s.end());
+	const double deadline = 1e3 * n / 48000.0, p50 = s[s.size() / 2], p99 = s[std::min(s.size() - 1, (size_t)(0.99 * (double)s.size()))], mx = s.back();
+	const double rmax = *std::max_element(r.begin(), r.end());
+	printf("{\"host\": \"klang_deadline (C++, pinned to cpu %d: %s, memory locked: %s)\", \"voices\": %lld, \"blocks\": %d, \"n\": %d, \"deadline_ms\": %.4f, \"p50_ms\": %.4f, \"p99_ms\": %.4f, \"max_ms\": %.4f, \"worst_block\": %d, "
+	       "\"release_max_ms\": %.4f, \"every_block_within_the_deadline\": %s, \"every_block_within_90_percent_of_the_deadline\": %s, \"finite\": %s, \"ten_largest\": [",
+	       cpu, pinned ? "yes" : "no", locked ? "yes" : "no", V, blocks, n, deadline, p50, p99, mx, order[0], rmax, std::max(mx, rmax) <= deadline ? "true" : "false", std::max(mx, rmax) <= 0.9 * deadline ? "true" : "false", finite ? "true" : "false");
+	for (int i = 0; i < 10 && i < blocks; i++) printf("%s[%d, %.4f]", i ? ", " : "", order[(size_t)i], t[(size_t)order[(size_t)i]]);
+	printf("]}\n");
+	klg_script_destroy(script); klg_synth_destroy(bank);
+	return 0;
+}

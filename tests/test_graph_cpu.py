@@ -356,3 +356,28 @@ end
     assert rc == 0, src
     assert "klg_fx_graph" in src or "struct PatchGen" in src
     assert "klg_fx_staged" not in src
+
+
+def test_code_objects_are_cached_on_disk(tmp_path):
+    """A second PROCESS that compiles the same program finds the first one's code object (klg_graph.hpp cache_file: keyed by the generated source, the headers'
+    bytes, the compiler's version and options) instead of running hipRTC again; KLG_CACHE=0 writes nothing; a damaged file is ignored and replaced."""
+    import sys
+    import time
+    code = ("import sys, time; sys.path.insert(0, %r); import ctypes as C; from klang_amd._lib import lib; L = lib(); b = C.create_string_buffer(1 << 16); "
+            "t = time.perf_counter(); rc = L.klg_graph_check(%r.encode(), 0, b, len(b)); print(rc, time.perf_counter() - t)") % (ROOT, SUB2B_LIKE.replace("0.1 20 10", "0.1 20 9.5"))
+    def run(env_extra):
+        env = dict(os.environ, KLG_CACHE_DIR=str(tmp_path / "cache"), **env_extra)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, check=True).stdout.split()
+        return int(out[0]), float(out[1])
+    rc, _ = run({"KLG_CACHE": "0"})
+    assert rc == 0 and not (tmp_path / "cache").exists() or not list((tmp_path / "cache").glob("*.klgco"))
+    rc, cold = run({})
+    files = list((tmp_path / "cache").glob("*.klgco"))
+    assert rc == 0 and len(files) == 1
+    rc, warm = run({})
+    assert rc == 0 and warm < 0.25 * cold and warm < 0.5, (cold, warm)
+    blob = bytearray(files[0].read_bytes()); blob[len(blob) // 2] ^= 0xFF; files[0].write_bytes(bytes(blob))      # a damaged file: compiled again, rewritten
+    rc, again = run({})
+    assert rc == 0 and again > 2 * warm
+    rc, warm2 = run({})
+    assert rc == 0 and warm2 < 0.25 * cold
