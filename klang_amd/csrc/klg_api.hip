@@ -24,6 +24,7 @@
 #include "klg_fx.hpp"
 #include "klg_render_x2.hpp"
 #include "klg_render_lanes.hpp"
+#include "klg_render_supersaw_sp.hpp"
 
 // Kernel timing (klg_timing_* / klg_fx_timing_*): the dominant kernel of a call is launched with its two events ATTACHED TO THE DISPATCH
 // (hipExtLaunchKernelGGL / hipExtModuleLaunchKernel): they hold the kernel's own start and end, what rocprofv3's kernel trace reads.  Events recorded
@@ -275,7 +276,8 @@ struct klg_synth {
 	int mix_mode = 0; int* d_solo = nullptr;      // klg_synth_set_mix_mode: KLG_MIX_LAST_ACTIVE keeps one voice per instance (d_solo[synths])
 	bool x2 = true;               // KLG_RENDER_X1=1 in the environment selects the one-voice-per-lane kernel (A/B tests)
 	bool lanes = false;           // SuperSaw banks that do not fill the chip: an oscillator pair — or one oscillator — per lane (klg_render_lanes.hpp); KLG_SUPERSAW_LANES=0 / 1 / 2 forces the choice
-	bool pairs = false; int pairs_p = 1;   // ... the pair form (2; the default for such banks) and its sample slots per voice (KLG_SUPERSAW_PAIRS_P forces 1 / 2 / 4)
+	bool pairs = false; int pairs_p = 1;   // ... the pair form (2) and its sample slots per voice (KLG_SUPERSAW_PAIRS_P forces 1 / 2 / 4)
+	bool sp = false;              // ... the sample-parallel form (3; the default for such banks: klg_render_supersaw_sp.hpp)
 	int grid_lanes = 0;
 	// graph patches (klg_graph.hpp): the render kernels come from a hipRTC code object instead of this library
 	const graphrt::Compiled* graph = nullptr;
@@ -462,13 +464,14 @@ static klg_synth* synth_create_common(int device, int patch_id, const PatchInfo*
 	ok = ok && hipMalloc(&s->d_controls, (size_t)s->S * KLG_MAX_CTL * 4) == hipSuccess;
 	if (patch_id == KLG_PATCH_SUPERSAW) {
 		const char* e = getenv("KLG_SUPERSAW_LANES");
-		s->lanes = e ? (e[0] == '1' || e[0] == '2') : s->V <= KLG_LANES_MAX_VOICES;
-		s->pairs = s->lanes && !(e && e[0] == '1');
+		s->lanes = e ? (e[0] == '1' || e[0] == '2' || e[0] == '3') : s->V <= KLG_LANES_MAX_VOICES;
+		s->sp = s->lanes && !(e && (e[0] == '1' || e[0] == '2'));
+		s->pairs = s->lanes && e && e[0] == '2';
 		// sample slots per voice: enough waves for four per SIMD (a 16,384-voice bank: 4096); a bank that has them anyway keeps one
 		const char* pe = getenv("KLG_SUPERSAW_PAIRS_P");
 		s->pairs_p = pe ? atoi(pe) : (s->V <= 16384 ? 4 : 1);     // measured: 16,384 voices 58 / 49 / 49 us with 1 / 2 / 4 slots, 32,768 voices 77 / 82 / 87
 		if (s->pairs_p != 1 && s->pairs_p != 2 && s->pairs_p != 4) s->pairs_p = 1;
-		const int per_wg = s->pairs ? 16 / s->pairs_p * WAVES : KLG_LANES_VOICES_PER_WG;
+		const int per_wg = s->sp ? (int)SP_VPWG : s->pairs ? 16 / s->pairs_p * WAVES : KLG_LANES_VOICES_PER_WG;
 		s->grid_lanes = std::min((s->V + per_wg - 1) / per_wg, (ok ? prop.multiProcessorCount : 256) * 8);
 	}
 	ok = ok && hipMalloc(&s->d_partials, (size_t)std::max(s->grid, s->lanes ? s->grid_lanes : 0) * max_block * 4 * s->note_ch) == hipSuccess;
@@ -620,7 +623,13 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 		else KLG_LAUNCH(klg_render_sub2a_x2<false>, g, b, render_lds_bytes(a.n), st, a);
 		return;
 	}
-	if (s->pairs) {                                       // SuperSaw, an oscillator pair per lane (small banks)
+	if (s->sp) {                                          // SuperSaw, samples side by side and the rare cases apart (small banks)
+		const dim3 g(render_grid(s)), b(WG);
+		if (pv) KLG_LAUNCH(klg_render_supersaw_sp<true>, g, b, render_lds_bytes(a.n), st, a);
+		else KLG_LAUNCH(klg_render_supersaw_sp<false>, g, b, render_lds_bytes(a.n), st, a);
+		return;
+	}
+	if (s->pairs) {                                       // SuperSaw, an oscillator pair per lane (KLG_SUPERSAW_LANES=2)
 		const dim3 g(render_grid(s)), b(WG);
 		const size_t lds = render_lds_bytes(a.n);
 		switch (s->pairs_p * 2 + (pv ? 1 : 0)) {
@@ -1004,7 +1013,7 @@ static int note_prepass(klg_synth* s, RenderArgs& a, int n, hipStream_t st) {
 }
 // does the render launch of this bank apply events / combine its partial rows itself (RenderArgs::ev / ticket)?  The kernels that can: klg_render<P>
 // (hand-written and generated patches, one voice per lane), klg_render_sub2a_x2, klg_render_supersaw_pairs.
-static bool fusing_kernel(const klg_synth* s) { return !(s->graph && s->graph->x2) && !(s->lanes && !s->pairs); }
+static bool fusing_kernel(const klg_synth* s) { return !(s->graph && s->graph->x2) && !(s->lanes && !s->pairs && !s->sp); }
 static int enqueue_block(klg_synth* s, float* d_mix, int n, bool per_voice, hipStream_t st, const EventArgs* script_events = nullptr) {
 	const bool prepass = s->graph && (s->graph->noise_calls > 0 || !s->graph->smooths.empty());
 	const char* fuse_env = getenv("KLG_FUSE"); const bool fuse_off = fuse_env && fuse_env[0] == '0';   // KLG_FUSE=0: always the separate launches (A/B; read per block so that a test can flip it)

@@ -153,7 +153,7 @@ def test_one_voice_per_lane_kernel_matches_too(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["supersaw_ctl", "supersaw_poly"])
-@pytest.mark.parametrize("lanes", ["0", "1", "2:1", "2:2", "2:4"])
+@pytest.mark.parametrize("lanes", ["0", "1", "2:1", "2:2", "2:4", "3"])
 def test_all_supersaw_kernels_match(name, lanes, monkeypatch):
     """SuperSaw banks of up to 131,072 voices run the oscillator-pair-per-lane kernel (klg_render_lanes.hpp; 1: its one-oscillator-per-lane
     predecessor), larger ones the voice-per-lane kernel; KLG_SUPERSAW_LANES forces the choice, KLG_SUPERSAW_PAIRS_P the pair kernel's
@@ -228,22 +228,22 @@ def test_supersaw_pair_kernel_rebuilds_oscillators_of_records_it_cannot_hold(mon
         return np.stack(pv), recs
     for n in (256, 37, 1):                                                # whole chunks; a ragged last iteration; a single sample
         a, ra = run("0", N=n)
-        for p in ("1", "2", "4"):
-            b, rb = run("2", p, N=n)
+        for p in ("1", "2", "4", "sp"):                                   # ("sp": the sample-parallel kernel, klg_render_supersaw_sp.hpp — such voices have ALL their samples redone oscillator by oscillator)
+            b, rb = run("2", p, N=n) if p != "sp" else run("3", N=n)
             assert np.array_equal(np.isnan(a), np.isnan(b)), (n, p)
             assert np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32)), (n, p)
             assert np.array_equal(ra, rb), (n, p)
         assert np.abs(a[~np.isnan(a)]).max() > 0
 
 
-@pytest.mark.parametrize("p", ["1", "2", "4"])
+@pytest.mark.parametrize("p", ["1", "2", "4", "sp"])
 @pytest.mark.parametrize("n", [256, 37, 1])
 def test_supersaw_pair_kernel_block_lengths(p, n, monkeypatch):
     """Ordinary records (note_on), odd block lengths: the pair kernel's sample slots against the voice-per-lane kernel, samples and records."""
     import klang_amd
     def run(lanes):
-        monkeypatch.setenv("KLG_SUPERSAW_LANES", lanes)
-        monkeypatch.setenv("KLG_SUPERSAW_PAIRS_P", p)
+        monkeypatch.setenv("KLG_SUPERSAW_LANES", "3" if (p == "sp" and lanes == "2") else lanes)
+        monkeypatch.setenv("KLG_SUPERSAW_PAIRS_P", p if p != "sp" else "1")
         bank = klang_amd.SynthBank("supersaw", synths=3, notes=32, max_block=256)
         rng = np.random.default_rng(5)
         for sy in range(3):
