@@ -41,7 +41,7 @@ NOTES = {"sub2a": 128, "sine": 128, "bsine": 128}          # note slots per Synt
 SCRIPT_BLOCKS, OFF_BLOCK, OFF_SPREAD = 375, 150, 64        # SURVEY §8(d) cfg 2: 2 s, note-off at 150 + (v mod 64)
 # blocks a voice still sounds after its note-off: ceil(release time * 48000 / 256) — sub2a 0.25 s + 5 ms = 12240 samples, SuperSaw.k 0.5 s + 5 ms, FM 1 s + 5 ms
 RELEASE_BLOCKS = {"sub2a": 48, "supersaw": 95, "fm3": 189, "fm4": 189}
-KERNEL_OF = {"sub2a": "klg_render_sub2a_x2", "supersaw": "klg_render<klg::PatchSuperSaw", "fm4": "klg_render<klg::PatchFM<4>", "fm3": "klg_render<klg::PatchFM<3>",
+KERNEL_OF = {"sub2a": "klg_render_sub2a_x2", "supersaw": "klg_render_supersaw_sp", "fm4": "klg_render<klg::PatchFM<4>", "fm3": "klg_render<klg::PatchFM<3>",
              "pingpong": "klg_fx_pingpong_x", "reverb": "klg_fx_reverb16"}
 
 
@@ -207,8 +207,7 @@ def cpu_reference_node(patch, block, blocks):
 
 # VALU wave-instructions per voice*sample of the two other synth kernels, from their counters (SQ_INSTS_VALU per launch / voices x samples;
 # they do not depend on the data: the sustain loop's paths are wave-uniform)
-VALU_INSTR_PER_VOICE_SAMPLE = {"fm4": (48537600 / (131072 * 256), "profiles/r04_pmc/pmc_fm4.json: SQ_INSTS_VALU 48,537,600 per launch of 131,072 voices x 256 samples"),
-                               "supersaw": (22462464 / (16384 * 256), "profiles/r04_pmc/pmc_supersaw_pairs.json: SQ_INSTS_VALU 22,462,464 per launch of klg_render_supersaw_pairs<4>, 16,384 voices x 256 samples")}
+VALU_INSTR_PER_VOICE_SAMPLE = {"fm4": (48537600 / (131072 * 256), "profiles/r04_pmc/pmc_fm4.json: SQ_INSTS_VALU 48,537,600 per launch of 131,072 voices x 256 samples")}
 
 
 def valu_issue(wave_samples, kern_s, per_sample):
@@ -373,7 +372,7 @@ def run_literal_script(patch, voices, N, label, phases=False):
     tf = FLOPS_PER_VOICE_SAMPLE.get(patch, 0) * V * N / kern_s / 1e12
     res["roofline"] = {"bound": "valu", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,
                        "flops_per_voice_sample_est": FLOPS_PER_VOICE_SAMPLE.get(patch, 0),
-                       "kernel": ("klg_render_supersaw_pairs" if patch == "supersaw" and voices <= 131072 else KERNEL_OF.get(patch, patch)), "phase": "sustain (block time incl. event kernel + reduce)",
+                       "kernel": KERNEL_OF.get(patch, patch), "phase": "sustain (block time incl. event kernel + reduce)",
                        "hbm": {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab},
                        "note": "voice state lives in registers: VALU-issue bound by design (DESIGN.md §3); 157.3 TFLOP/s is the packed-FMA peak, separate mul / add (bit-parity) reach at most half"}
     if patch in VALU_INSTR_PER_VOICE_SAMPLE and V == {"fm4": 131072, "supersaw": 16384}[patch]:

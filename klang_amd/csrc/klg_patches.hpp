@@ -228,7 +228,7 @@ struct PatchSuperSaw {
 	using Rec = rec::SuperSaw;                                                               // 37 words = 148 B read, 12 words written
 	static constexpr uint64_t kStoreMask = KLG_W(Rec, flags, 1) | KLG_W(Rec, osc[0].offset, 1) | KLG_W(Rec, osc[1].offset, 1) | KLG_W(Rec, osc[2].offset, 1)
 		| KLG_W(Rec, osc[3].offset, 1) | KLG_W(Rec, osc[4].offset, 1) | KLG_W(Rec, osc[5].offset, 1) | KLG_W(Rec, osc[6].offset, 1) | KLG_W(Rec, adsr.r_out, 4);
-	static constexpr int kWavesPerEu = 4;
+	static constexpr int kWavesPerEu = 3;                                                   // (no spills.  Four waves per SIMD with 25 spilled registers rendered 8 % faster while this kernel served the large banks; klg_render_supersaw_sp does now, this one is the A/B reference: KLG_SUPERSAW_LANES=0)
 	struct Live { Osm osc[7]; Adsr adsr; int stage; bool duty0; float step, tstep, tinc; };
 	static __device__ __forceinline__ void begin(Live& L, const Rec& r, const BlockCtx& c) {
 		L.tinc = c.fs.timeInc;

@@ -2,23 +2,24 @@
 //
 // klg_render<PatchSuperSaw> gives a lane a whole voice: seven six-case OSM tables, the `/ 7`s and the ADSR are ~380 instructions per
 // sample, strictly in sequence — config 3's 16,384 voices are 256 waves, one per SIMD on a quarter of the chip, and a block takes the
-// 0.19 ms that one wave needs for 256 x 380 instructions whatever else is idle.  Two kernels spread a voice over lanes instead:
-//   klg_render_supersaw_pairs<P>  (below; what banks of up to KLG_LANES_MAX_VOICES voices run) — an oscillator PAIR per lane, P samples
-//                                 of a voice side by side: 49 us per block at 16,384 voices, 133 us at 65,536 (voice per lane: 216 / 218)
+// 0.19 ms that one wave needs for 256 x 380 instructions whatever else is idle.  Two kernels here spread a voice over lanes instead (A/B references since
+// round 5: SuperSaw banks of every size run klg_render_supersaw_sp.hpp — samples side by side, the six-case table only where it is needed):
+//   klg_render_supersaw_pairs<P>  (below; KLG_SUPERSAW_LANES=2) — an oscillator PAIR per lane, P samples
+//                                 of a voice side by side: 37 us per block at 16,384 voices (voice per lane: 181)
 //   klg_render_supersaw_lanes     (KLG_SUPERSAW_LANES=1; the first form, kept for A/B runs) — ONE oscillator per lane: 75 / 158 us
 // klg_render_supersaw_lanes: lane = (voice vi of 8) x (slot k of 8): slot
 // k < 7 runs oscillator k, all eight lanes of a voice carry a copy of its ADSR (a copy costs an issue slot nobody else wants), and
 // `for s < 7: out += osc[s] / 7` (SuperSaw.k:28-29) — a sum in that order — is a running sum through the lanes: six v_add_f32 with a
 // DPP row_shr:1 source, lane k taking lane k - 1's partial sum, ending in slot 6.  ~100 instructions per sample for 8 voices: the bank
 // is eight times as many waves, each a quarter as long.  Same arithmetic, same order, same record layout as klg_render<PatchSuperSaw>,
-// which banks above KLG_LANES_MAX_VOICES keep (per voice·sample it is the fewest instructions once the chip is full):
+// (KLG_SUPERSAW_LANES=0):
 // tests/test_gpu_parity.py runs all of them against the golden vectors (KLG_SUPERSAW_LANES=0 / 1 / 2 forces the choice).
 #pragma once
 #include "klg_kernels.hpp"
 
 namespace klg {
 
-enum { KLG_LANES_VOICES_PER_WAVE = 8, KLG_LANES_VOICES_PER_WG = KLG_LANES_VOICES_PER_WAVE * WAVES, KLG_LANES_MAX_VOICES = 131072 };
+enum { KLG_LANES_VOICES_PER_WAVE = 8, KLG_LANES_VOICES_PER_WG = KLG_LANES_VOICES_PER_WAVE * WAVES };
 
 template<bool PER_VOICE>
 __global__ __launch_bounds__(WG) void klg_render_supersaw_lanes(const RenderArgs a) {

@@ -1,7 +1,7 @@
 // klang_amd/csrc/klg_render_supersaw_sp.hpp — SuperSaw.k (config 3) with its SAMPLES side by side and the rare cases apart.
 //
 // Replaces: SuperSaw.k:21-33 `out = 0; for s < 7: out += osc[s] / 7; out *= adsr++;` per note and sample (Fast::OSM::saw klang.h:5290-5302 over
-// OSM::tick 5251-5263), for banks that do not fill the chip with a voice per lane (up to KLG_LANES_MAX_VOICES voices).
+// OSM::tick 5251-5263), for SuperSaw banks of every size.
 //
 // klg_render_supersaw_pairs issues 343 lane-instructions per voice·sample: every lane evaluates all six cases of the saw's table for both of its
 // oscillators on every sample, and the four lanes of a voice·sample each repeat the ADSR steps and carry a quarter of the sum.  But:
