@@ -25,6 +25,7 @@
 #include "klg_render_x2.hpp"
 #include "klg_render_lanes.hpp"
 #include "klg_render_supersaw_sp.hpp"
+#include "klg_render_sub2a_sp.hpp"
 
 // Kernel timing (klg_timing_* / klg_fx_timing_*): the dominant kernel of a call is launched with its two events ATTACHED TO THE DISPATCH
 // (hipExtLaunchKernelGGL / hipExtModuleLaunchKernel): they hold the kernel's own start and end, what rocprofv3's kernel trace reads.  Events recorded
@@ -277,7 +278,8 @@ struct klg_synth {
 	bool x2 = true;               // KLG_RENDER_X1=1 in the environment selects the one-voice-per-lane kernel (A/B tests)
 	bool lanes = false;           // SuperSaw banks that do not fill the chip: an oscillator pair — or one oscillator — per lane (klg_render_lanes.hpp); KLG_SUPERSAW_LANES=0 / 1 / 2 forces the choice
 	bool pairs = false; int pairs_p = 1;   // ... the pair form (2) and its sample slots per voice (KLG_SUPERSAW_PAIRS_P forces 1 / 2 / 4)
-	bool sp = false;              // ... the sample-parallel form (3; the default for such banks: klg_render_supersaw_sp.hpp)
+	bool sp = false;              // ... the sample-parallel form (3; the default: klg_render_supersaw_sp.hpp)
+	bool sub_sp = false; int grid_sp = 0;   // sub2a banks of up to KLG_SUB2A_SP_MAX_VOICES voices: one voice per wave, samples side by side (klg_render_sub2a_sp.hpp; KLG_SUB2A_SP=0 / 1 forces the choice)
 	int grid_lanes = 0;
 	// graph patches (klg_graph.hpp): the render kernels come from a hipRTC code object instead of this library
 	const graphrt::Compiled* graph = nullptr;
@@ -474,7 +476,12 @@ static klg_synth* synth_create_common(int device, int patch_id, const PatchInfo*
 		const int per_wg = s->sp ? (int)SP_VPWG : s->pairs ? 16 / s->pairs_p * WAVES : KLG_LANES_VOICES_PER_WG;
 		s->grid_lanes = std::min((s->V + per_wg - 1) / per_wg, (ok ? prop.multiProcessorCount : 256) * 8);
 	}
-	ok = ok && hipMalloc(&s->d_partials, (size_t)std::max(s->grid, s->lanes ? s->grid_lanes : 0) * max_block * 4 * s->note_ch) == hipSuccess;
+	if (patch_id == KLG_PATCH_SUB2A) {
+		const char* e = getenv("KLG_SUB2A_SP");
+		s->sub_sp = e ? e[0] == '1' : s->V <= KLG_SUB2A_SP_MAX_VOICES;
+		s->grid_sp = std::min((s->V + WAVES - 1) / WAVES, (ok ? prop.multiProcessorCount : 256) * 8);
+	}
+	ok = ok && hipMalloc(&s->d_partials, (size_t)std::max(std::max(s->grid, s->lanes ? s->grid_lanes : 0), s->sub_sp ? s->grid_sp : 0) * max_block * 4 * s->note_ch) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_mix, (size_t)2 * max_block * 4) == hipSuccess;
 	ok = ok && hipMalloc((void**)&s->d_ticket, sizeof(unsigned)) == hipSuccess && hipMemset(s->d_ticket, 0, sizeof(unsigned)) == hipSuccess;
 	ok = ok && hipMalloc(&s->d_scratch_rec, (size_t)std::max(64, s->W) * 4) == hipSuccess;
@@ -607,6 +614,7 @@ template<class P> static void launch_render_t(klg_synth* s, const RenderArgs& a,
 }
 static int render_grid(const klg_synth* s) {      // workgroups (= partial rows) of the render launch
 	if (s->lanes) return s->grid_lanes;
+	if (s->sub_sp) return s->grid_sp;
 	if ((s->patch == KLG_PATCH_SUB2A && s->x2) || (s->graph && s->graph->x2)) return std::min((int)((s->stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG), s->grid);
 	return s->grid;
 }
@@ -615,6 +623,12 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 		RenderArgs args = a;
 		void* params[] = { &args };
 		s->launch_error = klg_module_launch(s->graph_fn[pv ? 1 : 0], (unsigned)render_grid(s), WG, (unsigned)render_lds_bytes(a.n, s->note_ch), st, params);
+		return;
+	}
+	if (s->sub_sp) {                                      // sub2a, small banks: one voice per wave, samples side by side (klg_render_sub2a_sp.hpp)
+		const dim3 g(render_grid(s)), b(WG);
+		if (pv) KLG_LAUNCH(klg_render_sub2a_sp<true>, g, b, render_lds_bytes(a.n), st, a);
+		else KLG_LAUNCH(klg_render_sub2a_sp<false>, g, b, render_lds_bytes(a.n), st, a);
 		return;
 	}
 	if (s->patch == KLG_PATCH_SUB2A && s->x2) {           // two voices per lane, packed fp32 (klg_render_x2.hpp)

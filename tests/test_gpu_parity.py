@@ -140,11 +140,15 @@ def test_voice_state_roundtrip_and_abi_errors():
     bank.close()
 
 
+@pytest.mark.parametrize("kernel", ["voice per lane", "two voices per lane", "voice per wave"])
 @pytest.mark.parametrize("name", ["sub2a_poly", "sub2a_steal", "sub2a_long"])
-def test_one_voice_per_lane_kernel_matches_too(name, monkeypatch):
-    """Config 2a normally runs the two-voices-per-lane packed-fp32 kernel (klg_render_x2.hpp); KLG_RENDER_X1=1
-    selects the generic one-voice-per-lane kernel.  Both must reproduce the reference bit for bit."""
-    monkeypatch.setenv("KLG_RENDER_X1", "1")
+def test_every_sub2a_kernel_matches(name, kernel, monkeypatch):
+    """Config 2a has three kernels: banks of up to 2,048 voices run one voice per WAVE with the samples side by side (klg_render_sub2a_sp.hpp: what these
+    fixtures' banks get by default), larger ones the two-voices-per-lane packed-fp32 kernel (klg_render_x2.hpp); KLG_SUB2A_SP=0 / 1 forces that choice,
+    KLG_RENDER_X1=1 selects the generic one-voice-per-lane kernel.  All must reproduce the reference bit for bit."""
+    monkeypatch.setenv("KLG_SUB2A_SP", "1" if kernel == "voice per wave" else "0")
+    if kernel == "voice per lane":
+        monkeypatch.setenv("KLG_RENDER_X1", "1")
     s = Scenario.load(os.path.join(GOLDEN, name + ".scn"))
     ref = np.load(os.path.join(GOLDEN, name + ".npz"))
     got = run_scenario_gpu(s)
