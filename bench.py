@@ -616,6 +616,56 @@ def respawn(args):
     raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
 
 
+def in_library(args):
+    """`bench.py --gpus N --in-library`: the multi-GPU path a C++ host of the library takes — ONE process, klg_init(ids), every bank sharded over the devices inside the
+    library (contiguous ranges of synth instances), one ncclAllReduce (RCCL over xGMI, loaded by the library) of the [2][n] block per klg_process_device — beside the
+    one-process-per-GPU arrangement the default mode measures.  Weak scaling: --voices per GPU, all sustaining; K timed blocks between two device-wide waits.
+    Launched under torch.distributed.run every rank but 0 leaves at once (the library drives all N devices from rank 0's process)."""
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
+    import torch
+    import klang_amd
+    N, n = args.gpus, args.block
+    have = torch.cuda.device_count()
+    one_gpu = os.environ.get("KLG_BENCH_ONE_GPU") == "1"
+    if have < N and not one_gpu:
+        raise SystemExit(f"bench.py --gpus {N} --in-library: only {have} GPU(s) visible (KLG_BENCH_ONE_GPU=1 puts every shard on cuda:0: a functional test, not a measurement)")
+    ids = [0] * N if one_gpu else list(range(N))
+    patch, notes = args.patch, NOTES.get(args.patch, 32)
+    V = groups_voices(args.voices)
+    rec_bank = klang_amd.SynthBank(patch, synths=1, notes=notes, max_block=n)          # (records from a one-instance bank on device 0, before the process is made multi-device)
+    rng = np.random.default_rng(20250314)
+    base = min(V, 1 << 16)
+    rec = rec_bank.note_records(np.zeros(base, np.int32), rng.integers(36, 97, size=base).astype(np.int32), np.full(base, 0.8, np.float32))
+    rec_bank.close()
+    klang_amd.init(ids)
+    bank = klang_amd.SynthBank(patch, synths=(V // notes) * N, notes=notes, max_block=n)
+    total = bank.voices
+    for c0 in range(0, total, base):
+        cnt = min(base, total - c0)
+        bank.voices_upload(np.arange(c0, c0 + cnt, dtype=np.int32), rec[:cnt])
+    torch.cuda.set_device(ids[0])
+    mix = torch.zeros((2, n), dtype=torch.float32, device="cuda")
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        st = ts.cuda_stream
+        for _ in range(max(args.warmup, 40)):                                            # (past the attack: every voice holding at its sustain level)
+            mix.zero_(); bank.process_device(mix.data_ptr(), n, st)
+        bank.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mix.zero_(); bank.process_device(mix.data_ptr(), n, st)
+        bank.sync(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out = {"metric": "voice*samples/s @48kHz Subtractive", "value": total * n * args.steps / dt, "unit": "voice*samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mode": "in-library",
+           "config": {"workload": f"{patch}: {V} voices/GPU, all sustaining, {n}-sample blocks @48kHz, stereo mix resident on device {ids[0]}", "voices_per_gpu": V, "block": n,
+                      "parallelism": f"ONE process, klg_init({ids}): voice-shard x{N} inside libklang_mi355.so + " + ("a device-side add of the shards' blocks (one physical GPU)" if one_gpu else f"one ncclAllReduce (RCCL) of [2][{n}] per block"),
+                      "mix_checksum": float(mix.abs().sum().item())}}
+    bank.close()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -628,12 +678,15 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="headline only (what ranks of an N > 1 run do anyway)")
     ap.add_argument("--realtime-voices", type=int, default=32 << 20, help="the deadline test: 32 Mi voices pass (p99 4.4 ms, every block under 5.33 ms); 36 Mi have blocks over the deadline")
     ap.add_argument("--realtime-margin-voices", type=int, default=28 << 20, help="the deadline test with a margin: every block of 28 Mi voices within 90 %% of the 5.33 ms")
+    ap.add_argument("--in-library", action="store_true", help="N > 1 through the C-ABI's own sharding: ONE process, klg_init(ids 0..N-1), one ncclAllReduce of the [2][n] block per klg_process_device inside the library (what a C++ host uses) instead of one process per GPU + torch.distributed")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-fx", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
 
+    if args.in_library:
+        return in_library(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return respawn(args)

@@ -49,6 +49,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <typeindex>
 #include <typeinfo>
@@ -490,6 +491,9 @@ KLANG_CONTROL_NUM(+) KLANG_CONTROL_NUM(-) KLANG_CONTROL_NUM(*) KLANG_CONTROL_NUM
 KLANG_CONTROL_DBL(+) KLANG_CONTROL_DBL(-) KLANG_CONTROL_DBL(*) KLANG_CONTROL_DBL(/)
 #undef KLANG_CONTROL_DBL
 // sqr / cube (klang.h:3067-3069: Function<float> objects; applied to a signal they are the same fp32 products)
+// tanh of a signal: where the reference's patch code writes `tanh(x)` on a float (a plain C function: examples/Distortion/Shaping.k:15) it is the C library's DOUBLE
+// tanh of the converted float, rounded back (the pinned build imports `tanh`); the device restates glibc's (klg_device.hpp tanh_f64, tools/verify_tanh_f64.c)
+inline signal tanh(const signal& x) { gpu::Recorder* r = gpu::recording(); signal s((float)::tanh((double)x.value)); if (r && x.reg >= 0) s.reg = r->emit(klg::graph::OP_FUNC, x.reg, -1, -1, 0, true); return s; }
 inline signal sqr(const signal& x) { return x * x; }
 inline signal cube(const signal& x) { return x * x * x; }
 // `x >> debug`: the plugin's debug scope (klang.h:3299); nothing to plot here
@@ -562,6 +566,37 @@ inline signal& operator+=(signal& s, Generic::Output<signal>& o) { s.value += si
 #define KLANG_CONTROL_OBJECT_OPS(OP) inline signal operator OP(Control& c, Generic::Output<signal>& o) { const signal& b = o; return c.value OP b; }
 KLANG_CONTROL_OBJECT_OPS(+) KLANG_CONTROL_OBJECT_OPS(-) KLANG_CONTROL_OBJECT_OPS(*) KLANG_CONTROL_OBJECT_OPS(/)
 #undef KLANG_CONTROL_OBJECT_OPS
+
+// Function<Args...> (klang.h:2331-2532 as the `optimised` / `basic` namespaces spell it: the signal type first): a C function applied to the signal stream —
+// `Function<float, float> f(softclip); in >> f(distort) >> out;` calls softclip(in, distort) per sample (all but the first argument bound by operator(); all of them:
+// the first one is the input).  The function is the patch's own code: to be RECORDED its arguments must be the tracing type, i.e. the patch is compiled with
+// -DKLANG_GPU_TRACE_FLOAT (the end of this header): `float` in the patch's text is then klang::signal, and so are Args.
+struct GraphStub;
+template<typename... Args> struct Function : Modifier {
+	static_assert(sizeof...(Args) >= 1, "Function<x, ...>: at least the input");
+	static constexpr bool kTraced = (std::is_base_of_v<signal, Args> && ...);
+	std::function<signal(Args...)> function;
+	std::tuple<Args...> inputs;
+	Function() {}
+	template<class F, typename = std::enable_if_t<std::is_invocable_v<F, Args...>>> Function(F fn) : function(fn) {}
+	template<class F, class... O, typename = std::enable_if_t<std::is_invocable_v<F, Args...>>> Function(F fn, O... o) : function(fn) { with(o...); }
+	template<class... O> Function& with(O... o) { static_assert(sizeof...(O) + 1 == sizeof...(Args), "with(): all but the first argument"); inputs = std::tuple<Args...>(in, o...); return *this; }
+	template<class... FA> Function& operator()(const FA&... a) {
+		if constexpr (sizeof...(FA) == sizeof...(Args)) { inputs = std::tuple<Args...>(a...); in = signal(std::get<0>(inputs)); }
+		else { static_assert(sizeof...(FA) + 1 == sizeof...(Args), "Function: only the first argument (the input) may be omitted"); inputs = std::tuple<Args...>(in, a...); }
+		return *this;
+	}
+	GraphStub& operator>>(GraphStub& g) { return g; }                                // `f(distort) >> graph;`: the UI plot
+	using Modifier::operator>>;
+	using Modifier::input;
+protected:
+	void input() override { std::get<0>(inputs) = in; }
+	void process() override {
+		if (!function) { out = 0.f; return; }
+		if constexpr (!kTraced) if (gpu::Recorder* r = gpu::recording()) r->fail("a Function<> over plain floats cannot be recorded: compile the patch with -DKLANG_GPU_TRACE_FLOAT (include/klang/klang.h)");
+		out = std::apply(function, inputs);
+	}
+};
 
 // `a >> b`: b.input(a) when b is an Input, else plain assignment (klang.h:4868-4890)
 template<class SRC, class DST, typename = std::enable_if_t<!std::is_arithmetic_v<SRC>>>
@@ -1079,7 +1114,8 @@ template<typename TYPE, int SIZE> struct Table {
 		return items[i] + (index - x) * (items[i + 1] - items[i]);
 	}
 };
-struct GraphStub { void clear() {} template<class... A> void add(A...) {} template<class... A> void plot(A...) {} };   // the UI line plotter: nothing to draw on here
+struct GraphStub { void clear() {} template<class... A> void add(A...) {} template<class... A> void plot(A...) {} template<class... A> GraphStub& operator()(A...) { return *this; } };   // the UI line plotter: nothing to draw on here (`graph(-2, 2)`: its axes)
+template<class R, class... A> inline GraphStub& operator>>(R (*)(A...), GraphStub& g) { return g; }   // `hardclip >> graph(-2, 2);` (Distortion/Functions.k:22): plotting a function
 inline thread_local GraphStub graph;
 
 // =================================================================================================
@@ -2301,3 +2337,12 @@ namespace minimal { using namespace klang; }
 // `std::abs(x)` of a signal: in the reference the signal converts to float and takes std::abs(float).  A recorded value has no float to
 // convert to, so the call is given the signal itself (an exact match beats the float conversion); same value, recordable.
 namespace std { inline klang::signal abs(const klang::signal& x) { return klang::abs(x); } }
+
+// ---- plain-`float` C functions applied to signals (examples/Distortion/Functions.k: `float hardclip(float x) {...}`, `hardclip(in * gain) >> out`) ----
+// A tracing facade cannot see into `float f(float)`: the signal converts to a float and the recorded world ends there.  A patch of that kind is compiled
+// with -DKLANG_GPU_TRACE_FLOAT: from here on — i.e. in the patch's OWN text, which follows this header — the word `float` names klang::signal, the value
+// that records what is done to it (arithmetic, comparisons in `if`: one traced run of process() per outcome).  The .k file itself stays as it is; whoever
+// includes it puts `#undef float` behind the include (include/klang/bindings.h and the test drivers do).
+#ifdef KLANG_GPU_TRACE_FLOAT
+#define float ::klang::signal
+#endif

@@ -174,10 +174,12 @@ enum OpCode {
 	OP_D2F,         /* dst = (float) a   (round to nearest even)                                                                                       */
 	OP_ENVOFF,      /* dst = env/adsr node .finished() ? 1.0 : 0.0     Envelope::finished klang.h:4094 (stage == Off) as a VALUE: `if (adsr.finished()) { ...; stop(); return; }`,
 	                   `!adsr.finished()`, `finished() && x > y` — the recorder turns the plain `if (env.finished()) stop();` back into stopif                 */
+	OP_FUNC,        /* dst = f(a), f by imm: 0 = (float) tanh((double) a) — what `tanh(x)` of a float is inside a patch's plain C function (the C library's DOUBLE
+	                   tanh: examples/Distortion/Shaping.k:15; klg_device.hpp tanh_f64 restates glibc 2.35's, equal on all 2^32 floats: tools/verify_tanh_f64.c) */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs", "f2d", "dconst", "dlow", "dadd", "dsub", "dmul", "ddiv", "d2f", "envoff" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs", "f2d", "dconst", "dlow", "dadd", "dsub", "dmul", "ddiv", "d2f", "envoff", "func" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -309,6 +311,7 @@ struct Program {
 			case OP_NOISE: if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;
 			case OP_SETCTL: if (k != N_CTLVAR) return bad("node is not a written control"); if (!channels) return bad("only an effect writes its controls"); if ((int)o.imm >= nctl) return bad("control index out of range"); need_a = true; break;
 			case OP_ABS: need_a = true; break;
+			case OP_FUNC: need_a = true; if (o.imm != 0u) return bad("no such function"); break;
 			case OP_F2D: need_a = true; if (is_dbl(o.a)) return bad("operand a is already a double"); dst_dbl = true; break;
 			case OP_DCONST: dst_dbl = true; break;
 			case OP_DLOW: need_a = true; if (!is_dbl(o.a)) return bad("operand a is not a double"); dst_dbl = true; break;

@@ -40,7 +40,7 @@ static hipError_t klg_module_launch(hipFunction_t fn, unsigned groups, unsigned 
 struct TimedLaunch {                                                // binds a handle's next pair of events to the launches made in its scope
 	template<class H> explicit TimedLaunch(H* h) {
 		if (!h->timing) return;
-		if ((int)h->tev.size() < 2 * (h->launches + 1)) { hipEvent_t e0 = nullptr, e1 = nullptr; if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return; h->tev.push_back(e0); h->tev.push_back(e1); }
+		if ((int)h->tev.size() < 2 * (h->launches + 1)) { hipEvent_t e0 = nullptr, e1 = nullptr; if (hipEventCreate(&e0) != hipSuccess) return; if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; } h->tev.push_back(e0); h->tev.push_back(e1); }
 		g_time0 = h->tev[2 * h->launches]; g_time1 = h->tev[2 * h->launches + 1]; h->launches++;
 	}
 	~TimedLaunch() { g_time0 = g_time1 = nullptr; }
@@ -48,7 +48,7 @@ struct TimedLaunch {                                                // binds a h
 struct TimedAux {                                                   // the same for a block's OTHER launches (its event kernel, the voice-mix reduce): a second list of events
 	template<class H> explicit TimedAux(H* h) {
 		if (!h->timing) return;
-		if ((int)h->tev_aux.size() < 2 * (h->launches_aux + 1)) { hipEvent_t e0 = nullptr, e1 = nullptr; if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return; h->tev_aux.push_back(e0); h->tev_aux.push_back(e1); }
+		if ((int)h->tev_aux.size() < 2 * (h->launches_aux + 1)) { hipEvent_t e0 = nullptr, e1 = nullptr; if (hipEventCreate(&e0) != hipSuccess) return; if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; } h->tev_aux.push_back(e0); h->tev_aux.push_back(e1); }
 		g_time0 = h->tev_aux[2 * h->launches_aux]; g_time1 = h->tev_aux[2 * h->launches_aux + 1]; h->launches_aux++;
 	}
 	~TimedAux() { g_time0 = g_time1 = nullptr; }
@@ -1523,7 +1523,17 @@ extern "C" int klg_timing_begin(klg_synth* s) { if (!s) return fail(KLG_ERR_INVA
 // the block's OTHER kernels since klg_timing_begin (the event kernel, the voice-mix reduce): launches and summed duration; call before klg_timing_end
 extern "C" int klg_timing_end_aux(klg_synth* s, int* launches, float* total_ms) {
 	if (!s || !launches || !total_ms) return fail(KLG_ERR_INVALID, "klg_timing_end_aux: bad arguments");
-	if (s->multi) return klg_timing_end_aux(s->multi->shard[0], launches, total_ms);
+	if (s->multi) {                                                     // the shard klg_timing_end reports: the one whose render kernels took longest (they run concurrently)
+		int best = 0; float best_ms = -1.f;
+		for (size_t i = 0; i < s->multi->shard.size(); i++) {
+			klg_synth* sh = s->multi->shard[i]; DeviceGuard bound(sh->device); if (!bound.ok) return KLG_ERR_NO_DEVICE;
+			HIP_TRY(hipDeviceSynchronize());
+			float total = 0.f;
+			for (int k = 0; k < sh->launches; k++) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, sh->tev[2 * k], sh->tev[2 * k + 1])); total += ms; }
+			if (total > best_ms) { best_ms = total; best = (int)i; }
+		}
+		return on_shard(s, (size_t)best, [&](klg_synth* sh) { return klg_timing_end_aux(sh, launches, total_ms); });
+	}
 	KLG_BIND(s);
 	HIP_TRY(hipDeviceSynchronize());
 	float total = 0.f;

@@ -201,6 +201,60 @@ __device__ __forceinline__ float basic_triangle(BOsc& o) { const float y = fabsf
 __device__ __forceinline__ float basic_square(BOsc& o) { const float y = o.position > KLG_PI_F ? 1.f : -1.f; phase_advance(o.position, o.increment); return y; }
 __device__ __forceinline__ float basic_pulse(BOsc& o, float duty) { const float y = o.position > (duty * KLG_PI_F) ? 1.f : -1.f; phase_advance(o.position, o.increment); return y; }
 
+// ---- tanh of a float as a patch's plain C function computes it: the C library's DOUBLE tanh, rounded back to float ----
+// `float softclip(float x, float c) { return tanh(c * x) / tanh(c); }` (examples/Distortion/Shaping.k:15): unqualified tanh of a float is ::tanh(double) (the pinned
+// build imports `tanh`, not `tanhf`).  glibc 2.35 sysdeps/ieee754/dbl-64/s_tanh.c over s_expm1.c (fdlibm): restated here in fp64 without fma; the float-rounded
+// result equals the host library's on ALL 2^32 floats (tools/verify_tanh_f64.c).
+__device__ __forceinline__ uint32_t dbl_hi(double x) { return (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32); }
+__device__ __forceinline__ double dbl_with_hi(double x, uint32_t h) { return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(x) & 0xFFFFFFFFull) | ((unsigned long long)h << 32))); }
+__device__ inline double glibc_expm1(double x) {
+	const double one = 1.0, tiny = 1.0e-300, ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00,
+		Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03, Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06, Q5 = -2.01099218183624371326e-07;
+	double y, hi, lo, c = 0.0, t, e;
+	int k;
+	uint32_t hx = dbl_hi(x);
+	const uint32_t xsb = hx & 0x80000000u;
+	hx &= 0x7fffffffu;
+	if (hx >= 0x4043687Au) {                                   // |x| >= 56 ln2 (tanh never asks for more than 44: the overflow side is not reached)
+		if (hx >= 0x40862E42u) { if (hx >= 0x7ff00000u) return (xsb == 0 || x != x) ? x + x : -1.0; if (x > 7.09782712893383973096e+02) return 1.0e+300 * 1.0e+300; }
+		if (xsb != 0) return tiny - one;
+	}
+	if (hx > 0x3fd62e42u) {                                    // |x| > 0.5 ln2
+		if (hx < 0x3FF0A2B2u) { if (xsb == 0) { hi = x - ln2_hi; lo = ln2_lo; k = 1; } else { hi = x + ln2_hi; lo = -ln2_lo; k = -1; } }
+		else { k = (int)(invln2 * x + (xsb == 0 ? 0.5 : -0.5)); t = (double)k; hi = x - t * ln2_hi; lo = t * ln2_lo; }
+		x = hi - lo; c = (hi - x) - lo;
+	}
+	else if (hx < 0x3c900000u) return x;
+	else k = 0;
+	const double hfx = 0.5 * x, hxs = x * hfx;
+	const double R1 = one + hxs * Q1, h2 = hxs * hxs, R2 = Q2 + hxs * Q3, h4 = h2 * h2, R3 = Q4 + hxs * Q5;
+	const double r1 = R1 + h2 * R2 + h4 * R3;
+	t = 3.0 - r1 * hfx;
+	e = hxs * ((r1 - t) / (6.0 - x * t));
+	if (k == 0) return x - (x * e - hxs);
+	e = (x * (e - c) - c); e -= hxs;
+	if (k == -1) return 0.5 * (x - e) - 0.5;
+	if (k == 1) return (x < -0.25) ? -2.0 * (e - (x + 0.5)) : one + 2.0 * (x - e);
+	if (k <= -2 || k > 56) { y = one - (e - x); y = dbl_with_hi(y, dbl_hi(y) + ((uint32_t)k << 20)); return y - one; }
+	if (k < 20) { t = dbl_with_hi(one, 0x3ff00000u - (0x200000u >> k)); y = t - (e - x); return dbl_with_hi(y, dbl_hi(y) + ((uint32_t)k << 20)); }
+	t = dbl_with_hi(one, (uint32_t)(0x3ff - k) << 20); y = x - (e + t); y += one;
+	return dbl_with_hi(y, dbl_hi(y) + ((uint32_t)k << 20));
+}
+__device__ inline float tanh_f64(float xf) {
+	const double x = (double)xf, one = 1.0, two = 2.0, tiny = 1.0e-300;
+	const uint32_t jx = dbl_hi(x), ix = jx & 0x7fffffffu;
+	double z;
+	if (ix >= 0x7ff00000u) return (float)(((int32_t)jx >= 0) ? one / x + one : one / x - one);
+	if (ix < 0x40360000u) {                                    // |x| < 22
+		if (x == 0.0) return xf;
+		if (ix < 0x3c800000u) return (float)(x * (one + x));
+		if (ix >= 0x3ff00000u) { const double t = glibc_expm1(two * __builtin_fabs(x)); z = one - two / (t + two); }
+		else { const double t = glibc_expm1(-two * __builtin_fabs(x)); z = -t / (t + two); }
+	}
+	else z = one - tiny;
+	return (float)(((int32_t)jx >= 0) ? z : -z);
+}
+
 // ---- Noise klang.h:4947-4951 (Basic), 5357-5366 (Fast) ----
 // The reference draws from libc rand(), one global sequential stream shared by every voice (F5).  The device
 // functions are the pure arithmetic applied to a rand() result; the stream itself is produced by klg_rand_fill (klg_rand_dev.hpp)

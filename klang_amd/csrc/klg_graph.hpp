@@ -366,6 +366,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			body += d + "(" + a + fmt(" < u2f(0x%08xu)) ? u2f(0x%08xu) : r%dh;\n\t\t", mn, mn, o.dst) + n + fmt(" = r%d;\n", o.dst);
 		} break;
 		case OP_ABS: body += d + "__builtin_fabsf(" + a + ");\n"; break;
+		case OP_FUNC: body += d + "tanh_f64(" + a + ");\n"; break;                              // (imm 0: the one function there is)
 		case OP_PARAM: body += d + n + ";\n"; break;
 		case OP_OSC: {
 			std::string e;

@@ -77,7 +77,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			case OP_CTL: reg_inv[(size_t)o.dst] = in.ctlvar[o.imm & 7u] < 0; break;
 			case OP_PARAM: reg_inv[(size_t)o.dst] = !written[(size_t)o.node]; break;
 			case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_CMP: case OP_DADD: case OP_DSUB: case OP_DMUL: case OP_DDIV: reg_inv[(size_t)o.dst] = depth == 0 && ri(o.a) && ri(o.b); break;
-			case OP_NEG: case OP_ABS: case OP_F2D: case OP_D2F: case OP_DLOW: reg_inv[(size_t)o.dst] = depth == 0 && ri(o.a); break;
+			case OP_NEG: case OP_ABS: case OP_FUNC: case OP_F2D: case OP_D2F: case OP_DLOW: reg_inv[(size_t)o.dst] = depth == 0 && ri(o.a); break;
 			default: break;
 			}
 		}
@@ -168,7 +168,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		case OP_CTL: inv[(size_t)i] = in.ctlvar[v.imm & 7u] < 0; break;
 		case OP_PARAM: inv[(size_t)i] = !written[(size_t)v.node]; break;
 		case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_CMP: case OP_DADD: case OP_DSUB: case OP_DMUL: case OP_DDIV: inv[(size_t)i] = v.path.empty() && opinv(v.a) && opinv(v.b); break;
-		case OP_NEG: case OP_ABS: case OP_F2D: case OP_D2F: case OP_DLOW: inv[(size_t)i] = v.path.empty() && opinv(v.a); break;
+		case OP_NEG: case OP_ABS: case OP_FUNC: case OP_F2D: case OP_D2F: case OP_DLOW: inv[(size_t)i] = v.path.empty() && opinv(v.a); break;
 		case V_LPFQ: case V_LPFCOEF: inv[(size_t)i] = v.path.empty() && opinv(v.a) && opinv(v.b); break;   // (dials only: once per chunk by whoever needs them)
 		}
 	}
@@ -322,6 +322,8 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		if (pipelined) { bool l0 = false; for (int i = 0; i < NV; i++) if (comp[(size_t)i] >= 0 && pfx[(size_t)i] && level[(size_t)i] == 0) l0 = true; poff = l0 ? 0 : 1; }
 		const int NTP = G * C;
 		if (NTP < 64 || NTP > 1024 || (NTP & 63)) return refuse("G x C must be 64 .. 1024 lanes");
+		// RingS (klg_delay.hpp) addresses a line's rows with 32-bit byte offsets from a wave-uniform base: (SIZE + 1) rows of G floats must stay below 4 GB
+		for (size_t d = 0; d < NN; d++) if (g.nodes[d] == N_DELAY && ((unsigned long long)g.arg((int)d) + 1ull) * (unsigned long long)G * 4ull >= (1ull << 32)) return refuse("a Delay line of 2^32 bytes or more per workgroup (32-bit row offsets)");
 		int NSW = 1;
 		for (int lv = 1; lv <= std::max(max_level, pmax); lv += 2) for (int grp = 0; grp < 2; grp++) {
 			std::vector<int> st; for (int c = 0; c < ncomp; c++) if (cserial[(size_t)c] && clevel[(size_t)c] == lv && (cpfx(c, members) ? 1 : 0) == grp) st.push_back(strand[(size_t)c]);
@@ -372,7 +374,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 							const VOp& v = V[(size_t)i];
 							switch (v.code) {
 							case OP_OSC: case V_OSCARG: case OP_OSCSET: case OP_LPF: case V_LPFAPPLY: case OP_ENV: case OP_OPERATOR: case OP_PARAM: case OP_SETPARAM: case OP_FREQ:
-							case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_NEG: case OP_ABS: case OP_CMP: break;
+							case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_NEG: case OP_ABS: case OP_FUNC: case OP_CMP: break;
 							default: ok = false;
 							}
 							if (!v.path.empty()) ok = false;

@@ -64,6 +64,11 @@ FX["fx_ownfdn"] = [(0.5, 3.0), (20.0, 900.0), (0.02, 0.24), (0.2, 1.0)]
 FX["fx_reverb2"] = [(0.0, 0.5), (0.0, 0.4), (500.0, 5000.0)]
 # tests/patches/fx_comb.k (OUR OWN effect, added after everything else): a Delay<0> sized with resize() read with tap(float), Delay::lagrange() on a Delay<2400>
 FX["fx_owncomb"] = [(0.6, 19.0), (0.0, 0.85), (0.0, 1.0)]
+# Distortion/Functions.k and Distortion/Shaping.k (added after everything else): a plain-`float` C function applied to the signal stream — `hardclip(in * gain) >> out`,
+# `Function<float, float> f(softclip); in >> f(distort) >> out` with softclip = tanh(c * x) / tanh(c), the C library's DOUBLE tanh.  Recorded by compiling the patch
+# with -DKLANG_GPU_TRACE_FLOAT (include/klang/klang.h: `float` in the patch's own text names the tracing signal)
+FX["fx_functions"] = [(1.0, 25.0)]
+FX["fx_shaping"] = [(0.001, 5.6)]
 SHAPE = {"fx_patterns": dict(K=4, blocks=110),       # name -> instances / blocks (default 9 / 24)
          "fx_topreverb": dict(K=9, blocks=64),
          "fx_reverb2": dict(K=9, blocks=40)}         # 8,192 samples: the early reflections arrive after ~2,600, mid[] ~400 later, late[] ~1,000 after that

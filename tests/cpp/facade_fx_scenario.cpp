@@ -7,6 +7,9 @@
 #include <vector>
 
 #include PATCH_FILE
+#ifdef KLANG_GPU_TRACE_FLOAT
+#undef float                 // (include/klang/klang.h: the patch's own text was compiled with `float` = the tracing signal)
+#endif
 #ifdef FX_BIND_LINE
 FX_BIND_LINE
 #endif

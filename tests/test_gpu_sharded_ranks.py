@@ -125,6 +125,25 @@ def test_bench_py_eight_ranks_end_to_end():
     assert out["config"]["mix_checksum"] > 0 and "x8" in out["config"]["parallelism"]
 
 
+
+def test_bench_py_in_library_mode():
+    """`python bench.py --gpus 4 --in-library`: ONE process, klg_init(ids), the bank sharded inside the library, the shards' blocks combined by the library's own
+    reduction (RCCL between distinct GPUs; a device-side add where KLG_BENCH_ONE_GPU=1 puts every shard on cuda:0: the functional run a one-GPU box can make)."""
+    import json
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 4:
+        env["KLG_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--in-library", "--steps", "6", "--warmup", "2", "--voices", str(375 * 512)],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["mode"] == "in-library" and out["steps"] == 6 and np.isfinite(out["value"]) and out["value"] > 0
+    assert out["config"]["mix_checksum"] > 0 and "x4" in out["config"]["parallelism"]
+
+
 FX_RANK = r'''
 import os, sys
 import numpy as np
