@@ -492,8 +492,12 @@ KLANG_CONTROL_DBL(+) KLANG_CONTROL_DBL(-) KLANG_CONTROL_DBL(*) KLANG_CONTROL_DBL
 #undef KLANG_CONTROL_DBL
 // sqr / cube (klang.h:3067-3069: Function<float> objects; applied to a signal they are the same fp32 products)
 // tanh of a signal: where the reference's patch code writes `tanh(x)` on a float (a plain C function: examples/Distortion/Shaping.k:15) it is the C library's DOUBLE
-// tanh of the converted float, rounded back (the pinned build imports `tanh`); the device restates glibc's (klg_device.hpp tanh_f64, tools/verify_tanh_f64.c)
-inline signal tanh(const signal& x) { gpu::Recorder* r = gpu::recording(); signal s((float)::tanh((double)x.value)); if (r && x.reg >= 0) s.reg = r->emit(klg::graph::OP_FUNC, x.reg, -1, -1, 0, true); return s; }
+// tanh of the converted float (the pinned build imports `tanh`); the device restates glibc's (klg_device.hpp glibc_tanh, tools/verify_tanh_f64.c)
+inline dsignal tanh(const signal& x) {                                  // (a double: the expression around it stays double in the reference — `tanh(c * x) / tanh(c)` divides doubles)
+	const dsignal a = dsignal::from(x); dsignal d(::tanh(a.value));
+	if (a.reg >= 0) if (gpu::Recorder* r = gpu::recording()) d.reg = r->emit(klg::graph::OP_FUNC, a.reg, -1, -1, 0, true);
+	return d;
+}
 inline signal sqr(const signal& x) { return x * x; }
 inline signal cube(const signal& x) { return x * x * x; }
 // `x >> debug`: the plugin's debug scope (klang.h:3299); nothing to plot here
@@ -1330,7 +1334,7 @@ inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	// ---- dead code: pure ops nobody reads, params nobody reads (and their write-backs), primitives nobody uses ----
 	std::vector<Op>& ops = R.prog.ops;
 	std::vector<char> keep(ops.size(), 1), used;
-	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG || c == OP_CMP || c == OP_ENVOFF || c == OP_PHI || c == OP_TABREAD || (c >= OP_F2D && c <= OP_D2F); };
+	auto pure = [](int c) { return c == OP_CONST || c == OP_CTL || c == OP_PARAM || c == OP_FREQ || c == OP_IN || c == OP_ADD || c == OP_SUB || c == OP_MUL || c == OP_DIV || c == OP_NEG || c == OP_CMP || c == OP_ENVOFF || c == OP_PHI || c == OP_TABREAD || c == OP_FUNC || (c >= OP_F2D && c <= OP_D2F); };
 	for (bool changed = true; changed;) {
 		changed = false;
 		used.assign(MAX_OPS + 1, 0); used[(size_t)R.prog.ret] = 1; if (R.prog.ret_r >= 0) used[(size_t)R.prog.ret_r] = 1;

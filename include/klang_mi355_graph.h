@@ -174,8 +174,9 @@ enum OpCode {
 	OP_D2F,         /* dst = (float) a   (round to nearest even)                                                                                       */
 	OP_ENVOFF,      /* dst = env/adsr node .finished() ? 1.0 : 0.0     Envelope::finished klang.h:4094 (stage == Off) as a VALUE: `if (adsr.finished()) { ...; stop(); return; }`,
 	                   `!adsr.finished()`, `finished() && x > y` — the recorder turns the plain `if (env.finished()) stop();` back into stopif                 */
-	OP_FUNC,        /* dst = f(a), f by imm: 0 = (float) tanh((double) a) — what `tanh(x)` of a float is inside a patch's plain C function (the C library's DOUBLE
-	                   tanh: examples/Distortion/Shaping.k:15; klg_device.hpp tanh_f64 restates glibc 2.35's, equal on all 2^32 floats: tools/verify_tanh_f64.c) */
+	OP_FUNC,        /* dst(double) = f(a), a a double, f by imm: 0 = tanh — what `tanh(x)` of a float is inside a patch's plain C function: the C library's DOUBLE tanh of the
+	                   converted float, and the expression around it stays double (`tanh(c * x) / tanh(c)`, examples/Distortion/Shaping.k:15: f2d, func, ddiv, d2f).
+	                   klg_device.hpp glibc_tanh restates glibc 2.35's (float-rounded result equal on all 2^32 floats: tools/verify_tanh_f64.c) */
 	OP_CODES
 };
 inline const char* op_name(int code) {
@@ -311,7 +312,7 @@ struct Program {
 			case OP_NOISE: if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;
 			case OP_SETCTL: if (k != N_CTLVAR) return bad("node is not a written control"); if (!channels) return bad("only an effect writes its controls"); if ((int)o.imm >= nctl) return bad("control index out of range"); need_a = true; break;
 			case OP_ABS: need_a = true; break;
-			case OP_FUNC: need_a = true; if (o.imm != 0u) return bad("no such function"); break;
+			case OP_FUNC: need_a = true; if (o.imm != 0u) return bad("no such function"); if (!is_dbl(o.a)) return bad("operand a is not a double"); dst_dbl = true; break;
 			case OP_F2D: need_a = true; if (is_dbl(o.a)) return bad("operand a is already a double"); dst_dbl = true; break;
 			case OP_DCONST: dst_dbl = true; break;
 			case OP_DLOW: need_a = true; if (!is_dbl(o.a)) return bad("operand a is not a double"); dst_dbl = true; break;
@@ -339,7 +340,7 @@ struct Program {
 			after_endif = o.code == OP_ENDIF || o.code == OP_PHI;
 			if (need_a && !def(o.a)) return bad("operand a is not defined");
 			if (need_b && !def(o.b)) return bad("operand b is not defined");
-			if (!(o.code >= OP_F2D && o.code <= OP_D2F) && ((need_a && is_dbl(o.a)) || (need_b && is_dbl(o.b)) || (o.code == OP_PHI && (is_dbl(o.a) || is_dbl(o.b))))) return bad("a double register may only be read by dlow / dadd / dsub / dmul / ddiv / d2f");
+			if (!((o.code >= OP_F2D && o.code <= OP_D2F) || o.code == OP_FUNC) && ((need_a && is_dbl(o.a)) || (need_b && is_dbl(o.b)) || (o.code == OP_PHI && (is_dbl(o.a) || is_dbl(o.b))))) return bad("a double register may only be read by dlow / dadd / dsub / dmul / ddiv / d2f");
 			if (has_dst) {
 				if (o.dst < 0 || o.dst >= MAX_OPS) return bad("bad destination register");
 				if ((int)defined.size() <= o.dst) defined.resize((size_t)o.dst + 1, 0);

@@ -203,8 +203,8 @@ __device__ __forceinline__ float basic_pulse(BOsc& o, float duty) { const float 
 
 // ---- tanh of a float as a patch's plain C function computes it: the C library's DOUBLE tanh, rounded back to float ----
 // `float softclip(float x, float c) { return tanh(c * x) / tanh(c); }` (examples/Distortion/Shaping.k:15): unqualified tanh of a float is ::tanh(double) (the pinned
-// build imports `tanh`, not `tanhf`).  glibc 2.35 sysdeps/ieee754/dbl-64/s_tanh.c over s_expm1.c (fdlibm): restated here in fp64 without fma; the float-rounded
-// result equals the host library's on ALL 2^32 floats (tools/verify_tanh_f64.c).
+// build imports `tanh`, not `tanhf`).  glibc 2.35 sysdeps/ieee754/dbl-64/s_tanh.c over s_expm1.c (fdlibm): restated here in fp64 without fma; for every float argument the result's
+// float rounding equals the host library's (all 2^32 floats: tools/verify_tanh_f64.c) — the double itself is the same sequence of IEEE operations.
 __device__ __forceinline__ uint32_t dbl_hi(double x) { return (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32); }
 __device__ __forceinline__ double dbl_with_hi(double x, uint32_t h) { return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(x) & 0xFFFFFFFFull) | ((unsigned long long)h << 32))); }
 __device__ inline double glibc_expm1(double x) {
@@ -240,19 +240,19 @@ __device__ inline double glibc_expm1(double x) {
 	t = dbl_with_hi(one, (uint32_t)(0x3ff - k) << 20); y = x - (e + t); y += one;
 	return dbl_with_hi(y, dbl_hi(y) + ((uint32_t)k << 20));
 }
-__device__ inline float tanh_f64(float xf) {
-	const double x = (double)xf, one = 1.0, two = 2.0, tiny = 1.0e-300;
+__device__ inline double glibc_tanh(double x) {
+	const double one = 1.0, two = 2.0, tiny = 1.0e-300;
 	const uint32_t jx = dbl_hi(x), ix = jx & 0x7fffffffu;
 	double z;
-	if (ix >= 0x7ff00000u) return (float)(((int32_t)jx >= 0) ? one / x + one : one / x - one);
+	if (ix >= 0x7ff00000u) return ((int32_t)jx >= 0) ? one / x + one : one / x - one;
 	if (ix < 0x40360000u) {                                    // |x| < 22
-		if (x == 0.0) return xf;
-		if (ix < 0x3c800000u) return (float)(x * (one + x));
+		if (x == 0.0) return x;
+		if (ix < 0x3c800000u) return x * (one + x);
 		if (ix >= 0x3ff00000u) { const double t = glibc_expm1(two * __builtin_fabs(x)); z = one - two / (t + two); }
 		else { const double t = glibc_expm1(-two * __builtin_fabs(x)); z = -t / (t + two); }
 	}
 	else z = one - tiny;
-	return (float)(((int32_t)jx >= 0) ? z : -z);
+	return ((int32_t)jx >= 0) ? z : -z;
 }
 
 // ---- Noise klang.h:4947-4951 (Basic), 5357-5366 (Fast) ----

@@ -366,7 +366,6 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			body += d + "(" + a + fmt(" < u2f(0x%08xu)) ? u2f(0x%08xu) : r%dh;\n\t\t", mn, mn, o.dst) + n + fmt(" = r%d;\n", o.dst);
 		} break;
 		case OP_ABS: body += d + "__builtin_fabsf(" + a + ");\n"; break;
-		case OP_FUNC: body += d + "tanh_f64(" + a + ");\n"; break;                              // (imm 0: the one function there is)
 		case OP_PARAM: body += d + n + ";\n"; break;
 		case OP_OSC: {
 			std::string e;
@@ -413,6 +412,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		case OP_NEG: body += d + "-" + a + ";\n"; break;
 		// double registers (include/klang_mi355_graph.h): IEEE double arithmetic, contraction off like everything else
 		case OP_F2D: body += dd + "(double)" + a + ";\n"; break;
+		case OP_FUNC: body += dd + "glibc_tanh(" + a + ");\n"; break;                           // (imm 0: the one function there is)
 		case OP_DCONST: body += dd + fmt("__longlong_as_double(0x%08x00000000ll);\n", o.imm); break;
 		case OP_DLOW: body += dd + "__longlong_as_double(__double_as_longlong(" + a + fmt(") | 0x%08xll);\n", o.imm); break;
 		case OP_DADD: body += dd + a + " + " + b + ";\n"; break;

@@ -60,7 +60,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 	int maxreg = -1;
 	for (const Op& o : g.ops) maxreg = std::max(maxreg, std::max(o.dst, std::max(o.a, o.b)));
 	std::vector<char> is_dbl((size_t)maxreg + 2 + 8 * (size_t)N, 0);
-	for (const Op& o : g.ops) if (o.code == OP_F2D || o.code == OP_DCONST || o.code == OP_DLOW || (o.code >= OP_DADD && o.code <= OP_DDIV)) is_dbl[(size_t)o.dst] = 1;
+	for (const Op& o : g.ops) if (o.code == OP_F2D || o.code == OP_DCONST || o.code == OP_DLOW || o.code == OP_FUNC || (o.code >= OP_DADD && o.code <= OP_DDIV)) is_dbl[(size_t)o.dst] = 1;
 	std::vector<bool> written(g.nodes.size(), false);
 	for (int i = first; i < N; i++) if (g.ops[(size_t)i].code == OP_SETPARAM) written[(size_t)g.ops[(size_t)i].node] = true;
 	// (which registers are block invariants, on the recorded ops: a set(f, Q) of dials only stays one op — its test against the cached pair is all a sample costs)
