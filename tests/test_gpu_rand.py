@@ -153,3 +153,44 @@ def test_noise_notes_draw_in_the_order_synth_process_walks_them(S, P, density):
     LIBC.srand(seed); libc_draws(total * n * 2)
     assert LIBC.rand() == nxt
     bank.close()
+
+
+@pytest.mark.parametrize("devs", [(0, 0), (0, 0, 0)])
+def test_noise_banks_sharded_over_devices_keep_the_one_sequence(devs):
+    """A bank sharded inside the library (klg_init with several ids; here the shards share cuda:0): the rand() sequence is handed from shard to shard in instance
+    order — what ONE Synth::process loop over all the notes would draw — for notes (7 instances over 2 / 3 shards) and for an effect bank sharded by instance."""
+    L = klang_amd.lib()
+    S, P, n = 7, 16, 64
+    V, rng = S * P, np.random.default_rng(3)
+    on = rng.random(V) < 0.6
+    def notes():
+        bank = klang_amd.SynthBank(NOISE_NOTE, synths=S, notes=P, max_block=n)
+        W = bank.state_bytes // 4
+        recs = np.zeros((int(on.sum()), W), np.uint32); recs[:, 0] = ST_SUSTAIN
+        bank.voices_upload(np.nonzero(on)[0].tolist(), recs)
+        L.klg_random_seed(77)
+        out = [bank.process_voices(n)[0].copy() for _ in range(3)]
+        bank.close()
+        return np.stack(out)
+    def effect():
+        K = 23
+        bank = klang_amd.FxBank(NOISE_FX, K, max_block=n, channels=1)
+        L.klg_random_seed(78)
+        out = []
+        for _ in range(3):
+            io = np.full((K, 1, n), 0.25, np.float32)
+            bank.process(io); out.append(io.copy())
+        bank.close()
+        return np.stack(out)
+    klang_amd.init([0])
+    try:
+        ref_n, ref_f = notes(), effect()
+        LIBC.srand(77)
+        r = libc_draws(int(on.sum()) * n * 2).reshape(-1, n, 2)
+        assert np.array_equal(ref_n[0][on].view(np.uint32), (basic_noise(r[..., 0]) + fast_noise(r[..., 1])).view(np.uint32))
+        klang_amd.init(list(devs))
+        got_n, got_f = notes(), effect()
+    finally:
+        klang_amd.init([0])
+    assert np.array_equal(got_n.view(np.uint32), ref_n.view(np.uint32)) and np.array_equal(got_f.view(np.uint32), ref_f.view(np.uint32))
+    assert np.abs(ref_f - 0.25).max() > 0.1
