@@ -1966,8 +1966,22 @@ template<class NOTE> inline const float* solo_render(NOTE* note, int at, int m) 
 namespace gpu { enum MixMode { Sum = 0, LastActiveVoice = 1 }; }          // how the voices of a MONO Synth combine (see klang::Synth below)
 
 template<class NOTEBASE> struct SynthCore : Plugin {
-	struct Slot { NOTEBASE* note = nullptr; NoteBinding b = { -1, nullptr, nullptr }; const gpu::GraphLayout* graph = nullptr; };
+	struct Slot { NOTEBASE* note = nullptr; NoteBinding b = { -1, nullptr, nullptr }; const gpu::GraphLayout* graph = nullptr; const char* lo = nullptr; };   // lo: the most derived object's address
+	// NOTE VARIANTS (-DKLANG_GPU_NOTE_VARIANTS).  A recorded body is one program per Note TYPE — but a note's process() may depend on HOST state that its on() sets: a pointer to
+	// one of several member oscillators (examples/Additive/Inheritance.k: `Additive* osc` chosen by a Menu in on(), `*osc >> out` in process()), an `int` that selects a
+	// branch.  With the switch nothing is recorded at notes.add<T>(); instead every event of a note (noteOn, noteOff, a hook) is followed by a recording of THAT note's
+	// process() with its host state as the event left it.  Equal program texts share a bank ("variant"); a note whose text changed moves to the other variant's bank (its
+	// record travels through the host mirror, as at any event); a block renders every variant's bank into the same buffers.  What notes of DIFFERENT variants would share
+	// through their Synth — a smooth()ed control, the rand() sequence of Noise generators — is ordered per bank, not per slot: such patches keep to one variant.
+#ifdef KLANG_GPU_NOTE_VARIANTS
+	static constexpr bool kVariants = true;
+#else
+	static constexpr bool kVariants = false;
+#endif
+	struct Variant { gpu::GraphLayout* layout = nullptr; klg_synth* bank = nullptr; std::vector<uint32_t> words; std::vector<uint8_t> stages; };
+	std::vector<Variant> variants; std::vector<int> slot_variant;
 	struct NotesT {
+		std::vector<gpu::Obj> proto_objs; const char* proto_lo = nullptr; size_t proto_size = 0; std::string type_name;   // (variants: the prototype's members, re-based onto each note)
 		SynthCore* owner; std::vector<Slot> items; unsigned noteOns = 0; unsigned noteStart[128] = { 0 };
 		unsigned count = 0;
 		std::vector<gpu::GraphLayout*> layouts;
@@ -1979,11 +1993,17 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 			note_type = &typeid(T); hooks = gpu::NoteHooks<T>::mask();
 			const bool bound = klang_gpu_patch((const T*)nullptr) >= 0 && !std::getenv("KLANG_MI355_FORCE_GRAPH");
 			const gpu::GraphLayout* layout = items.empty() ? nullptr : items[0].graph;
+			type_name = typeid(T).name();
 			for (int i = 0; i < n && items.size() < 128; i++) {
 				T* t = nullptr;
-				if (!bound && !layout) { gpu::GraphLayout* l = new gpu::GraphLayout(); layouts.push_back(l); t = record<T>(*l); layout = l; }   // the prototype becomes note 0
+				if (kVariants && !bound) {                                        // (see NOTE VARIANTS above: members noted once, nothing recorded yet)
+					if (!proto_lo) { gpu::Recorder C; gpu::rec = &C; C.constructing = true; t = new T(); C.constructing = false; gpu::rec = nullptr; proto_lo = (const char*)t; proto_size = sizeof(T); proto_objs = gpu::member_objs(C, proto_lo, proto_lo + sizeof(T)); }
+					else { gpu::log_suppress++; t = new T(); gpu::log_suppress--; }
+					t->attach(static_cast<typename T::synth_type*>(owner));
+				}
+				else if (!bound && !layout) { gpu::GraphLayout* l = new gpu::GraphLayout(); layouts.push_back(l); t = record<T>(*l); layout = l; }   // the prototype becomes note 0
 				else { gpu::log_suppress++; t = new T(); gpu::log_suppress--; t->attach(static_cast<typename T::synth_type*>(owner)); }
-				Slot s; s.note = t; s.graph = layout;
+				Slot s; s.note = t; s.graph = layout; s.lo = (const char*)t;
 				s.b.patch = bound ? klang_gpu_patch((const T*)t) : -1;
 				s.b.pack = [](const void* p, uint32_t* w) { klang_gpu_pack((const T*)p, w); };
 				s.b.unpack = [](void* p, const uint32_t* w) { klang_gpu_unpack((T*)p, w); };
@@ -2023,13 +2043,14 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 	gpu::FxRunner post;                                                      // the Synth's own process() (post-processing of the mix), if it has one
 
 	SynthCore() { notes.owner = this; }
-	~SynthCore() { if (gpu) klg_synth_destroy(gpu); }
+	~SynthCore() { if (kVariants) { for (auto& v : variants) { if (v.bank) klg_synth_destroy(v.bank); delete v.layout; } } else if (gpu) klg_synth_destroy(gpu); }
 
 	virtual bool mono_synth() const { return false; }
 	void fail(const char* what) { std::fprintf(stderr, "klang-mi355: %s: %s\n", what, klg_last_error()); std::abort(); }
 	void ensure_gpu() {
 		if (gpu) return;
 		gpu::close_log();
+		if (kVariants && notes.count && notes.proto_lo) { if (slot_variant.size() != notes.count) slot_variant.assign(notes.count, -1); return; }   // (banks are made per variant, at the first event that needs one)
 		if (!notes.count) { std::fprintf(stderr, "klang-mi355: Synth has no notes (call notes.add<T>(n))\n"); std::abort(); }
 		const int patch = notes.items[0].b.patch;
 		if (const gpu::GraphLayout* g = notes.items[0].graph) {              // recorded process(): compiled for gfx950 now (hipRTC)
@@ -2049,13 +2070,64 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		sync_controls();
 		push_smoothed();
 	}
-	void sync_controls() { for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_set_control(gpu, 0, (int)c, controls.items[c].value.value); }
+	void sync_controls() { if (kVariants && notes.proto_lo) { for (auto& v : variants) for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(v.bank); c++) klg_set_control(v.bank, 0, (int)c, controls.items[c].value.value); return; }
+		for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_set_control(gpu, 0, (int)c, controls.items[c].value.value); }
 	// Control::smoothed (klang.h:1707): the bank advances it (every sounding note's smooth() calls, in order); the host objects follow
-	void push_smoothed() { for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_set_control_smoothed(gpu, 0, (int)c, controls.items[c].smoothed.value); }
-	void pull_smoothed() { for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_get_control_smoothed(gpu, 0, (int)c, &controls.items[c].smoothed.value); }
+	void push_smoothed() { if (kVariants && notes.proto_lo) return; for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_set_control_smoothed(gpu, 0, (int)c, controls.items[c].smoothed.value); }
+	void pull_smoothed() { if (kVariants && notes.proto_lo) return; for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_get_control_smoothed(gpu, 0, (int)c, &controls.items[c].smoothed.value); }
+	// ---- NOTE VARIANTS: the event path and the block ----
+	std::vector<gpu::Obj> rebased_objs(const Slot& s) const {
+		std::vector<gpu::Obj> objs = notes.proto_objs;
+		const ptrdiff_t d = s.lo - notes.proto_lo;
+		auto move = [&](const void* p) -> const void* { const char* c = (const char*)p; return (c >= notes.proto_lo && c < notes.proto_lo + notes.proto_size) ? c + d : c; };
+		for (auto& o : objs) { o.addr = move(o.addr); if (o.packable) o.packable = (const gpu::Packable*)move(o.packable); if (o.key) o.key = move(o.key); if (o.live_arg) o.live_arg = (const int*)move(o.live_arg); }
+		return objs;
+	}
+	int variant_of(gpu::GraphLayout* L) {                                    // takes L (kept by a new variant, deleted when its text is known)
+		for (size_t i = 0; i < variants.size(); i++) if (variants[i].layout->program == L->program) { delete L; return (int)i; }
+		Variant v; v.layout = L;
+		v.bank = klg_synth_create_graph(L->program.c_str(), 1, (int)notes.count, fs.f, 1024);
+		if (!v.bank) fail("klg_synth_create_graph (note variant)");
+		for (size_t k = 0; k < L->tables.size(); k++) if (klg_table_upload(v.bank, L->tables[k].data(), (int)L->tables[k].size(), 0) != (int)k + 1) fail("klg_table_upload (Table read by process())");
+		if (mix != gpu::Sum) { std::fprintf(stderr, "klang-mi355: KLANG_GPU_NOTE_VARIANTS renders every variant's bank into the block: only the summing mix\n"); std::abort(); }
+		v.words.assign(klg_synth_state_bytes(v.bank) / 4, 0u); v.stages.assign(notes.count, (uint8_t)klg::ST_OFF);
+		variants.push_back(v);
+		if (!gpu) gpu = v.bank;                                               // (what asks a bank for the number of controls)
+		for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(v.bank); c++) { klg_set_control(v.bank, 0, (int)c, controls.items[c].value.value); klg_set_control_smoothed(v.bank, 0, (int)c, controls.items[c].smoothed.value); }
+		return (int)variants.size() - 1;
+	}
+	template<class F> void with_voice_variant(int n, F&& event_code) {
+		Slot& s = notes.items[(size_t)n];
+		const int v = slot_variant[(size_t)n];
+		if (v >= 0) {
+			Variant& V = variants[(size_t)v];
+			if (klg_voice_download(V.bank, n, V.words.data(), V.words.size() * 4)) fail("klg_voice_download");
+			bool used = (V.words[0] & 3u) != (uint32_t)klg::ST_OFF || s.note->stage != NOTEBASE::Off;
+			for (size_t w = 1; w < V.words.size() && !used; w++) used = V.words[w] != 0u;
+			if (used) V.layout->unpack(s.note, V.words.data());
+			gpu::upload_target = V.bank; gpu::current_voice = n; gpu::current_note = s.note; gpu::current_layout = V.layout;
+		}
+		event_code(s.note);
+		gpu::GraphLayout* L = new gpu::GraphLayout();
+		gpu::record_note(s.note, rebased_objs(s), controls, s.lo, *L, notes.type_name.c_str());   // process() with the host state this event left
+		const int v2 = variant_of(L);
+		Variant& W = variants[(size_t)v2];
+		if (v >= 0 && v2 != v) {                                               // the voice leaves its old variant's bank (Off there) with everything its record held
+			Variant& V = variants[(size_t)v];
+			if (V.words.size() == W.words.size()) W.words = V.words;
+			std::vector<uint32_t> off(V.words.size(), 0u); off[0] = (uint32_t)klg::ST_OFF;
+			if (klg_voice_upload(V.bank, n, off.data(), off.size() * 4)) fail("klg_voice_upload");
+		}
+		else if (v < 0) std::fill(W.words.begin(), W.words.end(), 0u);
+		W.layout->pack(s.note, W.words.data());
+		W.words[0] = (W.words[0] & ~3u) | (uint32_t)s.note->stage;
+		if (klg_voice_upload(W.bank, n, W.words.data(), W.words.size() * 4)) fail("klg_voice_upload");
+		slot_variant[(size_t)n] = v2; s.graph = W.layout;
+	}
 	// host mirror <- lane ; run the event ; lane <- host mirror
 	template<class F> void with_voice(int n, F&& event_code) {
 		ensure_gpu();
+		if (kVariants && notes.proto_lo) { with_voice_variant(n, event_code); return; }
 		Slot& s = notes.items[(size_t)n];
 		if (klg_voice_download(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_download");
 		// the lane's record -> the host mirror.  A note keeps ALL its member state from one note to the next in the reference (filter memories,
@@ -2098,6 +2170,13 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		else onMIDI(status, byte1, byte2);
 	}
 	void refresh_stages() {
+		if (kVariants && notes.proto_lo) {
+			for (size_t v = 0; v < variants.size(); v++) {
+				if (klg_voice_stages(variants[v].bank, variants[v].stages.data(), (int)notes.count)) fail("klg_voice_stages");
+				for (unsigned n = 0; n < notes.count; n++) if (slot_variant[n] == (int)v && variants[v].stages[n] == klg::ST_OFF) notes[(int)n]->stage = NOTEBASE::Off;
+			}
+			return;
+		}
 		if (klg_voice_stages(gpu, stages.data(), (int)notes.count)) fail("klg_voice_stages");
 		for (unsigned n = 0; n < notes.count; n++) if (stages[n] == klg::ST_OFF) notes[(int)n]->stage = NOTEBASE::Off;    // `if (!note->process(..)) note->stop()`
 	}
@@ -2105,6 +2184,21 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 	void render_voices(float* const* buffers, int channels, int length) {
 		ensure_gpu();
 		sync_controls();
+		if (kVariants && notes.proto_lo) {                                       // every variant's bank adds its sounding voices to the block
+			std::vector<float> tmp;
+			for (size_t v = 0; v < variants.size(); v++) {
+				if (per_voice_sink) {
+					const size_t row = (size_t)klg_synth_note_channels(variants[v].bank) * (size_t)length;
+					tmp.assign(row * notes.count, 0.f);
+					if (klg_process_voices(variants[v].bank, tmp.data(), buffers, channels, length)) fail("klg_process_voices");
+					for (unsigned n = 0; n < notes.count; n++) if (slot_variant[n] == (int)v) std::memcpy(per_voice_sink + (size_t)n * row, tmp.data() + (size_t)n * row, row * sizeof(float));
+				}
+				else if (klg_process(variants[v].bank, buffers, channels, length, nullptr)) fail("klg_process");
+			}
+			if (per_voice_sink) for (unsigned n = 0; n < notes.count; n++) if (slot_variant[n] < 0) std::memset(per_voice_sink + (size_t)n * (size_t)length * (variants.empty() ? 1 : (size_t)klg_synth_note_channels(variants[0].bank)), 0, (size_t)length * (variants.empty() ? 1 : (size_t)klg_synth_note_channels(variants[0].bank)) * sizeof(float));
+			refresh_stages();
+			return;
+		}
 		if (per_voice_sink) { if (klg_process_voices(gpu, per_voice_sink, buffers, channels, length)) fail("klg_process_voices"); }
 		else if (klg_process(gpu, buffers, channels, length, nullptr)) fail("klg_process");
 		refresh_stages();

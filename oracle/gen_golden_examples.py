@@ -105,10 +105,13 @@ def scenarios():
     out["own_finish_body"] = poly("own_finish_body", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 0, 0.05)])
     # pwm.k: set(f, phase, duty) on Fast::Pulse / Fast::Saw / Basic::Pulse from inside branches of process()
     out["own_pwm"] = poly("own_pwm", 40, [0, 1, 7, 8, 39], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 0, 0.1)])
+    # (added in round 5) Additive/Inheritance.k: on() points `Additive* osc` at one of three member oscillators by a Menu control, process() is `*osc >> out` — the body
+    # depends on HOST state of the note: recorded per note after its events (-DKLANG_GPU_NOTE_VARIANTS).  The menu moves while notes start: three variants sound together
+    out["ex_inheritance"] = poly("ex_inheritance", 32, [0, 1, 5, 9, 31], off_base=12, ctl=[(0, 0.0)], ctl_events=[(3, 0, 1.0), (6, 0, 2.0), (8, 0, 0.0), (9, 0, 2.0)])
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],
-                "ex_operators": [(0, 1.0), (1, 0.5), (2, 1.0), (3, 4.296), (4, 2.0)], "own_early_return": [(0, 0.9)], "own_smooth_note": [(0, 2500.0), (1, 0.5)]}
+                "ex_operators": [(0, 1.0), (1, 0.5), (2, 1.0), (3, 4.296), (4, 2.0)], "own_early_return": [(0, 0.9)], "own_smooth_note": [(0, 2500.0), (1, 0.5)], "ex_inheritance": [(0, 2.0)]}
     for name in list(out):
         src = out[name]
         s = Scenario(patch=src.patch, block=256, blocks=24, synths=1, notes=src.notes, dump=[0, 23])
