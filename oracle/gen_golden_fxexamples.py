@@ -69,6 +69,8 @@ FX["fx_owncomb"] = [(0.6, 19.0), (0.0, 0.85), (0.0, 1.0)]
 # with -DKLANG_GPU_TRACE_FLOAT (include/klang/klang.h: `float` in the patch's own text names the tracing signal)
 FX["fx_functions"] = [(1.0, 25.0)]
 FX["fx_shaping"] = [(0.001, 5.6)]
+# tests/patches/fx_lines.k (OUR OWN effect, added last): an ARRAY of user Modifiers as a member, Delay -> LPF -> gain, a Matrix with zero entries
+FX["fx_ownlines"] = [(2.0, 30.0), (300.0, 9000.0), (0.0, 0.55), (0.2, 1.0)]
 SHAPE = {"fx_patterns": dict(K=4, blocks=110),       # name -> instances / blocks (default 9 / 24)
          "fx_topreverb": dict(K=9, blocks=64),
          "fx_reverb2": dict(K=9, blocks=40)}         # 8,192 samples: the early reflections arrive after ~2,600, mid[] ~400 later, late[] ~1,000 after that

@@ -130,6 +130,16 @@ def test_own_fdn_effect_with_user_modifiers_signals4_and_matrix(tmp_path):
     assert exact == 1.0 and np.abs(ref).max() > 0.1
 
 
+def test_own_effect_with_an_array_of_user_modifiers_and_a_sparse_matrix(tmp_path):
+    """tests/patches/fx_lines.k (ours): `Line line[4]` — an array of a user Modifier type as a member, every element's Delay / LPF / param its own state of the record —
+    each line `(in >> tape >> tone) * level` (Delay -> LPF -> gain), set up in a loop in prepare(); `signals<4> >> Matrix` with zero entries (the `0 * x` products are
+    computed, as in the reference), the rows fed back.  Nine instances, dials changed mid-run, bit for bit against the genuine header."""
+    got, ref = run_effect("fx_ownlines", tmp_path, own=True)
+    exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+    print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e}")
+    assert exact == 1.0 and np.abs(ref).max() > 0.1
+
+
 def test_own_comb_effect_with_a_resizable_delay_and_a_lagrange_tap(tmp_path):
     """tests/patches/fx_comb.k (ours): a `Delay<0>` — the resizable line of klang.h:3515-3624, sized with resize(9600) in the constructor: the node's SIZE is
     read when the recording is finished — as a feedback comb read with tap(float), and `pre.lagrange(t)` (klang.h:3429-3458: four rows, third-order
