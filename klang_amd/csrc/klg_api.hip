@@ -147,7 +147,7 @@ extern "C" int klg_init(const int* device_ids, int n_devices) {
 struct RngChain {
 	bool on_device = false; int device = -1;
 	std::map<int, uint32_t*> d_state;                              // per device: 32 words
-	std::map<int, hipEvent_t> last; hipStream_t last_stream = nullptr;   // after the last launch that used the state on that device
+	std::map<int, hipEvent_t> last; std::map<int, bool> used; hipStream_t last_stream = nullptr;   // after the last launch that used the state on that device (used: the event has been recorded)
 	std::map<std::pair<int, unsigned long long>, uint32_t*> tables;    // (device, per) -> klg_rand::jump_table(per) in HBM
 };
 static RngChain g_rng;
@@ -166,6 +166,7 @@ static int rng_acquire(int device, hipStream_t st, uint32_t** state) {
 		klg_rand::State s;
 		if (!klg_rand::libc_state(s)) return fail(KLG_ERR_INVALID, "the C library's rand() is not running its default generator (initstate() with a small state?): the Noise generators have no stream to continue");
 		RandStateArg arg; std::memcpy(arg.x, s.x, sizeof arg.x);
+		if (g.used.count(device) && g.last_stream != st) HIP_TRY(hipStreamWaitEvent(st, g.last[device], 0));   // (an earlier sequence's last Noise block may still be reading these words on another stream)
 		hipLaunchKernelGGL(klg_rand_set, dim3(1), dim3(64), 0, st, mine, arg);
 		HIP_TRY(hipGetLastError());
 	}
@@ -181,6 +182,7 @@ static int rng_acquire(int device, hipStream_t st, uint32_t** state) {
 static int rng_release(int device, hipStream_t st) {                // after the launches that read / advanced the state
 	std::lock_guard<std::recursive_mutex> lock(RandGuard::mu());
 	HIP_TRY(hipEventRecord(g_rng.last[device], st));
+	g_rng.used[device] = true;
 	return 0;
 }
 static int rng_table(int device, unsigned long long per, const uint32_t** table) {

@@ -254,7 +254,7 @@ template<int I> struct IntTag { static constexpr int value = I; };
 // waits for LDS only, and the requests come back in the order they are used in).  P per workgroup width: what the registers hold.
 // Arithmetic and its order are those of klg_fx_pingpong (KLG_FX_PINGPONG1=1) and the reference, bit for bit.
 #ifndef KLG_PPX_VARIANT
-#define KLG_PPX_VARIANT 0         // measurement builds only: 1 the filter waves store their chunk (one step fewer), 2 the first requests wait for the decision, 8 vibrato: no sines ahead
+#define KLG_PPX_VARIANT 0         // measurement builds only: 1 the filter waves store their chunk (one step fewer), 2 the first requests wait for the decision, 4 workgroups take their instances in blockIdx order, 8 vibrato: no sines ahead
 #endif
 #ifndef KLG_PPX_ABLATE
 #define KLG_PPX_ABLATE 0          // measurement builds only (tools/ppx_ablate.sh): 1 no DC filter chain, 2 no output stores, 4 no ring requests, 8 no audio stage
@@ -287,7 +287,15 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int li = lane & (G - 1), lq = lane / G;                                  // this lane's instance of the workgroup; its sample slot in an audio pass
-	const int k0 = blockIdx.x * G, k = k0 + li;
+	// Which instances this workgroup takes.  The delay lines are rows of 64 instances (256 bytes); at G = 16 / 32 a workgroup reads and writes a quarter / half of
+	// every row, and a 128-byte line of the memory system then belongs to TWO workgroups.  Dealt out in blockIdx order the parts of a ring group land on different
+	// XCDs (workgroups go to the eight XCDs in turn), each with its own L2, and every XCD fetches whole lines for the half it uses: 42.1 MB moved per block against
+	// 33.6 MB algorithmic at 4,096 instances (`FETCH_SIZE`, profiles/r04_pmc/pmc_pingpong_4096_spans64.json: exactly the ring reads counted twice).  So the 64 / G
+	// parts of a group go to workgroups w, w + 8, w + 16, ... — the same XCD: the second reader of a line finds it in that XCD's L2.
+	constexpr int PARTS = 64 / G;
+	const int nwg = (int)(a.kpad / G), wg = (int)blockIdx.x;
+	const bool remap = PARTS > 1 && (nwg % (8 * PARTS)) == 0 && !(KLG_PPX_VARIANT & 4);
+	const int k0 = remap ? (((wg / (8 * PARTS)) * 8 + (wg % 8)) * PARTS + (wg / 8) % PARTS) * G : wg * G, k = k0 + li;
 	const int SIZE = 192000, n = a.n;
 	const int nb = a.nb > 0 ? a.nb : n;                                            // the length of a row of the caller's buffer (a span: one block's)
 	// where the caller's rows of this workgroup's first instance stand for sample s of the span (s a multiple of the chunk: a chunk never straddles two blocks)
