@@ -233,7 +233,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 template<bool B> struct BoolTag { static constexpr bool value = B; };   // (std::true_type without <type_traits>: this header is also compiled by hipRTC)
 template<int I> struct IntTag { static constexpr int value = I; };
 // -------------------------------------------------------------------------------------------------
-// PingPong.k, eleven waves per 64 instances (the production kernel).
+// PingPong.k, twelve waves per 64 instances (the production kernel).
 //
 // Once every tap of a chunk lies further behind the write cursor than the chunk is long, the samples of the chunk no
 // longer depend on each other through the delay lines: only three short recurrences are sequential in time — the control
@@ -257,15 +257,18 @@ template<int I> struct IntTag { static constexpr int value = I; };
 #define KLG_PPX_VARIANT 0         // measurement builds only: 1 the filter waves store their chunk (one step fewer), 2 the first requests wait for the decision, 4 workgroups take their instances in blockIdx order, 8 vibrato: no sines ahead
 #endif
 #ifndef KLG_PPX_ABLATE
-#define KLG_PPX_ABLATE 0          // measurement builds only (tools/ppx_ablate.sh): 1 no DC filter chain, 2 no output stores, 4 no ring requests, 8 no audio stage
+#define KLG_PPX_ABLATE 0          // measurement builds only (tools/ppx_ablate.sh): 1 no DC filter chain, 2 no output stores, 4 no ring requests, 8 no audio stage, 16 / 64 moving dials: no first / second half of the control chain, 32 no LFO phase walk in the second
 #endif
-enum { PPX_CHUNK = 32, PPX_AUDIO = 8, PPX_PER = PPX_CHUNK / PPX_AUDIO, PPX_WAVES = 1 + PPX_AUDIO + 2, PPX_THREADS = PPX_WAVES * 64 };
+enum { PPX_MOVING_MIN = 32 };       // the shortest span (chunks) that runs the request-ahead pipeline with moving dials
+enum { PPX_CHUNK = 32, PPX_AUDIO = 8, PPX_PER = PPX_CHUNK / PPX_AUDIO, PPX_WAVES = 1 + PPX_AUDIO + 2 + 1, PPX_THREADS = PPX_WAVES * 64 };
 
 template<int G> struct PpxLds {
 	float tile[4][2][PPX_CHUNK][G + 1];         // [chunk & 3][channel][sample][instance]: loaded, audio, filter, store
-	float D[2][PPX_CHUNK][G];                   // delay time (smoothed controls[1]) per sample, [chunk & 1]
+	float C1[2][G <= 32 ? PPX_CHUNK : 1][G];    // moving dials, running ahead: controls[1] per sample, from the first control wave to the second, [chunk & 1]
+	int lastu[2][G];                            // ... and the chunk's last sample at which the scratch detector fired (-1: none)
+	float D[G <= 32 ? 8 : 2][PPX_CHUNK][G];     // delay time (smoothed controls[1]) per sample, [chunk & 1]; the request-ahead pipeline with MOVING dials (G <= 32): [chunk & 7]
 	int far[2];                                 // 1: every tap of the chunk is far from the write cursor
-	int deep;                                   // the block runs the request-ahead pipeline (see PPX_DEEP below)
+	int deep;                                   // the block runs the request-ahead pipeline (see PPX_DEEP below): 1 with stationary dials, 2 with moving ones (the control chain P + 1 chunks ahead)
 	int vibfast;                                // vibrato: the LFO's sines are taken by the audio waves, two chunks ahead of the chain
 	float ph[2][PPX_CHUNK + 1][G], sn[2][PPX_CHUNK][G];   // [chunk & 1]: the LFO's phase at every sample of the chunk (row PPX_CHUNK: after it), and their sines
 	// a chunk with a NEAR tap (G <= 32; G = 64 has no room and keeps the walk through memory): the six ring values of every sample as they stood before the
@@ -301,7 +304,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	// where the caller's rows of this workgroup's first instance stand for sample s of the span (s a multiple of the chunk: a chunk never straddles two blocks)
 	auto io_rows = [&](const int s) { const int b = s / nb; return (char*)(a.io + (size_t)b * a.block_stride + (size_t)k0 * 2 * nb + (s - b * nb)); };
 	const int nchunks = (n + PPX_CHUNK - 1) / PPX_CHUNK;
-	const bool w_control = wv == 0, w_audio = wv >= 1 && wv <= PPX_AUDIO, w_filter = wv > PPX_AUDIO;
+	const bool w_control = wv == 0, w_audio = wv >= 1 && wv <= PPX_AUDIO, w_filter = wv > PPX_AUDIO && wv <= PPX_AUDIO + 2;
+	const bool w_control2 = wv == PPX_AUDIO + 3;                                   // the second half of the control chain when the dials move and the pipeline runs ahead (see `moving`)
 	// the control and filter waves are dependent chains that pace the pipeline; the audio waves share their SIMDs and mostly wait for
 	// memory: when both are ready, the chain issues first
 	if (!w_audio) __builtin_amdgcn_s_setprio(3);
@@ -320,6 +324,12 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		vibrato = (c2 * c2) * rate * 1.41421354f;                                  // sqr(controls[2]) * rate * root2
 		any_vibrato = __ballot(vibrato != 0.f) != 0ull;
 	}
+	if (w_control2) {
+		const float c3 = PPW(3);
+		sm1 = PPW(PP_SM1); lfo.position = PPW(PP_LFO_POS);
+		lfo_inc = ((c3 * c3) * 100.f) * 2.f * KLG_PI_F / a.fs.f;
+	}
+	bool moving = false, rest5_all = false;                                        // (set where the block's pipeline is chosen)
 	// STATIONARY controls: once both smoothers sit at their fp32 fixed points (x * 0.999f + (1.f - 0.999f) * v == x: some ten thousand samples
 	// after a dial last moved), no scratch is detected and there is no vibrato, every sample of the block leaves sm5, mdelay (= controls[5]),
 	// controls[1] and sm1 exactly as it found them: the delay time of every sample IS sm1.  The serial chain that otherwise paces the pipeline
@@ -419,9 +429,10 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		// the audio waves' part of step j; SLOT = j mod P (compile-time: the register arrays are indexed by constants only); nch = the block's chunks
 		// STEADY (a span's inner steps, 2 <= j <= nch - P - 2: every chunk the step touches exists): no test of j at all — through run-time guards every part of
 		// a step ends in a join, and behind a join the compiler waits for everything that is under way
-		auto audio_part = [&](auto slot_c, auto steady_c, const int j, const int nch) __attribute__((always_inline)) {
+		// MOVING: the delay time of every sample comes from the control chain's buffers (S.D[chunk & 7]) instead of being the one stationary value
+		auto audio_part = [&](auto slot_c, auto steady_c, auto moving_c, const int j, const int nch) __attribute__((always_inline)) {
 			constexpr int RS = decltype(slot_c)::value, IS = (RS + 1) % P;
-			constexpr bool ST = decltype(steady_c)::value;
+			constexpr bool ST = decltype(steady_c)::value, MOVING = decltype(moving_c)::value && G <= 32;
 			int at = tid - 64; asm volatile("" : "+v"(at));                    // (see the general loop: keeps per-thread addresses out of loop-invariant registers)
 			const int acol = at & 31, arow = at >> 5;
 			const int jn = j + 1, js = j - 2;
@@ -445,7 +456,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				for (int q = 0; q < PASSES; q++) {
 					const int u = u0 + q * SPW, pos = wrap(pos0 + u);
 					const float in_l = T[0][u][li], in_r = T[1][u][li];
-					const float fl = delay_set(pos, SIZE, dly * a.fs.f).fraction, fr = delay_set(pos, SIZE, 0.5f * dly * a.fs.f).fraction;   // (as at the request: a dozen operations, not registers held for P steps)
+					const float dl = MOVING ? S.D[j & 7][u][li] : dly;
+					const float fl = delay_set(pos, SIZE, dl * a.fs.f).fraction, fr = delay_set(pos, SIZE, 0.5f * dl * a.fs.f).fraction;   // (as at the request: a dozen operations, not registers held for P steps)
 					// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
 					const float r1 = rwr[RS][q][0] + fr * (rwr[RS][q][1] - rwr[RS][q][0]);
 					ring_wr(0, pos, in_l + r1 * gain);
@@ -464,8 +476,9 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 #pragma unroll
 				for (int q = 0; q < PASSES; q++) {
 					const int u = u0 + q * SPW, pos = wrap(pos1 + u);
-					const Tap tl = delay_set(pos, SIZE, dly * a.fs.f);              // left.set(delay * fs)
-					const Tap tr = delay_set(pos, SIZE, 0.5f * dly * a.fs.f);       // right.set(0.5f * delay * fs)
+					const float dl = MOVING ? S.D[c & 7][u][li] : dly;
+					const Tap tl = delay_set(pos, SIZE, dl * a.fs.f);               // left.set(delay * fs)
+					const Tap tr = delay_set(pos, SIZE, 0.5f * dl * a.fs.f);        // right.set(0.5f * delay * fs)
 					const int i0 = tl.position, i1 = ring_succ(i0, SIZE), i2 = ring_succ(i1, SIZE);   // (a tap may sit on the pad row SIZE: klg_delay.hpp)
 					const int j0 = tr.position, j1 = ring_succ(j0, SIZE), j2 = ring_succ(j1, SIZE);
 					rwl[RS][q][0] = ring_rd(0, i0); rwl[RS][q][1] = ring_rd(0, i1); rwl[RS][q][2] = ring_rd(0, i2);
@@ -491,10 +504,10 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		// The first P steps only request — chunks 0 .. P - 1's ring rows, chunks 0 .. P's caller rows — and need nothing but this lane's own delay time:
 		// they are issued BEFORE the workgroup knows whether the block qualifies (the control wave's words are still on their way), so the
 		// decision costs no round trip of its own.  A block that does not qualify ignores what arrives (every address is a valid one).
-		auto first_requests = [&]() __attribute__((always_inline)) {
+		auto first_requests = [&](auto moving_c) __attribute__((always_inline)) {
 			auto prologue = [&](auto self, auto t_c) __attribute__((always_inline)) {
 				constexpr int T = decltype(t_c)::value, J = T - P - 1;
-				if constexpr (T < P) { audio_part(IntTag<((J % P) + P) % P>{}, BoolTag<false>{}, J, nchunks); self(self, IntTag<T + 1>{}); }
+				if constexpr (T < P) { audio_part(IntTag<((J % P) + P) % P>{}, BoolTag<false>{}, moving_c, J, nchunks); self(self, IntTag<T + 1>{}); }
 			};
 			prologue(prologue, IntTag<0>{});
 		};
@@ -502,12 +515,28 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		//  see that in two words of their own instances)
 		bool may_qualify = w_audio && whole_chunks;
 		if (may_qualify) { const float c2 = PPW(2), c3 = PPW(3); may_qualify = __ballot((c2 * c2) * ((c3 * c3) * 100.f) * 1.41421354f != 0.f) == 0ull; }
-		if (may_qualify && !(KLG_PPX_VARIANT & 2)) first_requests();
+		if (may_qualify && !(KLG_PPX_VARIANT & 2)) first_requests(BoolTag<false>{});
 		if (w_control) {
 			// (stationary: every sample's delay time is sm1.)  Rows of chunk c are requested while chunks c - P .. c - 1 are not written yet.
 			const bool far_deep = 0.5f * sm1 * a.fs.f >= (float)((P + 1) * PPX_CHUNK + 3) && sm1 * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
 			const bool ok = stationary && whole_chunks && __ballot(k < a.K && !far_deep) == 0ull;
-			if (lane == 0) S.deep = ok ? 1 : 0;
+			// MOVING dials without vibrato (a dial being turned, a scratch, the smoothers still converging after either): every delay time of the block lies between the
+			// smallest and the largest of where the chain's values are and where they are heading — controls[1].smooth() moves towards controls[1], which only ever
+			// takes clamped values of controls[5].smooth(), which moves towards controls[5] — so "far" is decided for the whole block here.  The chain then runs
+			// P + 1 chunks ahead of the audio; its head start (P chunks before the first request) is repaid over a span, not inside one block.
+			bool ok2 = false;
+			rest5_all = false;
+			if constexpr (G <= 32) {
+				const float t5 = __builtin_amdgcn_fmed3f(c5, a.c1_min, a.c1_max), s5 = __builtin_amdgcn_fmed3f(sm5, a.c1_min, a.c1_max);
+				// (controls[5] at rest — smoother at its fixed point, detector quiet, as in `stationary` — sets nothing: only controls[1].smooth() still moves, towards controls[1])
+				const bool rest5 = (sm5 * 0.999f + (1.f - 0.999f) * c5 == sm5) && !(fabsf(mdelay - sm5) >= 0.001f) && !(fabsf(c5 - sm5) >= 0.001f);
+				const float lo = rest5 ? __builtin_fminf(sm1, c1) : __builtin_fminf(__builtin_fminf(sm1, c1), __builtin_fminf(t5, s5));
+				const float hi = rest5 ? __builtin_fmaxf(sm1, c1) : __builtin_fmaxf(__builtin_fmaxf(sm1, c1), __builtin_fmaxf(t5, s5));
+				const bool far2 = 0.5f * lo * a.fs.f >= (float)((P + 1) * PPX_CHUNK + 4) && hi * a.fs.f <= (float)(SIZE - PPX_CHUNK - 5);
+				rest5_all = __ballot(!rest5) == 0ull;
+				ok2 = !stationary && !any_vibrato && whole_chunks && nchunks >= PPX_MOVING_MIN && !(KLG_PPX_VARIANT & 16) && __ballot(k < a.K && !far2) == 0ull;
+			}
+			if (lane == 0) S.deep = ok ? 1 : ok2 ? 2 : 0;
 			// vibrato (never stationary): a phase no LFO walks to (an uploaded record) keeps the plain chain, with sin's range test
 			const bool vf = any_vibrato && __ballot(!(fabsf(lfo.position) < 1.0e4f)) == 0ull && !(KLG_PPX_VARIANT & 8);
 			if (lane == 0) S.vibfast = vf ? 1 : 0;
@@ -517,11 +546,93 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	const bool vibfast = S.vibfast != 0;
 	if (vibfast) { if (w_audio) sines(0); __syncthreads(); }                        // (chunk 1's are taken in step -1, chunk j + 2's in step j)
 	if (S.deep) {
-		if (w_control) mdelay = c5;                                             // (no scratch: `else delay = controls[5]`)
-		if (w_audio && (KLG_PPX_VARIANT & 2)) first_requests();
+		moving = G <= 32 && S.deep == 2;
+		// The control chain with moving dials, a chunk at a time.  One wave running all of it (the general loop: ~17 instructions a sample, each waiting for the one
+		// before: ~128 cycles a sample, 1.95 us a chunk) is slower than the memory pipeline it feeds (1.3 us a chunk), however far ahead it runs.  So it is cut where it
+		// only flows one way: the FIRST control wave smooths controls[5], runs the scratch detector and sets controls[1] (PingPong.k:47-56) and leaves controls[1] per sample
+		// and the chunk's last detection in LDS; the SECOND, a step behind, smooths controls[1] into the delay times (PingPong.k:58) and walks the LFO's phase — which, with no
+		// vibrato in the wave, only a detection touches (lfo.set(rate, pi)): from the last one of the chunk on, or all the way when there was none.
+		auto chain_first = [&](const int cc) __attribute__((always_inline)) {
+			const float k5 = (1.f - 0.999f) * c5;
+			float (*C)[G] = S.C1[cc & 1];
+			int lu = -1;
+			if (KLG_PPX_ABLATE & 16) return;
+			if (rest5_all) {                                                        // controls[5] at rest in every instance: controls[1] stays what it is — both buffers, once
+				if (cc < 2) {
+#pragma unroll 8
+					for (int u = 0; u < PPX_CHUNK; u++) C[u][li] = c1;
+					S.lastu[cc & 1][li] = -1;
+				}
+				mdelay = c5;                                                        // (no scratch: `else delay = controls[5]`)
+				return;
+			}
+#pragma unroll 8
+			for (int u = 0; u < PPX_CHUNK; u++) {
+				sm5 = sm5 * 0.999f + k5;                                            // controls[5].smooth()  klang.h:1715
+				const bool trig = fabsf(mdelay - sm5) >= 0.001f;                    // (double)fabsf(d) > 0.001
+				mdelay = trig ? sm5 : c5;
+				c1 = trig ? __builtin_amdgcn_fmed3f(sm5, a.c1_min, a.c1_max) : c1;  // controls[1].set(new_delay)
+				lu = trig ? u : lu;
+				C[u][li] = c1;
+			}
+			S.lastu[cc & 1][li] = lu;
+		};
+		auto chain_second = [&](const int cc) __attribute__((always_inline)) {
+			const float (*C)[G] = S.C1[cc & 1];
+			float (*D)[G] = S.D[cc & 7];
+			const int lu = S.lastu[cc & 1][li];
+			if (KLG_PPX_ABLATE & 64) { for (int u = 0; u < PPX_CHUNK; u++) D[u][li] = sm1; return; }
+			const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);
+			float pos = lu >= 0 ? KLG_PI_F : lfo.position;                          // lfo.set(rate, pi)
+			float cv[PPX_CHUNK];                                                    // (all of the chunk's values requested at once: one round trip to LDS, not one a sample)
+#pragma unroll
+			for (int u = 0; u < PPX_CHUNK; u++) cv[u] = (1.f - 0.999f) * C[u][li];
+			if (__ballot(lu >= 0 || !inc_ok) == 0ull && !(KLG_PPX_ABLATE & 32)) {   // no detection in the chunk, no LFO at a standstill: both recurrences side by side, nothing to test
+#pragma unroll
+				for (int u = 0; u < PPX_CHUNK; u++) {
+					sm1 = sm1 * 0.999f + cv[u];                                     // controls[1].smooth()
+					D[u][li] = sm1;
+					const float p1 = pos + lfo_inc;                                 // Phase::operator+= klang.h:1518-1525
+					pos = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
+				}
+			}
+			else {
+#pragma unroll
+				for (int u = 0; u < PPX_CHUNK; u++) { sm1 = sm1 * 0.999f + cv[u]; D[u][li] = sm1; }
+				// the phase: from the earliest "last detection" of the wave's instances on (while a scratch converges the detector fires every other sample: the last
+				// two samples of the chunk), every instance from its own
+				int first = 0;
+#pragma unroll
+				for (int bit = PPX_CHUNK / 2; bit > 0; bit >>= 1) if (__ballot(lu < first + bit) == 0ull) first += bit;
+				if (!(KLG_PPX_ABLATE & 32))
+				for (int u = first; u < PPX_CHUNK; u++) {
+					const float p1 = pos + lfo_inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
+					pos = (inc_ok && u >= lu) ? p2 : pos;
+				}
+			}
+			lfo.position = pos;
+		};
+		if (moving) {
+			// the chain's head start: delay times of chunks 0 .. P - 1 (chunk j + P's are computed in step j - 1), controls[1] of chunks 0 .. P; only then the first requests
+			for (int t = 0; t <= P; t++) {
+				if (w_control) { if (t < nchunks) chain_first(t); }
+				else if (w_control2 && t >= 1) chain_second(t - 1);
+				__syncthreads();
+			}
+			if (w_control) lfo.increment = lfo_inc;
+			if (w_audio) first_requests(BoolTag<true>{});
+		}
+		else {
+			if (w_control) mdelay = c5;                                         // (no scratch: `else delay = controls[5]`)
+			if (w_audio && (KLG_PPX_VARIANT & 2)) first_requests(BoolTag<false>{});
+		}
 		// the other waves' part: the LFO keeps running, a chunk per step (control: beside the filter waves, which are slower); FILTER of chunk j - 1
 		auto other_part = [&](const int j) __attribute__((always_inline)) {
-			if (w_control) {
+			if (moving && !w_filter) {
+				if (w_control) { const int cc = j + P + 2; if (cc < nchunks) chain_first(cc); }
+				else if (w_control2) { const int cc = j + P + 1; if (cc < nchunks) chain_second(cc); }
+			}
+			else if (w_control) {
 				const int cc = j - 1;
 				if (cc >= 0 && cc < nchunks) {
 					lfo.increment = lfo_inc;
@@ -531,7 +642,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 					lfo.position = pos;
 				}
 			}
-			else if (j >= 1 && j <= nchunks) filter_stage(j - 1, BoolTag<(KLG_PPX_VARIANT & 1) != 0>{});
+			else if (w_filter && j >= 1 && j <= nchunks) filter_stage(j - 1, BoolTag<(KLG_PPX_VARIANT & 1) != 0>{});
 		};
 		// Blocks of 4 / 8 / 16 chunks (128 / 256 / 512 samples): the audio waves' steps are written out one after the other — in straight-line code
 		// the compiler's wait before a use is exactly "everything requested since may still be under way"; through the loop below, with its
@@ -541,7 +652,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			auto run = [&](auto self, auto t_c) __attribute__((always_inline)) {
 				constexpr int T = decltype(t_c)::value, J = T - 1;
 				if constexpr (J <= NCH + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) {
-					audio_part(IntTag<((J % P) + P) % P>{}, BoolTag<false>{}, J, NCH);
+					audio_part(IntTag<((J % P) + P) % P>{}, BoolTag<false>{}, BoolTag<false>{}, J, NCH);
 					__syncthreads();
 					self(self, IntTag<T + 1>{});
 				}
@@ -556,8 +667,9 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			for (int j = -1; j <= nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1); j++) { other_part(j); __syncthreads(); }
 		}
 		else {
+		auto steps = [&](auto moving_c) __attribute__((always_inline)) {
 			auto deep_step = [&](auto slot_c, auto steady_c, const int j) __attribute__((always_inline)) {
-				if (w_audio) audio_part(slot_c, steady_c, j, nchunks); else other_part(j);
+				if (w_audio) audio_part(slot_c, steady_c, moving_c, j, nchunks); else other_part(j);
 				__syncthreads();
 			};
 			const int jend = nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1);
@@ -580,6 +692,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				while (j + P - 1 <= nchunks - P - 2) group(BoolTag<true>{});
 				while (group(BoolTag<false>{})) {}
 			}
+		};
+			if (moving) steps(BoolTag<true>{}); else steps(BoolTag<false>{});
 		}
 	}
 	else
@@ -859,9 +973,10 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	if (k < a.K && lane < G) {
 		float* Wr = a.state + k;
 		if (w_control) {
-			Wr[(size_t)1 * a.kpad] = c1; Wr[(size_t)PP_SM1 * a.kpad] = sm1; Wr[(size_t)PP_SM5 * a.kpad] = sm5; Wr[(size_t)PP_DELAY * a.kpad] = mdelay;
-			Wr[(size_t)PP_LFO_POS * a.kpad] = lfo.position; Wr[(size_t)PP_LFO_INC * a.kpad] = lfo.increment;
+			Wr[(size_t)1 * a.kpad] = c1; Wr[(size_t)PP_SM5 * a.kpad] = sm5; Wr[(size_t)PP_DELAY * a.kpad] = mdelay; Wr[(size_t)PP_LFO_INC * a.kpad] = lfo.increment;
+			if (!moving) { Wr[(size_t)PP_SM1 * a.kpad] = sm1; Wr[(size_t)PP_LFO_POS * a.kpad] = lfo.position; }
 		}
+		if (w_control2 && moving) { Wr[(size_t)PP_SM1 * a.kpad] = sm1; Wr[(size_t)PP_LFO_POS * a.kpad] = lfo.position; }   // (the second control wave's part of the chain)
 		if (w_filter) { Wr[(size_t)(PP_Z + 2 * fch) * a.kpad] = dc.z0; Wr[(size_t)(PP_Z + 2 * fch + 1) * a.kpad] = dc.z1; }
 	}
 #undef PPW

@@ -523,7 +523,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st, int blocks 
 			const int G = forced == 16 || forced == 32 || forced == 64 ? forced : (f->kpad <= 4096 ? 16 : f->kpad <= 8192 ? 32 : 64);
 			if (G == 16) KLG_LAUNCH(klg_fx_pingpong_x<16>, dim3((unsigned)(f->kpad / 16)), dim3(PPX_THREADS), 0, st, a);
 			else if (G == 32) KLG_LAUNCH(klg_fx_pingpong_x<32>, dim3((unsigned)(f->kpad / 32)), dim3(PPX_THREADS), 0, st, a);
-			else KLG_LAUNCH(klg_fx_pingpong_x<64>, grid, dim3(PPX_THREADS), 0, st, a);   // control / audio / filter pipeline over eleven waves
+			else KLG_LAUNCH(klg_fx_pingpong_x<64>, grid, dim3(PPX_THREADS), 0, st, a);   // control / audio / filter pipeline over twelve waves
 		}
 	}
 	else {

@@ -92,6 +92,56 @@ def test_a_span_of_blocks_equals_block_by_block(kind, n, spans):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("width", [16, 32, 64])
+def test_spans_with_moving_dials_equal_block_by_block(width, monkeypatch):
+    """Spans whose dials are NOT at rest (no vibrato anywhere): klg_fx_pingpong_x runs the control chain P + 1 chunks ahead of the audio and the
+    request-ahead pipeline reads every sample's delay time from its buffers (klg_fx.hpp, `moving`; spans of >= PPX_MOVING_MIN = 32 chunks, widths 16 / 32).
+    Between spans: dials turned (the scratch detector fires, controls[1] is re-set, both smoothers converge again), one instance taken to a delay too near
+    to run ahead (its workgroup falls back to the general loop), one to the longest delay the dial allows.  Against the same blocks one by one (the
+    general loop, which the oracle tests cover), bit for bit, every span; and the instances' records afterwards.  Later spans: controls[5] at rest in every instance
+    (the first half of the chain is then not run), only the time dial turned."""
+    monkeypatch.setenv("KLG_FX_PINGPONG_G", str(width))
+    K, n = 70, 256
+    spans = (6, 4, 12, 3, 9, 20, 20, 20, 10, 7)                                  # (the 20s: controls[5] comes to rest everywhere; then the time dial alone is turned)
+    rng = np.random.default_rng(31)
+    a, CH = make("pingpong", K, n)
+    b, _ = make("pingpong", K, n)
+    def dial(k, idx, v):
+        for bank in (a, b): bank.set_control(k, idx, v)
+    for k in range(K):
+        t = float(rng.uniform(0.03, 0.7))
+        dial(k, 5, t); dial(k, 1, t); dial(k, 0, float(rng.uniform(0.2, 0.9))); dial(k, 4, float(rng.uniform(0.3, 1.0)))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for si, blocks in enumerate(spans):
+            x = (torch.from_numpy(rng.random((blocks, K, CH, n), dtype=np.float32)) - 0.5).cuda()
+            ya, yb = x.clone(), x.clone()
+            a.render_device(ya.data_ptr(), blocks, n, st.cuda_stream)
+            for blk in range(blocks):
+                b.process_device(yb[blk].data_ptr(), n, st.cuda_stream)
+            st.synchronize()
+            bad = (ya.view(torch.int32) != yb.view(torch.int32)).nonzero()
+            assert len(bad) == 0, f"span {si} ({blocks} blocks of {n}): {len(bad)} samples differ, first [block, instance, channel, sample] {bad[0].tolist()}"
+            assert float(ya.abs().max()) > 1e-3
+            if si == 0:
+                for k in range(0, K, 5): dial(k, 5, float(rng.uniform(0.03, 0.9)))      # scratches
+                dial(7, 1, 0.5)                                                        # the time dial alone
+            elif si == 1:
+                dial(33, 5, 0.002)                                                     # heading to a near delay: this workgroup may not run ahead
+                dial(50, 5, 1.0); dial(2, 5, 0.011)                                    # the longest; one whose taps get close
+            elif si == 2:
+                dial(33, 5, 0.4); dial(12, 4, 0.1); dial(13, 0, 0.95)
+            elif si == 3:
+                for k in range(1, K, 7): dial(k, 5, float(rng.uniform(0.05, 0.3)))
+            elif si == 7:
+                for k in range(2, K, 6): dial(k, 1, float(rng.uniform(0.05, 0.9)))     # controls[5] at rest, controls[1].smooth() on its way: the first control wave has nothing to do
+            elif si == 8:
+                dial(4, 1, 0.004); dial(60, 1, 1.0)
+    for k in (0, 7, 33, 50, K - 1):
+        assert np.array_equal(a.download_record(k), b.download_record(k))
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("kind,width", [("pingpong", 16), ("pingpong", 32), ("pingpong", 64), ("pingpong_recorded", 0)])
 def test_stationary_spans_after_convergence(kind, width, oracle_build, monkeypatch):
     """The path the cfg-4 bench legs time: a span on a bank whose dials have been still for so long that both Control::smooth chains sit at their fp32 fixed

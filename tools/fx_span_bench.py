@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/fx_span_bench.py [K] — an effect bank's time per 256-sample block when the blocks are submitted as spans (klg_fx_render_device) of 1 / 4 / 16 / 64 blocks:
 the kernel's own duration (events attached to the dispatch) and the stream's wall time around the spans, per block.  PingPong (hand-written; the recorded form),
-Reverb.  Dials at rest (the blocks before the timed ones let PingPong's smoothers converge).  One JSON line per (effect, span length)."""
+Reverb.  Dials at rest (the blocks before the timed ones let PingPong's smoothers converge; FX_SPAN_FRESH=r: the first r spans of a new bank instead).  One JSON line per (effect, span length)."""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,8 +25,11 @@ def main():
             else:
                 bank = klang_amd.FxBank(effect, K, max_block=N)
             io = (torch.rand((B, K, 2, N), device="cuda") - 0.5) * (0.0 if os.environ.get("FX_SPAN_SILENCE") else 0.1)
-            for _ in range(max(2, 128 // B)): bank.render_device(io.data_ptr(), B, N, st)      # converge
-            reps = max(4, 256 // B)
+            fresh = int(os.environ.get("FX_SPAN_FRESH", "0"))                                  # time the first `fresh` spans of a new bank: the smoothers still converging
+            if fresh: bank.render_device(io.data_ptr(), min(B, 8), N, st)                     # (as bench.py's cfg-4 legs: eight untimed blocks — a new object's smoothers start from 0, a delay too near to run ahead)
+            else:
+                for _ in range(max(2, 128 // B)): bank.render_device(io.data_ptr(), B, N, st)  # converge
+            reps = fresh or max(4, 256 // B)
             torch.cuda.synchronize(); bank.timing_begin()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
