@@ -543,6 +543,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			if (vf) { spec_pos = lfo.position; prescan(0); prescan(1); }
 		}
 		__syncthreads();
+	if (w_control2 && S.deep != 2) return;                                         // (the twelfth wave has a part only when dials move and the pipeline runs ahead: a wave that has ended is not waited for at a barrier)
 	const bool vibfast = S.vibfast != 0;
 	if (vibfast) { if (w_audio) sines(0); __syncthreads(); }                        // (chunk 1's are taken in step -1, chunk j + 2's in step j)
 	if (S.deep) {
