@@ -75,6 +75,9 @@ struct constant {
 	double d; float f; int i; float inv;
 	constexpr constant(double v) : d(v), f((float)v), i((int)v), inv(v == 0.0f ? 0.0f : (float)(1.0 / v)) {}
 	constexpr operator float() const { return f; }
+	float operator^(float x) const { return std::pow(f, x); }                     // klang.h:107-110: the constant raised to a power
+	float operator^(int x) const { return static_cast<float>(std::pow(d, x)); }
+	float operator^(double x) const { return static_cast<float>(std::pow(d, x)); }
 };
 constexpr constant pi = { 3.1415926535897932384626433832795 };
 constexpr constant ln2 = { 0.6931471805599453094172321214581 };
@@ -82,6 +85,25 @@ constexpr constant root2 = { 1.4142135623730950488016887242097 };
 
 template<typename T1, typename T2> inline T1 max(T1 a, T2 b) { return a > b ? a : (T1)b; }                              // klang.h:224 (returns the FIRST type)
 template<typename T1, typename T2> inline T1 min(T1 a, T2 b) { return a < b ? a : (T1)b; }                              // klang.h:223
+// power(base, exp) klang.h:152-218 (the overload for run-time exponents): an integral base is taken as float; integral exponents 0, +-1 .. +-4 are written-out
+// products; a floating exponent first asks whether the base is 10 (then exp(exp * ln 10), the C library's, in double on the float product — see db_to_amplitude
+// below, pinned against the reference), then for the same nine exponents; everything else is std::pow
+template<typename BASE, typename EXP, std::enable_if_t<std::is_arithmetic_v<BASE> && std::is_arithmetic_v<EXP>, int> = 0>
+inline std::conditional_t<std::is_integral_v<BASE>, float, BASE> power(BASE base, EXP exp) {
+	if constexpr (std::is_integral_v<BASE>) return power((float)base, exp);
+	else {
+		auto small = [&](int e) -> BASE { BASE p = 1; const int m = e < 0 ? -e : e; if (m >= 1) p = base; for (int q = 1; q < m; q++) p = p * base; return e < 0 ? (BASE)1 / p : p; };
+		if constexpr (std::is_integral_v<EXP>) { if (exp >= -4 && exp <= 4) return small((int)exp); }
+		else {
+			if (base == (BASE)10) {
+				if constexpr (std::is_same_v<EXP, float>) return (BASE)(float)std::exp((double)(exp * 2.3025850929940456840179914546843642076011014886287729760333279009f));
+				else return (BASE)std::exp(exp * (EXP)2.3025850929940456840179914546843642076011014886287729760333279009);
+			}
+			for (int e = -4; e <= 4; e++) if (exp == (EXP)e) return small(e);
+		}
+		return (BASE)std::pow(base, exp);
+	}
+}
 // (klg_rand_sync: Noise generators draw from the same sequence on the device; the C library gets it back before host code draws — include/klang_mi355.h)
 template<typename T> inline T random(const T mn, const T mx) { klg_rand_sync(); return std::rand() * ((mx - mn) / (T)RAND_MAX) + mn; }   // klang.h:236
 inline void random(const unsigned seed) { std::srand(seed); klg_random_seed(seed); }                                     // klang.h:239
@@ -306,7 +328,19 @@ KLANG_SIGNAL_PAIR(+, OP_ADD) KLANG_SIGNAL_PAIR(-, OP_SUB) KLANG_SIGNAL_PAIR(*, O
 inline int gpu::Recorder::reg_of(const signal& s) { return s.reg >= 0 ? s.reg : const_reg(gpu::fbits(s.value)); }
 
 // std::abs / abs of a signal (PingPong.k:46 `std::abs(delay - new_delay) > 0.001`): fabsf of the float the reference converts it to — recordable
-inline signal abs(const signal& x) { gpu::Recorder* r = gpu::recording(); signal s(__builtin_fabsf(x.value)); if (r && x.reg >= 0) s.reg = r->emit(klg::graph::OP_ABS, x.reg, -1, -1, 0, true); return s; }
+inline signal abs_of(const signal& x) { gpu::Recorder* r = gpu::recording(); signal s(__builtin_fabsf(x.value)); if (r && x.reg >= 0) s.reg = r->emit(klg::graph::OP_ABS, x.reg, -1, -1, 0, true); return s; }
+// power(signal, literal float): inside a recorded process() one op for the exponents the reference writes out (graph OP_POWC); any other exponent is the C library's powf
+inline signal power(const signal& base, float e) {
+	signal s(power(base.value, e));
+	if (base.reg >= 0) if (gpu::Recorder* r = gpu::recording()) {
+		bool small = false; for (int q = -4; q <= 4; q++) small = small || e == (float)q;
+		if (!small) r->fail("power(x, e) of a value computed in process() with an exponent other than 0, +-1 .. +-4 (the C library's powf is not restated on the device)");
+		else s.reg = r->emit(klg::graph::OP_POWC, base.reg, -1, -1, gpu::fbits(e), true);
+	}
+	return s;
+}
+inline signal power(const signal& base, double e) { if (base.reg >= 0 && gpu::recording()) gpu::rec->fail("power(x, double) of a value computed in process()"); return signal(power(base.value, e)); }
+inline signal power(const signal& base, int e) { signal p(1.f); const int m = e < 0 ? -e : e; if (m > 4) { base.concrete_only("power(x, n) with |n| > 4"); return signal(power(base.value, e)); } if (m >= 1) p = base; for (int q = 1; q < m; q++) p = p * base; return e < 0 ? signal(1.f) / p : p; }
 struct Control;
 struct param : signal {
 	param(constant c) : signal(c.f) {}
@@ -319,7 +353,10 @@ struct param : signal {
 
 // ---- Control / Controls / Presets (klang.h:1654-1981; UI fields omitted) ----
 struct Control {
+	enum Type { NONE, ROTARY, BUTTON, TOGGLE, SLIDER, MENU, METER, WHEEL };                                  // klang.h:1657-1667 (what a UI draws; nothing here depends on it)
+	struct Size { int x, y, width, height; Size(int x_ = -1, int y_ = -1, int w_ = -1, int h_ = -1) : x(x_), y(y_), width(w_), height(h_) {} };   // klang.h:1670-1685
 	std::string name; float min = 0.f, max = 1.f, initial = 0.f;
+	Type type = ROTARY; Size size;
 	signal value, smoothed; int index = 0;                   // index: position in its Controls (set by Controls::operator=)
 	operator signal&() { return value; }
 	operator param() const { return param(value); }
@@ -344,6 +381,15 @@ struct Control {
 		if (!r->effect) { r->fail("controls[i].set() inside a Note::process(): the control is the Synth's, shared by its notes"); return *this; }
 		const float v = (x.value < min) ? min : (max < x.value) ? max : x.value;
 		value.reg = r->emit(klg::graph::OP_SETCTL, r->reg_of(x), -1, r->ctlvar_node(&value), (uint32_t)index, true); value.value = v;
+		return *this;
+	}
+	// `x >> controls[i]` / `controls[i] << x` (klang.h:1745-1746): the plain assignment, no clamp — a METER fed by process() (Vocoder.k:104).  Recorded in an Effect like
+	// set(): the control becomes state of the instance (what the UI reads back is that word of its record)
+	Control& operator<<(const signal& x) {
+		gpu::Recorder* r = gpu::recording();
+		if (!r || (x.reg < 0 && !r->effect)) { value = x.value; return *this; }
+		if (!r->effect) { r->fail("controls[i] << x inside a Note::process(): the control is the Synth's, shared by its notes"); return *this; }
+		value.reg = r->emit(klg::graph::OP_SETCTL, r->reg_of(x), -1, r->ctlvar_node(&value), (uint32_t)index | 0x100u, true); value.value = x.value;
 		return *this;
 	}
 	float range() const { return max - min; }                                                                // klang.h:1719-1721: what a host's 0..1 parameter maps to
@@ -393,6 +439,10 @@ struct Controls {
 	// (controls are assigned in the constructor BODY of a plugin and read by its host: either way every member of the plugin has been
 	//  constructed, so the owner's construction log ends here)
 	void operator=(std::initializer_list<Group> l) { gpu::close_log(); items.clear(); for (const Group& g : l) for (const Control& c : g.controls) { items.push_back(c); items.back().index = (int)items.size() - 1; } }   // klang.h:1895-1902
+	void add(const char* name, Control::Type type = Control::ROTARY, float mn = 0.f, float mx = 1.f, float initial = 0.f, Control::Size size = Control::Size()) {   // klang.h:1904-1912
+		gpu::close_log(); Control c; c.name = name; c.type = type; c.min = mn; c.max = mx; c.initial = initial; c.value = initial; c.size = size; items.push_back(c); items.back().index = (int)items.size() - 1;
+	}
+	void group(const char* /*name*/, unsigned /*start*/, unsigned /*length*/, Control::Size = Control::Size()) {}      // klang.h:1925-1928: a UI frame around controls
 	Control& operator[](int i) { gpu::close_log(); return items[(size_t)i]; }
 	const Control& operator[](int i) const { return items[(size_t)i]; }
 	unsigned size() const { gpu::close_log(); return (unsigned)items.size(); }
@@ -409,7 +459,7 @@ struct Frequency : param { using param::param; Frequency(float f = 1000.f) : par
 struct Pitch : param {
 	using param::param;
 	static inline thread_local Conversion Frequency;
-	const Pitch* operator->() { Frequency = klg::host::pitch_to_frequency(value); return this; }             // klang.h:1568-1571
+	const Pitch* operator->() { concrete_only("Pitch -> Frequency"); Frequency = klg::host::pitch_to_frequency(value); return this; }             // klang.h:1568-1571
 };
 // dB <-> linear (klang.h:1609-1652): `GAIN[o]->Amplitude`.  power(10, x) of the reference is ::exp(x * ln 10) on the float product,
 // evaluated in double (the global ::exp of <cmath>) and rounded once
@@ -566,6 +616,12 @@ struct Output : Generic::Output<signal> {};
 struct Generator : Generic::Generator<signal> {};
 struct Modifier : Generic::Modifier<signal> {};
 inline signal& operator+=(signal& s, Generic::Output<signal>& o) { s.value += signal(o).value; return s; }
+// double (op) object — `0.125 / controls[1] * (in >> hpf[0])` (Vocoder.k:91): the reference's operator(float, Output&) klang.h:2236-2244 — the double rounds to float, then fp32
+#define KLANG_DSIGNAL_OBJECT_OPS(OP) \
+	inline signal operator OP(const dsignal& d, Generic::Output<signal>& o) { const signal a(d); const signal& b = o; return a OP b; } \
+	inline signal operator OP(Generic::Output<signal>& o, const dsignal& d) { const signal& a = o; const signal b(d); return a OP b; }
+KLANG_DSIGNAL_OBJECT_OPS(+) KLANG_DSIGNAL_OBJECT_OPS(-) KLANG_DSIGNAL_OBJECT_OPS(*) KLANG_DSIGNAL_OBJECT_OPS(/)
+#undef KLANG_DSIGNAL_OBJECT_OPS
 // Control (op) object (`controls[1] * lfo`): the control's value and the object's next output (the reference: Control -> signal&, then signal (op) object)
 #define KLANG_CONTROL_OBJECT_OPS(OP) inline signal operator OP(Control& c, Generic::Output<signal>& o) { const signal& b = o; return c.value OP b; }
 KLANG_CONTROL_OBJECT_OPS(+) KLANG_CONTROL_OBJECT_OPS(-) KLANG_CONTROL_OBJECT_OPS(*) KLANG_CONTROL_OBJECT_OPS(/)
@@ -575,6 +631,18 @@ KLANG_CONTROL_OBJECT_OPS(+) KLANG_CONTROL_OBJECT_OPS(-) KLANG_CONTROL_OBJECT_OPS
 // `Function<float, float> f(softclip); in >> f(distort) >> out;` calls softclip(in, distort) per sample (all but the first argument bound by operator(); all of them:
 // the first one is the input).  The function is the patch's own code: to be RECORDED its arguments must be the tracing type, i.e. the patch is compiled with
 // -DKLANG_GPU_TRACE_FLOAT (the end of this header): `float` in the patch's text is then klang::signal, and so are Args.
+// `a >> b`: b.input(a) when b is an Input, else plain assignment (klang.h:4868-4890)
+template<class SRC, class DST, typename = std::enable_if_t<!std::is_arithmetic_v<SRC>>>
+inline DST& operator>>(SRC& src, DST& dst) {
+	if constexpr (std::is_base_of_v<Generic::Input<signal>, DST>) dst.input(src); else dst << src;
+	return dst;
+}
+template<class SRC, class DST, typename = std::enable_if_t<!std::is_arithmetic_v<SRC>>>
+inline DST& operator>>(const SRC& src, DST& dst) {
+	if constexpr (std::is_base_of_v<Generic::Input<signal>, DST>) dst.input(src); else dst << src;
+	return dst;
+}
+
 struct GraphStub;
 template<typename... Args> struct Function : Modifier {
 	static_assert(sizeof...(Args) >= 1, "Function<x, ...>: at least the input");
@@ -591,7 +659,7 @@ template<typename... Args> struct Function : Modifier {
 		return *this;
 	}
 	GraphStub& operator>>(GraphStub& g) { return g; }                                // `f(distort) >> graph;`: the UI plot
-	using Modifier::operator>>;
+	template<class T> T& operator>>(T& dst) { return klang::operator>>(static_cast<Modifier&>(*this), dst); }   // (the GraphStub overload above hides the plain `>>`: an Input takes input(), anything else is assigned)
 	using Modifier::input;
 protected:
 	void input() override { std::get<0>(inputs) = in; }
@@ -602,17 +670,14 @@ protected:
 	}
 };
 
-// `a >> b`: b.input(a) when b is an Input, else plain assignment (klang.h:4868-4890)
-template<class SRC, class DST, typename = std::enable_if_t<!std::is_arithmetic_v<SRC>>>
-inline DST& operator>>(SRC& src, DST& dst) {
-	if constexpr (std::is_base_of_v<Generic::Input<signal>, DST>) dst.input(src); else dst << src;
-	return dst;
-}
-template<class SRC, class DST, typename = std::enable_if_t<!std::is_arithmetic_v<SRC>>>
-inline DST& operator>>(const SRC& src, DST& dst) {
-	if constexpr (std::is_base_of_v<Generic::Input<signal>, DST>) dst.input(src); else dst << src;
-	return dst;
-}
+// `abs` (klang.h:3065, 3072: a Function<float> object over fabsf that the header's `#define abs klang::abs` puts in std::abs's place): called — `abs(x)` — or streamed
+// through — `x >> abs >> y` (Vocoder.k:102)
+struct AbsFunction : Modifier {
+	signal operator()(const signal& x) const { return abs_of(x); }
+protected:
+	void process() override { out = abs_of(in); }
+};
+inline thread_local AbsFunction abs;
 
 // ---- oscillators: host halves only ----
 struct Oscillator : Generator {
@@ -1144,17 +1209,19 @@ struct NoteBinding { int patch; void (*pack)(const void*, uint32_t*); void (*unp
 // type has the same layout, so the offsets found on the prototype serve all of them).
 namespace gpu {
 struct GraphLayout {
-	struct Member { size_t offset; int kind; int word0; bool shared = false; };   // offset: of the Packable subobject (primitives) or of the signal (params); shared: a Note's smoothed control — it lives in the Synth, the bank sets the word per block
+	struct Member { size_t offset; int kind; int word0; bool shared = false; int ctl = -1; bool ctl_smoothed = false; };   // ctl: an EFFECT's smoothed / written control — it lives in the object's Controls (a vector), not inside the object   // offset: of the Packable subobject (primitives) or of the signal (params); shared: a Note's smoothed control — it lives in the Synth, the bank sets the word per block
 	std::vector<Member> members;
 	std::string program;
 	int words = 0;
 	std::vector<std::vector<float>> tables;                        // tabread slot k + 1 -> samples (uploaded by the Synth when the bank is created)
 	bool host_prepare = false;                                     // an effect whose prepare() stays host code (Controls::changed())
 	std::vector<int> delay_inputs;                                 // per member: an effect's Delay takes this many inputs per sample (its write cursor = samples x inputs, modulo SIZE)
-	void pack(const void* note, uint32_t* w) const {
+	// (own: the Controls of the object being packed, when it is not the recorded prototype — a host mirror of an instance: member offsets into the prototype's Controls mean nothing there)
+	void pack(const void* note, uint32_t* w, const Controls* own = nullptr) const {
 		for (const Member& m : members) {
 			const char* obj = (const char*)note + m.offset;
 			if (m.shared) { w[m.word0] = 0u; continue; }
+			if (m.ctl >= 0 && own) { const Control& c = own->items[(size_t)m.ctl]; w[m.word0] = fbits(m.ctl_smoothed ? c.smoothed.value : c.value.value); continue; }
 			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH || m.kind == klg::graph::N_CTLVAR) w[m.word0] = fbits(reinterpret_cast<const signal*>(obj)->value);
 			else reinterpret_cast<const Packable*>(obj)->pack(w + m.word0);
 		}
@@ -1163,10 +1230,11 @@ struct GraphLayout {
 	void unpack_delays(void* note, const uint32_t* w) const {
 		for (const Member& m : members) if (m.kind == klg::graph::N_NDELAY) reinterpret_cast<Packable*>((char*)note + m.offset)->unpack(w + m.word0);
 	}
-	void unpack(void* note, const uint32_t* w) const {
+	void unpack(void* note, const uint32_t* w, Controls* own = nullptr) const {
 		for (const Member& m : members) {
 			char* obj = (char*)note + m.offset;
 			if (m.shared) continue;
+			if (m.ctl >= 0 && own) { Control& c = own->items[(size_t)m.ctl]; std::memcpy(m.ctl_smoothed ? &c.smoothed.value : &c.value.value, &w[m.word0], 4); continue; }
 			if (m.kind == klg::graph::N_PARAM || m.kind == klg::graph::N_SMOOTH || m.kind == klg::graph::N_CTLVAR) std::memcpy(&reinterpret_cast<signal*>(obj)->value, &w[m.word0], 4);
 			else reinterpret_cast<Packable*>(obj)->unpack(w + m.word0);
 		}
@@ -1442,7 +1510,7 @@ template<class NOTEBASE> inline void record_note(NOTEBASE* nb, std::vector<Obj> 
 	using namespace klg::graph;
 	Recorder R; rec = &R;
 	R.objs = std::move(objs);
-	R.prog.nctl = (int)ctl.items.size() < 8 ? (int)ctl.items.size() : 8;
+	R.prog.nctl = (int)ctl.items.size() < (int)klg::KLG_MAX_CTL ? (int)ctl.items.size() : (int)klg::KLG_MAX_CTL;
 	for (int c = 0; c < R.prog.nctl; c++) R.prog.dials[c] = { ctl.items[(size_t)c].min, ctl.items[(size_t)c].max, ctl.items[(size_t)c].initial };
 	R.recording = true;
 	std::vector<int> first_reg(R.objs.size(), -1);
@@ -1498,7 +1566,7 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 	Recorder R; R.effect = true; rec = &R;
 	R.objs = std::move(objs);
 	R.prog.channels = channels;
-	R.prog.nctl = (int)ctl.items.size() < 8 ? (int)ctl.items.size() : 8;
+	R.prog.nctl = (int)ctl.items.size() < (int)klg::KLG_MAX_CTL ? (int)ctl.items.size() : (int)klg::KLG_MAX_CTL;
 	for (int c = 0; c < R.prog.nctl; c++) R.prog.dials[c] = { ctl.items[(size_t)c].min, ctl.items[(size_t)c].max, ctl.items[(size_t)c].initial };
 	// prepare() is recorded too: it becomes the program's per-block prologue (`prepare <n>`), so `filter.set(controls[2])`
 	// follows each instance's own control.  Member params it assigns are written to the record and read back by process().
@@ -1512,8 +1580,17 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 		for (int c = 0; c < R.prog.nctl; c++) ctl.items[(size_t)c].value.reg = R.emit(OP_CTL, -1, -1, -1, (uint32_t)c, true);
 		for (size_t q = 0; q < oscs.size(); q++) oscs[q]->frequency.reg = R.emit(OP_FREQ, -1, -1, osc_node[q], 0, true);
 	};
+	const size_t nobjs0 = R.objs.size();
 	fresh_inputs();
 	prepare();
+	if (!R.error.empty() && !R.host_prepare) {
+		// prepare() does something a recorded prologue cannot express (Vocoder.k:51-78: Pitch -> Frequency and power() on values read from dials, constants built
+		// from them, loops of std::pow): it stays HOST code, exactly as an effect whose prepare() asks Controls::changed() — EffectBank / FxRunner run it on a host
+		// mirror of every instance whose dials moved and upload what it changed.  Nothing of the attempt is kept.
+		if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: %s::prepare() stays host code: %s\n", type_name, R.error.c_str());
+		R.host_prepare = true; R.error.clear(); R.prog.ops.clear(); R.next_reg = 0; R.objs.resize(nobjs0);
+		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { ((signal*)R.objs[i].addr)->reg = -1; first_reg[i] = -1; }
+	}
 	for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { signal* sg = (signal*)R.objs[i].addr; if (sg->reg != first_reg[i]) R.emit(OP_SETPARAM, R.reg_of(*sg), -1, (int)i, 0, false); }
 	R.prog.prepare_ops = (int)R.prog.ops.size();
 	fresh_inputs();
@@ -1554,6 +1631,10 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 		if (*identity) return;
 	}
 	finish_program(R, lo, layout);
+	for (GraphLayout::Member& m : layout.members) if (m.kind == N_SMOOTH || m.kind == N_CTLVAR) for (size_t c = 0; c < ctl.items.size(); c++) {
+		if (lo + m.offset == (const char*)&ctl.items[c].value) { m.ctl = (int)c; m.ctl_smoothed = false; }
+		if (lo + m.offset == (const char*)&ctl.items[c].smoothed) { m.ctl = (int)c; m.ctl_smoothed = true; }
+	}
 	layout.host_prepare = R.host_prepare;
 	layout.delay_inputs.assign(layout.members.size(), 0);             // (member j is node j of the finished program)
 	for (size_t i = (size_t)R.prog.prepare_ops; i < R.prog.ops.size(); i++) if (R.prog.ops[i].code == OP_DELAYIN && R.prog.ops[i].node >= 0 && (size_t)R.prog.ops[i].node < layout.delay_inputs.size()) layout.delay_inputs[(size_t)R.prog.ops[i].node]++;
@@ -1656,7 +1737,7 @@ struct FxRunner {
 	klg_fx* h = nullptr; GraphLayout layout; bool built = false, identity = false; int channels = 1, cap = 1024;
 	std::vector<float> io, sent;
 	// an effect whose prepare() stays host code (Controls::changed(): see gpu::EffectBank) — here the host's own object is the mirror of the one instance
-	void* host_obj = nullptr; std::function<void()> host_prepare_fn; unsigned long long samples = 0; int device_controls = 8; std::vector<uint32_t> before, after;
+	void* host_obj = nullptr; std::function<void()> host_prepare_fn; unsigned long long samples = 0; int device_controls = (int)klg::KLG_MAX_CTL; std::vector<uint32_t> before, after;
 	FxRunner() {}
 	FxRunner(const FxRunner&) {}
 	FxRunner& operator=(const FxRunner&) { return *this; }
@@ -1680,7 +1761,7 @@ struct FxRunner {
 		layout.pack(lo, words.data());
 		h = klg_fx_create_graph(layout.program.c_str(), 1, fs.f, cap, words.data());
 		if (!h) die("klg_fx_create_graph");
-		device_controls = (int)ctl.items.size() < 8 ? (int)ctl.items.size() : 8;
+		device_controls = (int)ctl.items.size() < (int)klg::KLG_MAX_CTL ? (int)ctl.items.size() : (int)klg::KLG_MAX_CTL;
 		if (layout.host_prepare) { host_obj = (void*)lo; host_prepare_fn = [fx]() { fx->prepare(); }; before.resize((size_t)layout.words); after.resize((size_t)layout.words); }
 	}
 	void host_prepare() {                                                            // (gpu::EffectBank::host_prepare, for the one instance the host object itself mirrors)
@@ -1724,7 +1805,7 @@ struct FxRunner {
 			for (int c = 0; c < channels; c++) std::memcpy(ch[c] + at, &io[(size_t)c * (size_t)m], (size_t)m * sizeof(float));
 		}
 		// what the effect wrote to its own controls (PingPong.k:48,60) comes back to the host's Control objects, as in the reference
-		for (int c = 0; c < (int)ctl.items.size() && c < 8; c++) {
+		for (int c = 0; c < (int)ctl.items.size() && c < (int)klg::KLG_MAX_CTL; c++) {
 			float v = 0.f;
 			if (klg_fx_get_control(h, 0, c, &v)) die("klg_fx_get_control");
 			if (v != ctl.items[(size_t)c].value.value) { ctl.items[(size_t)c].value.value = v; sent[(size_t)c] = v; }
@@ -2368,7 +2449,7 @@ template<class FX> struct EffectBank {
 		if (std::getenv("KLANG_MI355_DUMP_GRAPH")) { std::fprintf(stderr, "klang-mi355: initial record:"); for (uint32_t w : words) std::fprintf(stderr, " %08x", w); std::fprintf(stderr, "\n"); }
 		h = klg_fx_create_graph(layout.program.c_str(), instances, fs.f, max_block, words.data());
 		if (!h) { std::fprintf(stderr, "klang-mi355: klg_fx_create_graph: %s\n", klg_last_error()); std::abort(); }
-		device_controls = (int)fx->controls.items.size() < 8 ? (int)fx->controls.items.size() : 8;      // (record_effect: the controls a program knows)
+		device_controls = (int)fx->controls.items.size() < (int)klg::KLG_MAX_CTL ? (int)fx->controls.items.size() : (int)klg::KLG_MAX_CTL;      // (record_effect: the controls a program knows)
 	}
 	~EffectBank() { if (h) klg_fx_destroy(h); delete fx; for (FX* m : mirror) delete m; }
 	void set(int instance, int control, float value) {
@@ -2405,12 +2486,12 @@ template<class FX> struct EffectBank {
 		for (int k : touched) {
 			FX* m = mirror_of(k);
 			if (klg_fx_download_record(h, k, before.data(), before.size() * 4)) { std::fprintf(stderr, "klang-mi355: %s\n", klg_last_error()); std::abort(); }
-			layout.unpack(m, before.data());
+			layout.unpack(m, before.data(), &m->controls);
 			for (size_t j = 0; j < layout.members.size(); j++) if (layout.members[j].kind == klg::graph::N_DELAY)
 				reinterpret_cast<Packable*>((char*)m + layout.members[j].offset)->host_cursor(samples * (unsigned long long)layout.delay_inputs[j]);
-			layout.pack(m, before.data());                          // (what the mirror holds — not everything a primitive keeps on the device has a host side: only what prepare() CHANGES goes back)
+			layout.pack(m, before.data(), &m->controls);            // (what the mirror holds — not everything a primitive keeps on the device has a host side: only what prepare() CHANGES goes back)
 			m->prepare();
-			layout.pack(m, after.data());
+			layout.pack(m, after.data(), &m->controls);
 			for (int w = 0; w < layout.words;) {
 				if (after[(size_t)w] == before[(size_t)w]) { w++; continue; }
 				int e = w + 1; while (e < layout.words && after[(size_t)e] != before[(size_t)e]) e++;
@@ -2434,13 +2515,20 @@ namespace minimal { using namespace klang; }
 
 // `std::abs(x)` of a signal: in the reference the signal converts to float and takes std::abs(float).  A recorded value has no float to
 // convert to, so the call is given the signal itself (an exact match beats the float conversion); same value, recordable.
-namespace std { inline klang::signal abs(const klang::signal& x) { return klang::abs(x); } }
+namespace std { inline ::klang::signal abs(const ::klang::signal& x) { return ::klang::abs_of(x); } }
+// `abs` in a patch's text names klang's object (klang.h:3072 `#define abs klang::abs`), and what a patch writes as `std::abs(x)` is therefore `std::klang::abs(x)`: the
+// original math function (klang.h:56-62).  Both as the reference has them — the macro at the very end of this header.
+namespace std { namespace klang {
+	inline ::klang::signal abs(const ::klang::signal& x) { return ::klang::abs_of(x); }
+	template<class T, std::enable_if_t<std::is_arithmetic_v<T>, int> = 0> inline T abs(T x) { return std::abs(x); }
+} }
 
 // ---- plain-`float` C functions applied to signals (examples/Distortion/Functions.k: `float hardclip(float x) {...}`, `hardclip(in * gain) >> out`) ----
 // A tracing facade cannot see into `float f(float)`: the signal converts to a float and the recorded world ends there.  A patch of that kind is compiled
 // with -DKLANG_GPU_TRACE_FLOAT: from here on — i.e. in the patch's OWN text, which follows this header — the word `float` names klang::signal, the value
 // that records what is done to it (arithmetic, comparisons in `if`: one traced run of process() per outcome).  The .k file itself stays as it is; whoever
 // includes it puts `#undef float` behind the include (include/klang/bindings.h and the test drivers do).
+#define abs klang::abs
 #ifdef KLANG_GPU_TRACE_FLOAT
 #define float ::klang::signal
 #endif

@@ -14,7 +14,7 @@
  *     klgg 1
  *     kind effect <channels>              optional: the body of an Effect::process() (1 = klang::Effect, 2 = Stereo::Effect) instead
  *                                         of a Note's; one lane per effect instance, input samples via `in`, output via ret / ret2
- *     ctl <count>                         number of controls of the synth / effect (<= 8)
+ *     ctl <count>                         number of controls of the synth / effect (<= 32)
  *     dial <i> <min> <max> <initial>      Dial(...) of control i              klang.h:1797-1800
  *     node <id> <kind> [size]             a primitive object of the Note / Effect, ids 0,1,2,... in order (size: Delay<SIZE>)
  *     op <code> <dst> <a> <b> <node> <imm>   one op; unused fields are -1; imm = IEEE-754 bits (hex) of a constant
@@ -93,7 +93,7 @@ enum { OPER_INC = 0, OPER_POS, OPER_FREQ, OPER_AMP, OPER_ENV, OPER_WORDS = OPER_
 enum { WT_INC = 0, WT_POS, WT_OFFSET, WT_FREQ, WT_TABLE, WT_WORDS };
 enum { ND_POS = 0, ND_LASTPOS, ND_LASTFRAC, ND_TIME, ND_WORDS };
 enum { ED_LASTPOS = 0, ED_LASTFRAC, ED_WORDS };   /* an effect's Delay: the read head of set() / process() (Delay::last klang.h:3388) */
-enum { MAX_WORDS = 512, MAX_NODES = 256, MAX_OPS = 16384 };   // (round 3: the shipped Reverb.k records — 16 FilteredDelays, 20 stereo taps — at ~330 words / ~3 k ops)
+enum { MAX_WORDS = 2048, MAX_NODES = 256, MAX_OPS = 16384 };   // (round 3: the shipped Reverb.k records — 16 FilteredDelays, 20 stereo taps — at ~330 words / ~3 k ops)
 
 inline bool is_oscillator(int k) { return k == N_FSINE || k == N_SAW || k == N_PULSE || (k >= N_BSINE && k <= N_BPULSE) || k == N_WAVETABLE; }
 inline bool is_modifier(int k) { return k == N_LPF || (k >= N_OPLPF && k <= N_FOLLOWRMS) || k == N_IIRN; }
@@ -161,7 +161,8 @@ enum OpCode {
 	                   its instances in one process (instance-major, then sample, then the ops in program order).  Effects only, never inside an `if` */
 	OP_DELAYOUT,    /* dst = delay node process()          Delay::process 3470-3473: the read head set by set() (note delays)   */
 	OP_TABREAD,     /* dst = table imm [ a ]               Table<float, SIZE>::operator[](float): clamped, linear   klang.h:3365-3377; imm = table id (klg_table_upload) */
-	OP_SETCTL,      /* dst = ctlvar node = clamp(a)        controls[imm].set(a): (a < min) ? min : (max < a) ? max : a, the dial's range   Control::set klang.h:1725-1728 (effects) */
+	OP_SETCTL,      /* dst = ctlvar node = clamp(a)        controls[imm & 0xFF].set(a): (a < min) ? min : (max < a) ? max : a, the dial's range   Control::set klang.h:1725-1728 (effects);
+	                   imm bit 8: `x >> controls[i]` / `controls[i] << x` — the plain assignment of Control::operator<< klang.h:1745-1746 (a METER fed by process(): Vocoder.k:104), no clamp */
 	OP_DELAYSET,    /* delay node .set(samples = a)        Delay::set 3480-3489: the read head `samples` behind the write cursor (in process(), or in an
 	                   effect's prepare(): placed once per block, then walked by every `delay >> x`) */
 	OP_ABS,         /* dst = |a|                           std::abs of a signal: fabsf                                                               */
@@ -177,19 +178,23 @@ enum OpCode {
 	OP_FUNC,        /* dst(double) = f(a), a a double, f by imm: 0 = tanh — what `tanh(x)` of a float is inside a patch's plain C function: the C library's DOUBLE tanh of the
 	                   converted float, and the expression around it stays double (`tanh(c * x) / tanh(c)`, examples/Distortion/Shaping.k:15: f2d, func, ddiv, d2f).
 	                   klg_device.hpp glibc_tanh restates glibc 2.35's (float-rounded result equal on all 2^32 floats: tools/verify_tanh_f64.c) */
+	OP_POWC,        /* dst = power(a, e), e the float whose bits are imm, one of 0, +-1 .. +-4: klang's `power(float base, float exp)` with a literal exponent (klang.h:188-218;
+	                   Vocoder.k:83 `power(1.f - x, 2.f)`): base == 10 ? (float)exp(e * ln 10) : the product / quotient of bases the reference writes out for these exponents.
+	                   (Any other exponent is the C library's powf and is refused by the recorder.) */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs", "f2d", "dconst", "dlow", "dadd", "dsub", "dmul", "ddiv", "d2f", "envoff", "func" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs", "f2d", "dconst", "dlow", "dadd", "dsub", "dmul", "ddiv", "d2f", "envoff", "func", "powc" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
 struct Op { int code, dst, a, b, node; uint32_t imm; };
 struct Dial { float min, max, initial; };
+enum { GRAPH_MAX_CTL = 32 };     /* = KLG_MAX_CTL (klang_mi355_records.h) */
 
 struct Program {
 	int nctl = 0;
-	Dial dials[8] = {};
+	Dial dials[GRAPH_MAX_CTL] = {};
 	std::vector<int> nodes;      /* kind of node i */
 	std::vector<int> node_arg;   /* Delay<SIZE>: SIZE; else 0 */
 	std::vector<Op> ops;
@@ -237,7 +242,7 @@ struct Program {
 			if (!strcmp(kw, "klgg")) { int v = 0; if (sscanf(rest, "%d", &v) != 1 || v != 1) return bad("unsupported version"); header = true; }
 			else if (!header) return bad("missing 'klgg 1' header");
 			else if (!strcmp(kw, "kind")) { char w[32]; if (sscanf(rest, "%31s %d", w, &channels) != 2 || strcmp(w, "effect") || channels < 1 || channels > 2) return bad("expected: kind effect 1|2"); }
-			else if (!strcmp(kw, "ctl")) { if (sscanf(rest, "%d", &nctl) != 1 || nctl < 0 || nctl > 8) return bad("ctl count must be 0..8"); }
+			else if (!strcmp(kw, "ctl")) { if (sscanf(rest, "%d", &nctl) != 1 || nctl < 0 || nctl > GRAPH_MAX_CTL) return bad("ctl count must be 0..32"); }
 			else if (!strcmp(kw, "dial")) { int i; float a, b, c; if (sscanf(rest, "%d %g %g %g", &i, &a, &b, &c) != 4 || i < 0 || i >= nctl) return bad("bad dial"); dials[i] = { a, b, c }; }
 			else if (!strcmp(kw, "node")) {
 				int id, size = 0; char kind[32];
@@ -270,7 +275,7 @@ struct Program {
 
 	/* single assignment, defined-before-use, node kinds match their ops */
 	std::string validate() const {
-		if (words() > MAX_WORDS) return "graph program: the voice record exceeds 512 words";
+		if (words() > MAX_WORDS) return "graph program: the voice record exceeds 2048 words";
 		std::vector<char> defined;                                 /* 1 = visible here, 2 = assigned in a branch side that has ended */
 		auto def = [&](int r) { return r >= 0 && r < (int)defined.size() && defined[(size_t)r] == 1; };
 		struct Side { std::vector<int> regs; bool in_else; std::vector<int> then_side; };
@@ -310,8 +315,9 @@ struct Program {
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			case OP_CMP: if (o.imm > 5u) return bad("unknown relation"); need_a = need_b = true; break;
 			case OP_NOISE: if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;
-			case OP_SETCTL: if (k != N_CTLVAR) return bad("node is not a written control"); if (!channels) return bad("only an effect writes its controls"); if ((int)o.imm >= nctl) return bad("control index out of range"); need_a = true; break;
+			case OP_SETCTL: if (k != N_CTLVAR) return bad("node is not a written control"); if (!channels) return bad("only an effect writes its controls"); if ((int)(o.imm & 0xFFu) >= nctl || (o.imm >> 9)) return bad("control index out of range"); need_a = true; break;
 			case OP_ABS: need_a = true; break;
+			case OP_POWC: { need_a = true; float e; memcpy(&e, &o.imm, 4); if (!(e == 0.f || e == 1.f || e == 2.f || e == 3.f || e == 4.f || e == -1.f || e == -2.f || e == -3.f || e == -4.f)) return bad("powc: the exponent must be one of 0, +-1 .. +-4"); } break;
 			case OP_FUNC: need_a = true; if (o.imm != 0u) return bad("no such function"); if (!is_dbl(o.a)) return bad("operand a is not a double"); dst_dbl = true; break;
 			case OP_F2D: need_a = true; if (is_dbl(o.a)) return bad("operand a is already a double"); dst_dbl = true; break;
 			case OP_DCONST: dst_dbl = true; break;

@@ -21,7 +21,7 @@ namespace klg {
 
 enum { ST_ONSET = 0, ST_SUSTAIN = 1, ST_RELEASE = 2, ST_OFF = 3 };   /* NoteBase::Stage */
 enum { ENV_SUSTAIN = 0, ENV_RELEASE = 1, ENV_OFF = 2 };              /* Envelope::Stage klang.h:3809 */
-enum { KLG_MAX_CTL = 8 };
+enum { KLG_MAX_CTL = 32 };                                            /* controls per synth / effect instance (Vocoder.k: 5 dials + 22 meters) */
 
 struct OsmRec { int32_t inc; uint32_t offset, duty; float delta; };                 /* Fast::OSM klang.h:5196-5200 */
 struct AdsrRec { float r_out, r_target, r_rate, time, A, AD, S, R; };               /* ADSR: points (0,0) (A,1) (A+D,S); R for release() */

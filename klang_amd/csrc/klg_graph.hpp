@@ -63,8 +63,9 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 	for (const Op& o : g.ops) if (o.code == OP_DELAYSET) reset_head[(size_t)o.node] = true;
 	for (const Op& o : g.ops) { if (o.code == OP_LPFSET) swept[(size_t)o.node] = true; if (o.code == OP_SETPARAM) written[(size_t)o.node] = true; if (o.code == OP_OSCSET) { retuned[(size_t)o.node] = true; if (o.imm == 3u) dutied[(size_t)o.node] = true; } }
 	const bool fx = g.channels > 0;
-	int ctlvar[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };                      // control index -> the ctlvar node holding the instance's own copy (controls the effect writes)
-	for (const Op& o : g.ops) if (o.code == OP_SETCTL) ctlvar[o.imm & 7u] = o.node;
+	static_assert((int)GRAPH_MAX_CTL == (int)KLG_MAX_CTL, "one control count");
+	int ctlvar[KLG_MAX_CTL]; for (int& v : ctlvar) v = -1;                    // control index -> the ctlvar node holding the instance's own copy (controls the effect writes)
+	for (const Op& o : g.ops) if (o.code == OP_SETCTL) ctlvar[o.imm & 0xFFu] = o.node;
 	auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
 	std::vector<long long> ring_off(g.nodes.size(), 0); std::vector<int> inputs(g.nodes.size(), 0);   // Delay nodes: first row in the group's ring tile, inputs per sample
 	{ long long rows = 0; for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == N_DELAY || g.nodes[i] == N_NDELAY) { ring_off[i] = rows; rows += g.arg((int)i) + 1; } }   // SIZE + 1: the pad element (klg_delay.hpp)
@@ -242,7 +243,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 	}
 	if (fx) {                                                         // an effect's dials are the block's (klg_fx_set_control uploads them before the launch): read once, not in every sample
 		bool used[KLG_MAX_CTL] = {};
-		for (const Op& o : g.ops) if ((o.code == OP_CTL || o.code == OP_SMOOTH) && ctlvar[o.imm & 7u] < 0 && o.imm < (unsigned)KLG_MAX_CTL) used[o.imm] = true;
+		for (const Op& o : g.ops) if ((o.code == OP_CTL || o.code == OP_SMOOTH) && ctlvar[o.imm & 0xFFu] < 0 && o.imm < (unsigned)KLG_MAX_CTL) used[o.imm] = true;
 		for (unsigned i = 0; i < (unsigned)KLG_MAX_CTL; i++) if (used[i]) { live += fmt(" float ctl%u;", i); ctl_begin += fmt("\t\tL.ctl%u = c.ctl[%u];\n", i, i); }
 		begin += ctl_begin;
 	}
@@ -359,13 +360,23 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		const int k = (o.node >= 0 && o.node < (int)g.nodes.size()) ? g.nodes[(size_t)o.node] : -1;
 		switch (o.code) {
 		case OP_CONST: body += d + "kf<" + TF + fmt(">(0x%08xu);\n", o.imm); break;
-		case OP_CTL: body += d + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d;\n", ctlvar[o.imm & 7u]) : fx ? fmt("L.ctl%u;\n", o.imm) : fmt("ctl_read(c, %uu);\n", o.imm)); break;   // (a control the effect writes: its own copy)
+		case OP_CTL: body += d + (ctlvar[o.imm & 0xFFu] >= 0 ? fmt("L.n%d;\n", ctlvar[o.imm & 0xFFu]) : fx ? fmt("L.ctl%u;\n", o.imm) : fmt("ctl_read(c, %uu);\n", o.imm)); break;   // (a control the effect writes: its own copy)
 		case OP_SETCTL: {                                                  // Control::set klang.h:1725-1728: (x < min) ? min : (max < x) ? max : x — as two selects (min < max: at most one of the tests holds; a NaN passes both)
-			const uint32_t mn = fbits(g.dials[o.imm & 7u].min), mx = fbits(g.dials[o.imm & 7u].max);
+			if (o.imm & 0x100u) { body += d + a + ";\n\t\t" + n + fmt(" = r%d;\n", o.dst); break; }   // Control::operator<< klang.h:1745-1746: the plain assignment (a meter)
+			const uint32_t mn = fbits(g.dials[o.imm & 0xFFu].min), mx = fbits(g.dials[o.imm & 0xFFu].max);
 			body += fmt("\t\tconst float r%dh = (u2f(0x%08xu) < ", o.dst, mx) + a + fmt(") ? u2f(0x%08xu) : ", mx) + a + ";\n";
 			body += d + "(" + a + fmt(" < u2f(0x%08xu)) ? u2f(0x%08xu) : r%dh;\n\t\t", mn, mn, o.dst) + n + fmt(" = r%d;\n", o.dst);
 		} break;
 		case OP_ABS: body += d + "__builtin_fabsf(" + a + ");\n"; break;
+		case OP_POWC: {                                                    // klang.h:188-218 with a literal float exponent: the test for base 10 first, then the written-out products
+			float e; memcpy(&e, &o.imm, 4);
+			const float ten = (float)exp((double)(e * 2.3025850929940456840179914546843642076011014886287729760333279009f));   // (the C library's exp, here on the host: the value the reference computes at run time)
+			const int m = (int)(e < 0 ? -e : e);
+			std::string p = m == 0 ? "1.f" : a; for (int q = 1; q < m; q++) p += " * " + a;
+			if (m > 1) p = "(" + p + ")";
+			if (e < 0) p = "1.f / " + p;
+			body += d + "(" + a + fmt(" == 10.f) ? u2f(0x%08xu) : ", fbits(ten)) + p + ";\n";
+		} break;
 		case OP_PARAM: body += d + n + ";\n"; break;
 		case OP_OSC: {
 			std::string e;
@@ -462,7 +473,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		case OP_DELAYTAP:
 			if (hoist_of[oi] >= 0) { body += d + (o.imm == 2u ? "delay_tap_stereo_h(" : "delay_tap_float_h(") + ring(o.node) + ", " + n + "pos, " + a + fmt(", h%d, h%da, h%db, ", hoist_of[oi], hoist_of[oi], hoist_of[oi]) + hazard_of(hoist_of[oi]) + ");\n"; break; }
 			body += d + (o.imm == 1u ? "delay_tap_int(" + ring(o.node) + ", " + n + "pos, (int)" + a + ");\n" : (o.imm == 3u ? "delay_lagrange(" : o.imm == 2u ? "delay_tap_stereo(" : "delay_tap_float(") + ring(o.node) + ", " + n + "pos, " + a + ");\n"); break;   // imm 1: tap(int), klang.h:3405-3410; 3: lagrange(float) 3429-3458
-		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 7u] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 7u]) : fx ? fmt("L.ctl%u", o.imm) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
+		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 0xFFu] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 0xFFu]) : fx ? fmt("L.ctl%u", o.imm) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";
 			body += d + "fsine_process(" + n + ", fsine_rel_offset(" + (o.a >= 0 ? a : std::string("0.f")) + ")) * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs) * " + n + "a);\n";
@@ -639,7 +650,7 @@ struct Rtc {
 };
 
 struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; int note_channels = 1;   // note_channels: 2 = the notes' `out` is stereo (ret2 in a note program)
-	 long long ring_rows = 0; int noise_calls = 0; struct Smooth { int word, ctl, calls; }; std::vector<Smooth> smooths; int ctlvar_word[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };   // ctlvar_word[i]: the record word of control i's own copy (an effect that writes it), else -1
+	 long long ring_rows = 0; int noise_calls = 0; struct Smooth { int word, ctl, calls; }; std::vector<Smooth> smooths; int ctlvar_word[KLG_MAX_CTL] = { -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1 };   // ctlvar_word[i]: the record word of control i's own copy (an effect that writes it), else -1
 	 bool x2 = false; std::vector<std::pair<long long, int>> delays;
 	 bool staged = false; std::string staged_why; int staged_G = 0, staged_C = 0, staged_threads = 0, staged_lds = 0, staged_levels = 0, staged_slots = 0; };   // staged: the code object also holds klg_fx_staged (klg_graph_staged.hpp)   // delays: (first ring row, SIZE) of each delay node in node order   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
 
@@ -742,7 +753,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	c.words = g.words(); c.channels = g.channels; c.x2 = x2; c.note_channels = g.stereo_note() ? 2 : 1;
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY || g.nodes[i] == graph::N_NDELAY) { c.delays.push_back({ c.ring_rows, g.arg((int)i) }); c.ring_rows += g.arg((int)i) + 1; }   // (+ the pad element of every line: klg_delay.hpp)
 	c.noise_calls = g.noise_calls();
-	for (const graph::Op& o : g.ops) if (o.code == graph::OP_SETCTL) c.ctlvar_word[o.imm & 7u] = g.node_word0(o.node);
+	for (const graph::Op& o : g.ops) if (o.code == graph::OP_SETCTL) c.ctlvar_word[o.imm & 0xFFu] = g.node_word0(o.node);
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_SMOOTH) {            // controls[ctl].smooth(): state word, control, calls per sample
 		Compiled::Smooth sm = { g.node_word0((int)i), -1, 0 };
 		for (const graph::Op& o : g.ops) if (o.code == graph::OP_SMOOTH && o.node == (int)i) { sm.ctl = (int)o.imm; sm.calls++; }

@@ -71,9 +71,13 @@ FX["fx_functions"] = [(1.0, 25.0)]
 FX["fx_shaping"] = [(0.001, 5.6)]
 # tests/patches/fx_lines.k (OUR OWN effect, added last): an ARRAY of user Modifiers as a member, Delay -> LPF -> gain, a Matrix with zero entries
 FX["fx_ownlines"] = [(2.0, 30.0), (300.0, 9000.0), (0.0, 0.55), (0.2, 1.0)]
+# examples/Vocoder.k (added last): 22 band-pass pairs, followers, saws; 27 controls (5 dials + 22 METERs that process() feeds: `... >> follower[b] >> controls[5 + b]`); prepare() — Pitch -> Frequency,
+# power(), constants to integer powers — stays host code; `_boost(float)` is a plain C function (-DKLANG_GPU_TRACE_FLOAT)
+FX["fx_vocoder"] = [(40.0, 80.0), (1.0, 3.5), (0.01, 0.1), (0.01, 0.1), (0.5, 14.0)]
 SHAPE = {"fx_patterns": dict(K=4, blocks=110),       # name -> instances / blocks (default 9 / 24)
          "fx_topreverb": dict(K=9, blocks=64),
-         "fx_reverb2": dict(K=9, blocks=40)}         # 8,192 samples: the early reflections arrive after ~2,600, mid[] ~400 later, late[] ~1,000 after that
+         "fx_reverb2": dict(K=9, blocks=40),
+         "fx_vocoder": dict(K=5, blocks=24)}         # 8,192 samples: the early reflections arrive after ~2,600, mid[] ~400 later, late[] ~1,000 after that
 
 
 def draw(rng, lo, hi):

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 NAMES = ["fx_gain", "fx_pan", "fx_rm", "fx_tremolo", "fx_eq", "fx_iir", "fx_wahwah", "fx_echo", "fx_feedback", "fx_flanger", "fx_moddelay", "fx_chorus", "fx_reverb1", "fx_reverb2", "fx_clipping", "fx_mute", "fx_bands", "fx_objects", "fx_dpingpong", "fx_patterns", "fx_topchorus",
-         "fx_functions", "fx_shaping"]      # (the last two: plain-`float` C functions on the signal stream, compiled with -DKLANG_GPU_TRACE_FLOAT — tests/cpp/Makefile)
+         "fx_functions", "fx_shaping",      # (these two: plain-`float` C functions on the signal stream, compiled with -DKLANG_GPU_TRACE_FLOAT — tests/cpp/Makefile)
+         "fx_vocoder"]                      # examples/Vocoder.k: 27 controls (22 meters fed by process()), prepare() as host code, power(x, 2.f) in a plain-float function
 
 
 def run_effect(name, tmp_path, own=False):
