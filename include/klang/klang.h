@@ -329,6 +329,17 @@ inline int gpu::Recorder::reg_of(const signal& s) { return s.reg >= 0 ? s.reg : 
 
 // std::abs / abs of a signal (PingPong.k:46 `std::abs(delay - new_delay) > 0.001`): fabsf of the float the reference converts it to — recordable
 inline signal abs_of(const signal& x) { gpu::Recorder* r = gpu::recording(); signal s(__builtin_fabsf(x.value)); if (r && x.reg >= 0) s.reg = r->emit(klg::graph::OP_ABS, x.reg, -1, -1, 0, true); return s; }
+// min / max with a plain number FIRST and a signal second (klang.h:223-224: `a < b ? a : (T1)b` — the result has the FIRST type, so `min(20000, x)` of Modular.k:155 is an int:
+// x truncated).  Recordable: the comparison is a data-dependent branch, the truncation an op
+inline signal trunc_of(const signal& x) { gpu::Recorder* r = gpu::recording(); signal s((float)(int)x.value); if (r && x.reg >= 0) s.reg = r->emit(klg::graph::OP_TRUNC, x.reg, -1, -1, 0, true); return s; }
+template<class A, std::enable_if_t<std::is_arithmetic_v<A>, int> = 0> inline signal min(A a, const signal& b) {
+	if ((bool)(a < b)) return signal((float)a);
+	if constexpr (std::is_integral_v<A>) return trunc_of(b); else return signal(b);
+}
+template<class A, std::enable_if_t<std::is_arithmetic_v<A>, int> = 0> inline signal max(A a, const signal& b) {
+	if ((bool)(a > b)) return signal((float)a);
+	if constexpr (std::is_integral_v<A>) return trunc_of(b); else return signal(b);
+}
 // power(signal, literal float): inside a recorded process() one op for the exponents the reference writes out (graph OP_POWC); any other exponent is the C library's powf
 inline signal power(const signal& base, float e) {
 	signal s(power(base.value, e));
@@ -420,19 +431,22 @@ KLANG_CONTROL_OPS(+) KLANG_CONTROL_OPS(-) KLANG_CONTROL_OPS(*) KLANG_CONTROL_OPS
 	template<class S, std::enable_if_t<std::is_base_of_v<signal, S>, int> = 0> inline gpu::Pred operator OP(const S& s, Control& c) { return static_cast<const signal&>(s) OP c.value; }
 KLANG_CONTROL_CMP(<) KLANG_CONTROL_CMP(>) KLANG_CONTROL_CMP(<=) KLANG_CONTROL_CMP(>=) KLANG_CONTROL_CMP(==) KLANG_CONTROL_CMP(!=)
 #undef KLANG_CONTROL_CMP
-inline Control Dial(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f) { Control c; c.name = name; c.min = mn; c.max = mx; c.initial = initial; c.value = initial; return c; }
-// the other control kinds (klang.h:1801-1856): on this side of the boundary a control is its range and value
-inline Control Slider(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f) { return Dial(name, mn, mx, initial); }
-inline Control Meter(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f) { return Dial(name, mn, mx, initial); }
-inline Control Button(const char* name) { return Dial(name, 0.f, 1.f, 0.f); }
+inline Control Dial(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f, Control::Size size = Control::Size()) { Control c; c.name = name; c.min = mn; c.max = mx; c.initial = initial; c.value = initial; c.size = size; return c; }
+// the other control kinds (klang.h:1801-1856): on this side of the boundary a control is its range and value (type and size are kept for a host that draws them)
+inline Control Slider(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f, Control::Size size = Control::Size()) { Control c = Dial(name, mn, mx, initial, size); c.type = Control::SLIDER; return c; }
+inline Control Meter(const char* name, float mn = 0.f, float mx = 1.f, float initial = 0.f, Control::Size size = Control::Size()) { Control c = Dial(name, mn, mx, initial, size); c.type = Control::METER; return c; }
+inline Control Button(const char* name, Control::Size size = Control::Size()) { Control c = Dial(name, 0.f, 1.f, 0.f, size); c.type = Control::BUTTON; return c; }
 inline Control Toggle(const char* name, bool initial = false) { return Dial(name, 0.f, 1.f, initial ? 1.f : 0.f); }
-template<typename... Options> inline Control Menu(const char* name, const Options... options) { return Dial(name, 0.f, (float)sizeof...(options) - 1.f, 0.f); }
+template<typename... Options> inline Control Menu(const char* name, const Options... options) { Control c = Dial(name, 0.f, (float)sizeof...(options) - 1.f, 0.f); c.type = Control::MENU; return c; }
+template<typename... Options> inline Control Menu(const char* name, Control::Size size, const Options... options) { Control c = Dial(name, 0.f, (float)sizeof...(options) - 1.f, 0.f, size); c.type = Control::MENU; return c; }   // klang.h:1829-1838
 inline Control PitchBend() { return Dial("PITCH\nBEND", 0.f, 16384.f, 8192.f); }
 inline Control ModWheel() { return Dial("MOD\nWHEEL", 0.f, 127.f, 0.f); }
 struct Group {                                          // klang.h:1853-1873: `{ Dial(..) }` or `{ "name", Dial(..), Dial(..) }`
 	const char* name; std::vector<Control> controls;
 	template<typename... C> Group(const char* n, C... c) : name(n), controls{ c... } {}
 	template<typename... C> Group(C... c) : name(""), controls{ c... } {}
+	template<typename... C> Group(const char* n, Control::Size, C... c) : name(n), controls{ c... } {}     // `{ "LFO", { 269, 131 }, Dial(..), .. }`: a frame with a position (klang.h:1866-1871)
+	template<typename... C> Group(Control::Size, C... c) : name(""), controls{ c... } {}
 };
 struct Controls {
 	std::vector<Control> items; float cache[128] = { 0 };
@@ -546,6 +560,20 @@ KLANG_CONTROL_DBL(+) KLANG_CONTROL_DBL(-) KLANG_CONTROL_DBL(*) KLANG_CONTROL_DBL
 inline dsignal tanh(const signal& x) {                                  // (a double: the expression around it stays double in the reference — `tanh(c * x) / tanh(c)` divides doubles)
 	const dsignal a = dsignal::from(x); dsignal d(::tanh(a.value));
 	if (a.reg >= 0) if (gpu::Recorder* r = gpu::recording()) d.reg = r->emit(klg::graph::OP_FUNC, a.reg, -1, -1, 0, true);
+	return d;
+}
+// pow(B, x) of a signal with a plain number as the base (examples/Subtractive/Modular.k:24 `pow(10, 2 * (x - 1))`, :123 `pow(2, (signal)osc)`): in the reference std::pow(int, float)
+// — the C library's DOUBLE pow of the converted float, and for the base 2 the pinned compiler calls exp2 instead (the reference binary imports `pow` and `exp2`).  A double: the
+// expression around it stays double (`pow(2, x) * 0.5`).  On the device: klg_glibc_pow.hpp (graph OP_FUNC 1 / 2)
+template<class B, std::enable_if_t<std::is_arithmetic_v<B>, int> = 0> inline dsignal pow(B base, const signal& e) {
+	const double b = (double)base; const dsignal a = dsignal::from(e);
+	dsignal d(b == 2.0 ? ::exp2(a.value) : ::pow(b, a.value));
+	if (a.reg >= 0) if (gpu::Recorder* r = gpu::recording()) {
+		const float bf = (float)b; const uint32_t bits = gpu::fbits(bf);
+		if (b == 2.0) d.reg = r->emit(klg::graph::OP_FUNC, a.reg, -1, -1, 1u, true);
+		else if ((double)bf != b || (bits & 0xFFu) || !(bf >= 1.17549435e-38f && bf < 3.0e38f)) r->fail("pow(B, x) of a value computed in process(): the base must be a positive number with at most 16 significant bits");
+		else d.reg = r->emit(klg::graph::OP_FUNC, a.reg, -1, -1, bits | 2u, true);
+	}
 	return d;
 }
 inline signal sqr(const signal& x) { return x * x; }
@@ -958,7 +986,8 @@ struct ADSR : Envelope {
 	klg::host::AdsrH a;
 	ADSR() { if (gpu::Sink* r = gpu::constructing()) r->note(static_cast<Envelope*>(this), sizeof(ADSR), klg::graph::N_ADSR, this); set(0.5, 0.5, 1, 0.5); }
 	using Envelope::set;
-	void set(param attack, param decay, param sustain, param release) override { if (gpu::no_set_while_recording("ADSR::set()")) return; a.set(attack, decay, sustain, release, host_fs()); h = a.env; }
+	float A = 0.f, D = 0.f, S = 0.f, R = 0.f;                                  // klang.h:4100-4103: the envelope's times as set() keeps them (`if (env.R > 0.01) env.release();`, Modular.k:93 — event code)
+	void set(param attack, param decay, param sustain, param release) override { if (gpu::no_set_while_recording("ADSR::set()")) return; a.set(attack, decay, sustain, release, host_fs()); h = a.env; A = a.A; D = a.D; S = a.S; R = a.R; }
 	void pack(uint32_t* w) const override {
 		using namespace klg::graph;
 		w[ADSR_OUT] = gpu::fbits(h.r_out); w[ADSR_TARGET] = gpu::fbits(h.r_target); w[ADSR_RATE] = gpu::fbits(h.r_rate); w[ADSR_TIME] = gpu::fbits(h.time); w[ADSR_BITS] = h.bits();

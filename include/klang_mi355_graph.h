@@ -177,14 +177,19 @@ enum OpCode {
 	                   `!adsr.finished()`, `finished() && x > y` — the recorder turns the plain `if (env.finished()) stop();` back into stopif                 */
 	OP_FUNC,        /* dst(double) = f(a), a a double, f by imm: 0 = tanh — what `tanh(x)` of a float is inside a patch's plain C function: the C library's DOUBLE tanh of the
 	                   converted float, and the expression around it stays double (`tanh(c * x) / tanh(c)`, examples/Distortion/Shaping.k:15: f2d, func, ddiv, d2f).
-	                   klg_device.hpp glibc_tanh restates glibc 2.35's (float-rounded result equal on all 2^32 floats: tools/verify_tanh_f64.c) */
+	                   klg_device.hpp glibc_tanh restates glibc 2.35's (float-rounded result equal on all 2^32 floats: tools/verify_tanh_f64.c).
+	                   imm & 0xFF: 1 = exp2(a), 2 = pow(B, a) with the constant base B = the float whose pattern is imm & 0xFFFFFF00 (positive, normal) — the C library's DOUBLE
+	                   functions, what `pow(2, (signal)osc)` (the pinned compiler calls exp2) and `pow(10, 2 * (x - 1))` of examples/Subtractive/Modular.k:24, 123 are in the
+	                   reference build: klg_glibc_pow.hpp (bit-equal as doubles: tools/verify_glibc_pow.cpp) */
 	OP_POWC,        /* dst = power(a, e), e the float whose bits are imm, one of 0, +-1 .. +-4: klang's `power(float base, float exp)` with a literal exponent (klang.h:188-218;
 	                   Vocoder.k:83 `power(1.f - x, 2.f)`): base == 10 ? (float)exp(e * ln 10) : the product / quotient of bases the reference writes out for these exponents.
 	                   (Any other exponent is the C library's powf and is refused by the recorder.) */
+	OP_TRUNC,       /* dst = (float)(int)a                 a float forced through an int: klang's `min(20000, x)` returns its FIRST type (klang.h:223; Modular.k:155).  As the x86-64
+	                   conversion has it: truncation towards zero; NaN and |a| >= 2^31 give INT_MIN */
 	OP_CODES
 };
 inline const char* op_name(int code) {
-	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs", "f2d", "dconst", "dlow", "dadd", "dsub", "dmul", "ddiv", "d2f", "envoff", "func", "powc" };
+	static const char* names[OP_CODES] = { "const", "ctl", "param", "osc", "oscset", "lpf", "lpfset", "env", "add", "sub", "mul", "div", "neg", "stopif", "stop", "setparam", "freq", "in", "delayin", "delaytap", "smooth", "operator", "cmp", "if", "else", "endif", "phi", "noise", "delayout", "tabread", "setctl", "delayset", "abs", "f2d", "dconst", "dlow", "dadd", "dsub", "dmul", "ddiv", "d2f", "envoff", "func", "powc", "trunc" };
 	return (code >= 0 && code < OP_CODES) ? names[code] : "?";
 }
 
@@ -316,9 +321,10 @@ struct Program {
 			case OP_CMP: if (o.imm > 5u) return bad("unknown relation"); need_a = need_b = true; break;
 			case OP_NOISE: if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;
 			case OP_SETCTL: if (k != N_CTLVAR) return bad("node is not a written control"); if (!channels) return bad("only an effect writes its controls"); if ((int)(o.imm & 0xFFu) >= nctl || (o.imm >> 9)) return bad("control index out of range"); need_a = true; break;
-			case OP_ABS: need_a = true; break;
+			case OP_ABS: case OP_TRUNC: need_a = true; break;
 			case OP_POWC: { need_a = true; float e; memcpy(&e, &o.imm, 4); if (!(e == 0.f || e == 1.f || e == 2.f || e == 3.f || e == 4.f || e == -1.f || e == -2.f || e == -3.f || e == -4.f)) return bad("powc: the exponent must be one of 0, +-1 .. +-4"); } break;
-			case OP_FUNC: need_a = true; if (o.imm != 0u) return bad("no such function"); if (!is_dbl(o.a)) return bad("operand a is not a double"); dst_dbl = true; break;
+			case OP_FUNC: need_a = true; if ((o.imm & 0xFFu) > 2u || ((o.imm & 0xFFu) < 2u && (o.imm >> 8))) return bad("no such function");
+				if ((o.imm & 0xFFu) == 2u) { const uint32_t bb = o.imm & 0xFFFFFF00u; float base; memcpy(&base, &bb, 4); if (!(base >= 1.17549435e-38f && base < 3.0e38f)) return bad("func pow: the base must be a positive normal number"); } if (!is_dbl(o.a)) return bad("operand a is not a double"); dst_dbl = true; break;
 			case OP_F2D: need_a = true; if (is_dbl(o.a)) return bad("operand a is already a double"); dst_dbl = true; break;
 			case OP_DCONST: dst_dbl = true; break;
 			case OP_DLOW: need_a = true; if (!is_dbl(o.a)) return bad("operand a is not a double"); dst_dbl = true; break;

@@ -11,6 +11,7 @@
 #include <stdint.h>
 #endif
 #include "../../include/klang_mi355_records.h"
+#include "klg_glibc_pow.hpp"                     // glibc 2.35's double pow (constant base) / exp2, restated: graph OP_FUNC 1, 2
 
 #pragma clang fp contract(off)
 

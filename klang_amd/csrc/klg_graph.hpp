@@ -368,6 +368,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			body += d + "(" + a + fmt(" < u2f(0x%08xu)) ? u2f(0x%08xu) : r%dh;\n\t\t", mn, mn, o.dst) + n + fmt(" = r%d;\n", o.dst);
 		} break;
 		case OP_ABS: body += d + "__builtin_fabsf(" + a + ");\n"; break;
+		case OP_TRUNC: body += d + "(__builtin_fabsf(" + a + ") < 2147483648.f) ? __builtin_truncf(" + a + ") + 0.f : -2147483648.f;\n"; break;   // (float)(int)x as cvttss2si has it (+ 0.f: an int has no negative zero)
 		case OP_POWC: {                                                    // klang.h:188-218 with a literal float exponent: the test for base 10 first, then the written-out products
 			float e; memcpy(&e, &o.imm, 4);
 			const float ten = (float)exp((double)(e * 2.3025850929940456840179914546843642076011014886287729760333279009f));   // (the C library's exp, here on the host: the value the reference computes at run time)
@@ -423,7 +424,16 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		case OP_NEG: body += d + "-" + a + ";\n"; break;
 		// double registers (include/klang_mi355_graph.h): IEEE double arithmetic, contraction off like everything else
 		case OP_F2D: body += dd + "(double)" + a + ";\n"; break;
-		case OP_FUNC: body += dd + "glibc_tanh(" + a + ");\n"; break;                           // (imm 0: the one function there is)
+		case OP_FUNC:
+			if ((o.imm & 0xFFu) == 0u) body += dd + "glibc_tanh(" + a + ");\n";
+			else if ((o.imm & 0xFFu) == 1u) body += dd + "klg::glibc::exp2(" + a + ");\n";
+			else {                                                              // pow(B, a), B constant: log(B) = hi + lo from the host's restatement, as literals
+				const uint32_t bb = o.imm & 0xFFFFFF00u; float base; memcpy(&base, &bb, 4);
+				double lo; const double hi = klg::glibc::pow_log((double)base, &lo);
+				uint64_t ub, uh, ul; const double db = (double)base; memcpy(&ub, &db, 8); memcpy(&uh, &hi, 8); memcpy(&ul, &lo, 8);
+				body += dd + fmt("klg::glibc::pow_of_log(klg::glibc::as_f64(0x%016llxull), ", (unsigned long long)ub) + a + fmt(", klg::glibc::as_f64(0x%016llxull), klg::glibc::as_f64(0x%016llxull));\n", (unsigned long long)uh, (unsigned long long)ul);
+			}
+			break;
 		case OP_DCONST: body += dd + fmt("__longlong_as_double(0x%08x00000000ll);\n", o.imm); break;
 		case OP_DLOW: body += dd + "__longlong_as_double(__double_as_longlong(" + a + fmt(") | 0x%08xll);\n", o.imm); break;
 		case OP_DADD: body += dd + a + " + " + b + ";\n"; break;

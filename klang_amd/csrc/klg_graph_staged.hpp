@@ -77,7 +77,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			case OP_CTL: reg_inv[(size_t)o.dst] = in.ctlvar[o.imm & 0xFFu] < 0; break;
 			case OP_PARAM: reg_inv[(size_t)o.dst] = !written[(size_t)o.node]; break;
 			case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_CMP: case OP_DADD: case OP_DSUB: case OP_DMUL: case OP_DDIV: reg_inv[(size_t)o.dst] = depth == 0 && ri(o.a) && ri(o.b); break;
-			case OP_NEG: case OP_ABS: case OP_POWC: case OP_FUNC: case OP_F2D: case OP_D2F: case OP_DLOW: reg_inv[(size_t)o.dst] = depth == 0 && ri(o.a); break;
+			case OP_NEG: case OP_ABS: case OP_TRUNC: case OP_POWC: case OP_FUNC: case OP_F2D: case OP_D2F: case OP_DLOW: reg_inv[(size_t)o.dst] = depth == 0 && ri(o.a); break;
 			default: break;
 			}
 		}
@@ -168,7 +168,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		case OP_CTL: inv[(size_t)i] = in.ctlvar[v.imm & 0xFFu] < 0; break;
 		case OP_PARAM: inv[(size_t)i] = !written[(size_t)v.node]; break;
 		case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_CMP: case OP_DADD: case OP_DSUB: case OP_DMUL: case OP_DDIV: inv[(size_t)i] = v.path.empty() && opinv(v.a) && opinv(v.b); break;
-		case OP_NEG: case OP_ABS: case OP_POWC: case OP_FUNC: case OP_F2D: case OP_D2F: case OP_DLOW: inv[(size_t)i] = v.path.empty() && opinv(v.a); break;
+		case OP_NEG: case OP_ABS: case OP_TRUNC: case OP_POWC: case OP_FUNC: case OP_F2D: case OP_D2F: case OP_DLOW: inv[(size_t)i] = v.path.empty() && opinv(v.a); break;
 		case V_LPFQ: case V_LPFCOEF: inv[(size_t)i] = v.path.empty() && opinv(v.a) && opinv(v.b); break;   // (dials only: once per chunk by whoever needs them)
 		}
 	}
@@ -374,7 +374,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 							const VOp& v = V[(size_t)i];
 							switch (v.code) {
 							case OP_OSC: case V_OSCARG: case OP_OSCSET: case OP_LPF: case V_LPFAPPLY: case OP_ENV: case OP_OPERATOR: case OP_PARAM: case OP_SETPARAM: case OP_FREQ:
-							case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_NEG: case OP_ABS: case OP_POWC: case OP_FUNC: case OP_CMP: break;
+							case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_NEG: case OP_ABS: case OP_TRUNC: case OP_POWC: case OP_FUNC: case OP_CMP: break;
 							default: ok = false;
 							}
 							if (!v.path.empty()) ok = false;

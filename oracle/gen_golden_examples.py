@@ -108,10 +108,17 @@ def scenarios():
     # (added in round 5) Additive/Inheritance.k: on() points `Additive* osc` at one of three member oscillators by a Menu control, process() is `*osc >> out` — the body
     # depends on HOST state of the note: recorded per note after its events (-DKLANG_GPU_NOTE_VARIANTS).  The menu moves while notes start: three variants sound together
     out["ex_inheritance"] = poly("ex_inheritance", 32, [0, 1, 5, 9, 31], off_base=12, ctl=[(0, 0.0)], ctl_events=[(3, 0, 1.0), (6, 0, 2.0), (8, 0, 0.0), (9, 0, 2.0)])
+    # Subtractive/Modular.k (added last): twenty controls; a Menu picks the filter through a host `int` (`switch (filter)` in FLT::process(): -DKLANG_GPU_NOTE_VARIANTS), data-dependent
+    # branches on params and on the signal (the Distortion's clipper), `pow(10, x)` / `pow(2, x)` — the C library's DOUBLE pow / exp2 (klg_glibc_pow.hpp) —, `min(20000, signal)` that
+    # returns an int.  The menu, the drive and the LFO / MOD amounts (either sign: both branches of their generators) move while notes start
+    out["ex_modular"] = poly("ex_modular", 32, [0, 1, 5, 9, 31], off_base=12,
+                             ctl=[(3, 0.4), (12, 0.0), (13, 3000.0), (14, 2.0), (15, 4.0), (16, 0.5), (17, -0.6), (18, 5.0), (19, 0.7), (4, 0.1), (7, 0.2), (8, 0.2)],
+                             ctl_events=[(3, 12, 1.0), (6, 12, 2.0), (8, 16, -0.4), (9, 17, 0.5), (10, 15, 1.0), (11, 12, 0.0), (14, 13, 800.0)])
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],
-                "ex_operators": [(0, 1.0), (1, 0.5), (2, 1.0), (3, 4.296), (4, 2.0)], "own_early_return": [(0, 0.9)], "own_smooth_note": [(0, 2500.0), (1, 0.5)], "ex_inheritance": [(0, 2.0)]}
+                "ex_operators": [(0, 1.0), (1, 0.5), (2, 1.0), (3, 4.296), (4, 2.0)], "own_early_return": [(0, 0.9)], "own_smooth_note": [(0, 2500.0), (1, 0.5)], "ex_inheritance": [(0, 2.0)],
+                "ex_modular": [(3, 0.3), (12, 2.0), (13, 1500.0), (14, 4.0), (15, 8.0), (16, -0.7), (17, 0.8), (18, 3.0), (19, 0.5), (4, 0.05), (7, 0.1)]}
     for name in list(out):
         src = out[name]
         s = Scenario(patch=src.patch, block=256, blocks=24, synths=1, notes=src.notes, dump=[0, 23])

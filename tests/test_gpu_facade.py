@@ -86,7 +86,8 @@ def test_shipped_k_files_recorded_as_graph(binary, scenario, tmp_path):
 
 @pytest.mark.parametrize("name", ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter", "ex_expression",
                                   "ex_addsaw", "ex_am", "ex_fmmod", "ex_fm2", "ex_operators", "ex_nyquist", "ex_square", "ex_resynthesis",
-                                  "ex_inheritance"])      # (the last: process() depends on a pointer set in on() — recorded per note, -DKLANG_GPU_NOTE_VARIANTS; three variants sound together)
+                                  "ex_inheritance",       # (process() depends on a pointer set in on() — recorded per note, -DKLANG_GPU_NOTE_VARIANTS; three variants sound together)
+                                  "ex_modular"])          # (Subtractive/Modular.k: 20 controls, a host int picks the filter, branches on signals, the C library's double pow / exp2, min() returning an int)
 def test_example_synths_without_a_handwritten_kernel(name, tmp_path):
     """examples/Subtractive/{Breakpoint,Ramp,Release,Filter,Expression}.k of the reference, compiled unchanged: there is no kernel for
     them in the library, only the recorded graph.  Goldens: oracle/gen_golden_examples.py (genuine reference header)."""
@@ -107,7 +108,7 @@ def test_own_patches_for_the_other_node_kinds(name, tmp_path):
     check(*run_facade(path, name, tmp_path), name)
 
 
-SOLO = ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter", "ex_expression", "ex_addsaw", "ex_am", "ex_fmmod", "ex_fm2", "ex_operators", "ex_nyquist", "ex_square", "ex_resynthesis", "ex_inheritance",
+SOLO = ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter", "ex_expression", "ex_addsaw", "ex_am", "ex_fmmod", "ex_fm2", "ex_operators", "ex_nyquist", "ex_square", "ex_resynthesis", "ex_inheritance", "ex_modular",
         "own_basic_mix", "own_filters_f2", "own_modal_follow", "own_branches", "own_wavetable", "own_sample", "own_pluck", "own_pluck_keep", "own_early_return", "own_iirn", "own_noise_note", "own_smooth_note", "own_hardsync", "own_vibstring", "own_finish_body", "own_pwm"]
 
 
