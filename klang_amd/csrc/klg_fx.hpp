@@ -547,7 +547,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	const bool vibfast = S.vibfast != 0;
 	if (vibfast) { if (w_audio) sines(0); __syncthreads(); }                        // (chunk 1's are taken in step -1, chunk j + 2's in step j)
 	if (S.deep) {
-		moving = G <= 32 && S.deep == 2;
+		moving = G <= 32 && S.deep == 2 && !(KLG_PPX_VARIANT & 16);
 		// The control chain with moving dials, a chunk at a time.  One wave running all of it (the general loop: ~17 instructions a sample, each waiting for the one
 		// before: ~128 cycles a sample, 1.95 us a chunk) is slower than the memory pipeline it feeds (1.3 us a chunk), however far ahead it runs.  So it is cut where it
 		// only flows one way: the FIRST control wave smooths controls[5], runs the scratch detector and sets controls[1] (PingPong.k:47-56) and leaves controls[1] per sample
@@ -585,32 +585,33 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			if (KLG_PPX_ABLATE & 64) { for (int u = 0; u < PPX_CHUNK; u++) D[u][li] = sm1; return; }
 			const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);
 			float pos = lu >= 0 ? KLG_PI_F : lfo.position;                          // lfo.set(rate, pi)
-			float cv[PPX_CHUNK];                                                    // (all of the chunk's values requested at once: one round trip to LDS, not one a sample)
+			const bool plain = __ballot(lu >= 0 || !inc_ok) == 0ull && !(KLG_PPX_ABLATE & 32);   // no detection in the chunk, no LFO at a standstill: both recurrences side by side, nothing to test
+			int first = 0;                                                          // else the phase from the earliest "last detection" of the wave's instances on (while a scratch converges the detector fires every
+#pragma unroll                                                                  // other sample: the last two samples of the chunk), every instance from its own
+			for (int bit = PPX_CHUNK / 2; bit > 0; bit >>= 1) if (__ballot(lu < first + bit) == 0ull) first += bit;
+			for (int u0 = 0; u0 < PPX_CHUNK; u0 += 8) {
+				float cv[8];                                                        // (eight values requested at once: a round trip to LDS per eight samples, not one a sample)
 #pragma unroll
-			for (int u = 0; u < PPX_CHUNK; u++) cv[u] = (1.f - 0.999f) * C[u][li];
-			if (__ballot(lu >= 0 || !inc_ok) == 0ull && !(KLG_PPX_ABLATE & 32)) {   // no detection in the chunk, no LFO at a standstill: both recurrences side by side, nothing to test
+				for (int i = 0; i < 8; i++) cv[i] = (1.f - 0.999f) * C[u0 + i][li];
+				if (plain) {
 #pragma unroll
-				for (int u = 0; u < PPX_CHUNK; u++) {
-					sm1 = sm1 * 0.999f + cv[u];                                     // controls[1].smooth()
-					D[u][li] = sm1;
-					const float p1 = pos + lfo_inc;                                 // Phase::operator+= klang.h:1518-1525
-					pos = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
+					for (int i = 0; i < 8; i++) {
+						sm1 = sm1 * 0.999f + cv[i];                                 // controls[1].smooth()
+						D[u0 + i][li] = sm1;
+						const float p1 = pos + lfo_inc;                             // Phase::operator+= klang.h:1518-1525
+						pos = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
+					}
+				}
+				else {
+#pragma unroll
+					for (int i = 0; i < 8; i++) { sm1 = sm1 * 0.999f + cv[i]; D[u0 + i][li] = sm1; }
 				}
 			}
-			else {
-#pragma unroll
-				for (int u = 0; u < PPX_CHUNK; u++) { sm1 = sm1 * 0.999f + cv[u]; D[u][li] = sm1; }
-				// the phase: from the earliest "last detection" of the wave's instances on (while a scratch converges the detector fires every other sample: the last
-				// two samples of the chunk), every instance from its own
-				int first = 0;
-#pragma unroll
-				for (int bit = PPX_CHUNK / 2; bit > 0; bit >>= 1) if (__ballot(lu < first + bit) == 0ull) first += bit;
-				if (!(KLG_PPX_ABLATE & 32))
+			if (!plain && !(KLG_PPX_ABLATE & 32))
 				for (int u = first; u < PPX_CHUNK; u++) {
 					const float p1 = pos + lfo_inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
 					pos = (inc_ok && u >= lu) ? p2 : pos;
 				}
-			}
 			lfo.position = pos;
 		};
 		if (moving) {

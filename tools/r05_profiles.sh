@@ -28,3 +28,10 @@ for V in 1024 2048 4096; do for SP in 1 0; do KLG_SUB2A_SP=$SP python $R/tools/s
 python $R/tools/pmc_any.py klg_render_sub2a_sp $SQ1 $SQ2 FETCH_SIZE WRITE_SIZE -- python $R/tools/sub2a_bench.py 1024 > $O/pmc/pmc_sub2a_sp_1024.json 2>&1
 python $R/tools/pmc_any.py klg_rand_fill $SQ1 $SQ2 FETCH_SIZE WRITE_SIZE -- python $R/tools/noise_bench.py 16384 > $O/pmc/pmc_rand_fill_16384.json 2>&1
 ls -la $O $O/pmc
+# PingPong: the driver-shaped leg five times in one process (run-to-run spread), spans at rest and with converging smoothers, traffic of a 64-block span
+cd $R
+python tools/pingpong_leg_repeat.py 5 > $O/pingpong_leg_repeat.txt 2>/dev/null
+(FX_SPAN_BLOCKS=1,25,64,256 python tools/fx_span_bench.py 4096 pingpong; FX_SPAN_FRESH=2 FX_SPAN_BLOCKS=25 python tools/fx_span_bench.py 4096 pingpong; FX_SPAN_BLOCKS=64 python tools/fx_span_bench.py 8192 pingpong; FX_SPAN_FRESH=2 FX_SPAN_BLOCKS=25 python tools/fx_span_bench.py 8192 pingpong) 2>/dev/null | grep effect > $O/pingpong_spans.jsonl
+cd /tmp
+FX_SPAN_BLOCKS=64 python $R/tools/pmc_any.py klg_fx_pingpong_x FETCH_SIZE WRITE_SIZE -- python $R/tools/fx_span_bench.py 4096 pingpong > $O/pmc/pmc_pingpong_4096_spans64.json 2>&1
+ls -la $O $O/pmc
