@@ -24,6 +24,9 @@ def main():
                 prog, rec = recorded("pingpong_recorded"); bank = klang_amd.FxBank(prog, K, max_block=N, initial_record=rec, channels=2)
             else:
                 bank = klang_amd.FxBank(effect, K, max_block=N)
+            for spec in filter(None, os.environ.get("FX_SPAN_DIALS", "").split(",")):             # e.g. FX_SPAN_DIALS=2=0.5,3=0.5: vibrato on every instance
+                c, v = spec.split("=")
+                for k in range(K): bank.set_control(k, int(c), float(v))
             io = (torch.rand((B, K, 2, N), device="cuda") - 0.5) * (0.0 if os.environ.get("FX_SPAN_SILENCE") else 0.1)
             fresh = int(os.environ.get("FX_SPAN_FRESH", "0"))                                  # time the first `fresh` spans of a new bank: the smoothers still converging
             if fresh: bank.render_device(io.data_ptr(), min(B, 8), N, st)                     # (as bench.py's cfg-4 legs: eight untimed blocks — a new object's smoothers start from 0, a delay too near to run ahead)
