@@ -281,6 +281,7 @@ struct klg_synth {
 	bool lanes = false;           // SuperSaw banks that do not fill the chip: an oscillator pair — or one oscillator — per lane (klg_render_lanes.hpp); KLG_SUPERSAW_LANES=0 / 1 / 2 forces the choice
 	bool pairs = false; int pairs_p = 1;   // ... the pair form (2) and its sample slots per voice (KLG_SUPERSAW_PAIRS_P forces 1 / 2 / 4)
 	bool sp = false;              // ... the sample-parallel form (3; the default: klg_render_supersaw_sp.hpp)
+	int sp_vpw = 8;               // ... its voices per wave (8 / 4 / 2: by bank size, so that a SIMD has waves to switch between)
 	bool sub_sp = false; int grid_sp = 0;   // sub2a banks of up to KLG_SUB2A_SP_MAX_VOICES voices: one voice per wave, samples side by side (klg_render_sub2a_sp.hpp; KLG_SUB2A_SP=0 / 1 forces the choice)
 	int grid_lanes = 0;
 	// graph patches (klg_graph.hpp): the render kernels come from a hipRTC code object instead of this library
@@ -475,7 +476,10 @@ static klg_synth* synth_create_common(int device, int patch_id, const PatchInfo*
 		const char* pe = getenv("KLG_SUPERSAW_PAIRS_P");
 		s->pairs_p = pe ? atoi(pe) : (s->V <= 16384 ? 4 : 1);     // measured: 16,384 voices 58 / 49 / 49 us with 1 / 2 / 4 slots, 32,768 voices 77 / 82 / 87
 		if (s->pairs_p != 1 && s->pairs_p != 2 && s->pairs_p != 4) s->pairs_p = 1;
-		const int per_wg = s->sp ? (int)SP_VPWG : s->pairs ? 16 / s->pairs_p * WAVES : KLG_LANES_VOICES_PER_WG;
+		const char* ve = getenv("KLG_SUPERSAW_VPW");
+		s->sp_vpw = ve ? atoi(ve) : (s->V <= KLG_SP_VPW2_MAX_VOICES ? 2 : s->V <= KLG_SP_VPW4_MAX_VOICES ? 4 : 8);
+		if (s->sp_vpw != 2 && s->sp_vpw != 4) s->sp_vpw = 8;
+		const int per_wg = s->sp ? s->sp_vpw * WAVES : s->pairs ? 16 / s->pairs_p * WAVES : KLG_LANES_VOICES_PER_WG;
 		s->grid_lanes = std::min((s->V + per_wg - 1) / per_wg, (ok ? prop.multiProcessorCount : 256) * 8);
 	}
 	if (patch_id == KLG_PATCH_SUB2A) {
@@ -641,8 +645,11 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 	}
 	if (s->sp) {                                          // SuperSaw, samples side by side and the rare cases apart (small banks)
 		const dim3 g(render_grid(s)), b(WG);
-		if (pv) KLG_LAUNCH(klg_render_supersaw_sp<true>, g, b, render_lds_bytes(a.n), st, a);
-		else KLG_LAUNCH(klg_render_supersaw_sp<false>, g, b, render_lds_bytes(a.n), st, a);
+		const size_t lds = render_lds_bytes(a.n);
+		if (s->sp_vpw == 2) { if (pv) KLG_LAUNCH((klg_render_supersaw_sp<true, 2>), g, b, lds, st, a); else KLG_LAUNCH((klg_render_supersaw_sp<false, 2>), g, b, lds, st, a); }
+		else if (s->sp_vpw == 4) { if (pv) KLG_LAUNCH((klg_render_supersaw_sp<true, 4>), g, b, lds, st, a); else KLG_LAUNCH((klg_render_supersaw_sp<false, 4>), g, b, lds, st, a); }
+		else if (pv) KLG_LAUNCH((klg_render_supersaw_sp<true, 8>), g, b, lds, st, a);
+		else KLG_LAUNCH((klg_render_supersaw_sp<false, 8>), g, b, lds, st, a);
 		return;
 	}
 	if (s->pairs) {                                       // SuperSaw, an oscillator pair per lane (KLG_SUPERSAW_LANES=2)

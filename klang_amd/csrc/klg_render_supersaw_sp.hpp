@@ -24,35 +24,44 @@
 
 namespace klg {
 
-enum { SP_VPW = 8, SP_VPWG = SP_VPW * WAVES, SP_ROW = 40 };                  // voices per wave / workgroup; float4 slots per voice row of X (32 + 8: the two voices of a quarter-wave land on different banks)
+enum { SP_VPW = 8, SP_VPWG = SP_VPW * WAVES, SP_ROW = 40 };                  // voices per wave / workgroup (the default form; VPW = 4 / 2: banks that would otherwise leave SIMDs with one or two waves); float4 slots per voice row of X (32 + 8: the two voices of a quarter-wave land on different banks)
 
-template<bool PER_VOICE>
+#ifndef KLG_SP_VPW4_MAX_VOICES
+// Voices per wave: 8 is the default at every size.  4 / 2 (KLG_SUPERSAW_VPW; bit-identical) give a small bank more, shorter waves — but pass 2's walk costs a wave the same whatever
+// it carries, so the work per voice doubles with each halving: 16,384 voices 26.3 / 40.2 / 60.5 us per block with 8 / 4 / 2, 262,144: 0.27 / 0.42 / 0.74 ms; below ~8,192 voices
+// the kernel's time on a mostly idle device moves more from run to run than between the forms (2,048 voices: 37 / 49 / 19 us, 4,096: 51 / 20 / 22): no size is given to them.
+#define KLG_SP_VPW4_MAX_VOICES 0          // banks up to this size: four voices per wave; up to KLG_SP_VPW2_MAX_VOICES: two
+#define KLG_SP_VPW2_MAX_VOICES 0
+#endif
+template<bool PER_VOICE, int VPW = SP_VPW>
 __global__ __launch_bounds__(WG) void klg_render_supersaw_sp(const RenderArgs a) {
+	static_assert(VPW == 8 || VPW == 4 || VPW == 2, "voices per wave");
+	constexpr int SLOTS = 64 / VPW, ITERS = CHUNK / SLOTS, VPWG = VPW * WAVES, OLANES = 7 * VPW;   // sample slots side by side per voice; iterations per chunk; voices per workgroup; oscillator lanes of pass 2
 	using Rec = rec::SuperSaw;
 	constexpr int O0 = offsetof(Rec, osc) / 4, A0 = offsetof(Rec, adsr) / 4;
 	typedef float f4 __attribute__((ext_vector_type(4)));
-	__shared__ f4 xa_all[WAVES][SP_VPW * SP_ROW], xb_all[WAVES][SP_VPW * SP_ROW];     // X[voice][sample]: oscillators 0-3, 4-6
-	__shared__ uint32_t bits_all[WAVES][SP_VPW];
+	__shared__ f4 xa_all[WAVES][VPW * SP_ROW], xb_all[WAVES][VPW * SP_ROW];     // X[voice][sample]: oscillators 0-3, 4-6
+	__shared__ uint32_t bits_all[WAVES][VPW];
 	__shared__ int lds_flag;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	f4* const XA = xa_all[wave]; f4* const XB = xb_all[wave]; uint32_t* const SB = bits_all[wave];
-	const int vi = lane >> 3, j = lane & 7;                                     // passes 1 and 3
-	const int ev = lane < 56 ? lane / 7 : 0, ek = lane < 56 ? lane % 7 : 0;     // pass 2: the oscillator lanes
+	const int vi = lane / SLOTS, j = lane % SLOTS;                              // passes 1 and 3
+	const int ev = lane < OLANES ? lane / 7 : 0, ek = lane < OLANES ? lane % 7 : 0;   // pass 2: the oscillator lanes
 	const int n = a.n;
 	float* acc = klg_mix_rows + wave * n;                                       // this wave's own mix row
 	for (int i = lane; i < n; i += 64) acc[i] = 0.f;
 	wave_sync();
-	fused_events<PatchSuperSaw>(a, SP_VPWG);
+	fused_events<PatchSuperSaw>(a, VPWG);
 
-	const int groups = (a.voices + SP_VPWG - 1) / SP_VPWG;
+	const int groups = (a.voices + VPWG - 1) / VPWG;
 	for (int g = blockIdx.x; g < groups; g += gridDim.x) {
-		const int v0 = g * SP_VPWG + wave * SP_VPW, v = v0 + vi;
+		const int v0 = g * VPWG + wave * VPW, v = v0 + vi;
 		const uint32_t flags = (v < a.voices) ? a.state[v] : (uint32_t)ST_OFF;
 		const bool live = (flags & 3u) != (uint32_t)ST_OFF;
 		const bool audible = live && (!a.solo || a.solo[v / a.notes_per_synth] == v);   // KLG_MIX_LAST_ACTIVE (see klg_render)
 		const bool heard = PER_VOICE ? live : audible;
 		if (__ballot(live) == 0ull) {
-			if (PER_VOICE) for (int q = 0; q < SP_VPW && v0 + q < a.voices; q++) for (int i = lane; i < n; i += 64) a.per_voice[(size_t)(v0 + q) * n + i] = 0.f;
+			if (PER_VOICE) for (int q = 0; q < VPW && v0 + q < a.voices; q++) for (int i = lane; i < n; i += 64) a.per_voice[(size_t)(v0 + q) * n + i] = 0.f;
 			continue;
 		}
 		// ---- pass 1's view: the seven oscillators of voice vi, at sample slot j ----
@@ -70,9 +79,9 @@ __global__ __launch_bounds__(WG) void klg_render_supersaw_sp(const RenderArgs a)
 		const float col = fast_phase_float(duty), c1 = 1.f / col, c2 = -1.f / (1.0f - col);   // OSM::init 5206-5215
 		// ---- pass 2's view: oscillator ek of voice ev ----
 		const int evv = v0 + ev;
-		const uint32_t eflags = __shfl(flags, ev * 8);
-		const bool elive = lane < 56 && (eflags & 3u) != (uint32_t)ST_OFF;
-		const int efits = __shfl((int)fits, ev * 8);                                // (every lane takes part in the exchange: not under `elive &&`)
+		const uint32_t eflags = __shfl(flags, ev * SLOTS);
+		const bool elive = lane < OLANES && (eflags & 3u) != (uint32_t)ST_OFF;
+		const int efits = __shfl((int)fits, ev * SLOTS);                                // (every lane takes part in the exchange: not under `elive &&`)
 		const bool eall = elive && !efits;                                         // every sample of this oscillator is redone with its own coefficients
 		Osm eo;
 		{
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(WG) void klg_render_supersaw_sp(const RenderArgs a)
 			const int cl = (n - c0 < CHUNK) ? (n - c0) : CHUNK;
 			// ---- pass 1: the linear values ----
 #pragma unroll
-			for (int it = 0; it < 4; it++) {
+			for (int it = 0; it < ITERS; it++) {
 				float x[8];
 #pragma unroll
 				for (int k = 0; k < 8; k += 2) {                                       // oscillator pairs (0,1) (2,3) (4,5) and 6 with a copy of itself
@@ -117,8 +126,8 @@ __global__ __launch_bounds__(WG) void klg_render_supersaw_sp(const RenderArgs a)
 					x[k] = q.x; x[k + 1] = q.y;
 				}
 #pragma unroll
-				for (int k = 0; k < 7; k++) off[k] += inc[k] * 8u;
-				const int s = it * 8 + j;
+				for (int k = 0; k < 7; k++) off[k] += inc[k] * (uint32_t)SLOTS;
+				const int s = it * SLOTS + j;
 				f4 qa = { x[0], x[1], x[2], x[3] }, qb = { x[4], x[5], x[6], 0.f };
 				XA[vi * SP_ROW + s] = qa; XB[vi * SP_ROW + s] = qb;
 			}
@@ -166,16 +175,16 @@ __global__ __launch_bounds__(WG) void klg_render_supersaw_sp(const RenderArgs a)
 			auto pass3 = [&](auto glide_c, auto full_c) {                            // (compile-time forms: the loop a whole chunk runs has no test inside it)
 				constexpr bool GLIDE = decltype(glide_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
-				for (int it = 0; it < 4; it++) {
+				for (int it = 0; it < ITERS; it++) {
 					float env = 0.f;
 #pragma unroll
-					for (int q = 0; q < 8; q++) if (FULL || it * 8 + q < cl) {            // (cl is the same for the whole wave)
+					for (int q = 0; q < SLOTS; q++) if (FULL || it * SLOTS + q < cl) {            // (cl is the same for the whole wave)
 						float e;
 						if (GLIDE) e = env_glide(adsr.e, step, tstep);
 						else { e = adsr_process(adsr, a.fs); stage = (adsr.e.stage == ENV_OFF) ? (int)ST_OFF : stage; }
 						env = (j == q) ? e : env;
 					}
-					const int s = it * 8 + j;
+					const int s = it * SLOTS + j;
 					const f4 qa = XA[vi * SP_ROW + s], qb = XB[vi * SP_ROW + s];
 					float sum = 0.f + qa.x; sum += qa.y; sum += qa.z; sum += qa.w; sum += qb.x; sum += qb.y; sum += qb.z;   // out = 0; out += osc[s] / 7 ...   SuperSaw.k:27-29
 					const float y = (heard && (FULL || s < cl)) ? sum * env : 0.f;                    // out *= adsr++   SuperSaw.k:31
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(WG) void klg_render_supersaw_sp(const RenderArgs a)
 			if (lane < cl) {                                                            // the wave's eight voices, a fixed order, into the wave's own mix row (program order, no atomics)
 				float t = 0.f;
 #pragma unroll
-				for (int q = 0; q < SP_VPW; q++) t += reinterpret_cast<const float*>(XA + q * SP_ROW + lane)[0];
+				for (int q = 0; q < VPW; q++) t += reinterpret_cast<const float*>(XA + q * SP_ROW + lane)[0];
 				acc[c0 + lane] += t;
 			}
 			wave_sync();
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(WG) void klg_render_supersaw_sp(const RenderArgs a)
 		// ---- write back: every oscillator lane its phase and state bits, slot 0 of a voice the envelope and the flags ----
 		// the phase after n samples; OSM state = the last two samples' "offset < duty" (tick 5251-5263): one and two increments behind it
 		// (after a single sample the older one is what the block started with)
-		if (lane < 8) SB[lane] = 0u;
+		if (lane < VPW) SB[lane] = 0u;
 		wave_sync();
 		if (elive) {
 			const uint32_t fin = eoff0 + einc * (uint32_t)n;

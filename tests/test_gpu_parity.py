@@ -157,7 +157,7 @@ def test_every_sub2a_kernel_matches(name, kernel, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["supersaw_ctl", "supersaw_poly"])
-@pytest.mark.parametrize("lanes", ["0", "1", "2:1", "2:2", "2:4", "3"])
+@pytest.mark.parametrize("lanes", ["0", "1", "2:1", "2:2", "2:4", "3", "3/4", "3/2"])      # ("3/4", "3/2": the sample-parallel kernel with four / two voices per wave, KLG_SUPERSAW_VPW)
 def test_all_supersaw_kernels_match(name, lanes, monkeypatch):
     """SuperSaw banks of up to 131,072 voices run the oscillator-pair-per-lane kernel (klg_render_lanes.hpp; 1: its one-oscillator-per-lane
     predecessor), larger ones the voice-per-lane kernel; KLG_SUPERSAW_LANES forces the choice, KLG_SUPERSAW_PAIRS_P the pair kernel's
@@ -167,6 +167,8 @@ def test_all_supersaw_kernels_match(name, lanes, monkeypatch):
     monkeypatch.setenv("KLG_SUPERSAW_LANES", lanes[0])
     if ":" in lanes:
         monkeypatch.setenv("KLG_SUPERSAW_PAIRS_P", lanes[2])              # sample slots per voice of the pair kernel
+    if "/" in lanes:
+        monkeypatch.setenv("KLG_SUPERSAW_VPW", lanes[2])
     s = Scenario.load(os.path.join(GOLDEN, name + ".scn"))
     ref = np.load(os.path.join(GOLDEN, name + ".npz"))
     got = run_scenario_gpu(s)
