@@ -700,7 +700,7 @@ static void launch_events(klg_synth* s, const EventArgs& a, hipStream_t st) {
 // events: host queue -> one staged H2D copy -> klg_apply_events
 // ------------------------------------------------------------------------------------------------
 // stages the queued events on the device and fills `a`; launches klg_apply_events unless the caller takes the run list into the render launch (`fused`)
-enum { KLG_FUSE_MAX_ROWS = 128, KLG_FUSE_MAX_RUNS = 2048 };     // one launch per block: partial rows the last workgroup still adds up quickly; event runs every workgroup can scan
+enum { KLG_FUSE_MAX_ROWS = 128, KLG_FUSE_MAX_RUNS = 2048 };     // one launch per block: partial rows the last workgroup still adds up quickly (32 loads under way at a time: ~1.1 us per 32 rows; with 256 rows the separate klg_reduce launch is faster: sub2a at 1,024 voices 19.8 against 13.5 us per block); event runs every workgroup can scan
 static int flush_events(klg_synth* s, hipStream_t st, EventArgs* fused = nullptr) {
 	if (fused) fused->runs = 0;
 	if (s->events.empty()) return 0;

@@ -147,8 +147,25 @@ __device__ __forceinline__ void fused_combine(const RenderArgs& a, int n, int nc
 	if (!*lds_flag) return;
 	const int rows = (int)gridDim.x, len = n * nc;
 	for (int i = threadIdx.x; i < len; i += blockDim.x) {
+		// (the rows were written on other XCDs: behind the acquire every load is a trip to memory.  Thirty-two under way at a time, added in row order — one at a
+		//  time it was ~0.23 us a row: a SuperSaw bank of 4,096 voices, 128 rows, 51 us per block against 20 for its render alone)
 		float t = 0.f;
-		for (int r = 0; r < rows; r++) t += a.partials[(size_t)r * len + i];
+		int r = 0;
+		for (; r + 32 <= rows; r += 32) {
+			float x[32];
+#pragma unroll
+			for (int q = 0; q < 32; q++) x[q] = a.partials[(size_t)(r + q) * len + i];
+#pragma unroll
+			for (int q = 0; q < 32; q++) t += x[q];
+		}
+		for (; r + 8 <= rows; r += 8) {
+			float x[8];
+#pragma unroll
+			for (int q = 0; q < 8; q++) x[q] = a.partials[(size_t)(r + q) * len + i];
+#pragma unroll
+			for (int q = 0; q < 8; q++) t += x[q];
+		}
+		for (; r < rows; r++) t += a.partials[(size_t)r * len + i];
 		if (nc == 2) { if (i / n < a.mix_channels) a.mix[i] += t; }                                      // stereo notes: rows are [2][n], left to left, right to right
 		else for (int c = 0; c < a.mix_channels; c++) a.mix[(size_t)c * n + i] += t;              // a mono `out` goes to every channel (klg_reduce)
 	}
