@@ -19,6 +19,9 @@
 #include <vector>
 
 #include PATCH_FILE
+#ifdef KLANG_GPU_TRACE_FLOAT
+#undef float                 // (include/klang/klang.h: the patch's own text was compiled with `float` = the tracing signal)
+#endif
 #ifdef KLANG_MI355
 HOST_BIND_LINE
 #endif

@@ -73,7 +73,8 @@ def test_effect_host_reproduces_the_effect_bank_fixture(tmp_path, how, monkeypat
 
 
 @pytest.mark.parametrize("binary,scn,how", [("facade_host_fx_topreverb", "fx_topreverb", "kernel"), ("facade_host_fx_topreverb", "fx_topreverb", "recorded"),
-                                            ("facade_host_fx_dpingpong", "fx_dpingpong", "recorded"), ("facade_host_fx_echo", "fx_echo", "recorded")])
+                                            ("facade_host_fx_dpingpong", "fx_dpingpong", "recorded"), ("facade_host_fx_echo", "fx_echo", "recorded"),
+                                            ("facade_host_fx_vocoder", "fx_vocoder", "recorded")])      # (27 controls set every block, 22 of them meters process() feeds; prepare() host code on the host's own object)
 def test_effect_process_buffer_on_a_host_constructed_object(binary, scn, how, tmp_path, monkeypatch):
     """Reverb.k (tied to its kernel, and RECORDED: KLANG_MI355_FORCE_GRAPH — its prepare() is host code and runs on the host's own object, which
     is the one instance's mirror: gpu::FxRunner::host_prepare), Delay/PingPong.k (Stereo::Effect) and Delay/Echo.k (mono klang::Effect): recorded
