@@ -42,7 +42,7 @@ SCRIPT_BLOCKS, OFF_BLOCK, OFF_SPREAD = 375, 150, 64        # SURVEY §8(d) cfg 2
 # blocks a voice still sounds after its note-off: ceil(release time * 48000 / 256) — sub2a 0.25 s + 5 ms = 12240 samples, SuperSaw.k 0.5 s + 5 ms, FM 1 s + 5 ms
 RELEASE_BLOCKS = {"sub2a": 48, "supersaw": 95, "fm3": 189, "fm4": 189}
 KERNEL_OF = {"sub2a": "klg_render_sub2a_x2", "supersaw": "klg_render_supersaw_sp", "fm4": "klg_render<klg::PatchFM<4>", "fm3": "klg_render<klg::PatchFM<3>",
-             "pingpong": "klg_fx_pingpong_x", "reverb": "klg_fx_reverb16"}
+             "pingpong": "klg_fx_pingpong_x", "reverb": "klg_fx_reverb_q"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -445,7 +445,7 @@ def run_fx(patch, K, N, dials=None, tag="", args=None, per_block=False):
     kern_s = 1e-3 * (head_ms + rest_ms) / SCRIPT_BLOCKS                     # per BLOCK (a PingPong span is one launch, a Reverb block one or two)
     rest_s = 1e-3 * rest_ms / (SCRIPT_BLOCKS - head)
     ab = K * N * FX_BYTES_PER_SAMPLE[patch]
-    kernel = ("klg_fx_reverb_q" if patch == "reverb" and K <= 8192 else KERNEL_OF[patch])
+    kernel = KERNEL_OF[patch]
     traffic, how = None, "not collected"
     spec = f"{patch}:{K}:" + ("random7" if dials == "random7" else ",".join(f"{c}={v}" for c, v in (dials or {}).items()))
     one_launch = patch == "pingpong"

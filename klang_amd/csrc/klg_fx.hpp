@@ -1009,7 +1009,7 @@ struct ReverbArgs {
 	int epos;                   // early write cursor at block start
 	int fpos;                   // FilteredDelay write cursor at block start (advances 2 per sample)
 	float* io; int n;
-	int layout;                 // 0: rings tiled per 64 instances, position-major rows (klg_fx_reverb16); 1: every (instance, line) its own contiguous ring (klg_fx_reverb_q)
+	int layout;                 // 1: every (instance, line) its own contiguous ring (klg_fx_reverb_q; the one layout since round 5).  0 — rings tiled per 64 instances, position-major rows — was klg_fx_reverb16's; klg_fx_reverb still reads both
 	float* early_sums;          // layout 1: [kpad][2][n] the block's early-reflection sums (klg_fx_reverb_early writes them, klg_fx_reverb_q<true> reads them), else null
 };
 
@@ -1132,243 +1132,9 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_reverb(const ReverbArgs a) {
 }
 
 // =================================================================================================
-// Reverb.k, sixteen waves per 64 instances
-// =================================================================================================
-// klg_fx_reverb above walks the whole per-sample graph of an instance in ONE lane: ~2000 dependent instructions and
-// 144 ring reads per sample with a single wave per CU to hide them.  The graph has far more parallelism than that:
-//   * the 16 FilteredDelays only meet in the 4x4 feedback matrix of their LateReflections and in the output sum;
-//   * the delay lines are read >= 150 samples behind their write cursors, so no ring value read in a block segment
-//     depends on anything computed in it: every tap address is known ahead of time;
-//   * the 40 (tap, channel) products of the early reflections are independent; only their SUM is ordered.
-// This kernel gives the same 64 instances (lane = instance, as before) to a workgroup of SIXTEEN waves:
-//   wave w  = FilteredDelay w   (LateReflections a = w / 4: mid[0], mid[1], late[0], late[1]; line k = w % 4)
-//           + the early-reflection products of channel w / 8 for taps (w % 8), +8, +16
-//   three per-channel extras are spread over the four SIMDs (wave w runs on SIMD w % 4): waves 1 / 11 run the early
-//   LPF >> HPF of the left / right channel and write the early rings, waves 2 / 8 sum the forty early products, waves
-//   3 / 13 produce the left / right output sample.
-// The three stages run skewed so that every wave has work between the same two barriers: in iteration t the early
-// stage handles sample t+2, mid[] handles t+1, late[] handles t, the output sample t-1.  Values cross waves through
-// LDS (double-buffered by sample slot); there is no cross-lane traffic at all.  Each wave prefetches the ring rows of
-// its next sample into registers, so HBM latency is hidden behind the other three waves of its SIMD.
-// Arithmetic, operand order and summation order are exactly those of klg_fx_reverb / the reference; the two kernels
-// are compared bit for bit in tests/test_gpu_fx.py (KLG_FX_REVERB1=1 selects the single-wave kernel).
-enum { RV16_WAVES = 16, RV16_THREADS = 1024, RV16_SLOTS = 4 };
-
-struct Rv16Lds {
-	float tile[2][2][FX_CHUNK][FX_LD];          // [buffer][channel][sample][instance]  in-place io staging
-	float P[2][40][64];                         // early products  [slot e&1][ch*20 + d][instance]
-	float R1[RV16_SLOTS][2][64];                // early reflections  r1[ch]
-	float DL[16][64];                           // FilteredDelay outputs of the first process() (feedback-matrix input)
-	float OM[RV16_SLOTS][8][64];                // second-process outputs of mid[0], mid[1]
-	float OL[RV16_SLOTS][8][64];                // second-process outputs of late[0], late[1]
-	float CF[15][64];                           // per-instance constants only two waves per channel need: early LPF / HPF coefficients, dry/c1/c2/c3/wet
-};
-
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every ring-row
-// prefetch and ring store in flight twice per sample; the rings need no cross-wave ordering inside a block (a row written at
-// sample e is next read `time` >= 45 ms later, and only after the writer's in-order vmcnt has retired the store).
-__device__ __forceinline__ void wg_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ int ring_next(int i, int size) { return (i + 1 == size) ? 0 : i + 1; }
-
-__global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs a) {
-	__shared__ Rv16Lds S;
-	const int tid = threadIdx.x, lane = tid & 63;
-	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: every role test below is a scalar branch
-	const int k0 = blockIdx.x * FX_WG, k = k0 + lane;
-	const size_t KP = a.kpad;
-	const float* W = a.state + k;
-#define RVW(w) W[(size_t)(w) * KP]
-	const int n = a.n;
-	// ring rows are addressed as (wave-uniform base pointer) + (32-bit per-lane byte offset): one VGPR per address
-	struct URing {
-		float* base; unsigned lane4;
-		__device__ __forceinline__ float rd(int i) const { return *(const float*)((const char*)base + ((unsigned)i * (FX_WG * 4u) + lane4)); }
-		__device__ __forceinline__ void wr(int i, float v) const { *(float*)((char*)base + ((unsigned)i * (FX_WG * 4u) + lane4)) = v; }
-	};
-	// ---- this wave's FilteredDelay ----
-	const int fd = wv, lr = wv >> 2, kk = wv & 3;
-	const int fw = RV_FD + fd * FD_WORDS;
-	Biquad ff = { RVW(fw + FD_COEF + 0), RVW(fw + FD_COEF + 1), RVW(fw + FD_COEF + 2), RVW(fw + FD_COEF + 3), RVW(fw + FD_COEF + 4), RVW(fw + FD_Z0), RVW(fw + FD_Z1) };
-	float fin = RVW(fw + FD_IN);
-	const float fgain = RVW(fw + FD_GAIN), ffrac = RVW(fw + FD_LASTF);
-	const int flast = __float_as_int(RVW(fw + FD_LASTP));
-	const URing fring = { a.fd_rings + ((size_t)blockIdx.x * 16 + fd) * RV_FSIZE * FX_WG, (unsigned)lane * 4u };
-	// ---- this wave's share of the early reflections ----
-	const int ech = wv >> 3, ej = wv & 7;
-	const int ecount = __float_as_int(RVW(RV_ECOUNT));
-	float etime[3], egain[3]; bool eload[3];    // eload[q]: some instance of this wave has tap d (wave-uniform: its loads are never lane-predicated)
-#pragma unroll
-	for (int q = 0; q < 3; q++) {
-		const int d = ej + 8 * q;
-		const bool has = d < 20 && d < ecount;
-		eload[q] = __ballot(has) != 0ull;
-		etime[q] = has ? RVW(RV_ETIMES + d) : 0.f;                                  // an instance without the tap reads a valid row and its product is never summed
-		egain[q] = has ? RVW((ech ? RV_EGR : RV_EGL) + d) : 0.f;
-	}
-	const URing ering = { a.early_rings + ((size_t)blockIdx.x * 2 + ech) * RV_ESIZE * FX_WG, (unsigned)lane * 4u };
-	// the three per-channel extras are spread over the four SIMDs (wave w runs on SIMD w % 4): filter L/R on waves 1 / 11,
-	// sum on 2 / 8, output on 3 / 13
-	const bool efilter = wv == 1 || wv == 11;   // in >> lpf >> hpf >> delay for channel ech
-	float elz0 = RVW(RV_EZ + 2 * ech), elz1 = RVW(RV_EZ + 2 * ech + 1), ehz0 = RVW(RV_EZ + 4 + 2 * ech), ehz1 = RVW(RV_EZ + 4 + 2 * ech + 1);
-	const bool outwave = wv == 3 || wv == 13;   // output of channel ech
-	const bool sumwave = wv == 2 || wv == 8;    // sum of the early products of channel ech
-	if (wv < 15) S.CF[wv][lane] = RVW(wv < 5 ? RV_ELPF + wv : wv < 10 ? RV_EHPF + (wv - 5) : RV_CTL + (wv - 10));
-	__syncthreads();
-
-	// ---- prefetch registers: two sets, used alternately by even / odd iterations (the loop is unrolled by two so that
-	// a set is loaded at the TOP of the iteration before the one that consumes it: a whole iteration hides the latency) ----
-	struct Pre { float fr1, fr2, ea[3], eb[3], ef[3]; };
-	Pre A, B;
-	float fr0;                                  // ring row `last` of the FilteredDelay's current sample ( = row last+2 of the previous one)
-	// rows are fetched by byte offset (row * 256 + lane * 4), advanced by two rows per sample with one compare-and-wrap each
-	const unsigned FROW = FX_WG * 4u, FEND = (unsigned)RV_FSIZE * FROW;
-	auto frow = [&](unsigned off) { return *(const float*)((const char*)fring.base + off); };
-	auto fwrap = [&](unsigned off) { return off >= FEND ? off - FEND : off; };
-	unsigned foff = (unsigned)flast * FROW + fring.lane4;       // byte offset of row `last` of this wave's current sample
-	auto fd_rows = [&](unsigned off, Pre& X) { const unsigned o1 = fwrap(off + FROW), o2 = fwrap(o1 + FROW); X.fr1 = frow(o1); X.fr2 = frow(o2); };
-	fr0 = frow(foff); fd_rows(foff, A);
-	auto early_taps = [&](int wpos, Pre& X) {   // Stereo::Delay::tap(float) klang.h:4668-4681; wpos = write cursor of the sample
-		const int pos = ring_next(wpos, RV_ESIZE);                                   // cursor after Delay::input()
-#pragma unroll
-		for (int q = 0; q < 3; q++) {
-			float read = (float)(pos - 1) - etime[q];
-			if (read < 0.f) read += RV_ESIZE;
-			X.ef[q] = read - (float)floor((double)read);
-			int i = (int)read, j = (i == RV_ESIZE - 1) ? 0 : (i + 1);
-			const bool pad = i == RV_ESIZE;                                           // (read rounded up to SIZE: stereo_delay_tap — the tap is 0; a wave-uniform, almost never taken branch.
-			if (__ballot(pad) != 0ull) { i = pad ? 0 : i; j = pad ? 0 : j; }          //  Selects on the loaded values instead were measured: 0.76 against 0.50 ms at 16,384 instances — they end the prefetch)
-			if (eload[q]) { X.ea[q] = ering.rd(i); X.eb[q] = ering.rd(j); }
-			if (__ballot(pad) != 0ull) { if (pad) { X.ea[q] = 0.f; X.eb[q] = 0.f; } }
-		}
-	};
-	int ewpos = a.epos % RV_ESIZE;              // early write cursor of sample e (advanced once per iteration)
-	A.ea[0] = A.ea[1] = A.ea[2] = A.eb[0] = A.eb[1] = A.eb[2] = 0.f;
-	early_taps(ewpos, A);
-	B = A;
-	int fwpos = a.fpos % RV_FSIZE;              // FilteredDelay write cursor of this wave's sample (two inputs per sample)
-
-	auto load_chunk = [&](int c) {              // all 1024 threads: 128 (instance, channel) rows x <= 32 samples
-		const int s0 = c * FX_CHUNK, cl = (n - s0 < FX_CHUNK) ? (n - s0) : FX_CHUNK, col = tid & 31;
-		const char* src = (const char*)(a.io + (size_t)k0 * 2 * n + s0);
-#pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const int row = (tid >> 5) + 32 * j, inst = row >> 1, ch = row & 1;
-			S.tile[c & 1][ch][col][inst] = (col < cl && k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * n + col) * 4u) : 0.f;
-		}
-	};
-	auto store_chunk = [&](int c) {
-		const int s0 = c * FX_CHUNK, cl = (n - s0 < FX_CHUNK) ? (n - s0) : FX_CHUNK, col = tid & 31;
-#pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const int row = (tid >> 5) + 32 * j, inst = row >> 1, ch = row & 1;
-			if (col < cl && k0 + inst < a.K) *(float*)((char*)(a.io + (size_t)k0 * 2 * n + s0) + (unsigned)(row * n + col) * 4u) = S.tile[c & 1][ch][col][inst];
-		}
-	};
-	float lr_in = 0.f;                          // input of this wave's LateReflections for the sample in flight
-	// One iteration.  G = guarded: the ramp-up / ramp-down iterations test which stages are active; the steady-state
-	// iterations (1 <= t <= n-4: every stage active and a next sample to prefetch) run the same code with no guards, so the
-	// compiler's vmcnt bookkeeping stays exact and nothing waits for a load younger than one iteration.
-	auto step = [&](auto guarded, const int t, const Pre& C, Pre& N) {   // C: rows of this iteration's samples; N: loaded here for the next iteration
-		constexpr bool G = decltype(guarded)::value;
-		const int e = t + 2, m = t + 1, l = t, o = t - 1;
-		const int s_fd = (lr < 2) ? m : l;                                          // the sample this wave's FilteredDelay works on
-		const bool fd_on = !G || (s_fd >= 0 && s_fd < n);
-		const bool e_on = !G || e < n, o_on = !G || (o >= 0 && o < n);
-		if (!G || (fd_on && s_fd + 1 < n)) fd_rows(fwrap(fwrap(foff + FROW) + FROW), N);
-		if (!G || e + 1 < n) early_taps(ring_next(ewpos, RV_ESIZE), N);
-		// the early taps of sample e are consumed first: after this point nothing in the iteration depends on a load in flight
-		float prod[3];
-#pragma unroll
-		for (int q = 0; q < 3; q++) prod[q] = (C.ea[q] * (1.f - C.ef[q]) + C.eb[q] * C.ef[q]) * egain[q];   // delay(times[d]) * gains[d]
-		float r0 = fr0, r1v = C.fr1, r2v = C.fr2;
-		const float fdt1 = r0 + ffrac * (r1v - r0), fdt2 = r1v + ffrac * (r2v - r1v);    // the two delay reads of this sample (Delay::operator>> klang.h:3491-3500)
-		if (e_on && (e & (FX_CHUNK - 1)) == 0) { load_chunk(e >> 5); wg_sync_lds(); }
-		// ================= phase 1 =================
-		if (e_on) {                                                                // ---- early stage, sample e ----
-			if (efilter) {                                                         // EarlyReflections: in >> lpf >> hpf >> delay  Reverb.k:88
-				const float x = S.tile[(e >> 5) & 1][ech][e & 31][lane];
-				Biquad elpf = { S.CF[0][lane], S.CF[1][lane], S.CF[2][lane], S.CF[3][lane], S.CF[4][lane], elz0, elz1 };
-				Biquad ehpf = { S.CF[5][lane], S.CF[6][lane], S.CF[7][lane], S.CF[8][lane], S.CF[9][lane], ehz0, ehz1 };
-				ering.wr(ewpos, biquad_process(ehpf, biquad_process(elpf, x)));
-				elz0 = elpf.z0; elz1 = elpf.z1; ehz0 = ehpf.z0; ehz1 = ehpf.z1;
-			}
-#pragma unroll
-			for (int q = 0; q < 3; q++) if (eload[q]) S.P[e & 1][ech * 20 + ej + 8 * q][lane] = prod[q];
-			ewpos = ring_next(ewpos, RV_ESIZE);
-		}
-		if (fd_on) {
-			if (lr < 2) lr_in = S.R1[m & 3][lr][lane];                              // mid[lr]: input = early reflections of channel lr (summed in phase 2 of the previous iteration)
-			else {                                                                  // late[lr-2]: input = mid[lr-2] of the same sample
-				const float* om = &S.OM[l & 3][(lr - 2) * 4][lane];
-				lr_in = om[3 * 64] + (om[2 * 64] + (om[0] + om[64]));               // ((o0 + o1) + o2) + o3 as the reference's `+` chain associates
-			}
-			fring.wr(fwpos, fin);                                                   // FilteredDelay::process Reverb.k:130-132: (in >> delay >> filter) * gain
-			S.DL[wv][lane] = biquad_process(ff, fdt1) * fgain;                      // signals<4> delays = { delay[0..3] }: first process()
-		}
-		if (o_on && outwave) {                                                      // ---- output, sample o ----  Reflections::process + Reverb::process
-			const float in = S.tile[(o >> 5) & 1][ech][o & 31][lane];
-			const float* om = &S.OM[o & 3][ech * 4][lane]; const float* ol = &S.OL[o & 3][ech * 4][lane];
-			const float r1o = S.R1[o & 3][ech][lane];
-			const float r2o = om[3 * 64] + (om[2 * 64] + (om[0] + om[64]));
-			const float r3o = ol[3 * 64] + (ol[2 * 64] + (ol[0] + ol[64]));
-			const float dry = S.CF[10][lane], c1 = S.CF[11][lane], c2 = S.CF[12][lane], c3 = S.CF[13][lane], wet = S.CF[14][lane];
-			const float refl = (r1o * c1 + r2o * c2) + r3o * c3;
-			S.tile[(o >> 5) & 1][ech][o & 31][lane] = in * dry + refl * (ech ? 0.f : wet);   // wet side is signals<2>{ wet, 0 }
-		}
-		wg_sync_lds();
-		// ================= phase 2 =================
-		if (fd_on) {
-			const float* dl = &S.DL[lr * 4][lane];
-			const float d0 = dl[0], d1 = dl[64], d2 = dl[128], d3 = dl[192];
-			float fb;                                                               // row kk of the FDN matrix (Reverb.k:158-161), products summed left to right
-			if (kk == 0) fb = 0.f * d0 + 1.f * d1 + 1.f * d2 + -1.f * d3;
-			else if (kk == 1) fb = -1.f * d0 + 0.f * d1 + -1.f * d2 + 1.f * d3;
-			else if (kk == 2) fb = -1.f * d0 + 1.f * d1 + 0.f * d2 + -1.f * d3;
-			else fb = 1.f * d0 + -1.f * d1 + 1.f * d2 + 0.f * d3;
-			fin = fb + lr_in;                                                       // fb = (delays >> matrix) + in ; fb[k] >> delay[k]
-			fring.wr(fwpos + 1, fin);                                               // fpos is even and RV_FSIZE is even: +1 never wraps
-			const float o2 = biquad_process(ff, fdt2) * fgain;                      // the `+` chain processes each FilteredDelay a second time
-			fwpos = (fwpos + 2 >= RV_FSIZE) ? fwpos + 2 - RV_FSIZE : fwpos + 2;
-			if (lr < 2) S.OM[s_fd & 3][wv][lane] = o2; else S.OL[s_fd & 3][wv - 8][lane] = o2;
-			foff = fwrap(fwrap(foff + FROW) + FROW);
-			fr0 = r2v;                                                              // row last+2 of this sample is row `last` of the next
-		}
-		if (e_on && sumwave) {                                                      // waves 2 / 10: out = 0; for d < count: out += delay(times[d]) * gains[d]   Reverb.k:90-92
-			float p[20], sum = 0.f;                                                 // all twenty LDS reads are issued before the (sequential, as in the reference) add chain
-#pragma unroll
-			for (int d = 0; d < 20; d++) p[d] = S.P[e & 1][ech * 20 + d][lane];
-			__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-			for (int d = 0; d < 20; d++) sum = (d < ecount) ? sum + p[d] : sum;
-			S.R1[e & 3][ech][lane] = sum;
-		}
-		wg_sync_lds();
-		if (o_on && ((o & (FX_CHUNK - 1)) == FX_CHUNK - 1 || o == n - 1)) { store_chunk(o >> 5); }
-	};
-	const BoolTag<true> ramp; const BoolTag<false> steady;
-	int t = -2;
-	for (; t <= 0 && t <= n; t++) { if (t & 1) step(ramp, t, B, A); else step(ramp, t, A, B); }      // even t: set A holds this iteration's rows
-	for (; t + 1 <= n - 4; t += 2) { step(steady, t, B, A); step(steady, t + 1, A, B); }                 // t is odd here
-	for (; t <= n; t++) { if (t & 1) step(ramp, t, B, A); else step(ramp, t, A, B); }
-	// ---- write back what changed ----
-	if (k < a.K) {
-		float* Wr = a.state + k;
-		Wr[(size_t)(fw + FD_Z0) * KP] = ff.z0; Wr[(size_t)(fw + FD_Z1) * KP] = ff.z1; Wr[(size_t)(fw + FD_IN) * KP] = fin;
-		Wr[(size_t)(fw + FD_LASTP) * KP] = __int_as_float((int)((foff - fring.lane4) / FROW));
-		if (efilter) {
-			Wr[(size_t)(RV_EZ + 2 * ech) * KP] = elz0; Wr[(size_t)(RV_EZ + 2 * ech + 1) * KP] = elz1;
-			Wr[(size_t)(RV_EZ + 4 + 2 * ech) * KP] = ehz0; Wr[(size_t)(RV_EZ + 4 + 2 * ech + 1) * KP] = ehz1;
-		}
-	}
-#undef RVW
-}
-
-// =================================================================================================
 // Reverb.k, one wave per FOUR instances (the production kernel)
 // =================================================================================================
-// klg_fx_reverb16 above spreads the graph of 64 instances over sixteen WAVES: the 16 FilteredDelays meet twice per sample through LDS and
+// (Round 2's klg_fx_reverb16 — retired in round 5: this kernel serves every bank that fits in memory — spread the graph of 64 instances over sixteen WAVES: the 16 FilteredDelays met twice per sample through LDS and
 // two workgroup barriers, a 64-instance group is the unit of work, and a bank of 4096 instances is 64 workgroups on 64 of the 256 CUs —
 // 380 us per 256-sample block whatever the bank size below 16k, bound by barriers and by one CU's instruction issue.
 // This kernel gives a wave four instances and runs a block in two phases:
@@ -1392,8 +1158,8 @@ __global__ __launch_bounds__(RV16_THREADS) void klg_fx_reverb16(const ReverbArgs
 // samples per lane (16 consecutive positions: four 16-byte loads), requested a batch ahead; what a batch writes is collected in
 // registers and stored as whole 64-byte pieces.  So that a window never straddles the end of a ring, every line carries a MIRROR of
 // its first positions behind its last one (RV_FPAD / RV_EPAD floats, written together with the original).
-// Arithmetic, operand order and summation order are exactly those of klg_fx_reverb / the reference (the three kernels are compared bit
-// for bit in tests/test_gpu_fx.py: KLG_FX_REVERB1=1 selects the single-lane kernel, KLG_FX_REVERB16=1 the sixteen-wave one).
+// Arithmetic, operand order and summation order are exactly those of klg_fx_reverb / the reference (the two kernels are compared bit
+// for bit in tests/test_gpu_fx.py: KLG_FX_REVERB1=1 selects the single-lane kernel).
 enum { RVQ_MAX_INSTANCES = 65536 };      // banks up to this size run klg_fx_reverb_q: every bank that fits (12.5 MB of rings per instance: ~22 k in 288 GB).  Round 2 drew the line at 8,192
                                          // (profiles/r02_fx_sizes.md); since round 3's write-side work the kernel also wins above it — 16,384 instances: 0.467 against klg_fx_reverb16's 0.490 ms
 enum { RVQ_WG = 64 };

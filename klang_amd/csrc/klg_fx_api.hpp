@@ -38,7 +38,7 @@ struct klg_fx {
 	std::vector<int> rv_touched; std::vector<unsigned char> rv_flag;   // Reverb instances whose dials were set since their last prepare() (Controls::changed() is only evaluated for those)
 	BiquadCoef pp_dc;
 	int lds_limit = 64 * 1024;                         // hipDeviceAttributeMaxSharedMemoryPerBlock of this bank's device (gfx950: 160 KB)
-	int rv_layout = 1;                                 // Reverb ring layout: 1 = a contiguous ring per (instance, line) [klg_fx_reverb_q], 0 = tiles of 64 instances [klg_fx_reverb16]
+	int rv_layout = 1;                                 // Reverb ring layout: 1 = a contiguous ring per (instance, line) [klg_fx_reverb_q] — the only one since klg_fx_reverb16 was retired
 	bool timing = false; std::vector<hipEvent_t> tev; int launches = 0;
 	// graph effects (klg_graph.hpp, `kind effect`): hipRTC code object, per-instance controls in HBM
 	const graphrt::Compiled* graph = nullptr;
@@ -145,11 +145,9 @@ static klg_fx* fx_create_on(int device, int patch_id, int instances, float sampl
 	f->nctl = pp ? 6 : 10;
 	f->words = pp ? (int)PP_WORDS : (int)RV_WORDS;
 	if (!pp) {
-		// Which Reverb kernel serves this bank: klg_fx_reverb_q is one independent wave per four instances — it fills the chip from 1024
-		// instances up and is the faster one while a SIMD holds one or two of its waves; klg_fx_reverb16 (sixteen waves per 64 instances,
-		// LDS + barriers) hides its latencies behind other workgroups and wins once every CU holds several.  KLG_FX_REVERB16=0/1 overrides.
-		f->rv_layout = instances <= RVQ_MAX_INSTANCES ? 1 : 0;
-		if (const char* e = getenv("KLG_FX_REVERB16")) { if (e[0] == '1') f->rv_layout = 0; else if (e[0] == '0') f->rv_layout = 1; }
+		// klg_fx_reverb_q — one independent wave per four instances, a contiguous ring per (instance, line) — serves every Reverb bank (round 2's
+		// sixteen-waves-per-64-instances kernel, which took banks above 8,192 instances, lost to it at every size that fits in memory and was retired in round 5)
+		f->rv_layout = 1;
 	}
 	const size_t ring1 = pp ? (size_t)2 * PP_ROWS * f->kpad : (size_t)2 * RV_ESTRIDE * f->kpad;     // (Reverb: lines + the mirror tails of klg_fx_reverb_q)
 	const size_t ring2 = pp ? 0 : (size_t)16 * RV_FSTRIDE * f->kpad;
@@ -580,7 +578,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st, int blocks 
 				HIP_TRY(hipEventRecord(f->q_done[turn], st)); f->q_used[turn] = true;       // (recorded in mode 1 as well: a later mode-2 block's sums wait for the last reader of this buffer whichever mode it ran in)
 			}
 		}
-		else hipLaunchKernelGGL(klg_fx_reverb16, grid, dim3(RV16_THREADS), 0, st, a);              // sixteen waves per 64 instances (KLG_FX_REVERB16=1)
+		else return fail(KLG_ERR_INVALID, "klg_fx: no Reverb kernel for ring layout %d", f->rv_layout);
 	}
 	HIP_TRY(hipGetLastError());
 	if (bracket) { HIP_TRY(hipEventRecord(f->tev[2 * f->launches + 1], st)); f->launches++; }

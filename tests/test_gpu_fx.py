@@ -170,10 +170,10 @@ def test_fx_silence_in_silence_out():
     bank.close()
 
 
-@pytest.mark.parametrize("env", [{"KLG_FX_REVERB16": "1"}, {"KLG_FX_REVERB1": "1"}])
+@pytest.mark.parametrize("env", [{"KLG_FX_REVERB1": "1"}])
 def test_reverb_kernels_agree_bit_for_bit(env, monkeypatch):
-    """Three kernels render Reverb.k: the production one (a wave per four instances, a contiguous ring per line), the sixteen-waves-per-64-
-    instances one (KLG_FX_REVERB16=1, position-major ring tiles) and the single-lane walk of the whole graph (KLG_FX_REVERB1=1).  70 instances
+    """Two kernels render Reverb.k: the production one (a wave per four instances, a contiguous ring per line) and the single-lane walk of the
+    whole graph (KLG_FX_REVERB1=1).  70 instances
     with different controls, a control change mid-run, odd block length: identical bits."""
     def render():
         s = Scenario(patch="reverb", block=200, blocks=20, instances=70, burst=2000, seed=21, dump=list(range(0, 20, 3)))
