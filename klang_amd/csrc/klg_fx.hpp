@@ -434,19 +434,32 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			constexpr int RS = decltype(slot_c)::value, IS = (RS + 1) % P;
 			constexpr bool ST = decltype(steady_c)::value, MOVING = decltype(moving_c)::value && G <= 32;
 			int at = tid - 64; asm volatile("" : "+v"(at));                    // (see the general loop: keeps per-thread addresses out of loop-invariant registers)
-			const int acol = at & 31, arow = at >> 5;
+			// The caller's rows move as VECTORS: a thread takes VW consecutive samples of a row (a 32-sample row of the chunk is 128 contiguous bytes): 2 / 4 / 2 x 4 samples
+			// at G = 16 / 32 / 64 — a chunk's 2 G rows are 8 / 8 / 16 wave-instructions each way instead of 16 / 32 / 64.  A step is paced by how many vector-memory
+			// instructions the CU's one address path takes as much as by their bytes: 8,192 instances 18.0 -> 15.8 us per block in 64-block spans, 65,536: 99.8 -> 94
+			// (G = 16, two samples a thread: as before; four samples on half the threads: not faster in spans, slower in single blocks)
+			constexpr int VW = DIOV < 4 ? DIOV : 4, NV = DIOV / VW, TPR = PPX_CHUNK / VW, RPP = PPX_AUDIO * 64 / TPR;   // samples per vector, vectors per thread, threads per row, rows per pass
+			typedef float fvec __attribute__((ext_vector_type(VW), aligned(4)));
+			const int vcol = (at % TPR) * VW, vrow = at / TPR;
 			const int jn = j + 1, js = j - 2;
 			if ((ST || (js >= 0 && js < nch)) && !(KLG_PPX_ABLATE & 2) && !(KLG_PPX_VARIANT & 1)) {       // the caller's rows of chunk j - 2 (filtered in the step before): to memory
 				char* dst = io_rows(js * PPX_CHUNK);
 #pragma unroll
-				for (int i = 0; i < DIOV; i++) {
-					const int row = arow + 16 * i;
-					if (whole_group || k0 + (row >> 1) < a.K) *(float*)(dst + (unsigned)(row * nb + acol) * 4u) = S.tile[js & 3][row & 1][acol][row >> 1];
+				for (int i = 0; i < NV; i++) {
+					const int row = vrow + RPP * i;
+					fvec v;
+#pragma unroll
+					for (int q = 0; q < VW; q++) v[q] = S.tile[js & 3][row & 1][vcol + q][row >> 1];
+					if (whole_group || k0 + (row >> 1) < a.K) *(fvec*)(dst + (unsigned)(row * nb + vcol) * 4u) = v;
 				}
 			}
 			if (ST || (jn >= 0 && jn < nch)) {                              // the caller's rows of chunk j + 1 (requested in step j - P): into LDS
 #pragma unroll
-				for (int i = 0; i < DIOV; i++) { const int row = arow + 16 * i; S.tile[jn & 3][row & 1][acol][row >> 1] = iov[IS][i]; }
+				for (int i = 0; i < NV; i++) {
+					const int row = vrow + RPP * i;
+#pragma unroll
+					for (int q = 0; q < VW; q++) S.tile[jn & 3][row & 1][vcol + q][row >> 1] = iov[IS][i * VW + q];
+				}
 			}
 			const int u0 = (wv - 1) * PPX_PER + lq;
 			if ((ST || (j >= 0 && j < nch)) && !(KLG_PPX_ABLATE & 8)) {                              // AUDIO of chunk j: its rows were requested in step j - P
@@ -488,16 +501,15 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			const int c2 = j + P + 1;
 			if (ST || (c2 >= 0 && c2 < nch)) {                              // the caller's rows of chunk j + P + 1
 				const char* src = io_rows(c2 * PPX_CHUNK);
-				if (whole_group) {
 #pragma unroll
-					for (int i = 0; i < DIOV; i++) iov[IS][i] = *(const float*)(src + (unsigned)((arow + 16 * i) * nb + acol) * 4u);
-				}
-				else {
+				for (int i = 0; i < NV; i++) {
+					const int row = vrow + RPP * i;
+					fvec v;
 #pragma unroll
-					for (int i = 0; i < DIOV; i++) {
-						const int row = arow + 16 * i, inst = row >> 1;
-						iov[IS][i] = (k0 + inst < a.K) ? *(const float*)(src + (unsigned)(row * nb + acol) * 4u) : 0.f;
-					}
+					for (int q = 0; q < VW; q++) v[q] = 0.f;
+					if (whole_group || k0 + (row >> 1) < a.K) v = *(const fvec*)(src + (unsigned)(row * nb + vcol) * 4u);
+#pragma unroll
+					for (int q = 0; q < VW; q++) iov[IS][i * VW + q] = v[q];
 				}
 			}
 		};
