@@ -434,11 +434,12 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			constexpr int RS = decltype(slot_c)::value, IS = (RS + 1) % P;
 			constexpr bool ST = decltype(steady_c)::value, MOVING = decltype(moving_c)::value && G <= 32;
 			int at = tid - 64; asm volatile("" : "+v"(at));                    // (see the general loop: keeps per-thread addresses out of loop-invariant registers)
-			// The caller's rows move as VECTORS: a thread takes VW consecutive samples of a row (a 32-sample row of the chunk is 128 contiguous bytes): 2 / 4 / 2 x 4 samples
-			// at G = 16 / 32 / 64 — a chunk's 2 G rows are 8 / 8 / 16 wave-instructions each way instead of 16 / 32 / 64.  A step is paced by how many vector-memory
+			// The caller's rows move as VECTORS: a thread takes VW consecutive samples of a row (a 32-sample row of the chunk is 128 contiguous bytes): 4 / 2 x 4 samples
+			// at G = 32 / 64 — a chunk's 2 G rows are 8 / 16 wave-instructions each way instead of 32 / 64.  A step is paced by how many vector-memory
 			// instructions the CU's one address path takes as much as by their bytes: 8,192 instances 18.0 -> 15.8 us per block in 64-block spans, 65,536: 99.8 -> 94
-			// (G = 16, two samples a thread: as before; four samples on half the threads: not faster in spans, slower in single blocks)
-			constexpr int VW = DIOV < 4 ? DIOV : 4, NV = DIOV / VW, TPR = PPX_CHUNK / VW, RPP = PPX_AUDIO * 64 / TPR;   // samples per vector, vectors per thread, threads per row, rows per pass
+			// (G = 16: two samples a thread changed nothing in spans; four samples on half the threads: not faster in spans, slower in single blocks
+			//  — and the two-sample form costs the <16> kernel's OTHER loops 7 % through its register allocation (the vibrato leg 19.9 -> 21.5 us): G = 16 keeps one sample a thread)
+			constexpr int VW = DIOV < 4 ? 1 : 4, NV = DIOV / VW, TPR = PPX_CHUNK / VW, RPP = PPX_AUDIO * 64 / TPR;   // samples per vector, vectors per thread, threads per row, rows per pass
 			typedef float fvec __attribute__((ext_vector_type(VW), aligned(4)));
 			const int vcol = (at % TPR) * VW, vrow = at / TPR;
 			const int jn = j + 1, js = j - 2;
