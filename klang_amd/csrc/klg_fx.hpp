@@ -264,9 +264,9 @@ enum { PPX_CHUNK = 32, PPX_AUDIO = 8, PPX_PER = PPX_CHUNK / PPX_AUDIO, PPX_WAVES
 
 template<int G> struct PpxLds {
 	float tile[4][2][PPX_CHUNK][G + 1];         // [chunk & 3][channel][sample][instance]: loaded, audio, filter, store
-	float C1[2][G <= 32 ? PPX_CHUNK : 1][G];    // moving dials, running ahead: controls[1] per sample, from the first control wave to the second, [chunk & 1]
+	float C1[2][PPX_CHUNK][G];                  // moving dials, running ahead: controls[1] per sample, from the first control wave to the second, [chunk & 1]
 	int lastu[2][G];                            // ... and the chunk's last sample at which the scratch detector fired (-1: none)
-	float D[G <= 32 ? 8 : 2][PPX_CHUNK][G];     // delay time (smoothed controls[1]) per sample, [chunk & 1]; the request-ahead pipeline with MOVING dials (G <= 32): [chunk & 7]
+	float D[G <= 32 ? 8 : 4][PPX_CHUNK][G];     // delay time (smoothed controls[1]) per sample, [chunk & 1]; the request-ahead pipeline with MOVING dials: a ring of P + 2 <= ND chunks, [chunk & (ND - 1)] (G = 64: P = 2, four buffers — what its LDS has room for)
 	int far[2];                                 // 1: every tap of the chunk is far from the write cursor
 	int deep;                                   // the block runs the request-ahead pipeline (see PPX_DEEP below): 1 with stationary dials, 2 with moving ones (the control chain P + 1 chunks ahead)
 	int vibfast;                                // vibrato: the LFO's sines are taken by the audio waves, two chunks ahead of the chain
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		// MOVING: the delay time of every sample comes from the control chain's buffers (S.D[chunk & 7]) instead of being the one stationary value
 		auto audio_part = [&](auto slot_c, auto steady_c, auto moving_c, const int j, const int nch) __attribute__((always_inline)) {
 			constexpr int RS = decltype(slot_c)::value, IS = (RS + 1) % P;
-			constexpr bool ST = decltype(steady_c)::value, MOVING = decltype(moving_c)::value && G <= 32;
+			constexpr bool ST = decltype(steady_c)::value, MOVING = decltype(moving_c)::value;
+			constexpr int ND = G <= 32 ? 8 : 4;
 			int at = tid - 64; asm volatile("" : "+v"(at));                    // (see the general loop: keeps per-thread addresses out of loop-invariant registers)
 			// The caller's rows move as VECTORS: a thread takes VW consecutive samples of a row (a 32-sample row of the chunk is 128 contiguous bytes): 4 / 2 x 4 samples
 			// at G = 32 / 64 — a chunk's 2 G rows are 8 / 16 wave-instructions each way instead of 32 / 64.  A step is paced by how many vector-memory
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				for (int q = 0; q < PASSES; q++) {
 					const int u = u0 + q * SPW, pos = wrap(pos0 + u);
 					const float in_l = T[0][u][li], in_r = T[1][u][li];
-					const float dl = MOVING ? S.D[j & 7][u][li] : dly;
+					const float dl = MOVING ? S.D[j & (ND - 1)][u][li] : dly;
 					const float fl = delay_set(pos, SIZE, dl * a.fs.f).fraction, fr = delay_set(pos, SIZE, 0.5f * dl * a.fs.f).fraction;   // (as at the request: a dozen operations, not registers held for P steps)
 					// dry * in.l + (1.f - dry) * ((in.l + right * gain) >> left) >> out.l;   PingPong.k:66
 					const float r1 = rwr[RS][q][0] + fr * (rwr[RS][q][1] - rwr[RS][q][0]);
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 #pragma unroll
 				for (int q = 0; q < PASSES; q++) {
 					const int u = u0 + q * SPW, pos = wrap(pos1 + u);
-					const float dl = MOVING ? S.D[c & 7][u][li] : dly;
+					const float dl = MOVING ? S.D[c & (ND - 1)][u][li] : dly;
 					const Tap tl = delay_set(pos, SIZE, dl * a.fs.f);               // left.set(delay * fs)
 					const Tap tr = delay_set(pos, SIZE, 0.5f * dl * a.fs.f);        // right.set(0.5f * delay * fs)
 					const int i0 = tl.position, i1 = ring_succ(i0, SIZE), i2 = ring_succ(i1, SIZE);   // (a tap may sit on the pad row SIZE: klg_delay.hpp)
@@ -533,13 +534,13 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			// (stationary: every sample's delay time is sm1.)  Rows of chunk c are requested while chunks c - P .. c - 1 are not written yet.
 			const bool far_deep = 0.5f * sm1 * a.fs.f >= (float)((P + 1) * PPX_CHUNK + 3) && sm1 * a.fs.f <= (float)(SIZE - PPX_CHUNK - 4);
 			const bool ok = stationary && whole_chunks && __ballot(k < a.K && !far_deep) == 0ull;
-			// MOVING dials without vibrato (a dial being turned, a scratch, the smoothers still converging after either): every delay time of the block lies between the
+			// MOVING dials without vibrato, every width (a dial being turned, a scratch, the smoothers still converging after either): every delay time of the block lies between the
 			// smallest and the largest of where the chain's values are and where they are heading — controls[1].smooth() moves towards controls[1], which only ever
 			// takes clamped values of controls[5].smooth(), which moves towards controls[5] — so "far" is decided for the whole block here.  The chain then runs
 			// P + 1 chunks ahead of the audio; its head start (P chunks before the first request) is repaid over a span, not inside one block.
 			bool ok2 = false;
 			rest5_all = false;
-			if constexpr (G <= 32) {
+			{
 				const float t5 = __builtin_amdgcn_fmed3f(c5, a.c1_min, a.c1_max), s5 = __builtin_amdgcn_fmed3f(sm5, a.c1_min, a.c1_max);
 				// (controls[5] at rest — smoother at its fixed point, detector quiet, as in `stationary` — sets nothing: only controls[1].smooth() still moves, towards controls[1])
 				const bool rest5 = (sm5 * 0.999f + (1.f - 0.999f) * c5 == sm5) && !(fabsf(mdelay - sm5) >= 0.001f) && !(fabsf(c5 - sm5) >= 0.001f);
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	const bool vibfast = S.vibfast != 0;
 	if (vibfast) { if (w_audio) sines(0); __syncthreads(); }                        // (chunk 1's are taken in step -1, chunk j + 2's in step j)
 	if (S.deep) {
-		moving = G <= 32 && S.deep == 2 && !(KLG_PPX_VARIANT & 16);
+		moving = S.deep == 2 && !(KLG_PPX_VARIANT & 16);
 		// The control chain with moving dials, a chunk at a time.  One wave running all of it (the general loop: ~17 instructions a sample, each waiting for the one
 		// before: ~128 cycles a sample, 1.95 us a chunk) is slower than the memory pipeline it feeds (1.3 us a chunk), however far ahead it runs.  So it is cut where it
 		// only flows one way: the FIRST control wave smooths controls[5], runs the scratch detector and sets controls[1] (PingPong.k:47-56) and leaves controls[1] per sample
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		};
 		auto chain_second = [&](const int cc) __attribute__((always_inline)) {
 			const float (*C)[G] = S.C1[cc & 1];
-			float (*D)[G] = S.D[cc & 7];
+			float (*D)[G] = S.D[cc & ((G <= 32 ? 8 : 4) - 1)];
 			const int lu = S.lastu[cc & 1][li];
 			if (KLG_PPX_ABLATE & 64) { for (int u = 0; u < PPX_CHUNK; u++) D[u][li] = sm1; return; }
 			const bool inc_ok = !(lfo_inc >= KLG_TWO_PI);
