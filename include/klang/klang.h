@@ -1616,7 +1616,7 @@ inline void record_effect(std::vector<Obj> objs, Controls& ctl, int channels, si
 		// prepare() does something a recorded prologue cannot express (Vocoder.k:51-78: Pitch -> Frequency and power() on values read from dials, constants built
 		// from them, loops of std::pow): it stays HOST code, exactly as an effect whose prepare() asks Controls::changed() — EffectBank / FxRunner run it on a host
 		// mirror of every instance whose dials moved and upload what it changed.  Nothing of the attempt is kept.
-		if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: %s::prepare() stays host code: %s\n", type_name, R.error.c_str());
+		if (!std::getenv("KLANG_MI355_QUIET")) std::fprintf(stderr, "klang-mi355: note: %s::prepare() stays host code (it runs per instance on the host whenever a dial moved): %s\n", type_name, R.error.c_str());
 		R.host_prepare = true; R.error.clear(); R.prog.ops.clear(); R.next_reg = 0; R.objs.resize(nobjs0);
 		for (size_t i = 0; i < R.objs.size(); i++) if (R.objs[i].kind == N_PARAM) { ((signal*)R.objs[i].addr)->reg = -1; first_reg[i] = -1; }
 	}
