@@ -752,7 +752,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	if (!perr.empty()) return perr;
 	if (x2 && !x2_eligible(g)) return "graph program: not every node / op has a two-voices-per-lane form";
 	auto envs = [](const char* n) { const char* e = getenv(n); return std::string(e ? e : ""); };
-	const std::string key = (x2 ? "x2\n" : "") + (g.channels ? "staged G" + std::to_string(staged_G) + " " + envs("KLG_FX_STAGED") + "," + envs("KLG_FX_STAGED_G") + "," + envs("KLG_FX_STAGED_C") + "," + envs("KLG_FX_STAGED_LDS") + "," + envs("KLG_FX_STAGED_SKIP") + "," + envs("KLG_FX_STAGED_STAMP") + "," + envs("KLG_FX_STAGED_PIPE") + "," + envs("KLG_FX_STAGED_BATCH") + "," + envs("KLG_FX_STAGED_NEAR") + "," + envs("KLG_FX_STAGED_PACK") + "," + envs("KLG_FX_STAGED_TILES") + "\n" : std::string()) + g.text();
+	const std::string key = (x2 ? "x2\n" : "") + (g.channels ? "staged G" + std::to_string(staged_G) + " " + envs("KLG_FX_STAGED") + "," + envs("KLG_FX_STAGED_G") + "," + envs("KLG_FX_STAGED_C") + "," + envs("KLG_FX_STAGED_LDS") + "," + envs("KLG_FX_STAGED_SKIP") + "," + envs("KLG_FX_STAGED_STAMP") + "," + envs("KLG_FX_STAGED_PIPE") + "," + envs("KLG_FX_STAGED_BATCH") + "," + envs("KLG_FX_STAGED_NEAR") + "," + envs("KLG_FX_STAGED_PACK") + "," + envs("KLG_FX_STAGED_TILES") + "," + envs("KLG_FX_STAGED_RETRY") + "\n" : std::string()) + g.text();
 	auto it = cache.find(key);
 	if (it != cache.end()) { *out = &it->second; return ""; }
 	if (!rtc.load()) return rtc.error;

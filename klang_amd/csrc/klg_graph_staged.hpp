@@ -26,7 +26,7 @@ namespace klg { namespace graphrt {
 
 struct StagedPlan {
 	bool ok = false; std::string why;
-	int G = 16, C = 32, threads = 0, lds_bytes = 0, levels = 0, slots = 0, serial_ops = 0, parallel_ops = 0; bool pipelined = false;
+	int G = 16, C = 32, threads = 0, lds_bytes = 0, levels = 0, slots = 0, serial_ops = 0, parallel_ops = 0, retry_min = 0; bool pipelined = false;   // retry_min: the shortest part a chunk that failed its ring check is tried again in (0: never — straight to the plain body)
 	std::string prefix_commit;                                           // (scratch of plan_staged)
 	std::string source;                                                  // the kernel (appended to the generated translation unit, inside namespace klg)
 };
@@ -479,10 +479,20 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		const char* te = getenv("KLG_FX_STAGED_TILES");
 		const bool two_tiles = !(te && te[0] == '1') && (lds_words + (long long)CH * C * G) * 4 <= budget;
 		if (two_tiles) lds_words += (long long)CH * C * G;                 // gfx950 grants a workgroup up to 160 KB; a plan that needs most of it (the recorded Reverb.k: 68 values x 32 samples x 16 instances) is one workgroup of 8 waves per CU — measured 0.61 against 0.83 ms at 4,096 instances, 2.5 against 4.4 ms at 16,384, with half the chunk
+		// A chunk whose ring check fails is tried again in PARTS before it goes to the plain body: halves, then quarters (never below 8 samples: the serial
+		// loops take their inputs eight at a time) — a tap 20 samples behind the cursor fails a 32-sample chunk and passes its halves; the plain body (one lane
+		// per instance, the whole sample's dependent chain) then walks only what no part could take.  A part runs the audio path's levels on its samples; of the
+		// control path — computed a chunk ahead: its values for this chunk stay where they are — it runs the SERIAL loops again, on the architectural records
+		// (the same arithmetic on the same inputs), so that the records are complete at the end of every part and the plain body can take over at any of them.
+		// Nothing of this is on the path of a chunk that passes its check.
+		const char* re = getenv("KLG_FX_STAGED_RETRY");
+		const int CMIN = std::max(8, C / 4);
+		const bool retry = !(re && re[0] == '0') && C >= 16 && guard_level >= 0;
 		if (lds_words * 4 > budget) { if (in.C > 0 && !in.C_is_a_preference) return refuse("the requested chunk length does not fit the LDS budget"); continue; }
 
 		// =========================================================== source ===========================================================
 		std::string s;
+		bool part = false;                                                         // generating the text of a PART of a chunk (the retry after a failed check): samples OFF .. OFF + CC - 1 of the chunk
 		auto ring = [&](int node) { return F("RingS{ (const char*)(ring0 + (size_t)%lldll * %d), (unsigned)pg * 4u, %du, %d }", (*in.ring_off)[(size_t)node], G, G * 4, g.arg(node)); };   // rows of G instances: this workgroup's own (PatchGen::kRingRow); a wave-uniform base + 32-bit offsets (klg_delay.hpp RingS)
 		auto ty = [&](int r) { return std::string(is_dbl[(size_t)r] ? "double" : "float"); };
 		auto in_branch = [&](int i) { return !V[(size_t)i].path.empty(); };
@@ -491,7 +501,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		auto slot_ref = [&](int r, bool reader_pf) {
 			if (!slot_override.empty()) { const auto it = slot_override.find(r); if (it != slot_override.end()) return it->second; }
 			const Reg& R = regs[(size_t)r];
-			if (pfx[(size_t)R.def]) return F("SLP(%d, %s)", R.slot_id, reader_pf ? "parn" : "parc");
+			if (pfx[(size_t)R.def]) return F("SLP(%d, %s)", R.slot_id, (reader_pf && !part) ? "parn" : "parc");
 			return F("SL(%d)", R.slot_id);
 		};
 		std::string inst = "pg";                                                   // which instance the code being generated works for: a lane of a parallel level (pg) or of a serial loop (ln)
@@ -522,11 +532,11 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			case OP_DELAYOUT:
 				if (tap_mode == 1) d = F("\t\ttf%d = ", i);
 				if (set_at[(size_t)v.node] >= 0) b += d + (tap_mode == 1 ? "staged_process_fetch(" : "staged_process(") + ring(v.node) + F(", ring_walk(d%dt.position, %d, %d), d%dt.fraction, d%dw, bad);\n", v.node, out_index[(size_t)i], SZ, v.node, v.node);
-				else b += d + (tap_mode == 1 ? "staged_process_fetch(" : "staged_process(") + ring(v.node) + F(", ring_walk(d%dh.position, ps * %d + %d, %d), d%dh.fraction, d%dw, bad);\n", v.node, outs[(size_t)v.node], out_index[(size_t)i], SZ, v.node, v.node);
+				else b += d + (tap_mode == 1 ? "staged_process_fetch(" : "staged_process(") + ring(v.node) + F(", ring_walk(d%dh.position, %s * %d + %d, %d), d%dh.fraction, d%dw, bad);\n", v.node, part ? "(ps - OFF)" : "ps", outs[(size_t)v.node], out_index[(size_t)i], SZ, v.node, v.node);
 				break;
 			case OP_DELAYTAP:
 				if (v.imm == 0u && near_ch[(size_t)v.node] >= 0) {                      // a line fed by `in`: no check (see near_ch)
-					const std::string args = ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", r%d, d%dw.w0, ps + %d, incopy + (%d * C) * G + pg, G);\n", v.a, v.node, in_index[(size_t)i], near_ch[(size_t)v.node]);
+					const std::string args = ring(v.node) + ", " + pos(in_index[(size_t)i]) + F(", r%d, d%dnw0, ps + %d, incopy + (%d * C) * G + pg, G);\n", v.a, v.node, in_index[(size_t)i], near_ch[(size_t)v.node]);
 					if (tap_mode == 2) b += d + F("staged_tap_float_finish_near(tf%d);\n", i);
 					else if (tap_mode == 1) b += F("\t\ttf%d = staged_tap_float_fetch_near(", i) + args;
 					else b += d + "staged_tap_float_near(" + args;
@@ -727,7 +737,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		bool first_pass = true;                                                      // (the control path's blocks are generated twice: for chunk 0 ahead of the loop, and inside it)
 		auto block = [&](bool pf, int lv) {
 			std::string code;
-			const char* cond = pf ? "pre" : "ok";
+			const char* cond = (pf && !part) ? "pre" : "ok";                        // (a part of a chunk runs the control path's serial loops with the audio path's: above)
 			if (!pf && lv < 32 && ((skip_mask >> lv) & 1u)) return code;
 			inst = (lv & 1) ? "ln" : "pg";
 			if (!(lv & 1)) {
@@ -768,12 +778,12 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 					if (lv == last_level) {                                                  // the read heads as the chunk leaves them (Delay::last)
 						for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY && head_used[nd]) {
 							const int SZ = g.arg((int)nd), w0 = g.node_word0((int)nd);
-							if (set_at[nd] >= 0) body += F("\t\tif (ps == C - 1) { srec[%d * G + pg] = (uint32_t)ring_walk(d%zut.position, %d, %d); srec[%d * G + pg] = f2u(d%zut.fraction); }\n", w0 + ED_LASTPOS, nd, outs[nd], SZ, w0 + ED_LASTFRAC, nd);
-							else if (outs[nd] > 0) body += F("\t\tif (ps == 0) srec[%d * G + pg] = (uint32_t)ring_walk(d%zuh.position, C * %d, %d);\n", w0 + ED_LASTPOS, nd, outs[nd], SZ);
+							if (set_at[nd] >= 0) body += F("\t\tif (ps == %s) { srec[%d * G + pg] = (uint32_t)ring_walk(d%zut.position, %d, %d); srec[%d * G + pg] = f2u(d%zut.fraction); }\n", part ? "OFF + CC - 1" : "C - 1", w0 + ED_LASTPOS, nd, outs[nd], SZ, w0 + ED_LASTFRAC, nd);
+							else if (outs[nd] > 0) body += F("\t\tif (ps == %s) srec[%d * G + pg] = (uint32_t)ring_walk(d%zuh.position, %s * %d, %d);\n", part ? "OFF" : "0", w0 + ED_LASTPOS, nd, part ? "CC" : "C", outs[nd], SZ);
 						}
 					}
 				}
-				if (!decl.empty() || !body.empty()) code += F("\t\tif (%s && t < NTP) { auto& L = %s; const FxCtx& c = cp; (void)L; (void)c;\n", cond, pf ? "Lq" : "Lp") + decl + body + "\t\t}\n";
+				if (!decl.empty() || !body.empty()) code += F("\t\tif (%s && t < NTP%s) { auto& L = %s; const FxCtx& c = cp; (void)L; (void)c;\n", cond, part ? " && ps >= OFF && ps < OFF + CC" : "", pf ? "Lq" : "Lp") + decl + body + "\t\t}\n";
 			}
 			else {
 				for (int w = 0; w < NWV; w++) {
@@ -823,7 +833,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 								const int rm = field < 0 ? vm.dst : field == 0 ? vm.a : field == 1 ? vm.b : vm.x[(size_t)field - 2];
 								ids.push_back(regs[(size_t)rm].slot_id); dpf = pfx[(size_t)regs[(size_t)rm].def] != 0;
 							}
-							if (dpf) slot_override[r] = F("(pslots + ((%s) * 2 + %s) * (C * G))", qsel(ids).c_str(), pf ? "parn" : "parc");
+							if (dpf) slot_override[r] = F("(pslots + ((%s) * 2 + %s) * (C * G))", qsel(ids).c_str(), (pf && !part) ? "parn" : "parc");
 							else slot_override[r] = F("(slots + (%s) * (C * G))", qsel(ids).c_str());
 						};
 						for (size_t pos = 0; pos < pk->ops[0].size(); pos++) {
@@ -843,12 +853,12 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 					for (int r : from_slot) { fetch += F("\t\tfloat i%d[%d];\n#pragma unroll\n\t\tfor (int u = 0; u < %d; u++) i%d[u] = ", r, U, U, r) + slot_ref(r, pf) + "[(sb + u) * G + " + li + "];\n"; decl += "\t\tconst " + ty(r) + F(" r%d = i%d[u];\n", r, r); }
 					for (int i : mine) if (V[(size_t)i].dst >= 0 && in_branch(i) && def_at[(size_t)V[(size_t)i].dst] == i) { const int r = V[(size_t)i].dst; predecl[(size_t)r] = 1; decl += "\t\t" + ty(r) + F(" r%d = 0; (void)r%d;\n", r, r); }
 					emit_ops(pf, lv, w, "q", loop, predecl);
-					if (first_pass) P.serial_ops += (int)mine.size() * K;
+					if (first_pass && !part) P.serial_ops += (int)mine.size() * K;
 					// the suffix works on the architectural records; the prefix on its own two copies: from the one its previous chunk left, into the other
-					const std::string from = pf ? "srecp + (parn ^ 1) * (NW * G)" : "srec", to = pf ? "srecp + parn * (NW * G)" : "srec";
+					const std::string from = (pf && !part) ? "srecp + (parn ^ 1) * (NW * G)" : "srec", to = (pf && !part) ? "srecp + parn * (NW * G)" : "srec";
 					const std::string lanes = F("ln < %d", G * K);
 					code += F("\t\tif (%s && sw == %d && %s) { auto& L = Ls; const FxCtx& c = cs; (void)L; (void)c;\n", cond, w, lanes.c_str()) + pack_decl + F("\t\t{ const StagedRec r = { { %s + %s } }; (void)r;\n", from.c_str(), li.c_str()) + load + "\t\t}\n" + inv_prelude(pf, lv, w);
-					code += F("\t\tfor (int sb = 0; sb < C; sb += %d) {\n", U) + fetch + F("#pragma unroll\n\t\tfor (int u = 0; u < %d; u++) { const int q = (sb + u) * G + %s; (void)q;\n", U, li.c_str()) + decl + loop + "\t\t}\n\t\t}\n";
+					code += (part ? F("\t\tfor (int sb = OFF; sb < OFF + CC; sb += %d) {\n", U) : F("\t\tfor (int sb = 0; sb < C; sb += %d) {\n", U)) + fetch + F("#pragma unroll\n\t\tfor (int u = 0; u < %d; u++) { const int q = (sb + u) * G + %s; (void)q;\n", U, li.c_str()) + decl + loop + "\t\t}\n\t\t}\n";
 					const std::string cm = F("\t\t{ StagedRec r = { { %s + %s } }; (void)r;\n", to.c_str(), li.c_str()) + commit + "\t\t}\n";
 					if (pf || lv > guard_level) code += cm + "\t\t}\n";
 					else { code += "\t\t}\n"; deferred.push_back(F("\t\tif (ok && sw == %d && %s) { auto& L = Ls; (void)L;\n", w, lanes.c_str()) + pack_decl + cm + "\t\t}\n"); }
@@ -893,17 +903,17 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "\tP::Live Lp, Lq, Ls;\n\tLp.unused_ = 0; Lp.sidx = 0; Lq.unused_ = 0; Lq.sidx = 0; Ls.unused_ = 0; Ls.sidx = 0;\n";
 		s += "\t__syncthreads();\n";
 		// the plain body over [from, from + count) of the block, on one lane per instance (wave 0): prepare() at the head of the block, chunks whose check failed, a ragged tail
-		s += "\tauto plain = [&](int from, int count, bool with_prepare) {\n";
+		s += "\tauto plain = [&](int from, int count, bool with_prepare, int tq0) {             // tq0: where `from` stands in the chunk's tile\n";
 		s += "\t\tif (wv != 0 || ln >= G) return;\n\t\tP::Rec rec;\n#pragma unroll\n\t\tfor (int w = 0; w < NW; w++) rec.w[w] = srec[w * G + ln];\n";
 		s += "\t\tP::Live L; FxCtx c = cs; c.samples = samples0 + (unsigned long long)from;\n";
 		s += "\t\tif (with_prepare) P::begin(L, rec, c); else P::begin_core(L, rec, c);\n\t\tL.sidx = from;\n";
-		s += "\t\tfor (int q = 0; q < count; q++) {\n\t\t\tconst float in0 = tile[(0 * C + q) * G + ln], in1 = CH > 1 ? tile[(1 * C + q) * G + ln] : 0.f;\n\t\t\tfloat out0 = 0.f, out1 = 0.f;\n";
-		s += "\t\t\tP::sample(L, c, in0, in1, out0, out1);\n\t\t\ttile[(0 * C + q) * G + ln] = out0;\n\t\t\tif (CH > 1) tile[(1 * C + q) * G + ln] = out1;\n\t\t}\n";
+		s += "\t\tfor (int q = 0; q < count; q++) {\n\t\t\tconst float in0 = tile[(0 * C + tq0 + q) * G + ln], in1 = CH > 1 ? tile[(1 * C + tq0 + q) * G + ln] : 0.f;\n\t\t\tfloat out0 = 0.f, out1 = 0.f;\n";
+		s += "\t\t\tP::sample(L, c, in0, in1, out0, out1);\n\t\t\ttile[(0 * C + tq0 + q) * G + ln] = out0;\n\t\t\tif (CH > 1) tile[(1 * C + tq0 + q) * G + ln] = out1;\n\t\t}\n";
 		s += "\t\tP::end(L, rec);\n#pragma unroll\n\t\tfor (int w = 0; w < NW; w++) if (patch_stores<P>(w)) srec[w * G + ln] = rec.w[w];\n\t};\n";
 		s += "\tconst int nblk = a.blocks > 1 ? a.blocks : 1;\n\tfor (int blk = 0; blk < nblk; blk++) {                                          // Effect::process(buffer), block after block (klang.h:4208-4216)\n";
 		s += "\tsamples0 = a.samples + (unsigned long long)blk * (unsigned long long)a.n; io = a.io + (size_t)blk * a.block_stride; cp.samples = cs.samples = samples0;\n";
 		s += "\tif (a.rand) { cp.rand = a.rand + (size_t)blk * (size_t)a.K + (size_t)(k0 + pg < a.K ? k0 + pg : 0); cs.rand = a.rand + (size_t)blk * (size_t)a.K + (size_t)(k0 + sg < a.K ? k0 + sg : 0); }   // this block's columns of the span's draws\n";
-		if (g.prepare_ops > 0) s += "\tplain(0, 0, true);                                                           // Effect::prepare(): once per block\n\t__syncthreads();\n";
+		if (g.prepare_ops > 0) s += "\tplain(0, 0, true, 0);                                                           // Effect::prepare(): once per block\n\t__syncthreads();\n";
 		if (pipelined) s += "\tfor (int i = t; i < NW * G; i += NT) { srecp[i] = srec[i]; srecp[NW * G + i] = srec[i]; }\n\t__syncthreads();\n";
 		// what the lanes hold for the whole block: the dials, the members process() only reads
 		{
@@ -913,12 +923,12 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			s += "\t{ auto& L = Ls; const FxCtx& c = cs; const StagedRec r = { { srec + sg } }; (void)L; (void)c; (void)r;\n" + in.ctl_begin + pb + "\t}\n";
 		}
 		// registers handed from the control path to the audio path: computed during the previous iteration (xn), taken at the top of this one (xc)
-		std::string xdecl, xrot, pcdecl, cdecl;
+		std::string xdecl, xrot, pcdecl, cdecl, cdecl_sub;
 		for (size_t r = 0; r < regs.size(); r++) if (regs[r].def >= 0 && !ser_of(regs[r].def)) {
 			const bool dpf = pfx[(size_t)regs[r].def] != 0;
 			if (dpf && regs[r].xrot) { xdecl += "\t" + ty((int)r) + F(" xn_r%zu = 0, xc_r%zu = 0; (void)xc_r%zu;\n", r, r, r); xrot += F("\t\txc_r%zu = xn_r%zu;\n", r, r); cdecl += "\t\tconst " + ty((int)r) + F(" r%zu = xc_r%zu; (void)r%zu;\n", r, r, r); }
 			else if (dpf && regs[r].chunk) pcdecl += "\t\t" + ty((int)r) + F(" pc_r%zu = 0; (void)pc_r%zu;\n", r, r);
-			else if (!dpf && regs[r].chunk) cdecl += "\t\t" + ty((int)r) + F(" r%zu = 0; (void)r%zu;\n", r, r);
+			else if (!dpf && regs[r].chunk) { cdecl += "\t\t" + ty((int)r) + F(" r%zu = 0; (void)r%zu;\n", r, r); cdecl_sub += "\t\t" + ty((int)r) + F(" r%zu = 0; (void)r%zu;\n", r, r); }
 		}
 		for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY && set_at[nd] >= 0 && pfx[(size_t)set_at[nd]]) { xdecl += F("\tTap xn_d%zut = { 0, 0.f }, xc_d%zut = { 0, 0.f }; (void)xc_d%zut;\n", nd, nd, nd); xrot += F("\t\txc_d%zut = xn_d%zut;\n", nd, nd); }
 		s += xdecl;
@@ -957,6 +967,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			const int SZ = g.arg((int)nd), w0 = g.node_word0((int)nd);
 			s += F("\t\tconst int d%zup0 = (int)((d%zub + (unsigned)(s0 + ps) * %du) %% %du); (void)d%zup0;\n", nd, nd, k_in[nd], SZ, nd);
 			s += F("\t\tconst RingWindow d%zuw = { (int)((d%zub + (unsigned)s0 * %du) %% %du), %d * C }; (void)d%zuw;\n", nd, nd, k_in[nd], SZ, k_in[nd], nd);
+			s += F("\t\tconst int d%zunw0 = d%zuw.w0; (void)d%zunw0;\n", nd, nd, nd);
 			if (set_at[nd] >= 0 && pfx[(size_t)set_at[nd]]) s += F("\t\tconst Tap d%zut = xc_d%zut; (void)d%zut;\n", nd, nd, nd);
 			else if (set_at[nd] >= 0) s += F("\t\tTap d%zut = { 0, 0.f }; (void)d%zut;\n", nd, nd);
 			else if (outs[nd] > 0) s += F("\t\tconst Tap d%zuh = { (int)srec[%d * G + pg], u2f(srec[%d * G + pg]) };\n", nd, w0 + ED_LASTPOS, w0 + ED_LASTFRAC);
@@ -974,7 +985,48 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			if (lv == guard_level && !guard_emitted) { s += "\t\tok = ok && *flag == 0;                                                   // every ring read of the chunk lies outside the rows the chunk writes\n"; guard_emitted = true; }
 		}
 		{ std::string rest; for (const std::string& d : deferred) rest += d; deferred.clear(); rest += P.prefix_commit; if (!rest.empty()) s += rest + "\t\t__syncthreads();\n"; }
-		s += "\t\tif (!ok) { plain(s0, cl, false); __syncthreads(); }\n";
+		if (retry) {
+			// the chunk again in parts (the audio path alone): halves, a half that fails in quarters, and only a part of CMIN samples that fails goes to the plain body
+			// (a ragged last chunk takes the same way out with nothing to try: one copy of the plain body.  What the part's code needs of the chunk's own values is
+			// taken again rather than kept — the thread index laundered once more, `in` from the tile, the cursors —: kept, they would stay live across every level
+			// of every chunk for the sake of a path that is almost never taken: the recorded PingPong.k's kernel then spilled 36 registers, 9 this way)
+			s += "\t\tif (!ok) {\n\t\tint OFF = 0, CC = cl == C ? C / 2 : cl, ctl_at = 0; (void)ctl_at;              // ctl_at: the sample of the chunk the control path's ARCHITECTURAL records stand at\n\t\twhile (OFF < cl) {\n";
+			s += "\t\tint tv = threadIdx.x; asm volatile(\"\" : \"+v\"(tv));\n";
+			s += "\t\tconst int t = tv, tp = t < NTP ? t : 0, ps = tp / G, pg = tp % G, wv = t >> 6, sw = wv - SW0, ln = t & 63; (void)ps; (void)pg; (void)sw; (void)ln; (void)wv;\n";
+			s += "\t\tif (t == 0) *flag = 0;\n\t\t__syncthreads();\n\t\tbool ok = cl == C; int bad = 0; (void)bad;\n";
+			s += "\t\tconst float in0 = tile[(0 * C + ps) * G + pg], in1 = CH > 1 ? tile[(1 * C + ps) * G + pg] : 0.f; (void)in0; (void)in1;\n";
+			for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY) {
+				const int SZ = g.arg((int)nd), w0 = g.node_word0((int)nd);
+				s += F("\t\tconst int d%zup0 = (int)((d%zub + (unsigned)(s0 + ps) * %du) %% %du); (void)d%zup0;\n", nd, nd, k_in[nd], SZ, nd);
+				s += F("\t\tconst RingWindow d%zuw = { (int)((d%zub + (unsigned)(s0 + OFF) * %du) %% %du), %d * CC }; (void)d%zuw;\n", nd, nd, k_in[nd], SZ, k_in[nd], nd);
+				if (set_at[nd] >= 0 && pfx[(size_t)set_at[nd]]) {}
+				else if (set_at[nd] >= 0) s += F("\t\tTap d%zut = { 0, 0.f }; (void)d%zut;\n", nd, nd);
+				else if (outs[nd] > 0) s += F("\t\tconst Tap d%zuh = { (int)srec[%d * G + pg], u2f(srec[%d * G + pg]) };\n", nd, w0 + ED_LASTPOS, w0 + ED_LASTFRAC);
+			}
+			s += cdecl_sub;
+			part = true;
+			bool guard_seen = guard_level < 0;
+			for (int lv = 0; lv <= last_level; lv++) {
+				const std::string code = block(false, lv);
+				if (code.empty() && lv != guard_level) continue;
+				s += F("\t\t// ---- a part of the chunk, level %d ----\n", lv) + code + "\t\t__syncthreads();\n";
+				if (lv == guard_level && !guard_seen) { s += "\t\tok = ok && *flag == 0;\n"; guard_seen = true; }
+			}
+			{ std::string rest; for (const std::string& d : deferred) rest += d; deferred.clear(); if (!rest.empty()) s += rest + "\t\t__syncthreads();\n"; }
+			// The plain body starts from the architectural records.  The control path's are where the last plain walk left them (ctl_at; the chunk's start at
+			// first) — parts that passed ran the audio path alone —: its serial loops run over [ctl_at, OFF) on those records first (the same arithmetic on the
+			// inputs the run a chunk ahead left in LDS), and only then: nothing of the control path is repeated for a chunk whose parts all pass.
+			std::string catchup;
+			if (pipelined) for (int lv = 1; lv <= pmax; lv += 2) catchup += block(true, lv);
+			part = false;
+			s += F("\t\tif (ok) OFF += CC; else if (cl == C && CC > %d) CC >>= 1; else {\n", CMIN);
+			if (!catchup.empty()) s += "\t\tif (OFF > ctl_at) { const int part_at = OFF; { const int OFF = ctl_at, CC = part_at - ctl_at; const bool ok = true; (void)ok;\n" + catchup + "\t\t} __syncthreads(); }\n";
+			s += "\t\tplain(s0 + OFF, CC, false, OFF); __syncthreads(); OFF += CC; ctl_at = OFF; }\n";
+			s += "\t\t}\n";
+			if (!P.prefix_commit.empty()) s += "\t\tif (cl == C) { const bool ok = true; (void)ok;                                  // the control path's records at the end of the chunk (where a plain walk ended the chunk they are there already: the same values)\n" + P.prefix_commit + "\t\t}\n\t\t__syncthreads();\n";
+			s += "\t\t}\n";
+		}
+		else s += "\t\tif (!ok) { plain(s0, cl, false, 0); __syncthreads(); }\n";
 		s += "\t\tfor (int i = t; i < G * CH * C; i += NT) { const int row = i / C, q = i % C, gi = row / CH, ch = row % CH;\n";
 		s += "\t\t\tif (q < cl && k0 + gi < a.K) io[((size_t)(k0 + gi) * CH + ch) * a.n + s0 + q] = tile[(ch * C + q) * G + gi]; }\n";
 		if (!two_tiles) s += "\t\t__syncthreads();\n";                            // (two tiles: the next chunk's input goes to the other one, and this one is not touched before the barriers of that chunk)
@@ -986,7 +1038,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "\tfor (int i = t; i < NW * G; i += NT) if (k0 + (i % G) < a.K && patch_stores<P>(i / G)) a.state[(size_t)(i / G) * a.kpad + k0 + (i % G)] = srec[i];\n";
 		s += "#undef SL\n#undef SLP\n}\n";
 		for (int i = 0; i < NV; i++) if (live_op(i) && !ser_of(i)) P.parallel_ops++;
-		P.ok = true; P.G = G; P.C = C; P.threads = NT; P.lds_bytes = (int)(lds_words * 4); P.levels = last_level + 1; P.slots = nslots + npslots; P.pipelined = pipelined; P.source = s;
+		P.ok = true; P.G = G; P.C = C; P.threads = NT; P.lds_bytes = (int)(lds_words * 4); P.levels = last_level + 1; P.slots = nslots + npslots; P.pipelined = pipelined; P.retry_min = retry ? CMIN : 0; P.source = s;
 		return P;
 	}
 }

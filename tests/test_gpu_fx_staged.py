@@ -77,7 +77,7 @@ def pingpong_program():
 def test_staged_pingpong_with_near_taps_ragged_blocks_and_moving_dials(monkeypatch):
     """Recorded PingPong.k, three banks fed the same blocks: the hand-written kernel, the staged form, one lane per instance.  70 instances: a third
     with the Delay dial near 0 (the left tap 48 samples behind the cursor, the right one 24: inside a 32-sample chunk — the ring check fails and the
-    chunk is walked by the plain body), some with vibrato (taps that move), the rest at rest; block lengths that are no multiple of a chunk, shorter
+    chunk is tried again in halves and quarters, and what no part can take is walked by the plain body: KLG_FX_STAGED_RETRY), some with vibrato (taps that move), the rest at rest; block lengths that are no multiple of a chunk, shorter
     than one, and 1; dials moved between blocks (host set() on a control the effect itself writes)."""
     prog, rec = pingpong_program()
     K = 70
@@ -98,7 +98,9 @@ def test_staged_pingpong_with_near_taps_ragged_blocks_and_moving_dials(monkeypat
     for k in range(K):
         dial(k, 0, rng.uniform(0.2, 0.95))
         if k % 3 == 0:
-            dial(k, 5, rng.uniform(0.0, 0.0008)); dial(k, 1, 0.001)          # taps inside the chunk
+            dial(k, 5, rng.uniform(0.0, 0.0012)); dial(k, 1, 0.001)          # taps inside the chunk (the right one 0 .. 26 samples behind the cursor: parts of 16 and 8 samples pass where the chunk fails)
+            if k % 2 == 0:
+                dial(k, 2, rng.uniform(0.6, 1.0)); dial(k, 3, rng.uniform(0.3, 1.0))   # ... that move by the sample (vibrato): a part that passes, then one that does not — the plain body takes over inside a chunk
         elif k % 3 == 1:
             dial(k, 5, rng.uniform(0.05, 0.6)); dial(k, 2, rng.uniform(0.2, 1.0)); dial(k, 3, rng.uniform(0.05, 1.0))   # vibrato
     lengths = [256, 37, 1, 100, 32, 33, 64, 250, 7, 256, 31, 256, 96, 256, 256, 5, 128, 256]

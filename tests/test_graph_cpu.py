@@ -301,8 +301,8 @@ def test_the_recorded_config_4_effects_get_a_staged_form():
     A parallel level's ring reads come in two halves (rows + check + loads, then the arithmetic) with several under way at a time; a read recorded inside an
     `if` is taken outside it, its check counting under the branch's condition alone.  KLG_FX_STAGED=0 leaves the one-lane kernel alone;
     KLG_FX_STAGED_BATCH=0 writes every read in one piece."""
-    for name, needles in (("pingpong_recorded", ("extern \"C\" __global__", "klg_fx_staged", "beside the", "basic_sine_of(", "basic_sine_arg(L.n2)", "staged_process_fetch(RingS{ (const char*)(ring0 + ", "staged_process_finish(tf", "xc_d0t = xn_d0t;", "plain(s0, cl, false)")),
-                          ("reverb_recorded", ("klg_fx_staged", "staged_tap_stereo_fetch(RingS{", "bad |= ((r", "asm volatile(\"\" ::: \"memory\");", "staged_tap_stereo_finish(tf", "biquad_process(L.n", "if (bad) *flag = 1;", "plain(s0, cl, false)"))):
+    for name, needles in (("pingpong_recorded", ("extern \"C\" __global__", "klg_fx_staged", "beside the", "basic_sine_of(", "basic_sine_arg(L.n2)", "staged_process_fetch(RingS{ (const char*)(ring0 + ", "staged_process_finish(tf", "xc_d0t = xn_d0t;", "plain(s0 + OFF, CC, false, OFF)", "a part of the chunk, level 0")),
+                          ("reverb_recorded", ("klg_fx_staged", "staged_tap_stereo_fetch(RingS{", "bad |= ((r", "asm volatile(\"\" ::: \"memory\");", "staged_tap_stereo_finish(tf", "biquad_process(L.n", "if (bad) *flag = 1;", "plain(s0 + OFF, CC, false, OFF)", "a part of the chunk, level 0"))):
         prog = open(os.path.join(ROOT, "tests", "golden", name + ".klgg")).read()
         rc, src = check(prog, want_source=True)
         assert rc == 0, src
@@ -329,6 +329,16 @@ def test_the_recorded_config_4_effects_get_a_staged_form():
         assert rc == 0 and "staged_tap_stereo(RingS{" in src and "TapFetch tf" not in src
     finally:
         del os.environ["KLG_FX_STAGED_BATCH"]
+    # a chunk that fails its ring check is tried again in halves and quarters (the audio path alone; the control path's serial loops catch up on the
+    # architectural records only in front of a plain walk): KLG_FX_STAGED_RETRY=0 sends it straight to the plain body
+    rc, src = check(open(os.path.join(ROOT, "tests", "golden", "pingpong_recorded.klgg")).read(), want_source=True)
+    assert rc == 0 and "while (OFF < cl)" in src and "if (OFF > ctl_at) { const int part_at = OFF;" in src and "for (int sb = OFF; sb < OFF + CC; sb += 8)" in src
+    os.environ["KLG_FX_STAGED_RETRY"] = "0"
+    try:
+        rc, src = check(open(os.path.join(ROOT, "tests", "golden", "pingpong_recorded.klgg")).read(), want_source=True)
+        assert rc == 0 and "while (OFF < cl)" not in src and "plain(s0, cl, false, 0)" in src
+    finally:
+        del os.environ["KLG_FX_STAGED_RETRY"]
 
 
 def test_a_conditional_delay_input_keeps_the_one_lane_kernel():
