@@ -262,6 +262,45 @@ def random_dials(bank, K):
             bank.set_control(k, c, float(rng.uniform(lo, hi)))
 
 
+def run_fx_recorded(K, N, dials=None, tag=""):
+    """f1, the GENERATED path at config 4's size: the unchanged examples/PingPong.k as the facade records it (tests/golden/pingpong_recorded.klgg + the record a
+    fresh object packs to) — the hipRTC-compiled sample-parallel kernel of klg_graph_staged.hpp —, one block per call like a real-time host, against the
+    hand-written kernel's bytes.  200 blocks after 60 untimed ones (a fresh object's dial smoothers have arrived); random dials: see random_dials()."""
+    import torch
+    import klang_amd
+    root = os.path.dirname(os.path.abspath(__file__))
+    prog = open(os.path.join(root, "tests", "golden", "pingpong_recorded.klgg")).read()
+    rec = np.array([int(w, 16) for w in open(os.path.join(root, "tests", "golden", "pingpong_recorded.rec")).read().split()], np.uint32)
+    bank = klang_amd.FxBank(prog, K, max_block=N, initial_record=rec, channels=2)
+    form = bank.graph_form()
+    if dials == "random7":
+        random_dials(bank, K)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    io = torch.rand((K, 2, N), device="cuda", generator=g) - 0.5
+    ts = torch.cuda.Stream()
+    blocks = 200
+    with torch.cuda.stream(ts):
+        st = ts.cuda_stream
+        for _ in range(60):
+            bank.process_device(io.data_ptr(), N, st)
+        torch.cuda.synchronize()
+        bank.timing_begin()
+        t0 = time.perf_counter()
+        for _ in range(blocks):
+            bank.process_device(io.data_ptr(), N, st)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    launches, ms = bank.timing_end()
+    kern_s = 1e-3 * ms / blocks
+    ab = K * N * FX_BYTES_PER_SAMPLE["pingpong"]
+    res = {"name": f"cfg4_pingpong_{K}_recorded{tag}", "workload": ("one instance in seven with random dials: " if dials == "random7" else "") + f"{K} x the unchanged examples/PingPong.k RECORDED (generated kernel klg_fx_staged: {form}), {blocks} blocks of {N} samples, one per call",
+           "value": K * N * blocks / dt, "unit": "instance*samples/s", "ms_per_step": 1e3 * dt / blocks, "steps": blocks, "kernel_ms_mean": 1e3 * kern_s, "finite": bool(torch.isfinite(io).all().item()),
+           "roofline": {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": "not collected",
+                        "kernel": "klg_fx_staged (hipRTC, generated from the recorded program)", "algorithmic_bytes_per_launch": ab, "bytes_per_instance_sample": FX_BYTES_PER_SAMPLE["pingpong"], "per": f"block of {N} samples, one launch"}}
+    bank.close()
+    return res
+
+
 def pmc_child_fx(spec, N):
     """what rocprofv3 wraps for an effect leg: `patch:K[:ctl=value,...]` — the bank with its dials at rest (the spans before the counted ones let a
     PingPong's smoothers converge), spans of PMC_FX_SPAN blocks through klg_fx_render_device"""
@@ -898,6 +937,8 @@ def main():
             leg(run_realtime, "sub2a", args.realtime_margin_voices, N, name="realtime_deadline_with_margin")
             leg(run_fx, "pingpong", 4096, N, tag="_block_by_block", per_block=True)   # the same bank handed over one block per call (a real-time host): nothing runs across a block boundary
             leg(run_noise_notes, 16384, N)
+            leg(run_fx_recorded, 4096, N)                                          # the generated path (f1) at config 4's size: the recorded PingPong.k, one block per call
+            leg(run_fx_recorded, 4096, N, dials="random7", tag="_random_dials")   # ... with taps inside a chunk (tried again in halves and quarters: klg_graph_staged.hpp)
             out["configs"] = configs
             # every leg's roofline in the object the driver keeps: name -> [frac of the bound's peak, kernel ms per block, HBM traffic / algorithmic bytes (PMC) or null,
             # frac on the distinct bytes (Reverb) or null]; the deadline legs and the Noise leg beside them

@@ -1021,8 +1021,8 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			part = false;
 			s += F("\t\tif (ok) OFF += CC; else if (cl == C && CC > %d) CC >>= 1; else {\n", CMIN);
 			if (!catchup.empty()) s += "\t\tif (OFF > ctl_at) { const int part_at = OFF; { const int OFF = ctl_at, CC = part_at - ctl_at; const bool ok = true; (void)ok;\n" + catchup + "\t\t} __syncthreads(); }\n";
-			s += "\t\tplain(s0 + OFF, CC, false, OFF); __syncthreads(); OFF += CC; ctl_at = OFF; }\n";
-			s += "\t\t}\n";
+			s += "\t\tplain(s0 + OFF, CC, false, OFF); OFF += CC; ctl_at = OFF; }\n";
+			s += "\t\t__syncthreads();                                                          // (the next part resets the flag this one's lanes have read)\n\t\t}\n";
 			if (!P.prefix_commit.empty()) s += "\t\tif (cl == C) { const bool ok = true; (void)ok;                                  // the control path's records at the end of the chunk (where a plain walk ended the chunk they are there already: the same values)\n" + P.prefix_commit + "\t\t}\n\t\t__syncthreads();\n";
 			s += "\t\t}\n";
 		}

@@ -123,6 +123,48 @@ def test_staged_pingpong_with_near_taps_ragged_blocks_and_moving_dials(monkeypat
         b.close()
 
 
+@pytest.mark.parametrize("shape", ["16,32", "32,16", "64,8"])
+def test_staged_parts_of_a_failed_chunk_with_a_read_head_that_walks(shape, monkeypatch):
+    """tests/patches/fx_headcomb.klgg — a feedback comb whose read head is placed once per block (prepare(): delay.set(controls[1]), 1 .. 64 samples) and
+    then WALKS with every `delay >> x` (a process() without a set() of its own: the head a part of a chunk starts from is where the part before it left it),
+    its sum through a biquad (a serial loop of the audio path, over the part's samples only).  Delays under a chunk fail the chunk's ring check: it is tried
+    again in halves and quarters, and what no part can take is walked by the plain body (16 x 32: parts of 16 and 8; 32 x 16: of 8; 64 x 8: no parts) —
+    against the same kernel with KLG_FX_STAGED_RETRY=0 (a failed chunk straight to the plain body) and the one-lane-per-instance kernel, bit for bit;
+    ragged blocks, dials moved between blocks."""
+    prog = open(os.path.join(ROOT, "tests", "patches", "fx_headcomb.klgg")).read()
+    g, c = shape.split(",")
+    K = 70
+    monkeypatch.setenv("KLG_FX_STAGED_G", g); monkeypatch.setenv("KLG_FX_STAGED_C", c)
+    banks = []
+    for staged, retry in (("1", "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("KLG_FX_STAGED", staged); monkeypatch.setenv("KLG_FX_STAGED_RETRY", retry)
+        banks.append(klang_amd.FxBank(prog, K, max_block=256, channels=1))
+    f = banks[0].graph_form()
+    assert f["staged"] and f["instances_per_workgroup"] == int(g) and f["samples_per_chunk"] == int(c), f
+    assert banks[1].graph_form()["staged"] and not banks[2].graph_form()["staged"]
+    rng = np.random.default_rng(23)
+    def dial(k, ctl, v):
+        for b in banks:
+            b.set_control(k, ctl, float(v))
+    for k in range(K):
+        dial(k, 0, rng.uniform(0.3, 0.95))
+        dial(k, 1, [rng.uniform(1.0, 64.0), float(rng.integers(1, 40)), rng.uniform(8.0, 20.0)][k % 3])
+    peak = 0.0
+    for bi, n in enumerate([256, 37, 1, 100, 32, 33, 64, 250, 7, 256, 16, 8, 9, 256, 96, 256]):
+        if bi in (3, 7, 10, 13):
+            for k in rng.choice(K, 20, replace=False):
+                dial(int(k), 1, rng.uniform(1.0, 48.0))
+        x = (rng.random((K, 1, n), dtype=np.float32) - 0.5).astype(np.float32)
+        outs = [b.process(x.copy()) for b in banks]
+        for name, o in zip(("a failed chunk straight to the plain body", "one lane per instance"), outs[1:]):
+            bad = np.argwhere(bits(o) != bits(outs[0]))
+            assert len(bad) == 0, f"block {bi} (n = {n}): the parts differ from '{name}' in {len(bad)} samples, first [instance, channel, sample] {bad[0]}"
+        peak = max(peak, float(np.abs(outs[0]).max()))
+    assert peak > 0.3
+    for b in banks:
+        b.close()
+
+
 @pytest.mark.parametrize("shape", ["16,32", "16,16", "8,32", "32,16"])
 def test_staged_pingpong_workgroup_shapes(shape, monkeypatch):
     """The staged kernel for other workgroup shapes (G instances x C samples: KLG_FX_STAGED_G / _C) and without the control path running ahead
