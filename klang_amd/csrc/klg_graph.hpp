@@ -557,6 +557,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			*staged = staged_plan(false);
 			if (staged->ok != has_staged || (staged->ok && staged->G != ring_row)) { staged->ok = false; staged->why = "the plan changed between its two passes"; }     // (cannot happen: the plan does not depend on the ops' text)
 			if (staged->ok) s += staged->source;
+			else s += "// no sample-parallel form (klg_graph_staged.hpp): " + staged->why + "\n";
 		}
 		s += "}\n";
 	}

@@ -881,7 +881,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		const char* stamp_env = getenv("KLG_FX_STAGED_STAMP");                       // (measurement only: workgroup 0 prints what its chunks spent between the barriers, 10 ns units: top of chunk, each level, tail)
 		const bool stamp = stamp_env && stamp_env[0] == '1';
 		s += "\tusing P = PatchGen;\n\textern __shared__ float lds[];\n";
-		if (stamp) s += "\tconst long long tstart = wall_clock64();\n";
+		if (stamp) s += "\tconst long long tstart = wall_clock64();\n\tint pcount[5] = { 0, 0, 0, 0, 0 };                                              // chunks that failed their check; parts that passed; parts cut in two; plain walks; catch-ups of the control path\n";
 		s += "\tuint32_t* const srec = reinterpret_cast<uint32_t*>(lds);                 // [NW][G]: the G records between chunks\n";
 		s += F("\tuint32_t* const srecp = srec + NW * G;                                    // [2][NW][G]: the control path's own copies (it runs a chunk ahead)%s\n", pipelined ? "" : " — unused");
 		s += F("\tfloat* const tile0 = lds + NW * G * %d;                                   // [%d][CH][C][G]: the caller's block, chunk by chunk (two: by the chunk's parity)\n", pipelined ? 3 : 1, two_tiles ? 2 : 1);
@@ -990,6 +990,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			// (a ragged last chunk takes the same way out with nothing to try: one copy of the plain body.  What the part's code needs of the chunk's own values is
 			// taken again rather than kept — the thread index laundered once more, `in` from the tile, the cursors —: kept, they would stay live across every level
 			// of every chunk for the sake of a path that is almost never taken: the recorded PingPong.k's kernel then spilled 36 registers, 9 this way)
+			if (stamp) s += "\t\tif (!ok && cl == C) pcount[0]++;\n";
 			s += "\t\tif (!ok) {\n\t\tint OFF = 0, CC = cl == C ? C / 2 : cl, ctl_at = 0; (void)ctl_at;              // ctl_at: the sample of the chunk the control path's ARCHITECTURAL records stand at\n\t\twhile (OFF < cl) {\n";
 			s += "\t\tint tv = threadIdx.x; asm volatile(\"\" : \"+v\"(tv));\n";
 			s += "\t\tconst int t = tv, tp = t < NTP ? t : 0, ps = tp / G, pg = tp % G, wv = t >> 6, sw = wv - SW0, ln = t & 63; (void)ps; (void)pg; (void)sw; (void)ln; (void)wv;\n";
@@ -1019,6 +1020,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			std::string catchup;
 			if (pipelined) for (int lv = 1; lv <= pmax; lv += 2) catchup += block(true, lv);
 			part = false;
+			if (stamp) s += F("\t\tif (ok) pcount[1]++; else if (cl == C && CC > %d) pcount[2]++; else { if (cl == C) pcount[3]++; if (OFF > ctl_at) pcount[4]++; }\n", CMIN);
 			s += F("\t\tif (ok) OFF += CC; else if (cl == C && CC > %d) CC >>= 1; else {\n", CMIN);
 			if (!catchup.empty()) s += "\t\tif (OFF > ctl_at) { const int part_at = OFF; { const int OFF = ctl_at, CC = part_at - ctl_at; const bool ok = true; (void)ok;\n" + catchup + "\t\t} __syncthreads(); }\n";
 			s += "\t\tplain(s0 + OFF, CC, false, OFF); OFF += CC; ctl_at = OFF; }\n";
@@ -1034,6 +1036,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "\t}\n";
 
 		if (stamp) s += "\tif (t == 0 && blockIdx.x == 0) { printf(\"staged stamps (10 ns): head %lld |\", thead); for (int i = 0; i < 16; i++) printf(\" %lld\", tacc[i]); printf(\"\\n\"); }\n";
+		if (stamp && retry) s += "\tif (t == 0 && blockIdx.x == 0) printf(\"staged parts: %d chunks failed their check, %d parts passed, %d cut in two, %d walked by the plain body, %d control catch-ups\\n\", pcount[0], pcount[1], pcount[2], pcount[3], pcount[4]);\n";
 		s += "\t}                                                                          // (the next block of the span)\n";
 		s += "\tfor (int i = t; i < NW * G; i += NT) if (k0 + (i % G) < a.K && patch_stores<P>(i / G)) a.state[(size_t)(i / G) * a.kpad + k0 + (i % G)] = srec[i];\n";
 		s += "#undef SL\n#undef SLP\n}\n";

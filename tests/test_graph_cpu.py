@@ -391,3 +391,18 @@ def test_code_objects_are_cached_on_disk(tmp_path):
     assert rc == 0 and again > 2 * warm
     rc, warm2 = run({})
     assert rc == 0 and warm2 < 0.25 * cold
+
+
+def test_random_effect_programs_compile_for_gfx950_with_a_staged_form():
+    """tests/fx_fuzz.py: the random effect programs test_gpu_fx_fuzz.py runs through both generated kernels — here that they parse, get the sample-parallel form
+    (with the parts of a failed chunk) and compile for gfx950, without a device."""
+    from fx_fuzz import program                      # (tests/ is on sys.path: conftest.py / rootdir)
+    for seed, ch in ((0, 2), (5, 2), (14, 1)):
+        prog, what, _ = program(seed, channels=ch)
+        rc, src = check(prog, want_source=True)
+        assert rc == 0, (seed, what, src[:2000])
+        assert "klg_fx_staged" in src and "while (OFF < cl)" in src and "no sample-parallel form" not in src, (seed, what)
+    # a line read by process() that is no longer than 1,024 samples keeps the one-lane kernel, and the source says why
+    prog, _, _ = program(0)
+    rc, src = check(prog.replace("delay 4096", "delay 512"), want_source=True)
+    assert rc == 0 and "// no sample-parallel form (klg_graph_staged.hpp): a Delay shorter than a chunk's inputs" in src and "klg_fx_staged" not in src
