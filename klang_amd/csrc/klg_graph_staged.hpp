@@ -770,7 +770,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 				emit_ops(pf, lv, -1, "t", body, predecl);
 				if (!pf) {
 					if (lv > guard_level && !deferred.empty()) { for (const std::string& d : deferred) code += d; deferred.clear(); }
-					if (lv == guard_level) body += "\t\tif (bad) *flag = 1;\n";
+					if (lv == guard_level) body += "\t\tif (bad && k0 + pg < a.K) *flag = 1;                                    // (the lanes past the bank's last instance — a last workgroup that is not full — have no say: their dials are zeros, their taps sit on the cursor)\n";
 					if (lv == out_level) {
 						body += F("\t\ttile[(0 * C + ps) * G + pg] = r%d;\n", g.ret);
 						if (CH == 2) body += F("\t\ttile[(1 * C + ps) * G + pg] = r%d;\n", g.ret_r);

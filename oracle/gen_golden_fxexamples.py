@@ -74,6 +74,8 @@ FX["fx_ownlines"] = [(2.0, 30.0), (300.0, 9000.0), (0.0, 0.55), (0.2, 1.0)]
 # examples/Vocoder.k (added last): 22 band-pass pairs, followers, saws; 27 controls (5 dials + 22 METERs that process() feeds: `... >> follower[b] >> controls[5 + b]`); prepare() — Pitch -> Frequency,
 # power(), constants to integer powers — stays host code; `_boost(float)` is a plain C function (-DKLANG_GPU_TRACE_FLOAT)
 FX["fx_vocoder"] = [(40.0, 80.0), (1.0, 3.5), (0.01, 0.1), (0.01, 0.1), (0.5, 14.0)]
+# tests/patches/fx_short.k (OUR OWN effect, added last): two feedback lines read 0.2 .. 120 samples behind the cursor — inside a chunk of the sample-parallel kernel
+FX["fx_ownshort"] = [(0.1, 0.9), (0.5, 40.0), (0.0, 0.5), (0.3, 1.6)]      # (the last two — Bend, Length — change mid-run on every other instance)
 SHAPE = {"fx_patterns": dict(K=4, blocks=110),       # name -> instances / blocks (default 9 / 24)
          "fx_topreverb": dict(K=9, blocks=64),
          "fx_reverb2": dict(K=9, blocks=40),

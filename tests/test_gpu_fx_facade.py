@@ -149,3 +149,25 @@ def test_own_comb_effect_with_a_resizable_delay_and_a_lagrange_tap(tmp_path):
     exact = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
     print(f"bit-exact samples {100 * exact:.2f} %, max abs err {np.abs(got - ref).max():.3e}")
     assert exact == 1.0 and np.abs(ref).max() > 0.1
+
+
+def test_own_effect_with_taps_inside_the_chunk_of_the_sample_parallel_kernel(tmp_path, monkeypatch, capfd):
+    """tests/patches/fx_short.k (ours): two feedback lines read with tap(float) BEFORE the sample's input() at 0.2 .. 120 samples behind the cursor (a smoothed
+    dial bent by an LFO) — mostly inside the 32 samples the generated sample-parallel kernel computes side by side: its chunks fail their ring check and are
+    tried again in halves and quarters, what no part can take is walked by the plain body, the control path (smoother, LFO) catching up in front of a walk
+    (klg_graph_staged.hpp).  Nine instances, dials changed mid-run, bit for bit against the GENUINE header — and the kernel's own counters
+    (KLG_FX_STAGED_STAMP=1) say that those ways were taken."""
+    import re
+    got, ref = run_effect("fx_ownshort", tmp_path, own=True)
+    bad = np.argwhere(got.view(np.uint32) != ref.view(np.uint32))
+    assert len(bad) == 0, f"{len(bad)} of {got.size} samples differ from the genuine header, first [block, instance, channel, sample] {bad[0]}, max abs err {np.abs(got - ref).max()}"
+    assert np.abs(ref).max() > 0.5
+    capfd.readouterr()
+    monkeypatch.setenv("KLG_FX_STAGED_STAMP", "1")
+    got, _ = run_effect("fx_ownshort", tmp_path, own=True)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    rows = re.findall(r"staged parts: (\d+) chunks failed their check, (\d+) parts passed, (\d+) cut in two, (\d+) walked by the plain body, (\d+) control catch-ups", capfd.readouterr().out)
+    assert rows, "the recorded effect did not run the sample-parallel kernel"
+    total = np.array(rows, dtype=np.int64).sum(axis=0)
+    print(f"fx_ownshort over {len(rows)} launches: failed chunks {total[0]}, parts passed {total[1]}, cut in two {total[2]}, plain walks {total[3]}, control catch-ups {total[4]}")
+    assert (total[:4] > 0).all(), total

@@ -37,7 +37,7 @@ def test_example_effect_with_one_lane_per_instance_is_bit_exact(name, tmp_path, 
     assert len(bad) == 0, f"{len(bad)} of {got.size} samples differ, first at {bad[0]}, max abs err {np.abs(got - ref).max()}"
 
 
-@pytest.mark.parametrize("name", ["fx_owntape", "fx_ownfdn", "fx_owncomb"])
+@pytest.mark.parametrize("name", ["fx_owntape", "fx_ownfdn", "fx_owncomb", "fx_ownlines", "fx_ownshort"])
 def test_own_effect_with_one_lane_per_instance_is_bit_exact(name, tmp_path, monkeypatch):
     monkeypatch.setenv("KLG_FX_STAGED", "0")
     got, ref = run_effect(name, tmp_path, own=True)

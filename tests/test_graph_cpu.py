@@ -302,7 +302,7 @@ def test_the_recorded_config_4_effects_get_a_staged_form():
     `if` is taken outside it, its check counting under the branch's condition alone.  KLG_FX_STAGED=0 leaves the one-lane kernel alone;
     KLG_FX_STAGED_BATCH=0 writes every read in one piece."""
     for name, needles in (("pingpong_recorded", ("extern \"C\" __global__", "klg_fx_staged", "beside the", "basic_sine_of(", "basic_sine_arg(L.n2)", "staged_process_fetch(RingS{ (const char*)(ring0 + ", "staged_process_finish(tf", "xc_d0t = xn_d0t;", "plain(s0 + OFF, CC, false, OFF)", "a part of the chunk, level 0")),
-                          ("reverb_recorded", ("klg_fx_staged", "staged_tap_stereo_fetch(RingS{", "bad |= ((r", "asm volatile(\"\" ::: \"memory\");", "staged_tap_stereo_finish(tf", "biquad_process(L.n", "if (bad) *flag = 1;", "plain(s0 + OFF, CC, false, OFF)", "a part of the chunk, level 0"))):
+                          ("reverb_recorded", ("klg_fx_staged", "staged_tap_stereo_fetch(RingS{", "bad |= ((r", "asm volatile(\"\" ::: \"memory\");", "staged_tap_stereo_finish(tf", "biquad_process(L.n", "if (bad && k0 + pg < a.K) *flag = 1;", "plain(s0 + OFF, CC, false, OFF)", "a part of the chunk, level 0"))):
         prog = open(os.path.join(ROOT, "tests", "golden", name + ".klgg")).read()
         rc, src = check(prog, want_source=True)
         assert rc == 0, src
