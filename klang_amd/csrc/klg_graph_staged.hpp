@@ -910,6 +910,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "\t\tfor (int q = 0; q < count; q++) {\n\t\t\tconst float in0 = tile[(0 * C + tq0 + q) * G + ln], in1 = CH > 1 ? tile[(1 * C + tq0 + q) * G + ln] : 0.f;\n\t\t\tfloat out0 = 0.f, out1 = 0.f;\n";
 		s += "\t\t\tP::sample(L, c, in0, in1, out0, out1);\n\t\t\ttile[(0 * C + tq0 + q) * G + ln] = out0;\n\t\t\tif (CH > 1) tile[(1 * C + tq0 + q) * G + ln] = out1;\n\t\t}\n";
 		s += "\t\tP::end(L, rec);\n#pragma unroll\n\t\tfor (int w = 0; w < NW; w++) if (patch_stores<P>(w)) srec[w * G + ln] = rec.w[w];\n\t};\n";
+		if (retry) s += "\tint part_cc = C / 2;                                                          // the largest part that passed in the last chunk that failed its check (0: none)\n";
 		s += "\tconst int nblk = a.blocks > 1 ? a.blocks : 1;\n\tfor (int blk = 0; blk < nblk; blk++) {                                          // Effect::process(buffer), block after block (klang.h:4208-4216)\n";
 		s += "\tsamples0 = a.samples + (unsigned long long)blk * (unsigned long long)a.n; io = a.io + (size_t)blk * a.block_stride; cp.samples = cs.samples = samples0;\n";
 		s += "\tif (a.rand) { cp.rand = a.rand + (size_t)blk * (size_t)a.K + (size_t)(k0 + pg < a.K ? k0 + pg : 0); cs.rand = a.rand + (size_t)blk * (size_t)a.K + (size_t)(k0 + sg < a.K ? k0 + sg : 0); }   // this block's columns of the span's draws\n";
@@ -957,7 +958,10 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		s += "#pragma unroll\n\t\tfor (int j = 0; j < CH; j++) { const int i = tp + j * NTP, row = i / C, q = i % C, gi = row / CH, ch = row % CH; if (t < NTP) { tile[(ch * C + q) * G + gi] = nx[j];" + std::string(any_near ? " incopy[(ch * C + q) * G + gi] = nx[j];" : "") + " } }\n";
 		s += "\t\tif (t == 0) *flag = 0;\n\t\t__syncthreads();\n";
 		s += "\t\tif (s0 + C < a.n) fetch(s0 + C);\n";
-		s += "\t\tbool ok = cl == C;\n\t\tint bad = 0; (void)bad;\n";
+		// (Leaving out the attempt on the WHOLE chunk after two failures in a row — taps that stay inside the chunk fail it every time — was measured and lost: the
+		//  attempt's ring reads are what brings the parts' rows into the cache: fx_short.k at 12 / 22 samples 60.2 -> 62.6 / 44.7 -> 46.0 us, PingPong.k random dials 72.7 -> 80.7)
+		if (retry) s += "\t\tconst bool probe = ((s0 / C) & 7) == 0; (void)probe;\n\t\tbool ok = cl == C;\n\t\tint bad = 0; (void)bad;\n";
+		else s += "\t\tbool ok = cl == C;\n\t\tint bad = 0; (void)bad;\n";
 		s += "\t\tconst bool pre = s0 + 2 * C <= a.n; const int parc = (s0 / C) & 1, parn = parc ^ 1; (void)pre; (void)parc; (void)parn;\n";
 		s += "\t\tconst float in0 = tile[(0 * C + ps) * G + pg], in1 = CH > 1 ? tile[(1 * C + ps) * G + pg] : 0.f; (void)in0; (void)in1;\n";
 		s += "\t\tLp.sidx = s0 + ps;\n";
@@ -991,10 +995,15 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			// taken again rather than kept — the thread index laundered once more, `in` from the tile, the cursors —: kept, they would stay live across every level
 			// of every chunk for the sake of a path that is almost never taken: the recorded PingPong.k's kernel then spilled 36 registers, 9 this way)
 			if (stamp) s += "\t\tif (!ok && cl == C) pcount[0]++;\n";
-			s += "\t\tif (!ok) {\n\t\tint OFF = 0, CC = cl == C ? C / 2 : cl, ctl_at = 0; (void)ctl_at;              // ctl_at: the sample of the chunk the control path's ARCHITECTURAL records stand at\n\t\twhile (OFF < cl) {\n";
+			// (the parts start at the size that got through the last failed chunk — none: the plain body at once, as if there were no parts — and one chunk in
+			//  eight starts at halves again: what a short comb costs is its parts, not the attempts that come before them — fx_short.k, 4,096 instances, taps 5 / 12
+			//  samples behind the cursor: 131.8 -> 116.6 / 60.2 -> 55.9 us per block; a failed chunk straight to the plain body: 110.6 / 108.7)
+			s += "\t\tif (!ok) {\n\t\tconst int start_cc = probe ? C / 2 : part_cc;\n";
+			s += "\t\tconst bool try_parts = cl == C && start_cc != 0;\n";
+			s += "\t\tint OFF = 0, CC = try_parts ? start_cc : cl, ctl_at = 0, best = 0; (void)ctl_at; (void)best;   // ctl_at: the sample of the chunk the control path's ARCHITECTURAL records stand at\n\t\twhile (OFF < cl) {\n";
 			s += "\t\tint tv = threadIdx.x; asm volatile(\"\" : \"+v\"(tv));\n";
 			s += "\t\tconst int t = tv, tp = t < NTP ? t : 0, ps = tp / G, pg = tp % G, wv = t >> 6, sw = wv - SW0, ln = t & 63; (void)ps; (void)pg; (void)sw; (void)ln; (void)wv;\n";
-			s += "\t\tif (t == 0) *flag = 0;\n\t\t__syncthreads();\n\t\tbool ok = cl == C; int bad = 0; (void)bad;\n";
+			s += "\t\tif (t == 0) *flag = 0;\n\t\t__syncthreads();\n\t\tbool ok = try_parts; int bad = 0; (void)bad;\n";
 			s += "\t\tconst float in0 = tile[(0 * C + ps) * G + pg], in1 = CH > 1 ? tile[(1 * C + ps) * G + pg] : 0.f; (void)in0; (void)in1;\n";
 			for (size_t nd = 0; nd < NN; nd++) if (g.nodes[nd] == N_DELAY) {
 				const int SZ = g.arg((int)nd), w0 = g.node_word0((int)nd);
@@ -1020,11 +1029,11 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			std::string catchup;
 			if (pipelined) for (int lv = 1; lv <= pmax; lv += 2) catchup += block(true, lv);
 			part = false;
-			if (stamp) s += F("\t\tif (ok) pcount[1]++; else if (cl == C && CC > %d) pcount[2]++; else { if (cl == C) pcount[3]++; if (OFF > ctl_at) pcount[4]++; }\n", CMIN);
-			s += F("\t\tif (ok) OFF += CC; else if (cl == C && CC > %d) CC >>= 1; else {\n", CMIN);
+			if (stamp) s += F("\t\tif (ok) pcount[1]++; else if (try_parts && CC > %d) pcount[2]++; else { if (cl == C) pcount[3]++; if (OFF > ctl_at) pcount[4]++; }\n", CMIN);
+			s += F("\t\tif (ok) { OFF += CC; best = CC > best ? CC : best; } else if (try_parts && CC > %d) CC >>= 1; else {\n", CMIN);
 			if (!catchup.empty()) s += "\t\tif (OFF > ctl_at) { const int part_at = OFF; { const int OFF = ctl_at, CC = part_at - ctl_at; const bool ok = true; (void)ok;\n" + catchup + "\t\t} __syncthreads(); }\n";
 			s += "\t\tplain(s0 + OFF, CC, false, OFF); OFF += CC; ctl_at = OFF; }\n";
-			s += "\t\t__syncthreads();                                                          // (the next part resets the flag this one's lanes have read)\n\t\t}\n";
+			s += "\t\t__syncthreads();                                                          // (the next part resets the flag this one's lanes have read)\n\t\t}\n\t\tif (cl == C) part_cc = best;\n";
 			if (!P.prefix_commit.empty()) s += "\t\tif (cl == C) { const bool ok = true; (void)ok;                                  // the control path's records at the end of the chunk (where a plain walk ended the chunk they are there already: the same values)\n" + P.prefix_commit + "\t\t}\n\t\t__syncthreads();\n";
 			s += "\t\t}\n";
 		}

@@ -115,3 +115,39 @@ def test_every_way_through_the_parts_of_a_failed_chunk_is_taken(monkeypatch, cap
     with capfd.disabled():
         print(f"parts of failed chunks over {launches} launches: failed chunks {total[0]}, parts passed {total[1]}, cut in two {total[2]}, plain walks {total[3]}, control catch-ups {total[4]}")
     assert (total[:4] > 50).all() and total[4] >= 1, total
+
+
+@pytest.mark.parametrize("seed,n", [(2, 96), (6, 256), (10, 80), (16, 128), (18, 33), (21, 256)])
+def test_random_effect_program_a_span_in_one_launch_equals_one_lane_block_by_block(seed, n, monkeypatch):
+    """klg_fx_render_device on the staged form — ONE launch walks the span's blocks, prepare() at the head of each (a read head placed in prepare() is placed
+    again), the parts of failed chunks inside it — against the one-lane kernel fed the same blocks one call at a time; dials moved between the spans;
+    the records both leave are the same words."""
+    import torch
+    prog, what, dials = program(seed)
+    K = 40
+    monkeypatch.setenv("KLG_FX_STAGED", "1")
+    staged = klang_amd.FxBank(prog, K, max_block=n, channels=2)
+    assert staged.graph_form()["staged"]
+    monkeypatch.setenv("KLG_FX_STAGED", "0")
+    lane = klang_amd.FxBank(prog, K, max_block=n, channels=2)
+    rng = np.random.default_rng(2000 + seed)
+    def dial(k, c, v):
+        staged.set_control(k, c, float(v)); lane.set_control(k, c, float(v))
+    for k in range(K):
+        dial(k, 0, rng.uniform(0.1, 0.9)); dial(k, 1, rng.uniform(1.0, 40.0)); dial(k, 2, rng.uniform(0.0, 12.0) if k % 2 else 0.0); dial(k, 3, rng.uniform(0.0, 1.0))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for si, blocks in enumerate((5, 1, 7, 3)):
+            x = (torch.from_numpy(rng.random((blocks, K, 2, n), dtype=np.float32)) - 0.5).cuda()
+            ya, yb = x.clone(), x.clone()
+            staged.render_device(ya.data_ptr(), blocks, n, st.cuda_stream)
+            for blk in range(blocks):
+                lane.process_device(yb[blk].data_ptr(), n, st.cuda_stream)
+            st.synchronize()
+            bad = (ya.view(torch.int32) != yb.view(torch.int32)).nonzero()
+            assert len(bad) == 0, f"seed {seed} ({what}), span {si} ({blocks} blocks of {n}): {len(bad)} samples differ, first [block, instance, channel, sample] {bad[0].tolist()}"
+            for k in rng.choice(K, 10, replace=False):
+                dial(int(k), 1, rng.uniform(1.0, 40.0))
+    for k in (0, 1, K - 1):
+        assert np.array_equal(staged.download_record(k), lane.download_record(k)), f"seed {seed} ({what}): instance {k}'s record"
+    staged.close(); lane.close()
