@@ -2160,7 +2160,11 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 	void ensure_gpu() {
 		if (gpu) return;
 		gpu::close_log();
-		if (kVariants && notes.count && notes.proto_lo) { if (slot_variant.size() != notes.count) slot_variant.assign(notes.count, -1); return; }   // (banks are made per variant, at the first event that needs one)
+		if (kVariants && notes.count && notes.proto_lo) {                       // (banks are made per variant, at the first event that needs one)
+			if (slot_variant.size() != notes.count) slot_variant.assign(notes.count, -1);
+			if (variants.empty()) if (const char* e = std::getenv("KLANG_MI355_MONO_MIX")) if (mono_synth() && (!std::strcmp(e, "last") || !std::strcmp(e, "reference"))) mix = gpu::LastActiveVoice;
+			return;
+		}
 		if (!notes.count) { std::fprintf(stderr, "klang-mi355: Synth has no notes (call notes.add<T>(n))\n"); std::abort(); }
 		const int patch = notes.items[0].b.patch;
 		if (const gpu::GraphLayout* g = notes.items[0].graph) {              // recorded process(): compiled for gfx950 now (hipRTC)
@@ -2199,7 +2203,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		v.bank = klg_synth_create_graph(L->program.c_str(), 1, (int)notes.count, fs.f, 1024);
 		if (!v.bank) fail("klg_synth_create_graph (note variant)");
 		for (size_t k = 0; k < L->tables.size(); k++) if (klg_table_upload(v.bank, L->tables[k].data(), (int)L->tables[k].size(), 0) != (int)k + 1) fail("klg_table_upload (Table read by process())");
-		if (mix != gpu::Sum) { std::fprintf(stderr, "klang-mi355: KLANG_GPU_NOTE_VARIANTS renders every variant's bank into the block: only the summing mix\n"); std::abort(); }
+		if (klg_synth_set_mix_mode(v.bank, (int)mix)) fail("klg_synth_set_mix_mode (note variant)");   // (LastActiveVoice: the bank's own last sounding slot; render_voices() keeps the block of the bank that holds the synth's last one)
 		v.words.assign(klg_synth_state_bytes(v.bank) / 4, 0u); v.stages.assign(notes.count, (uint8_t)klg::ST_OFF);
 		variants.push_back(v);
 		if (!gpu) gpu = v.bank;                                               // (what asks a bank for the number of controls)
@@ -2296,14 +2300,22 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		sync_controls();
 		if (kVariants && notes.proto_lo) {                                       // every variant's bank adds its sounding voices to the block
 			std::vector<float> tmp;
+			// a mono Synth with mix = LastActiveVoice (klang.h:4450-4457: every sounding note overwrites the block in slot order): the block is the one of
+			// the bank that holds the synth's LAST sounding slot — the stages are the host's own at this point (events run on the host mirror, the end of
+			// the last block came back in refresh_stages()); every other bank renders too (its notes' state moves on) into samples nobody hears.
+			int heard = -1;
+			if (mix == gpu::LastActiveVoice) for (unsigned n = 0; n < notes.count; n++) if (notes[(int)n]->stage != NOTEBASE::Off && slot_variant[n] >= 0) heard = slot_variant[n];
+			std::vector<float> unheard; float* sink[2] = { nullptr, nullptr };
+			if (mix == gpu::LastActiveVoice) { unheard.assign((size_t)channels * (size_t)length, 0.f); for (int c = 0; c < channels && c < 2; c++) sink[c] = unheard.data() + (size_t)c * (size_t)length; }
 			for (size_t v = 0; v < variants.size(); v++) {
+				float* const* dst = (mix == gpu::LastActiveVoice && (int)v != heard) ? sink : buffers;
 				if (per_voice_sink) {
 					const size_t row = (size_t)klg_synth_note_channels(variants[v].bank) * (size_t)length;
 					tmp.assign(row * notes.count, 0.f);
-					if (klg_process_voices(variants[v].bank, tmp.data(), buffers, channels, length)) fail("klg_process_voices");
+					if (klg_process_voices(variants[v].bank, tmp.data(), dst, channels, length)) fail("klg_process_voices");
 					for (unsigned n = 0; n < notes.count; n++) if (slot_variant[n] == (int)v) std::memcpy(per_voice_sink + (size_t)n * row, tmp.data() + (size_t)n * row, row * sizeof(float));
 				}
-				else if (klg_process(variants[v].bank, buffers, channels, length, nullptr)) fail("klg_process");
+				else if (klg_process(variants[v].bank, dst, channels, length, nullptr)) fail("klg_process");
 			}
 			if (per_voice_sink) for (unsigned n = 0; n < notes.count; n++) if (slot_variant[n] < 0) std::memset(per_voice_sink + (size_t)n * (size_t)length * (variants.empty() ? 1 : (size_t)klg_synth_note_channels(variants[0].bank)), 0, (size_t)length * (variants.empty() ? 1 : (size_t)klg_synth_note_channels(variants[0].bank)) * sizeof(float));
 			refresh_stages();

@@ -88,6 +88,10 @@ def main():
     # 4450-4457) — the shipped SuperSaw.k and FM.k are such Synths — on the polyphonic scenarios of the per-voice fixtures
     synth_host("ref_host_synth_supersaw", os.path.join(GOLDEN, "supersaw_poly.scn"), "host_synth_supersaw")
     synth_host("ref_host_synth_fm", os.path.join(GOLDEN, "fm3_poly.scn"), "host_synth_fm")
+    # (round 5) Subtractive/Modular.k and Additive/Inheritance.k are mono Synths too; their notes' bodies follow host state (a Menu control read in on()), so the
+    # scenarios of their per-voice fixtures (oracle/gen_golden_examples.py: the menu moves while notes start) have notes of different bodies sounding together
+    synth_host("ref_host_synth_modular", os.path.join(GOLDEN, "ex_modular.scn"), "host_synth_modular")
+    synth_host("ref_host_synth_inheritance", os.path.join(GOLDEN, "ex_inheritance.scn"), "host_synth_inheritance")
     # Synths with a post-processing process() of their own (tests/patches/post_synth.k), control changes mid-run
     rng = np.random.default_rng(20250928)
     for patch, binary in (("host_synth_postmono", "ref_host_synth_postmono"), ("host_synth_poststereo", "ref_host_synth_poststereo")):

@@ -123,7 +123,9 @@ def run_synth_host(exe, scn, tmp_path, env=None):
     return np.frombuffer(d, np.float32, B * 2 * N, 16).reshape(B, 2, N), np.frombuffer(d, np.uint8, B * P, 16 + B * 2 * N * 4).reshape(B, P)
 
 
-@pytest.mark.parametrize("binary,scn,golden", [("facade_host_synth_supersaw", "supersaw_poly", "host_synth_supersaw"), ("facade_host_synth_fm", "fm3_poly", "host_synth_fm")])
+@pytest.mark.parametrize("binary,scn,golden", [("facade_host_synth_supersaw", "supersaw_poly", "host_synth_supersaw"), ("facade_host_synth_fm", "fm3_poly", "host_synth_fm"),
+                                                 # (notes of different recorded bodies sound together, one bank per body: the block is the bank's that holds the synth's last sounding slot)
+                                                 ("facade_host_synth_modular", "ex_modular", "host_synth_modular"), ("facade_host_synth_inheritance", "ex_inheritance", "host_synth_inheritance")])
 def test_mono_synth_last_sounding_note_wins_like_the_reference(binary, scn, golden, tmp_path):
     """Shipped SuperSaw.k / FM.k are mono klang::Synths: in the reference their block is the LAST sounding note alone (klang.h:4299).  With
     gpu::LastActiveVoice (here: KLANG_MI355_MONO_MIX=reference) the facade returns exactly that; one voice, so bit for bit."""
