@@ -953,7 +953,7 @@ def main():
             out["roofline"]["legs_columns"] = ["frac (of HBM peak for cfg4_*, of fp32 peak otherwise)", "kernel ms per block", "PMC traffic / algorithmic bytes", "frac on distinct bytes"]
             out["deadline"] = {c["name"]: {"voices": c["voices"], "p99_ms": round(c["p99_ms"], 3), "max_ms": round(c["max_ms"], 3), "worst_block": c["worst_block"], "release_max_ms": round(c["release_max_ms"], 3),
                                            "within_90_percent": c["every_block_within_90_percent_of_the_deadline"],
-                                           "c_host": {k: c["c_host"].get(k) for k in ("p99_ms", "max_ms", "worst_block", "release_max_ms", "every_block_within_90_percent_of_the_deadline", "error") if k in c.get("c_host", {})}}
+                                           "c_host": {k: c["c_host"].get(k) for k in ("p99_ms", "max_ms", "worst_block", "release_max_ms", "every_block_within_90_percent_of_the_deadline", "blocks_over_90_percent", "of_them_the_devices", "device_max_ms", "error") if k in c.get("c_host", {})}}
                                for c in configs if c.get("name", "").startswith("realtime") and "p99_ms" in c}
             for c in configs:
                 if c.get("name", "").startswith("noise_note") and "value" in c:

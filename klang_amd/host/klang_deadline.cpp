@@ -4,9 +4,12 @@
 // (klg_script_*), then `blocks` consecutive blocks of n samples, each: clear the [2][n] mix, klg_process_device, hipStreamSynchronize — timed with
 // CLOCK_MONOTONIC around the three; then every voice released and 44 more blocks (all voices in their release ramp: the worst case).  The process
 // is pinned to one core and its memory locked; nothing allocates inside the loop.  Prints ONE JSON line: p50 / p99 / max, the index of the worst
-// block and the ten largest block times with their indices (so that a spike can be told from a pattern).
+// block and the ten largest block times with their indices (so that a spike can be told from a pattern).  Every block is also bracketed by two HIP events on its
+// stream: the ten largest come with the time the DEVICE spent between them, so that a late block is either the device's (both large) or the wake-up of the waiting
+// host thread's (wall clock large, device time ordinary).  --spin 1 waits by polling (hipDeviceScheduleSpin) instead of sleeping on the interrupt; --rt 1 asks for SCHED_FIFO (and says whether it got it).  The wall clock of a
+// block is also split where the last call that queues work returns: a late block's host time is either before that point (queueing) or after it (waiting).
 // Build: hipcc -O2 -std=c++17 klang_deadline.cpp -I../../include -L.. -lklang_mi355 -Wl,-rpath,'$ORIGIN/..' -o klang_deadline   (klang_amd/csrc/build.sh does)
-// Run:   klang_deadline [--voices V] [--blocks B] [--n N] [--patch id] [--notes P] [--cpu c]
+// Run:   klang_deadline [--voices V] [--blocks B] [--n N] [--patch id] [--notes P] [--cpu c] [--spin 0|1] [--rt 0|1]
 #include <hip/hip_runtime.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -26,16 +29,19 @@ static double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 
 #define HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) DIE("%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
 int main(int argc, char** argv) {
-	long long V = 1 << 20; int blocks = 2000, n = 256, patch = KLG_PATCH_SUB2A, notes = 32, cpu = -1;
+	long long V = 1 << 20; int blocks = 2000, n = 256, patch = KLG_PATCH_SUB2A, notes = 32, cpu = -1, spin = 0, rt = 0;
 	for (int i = 1; i + 1 < argc; i += 2) {
 		if (!strcmp(argv[i], "--voices")) V = atoll(argv[i + 1]); else if (!strcmp(argv[i], "--blocks")) blocks = atoi(argv[i + 1]);
 		else if (!strcmp(argv[i], "--n")) n = atoi(argv[i + 1]); else if (!strcmp(argv[i], "--patch")) patch = atoi(argv[i + 1]);
 		else if (!strcmp(argv[i], "--notes")) notes = atoi(argv[i + 1]); else if (!strcmp(argv[i], "--cpu")) cpu = atoi(argv[i + 1]);
+		else if (!strcmp(argv[i], "--spin")) spin = atoi(argv[i + 1]); else if (!strcmp(argv[i], "--rt")) rt = atoi(argv[i + 1]);
 		else DIE("unknown option %s", argv[i]);
 	}
 	if (cpu < 0) cpu = sched_getcpu();
 	cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpu, &set);
 	const bool pinned = sched_setaffinity(0, sizeof set, &set) == 0;
+	bool fifo = false; if (rt) { sched_param sp; memset(&sp, 0, sizeof sp); sp.sched_priority = 50; fifo = sched_setscheduler(0, SCHED_FIFO, &sp) == 0; }
+	if (spin) HIP(hipSetDeviceFlags(hipDeviceScheduleSpin));                 // (before the first call that makes the context)
 	const int base = 1 << 20;                                                // distinct note records (pitch by voice); voices beyond share them
 	klg_synth* bank = klg_synth_create(patch, (int)(V / notes), notes, 48000.f, n);
 	if (!bank) DIE("klg_synth_create: %s", klg_last_error());
@@ -61,16 +67,20 @@ int main(int argc, char** argv) {
 	float* d_mix = nullptr; hipStream_t st = nullptr;
 	HIP(hipMalloc((void**)&d_mix, (size_t)2 * n * sizeof(float)));
 	HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-	std::vector<double> t((size_t)blocks), r(44);
+	std::vector<double> t((size_t)blocks), r(44); std::vector<float> g((size_t)blocks, 0.f); std::vector<double> q((size_t)blocks, 0.0); double queued_at = 0.0;
+	hipEvent_t e0, e1; HIP(hipEventCreate(&e0)); HIP(hipEventCreate(&e1));
 	const bool locked = mlockall(MCL_CURRENT | MCL_FUTURE) == 0;
 	auto block = [&](int script_block) -> int {
+		HIP(hipEventRecord(e0, st));
 		HIP(hipMemsetAsync(d_mix, 0, (size_t)2 * n * sizeof(float), st));
 		if (script_block >= 0) KLG(klg_script_play_device(script, script_block, d_mix, n, st)); else KLG(klg_process_device(bank, d_mix, n, st));
+		HIP(hipEventRecord(e1, st));
+		queued_at = now_ms();
 		HIP(hipStreamSynchronize(st));
 		return 0;
 	};
 	if (block(0)) return 1;
-	for (int b = 0; b < blocks; b++) { const double t0 = now_ms(); if (block(-1)) return 1; t[(size_t)b] = now_ms() - t0; }
+	for (int b = 0; b < blocks; b++) { const double t0 = now_ms(); if (block(-1)) return 1; t[(size_t)b] = now_ms() - t0; q[(size_t)b] = queued_at - t0; HIP(hipEventElapsedTime(&g[(size_t)b], e0, e1)); }   // (the clock stops before the events are read)
 	if (block(1)) return 1;
 	for (int b = 0; b < 44; b++) { const double t0 = now_ms(); if (block(-1)) return 1; r[(size_t)b] = now_ms() - t0; }
 	std::vector<float> mix((size_t)2 * n);
@@ -82,11 +92,19 @@ int main(int argc, char** argv) {
 	std::vector<double> s = t; std::sort(s.begin(), s.end());
 	const double deadline = 1e3 * n / 48000.0, p50 = s[s.size() / 2], p99 = s[std::min(s.size() - 1, (size_t)(0.99 * (double)s.size()))], mx = s.back();
 	const double rmax = *std::max_element(r.begin(), r.end());
-	printf("{\"host\": \"klang_deadline (C++, pinned to cpu %d: %s, memory locked: %s)\", \"voices\": %lld, \"blocks\": %d, \"n\": %d, \"deadline_ms\": %.4f, \"p50_ms\": %.4f, \"p99_ms\": %.4f, \"max_ms\": %.4f, \"worst_block\": %d, "
+	printf("{\"host\": \"klang_deadline (C++, pinned to cpu %d: %s, memory locked: %s, waits by %s, %s)\", \"voices\": %lld, \"blocks\": %d, \"n\": %d, \"deadline_ms\": %.4f, \"p50_ms\": %.4f, \"p99_ms\": %.4f, \"max_ms\": %.4f, \"worst_block\": %d, "
 	       "\"release_max_ms\": %.4f, \"every_block_within_the_deadline\": %s, \"every_block_within_90_percent_of_the_deadline\": %s, \"finite\": %s, \"ten_largest\": [",
-	       cpu, pinned ? "yes" : "no", locked ? "yes" : "no", V, blocks, n, deadline, p50, p99, mx, order[0], rmax, std::max(mx, rmax) <= deadline ? "true" : "false", std::max(mx, rmax) <= 0.9 * deadline ? "true" : "false", finite ? "true" : "false");
+	       cpu, pinned ? "yes" : "no", locked ? "yes" : "no", spin ? "polling" : "the interrupt", !rt ? "SCHED_OTHER" : fifo ? "SCHED_FIFO 50" : "SCHED_FIFO refused", V, blocks, n, deadline, p50, p99, mx, order[0], rmax, std::max(mx, rmax) <= deadline ? "true" : "false", std::max(mx, rmax) <= 0.9 * deadline ? "true" : "false", finite ? "true" : "false");
 	for (int i = 0; i < 10 && i < blocks; i++) printf("%s[%d, %.4f]", i ? ", " : "", order[(size_t)i], t[(size_t)order[(size_t)i]]);
-	printf("]}\n");
+	std::vector<float> gs = g; std::sort(gs.begin(), gs.end());
+	printf("], \"ten_largest_device_ms\": [");                               // the same ten blocks: what the device spent between the block's two events
+	for (int i = 0; i < 10 && i < blocks; i++) printf("%s%.4f", i ? ", " : "", g[(size_t)order[(size_t)i]]);
+	printf("], \"ten_largest_queueing_ms\": [");                             // the same ten blocks: host time until the last queueing call returned
+	for (int i = 0; i < 10 && i < blocks; i++) printf("%s%.4f", i ? ", " : "", q[(size_t)order[(size_t)i]]);
+	int late = 0, late_dev = 0; for (int i = 0; i < blocks; i++) if (t[(size_t)i] > 0.9 * deadline) { late++; if (g[(size_t)i] > 0.9 * deadline) late_dev++; }
+	printf("], \"blocks_over_90_percent\": %d, \"of_them_the_devices\": %d", late, late_dev);
+	printf(", \"device_p50_ms\": %.4f, \"device_max_ms\": %.4f, \"worst_block_is\": \"%s\"}\n", gs[gs.size() / 2], gs.back(),
+	       g[(size_t)order[0]] > 0.8 * t[(size_t)order[0]] ? "the device's (its own time between the block's events is as long)" : "the waiting host thread's (the device finished on time)");
 	klg_script_destroy(script); klg_synth_destroy(bank);
 	return 0;
 }
