@@ -8,8 +8,11 @@
 // stream: the ten largest come with the time the DEVICE spent between them, so that a late block is either the device's (both large) or the wake-up of the waiting
 // host thread's (wall clock large, device time ordinary).  --spin 1 waits by polling (hipDeviceScheduleSpin) instead of sleeping on the interrupt; --rt 1 asks for SCHED_FIFO (and says whether it got it).  The wall clock of a
 // block is also split where the last call that queues work returns: a late block's host time is either before that point (queueing) or after it (waiting).
+// --paced 1: the loop runs against the audio clock instead of back to back — block k is not started before T0 + k * (n / fs) (the callback's moment), and its lateness is its end
+// minus that moment: a host that plays with L blocks of buffering hears a gap when a block's lateness exceeds L block times (a late block delays the ones behind it until the
+// loop has caught up).  Reported: the largest lateness and the number of blocks beyond 1, 2 and 3 block times.
 // Build: hipcc -O2 -std=c++17 klang_deadline.cpp -I../../include -L.. -lklang_mi355 -Wl,-rpath,'$ORIGIN/..' -o klang_deadline   (klang_amd/csrc/build.sh does)
-// Run:   klang_deadline [--voices V] [--blocks B] [--n N] [--patch id] [--notes P] [--cpu c] [--spin 0|1] [--rt 0|1]
+// Run:   klang_deadline [--voices V] [--blocks B] [--n N] [--patch id] [--notes P] [--cpu c] [--spin 0|1] [--rt 0|1] [--paced 0|1]
 #include <hip/hip_runtime.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -29,12 +32,13 @@ static double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 
 #define HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) DIE("%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
 int main(int argc, char** argv) {
-	long long V = 1 << 20; int blocks = 2000, n = 256, patch = KLG_PATCH_SUB2A, notes = 32, cpu = -1, spin = 0, rt = 0;
+	long long V = 1 << 20; int blocks = 2000, n = 256, patch = KLG_PATCH_SUB2A, notes = 32, cpu = -1, spin = 0, rt = 0, paced = 0;
 	for (int i = 1; i + 1 < argc; i += 2) {
 		if (!strcmp(argv[i], "--voices")) V = atoll(argv[i + 1]); else if (!strcmp(argv[i], "--blocks")) blocks = atoi(argv[i + 1]);
 		else if (!strcmp(argv[i], "--n")) n = atoi(argv[i + 1]); else if (!strcmp(argv[i], "--patch")) patch = atoi(argv[i + 1]);
 		else if (!strcmp(argv[i], "--notes")) notes = atoi(argv[i + 1]); else if (!strcmp(argv[i], "--cpu")) cpu = atoi(argv[i + 1]);
 		else if (!strcmp(argv[i], "--spin")) spin = atoi(argv[i + 1]); else if (!strcmp(argv[i], "--rt")) rt = atoi(argv[i + 1]);
+		else if (!strcmp(argv[i], "--paced")) paced = atoi(argv[i + 1]);
 		else DIE("unknown option %s", argv[i]);
 	}
 	if (cpu < 0) cpu = sched_getcpu();
@@ -80,7 +84,10 @@ int main(int argc, char** argv) {
 		return 0;
 	};
 	if (block(0)) return 1;
-	for (int b = 0; b < blocks; b++) { const double t0 = now_ms(); if (block(-1)) return 1; t[(size_t)b] = now_ms() - t0; q[(size_t)b] = queued_at - t0; HIP(hipEventElapsedTime(&g[(size_t)b], e0, e1)); }   // (the clock stops before the events are read)
+	const double period = 1e3 * n / 48000.0; std::vector<double> lateness((size_t)(paced ? blocks : 0));
+	const double T0 = now_ms();
+	for (int b = 0; b < blocks; b++) { if (paced) while (now_ms() < T0 + b * period) {}
+		const double t0 = now_ms(); if (block(-1)) return 1; t[(size_t)b] = now_ms() - t0; q[(size_t)b] = queued_at - t0; HIP(hipEventElapsedTime(&g[(size_t)b], e0, e1)); if (paced) lateness[(size_t)b] = t0 + t[(size_t)b] - (T0 + b * period); }   // (the clock stops before the events are read)
 	if (block(1)) return 1;
 	for (int b = 0; b < 44; b++) { const double t0 = now_ms(); if (block(-1)) return 1; r[(size_t)b] = now_ms() - t0; }
 	std::vector<float> mix((size_t)2 * n);
@@ -103,6 +110,10 @@ int main(int argc, char** argv) {
 	for (int i = 0; i < 10 && i < blocks; i++) printf("%s%.4f", i ? ", " : "", q[(size_t)order[(size_t)i]]);
 	int late = 0, late_dev = 0; for (int i = 0; i < blocks; i++) if (t[(size_t)i] > 0.9 * deadline) { late++; if (g[(size_t)i] > 0.9 * deadline) late_dev++; }
 	printf("], \"blocks_over_90_percent\": %d, \"of_them_the_devices\": %d", late, late_dev);
+	if (paced) { int over[3] = { 0, 0, 0 }; double worst = 0.0; int at = 0;
+		for (int i = 0; i < blocks; i++) { for (int L = 1; L <= 3; L++) if (lateness[(size_t)i] > L * period) over[L - 1]++; if (lateness[(size_t)i] > worst) { worst = lateness[(size_t)i]; at = i; } }
+		printf(", \"paced\": {\"period_ms\": %.4f, \"largest_lateness_ms\": %.4f, \"at_block\": %d, \"blocks_later_than_1_2_3_periods\": [%d, %d, %d], \"buffering_with_no_gap_in_this_run_blocks\": %d}",
+		       period, worst, at, over[0], over[1], over[2], !over[0] ? 1 : !over[1] ? 2 : !over[2] ? 3 : 4); }
 	printf(", \"device_p50_ms\": %.4f, \"device_max_ms\": %.4f, \"worst_block_is\": \"%s\"}\n", gs[gs.size() / 2], gs.back(),
 	       g[(size_t)order[0]] > 0.8 * t[(size_t)order[0]] ? "the device's (its own time between the block's events is as long)" : "the waiting host thread's (the device finished on time)");
 	klg_script_destroy(script); klg_synth_destroy(bank);

@@ -217,3 +217,26 @@ def test_controllers_and_initial_controls_reach_the_patch(tmp_path):
     got = audio[0].reshape(blocks, N)
     peak = np.abs(ref).max()
     assert peak > 0.1 and np.abs(got - ref).max() <= 1e-5 * peak
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--spin", "1"], ["--paced", "1"]])
+def test_deadline_host_reports_every_block_and_whose_the_worst_one_was(extra):
+    """klang_amd/host/klang_deadline.cpp (bench.py's `c_host` legs): a small bank, every block between two HIP events — the record says how many blocks were over 90 % of the
+    deadline, how many of those were the device's own, and (paced: against the audio clock) how many blocks of buffering had no gap."""
+    import json
+    exe = os.path.join(ROOT, "klang_amd", "host", "klang_deadline")
+    assert os.path.exists(exe), "klang_amd/csrc/build.sh builds it"
+    p = subprocess.run([exe, "--voices", "65536", "--blocks", "200"] + extra, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["voices"] == 65536 and d["blocks"] == 200 and d["finite"] is True
+    assert len(d["ten_largest"]) == 10 and len(d["ten_largest_device_ms"]) == 10 and len(d["ten_largest_queueing_ms"]) == 10
+    assert 0 < d["device_p50_ms"] <= d["p50_ms"] < d["deadline_ms"]         # 65,536 voices are far inside the deadline; the device's share is inside the wall clock
+    assert 0 <= d["of_them_the_devices"] <= d["blocks_over_90_percent"] <= 200
+    assert ("polling" in d["host"]) == ("--spin" in extra)
+    if "--paced" in extra:
+        pc = d["paced"]
+        assert abs(pc["period_ms"] - 256e3 / 48000) < 1e-3 and len(pc["blocks_later_than_1_2_3_periods"]) == 3 and 1 <= pc["buffering_with_no_gap_in_this_run_blocks"] <= 4
+    else:
+        assert "paced" not in d
