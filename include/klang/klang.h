@@ -2294,6 +2294,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		if (klg_voice_stages(gpu, stages.data(), (int)notes.count)) fail("klg_voice_stages");
 		for (unsigned n = 0; n < notes.count; n++) if (stages[n] == klg::ST_OFF) notes[(int)n]->stage = NOTEBASE::Off;    // `if (!note->process(..)) note->stop()`
 	}
+	std::vector<float> unheard;                                               // (note variants + LastActiveVoice: where the banks that are not heard render)
 	float* per_voice_sink = nullptr;                                          // tests: every voice's own block ([voice][note channels][length]) is written here too
 	void render_voices(float* const* buffers, int channels, int length) {
 		ensure_gpu();
@@ -2305,8 +2306,8 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 			// the last block came back in refresh_stages()); every other bank renders too (its notes' state moves on) into samples nobody hears.
 			int heard = -1;
 			if (mix == gpu::LastActiveVoice) for (unsigned n = 0; n < notes.count; n++) if (notes[(int)n]->stage != NOTEBASE::Off && slot_variant[n] >= 0) heard = slot_variant[n];
-			std::vector<float> unheard; float* sink[2] = { nullptr, nullptr };
-			if (mix == gpu::LastActiveVoice) { unheard.assign((size_t)channels * (size_t)length, 0.f); for (int c = 0; c < channels && c < 2; c++) sink[c] = unheard.data() + (size_t)c * (size_t)length; }
+			float* sink[2] = { nullptr, nullptr };                                  // (`unheard` is a member: nothing is allocated per block once it has its size)
+			if (mix == gpu::LastActiveVoice) { if (unheard.size() < (size_t)channels * (size_t)length) unheard.resize((size_t)channels * (size_t)length); for (int c = 0; c < channels && c < 2; c++) sink[c] = unheard.data() + (size_t)c * (size_t)length; }
 			for (size_t v = 0; v < variants.size(); v++) {
 				float* const* dst = (mix == gpu::LastActiveVoice && (int)v != heard) ? sink : buffers;
 				if (per_voice_sink) {
