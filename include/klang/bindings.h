@@ -17,7 +17,14 @@ inline void env_from_rec(klg::host::EnvH& e, float r_out, float r_target, float 
 	e.r_out = r_out; e.r_target = r_target; e.r_rate = r_rate; e.time = time;
 	e.stage = (int)(bits & 3u); e.point = (int)((bits >> 2) & 7u); e.active = ((bits >> 5) & 1u) != 0;
 }
-inline void adsr_pack(const ADSR& a, klg::AdsrRec& r) { env_to_rec(a.h, r.r_out, r.r_target, r.r_rate, r.time); r.A = a.a.A; r.AD = a.h.px[2]; r.S = a.a.S; r.R = a.a.R; }
+// the hand-written kernels' records hold Time-mode envelopes of at most three points: anything else stops here (never a truncated or re-interpreted envelope)
+inline void needs_hand_shape(const klg::host::EnvH& e, int max_points, const char* what) {
+	if (e.fits_hand_kernel(max_points)) return;
+	std::fprintf(stderr, "klang-mi355: %s holds %d points%s, but the hand-written kernel this Note type is bound to (KLANG_GPU_BIND) keeps %d Time-mode points: remove the binding — the recorded form takes any envelope\n",
+		what, e.npoints, e.rate_mode ? " in Rate mode" : "", max_points);
+	std::abort();
+}
+inline void adsr_pack(const ADSR& a, klg::AdsrRec& r) { needs_hand_shape(a.h, 3, "the ADSR"); env_to_rec(a.h, r.r_out, r.r_target, r.r_rate, r.time); r.A = a.a.A; r.AD = a.h.px[2]; r.S = a.a.S; r.R = a.a.R; }
 
 template<class NOTE> struct SawLpfAdsr {            // members: osc (Fast::Saw), lpf (Biquad::LPF), adsr (ADSR)
 	static void pack(const NOTE& n, uint32_t* w) {
@@ -38,6 +45,7 @@ template<class NOTE> struct SubtractiveK {          // members: osc (Fast::Squar
 	static void pack(const NOTE& n, uint32_t* w) {
 		klg::rec::Sub2b r;
 		n.osc.h.pack(r.osc); adsr_pack(n.adsr, r.adsr);
+		needs_hand_shape(n.env.h, 3, "the filter Envelope");
 		env_to_rec(n.env.h, r.env.r_out, r.env.r_target, r.env.r_rate, r.env.time);
 		for (int k = 0; k < 3; k++) { r.env.px[k] = n.env.h.px[k]; r.env.py[k] = n.env.h.py[k]; }
 		r.filter.f = n.filter.h.f; r.filter.Q = n.filter.h.Q; n.filter.h.pack(r.filter.c);

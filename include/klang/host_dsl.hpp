@@ -7,6 +7,7 @@
 // path in this library.  Citations are file:line into the reference's klang.h (v0.7.8).
 #pragma once
 #include <cmath>
+#include <vector>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -200,26 +201,41 @@ struct FollowerArH {
 	}
 };
 
-// ---- Envelope set()/initialise() side (klang.h:3893-3989, 4077-4081) ----
+// ---- Envelope set()/initialise() side (klang.h:3893-3989, 4064-4092) ----
+// Any number of points (the reference keeps a std::vector<Point>, klang.h:4093); Time or Rate mode (setMode 4064-4071).
 struct EnvH {
 	float r_out = 1.f, r_target = 1.f, r_rate = 0.f; bool active = false;
-	int npoints = 0; float px[4] = { 0 }, py[4] = { 0 };
+	int npoints = 0; std::vector<float> px = std::vector<float>(4, 0.f), py = std::vector<float>(4, 0.f);   // (at least four slots, zeros behind the points: what the four register slots of a lane read)
 	int point = 0; float time = 0.f; int stage = ENV_SUSTAIN;
 	int loop_start = -1, loop_end = -1;                                        // Envelope::Loop klang.h:3853-3864
+	bool rate_mode = false;                                                    // setMode(Rate): a point's x is the ramp's step per sample, not a time (setTargetRate 4083-4092)
 	void set_loop(int a, int b) { if (a >= 0 && b < npoints) { loop_start = a; loop_end = b; } }   // setLoop klang.h:3923-3926
 	void set_value(float v) { r_out = v; r_target = v; active = false; }
 	void set_target(float x, float y, float t, const Fs& fs) {
-		time = t; r_target = y; active = (r_out != y);
-		r_rate = std::fabs(y - r_out) / ((x - t) * fs.f);
+		if (!rate_mode) {                                                      // setTargetTime 4077-4081
+			time = t; r_target = y; active = (r_out != y);
+			r_rate = std::fabs(y - r_out) / ((x - t) * fs.f);
+		}
+		else {                                                                 // setTargetRate 4083-4092
+			time = 0.f;
+			if (x == 0.f) set_value(y);
+			else { r_target = y; active = (r_out != y); r_rate = x; }
+		}
+	}
+	void initialise(const Fs& fs) {                                            // klang.h:3974-3989
+		point = 0; stage = ENV_SUSTAIN; loop_start = loop_end = -1;            // (initialise() resets the loop, klang.h:3977)
+		if (npoints) { set_value(py[0]); if (npoints > 1) set_target(px[1], py[1], px[0], fs); }
+		else set_value(1.f);
 	}
 	void set_points(int n, const float* xy, const Fs& fs) {
 		npoints = n;
-		for (int i = 0; i < n; i++) { px[i] = xy[2 * i]; py[i] = xy[2 * i + 1]; }
-		point = 0; stage = ENV_SUSTAIN; loop_start = loop_end = -1;            // initialise() resets the loop (klang.h:3977)
-		set_value(py[0]);
-		if (n > 1) set_target(px[1], py[1], px[0], fs);
+		px.assign((size_t)(n > 4 ? n : 4), 0.f); py.assign((size_t)(n > 4 ? n : 4), 0.f);
+		for (int i = 0; i < n; i++) { px[(size_t)i] = xy[2 * i]; py[(size_t)i] = xy[2 * i + 1]; }
+		initialise(fs);
 	}
+	// stage(2) | point(3) | active(1): the six flag bits of the hand-written kernels' records (three-point Time-mode envelopes; fits_hand_kernel() below)
 	uint32_t bits() const { return (uint32_t)stage | ((uint32_t)point << 2) | ((uint32_t)active << 5); }
+	bool fits_hand_kernel(int max_points) const { return !rate_mode && npoints <= max_points && point < 8; }
 };
 
 // ---- ADSR::set (klang.h:4116-4129) ----

@@ -134,7 +134,7 @@ struct Sink {
 		if (!key) key = p ? (const void*)p : addr;
 		uint64_t serial = 0;
 		if (tracked) { if (!live) live = new LiveMap(); auto it = live->serial.find(key); serial = it != live->serial.end() ? it->second : (live->serial[key] = live->next++); }
-		for (Obj& o : objs) if (o.addr == addr && (!tracked || o.serial == serial)) { o.kind = kind; o.size = size; if (p) o.packable = p; return; }       // ADSR refines the Envelope it derives from
+		for (Obj& o : objs) if (o.addr == addr && (!tracked || o.serial == serial)) { o.kind = kind; o.size = size; if (p) o.packable = p; if (arg) o.arg = arg; if (live_arg) o.live_arg = live_arg; return; }       // ADSR refines the Envelope it derives from, an Operator its oscillator
 		objs.push_back({ addr, size, kind, p, arg, key, serial, live_arg });
 	}
 	bool alive(const Obj& o) const { if (!tracked) return true; if (!live) return false; const auto it = live->serial.find(o.key); return it != live->serial.end() && it->second == o.serial; }
@@ -950,59 +950,148 @@ namespace Modifiers {
 enum Mode { Peak, RMS, Mean };
 
 // ---- Envelope / ADSR (klang.h:3722-4137) ----
+// Points: any number on the host (the reference keeps a std::vector<Point>, klang.h:4093).  A lane record holds `capacity` point slots, fixed when the
+// program is recorded: KLANG_GPU_ENV_POINTS (default 16; 4 .. 128), or more when the member is given more points while its owner is constructed
+// (`Envelope env = { ... }`, a constructor body).  An envelope that holds more points than its record when a note starts STOPS with a message that
+// names the macro — nothing is ever truncated.
+#ifndef KLANG_GPU_ENV_POINTS
+#define KLANG_GPU_ENV_POINTS 16
+#endif
+static_assert(KLANG_GPU_ENV_POINTS >= 4 && KLANG_GPU_ENV_POINTS <= klg::graph::ENV_MAX_POINTS, "KLANG_GPU_ENV_POINTS: 4 .. 128 point slots per Envelope record");
 struct Envelope : Generator, gpu::Packable {
 	struct Follower;
 	struct Point { float x, y; Point() : x(0), y(0) {} template<class A, class B> Point(A a, B b) : x(float(a)), y(float(b)) {} };
+	// Envelope::Points(0, 1)(1, 0)... (klang.h:3818-3851): the inline point list
+	struct Points : Point {
+		std::vector<Point> rest;
+		Points(float x_, float y_) { x = x_; y = y_; }
+		Points& operator()(float x_, float y_) { rest.push_back(Point(x_, y_)); return *this; }
+		int count() const { return 1 + (int)rest.size(); }
+	};
 	enum Stage { Sustain, Release, Off };
+	enum Mode { Time, Rate };
 	klg::host::EnvH h;
-	void reg_member() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Envelope), klg::graph::N_ENV, this); }
+	int capacity = KLANG_GPU_ENV_POINTS;                                           // point slots of this member's lane record (read when the program is finished)
+	void reg_member() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Envelope), klg::graph::N_ENV, this, 0, nullptr, &capacity); }
 	Envelope() { reg_member(); const float one[2] = { 0.f, 1.f }; h.set_points(1, one, host_fs()); }
-	Envelope(std::initializer_list<Point> p) { reg_member(); assign(p); }
-	Envelope& operator=(std::initializer_list<Point> p) { assign(p); return *this; }
-	void assign(std::initializer_list<Point> p) {
-		float xy[8]; int n = 0;
-		for (const Point& q : p) if (n < 4) { xy[2 * n] = q.x; xy[2 * n + 1] = q.y; n++; }
-		h.set_points(n, xy, host_fs());
+	Envelope(const Points& p) { reg_member(); set(p); }
+	Envelope(std::initializer_list<Point> p) { reg_member(); assign(p.begin(), (int)p.size()); }
+	Envelope(const Envelope& in) : Generator(), gpu::Packable() { reg_member(); const std::vector<Point> p = in.points(); assign(p.data(), (int)p.size()); }   // klang.h:3879: the POINTS of the other envelope, initialised afresh (Time mode, no loop)
+	Envelope& operator=(const Envelope& in) { h = in.h; out.value = in.out.value; grow(h.npoints); return *this; }
+	Envelope& operator=(std::initializer_list<Point> p) { assign(p.begin(), (int)p.size()); return *this; }
+	std::vector<Point> points() const { std::vector<Point> p((size_t)h.npoints); for (int i = 0; i < h.npoints; i++) p[(size_t)i] = Point(h.px[(size_t)i], h.py[(size_t)i]); return p; }
+	void grow(int n) { if (n > capacity && gpu::constructing()) capacity = n; }   // (only while the owner is constructed: every note of a type then has the same record)
+	void assign(const Point* p, int n) {                                          // set(points) + initialise()  klang.h:3893-3896, 3974-3989
+		if (gpu::no_set_while_recording("Envelope::set(points)")) return;
+		std::vector<float> xy((size_t)(2 * n + 2));
+		for (int i = 0; i < n; i++) { xy[(size_t)(2 * i)] = p[i].x; xy[(size_t)(2 * i + 1)] = p[i].y; }
+		h.set_points(n, xy.data(), host_fs());
+		out.value = h.r_out;
+		grow(n);
 	}
+	using Generator::set;
+	void set(const std::vector<Point>& p) { assign(p.data(), (int)p.size()); }                                    // klang.h:3893-3896
+	void set(const Points& p) { std::vector<Point> v; v.push_back(p); v.insert(v.end(), p.rest.begin(), p.rest.end()); assign(v.data(), (int)v.size()); }   // 3899-3909
+	void initialise() { if (gpu::no_set_while_recording("Envelope::initialise()")) return; h.initialise(host_fs()); out.value = h.r_out; }   // 3974-3989
+	void sequence() {                                                              // relative -> absolute times  klang.h:3912-3920
+		if (gpu::no_set_while_recording("Envelope::sequence()")) return;
+		float time = 0.f;
+		for (int i = 0; i < h.npoints; i++) { const float delta = h.px[(size_t)i]; time += delta + 0.00001f; h.px[(size_t)i] = time; }
+		h.initialise(host_fs()); out.value = h.r_out;
+	}
+	void resize(float length) {                                                    // klang.h:3992-4005 (as written there: length / (fs * old length))
+		if (gpu::no_set_while_recording("Envelope::resize()")) return;
+		const float old_length = getLength();
+		if (old_length == 0.0) return;
+		const float multiplier = length / (fs.f * old_length);
+		for (int i = 0; i < h.npoints; i++) h.px[(size_t)i] *= multiplier;
+		h.initialise(host_fs()); out.value = h.r_out;
+	}
+	float getLength() const { return h.npoints ? h.px[(size_t)(h.npoints - 1)] : 0.f; }   // klang.h:3958
+	const Point operator[](int i) const { return Point(h.px[(size_t)i], h.py[(size_t)i]); }   // klang.h:4054-4056
+	// value at a time in seconds, klang.h:3929-3943 — host arithmetic on the points (a lookup table such as SynTHX.k's `transposition.at(x)`)
+	signal at(param time) const {
+		if (time.reg >= 0 && gpu::recording()) { gpu::recording()->fail("Envelope::at(t) of a value computed inside process() is not supported in a recorded graph"); return signal(0.f); }
+		if (h.npoints == 0) return 0;
+		float lx = 0.f, ly = h.py[0];
+		for (int i = 0; i < h.npoints; i++) {
+			const float x = h.px[(size_t)i], y = h.py[(size_t)i];
+			if (x >= time.value) { const float dx = x - lx, dy = y - ly, t = time.value - lx; return dx == 0 ? ly : (ly + t * dy / dx); }
+			lx = x; ly = y;
+		}
+		return h.py[(size_t)(h.npoints - 1)];
+	}
+	void setMode(Mode m) { if (gpu::no_set_while_recording("Envelope::setMode()")) return; h.rate_mode = (m == Rate); }   // klang.h:4064-4071 (takes effect at the next setTarget, as there)
+	Mode mode() const { return h.rate_mode ? Rate : Time; }
+	void setStage(Stage st) { if (gpu::no_set_while_recording("Envelope::setStage()")) return; h.stage = (int)st; }   // klang.h:3952
+	Stage getStage() const { return (Stage)h.stage; }                              // (host state: in a recorded process() ask `env == Envelope::Off` / finished())
+	void setTarget(const Point& p, float time = 0.f) { if (gpu::no_set_while_recording("Envelope::setTarget()")) return; h.set_target(p.x, p.y, time, host_fs()); }   // klang.h:4008-4010
 	virtual void release(float time, float level = 0.f) { if (gpu::no_set_while_recording("Envelope::release()")) return; h.stage = klg::ENV_RELEASE; h.set_target(time, level, 0.f, host_fs()); }   // klang.h:3961-3966
 	void setLoop(int startPoint, int endPoint) { if (gpu::no_set_while_recording("Envelope::setLoop()")) return; h.set_loop(startPoint, endPoint); }   // klang.h:3923-3926
+	void resetLoop() {                                                             // klang.h:3946-3950
+		if (gpu::no_set_while_recording("Envelope::resetLoop()")) return;
+		h.loop_start = h.loop_end = -1;
+		if (h.stage == klg::ENV_SUSTAIN && (h.point + 1) < h.npoints) h.set_target(h.px[(size_t)(h.point + 1)], h.py[(size_t)(h.point + 1)], h.px[(size_t)h.point], host_fs());
+	}
 	// klang.h:4094.  In a recorded process() the test is a VALUE (envoff): `if (env.finished()) stop();`, `if (env.finished()) { ...; stop(); return; }`,
 	// `!env.finished()`, `env.finished() && x > y` all record; the plain stop() idiom is folded back into `stopif` (gpu::fold_stop_idiom)
-	gpu::Pred finished() const { if (gpu::Recorder* r = gpu::recording()) return gpu::Pred{ h.stage == klg::ENV_OFF, r->emit(klg::graph::OP_ENVOFF, -1, -1, r->node(this, "Envelope"), 0, true) }; return gpu::Pred{ h.stage == klg::ENV_OFF, -1 }; }
+	gpu::Pred stage_is(Stage st) const {
+		if (gpu::Recorder* r = gpu::recording()) return gpu::Pred{ h.stage == (int)st, r->emit(klg::graph::OP_ENVOFF, -1, -1, r->node(this, "Envelope"), st == Off ? 0u : (st == Sustain ? 1u : 2u), true) };
+		return gpu::Pred{ h.stage == (int)st, -1 };
+	}
+	gpu::Pred finished() const { return stage_is(Off); }
+	gpu::Pred operator==(Stage st) const { return stage_is(st); }                  // klang.h:3883
+	gpu::Pred operator!=(Stage st) const { return !stage_is(st); }                 // klang.h:3884
 	signal& operator++(int) { this->process(); return out; }
 	void process() override { if (gpu::Recorder* r = gpu::recording()) { out.reg = r->emit(klg::graph::OP_ENV, -1, -1, r->node(this, "Envelope"), 0, true); return; } device_only("Envelope::process()"); }
+	[[noreturn]] void too_many_points() const {
+		std::fprintf(stderr, "klang-mi355: an Envelope holds %d points but its lane record was recorded with %d point slots.  Give the member its points while the note is constructed, or compile with "
+			"-DKLANG_GPU_ENV_POINTS=%d (at most %d).\n", h.npoints, capacity, h.npoints, (int)klg::graph::ENV_MAX_POINTS);
+		std::abort();
+	}
 	void pack(uint32_t* w) const override {
 		using namespace klg::graph;
-		w[ENV_OUT] = gpu::fbits(h.r_out); w[ENV_TARGET] = gpu::fbits(h.r_target); w[ENV_RATE] = gpu::fbits(h.r_rate); w[ENV_TIME] = gpu::fbits(h.time); w[ENV_BITS] = h.bits(); w[ENV_NPOINTS] = (uint32_t)h.npoints;
+		if (h.npoints > capacity || h.npoints > (int)ENV_MAX_POINTS) too_many_points();
+		w[ENV_OUT] = gpu::fbits(h.r_out); w[ENV_TARGET] = gpu::fbits(h.r_target); w[ENV_RATE] = gpu::fbits(h.r_rate); w[ENV_TIME] = gpu::fbits(h.time); w[ENV_NPOINTS] = (uint32_t)h.npoints;
+		w[ENV_BITS] = env_bits(h.stage, h.point, h.active, h.rate_mode);
 		w[ENV_LOOP] = (uint32_t)(h.loop_start & 0xFF) | ((uint32_t)(h.loop_end & 0xFF) << 8);
-		for (int i = 0; i < 4; i++) { w[ENV_PX + i] = gpu::fbits(h.px[i]); w[ENV_PY + i] = gpu::fbits(h.py[i]); }
+		for (int i = 0; i < 4; i++) { w[ENV_PX + i] = gpu::fbits(h.px[(size_t)i]); w[ENV_PY + i] = gpu::fbits(h.py[(size_t)i]); }
+		const int ext = env_capacity(capacity) - 4;                                // x of points 4.., then their y (zeros behind the last point)
+		for (int i = 0; i < ext; i++) { const bool has = 4 + i < h.npoints; w[ENV_WORDS + i] = has ? gpu::fbits(h.px[(size_t)(4 + i)]) : 0u; w[ENV_WORDS + ext + i] = has ? gpu::fbits(h.py[(size_t)(4 + i)]) : 0u; }
 	}
 	void unpack(const uint32_t* w) override {
 		std::memcpy(&h.r_out, &w[0], 4); std::memcpy(&h.r_target, &w[1], 4); std::memcpy(&h.r_rate, &w[2], 4); std::memcpy(&h.time, &w[3], 4);
-		const uint32_t bits = w[4]; h.stage = (int)(bits & 3u); h.point = (int)((bits >> 2) & 7u); h.active = ((bits >> 5) & 1u) != 0;
+		const uint32_t bits = w[4]; h.stage = (int)(bits & 3u); h.point = klg::graph::env_bits_point(bits); h.active = ((bits >> 5) & 1u) != 0;
 	}
 };
 struct ADSR : Envelope {
 	klg::host::AdsrH a;
+	enum Mode { Time, Rate }; Mode mode = (Mode)0;                                     // (klang.h:4112: a member the reference declares and never reads; Envelope::setMode is what changes the ramps)
 	ADSR() { if (gpu::Sink* r = gpu::constructing()) r->note(static_cast<Envelope*>(this), sizeof(ADSR), klg::graph::N_ADSR, this); set(0.5, 0.5, 1, 0.5); }
 	using Envelope::set;
 	float A = 0.f, D = 0.f, S = 0.f, R = 0.f;                                  // klang.h:4100-4103: the envelope's times as set() keeps them (`if (env.R > 0.01) env.release();`, Modular.k:93 — event code)
-	void set(param attack, param decay, param sustain, param release) override { if (gpu::no_set_while_recording("ADSR::set()")) return; a.set(attack, decay, sustain, release, host_fs()); h = a.env; A = a.A; D = a.D; S = a.S; R = a.R; }
+	void set(param attack, param decay, param sustain, param release) override { if (gpu::no_set_while_recording("ADSR::set()")) return; const bool rate = h.rate_mode; a.env.rate_mode = rate; a.set(attack, decay, sustain, release, host_fs()); h = a.env; A = a.A; D = a.D; S = a.S; R = a.R; }
+	// The ADSR lane record is the shape ADSR::set() gives the envelope — (0,0) (A,1) (A+D,S), loop (2,2), Time mode — with A, A+D, S, R as its words.  An ADSR object
+	// that was given other points / another loop / Rate mode through the Envelope interface has no such record: stop, do not play something else.
 	void pack(uint32_t* w) const override {
 		using namespace klg::graph;
+		auto same = [](float x, float y) { return gpu::fbits(x) == gpu::fbits(y); };
+		const bool shaped = !h.rate_mode && h.npoints == 3 && same(h.px[0], 0.f) && same(h.py[0], 0.f) && same(h.px[1], a.A) && same(h.py[1], 1.f) && same(h.py[2], a.S) && (h.stage != klg::ENV_SUSTAIN || (h.loop_start == 2 && h.loop_end == 2));
+		if (!shaped) { std::fprintf(stderr, "klang-mi355: an ADSR whose points, loop or mode were changed through the Envelope interface (operator=, setLoop, resetLoop, setMode(Rate)) has no GPU record: use an Envelope member for that shape\n"); std::abort(); }
 		w[ADSR_OUT] = gpu::fbits(h.r_out); w[ADSR_TARGET] = gpu::fbits(h.r_target); w[ADSR_RATE] = gpu::fbits(h.r_rate); w[ADSR_TIME] = gpu::fbits(h.time); w[ADSR_BITS] = h.bits();
 		w[ADSR_A] = gpu::fbits(a.A); w[ADSR_AD] = gpu::fbits(h.px[2]); w[ADSR_S] = gpu::fbits(a.S); w[ADSR_R] = gpu::fbits(a.R);
 	}
 	void release(float time = 0.f, float level = 0.f) override { Envelope::release(time ? time : a.R, level); }
+	gpu::Pred operator==(Envelope::Stage st) const { return stage_is(st); }    // klang.h:4135
 };
 
 // ---- Envelope::Follower (klang.h:5862-5903): the AR smoother with abs / square-sqrt around it ----
 struct Envelope::Follower : Modifier, gpu::Packable {
-	klg::host::FollowerArH ar; Mode mode = RMS;
+	klg::host::FollowerArH ar; klang::Mode mode = RMS;
 	Follower() { if (gpu::Sink* r = gpu::constructing()) r->note(this, sizeof(Follower), klg::graph::N_FOLLOWRMS, this); set(0.01f, 0.1f); }
 	using Modifier::set;
 	void set(param attack, param release) override { if (gpu::no_set_while_recording("Envelope::Follower::set()")) return; ar.set(attack, release, host_fs()); }
-	Follower& operator=(Mode m) {                                              // klang.h:5892-5895 (choose before the Synth is created: the mode is part of the recorded program)
+	Follower& operator=(klang::Mode m) {                                              // klang.h:5892-5895 (choose before the Synth is created: the mode is part of the recorded program)
 		mode = m;
 		if (gpu::Sink* r = gpu::rec ? static_cast<gpu::Sink*>(gpu::rec) : static_cast<gpu::Sink*>(gpu::log_target)) r->note(this, sizeof(Follower), m == RMS ? klg::graph::N_FOLLOWRMS : klg::graph::N_FOLLOWPEAK, this);
 		return *this;
@@ -1015,10 +1104,14 @@ struct Envelope::Follower : Modifier, gpu::Packable {
 // ---- FM operator (klang.h:4140-4180) ----
 template<class OSC> struct Operator : OSC, Input {
 	Envelope env; Amplitude amp = 1.f;
-	Operator() { if (gpu::Sink* r = gpu::constructing()) r->note(static_cast<OSC*>(this), sizeof(Operator), klg::graph::N_OPERATOR, static_cast<gpu::Packable*>(static_cast<OSC*>(this))); }
+	Operator() { if (gpu::Sink* r = gpu::constructing()) r->note(static_cast<OSC*>(this), sizeof(Operator), klg::graph::N_OPERATOR, static_cast<gpu::Packable*>(static_cast<OSC*>(this)), 0, nullptr, &env.capacity); }   // (the node's argument: its envelope's point slots)
 	Operator& operator()(param f) { OSC::set(f); return *this; }
 	Operator& operator()(param f, relative phase) { OSC::set(f, phase); return *this; }
-	Operator& operator=(std::initializer_list<Envelope::Point> p) { env = p; return *this; }
+	// klang.h:4149-4157: `op = { {0,0}, {3,1} }` builds a TEMPORARY Envelope and copy-assigns it — points, state AND mode: an operator envelope is back in Time mode
+	// after every assignment (set Rate mode after it, then initialise())
+	Operator& operator=(std::initializer_list<Envelope::Point> p) { env.h.rate_mode = false; env = p; return *this; }
+	Operator& operator=(const Envelope::Points& p) { env.h.rate_mode = false; env.set(p); return *this; }
+	Operator& operator=(const Envelope& e) { env = e; return *this; }
 	Operator& operator*(signal a) { amp = a; return *this; }                     // (while recording, `a` may be a recorded value: the operator's amp operand)
 	template<class S, typename = std::enable_if_t<std::is_base_of_v<signal, S>>> Operator& operator*(const S& a) { amp = static_cast<const signal&>(a); return *this; }   // exact for param / Frequency / ...
 	Operator& operator>>(Operator& carrier) { carrier << *this; return carrier; }
@@ -1449,7 +1542,7 @@ inline void finish_program(Recorder& R, const char* lo, GraphLayout& L) {
 	std::vector<int> node_id(R.objs.size(), -1);
 	std::vector<char> node_used(R.objs.size(), 0);
 	for (size_t i = 0; i < ops.size(); i++) if (keep[i] && ops[i].node >= 0) node_used[(size_t)ops[i].node] = 1;
-	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) { node_id[i] = (int)R.prog.nodes.size(); R.prog.nodes.push_back(R.objs[i].kind); R.prog.node_arg.push_back(R.objs[i].live_arg ? *R.objs[i].live_arg : R.objs[i].arg); }
+	for (size_t i = 0; i < R.objs.size(); i++) if (node_used[i]) { node_id[i] = (int)R.prog.nodes.size(); R.prog.nodes.push_back(R.objs[i].kind); R.prog.node_arg.push_back(klg::graph::node_arg_of(R.objs[i].kind, R.objs[i].live_arg ? *R.objs[i].live_arg : R.objs[i].arg)); }
 	std::vector<Op> out_ops;
 	int kept_prepare = 0;
 	for (size_t i = 0; i < ops.size(); i++) if (keep[i]) { Op o = ops[i]; if (o.node >= 0) o.node = node_id[(size_t)o.node]; out_ops.push_back(o); if ((int)i < R.prog.prepare_ops) kept_prepare++; }

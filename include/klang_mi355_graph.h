@@ -51,7 +51,11 @@ enum NodeKind {
 	N_SAW = 1,      /* Fast::OSM, saw family (Saw, Triangle)   5175-5354   words: inc, offset, duty, delta, state, frequency */
 	N_PULSE = 2,    /* Fast::OSM, pulse family (Square, Pulse)             same words */
 	N_LPF = 3,      /* Filters::Biquad::{LPF,HPF,BPF,BRF,APF}  5550-5773   words: b0 b1 b2 a1 a2 z0 z1 f Q  (process() is type-independent; only LPF may be set() per sample) */
-	N_ENV = 4,      /* Envelope, <= 4 breakpoints       3867-4102           words: r_out r_target r_rate time bits npoints loop px[4] py[4] */
+	N_ENV = 4,      /* Envelope                         3867-4102           words: r_out r_target r_rate time bits npoints loop px[4] py[4], then — when the node's
+	                                                                        argument (its POINT CAPACITY, 5 .. ENV_MAX_POINTS; none = 4) says so — x of points 4 .. cap-1 and
+	                                                                        their y.  The first four points sit in registers; the others are read from the record when (and only
+	                                                                        when) a segment ends.  bits: stage(2) | point & 7 (3) | ramp active (1) | Rate mode (1: setMode,
+	                                                                        klang.h:4064-4092) | point >> 3 (from bit 7) */
 	N_ADSR = 5,     /* ADSR                             4105-4137           words: r_out r_target r_rate time bits A AD S R */
 	N_PARAM = 6,    /* a signal / param member of the Note that process() reads (and may write)   words: value */
 	N_BSINE = 7, N_BSAW, N_BTRI, N_BSQUARE, N_BPULSE,   /* Generators::Basic::*   2849-2880, 4899-4944   words: increment, position, offset, duty, frequency */
@@ -80,7 +84,12 @@ enum NodeKind {
 enum { FSINE_INC = 0, FSINE_POS, FSINE_FREQ, FSINE_WORDS };
 enum { OSM_INC = 0, OSM_OFFSET, OSM_DUTY, OSM_DELTA, OSM_STATE, OSM_FREQ, OSM_WORDS };
 enum { LPF_B0 = 0, LPF_B1, LPF_B2, LPF_A1, LPF_A2, LPF_Z0, LPF_Z1, LPF_F, LPF_Q, LPF_WORDS };
-enum { ENV_OUT = 0, ENV_TARGET, ENV_RATE, ENV_TIME, ENV_BITS, ENV_NPOINTS, ENV_LOOP /* start | end << 8, 0xFF = none (setLoop) */, ENV_PX, ENV_PY = ENV_PX + 4, ENV_WORDS = ENV_PY + 4 };
+enum { ENV_OUT = 0, ENV_TARGET, ENV_RATE, ENV_TIME, ENV_BITS, ENV_NPOINTS, ENV_LOOP /* start | end << 8, 0xFF = none (setLoop) */, ENV_PX, ENV_PY = ENV_PX + 4, ENV_WORDS = ENV_PY + 4 /* + env_ext_words(capacity) */ };
+enum { ENV_MAX_POINTS = 128, ENV_BIT_RATE = 1u << 6 };   /* (loop indices are bytes with 0xFF = none; the record keeps x and y of every point slot) */
+inline int env_capacity(int arg) { return arg > 4 ? arg : 4; }                 /* an Envelope / Operator node's argument: how many points its record holds */
+inline int env_ext_words(int arg) { return 2 * (env_capacity(arg) - 4); }      /* x of points 4.., then their y, behind the ENV_WORDS */
+inline uint32_t env_bits(int stage, int point, bool active, bool rate) { return (uint32_t)stage | ((uint32_t)(point & 7) << 2) | ((uint32_t)active << 5) | (rate ? (uint32_t)ENV_BIT_RATE : 0u) | ((uint32_t)(point >> 3) << 7); }
+inline int env_bits_point(uint32_t b) { return (int)(((b >> 2) & 7u) | ((b >> 7) << 3)); }
 enum { ADSR_OUT = 0, ADSR_TARGET, ADSR_RATE, ADSR_TIME, ADSR_BITS, ADSR_A, ADSR_AD, ADSR_S, ADSR_R, ADSR_WORDS };
 enum { BOSC_INC = 0, BOSC_POS, BOSC_OFFSET, BOSC_DUTY, BOSC_FREQ, BOSC_WORDS };
 enum { OP1_B0 = 0, OP1_B1, OP1_A1, OP1_Z, OP1_OUT, OP1_WORDS };
@@ -102,7 +111,7 @@ inline int node_words(int kind, int arg = 0) {
 	case N_FSINE: return FSINE_WORDS;
 	case N_SAW: case N_PULSE: return OSM_WORDS;
 	case N_LPF: return LPF_WORDS;
-	case N_ENV: return ENV_WORDS;
+	case N_ENV: return ENV_WORDS + env_ext_words(arg);
 	case N_ADSR: return ADSR_WORDS;
 	case N_PARAM: return 1;
 	case N_BSINE: case N_BSAW: case N_BTRI: case N_BSQUARE: case N_BPULSE: return BOSC_WORDS;
@@ -112,7 +121,7 @@ inline int node_words(int kind, int arg = 0) {
 	case N_BUTTER1: return BW1_WORDS;
 	case N_MODAL: return MODAL_WORDS;
 	case N_FOLLOWPEAK: case N_FOLLOWRMS: return FOLLOW_WORDS;
-	case N_OPERATOR: return OPER_WORDS;
+	case N_OPERATOR: return OPER_WORDS + env_ext_words(arg);
 	case N_DELAY: return ED_WORDS;
 	case N_SMOOTH: return 1;
 	case N_WAVETABLE: return WT_WORDS;
@@ -120,6 +129,12 @@ inline int node_words(int kind, int arg = 0) {
 	case N_IIRN: return 2 * arg;
 	case N_CTLVAR: return 1;
 	}
+	return 0;
+}
+/* the argument a node of this kind keeps (0: none).  An Envelope / Operator with the four built-in point slots has none, so that its program text is what it always was */
+inline int node_arg_of(int kind, int arg) {
+	if (kind == N_DELAY || kind == N_NDELAY || kind == N_IIRN) return arg;
+	if (kind == N_ENV || kind == N_OPERATOR) return arg > 4 ? arg : 0;
 	return 0;
 }
 inline const char* node_name(int kind) {
@@ -174,7 +189,8 @@ enum OpCode {
 	OP_DADD, OP_DSUB, OP_DMUL, OP_DDIV,   /* dst(double) = a OP b, both doubles                                                                          */
 	OP_D2F,         /* dst = (float) a   (round to nearest even)                                                                                       */
 	OP_ENVOFF,      /* dst = env/adsr node .finished() ? 1.0 : 0.0     Envelope::finished klang.h:4094 (stage == Off) as a VALUE: `if (adsr.finished()) { ...; stop(); return; }`,
-	                   `!adsr.finished()`, `finished() && x > y` — the recorder turns the plain `if (env.finished()) stop();` back into stopif                 */
+	                   `!adsr.finished()`, `finished() && x > y` — the recorder turns the plain `if (env.finished()) stop();` back into stopif.
+	                   imm: the stage asked for — 0 Off (finished()), 1 Sustain, 2 Release (`env == Envelope::Release`, klang.h:3883-3884)                   */
 	OP_FUNC,        /* dst(double) = f(a), a a double, f by imm: 0 = tanh — what `tanh(x)` of a float is inside a patch's plain C function: the C library's DOUBLE tanh of the
 	                   converted float, and the expression around it stays double (`tanh(c * x) / tanh(c)`, examples/Distortion/Shaping.k:15: f2d, func, ddiv, d2f).
 	                   klg_device.hpp glibc_tanh restates glibc 2.35's (float-rounded result equal on all 2^32 floats: tools/verify_tanh_f64.c).
@@ -201,7 +217,7 @@ struct Program {
 	int nctl = 0;
 	Dial dials[GRAPH_MAX_CTL] = {};
 	std::vector<int> nodes;      /* kind of node i */
-	std::vector<int> node_arg;   /* Delay<SIZE>: SIZE; else 0 */
+	std::vector<int> node_arg;   /* Delay<SIZE>: SIZE; IIR<ORDER>: ORDER; Envelope / Operator: point capacity above four; else 0 */
 	std::vector<Op> ops;
 	int ret = -1, ret_r = -1;    /* ret_r: right channel of a Stereo::Effect / of a Stereo::Note (a note program with ret2) */
 	bool stereo_note() const { return channels == 0 && ret_r >= 0; }
@@ -257,7 +273,8 @@ struct Program {
 				if ((int)nodes.size() >= MAX_NODES) return bad("too many nodes");
 				if ((k == N_DELAY || k == N_NDELAY) && (size < 2 || size > (1 << 24))) return bad("delay needs its SIZE (2 .. 2^24)");
 				if (k == N_IIRN && (size < 2 || size > 8)) return bad("iirn needs its ORDER (2 .. 8)");
-				nodes.push_back(k); node_arg.push_back((k == N_DELAY || k == N_NDELAY || k == N_IIRN) ? size : 0);
+				if ((k == N_ENV || k == N_OPERATOR) && size != 0 && (size < 5 || size > ENV_MAX_POINTS)) return bad("an envelope's point capacity is 5 .. 128 (none: four points)");
+				nodes.push_back(k); node_arg.push_back(node_arg_of(k, size));
 			}
 			else if (!strcmp(kw, "op")) {
 				char code[32]; Op o; unsigned imm;
@@ -330,7 +347,7 @@ struct Program {
 			case OP_DLOW: need_a = true; if (!is_dbl(o.a)) return bad("operand a is not a double"); dst_dbl = true; break;
 			case OP_DADD: case OP_DSUB: case OP_DMUL: case OP_DDIV: need_a = need_b = true; if (!is_dbl(o.a) || !is_dbl(o.b)) return bad("both operands must be doubles"); dst_dbl = true; break;
 			case OP_D2F: need_a = true; if (!is_dbl(o.a)) return bad("operand a is not a double"); break;
-			case OP_ENVOFF: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); break;
+			case OP_ENVOFF: if (k != N_ENV && k != N_ADSR) return bad("node is not an envelope"); if (o.imm > 2u) return bad("unknown envelope stage"); break;
 			case OP_TABREAD: if (channels) return bad("tables are only available to synth notes"); if (o.imm == 0u) return bad("table id 0 is reserved"); need_a = true; break;
 			case OP_IF: if ((int)i < prepare_ops) return bad("prepare() may not branch"); need_a = true; has_dst = false; open.push_back({ {}, false, {} }); break;
 			case OP_ELSE:

@@ -621,28 +621,48 @@ __device__ __forceinline__ float env_process(Env& e, const PTS& p, int npoints, 
 	return out;
 }
 
-// The same with the breakpoint count and the loop (Envelope::setLoop, klang.h:3923-3926; Loop 3853-3864) known only at run
-// time: what a recorded graph patch uses for its Envelope members.  ls / le = loop.start / loop.end, -1 = no loop.
-__device__ __forceinline__ void env_segment_end_rt(Env& e, const Pts4& p, int npoints, int ls, int le, const SampleRate& fs) {
+// The same with everything known only at run time: what a recorded graph patch uses for its Envelope members.  Any number of breakpoints (the first
+// four in registers — Pts4 —, the others read from the voice's record when a segment ends: PtsN), the loop (Envelope::setLoop, klang.h:3923-3926;
+// Loop 3853-3864: ls / le = loop.start / loop.end, -1 = no loop) and the mode (setMode, klang.h:4064-4071): in Rate mode a point's x is the ramp's step
+// per sample (setTargetRate 4083-4092) and a finished segment goes on at once (`mode() == Rate ||`, 4031).  `npm` = point count | Rate mode << 16.
+struct PtsN { Pts4 head; const uint32_t* ext; size_t stride; int slots;      // ext: the record word of point 4's x; x of points 4 .. follow, then (slots words on) their y
+	__device__ __forceinline__ float x(int i) const { const float far = u2f(ext[(size_t)(i > 4 ? i - 4 : 0) * stride]); return i < 4 ? head.x(i) : far; }
+	__device__ __forceinline__ float y(int i) const { const float far = u2f(ext[(size_t)(slots + (i > 4 ? i - 4 : 0)) * stride]); return i < 4 ? head.y(i) : far; } };
+enum { ENV_NPM_RATE = 1 << 16 };
+__device__ __forceinline__ void env_set_target_rt(Env& e, float px, float py, float time, float fs, bool rate) {
+	if (!rate) { env_set_target_time(e, px, py, time, fs); return; }
+	e.time = 0.f;                                                       // setTargetRate 4083-4092
+	if (px == 0.f) env_set_value(e, py);
+	else { e.r_target = py; e.active = (e.r_out != py); e.r_rate = px; }
+}
+__device__ __forceinline__ void env_release_rt(Env& e, float time, float level, float fs, bool rate) { e.stage = ENV_RELEASE; env_set_target_rt(e, time, level, 0.f, fs, rate); }   // 3961-3966
+template<class PTS>
+__device__ __forceinline__ void env_segment_end_rt(Env& e, const PTS& p, int npm, int ls, int le, const SampleRate& fs) {
+	const int npoints = npm & 0xFFFF; const bool rate = (npm & ENV_NPM_RATE) != 0;
 	if (e.stage == ENV_SUSTAIN) {
 		if (ls >= 0 && le >= 0 && (e.point + 1) >= le) {                // loop.isActive() && (point + 1) >= loop.end
 			e.point = ls;
 			env_set_value(e, p.y(ls));
-			if (ls != le) env_set_target_time(e, p.x(ls + 1), p.y(ls + 1), p.x(ls), fs.f);
+			if (ls != le) env_set_target_rt(e, p.x(ls + 1), p.y(ls + 1), p.x(ls), fs.f, rate);
 		}
 		else if ((e.point + 1) < npoints) {
-			if (e.time >= p.x(e.point + 1)) {
+			if (rate || e.time >= p.x(e.point + 1)) {                      // mode() == Rate || time >= points[point + 1].x   4031
 				e.point++;
 				env_set_value(e, p.y(e.point));
 				if ((e.point + 1) < npoints)
-					env_set_target_time(e, p.x(e.point + 1), p.y(e.point + 1), p.x(e.point), fs.f);
+					env_set_target_rt(e, p.x(e.point + 1), p.y(e.point + 1), p.x(e.point), fs.f, rate);
 			}
 		}
 		else e.stage = ENV_OFF;
 	}
 	else if (e.stage == ENV_RELEASE) e.stage = ENV_OFF;
 }
-__device__ __forceinline__ float env_process_rt(Env& e, const Pts4& p, int npoints, int ls, int le, const SampleRate& fs) {
+// holding on a one-point loop re-applies setValue(points[start].y) every sample: nothing changes once it has been applied.  `hold_y` = points[loop.start].y,
+// looked up once per block (env_hold_y): the per-sample test reads no breakpoint.
+template<class PTS> __device__ __forceinline__ float env_hold_y(const PTS& p, int ls) { return p.y(ls < 0 ? 0 : ls); }
+__device__ __forceinline__ bool env_settled(const Env& e, int ls, int le, float hold_y) { return ls >= 0 && ls == le && e.point == ls && e.r_out == hold_y; }
+template<class PTS>
+__device__ __forceinline__ float env_process_rt(Env& e, const PTS& p, int npm, int ls, int le, float hold_y, const SampleRate& fs) {
 	const float out = e.r_out;
 	const bool up = e.r_target > e.r_out;
 	const float nxt = e.r_out + (up ? e.r_rate : -e.r_rate);
@@ -651,11 +671,9 @@ __device__ __forceinline__ float env_process_rt(Env& e, const Pts4& p, int npoin
 	e.active = e.active && (stepped != e.r_target);
 	const bool sustain = (e.stage == ENV_SUSTAIN);
 	e.time = sustain ? (e.time + fs.timeInc) : e.time;
-	// holding on a one-point loop re-applies setValue(points[start].y) every sample: nothing changes once it has been applied
-	const bool settled = ls >= 0 && ls == le && e.point == ls && e.r_out == p.y(ls);
-	const bool rare = !e.active && ((sustain && !settled) || e.stage == ENV_RELEASE);
+	const bool rare = !e.active && ((sustain && !env_settled(e, ls, le, hold_y)) || e.stage == ENV_RELEASE);
 	if (__ballot(rare) != 0ull) {
-		if (rare) env_segment_end_rt(e, p, npoints, ls, le, fs);
+		if (rare) env_segment_end_rt(e, p, npm, ls, le, fs);
 	}
 	return out;
 }
@@ -663,5 +681,8 @@ __device__ __forceinline__ float env_process_rt(Env& e, const Pts4& p, int npoin
 // Envelope state <-> 6 flag bits: stage(2) | point(3) | active(1)
 __device__ __forceinline__ uint32_t env_pack(const Env& e) { return (uint32_t)e.stage | ((uint32_t)e.point << 2) | ((uint32_t)e.active << 5); }
 __device__ __forceinline__ void env_unpack(Env& e, uint32_t b) { e.stage = (int)(b & 3u); e.point = (int)((b >> 2) & 7u); e.active = ((b >> 5) & 1u) != 0; }
+// ... and the bits word of a graph record (include/klang_mi355_graph.h env_bits): the same six, Rate mode in bit 6 (host-owned: kept as it came), the point's higher bits from bit 7
+__device__ __forceinline__ uint32_t env_pack_rt(const Env& e, int npm) { return (uint32_t)e.stage | ((uint32_t)(e.point & 7) << 2) | ((uint32_t)e.active << 5) | ((npm & ENV_NPM_RATE) ? 64u : 0u) | ((uint32_t)(e.point >> 3) << 7); }
+__device__ __forceinline__ void env_unpack_rt(Env& e, int& npm, uint32_t b, uint32_t npoints) { e.stage = (int)(b & 3u); e.point = (int)(((b >> 2) & 7u) | ((b >> 7) << 3)); e.active = ((b >> 5) & 1u) != 0; npm = (int)(npoints & 0xFFFFu) | ((b & 64u) ? (int)ENV_NPM_RATE : 0); }
 
 } // namespace klg

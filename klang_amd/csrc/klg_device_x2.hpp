@@ -34,6 +34,8 @@ __device__ __forceinline__ i2 stage_all_off(i2) { return (i2)(int)ST_OFF; }
 __device__ __forceinline__ int loop_index(uint32_t v) { return v == 255u ? -1 : (int)v; }              // record byte of Envelope::Loop start / end: 255 = none
 __device__ __forceinline__ i2 loop_index(u2 v) { return (v == 255u) ? (i2)(-1) : to_i(v); }
 __device__ __forceinline__ bool env_is_off(int stage) { return stage == ENV_OFF; }
+__device__ __forceinline__ bool env_is_sustain(int stage) { return stage == ENV_SUSTAIN; }
+__device__ __forceinline__ bool env_is_release(int stage) { return stage == ENV_RELEASE; }
 __device__ __forceinline__ i2 env_is_off(i2 stage) { return stage == (int)ENV_OFF; }
 
 // ---- Generators::Fast::Sine klang.h:5093-5172 ----
@@ -144,14 +146,26 @@ __device__ __forceinline__ f2 env_step(Env2& e, const SampleRate& fs, i2& sustai
 	return out;
 }
 __device__ __forceinline__ f2 y_at(const Pts4x2& p, i2 i) { return (i == 3) ? p.y3 : ((i == 2) ? p.y2 : ((i == 1) ? p.y1 : p.y0)); }
-__device__ __forceinline__ f2 env_process_rt(Env2& e, const Pts4x2& p, i2 npoints, i2 ls, i2 le, const SampleRate& fs) {
+// more than four point slots: the pair's record words in HBM behind the four in registers (PtsN, klg_device.hpp); voice 1's words are one further
+struct PtsNx2 { Pts4x2 head; const uint32_t* ext; size_t stride; int slots; };
+template<int c> __device__ __forceinline__ PtsN pts_get(const PtsNx2& p) { PtsN s; s.head = pts_get<c>(p.head); s.ext = p.ext + c; s.stride = p.stride; s.slots = p.slots; return s; }
+__device__ __forceinline__ f2 env_hold_y(const Pts4x2& p, i2 ls) { return y_at(p, ls); }
+__device__ __forceinline__ f2 env_hold_y(const PtsNx2& p, i2 ls) { f2 r = { env_hold_y(pts_get<0>(p), ls.x), env_hold_y(pts_get<1>(p), ls.y) }; return r; }
+// npm: point count | Rate mode << 16 per voice (env_process_rt, klg_device.hpp)
+__device__ __forceinline__ void env_unpack_rt(Env2& e, i2& npm, u2 b, u2 npoints) {
+	e.stage = to_i(b & 3u); e.point = to_i(((b >> 2) & 7u) | ((b >> 7) << 3)); e.active = -to_i((b >> 5) & 1u);
+	npm = to_i(npoints & 0xFFFFu) | (to_i((b >> 6) & 1u) << 16);
+}
+__device__ __forceinline__ u2 env_pack_rt(const Env2& e, i2 npm) { return to_u(e.stage) | ((to_u(e.point) & 7u) << 2) | ((to_u(e.active) & 1u) << 5) | (((to_u(npm) >> 16) & 1u) << 6) | ((to_u(e.point) >> 3) << 7); }
+template<class PTS2>
+__device__ __forceinline__ f2 env_process_rt(Env2& e, const PTS2& p, i2 npm, i2 ls, i2 le, f2 hold_y, const SampleRate& fs) {
 	i2 sustain;
 	const f2 out = env_step(e, fs, sustain);
-	const i2 settled = (ls >= 0) & (ls == le) & (e.point == ls) & (e.r_out == y_at(p, ls));
+	const i2 settled = (ls >= 0) & (ls == le) & (e.point == ls) & (e.r_out == hold_y);
 	const i2 rare = ~e.active & ((sustain & ~settled) | (e.stage == (int)ENV_RELEASE));
 	if (__ballot((rare.x | rare.y) != 0) != 0ull) {
-		if (rare.x) { Env s = env_get<0>(e); env_segment_end_rt(s, pts_get<0>(p), npoints.x, ls.x, le.x, fs); env_put<0>(e, s); }
-		if (rare.y) { Env s = env_get<1>(e); env_segment_end_rt(s, pts_get<1>(p), npoints.y, ls.y, le.y, fs); env_put<1>(e, s); }
+		if (rare.x) { Env s = env_get<0>(e); env_segment_end_rt(s, pts_get<0>(p), npm.x, ls.x, le.x, fs); env_put<0>(e, s); }
+		if (rare.y) { Env s = env_get<1>(e); env_segment_end_rt(s, pts_get<1>(p), npm.y, ls.y, le.y, fs); env_put<1>(e, s); }
 	}
 	return out;
 }

@@ -1762,7 +1762,7 @@ struct FxGraphArgs {
 	int blocks; size_t block_stride;         // klg_fx_staged only (klg_fx_render_device): a span of `blocks` blocks of n samples in one launch, block b's [K][CH][n] rows
 	                                         // block_stride floats after block b - 1's; prepare() at the head of every block as in Effect::process(buffer).  0 / 1: one block
 };
-struct FxCtx { SampleRate fs; const float* ctl; unsigned long long samples; float* ring; const int* rand; size_t rstride; };   // ring: this lane's column of the group's tile; rand: this instance's column of the block's draws
+struct FxCtx { SampleRate fs; const float* ctl; unsigned long long samples; float* ring; const int* rand; size_t rstride; const uint32_t* rec; size_t stride; };   // rec / stride: the instance's record in HBM (word w at rec[w * stride]): what an Envelope with more than four point slots reads when a segment ends   // ring: this lane's column of the group's tile; rand: this instance's column of the block's draws
 __device__ __forceinline__ float ctl_read(const FxCtx& c, unsigned i) { return c.ctl[i]; }
 
 template<class P>
@@ -1780,6 +1780,7 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_graph(const FxGraphArgs a) {
 	c.fs = a.fs; c.ctl = a.controls + (size_t)k * KLG_MAX_CTL; c.samples = a.samples;
 	c.ring = a.rings + (size_t)(k / P::kRingRow) * a.ring_rows * P::kRingRow + (k % P::kRingRow);     // (rows of 64 instances: blockIdx.x * ring_rows * 64 + lane)
 	c.rand = a.rand ? a.rand + (size_t)(k < a.K ? k : 0) : nullptr; c.rstride = a.rstride;
+	c.rec = a.state + k; c.stride = a.kpad;
 	P::begin(L, rec, c);
 	const int col = lane & 31, half = lane >> 5;
 	for (int s0 = 0; s0 < a.n; s0 += FX_CHUNK) {

@@ -125,16 +125,21 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 				mark(w0, LPF_WORDS);
 			}
 			break;
-		case N_ENV:
-			live += (x2 ? std::string(" Env2") : std::string(" Env")) + fmt(" n%zu; ", i) + (x2 ? "Pts4x2" : "Pts4") + fmt(" n%zup; ", i) + TI + fmt(" n%zunp, n%zuls, n%zule;", i, i, i);
+		case N_ENV: {
+			// four point slots in registers; a node with more (its argument) reads the others from the voice's record when a segment ends (PtsN / PtsNx2, klg_device.hpp)
+			const int cap = env_capacity(g.arg((int)i)); const bool far = cap > 4;
+			live += (x2 ? std::string(" Env2") : std::string(" Env")) + fmt(" n%zu; ", i) + (x2 ? (far ? "PtsNx2" : "Pts4x2") : (far ? "PtsN" : "Pts4")) + fmt(" n%zup; ", i) + TI + fmt(" n%zunp, n%zuls, n%zule; ", i, i, i) + TF + fmt(" n%zuhy;", i);
 			if (!x2) live += fmt(" float n%zugs, n%zugt;", i, i);                     // event-free chunks: this envelope's step and time step (quiet())
-			begin += "\t\t" + n + ".r_out = " + F(ENV_OUT) + "; " + n + ".r_target = " + F(ENV_TARGET) + "; " + n + ".r_rate = " + F(ENV_RATE) + "; " + n + ".time = " + F(ENV_TIME) + "; env_unpack(" + n + ", " + R(ENV_BITS) + "); "
-				+ n + "np = to_i(" + R(ENV_NPOINTS) + "); " + n + "ls = loop_index(" + R(ENV_LOOP) + " & 0xFFu); " + n + "le = loop_index((" + R(ENV_LOOP) + " >> 8) & 0xFFu);\n";
-			begin += "\t\t" + n + "p.x0 = " + F(ENV_PX) + "; " + n + "p.x1 = " + F(ENV_PX + 1) + "; " + n + "p.x2 = " + F(ENV_PX + 2) + "; " + n + "p.x3 = " + F(ENV_PX + 3) + "; "
-				+ n + "p.y0 = " + F(ENV_PY) + "; " + n + "p.y1 = " + F(ENV_PY + 1) + "; " + n + "p.y2 = " + F(ENV_PY + 2) + "; " + n + "p.y3 = " + F(ENV_PY + 3) + ";\n";
-			end += W(ENV_OUT, "f2u(" + n + ".r_out)") + W(ENV_TARGET, "f2u(" + n + ".r_target)") + W(ENV_RATE, "f2u(" + n + ".r_rate)") + W(ENV_TIME, "f2u(" + n + ".time)") + W(ENV_BITS, "env_pack(" + n + ")");
+			const std::string h = far ? n + "p.head" : n + "p";
+			begin += "\t\t" + n + ".r_out = " + F(ENV_OUT) + "; " + n + ".r_target = " + F(ENV_TARGET) + "; " + n + ".r_rate = " + F(ENV_RATE) + "; " + n + ".time = " + F(ENV_TIME) + "; env_unpack_rt(" + n + ", " + n + "np, " + R(ENV_BITS) + ", " + R(ENV_NPOINTS) + "); "
+				+ n + "ls = loop_index(" + R(ENV_LOOP) + " & 0xFFu); " + n + "le = loop_index((" + R(ENV_LOOP) + " >> 8) & 0xFFu);\n";
+			begin += "\t\t" + h + ".x0 = " + F(ENV_PX) + "; " + h + ".x1 = " + F(ENV_PX + 1) + "; " + h + ".x2 = " + F(ENV_PX + 2) + "; " + h + ".x3 = " + F(ENV_PX + 3) + "; "
+				+ h + ".y0 = " + F(ENV_PY) + "; " + h + ".y1 = " + F(ENV_PY + 1) + "; " + h + ".y2 = " + F(ENV_PY + 2) + "; " + h + ".y3 = " + F(ENV_PY + 3) + ";\n";
+			if (far) begin += "\t\t" + n + fmt("p.ext = c.rec + (size_t)%d * c.stride; ", w0 + ENV_WORDS) + n + "p.stride = c.stride; " + n + fmt("p.slots = %d;\n", cap - 4);
+			begin += "\t\t" + n + "hy = env_hold_y(" + n + "p, " + n + "ls);\n";
+			end += W(ENV_OUT, "f2u(" + n + ".r_out)") + W(ENV_TARGET, "f2u(" + n + ".r_target)") + W(ENV_RATE, "f2u(" + n + ".r_rate)") + W(ENV_TIME, "f2u(" + n + ".time)") + W(ENV_BITS, "env_pack_rt(" + n + ", " + n + "np)");
 			mark(w0 + ENV_OUT, 5);
-			break;
+		} break;
 		case N_ADSR:
 			live += " Adsr" + T2 + fmt(" n%zu;", i);
 			if (!x2) live += fmt(" float n%zugs, n%zugt;", i, i);
@@ -197,16 +202,20 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			mark(w0 + FOLLOW_OUT, 1);
 			break;
 		case N_OPERATOR: {
-			live += fmt(" FSine n%zu; float n%zua, n%zuf; Env n%zue; Pts4 n%zup; int n%zunp, n%zuls, n%zule; float n%zugs, n%zugt;", i, i, i, i, i, i, i, i, i, i);
+			const int cap = env_capacity(g.arg((int)i)); const bool far = cap > 4;
+			live += fmt(" FSine n%zu; float n%zua, n%zuf; Env n%zue; %s n%zup; int n%zunp, n%zuls, n%zule; float n%zuhy, n%zugs, n%zugt;", i, i, i, i, far ? "PtsN" : "Pts4", i, i, i, i, i, i, i);
 			const int e0 = OPER_ENV;
+			const std::string h = far ? n + "p.head" : n + "p";
 			begin += "\t\t" + n + ".inc = (int32_t)" + R(OPER_INC) + "; " + n + ".pos = " + R(OPER_POS) + "; " + n + "a = " + F(OPER_AMP) + "; " + n + "f = " + F(OPER_FREQ) + ";\n";
-			begin += "\t\t" + n + "e.r_out = " + F(e0 + ENV_OUT) + "; " + n + "e.r_target = " + F(e0 + ENV_TARGET) + "; " + n + "e.r_rate = " + F(e0 + ENV_RATE) + "; " + n + "e.time = " + F(e0 + ENV_TIME) + "; env_unpack(" + n + "e, " + R(e0 + ENV_BITS) + "); "
-				+ n + "np = (int)" + R(e0 + ENV_NPOINTS) + "; " + n + "ls = (int)(" + R(e0 + ENV_LOOP) + " & 0xFFu); " + n + "le = (int)((" + R(e0 + ENV_LOOP) + " >> 8) & 0xFFu); "
+			begin += "\t\t" + n + "e.r_out = " + F(e0 + ENV_OUT) + "; " + n + "e.r_target = " + F(e0 + ENV_TARGET) + "; " + n + "e.r_rate = " + F(e0 + ENV_RATE) + "; " + n + "e.time = " + F(e0 + ENV_TIME) + "; env_unpack_rt(" + n + "e, " + n + "np, " + R(e0 + ENV_BITS) + ", " + R(e0 + ENV_NPOINTS) + "); "
+				+ n + "ls = (int)(" + R(e0 + ENV_LOOP) + " & 0xFFu); " + n + "le = (int)((" + R(e0 + ENV_LOOP) + " >> 8) & 0xFFu); "
 				+ n + "ls = " + n + "ls == 255 ? -1 : " + n + "ls; " + n + "le = " + n + "le == 255 ? -1 : " + n + "le;\n";
-			begin += "\t\t" + n + "p.x0 = " + F(e0 + ENV_PX) + "; " + n + "p.x1 = " + F(e0 + ENV_PX + 1) + "; " + n + "p.x2 = " + F(e0 + ENV_PX + 2) + "; " + n + "p.x3 = " + F(e0 + ENV_PX + 3) + "; "
-				+ n + "p.y0 = " + F(e0 + ENV_PY) + "; " + n + "p.y1 = " + F(e0 + ENV_PY + 1) + "; " + n + "p.y2 = " + F(e0 + ENV_PY + 2) + "; " + n + "p.y3 = " + F(e0 + ENV_PY + 3) + ";\n";
+			begin += "\t\t" + h + ".x0 = " + F(e0 + ENV_PX) + "; " + h + ".x1 = " + F(e0 + ENV_PX + 1) + "; " + h + ".x2 = " + F(e0 + ENV_PX + 2) + "; " + h + ".x3 = " + F(e0 + ENV_PX + 3) + "; "
+				+ h + ".y0 = " + F(e0 + ENV_PY) + "; " + h + ".y1 = " + F(e0 + ENV_PY + 1) + "; " + h + ".y2 = " + F(e0 + ENV_PY + 2) + "; " + h + ".y3 = " + F(e0 + ENV_PY + 3) + ";\n";
+			if (far) begin += "\t\t" + n + fmt("p.ext = c.rec + (size_t)%d * c.stride; ", w0 + e0 + ENV_WORDS) + n + "p.stride = c.stride; " + n + fmt("p.slots = %d;\n", cap - 4);
+			begin += "\t\t" + n + "hy = env_hold_y(" + n + "p, " + n + "ls);\n";
 			end += W(OPER_POS, n + ".pos") + W(OPER_AMP, "f2u(" + n + "a)")
-				+ W(e0 + ENV_OUT, "f2u(" + n + "e.r_out)") + W(e0 + ENV_TARGET, "f2u(" + n + "e.r_target)") + W(e0 + ENV_RATE, "f2u(" + n + "e.r_rate)") + W(e0 + ENV_TIME, "f2u(" + n + "e.time)") + W(e0 + ENV_BITS, "env_pack(" + n + "e)");
+				+ W(e0 + ENV_OUT, "f2u(" + n + "e.r_out)") + W(e0 + ENV_TARGET, "f2u(" + n + "e.r_target)") + W(e0 + ENV_RATE, "f2u(" + n + "e.r_rate)") + W(e0 + ENV_TIME, "f2u(" + n + "e.time)") + W(e0 + ENV_BITS, "env_pack_rt(" + n + "e, " + n + "np)");
 			mark(w0 + OPER_POS, 1); mark(w0 + OPER_AMP, 1); mark(w0 + e0 + ENV_OUT, 5);
 		} break;
 		case N_WAVETABLE:
@@ -411,7 +420,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			body += d + fn + "(" + n + ", " + a + ");\n";
 		} break;
 		case OP_LPFSET: body += (o.imm == 0 ? "\t\tbiquad_lpf_set(" : fmt("\t\tbiquad_set<%u>(", o.imm)) + n + ", " + n + "s, " + a + ", " + b + ", c.fs.w);\n"; break;
-		case OP_ENV: body += d + (k == N_ADSR ? "adsr_process(" + n + ", c.fs)" : "env_process_rt(" + n + ", " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs)") + ";\n"; break;
+		case OP_ENV: body += d + (k == N_ADSR ? "adsr_process(" + n + ", c.fs)" : "env_process_rt(" + n + ", " + n + "p, " + n + "np, " + n + "ls, " + n + "le, " + n + "hy, c.fs)") + ";\n"; break;
 		case OP_ADD: body += d + a + " + " + b + ";\n"; break;
 		case OP_SUB: body += d + a + " - " + b + ";\n"; break;
 		case OP_MUL: body += d + a + " * " + b + ";\n"; break;
@@ -441,7 +450,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		case OP_DMUL: body += dd + a + " * " + b + ";\n"; break;
 		case OP_DDIV: body += dd + a + " / " + b + ";\n"; break;
 		case OP_D2F: body += d + "(float)" + a + ";\n"; break;
-		case OP_ENVOFF: body += d + "env_is_off(" + n + (k == N_ADSR ? ".e" : "") + ".stage) ? 1.f : 0.f;\n"; break;     // Envelope::finished klang.h:4094
+		case OP_ENVOFF: body += d + (o.imm == 0u ? "env_is_off(" : o.imm == 1u ? "env_is_sustain(" : "env_is_release(") + n + (k == N_ADSR ? ".e" : "") + ".stage) ? 1.f : 0.f;\n"; break;     // Envelope::finished klang.h:4094; `env == Envelope::Sustain / Release` 3883
 		case OP_CMP: { static const char* rel[6] = { "<", ">", "<=", ">=", "==", "!=" }; body += d + "(" + a + " " + rel[o.imm <= 5u ? o.imm : 0u] + " " + b + ") ? 1.f : 0.f;\n"; } break;
 		case OP_IF:
 			if_depth++;
@@ -486,7 +495,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 0xFFu] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 0xFFu]) : fx ? fmt("L.ctl%u", o.imm) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";
-			body += d + "fsine_process(" + n + ", fsine_rel_offset(" + (o.a >= 0 ? a : std::string("0.f")) + ")) * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, c.fs) * " + n + "a);\n";
+			body += d + "fsine_process(" + n + ", fsine_rel_offset(" + (o.a >= 0 ? a : std::string("0.f")) + ")) * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, " + n + "hy, c.fs) * " + n + "a);\n";
 			break;
 		}
 	};
@@ -590,8 +599,8 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 				for (size_t i = 0; i < g.nodes.size(); i++) {
 					const std::string n = fmt("L.n%zu", i);
 					if (g.nodes[i] == N_ADSR) glide_test += "\t\tsafe = env_safe(" + n + ".e, " + n + ".e.point == 2, " + n + "gs, " + n + "gt, L.tinc) && safe;\n";
-					else if (g.nodes[i] == N_ENV) glide_test += "\t\tsafe = env_safe(" + n + ", " + n + "ls >= 0 && " + n + "ls == " + n + "le && " + n + ".point == " + n + "ls && " + n + ".r_out == " + n + "p.y(" + n + "ls), " + n + "gs, " + n + "gt, L.tinc) && safe;\n";
-					else if (g.nodes[i] == N_OPERATOR) glide_test += "\t\tsafe = env_safe(" + n + "e, " + n + "ls >= 0 && " + n + "ls == " + n + "le && " + n + "e.point == " + n + "ls && " + n + "e.r_out == " + n + "p.y(" + n + "ls), " + n + "gs, " + n + "gt, L.tinc) && safe;\n";
+					else if (g.nodes[i] == N_ENV) glide_test += "\t\tsafe = env_safe(" + n + ", env_settled(" + n + ", " + n + "ls, " + n + "le, " + n + "hy), " + n + "gs, " + n + "gt, L.tinc) && safe;\n";
+					else if (g.nodes[i] == N_OPERATOR) glide_test += "\t\tsafe = env_safe(" + n + "e, env_settled(" + n + "e, " + n + "ls, " + n + "le, " + n + "hy), " + n + "gs, " + n + "gt, L.tinc) && safe;\n";
 				}
 				qbody = std::regex_replace(qbody, std::regex("adsr_process\\((L\\.n[0-9]+), c\\.fs\\)"), "env_glide($1.e, $1gs, $1gt)");
 				qbody = std::regex_replace(qbody, std::regex("env_process_rt\\((L\\.n[0-9]+)e, [^)]*\\)"), "env_glide($1e, $1gs, $1gt)");

@@ -87,6 +87,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 		for (int i = first; i < N; i++) {
 			const Op& o = g.ops[(size_t)i];
 			if (o.code == OP_STOP || o.code == OP_STOPIF || o.code == OP_TABREAD || o.code == OP_ENVOFF) return refuse("op without a staged form");
+			if ((o.code == OP_ENV || o.code == OP_OPERATOR) && o.node >= 0 && env_capacity(g.arg(o.node)) > 4) return refuse("an Envelope with more than four point slots has no staged form");
 			VOp v; v.code = o.code; v.dst = o.dst; v.a = o.a; v.b = o.b; v.node = o.node; v.imm = o.imm; v.orig = i;
 			if (o.code == OP_ELSE) { if (path.empty()) return refuse("unbalanced else"); path.back().second = 1; v.path = path; V.push_back(v); continue; }
 			if (o.code == OP_ENDIF) { if (path.empty()) return refuse("unbalanced endif"); path.pop_back(); v.path = path; V.push_back(v); continue; }

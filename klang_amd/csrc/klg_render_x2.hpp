@@ -292,6 +292,7 @@ struct BlockCtx2 {
 	SampleRate fs;
 	const float* ctl0; const float* ctl1;     // the two voices' synth instances (they differ when notes_per_synth is odd)
 	const TableDesc* tables;
+	const uint32_t* rec; size_t stride;       // the pair's records in HBM: word w of voice 0 at rec[w * stride], of voice 1 one further (what is read only when a segment ends: PtsNx2)
 };
 __device__ __forceinline__ float ctl_read(const BlockCtx& c, unsigned i) { return c.ctl[i]; }
 __device__ __forceinline__ f2 ctl_read(const BlockCtx2& c, unsigned i) { f2 r = { c.ctl0[i], c.ctl1[i] }; return r; }
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(WG) void klg_render_x2(const RenderArgs a) {
 		ctx.fs = a.fs; ctx.tables = a.tables;
 		ctx.ctl0 = a.controls + (size_t)((v < a.voices ? v : 0) / a.notes_per_synth) * KLG_MAX_CTL;
 		ctx.ctl1 = a.controls + (size_t)((v + 1 < a.voices ? v + 1 : 0) / a.notes_per_synth) * KLG_MAX_CTL;
+		ctx.rec = a.state + (in_range ? v : 0); ctx.stride = a.stride;       // (a pair outside the planes computes on zeros and keeps nothing: it may read any record)
 		P::begin(L, rec, ctx);
 		for (int c0 = 0; c0 < n; c0 += X2_CHUNK) {
 			const int cl = (n - c0 < X2_CHUNK) ? (n - c0) : X2_CHUNK;

@@ -28,7 +28,10 @@ enum {
 	ST_IIR1,                 // p: a, b ; in: signal
 	ST_BUTTER1,              // p: b0, a1 ; in: signal
 	ST_MODAL,                // p: a1, a2, gain ; in: signal
-	ST_FOLLOWER_AR, ST_FOLLOWER_PEAK, ST_FOLLOWER_RMS   // p: A, R ; in: signal
+	ST_FOLLOWER_AR, ST_FOLLOWER_PEAK, ST_FOLLOWER_RMS,  // p: A, R ; in: signal
+	// the run-time envelope of recorded graph patches — any number of points, loop, Time / Rate mode (env_process_rt over PtsN)
+	ST_ENVN                  // p: r_out r_target r_rate time bits(graph record form) npoints loop_start loop_end release_at rel_time rel_level fs capacity ;
+	                         // in: the record's point words — x0..x3 y0..y3, then x of points 4.. and their y (capacity - 4 each) ; out values + stage
 };
 
 struct SelfTestArgs { int prim, n, n_in; const float* p; const float* in; float* out; float* scratch; };
@@ -79,6 +82,18 @@ __global__ void klg_selftest_kernel(const SelfTestArgs a) {
 		Pts3 pt; pt.x0 = p[6]; pt.x1 = p[7]; pt.x2 = p[8]; pt.y0 = p[9]; pt.y1 = p[10]; pt.y2 = p[11];
 		SampleRate fs; fs.f = p[12]; fs.timeInc = 1.0f / fs.f; fs.w = 0.f;
 		for (int i = 0; i < n; i++) { out[i] = env_process<3, false>(e, pt, (int)p[5], fs); out[n + i] = (float)e.stage; }
+	} break;
+	case ST_ENVN: {
+		Env e; int npm; e.r_out = p[0]; e.r_target = p[1]; e.r_rate = p[2]; e.time = p[3]; env_unpack_rt(e, npm, bits(4), (uint32_t)p[5]);
+		const int ls = (int)p[6], le = (int)p[7], release_at = (int)p[8], cap = (int)p[12];
+		SampleRate fs; fs.f = p[11]; fs.timeInc = 1.0f / fs.f; fs.w = 0.f;
+		PtsN pt; pt.head.x0 = in[0]; pt.head.x1 = in[1]; pt.head.x2 = in[2]; pt.head.x3 = in[3]; pt.head.y0 = in[4]; pt.head.y1 = in[5]; pt.head.y2 = in[6]; pt.head.y3 = in[7];
+		pt.ext = reinterpret_cast<const uint32_t*>(in + 8); pt.stride = 1; pt.slots = cap - 4;
+		const float hy = env_hold_y(pt, ls);
+		for (int i = 0; i < n; i++) {
+			if (i == release_at) env_release_rt(e, p[9], p[10], fs.f, (npm & ENV_NPM_RATE) != 0);      // Envelope::release klang.h:3961-3966
+			out[i] = env_process_rt(e, pt, npm, ls, le, hy, fs); out[n + i] = (float)e.stage;
+		}
 	} break;
 	case ST_OPERATOR3: {
 		FSine osc[3]; Env env[3]; Pts2 pt[3]; int np[3]; float amp[3];
@@ -229,6 +244,11 @@ extern "C" int klg_selftest_host(int kind, const float* args, int n_args, float 
 	case 7: {
 		host::EnvH e; e.set_points((int)args[0], args + 1, fs);
 		out[0] = e.r_out; out[1] = e.r_target; out[2] = e.r_rate; out[3] = e.time; out[4] = f2b(e.bits());
+	} return 0;
+	case 13: {                                                                      // args: rate mode, loop start, loop end, point count, x y ... -> the state set(points) [+ setLoop] leaves
+		host::EnvH e; e.rate_mode = args[0] != 0.f; e.set_points((int)args[3], args + 4, fs);
+		if (args[1] >= 0.f) e.set_loop((int)args[1], (int)args[2]);
+		out[0] = e.r_out; out[1] = e.r_target; out[2] = e.r_rate; out[3] = e.time; out[4] = f2b(graph::env_bits(e.stage, e.point, e.active, e.rate_mode));
 	} return 0;
 	case 8: out[0] = host::pitch_to_frequency(args[0]); return 0;
 	case 9: { host::Butter1H q; q.set(args[0], fs); out[0] = q.b0; out[1] = q.a1; } return 0;

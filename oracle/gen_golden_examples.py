@@ -114,6 +114,9 @@ def scenarios():
     out["ex_modular"] = poly("ex_modular", 32, [0, 1, 5, 9, 31], off_base=12,
                              ctl=[(3, 0.4), (12, 0.0), (13, 3000.0), (14, 2.0), (15, 4.0), (16, 0.5), (17, -0.6), (18, 5.0), (19, 0.7), (4, 0.1), (7, 0.2), (8, 0.2)],
                              ctl_events=[(3, 12, 1.0), (6, 12, 2.0), (8, 16, -0.4), (9, 17, 0.5), (10, 15, 1.0), (11, 12, 0.0), (14, 13, 800.0)])
+    # (round 6, row a16) env_points.k: a seven-point envelope looping over points 2 .. 5 until off() lifts the loop, Rate-mode envelopes (a jump point, a loop, release in Rate mode),
+    # Envelope::Points + sequence(), a ten-point lookup envelope read with at(), Operators with a six-point and a Rate-mode envelope, `sweep == Envelope::Release`
+    out["own_env_points"] = poly("own_env_points", 56, [0, 1, 7, 8, 20, 55], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 0, 0.05)])
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],

@@ -374,12 +374,16 @@ void ko_env_init_default(ko_env* e) {                            /* Envelope() :
 	ko_env_set_points(e, 1, xy);
 }
 void ko_env_set_points(ko_env* e, int n, const float* xy) {     /* 3893-3896 */
-	if (n > KO_ENV_MAX_POINTS) n = KO_ENV_MAX_POINTS;
+	if (n > KO_ENV_MAX_POINTS) { fprintf(stderr, "ko_env_set_points: %d points (KO_ENV_MAX_POINTS = %d)\n", n, KO_ENV_MAX_POINTS); abort(); }
 	e->npoints = n;
 	for (int i = 0; i < n; i++) { e->px[i] = xy[2 * i]; e->py[i] = xy[2 * i + 1]; }
 	env_initialise(e);
 }
 void ko_env_set_loop(ko_env* e, int start, int end) { if (start >= 0 && end < e->npoints) { e->loop_start = start; e->loop_end = end; } }  /* 3923-3926 */
+void ko_env_reset_loop(ko_env* e) {                             /* 3946-3950 */
+	e->loop_start = e->loop_end = -1;
+	if (e->stage == KO_ENV_SUSTAIN && (e->point + 1) < e->npoints) env_set_target(e, e->px[e->point + 1], e->py[e->point + 1], e->px[e->point]);
+}
 void ko_env_release(ko_env* e, float time, float level) { e->stage = KO_ENV_RELEASE; env_set_target(e, time, level, 0.f); }            /* 3961-3966 */
 
 float ko_env_process(ko_env* e) {                                /* 4018-4051 */

@@ -118,6 +118,17 @@ int main(int argc, char** argv) {
 	{ ko_env e; ko_env_init_default(&e); for (int i = 0; i < 16; i++) { buf[i] = ko_env_process(&e); buf[64 + i] = (float)e.stage; } emit("envelope_default", buf, 16); emit("envelope_default_stage", buf + 64, 16); }
 	{ ko_env e; ko_env_init_default(&e); const float xy[4] = { 0, 1.5f, 3, 0.5f }; ko_env_set_points(&e, 2, xy); for (int i = 0; i < 1024; i++) buf[i] = ko_env_process(&e); emit("envelope_fm_op2", buf, 1024); }
 	{ ko_env e; ko_env_init_default(&e); e.mode = KO_ENV_RATE; const float xy[6] = { 0, 0, 0.001f, 1, 0.0005f, 0.2f }; ko_env_set_points(&e, 3, xy); for (int i = 0; i < 4096; i++) buf[i] = ko_env_process(&e); emit("envelope_rate_mode", buf, 4096); }
+	/* (round 6, row a16) any number of points, loops over later points, Rate mode with a jump point, release() in Rate mode */
+	{ ko_env e; ko_env_init_default(&e); const float xy[14] = { 0, 0, 0.004f, 1, 0.009f, 0.3f, 0.013f, 0.8f, 0.02f, 0.1f, 0.024f, 0.6f, 0.05f, 0 }; ko_env_set_points(&e, 7, xy); ko_env_set_loop(&e, 2, 5);
+	  for (int i = 0; i < 8192; i++) { if (i == 6000) ko_env_reset_loop(&e); buf[i] = ko_env_process(&e); buf[8192 + i] = (float)e.stage; } emit("envelope_7pt_loop_2_5", buf, 8192); emit("envelope_7pt_loop_2_5_stage", buf + 8192, 8192); }
+	{ ko_env e; ko_env_init_default(&e); const float xy[20] = { 0, 0.5f, 0.002f, 1, 0.004f, 0, 0.006f, 0.7f, 0.008f, 0.2f, 0.01f, 0.9f, 0.012f, 0.1f, 0.014f, 0.6f, 0.016f, 0.3f, 0.03f, 0 }; ko_env_set_points(&e, 10, xy);
+	  for (int i = 0; i < 2048; i++) { buf[i] = ko_env_process(&e); buf[4096 + i] = (float)e.stage; } emit("envelope_10pt", buf, 2048); emit("envelope_10pt_stage", buf + 4096, 2048); }
+	{ ko_env e; ko_env_init_default(&e); const float xy[12] = { 0, 0, 0.004f, 1, 0.009f, 0.3f, 0.013f, 0.8f, 0.02f, 0.1f, 0.024f, 0.6f }; ko_env_set_points(&e, 6, xy); ko_env_set_loop(&e, 5, 5);
+	  for (int i = 0; i < 2048; i++) { if (i == 1500) ko_env_release(&e, 0.004f, 0.05f); buf[i] = ko_env_process(&e); buf[4096 + i] = (float)e.stage; } emit("envelope_6pt_hold_5_release", buf, 2048); emit("envelope_6pt_hold_5_release_stage", buf + 4096, 2048); }
+	{ ko_env e; ko_env_init_default(&e); e.mode = KO_ENV_RATE; const float xy[12] = { 0, 0, 0.002f, 1, 0, 0.25f, 0.001f, 0.75f, 0.0005f, 0.5f, 0.004f, 0 }; ko_env_set_points(&e, 6, xy);
+	  for (int i = 0; i < 4096; i++) { buf[i] = ko_env_process(&e); buf[4096 + i] = (float)e.stage; } emit("envelope_rate_6pt_jump", buf, 4096); emit("envelope_rate_6pt_jump_stage", buf + 4096, 4096); }
+	{ ko_env e; ko_env_init_default(&e); e.mode = KO_ENV_RATE; const float xy[10] = { 0, 0, 0.002f, 1, 0.001f, 0.25f, 0.003f, 0.75f, 0.0005f, 0.5f }; ko_env_set_points(&e, 5, xy); ko_env_set_loop(&e, 1, 3);
+	  for (int i = 0; i < 4096; i++) { if (i == 3000) ko_env_release(&e, 0.0007f, 0.1f); buf[i] = ko_env_process(&e); buf[4096 + i] = (float)e.stage; } emit("envelope_rate_loop_1_3_release", buf, 4096); emit("envelope_rate_loop_1_3_release_stage", buf + 4096, 4096); }
 
 	{
 		ko_operator op1, op2, op3; ko_operator_init(&op1); ko_operator_init(&op2); ko_operator_init(&op3);

@@ -130,6 +130,12 @@ int main(int argc, char** argv) {
 	{ Envelope e; std::vector<float> v(16), st(16); for (int i = 0; i < 16; i++) { v[i] = e++; st[i] = (float)e.getStage(); } emit("envelope_default", v); emit("envelope_default_stage", st); }
 	{ Envelope e = { { 0, 1.5f }, { 3, 0.5f } }; std::vector<float> v(1024); for (int i = 0; i < 1024; i++) v[i] = e++; emit("envelope_fm_op2", v); }
 	{ Envelope e; e.setMode(Envelope::Rate); e = { { 0, 0 }, { 0.001f, 1 }, { 0.0005f, 0.2f } }; std::vector<float> v(4096); for (int i = 0; i < 4096; i++) v[i] = e++; emit("envelope_rate_mode", v); }
+	// (round 6) any number of points, loops over later points, Rate mode with a jump point (x == 0), release() in Rate mode (the `time` argument is the RATE there: setTarget({ time, level }, 0) -> setTargetRate)
+	{ Envelope e = { { 0, 0 }, { 0.004f, 1 }, { 0.009f, 0.3f }, { 0.013f, 0.8f }, { 0.02f, 0.1f }, { 0.024f, 0.6f }, { 0.05f, 0 } }; e.setLoop(2, 5); std::vector<float> v(8192), st(8192); for (int i = 0; i < 8192; i++) { if (i == 6000) e.resetLoop(); v[i] = e++; st[i] = (float)e.getStage(); } emit("envelope_7pt_loop_2_5", v); emit("envelope_7pt_loop_2_5_stage", st); }
+	{ Envelope e = { { 0, 0.5f }, { 0.002f, 1 }, { 0.004f, 0 }, { 0.006f, 0.7f }, { 0.008f, 0.2f }, { 0.01f, 0.9f }, { 0.012f, 0.1f }, { 0.014f, 0.6f }, { 0.016f, 0.3f }, { 0.03f, 0 } }; std::vector<float> v(2048), st(2048); for (int i = 0; i < 2048; i++) { v[i] = e++; st[i] = (float)e.getStage(); } emit("envelope_10pt", v); emit("envelope_10pt_stage", st); }
+	{ Envelope e = { { 0, 0 }, { 0.004f, 1 }, { 0.009f, 0.3f }, { 0.013f, 0.8f }, { 0.02f, 0.1f }, { 0.024f, 0.6f } }; e.setLoop(5, 5); std::vector<float> v(2048), st(2048); for (int i = 0; i < 2048; i++) { if (i == 1500) e.release(0.004f, 0.05f); v[i] = e++; st[i] = (float)e.getStage(); } emit("envelope_6pt_hold_5_release", v); emit("envelope_6pt_hold_5_release_stage", st); }
+	{ Envelope e; e.setMode(Envelope::Rate); e = { { 0, 0 }, { 0.002f, 1 }, { 0, 0.25f }, { 0.001f, 0.75f }, { 0.0005f, 0.5f }, { 0.004f, 0 } }; std::vector<float> v(4096), st(4096); for (int i = 0; i < 4096; i++) { v[i] = e++; st[i] = (float)e.getStage(); } emit("envelope_rate_6pt_jump", v); emit("envelope_rate_6pt_jump_stage", st); }
+	{ Envelope e; e.setMode(Envelope::Rate); e = { { 0, 0 }, { 0.002f, 1 }, { 0.001f, 0.25f }, { 0.003f, 0.75f }, { 0.0005f, 0.5f } }; e.setLoop(1, 3); std::vector<float> v(4096), st(4096); for (int i = 0; i < 4096; i++) { if (i == 3000) e.release(0.0007f, 0.1f); v[i] = e++; st[i] = (float)e.getStage(); } emit("envelope_rate_loop_1_3_release", v); emit("envelope_rate_loop_1_3_release_stage", st); }
 
 	// --- a18: Operator chain (FM.k shape, fixed indices)
 	{

@@ -97,7 +97,7 @@ def test_example_synths_without_a_handwritten_kernel(name, tmp_path):
     check(*run_facade(path, name, tmp_path), name)
 
 
-@pytest.mark.parametrize("name", ["own_basic_mix", "own_filters_f2", "own_modal_follow", "own_branches", "own_wavetable", "own_sample", "own_pluck", "own_pluck_keep", "own_early_return", "own_iirn", "own_noise_note", "own_smooth_note", "own_hardsync", "own_vibstring", "own_finish_body", "own_pwm"])
+@pytest.mark.parametrize("name", ["own_basic_mix", "own_filters_f2", "own_modal_follow", "own_branches", "own_wavetable", "own_sample", "own_pluck", "own_pluck_keep", "own_early_return", "own_iirn", "own_noise_note", "own_smooth_note", "own_hardsync", "own_vibstring", "own_finish_body", "own_pwm", "own_env_points"])
 def test_own_patches_for_the_other_node_kinds(name, tmp_path):
     """tests/patches/{basic_mix,filters_f2,modal_follow}.k (ours): Basic oscillators incl. per-sample set(f), OnePole LPF/HPF, DCF,
     Butterworth<1>/<2>, IIR<1>, Biquad HPF/BPF/BRF/APF, Modal, Envelope::Follower, a member written back by process().
@@ -109,7 +109,7 @@ def test_own_patches_for_the_other_node_kinds(name, tmp_path):
 
 
 SOLO = ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter", "ex_expression", "ex_addsaw", "ex_am", "ex_fmmod", "ex_fm2", "ex_operators", "ex_nyquist", "ex_square", "ex_resynthesis", "ex_inheritance", "ex_modular",
-        "own_basic_mix", "own_filters_f2", "own_modal_follow", "own_branches", "own_wavetable", "own_sample", "own_pluck", "own_pluck_keep", "own_early_return", "own_iirn", "own_noise_note", "own_smooth_note", "own_hardsync", "own_vibstring", "own_finish_body", "own_pwm"]
+        "own_basic_mix", "own_filters_f2", "own_modal_follow", "own_branches", "own_wavetable", "own_sample", "own_pluck", "own_pluck_keep", "own_early_return", "own_iirn", "own_noise_note", "own_smooth_note", "own_hardsync", "own_vibstring", "own_finish_body", "own_pwm", "own_env_points"]
 
 
 @pytest.mark.parametrize("name", SOLO)
@@ -126,6 +126,20 @@ def test_recorded_graph_single_voice_is_bit_exact(name, tmp_path):
     assert np.array_equal(stages, ref["stages"])
     assert np.array_equal(mix.view(np.uint32), ref["mix"].view(np.uint32)), f"max abs err {np.abs(mix - ref['mix']).max()}"
     assert np.abs(mix).max() > 0
+
+
+def test_envelope_record_capacity(tmp_path):
+    """an Envelope's lane record holds KLANG_GPU_ENV_POINTS point slots (default 16).  tests/patches/env_points.k assigns seven points in on():
+    compiled with 8 slots it renders the same bits from a smaller record; compiled with 6 the note-on STOPS with a message that names the macro — a record never
+    holds a truncated envelope (round 5 silently kept the first four points)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    b8 = os.path.join(ROOT, "tests", "cpp", "_bin", "facade_graph_own_env_points_cap8")
+    mix, stages = run_facade(b8, "own_env_points_solo", tmp_path)
+    ref = np.load(os.path.join(GOLDEN, "own_env_points_solo.npz"))
+    assert np.array_equal(stages, ref["stages"]) and np.array_equal(mix.view(np.uint32), ref["mix"].view(np.uint32))
+    b6 = os.path.join(ROOT, "tests", "cpp", "_bin", "facade_graph_own_env_points_cap6")
+    r = subprocess.run([b6, os.path.join(GOLDEN, "own_env_points_solo.scn"), str(tmp_path / "none.bin")], capture_output=True, text=True)
+    assert r.returncode != 0 and "holds 7 points" in r.stderr and "KLANG_GPU_ENV_POINTS" in r.stderr, (r.returncode, r.stderr[-600:])
 
 
 # ---- TRUE stereo notes (SURVEY §8 row a4): Stereo::Note with `out` = {l, r}, `buffer++ += out` (klang.h:4721-4733) ----

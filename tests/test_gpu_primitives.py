@@ -17,7 +17,7 @@ FREQS = [27.5, 110.0, 440.0, 1000.0, 2093.0045, 7040.0, 15000.0]
 (ST_BASIC_SINE, ST_BASIC_SAW, ST_BASIC_TRIANGLE, ST_BASIC_SQUARE, ST_BASIC_PULSE, ST_FAST_SINE, ST_OSM_SAW, ST_OSM_PULSE,
  ST_ONEPOLE_LPF, ST_ONEPOLE_HPF, ST_BIQUAD, ST_BIQUAD_LPF_SWEEP, ST_ADSR, ST_ENV3, ST_OPERATOR3, ST_DELAY, ST_STEREO_DELAY_TAP,
  ST_MATRIX, ST_CONTROL_SMOOTH, ST_NOISE_BASIC, ST_NOISE_FAST,
- ST_DCF, ST_IIR2, ST_IIR4, ST_IIR1, ST_BUTTER1, ST_MODAL, ST_FOLLOWER_AR, ST_FOLLOWER_PEAK, ST_FOLLOWER_RMS) = range(30)
+ ST_DCF, ST_IIR2, ST_IIR4, ST_IIR1, ST_BUTTER1, ST_MODAL, ST_FOLLOWER_AR, ST_FOLLOWER_PEAK, ST_FOLLOWER_RMS, ST_ENVN) = range(31)
 F32P = C.POINTER(C.c_float)
 
 
@@ -185,6 +185,39 @@ def test_adsr_and_envelopes(L, kat):
     o = env([(0, 1)], 16)
     assert same(o[:16], kat["envelope_default"]) and same(o[16:], kat["envelope_default_stage"])
     assert same(env([(0, 1.5), (3, 0.5)], 1024)[:1024], kat["envelope_fm_op2"])
+
+
+def test_envelopes_of_any_length_loops_and_rate_mode(L, kat):
+    """SURVEY row a16 (klang.h:3812, 3893-3909, 3923-3950, 4031, 4064-4092): the run-time envelope of recorded graph patches — env_process_rt over
+    PtsN: four points in registers, the others read from the record when a segment ends — against the genuine header's vectors: more than four
+    points, loops over later points, resetLoop(), Rate mode (a jump point, a loop), release() in either mode.  Two record capacities each."""
+    def envn(points, n, rate=False, loop=(-1, -1), release=(-1, 0.0, 0.0), cap=None):
+        cap = cap or max(5, len(points))
+        flat = [v for p in points for v in p]
+        st = host(L, 13, [1.0 if rate else 0.0, loop[0], loop[1], len(points)] + flat, 5)
+        xs = [p[0] for p in points] + [0.0] * (cap - len(points)); ys = [p[1] for p in points] + [0.0] * (cap - len(points))
+        words = xs[:4] + ys[:4] + xs[4:] + ys[4:]
+
+        def go(state, n_, ls, le, rel):
+            return run(L, ST_ENVN, list(state) + [len(points), ls, le, rel[0], rel[1], rel[2], FS, cap], n_, inp=words, n_out=2 * n_)
+        return go(st, n, loop[0], loop[1], release)
+    for cap in (None, 16):
+        o = envn([(0, 0.5), (0.002, 1), (0.004, 0), (0.006, 0.7), (0.008, 0.2), (0.01, 0.9), (0.012, 0.1), (0.014, 0.6), (0.016, 0.3), (0.03, 0)], 2048, cap=cap)
+        assert same(o[:2048], kat["envelope_10pt"]) and same(o[2048:], kat["envelope_10pt_stage"])
+        o = envn([(0, 0), (0.004, 1), (0.009, 0.3), (0.013, 0.8), (0.02, 0.1), (0.024, 0.6)], 2048, loop=(5, 5), release=(1500, 0.004, 0.05), cap=cap)
+        assert same(o[:2048], kat["envelope_6pt_hold_5_release"]) and same(o[2048:], kat["envelope_6pt_hold_5_release_stage"])
+        o = envn([(0, 0), (0.002, 1), (0, 0.25), (0.001, 0.75), (0.0005, 0.5), (0.004, 0)], 4096, rate=True, cap=cap)
+        assert same(o[:4096], kat["envelope_rate_6pt_jump"]) and same(o[4096:], kat["envelope_rate_6pt_jump_stage"])
+        o = envn([(0, 0), (0.002, 1), (0.001, 0.25), (0.003, 0.75), (0.0005, 0.5)], 4096, rate=True, loop=(1, 3), release=(3000, 0.0007, 0.1), cap=cap)
+        assert same(o[:4096], kat["envelope_rate_loop_1_3_release"]) and same(o[4096:], kat["envelope_rate_loop_1_3_release_stage"])
+        # the seven-point loop 2 .. 5 up to the sample where the reference lifts the loop (resetLoop at 6000 is host code: the note-level fixture own_env_points covers it)
+        o = envn([(0, 0), (0.004, 1), (0.009, 0.3), (0.013, 0.8), (0.02, 0.1), (0.024, 0.6), (0.05, 0)], 6000, loop=(2, 5), cap=cap)
+        assert same(o[:6000], kat["envelope_7pt_loop_2_5"][:6000]) and same(o[6000:], kat["envelope_7pt_loop_2_5_stage"][:6000])
+    # the older vectors through the run-time form too: three points, the four-point loop 1 .. 3, the Rate-mode KAT of round 1 (which nothing ran on the device until now)
+    o = envn([(0, 880), (0.01, 4400), (0.03, 2200)], 2048)
+    assert same(o[:2048], kat["envelope_3pt"]) and same(o[2048:], kat["envelope_3pt_stage"])
+    assert same(envn([(0, 0), (0.005, 1), (0.01, 0.25), (0.02, 0.5)], 4096, loop=(1, 3))[:4096], kat["envelope_loop_1_3"])
+    assert same(envn([(0, 0), (0.001, 1), (0.0005, 0.2)], 4096, rate=True)[:4096], kat["envelope_rate_mode"])
 
 
 def test_operator_chain(L, kat):
