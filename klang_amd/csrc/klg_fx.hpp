@@ -95,6 +95,9 @@ struct PingPongArgs {
 	BiquadCoef dc;              // dcfilter[k].set(50, 1) — PingPong.k:39-40, computed on the host
 	float c1_min, c1_max;
 	int ablate;                 // measurement only (KLG_FX_ABLATE, the one-wave kernel): 1 = no ring reads, 2 = no ring writes, 4 = no io staging
+	// a long span as TWO launches (klg_fx_pingpong_x, round 6): pass 1 = the kernel compiled without the moving-dials pipeline renders the workgroups whose span
+	// is stationary (decided on the device, as ever) and says so in done[workgroup]; pass 2 = the full kernel renders the others.  0: one launch renders everything.
+	int pass; int* done;
 };
 
 // The kernel works in sub-chunks of PP_SUB samples:
@@ -282,9 +285,19 @@ template<int G> struct PpxLds {
 // workgroups on a chip of 256 CUs.  With G = 16 an audio wave's 64 lanes are 4 samples x 16 instances — its four samples side by
 // side instead of one after the other — so the audio stage is a quarter of the instructions and the bank covers every CU; the control
 // and filter waves run their recurrences on 16 lanes (a lane costs nothing, an instruction does).  The ring layout is the same.
-template<int G>
+// MODE (round 6): three compilations of the one kernel.  The per-sample delay-time arithmetic of the moving-dials steps — and the general loop's near-tap / vibrato
+// forms — share the register allocation of everything around them: the full kernel keeps 36 / 160 / 16 bytes of scratch at G = 16 / 32 / 64.
+//   PPX_FULL        everything (a long span whose dials may move)
+//   PPX_NO_MOVING   without the moving-dials pipeline, which only spans of PPX_MOVING_MIN chunks and more ever run: what a shorter launch — a real-time host's one
+//                   block per call — takes; the same paths otherwise
+//   PPX_STATIONARY  the request-ahead pipeline with dials at rest and nothing else: the FIRST of a long span's two launches (PingPongArgs::pass).  A workgroup whose
+//                   span is not stationary — decided on the device, on the dials as they are — leaves it to the second launch (the full kernel)
+// Same bits whichever compilation renders a block (tests/test_gpu_fx_spans.py).
+enum { PPX_FULL = 0, PPX_NO_MOVING = 1, PPX_STATIONARY = 2 };
+template<int G, int MODE>
 __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongArgs a) {
 	static_assert(G == 64 || G == 32 || G == 16, "instances per workgroup");
+	constexpr bool MV = MODE == PPX_FULL, DEEP_ONLY = MODE == PPX_STATIONARY;
 	constexpr int SPW = 64 / G, PASSES = PPX_PER / SPW;                           // samples a wave holds side by side; passes over its PPX_PER samples
 	__shared__ PpxLds<G> S;
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -299,13 +312,14 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	const int nwg = (int)(a.kpad / G), wg = (int)blockIdx.x;
 	const bool remap = PARTS > 1 && (nwg % (8 * PARTS)) == 0 && !(KLG_PPX_VARIANT & 4);
 	const int k0 = remap ? (((wg / (8 * PARTS)) * 8 + (wg % 8)) * PARTS + (wg / 8) % PARTS) * G : wg * G, k = k0 + li;
+	if (a.pass == 2 && a.done[wg]) return;                                         // rendered by the first launch
 	const int SIZE = 192000, n = a.n;
 	const int nb = a.nb > 0 ? a.nb : n;                                            // the length of a row of the caller's buffer (a span: one block's)
 	// where the caller's rows of this workgroup's first instance stand for sample s of the span (s a multiple of the chunk: a chunk never straddles two blocks)
 	auto io_rows = [&](const int s) { const int b = s / nb; return (char*)(a.io + (size_t)b * a.block_stride + (size_t)k0 * 2 * nb + (s - b * nb)); };
 	const int nchunks = (n + PPX_CHUNK - 1) / PPX_CHUNK;
 	const bool w_control = wv == 0, w_audio = wv >= 1 && wv <= PPX_AUDIO, w_filter = wv > PPX_AUDIO && wv <= PPX_AUDIO + 2;
-	const bool w_control2 = wv == PPX_AUDIO + 3;                                   // the second half of the control chain when the dials move and the pipeline runs ahead (see `moving`)
+	const bool w_control2 = MV && wv == PPX_AUDIO + 3;                                   // the second half of the control chain when the dials move and the pipeline runs ahead (see `moving`)
 	// the control and filter waves are dependent chains that pace the pipeline; the audio waves share their SIMDs and mostly wait for
 	// memory: when both are ready, the chain issues first
 	if (!w_audio) __builtin_amdgcn_s_setprio(3);
@@ -430,9 +444,34 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		// STEADY (a span's inner steps, 2 <= j <= nch - P - 2: every chunk the step touches exists): no test of j at all — through run-time guards every part of
 		// a step ends in a join, and behind a join the compiler waits for everything that is under way
 		// MOVING: the delay time of every sample comes from the control chain's buffers (S.D[chunk & 7]) instead of being the one stationary value
+		// Where step j stands, kept from step to step instead of being derived from j (round 6): a step's two write-cursor positions were 64-bit remainders and its
+		// two row addresses divisions by the block length — on the scalar unit, but ~100 of the ~235 instructions an audio wave issues per step, and a wave issues its
+		// instructions one after the other.  Steps come in order (first_requests starts at j = -P - 1, every later step is the next): pos_j = the write cursor at chunk
+		// j; st_* / ld_*: the caller's rows of chunk j - 2 (to be stored) and of chunk j + P + 1 (to be requested): pointer, samples into the block, chunk number.
+		int pos_j = 0, st_off = 0, st_c = 0, ld_off = 0;
+		char* st_ptr = nullptr; const char* ld_ptr = nullptr;
+		auto cursors_begin = [&]() __attribute__((always_inline)) {
+			const int j0 = -P - 1;
+			int p0 = (int)(((long long)a.position + (long long)j0 * PPX_CHUNK) % SIZE);
+			pos_j = p0 < 0 ? p0 + SIZE : p0;
+			st_c = j0 - 2; st_off = 0; st_ptr = io_rows(0);                 // (chunks before 0 do not exist: the cursor waits at chunk 0 until its step comes)
+			ld_off = 0; ld_ptr = io_rows(0);                                // chunk j0 + P + 1 = 0
+		};
+		auto cursors_next = [&]() __attribute__((always_inline)) {
+			pos_j += PPX_CHUNK; pos_j = pos_j >= SIZE ? pos_j - SIZE : pos_j;
+			const long long skip = ((long long)a.block_stride - nb) * 4;    // from the end of a block's row to the same row of the next block
+			if (st_c >= 0) { st_off += PPX_CHUNK; st_ptr += PPX_CHUNK * 4; if (st_off == nb) { st_off = 0; st_ptr += skip; } }
+			st_c++;
+			ld_off += PPX_CHUNK; ld_ptr += PPX_CHUNK * 4; if (ld_off == nb) { ld_off = 0; ld_ptr += skip; }
+		};
+		// (steady_c: false = guarded, true = steady, IntTag<2> = steady AND the workgroup's instances all exist — no access is predicated: what the compiler needs to
+		//  count the requests under way instead of waiting for all of them, `s_waitcnt vmcnt(0)`, once per step)
 		auto audio_part = [&](auto slot_c, auto steady_c, auto moving_c, const int j, const int nch) __attribute__((always_inline)) {
 			constexpr int RS = decltype(slot_c)::value, IS = (RS + 1) % P;
-			constexpr bool ST = decltype(steady_c)::value, MOVING = decltype(moving_c)::value;
+			constexpr int SV = (int)decltype(steady_c)::value;             // 0 guarded, 1 steady, 2 steady + whole group, 3 guarded + whole group
+			constexpr bool ST = SV == 1 || SV == 2, MOVING = decltype(moving_c)::value;
+			constexpr bool WHOLE = SV == 2 || SV == 3;
+			const bool whole_group = WHOLE || k0 + G <= a.K;
 			constexpr int ND = G <= 32 ? 8 : 4;
 			int at = tid - 64; asm volatile("" : "+v"(at));                    // (see the general loop: keeps per-thread addresses out of loop-invariant registers)
 			// The caller's rows move as VECTORS: a thread takes VW consecutive samples of a row (a 32-sample row of the chunk is 128 contiguous bytes): 4 / 2 x 4 samples
@@ -445,7 +484,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			const int vcol = (at % TPR) * VW, vrow = at / TPR;
 			const int jn = j + 1, js = j - 2;
 			if ((ST || (js >= 0 && js < nch)) && !(KLG_PPX_ABLATE & 2) && !(KLG_PPX_VARIANT & 1)) {       // the caller's rows of chunk j - 2 (filtered in the step before): to memory
-				char* dst = io_rows(js * PPX_CHUNK);
+				char* dst = st_ptr;
 #pragma unroll
 				for (int i = 0; i < NV; i++) {
 					const int row = vrow + RPP * i;
@@ -465,7 +504,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			}
 			const int u0 = (wv - 1) * PPX_PER + lq;
 			if ((ST || (j >= 0 && j < nch)) && !(KLG_PPX_ABLATE & 8)) {                              // AUDIO of chunk j: its rows were requested in step j - P
-				const int pos0 = (int)(((long long)a.position + j * PPX_CHUNK) % SIZE);
+				const int pos0 = pos_j;
 				float (*T)[PPX_CHUNK][G + 1] = S.tile[j & 3];
 #pragma unroll
 				for (int q = 0; q < PASSES; q++) {
@@ -487,7 +526,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			}
 			const int c = j + P;
 			if ((ST || (c >= 0 && c < nch)) && !(KLG_PPX_ABLATE & 4)) {                              // the ring rows of chunk j + P
-				const int pos1 = (int)(((long long)a.position + c * PPX_CHUNK) % SIZE);
+				const int pos1 = wrap(pos_j + P * PPX_CHUNK);
 #pragma unroll
 				for (int q = 0; q < PASSES; q++) {
 					const int u = u0 + q * SPW, pos = wrap(pos1 + u);
@@ -502,7 +541,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			}
 			const int c2 = j + P + 1;
 			if (ST || (c2 >= 0 && c2 < nch)) {                              // the caller's rows of chunk j + P + 1
-				const char* src = io_rows(c2 * PPX_CHUNK);
+				const char* src = ld_ptr;
 #pragma unroll
 				for (int i = 0; i < NV; i++) {
 					const int row = vrow + RPP * i;
@@ -514,11 +553,13 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 					for (int q = 0; q < VW; q++) iov[IS][i * VW + q] = v[q];
 				}
 			}
+			cursors_next();
 		};
 		// The first P steps only request — chunks 0 .. P - 1's ring rows, chunks 0 .. P's caller rows — and need nothing but this lane's own delay time:
 		// they are issued BEFORE the workgroup knows whether the block qualifies (the control wave's words are still on their way), so the
 		// decision costs no round trip of its own.  A block that does not qualify ignores what arrives (every address is a valid one).
 		auto first_requests = [&](auto moving_c) __attribute__((always_inline)) {
+			cursors_begin();
 			auto prologue = [&](auto self, auto t_c) __attribute__((always_inline)) {
 				constexpr int T = decltype(t_c)::value, J = T - P - 1;
 				if constexpr (T < P) { audio_part(IntTag<((J % P) + P) % P>{}, BoolTag<false>{}, moving_c, J, nchunks); self(self, IntTag<T + 1>{}); }
@@ -540,7 +581,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			// P + 1 chunks ahead of the audio; its head start (P chunks before the first request) is repaid over a span, not inside one block.
 			bool ok2 = false;
 			rest5_all = false;
-			{
+			if constexpr (MV) {
 				const float t5 = __builtin_amdgcn_fmed3f(c5, a.c1_min, a.c1_max), s5 = __builtin_amdgcn_fmed3f(sm5, a.c1_min, a.c1_max);
 				// (controls[5] at rest — smoother at its fixed point, detector quiet, as in `stationary` — sets nothing: only controls[1].smooth() still moves, towards controls[1])
 				const bool rest5 = (sm5 * 0.999f + (1.f - 0.999f) * c5 == sm5) && !(fabsf(mdelay - sm5) >= 0.001f) && !(fabsf(c5 - sm5) >= 0.001f);
@@ -557,11 +598,15 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			if (vf) { spec_pos = lfo.position; prescan(0); prescan(1); }
 		}
 		__syncthreads();
+	if (DEEP_ONLY || a.pass == 1) {                                                  // (wave-uniform: S.deep is the workgroup's)
+		if (tid == 0) a.done[wg] = S.deep == 1;
+		if (S.deep != 1) return;                                                     // not stationary: nothing was written yet — the second launch renders this workgroup
+	}
 	if (w_control2 && S.deep != 2) return;                                         // (the twelfth wave has a part only when dials move and the pipeline runs ahead: a wave that has ended is not waited for at a barrier)
 	const bool vibfast = S.vibfast != 0;
-	if (vibfast) { if (w_audio) sines(0); __syncthreads(); }                        // (chunk 1's are taken in step -1, chunk j + 2's in step j)
+	if (!DEEP_ONLY && vibfast) { if (w_audio) sines(0); __syncthreads(); }                        // (chunk 1's are taken in step -1, chunk j + 2's in step j)
 	if (S.deep) {
-		moving = S.deep == 2 && !(KLG_PPX_VARIANT & 16);
+		moving = MV && S.deep == 2 && !(KLG_PPX_VARIANT & 16);
 		// The control chain with moving dials, a chunk at a time.  One wave running all of it (the general loop: ~17 instructions a sample, each waiting for the one
 		// before: ~128 cycles a sample, 1.95 us a chunk) is slower than the memory pipeline it feeds (1.3 us a chunk), however far ahead it runs.  So it is cut where it
 		// only flows one way: the FIRST control wave smooths controls[5], runs the scratch detector and sets controls[1] (PingPong.k:47-56) and leaves controls[1] per sample
@@ -628,7 +673,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 				}
 			lfo.position = pos;
 		};
-		if (moving) {
+		if (MV && moving) {
 			// the chain's head start: delay times of chunks 0 .. P - 1 (chunk j + P's are computed in step j - 1), controls[1] of chunks 0 .. P; only then the first requests
 			for (int t = 0; t <= P; t++) {
 				if (w_control) { if (t < nchunks) chain_first(t); }
@@ -644,7 +689,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		}
 		// the other waves' part: the LFO keeps running, a chunk per step (control: beside the filter waves, which are slower); FILTER of chunk j - 1
 		auto other_part = [&](const int j) __attribute__((always_inline)) {
-			if (moving && !w_filter) {
+			if (MV && moving && !w_filter) {
 				if (w_control) { const int cc = j + P + 2; if (cc < nchunks) chain_first(cc); }
 				else if (w_control2) { const int cc = j + P + 1; if (cc < nchunks) chain_second(cc); }
 			}
@@ -663,12 +708,12 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		// Blocks of 4 / 8 / 16 chunks (128 / 256 / 512 samples): the audio waves' steps are written out one after the other — in straight-line code
 		// the compiler's wait before a use is exactly "everything requested since may still be under way"; through the loop below, with its
 		// guards, it waits for more than it has to (measured at 4,096 instances: 19.4 us with the loop).
-		auto audio_unrolled = [&](auto nch_c) __attribute__((always_inline)) {
+		auto audio_unrolled = [&](auto nch_c, auto whole_c) __attribute__((always_inline)) {
 			constexpr int NCH = decltype(nch_c)::value;
 			auto run = [&](auto self, auto t_c) __attribute__((always_inline)) {
 				constexpr int T = decltype(t_c)::value, J = T - 1;
 				if constexpr (J <= NCH + ((KLG_PPX_VARIANT & 1) ? 0 : 1)) {
-					audio_part(IntTag<((J % P) + P) % P>{}, BoolTag<false>{}, BoolTag<false>{}, J, NCH);
+					audio_part(IntTag<((J % P) + P) % P>{}, whole_c, BoolTag<false>{}, J, NCH);
 					__syncthreads();
 					self(self, IntTag<T + 1>{});
 				}
@@ -677,15 +722,21 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 		};
 		const bool unrolled = nchunks == 4 || nchunks == 8 || nchunks == 16;
 		if (unrolled && w_audio) {
-			if (nchunks == 8) audio_unrolled(IntTag<8>{}); else if (nchunks == 4) audio_unrolled(IntTag<4>{}); else audio_unrolled(IntTag<16>{});
+			// (a workgroup whose instances all exist — every one but a bank's last — runs the form in which no access is predicated: the compiler then counts what is under way)
+			if (nchunks == 8) { if (whole_group) audio_unrolled(IntTag<8>{}, IntTag<3>{}); else audio_unrolled(IntTag<8>{}, IntTag<0>{}); }
+			else if (nchunks == 4) audio_unrolled(IntTag<4>{}, IntTag<0>{}); else audio_unrolled(IntTag<16>{}, IntTag<0>{});
 		}
 		else if (unrolled) {
 			for (int j = -1; j <= nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1); j++) { other_part(j); __syncthreads(); }
 		}
 		else {
-		auto steps = [&](auto moving_c) __attribute__((always_inline)) {
+		// (audio_c: the audio waves and the others walk the SAME steps — the same barriers — in loops of their own (round 6).  In one loop with the role tested inside
+		//  every step, the compiler's count of the requests under way, which follows no particular path, allowed for a wave that is an audio wave in one step and not
+		//  in the next three: it made every audio step wait for all but the last two or three requests, and the pipeline ran one step deep instead of P.)
+		auto steps = [&](auto moving_c, auto audio_c) __attribute__((always_inline)) {
+			constexpr bool AUDIO = decltype(audio_c)::value;
 			auto deep_step = [&](auto slot_c, auto steady_c, const int j) __attribute__((always_inline)) {
-				if (w_audio) audio_part(slot_c, steady_c, moving_c, j, nchunks); else other_part(j);
+				if constexpr (AUDIO) audio_part(slot_c, steady_c, moving_c, j, nchunks); else other_part(j);
 				__syncthreads();
 			};
 			const int jend = nchunks + ((KLG_PPX_VARIANT & 1) ? 0 : 1);
@@ -693,7 +744,7 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			deep_step(IntTag<P - 1>{}, BoolTag<false>{}, j); ++j;                   // (-1 = P - 1 mod P)
 			// a group of P steps, slots 0 .. P - 1 (j is a multiple of P at its head); guarded: leaves where the block ends
 			auto group = [&](auto steady_c) __attribute__((always_inline)) -> bool {
-				constexpr bool ST = decltype(steady_c)::value;
+				constexpr bool ST = decltype(steady_c)::value != 0;
 				if (!ST && j > jend) return false;
 				deep_step(IntTag<0>{}, steady_c, j); ++j;
 				if (!ST && j > jend) return false;
@@ -705,14 +756,19 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 			// the head of the span with its guards (steps 0 .. P - 1), the inner steps in groups without any (every chunk a step of theirs touches
 			// exists: 2 <= j, j + P - 1 <= nchunks - P - 2), the tail with guards again
 			if (group(BoolTag<false>{})) {
-				while (j + P - 1 <= nchunks - P - 2) group(BoolTag<true>{});
+				// (everything requested so far is waited for ONCE here, visibly to the compiler: what is under way when the loop is entered came from guarded steps, and merged
+				//  into the loop's own state it made every step of the loop wait for all but two or three of its requests — the request-ahead pipeline ran one step deep)
+				if (whole_group) { if constexpr (AUDIO) __builtin_amdgcn_s_waitcnt(0x0F70); while (j + P - 1 <= nchunks - P - 2) group(IntTag<2>{}); }
+				else while (j + P - 1 <= nchunks - P - 2) group(BoolTag<true>{});
 				while (group(BoolTag<false>{})) {}
 			}
 		};
-			if (moving) steps(BoolTag<true>{}); else steps(BoolTag<false>{});
+			auto by_role = [&](auto moving_c) __attribute__((always_inline)) { if (w_audio) steps(moving_c, BoolTag<true>{}); else steps(moving_c, BoolTag<false>{}); };
+			if constexpr (MV) { if (moving) by_role(BoolTag<true>{}); else by_role(BoolTag<false>{}); }
+			else by_role(BoolTag<false>{});
 		}
 	}
-	else
+	else if constexpr (!DEEP_ONLY)
 	for (int j = -1; j <= nchunks; j++) {
 		// ---------------- io rows of chunk j+1 (audio waves; landed in LDS at the end of the step) ----------------
 		const int jn = j + 1;

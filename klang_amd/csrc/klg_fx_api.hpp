@@ -32,6 +32,8 @@ struct klg_fx {
 	bool early_alloc_failed = false; int rv_prev_n = 1 << 30; hipStream_t rv_prev_stream = nullptr;   // (mode 2: length and stream of the previous Reverb block)
 	int* d_upd = nullptr; size_t d_upd_cap = 0;
 	unsigned long long samples = 0;                    // samples processed so far (defines every write cursor)
+	unsigned long long pp_touched_at = 0;              // PingPong: `samples` when a dial / record word was last written (a fresh bank: 0 — its smoothers start converging there)
+	int* pp_done = nullptr;                            // PingPong spans in two launches: [kpad / 16] which workgroups the first one rendered (klg_fx.hpp PingPongArgs::done)
 	std::vector<host::ControlH> controls;              // [K][nctl]
 	std::vector<FxUpdate> upd;
 	std::vector<RvHost> rv;
@@ -63,6 +65,7 @@ static void fx_free(klg_fx* f) {
 	if (f->module) (void)hipModuleUnload(f->module);
 	for (auto e : f->tev) (void)hipEventDestroy(e);
 	if (f->d_rand) (void)hipFree(f->d_rand);
+	if (f->pp_done) (void)hipFree(f->pp_done);
 	if (f->rand_done) (void)hipEventDestroy(f->rand_done);
 	if (f->stream) (void)hipStreamDestroy(f->stream);
 	delete f;
@@ -430,6 +433,7 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st, int b
 			HIP_TRY(hipStreamSynchronize(st));
 			if (f->rand_done) HIP_TRY(hipEventSynchronize(f->rand_done)); else HIP_TRY(hipEventCreateWithFlags(&f->rand_done, hipEventDisableTiming));
 			if (f->d_rand) (void)hipFree(f->d_rand);
+	if (f->pp_done) (void)hipFree(f->pp_done);
 			f->d_rand = nullptr; f->rand_cap = 0;
 			if (hipMalloc((void**)&f->d_rand, need * sizeof(int)) != hipSuccess) return fail(KLG_ERR_NOMEM, "the Noise generators' draws (%zu instances x blocks, %d samples, %d generators: %.2f GB) could not be allocated", ranks, n, draws, need * 4 / 1e9);
 			f->rand_cap = need;
@@ -492,6 +496,7 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st, int blocks 
 		for (int k : f->rv_touched) { rv_prepare(f, k); f->rv_flag[k] = 0; }
 		f->rv_touched.clear();
 	}
+	if (!f->upd.empty()) f->pp_touched_at = f->samples;                              // a dial or a record word was written since the last block (PingPong: which kernel a span takes, below)
 	if (int rc = fx_flush_updates(f, st)) return rc;
 	// kernel timing: PingPong is one launch, timed by events attached to its dispatch; a Reverb block is the early-sum kernel and klg_fx_reverb_q
 	// (the pair is what a block costs): events recorded around both on the stream
@@ -502,8 +507,8 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st, int blocks 
 	}
 	const dim3 grid((unsigned)(f->kpad / FX_WG)), block(FX_WG);
 	if (f->patch == KLG_PATCH_PINGPONG) {
-		TimedLaunch timed(f);
 		PingPongArgs a;
+		a.pass = 0; a.done = nullptr;
 		a.state = f->d_state; a.kpad = f->kpad; a.K = f->K; a.rings = f->d_rings;
 		a.position = (int)(f->samples % 192000ull);
 		a.io = d_io; a.n = n * blocks; a.nb = blocks > 1 ? n : 0; a.block_stride = (size_t)f->K * 2 * (size_t)n;
@@ -512,16 +517,36 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st, int blocks 
 		static const int ablate = []() { const char* e = getenv("KLG_FX_ABLATE"); return e ? atoi(e) : 0; }();
 		a.ablate = ablate;
 		static const bool single_wave = []() { const char* e = getenv("KLG_FX_PINGPONG1"); return e && e[0] == '1'; }();
-		if (single_wave || a.ablate) KLG_LAUNCH(klg_fx_pingpong, grid, block, 0, st, a);   // one wave per 64 instances (A/B reference, ablation)
+		if (single_wave || a.ablate) { TimedLaunch timed(f); KLG_LAUNCH(klg_fx_pingpong, grid, block, 0, st, a); }   // one wave per 64 instances (A/B reference, ablation)
 		// the pipeline's time is a workgroup's instruction count on its one CU: a quarter / a half of a ring group per workgroup while
 		// the bank does not fill the chip that way either (klg_fx_pingpong_x<G>; KLG_FX_PINGPONG_G = 16 / 32 / 64 forces the width)
 		else {
 			const char* const forced_env = getenv("KLG_FX_PINGPONG_G");                 // (read per launch: the tests switch it)
 			const int forced = forced_env ? atoi(forced_env) : 0;
 			const int G = forced == 16 || forced == 32 || forced == 64 ? forced : (f->kpad <= 4096 ? 16 : f->kpad <= 8192 ? 32 : 64);
-			if (G == 16) KLG_LAUNCH(klg_fx_pingpong_x<16>, dim3((unsigned)(f->kpad / 16)), dim3(PPX_THREADS), 0, st, a);
-			else if (G == 32) KLG_LAUNCH(klg_fx_pingpong_x<32>, dim3((unsigned)(f->kpad / 32)), dim3(PPX_THREADS), 0, st, a);
-			else KLG_LAUNCH(klg_fx_pingpong_x<64>, grid, dim3(PPX_THREADS), 0, st, a);   // control / audio / filter pipeline over twelve waves
+			// Which compilation of the kernel (klg_fx.hpp: MODE).  The moving-dials pipeline only ever runs for spans of PPX_MOVING_MIN chunks and more: shorter launches
+			// take the kernel compiled without it (the same paths otherwise).  A longer span goes out TWICE unless a dial was touched within the last 8,192 samples
+			// (then it surely moves): first the stationary-only kernel (no scratch, 11 waves' worth of code), in which every workgroup whose span is stationary — decided
+			// on the device, on the dials as they are — renders it and says so in pp_done; then the full kernel for the workgroups that were not (the others leave at
+			// once).  KLG_FX_PINGPONG_MV = 1 / 0 forces the full kernel alone / the kernel without the moving-dials pipeline alone (A/B; the same bits every way).
+			static const int force_mv = []() { const char* e = getenv("KLG_FX_PINGPONG_MV"); return e ? atoi(e) : -1; }();
+			const int chunks = (n * blocks + PPX_CHUNK - 1) / PPX_CHUNK;
+			const bool long_span = chunks >= PPX_MOVING_MIN;
+			const bool touched = f->samples - f->pp_touched_at < 8192ull;
+			int plan = !long_span ? 0 : touched ? 1 : 2;                                // 0: the kernel without the moving-dials pipeline alone, 1: the full kernel alone, 2: both
+			if (force_mv == 1) plan = 1; else if (force_mv == 0) plan = 0;
+			if (plan == 2 && !f->pp_done) { if (hipMalloc((void**)&f->pp_done, (f->kpad / 16) * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); f->pp_done = nullptr; plan = 1; } }
+			auto launch = [&](auto mode_c, int pass) {
+				constexpr int MV = decltype(mode_c)::value;
+				a.pass = pass; a.done = f->pp_done;
+				TimedLaunch timed2(f);                                                  // (each launch its own pair of events: a two-launch span's time is their sum)
+				if (G == 16) KLG_LAUNCH((klg_fx_pingpong_x<16, MV>), dim3((unsigned)(f->kpad / 16)), dim3(PPX_THREADS), 0, st, a);
+				else if (G == 32) KLG_LAUNCH((klg_fx_pingpong_x<32, MV>), dim3((unsigned)(f->kpad / 32)), dim3(PPX_THREADS), 0, st, a);
+				else KLG_LAUNCH((klg_fx_pingpong_x<64, MV>), grid, dim3(PPX_THREADS), 0, st, a);   // control / audio / filter pipeline over twelve waves
+			};
+			if (plan == 0) launch(IntTag<PPX_NO_MOVING>{}, 0);
+			else if (plan == 1) launch(IntTag<PPX_FULL>{}, 0);
+			else { launch(IntTag<PPX_STATIONARY>{}, 1); launch(IntTag<PPX_FULL>{}, 2); }
 		}
 	}
 	else {
