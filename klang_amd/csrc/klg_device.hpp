@@ -67,41 +67,53 @@ template<uint32_t YBITS> __device__ __forceinline__ float div_const(float x) {
 }
 
 // ---- Generators::Fast helpers ----
-// Fast::Phase::operator=(float radians) klang.h:4993-4998: position = (uint32_t)(int64_t)(radians * FINTMAX / twoPi), the float -> unsigned
-// wrap of F3 (f2u_wrap).  Written here WITHOUT the IEEE division expansion (11 operations) and the 64-bit conversion (10): with
-// n = radians * FINTMAX, r = RN(1 / twoPi):  q = n * r;  e = fma(-twoPi, q, n);  q2 = fma(e, r, q)  is the IEEE quotient wherever the
-// conversion can see it (quotients of magnitude [1, 2^63); anything smaller truncates to 0, anything larger — infinities, NaN — wraps to
-// 0 either way), and the low word of trunc(|q2|) is cvt_u32(|q2| - floor(|q2| * 2^-32) * 2^32) (exact: one fma; v_cvt_u32_f32 truncates,
-// and gives 0 for the NaN that an infinite q2 leaves), negated for a negative q2.  tools/verify_fast_phase.c compares this composition
-// with f2u_wrap(n / twoPi) on ALL 2^32 floats n: 0 mismatches (the 3-operation quotient by itself differs from IEEE on 3.4 M of them —
-// all outside the range the conversion looks at).  10 VALU operations where the plain form has 23.
+// Fast::Phase::operator=(float radians) klang.h:4993-4998: position = (uint32_t)(int64_t)(radians * FINTMAX / twoPi), FINTMAX = 2^31, with the float ->
+// unsigned wrap of F3 (f2u_wrap).  Written here WITHOUT the IEEE division expansion (11 operations), the 64-bit conversion (10) and the scaling by FINTMAX
+// (a power of two commutes with every rounding below): with Y = 2 twoPi and R = RN(1 / twoPi) / 2,
+//   q = radians * R;  e = fma(-Y, q, radians);  q2 = fma(e, R, q)
+// is the IEEE quotient radians / twoPi, halved, wherever the conversion can see it (anything much smaller truncates to 0, anything much larger — infinities, NaN —
+// wraps to 0 either way); the position is the low word of trunc(|q2| * 2^32) = cvt_u32(fract(|q2|) * 2^32): the integer part of |q2| only contributes multiples of
+// 2^32, v_fract_f32 of a non-negative number is exact, v_cvt_u32_f32 truncates and gives 0 for the NaN that an infinite q2 leaves; negated for a negative q2.
+// tools/verify_fast_phase_fract.c compares this composition with f2u_wrap((radians * FINTMAX) / twoPi) on ALL 2^32 floats: 0 mismatches.
+// 9 VALU operations (round 5's form through floor / fma: 10, the plain form: 23); as a pair 15 instead of 19.
 __device__ __forceinline__ uint32_t cvt_u32_trunc(float x) { uint32_t u; asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(u) : "v"(x)); return u; }   // (the C cast is undefined for NaN; the instruction is not)
 __device__ __forceinline__ uint32_t fast_phase(float radians) {
-	const float n = radians * KLG_FINTMAX;
-	constexpr float r = 1.0f / KLG_TWO_PI;
-	const float q = n * r;
-	const float e = __builtin_fmaf(-KLG_TWO_PI, q, n);
+	constexpr float r = 0.5f * (1.0f / KLG_TWO_PI);
+	const float q = radians * r;
+	const float e = __builtin_fmaf(-2.f * KLG_TWO_PI, q, radians);
 	const float q2 = __builtin_fmaf(e, r, q);
-	const float a = __builtin_fabsf(q2);
-	const float hi = __builtin_floorf(a * 2.3283064365386963e-10f);         // 2^-32
-	const float lo = __builtin_fmaf(hi, -4294967296.0f, a);
-	const uint32_t u = cvt_u32_trunc(lo);
+	const float f = __builtin_amdgcn_fractf(__builtin_fabsf(q2));
+	const uint32_t u = cvt_u32_trunc(f * 4294967296.0f);
 	const uint32_t s = (uint32_t)((int32_t)__float_as_uint(q2) >> 31);
 	return (u ^ s) - s;
 }
 // ... of two values at once (packed multiplies / fmas)
 __device__ __forceinline__ u2 fast_phase(f2 radians) {
-	const f2 n = radians * KLG_FINTMAX;
-	constexpr float r = 1.0f / KLG_TWO_PI;
-	const f2 q = n * r;
-	const f2 e = __builtin_elementwise_fma(splat(-KLG_TWO_PI), q, n);
+	constexpr float r = 0.5f * (1.0f / KLG_TWO_PI);
+	const f2 q = radians * r;
+	const f2 e = __builtin_elementwise_fma(splat(-2.f * KLG_TWO_PI), q, radians);
 	const f2 q2 = __builtin_elementwise_fma(e, splat(r), q);
-	const f2 a = __builtin_elementwise_abs(q2);
-	const f2 hi = __builtin_elementwise_floor(a * 2.3283064365386963e-10f);
-	const f2 lo = __builtin_elementwise_fma(hi, splat(-4294967296.0f), a);
-	u2 u = { cvt_u32_trunc(lo.x), cvt_u32_trunc(lo.y) };
+	f2 f; f.x = __builtin_amdgcn_fractf(__builtin_fabsf(q2.x)); f.y = __builtin_amdgcn_fractf(__builtin_fabsf(q2.y));
+	const f2 g = f * 4294967296.0f;
+	u2 u = { cvt_u32_trunc(g.x), cvt_u32_trunc(g.y) };
 	const u2 s = __builtin_bit_cast(u2, __builtin_bit_cast(i2, q2) >> 31);
 	return (u ^ s) - s;
+}
+// pos + fast_phase(radians) (an oscillator's position plus a modulation's phase: OSCILLATOR::set(+in), klang.h:4165), associated as ((u ^ s) + pos) - s — integer
+// arithmetic modulo 2^32, the same value — so that the exclusive-or and the first addition are ONE v_xad_u32
+__device__ __forceinline__ u2 fast_phase_add(u2 pos, f2 radians) {
+	constexpr float r = 0.5f * (1.0f / KLG_TWO_PI);
+	const f2 q = radians * r;
+	const f2 e = __builtin_elementwise_fma(splat(-2.f * KLG_TWO_PI), q, radians);
+	const f2 q2 = __builtin_elementwise_fma(e, splat(r), q);
+	f2 f; f.x = __builtin_amdgcn_fractf(__builtin_fabsf(q2.x)); f.y = __builtin_amdgcn_fractf(__builtin_fabsf(q2.y));
+	const f2 g = f * 4294967296.0f;
+	u2 u = { cvt_u32_trunc(g.x), cvt_u32_trunc(g.y) };
+	const u2 s = __builtin_bit_cast(u2, __builtin_bit_cast(i2, q2) >> 31);
+	u2 t;                                                                  // (written as the instruction: the compiler re-associates the C expression into xor, shift, three-way add)
+	asm("v_xad_u32 %0, %1, %2, %3" : "=v"(t.x) : "v"(u.x), "v"(s.x), "v"(pos.x));
+	asm("v_xad_u32 %0, %1, %2, %3" : "=v"(t.y) : "v"(u.y), "v"(s.y), "v"(pos.y));
+	return t - s;
 }
 __device__ __forceinline__ float fast_phase_float(uint32_t pos) {        // Fast::Phase::operator float 5004-5007
 	return u2f(phase_mantissa<0x7Fu>(pos)) - 1.f;
@@ -118,14 +130,17 @@ __device__ __forceinline__ float polysin(float x) {                      // klan
 // two, (pi-x, x-2pi, x) in the last — : one v_med3_f32 instead of two compares and two selects (or exec-masked branches), bit for bit on
 // all 2^23 phase mantissas (tools/verify_fastsinp_med3.c).
 __device__ __forceinline__ float fold_quadrant(float x) { return __builtin_amdgcn_fmed3f(x, KLG_PI_F - x, x - KLG_TWO_PI); }
+// (m - 1) * twoPi for the mantissa float m in [1, 2): m - 1 is exact, so the product is ONE rounding of the real number m * twoPi - twoPi — which is what
+//  fma(m, twoPi, -twoPi) rounds: the same bits in one operation instead of two (all 2^23 mantissas: tools/verify_fastsinp_med3.c)
+__device__ __forceinline__ float phase_radians(uint32_t p) { return __builtin_fmaf(u2f(phase_mantissa<0x7Fu>(p)), KLG_TWO_PI, -KLG_TWO_PI); }
 __device__ __forceinline__ float fastsinp(uint32_t p) {
-	const float x = (u2f(phase_mantissa<0x7Fu>(p)) - 1.f) * KLG_TWO_PI;
+	const float x = phase_radians(p);
 	return polysin(fold_quadrant(x));
 }
 // ... of two phases at once (two voices of a lane, or two consecutive samples of one voice): the polynomial as packed operations
 __device__ __forceinline__ f2 polysin(f2 x) { const f2 x2 = x * x; return (((-0.00018542f * x2 + 0.0083143f) * x2 - 0.16666f) * x2 + 1.0f) * x; }
 __device__ __forceinline__ f2 fastsinp(u2 p) {
-	const f2 x = (phase_float2<0x7Fu>(p) - 1.f) * KLG_TWO_PI;
+	const f2 x = __builtin_elementwise_fma(phase_float2<0x7Fu>(p), splat(KLG_TWO_PI), splat(-KLG_TWO_PI));   // (see phase_radians)
 	const f2 a = KLG_PI_F - x, b = x - KLG_TWO_PI;                     // (packed), then the median per half
 	f2 r; r.x = __builtin_amdgcn_fmed3f(x.x, a.x, b.x); r.y = __builtin_amdgcn_fmed3f(x.y, a.y, b.y);
 	return polysin(r);
@@ -151,6 +166,24 @@ __device__ __forceinline__ float fsine_process(FSine& o, uint32_t off) {
 }
 // Sine::set(relative phase) klang.h:5160-5162: offset = phase * twoPi -> Fast::Phase
 __device__ __forceinline__ uint32_t fsine_rel_offset(float rel) { return fast_phase(rel * KLG_TWO_PI); }
+// ... and the oscillator processed with that offset — an FM operator's `OSCILLATOR::set(+in); OSCILLATOR::process()` (klang.h:4165-4166) — with the sign
+// of the offset folded into the addition (fast_phase_add: one operation fewer than fsine_process(o, fsine_rel_offset(rel)), the same bits)
+__device__ __forceinline__ uint32_t fast_phase_add(uint32_t pos, float radians) {
+	constexpr float r = 0.5f * (1.0f / KLG_TWO_PI);
+	const float q = radians * r;
+	const float e = __builtin_fmaf(-2.f * KLG_TWO_PI, q, radians);
+	const float q2 = __builtin_fmaf(e, r, q);
+	const float f = __builtin_amdgcn_fractf(__builtin_fabsf(q2));
+	const uint32_t u = cvt_u32_trunc(f * 4294967296.0f);
+	const uint32_t s = (uint32_t)((int32_t)__float_as_uint(q2) >> 31);
+	uint32_t t; asm("v_xad_u32 %0, %1, %2, %3" : "=v"(t) : "v"(u), "v"(s), "v"(pos));
+	return t - s;
+}
+__device__ __forceinline__ float fsine_process_rel(FSine& o, float rel) {
+	const float y = fastsinp(fast_phase_add(o.pos, rel * KLG_TWO_PI));
+	o.pos += (uint32_t)o.inc;
+	return y;
+}
 
 // ---- Generic::Oscillator + Generators::Basic klang.h:2849-2880, 4899-4944 ----
 struct BOsc { float increment, position, offset; };

@@ -495,7 +495,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 		case OP_SMOOTH: body += "\t\t" + n + " = " + n + " * 0.999f + (1.f - 0.999f) * " + (ctlvar[o.imm & 0xFFu] >= 0 ? fmt("L.n%d", ctlvar[o.imm & 0xFFu]) : fx ? fmt("L.ctl%u", o.imm) : fmt("c.ctl[%u]", o.imm)) + ";\n" + d + n + ";\n"; break;   // Control::smooth klang.h:1715
 		case OP_OPERATOR:                                           // OSC::set(+in); OSC::process(); out *= env++ * amp   klang.h:4164-4168
 			if (o.b >= 0) body += "\t\t" + n + "a = " + b + ";\n";
-			body += d + "fsine_process(" + n + ", fsine_rel_offset(" + (o.a >= 0 ? a : std::string("0.f")) + ")) * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, " + n + "hy, c.fs) * " + n + "a);\n";
+			body += d + (o.a >= 0 ? "fsine_process_rel(" + n + ", " + a + ")" : "fsine_process(" + n + ", 0u)") + " * (env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, " + n + "hy, c.fs) * " + n + "a);\n";
 			break;
 		}
 	};

@@ -331,8 +331,7 @@ struct PatchFM {
 	}
 	// Operator::process klang.h:4164-4168
 	static __device__ __forceinline__ float op_process(Op& o, int k, uint32_t meta, float in, const BlockCtx& c) {
-		const uint32_t off = fsine_rel_offset(in);                 // OSCILLATOR::set(+in)
-		float y = fsine_process(o.osc, off);
+		float y = fsine_process_rel(o.osc, in);                    // OSCILLATOR::set(+in); OSCILLATOR::process()
 		y *= env_process<2, false>(o.env, op_pts(c, k), (int)KLG_FLAG_GET(meta, 2 * k, 2), c.fs) * o.amp;
 		return y;
 	}
@@ -360,7 +359,7 @@ struct PatchFM {
 #pragma unroll
 		for (int k = 0; k < NOPS; k++) {
 			Op& o = L.op[k];
-			float y = fsine_process(o.osc, fsine_rel_offset(m));
+			float y = fsine_process_rel(o.osc, m);
 			y *= env_glide(o.env, L.step[k], L.tstep[k]) * o.amp;
 			m = y;
 		}
@@ -386,28 +385,48 @@ struct PatchFM {
 		f2 m[PAIRS];
 #pragma unroll
 		for (int j = 0; j < PAIRS; j++) m[j] = splat(0.f);
+		// the Sustain clocks of the NOPS + 1 envelopes: nothing in an event-free chunk reads them — they are only carried — so two envelopes' clocks advance in ONE
+		// packed addition (round 6: 2 x ceil((NOPS + 1) / 2) operations per sample pair instead of 2 x (NOPS + 1))
+		constexpr int NT = (NOPS + 2) / 2;
+		f2 tm[NT], tsp[NT];
+#pragma unroll
+		for (int i = 0; i < NT; i++) {
+			const int a = 2 * i, b = 2 * i + 1;
+			tm[i].x = a < NOPS ? L.op[a < NOPS ? a : 0].env.time : L.adsr.time;
+			tm[i].y = b < NOPS ? L.op[b < NOPS ? b : 0].env.time : (b == NOPS ? L.adsr.time : 0.f);
+			tsp[i].x = L.tstep[a]; tsp[i].y = b <= NOPS ? L.tstep[b <= NOPS ? b : 0] : 0.f;
+		}
+#pragma unroll
+		for (int j = 0; j < PAIRS; j++) {
+#pragma unroll
+			for (int i = 0; i < NT; i++) tm[i] = (tm[i] + tsp[i]) + tsp[i];
+		}
+#pragma unroll
+		for (int i = 0; i < NT; i++) {
+			const int a = 2 * i, b = 2 * i + 1;
+			if (a < NOPS) L.op[a < NOPS ? a : 0].env.time = tm[i].x; else L.adsr.time = tm[i].x;
+			if (b < NOPS) L.op[b < NOPS ? b : 0].env.time = tm[i].y; else if (b == NOPS) L.adsr.time = tm[i].y;
+		}
 #pragma unroll
 		for (int k = 0; k < NOPS; k++) {
 			Op& o = L.op[k];
 			const uint32_t inc = (uint32_t)o.osc.inc;
-			const float st = L.step[k], ts = L.tstep[k];
+			const float st = L.step[k];
 #pragma unroll
 			for (int j = 0; j < PAIRS; j++) {
 				u2 pos = { o.osc.pos, o.osc.pos + inc };
 				o.osc.pos += 2u * inc;
-				if (k > 0) pos += fast_phase(m[j] * KLG_TWO_PI);               // OSCILLATOR::set(+in): fsine_rel_offset (operator 0 is not modulated: offset 0)
+				if (k > 0) pos = fast_phase_add(pos, m[j] * KLG_TWO_PI);       // OSCILLATOR::set(+in): fsine_rel_offset (operator 0 is not modulated: offset 0)
 				f2 y = fastsinp(pos);
 				f2 ev; ev.x = o.env.r_out; ev.y = ev.x + st; o.env.r_out = ev.y + st;      // two steps of env_glide
-				o.env.time = (o.env.time + ts) + ts;
 				y *= ev * o.amp;
 				m[j] = y;
 			}
 		}
-		const float st = L.step[NOPS], ts = L.tstep[NOPS];
+		const float st = L.step[NOPS];
 #pragma unroll
 		for (int j = 0; j < PAIRS; j++) {
 			f2 av; av.x = L.adsr.r_out; av.y = av.x + st; L.adsr.r_out = av.y + st;
-			L.adsr.time = (L.adsr.time + ts) + ts;
 			out[j] = m[j] * (av * 0.1f);
 		}
 	}
