@@ -677,6 +677,28 @@ def in_library(args):
     base = min(V, 1 << 16)
     rec = rec_bank.note_records(np.zeros(base, np.int32), rng.integers(36, 97, size=base).astype(np.int32), np.full(base, 0.8, np.float32))
     rec_bank.close()
+
+    def timed(bank, mix, st, steps):
+        for _ in range(max(args.warmup, 40)):                                            # (past the attack: every voice holding at its sustain level)
+            mix.zero_(); bank.process_device(mix.data_ptr(), n, st)
+        bank.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mix.zero_(); bank.process_device(mix.data_ptr(), n, st)
+        bank.sync(); torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    # the N = 1 value of THIS invocation (the same workload on device ids[0] alone, before the process is made multi-device): what the N-device value is divided by
+    torch.cuda.set_device(ids[0])
+    one = klang_amd.SynthBank(patch, synths=V // notes, notes=notes, max_block=n)
+    for c0 in range(0, one.voices, base):
+        cnt = min(base, one.voices - c0)
+        one.voices_upload(np.arange(c0, c0 + cnt, dtype=np.int32), rec[:cnt])
+    mix1 = torch.zeros((2, n), dtype=torch.float32, device="cuda")
+    ts1 = torch.cuda.Stream()
+    with torch.cuda.stream(ts1):
+        dt1 = timed(one, mix1, ts1.cuda_stream, args.steps)
+    value_one_gpu = one.voices * n * args.steps / dt1
+    one.close()
     klang_amd.init(ids)
     bank = klang_amd.SynthBank(patch, synths=(V // notes) * N, notes=notes, max_block=n)
     total = bank.voices
@@ -688,16 +710,22 @@ def in_library(args):
     ts = torch.cuda.Stream()
     with torch.cuda.stream(ts):
         st = ts.cuda_stream
-        for _ in range(max(args.warmup, 40)):                                            # (past the attack: every voice holding at its sustain level)
-            mix.zero_(); bank.process_device(mix.data_ptr(), n, st)
-        bank.sync(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        dt = timed(bank, mix, st, args.steps)
+        bank.timing_begin()                                                              # a second pass with the kernels' own durations (events attached to every dispatch)
         for _ in range(args.steps):
             mix.zero_(); bank.process_device(mix.data_ptr(), n, st)
         bank.sync(); torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    out = {"metric": "voice*samples/s @48kHz Subtractive", "value": total * n * args.steps / dt, "unit": "voice*samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        info = bank.multi_info(n, probe_reps=200)
+        bank.timing_end()
+    # the run proves itself: the communicator's own rank count and the devices the shards sit on must be the N that was asked for
+    if not one_gpu and (info["rccl_ranks"] != N or info["distinct_devices"] != N or info["shards"] != N):
+        raise SystemExit(f"bench.py --gpus {N} --in-library: the bank has {info['shards']} shard(s) on {info['distinct_devices']} device(s) and its RCCL communicator reports {info['rccl_ranks']} rank(s): not reporting a {N}-GPU number")
+    value = total * n * args.steps / dt
+    out = {"metric": "voice*samples/s @48kHz Subtractive", "value": value, "unit": "voice*samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mode": "in-library",
+           "shards": info["shards"], "rccl_ranks_seen": info["rccl_ranks"], "devices_distinct": info["distinct_devices"], "functional_test_only": bool(one_gpu),
+           "allreduce_us_per_block": info["allreduce_us"], "per_rank_kernel_ms": [ms / args.steps for ms in info["per_shard_kernel_ms"]],
+           "value_one_gpu_same_invocation": value_one_gpu, "weak_scaling_efficiency": value / (N * value_one_gpu),
            "config": {"workload": f"{patch}: {V} voices/GPU, all sustaining, {n}-sample blocks @48kHz, stereo mix resident on device {ids[0]}", "voices_per_gpu": V, "block": n,
                       "parallelism": f"ONE process, klg_init({ids}): voice-shard x{N} inside libklang_mi355.so + " + ("a device-side add of the shards' blocks (one physical GPU)" if one_gpu else f"one ncclAllReduce (RCCL) of [2][{n}] per block"),
                       "mix_checksum": float(mix.abs().sum().item())}}
@@ -749,6 +777,17 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # The run proves itself: how many ranks the COMMUNICATOR carries — a sum of ones through it, not argv — and how many different GPUs they sit on
+        # (PCI bus ids gathered through it).  Fewer than --gpus of either: no number is reported (KLG_BENCH_ONE_GPU, the functional test on one GPU, says so in the line).
+        ones = torch.ones(1, device="cpu" if one_gpu else "cuda")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        ident = [None] * world
+        props = torch.cuda.get_device_properties(local_rank)
+        dist.all_gather_object(ident, (os.uname().nodename, str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", local_rank)), local_rank))
+        devices_distinct = len({(h, u) for (h, u, _) in ident})
+        if ranks_seen != args.gpus or (devices_distinct != args.gpus and not one_gpu):
+            raise SystemExit(f"bench.py --gpus {args.gpus}: the communicator carries {ranks_seen} rank(s) on {devices_distinct} distinct GPU(s): not reporting a {args.gpus}-GPU number")
 
     import klang_amd
     patch, N = args.patch, args.block
@@ -772,7 +811,7 @@ def main():
     stream = work_stream.cuda_stream
     state = {"i": 0}
 
-    def step():
+    def step(collective=True):
         i = state["i"]
         k = i % RING
         state["i"] += 1
@@ -781,8 +820,11 @@ def main():
             pending[k] = None
         mixes[k].zero_()
         script.play_device(i % SCRIPT_BLOCKS, mixes[k].data_ptr(), N, stream)      # this block's note events (from HBM), render, reduce
-        if world > 1:
+        if world > 1 and collective:
             pending[k] = dist.all_reduce(mixes[k], async_op=True)                 # ONE RCCL all-reduce of the [2][N] block
+
+    def first_pos(i):
+        return i % SCRIPT_BLOCKS
 
     def drain():
         for k in range(RING):
@@ -797,7 +839,21 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
+    value_alone = None
     if world > 1:
+        # the N = 1 value of THIS invocation: every rank renders K blocks of its own share with no collective (what one GPU does alone, on this node, minutes apart from
+        # nothing), a whole number of script cycles later the N-rank region starts from the same place in the script
+        dist.barrier(); torch.cuda.synchronize()
+        i0 = state["i"]
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(collective=False)
+        torch.cuda.synchronize()
+        dt_alone = time.perf_counter() - t0
+        value_alone = float(sum(int(sounding[(i0 + j) % SCRIPT_BLOCKS]) for j in range(args.steps))) * N / dt_alone
+        while state["i"] % SCRIPT_BLOCKS != first_pos(i0):
+            step(collective=False)
+        drain(); torch.cuda.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
     first_timed = state["i"]
@@ -834,10 +890,23 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         launches, kernel_ms = bank.timing_end()
+        multi = None
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+            # the collective by itself: 200 all-reduces of the [2][N] block, each between a pair of events on this rank's stream (after 10 untimed)
+            probe = torch.zeros((2, N), dtype=torch.float32, device="cuda")
+            e0, e1, ar_ms = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), 0.0
+            for r in range(210):
+                e0.record()
+                dist.all_reduce(probe, async_op=True).wait()
+                e1.record(); e1.synchronize()
+                if r >= 10:
+                    ar_ms += e0.elapsed_time(e1)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, {"rank": rank, "kernel_ms": kernel_ms / max(1, launches), "value_alone": value_alone, "allreduce_us": 1e3 * ar_ms / 200})
+            multi = gathered
         checksum = float(mixes[(state["i"] - 1) % RING].abs().sum().item())
     alive_now = int((bank.stages() != 3).sum())
     expect_alive = int(sounding.alive_after[(state["i"] - 1) % SCRIPT_BLOCKS])
@@ -887,6 +956,10 @@ def main():
             "value": value, "unit": "voice*samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            **({"rccl_ranks_seen": ranks_seen, "devices_distinct": devices_distinct, "backend": dist.get_backend(), "functional_test_only": bool(one_gpu),
+                "allreduce_us_per_block": max(g["allreduce_us"] for g in multi), "per_rank_kernel_ms": [g["kernel_ms"] for g in sorted(multi, key=lambda g: g["rank"])],
+                "value_one_gpu_same_invocation": [g["value_alone"] for g in sorted(multi, key=lambda g: g["rank"])],
+                "weak_scaling_efficiency": value / sum(g["value_alone"] for g in multi)} if world > 1 and multi else {}),
             "config": {"workload": f"{patch}: {V} voices/GPU (Saw>>Biquad LPF>>ADSR) playing SURVEY 8(d)'s cfg-2 note script (375 blocks: on at 0, off at 150 + (v mod 64), 0.255 s release) as a steady state of 375 phase-shifted groups; {N}-sample blocks @48kHz; note events applied from an HBM-resident script; stereo mix resident in HBM",
                        "voices_per_gpu": V, "voices_sounding_per_gpu_mean": live_mean, "block": N, "parallelism": f"voice-shard x{world}" + (" + RCCL all-reduce of [2][%d] per block" % N if world > 1 else ""),
                        "value_counts": "sounding voices x samples / s (SURVEY 8d: active voices); resident voices x samples / s = %.6g" % (world * V * N * args.steps / dt),

@@ -260,6 +260,16 @@ int klg_timing_end(klg_synth* s, int* launches, float* total_ms);
 /* ... and, while timing is armed, the same for a block's OTHER kernels — the event kernel and the voice-mix reduce (none for small banks, whose render launch
  * does both): launches and summed duration since klg_timing_begin.  Call it before klg_timing_end.  (What lets bench.py check that the kernels of a step fit the step.) */
 int klg_timing_end_aux(klg_synth* s, int* launches, float* total_ms);
+/* What a multi-device bank (klg_init with several ids; the voice sum of Stereo::Synth::process, klang.h:4830-4858, taken across GPUs) really runs through —
+ * so that a scaling measurement proves itself instead of being believed (bench.py --in-library):
+ *   *shards            how many shards the bank has (1: a one-device bank);
+ *   *rccl_ranks        the ranks the RCCL communicator ITSELF reports (ncclCommCount of shard 0's communicator), 0 if there is none — one device, or shards that share a GPU
+ *                      and are summed by a device-side add;
+ *   *distinct_devices  how many different HIP devices the shards sit on;
+ *   per_shard_kernel_ms[0 .. min(shards, cap))   every shard's render-kernel milliseconds since klg_timing_begin (call before klg_timing_end; may be NULL);
+ *   *allreduce_us      measured here: the mean duration of ONE all-reduce of a [2][n] block over the shards (`probe_reps` of them, each between a pair of events on shard 0's
+ *                      stream, outside any block); 0 without a communicator or with probe_reps <= 0. */
+int klg_synth_multi_info(klg_synth* s, int n, int probe_reps, int* shards, int* rccl_ranks, int* distinct_devices, float* per_shard_kernel_ms, int cap, float* allreduce_us);
 
 /* ------------------------------------------------------------------------------------------------
  * Effect banks: `instances` independent Stereo::Effect objects (klang.h:4703-4717) of one patch.

@@ -95,6 +95,7 @@ def load():
         "klg_timing_begin": (C.c_int, [vp]),
         "klg_timing_end": (C.c_int, [vp, C.POINTER(C.c_int), f32p]),
         "klg_timing_end_aux": (C.c_int, [vp, C.POINTER(C.c_int), f32p]),
+        "klg_synth_multi_info": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), f32p, C.c_int, f32p]),
         "klg_selftest": (C.c_int, [C.c_int, f32p, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_int]),
         "klg_selftest_host": (C.c_int, [C.c_int, f32p, C.c_int, C.c_float, f32p, C.c_int]),
         "klg_fx_create": (vp, [C.c_int, C.c_int, C.c_float, C.c_int]),

@@ -186,6 +186,14 @@ class SynthBank:
         check(self._L.klg_timing_end(self._h, C.byref(n), C.byref(ms)), "klg_timing_end")
         return n.value, ms.value
 
+    def multi_info(self, n=256, probe_reps=0):
+        """klg_synth_multi_info: {shards, rccl_ranks (what the communicator reports), distinct_devices, per_shard_kernel_ms (since timing_begin; before timing_end),
+        allreduce_us (mean of `probe_reps` all-reduces of a [2][n] block, measured by the library)}"""
+        sh, rk, dd, us = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        per = (C.c_float * 64)()
+        check(self._L.klg_synth_multi_info(self._h, n, probe_reps, C.byref(sh), C.byref(rk), C.byref(dd), per, 64, C.byref(us)), "klg_synth_multi_info")
+        return {"shards": sh.value, "rccl_ranks": rk.value, "distinct_devices": dd.value, "per_shard_kernel_ms": [per[i] for i in range(min(sh.value, 64))], "allreduce_us": us.value}
+
 
 class EventScript:
     """An event stream known in advance, resident in HBM (klg_script_*): every on() runs on the host once, up front; the blocks then

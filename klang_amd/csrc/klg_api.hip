@@ -356,6 +356,7 @@ struct Rccl {
 	int (*CommDestroy)(void* comm) = nullptr;
 	int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t stream) = nullptr;
 	int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
+	int (*CommCount)(void* comm, int* count) = nullptr;
 	const char* (*GetErrorString)(int) = nullptr;
 	bool load() {
 		if (lib) return true;
@@ -367,6 +368,7 @@ struct Rccl {
 		CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
 		AllReduce = (decltype(AllReduce))sym("ncclAllReduce"); GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
 		GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+		CommCount = (decltype(CommCount))sym("ncclCommCount");
 		if (!ok) { dlclose(lib); lib = nullptr; }
 		return ok;
 	}
@@ -1563,6 +1565,46 @@ extern "C" int klg_timing_end(klg_synth* s, int* launches, float* total_ms) {
 	for (int i = 0; i < s->launches; i++) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, s->tev[2 * i], s->tev[2 * i + 1])); total += ms; }
 	*launches = s->launches; *total_ms = total;
 	s->timing = false;
+	return 0;
+}
+
+extern "C" int klg_synth_multi_info(klg_synth* s, int n, int probe_reps, int* shards, int* rccl_ranks, int* distinct_devices, float* per_shard_kernel_ms, int cap, float* allreduce_us) {
+	if (!s || !shards || !rccl_ranks || !distinct_devices || !allreduce_us) return fail(KLG_ERR_INVALID, "klg_synth_multi_info: bad arguments");
+	*shards = 1; *rccl_ranks = 0; *distinct_devices = 1; *allreduce_us = 0.f;
+	auto shard_ms = [&](klg_synth* sh, float* out) -> int {
+		DeviceGuard bound(sh->device); if (!bound.ok) return KLG_ERR_NO_DEVICE;
+		HIP_TRY(hipDeviceSynchronize());
+		float total = 0.f;
+		for (int k = 0; k < sh->launches; k++) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, sh->tev[2 * k], sh->tev[2 * k + 1])); total += ms; }
+		*out = total; return 0;
+	};
+	if (!s->multi) { if (per_shard_kernel_ms && cap > 0) return shard_ms(s, per_shard_kernel_ms); return 0; }
+	Multi& m = *s->multi;
+	*shards = (int)m.shard.size();
+	{ std::vector<int> seen; for (klg_synth* sh : m.shard) if (std::find(seen.begin(), seen.end(), sh->device) == seen.end()) seen.push_back(sh->device); *distinct_devices = (int)seen.size(); }
+	for (int i = 0; per_shard_kernel_ms && i < *shards && i < cap; i++) if (int rc = shard_ms(m.shard[(size_t)i], per_shard_kernel_ms + i)) return rc;
+	if (!m.rccl || m.comm.empty()) return 0;
+	if (g_rccl.CommCount) { int c = 0; if (g_rccl.CommCount(m.comm[0], &c) == 0) *rccl_ranks = c; }
+	if (probe_reps <= 0 || n <= 0 || n > s->max_block) return 0;
+	klg_synth* s0 = m.shard[0];
+	DeviceGuard bound(s0->device); if (!bound.ok) return KLG_ERR_NO_DEVICE;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+	struct Free { hipEvent_t a, b; ~Free() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } release = { e0, e1 };
+	for (klg_synth* sh : m.shard) { DeviceGuard b2(sh->device); HIP_TRY(hipStreamSynchronize(sh->stream)); }
+	double total_ms = 0.0;
+	for (int r = 0; r < probe_reps + 3; r++) {                                 // (three untimed: the communicator's first collectives set up its channels)
+		HIP_TRY(hipEventRecord(e0, s0->stream));
+		int rc = g_rccl.GroupStart();
+		for (size_t i = 0; i < m.shard.size() && rc == 0; i++) rc = g_rccl.AllReduce(m.shard[i]->d_mix, m.shard[i]->d_mix, (size_t)2 * n, KLG_NCCL_FLOAT32, KLG_NCCL_SUM, m.comm[i], m.shard[i]->stream);
+		const int rc2 = g_rccl.GroupEnd();
+		if (rc != 0 || rc2 != 0) return fail(KLG_ERR_HIP, "klg_synth_multi_info: ncclAllReduce failed: %s", g_rccl.GetErrorString(rc ? rc : rc2));
+		HIP_TRY(hipEventRecord(e1, s0->stream));
+		for (klg_synth* sh : m.shard) { DeviceGuard b2(sh->device); HIP_TRY(hipStreamSynchronize(sh->stream)); }
+		float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+		if (r >= 3) total_ms += ms;
+	}
+	*allreduce_us = (float)(1e3 * total_ms / probe_reps);
 	return 0;
 }
 

@@ -102,6 +102,12 @@ def test_bench_py_two_ranks_end_to_end():
     assert out["config"]["voices_alive_after_last_block"] == out["config"]["voices_alive_expected"]
     assert out["config"]["mix_checksum"] > 0
     assert "all-reduce" in out["config"]["parallelism"]
+    # the line proves what it ran on: ranks counted THROUGH the communicator, the devices they sit on, the collective timed by itself, every rank's kernel,
+    # and the efficiency against the one-GPU value of the same invocation
+    assert out["rccl_ranks_seen"] == 2 and out["backend"] in ("nccl", "gloo")
+    assert out["functional_test_only"] == (env.get("KLG_BENCH_ONE_GPU") == "1") and out["devices_distinct"] == (1 if out["functional_test_only"] else 2)
+    assert out["allreduce_us_per_block"] > 0 and len(out["per_rank_kernel_ms"]) == 2 and all(ms > 0 for ms in out["per_rank_kernel_ms"])
+    assert len(out["value_one_gpu_same_invocation"]) == 2 and 0 < out["weak_scaling_efficiency"] < 1.5
 
 
 def test_bench_py_eight_ranks_end_to_end():
@@ -142,6 +148,23 @@ def test_bench_py_in_library_mode():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4 and out["mode"] == "in-library" and out["steps"] == 6 and np.isfinite(out["value"]) and out["value"] > 0
     assert out["config"]["mix_checksum"] > 0 and "x4" in out["config"]["parallelism"]
+    one = env.get("KLG_BENCH_ONE_GPU") == "1"
+    assert out["shards"] == 4 and out["functional_test_only"] == one and out["devices_distinct"] == (1 if one else 4) and out["rccl_ranks_seen"] == (0 if one else 4)
+    assert len(out["per_rank_kernel_ms"]) == 4 and all(ms > 0 for ms in out["per_rank_kernel_ms"]) and out["value_one_gpu_same_invocation"] > 0 and 0 < out["weak_scaling_efficiency"] < 1.5
+    assert (out["allreduce_us_per_block"] == 0) == one                                       # (shards that share a GPU are added on the device: there is no collective to time)
+
+
+def test_bench_py_refuses_to_report_more_gpus_than_it_ran_on():
+    """--gpus 2 on a one-GPU box without the functional-test switch: no JSON line, a message — a scaling number is never made from ranks that share a GPU."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    env = {k: v for k, v in os.environ.items() if k != "KLG_BENCH_ONE_GPU"}
+    for extra in ([], ["--in-library"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--voices", str(375 * 256)] + extra,
+                           env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], (r.stdout[-500:], r.stderr[-500:])
+        assert "GPU(s)" in r.stderr
 
 
 FX_RANK = r'''
