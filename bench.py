@@ -220,7 +220,7 @@ def valu_issue(wave_samples, kern_s, per_sample):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # live HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around a child of this script
 # ---------------------------------------------------------------------------------------------------------------------------------
-def pmc_traffic_live(args, kernel_substr, timeout_s=240, child_args=None, blocks_per_launch=1):
+def pmc_traffic_live(args, kernel_substr, timeout_s=240, child_args=None, blocks_per_launch=1, total_blocks=None):
     """bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024 (gfx950 FETCH_SIZE half-count, MI355X_MICROARCH.md §HBM), mean over the
     child's steady-state launches of the named kernel; None if rocprofv3 is unavailable or anything goes wrong (never costs the bench line)."""
     import csv
@@ -243,14 +243,18 @@ def pmc_traffic_live(args, kernel_substr, timeout_s=240, child_args=None, blocks
             shutil.rmtree(d, ignore_errors=True)
             if not vals:
                 return None, f"no {counter} rows for {kernel_substr}"
-            vals = vals[len(vals) // 2:]                                # the child's settled blocks
-            got[counter] = sum(vals) / len(vals)
+            if total_blocks:                                            # a span may be several launches of the kernel (PingPong: two): every launch of the child over every block of the child
+                got[counter] = sum(vals) / total_blocks * blocks_per_launch
+            else:
+                vals = vals[len(vals) // 2:]                            # the child's settled blocks
+                got[counter] = sum(vals) / len(vals)
         return (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0 / blocks_per_launch, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in this run (2 passes, {len(vals)} launches each" + (f" of {blocks_per_launch} blocks" if blocks_per_launch > 1 else "") + "); (2*FETCH_SIZE + WRITE_SIZE) KB * 1024"
     except Exception as e:                                              # noqa: BLE001
         return None, f"pmc leg failed: {type(e).__name__}"
 
 
 PMC_FX_SPAN = 16                 # blocks per span in the effect legs' counter children
+PMC_FX_SPANS = 12                # ... and spans per child
 
 
 def random_dials(bank, K):
@@ -318,7 +322,7 @@ def pmc_child_fx(spec, N):
                 bank.set_control(k, int(c), float(v))
     io = (torch.rand((PMC_FX_SPAN, K, 2, N), device="cuda") - 0.5) * 0.1
     ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
-    for _ in range(12):                                                    # 8 spans to settle, the later half of the rest is what counts
+    for _ in range(PMC_FX_SPANS):                                          # (PingPong: every launch of every span is counted — a span is one or two launches —; Reverb: the later half)
         bank.render_device(io.data_ptr(), PMC_FX_SPAN, N, ts.cuda_stream)
     torch.cuda.synchronize()
     bank.close()
@@ -402,7 +406,9 @@ def run_literal_script(patch, voices, N, label, phases=False):
     res = {"name": label, "workload": f"{patch}: {V} voices, SURVEY 8(d) script as written: note-on at block 0, note-off at block 150 + (v mod 64), {SCRIPT_BLOCKS} blocks of {N} samples, events from HBM",
            "value": float(sounding.sum()) * N / dt, "unit": "voice*samples/s (sounding voices)", "ms_per_step": 1e3 * dt / SCRIPT_BLOCKS, "steps": SCRIPT_BLOCKS,
            "kernel_ms_mean": kms / max(1, launches), "voices_sounding_mean": float(sounding.mean()), "voices_alive_at_end": alive,
-           "ms_per_block_sustain": float(np.median(ms[40:OFF_BLOCK])), "value_sustain_phase": V * N / (1e-3 * float(np.median(ms[40:OFF_BLOCK])))}
+           "ms_per_block_sustain": float(np.median(ms[40:OFF_BLOCK])), "value_sustain_phase": V * N / (1e-3 * float(np.median(ms[40:OFF_BLOCK]))),
+           # every block of the script — attack, sustain, the staggered releases — between its own pair of events on the stream the library launches on
+           "ms_per_block_max": float(ms.max()), "ms_per_block_max_at": int(ms.argmax()), "block_deadline_ms": 1e3 * N / 48000.0, "every_block_within_the_deadline": bool(ms.max() <= 1e3 * N / 48000.0)}
     if one_call:
         res["python_loop"] = {"ms_per_step": res["ms_per_step"], "value": res["value"], "kernel_ms_mean": res["kernel_ms_mean"], "what": "one Python -> C-ABI call per block (mix.zero_() + klg_script_play_device): host submission bound at this size"}
         res.update(ms_per_step=one_call["ms_per_step"], value=one_call["value"], kernel_ms_mean=one_call["kernel_ms_mean"], one_call=one_call)
@@ -489,7 +495,8 @@ def run_fx(patch, K, N, dials=None, tag="", args=None, per_block=False):
     spec = f"{patch}:{K}:" + ("random7" if dials == "random7" else ",".join(f"{c}={v}" for c, v in (dials or {}).items()))
     one_launch = patch == "pingpong"
     if args is not None and os.environ.get("KLG_BENCH_PMC_FX", "1") != "0" and not per_block:
-        traffic, how = pmc_traffic_live(args, kernel, timeout_s=180, child_args=["--pmc-fx", spec, "--block", str(N)], blocks_per_launch=PMC_FX_SPAN if one_launch else 1)
+        traffic, how = pmc_traffic_live(args, kernel, timeout_s=180, child_args=["--pmc-fx", spec, "--block", str(N)], blocks_per_launch=PMC_FX_SPAN if one_launch else 1,
+                                        total_blocks=PMC_FX_SPANS * PMC_FX_SPAN if one_launch else None)
     roof = {"bound": "hbm", "achieved": ab / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": how,
             "kernel": kernel, "algorithmic_bytes_per_launch": ab, "bytes_per_instance_sample": FX_BYTES_PER_SAMPLE[patch], "per": "block of %d samples (a PingPong span of %d blocks is ONE launch: its duration / %d)" % (N, rest_span, rest_span),
             "after_the_first_fifth": {"kernel_ms_mean": 1e3 * rest_s, "frac": ab / rest_s / 1e9 / HBM_PEAK_GBS, "launches": rest_launches,
@@ -638,6 +645,36 @@ def run_realtime(patch, voices, N, blocks=2000, name="realtime_deadline"):
             res["every_block_within_90_percent_of_the_deadline"] = bool(c["every_block_within_90_percent_of_the_deadline"])
             res["every_block_within_90_percent_of_the_deadline_source"] = "c_host (klang_deadline: C++ loop over klg_process_device + hipStreamSynchronize, pinned, memory locked)"
     return res
+
+
+def run_max_realtime(patch, N, start_voices, blocks=2000):
+    """deadline.max_realtime_voices: the LARGEST bank whose EVERY block — 2,000 sustaining blocks and the 44 of the all-voices release — ends within its
+    5.33 ms, found by the product's own host loop (klang_amd/host/klang_deadline.cpp, pinned, memory locked) run AGAINST THE AUDIO CLOCK (--paced 1: block k is not started
+    before k periods): sizes from `start_voices` down in steps of 2 Mi until one passes.  The sizes that failed are reported with what failed in them — blocks over the
+    deadline, whether they were the device's, and the buffering depth (in blocks) that would have hidden them."""
+    exe = os.path.join(ROOT, "klang_amd", "host", "klang_deadline")
+    notes = NOTES.get(patch, 32)
+    deadline = 1e3 * N / 48000.0
+    tried, best = [], None
+    V = start_voices
+    while V >= (8 << 20) and len(tried) < 6:
+        try:
+            p = subprocess.run([exe, "--voices", str(V), "--blocks", str(blocks), "--n", str(N), "--patch", str(PATCH_ID[patch]), "--notes", str(notes), "--paced", "1"], capture_output=True, text=True, timeout=600)
+            c = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else {"error": (p.stderr or p.stdout)[-300:]}
+        except Exception as e:                                                # noqa: BLE001
+            c = {"error": f"{type(e).__name__}: {e}"}
+        if "max_ms" not in c:
+            tried.append({"voices": V, "error": c.get("error", "?")}); break
+        over = sum(1 for (_, ms) in c["ten_largest"] if ms > deadline)
+        rec = {"voices": V, "p99_ms": c["p99_ms"], "max_ms": c["max_ms"], "release_max_ms": c["release_max_ms"], "every_block_within_the_deadline": bool(c["every_block_within_the_deadline"]),
+               "blocks_over_the_deadline_among_the_ten_largest": over, "worst_block_is": c.get("worst_block_is"), "device_max_ms": c.get("device_max_ms"),
+               "buffering_that_hides_the_late_blocks_blocks": (c.get("paced") or {}).get("buffering_with_no_gap_in_this_run_blocks")}
+        tried.append(rec)
+        if rec["every_block_within_the_deadline"]:
+            best = V; break
+        V -= 2 << 20
+    return {"name": "max_realtime_voices", "voices": best, "deadline_ms": deadline, "blocks": blocks, "tried": tried, "host": "klang_deadline --paced 1 (C++, pinned, memory locked, one block of buffering)",
+            "reading": "the largest bank of which every one of 2,044 consecutive blocks, started on the audio clock, ended within its own period on this node in this run"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -1005,6 +1042,8 @@ def main():
             leg(run_fx, "pingpong", 4096, N, dials="random7", tag="_random_dials", args=args)   # one instance in seven with random dials: moving smoothers, vibrato, taps inside a chunk
             leg(run_fx, "pingpong", 65536, N, args=args)                             # the same patch at bank scale: where config 4 meets north_star's "≥ 40 % of the HBM roofline" (100 GB of delay lines)
             leg(run_literal_script, "fm4", 131072, N, "cfg5_share_131072_fm4_voices")
+            leg(run_literal_script, "fm4", 1 << 20, N, "cfg5_1048576_fm4_one_gpu")   # config 5 WHOLE on one GPU (no 8-GPU node has been offered to this repo): 1 Mi voices of the 4-operator patch, every block against its 5.33 ms
+            leg(run_max_realtime, "sub2a", N, args.realtime_voices)
             leg(run_realtime, "sub2a", args.realtime_voices, N)
             # ... and the largest bank (to the nearest 4 Mi voices) whose WORST block — attack, sustain or the all-voices release — stays within 90 % of the deadline
             leg(run_realtime, "sub2a", args.realtime_margin_voices, N, name="realtime_deadline_with_margin")
@@ -1028,6 +1067,13 @@ def main():
                                            "within_90_percent": c["every_block_within_90_percent_of_the_deadline"],
                                            "c_host": {k: c["c_host"].get(k) for k in ("p99_ms", "max_ms", "worst_block", "release_max_ms", "every_block_within_90_percent_of_the_deadline", "blocks_over_90_percent", "of_them_the_devices", "device_max_ms", "error") if k in c.get("c_host", {})}}
                                for c in configs if c.get("name", "").startswith("realtime") and "p99_ms" in c}
+            for c in configs:
+                if c.get("name") == "max_realtime_voices":
+                    out["deadline"]["max_realtime_voices"] = c.get("voices")
+                    out["deadline"]["max_realtime_voices_tried"] = [[t.get("voices"), t.get("max_ms"), t.get("blocks_over_the_deadline_among_the_ten_largest"), t.get("buffering_that_hides_the_late_blocks_blocks")] for t in c.get("tried", [])]
+                    out["deadline"]["max_realtime_voices_columns"] = ["voices", "largest block ms (deadline %.3f)" % c.get("deadline_ms", 0), "of the ten largest blocks: over the deadline", "blocks of buffering that hide them"]
+                if c.get("name") == "cfg5_1048576_fm4_one_gpu" and "roofline" in c:
+                    out["deadline"]["cfg5_1048576_fm4_one_gpu"] = {"kernel_ms_mean": c.get("kernel_ms_mean"), "ms_per_block_max": c.get("ms_per_block_max"), "every_block_within_the_deadline": c.get("every_block_within_the_deadline"), "frac_of_fp32_peak": c["roofline"]["frac"]}
             for c in configs:
                 if c.get("name", "").startswith("noise_note") and "value" in c:
                     out["noise"] = {"name": c["name"], "ms_per_block_with_wait_median": round(c["ms_per_block_with_wait_median"], 4), "ms_per_block_queued": round(c["ms_per_step"], 4), "kernel_ms": round(c["kernel_ms_mean"], 4), "round_4_ms_per_block": 82.0}

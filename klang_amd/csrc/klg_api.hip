@@ -474,6 +474,11 @@ static klg_synth* synth_create_common(int device, int patch_id, const PatchInfo*
 		s->lanes = e ? (e[0] == '1' || e[0] == '2' || e[0] == '3') : true;          // (the sample-parallel form at every size: 16,384 voices 26 us per block against 37 for the pair form, 524,288 voices 0.53 ms against 0.58 for a voice per lane)
 		s->sp = s->lanes && !(e && (e[0] == '1' || e[0] == '2'));
 		s->pairs = s->lanes && e && e[0] == '2';
+#ifndef KLG_AB_KERNELS
+		// (round 6) the oscillator-per-lane and pair-per-lane kernels are A/B references of klg_render_supersaw_sp: they are in the library only when it is built with
+		// klang_amd/csrc/build.sh -DKLG_AB_KERNELS — the shipped .so holds what runs
+		if (s->lanes && !s->sp) { fail(KLG_ERR_INVALID, "KLG_SUPERSAW_LANES=%s asks for an A/B reference kernel; this library was built without -DKLG_AB_KERNELS", e); synth_free(s); return nullptr; }
+#endif
 		// sample slots per voice: enough waves for four per SIMD (a 16,384-voice bank: 4096); a bank that has them anyway keeps one
 		const char* pe = getenv("KLG_SUPERSAW_PAIRS_P");
 		s->pairs_p = pe ? atoi(pe) : (s->V <= 16384 ? 4 : 1);     // measured: 16,384 voices 58 / 49 / 49 us with 1 / 2 / 4 slots, 32,768 voices 77 / 82 / 87
@@ -654,6 +659,7 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 		else KLG_LAUNCH((klg_render_supersaw_sp<false, 8>), g, b, lds, st, a);
 		return;
 	}
+#ifdef KLG_AB_KERNELS
 	if (s->pairs) {                                       // SuperSaw, an oscillator pair per lane (KLG_SUPERSAW_LANES=2)
 		const dim3 g(render_grid(s)), b(WG);
 		const size_t lds = render_lds_bytes(a.n);
@@ -673,6 +679,7 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 		else KLG_LAUNCH(klg_render_supersaw_lanes<false>, g, b, render_lds_bytes(a.n), st, a);
 		return;
 	}
+#endif
 	switch (s->patch) {
 	case KLG_PATCH_SINE: launch_render_t<PatchSine>(s, a, pv, st); break;
 	case KLG_PATCH_BSINE: launch_render_t<PatchBSine>(s, a, pv, st); break;

@@ -112,6 +112,7 @@ struct PingPongArgs {
 // Arithmetic and its order are identical in both paths (bit-exact vs the reference, tests/test_gpu_fx.py).
 enum { PP_SUB = 8 };
 
+#ifdef KLG_AB_KERNELS   // (the one-wave reference of klg_fx_pingpong_x: in the library only when built with -DKLG_AB_KERNELS)
 __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 	__shared__ float tile[2 * FX_CHUNK * FX_LD];
 	const int lane = threadIdx.x, k0 = blockIdx.x * FX_WG, k = k0 + lane;
@@ -232,6 +233,8 @@ __global__ __launch_bounds__(FX_WG) void klg_fx_pingpong(const PingPongArgs a) {
 		a.state[(size_t)(PP_Z + 2) * a.kpad + k] = dcr.z0; a.state[(size_t)(PP_Z + 3) * a.kpad + k] = dcr.z1;
 	}
 }
+
+#endif
 
 template<bool B> struct BoolTag { static constexpr bool value = B; };   // (std::true_type without <type_traits>: this header is also compiled by hipRTC)
 template<int I> struct IntTag { static constexpr int value = I; };

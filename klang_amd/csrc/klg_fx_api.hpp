@@ -517,7 +517,13 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st, int blocks 
 		static const int ablate = []() { const char* e = getenv("KLG_FX_ABLATE"); return e ? atoi(e) : 0; }();
 		a.ablate = ablate;
 		static const bool single_wave = []() { const char* e = getenv("KLG_FX_PINGPONG1"); return e && e[0] == '1'; }();
-		if (single_wave || a.ablate) { TimedLaunch timed(f); KLG_LAUNCH(klg_fx_pingpong, grid, block, 0, st, a); }   // one wave per 64 instances (A/B reference, ablation)
+		if (single_wave || a.ablate) {                                                  // one wave per 64 instances (A/B reference, ablation)
+#ifdef KLG_AB_KERNELS
+			TimedLaunch timed(f); KLG_LAUNCH(klg_fx_pingpong, grid, block, 0, st, a);
+#else
+			return fail(KLG_ERR_INVALID, "KLG_FX_PINGPONG1 / KLG_FX_ABLATE ask for the one-wave A/B reference kernel; this library was built without -DKLG_AB_KERNELS");
+#endif
+		}
 		// the pipeline's time is a workgroup's instruction count on its one CU: a quarter / a half of a ring group per workgroup while
 		// the bank does not fill the chip that way either (klg_fx_pingpong_x<G>; KLG_FX_PINGPONG_G = 16 / 32 / 64 forces the width)
 		else {

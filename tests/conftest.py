@@ -68,3 +68,15 @@ def oracle_build():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.hookimpl(wrapper=True)
+def pytest_runtest_call(item):
+    """A/B reference kernels (the one-wave PingPong, SuperSaw's oscillator-per-lane and pair-per-lane forms) are in the library only when it is built with
+    klang_amd/csrc/build.sh -DKLG_AB_KERNELS: a test that asks for one through its environment switch is skipped on the shipped build (the library says so itself)."""
+    try:
+        return (yield)
+    except Exception as e:   # noqa: BLE001
+        if "built without -DKLG_AB_KERNELS" in str(e):
+            pytest.skip("A/B reference kernel: the library was built without -DKLG_AB_KERNELS")
+        raise
