@@ -2169,7 +2169,12 @@ template<class NOTE> inline const float* solo_render(NOTE* note, int at, int m) 
 namespace gpu { enum MixMode { Sum = 0, LastActiveVoice = 1 }; }          // how the voices of a MONO Synth combine (see klang::Synth below)
 
 template<class NOTEBASE> struct SynthCore : Plugin {
-	struct Slot { NOTEBASE* note = nullptr; NoteBinding b = { -1, nullptr, nullptr }; const gpu::GraphLayout* graph = nullptr; const char* lo = nullptr; };   // lo: the most derived object's address
+	struct Slot { NOTEBASE* note = nullptr; NoteBinding b = { -1, nullptr, nullptr }; const gpu::GraphLayout* graph = nullptr; const char* lo = nullptr; int type = 0; };   // lo: the most derived object's address; type: which notes.add<T>() made it
+	// SEVERAL NOTE TYPES (round 6; Notes::add<TYPE>, klang.h:4323-4330, takes several): slots in add order, `assign()` over all of them as the reference's (4336-4372); every
+	// type has its own kernel and record layout, hence its own bank of `count` voices in which only that type's slots ever sound.  A block renders every bank into the same
+	// buffers.  What notes of different types would share through their Synth — a smooth()ed control, the rand() sequence of Noise generators — is ordered per bank, not per slot.
+	struct TypeBank { klg_synth* bank = nullptr; std::vector<uint32_t> words; std::vector<uint8_t> stages; };
+	std::vector<TypeBank> types;
 	// NOTE VARIANTS (-DKLANG_GPU_NOTE_VARIANTS).  A recorded body is one program per Note TYPE — but a note's process() may depend on HOST state that its on() sets: a pointer to
 	// one of several member oscillators (examples/Additive/Inheritance.k: `Additive* osc` chosen by a Menu in on(), `*osc >> out` in process()), an `int` that selects a
 	// branch.  With the switch nothing is recorded at notes.add<T>(); instead every event of a note (noteOn, noteOff, a hook) is followed by a recording of THAT note's
@@ -2189,13 +2194,18 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		unsigned count = 0;
 		std::vector<gpu::GraphLayout*> layouts;
 		const std::type_info* note_type = nullptr; unsigned hooks = 0;
+		std::vector<const std::type_info*> type_ids; std::vector<const gpu::GraphLayout*> type_layout;
 		template<class T> void add(int n) {
 			gpu::close_log();
-			// one Note type per Synth: the bank is ONE kernel over ONE record layout (the reference's Notes would take several)
-			if (note_type && *note_type != typeid(T)) { std::fprintf(stderr, "klang-mi355: notes.add<%s>() after notes.add<%s>(): a Synth renders ONE Note type (one kernel, one record layout); use a Synth per type\n", typeid(T).name(), note_type->name()); std::abort(); }
-			note_type = &typeid(T); hooks = gpu::NoteHooks<T>::mask();
+			int ti = -1;
+			for (size_t k = 0; k < type_ids.size(); k++) if (*type_ids[k] == typeid(T)) ti = (int)k;
+			if (ti < 0) { ti = (int)type_ids.size(); type_ids.push_back(&typeid(T)); type_layout.push_back(nullptr); }
+			if (owner->gpu) { std::fprintf(stderr, "klang-mi355: notes.add<%s>() after the Synth's first event or block: the banks exist by then (add every Note type in the Synth's constructor)\n", typeid(T).name()); std::abort(); }
+			// (per-note recorded bodies, -DKLANG_GPU_NOTE_VARIANTS, keep to one Note type: a variant is a program of THE type's members)
+			if (kVariants && note_type && *note_type != typeid(T)) { std::fprintf(stderr, "klang-mi355: notes.add<%s>() after notes.add<%s>() with -DKLANG_GPU_NOTE_VARIANTS: per-note recorded bodies keep to ONE Note type (build without the switch, or use a Synth per type)\n", typeid(T).name(), note_type->name()); std::abort(); }
+			note_type = &typeid(T); hooks |= gpu::NoteHooks<T>::mask();
 			const bool bound = klang_gpu_patch((const T*)nullptr) >= 0 && !std::getenv("KLANG_MI355_FORCE_GRAPH");
-			const gpu::GraphLayout* layout = items.empty() ? nullptr : items[0].graph;
+			const gpu::GraphLayout* layout = type_layout[(size_t)ti];
 			type_name = typeid(T).name();
 			for (int i = 0; i < n && items.size() < 128; i++) {
 				T* t = nullptr;
@@ -2204,9 +2214,9 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 					else { gpu::log_suppress++; t = new T(); gpu::log_suppress--; }
 					t->attach(static_cast<typename T::synth_type*>(owner));
 				}
-				else if (!bound && !layout) { gpu::GraphLayout* l = new gpu::GraphLayout(); layouts.push_back(l); t = record<T>(*l); layout = l; }   // the prototype becomes note 0
+				else if (!bound && !layout) { gpu::GraphLayout* l = new gpu::GraphLayout(); layouts.push_back(l); t = record<T>(*l); layout = l; type_layout[(size_t)ti] = l; }   // the prototype becomes the type's first note
 				else { gpu::log_suppress++; t = new T(); gpu::log_suppress--; t->attach(static_cast<typename T::synth_type*>(owner)); }
-				Slot s; s.note = t; s.graph = layout; s.lo = (const char*)t;
+				Slot s; s.note = t; s.graph = layout; s.lo = (const char*)t; s.type = ti;
 				s.b.patch = bound ? klang_gpu_patch((const T*)t) : -1;
 				s.b.pack = [](const void* p, uint32_t* w) { klang_gpu_pack((const T*)p, w); };
 				s.b.unpack = [](void* p, const uint32_t* w) { klang_gpu_unpack((T*)p, w); };
@@ -2246,7 +2256,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 	gpu::FxRunner post;                                                      // the Synth's own process() (post-processing of the mix), if it has one
 
 	SynthCore() { notes.owner = this; }
-	~SynthCore() { if (kVariants) { for (auto& v : variants) { if (v.bank) klg_synth_destroy(v.bank); delete v.layout; } } else if (gpu) klg_synth_destroy(gpu); }
+	~SynthCore() { if (kVariants) { for (auto& v : variants) { if (v.bank) klg_synth_destroy(v.bank); delete v.layout; } } else for (auto& t : types) if (t.bank) klg_synth_destroy(t.bank); }
 
 	virtual bool mono_synth() const { return false; }
 	void fail(const char* what) { std::fprintf(stderr, "klang-mi355: %s: %s\n", what, klg_last_error()); std::abort(); }
@@ -2259,28 +2269,38 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 			return;
 		}
 		if (!notes.count) { std::fprintf(stderr, "klang-mi355: Synth has no notes (call notes.add<T>(n))\n"); std::abort(); }
-		const int patch = notes.items[0].b.patch;
-		if (const gpu::GraphLayout* g = notes.items[0].graph) {              // recorded process(): compiled for gfx950 now (hipRTC)
-			gpu = klg_synth_create_graph(g->program.c_str(), 1, (int)notes.count, fs.f, 1024);
-			if (!gpu) fail("klg_synth_create_graph");
-			for (size_t k = 0; k < g->tables.size(); k++) if (klg_table_upload(gpu, g->tables[k].data(), (int)g->tables[k].size(), 0) != (int)k + 1) fail("klg_table_upload (Table read by process())");
-		}
-		else {
-			if (patch < 0) { std::fprintf(stderr, "klang-mi355: no GPU kernel is bound to this Note type\n"); std::abort(); }
-			gpu = klg_synth_create(patch, 1, (int)notes.count, fs.f, 1024);
-			if (!gpu) fail("klg_synth_create");
-		}
 		if (const char* e = std::getenv("KLANG_MI355_MONO_MIX")) if (mono_synth() && (!std::strcmp(e, "last") || !std::strcmp(e, "reference"))) mix = gpu::LastActiveVoice;   // (no source change needed to get the reference's literal mono behaviour)
-		if (klg_synth_set_mix_mode(gpu, (int)mix)) fail("klg_synth_set_mix_mode");
-		words.resize(klg_synth_state_bytes(gpu) / 4);
+		types.assign(notes.type_ids.size(), TypeBank());
+		for (size_t ti = 0; ti < types.size(); ti++) {                          // one bank per Note type (see SEVERAL NOTE TYPES above), every bank with all `count` slots
+			const Slot* first = nullptr;
+			for (const Slot& sl : notes.items) if (sl.type == (int)ti) { first = &sl; break; }
+			if (!first) continue;
+			klg_synth* bank = nullptr;
+			if (const gpu::GraphLayout* g = first->graph) {                      // recorded process(): compiled for gfx950 now (hipRTC)
+				bank = klg_synth_create_graph(g->program.c_str(), 1, (int)notes.count, fs.f, 1024);
+				if (!bank) fail("klg_synth_create_graph");
+				for (size_t k = 0; k < g->tables.size(); k++) if (klg_table_upload(bank, g->tables[k].data(), (int)g->tables[k].size(), 0) != (int)k + 1) fail("klg_table_upload (Table read by process())");
+			}
+			else {
+				if (first->b.patch < 0) { std::fprintf(stderr, "klang-mi355: no GPU kernel is bound to this Note type\n"); std::abort(); }
+				bank = klg_synth_create(first->b.patch, 1, (int)notes.count, fs.f, 1024);
+				if (!bank) fail("klg_synth_create");
+			}
+			if (klg_synth_set_mix_mode(bank, (int)mix)) fail("klg_synth_set_mix_mode");   // (LastActiveVoice with several types: the bank's own last sounding slot; render_voices() keeps the block of the bank that holds the synth's last one)
+			types[ti].bank = bank;
+			types[ti].words.resize(klg_synth_state_bytes(bank) / 4);
+			types[ti].stages.assign(notes.count, (uint8_t)klg::ST_OFF);
+			if (klg_synth_note_channels(bank) != klg_synth_note_channels(types[0].bank)) { std::fprintf(stderr, "klang-mi355: the Note types of one Synth must all have a mono or all a stereo `out`\n"); std::abort(); }
+		}
+		gpu = types[0].bank;
 		stages.resize(notes.count);
 		sync_controls();
 		push_smoothed();
 	}
 	void sync_controls() { if (kVariants && notes.proto_lo) { for (auto& v : variants) for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(v.bank); c++) klg_set_control(v.bank, 0, (int)c, controls.items[c].value.value); return; }
-		for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_set_control(gpu, 0, (int)c, controls.items[c].value.value); }
+		for (auto& t : types) for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(t.bank); c++) klg_set_control(t.bank, 0, (int)c, controls.items[c].value.value); }
 	// Control::smoothed (klang.h:1707): the bank advances it (every sounding note's smooth() calls, in order); the host objects follow
-	void push_smoothed() { if (kVariants && notes.proto_lo) return; for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_set_control_smoothed(gpu, 0, (int)c, controls.items[c].smoothed.value); }
+	void push_smoothed() { if (kVariants && notes.proto_lo) return; for (auto& t : types) for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(t.bank); c++) klg_set_control_smoothed(t.bank, 0, (int)c, controls.items[c].smoothed.value); }
 	void pull_smoothed() { if (kVariants && notes.proto_lo) return; for (unsigned c = 0; c < controls.items.size() && (int)c < klg_synth_controls(gpu); c++) klg_get_control_smoothed(gpu, 0, (int)c, &controls.items[c].smoothed.value); }
 	// ---- NOTE VARIANTS: the event path and the block ----
 	std::vector<gpu::Obj> rebased_objs(const Slot& s) const {
@@ -2336,6 +2356,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		ensure_gpu();
 		if (kVariants && notes.proto_lo) { with_voice_variant(n, event_code); return; }
 		Slot& s = notes.items[(size_t)n];
+		klg_synth* const gpu = types[(size_t)s.type].bank; std::vector<uint32_t>& words = types[(size_t)s.type].words;   // the slot's own type's bank
 		if (klg_voice_download(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_download");
 		// the lane's record -> the host mirror.  A note keeps ALL its member state from one note to the next in the reference (filter memories,
 		// oscillator phases, delay cursors: nothing is reset unless on() does it), so a slot that has sounded before is unpacked whatever its
@@ -2384,8 +2405,10 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 			}
 			return;
 		}
-		if (klg_voice_stages(gpu, stages.data(), (int)notes.count)) fail("klg_voice_stages");
-		for (unsigned n = 0; n < notes.count; n++) if (stages[n] == klg::ST_OFF) notes[(int)n]->stage = NOTEBASE::Off;    // `if (!note->process(..)) note->stop()`
+		for (size_t ti = 0; ti < types.size(); ti++) {
+			if (klg_voice_stages(types[ti].bank, types[ti].stages.data(), (int)notes.count)) fail("klg_voice_stages");
+			for (unsigned n = 0; n < notes.count; n++) if (notes.items[n].type == (int)ti) { stages[n] = types[ti].stages[n]; if (stages[n] == klg::ST_OFF) notes[(int)n]->stage = NOTEBASE::Off; }    // `if (!note->process(..)) note->stop()`
+		}
 	}
 	std::vector<float> unheard;                                               // (note variants + LastActiveVoice: where the banks that are not heard render)
 	float* per_voice_sink = nullptr;                                          // tests: every voice's own block ([voice][note channels][length]) is written here too
@@ -2413,6 +2436,26 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 			}
 			if (per_voice_sink) for (unsigned n = 0; n < notes.count; n++) if (slot_variant[n] < 0) std::memset(per_voice_sink + (size_t)n * (size_t)length * (variants.empty() ? 1 : (size_t)klg_synth_note_channels(variants[0].bank)), 0, (size_t)length * (variants.empty() ? 1 : (size_t)klg_synth_note_channels(variants[0].bank)) * sizeof(float));
 			refresh_stages();
+			return;
+		}
+		if (types.size() > 1) {                                                  // several Note types: every type's bank adds its sounding voices to the block (as the variants' banks above)
+			std::vector<float> tmp;
+			int heard = -1;
+			if (mix == gpu::LastActiveVoice) for (unsigned n = 0; n < notes.count; n++) if (notes[(int)n]->stage != NOTEBASE::Off) heard = notes.items[n].type;
+			float* sink[2] = { nullptr, nullptr };
+			if (mix == gpu::LastActiveVoice) { if (unheard.size() < (size_t)channels * (size_t)length) unheard.resize((size_t)channels * (size_t)length); for (int c = 0; c < channels && c < 2; c++) sink[c] = unheard.data() + (size_t)c * (size_t)length; }
+			const size_t row = (size_t)klg_synth_note_channels(gpu) * (size_t)length;
+			for (size_t ti = 0; ti < types.size(); ti++) {
+				float* const* dst = (mix == gpu::LastActiveVoice && (int)ti != heard) ? sink : buffers;
+				if (per_voice_sink) {
+					tmp.assign(row * notes.count, 0.f);
+					if (klg_process_voices(types[ti].bank, tmp.data(), dst, channels, length)) fail("klg_process_voices");
+					for (unsigned n = 0; n < notes.count; n++) if (notes.items[n].type == (int)ti) std::memcpy(per_voice_sink + (size_t)n * row, tmp.data() + (size_t)n * row, row * sizeof(float));
+				}
+				else if (klg_process(types[ti].bank, dst, channels, length, nullptr)) fail("klg_process");
+			}
+			refresh_stages();
+			pull_smoothed();
 			return;
 		}
 		if (per_voice_sink) { if (klg_process_voices(gpu, per_voice_sink, buffers, channels, length)) fail("klg_process_voices"); }
