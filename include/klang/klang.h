@@ -1628,6 +1628,7 @@ inline void drop_idle_writebacks(Recorder& R, const std::vector<int>& first_reg)
 // ---- recording a Note's process() (+ prepare()) into a graph program ----
 // `objs`: the note's members (member_objs).  prepare() — host code that runs once per block in the reference (klang.h:4292-4296) —
 // becomes the program's per-block prologue, like an effect's.
+inline thread_local bool quiet_recording = false;                              // (a body re-recorded only to be compared: SynthCore::check_body)
 template<class NOTEBASE> inline void record_note(NOTEBASE* nb, std::vector<Obj> objs, Controls& ctl, const char* lo, GraphLayout& L, const char* type_name) {
 	using namespace klg::graph;
 	Recorder R; rec = &R;
@@ -1676,7 +1677,7 @@ template<class NOTEBASE> inline void record_note(NOTEBASE* nb, std::vector<Obj> 
 	rec = nullptr;
 	if (!R.error.empty()) { std::fprintf(stderr, "klang-mi355: cannot record %s::process() as a graph patch: %s\n", type_name, R.error.c_str()); std::abort(); }
 	finish_program(R, lo, L);
-	if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", type_name, L.program.c_str());
+	if (std::getenv("KLANG_MI355_DUMP_GRAPH") && !quiet_recording) std::fprintf(stderr, "klang-mi355: recorded %s::process():\n%s", type_name, L.program.c_str());
 }
 
 // ---- recording an Effect's prepare() + process() into a `kind effect` program ----
@@ -2195,11 +2196,14 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		std::vector<gpu::GraphLayout*> layouts;
 		const std::type_info* note_type = nullptr; unsigned hooks = 0;
 		std::vector<const std::type_info*> type_ids; std::vector<const gpu::GraphLayout*> type_layout;
+		struct Proto { std::vector<gpu::Obj> objs; const char* lo = nullptr; size_t size = 0; std::string name; };   // a recorded type's prototype: its members, re-based onto each note (check_body)
+		std::vector<Proto> type_proto;
 		template<class T> void add(int n) {
 			gpu::close_log();
 			int ti = -1;
 			for (size_t k = 0; k < type_ids.size(); k++) if (*type_ids[k] == typeid(T)) ti = (int)k;
-			if (ti < 0) { ti = (int)type_ids.size(); type_ids.push_back(&typeid(T)); type_layout.push_back(nullptr); }
+			if (ti < 0) { ti = (int)type_ids.size(); type_ids.push_back(&typeid(T)); type_layout.push_back(nullptr); type_proto.push_back(Proto()); }
+			cur_type = ti;
 			if (owner->gpu) { std::fprintf(stderr, "klang-mi355: notes.add<%s>() after the Synth's first event or block: the banks exist by then (add every Note type in the Synth's constructor)\n", typeid(T).name()); std::abort(); }
 			// (per-note recorded bodies, -DKLANG_GPU_NOTE_VARIANTS, keep to one Note type: a variant is a program of THE type's members)
 			if (kVariants && note_type && *note_type != typeid(T)) { std::fprintf(stderr, "klang-mi355: notes.add<%s>() after notes.add<%s>() with -DKLANG_GPU_NOTE_VARIANTS: per-note recorded bodies keep to ONE Note type (build without the switch, or use a Synth per type)\n", typeid(T).name(), note_type->name()); std::abort(); }
@@ -2225,6 +2229,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		}
 		// Construct the prototype Note with every primitive / signal member announcing itself, run its process() once in
 		// recording mode, and turn what was recorded into a graph program + the member layout of the Note type.
+		int cur_type = 0;
 		template<class T> T* record(gpu::GraphLayout& L) {
 			gpu::Recorder C;
 			gpu::rec = &C; C.constructing = true;
@@ -2233,7 +2238,9 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 			t->attach(static_cast<typename T::synth_type*>(owner));
 			const char* lo = (const char*)t;
 			NOTEBASE* nb = t;
-			gpu::record_note(nb, gpu::member_objs(C, lo, lo + sizeof(T)), owner->controls, lo, L, typeid(T).name());
+			Proto& P = type_proto[(size_t)cur_type];
+			P.objs = gpu::member_objs(C, lo, lo + sizeof(T)); P.lo = lo; P.size = sizeof(T); P.name = typeid(T).name();
+			gpu::record_note(nb, P.objs, owner->controls, lo, L, typeid(T).name());
 			return t;
 		}
 		NOTEBASE* operator[](int i) { return items[(size_t)i].note; }
@@ -2351,6 +2358,32 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		if (klg_voice_upload(W.bank, n, W.words.data(), W.words.size() * 4)) fail("klg_voice_upload");
 		slot_variant[(size_t)n] = v2; s.graph = W.layout;
 	}
+	// A recorded body is ONE program per Note type, recorded from the prototype at notes.add<T>().  A process() that follows HOST state of its note — a pointer or an `int` that
+	// on() sets and process() branches on (Additive/Inheritance.k, Subtractive/Modular.k), a plain `float` member used as a factor — would silently play the prototype's body for
+	// every note.  So after every event the note's process() is recorded AGAIN, with its host state as the event left it, and compared with the bank's program: a difference
+	// stops the run with the switch that handles it (-DKLANG_GPU_NOTE_VARIANTS: one bank per body).  -DKLANG_GPU_TRUST_BODIES skips the check (a host that has run it once).
+	void check_body(const Slot& s) {
+#ifndef KLANG_GPU_TRUST_BODIES
+		if (!s.graph || (size_t)s.type >= notes.type_proto.size() || !notes.type_proto[(size_t)s.type].lo) return;
+		const typename NotesT::Proto& P = notes.type_proto[(size_t)s.type];
+		std::vector<gpu::Obj> objs = P.objs;
+		const ptrdiff_t d = s.lo - P.lo;
+		auto move = [&](const void* p) -> const void* { const char* c = (const char*)p; return (c >= P.lo && c < P.lo + P.size) ? c + d : c; };
+		for (auto& o : objs) { o.addr = move(o.addr); if (o.packable) o.packable = (const gpu::Packable*)move(o.packable); if (o.key) o.key = move(o.key); if (o.live_arg) o.live_arg = (const int*)move(o.live_arg); }
+		gpu::GraphLayout L2;
+		gpu::quiet_recording = true;
+		gpu::record_note(s.note, std::move(objs), controls, s.lo, L2, P.name.c_str());
+		gpu::quiet_recording = false;
+		if (L2.program == s.graph->program) return;
+		std::fprintf(stderr, "klang-mi355: %s::process() follows HOST state of its note: recorded again after this event it is a different program from the one recorded at notes.add<T>() "
+			"(a pointer, an int or a plain float that on() / off() / a hook sets and process() reads).  One program per Note type cannot play that: compile with -DKLANG_GPU_NOTE_VARIANTS "
+			"(one bank per body), or keep such state in `param` / `signal` members.\n", P.name.c_str());
+		if (std::getenv("KLANG_MI355_DUMP_GRAPH")) std::fprintf(stderr, "---- at notes.add<T>():\n%s---- after this event:\n%s", s.graph->program.c_str(), L2.program.c_str());
+		std::abort();
+#else
+		(void)s;
+#endif
+	}
 	// host mirror <- lane ; run the event ; lane <- host mirror
 	template<class F> void with_voice(int n, F&& event_code) {
 		ensure_gpu();
@@ -2366,6 +2399,7 @@ template<class NOTEBASE> struct SynthCore : Plugin {
 		if (used) { if (s.graph) s.graph->unpack(s.note, words.data()); else s.b.unpack(s.note, words.data()); }
 		gpu::upload_target = gpu; gpu::current_voice = n; gpu::current_note = s.note; gpu::current_layout = s.graph;   // Wavetable uploads / Delay::clear() of this voice
 		event_code(s.note);
+		check_body(s);
 		if (s.graph) s.graph->pack(s.note, words.data()); else s.b.pack(s.note, words.data());
 		words[0] = (words[0] & ~3u) | (uint32_t)s.note->stage;
 		if (klg_voice_upload(gpu, n, words.data(), words.size() * 4)) fail("klg_voice_upload");
@@ -2706,7 +2740,31 @@ namespace std { namespace klang {
 // with -DKLANG_GPU_TRACE_FLOAT: from here on — i.e. in the patch's OWN text, which follows this header — the word `float` names klang::signal, the value
 // that records what is done to it (arithmetic, comparisons in `if`: one traced run of process() per outcome).  The .k file itself stays as it is; whoever
 // includes it puts `#undef float` behind the include (include/klang/bindings.h and the test drivers do).
+// What the renaming must never do SILENTLY: change the meaning of `sizeof(float)`, or let a `float*` that is really a signal* go through the C library's
+// byte copiers.  Both are compile errors with a message: `sizeof` of the tracing type (or of an array of it) in the patch's text does not compile, and memcpy / memmove /
+// memset / memcmp on klang::signal objects are deleted overloads — with or without the switch: a signal here is a value AND its place in a recording, not four bytes.
+// (`union { float f; unsigned u; }` does not compile either: the tracing type has constructors.)
+namespace klang { namespace gpu {
+template<class T> struct traced_sizeof_guard {
+	static_assert(!std::is_same<typename std::remove_cv<typename std::remove_all_extents<typename std::remove_reference<T>::type>::type>::type, ::klang::signal>::value,
+	              "klang-mi355: sizeof(float) in a patch compiled with -DKLANG_GPU_TRACE_FLOAT would be the size of the TRACING type (a value and its register), not 4: "
+	              "say sizeof(std::uint32_t) / 4 where bytes are meant, or move the byte-level code into a function compiled without the switch");
+	static constexpr std::size_t zero = 0;
+};
+} }
+void* memcpy(::klang::signal*, const void*, std::size_t) = delete;            // (a signal is a value and its place in a recording: not bytes)
+void* memcpy(void*, const ::klang::signal*, std::size_t) = delete;
+void* memcpy(::klang::signal*, const ::klang::signal*, std::size_t) = delete;
+void* memmove(::klang::signal*, const void*, std::size_t) = delete;
+void* memmove(void*, const ::klang::signal*, std::size_t) = delete;
+void* memmove(::klang::signal*, const ::klang::signal*, std::size_t) = delete;
+void* memset(::klang::signal*, int, std::size_t) = delete;
+int memcmp(const ::klang::signal*, const void*, std::size_t) = delete;
+int memcmp(const void*, const ::klang::signal*, std::size_t) = delete;
+int memcmp(const ::klang::signal*, const ::klang::signal*, std::size_t) = delete;
+namespace std { using ::memcpy; using ::memmove; using ::memset; using ::memcmp; }
 #define abs klang::abs
 #ifdef KLANG_GPU_TRACE_FLOAT
 #define float ::klang::signal
+#define sizeof(...) (sizeof(__VA_ARGS__) + ::klang::gpu::traced_sizeof_guard<__typeof__(__VA_ARGS__)>::zero)
 #endif

@@ -9,6 +9,7 @@
 #include PATCH_FILE
 #ifdef KLANG_GPU_TRACE_FLOAT
 #undef float                 // (include/klang/klang.h: the patch's own text was compiled with `float` = the tracing signal)
+#undef sizeof                // (... and with sizeof guarded against that type)
 #endif
 #ifdef FX_BIND_LINE
 FX_BIND_LINE

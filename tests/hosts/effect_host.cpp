@@ -21,6 +21,7 @@
 #include PATCH_FILE
 #ifdef KLANG_GPU_TRACE_FLOAT
 #undef float                 // (include/klang/klang.h: the patch's own text was compiled with `float` = the tracing signal)
+#undef sizeof                // (... and with sizeof guarded against that type)
 #endif
 #ifdef KLANG_MI355
 HOST_BIND_LINE

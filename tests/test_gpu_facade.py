@@ -128,6 +128,17 @@ def test_recorded_graph_single_voice_is_bit_exact(name, tmp_path):
     assert np.abs(mix).max() > 0
 
 
+def test_a_body_that_follows_host_state_stops_without_the_variants_switch(tmp_path):
+    """examples/Subtractive/Modular.k picks its filter through a host `int` that on() sets from a Menu (`switch (filter)` in process()).  Compiled WITHOUT
+    -DKLANG_GPU_NOTE_VARIANTS one body is recorded at notes.add<T>() — round 5 then played that body for every note, silently.  Now every event is followed by a
+    recording of the note's process() that is compared with the bank's program: the first note that starts after the menu moved stops the run with the switch's name."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "facade_graph_ex_modular_noswitch")
+    if not os.path.exists(exe):
+        pytest.skip("built only where the reference's .k files exist (build container); the binary travels in oracle/_ref/")
+    r = subprocess.run([exe, os.path.join(GOLDEN, "ex_modular.scn"), str(tmp_path / "none.bin")], capture_output=True, text=True)
+    assert r.returncode != 0 and "follows HOST state" in r.stderr and "KLANG_GPU_NOTE_VARIANTS" in r.stderr, (r.returncode, r.stderr[-800:])
+
+
 def test_envelope_record_capacity(tmp_path):
     """an Envelope's lane record holds KLANG_GPU_ENV_POINTS point slots (default 16).  tests/patches/env_points.k assigns seven points in on():
     compiled with 8 slots it renders the same bits from a smaller record; compiled with 6 the note-on STOPS with a message that names the macro — a record never
