@@ -278,6 +278,9 @@ struct klg_synth {
 	unsigned* d_ticket = nullptr; bool fuse_reduce = false;   // banks of <= KLG_FUSE_MAX_ROWS workgroups: the last one to finish adds the partial rows to the mix (no klg_reduce launch)
 	int mix_mode = 0; int* d_solo = nullptr;      // klg_synth_set_mix_mode: KLG_MIX_LAST_ACTIVE keeps one voice per instance (d_solo[synths])
 	bool x2 = true;               // KLG_RENDER_X1=1 in the environment selects the one-voice-per-lane kernel (A/B tests)
+	int gsp_vpw = 0;              // a graph bank that runs its sample-parallel form (klg_render_sp.hpp): voices per wave (1 / 8), else 0
+	hipFunction_t graph_sp_fn[2] = { nullptr, nullptr };   // ... its kernels [per_voice]
+	int grid_gsp = 0;
 	bool lanes = false;           // SuperSaw banks that do not fill the chip: an oscillator pair — or one oscillator — per lane (klg_render_lanes.hpp); KLG_SUPERSAW_LANES=0 / 1 / 2 forces the choice
 	bool pairs = false; int pairs_p = 1;   // ... the pair form (2) and its sample slots per voice (KLG_SUPERSAW_PAIRS_P forces 1 / 2 / 4)
 	bool sp = false;              // ... the sample-parallel form (3; the default: klg_render_supersaw_sp.hpp)
@@ -447,6 +450,10 @@ static int multi_process_host(klg_synth* r, float* per_voice, float* const* out,
 static int multi_process_device(klg_synth* r, float* d_mix, int n, void* hip_stream);
 
 enum { KLG_PATCH_GRAPH = 1000 };     // klg_synth::patch of a graph patch (not a klg_patch id)
+#ifndef KLG_GSP_MAX_VOICES
+#define KLG_GSP_VPW1_MAX_VOICES 4096   // graph banks up to this size: the sample-parallel form with a voice per wave (one wave per SIMD at 4,096 voices)
+#define KLG_GSP_MAX_VOICES 32768       // ... up to this size with eight voices per wave; larger banks: a lane (or half a lane) per voice
+#endif
 
 static klg_synth* synth_create_common(int device, int patch_id, const PatchInfo* pi, int synths, int notes_per_synth, float sample_rate, int max_block) {
 	if (synths <= 0 || notes_per_synth <= 0 || notes_per_synth > 128) { fail(KLG_ERR_INVALID, "klg_synth_create: synths=%d notes_per_synth=%d (1..128, Array<NOTE*,128>)", synths, notes_per_synth); return nullptr; }
@@ -548,11 +555,21 @@ static klg_synth* synth_create_graph_on(int device, const char* program, int syn
 	// two voices per lane (packed fp32, klg_render_x2<P>) when every node / op of the program has a packed form and the kernel
 	// keeps both voices in registers; KLG_GRAPH_X1=1 forces one voice per lane (A/B tests)
 	const char* x1env = getenv("KLG_GRAPH_X1");
-	bool x2 = graphrt::x2_eligible(g) && !(x1env && x1env[0] == '1');
+	// Small banks of a recorded patch run its SAMPLE-PARALLEL form where the body has one (klg_render_sp.hpp): a voice per wave up to KLG_GSP_VPW1_MAX_VOICES, eight
+	// voices per wave up to KLG_GSP_MAX_VOICES; beyond that a lane (or half a lane) per voice fills the chip.  KLG_GRAPH_SP = 0 / 1 / 8 forces none / a voice per wave /
+	// eight per wave at any size (the same bits every way).
+	const long long V_all = (long long)synths * notes_per_synth;
+	int sp_vpw = V_all <= KLG_GSP_VPW1_MAX_VOICES ? 1 : V_all <= KLG_GSP_MAX_VOICES ? 8 : 0;
+	if (const char* e = getenv("KLG_GRAPH_SP")) sp_vpw = e[0] == '1' ? 1 : e[0] == '8' ? 8 : e[0] == '0' ? 0 : sp_vpw;
+	const bool want_x2 = graphrt::x2_eligible(g) && !(x1env && x1env[0] == '1');
+	bool x2 = want_x2 && !sp_vpw;
 	for (;;) {
 		const std::string err = graphrt::compile(program, &c, x2);
 		if (!err.empty()) { fail(KLG_ERR_INVALID, "klg_synth_create_graph: %s", err.c_str()); return nullptr; }
-		if (!x2) break;
+		if (!x2) {
+			if (sp_vpw && !c->sp && want_x2) { sp_vpw = 0; x2 = true; continue; }   // (a body without a sample-parallel tile: the packed form after all)
+			break;
+		}
 		// worth it only for the smallest patches (tools/graph_width_bench.py, profiles/r01o_graph_width_bench.jsonl): one saw + biquad + ADSR
 		// (127-129 registers) gains 10 %, two saws (160) already lose 3 %, seven (296) lose 17 % — and a saw in its general form (duty != 0)
 		// loses 25 % even in the smallest.  Hence <= 130 registers; a patch of seven
@@ -575,6 +592,19 @@ static klg_synth* synth_create_graph_on(int device, const char* program, int syn
 	s->graph = c;
 	bool ok = hipModuleLoadData(&s->module, c->code.data()) == hipSuccess;
 	for (int i = 0; i < 2 && ok; i++) ok = hipModuleGetFunction(&s->graph_fn[i], s->module, c->name[i].c_str()) == hipSuccess;
+	if (ok && c->sp && sp_vpw) {                                       // small banks: the sample-parallel form of the recorded body (klg_render_sp.hpp)
+		bool got = true;
+		for (int i = 0; i < 2; i++) got = got && hipModuleGetFunction(&s->graph_sp_fn[i], s->module, graphrt::sp_kernel_name(i != 0, sp_vpw).c_str()) == hipSuccess;
+		if (!got) (void)hipGetLastError();
+		else {
+			hipDeviceProp_t prop; const int cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+			s->gsp_vpw = sp_vpw; s->grid_gsp = std::min((s->V + sp_vpw * WAVES - 1) / (sp_vpw * WAVES), cus * 8);
+			if (s->grid_gsp > s->grid) {                                    // (the partial rows: one per workgroup of the render launch)
+				(void)hipFree(s->d_partials); s->d_partials = nullptr;
+				ok = hipMalloc(&s->d_partials, (size_t)s->grid_gsp * max_block * 4 * s->note_ch) == hipSuccess;
+			}
+		}
+	}
 	if (!ok) { fail(KLG_ERR_HIP, "klg_synth_create_graph: loading the compiled patch failed: %s", hipGetErrorString(hipGetLastError())); synth_free(s); return nullptr; }
 	if (c->ring_rows > 0) {                                       // a delay line per voice and Delay member (zero-filled, like a fresh Delay)
 		const size_t bytes = (s->stride + 1) * (size_t)c->ring_rows * sizeof(float);      // + the scratch line dead lanes of a live wave write to (klg_render)
@@ -626,6 +656,7 @@ template<class P> static void launch_render_t(klg_synth* s, const RenderArgs& a,
 	else KLG_LAUNCH((klg_render<P, false>), dim3(s->grid), dim3(WG), render_lds_bytes(a.n), st, a);
 }
 static int render_grid(const klg_synth* s) {      // workgroups (= partial rows) of the render launch
+	if (s->gsp_vpw) return s->grid_gsp;
 	if (s->lanes) return s->grid_lanes;
 	if (s->sub_sp) return s->grid_sp;
 	if ((s->patch == KLG_PATCH_SUB2A && s->x2) || (s->graph && s->graph->x2)) return std::min((int)((s->stride + X2_VOICES_PER_WG - 1) / X2_VOICES_PER_WG), s->grid);
@@ -635,7 +666,7 @@ static void launch_render(klg_synth* s, const RenderArgs& a, bool pv, hipStream_
 	if (s->graph) {                                       // hipRTC code object: klg_render<PatchGen, pv>
 		RenderArgs args = a;
 		void* params[] = { &args };
-		s->launch_error = klg_module_launch(s->graph_fn[pv ? 1 : 0], (unsigned)render_grid(s), WG, (unsigned)render_lds_bytes(a.n, s->note_ch), st, params);
+		s->launch_error = klg_module_launch(s->gsp_vpw ? s->graph_sp_fn[pv ? 1 : 0] : s->graph_fn[pv ? 1 : 0], (unsigned)render_grid(s), WG, (unsigned)render_lds_bytes(a.n, s->note_ch), st, params);
 		return;
 	}
 	if (s->sub_sp) {                                      // sub2a, small banks: one voice per wave, samples side by side (klg_render_sub2a_sp.hpp)

@@ -532,7 +532,7 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 	begin += prologue;
 	std::string s;
 	s += "// generated by klg_graph.hpp from a recorded klang process() body (include/klang_mi355_graph.h)\n";
-	s += fx ? "#include \"klg_fx.hpp\"\n" : "#include \"klg_render_x2.hpp\"\n#include \"klg_delay.hpp\"\n";
+	s += fx ? "#include \"klg_fx.hpp\"\n" : "#include \"klg_render_x2.hpp\"\n#include \"klg_delay.hpp\"\n#include \"klg_render_sp.hpp\"\n";
 	s += "#pragma clang fp contract(off)\nnamespace klg {\n";
 	s += "struct PatchGen {\n";
 	s += "\tstruct Rec { " + TU + fmt(" w[%d]; };\n\tstatic constexpr int kWords = %d;\n", NW, NW);
@@ -623,6 +623,81 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			s += "\tstatic __device__ __forceinline__ " + RT + " sample_quiet(Live& L, const " + ctx + "& c) {\n" + (quiet ? qbody : body) + retline;
 			s += "\tstatic __device__ __forceinline__ " + RT + " sample_fast(Live& L, const " + ctx + "& c) {\n" + (quiet ? fbody : body) + retline;
 		}
+		// ---- the SAMPLE-PARALLEL tile of the same body (klg_render_sp.hpp: klg_render_gsp<PatchGen, ..>), when the program has one ----
+		// sample j of a tile of cnt <= SLOTS samples, from the state at the tile's start: oscillators closed-form, envelopes and filters walked by every lane of the voice
+		// together (each keeps its own sample's value), everything else per lane.  The SAME primitives in the same order per value as sample(): the same bits.
+		if (!x2) {
+			std::string why;
+			std::vector<int> uses(g.nodes.size(), 0);
+			for (const Op& o : g.ops) if (o.node >= 0 && (o.code == OP_OSC || o.code == OP_LPF || o.code == OP_ENV || o.code == OP_OPERATOR)) uses[(size_t)o.node]++;
+			if (st) why = "a stereo `out`";
+			else if (g.prepare_ops) why = "a prepare()";
+			for (size_t i = 0; i < g.nodes.size() && why.empty(); i++) {
+				const int k = g.nodes[i];
+				if (!(k == N_FSINE || k == N_SAW || k == N_PULSE || k == N_ENV || k == N_ADSR || k == N_PARAM || k == N_OPERATOR || is_modifier(k))) why = std::string("a ") + node_name(k) + " node";
+				else if (uses[i] > 1) why = std::string("a ") + node_name(k) + " node processed twice per sample";
+				else if (k == N_PARAM && written[i]) why = "a member written by process()";
+			}
+			for (const Op& o : g.ops) if (why.empty()) switch (o.code) {
+				case OP_CONST: case OP_CTL: case OP_PARAM: case OP_OSC: case OP_LPF: case OP_ENV: case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_NEG: case OP_ABS: case OP_TRUNC: case OP_POWC:
+				case OP_STOPIF: case OP_FREQ: case OP_OPERATOR: case OP_CMP: break;
+				default: why = std::string("op ") + op_name(o.code);
+			}
+			if (const char* e = getenv("KLG_GRAPH_SP")) if (e[0] == '0') why = "KLG_GRAPH_SP=0";
+			if (!why.empty()) s += "\t// no sample-parallel tile (klg_render_sp.hpp): " + why + "\n";
+			else {
+				std::string t = "\tstatic constexpr bool kHasSp = true;\n\tstatic __device__ __forceinline__ float sp_tile(Live& L, const BlockCtx& c, const int j, const int cnt, float* X) {\n\t\t(void)c; (void)X;\n";
+				// 1. the envelopes of the tile (they have no inputs): every lane of the voice steps them through the tile's samples, 32 at a time (what env_safe looks ahead)
+				auto env_walk = [&](size_t i, const std::string& ev, const std::string& settled, const std::string& full) {
+					const std::string n = fmt("L.n%zu", i);
+					t += fmt("\t\tfloat e%zu = 0.f;\n", i);
+					t += "\t\tfor (int h = 0; h < cnt; h += KLG_CHUNK_MAX) {\n\t\t\tconst int hl = (cnt - h < KLG_CHUNK_MAX) ? (cnt - h) : KLG_CHUNK_MAX;\n\t\t\tfloat st_ = 0.f, ts_ = 0.f;\n";
+					t += "\t\t\tif (L.stage == (int)ST_OFF || env_safe(" + ev + ", " + settled + ", st_, ts_, L.tinc)) { for (int i = 0; i < hl; i++) { const float v = env_glide(" + ev + fmt(", st_, ts_); e%zu = (h + i == j) ? v : e%zu; } }\n", i, i);
+					t += "\t\t\telse { for (int i = 0; i < hl; i++) { const float v = " + full + fmt("; e%zu = (h + i == j) ? v : e%zu; } }\n\t\t}\n", i, i);
+				};
+				for (size_t i = 0; i < g.nodes.size(); i++) {
+					const std::string n = fmt("L.n%zu", i);
+					if (!uses[i]) continue;
+					if (g.nodes[i] == N_ADSR) env_walk(i, n + ".e", n + ".e.point == 2", "adsr_process(" + n + ", c.fs)");
+					else if (g.nodes[i] == N_ENV) env_walk(i, n, "env_settled(" + n + ", " + n + "ls, " + n + "le, " + n + "hy)", "env_process_rt(" + n + ", " + n + "p, " + n + "np, " + n + "ls, " + n + "le, " + n + "hy, c.fs)");
+					else if (g.nodes[i] == N_OPERATOR) env_walk(i, n + "e", "env_settled(" + n + "e, " + n + "ls, " + n + "le, " + n + "hy)", "env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, " + n + "hy, c.fs)");
+				}
+				// 2. the ops in program order, a lane per sample; a filter's recurrence over the tile's inputs (through the wave's LDS)
+				std::string adv;                                              // the closed-form nodes moved on by cnt samples, behind the tile
+				for (size_t oi = 0; oi < g.ops.size(); oi++) {
+					const Op& o = g.ops[oi];
+					const int k = o.node >= 0 ? g.nodes[(size_t)o.node] : -1;
+					const std::string n = fmt("L.n%d", o.node), d = fmt("\t\tconst float r%d = ", o.dst), a = fmt("r%d", o.a), b = fmt("r%d", o.b);
+					switch (o.code) {
+					case OP_STOPIF: break;                                       // (in end(): the envelope's stage after the block)
+					case OP_ENV: t += d + fmt("e%d;\n", o.node); break;
+					case OP_OSC:
+						if (k == N_FSINE) { t += fmt("\t\tFSine t%zu = ", oi) + n + fmt("; t%zu.pos += (uint32_t)t%zu.inc * (uint32_t)j;\n", oi, oi) + d + fmt("fsine_process(t%zu, 0u);\n", oi); adv += "\t\t" + n + ".pos += (uint32_t)" + n + ".inc * (uint32_t)cnt;\n"; }
+						else {
+							t += fmt("\t\tOsm t%zu = ", oi) + n + fmt("; osm_jump(t%zu, j);\n", oi);
+							t += d + (k == N_PULSE ? fmt("osm_pulse(t%zu)", oi) : (retuned[(size_t)o.node] ? fmt("osm_saw(t%zu)", oi) : "(" + n + fmt("d0 ? osm_saw_duty0(t%zu) : osm_saw(t%zu))", oi, oi))) + ";\n";
+							adv += "\t\tosm_advance(" + n + ", cnt);\n";
+						}
+						break;
+					case OP_OPERATOR:
+						if (o.b >= 0) t += "\t\t" + n + "a = " + b + ";\n";
+						t += fmt("\t\tFSine t%zu = ", oi) + n + fmt("; t%zu.pos += (uint32_t)t%zu.inc * (uint32_t)j;\n", oi, oi);
+						t += d + (o.a >= 0 ? fmt("fsine_process_rel(t%zu, ", oi) + a + ")" : fmt("fsine_process(t%zu, 0u)", oi)) + fmt(" * (e%d * ", o.node) + n + "a);\n";
+						adv += "\t\t" + n + ".pos += (uint32_t)" + n + ".inc * (uint32_t)cnt;\n";
+						break;
+					case OP_LPF: {
+						const char* fn = k == N_LPF ? "biquad_process" : k == N_OPLPF ? "onepole_lpf_process" : k == N_OPHPF ? "onepole_process" : k == N_DCF ? "dcf_process" : k == N_IIR1 ? "iir1_process" : k == N_IIRN ? "iir_process"
+							: k == N_BUTTER1 ? "butter1_process" : k == N_MODAL ? "modal_process" : k == N_FOLLOWPEAK ? "follower_peak" : "follower_rms";
+						t += "\t\tX[j] = " + a + ";\n\t\twave_sync();\n" + fmt("\t\tfloat r%d = 0.f;\n", o.dst);
+						t += std::string("\t\tfor (int i = 0; i < cnt; i++) { const float v = ") + fn + "(" + n + fmt(", X[i]); r%d = (i == j) ? v : r%d; }\n\t\twave_sync();\n", o.dst, o.dst);
+					} break;
+					default: emit_op(oi, t, false); break;                       // arithmetic, literals, controls, members, `osc.frequency`: per lane, as in sample()
+					}
+				}
+				t += adv + fmt("\t\treturn r%d;\n\t}\n", g.ret);
+				s += t;
+			}
+		}
 		std::string stage_expr = "L.stage";
 		for (const std::string& t : stop_at_end) stage_expr = t + stage_expr + ")";
 		s += "\tstatic __device__ __forceinline__ void end(const Live& L, Rec& r) {\n\t\tr.w[0] = to_u(" + stage_expr + ");\n" + end + "\t}\n";
@@ -672,8 +747,11 @@ struct Rtc {
 struct Compiled { std::vector<char> code; std::string name[2]; std::string source; int words = 0; int channels = 0; int note_channels = 1;   // note_channels: 2 = the notes' `out` is stereo (ret2 in a note program)
 	 long long ring_rows = 0; int noise_calls = 0; struct Smooth { int word, ctl, calls; }; std::vector<Smooth> smooths; int ctlvar_word[KLG_MAX_CTL] = { -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1 };   // ctlvar_word[i]: the record word of control i's own copy (an effect that writes it), else -1
 	 bool x2 = false; std::vector<std::pair<long long, int>> delays;
+	 bool sp = false;                                                    // the code object also holds klg_render_gsp<PatchGen, pv, 1 | 8> (klg_render_sp.hpp): sp_kernel_name()
 	 bool staged = false; std::string staged_why; int staged_G = 0, staged_C = 0, staged_threads = 0, staged_lds = 0, staged_levels = 0, staged_slots = 0; };   // staged: the code object also holds klg_fx_staged (klg_graph_staged.hpp)   // delays: (first ring row, SIZE) of each delay node in node order   // name[pv] (effects: name[0] only); x2: two voices per lane (klg_render_x2<P>)
 
+// the sample-parallel note kernels of a code object, by their (Itanium-mangled) names: klg::klg_render_gsp<klg::PatchGen, PER_VOICE, VPW>(klg::RenderArgs)
+inline std::string sp_kernel_name(bool per_voice, int vpw) { char b[96]; snprintf(b, sizeof b, "_ZN3klg14klg_render_gspINS_8PatchGenELb%dELi%dEEEvNS_10RenderArgsE", per_voice ? 1 : 0, vpw); return b; }
 // directory holding klg_kernels.hpp etc.: next to the shared library (klang_amd/csrc), or $KLG_GRAPH_SRC
 inline std::string source_dir() {
 	if (const char* e = getenv("KLG_GRAPH_SRC")) return e;
@@ -762,7 +840,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	if (!perr.empty()) return perr;
 	if (x2 && !x2_eligible(g)) return "graph program: not every node / op has a two-voices-per-lane form";
 	auto envs = [](const char* n) { const char* e = getenv(n); return std::string(e ? e : ""); };
-	const std::string key = (x2 ? "x2\n" : "") + (g.channels ? "staged G" + std::to_string(staged_G) + " " + envs("KLG_FX_STAGED") + "," + envs("KLG_FX_STAGED_G") + "," + envs("KLG_FX_STAGED_C") + "," + envs("KLG_FX_STAGED_LDS") + "," + envs("KLG_FX_STAGED_SKIP") + "," + envs("KLG_FX_STAGED_STAMP") + "," + envs("KLG_FX_STAGED_PIPE") + "," + envs("KLG_FX_STAGED_BATCH") + "," + envs("KLG_FX_STAGED_NEAR") + "," + envs("KLG_FX_STAGED_PACK") + "," + envs("KLG_FX_STAGED_TILES") + "," + envs("KLG_FX_STAGED_RETRY") + "\n" : std::string()) + g.text();
+	const std::string key = (x2 ? "x2\n" : "") + std::string(envs("KLG_GRAPH_SP") == "0" ? "nosp\n" : "") + (g.channels ? "staged G" + std::to_string(staged_G) + " " + envs("KLG_FX_STAGED") + "," + envs("KLG_FX_STAGED_G") + "," + envs("KLG_FX_STAGED_C") + "," + envs("KLG_FX_STAGED_LDS") + "," + envs("KLG_FX_STAGED_SKIP") + "," + envs("KLG_FX_STAGED_STAMP") + "," + envs("KLG_FX_STAGED_PIPE") + "," + envs("KLG_FX_STAGED_BATCH") + "," + envs("KLG_FX_STAGED_NEAR") + "," + envs("KLG_FX_STAGED_PACK") + "," + envs("KLG_FX_STAGED_TILES") + "," + envs("KLG_FX_STAGED_RETRY") + "\n" : std::string()) + g.text();
 	auto it = cache.find(key);
 	if (it != cache.end()) { *out = &it->second; return ""; }
 	if (!rtc.load()) return rtc.error;
@@ -771,6 +849,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	c.source = generate_source(g, x2, g.channels ? &plan : nullptr, staged_G);
 	c.staged = plan.ok; c.staged_why = plan.why; c.staged_G = plan.G; c.staged_C = plan.C; c.staged_threads = plan.threads; c.staged_lds = plan.lds_bytes; c.staged_levels = plan.levels; c.staged_slots = plan.slots;
 	c.words = g.words(); c.channels = g.channels; c.x2 = x2; c.note_channels = g.stereo_note() ? 2 : 1;
+	c.sp = !g.channels && !x2 && c.source.find("kHasSp") != std::string::npos;
 	for (size_t i = 0; i < g.nodes.size(); i++) if (g.nodes[i] == graph::N_DELAY || g.nodes[i] == graph::N_NDELAY) { c.delays.push_back({ c.ring_rows, g.arg((int)i) }); c.ring_rows += g.arg((int)i) + 1; }   // (+ the pad element of every line: klg_delay.hpp)
 	c.noise_calls = g.noise_calls();
 	for (const graph::Op& o : g.ops) if (o.code == graph::OP_SETCTL) c.ctlvar_word[o.imm & 0xFFu] = g.node_word0(o.node);
@@ -793,6 +872,7 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	if (g.channels) expr[0] = expr[1] = "klg::klg_fx_graph<klg::PatchGen>";
 	if (x2) { expr[0] = "klg::klg_render_x2<klg::PatchGen, false>"; expr[1] = "klg::klg_render_x2<klg::PatchGen, true>"; }
 	rtc.AddNameExpression(prog, expr[0]); if (!g.channels) rtc.AddNameExpression(prog, expr[1]);
+	if (c.sp) for (const char* e : { "klg::klg_render_gsp<klg::PatchGen, false, 1>", "klg::klg_render_gsp<klg::PatchGen, true, 1>", "klg::klg_render_gsp<klg::PatchGen, false, 8>", "klg::klg_render_gsp<klg::PatchGen, true, 8>" }) rtc.AddNameExpression(prog, e);
 	const std::string inc = "-I" + source_dir();
 	const char* extra = getenv("KLG_RTC_EXTRA");                             // (measurement: one more compiler option for the generated kernels)
 	const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str(), extra };

@@ -31,18 +31,20 @@ def sub2a_to_graph(r):
     return g
 
 
-@pytest.mark.parametrize("lanes", ["two voices per lane", "one voice per lane"])
+@pytest.mark.parametrize("lanes", ["two voices per lane", "one voice per lane", "a voice per wave", "eight voices per wave"])
 def test_graph_sub2a_equals_handwritten_kernel(lanes, monkeypatch):
     """The generated patch runs two voices per lane (packed primitives, klg_render_x2<P>) when every node has a packed form —
-    this program does — and one per lane with KLG_GRAPH_X1=1: both must equal the hand-written kernel bit for bit."""
+    this program does — and one per lane with KLG_GRAPH_X1=1; a bank as small as this one takes the sample-parallel form by default
+    (klg_render_gsp<PatchGen>, klg_render_sp.hpp; KLG_GRAPH_SP = 0 / 1 / 8).  All must equal the hand-written kernel bit for bit."""
     import klang_amd
+    monkeypatch.setenv("KLG_GRAPH_SP", {"a voice per wave": "1", "eight voices per wave": "8"}.get(lanes, "0"))
     if lanes == "one voice per lane":
         monkeypatch.setenv("KLG_GRAPH_X1", "1")
     S, P, N = 3, 32, 192
     hand = klang_amd.SynthBank("sub2a", synths=S, notes=P, max_block=N)
     gen = klang_amd.SynthBank(SUB2A_PROGRAM, synths=S, notes=P, max_block=N)
     assert gen.state_bytes == 25 * 4 and gen.voices == hand.voices
-    assert gen.voices_per_lane == (1 if lanes == "one voice per lane" else 2) and hand.voices_per_lane == 2
+    assert gen.voices_per_lane == (2 if lanes == "two voices per lane" else 1) and hand.voices_per_lane == 2
     rng = np.random.default_rng(4)
     held = []
     def mirror(voices):
@@ -171,6 +173,7 @@ def test_graph_two_voices_per_lane_reads_each_voices_own_controls(monkeypatch):
     import klang_amd
     S, P, N = 5, 3, 96
     rng = np.random.default_rng(21)
+    monkeypatch.setenv("KLG_GRAPH_SP", "0")                           # (a bank this small would take the sample-parallel form: this test is about the packed one)
     def make(env):
         if env:
             monkeypatch.setenv("KLG_GRAPH_X1", "1")
