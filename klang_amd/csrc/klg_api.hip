@@ -451,8 +451,9 @@ static int multi_process_device(klg_synth* r, float* d_mix, int n, void* hip_str
 
 enum { KLG_PATCH_GRAPH = 1000 };     // klg_synth::patch of a graph patch (not a klg_patch id)
 #ifndef KLG_GSP_MAX_VOICES
-#define KLG_GSP_VPW1_MAX_VOICES 4096   // graph banks up to this size: the sample-parallel form with a voice per wave (one wave per SIMD at 4,096 voices)
-#define KLG_GSP_MAX_VOICES 32768       // ... up to this size with eight voices per wave; larger banks: a lane (or half a lane) per voice
+#define KLG_GSP_VPW1_MAX_VOICES 2048   // graph banks up to this size: the sample-parallel form with a voice per wave (two waves per SIMD at 2,048 voices)
+#define KLG_GSP_VPW4_MAX_VOICES 8192   // ... up to this size with four voices per wave
+#define KLG_GSP_MAX_VOICES 32768       // ... up to this size with eight voices per wave (bodies of four oscillators and more); larger banks: a lane (or half a lane) per voice
 #endif
 
 static klg_synth* synth_create_common(int device, int patch_id, const PatchInfo* pi, int synths, int notes_per_synth, float sample_rate, int max_block) {
@@ -555,12 +556,15 @@ static klg_synth* synth_create_graph_on(int device, const char* program, int syn
 	// two voices per lane (packed fp32, klg_render_x2<P>) when every node / op of the program has a packed form and the kernel
 	// keeps both voices in registers; KLG_GRAPH_X1=1 forces one voice per lane (A/B tests)
 	const char* x1env = getenv("KLG_GRAPH_X1");
-	// Small banks of a recorded patch run its SAMPLE-PARALLEL form where the body has one (klg_render_sp.hpp): a voice per wave up to KLG_GSP_VPW1_MAX_VOICES, eight
-	// voices per wave up to KLG_GSP_MAX_VOICES; beyond that a lane (or half a lane) per voice fills the chip.  KLG_GRAPH_SP = 0 / 1 / 8 forces none / a voice per wave /
-	// eight per wave at any size (the same bits every way).
+	// Small banks of a recorded patch run its SAMPLE-PARALLEL form where the body has one (klg_render_sp.hpp): a voice per wave up to KLG_GSP_VPW1_MAX_VOICES, four
+	// per wave up to KLG_GSP_VPW4_MAX_VOICES, eight up to KLG_GSP_MAX_VOICES; beyond that a lane (or half a lane) per voice fills the chip.  KLG_GRAPH_SP = 0 / 1 / 4 / 8
+	// forces none / a voice per wave / four / eight per wave at any size (the same bits every way).
 	const long long V_all = (long long)synths * notes_per_synth;
-	int sp_vpw = V_all <= KLG_GSP_VPW1_MAX_VOICES ? 1 : V_all <= KLG_GSP_MAX_VOICES ? 8 : 0;
-	if (const char* e = getenv("KLG_GRAPH_SP")) sp_vpw = e[0] == '1' ? 1 : e[0] == '8' ? 8 : e[0] == '0' ? 0 : sp_vpw;
+	// (measured, tools/recorded_small_banks.py -> profiles/r06/recorded_small_banks.jsonl: the form that wins follows the waves it makes — up to ~2 per SIMD.  Eight voices
+	//  per wave only pay for bodies whose voice-per-lane kernel is slow: several general oscillators per voice — the recorded SuperSaw.k at 16,384 voices 71 us against 242)
+	int n_osc = 0; for (const graph::Op& o : g.ops) if (o.code == graph::OP_OSC) n_osc++;
+	int sp_vpw = V_all <= KLG_GSP_VPW1_MAX_VOICES ? 1 : V_all <= KLG_GSP_VPW4_MAX_VOICES ? 4 : (V_all <= KLG_GSP_MAX_VOICES && n_osc >= 4) ? 8 : 0;
+	if (const char* e = getenv("KLG_GRAPH_SP")) sp_vpw = e[0] == '1' ? 1 : e[0] == '4' ? 4 : e[0] == '8' ? 8 : e[0] == '0' ? 0 : sp_vpw;
 	const bool want_x2 = graphrt::x2_eligible(g) && !(x1env && x1env[0] == '1');
 	bool x2 = want_x2 && !sp_vpw;
 	for (;;) {

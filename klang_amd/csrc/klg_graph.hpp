@@ -646,23 +646,48 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 			if (const char* e = getenv("KLG_GRAPH_SP")) if (e[0] == '0') why = "KLG_GRAPH_SP=0";
 			if (!why.empty()) s += "\t// no sample-parallel tile (klg_render_sp.hpp): " + why + "\n";
 			else {
-				std::string t = "\tstatic constexpr bool kHasSp = true;\n\tstatic __device__ __forceinline__ float sp_tile(Live& L, const BlockCtx& c, const int j, const int cnt, float* X) {\n\t\t(void)c; (void)X;\n";
-				// 1. the envelopes of the tile (they have no inputs): every lane of the voice steps them through the tile's samples, 32 at a time (what env_safe looks ahead)
-				auto env_walk = [&](size_t i, const std::string& ev, const std::string& settled, const std::string& full) {
-					const std::string n = fmt("L.n%zu", i);
-					t += fmt("\t\tfloat e%zu = 0.f;\n", i);
-					t += "\t\tfor (int h = 0; h < cnt; h += KLG_CHUNK_MAX) {\n\t\t\tconst int hl = (cnt - h < KLG_CHUNK_MAX) ? (cnt - h) : KLG_CHUNK_MAX;\n\t\t\tfloat st_ = 0.f, ts_ = 0.f;\n";
-					t += "\t\t\tif (L.stage == (int)ST_OFF || env_safe(" + ev + ", " + settled + ", st_, ts_, L.tinc)) { for (int i = 0; i < hl; i++) { const float v = env_glide(" + ev + fmt(", st_, ts_); e%zu = (h + i == j) ? v : e%zu; } }\n", i, i);
-					t += "\t\t\telse { for (int i = 0; i < hl; i++) { const float v = " + full + fmt("; e%zu = (h + i == j) ? v : e%zu; } }\n\t\t}\n", i, i);
-				};
+				// the envelope-like nodes of the body, in node order: what is a chain through the samples and has no input
+				struct EnvNode { size_t i; std::string ev, settled, full; };
+				std::vector<EnvNode> envs;
 				for (size_t i = 0; i < g.nodes.size(); i++) {
 					const std::string n = fmt("L.n%zu", i);
 					if (!uses[i]) continue;
-					if (g.nodes[i] == N_ADSR) env_walk(i, n + ".e", n + ".e.point == 2", "adsr_process(" + n + ", c.fs)");
-					else if (g.nodes[i] == N_ENV) env_walk(i, n, "env_settled(" + n + ", " + n + "ls, " + n + "le, " + n + "hy)", "env_process_rt(" + n + ", " + n + "p, " + n + "np, " + n + "ls, " + n + "le, " + n + "hy, c.fs)");
-					else if (g.nodes[i] == N_OPERATOR) env_walk(i, n + "e", "env_settled(" + n + "e, " + n + "ls, " + n + "le, " + n + "hy)", "env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, " + n + "hy, c.fs)");
+					if (g.nodes[i] == N_ADSR) envs.push_back({ i, n + ".e", n + ".e.point == 2", "adsr_process(" + n + ", c.fs)" });
+					else if (g.nodes[i] == N_ENV) envs.push_back({ i, n, "env_settled(" + n + ", " + n + "ls, " + n + "le, " + n + "hy)", "env_process_rt(" + n + ", " + n + "p, " + n + "np, " + n + "ls, " + n + "le, " + n + "hy, c.fs)" });
+					else if (g.nodes[i] == N_OPERATOR) envs.push_back({ i, n + "e", "env_settled(" + n + "e, " + n + "ls, " + n + "le, " + n + "hy)", "env_process_rt(" + n + "e, " + n + "p, " + n + "np, " + n + "ls, " + n + "le, " + n + "hy, c.fs)" });
 				}
-				// 2. the ops in program order, a lane per sample; a filter's recurrence over the tile's inputs (through the wave's LDS)
+				const int K = (int)envs.size();
+				std::string t = fmt("\tstatic constexpr bool kHasSp = true;\n\tstatic constexpr int kSpEnvs = %d;\n", K);
+				t += "\ttemplate<int SLOTS> static __device__ __forceinline__ float sp_tile(Live& L, const BlockCtx& c, const int j, const int cnt, float* X, float* E) {\n\t\t(void)c; (void)X; (void)E;\n";
+				// 1. the envelopes of the tile, 32 samples at a time (what env_safe looks ahead).  While no envelope of any voice of the wave has an event inside those
+				//    samples, an envelope is `value += step` per sample — and the K envelopes of a voice are K LANES of it: lane k walks envelope k through the samples,
+				//    leaves the values in the wave's LDS (E[k][sample]) and the state it arrives at behind them; every lane then takes the K values of ITS sample.  (One walk
+				//    for all of a voice's envelopes instead of one per envelope repeated in every lane.)  With fewer lanes per voice than envelopes, or an event in reach:
+				//    every lane walks every envelope itself through env_glide / the full Envelope::process.
+				for (int k = 0; k < K; k++) t += fmt("\t\tfloat e%zu = 0.f;\n", envs[(size_t)k].i);
+				if (K) {
+					t += "\t\tfor (int h = 0; h < cnt; h += KLG_CHUNK_MAX) {\n\t\t\tconst int hl = (cnt - h < KLG_CHUNK_MAX) ? (cnt - h) : KLG_CHUNK_MAX;\n";
+					t += "\t\t\tbool safe = true;\n";
+					for (int k = 0; k < K; k++) t += fmt("\t\t\tfloat st%d = 0.f, ts%d = 0.f; safe = env_safe(", k, k) + envs[(size_t)k].ev + ", " + envs[(size_t)k].settled + fmt(", st%d, ts%d, L.tinc) && safe;\n", k, k);
+					t += "\t\t\tsafe = safe || L.stage == (int)ST_OFF;\n";
+					t += fmt("\t\t\tif (SLOTS >= %d && __ballot(!safe) == 0ull) {\n", 2 * K);       // (a lane per envelope, and two words per envelope for where it ends)
+					t += "\t\t\t\tfloat r = 0.f, sr = 0.f, tm = 0.f, stm = 0.f;\n";
+					for (int k = 0; k < K; k++) t += fmt("\t\t\t\tif (j == %d) { r = ", k) + envs[(size_t)k].ev + fmt(".r_out; sr = st%d; tm = ", k) + envs[(size_t)k].ev + fmt(".time; stm = ts%d; }\n", k);
+					t += fmt("\t\t\t\tif (j < %d) {\n\t\t\t\t\tfloat* row = E + j * SLOTS + h;\n", K);
+					t += "\t\t\t\t\tfor (int i = 0; i < hl; i++) { row[i] = r; r += sr; tm += stm; }\n";
+					t += fmt("\t\t\t\t\tE[%d * SLOTS + 2 * j] = r; E[%d * SLOTS + 2 * j + 1] = tm;\n\t\t\t\t}\n\t\t\t\twave_sync();\n", K, K);
+					for (int k = 0; k < K; k++) {
+						t += fmt("\t\t\t\te%zu = (j >= h && j < h + hl) ? E[%d * SLOTS + j] : e%zu; ", envs[(size_t)k].i, k, envs[(size_t)k].i) + envs[(size_t)k].ev + fmt(".r_out = E[%d * SLOTS + %d]; ", K, 2 * k) + envs[(size_t)k].ev + fmt(".time = E[%d * SLOTS + %d];\n", K, 2 * k + 1);
+					}
+					t += "\t\t\t\twave_sync();\n\t\t\t}\n\t\t\telse {\n";
+					for (int k = 0; k < K; k++) {
+						const EnvNode& e = envs[(size_t)k];
+						t += fmt("\t\t\t\tif (safe) { for (int i = 0; i < hl; i++) { const float v = env_glide(", 0) + e.ev + fmt(", st%d, ts%d); e%zu = (h + i == j) ? v : e%zu; } }\n", k, k, e.i, e.i);
+						t += "\t\t\t\telse { for (int i = 0; i < hl; i++) { const float v = " + e.full + fmt("; e%zu = (h + i == j) ? v : e%zu; } }\n", e.i, e.i);
+					}
+					t += "\t\t\t}\n\t\t}\n";
+				}
+				// 2. the ops in program order, a lane per sample; a filter's recurrence over the tile's inputs (through the wave's LDS: four at a time in a full tile)
 				std::string adv;                                              // the closed-form nodes moved on by cnt samples, behind the tile
 				for (size_t oi = 0; oi < g.ops.size(); oi++) {
 					const Op& o = g.ops[oi];
@@ -689,7 +714,9 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 						const char* fn = k == N_LPF ? "biquad_process" : k == N_OPLPF ? "onepole_lpf_process" : k == N_OPHPF ? "onepole_process" : k == N_DCF ? "dcf_process" : k == N_IIR1 ? "iir1_process" : k == N_IIRN ? "iir_process"
 							: k == N_BUTTER1 ? "butter1_process" : k == N_MODAL ? "modal_process" : k == N_FOLLOWPEAK ? "follower_peak" : "follower_rms";
 						t += "\t\tX[j] = " + a + ";\n\t\twave_sync();\n" + fmt("\t\tfloat r%d = 0.f;\n", o.dst);
-						t += std::string("\t\tfor (int i = 0; i < cnt; i++) { const float v = ") + fn + "(" + n + fmt(", X[i]); r%d = (i == j) ? v : r%d; }\n\t\twave_sync();\n", o.dst, o.dst);
+						t += "\t\tif (SLOTS >= 4 && cnt == SLOTS) {\n\t\t\ttypedef float f4_ __attribute__((ext_vector_type(4)));\n#pragma unroll\n\t\t\tfor (int i0 = 0; i0 < SLOTS; i0 += 4) {\n\t\t\t\tconst f4_ x4 = *reinterpret_cast<const f4_*>(X + i0);\n";
+						t += std::string("#pragma unroll\n\t\t\t\tfor (int q = 0; q < 4; q++) { const float v = ") + fn + "(" + n + fmt(", x4[q]); r%d = (i0 + q == j) ? v : r%d; }\n\t\t\t}\n\t\t}\n", o.dst, o.dst);
+						t += std::string("\t\telse for (int i = 0; i < cnt; i++) { const float v = ") + fn + "(" + n + fmt(", X[i]); r%d = (i == j) ? v : r%d; }\n\t\twave_sync();\n", o.dst, o.dst);
 					} break;
 					default: emit_op(oi, t, false); break;                       // arithmetic, literals, controls, members, `osc.frequency`: per lane, as in sample()
 					}
@@ -872,7 +899,8 @@ inline std::string compile(const char* text, const Compiled** out, bool x2 = fal
 	if (g.channels) expr[0] = expr[1] = "klg::klg_fx_graph<klg::PatchGen>";
 	if (x2) { expr[0] = "klg::klg_render_x2<klg::PatchGen, false>"; expr[1] = "klg::klg_render_x2<klg::PatchGen, true>"; }
 	rtc.AddNameExpression(prog, expr[0]); if (!g.channels) rtc.AddNameExpression(prog, expr[1]);
-	if (c.sp) for (const char* e : { "klg::klg_render_gsp<klg::PatchGen, false, 1>", "klg::klg_render_gsp<klg::PatchGen, true, 1>", "klg::klg_render_gsp<klg::PatchGen, false, 8>", "klg::klg_render_gsp<klg::PatchGen, true, 8>" }) rtc.AddNameExpression(prog, e);
+	if (c.sp) for (const char* e : { "klg::klg_render_gsp<klg::PatchGen, false, 1>", "klg::klg_render_gsp<klg::PatchGen, true, 1>", "klg::klg_render_gsp<klg::PatchGen, false, 4>", "klg::klg_render_gsp<klg::PatchGen, true, 4>",
+	                                "klg::klg_render_gsp<klg::PatchGen, false, 8>", "klg::klg_render_gsp<klg::PatchGen, true, 8>" }) rtc.AddNameExpression(prog, e);
 	const std::string inc = "-I" + source_dir();
 	const char* extra = getenv("KLG_RTC_EXTRA");                             // (measurement: one more compiler option for the generated kernels)
 	const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str(), extra };

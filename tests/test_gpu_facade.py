@@ -128,13 +128,13 @@ def test_recorded_graph_single_voice_is_bit_exact(name, tmp_path):
     assert np.abs(mix).max() > 0
 
 
-@pytest.mark.parametrize("sp", ["0", "1", "8"])
+@pytest.mark.parametrize("sp", ["0", "1", "4", "8"])
 @pytest.mark.parametrize("binary,scenario", [("facade_graph_sub2a_n4", "sub2a_steal"), ("facade_graph_sub2a_n16", "sub2a_long"), ("facade_graph_fm", "fm3_poly"), ("facade_graph_fm", "fm3_ctl"),
                                              ("facade_graph_supersaw", "supersaw_poly"), ("facade_graph_supersaw", "supersaw_ctl"), ("facade_graph_ex_operators", "ex_operators"),
                                              ("facade_graph_ex_breakpoint", "ex_breakpoint"), ("facade_graph_ex_release", "ex_release"), ("facade_graph_own_two_types", "own_two_types")])
 def test_recorded_notes_in_their_sample_parallel_form(binary, scenario, sp, tmp_path, monkeypatch):
     """SURVEY row f1, rank 1 (round 6): small banks of a recorded patch run klg_render_gsp<PatchGen> (klang_amd/csrc/klg_render_sp.hpp) — a tile's samples side by side,
-    oscillators closed-form, envelopes and filters walked by the voice's lanes together.  KLG_GRAPH_SP = 0 / 1 / 8: the voice-per-lane kernel, a voice per wave, eight voices
+    oscillators closed-form, envelopes and filters walked by the voice's lanes together.  KLG_GRAPH_SP = 0 / 1 / 4 / 8: the voice-per-lane kernel, a voice per wave, four / eight voices
     per wave — the same goldens of the genuine header every way (stages equal, mix within the summation bound; the `_solo` fixtures below are bit for bit)."""
     monkeypatch.setenv("KLG_GRAPH_SP", sp)
     d = os.path.join(ROOT, "tests", "cpp", "_bin") if os.path.exists(os.path.join(ROOT, "tests", "cpp", "_bin", binary)) else os.path.join(ROOT, "oracle", "_ref")
