@@ -258,7 +258,9 @@ int klg_fx_graph_form(const klg_fx* f, int* instances_per_workgroup, int* sample
 int klg_timing_begin(klg_synth* s);
 int klg_timing_end(klg_synth* s, int* launches, float* total_ms);
 /* ... and, while timing is armed, the same for a block's OTHER kernels — the event kernel and the voice-mix reduce (none for small banks, whose render launch
- * does both): launches and summed duration since klg_timing_begin.  Call it before klg_timing_end.  (What lets bench.py check that the kernels of a step fit the step.) */
+ * does both): launches and summed duration since klg_timing_begin.  Call it before klg_timing_end.  (What lets bench.py check that the kernels of a step fit the step.)
+ * Banks with Noise generators: the figure covers the rank pass's first launch and a Note's smooth() pass, NOT the draw kernels (klg_rand_fill / klg_rand_advance)
+ * nor the later launches of a multi-group rank pass — for those take the stream's own time around the block. */
 int klg_timing_end_aux(klg_synth* s, int* launches, float* total_ms);
 /* What a multi-device bank (klg_init with several ids; the voice sum of Stereo::Synth::process, klang.h:4830-4858, taken across GPUs) really runs through —
  * so that a scaling measurement proves itself instead of being believed (bench.py --in-library):

@@ -315,7 +315,7 @@ struct Program {
 			bool need_a = false, need_b = false, has_dst = true, dst_dbl = false; int k = kind(o.node);
 			switch (o.code) {
 			case OP_CONST: break;
-			case OP_CTL: if ((int)o.imm >= nctl) return bad("control index out of range"); break;
+			case OP_CTL: if (o.imm >= (uint32_t)nctl) return bad("control index out of range"); break;
 			case OP_PARAM: if (k != N_PARAM) return bad("node is not a param"); break;
 			case OP_OSC: if (!is_oscillator(k)) return bad("node is not an oscillator"); break;
 			case OP_OSCSET: if (!is_oscillator(k)) return bad("node is not an oscillator"); if (o.imm > 3u || (o.imm && k == N_WAVETABLE) || (o.imm == 2u && (k == N_SAW || k == N_PULSE)) || (o.imm == 3u && !(k == N_SAW || k == N_PULSE || k == N_BPULSE))) return bad("this oscillator has no such set() / reset() on the device"); need_a = o.imm != 2u; need_b = o.imm == 1u; has_dst = false; break;
@@ -333,7 +333,7 @@ struct Program {
 			case OP_DELAYTAP: if (k != N_DELAY && k != N_NDELAY) return bad("node is not a delay"); if (o.imm > 3u || (o.imm == 3u && k != N_DELAY)) return bad("unknown tap kind"); need_a = true; break;
 			case OP_DELAYOUT: if (k != N_NDELAY && k != N_DELAY) return bad("node is not a delay"); break;
 			case OP_DELAYSET: if (k != N_NDELAY && k != N_DELAY) return bad("node is not a delay"); need_a = true; has_dst = false; break;
-			case OP_SMOOTH: if (k != N_SMOOTH || (int)o.imm >= nctl) return bad("node is not a smoothed control"); if (!channels && !open.empty()) return bad("a Note's controls[i].smooth() may not sit inside an `if`: the bank advances the Synth's control by a fixed number of steps per sounding note and sample"); break;
+			case OP_SMOOTH: if (k != N_SMOOTH || o.imm >= (uint32_t)nctl) return bad("node is not a smoothed control"); if (!channels && !open.empty()) return bad("a Note's controls[i].smooth() may not sit inside an `if`: the bank advances the Synth's control by a fixed number of steps per sounding note and sample"); break;
 			case OP_OPERATOR: if (k != N_OPERATOR) return bad("node is not an operator"); need_a = o.a >= 0; need_b = o.b >= 0; break;
 			case OP_CMP: if (o.imm > 5u) return bad("unknown relation"); need_a = need_b = true; break;
 			case OP_NOISE: if (!open.empty() || (int)i < prepare_ops) return bad("Noise may not sit inside an `if` or prepare()"); if (o.imm > 1u) return bad("unknown noise kind"); break;

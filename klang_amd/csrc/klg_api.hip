@@ -147,7 +147,7 @@ extern "C" int klg_init(const int* device_ids, int n_devices) {
 struct RngChain {
 	bool on_device = false; int device = -1;
 	std::map<int, uint32_t*> d_state;                              // per device: 32 words
-	std::map<int, hipEvent_t> last; std::map<int, bool> used; hipStream_t last_stream = nullptr;   // after the last launch that used the state on that device (used: the event has been recorded)
+	std::map<int, hipEvent_t> last; std::map<int, bool> used; std::map<int, hipStream_t> last_stream;   // (per device: the stream of the last launch that used that device's words)   // after the last launch that used the state on that device (used: the event has been recorded)
 	std::map<std::pair<int, unsigned long long>, uint32_t*> tables;    // (device, per) -> klg_rand::jump_table(per) in HBM
 };
 static RngChain g_rng;
@@ -166,7 +166,7 @@ static int rng_acquire(int device, hipStream_t st, uint32_t** state) {
 		klg_rand::State s;
 		if (!klg_rand::libc_state(s)) return fail(KLG_ERR_INVALID, "the C library's rand() is not running its default generator (initstate() with a small state?): the Noise generators have no stream to continue");
 		RandStateArg arg; std::memcpy(arg.x, s.x, sizeof arg.x);
-		if (g.used.count(device) && g.last_stream != st) HIP_TRY(hipStreamWaitEvent(st, g.last[device], 0));   // (an earlier sequence's last Noise block may still be reading these words on another stream)
+		if (g.used.count(device) && g.last_stream[device] != st) HIP_TRY(hipStreamWaitEvent(st, g.last[device], 0));   // (an earlier sequence's last Noise block may still be reading these words on another stream)
 		hipLaunchKernelGGL(klg_rand_set, dim3(1), dim3(64), 0, st, mine, arg);
 		HIP_TRY(hipGetLastError());
 	}
@@ -174,8 +174,8 @@ static int rng_acquire(int device, hipStream_t st, uint32_t** state) {
 		HIP_TRY(hipStreamWaitEvent(st, g.last[g.device], 0));
 		HIP_TRY(hipMemcpyPeerAsync(mine, device, g.d_state[g.device], g.device, klg_rand::DEG * sizeof(uint32_t), st));
 	}
-	else if (g.last_stream != st) HIP_TRY(hipStreamWaitEvent(st, g.last[device], 0));
-	g.on_device = true; g.device = device; g.last_stream = st;
+	else if (g.last_stream[device] != st) HIP_TRY(hipStreamWaitEvent(st, g.last[device], 0));
+	g.on_device = true; g.device = device; g.last_stream[device] = st;
 	*state = mine;
 	return 0;
 }
@@ -219,6 +219,9 @@ extern "C" void klg_random_seed(unsigned seed) {                   // klang::ran
 // `ranks` x `per` draws of the stream, in order, into device memory: out[i * rstride + r] = the (r * per + i)-th rand() from here — what `ranks` Noise
 // objects processing `per / draws` samples one after the other would draw (klang.h:4842-4848)
 static int rng_fill(int device, hipStream_t st, int* d_out, size_t rstride, const unsigned* d_count, unsigned ranks_bound, unsigned count_imm, int per) {
+	// (the whole sequence under the one lock — acquire, the two launches, the event —: two host threads with Noise banks on one device must not interleave their
+	//  launches on the 31 state words; the mutex is recursive, rng_acquire / rng_release take it again)
+	std::lock_guard<std::recursive_mutex> lock(RandGuard::mu());
 	uint32_t* state = nullptr; const uint32_t* table = nullptr;
 	if (int rc = rng_table(device, (unsigned long long)per, &table)) return rc;
 	if (int rc = rng_acquire(device, st, &state)) return rc;

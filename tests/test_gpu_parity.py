@@ -269,3 +269,49 @@ def test_supersaw_pair_kernel_block_lengths(p, n, monkeypatch):
     a, ra = run("0")
     b, rb = run("2")
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(ra, rb) and np.abs(a).max() > 0
+
+
+@pytest.mark.parametrize("patch,voices,env_ref,env_new", [
+    ("supersaw", 100032, {"KLG_SUPERSAW_LANES": "0"}, {}),            # above the grid cap (CUs x 8 workgroups of 32 voices): the grid-stride loop; a last group that is part dead
+    ("supersaw", 6144, {"KLG_SUPERSAW_LANES": "0"}, {}),              # more than 128 partial rows: the separate klg_reduce instead of the fused combine
+    ("sub2a", 2048, {"KLG_SUB2A_SP": "0"}, {"KLG_SUB2A_SP": "1"}),    # the voice-per-wave kernel at the largest bank it is given, against the packed kernel
+    ("sub2a", 2016, {"KLG_SUB2A_SP": "0"}, {"KLG_SUB2A_SP": "1"}),
+])
+def test_sample_parallel_kernels_at_the_sizes_the_small_fixtures_do_not_reach(patch, voices, env_ref, env_new, monkeypatch):
+    """klg_render_supersaw_sp is the default at every size and klg_render_sub2a_sp up to 2,048 voices, but the golden fixtures hold ~96 voices.  Here the
+    sizes where the launch changes shape: the same notes through the sample-parallel kernel and through the voice-per-lane / packed one — every voice's block, the mix
+    and every record afterwards, bit for bit (two thirds of the slots sounding, some released mid-run: live and dead voices share waves and groups)."""
+    import klang_amd
+    P, N = 32, 256
+    def run(env):
+        for k in ("KLG_SUPERSAW_LANES", "KLG_SUB2A_SP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        bank = klang_amd.SynthBank(patch, synths=voices // P, notes=P, max_block=N)
+        rng = np.random.default_rng(99)
+        sy = np.repeat(np.arange(voices // P), 21).astype(np.int32)
+        bank.random(4711)
+        bank.note_on_many(sy, rng.integers(36, 97, size=sy.size).astype(np.int32), rng.uniform(0.3, 1.0, size=sy.size).astype(np.float32))
+        outs = []
+        for b in range(3):
+            if b == 1:
+                off = np.arange(0, voices // P, 3, dtype=np.int32)
+                for s_ in off[:200]:
+                    bank.note_off(int(s_), int(bank_pitch[int(s_)]))
+            pv, mix = bank.process_voices(N)
+            outs.append((pv.copy(), mix.copy()))
+        recs = np.stack([bank.voice_download(v) for v in list(range(0, 64)) + list(range(voices - 64, voices))])
+        stages = bank.stages().copy()
+        bank.close()
+        return outs, recs, stages
+    rngp = np.random.default_rng(99)
+    bank_pitch = rngp.integers(36, 97, size=(voices // P) * 21).astype(np.int32)[::21]      # (the first note of every synth: what block 1 releases)
+    a, ra, sa = run(env_ref)
+    b, rb, sb = run(env_new)
+    assert np.array_equal(sa, sb)
+    for (pa, ma), (pb, mb) in zip(a, b):
+        assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))
+        assert np.allclose(ma, mb, rtol=0, atol=1e-5 * np.sqrt(voices) * 4 * max(1.0, float(np.abs(pa).max())))
+        assert np.abs(pa).max() > 0
+    assert np.array_equal(ra, rb)
