@@ -436,7 +436,11 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	};
 
 	// ---------------- the request-ahead pipeline (header comment) ----------------
-	constexpr int PPX_DEEP = G == 16 ? 4 : G == 32 ? 3 : 2;                   // chunks an audio wave runs ahead of itself
+#ifndef KLG_PPX_DEEP16_SHORT
+#define KLG_PPX_DEEP16_SHORT 2          // (measured, 4,096 instances, one block per call: 14.0 / 13.4 / 12.9 us with a lead of 4 / 3 / 2 chunks)
+#endif
+	// (the compilation that short launches take — a real-time host's one block per call: 8 chunks — may run less far ahead: every chunk of lead is a step the block spends filling and draining the pipeline)
+	constexpr int PPX_DEEP = G == 16 ? (MODE == PPX_NO_MOVING ? KLG_PPX_DEEP16_SHORT : 4) : G == 32 ? 3 : 2;                   // chunks an audio wave runs ahead of itself
 	constexpr int P = PPX_DEEP;
 	constexpr int DIOV = G * 2 * PPX_CHUNK / (PPX_AUDIO * 64);                  // values of the caller's chunk per audio thread
 	float iov[P][DIOV];                                                         // the caller's rows of a chunk, requested P steps before they go to LDS

@@ -539,7 +539,8 @@ static int fx_enqueue(klg_fx* f, float* d_io, int n, hipStream_t st, int blocks 
 			const int chunks = (n * blocks + PPX_CHUNK - 1) / PPX_CHUNK;
 			const bool long_span = chunks >= PPX_MOVING_MIN;
 			const bool touched = f->samples - f->pp_touched_at < 8192ull;
-			int plan = !long_span ? 0 : touched ? 1 : 2;                                // 0: the kernel without the moving-dials pipeline alone, 1: the full kernel alone, 2: both
+			// (two launches cost a span ~2.5 us: below 64 chunks — eight 256-sample blocks — a span whose dials have been left alone takes the kernel without the moving-dials pipeline alone)
+			int plan = !long_span ? 0 : touched ? 1 : chunks >= 2 * PPX_MOVING_MIN ? 2 : 0;   // 0: the kernel without the moving-dials pipeline alone, 1: the full kernel alone, 2: both
 			if (force_mv == 1) plan = 1; else if (force_mv == 0) plan = 0;
 			if (plan == 2 && !f->pp_done) { if (hipMalloc((void**)&f->pp_done, (f->kpad / 16) * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); f->pp_done = nullptr; plan = 1; } }
 			auto launch = [&](auto mode_c, int pass) {
