@@ -780,7 +780,7 @@ def main():
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only (what ranks of an N > 1 run do anyway)")
-    ap.add_argument("--realtime-voices", type=int, default=32 << 20, help="the deadline test: 32 Mi voices pass (p99 4.4 ms, every block under 5.33 ms); 36 Mi have blocks over the deadline")
+    ap.add_argument("--realtime-voices", type=int, default=32 << 20, help="the deadline test's bank (p99 over 2,000 blocks) and where the search for deadline.max_realtime_voices — the largest bank whose EVERY block fits, the number to quote — starts; 30 - 32 Mi on the nodes measured so far")
     ap.add_argument("--realtime-margin-voices", type=int, default=28 << 20, help="the deadline test with a margin: every block of 28 Mi voices within 90 %% of the 5.33 ms")
     ap.add_argument("--in-library", action="store_true", help="N > 1 through the C-ABI's own sharding: ONE process, klg_init(ids 0..N-1), one ncclAllReduce of the [2][n] block per klg_process_device inside the library (what a C++ host uses) instead of one process per GPU + torch.distributed")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
