@@ -15,17 +15,21 @@ def main():
     settle, warmup, steps = (int(x) for x in sys.argv[3:6]) if len(sys.argv) >= 6 else (24, 20, 200)
     trace = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))
     rows = []
+    per_kernel = {}                                                                           # name -> [calls, total ns] over EVERY process of the run (bench.py's children write their own .db)
     for db in sorted(glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)):      # rocprofv3's default (rocpd sqlite) output
         import sqlite3
         c = sqlite3.connect(db)
         for name_, start, end in c.execute("select name, start, end from kernels"):
+            k = per_kernel.setdefault(name_, [0, 0])
+            k[0] += 1; k[1] += int(end) - int(start)
             if name in name_:
                 rows.append((int(start), int(end) - int(start), name_))
-        if len(sys.argv) >= 7:                                                                # also write the per-kernel stats table
-            with open(sys.argv[6], "w") as f:
-                f.write("Name,Calls,TotalDurationUs,AverageUs,Percentage\n")
-                for r in c.execute("select * from top_kernels"):
-                    f.write('"%s",%d,%.3f,%.3f,%.4f\n' % (r[0], r[1], r[2], r[3], r[4]))
+    if len(sys.argv) >= 7 and per_kernel:                                                     # also write the per-kernel stats table
+        total = sum(v[1] for v in per_kernel.values()) or 1
+        with open(sys.argv[6], "w") as f:
+            f.write("Name,Calls,TotalDurationUs,AverageUs,Percentage\n")
+            for n_, (calls, ns) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
+                f.write('"%s",%d,%.3f,%.3f,%.4f\n' % (n_, calls, ns / 1e3, ns / 1e3 / calls, 100.0 * ns / total))
     for t in trace:
         for r in csv.DictReader(open(t)):
             if name in r["Kernel_Name"]:
