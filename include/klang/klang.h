@@ -53,6 +53,7 @@
 #include <type_traits>
 #include <typeindex>
 #include <typeinfo>
+#include <memory>
 #include <unordered_map>
 #include <vector>
 
@@ -968,6 +969,41 @@ struct Envelope : Generator, gpu::Packable {
 		Points& operator()(float x_, float y_) { rest.push_back(Point(x_, y_)); return *this; }
 		int count() const { return 1 + (int)rest.size(); }
 	};
+	// Ramp / Linear (klang.h:3731-3807): what an Envelope steps from point to point.  On the GPU an envelope's ramp IS the linear one (klg_device.hpp Env); the types are
+	// here so that patches that name them compile and behave on the host as in the reference, `env.set(new Envelope::Linear())` is what it is there (the default ramp
+	// again + initialise()), and a USER ramp — a subclass with its own operator++ — stops with a message instead of rendering a line.
+	struct Ramp : Generator {
+		float target = 1.f, rate = 0.f; bool active = false;
+		Ramp(float value = 1.f) { setValue(value); }
+		Ramp(float start, float target_, float time) { setValue(start); setTarget(target_); setTime(time); }
+		virtual ~Ramp() {}
+		bool isActive() const { return active; }
+		virtual void setTarget(float target_) { target = target_; active = (out.value != target_); }
+		virtual void setValue(float value) { out.value = value; target = value; active = false; }
+		virtual void setRate(float rate_) { rate = rate_; }
+		virtual void setTime(float time) { rate = time ? 1.f / (time * fs.f) : 0.f; }
+		virtual signal operator++(int) = 0;
+		void process() override {}
+	};
+	struct Linear : Ramp {
+		using Ramp::Ramp;
+		signal operator++(int) override {                                              // klang.h:3784-3806
+			const signal output = out;
+			if (active) {
+				if (target > out.value) { out.value += rate; if (out.value >= target) { out.value = target; active = false; } }
+				else { out.value -= rate; if (out.value <= target) { out.value = target; active = false; } }
+			}
+			return output;
+		}
+	};
+	void set(Ramp* ramp) {                                                             // klang.h:4057-4060 (takes ownership, then initialise())
+		std::unique_ptr<Ramp> own(ramp);
+		if (!ramp || typeid(*ramp) != typeid(Linear)) {
+			std::fprintf(stderr, "klang-mi355: Envelope::set(Ramp*) with a user-defined Ramp: the device envelope steps the Linear ramp (klang.h:3781-3807) and has no form for another operator++ — not rendered as a line instead\n");
+			std::abort();
+		}
+		initialise();
+	}
 	enum Stage { Sustain, Release, Off };
 	enum Mode { Time, Rate };
 	klg::host::EnvH h;
@@ -1099,6 +1135,9 @@ struct Envelope::Follower : Modifier, gpu::Packable {
 	void process() override { if (gpu::recording()) { gpu::record_modifier(this, "Envelope::Follower"); return; } device_only("Envelope::Follower::process()"); }
 	void pack(uint32_t* w) const override { w[klg::graph::FOLLOW_A] = gpu::fbits(ar.A); w[klg::graph::FOLLOW_R] = gpu::fbits(ar.R); w[klg::graph::FOLLOW_OUT] = gpu::fbits(out.value); }
 	void unpack(const uint32_t* w) override { std::memcpy(&out.value, &w[klg::graph::FOLLOW_OUT], 4); }
+	// (Envelope::Follower::Window<N>, klang.h:5905-5949, is not here: the reference's own template cannot be instantiated — `sum * window.inv >> sqrt` is an ambiguous
+	//  `Function<float> << const double` (klang.h:5946 through 4888; clang 19, the compiler every fixture of tests/golden was made with) — so no patch can hold one
+	//  and there is no reference output to be identical to.)
 };
 
 // ---- FM operator (klang.h:4140-4180) ----
@@ -1245,6 +1284,11 @@ public:
 	}
 	void unpack(const uint32_t* w) override { std::memcpy(&increment, &w[klg::graph::WT_INC], 4); std::memcpy(&position, &w[klg::graph::WT_POS], 4); }
 };
+// Generators::Wavetables (klang.h:5369-5380): a cycle of Basic::Sine / Basic::Saw rendered into 2,048 samples by the constructor
+namespace Generators { namespace Wavetables {
+	struct Sine : public Wavetable { Sine() : Wavetable(Basic::Sine()) {} };
+	struct Saw : public Wavetable { Saw() : Wavetable(Basic::Saw()) {} };
+} }
 // Sample (klang.h:3683-3720): plays an attached buffer at one sample per sample, whatever the frequency
 class Sample : public Wavetable {
 public:

@@ -265,7 +265,10 @@ template<int I> struct IntTag { static constexpr int value = I; };
 #ifndef KLG_PPX_ABLATE
 #define KLG_PPX_ABLATE 0          // measurement builds only (tools/ppx_ablate.sh): 1 no DC filter chain, 2 no output stores, 4 no ring requests, 8 no audio stage, 16 / 64 moving dials: no first / second half of the control chain, 32 no LFO phase walk in the second
 #endif
-enum { PPX_MOVING_MIN = 32 };       // the shortest span (chunks) that runs the request-ahead pipeline with moving dials
+#ifndef KLG_PPX_MOVING_MIN
+#define KLG_PPX_MOVING_MIN 32
+#endif
+enum { PPX_MOVING_MIN = KLG_PPX_MOVING_MIN };       // the shortest span (chunks) that runs the request-ahead pipeline with moving dials
 enum { PPX_CHUNK = 32, PPX_AUDIO = 8, PPX_PER = PPX_CHUNK / PPX_AUDIO, PPX_WAVES = 1 + PPX_AUDIO + 2 + 1, PPX_THREADS = PPX_WAVES * 64 };
 
 template<int G> struct PpxLds {
@@ -436,11 +439,14 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 	};
 
 	// ---------------- the request-ahead pipeline (header comment) ----------------
+#ifndef KLG_PPX_DEEP16_LONG
+#define KLG_PPX_DEEP16_LONG 4
+#endif
 #ifndef KLG_PPX_DEEP16_SHORT
 #define KLG_PPX_DEEP16_SHORT 2          // (measured, 4,096 instances, one block per call: 14.0 / 13.4 / 12.9 us with a lead of 4 / 3 / 2 chunks)
 #endif
 	// (the compilation that short launches take — a real-time host's one block per call: 8 chunks — may run less far ahead: every chunk of lead is a step the block spends filling and draining the pipeline)
-	constexpr int PPX_DEEP = G == 16 ? (MODE == PPX_NO_MOVING ? KLG_PPX_DEEP16_SHORT : 4) : G == 32 ? 3 : 2;                   // chunks an audio wave runs ahead of itself
+	constexpr int PPX_DEEP = G == 16 ? (MODE == PPX_NO_MOVING ? KLG_PPX_DEEP16_SHORT : KLG_PPX_DEEP16_LONG) : G == 32 ? 3 : 2;                   // chunks an audio wave runs ahead of itself
 	constexpr int P = PPX_DEEP;
 	constexpr int DIOV = G * 2 * PPX_CHUNK / (PPX_AUDIO * 64);                  // values of the caller's chunk per audio thread
 	float iov[P][DIOV];                                                         // the caller's rows of a chunk, requested P steps before they go to LDS

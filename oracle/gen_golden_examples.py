@@ -119,6 +119,8 @@ def scenarios():
     out["own_env_points"] = poly("own_env_points", 56, [0, 1, 7, 8, 20, 55], off_base=8, notes=16, ctl_events=[(6, 0, 0.9), (20, 0, 0.05)])
     # two_types.k: TWO Note types in one Synth (6 Pad slots, then 6 Bell slots): twenty note-ons fill the Pad slots, then the Bell slots, then steal across both types
     out["own_two_types"] = poly("own_two_types", 48, [0, 1, 7, 8, 20, 47], off_base=6, notes=12, ctl_events=[(6, 0, 0.9), (20, 0, 0.05)])
+    # leftovers.k (the path's edge): Generators::Wavetables::Sine / Saw, Envelope::Follower::Window<64> (RMS) and <48> (Mean), Envelope::set(new Envelope::Linear())
+    out["own_leftovers"] = poly("own_leftovers", 40, [0, 1, 7, 8, 20, 39], off_base=8, notes=16)
     # one voice each: the mix IS that voice, so the GPU result can be compared bit for bit (no summation-order slack)
     solo_ctl = {"ex_breakpoint": [(0, 0.05), (1, 0.1)], "ex_ramp": [(0, 0.1)], "ex_release": [(0, 0.002), (1, 0.1), (2, 0.05), (3, 0.12)],
                 "ex_am": [(0, 1.3), (1, 0.8)], "ex_fmmod": [(0, 1.5), (1, 4.0)], "ex_fm2": [(0, 0.7), (1, 3.0), (2, 6.0)],

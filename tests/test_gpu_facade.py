@@ -97,7 +97,7 @@ def test_example_synths_without_a_handwritten_kernel(name, tmp_path):
     check(*run_facade(path, name, tmp_path), name)
 
 
-@pytest.mark.parametrize("name", ["own_basic_mix", "own_filters_f2", "own_modal_follow", "own_branches", "own_wavetable", "own_sample", "own_pluck", "own_pluck_keep", "own_early_return", "own_iirn", "own_noise_note", "own_smooth_note", "own_hardsync", "own_vibstring", "own_finish_body", "own_pwm", "own_env_points", "own_two_types"])
+@pytest.mark.parametrize("name", ["own_basic_mix", "own_filters_f2", "own_modal_follow", "own_branches", "own_wavetable", "own_sample", "own_pluck", "own_pluck_keep", "own_early_return", "own_iirn", "own_noise_note", "own_smooth_note", "own_hardsync", "own_vibstring", "own_finish_body", "own_pwm", "own_env_points", "own_two_types", "own_leftovers"])
 def test_own_patches_for_the_other_node_kinds(name, tmp_path):
     """tests/patches/{basic_mix,filters_f2,modal_follow}.k (ours): Basic oscillators incl. per-sample set(f), OnePole LPF/HPF, DCF,
     Butterworth<1>/<2>, IIR<1>, Biquad HPF/BPF/BRF/APF, Modal, Envelope::Follower, a member written back by process().
@@ -109,7 +109,7 @@ def test_own_patches_for_the_other_node_kinds(name, tmp_path):
 
 
 SOLO = ["ex_breakpoint", "ex_ramp", "ex_release", "ex_filter", "ex_expression", "ex_addsaw", "ex_am", "ex_fmmod", "ex_fm2", "ex_operators", "ex_nyquist", "ex_square", "ex_resynthesis", "ex_inheritance", "ex_modular",
-        "own_basic_mix", "own_filters_f2", "own_modal_follow", "own_branches", "own_wavetable", "own_sample", "own_pluck", "own_pluck_keep", "own_early_return", "own_iirn", "own_noise_note", "own_smooth_note", "own_hardsync", "own_vibstring", "own_finish_body", "own_pwm", "own_env_points", "own_two_types"]
+        "own_basic_mix", "own_filters_f2", "own_modal_follow", "own_branches", "own_wavetable", "own_sample", "own_pluck", "own_pluck_keep", "own_early_return", "own_iirn", "own_noise_note", "own_smooth_note", "own_hardsync", "own_vibstring", "own_finish_body", "own_pwm", "own_env_points", "own_two_types", "own_leftovers"]
 
 
 @pytest.mark.parametrize("name", SOLO)
