@@ -433,7 +433,6 @@ static int fx_enqueue_graph(klg_fx* f, float* d_io, int n, hipStream_t st, int b
 			HIP_TRY(hipStreamSynchronize(st));
 			if (f->rand_done) HIP_TRY(hipEventSynchronize(f->rand_done)); else HIP_TRY(hipEventCreateWithFlags(&f->rand_done, hipEventDisableTiming));
 			if (f->d_rand) (void)hipFree(f->d_rand);
-	if (f->pp_done) (void)hipFree(f->pp_done);
 			f->d_rand = nullptr; f->rand_cap = 0;
 			if (hipMalloc((void**)&f->d_rand, need * sizeof(int)) != hipSuccess) return fail(KLG_ERR_NOMEM, "the Noise generators' draws (%zu instances x blocks, %d samples, %d generators: %.2f GB) could not be allocated", ranks, n, draws, need * 4 / 1e9);
 			f->rand_cap = need;
