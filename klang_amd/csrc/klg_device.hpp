@@ -188,9 +188,10 @@ __device__ __forceinline__ float fsine_process_rel(FSine& o, float rel) {
 // ---- Generic::Oscillator + Generators::Basic klang.h:2849-2880, 4899-4944 ----
 struct BOsc { float increment, position, offset; };
 __device__ __forceinline__ void phase_advance(float& value, float inc) {  // Phase::operator+=(float) 1518-1525
-	if (inc >= KLG_TWO_PI) return;
-	value += inc;
-	if (value > KLG_TWO_PI) value -= KLG_TWO_PI;
+	// (as selects: the same three operations on the path that is taken — add, compare, subtract — without the two nested branches a lone wave walking a recorded
+	//  effect's serial loop paid ~8 scalar instructions and two jumps a sample for)
+	const float p1 = value + inc, p2 = (p1 > KLG_TWO_PI) ? p1 - KLG_TWO_PI : p1;
+	value = (inc >= KLG_TWO_PI) ? value : p2;
 }
 // ::sin(double) for the arguments an oscillator has (klang.h:4902: `sin(position + offset)`, a float in [0, 2 pi] plus a phase offset).  The device
 // library's sin carries the whole-range argument reduction and was ~3,000 cycles per sample on a chain nothing overlaps (PingPong's LFO with vibrato,

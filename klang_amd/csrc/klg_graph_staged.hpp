@@ -574,6 +574,40 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 			}
 			out += res; return true;
 		};
+		// `if (c) osc.set(f, pi); else osc.set(f);` (PingPong.k:52-55) leaves, predicated, `X = c ? e : X` and later `X = !c ? e : X` for the same state X and the same
+		// expression e — the frequency and the increment either set() stores: X = e whatever c says.  Written so, e being a block invariant, X stops being carried from
+		// sample to sample at all (four selects a sample on the recorded PingPong.k's control chain).  Only the plain shape: one condition and its negation, the same text
+		// for e, nothing in between that names X.
+		auto merge_complementary = [](std::string& body) {
+			std::vector<std::string> lines; { size_t at = 0; while (at < body.size()) { size_t e = body.find('\n', at); if (e == std::string::npos) e = body.size() - 1; lines.push_back(body.substr(at, e - at + 1)); at = e + 1; } }
+			struct Sel { bool ok = false; std::string lhs, cond, rhs; };
+			auto parse = [](const std::string& ln) {
+				Sel r;
+				if (ln.rfind("\t\tL.", 0) != 0) return r;
+				const size_t eq = ln.find(" = ("); if (eq == std::string::npos) return r;
+				r.lhs = ln.substr(2, eq - 2);
+				size_t at = eq + 3; int depth = 0; size_t q = at;
+				for (; q < ln.size(); q++) { if (ln[q] == '(') depth++; else if (ln[q] == ')') { if (--depth == 0) break; } }
+				if (q >= ln.size()) return r;
+				r.cond = ln.substr(at + 1, q - at - 1);
+				const std::string mid = " ? (", tail = ") : " + r.lhs + ";\n";
+				if (ln.compare(q + 1, mid.size(), mid) != 0 || ln.size() < tail.size() + q + 1 + mid.size() || ln.compare(ln.size() - tail.size(), tail.size(), tail) != 0) return r;
+				r.rhs = ln.substr(q + 1 + mid.size(), ln.size() - tail.size() - (q + 1 + mid.size()));
+				r.ok = r.cond.find("&&") == std::string::npos;
+				return r;
+			};
+			bool changed = false;
+			for (size_t i = 0; i < lines.size(); i++) {
+				const Sel a = parse(lines[i]); if (!a.ok) continue;
+				for (size_t j = i + 1; j < lines.size(); j++) {
+					if (lines[j].find(a.lhs) == std::string::npos) continue;
+					const Sel b = parse(lines[j]);
+					if (b.ok && b.lhs == a.lhs && b.rhs == a.rhs && (b.cond == "!" + a.cond || a.cond == "!" + b.cond)) { lines[j] = "\t\t" + a.lhs + " = (" + a.rhs + ");\n"; lines[i].clear(); changed = true; }
+					break;                                                                   // (the first later line that names X decides)
+				}
+			}
+			if (changed) { body.clear(); for (const std::string& l : lines) body += l; }
+		};
 		// ops of one block in program order, with the branches they stand in re-opened around them
 		auto emit_ops = [&](bool pf, int lv, int wave /* -1: parallel */, const std::string& slot_index, std::string& out, const std::vector<char>& predeclared) {
 			std::vector<std::pair<int, int>> open;
@@ -854,6 +888,7 @@ inline StagedPlan plan_staged(const StagedInput& in) {
 					for (int r : from_slot) { fetch += F("\t\tfloat i%d[%d];\n#pragma unroll\n\t\tfor (int u = 0; u < %d; u++) i%d[u] = ", r, U, U, r) + slot_ref(r, pf) + "[(sb + u) * G + " + li + "];\n"; decl += "\t\tconst " + ty(r) + F(" r%d = i%d[u];\n", r, r); }
 					for (int i : mine) if (V[(size_t)i].dst >= 0 && in_branch(i) && def_at[(size_t)V[(size_t)i].dst] == i) { const int r = V[(size_t)i].dst; predecl[(size_t)r] = 1; decl += "\t\t" + ty(r) + F(" r%d = 0; (void)r%d;\n", r, r); }
 					emit_ops(pf, lv, w, "q", loop, predecl);
+					merge_complementary(loop);
 					if (first_pass && !part) P.serial_ops += (int)mine.size() * K;
 					// the suffix works on the architectural records; the prefix on its own two copies: from the one its previous chunk left, into the other
 					const std::string from = (pf && !part) ? "srecp + (parn ^ 1) * (NW * G)" : "srec", to = (pf && !part) ? "srecp + parn * (NW * G)" : "srec";
