@@ -674,7 +674,9 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 					t += "\t\t\t\tfloat r = 0.f, sr = 0.f, tm = 0.f, stm = 0.f;\n";
 					for (int k = 0; k < K; k++) t += fmt("\t\t\t\tif (j == %d) { r = ", k) + envs[(size_t)k].ev + fmt(".r_out; sr = st%d; tm = ", k) + envs[(size_t)k].ev + fmt(".time; stm = ts%d; }\n", k);
 					t += fmt("\t\t\t\tif (j < %d) {\n\t\t\t\t\tfloat* row = E + j * SLOTS + h;\n", K);
-					t += "\t\t\t\t\tfor (int i = 0; i < hl; i++) { row[i] = r; r += sr; tm += stm; }\n";
+					// (a whole chunk: written out — as a loop every sample pays a jump on a wave nothing else runs beside: 7 instructions and ~45 cycles a sample instead of 3 and ~15)
+					t += "\t\t\t\t\tconstexpr int WHOLE = SLOTS < KLG_CHUNK_MAX ? SLOTS : KLG_CHUNK_MAX;\n\t\t\t\t\tif (hl == WHOLE) {\n#pragma unroll\n\t\t\t\t\t\tfor (int i = 0; i < WHOLE; i++) { row[i] = r; r = sc_add(r, sr); tm = sc_add(tm, stm); }\n\t\t\t\t\t}\n";
+					t += "\t\t\t\t\telse for (int i = 0; i < hl; i++) { row[i] = r; r = sc_add(r, sr); tm = sc_add(tm, stm); }\n";
 					t += fmt("\t\t\t\t\tE[%d * SLOTS + 2 * j] = r; E[%d * SLOTS + 2 * j + 1] = tm;\n\t\t\t\t}\n\t\t\t\twave_sync();\n", K, K);
 					for (int k = 0; k < K; k++) {
 						t += fmt("\t\t\t\te%zu = (j >= h && j < h + hl) ? E[%d * SLOTS + j] : e%zu; ", envs[(size_t)k].i, k, envs[(size_t)k].i) + envs[(size_t)k].ev + fmt(".r_out = E[%d * SLOTS + %d]; ", K, 2 * k) + envs[(size_t)k].ev + fmt(".time = E[%d * SLOTS + %d];\n", K, 2 * k + 1);
@@ -713,9 +715,20 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 					case OP_LPF: {
 						const char* fn = k == N_LPF ? "biquad_process" : k == N_OPLPF ? "onepole_lpf_process" : k == N_OPHPF ? "onepole_process" : k == N_DCF ? "dcf_process" : k == N_IIR1 ? "iir1_process" : k == N_IIRN ? "iir_process"
 							: k == N_BUTTER1 ? "butter1_process" : k == N_MODAL ? "modal_process" : k == N_FOLLOWPEAK ? "follower_peak" : "follower_rms";
+						if (k == N_LPF) {
+							// a biquad: its feed-forward products b0 x, b1 x, b2 x are taken by the lane that owns the sample (three rows of the wave's LDS), the recurrence every
+							// lane walks is what is left — y = p0 + z0; z0 = p1 - a1 y + z1; z1 = p2 - a2 y: two multiplications and four additions a sample instead of five and four,
+							// the same operations on the same values in the same order per value (biquad_process; klg_render_sub2a_sp.hpp does this by hand)
+							t += "\t\tX[j] = " + n + ".b0 * " + a + "; X[KLG_SP_XROW + j] = " + n + ".b1 * " + a + "; X[2 * KLG_SP_XROW + j] = " + n + ".b2 * " + a + ";\n\t\twave_sync();\n" + fmt("\t\tfloat r%d = 0.f;\n", o.dst);
+							t += "\t\tif (SLOTS >= 4 && cnt == SLOTS) {\n\t\t\ttypedef float f4_ __attribute__((ext_vector_type(4)));\n#pragma unroll\n\t\t\tfor (int i0 = 0; i0 < SLOTS; i0 += 4) {\n";
+							t += "\t\t\t\tconst f4_ p0 = *reinterpret_cast<const f4_*>(X + i0), p1 = *reinterpret_cast<const f4_*>(X + KLG_SP_XROW + i0), p2 = *reinterpret_cast<const f4_*>(X + 2 * KLG_SP_XROW + i0);\n";
+							t += "#pragma unroll\n\t\t\t\tfor (int q = 0; q < 4; q++) { const float v = biquad_step(" + n + fmt(", p0[q], p1[q], p2[q]); r%d = sp_keep<SLOTS>(r%d, v, i0 + q); }\n\t\t\t}\n\t\t}\n", o.dst, o.dst);
+							t += "\t\telse for (int i = 0; i < cnt; i++) { const float v = biquad_step(" + n + fmt(", X[i], X[KLG_SP_XROW + i], X[2 * KLG_SP_XROW + i]); r%d = (i == j) ? v : r%d; }\n\t\twave_sync();\n", o.dst, o.dst);
+							break;
+						}
 						t += "\t\tX[j] = " + a + ";\n\t\twave_sync();\n" + fmt("\t\tfloat r%d = 0.f;\n", o.dst);
 						t += "\t\tif (SLOTS >= 4 && cnt == SLOTS) {\n\t\t\ttypedef float f4_ __attribute__((ext_vector_type(4)));\n#pragma unroll\n\t\t\tfor (int i0 = 0; i0 < SLOTS; i0 += 4) {\n\t\t\t\tconst f4_ x4 = *reinterpret_cast<const f4_*>(X + i0);\n";
-						t += std::string("#pragma unroll\n\t\t\t\tfor (int q = 0; q < 4; q++) { const float v = ") + fn + "(" + n + fmt(", x4[q]); r%d = (i0 + q == j) ? v : r%d; }\n\t\t\t}\n\t\t}\n", o.dst, o.dst);
+						t += std::string("#pragma unroll\n\t\t\t\tfor (int q = 0; q < 4; q++) { const float v = ") + fn + "(" + n + fmt(", x4[q]); r%d = sp_keep<SLOTS>(r%d, v, i0 + q); }\n\t\t\t}\n\t\t}\n", o.dst, o.dst);
 						t += std::string("\t\telse for (int i = 0; i < cnt; i++) { const float v = ") + fn + "(" + n + fmt(", X[i]); r%d = (i == j) ? v : r%d; }\n\t\twave_sync();\n", o.dst, o.dst);
 					} break;
 					default: emit_op(oi, t, false); break;                       // arithmetic, literals, controls, members, `osc.frequency`: per lane, as in sample()

@@ -2,7 +2,7 @@
 # tools/r06_final.sh — the round's closing measurements in ONE gpurun call (outputs under gpurun_out/r06/, copied to profiles/r06/ by hand):
 #   the GPU suite, the default bench line, rocprofv3 kernel stats of the headline and of the legs, PMC instruction counts of the FM kernel, the small-bank tables
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06; mkdir -p $O
-python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/final_gpu_suite.txt
+python -m pytest tests -m gpu -q > /tmp/suite_full.txt 2>&1; grep -aE "[0-9]+ (passed|failed)|^FAILED|^ERROR" /tmp/suite_full.txt | tail -6 > $O/final_gpu_suite.txt   # (device printf of the stamp tests lands behind pytest's summary: not `tail`)
 python -c "import __graft_entry__ as g; g.smoke()" > $O/final_smoke.txt 2>&1
 python bench.py > $O/final_bench_default.json 2> $O/final_bench_default.err; cp gpurun_out/bench_full.json $O/final_bench_default_full.json
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_head -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-configs > $GRAFT_REPO_ROOT/$O/final_bench_profiled.json 2>/tmp/prof_head.err )
