@@ -12,4 +12,5 @@ python tools/kernel_summary.py /tmp/prof_legs klg_fx_pingpong_x 0 0 1 $O/final_b
 python tools/pmc_any.py "PatchFM<4>" "SQ_INSTS_VALU,SQ_WAVES,SQ_WAVE_CYCLES,SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY" -- python $GRAFT_REPO_ROOT/tools/fm_leg.py 131072 > $O/pmc_fm4.json 2>&1
 python tools/pingpong_leg_repeat.py 5 > $O/pingpong_leg_repeat.txt 2>&1
 python tools/small_banks.py > $O/small_banks.jsonl 2>&1
+python tools/recorded_small_banks.py > $O/recorded_small_banks.jsonl 2>&1
 ls -la $O
