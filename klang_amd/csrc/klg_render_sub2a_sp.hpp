@@ -15,6 +15,14 @@
 
 namespace klg {
 
+// Every lane of the wave walks the same recurrence; lane k is to keep the value of sample k.  As `keep = (lane == s) ? v : keep` that is a scalar operation, a compare
+// and a select per sample and value — and on a wave that has its SIMD to itself EVERY instruction, scalar ones included, is one issue slot of four cycles (measured:
+// the loop ran 81 cycles a sample for ten vector operations).  Instead the values are pushed through the wave like a shift register: one DPP move (wave_shl:1 — lane
+// k takes lane k + 1's, lane 63 the new value) per sample and value; after 64 pushes lane k holds the k-th.  All 64 lanes must be active.
+__device__ __forceinline__ float wave_push(float hist, float v) {
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(hist), 0x130, 0xF, 0xF, false));
+}
+
 enum { S2_TILE = 64, KLG_SUB2A_SP_MAX_VOICES = 2048 };                      // samples side by side; banks up to this many voices take this kernel (one wave per voice: more than ~2 waves per SIMD and the packed kernel's 128 voices per wave win)
 
 template<bool PER_VOICE>
@@ -88,14 +96,14 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_sp(const RenderArgs a) {
 							float e;
 							if (GLIDE) e = env_glide(adsr.e, step, tstep);
 							else { e = adsr_process(adsr, a.fs); stage = (adsr.e.stage == ENV_OFF) ? (int)ST_OFF : stage; }
-							const bool mine = lane == h + s4 + k;
-							y_own = mine ? y : y_own; e_own = mine ? e : e_own;
+							y_own = wave_push(y_own, y); e_own = wave_push(e_own, e);       // (see wave_push: after the tile's 64 samples lane k holds sample k's)
 						}
 					}
 				};
 				if (hl == KLG_CHUNK_MAX) { if (glide) run(LanesFlag<true>{}, LanesFlag<true>{}); else run(LanesFlag<false>{}, LanesFlag<true>{}); }
 				else { if (glide) run(LanesFlag<true>{}, LanesFlag<false>{}); else run(LanesFlag<false>{}, LanesFlag<false>{}); }
 			}
+			for (int r = tl; r < S2_TILE; r++) { y_own = wave_push(y_own, 0.f); e_own = wave_push(e_own, 0.f); }   // (a ragged last tile: moved on to where a whole one ends)
 			const float out = lane < tl ? y_own * e_own : 0.f;                        // out *= adsr++
 			if (lane < tl) {
 				if (PER_VOICE) a.per_voice[(size_t)v * n + t0 + lane] = out;
