@@ -79,6 +79,23 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // Dynamic LDS of the render kernels: [WAVES][n] floats, one mix row per wave (render_lds_bytes(n) at launch); [WAVES][2][n] for stereo notes.
+// `keep = (this lane's sample == i) ? v : keep` for a recurrence every lane of a voice walks, called for i = 0 .. SLOTS - 1 in order (a whole tile): the lane's sample is
+// lane % SLOTS (klg_render_gsp).  On a wave that has its SIMD to itself every instruction — scalar ones too — is an issue slot, so the select is not written as a
+// compare and a select: with 64 or 16 samples per voice the values are PUSHED through the voice's lanes like a shift register, one DPP move a sample (wave_shl:1 /
+// row_shl:1 — lane k takes lane k + 1's, the voice's last lane the new value: after SLOTS pushes lane k holds the k-th; klg_render_sub2a_sp.hpp's wave_push); with 32
+// or 8 — no DPP shift of that width — WHICH lanes take the value is a constant of the unrolled loop, a 64-bit scalar mask.  All lanes of the wave must be active.
+template<int SLOTS> __device__ __forceinline__ float sp_keep(float keep, float v, int i) {
+	static_assert(SLOTS == 64 || SLOTS == 32 || SLOTS == 16 || SLOTS == 8, "samples per voice and tile");
+	if constexpr (SLOTS == 64) return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(keep), 0x130, 0xF, 0xF, false));
+	else if constexpr (SLOTS == 16) return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(keep), 0x101, 0xF, 0xF, false));
+	else {
+		constexpr unsigned long long rep = SLOTS == 32 ? 0x0000000100000001ull : 0x0101010101010101ull;
+		const unsigned long long m = rep << i;
+		float r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(keep), "v"(v), "s"(m));
+		return r;
+	}
+}
+
 extern __shared__ float klg_mix_rows[];
 __device__ __forceinline__ float mix_rows_sum(int i, int n) { return ((klg_mix_rows[i] + klg_mix_rows[n + i]) + klg_mix_rows[2 * n + i]) + klg_mix_rows[3 * n + i]; }   // fixed order
 __host__ __device__ inline unsigned render_lds_bytes(int n, int note_channels = 1) { return (unsigned)(WAVES * n * note_channels * sizeof(float)); }
