@@ -84,6 +84,9 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_sp(const RenderArgs a) {
 				const bool glide = __builtin_amdgcn_readfirstlane((int)(stage == (int)ST_OFF || safe)) != 0;
 				auto run = [&](auto glide_c, auto full_c) {                            // (compile-time forms: the loop a whole chunk runs has no test inside it)
 					constexpr bool GLIDE = decltype(glide_c)::value, FULL = decltype(full_c)::value;
+					// (gliding: the envelope's value and its Sustain clock advance together — ONE packed addition a sample: the pair is a chain of its own, nothing of the
+					//  filter's waits for it, and an instruction fewer is an issue slot fewer)
+					f2 et = { adsr.e.r_out, adsr.e.time }; const f2 es = { step, tstep }; (void)et; (void)es;
 #pragma unroll
 					for (int s4 = 0; s4 < KLG_CHUNK_MAX; s4 += 4) {
 						if (!FULL && s4 >= hl) break;
@@ -94,11 +97,12 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_sp(const RenderArgs a) {
 							q.z0 = p1[k] - q.a1 * y + q.z1;
 							q.z1 = p2[k] - q.a2 * y;
 							float e;
-							if (GLIDE) e = env_glide(adsr.e, step, tstep);
+							if (GLIDE) { e = et.x; et = et + es; }                            // env_glide: out, then out + step and time + tstep
 							else { e = adsr_process(adsr, a.fs); stage = (adsr.e.stage == ENV_OFF) ? (int)ST_OFF : stage; }
 							y_own = wave_push(y_own, y); e_own = wave_push(e_own, e);       // (see wave_push: after the tile's 64 samples lane k holds sample k's)
 						}
 					}
+					if (GLIDE) { adsr.e.r_out = et.x; adsr.e.time = et.y; }
 				};
 				if (hl == KLG_CHUNK_MAX) { if (glide) run(LanesFlag<true>{}, LanesFlag<true>{}); else run(LanesFlag<false>{}, LanesFlag<true>{}); }
 				else { if (glide) run(LanesFlag<true>{}, LanesFlag<false>{}); else run(LanesFlag<false>{}, LanesFlag<false>{}); }
