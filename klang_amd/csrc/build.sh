@@ -8,7 +8,8 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # -Bsymbolic: the library binds its own C++ inline functions (the graph-program parser of include/klang_mi355_graph.h is
 # compiled into host programs too) instead of letting a host executable's copies interpose on them.
 # -fno-slp-vectorize: where two independent fp32 operations should share a v_pk_* instruction the kernels say so (f2 vectors); what the SLP vectorizer packs
-# on its own lengthens dependent chains (a dependent v_pk_*_f32 waits ~20 cycles, a scalar one ~8): SuperSaw renders 2 - 3 % faster without it, nothing slower.
+# on its own comes with the moves that build and split the pairs (a dependent v_pk_add_f32 itself waits 8 cycles like a plain one: tools/calib/issue_latency.hip):
+# SuperSaw renders 2 - 3 % faster without it, nothing slower.
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Wl,-Bsymbolic \
     -Wall -Wno-unused-function "$@" "$HERE/klg_api.hip" -o "$OUT"
 echo "built $OUT"
