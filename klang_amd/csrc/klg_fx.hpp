@@ -409,7 +409,8 @@ __global__ __launch_bounds__(PPX_THREADS) void klg_fx_pingpong_x(const PingPongA
 #pragma unroll
 				for (int u = 0; u < 8; u++) x[u] = T[b + u][li];
 				// (packed fp32 operations for the independent products were tried — 5.5 instead of 9 VALU instructions per sample, bit-identical —
-				//  and are 2.3 x SLOWER here: a dependent v_pk_*_f32 waits ~20 cycles for its operand, a scalar one ~8)
+				//  and were 2.3 x SLOWER here when measured (round 3).  Not by the packed operations' own latency — a dependent v_pk_mul / add / fma_f32 waits 8 cycles like a
+				//  plain one, tools/calib/issue_latency.hip —: what builds and splits the pairs are instructions too, and this wave pays an issue slot for each)
 #pragma unroll
 				for (int u = 0; u < 8; u++) if ((FULL || b + u < cl) && !(KLG_PPX_ABLATE & 1)) x[u] = biquad_process(dc, x[u]);     // out >> dcfilter[ch] >> out
 				if (lane < G) {
