@@ -30,7 +30,7 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_sp(const RenderArgs a) {
 	using Rec = rec::Sub2a;
 	constexpr int O0 = offsetof(Rec, osc) / 4, B0 = offsetof(Rec, lpf) / 4, A0 = offsetof(Rec, adsr) / 4;
 	typedef float f4 __attribute__((ext_vector_type(4)));
-	__shared__ __attribute__((aligned(16))) float p_all[WAVES][3][S2_TILE];
+	__shared__ __attribute__((aligned(16))) float p_all[WAVES][3][S2_TILE];             // per wave: [0]: b0 x of the tile's 64 samples; [1 .. 2]: { b1 x, b2 x } sample by sample
 	__shared__ int lds_flag;
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	float (* const P)[S2_TILE] = p_all[wave];
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_sp(const RenderArgs a) {
 				Osm t = o;
 				t.offset = off0 + inc * (uint32_t)(t0 + lane);
 				const float x = osm_saw_duty0(t);                                     // `Saw osc` never gets a duty: duty == 0 (patch invariant, PatchSub2a)
-				P[0][lane] = q.b0 * x; P[1][lane] = q.b1 * x; P[2][lane] = q.b2 * x;
+				P[0][lane] = q.b0 * x; { f2 p12 = { q.b1 * x, q.b2 * x }; reinterpret_cast<f2*>(&P[1][0])[lane] = p12; }
 			}
 			wave_sync();
 			// ---- the recurrences, 32 samples at a time (what env_safe looks ahead): every lane the same values, each keeps its own sample's ----
@@ -87,15 +87,21 @@ __global__ __launch_bounds__(WG) void klg_render_sub2a_sp(const RenderArgs a) {
 					// (gliding: the envelope's value and its Sustain clock advance together — ONE packed addition a sample: the pair is a chain of its own, nothing of the
 					//  filter's waits for it, and an instruction fewer is an issue slot fewer)
 					f2 et = { adsr.e.r_out, adsr.e.time }; const f2 es = { step, tstep }; (void)et; (void)es;
+					const f2 a12 = { q.a1, q.a2 };
 #pragma unroll
 					for (int s4 = 0; s4 < KLG_CHUNK_MAX; s4 += 4) {
 						if (!FULL && s4 >= hl) break;
-						const f4 p0 = *reinterpret_cast<const f4*>(&P[0][h + s4]), p1 = *reinterpret_cast<const f4*>(&P[1][h + s4]), p2 = *reinterpret_cast<const f4*>(&P[2][h + s4]);
+						const f4 p0 = *reinterpret_cast<const f4*>(&P[0][h + s4]);
+						const f4 pa = reinterpret_cast<const f4*>(&P[1][0])[(h + s4) / 2], pb = reinterpret_cast<const f4*>(&P[1][0])[(h + s4) / 2 + 1];   // { b1 x, b2 x } of samples s4, s4 + 1 | s4 + 2, s4 + 3
 #pragma unroll
 						for (int k = 0; k < 4; k++) if (FULL || s4 + k < hl) {
-							const float y = p0[k] + q.z0;                                  // Biquad::process 5605-5612 (TDF-II): y = b0 * in + z0
-							q.z0 = p1[k] - q.a1 * y + q.z1;
-							q.z1 = p2[k] - q.a2 * y;
+							// Biquad::process 5605-5612 (TDF-II): y = b0 in + z0; z0 = b1 in - a1 y + z1; z1 = b2 in - a2 y — the two products with y and the two subtractions as ONE
+							// packed operation each (the same roundings per value; two issue slots fewer a sample on a wave that pays one for every instruction)
+							const float y = p0[k] + q.z0;
+							const f2 p12 = k == 0 ? f2{ pa.x, pa.y } : k == 1 ? f2{ pa.z, pa.w } : k == 2 ? f2{ pb.x, pb.y } : f2{ pb.z, pb.w };
+							const f2 d = p12 - a12 * y;
+							q.z0 = d.x + q.z1;
+							q.z1 = d.y;
 							float e;
 							if (GLIDE) { e = et.x; et = et + es; }                            // env_glide: out, then out + step and time + tstep
 							else { e = adsr_process(adsr, a.fs); stage = (adsr.e.stage == ENV_OFF) ? (int)ST_OFF : stage; }
