@@ -717,13 +717,19 @@ inline std::string generate_source(const Program& g, bool x2 = false, StagedPlan
 							: k == N_BUTTER1 ? "butter1_process" : k == N_MODAL ? "modal_process" : k == N_FOLLOWPEAK ? "follower_peak" : "follower_rms";
 						if (k == N_LPF) {
 							// a biquad: its feed-forward products b0 x, b1 x, b2 x are taken by the lane that owns the sample (three rows of the wave's LDS), the recurrence every
-							// lane walks is what is left — y = p0 + z0; z0 = p1 - a1 y + z1; z1 = p2 - a2 y: two multiplications and four additions a sample instead of five and four,
-							// the same operations on the same values in the same order per value (biquad_process; klg_render_sub2a_sp.hpp does this by hand)
-							t += "\t\tX[j] = " + n + ".b0 * " + a + "; X[KLG_SP_XROW + j] = " + n + ".b1 * " + a + "; X[2 * KLG_SP_XROW + j] = " + n + ".b2 * " + a + ";\n\t\twave_sync();\n" + fmt("\t\tfloat r%d = 0.f;\n", o.dst);
+							// lane walks is what is left — y = p0 + z0; z0 = p1 - a1 y + z1; z1 = p2 - a2 y, the two products with y and the two subtractions one packed operation each
+							// ({ b1 x, b2 x } lie side by side) — the same operations on the same values in the same order per value (biquad_process; klg_render_sub2a_sp.hpp does this by hand)
+							const std::string x12 = "X12_" + std::to_string(o.dst);
+							t += "\t\tf2* const " + x12 + " = sp_pairs(X, j);\n";
+							t += "\t\tX[j] = " + n + ".b0 * " + a + "; { const f2 p12 = { " + n + ".b1 * " + a + ", " + n + ".b2 * " + a + " }; " + x12 + "[j] = p12; }\n\t\twave_sync();\n" + fmt("\t\tfloat r%d = 0.f;\n", o.dst);
+							t += "\t\tconst f2 a12_" + std::to_string(o.dst) + " = { " + n + ".a1, " + n + ".a2 };\n";
 							t += "\t\tif (SLOTS >= 4 && cnt == SLOTS) {\n\t\t\ttypedef float f4_ __attribute__((ext_vector_type(4)));\n#pragma unroll\n\t\t\tfor (int i0 = 0; i0 < SLOTS; i0 += 4) {\n";
-							t += "\t\t\t\tconst f4_ p0 = *reinterpret_cast<const f4_*>(X + i0), p1 = *reinterpret_cast<const f4_*>(X + KLG_SP_XROW + i0), p2 = *reinterpret_cast<const f4_*>(X + 2 * KLG_SP_XROW + i0);\n";
-							t += "#pragma unroll\n\t\t\t\tfor (int q = 0; q < 4; q++) { const float v = biquad_step(" + n + fmt(", p0[q], p1[q], p2[q]); r%d = sp_keep<SLOTS>(r%d, v, i0 + q); }\n\t\t\t}\n\t\t}\n", o.dst, o.dst);
-							t += "\t\telse for (int i = 0; i < cnt; i++) { const float v = biquad_step(" + n + fmt(", X[i], X[KLG_SP_XROW + i], X[2 * KLG_SP_XROW + i]); r%d = (i == j) ? v : r%d; }\n\t\twave_sync();\n", o.dst, o.dst);
+							t += "\t\t\t\tconst f4_ p0 = *reinterpret_cast<const f4_*>(X + i0), pa = *reinterpret_cast<const f4_*>(" + x12 + " + i0), pb = *reinterpret_cast<const f4_*>(" + x12 + " + i0 + 2);\n";
+							t += fmt("\t\t\t\t{ const float v = biquad_step_pk(%s, a12_%d, p0[0], f2{ pa.x, pa.y }); r%d = sp_keep<SLOTS>(r%d, v, i0); }\n", n.c_str(), o.dst, o.dst, o.dst);
+							t += fmt("\t\t\t\t{ const float v = biquad_step_pk(%s, a12_%d, p0[1], f2{ pa.z, pa.w }); r%d = sp_keep<SLOTS>(r%d, v, i0 + 1); }\n", n.c_str(), o.dst, o.dst, o.dst);
+							t += fmt("\t\t\t\t{ const float v = biquad_step_pk(%s, a12_%d, p0[2], f2{ pb.x, pb.y }); r%d = sp_keep<SLOTS>(r%d, v, i0 + 2); }\n", n.c_str(), o.dst, o.dst, o.dst);
+							t += fmt("\t\t\t\t{ const float v = biquad_step_pk(%s, a12_%d, p0[3], f2{ pb.z, pb.w }); r%d = sp_keep<SLOTS>(r%d, v, i0 + 3); }\n\t\t\t}\n\t\t}\n", n.c_str(), o.dst, o.dst, o.dst);
+							t += fmt("\t\telse for (int i = 0; i < cnt; i++) { const float v = biquad_step_pk(%s, a12_%d, X[i], %s[i]); r%d = (i == j) ? v : r%d; }\n\t\twave_sync();\n", n.c_str(), o.dst, x12.c_str(), o.dst, o.dst);
 							break;
 						}
 						t += "\t\tX[j] = " + a + ";\n\t\twave_sync();\n" + fmt("\t\tfloat r%d = 0.f;\n", o.dst);
